@@ -1,0 +1,229 @@
+/*
+ * include/smarties_hip.h -- C-ABI of libsmarties_hip.so, the MI355X-native
+ * replacement for the learner-update hot path of cselab/smarties
+ * (V-RACER / ReF-ER off-policy update over a device-resident replay buffer).
+ *
+ * Plain C: pointers, sizes and PODs only.  No torch / HIP types cross this
+ * boundary.  Every entry point returns an int status (HL_OK == 0); nothing in
+ * the library aborts the process -- a C++ RACER-shaped host class converts a
+ * non-zero status into smarties' die() (reference: Utils/Warnings.h:34-44).
+ *
+ * What each group of entry points replaces in the reference
+ * (paths relative to /root/reference/source/smarties/):
+ *
+ *   hl_create / hl_destroy        RACER ctor + setupNet + Builder::build
+ *                                 (Learners/RACER_common.cpp:71-115,
+ *                                 Network/Builder.cpp:119-170,
+ *                                 Network/Approximator.cpp:179-229) and the
+ *                                 MemoryBuffer ctor (ReplayMemory/MemoryBuffer.cpp:23-46)
+ *   hl_init_weights               Layer::initialize draw order
+ *                                 (Network/Layers/Layer_Base.h:115-141)
+ *   hl_set/get_params             Parameters blob, padded layout
+ *                                 (Network/Layers/Parameters.h:159-176)
+ *   hl_append_episode             MemoryBuffer::addEpisodeToTrainingSet +
+ *                                 pushBackEpisode (MemoryBuffer.cpp:131-170,479-520)
+ *   hl_initialize                 Learner::initializeLearner (Learners/Learner.cpp:47-72)
+ *   hl_step / _begin / _end       RACER::setupTasks stepMain + stepComplete
+ *                                 (Learners/RACER.cpp:81-108):
+ *                                 Learner_approximator::spawnTrainTasks
+ *                                 (Learner_approximator.cpp:36-92) ->
+ *                                 MemoryBuffer::sampleMinibatch (MemoryBuffer.cpp:359-432),
+ *                                 RACER::Train (RACER_train.cpp:14-67),
+ *                                 Approximator::forward/backProp (Approximator.h:118-297),
+ *                                 AdamOptimizer::prepare_update/apply_update
+ *                                 (Network/Optimizer.cpp:110-178),
+ *                                 Learner::processMemoryBuffer (Learner.cpp:74-100)
+ *   hl_comm_*                     the MPI_Iallreduce calls C1-C3 of SURVEY.md 2.4
+ *                                 (Network/Optimizer.cpp:116, Utils/DelayedReductor.cpp:75,80)
+ *   hl_readback / hl_get_*        debug taps used by the parity tests
+ *
+ * The CPU oracle (oracle/port, test infrastructure only) exports the same
+ * functions with the prefix ol_ and the same structs, so a parity test is the
+ * same call sequence against two libraries.
+ */
+#ifndef SMARTIES_HIP_H
+#define SMARTIES_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HL_API __attribute__((visibility("default")))
+
+#define HL_MAX_DIMA   64
+#define HL_MAX_HIDDEN 8
+
+/* status codes */
+enum {
+  HL_OK = 0,
+  HL_ERR_BAD_ARG = 1,        /* null pointer, size mismatch, unsupported option      */
+  HL_ERR_NO_DEVICE = 2,      /* no HIP device / extension not usable                  */
+  HL_ERR_HIP = 3,            /* a HIP runtime call failed (see hl_last_error)         */
+  HL_ERR_STATE = 4,          /* call sequence violated (e.g. step before initialize)  */
+  HL_ERR_TOO_FEW_DATA = 5,   /* "Parameter minTotObsNum is too low" (Learner_approximator.cpp:38-41) */
+  HL_ERR_COMM = 6,           /* RCCL failure                                           */
+  HL_ERR_IO = 7,
+  HL_ERR_UNSUPPORTED = 8
+};
+
+/* nnFunc names accepted by the reference (Network/Layers/Functions.h:643-668) */
+enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU = 3,
+       HL_FUNC_LRELU = 4, HL_FUNC_SIGM = 5, HL_FUNC_HARDSIGN = 6, HL_FUNC_SOFTPLUS = 7,
+       HL_FUNC_EXPPLUS = 8, HL_FUNC_EXP = 9 };
+
+/* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
+enum { HL_ADV_ZERO = 0 /* VRACER */, HL_ADV_GAUSSIAN = 1 /* RACER continuous */,
+       HL_ADV_DISCRETE = 2 /* RACER discrete */ };
+
+/* episode ordering used for the flat-index -> (episode, step) prefix walk */
+enum { HL_ORDER_STABLE = 0,     /* stable sort by ID, newest first (product semantics)  */
+       HL_ORDER_REFERENCE = 1 };/* std::sort each step exactly as MemoryProcessing.cpp:336
+                                   (oracle only: reproduces the reference's permutation) */
+
+/*
+ * Learner configuration = the settings/*.json Learner surface
+ * (Settings/HyperParameters.cpp:132-171) + the MDP descriptor fields the hot
+ * path reads (Core/StateAction.h:57-112) + process layout.
+ */
+typedef struct hl_config {
+  uint32_t struct_size;              /* = sizeof(hl_config), checked                      */
+  int32_t dimS;                      /* MDP.dimStateObserved                               */
+  int32_t dimA;                      /* MDP.dimAction (continuous)                         */
+  uint8_t bounded[HL_MAX_DIMA];      /* MDP.bActionSpaceBounded[i]                         */
+  int32_t n_hidden;                  /* len(nnLayerSizes)                                  */
+  int32_t hidden[HL_MAX_HIDDEN];     /* nnLayerSizes                                       */
+  int32_t nnFunc;                    /* HL_FUNC_*                                          */
+  int32_t adv_kind;                  /* HL_ADV_*                                           */
+  int32_t batchSize;                 /* GLOBAL batch (split over ranks, HyperParameters.cpp:186-189) */
+  int64_t maxTotObsNum;              /* GLOBAL replay size (split over ranks, :196-197)    */
+  int64_t minTotObsNum;              /* GLOBAL; 0 = maxTotObsNum (HyperParameters.cpp:191)  */
+  double gamma, lambda;              /* Retrace                                            */
+  double clipImpWeight;              /* ReF-ER C0                                          */
+  double penalTol;                   /* ReF-ER D                                           */
+  double epsAnneal;
+  double learnrate;
+  double nnLambda;                   /* AdamW decay                                        */
+  double explNoise;
+  double outWeightsPrefac;
+  uint64_t randSeed;                 /* ExecutionInfo::randSeed (rank is added, ExecutionInfo.cpp:387) */
+  int32_t n_ranks, rank;             /* learner replicas on this node                      */
+  int32_t device_id;                 /* HIP device ordinal; -1 = rank % device count       */
+  int32_t episode_order;             /* HL_ORDER_*                                         */
+  int32_t ref_threads;               /* OMP threads of the reference being mirrored: one
+                                        mt19937 draw per thread per Adam step
+                                        (Network/Optimizer.cpp:139); default 1            */
+  int32_t reserved[7];
+} hl_config;
+
+typedef struct hl_learner hl_learner;  /* opaque */
+
+/* scalars of the learner state (device-resident in the HIP library) */
+typedef struct hl_scalars {
+  double beta, alpha, CmaxRet, CinvRet;            /* MemoryBuffer.h:41-44                 */
+  int64_t nGradSteps, nStoredSteps, nStoredEps;
+  int64_t nFarPolicySteps;                         /* ReplayStats::nFarPolicySteps          */
+  int64_t nSeenSteps, nSeenEps;
+  double adam_beta_t_1, adam_beta_t_2;             /* Optimizer.h:96                        */
+  int64_t adam_nStep;
+} hl_scalars;
+
+/* replay statistics as reduced by MemoryProcessing::updateTrainingStatistics (:236-258) */
+typedef struct hl_stats {
+  double avgKLdivergence, avgSquaredErr, maxAbsError, avgReturn, avgQ, stdevQ, minQ, maxQ;
+  int64_t nFarPolicySteps;
+} hl_stats;
+
+/* per-sample / per-step taps of the LAST executed step (hl_readback) */
+enum {
+  HL_TAP_FLAT = 0,      /* int64[B]   sampled flat transition indices (sorted)            */
+  HL_TAP_EPISODE = 1,   /* int64[B]   episode position in the current episode order       */
+  HL_TAP_TSTEP = 2,     /* int64[B]   step within episode                                  */
+  HL_TAP_TAG = 3,       /* int64[B]   caller-supplied episode tag                          */
+  HL_TAP_STATE = 4,     /* f32[B*dS]  standardized states (MiniBatch::S)                   */
+  HL_TAP_OUTPUT = 5,    /* f64[B*nOut] network outputs O                                   */
+  HL_TAP_OUTGRAD = 6,   /* f64[B*nOut] output gradient placed by RACER::Train              */
+  HL_TAP_RHO = 7,       /* f64[B]                                                          */
+  HL_TAP_DKL = 8,       /* f64[B]                                                          */
+  HL_TAP_DELTAQ = 9,    /* f64[B]                                                          */
+  HL_TAP_FAR = 10,      /* u8[B]     ReF-ER far-policy mask                                */
+  HL_TAP_GRADSUM = 11   /* f32[nParams] summed weight gradient before Adam (local rank)   */
+};
+
+/* per-step episode fields (hl_get_episode_field) */
+enum { HL_EP_RETURN = 0, HL_EP_VALUE = 1, HL_EP_ADVANTAGE = 2, HL_EP_IMPW = 3, HL_EP_DKL = 4,
+       HL_EP_DELTAQ = 5 };
+
+/* ---- lifetime ------------------------------------------------------------ */
+HL_API int hl_create(const hl_config* cfg, hl_learner** out);
+HL_API int hl_destroy(hl_learner* h);
+HL_API const char* hl_last_error(const hl_learner* h);   /* never NULL */
+HL_API const char* hl_status_string(int status);
+HL_API int hl_version(void);
+
+/* ---- network parameters ---------------------------------------------------- */
+HL_API int64_t hl_num_params(const hl_learner* h);        /* padded blob length (72 976 @ cfg-NS) */
+HL_API int32_t hl_num_outputs(const hl_learner* h);       /* 1 + 2*dA for VRACER */
+HL_API int32_t hl_num_layers(const hl_learner* h);
+/* per layer l: offset/length of W and b inside the padded blob (Parameters::indWeights etc.) */
+HL_API int hl_param_layout(const hl_learner* h, int64_t* indW, int64_t* nW, int64_t* indB, int64_t* nB);
+HL_API int hl_init_weights(hl_learner* h);                /* draws from the learner's mt19937 */
+HL_API int hl_set_params(hl_learner* h, const float* w, const float* m1, const float* m2); /* NULL = keep */
+HL_API int hl_get_params(hl_learner* h, float* w, float* m1, float* m2);                   /* NULL = skip */
+
+/* ---- sampler RNG: std::mt19937 generators[0] (ExecutionInfo.cpp:391) ------- */
+HL_API int hl_set_rng_state(hl_learner* h, const uint32_t state[625]); /* 624 words + position */
+HL_API int hl_get_rng_state(hl_learner* h, uint32_t state[625]);
+
+/* ---- replay ---------------------------------------------------------------- */
+/* One finished episode of nsteps states.  actions/mu/rewards are f64 as in
+ * Episode.h:73-74 (last action/mu row = zeros, rewards[0] = 0), values/advantages
+ * are the behaviour-time V(s_t) and A(s_t,a_t) (advantages may be NULL = 0).
+ * The library computes the Retrace estimate on insert (MemoryProcessing.cpp:452-458). */
+HL_API int hl_append_episode(hl_learner* h, int32_t nsteps, const float* states,
+                             const double* actions, const double* mu, const double* rewards,
+                             const float* values, const float* advantages,
+                             int32_t terminated, int64_t tag);
+HL_API int hl_get_scaling(hl_learner* h, float* stateMean, float* stateScale, float* rew3 /*mean,scale,std*/);
+HL_API int hl_set_scaling(hl_learner* h, const float* stateMean, const float* stateScale, const float* rew3);
+HL_API int hl_get_episode_field(hl_learner* h, int64_t episode_pos, int32_t field, float* dst, int32_t cap);
+HL_API int hl_get_episode_info(hl_learner* h, int64_t episode_pos, int64_t* tag, int32_t* nsteps, int32_t* terminated);
+
+/* ---- training ---------------------------------------------------------------- */
+HL_API int hl_initialize(hl_learner* h);                  /* Learner::initializeLearner */
+/* n_steps full gradient steps.  flat_indices == NULL: device-side sampler; else
+ * n_steps * batch_local sorted unique indices to use instead (the RNG is then
+ * advanced as if it had drawn them only by the per-step Adam draw). */
+HL_API int hl_step(hl_learner* h, int32_t n_steps, const int64_t* flat_indices);
+/* split form: begin = sample + train + local gradient sum; end = bookkeeping + Adam.
+ * Between the two the caller may all-reduce hl_grad_host() itself (host MPI/gloo path). */
+HL_API int hl_step_begin(hl_learner* h, const int64_t* flat_indices);
+HL_API int hl_grad_exchange(hl_learner* h, float* grad_io /*nParams, NULL = fetch only into internal host buf*/, int32_t write_back);
+HL_API int hl_counters_exchange(hl_learner* h, int64_t counters_io[4], int32_t write_back);
+/* every 1000th step: the 2*dS+3 reward/state moments of MemoryProcessing.cpp:139-150 (C3) */
+HL_API int hl_moments_exchange(hl_learner* h, double* io, int32_t write_back);
+HL_API int hl_step_end(hl_learner* h);
+HL_API int hl_sync(hl_learner* h);                         /* wait for all queued device work */
+
+/* ---- inspection ---------------------------------------------------------------- */
+HL_API int hl_set_tap(hl_learner* h, int32_t enable);
+HL_API int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t dst_bytes);
+HL_API int hl_get_scalars(hl_learner* h, hl_scalars* out);
+HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
+
+/* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------- */
+HL_API int hl_comm_unique_id(uint8_t id[128]);             /* rank 0 creates, caller broadcasts */
+HL_API int hl_comm_init(hl_learner* h, const uint8_t id[128]);
+
+/* ---- timing taps for bench.py ------------------------------------------------------ */
+/* average device time (ms) per launch of the named kernel over the launches since the
+ * last hl_timing_reset, measured with HIP events on the library's own stream */
+HL_API int hl_timing_enable(hl_learner* h, int32_t enable);
+HL_API int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMARTIES_HIP_H */

@@ -1,0 +1,950 @@
+/*
+ * oracle/port/vracer_port.cpp -- CPU restatement of the smarties V-RACER /
+ * ReF-ER learner update.
+ *
+ * TEST INFRASTRUCTURE ONLY (the oracle).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker; the product path (smarties_amd/csrc, libsmarties_hip.so) never does.
+ *
+ * Parity status: PINNED -- every function below is checked against golden
+ * fixtures produced by the compiled reference itself (oracle/_ref/ref_driver,
+ * generator script tests/golden/make_golden.sh; tests/test_oracle_golden.py).
+ *
+ * Written from the reference's behaviour, not from its text; each block cites
+ * the reference lines it restates (paths relative to
+ * /root/reference/source/smarties/).  Single-threaded: it restates the
+ * reference run with nThreads = 1, which fixes every summation order.
+ */
+#include "vracer_port.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+using Real = double;   // Settings/Definitions.h:27
+using nnReal = float;  // Settings/Definitions.h:46 (-DSINGLE_PREC)
+using Fval = float;    // Settings/Definitions.h:50
+
+constexpr nnReal nnEPS = FLT_EPSILON;  // Settings/Bund.h:113
+
+inline int64_t roundUp8(int64_t n) { return (n + 7) / 8 * 8; }  // Utils/FunctionUtilities.h:74-83
+
+// ---------------------------------------------------------------------------
+// std::mt19937 restated (32-bit Mersenne twister, same state layout as
+// libstdc++: 624 words + position; position 624 == "regenerate on next draw").
+// ---------------------------------------------------------------------------
+struct MT19937 {
+  uint32_t x[624];
+  uint32_t p;
+  void seed(uint32_t s) {
+    x[0] = s;
+    for (uint32_t i = 1; i < 624; ++i) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + i;
+    p = 624;
+  }
+  void twist() {
+    constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    for (int k = 0; k < 227; ++k) {
+      const uint32_t y = (x[k] & UP) | (x[k + 1] & LO);
+      x[k] = x[k + 397] ^ (y >> 1) ^ ((y & 1) ? A : 0);
+    }
+    for (int k = 227; k < 623; ++k) {
+      const uint32_t y = (x[k] & UP) | (x[k + 1] & LO);
+      x[k] = x[k - 227] ^ (y >> 1) ^ ((y & 1) ? A : 0);
+    }
+    const uint32_t y = (x[623] & UP) | (x[0] & LO);
+    x[623] = x[396] ^ (y >> 1) ^ ((y & 1) ? A : 0);
+    p = 0;
+  }
+  uint32_t next() {
+    if (p >= 624) twist();
+    uint32_t z = x[p++];
+    z ^= (z >> 11);
+    z ^= (z << 7) & 0x9d2c5680u;
+    z ^= (z << 15) & 0xefc60000u;
+    z ^= (z >> 18);
+    return z;
+  }
+};
+
+// std::uniform_int_distribution<size_t>(0, N-1) over mt19937 for N < 2^32 in
+// libstdc++ >= 10: Lemire's nearly-divisionless method on 32-bit words
+// (call site ReplayMemory/Sampling.cpp:84-88).
+inline uint64_t uniformIndex(MT19937& g, uint64_t N) {
+  const uint32_t range = (uint32_t)N;
+  uint64_t product = (uint64_t)g.next() * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (uint32_t)(-range) % range;
+    while (low < threshold) {
+      product = (uint64_t)g.next() * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return product >> 32;
+}
+
+// std::uniform_real_distribution<float>(a,b) over mt19937 in libstdc++:
+// generate_canonical<float,24> consumes one 32-bit word (call site
+// Network/Layers/Layer_Base.h:120-133).
+inline float uniformFloat(MT19937& g, float a, float b) {
+  float ret = (float)g.next() / 4294967296.0f;
+  if (ret >= 1.0f) ret = std::nextafter(1.0f, 0.0f);
+  return ret * (b - a) + a;
+}
+
+// ---------------------------------------------------------------------------
+// activation functions (Network/Layers/Functions.h)
+// ---------------------------------------------------------------------------
+inline nnReal fEval(int f, nnReal in) {
+  switch (f) {
+    case HL_FUNC_LINEAR: return in;                                   // :40-82
+    case HL_FUNC_TANH:                                                // :104-113
+      if (in > 0) { const nnReal e = std::exp(-2 * in); return (1 - e) / (1 + e); }
+      else        { const nnReal e = std::exp( 2 * in); return (e - 1) / (1 + e); }
+    case HL_FUNC_SOFTSIGN: return in / (1 + std::fabs(in));           // :328-331
+    case HL_FUNC_RELU: return in > 0 ? in : 0;                        // :415-418
+  }
+  return in;
+}
+inline nnReal fDiff(int f, nnReal in, nnReal out) {
+  switch (f) {
+    case HL_FUNC_LINEAR: return 1;
+    case HL_FUNC_TANH: return 1 - out * out;                          // :119-122
+    case HL_FUNC_SOFTSIGN: { const nnReal d = 1 + std::fabs(in); return 1 / (d * d); }  // :333-337
+    case HL_FUNC_RELU: return in > 0 ? 1 : 0;
+  }
+  return 1;
+}
+inline Real fInitFactor(int f, int inps, int outs) {
+  switch (f) {
+    case HL_FUNC_LINEAR: return std::sqrt(1. / inps);                 // :43-46
+    case HL_FUNC_TANH: return std::sqrt(6. / (inps + outs));          // :94-97
+    case HL_FUNC_SOFTSIGN: return std::sqrt(6.0 / (inps + outs));     // :318-321
+    case HL_FUNC_RELU: return std::sqrt(2. / inps);                   // :404-407
+  }
+  return 1;
+}
+// SoftPlus used by the policy for the stdev ("cheap softplus", Functions.h:552-568)
+inline Real spEval(Real in) { return (in + std::sqrt(1 + in * in)) / 2; }
+inline Real spDiff(Real in) { return (1 + in / std::sqrt(1 + in * in)) / 2; }
+inline Real spInv(Real in) { return (in * in - 0.25) / in; }
+
+// value squashing (Learners/RACER_common.cpp:18-32)
+inline Real scaleNet2V(Real x) {
+  if (x > 0) return 100 * (x + 51) - 100 * std::sqrt(2601 + 100 * x);
+  else       return 100 * (x - 51) + 100 * std::sqrt(2601 - 100 * x);
+}
+inline Real scaleVdiff(Real x) {
+  if (x > 0) return 100 - 5000 / std::sqrt(2601 + 100 * x);
+  else       return 100 - 5000 / std::sqrt(2601 - 100 * x);
+}
+// ReplayMemory/Episode.h:28-33 -- evaluated in Fval
+inline bool isFarPolicy(Fval W, Fval C, Fval invC) {
+  const bool isOff = W > C || W < invC;
+  return C > (Fval)1 && isOff;
+}
+
+// ---------------------------------------------------------------------------
+// network description (Network/Builder.cpp:48-117, Layers/*.h)
+// ---------------------------------------------------------------------------
+enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM };
+struct Layer {
+  LType type; int size = 0, nIn = 0, nOutSimd = 0, func = HL_FUNC_LINEAR;
+  bool bOutput = false, skipInpGrad = false;
+  int64_t indW = 0, nW = 0, indB = 0, nB = 0;
+  std::vector<Real> biasInit;  // ParamLayer initial values
+};
+
+struct Episode {  // ReplayMemory/Episode.h:40-108
+  int64_t tag = -1, ID = -1; int N = 0; bool term = false;
+  std::vector<float> S; std::vector<double> A, MU, R;
+  std::vector<nnReal> V, ADV, RET;         // stateValue, actionAdvantage, returnEstimator
+  std::vector<Fval> DQ, IMPW, DKL;         // deltaValue, offPolicImpW, KullbLeibDiv
+  Fval totR = 0, avgKL = 0, fracFar = 0, avgSqErr = 0, maxAbsErr = 0;
+  Fval sumQ2 = 0, sumQ = 0, maxQ = -1e9, minQ = 1e9;
+  int ndata() const { return N - 1; }
+  bool isTruncated(int t) const { return t + 1 == N && !term; }
+  bool isTerminal(int t) const { return t + 1 == N && term; }
+};
+
+}  // namespace
+
+struct ol_learner {
+  hl_config cfg;
+  std::string err;
+  int dS = 0, dA = 0, nOut = 0, B = 0, Bglobal = 0;
+  int64_t maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
+  std::vector<Layer> layers;
+  int64_t nParams = 0;
+  std::vector<nnReal> W, M1, M2, G;
+  MT19937 gen;
+  // replay
+  std::vector<std::unique_ptr<Episode>> episodes;
+  std::vector<nnReal> stMean, stStd, stScale; nnReal rewMean = 0, rewStd = 1, rewScale = 1;
+  Real beta = 1e-4, alpha = 0.5, CmaxRet = 5, CinvRet = 0.25;
+  int64_t nGradSteps = 0, nTransitions = 0, nSeenSteps = 0, nSeenEps = 0;
+  int64_t nGatheredB4Startup = INT64_MAX;
+  int64_t nFarGlobal = 0, nStoredGlobal = 0;  // result of counters reduction
+  bool countersReduced = false, momentsPending = false;
+  std::vector<long double> moments;
+  hl_stats stats{};
+  // adam (Network/Optimizer.h:38-47,96)
+  Real beta_t_1 = 0.9, beta_t_2 = 0.999; int64_t nStep = 0;
+  bool initialized = false, inStep = false, tap = false;
+  // activations workspace: per layer X, Y, E for current and next step
+  std::vector<std::vector<nnReal>> X, Y, E, Xn, Yn;
+  // last batch
+  std::vector<int64_t> bFlat, bEp, bT, bTag;
+  std::vector<float> tState; std::vector<double> tO, tG, tRho, tDkl, tDq; std::vector<uint8_t> tFar;
+  std::vector<nnReal> tGradSum;
+};
+
+namespace {
+
+int fail(ol_learner* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
+
+// Builder::addInput/addLayer/addParamLayer (Network/Builder.cpp:26-117) driven by
+// Approximator::buildFromSettings (Network/Approximator.cpp:179-229) and
+// RACER::setupNet (Learners/RACER_common.cpp:71-115) with RACER_simpleSigma.
+void buildNet(ol_learner* h) {
+  const hl_config& c = h->cfg;
+  std::vector<Layer>& L = h->layers;
+  L.clear();
+  { Layer in; in.type = L_INPUT; in.size = c.dimS; L.push_back(in); }
+  for (int j = 0; j < c.n_hidden; ++j) {
+    if (c.hidden[j] <= 0) continue;
+    const int ID = (int)L.size();
+    Layer d; d.type = L_DENSE; d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
+    d.nOutSimd = (int)roundUp8(d.size); d.func = c.nnFunc;
+    L.push_back(d);
+    // skip connection except after the first layer (Builder.cpp:89-95)
+    if (ID != 1) { Layer r; r.type = L_PARAMRES; r.size = d.size; L.push_back(r); }
+  }
+  const int nDense = 1 + c.dimA;  // VRACER: [V, mean x dA]; sigma is a ParamLayer
+  { const int ID = (int)L.size();
+    Layer o; o.type = L_DENSE; o.size = nDense; o.nIn = L[ID - 1].size;
+    o.nOutSimd = (int)roundUp8(o.size); o.func = HL_FUNC_LINEAR; o.bOutput = true; L.push_back(o); }
+  { Layer p; p.type = L_PARAM; p.size = c.dimA; p.func = HL_FUNC_LINEAR; p.bOutput = true;
+    // Continuous_policy::initial_Stdev -> SoftPlus::_inv(explNoise) (Continuous_policy.h:603-617,192-194)
+    Real S = c.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
+    p.biasInit.assign(c.dimA, spInv(S)); L.push_back(p); }
+  // layer 1 never back-propagates to the input vector (Approximator.cpp:146-170)
+  if (L.size() > 1) L[1].skipInpGrad = true;
+  // Parameters::_computeNParams (Layers/Parameters.h:159-176)
+  int64_t tot = 0;
+  for (auto& l : L) {
+    switch (l.type) {
+      case L_INPUT: l.nW = 0; l.nB = 0; break;
+      case L_DENSE: l.nW = (int64_t)l.nOutSimd * l.nIn; l.nB = l.size; break;   // Layer_Base.h:24-28
+      case L_PARAMRES: l.nW = l.size; l.nB = l.size; break;                    // Layers.h:334-338
+      case L_PARAM: l.nW = 0; l.nB = l.size; break;                            // Layers.h:494-497
+    }
+    l.indW = tot; tot += roundUp8(l.nW);
+    l.indB = tot; tot += roundUp8(l.nB);
+  }
+  h->nParams = tot;
+  h->nOut = nDense + c.dimA;
+  h->W.assign(tot, 0); h->M1.assign(tot, 0); h->M2.assign(tot, 0); h->G.assign(tot, 0);
+  const size_t nl = L.size();
+  h->X.resize(nl); h->Y.resize(nl); h->E.resize(nl); h->Xn.resize(nl); h->Yn.resize(nl);
+  for (size_t i = 0; i < nl; ++i) {
+    const size_t n = (size_t)roundUp8(L[i].size);
+    h->X[i].assign(n, 0); h->Y[i].assign(n, 0); h->E[i].assign(n, 0);
+    h->Xn[i].assign(n, 0); h->Yn[i].assign(n, 0);
+  }
+}
+
+// Layer::initialize in build order (Builder.cpp:131-137; Layer_Base.h:115-141;
+// Layers.h:395-400, 548-553)
+void initWeights(ol_learner* h) {
+  const hl_config& c = h->cfg;
+  for (const Layer& l : h->layers) {
+    nnReal* W = h->W.data() + l.indW; nnReal* Bv = h->W.data() + l.indB;
+    if (l.type == L_DENSE) {
+      const Real initializationFac = l.bOutput ? c.outWeightsPrefac : 1;
+      const nnReal fac = (initializationFac > 0) ? initializationFac : 1;
+      const nnReal init = fac * fInitFactor(l.func, l.nIn, l.size);
+      for (int o = 0; o < l.size; ++o) Bv[o] = 0;  // output bias init values are all 0 -> Linear inverse
+      for (int i = 0; i < l.nIn; ++i)
+        for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = uniformFloat(h->gen, -init, init);
+    } else if (l.type == L_PARAMRES) {
+      for (int o = 0; o < l.size; ++o) { Bv[o] = 0; W[o] = 1; }
+    } else if (l.type == L_PARAM) {
+      for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)l.biasInit[o];
+    }
+  }
+}
+
+// Network::forward (Network/Network.h:102-113) over Layer::forward of each type
+void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vector<nnReal>>& X,
+                std::vector<std::vector<nnReal>>& Y) {
+  const auto& L = h->layers;
+  std::copy(input, input + L[0].size, Y[0].begin());
+  for (size_t ID = 1; ID < L.size(); ++ID) {
+    const Layer& l = L[ID];
+    const nnReal* W = h->W.data() + l.indW; const nnReal* Bv = h->W.data() + l.indB;
+    if (l.type == L_DENSE) {  // Layer_Base.h:64-95
+      nnReal* suminp = X[ID].data();
+      std::memcpy(suminp, Bv, l.size * sizeof(nnReal));
+      const nnReal* inputs = Y[ID - 1].data();
+      for (int i = 0; i < l.nIn; ++i) {
+        const nnReal* Wi = W + (int64_t)l.nOutSimd * i;
+        for (int o = 0; o < l.size; ++o) suminp[o] += inputs[i] * Wi[o];
+      }
+      for (int o = 0; o < l.size; ++o) Y[ID][o] = fEval(l.func, suminp[o]);
+    } else if (l.type == L_PARAMRES) {  // Layers.h:347-361
+      nnReal* ret = Y[ID].data();
+      std::memcpy(ret, Y[ID - 1].data(), l.size * sizeof(nnReal));
+      const nnReal* inp = Y[ID - 2].data();
+      const int sizeInp = std::min(L[ID - 2].size, l.size);
+      for (int j = 0; j < sizeInp; ++j) ret[j] += inp[j] * W[j] + Bv[j];
+    } else if (l.type == L_PARAM) {  // Layers.h:510-520
+      for (int n = 0; n < l.size; ++n) { X[ID][n] = Bv[n]; Y[ID][n] = fEval(l.func, Bv[n]); }
+    }
+  }
+}
+
+// Activation::getOutput (Layers/Activation.h:134-148): output layers in order
+void getOutput(const ol_learner* h, const std::vector<std::vector<nnReal>>& Y, Real* O) {
+  int k = 0;
+  for (size_t i = 0; i < h->layers.size(); ++i)
+    if (h->layers[i].bOutput) for (int j = 0; j < h->layers[i].size; ++j) O[k++] = Y[i][j];
+}
+
+// GEMVomp (Layers/Layers.h:34-60): errors[o] += sum_i W[o*S+i]*deltas[i], blocked by 16
+void gemvOmp(int NX, int NY, int S, const nnReal* Wm, const nnReal* Xv, nnReal* Yv) {
+  constexpr int cacheLineLen = 64 / sizeof(nnReal);
+  for (int I = 0; I < NX; I += cacheLineLen)
+    for (int o = 0; o < NY; ++o) {
+      const nnReal* Wr = Wm + (int64_t)S * o;
+      nnReal acc = 0;
+      const int Ninner = std::min(NX, I + cacheLineLen);
+      for (int i = I; i < Ninner; ++i) acc += Wr[i] * Xv[i];
+      Yv[o] += acc;
+    }
+}
+
+// Network::backProp single step (Network/Network.h:155-166 -> :220-231) with the
+// per-type backward (Layers.h:123-188, 363-393, 522-546; Layer_Base.h:97-113).
+// E[] must hold the output deltas and zeros elsewhere; accumulates into G.
+void backwardNet(ol_learner* h) {
+  const auto& L = h->layers;
+  auto& X = h->X; auto& Y = h->Y; auto& E = h->E;
+  for (int ID = (int)L.size() - 1; ID >= 1; --ID) {
+    const Layer& l = L[ID];
+    const nnReal* W = h->W.data() + l.indW;
+    nnReal* gW = h->G.data() + l.indW; nnReal* gB = h->G.data() + l.indB;
+    if (l.type == L_PARAM) {
+      nnReal* deltas = E[ID].data();
+      for (int o = 0; o < l.size; ++o) { deltas[o] *= fDiff(l.func, X[ID][o], Y[ID][o]); gB[o] += deltas[o]; }
+    } else if (l.type == L_DENSE) {
+      nnReal* deltas = E[ID].data();
+      for (int o = 0; o < l.size; ++o) deltas[o] *= fDiff(l.func, X[ID][o], Y[ID][o]);
+      if (!l.skipInpGrad) gemvOmp(l.size, l.nIn, l.nOutSimd, W, deltas, E[ID - 1].data());
+      for (int o = 0; o < l.size; ++o) gB[o] += deltas[o];
+      const nnReal* inputs = Y[ID - 1].data();
+      for (int i = 0; i < l.nIn; ++i) {
+        nnReal* Gi = gW + (int64_t)l.nOutSimd * i;
+        for (int o = 0; o < l.size; ++o) Gi[o] += inputs[i] * deltas[o];
+      }
+    } else if (l.type == L_PARAMRES) {
+      const nnReal* delta = E[ID].data();
+      std::memcpy(E[ID - 1].data(), delta, l.size * sizeof(nnReal));
+      nnReal* gradInp = E[ID - 2].data();
+      const nnReal* inp = Y[ID - 2].data();
+      const int sizeInp = std::min(L[ID - 2].size, l.size);
+      for (int j = 0; j < sizeInp; ++j) {
+        gradInp[j] += delta[j] * W[j];
+        gW[j] += delta[j] * inp[j];
+        gB[j] += delta[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// RACER::Train head for VRACER (Learners/RACER_train.cpp:31-60) with
+// Continuous_policy (Math/Continuous_policy.h:569-738): NormalPolicy (:68-210)
+// for unbounded, SquashedNormalPolicy (:212-378) for bounded components.
+// ---------------------------------------------------------------------------
+extern "C" void ol_head_vracer(int dA, const uint8_t* bounded, const double* O, const double* act,
+                               const double* mu, double Qret, double beta, double Cmax, double Cinv,
+                               double* grad, double* rho, double* dkl, double* deltaQ, int* isFar,
+                               double* Vval) {
+  constexpr Real MAXM = 8.31776613503286;
+  constexpr Real LOG2PI_2 = 9.1893853320467266954096885456237942e-01;
+  constexpr Real FMIN = FLT_MIN;
+  Real logW = 0, kl = 0;
+  std::vector<Real> mean(dA), stdev(dA), invStd(dA), dPos(dA);
+  for (int i = 0; i < dA; ++i) {
+    mean[i] = O[1 + i];
+    const Real p = O[1 + dA + i];
+    stdev[i] = spEval(p); invStd[i] = 1 / stdev[i]; dPos[i] = spDiff(p);
+    const Real bMean = mu[i], bStd = mu[dA + i];
+    Real lpPi, lpMu;
+    if (bounded[i]) {
+      const Real m = mean[i] > MAXM ? MAXM : (mean[i] < -MAXM ? -MAXM : mean[i]);   // getMean() :217-222
+      const Real squash = std::tanh(act[i]), J = std::max(1 - squash * squash, FMIN);
+      lpPi = -std::pow((act[i] - m) * invStd[i], 2) / 2 + std::log(invStd[i] / J) - LOG2PI_2;  // :240-249
+      const Real bInv = 1 / bStd;
+      lpMu = -std::pow((act[i] - bMean) * bInv, 2) / 2 + std::log(bInv / J) - LOG2PI_2;         // :274-279
+    } else {
+      lpPi = -std::pow((act[i] - mean[i]) * invStd[i], 2) / 2 + std::log(invStd[i]) - LOG2PI_2;   // :91-97
+      const Real bInv = 1 / bStd;
+      lpMu = -std::pow((act[i] - bMean) * bInv, 2) / 2 + std::log(bInv) - LOG2PI_2;
+    }
+    logW += lpPi - lpMu;                                                              // :648-653
+    // KLdivergence with SMARTIES_OPPOSITE_KL (Settings/Bund.h:43): Dkl(pi||mu), raw mean (:286-298)
+    const Real CmuCpi = std::pow(stdev[i] / bStd, 2);
+    const Real sumDmeanC = std::pow((mean[i] - bMean) / bStd, 2);
+    kl += (CmuCpi - 1 + sumDmeanC - std::log(CmuCpi)) / 2;
+  }
+  const Real RHO = std::exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
+  const bool far = isFarPolicy((Fval)RHO, (Fval)Cmax, (Fval)Cinv);
+  const Real V = scaleNet2V(O[0]);
+  const Real A_RET = Qret - V, dQ = A_RET - 0;          // Zero_advantage: A == 0
+  const Real Ver = std::min((Real)1, RHO) * dQ;
+  grad[0] = far ? 0 : Ver * beta * scaleVdiff(O[0]);     // RACER_train.cpp:51
+  const Real coef = A_RET * std::min(Cmax, RHO);
+  for (int i = 0; i < dA; ++i) {
+    const Real bMean = mu[i], bStd = mu[dA + i];
+    // gradKLdiv(mu, factor=-1) with OPPOSITE_KL (:318-334)
+    const Real dMean = mean[i] - bMean;
+    const Real invVarMu = 1 / std::pow(bStd, 2);
+    const Real penalM = -1 * (dMean * invVarMu);
+    const Real penalS = dPos[i] * -1 * ((invVarMu - std::pow(invStd[i], 2)) * stdev[i]);
+    Real polM = 0, polS = 0;
+    if (!far) {
+      if (bounded[i]) {  // :300-316
+        const Real dLogPdMean = (act[i] - mean[i]) * invStd[i] * invStd[i];
+        const Real m = mean[i] > MAXM ? MAXM : (mean[i] < -MAXM ? -MAXM : mean[i]);
+        const Real u = (act[i] - m) * invStd[i];
+        const Real dLogPdStdv = (u * u - 1) * invStd[i];
+        polS = dPos[i] * coef * dLogPdStdv;
+        if (mean[i] >= MAXM && coef * dLogPdMean > 0) polM = 0;
+        else if (mean[i] <= -MAXM && coef * dLogPdMean < 0) polM = 0;
+        else polM = coef * dLogPdMean;
+      } else {           // :149-156
+        const Real u = (act[i] - mean[i]) * invStd[i];
+        polM = coef * (u * invStd[i]);
+        polS = dPos[i] * coef * ((u * u - 1) * invStd[i]);
+      }
+    }
+    // Utilities::penalizeReFER (Utils/FunctionUtilities.h:221-228) + makeNetworkGrad (:727-738)
+    grad[1 + i] = beta * polM + (1 - beta) * penalM;
+    grad[1 + dA + i] = beta * polS + (1 - beta) * penalS;
+  }
+  *rho = RHO; *dkl = kl; *deltaQ = dQ; *isFar = far ? 1 : 0; *Vval = V;
+}
+
+namespace {
+
+// Episode::updateCumulative_atomic (ReplayMemory/Episode.h:112-129)
+void epUpdateCumulative(Episode& EP, int t, Fval E, Fval D, Fval W, Fval C, Fval invC) {
+  const Fval wasFarPol = EP.IMPW[t] > C || EP.IMPW[t] < invC;
+  const Fval isFarPol = W > C || W < invC;
+  const Fval invN = 1 / (Fval)EP.N;
+  EP.avgKL += invN * (D - EP.DKL[t]);
+  EP.fracFar += invN * (isFarPol - wasFarPol);
+  EP.avgSqErr += invN * (E * E - EP.DQ[t] * EP.DQ[t]);
+  EP.maxAbsErr = std::max(EP.maxAbsErr, std::fabs(E));
+  EP.DQ[t] = E; EP.DKL[t] = D; EP.IMPW[t] = W;
+}
+// Episode::updateValues_atomic (Episode.h:131-145)
+void epUpdateValues(Episode& EP, int t, Fval V, Fval Q) {
+  const Fval oldQ = EP.ADV[t] + EP.V[t];
+  EP.sumQ2 += Q * Q - oldQ * oldQ;
+  EP.sumQ += Q - oldQ;
+  EP.maxQ = std::max(EP.maxQ, Q);
+  EP.minQ = std::min(EP.minQ, Q);
+  EP.V[t] = V; EP.ADV[t] = Q - V;
+}
+// Episode::updateCumulative (ReplayMemory/Episode.cpp:213-242)
+void epRecompute(Episode& EP, Fval C, Fval invC) {
+  const int N = EP.ndata();
+  const Fval invN = 1 / (Fval)N;
+  int64_t nFarPol = 0;
+  Fval sumE2 = 0, maxAE = -1e9, maxQ = -1e9, sumQ2 = 0, minQ = 1e9, sumQ1 = 0;
+  for (int t = 0; t < N; ++t) {
+    if (EP.IMPW[t] > C || EP.IMPW[t] < invC) ++nFarPol;
+    sumE2 += EP.DQ[t] * EP.DQ[t];
+    maxAE = std::max(maxAE, std::fabs(EP.DQ[t]));
+    const Fval Q = EP.ADV[t] + EP.V[t];
+    maxQ = std::max(maxQ, Q); minQ = std::min(minQ, Q);
+    sumQ2 += Q * Q; sumQ1 += Q;
+  }
+  EP.fracFar = invN * nFarPol; EP.avgSqErr = invN * sumE2; EP.maxAbsErr = maxAE;
+  EP.sumQ2 = sumQ2; EP.sumQ = sumQ1; EP.maxQ = maxQ; EP.minQ = minQ;
+  Real tot = 0; for (int t = 0; t < EP.N; ++t) tot += EP.R[t];   // Utilities::sum over Real
+  EP.totR = tot;
+  Fval sk = 0; for (int t = 0; t < EP.N; ++t) sk += EP.DKL[t];    // Utilities::sum over Fval
+  EP.avgKL = invN * sk;
+}
+
+// computeRetrace + updateReturnEstimator (ReplayMemory/MemoryProcessing.cpp:23-44,391-400)
+void retraceEpisode(const ol_learner* h, Episode& EP) {
+  const Fval gamma = h->cfg.gamma, lambda = h->cfg.lambda;
+  if (!EP.term) EP.RET[EP.N - 1] = EP.V[EP.N - 1];
+  for (int t = EP.N - 2; t >= 0; --t) {
+    const Fval R = (Fval)((EP.R[t + 1] - h->rewMean) * h->rewScale);   // Episode::scaledReward<Fval> (:185-189)
+    const Fval Q = EP.RET[t + 1], V = EP.V[t + 1], A = EP.ADV[t + 1];
+    const Fval w = EP.IMPW[t + 1] < 1 ? EP.IMPW[t + 1] : 1;            // clippedOffPolW (:191-195)
+    EP.RET[t] = R + gamma * (V + lambda * w * (Q - A - V));
+  }
+}
+
+// MemoryProcessing::updateCounters (MemoryProcessing.cpp:46-92)
+void updateCounters(ol_learner* h, bool /*bInit*/) {
+  int64_t nFar = h->stats.nFarPolicySteps, nStored = h->nTransitions;
+  if (h->cfg.n_ranks > 1 && h->countersReduced) { nFar = h->nFarGlobal; nStored = h->nStoredGlobal; }
+  h->countersReduced = false;
+  const Real fracOffPol = nFar / (Real)std::max(nStored, (int64_t)1);
+  const Real maxN = (Real)h->maxObsGlobal, BS = h->Bglobal;
+  const Real nDataSize = std::max(maxN, (Real)nStored);
+  const Real learnRefer = 0.1 * BS / nDataSize;
+  const auto fixPointIter = [&](const Real val, const bool goTo0) {
+    if (goTo0) return (1 - std::min(learnRefer, val)) * val;
+    else return (1 - std::min(learnRefer, val)) * val + std::min(learnRefer, 1 - val);
+  };
+  h->beta = fixPointIter(h->beta, fracOffPol > h->cfg.penalTol);
+  h->alpha = fixPointIter(h->alpha, std::fabs(h->cfg.penalTol - fracOffPol) < 1e-3);
+}
+
+// MemoryProcessing::updateRewardsStats (MemoryProcessing.cpp:94-185), split at the
+// StateRewRdx all-reduce (:139-150): computeMoments = local sums, applyMoments = EMA update
+void computeMoments(const ol_learner* h, std::vector<long double>& out) {
+  const int dS = h->dS;
+  long double count = 0, newRSum = 0, newRSqSum = 0;
+  std::vector<long double> SSum(dS, 0), SSqSum(dS, 0);
+  for (auto& ep : h->episodes) {
+    const Episode& EP = *ep; const int N = EP.ndata();
+    count += N;
+    for (int j = 0; j < N; ++j) {
+      const long double drk = EP.R[j + 1] - h->rewMean;
+      newRSum += drk; newRSqSum += drk * drk;
+      for (int k = 0; k < dS; ++k) {
+        const long double dsk = EP.S[(size_t)j * dS + k] - h->stMean[k];  // float - float
+        SSum[k] += dsk; SSqSum[k] += dsk * dsk;
+      }
+    }
+  }
+  out.assign(SSum.begin(), SSum.end());
+  out.insert(out.end(), SSqSum.begin(), SSqSum.end());
+  out.push_back(count); out.push_back(newRSum); out.push_back(newRSqSum);
+}
+void applyMoments(ol_learner* h, const std::vector<long double>& mom, bool bInit, Real rRateFac) {
+  const int dS = h->dS;
+  const Real learnR = (Real)h->cfg.learnrate / (1 + (Real)h->nGradSteps * h->cfg.epsAnneal);
+  const Real annealLearnR = std::min((Real)1, rRateFac * learnR);
+  const Real WS = bInit ? 1 : annealLearnR, WR = bInit ? 1 : annealLearnR;
+  const long double count = mom[2 * dS];
+  const auto updateStats = [](nnReal& mean, nnReal& stdev, nnReal& invstdev, const Real learnRate,
+                              const long double Evar, const long double Evar2) {
+    mean += learnRate * Evar;
+    auto variance = Evar2 - Evar * Evar * (2 * learnRate - learnRate * learnRate);
+    static constexpr long double EPS = FLT_EPSILON;
+    variance = std::max(variance, EPS);
+    stdev += learnRate * (std::sqrt(variance) - stdev);
+    invstdev = 1 / stdev;
+  };
+  if (WR > 0) updateStats(h->rewMean, h->rewStd, h->rewScale, WR, mom[2 * dS + 1] / count, mom[2 * dS + 2] / count);
+  if (WS > 0) for (int k = 0; k < dS; ++k)
+    updateStats(h->stMean[k], h->stStd[k], h->stScale[k], WS, mom[k] / count, mom[dS + k] / count);
+}
+
+// MemoryProcessing::updateTrainingStatistics (MemoryProcessing.cpp:187-259), nThreads = 1
+void updateTrainingStatistics(ol_learner* h) {
+  const int64_t nGradSteps = h->nGradSteps + 1;
+  const bool bRecompute = (nGradSteps % 1000) == 0;
+  const Real C = h->cfg.clipImpWeight, E = h->cfg.epsAnneal;
+  h->CmaxRet = 1 + C / (1 + (Real)nGradSteps * E);   // Utilities::annealRate (FunctionUtilities.h:69-72)
+  h->CinvRet = 1 / h->CmaxRet;
+  size_t nOffPol = 0;
+  Fval maxAbsE = -1e9, maxQ = -1e9, minQ = 1e9;
+  Real sumDKL = 0, sumE2 = 0, sumQ2 = 0, sumQ1 = 0, sumR = 0;
+  for (auto& ep : h->episodes) {
+    Episode& EP = *ep;
+    if (bRecompute) { epRecompute(EP, (Fval)h->CmaxRet, (Fval)h->CinvRet); retraceEpisode(h, EP); }
+    const Fval Nsteps = EP.N;
+    maxAbsE = std::max(EP.maxAbsErr, maxAbsE);
+    maxQ = std::max(EP.maxQ, maxQ); minQ = std::min(EP.minQ, minQ);
+    sumDKL += Nsteps * EP.avgKL;
+    nOffPol += Nsteps * EP.fracFar;   // size_t += float: float add, then truncation (:227)
+    sumE2 += Nsteps * EP.avgSqErr;
+    sumQ2 += EP.sumQ2; sumQ1 += EP.sumQ; sumR += EP.totR;
+  }
+  if (h->CmaxRet <= 1) nOffPol = 0;
+  const int64_t nData = h->nTransitions; const size_t setSize = h->episodes.size();
+  h->stats.nFarPolicySteps = (int64_t)nOffPol;
+  const Real maxN = (Real)h->maxObsGlobal, BS = h->Bglobal;
+  const Real learnRefer = 0.1 * BS / std::max(maxN, (Real)nData);
+  h->stats.maxAbsError += learnRefer * (maxAbsE - h->stats.maxAbsError);
+  h->stats.avgKLdivergence = sumDKL / nData;
+  h->stats.avgSquaredErr = sumE2 / nData;
+  h->stats.avgReturn = sumR / setSize;
+  h->stats.avgQ = sumQ1 / nData;
+  h->stats.maxQ = maxQ; h->stats.minQ = minQ;
+  h->stats.stdevQ = sumQ2 / nData - h->stats.avgQ * h->stats.avgQ;
+  h->stats.stdevQ = std::sqrt(std::max(h->stats.stdevQ, 1e-16));
+}
+
+// MemoryProcessing::applyEpisodesRemovalAlgo, "oldest" filter (MemoryProcessing.cpp:261-275,327-351)
+void applyEpisodesRemoval(ol_learner* h) {
+  const auto cmp = [](const std::unique_ptr<Episode>& a, const std::unique_ptr<Episode>& b) {
+    return a->ID > b->ID;
+  };
+  if (h->cfg.episode_order == HL_ORDER_REFERENCE) std::sort(h->episodes.begin(), h->episodes.end(), cmp);
+  else std::stable_sort(h->episodes.begin(), h->episodes.end(), cmp);
+  while (!h->episodes.empty() &&
+         h->nTransitions - (int64_t)h->episodes.back()->N > h->maxObsLocal) {
+    h->nTransitions -= h->episodes.back()->ndata();
+    h->episodes.pop_back();
+  }
+}
+
+// Sample_uniform::sample + Sampling::IDtoSeqStep (ReplayMemory/Sampling.cpp:26-47,82-96)
+void sampleUniform(ol_learner* h, std::vector<int64_t>& flat) {
+  const int B = h->B; const uint64_t nData = (uint64_t)h->nTransitions;
+  flat.resize(B);
+  size_t it = 0;
+  while (it != (size_t)B) {
+    for (size_t i = it; i < (size_t)B; ++i) flat[i] = (int64_t)uniformIndex(h->gen, nData);
+    std::sort(flat.begin(), flat.end());
+    it = std::unique(flat.begin(), flat.end()) - flat.begin();
+  }
+}
+void idToSeqStep(ol_learner* h, const std::vector<int64_t>& flat, std::vector<int64_t>& seq,
+                 std::vector<int64_t>& obs) {
+  const size_t B = flat.size(); seq.assign(B, 0); obs.assign(B, 0);
+  size_t i = 0; int64_t prefix = 0;
+  for (size_t k = 0; k < h->episodes.size() && i < B; ++k) {
+    const int64_t nsteps = h->episodes[k]->ndata();
+    while (i < B && flat[i] < prefix + nsteps) { obs[i] = flat[i] - prefix; seq[i] = (int64_t)k; ++i; }
+    prefix += nsteps;
+  }
+}
+
+// Adam::step + AdamOptimizer::apply_update (Network/Optimizer.cpp:61-108,122-160)
+void adamApply(ol_learner* h) {
+  const Real factor = 1.0 / h->Bglobal;
+  // Optimizer.h:52-53: nnReal eta = eta_init; annealRate<nnReal>(eta, nStep, epsAnneal)
+  const nnReal eta0 = (nnReal)h->cfg.learnrate;
+  const nnReal _eta = (nnReal)(eta0 / (1 + (nnReal)h->nStep * h->cfg.epsAnneal));
+  for (int t = 0; t < std::max(1, h->cfg.ref_threads); ++t) (void)h->gen.next();  // Saru seed draw (:139)
+  const nnReal betat1 = (nnReal)h->beta_t_1, betat2 = (nnReal)h->beta_t_2;
+  const nnReal eta = _eta * std::sqrt(1 - betat2) / (1 - betat1);
+  const nnReal B1 = (nnReal)0.9, B2 = (nnReal)0.999, lambda = (nnReal)h->cfg.nnLambda, fac = (nnReal)factor;
+  nnReal* Wp = h->W.data(); nnReal* M1 = h->M1.data(); nnReal* M2 = h->M2.data(); nnReal* Gp = h->G.data();
+  for (int64_t i = 0; i < h->nParams; ++i) {
+    const nnReal penal = -Wp[i] * lambda;
+    const nnReal DW = fac * Gp[i];
+    M1[i] = B1 * M1[i] + (1 - B1) * DW;
+    M2[i] = B2 * M2[i] + (1 - B2) * DW * DW;
+    const nnReal numer = B1 * M1[i] + (1 - B1) * DW;   // SMARTIES_NESTEROV_ADAM
+    M2[i] = M2[i] < M1[i] * M1[i] ? M1[i] * M1[i] : M2[i];  // SMARTIES_SAFE_ADAM
+    const nnReal ret = numer / (nnEPS + std::sqrt(M2[i]));
+    Wp[i] += eta * (ret + penal);                       // SMARTIES_ADAMW
+  }
+  std::fill(h->G.begin(), h->G.end(), 0);
+  h->beta_t_1 *= 0.9; if (h->beta_t_1 < nnEPS) h->beta_t_1 = 0;
+  h->beta_t_2 *= 0.999; if (h->beta_t_2 < nnEPS) h->beta_t_2 = 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C entry points
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int ol_create(const hl_config* cfg, ol_learner** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
+  if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
+      cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
+  if (cfg->adv_kind != HL_ADV_ZERO) return HL_ERR_UNSUPPORTED;
+  if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
+      cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
+  auto* h = new ol_learner(); h->cfg = *cfg;
+  h->dS = cfg->dimS; h->dA = cfg->dimA;
+  // HyperParameters::defineDistributedLearning (Settings/HyperParameters.cpp:177-205)
+  const Real nL = cfg->n_ranks;
+  h->Bglobal = cfg->batchSize > 1 ? (int)(std::ceil(cfg->batchSize / nL) * nL) : cfg->batchSize;
+  h->B = cfg->batchSize > 1 ? h->Bglobal / cfg->n_ranks : h->Bglobal;
+  h->maxObsGlobal = (int64_t)(std::ceil(cfg->maxTotObsNum / nL) * nL);
+  h->maxObsLocal = h->maxObsGlobal / cfg->n_ranks;
+  int64_t minObs = cfg->minTotObsNum <= 0 ? cfg->maxTotObsNum : cfg->minTotObsNum;
+  minObs = std::min(minObs, cfg->maxTotObsNum);
+  minObs = (int64_t)(std::ceil(minObs / nL) * nL);
+  h->minObsLocal = minObs / cfg->n_ranks;
+  buildNet(h);
+  h->gen.seed((uint32_t)(cfg->randSeed + (uint64_t)cfg->rank));   // ExecutionInfo.cpp:387,391
+  h->stMean.assign(h->dS, 0); h->stStd.assign(h->dS, 1); h->stScale.assign(h->dS, 1);
+  h->beta = cfg->clipImpWeight <= 0 ? 1 : 1e-4;                     // MemoryBuffer.h:41-44
+  h->CmaxRet = 1 + cfg->clipImpWeight; h->CinvRet = 1 / cfg->clipImpWeight;
+  *out = h; return HL_OK;
+}
+int ol_destroy(ol_learner* h) { delete h; return HL_OK; }
+const char* ol_last_error(const ol_learner* h) { return h ? h->err.c_str() : "null handle"; }
+int64_t ol_num_params(const ol_learner* h) { return h ? h->nParams : -1; }
+int32_t ol_num_outputs(const ol_learner* h) { return h ? h->nOut : -1; }
+int32_t ol_num_layers(const ol_learner* h) { return h ? (int32_t)h->layers.size() : -1; }
+int ol_param_layout(const ol_learner* h, int64_t* indW, int64_t* nW, int64_t* indB, int64_t* nB) {
+  if (!h) return HL_ERR_BAD_ARG;
+  for (size_t l = 0; l < h->layers.size(); ++l) {
+    if (indW) indW[l] = h->layers[l].indW; if (nW) nW[l] = h->layers[l].nW;
+    if (indB) indB[l] = h->layers[l].indB; if (nB) nB[l] = h->layers[l].nB;
+  }
+  return HL_OK;
+}
+int ol_init_weights(ol_learner* h) { if (!h) return HL_ERR_BAD_ARG; initWeights(h); return HL_OK; }
+int ol_set_params(ol_learner* h, const float* w, const float* m1, const float* m2) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (w) std::copy(w, w + h->nParams, h->W.begin());
+  if (m1) std::copy(m1, m1 + h->nParams, h->M1.begin());
+  if (m2) std::copy(m2, m2 + h->nParams, h->M2.begin());
+  return HL_OK;
+}
+int ol_get_params(ol_learner* h, float* w, float* m1, float* m2) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (w) std::copy(h->W.begin(), h->W.end(), w);
+  if (m1) std::copy(h->M1.begin(), h->M1.end(), m1);
+  if (m2) std::copy(h->M2.begin(), h->M2.end(), m2);
+  return HL_OK;
+}
+int ol_set_rng_state(ol_learner* h, const uint32_t s[625]) {
+  if (!h || !s) return HL_ERR_BAD_ARG;
+  std::memcpy(h->gen.x, s, 624 * 4); h->gen.p = s[624]; return HL_OK;
+}
+int ol_get_rng_state(ol_learner* h, uint32_t s[625]) {
+  if (!h || !s) return HL_ERR_BAD_ARG;
+  std::memcpy(s, h->gen.x, 624 * 4); s[624] = h->gen.p; return HL_OK;
+}
+
+// MemoryBuffer::addEpisodeToTrainingSet + Episode::finalize + pushBackEpisode
+// (MemoryBuffer.cpp:131-170, 479-520; Episode.cpp:244-267, 269-274)
+int ol_append_episode(ol_learner* h, int32_t N, const float* states, const double* actions,
+                      const double* mu, const double* rewards, const float* values,
+                      const float* advantages, int32_t terminated, int64_t tag) {
+  if (!h || !states || !actions || !mu || !rewards || !values) return HL_ERR_BAD_ARG;
+  if (N < 2) return fail(h, HL_ERR_BAD_ARG, "Episode must at least have s0 and sT");
+  auto EP = std::make_unique<Episode>();
+  const int dS = h->dS, dA = h->dA;
+  EP->N = N; EP->term = terminated != 0; EP->tag = tag;
+  EP->S.assign(states, states + (size_t)N * dS);
+  EP->A.assign(actions, actions + (size_t)N * dA);
+  EP->MU.assign(mu, mu + (size_t)N * 2 * dA);
+  EP->R.assign(rewards, rewards + N);
+  EP->V.assign(values, values + N);
+  if (advantages) EP->ADV.assign(advantages, advantages + N); else EP->ADV.assign(N, 0);
+  for (int t = 1; t < N; ++t) EP->totR += rewards[t];          // MemoryBuffer.cpp:95-96
+  h->nSeenSteps += N - 2;                                        // storeAction, t = 1..N-2 (:110)
+  EP->DQ.assign(N, 0); EP->DKL.assign(N, 0); EP->IMPW.assign(N, 1); EP->IMPW[N - 1] = 0;
+  EP->RET.assign(N, 0);
+  retraceEpisode(h, *EP);                                        // computeReturnEstimator (:138)
+  // pushBackEpisode: placeholder error (:486) and ID = max(nLocTimeStepsTrain(), 0) (:484, :515),
+  // evaluated BEFORE the final increaseLocalSeenSteps of addEpisodeToTrainingSet (:167)
+  const Real EPS = FLT_EPSILON;
+  const Fval maxError = (Fval)std::sqrt(std::max(EPS, h->stats.avgSquaredErr));
+  std::fill(EP->DQ.begin(), EP->DQ.end(), maxError);
+  EP->avgSqErr = maxError * maxError; EP->maxAbsErr = maxError;
+  const int64_t locTrain = h->nGatheredB4Startup == INT64_MAX ? -1 : h->nSeenSteps - h->nGatheredB4Startup;
+  EP->ID = std::max(locTrain, (int64_t)0);
+  h->nSeenSteps += 1;                                            // :167
+  h->nTransitions += EP->ndata();
+  h->episodes.push_back(std::move(EP));
+  h->nSeenEps += 1;
+  return HL_OK;
+}
+
+int ol_get_scaling(ol_learner* h, float* m, float* s, float* r3) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (m) std::copy(h->stMean.begin(), h->stMean.end(), m);
+  if (s) std::copy(h->stScale.begin(), h->stScale.end(), s);
+  if (r3) { r3[0] = h->rewMean; r3[1] = h->rewScale; r3[2] = h->rewStd; }
+  return HL_OK;
+}
+int ol_set_scaling(ol_learner* h, const float* m, const float* s, const float* r3) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (m) std::copy(m, m + h->dS, h->stMean.begin());
+  if (s) { std::copy(s, s + h->dS, h->stScale.begin()); for (int k = 0; k < h->dS; ++k) h->stStd[k] = 1 / s[k]; }
+  if (r3) { h->rewMean = r3[0]; h->rewScale = r3[1]; h->rewStd = r3[2]; }
+  return HL_OK;
+}
+int ol_get_episode_info(ol_learner* h, int64_t pos, int64_t* tag, int32_t* nsteps, int32_t* term) {
+  if (!h || pos < 0 || pos >= (int64_t)h->episodes.size()) return HL_ERR_BAD_ARG;
+  const Episode& EP = *h->episodes[pos];
+  if (tag) *tag = EP.tag; if (nsteps) *nsteps = EP.N; if (term) *term = EP.term;
+  return HL_OK;
+}
+int ol_get_episode_field(ol_learner* h, int64_t pos, int32_t field, float* dst, int32_t cap) {
+  if (!h || !dst || pos < 0 || pos >= (int64_t)h->episodes.size()) return HL_ERR_BAD_ARG;
+  const Episode& EP = *h->episodes[pos];
+  if (cap < EP.N) return HL_ERR_BAD_ARG;
+  const std::vector<float>* v = nullptr;
+  switch (field) {
+    case HL_EP_RETURN: v = &EP.RET; break; case HL_EP_VALUE: v = &EP.V; break;
+    case HL_EP_ADVANTAGE: v = &EP.ADV; break; case HL_EP_IMPW: v = &EP.IMPW; break;
+    case HL_EP_DKL: v = &EP.DKL; break; case HL_EP_DELTAQ: v = &EP.DQ; break;
+    default: return HL_ERR_BAD_ARG;
+  }
+  std::copy(v->begin(), v->end(), dst); return HL_OK;
+}
+
+// Learner::initializeLearner (Learners/Learner.cpp:47-72)
+int ol_initialize(ol_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (h->episodes.empty()) return fail(h, HL_ERR_TOO_FEW_DATA, "empty replay");
+  updateCounters(h, true);
+  { std::vector<long double> mom; computeMoments(h, mom); applyMoments(h, mom, true, 1); }
+  h->nGatheredB4Startup = h->minObsLocal;
+  for (auto& ep : h->episodes) retraceEpisode(h, *ep);   // rescaleAllReturnEstimator (:460-481)
+  h->initialized = true; return HL_OK;
+}
+
+// Learner_approximator::spawnTrainTasks (Learner_approximator.cpp:36-92), nThreads = 1
+int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (!h->initialized) return fail(h, HL_ERR_STATE, "step before initialize");
+  if (h->inStep) return fail(h, HL_ERR_STATE, "step_begin twice");
+  if (h->minObsLocal < h->cfg.batchSize && false) return HL_ERR_TOO_FEW_DATA;
+  if (h->nTransitions < h->B) return fail(h, HL_ERR_TOO_FEW_DATA, "Parameter minTotObsNum is too low for given problem");
+  const int B = h->B, dS = h->dS, dA = h->dA, nOut = h->nOut;
+  if (flat_in) h->bFlat.assign(flat_in, flat_in + B); else sampleUniform(h, h->bFlat);
+  idToSeqStep(h, h->bFlat, h->bEp, h->bT);
+  h->bTag.resize(B);
+  if (h->tap) { h->tState.assign((size_t)B * dS, 0); h->tO.assign((size_t)B * nOut, 0); h->tG.assign((size_t)B * nOut, 0);
+    h->tRho.assign(B, 0); h->tDkl.assign(B, 0); h->tDq.assign(B, 0); h->tFar.assign(B, 0); }
+  std::vector<nnReal> inp(dS); std::vector<Real> O(nOut), On(nOut), grad(nOut);
+  const size_t outDense = h->layers.size() - 2, outParam = h->layers.size() - 1;
+  for (int b = 0; b < B; ++b) {
+    Episode& EP = *h->episodes[h->bEp[b]]; const int t = (int)h->bT[b];
+    h->bTag[b] = EP.tag;
+    // MemoryBuffer::sampleMinibatch gather: Episode::standardizedState (Episode.h:172-183)
+    for (int i = 0; i < dS; ++i) inp[i] = (EP.S[(size_t)t * dS + i] - h->stMean[i]) * h->stScale[i];
+    if (h->tap) std::copy(inp.begin(), inp.end(), h->tState.begin() + (size_t)b * dS);
+    forwardNet(h, inp.data(), h->X, h->Y); getOutput(h, h->Y, O.data());
+    if (EP.isTruncated(t + 1)) {   // RACER_train.cpp:23-27
+      std::vector<nnReal> inpn(dS);
+      for (int i = 0; i < dS; ++i) inpn[i] = (EP.S[(size_t)(t + 1) * dS + i] - h->stMean[i]) * h->stScale[i];
+      forwardNet(h, inpn.data(), h->Xn, h->Yn); getOutput(h, h->Yn, On.data());
+      const Fval Vn = (Fval)scaleNet2V(On[0]);
+      epUpdateValues(EP, t + 1, Vn, Vn);
+    }
+    Real rho, dkl, dq, V; int far;
+    ol_head_vracer(dA, h->cfg.bounded, O.data(), &EP.A[(size_t)t * dA], &EP.MU[(size_t)t * 2 * dA],
+                   (Real)EP.RET[t], h->beta, h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V);
+    // Approximator::setGradient -> Activation::addOutputDelta (Approximator.h:190-204, Activation.h:108-117)
+    for (auto& e : h->E) std::fill(e.begin(), e.end(), 0);
+    for (int o = 0; o < 1 + dA; ++o) h->E[outDense][o] += grad[o];
+    for (int o = 0; o < dA; ++o) h->E[outParam][o] += grad[1 + dA + o];
+    if (h->tap) { for (int o = 0; o < nOut; ++o) { h->tO[(size_t)b * nOut + o] = O[o]; }
+      for (int o = 0; o < 1 + dA; ++o) h->tG[(size_t)b * nOut + o] = h->E[outDense][o];
+      for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + 1 + dA + o] = h->E[outParam][o];
+      h->tRho[b] = rho; h->tDkl[b] = dkl; h->tFar[b] = (uint8_t)far; }
+    // MiniBatch::setMseDklImpw / setValues (RACER_train.cpp:59-60; MiniBatch.h:161-175)
+    epUpdateCumulative(EP, t, (Fval)dq, (Fval)dkl, (Fval)rho, (Fval)h->CmaxRet, (Fval)h->CinvRet);
+    epUpdateValues(EP, t, (Fval)V, (Fval)V);
+    if (h->tap) h->tDq[b] = EP.DQ[t];
+    backwardNet(h);
+  }
+  if (h->tap) h->tGradSum = h->G;
+  h->nStep++;   // AdamOptimizer::prepare_update (Optimizer.cpp:119)
+  // Learner::processMemoryBuffer (Learner.cpp:74-100) up to the counters all-reduce; none of
+  // it reads the (possibly still in flight) gradient sum, so doing it here keeps the order
+  const int64_t currStep = h->nGradSteps + 1;
+  updateTrainingStatistics(h);
+  h->momentsPending = false;
+  if (currStep % 1000 == 0) {
+    computeMoments(h, h->moments);
+    if (h->cfg.n_ranks > 1) h->momentsPending = true; else applyMoments(h, h->moments, false, 10);
+  }
+  applyEpisodesRemoval(h);
+  h->inStep = true; return HL_OK;
+}
+int ol_moments_exchange(ol_learner* h, double* io, int32_t write_back) {
+  if (!h || !io) return HL_ERR_BAD_ARG;
+  if (!h->momentsPending) return fail(h, HL_ERR_STATE, "no reward/state moments pending this step");
+  const size_t n = h->moments.size();
+  if (write_back) for (size_t i = 0; i < n; ++i) h->moments[i] = io[i];
+  else for (size_t i = 0; i < n; ++i) io[i] = (double)h->moments[i];
+  return HL_OK;
+}
+int ol_grad_exchange(ol_learner* h, float* grad_io, int32_t write_back) {
+  if (!h || !grad_io) return HL_ERR_BAD_ARG;
+  if (write_back) std::copy(grad_io, grad_io + h->nParams, h->G.begin());
+  else std::copy(h->G.begin(), h->G.end(), grad_io);
+  return HL_OK;
+}
+int ol_counters_exchange(ol_learner* h, int64_t c[4], int32_t write_back) {
+  if (!h || !c) return HL_ERR_BAD_ARG;
+  if (write_back) { h->nFarGlobal = c[2]; h->nStoredGlobal = c[3]; h->countersReduced = true; }
+  else { c[0] = h->nSeenEps; c[1] = h->nSeenSteps; c[2] = h->stats.nFarPolicySteps; c[3] = h->nTransitions; }
+  return HL_OK;
+}
+int ol_step_end(ol_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (!h->inStep) return fail(h, HL_ERR_STATE, "step_end without step_begin");
+  if (h->momentsPending) { applyMoments(h, h->moments, false, 10); h->momentsPending = false; }
+  updateCounters(h, false);
+  adamApply(h);                                   // Learner_approximator::applyGradient (:99-105)
+  h->nGradSteps++;                                // Learner::globalGradCounterUpdate (Learner.cpp:130-133)
+  h->inStep = false; return HL_OK;
+}
+int ol_step(ol_learner* h, int32_t n, const int64_t* flat) {
+  if (!h) return HL_ERR_BAD_ARG;
+  for (int s = 0; s < n; ++s) {
+    int rc = ol_step_begin(h, flat ? flat + (size_t)s * h->B : nullptr); if (rc) return rc;
+    rc = ol_step_end(h); if (rc) return rc;
+  }
+  return HL_OK;
+}
+int ol_sync(ol_learner*) { return HL_OK; }
+int ol_set_tap(ol_learner* h, int32_t e) { if (!h) return HL_ERR_BAD_ARG; h->tap = e != 0; return HL_OK; }
+
+int ol_readback(ol_learner* h, int32_t what, void* dst, int64_t bytes) {
+  if (!h || !dst) return HL_ERR_BAD_ARG;
+  const void* src = nullptr; int64_t n = 0;
+  switch (what) {
+    case HL_TAP_FLAT: src = h->bFlat.data(); n = h->bFlat.size() * 8; break;
+    case HL_TAP_EPISODE: src = h->bEp.data(); n = h->bEp.size() * 8; break;
+    case HL_TAP_TSTEP: src = h->bT.data(); n = h->bT.size() * 8; break;
+    case HL_TAP_TAG: src = h->bTag.data(); n = h->bTag.size() * 8; break;
+    case HL_TAP_STATE: src = h->tState.data(); n = h->tState.size() * 4; break;
+    case HL_TAP_OUTPUT: src = h->tO.data(); n = h->tO.size() * 8; break;
+    case HL_TAP_OUTGRAD: src = h->tG.data(); n = h->tG.size() * 8; break;
+    case HL_TAP_RHO: src = h->tRho.data(); n = h->tRho.size() * 8; break;
+    case HL_TAP_DKL: src = h->tDkl.data(); n = h->tDkl.size() * 8; break;
+    case HL_TAP_DELTAQ: src = h->tDq.data(); n = h->tDq.size() * 8; break;
+    case HL_TAP_FAR: src = h->tFar.data(); n = h->tFar.size(); break;
+    case HL_TAP_GRADSUM: src = h->tGradSum.data(); n = h->tGradSum.size() * 4; break;
+    default: return HL_ERR_BAD_ARG;
+  }
+  if (n == 0) return fail(h, HL_ERR_STATE, "tap not recorded (hl_set_tap before the step)");
+  if (bytes < n) return HL_ERR_BAD_ARG;
+  std::memcpy(dst, src, n); return HL_OK;
+}
+int ol_get_scalars(ol_learner* h, hl_scalars* o) {
+  if (!h || !o) return HL_ERR_BAD_ARG;
+  o->beta = h->beta; o->alpha = h->alpha; o->CmaxRet = h->CmaxRet; o->CinvRet = h->CinvRet;
+  o->nGradSteps = h->nGradSteps; o->nStoredSteps = h->nTransitions; o->nStoredEps = h->episodes.size();
+  o->nFarPolicySteps = h->stats.nFarPolicySteps; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
+  o->adam_beta_t_1 = h->beta_t_1; o->adam_beta_t_2 = h->beta_t_2; o->adam_nStep = h->nStep;
+  return HL_OK;
+}
+int ol_get_stats(ol_learner* h, hl_stats* o) { if (!h || !o) return HL_ERR_BAD_ARG; *o = h->stats; return HL_OK; }
+
+int ol_synth_episode_len(const synth_cfg* c, uint64_t e, int* term) { return synth_episode_len(c, e, term); }
+void ol_synth_episode(const synth_cfg* c, uint64_t e, float* s, double* a, double* mu, double* r, float* v) {
+  synth_episode(c, e, s, a, mu, r, v);
+}
+
+}  // extern "C"

@@ -1,0 +1,392 @@
+/*
+ * oracle/ref_driver.cpp -- harness around the UNMODIFIED reference learner.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file contains no reference source: it
+ * #includes the reference headers where they lie under /root/reference and is
+ * linked against objects compiled from the reference .cpp files in place
+ * (oracle/Makefile; outputs only under oracle/_ref/).  It
+ *   (1) instantiates RACER<Zero_advantage,Continuous_policy,Rvec> (= VRACER,
+ *       Learners/AlgoFactory.cpp:132-152) exactly as Appendix B of SURVEY.md,
+ *   (2) fills its MemoryBuffer with the deterministic episodes of
+ *       oracle/synth.h (through Episode's public fields + finalize +
+ *       computeReturnEstimator + pushBackEpisode, i.e. the calls
+ *       MemoryBuffer::addEpisodeToTrainingSet makes, MemoryBuffer.cpp:131-170)
+ *       or through the plug-in path Learner::select (mode bench fill=select),
+ *   (3) either steps the learner through its own task queue ("official") or
+ *       re-plays the body of Learner_approximator::spawnTrainTasks
+ *       (Learner_approximator.cpp:36-92) + RACER::setupTasks stepMain /
+ *       stepComplete (RACER.cpp:81-108) call by call ("manual") so that
+ *       per-sample quantities can be tapped between the reference's own calls,
+ *   (4) writes golden fixtures (oracle/blobio.h format) or timing JSON.
+ * "official" and "manual" produce bit-identical weights (tests check this).
+ */
+#define protected public
+#define private public
+#include "smarties/Learners/RACER.h"
+#include "smarties/Math/Zero_advantage.h"
+#include "smarties/Math/Continuous_policy.h"
+#include "smarties/Network/Approximator.h"
+#include "smarties/Network/Optimizer.h"
+#include "smarties/Network/Network.h"
+#include "smarties/ReplayMemory/MemoryProcessing.h"
+#include "smarties/Utils/TaskQueue.h"
+#undef protected
+#undef private
+
+#include "synth.h"
+#include "blobio.h"
+
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <sstream>
+#include <string>
+
+using namespace smarties;
+
+struct Args {
+  std::map<std::string, std::string> kv;
+  std::string s(const std::string& k, const std::string& d) const {
+    auto it = kv.find(k); return it == kv.end() ? d : it->second;
+  }
+  double d(const std::string& k, double dflt) const {
+    auto it = kv.find(k); return it == kv.end() ? dflt : atof(it->second.c_str());
+  }
+  long l(const std::string& k, long dflt) const {
+    auto it = kv.find(k); return it == kv.end() ? dflt : atol(it->second.c_str());
+  }
+};
+
+static std::vector<Uint> parseList(const std::string& s) {
+  std::vector<Uint> r; std::stringstream ss(s); std::string tok;
+  while (std::getline(ss, tok, ',')) if (tok.size()) r.push_back((Uint)atol(tok.c_str()));
+  return r;
+}
+
+static std::vector<uint32_t> rngState(const std::mt19937& g) {
+  std::ostringstream ss; ss << g;
+  std::istringstream is(ss.str());
+  std::vector<uint32_t> r; unsigned long v;
+  while (is >> v) r.push_back((uint32_t)v);
+  return r;  // 624 state words + position
+}
+
+using VRACER = RACER<Zero_advantage, Continuous_policy, Rvec>;
+
+struct Harness {
+  ExecutionInfo& info;
+  MDPdescriptor MDP;
+  std::unique_ptr<HyperParameters> HP;
+  std::unique_ptr<VRACER> L;
+  std::unique_ptr<TaskQueue> algo, dataQ;
+  synth_cfg SC;
+
+  Harness(ExecutionInfo& I, const Args& A) : info(I) {
+    const int nThr = (int)A.l("threads", 1);
+    info.nThreads = nThr; omp_set_num_threads(nThr);
+    info.randSeed = A.l("seed", 42); info.initialze();
+    info.learners_train_comm = MPI_COMM_SELF; info.bIsMaster = true;
+    info.nAgents = 1; info.nOwnedEnvironments = 1; info.nEnvironments = 1;
+    info.logAllSamples = 0; info.learnersOnWorkers = false; info.restart = "none";
+    const Uint dS = A.l("dimS", 17), dA = A.l("dimA", 6);
+    MDP.dimState = dS; MDP.dimAction = dA;
+    const std::string bnd = A.s("bounded", std::string(dA, '1'));
+    MDP.bActionSpaceBounded = std::vector<bool>(dA, false);
+    for (Uint i = 0; i < dA && i < bnd.size(); ++i) MDP.bActionSpaceBounded[i] = bnd[i] == '1';
+    MDP.synchronize([](void*, size_t) {});
+    MDP.policyVecDim = 2 * dA;
+    HP = std::make_unique<HyperParameters>(dS, dA);
+    HP->learner = "VRACER"; HP->returnsEstimator = "retrace";
+    HP->nnLayerSizes = parseList(A.s("layers", "256,256"));
+    HP->nnFunc = A.s("nnFunc", "SoftSign");
+    HP->batchSize = A.l("batch", 256);
+    HP->maxTotObsNum = A.l("maxObs", 1000000);
+    HP->minTotObsNum = A.l("minObs", HP->maxTotObsNum);
+    HP->clipImpWeight = A.d("clip", 4);
+    HP->penalTol = A.d("penalTol", 0.1);
+    HP->epsAnneal = A.d("epsAnneal", 0);
+    HP->gamma = A.d("gamma", 0.995);
+    HP->lambda = A.d("lambda", 1);
+    HP->learnrate = A.d("learnrate", 1e-4);
+    HP->explNoise = A.d("explNoise", 0.4472135955);
+    HP->outWeightsPrefac = A.d("outWeightsPrefac", 0.1);
+    HP->nnLambda = A.d("nnLambda", 0);
+    HP->obsPerStep = 0;  // never block gradient steps on data
+    HP->saveFreq = 1000000000;
+    HP->defineDistributedLearning(info); HP->check();
+    L = std::make_unique<VRACER>(MDP, *HP, info);
+    L->setLearnerName("agent_00", 0);
+    algo = std::make_unique<TaskQueue>([]() { return false; });
+    dataQ = std::make_unique<TaskQueue>([]() { return false; });
+    L->setupTasks(*algo); L->setupDataCollectionTasks(*dataQ);
+    SC.seed = (uint64_t)A.l("synthSeed", 7); SC.dimS = (int)dS; SC.dimA = (int)dA;
+    SC.lenMin = (int)A.l("lenMin", 201); SC.lenMax = (int)A.l("lenMax", 201);
+    SC.pTerminated = A.d("pTerm", 0.0); SC.muSpread = A.d("muSpread", 0.5);
+    SC.actNoise = A.d("actNoise", 1.0);
+  }
+
+  // mirror of MemoryBuffer::addEpisodeToTrainingSet for a ready-made episode
+  void pushSynthEpisode(uint64_t e) {
+    int term = 0; const int N = synth_episode_len(&SC, e, &term);
+    const int dS = SC.dimS, dA = SC.dimA;
+    std::vector<float> S((size_t)N * dS), V(N);
+    std::vector<double> Act((size_t)N * dA), Mu((size_t)N * 2 * dA), R(N);
+    synth_episode(&SC, e, S.data(), Act.data(), Mu.data(), R.data(), V.data());
+    auto EP = std::make_unique<Episode>(MDP);
+    EP->bReachedTermState = term; EP->agentID = (Sint)e;  // agentID doubles as content tag
+    for (int t = 0; t < N; ++t) {
+      EP->states.push_back(Fvec(S.begin() + (size_t)t * dS, S.begin() + (size_t)(t + 1) * dS));
+      EP->latent_states.push_back(Fvec());
+      EP->actions.push_back(Rvec(Act.begin() + (size_t)t * dA, Act.begin() + (size_t)(t + 1) * dA));
+      EP->policies.push_back(Rvec(Mu.begin() + (size_t)t * 2 * dA, Mu.begin() + (size_t)(t + 1) * 2 * dA));
+      EP->rewards.push_back(R[t]);
+      if (t) EP->totR += R[t];
+      EP->stateValue.push_back(V[t]);
+      EP->actionAdvantage.push_back(0);
+      if (t && t < N - 1) L->data->increaseLocalSeenSteps();   // storeAction (MemoryBuffer.cpp:110)
+    }
+    const long tStamp = std::max(L->data->nLocTimeStepsTrain(), (long)0);
+    EP->finalize(tStamp);
+    MemoryProcessing::computeReturnEstimator(*L->data, *EP);
+    L->data->pushBackEpisode(std::move(EP));
+    L->data->increaseLocalSeenSteps();                         // MemoryBuffer.cpp:167
+    L->data->increaseLocalSeenEps();
+  }
+};
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::high_resolution_clock::now().time_since_epoch()).count();
+}
+
+struct StepTap {
+  std::vector<int64_t> flat, tag, tstep;
+  std::vector<double> O, G, rho, dkl, dq;   // double-precision taps
+  std::vector<uint8_t> far;
+};
+
+// One gradient step, call by call as the reference makes them, with taps.
+static void manualStep(Harness& H, StepTap* tap) {
+  VRACER& L = *H.L;
+  Approximator& NET = *L.networks[0];
+  const Uint B = H.HP->batchSize_local;
+  L.profiler->stop();
+  const MiniBatch MB = L.data->sampleMinibatch(B, L.nGradSteps());
+  const Uint nOut = NET.nOutputs();
+  if (tap) {
+    // episode order at sampling time -> flat index of each sample
+    std::map<const Episode*, int64_t> prefix; int64_t p = 0;
+    for (Uint k = 0; k < L.data->episodes.size(); ++k) {
+      prefix[L.data->episodes[k].get()] = p; p += L.data->episodes[k]->ndata();
+    }
+    tap->flat.resize(B); tap->tag.resize(B); tap->tstep.resize(B);
+    tap->O.resize(B * nOut); tap->G.resize(B * nOut);
+    tap->rho.resize(B); tap->dkl.resize(B); tap->dq.resize(B); tap->far.resize(B);
+    for (Uint b = 0; b < B; ++b) {
+      tap->tstep[b] = MB.sampledTstep(b);
+      tap->tag[b] = MB.episodes[b]->agentID;
+      tap->flat[b] = prefix[MB.episodes[b]] + MB.sampledTstep(b);
+    }
+  }
+  for (Uint b = 0; b < B; ++b) {
+    NET.load(MB, b, 0);
+    const Uint t = MB.sampledTstep(b);
+    const Real beta = L.beta, Cmax = L.CmaxRet, Cinv = L.CinvRet;
+    L.Train(MB, 0, b);
+    if (tap) {
+      const Activation* A = NET.getContext(b).activation(t, 0);
+      const Rvec O = A->getOutput();
+      const NNvec G = A->getOutputDelta();
+      for (Uint o = 0; o < nOut; ++o) { tap->O[b * nOut + o] = O[o]; tap->G[b * nOut + o] = G[o]; }
+      const Continuous_policy POL(L.pol_start, L.aInfo, O);
+      const Real RHO = POL.importanceWeight(MB.action(b, t), MB.mu(b, t));
+      tap->rho[b] = RHO; tap->dkl[b] = POL.KLDivergence(MB.mu(b, t));
+      tap->dq[b] = MB.episodes[b]->deltaValue[t];
+      tap->far[b] = isFarPolicy(RHO, Cmax, Cinv) ? 1 : 0;
+      (void)beta;
+    }
+    NET.backProp(b);
+  }
+  NET.prepareUpdate();
+  NET.updateGradStats(L.learner_name, L.nGradSteps());
+}
+
+static void finishStep(Harness& H) {
+  VRACER& L = *H.L;
+  L.processMemoryBuffer();
+  L.logStats();
+  L.applyGradient();
+  L.globalGradCounterUpdate();
+}
+
+static std::vector<float> paramsOf(const Parameters* P) {
+  return std::vector<float>(P->params, P->params + P->nParams);
+}
+
+static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& out) {
+  Harness H(info, A);
+  VRACER& L = *H.L;
+  const long nEps = A.l("nEps", 40), nSteps = A.l("nSteps", 10), tapSteps = A.l("tapSteps", nSteps);
+  const std::vector<Uint> gradSteps = parseList(A.s("gradSteps", "1,2"));
+  const std::vector<Uint> retSteps = parseList(A.s("retSteps", ""));
+  const bool official = A.s("path", "manual") == "official";
+  for (long e = 0; e < nEps; ++e) H.pushSynthEpisode((uint64_t)e);
+
+  BlobWriter W(out);
+  Approximator& NET = *L.networks[0];
+  AdamOptimizer* OPT = dynamic_cast<AdamOptimizer*>(NET.opt.get());
+  const Parameters* PW = NET.net->weights.get();
+  {
+    std::vector<int64_t> cfg = {(int64_t)H.MDP.dimStateObserved, (int64_t)H.MDP.dimAction,
+        (int64_t)H.HP->batchSize, nEps, nSteps, (int64_t)PW->nParams, (int64_t)NET.nOutputs(),
+        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax};
+    W.i64("cfg", cfg);
+    std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
+    W.i64("layers", lay);
+    std::vector<uint8_t> bnd; for (Uint i = 0; i < H.MDP.dimAction; ++i) bnd.push_back(H.MDP.bActionSpaceBounded[i]);
+    W.u8("bounded", bnd);
+    std::vector<double> hp = {H.HP->clipImpWeight, H.HP->penalTol, H.HP->epsAnneal, H.HP->gamma,
+        H.HP->lambda, H.HP->learnrate, H.HP->explNoise, H.HP->outWeightsPrefac, H.HP->nnLambda,
+        H.SC.pTerminated, H.SC.muSpread, H.SC.actNoise, (double)H.HP->maxTotObsNum};
+    W.f64("hp", hp);
+    std::vector<int64_t> iw, ib, nw, nb;
+    for (Uint l = 0; l < PW->nLayers; ++l) { iw.push_back(PW->indWeights[l]); ib.push_back(PW->indBiases[l]);
+      nw.push_back(PW->nWeights[l]); nb.push_back(PW->nBiases[l]); }
+    W.i64("indWeights", iw); W.i64("indBiases", ib); W.i64("nWeights", nw); W.i64("nBiases", nb);
+  }
+  W.f32("W0", paramsOf(PW));
+  W.u32("rng_before_init", rngState(info.generators[0]));
+
+  // stepInit (RACER.cpp:69-79): Learner::initializeLearner
+  L.initializeLearner(); L.algoSubStepID = 0; L.profiler->start("DATA");
+  W.u32("rng0", rngState(info.generators[0]));
+  W.scalar_d("beta0", L.data->beta); W.scalar_d("cmax0", L.data->CmaxRet);
+  {
+    std::vector<float> sc;
+    for (auto v : H.MDP.stateMean) sc.push_back(v);
+    for (auto v : H.MDP.stateScale) sc.push_back(v);
+    sc.push_back(H.MDP.rewardsMean); sc.push_back(H.MDP.rewardsScale); sc.push_back(H.MDP.rewardsStdDev);
+    W.f32("scaling0", sc);
+    // Retrace estimates after the initial rescale, keyed by content tag
+    std::vector<int64_t> tags, off; std::vector<float> ret; int64_t o = 0;
+    for (Uint k = 0; k < L.data->episodes.size(); ++k) {
+      const Episode& EP = *L.data->episodes[k];
+      tags.push_back(EP.agentID); off.push_back(o); o += EP.nsteps();
+      ret.insert(ret.end(), EP.returnEstimator.begin(), EP.returnEstimator.end());
+    }
+    W.i64("ret0_tags", tags); W.i64("ret0_off", off); W.f32("ret0", ret);
+  }
+
+  std::vector<double> traj_beta, traj_cmax, traj_wnorm; std::vector<int64_t> traj_nfar;
+  for (long k = 1; k <= nSteps; ++k) {
+    const std::string sk = "s" + std::to_string(k) + "_";
+    if (official) {
+      while (L.nGradSteps() < k) H.algo->run();
+    } else {
+      const bool bTap = k <= tapSteps;
+      if (bTap) {
+        W.u32(sk + "rng", rngState(info.generators[0]));
+        std::vector<int64_t> order;
+        for (Uint i = 0; i < L.data->episodes.size(); ++i) order.push_back(L.data->episodes[i]->agentID);
+        W.i64(sk + "order", order);
+        W.scalar_d(sk + "beta", L.data->beta); W.scalar_d(sk + "cmax", L.data->CmaxRet);
+      }
+      StepTap tap;
+      manualStep(H, bTap ? &tap : nullptr);
+      if (bTap) {
+        const int64_t B = tap.flat.size(), nO = NET.nOutputs();
+        W.i64(sk + "flat", tap.flat); W.i64(sk + "tag", tap.tag); W.i64(sk + "t", tap.tstep);
+        W.f64(sk + "O", tap.O, {B, nO}); W.f64(sk + "G", tap.G, {B, nO});
+        W.f64(sk + "rho", tap.rho); W.f64(sk + "dkl", tap.dkl); W.f64(sk + "dq", tap.dq);
+        W.u8(sk + "far", tap.far);
+      }
+      for (auto g : gradSteps) if ((long)g == k) W.f32(sk + "gradSum", paramsOf(OPT->gradSum.get()));
+      finishStep(H);
+    }
+    for (auto g : gradSteps) if ((long)g == k) {
+      W.f32(sk + "W", paramsOf(PW));
+      W.f32(sk + "M1", paramsOf(OPT->_1stMom.get())); W.f32(sk + "M2", paramsOf(OPT->_2ndMom.get()));
+    }
+    for (auto g : retSteps) if ((long)g == k) {
+      std::vector<int64_t> tags; std::vector<float> ret, val, impw, dkl, dq;
+      for (Uint i = 0; i < L.data->episodes.size(); ++i) {
+        const Episode& EP = *L.data->episodes[i];
+        tags.push_back(EP.agentID);
+        ret.insert(ret.end(), EP.returnEstimator.begin(), EP.returnEstimator.end());
+        val.insert(val.end(), EP.stateValue.begin(), EP.stateValue.end());
+        impw.insert(impw.end(), EP.offPolicImpW.begin(), EP.offPolicImpW.end());
+        dkl.insert(dkl.end(), EP.KullbLeibDiv.begin(), EP.KullbLeibDiv.end());
+        dq.insert(dq.end(), EP.deltaValue.begin(), EP.deltaValue.end());
+      }
+      W.i64(sk + "ep_tags", tags); W.f32(sk + "ret", ret); W.f32(sk + "val", val);
+      W.f32(sk + "impw", impw); W.f32(sk + "ep_dkl", dkl); W.f32(sk + "ep_dq", dq);
+      std::vector<float> sc;
+      for (auto v : H.MDP.stateMean) sc.push_back(v);
+      for (auto v : H.MDP.stateScale) sc.push_back(v);
+      sc.push_back(H.MDP.rewardsMean); sc.push_back(H.MDP.rewardsScale); sc.push_back(H.MDP.rewardsStdDev);
+      W.f32(sk + "scaling", sc);
+    }
+    traj_beta.push_back(L.data->beta); traj_cmax.push_back(L.data->CmaxRet);
+    traj_nfar.push_back((int64_t)L.data->nFarPolicySteps());
+    traj_wnorm.push_back((double)PW->compute_weight_norm());
+  }
+  W.f64("traj_beta", traj_beta); W.f64("traj_cmax", traj_cmax);
+  W.i64("traj_nfar", traj_nfar); W.f64("traj_wnorm", traj_wnorm);
+  W.f32("Wfinal", paramsOf(PW));
+  {
+    const ReplayStats& st = L.data->stats;
+    std::vector<double> s = {(double)st.avgKLdivergence, (double)st.avgSquaredErr, (double)st.maxAbsError,
+        (double)st.avgReturn, (double)st.avgQ, (double)st.stdevQ, (double)st.minQ, (double)st.maxQ,
+        (double)st.nFarPolicySteps};
+    W.f64("stats_final", s);
+  }
+  printf("fixture %s: nParams %lu nObs %ld steps %ld beta %.9g wnorm %.9Lg\n", out.c_str(),
+         (unsigned long)PW->nParams, L.data->nStoredSteps(), nSteps, L.data->beta, PW->compute_weight_norm());
+  return 0;
+}
+
+static int modeBench(ExecutionInfo& info, const Args& A) {
+  Harness H(info, A);
+  VRACER& L = *H.L;
+  const long nObs = A.l("nObs", 1000000), nSteps = A.l("nSteps", 100), warm = A.l("warmup", 10);
+  const double t0 = now_s();
+  if (A.s("fill", "synth") == "select") {
+    Agent AG(0, 0, 0, H.MDP); AG.initializeActionSampling(info.generators[0]);
+    std::mt19937 g(7); std::normal_distribution<double> N(0, 1);
+    while (L.locDataSetSize() < nObs) {
+      std::vector<double> s(H.MDP.dimState); for (auto& x : s) x = N(g);
+      AG.update(INIT, s, 0.0); L.select(AG);
+      for (int t = 1; t <= 200; ++t) { for (auto& x : s) x = N(g);
+        AG.update(t == 200 ? LAST : CONT, s, N(g)); L.select(AG); }
+    }
+  } else {
+    uint64_t e = 0;
+    while (L.locDataSetSize() < nObs) H.pushSynthEpisode(e++);
+  }
+  const double t1 = now_s();
+  H.algo->run();  // stepInit (+ first step)
+  while (L.nGradSteps() < warm) H.algo->run();
+  const long g0 = L.nGradSteps(); const double t2 = now_s();
+  while (L.nGradSteps() < g0 + nSteps) H.algo->run();
+  const double dt = now_s() - t2;
+  printf("{\"kind\":\"reference\",\"threads\":%d,\"nObs\":%ld,\"nEps\":%ld,\"steps\":%ld,\"seconds\":%.6f,"
+         "\"steps_per_s\":%.3f,\"transitions_per_s\":%.1f,\"fill_s\":%.3f,\"batch\":%lu,\"beta\":%.9g}\n",
+         (int)info.nThreads, L.locDataSetSize(), L.data->nStoredEps(), nSteps, dt, nSteps / dt,
+         nSteps * (double)H.HP->batchSize / dt, t1 - t0, (unsigned long)H.HP->batchSize, L.data->beta);
+  if (A.l("profile", 0)) printf("%s\n", L.profiler->printStatAndReset().c_str());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: ref_driver fixture <out.bin> k=v... | bench k=v...\n"); return 2; }
+  const std::string mode = argv[1];
+  Args A; std::string out;
+  for (int i = 2; i < argc; ++i) {
+    const std::string a = argv[i]; const auto p = a.find('=');
+    if (p == std::string::npos) out = a; else A.kv[a.substr(0, p)] = a.substr(p + 1);
+  }
+  int one = 1; char* av[] = {argv[0], nullptr}; char** avp = av;
+  ExecutionInfo info(one, avp);
+  if (mode == "fixture") return modeFixture(info, A, out);
+  if (mode == "bench") return modeBench(info, A);
+  fprintf(stderr, "unknown mode\n"); return 2;
+}

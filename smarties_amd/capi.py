@@ -1,0 +1,356 @@
+"""ctypes binding of the hl_* C-ABI declared in include/smarties_hip.h.
+
+The product library is ``smarties_amd/libsmarties_hip.so`` (hand-written HIP for
+gfx950 behind a C-ABI).  There is NO CPU fallback: if the shared library is
+missing or no HIP device is usable, loading / ``hl_create`` fail loudly.
+
+``CApi`` is parametrised by (library path, symbol prefix) only so that the test
+suite can drive the CPU oracle (``oracle/liboracle_port.so``, prefix ``ol_``)
+through the very same call sequence; nothing in this package loads the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HL_MAX_DIMA = 64
+HL_MAX_HIDDEN = 8
+
+FUNC = {"Linear": 0, "Tanh": 1, "SoftSign": 2, "Relu": 3, "LRelu": 4, "Sigm": 5, "HardSign": 6,
+        "SoftPlus": 7, "ExpPlus": 8, "Exp": 9}
+ADV_ZERO, ADV_GAUSSIAN, ADV_DISCRETE = 0, 1, 2
+ORDER_STABLE, ORDER_REFERENCE = 0, 1
+
+(TAP_FLAT, TAP_EPISODE, TAP_TSTEP, TAP_TAG, TAP_STATE, TAP_OUTPUT, TAP_OUTGRAD, TAP_RHO, TAP_DKL,
+ TAP_DELTAQ, TAP_FAR, TAP_GRADSUM) = range(12)
+EP_RETURN, EP_VALUE, EP_ADVANTAGE, EP_IMPW, EP_DKL, EP_DELTAQ = range(6)
+
+STATUS = {0: "HL_OK", 1: "HL_ERR_BAD_ARG", 2: "HL_ERR_NO_DEVICE", 3: "HL_ERR_HIP", 4: "HL_ERR_STATE",
+          5: "HL_ERR_TOO_FEW_DATA", 6: "HL_ERR_COMM", 7: "HL_ERR_IO", 8: "HL_ERR_UNSUPPORTED"}
+
+
+class HlConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("dimS", C.c_int32), ("dimA", C.c_int32),
+        ("bounded", C.c_uint8 * HL_MAX_DIMA), ("n_hidden", C.c_int32),
+        ("hidden", C.c_int32 * HL_MAX_HIDDEN), ("nnFunc", C.c_int32), ("adv_kind", C.c_int32),
+        ("batchSize", C.c_int32), ("maxTotObsNum", C.c_int64), ("minTotObsNum", C.c_int64),
+        ("gamma", C.c_double), ("lambda_", C.c_double), ("clipImpWeight", C.c_double),
+        ("penalTol", C.c_double), ("epsAnneal", C.c_double), ("learnrate", C.c_double),
+        ("nnLambda", C.c_double), ("explNoise", C.c_double), ("outWeightsPrefac", C.c_double),
+        ("randSeed", C.c_uint64), ("n_ranks", C.c_int32), ("rank", C.c_int32),
+        ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class HlScalars(C.Structure):
+    _fields_ = [("beta", C.c_double), ("alpha", C.c_double), ("CmaxRet", C.c_double),
+                ("CinvRet", C.c_double), ("nGradSteps", C.c_int64), ("nStoredSteps", C.c_int64),
+                ("nStoredEps", C.c_int64), ("nFarPolicySteps", C.c_int64), ("nSeenSteps", C.c_int64),
+                ("nSeenEps", C.c_int64), ("adam_beta_t_1", C.c_double), ("adam_beta_t_2", C.c_double),
+                ("adam_nStep", C.c_int64)]
+
+
+class HlStats(C.Structure):
+    _fields_ = [("avgKLdivergence", C.c_double), ("avgSquaredErr", C.c_double),
+                ("maxAbsError", C.c_double), ("avgReturn", C.c_double), ("avgQ", C.c_double),
+                ("stdevQ", C.c_double), ("minQ", C.c_double), ("maxQ", C.c_double),
+                ("nFarPolicySteps", C.c_int64)]
+
+
+def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSign", batchSize=256,
+                maxTotObsNum=1000000, minTotObsNum=0, gamma=0.995, lambda_=1.0, clipImpWeight=4.0,
+                penalTol=0.1, epsAnneal=0.0, learnrate=1e-4, nnLambda=0.0, explNoise=0.4472135955,
+                outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
+                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO):
+    """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
+    c = HlConfig()
+    c.struct_size = C.sizeof(HlConfig)
+    c.dimS, c.dimA = dimS, dimA
+    bounded = [1] * dimA if bounded is None else list(bounded)
+    for i in range(dimA):
+        c.bounded[i] = int(bounded[i])
+    c.n_hidden = len(hidden)
+    for i, hsz in enumerate(hidden):
+        c.hidden[i] = int(hsz)
+    c.nnFunc = FUNC[nnFunc] if isinstance(nnFunc, str) else int(nnFunc)
+    c.adv_kind = adv_kind
+    c.batchSize = batchSize
+    c.maxTotObsNum, c.minTotObsNum = int(maxTotObsNum), int(minTotObsNum)
+    c.gamma, c.lambda_, c.clipImpWeight, c.penalTol = gamma, lambda_, clipImpWeight, penalTol
+    c.epsAnneal, c.learnrate, c.nnLambda = epsAnneal, learnrate, nnLambda
+    c.explNoise, c.outWeightsPrefac = explNoise, outWeightsPrefac
+    c.randSeed, c.n_ranks, c.rank, c.device_id = randSeed, n_ranks, rank, device_id
+    c.episode_order, c.ref_threads = episode_order, ref_threads
+    return c
+
+
+class HlError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("%s (%d): %s" % (STATUS.get(status, "?"), status, msg))
+        self.status = status
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class CApi:
+    """Loads a shared library exporting <prefix>create, <prefix>step, ... (include/smarties_hip.h)."""
+
+    def __init__(self, path, prefix="hl_"):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no CPU fallback for the HIP path" % path)
+        self.path, self.prefix = path, prefix
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self._sig()
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    def _sig(self):
+        P, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
+        pf, pd = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        pi64, pu32, pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+        sig = {
+            "create": (C.c_int, [C.POINTER(HlConfig), C.POINTER(P)]),
+            "destroy": (C.c_int, [P]),
+            "last_error": (C.c_char_p, [P]),
+            "num_params": (I64, [P]), "num_outputs": (I32, [P]), "num_layers": (I32, [P]),
+            "param_layout": (C.c_int, [P, pi64, pi64, pi64, pi64]),
+            "init_weights": (C.c_int, [P]),
+            "set_params": (C.c_int, [P, pf, pf, pf]), "get_params": (C.c_int, [P, pf, pf, pf]),
+            "set_rng_state": (C.c_int, [P, pu32]), "get_rng_state": (C.c_int, [P, pu32]),
+            "append_episode": (C.c_int, [P, I32, pf, pd, pd, pd, pf, pf, I32, I64]),
+            "get_scaling": (C.c_int, [P, pf, pf, pf]), "set_scaling": (C.c_int, [P, pf, pf, pf]),
+            "get_episode_field": (C.c_int, [P, I64, I32, pf, I32]),
+            "get_episode_info": (C.c_int, [P, I64, pi64, pi32, pi32]),
+            "initialize": (C.c_int, [P]),
+            "step": (C.c_int, [P, I32, pi64]),
+            "step_begin": (C.c_int, [P, pi64]),
+            "grad_exchange": (C.c_int, [P, pf, I32]),
+            "counters_exchange": (C.c_int, [P, pi64, I32]),
+            "moments_exchange": (C.c_int, [P, pd, I32]),
+            "step_end": (C.c_int, [P]),
+            "sync": (C.c_int, [P]),
+            "set_tap": (C.c_int, [P, I32]),
+            "readback": (C.c_int, [P, I32, C.c_void_p, I64]),
+            "get_scalars": (C.c_int, [P, C.POINTER(HlScalars)]),
+            "get_stats": (C.c_int, [P, C.POINTER(HlStats)]),
+        }
+        for name, (res, args) in sig.items():
+            f = self.fn(name)
+            f.restype, f.argtypes = res, args
+        for name, (res, args) in {
+            "comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+            "comm_init": (C.c_int, [P, C.POINTER(C.c_uint8)]),
+            "timing_enable": (C.c_int, [P, I32]),
+            "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
+            "status_string": (C.c_char_p, [C.c_int]),
+            "version": (C.c_int, []),
+        }.items():
+            if self.has(name):
+                f = self.fn(name)
+                f.restype, f.argtypes = res, args
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+class Learner:
+    """Thin object wrapper over one hl_learner handle (names follow include/smarties_hip.h)."""
+
+    def __init__(self, api, cfg):
+        self.api, self.cfg = api, cfg
+        self.h = C.c_void_p()
+        rc = api.fn("create")(C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise HlError(rc, "hl_create failed")
+        self.nParams = api.fn("num_params")(self.h)
+        self.nOut = api.fn("num_outputs")(self.h)
+        self.dS, self.dA = cfg.dimS, cfg.dimA
+        self.B = max(1, cfg.batchSize // cfg.n_ranks) if cfg.batchSize > 1 else cfg.batchSize
+
+    def close(self):
+        if self.h:
+            self.api.fn("destroy")(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise HlError(rc, (self.api.fn("last_error")(self.h) or b"").decode())
+
+    # -- parameters -----------------------------------------------------------
+    def layout(self):
+        n = self.api.fn("num_layers")(self.h)
+        arrs = [np.zeros(n, np.int64) for _ in range(4)]
+        self._ck(self.api.fn("param_layout")(self.h, *[_ptr(a, C.c_int64) for a in arrs]))
+        return dict(indW=arrs[0], nW=arrs[1], indB=arrs[2], nB=arrs[3])
+
+    def init_weights(self):
+        self._ck(self.api.fn("init_weights")(self.h))
+
+    def set_params(self, w=None, m1=None, m2=None):
+        w, m1, m2 = [None if a is None else _f32(a) for a in (w, m1, m2)]
+        for a in (w, m1, m2):
+            assert a is None or a.size == self.nParams
+        self._ck(self.api.fn("set_params")(self.h, _ptr(w, C.c_float), _ptr(m1, C.c_float), _ptr(m2, C.c_float)))
+
+    def get_params(self):
+        w, m1, m2 = [np.zeros(self.nParams, np.float32) for _ in range(3)]
+        self._ck(self.api.fn("get_params")(self.h, _ptr(w, C.c_float), _ptr(m1, C.c_float), _ptr(m2, C.c_float)))
+        return w, m1, m2
+
+    def set_rng_state(self, st):
+        st = np.ascontiguousarray(st, dtype=np.uint32)
+        assert st.size == 625
+        self._ck(self.api.fn("set_rng_state")(self.h, _ptr(st, C.c_uint32)))
+
+    def get_rng_state(self):
+        st = np.zeros(625, np.uint32)
+        self._ck(self.api.fn("get_rng_state")(self.h, _ptr(st, C.c_uint32)))
+        return st
+
+    # -- replay -----------------------------------------------------------------
+    def append_episode(self, states, actions, mu, rewards, values, terminated, tag, advantages=None):
+        states, values = _f32(states), _f32(values)
+        actions, mu, rewards = _f64(actions), _f64(mu), _f64(rewards)
+        n = rewards.size
+        assert states.size == n * self.dS and actions.size == n * self.dA and mu.size == 2 * n * self.dA
+        adv = None if advantages is None else _f32(advantages)
+        self._ck(self.api.fn("append_episode")(
+            self.h, n, _ptr(states, C.c_float), _ptr(actions, C.c_double), _ptr(mu, C.c_double),
+            _ptr(rewards, C.c_double), _ptr(values, C.c_float), _ptr(adv, C.c_float), int(terminated), int(tag)))
+
+    def get_scaling(self):
+        m, s, r = np.zeros(self.dS, np.float32), np.zeros(self.dS, np.float32), np.zeros(3, np.float32)
+        self._ck(self.api.fn("get_scaling")(self.h, _ptr(m, C.c_float), _ptr(s, C.c_float), _ptr(r, C.c_float)))
+        return m, s, r
+
+    def set_scaling(self, m, s, r):
+        m, s, r = _f32(m), _f32(s), _f32(r)
+        self._ck(self.api.fn("set_scaling")(self.h, _ptr(m, C.c_float), _ptr(s, C.c_float), _ptr(r, C.c_float)))
+
+    def episode_info(self, pos):
+        tag, n, term = C.c_int64(), C.c_int32(), C.c_int32()
+        self._ck(self.api.fn("get_episode_info")(self.h, pos, C.byref(tag), C.byref(n), C.byref(term)))
+        return tag.value, n.value, term.value
+
+    def episode_field(self, pos, field):
+        _, n, _ = self.episode_info(pos)
+        out = np.zeros(n, np.float32)
+        self._ck(self.api.fn("get_episode_field")(self.h, pos, field, _ptr(out, C.c_float), n))
+        return out
+
+    # -- training -----------------------------------------------------------------
+    def initialize(self):
+        self._ck(self.api.fn("initialize")(self.h))
+
+    def step(self, n=1, flat=None):
+        if flat is not None:
+            flat = np.ascontiguousarray(flat, dtype=np.int64)
+            assert flat.size == n * self.B
+        self._ck(self.api.fn("step")(self.h, n, _ptr(flat, C.c_int64)))
+
+    def step_begin(self, flat=None):
+        if flat is not None:
+            flat = np.ascontiguousarray(flat, dtype=np.int64)
+        self._ck(self.api.fn("step_begin")(self.h, _ptr(flat, C.c_int64)))
+
+    def step_end(self):
+        self._ck(self.api.fn("step_end")(self.h))
+
+    def grad_fetch(self):
+        g = np.zeros(self.nParams, np.float32)
+        self._ck(self.api.fn("grad_exchange")(self.h, _ptr(g, C.c_float), 0))
+        return g
+
+    def grad_store(self, g):
+        g = _f32(g)
+        self._ck(self.api.fn("grad_exchange")(self.h, _ptr(g, C.c_float), 1))
+
+    def counters_fetch(self):
+        c = np.zeros(4, np.int64)
+        self._ck(self.api.fn("counters_exchange")(self.h, _ptr(c, C.c_int64), 0))
+        return c
+
+    def counters_store(self, c):
+        c = np.ascontiguousarray(c, dtype=np.int64)
+        self._ck(self.api.fn("counters_exchange")(self.h, _ptr(c, C.c_int64), 1))
+
+    def moments_fetch(self):
+        m = np.zeros(2 * self.dS + 3, np.float64)
+        rc = self.api.fn("moments_exchange")(self.h, _ptr(m, C.c_double), 0)
+        return None if rc else m
+
+    def moments_store(self, m):
+        m = _f64(m)
+        self._ck(self.api.fn("moments_exchange")(self.h, _ptr(m, C.c_double), 1))
+
+    def sync(self):
+        self._ck(self.api.fn("sync")(self.h))
+
+    # -- inspection -----------------------------------------------------------------
+    def set_tap(self, on=True):
+        self._ck(self.api.fn("set_tap")(self.h, int(on)))
+
+    def readback(self, what):
+        B, nO = self.B, self.nOut
+        shape, dt = {
+            TAP_FLAT: ((B,), np.int64), TAP_EPISODE: ((B,), np.int64), TAP_TSTEP: ((B,), np.int64),
+            TAP_TAG: ((B,), np.int64), TAP_STATE: ((B, self.dS), np.float32),
+            TAP_OUTPUT: ((B, nO), np.float64), TAP_OUTGRAD: ((B, nO), np.float64),
+            TAP_RHO: ((B,), np.float64), TAP_DKL: ((B,), np.float64), TAP_DELTAQ: ((B,), np.float64),
+            TAP_FAR: ((B,), np.uint8), TAP_GRADSUM: ((self.nParams,), np.float32)}[what]
+        out = np.zeros(shape, dt)
+        self._ck(self.api.fn("readback")(self.h, what, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def scalars(self):
+        s = HlScalars()
+        self._ck(self.api.fn("get_scalars")(self.h, C.byref(s)))
+        return s
+
+    def stats(self):
+        s = HlStats()
+        self._ck(self.api.fn("get_stats")(self.h, C.byref(s)))
+        return s
+
+    # -- RCCL / timing (HIP library only) --------------------------------------------
+    def comm_init(self, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._ck(self.api.fn("comm_init")(self.h, buf))
+
+    def timing_enable(self, on=True):
+        self._ck(self.api.fn("timing_enable")(self.h, int(on)))
+
+    def timing_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.api.fn("timing_get")(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "libsmarties_hip.so")
+
+
+def load_hip():
+    """The product library.  Raises if it has not been built (no CPU fallback)."""
+    return CApi(HIP_LIB, "hl_")

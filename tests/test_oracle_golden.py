@@ -1,0 +1,133 @@
+"""CPU suite: pins the oracle (oracle/port, CPU restatement) against golden fixtures that were
+produced by the compiled reference itself (tests/golden/make_golden.sh).  No GPU needed."""
+import numpy as np
+import pytest
+
+from oracle_api import oracle_learner, synth_episode
+from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
+                    episode_arrays_by_tag, fixture_arrays_by_tag)
+from smarties_amd import capi
+
+FUNC_OF = {"deep_tanh.bin": "Tanh"}
+
+
+def make(name):
+    fx = load_fixture(name)
+    cfg = fixture_config(fx, nnFunc=FUNC_OF.get(name), episode_order=capi.ORDER_REFERENCE)
+    L = oracle_learner(cfg)
+    return fx, L
+
+
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin"])
+def test_layout_init_and_rng_match_reference(name):
+    """Parameters blob layout (Parameters.h:159-176), Layer::initialize draw order and the
+    libstdc++ uniform_real_distribution<float> restatement: weights and RNG state bit-exact."""
+    fx, L = make(name)
+    assert L.nParams == int(fx["cfg"][5]) and L.nOut == int(fx["cfg"][6])
+    lay = L.layout()
+    assert np.array_equal(lay["indW"], fx["indWeights"]) and np.array_equal(lay["indB"], fx["indBiases"])
+    assert np.array_equal(lay["nW"], fx["nWeights"]) and np.array_equal(lay["nB"], fx["nBiases"])
+    L.init_weights()
+    w, m1, m2 = L.get_params()
+    assert np.array_equal(w, fx["W0"])
+    assert not m1.any() and not m2.any()
+    assert np.array_equal(L.get_rng_state(), fx["rng_before_init"])
+
+
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin"])
+def test_initialize_matches_reference(name):
+    """Learner::initializeLearner: beta after the init updateCounters, exact reward/state
+    statistics, Retrace of every episode after rescaling."""
+    fx, L = make(name)
+    setup_from_fixture(L, fx)
+    s = L.scalars()
+    assert s.nStoredSteps == int(fx["cfg"][7])
+    assert s.beta == fx["beta0"][0] and s.CmaxRet == fx["cmax0"][0]
+    m, sc, r = L.get_scaling()
+    assert np.array_equal(np.concatenate([m, sc, r]), fx["scaling0"])
+    lens = {e: synth_episode(fixture_synth(fx), e)["rewards"].size for e in range(int(fx["cfg"][3]))}
+    mine = episode_arrays_by_tag(L, capi.EP_RETURN)
+    ref = fixture_arrays_by_tag(fx, "ret0_tags", "ret0", lens)
+    for tag, arr in ref.items():
+        assert np.allclose(mine[tag], arr, rtol=1e-6, atol=1e-6), tag
+    assert np.array_equal(L.get_rng_state(), fx["rng0"])
+
+
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin"])
+def test_steps_match_reference(name):
+    """Every tapped step: sampled flat indices / (episode, t) bit-exact (mt19937 + Lemire
+    uniform_int + sort/unique/redraw + the reference's std::sort episode permutation); network
+    outputs, rho, D_KL, delta-Q, output gradients to 1e-6 relative (f64 head: 1e-12); ReF-ER mask
+    exact; summed weight gradient, weights and Adam moments to 1e-5 of the infinity norm."""
+    fx, L = make(name)
+    setup_from_fixture(L, fx)
+    L.set_tap(True)
+    nSteps = int(fx["cfg"][4])
+    for k in range(1, nSteps + 1):
+        sk = "s%d_" % k
+        if sk + "rng" in fx:
+            assert np.array_equal(L.get_rng_state(), fx[sk + "rng"]), "rng stream diverged before step %d" % k
+            sca = L.scalars()
+            assert sca.beta == fx[sk + "beta"][0] and sca.CmaxRet == fx[sk + "cmax"][0]
+        L.step(1)
+        if sk + "flat" in fx:
+            assert np.array_equal(L.readback(capi.TAP_FLAT), fx[sk + "flat"])
+            assert np.array_equal(L.readback(capi.TAP_TAG), fx[sk + "tag"])
+            assert np.array_equal(L.readback(capi.TAP_TSTEP), fx[sk + "t"])
+            assert relinf(L.readback(capi.TAP_OUTPUT), fx[sk + "O"]) < 1e-6
+            assert relinf(L.readback(capi.TAP_RHO), fx[sk + "rho"]) < 1e-6
+            assert relinf(L.readback(capi.TAP_DKL), fx[sk + "dkl"]) < 1e-6
+            assert relinf(L.readback(capi.TAP_DELTAQ), fx[sk + "dq"]) < 1e-6
+            assert relinf(L.readback(capi.TAP_OUTGRAD), fx[sk + "G"]) < 1e-6
+            assert np.array_equal(L.readback(capi.TAP_FAR), fx[sk + "far"])
+        if sk + "gradSum" in fx:
+            assert relinf(L.readback(capi.TAP_GRADSUM), fx[sk + "gradSum"]) < 1e-5
+        if sk + "W" in fx:
+            w, m1, m2 = L.get_params()
+            assert relinf(w, fx[sk + "W"]) < 1e-6
+            assert relinf(m1, fx[sk + "M1"]) < 1e-5 and relinf(m2, fx[sk + "M2"]) < 1e-5
+        sca = L.scalars()
+        assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-14 * abs(sca.beta)
+        assert sca.CmaxRet == fx["traj_cmax"][k - 1]
+        assert sca.nFarPolicySteps == fx["traj_nfar"][k - 1]
+    w, _, _ = L.get_params()
+    assert relinf(w, fx["Wfinal"]) < 1e-6
+
+
+def test_far_policy_masks_are_exercised():
+    """The fixtures must contain both accepted and rejected (far-policy) samples."""
+    fx = load_fixture("small_mixed.bin")
+    far = np.concatenate([fx["s%d_far" % k] for k in range(1, 13)])
+    assert 0 < far.sum() < far.size
+
+
+def test_long_trajectory_crosses_1000_step_sweep():
+    """1200 steps: beta / CmaxRet / nFarPolicySteps trajectories, the 1000-step
+    Episode::updateCumulative + full Retrace sweep and the reward/state statistics EMA."""
+    fx, L = make("traj_1200.bin")
+    setup_from_fixture(L, fx)
+    lens = {e: synth_episode(fixture_synth(fx), e)["rewards"].size for e in range(int(fx["cfg"][3]))}
+    for k in range(1, 1201):
+        L.step(1)
+        sca = L.scalars()
+        assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-12 * abs(sca.beta), k
+        assert sca.nFarPolicySteps == fx["traj_nfar"][k - 1], k
+        assert sca.CmaxRet == fx["traj_cmax"][k - 1]
+        sk = "s%d_" % k
+        if sk + "ret" in fx:
+            for field, key, tol in ((capi.EP_RETURN, "ret", 2e-5), (capi.EP_VALUE, "val", 2e-5),
+                                    (capi.EP_IMPW, "impw", 2e-5), (capi.EP_DKL, "ep_dkl", 2e-5),
+                                    (capi.EP_DELTAQ, "ep_dq", 2e-4)):
+                mine = episode_arrays_by_tag(L, field)
+                ref = fixture_arrays_by_tag(fx, sk + "ep_tags", sk + key, lens)
+                for tag, arr in ref.items():
+                    assert np.allclose(mine[tag], arr, rtol=tol, atol=tol), (k, key, tag)
+            m, sc, r = L.get_scaling()
+            assert np.allclose(np.concatenate([m, sc, r]), fx[sk + "scaling"], rtol=1e-6, atol=1e-7)
+    w, _, _ = L.get_params()
+    assert relinf(w, fx["Wfinal"]) < 1e-5
+    st = L.stats()
+    ref = fx["stats_final"]
+    mine = [st.avgKLdivergence, st.avgSquaredErr, st.maxAbsError, st.avgReturn, st.avgQ, st.stdevQ, st.minQ, st.maxQ]
+    assert np.allclose(mine, ref[:8], rtol=1e-4, atol=1e-6)
+    assert st.nFarPolicySteps == int(ref[8])
