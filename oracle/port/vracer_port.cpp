@@ -163,7 +163,7 @@ struct Layer {
 };
 
 struct Episode {  // ReplayMemory/Episode.h:40-108
-  int64_t tag = -1, ID = -1; int N = 0; bool term = false;
+  int64_t tag = -1, ID = -1, seq = 0; int N = 0; bool term = false;
   std::vector<float> S; std::vector<double> A, MU, R;
   std::vector<nnReal> V, ADV, RET;         // stateValue, actionAdvantage, returnEstimator
   std::vector<Fval> DQ, IMPW, DKL;         // deltaValue, offPolicImpW, KullbLeibDiv
@@ -603,7 +603,10 @@ void applyEpisodesRemoval(ol_learner* h) {
     return a->ID > b->ID;
   };
   if (h->cfg.episode_order == HL_ORDER_REFERENCE) std::sort(h->episodes.begin(), h->episodes.end(), cmp);
-  else std::stable_sort(h->episodes.begin(), h->episodes.end(), cmp);
+  else  // product semantics (HL_ORDER_STABLE): strict FIFO, newest episode first (IDs are non-decreasing
+        // in insertion order, so this is one of the orders the reference's comparator admits)
+    std::sort(h->episodes.begin(), h->episodes.end(),
+              [](const std::unique_ptr<Episode>& a, const std::unique_ptr<Episode>& b) { return a->seq > b->seq; });
   while (!h->episodes.empty() &&
          h->nTransitions - (int64_t)h->episodes.back()->N > h->maxObsLocal) {
     h->nTransitions -= h->episodes.back()->ndata();
@@ -759,8 +762,10 @@ int ol_append_episode(ol_learner* h, int32_t N, const float* states, const doubl
   const int64_t locTrain = h->nGatheredB4Startup == INT64_MAX ? -1 : h->nSeenSteps - h->nGatheredB4Startup;
   EP->ID = std::max(locTrain, (int64_t)0);
   h->nSeenSteps += 1;                                            // :167
+  EP->seq = h->nSeenEps;
   h->nTransitions += EP->ndata();
-  h->episodes.push_back(std::move(EP));
+  if (h->cfg.episode_order == HL_ORDER_REFERENCE) h->episodes.push_back(std::move(EP));
+  else h->episodes.insert(h->episodes.begin(), std::move(EP));   // newest first
   h->nSeenEps += 1;
   return HL_OK;
 }

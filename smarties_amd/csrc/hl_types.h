@@ -1,0 +1,116 @@
+// smarties_amd/csrc/hl_types.h -- structures shared by the host learner (learner.cpp) and the
+// gfx950 kernels (kernels.hip).  Device-resident state of one learner replica.
+#pragma once
+#include <stdint.h>
+#include "../../include/smarties_hip.h"
+
+namespace hl {
+
+// ---------------------------------------------------------------------------
+// Device-resident scalars of the learner (reference: MemoryBuffer.h:41-44 beta/Cmax/Cinv,
+// ReplayStats / ReplayCounters (ReplayStatsCounters.h), Optimizer.h:96 beta_t, mt19937
+// generators[0] (ExecutionInfo.cpp:391)).  Only single-block kernels write it.
+// ---------------------------------------------------------------------------
+struct DevScalars {
+  double beta, alpha, Cmax, Cinv;
+  double adam_bt1, adam_bt2;
+  double maxAbsErrEMA;            // ReplayStats::maxAbsError
+  long long nStep;                // AdamOptimizer::nStep (completed prepare_update calls)
+  long long nGradSteps;
+  long long nFarTotal;            // ReplayStats::nFarPolicySteps (this replica)
+  long long nTransitions;         // ReplayCounters::nTransitions (this replica)
+  long long nEpisodes;
+  long long cnt[4];               // {seenEps, seenSteps, nFar, nStored}: local, then all-reduced (C2)
+  float rewMean, rewScale, rewStd;
+  float maxAbsErrAll;             // max over episodes of Episode::maxAbsError
+  int nNext;                      // rows B..B+nNext-1 of the minibatch hold truncated next states
+  int nRows;                      // B + nNext
+  int errFlag;                    // sticky device-side error code (0 = ok)
+  unsigned rngPos;
+  unsigned rng[624];
+};
+
+// ---------------------------------------------------------------------------
+// Replay buffer in HBM: structure-of-arrays over "slots" (one slot per stored state,
+// Episode.h:66-82), episodes occupy contiguous slot ranges.
+// ---------------------------------------------------------------------------
+struct DevReplay {
+  float* S;        // [cap][dS]      states (raw; standardized on gather, Episode.h:172-183)
+  double* A;       // [cap][dA]      actions (f64 as in the reference, Episode.h:73)
+  double* MU;      // [cap][2dA]     behaviour policy mean|stdev
+  double* R;       // [cap]          rewards
+  float *V, *ADV, *RET;    // stateValue, actionAdvantage, returnEstimator
+  float *DQ, *IMPW, *DKL;  // deltaValue, offPolicImpW, KullbLeibDiv
+  // per episode storage id (eid)
+  long long* epOff;        // first slot
+  int* epN;                // number of states
+  unsigned char* epTerm;   // bReachedTermState
+  float* epAgg;            // [nEpCap][AGG_N] running aggregates (Episode.h:99-103)
+  // current episode order (position -> eid) and transition prefix (Sampling.cpp:26-47)
+  int* posEid;             // [nEp]
+  long long* posPrefix;    // [nEp+1]
+  float* stMean; float* stScale; float* stStd;   // [dS]
+};
+enum { AGG_TOTR = 0, AGG_AVGKL, AGG_FRACFAR, AGG_AVGSQERR, AGG_MAXABSERR, AGG_SUMQ2, AGG_SUMQ,
+       AGG_MAXQ, AGG_MINQ, AGG_N = 12 };
+
+// ---------------------------------------------------------------------------
+// Minibatch workspace (MiniBatch.h) + taps
+// ---------------------------------------------------------------------------
+struct DevBatch {
+  long long* flat;     // [B] sorted unique flat indices
+  int* pos;            // [B] episode position
+  int* eid;            // [B]
+  int* t;              // [B] step within episode
+  long long* slot;     // [B] replay slot of the sampled state
+  int* nextOf;         // [B] row index (>= B) holding s_{t+1} if truncated, else -1
+  int* nextSrc;        // [B] for next row j: sample b it belongs to
+  // head outputs / write-back staging (old values are needed by the aggregate updates)
+  double* O;           // [2B][nOut]
+  double* G;           // [B][nOut]
+  double *rho, *dkl, *dq;        // [B]
+  unsigned char* far;            // [B]
+  float *newDQ, *newDKL, *newW, *newV;   // [B] values written to the replay (Fval casts)
+  float *oldDQ, *oldDKL, *oldW, *oldV, *oldADV;   // [B]
+  float *nextV, *oldNextV, *oldNextADV;           // [B] (indexed by sample b)
+  float* gParam;       // [B][dA] gradient wrt the ParamLayer outputs
+};
+
+// one dense hidden block of the MLP (BaseLayer [+ ParametricResidualLayer])
+struct DevHidden {
+  int nIn, size, ldW;            // ldW = nOut_simd (Layer_Base.h:46)
+  int func;
+  long long indW, indB;          // dense weights / bias offsets in the blob
+  int hasRes, resW;              // resW = min(nIn, size) (Layers.h:357)
+  long long indWr, indBr;        // residual w / b offsets
+  float *X, *Y, *Rr;             // pre-activation, activation, residual output  [Mmax][ldA]
+  float *D, *Dres;               // delta after act', gradient wrt block output  [B][ldA]
+  int ldA;
+};
+
+// ---------------------------------------------------------------------------
+// generic small-GEMM problem descriptor (see kernels.hip: gemm16_kernel)
+// ---------------------------------------------------------------------------
+enum { GEMM_F = 0,   // C[M,N] = A[M,K] * B[K,N]         A rows, B = weights [K][ldb]
+       GEMM_X = 1,   // C[M,N] = A[M,K] * B^T,           B = weights [N][ldb] (reduce over its columns)
+       GEMM_W = 2,   // C[M,N] = A^T * B,                A = acts [K][lda] (+ ones row M-1), B = deltas [K][ldb]
+       RED_COL = 3 };// out[j] = sum_m A[m][j] * (B ? B[m][j] : 1)
+enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2, EPI_NONE = 3 };
+
+struct GemmProblem {
+  int flavor, epi;
+  int M, N, K;           // output M x N, reduction length K
+  int dynRows;           // 1: number of valid rows of A (and C) = DevScalars::nRows (GEMM_F only)
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;     // primary output
+  // epilogue operands
+  const float* bias;     // EPI_FWD
+  float* C2; float* C3;  // EPI_FWD: Y, R ; EPI_DX: D (C = Dres)
+  const float* resW; const float* resB; const float* resIn; int ldRes; int resN;  // residual
+  const float* actX; const float* actY; int ldAct; int func;                        // EPI_DX
+  float* biasOut;        // EPI_DW: row M-1 of the product (the ones row) goes here
+  int tileStart, tilesM, tilesN;
+};
+
+}  // namespace hl

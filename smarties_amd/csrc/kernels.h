@@ -1,0 +1,71 @@
+// smarties_amd/csrc/kernels.h -- launchers of the gfx950 kernels (kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hl_types.h"
+
+namespace hl {
+
+struct SampleArgs {
+  DevScalars* sc; DevReplay rp; DevBatch bt;
+  int B, dS, ldX0;        // local batch, state dim, leading dim of X0
+  float* X0;              // [Mmax][ldX0] standardized states (MiniBatch::S)
+  const long long* flatGiven;  // != nullptr: use these indices instead of drawing
+  int adamDraws;          // mt19937 draws consumed by the Adam step (Optimizer.cpp:139)
+};
+
+struct HeadArgs {
+  DevScalars* sc; DevReplay rp; DevBatch bt;
+  int B, dA, nDense, nOut, H;       // H = width of the last hidden block
+  const float* Yin; int ldY;        // input of the output layer [Mmax][ldY]
+  const float* Xlast; const float* Ylast; int func;   // last hidden block pre/post activation (for act')
+  const float* params;              // weight blob
+  long long indWo, indBo, indBp; int ldWo;   // output dense W/b, ParamLayer bias
+  float* dOut; int ldDo;            // [B][ldDo] output-layer deltas (f32)
+  float* Dres; float* D; int ldD;   // gradient wrt last hidden block output / after act'
+  unsigned char bounded[HL_MAX_DIMA];
+};
+
+struct PostArgs {
+  DevScalars* sc; DevReplay rp; DevBatch bt;
+  int B, mode;                       // mode bits: 1 aggregates, 2 beta+counters, 4 init (beta only)
+  double clipImpWeight, epsAnneal, penalTol, maxObsGlobal, batchGlobal;
+  int nRanks;
+};
+enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4 };
+
+struct AdamArgs {
+  const DevScalars* sc; float* W; float* M1; float* M2; const float* G; long long n;
+  float eta0, lambda, fac; double epsAnneal;
+};
+
+struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
+  DevScalars* sc; DevReplay rp;
+  const int* eids; int count;        // eids == nullptr: all current positions (count = nEpisodes)
+  float gamma, lambda; int recompute; // recompute=1: Episode::updateCumulative first
+  long long* redNFar; float* redMaxAbs;   // per-block partials (recompute only)
+};
+
+struct MomentsArgs {
+  DevScalars* sc; DevReplay rp; int dS; int nEpisodes;
+  double* partial; int nBlocks;      // [nBlocks][2dS+3]
+  double* moments;                   // [2dS+3]
+  int bInit; double learnrate, epsAnneal, rRateFac;
+};
+
+hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
+hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc, hipStream_t s);
+hipError_t launch_head(const HeadArgs& a, int maxRows, hipStream_t s);
+hipError_t launch_post(const PostArgs& a, hipStream_t s);
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);
+hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s);
+hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);          // partial sums + final sum
+hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s);    // EMA update of the scaling
+hipError_t launch_set_counts(DevScalars* sc, long long nTransitions, long long nEpisodes,
+                             long long seenEps, long long seenSteps, hipStream_t s);
+hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s);
+hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out /*16 doubles*/, hipStream_t s);
+int sweep_blocks(int count);
+int moments_blocks(int nEpisodes);
+
+}  // namespace hl

@@ -1,0 +1,1049 @@
+// smarties_amd/csrc/learner.cpp -- host side of libsmarties_hip.so: the hl_* C-ABI of
+// include/smarties_hip.h.  Owns the device-resident replay buffer, the parameter blob, the
+// per-step launch sequence (eager or as a replayed hipGraph) and the RCCL communicator.
+// There is no CPU compute path in this library: every entry point that needs the GPU fails
+// with HL_ERR_NO_DEVICE / HL_ERR_HIP if HIP is not usable.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace hl;
+
+namespace {
+
+inline long long roundUp(long long n, long long m) { return (n + m - 1) / m * m; }
+
+struct EpMeta { int eid; long long off; int N; bool term; long long tag, ID; };
+
+struct TimeRec { int name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct hl_learner {
+  hl_config cfg{};
+  std::string err;
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nHidden = 0, Mmax = 0;
+  long long maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
+  // parameter blob layout (Parameters::_computeNParams, Layers/Parameters.h:159-176)
+  std::vector<long long> indW, nW, indB, nB;
+  long long nParams = 0;
+  float *W = nullptr, *M1 = nullptr, *M2 = nullptr, *G = nullptr;
+  DevScalars* sc = nullptr;
+  DevReplay rp{};
+  DevBatch bt{};
+  float* X0 = nullptr; int ldX0 = 0;
+  DevHidden hid[HL_MAX_HIDDEN];
+  float* dOut = nullptr; int ldDo = 0;
+  long long indWo = 0, indBo = 0, indBp = 0; int ldWo = 0;
+  // gemm problem tables (device) + launch geometry
+  GemmProblem* dProbs = nullptr;           // all problems, contiguous
+  std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwCount = 0, dwBlocks = 0;
+  // replay bookkeeping (host)
+  long long capSlots = 0; int capEps = 0;
+  long long ringHead = 0;                  // next free slot
+  std::deque<EpMeta> order;                // front = newest (position 0), back = oldest
+  std::vector<int> freeEids; int nextEid = 0;
+  std::vector<int> pendingRetrace;
+  long long nTransitions = 0, nSeenSteps = 0, nSeenEps = 0, nGradSteps = 0;
+  long long nGatheredB4Startup = INT64_MAX;
+  bool tableDirty = true, countsDirty = true, initialized = false, inStep = false;
+  double lastAvgSqErr = 0;
+  // staging
+  void* pinned = nullptr; size_t pinnedBytes = 0;
+  long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
+  long long* dRedNFar = nullptr; float* dRedMax = nullptr; int redCap = 0;
+  double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
+  double* dStatsOut = nullptr;
+  // graph
+  hipGraph_t graph = nullptr; hipGraphExec_t graphExec = nullptr; bool graphValid = false; bool useGraph = true;
+  // rccl
+  ncclComm_t comm = nullptr;
+  // moments exchange state
+  bool momentsPending = false;
+  // timing
+  bool timing = false; std::vector<std::string> tnames; std::vector<double> tsum; std::vector<long long> tcnt;
+  std::vector<TimeRec> trecs;
+};
+
+namespace {
+
+int fail(hl_learner* h, int code, const std::string& m) { if (h) h->err = m; return code; }
+int hipFail(hl_learner* h, hipError_t e, const char* what) {
+  return fail(h, HL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return hipFail(h, e__, #x); } while (0)
+#define NCCLCK(x) do { ncclResult_t r__ = (x); if (r__ != ncclSuccess) return fail(h, HL_ERR_COMM, std::string(#x) + ": " + ncclGetErrorString(r__)); } while (0)
+
+template <typename T> hipError_t devAlloc(T** p, size_t n) {
+  hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+  if (e == hipSuccess) e = hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T));
+  return e;
+}
+template <typename T> hipError_t devGrow(T** p, size_t oldN, size_t newN, hipStream_t s) {
+  T* q = nullptr;
+  hipError_t e = devAlloc(&q, newN);
+  if (e != hipSuccess) return e;
+  if (*p) {
+    e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
+    if (oldN) { e = hipMemcpy(q, *p, oldN * sizeof(T), hipMemcpyDeviceToDevice); if (e != hipSuccess) return e; }
+    hipFree(*p);
+  }
+  *p = q; return hipSuccess;
+}
+
+int timerId(hl_learner* h, const char* name) {
+  for (size_t i = 0; i < h->tnames.size(); ++i) if (h->tnames[i] == name) return (int)i;
+  h->tnames.push_back(name); h->tsum.push_back(0); h->tcnt.push_back(0);
+  return (int)h->tnames.size() - 1;
+}
+void timerFlush(hl_learner* h) {
+  if (h->trecs.empty()) return;
+  hipStreamSynchronize(h->stream);
+  for (auto& r : h->trecs) {
+    float ms = 0; hipEventElapsedTime(&ms, r.a, r.b);
+    h->tsum[r.name] += ms; h->tcnt[r.name] += 1;
+    hipEventDestroy(r.a); hipEventDestroy(r.b);
+  }
+  h->trecs.clear();
+}
+// run a launch, optionally bracketed by HIP events on the library's own stream
+template <typename F> hipError_t timed(hl_learner* h, const char* name, F&& f) {
+  if (!h->timing) return f();
+  TimeRec r; r.name = timerId(h, name);
+  hipEventCreate(&r.a); hipEventCreate(&r.b);
+  hipEventRecord(r.a, h->stream);
+  hipError_t e = f();
+  hipEventRecord(r.b, h->stream);
+  h->trecs.push_back(r);
+  if (h->trecs.size() >= 4096) timerFlush(h);
+  return e;
+}
+
+// ---- network description: same construction rules as the reference Builder --------------
+// (Network/Builder.cpp:48-117 via Approximator::buildFromSettings and RACER::setupNet)
+int buildNet(hl_learner* h) {
+  const hl_config& c = h->cfg;
+  h->indW.clear(); h->nW.clear(); h->indB.clear(); h->nB.clear();
+  std::vector<long long> lw, lb;          // per layer requested sizes
+  lw.push_back(0); lb.push_back(0);       // input layer
+  int prev = c.dimS, nH = 0;
+  struct Tmp { int nIn, size, hasRes; int denseLayer, resLayer; };
+  std::vector<Tmp> hs;
+  for (int j = 0; j < c.n_hidden; ++j) {
+    if (c.hidden[j] <= 0) continue;
+    Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
+    lw.push_back(roundUp(t.size, 8) * t.nIn); lb.push_back(t.size);
+    t.hasRes = (t.denseLayer != 1);        // no skip connection after the first layer (Builder.cpp:89-95)
+    t.resLayer = -1;
+    if (t.hasRes) { t.resLayer = (int)lw.size(); lw.push_back(t.size); lb.push_back(t.size); }
+    hs.push_back(t); prev = t.size; ++nH;
+  }
+  if (nH < 1) return HL_ERR_BAD_ARG;
+  h->nHidden = nH;
+  h->nDense = 1 + c.dimA; h->nOut = h->nDense + c.dimA;
+  const int outLayer = (int)lw.size();
+  lw.push_back(roundUp(h->nDense, 8) * prev); lb.push_back(h->nDense);
+  const int paramLayer = (int)lw.size();
+  lw.push_back(0); lb.push_back(c.dimA);
+  long long tot = 0;
+  for (size_t l = 0; l < lw.size(); ++l) {
+    h->indW.push_back(tot); h->nW.push_back(lw[l]); tot += roundUp(lw[l], 8);
+    h->indB.push_back(tot); h->nB.push_back(lb[l]); tot += roundUp(lb[l], 8);
+  }
+  h->nParams = tot;
+  for (int j = 0; j < nH; ++j) {
+    DevHidden& d = h->hid[j];
+    d.nIn = hs[j].nIn; d.size = hs[j].size; d.ldW = (int)roundUp(d.size, 8); d.func = c.nnFunc;
+    d.indW = h->indW[hs[j].denseLayer]; d.indB = h->indB[hs[j].denseLayer];
+    d.hasRes = hs[j].hasRes; d.resW = std::min(d.nIn, d.size);
+    d.indWr = d.hasRes ? h->indW[hs[j].resLayer] : 0; d.indBr = d.hasRes ? h->indB[hs[j].resLayer] : 0;
+    d.ldA = (int)roundUp(d.size, 16);
+  }
+  h->indWo = h->indW[outLayer]; h->indBo = h->indB[outLayer]; h->ldWo = (int)roundUp(h->nDense, 8);
+  h->indBp = h->indB[paramLayer];
+  return HL_OK;
+}
+
+// std::mt19937 + libstdc++ uniform_real_distribution<float> for hl_init_weights (host, one-off)
+struct HostMT {
+  uint32_t x[624]; uint32_t p;
+  void twist() {
+    const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+    for (int k = 0; k < 624; ++k) {
+      const uint32_t y = (x[k] & UP) | (x[(k + 1) % 624] & LO);
+      x[k] = x[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1) ? A : 0);
+    }
+    p = 0;
+  }
+  uint32_t next() {
+    if (p >= 624) twist();
+    uint32_t z = x[p++];
+    z ^= (z >> 11); z ^= (z << 7) & 0x9d2c5680u; z ^= (z << 15) & 0xefc60000u; z ^= (z >> 18);
+    return z;
+  }
+};
+
+int syncScalarsToHost(hl_learner* h, DevScalars* out) {
+  HIPCK(hipMemcpyAsync(out, h->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
+int ensurePinned(hl_learner* h, size_t bytes) {
+  if (bytes <= h->pinnedBytes) return HL_OK;
+  HIPCK(hipStreamSynchronize(h->stream));
+  if (h->pinned) hipHostFree(h->pinned);
+  h->pinnedBytes = std::max(bytes, h->pinnedBytes * 2);
+  HIPCK(hipHostMalloc(&h->pinned, h->pinnedBytes, hipHostMallocDefault));
+  return HL_OK;
+}
+
+// Re-allocate the slot arrays with a larger capacity and re-pack the live episodes contiguously
+// (oldest first), so that the FIFO ring is un-wrapped afterwards.  Rare: capacity is sized from
+// maxTotObsNum at creation.
+template <typename T> hipError_t repack(T** arr, size_t width, long long newCap,
+                                        const std::deque<EpMeta>& order, hipStream_t s) {
+  T* q = nullptr;
+  hipError_t e = devAlloc(&q, (size_t)newCap * width);
+  if (e != hipSuccess) return e;
+  long long off = 0;
+  for (auto it = order.rbegin(); it != order.rend(); ++it) {
+    e = hipMemcpyAsync(q + (size_t)off * width, *arr + (size_t)it->off * width, (size_t)it->N * width * sizeof(T),
+                       hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    off += it->N;
+  }
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  if (*arr) hipFree(*arr);
+  *arr = q;
+  return hipSuccess;
+}
+int growSlots(hl_learner* h, long long need) {
+  if (need <= h->capSlots) return HL_OK;
+  const long long newCap = std::max(need, h->capSlots + h->capSlots / 2 + 4096);
+  const int dS = h->dS, dA = h->dA; hipStream_t s = h->stream;
+  HIPCK(repack(&h->rp.S, dS, newCap, h->order, s)); HIPCK(repack(&h->rp.A, dA, newCap, h->order, s));
+  HIPCK(repack(&h->rp.MU, 2 * dA, newCap, h->order, s)); HIPCK(repack(&h->rp.R, 1, newCap, h->order, s));
+  HIPCK(repack(&h->rp.V, 1, newCap, h->order, s)); HIPCK(repack(&h->rp.ADV, 1, newCap, h->order, s));
+  HIPCK(repack(&h->rp.RET, 1, newCap, h->order, s)); HIPCK(repack(&h->rp.DQ, 1, newCap, h->order, s));
+  HIPCK(repack(&h->rp.IMPW, 1, newCap, h->order, s)); HIPCK(repack(&h->rp.DKL, 1, newCap, h->order, s));
+  long long off = 0;
+  for (auto it = h->order.rbegin(); it != h->order.rend(); ++it) {
+    it->off = off; off += it->N;
+    HIPCK(hipMemcpyAsync(h->rp.epOff + it->eid, &it->off, sizeof(long long), hipMemcpyHostToDevice, s));
+  }
+  HIPCK(hipStreamSynchronize(s));
+  h->ringHead = off; h->capSlots = newCap; h->graphValid = false;
+  return HL_OK;
+}
+int growEpisodes(hl_learner* h, int need) {
+  if (need <= h->capEps) return HL_OK;
+  const int newCap = std::max(need, h->capEps * 2 + 1024);
+  const size_t o = (size_t)h->capEps, n = (size_t)newCap;
+  HIPCK(devGrow(&h->rp.epOff, o, n, h->stream)); HIPCK(devGrow(&h->rp.epN, o, n, h->stream));
+  HIPCK(devGrow(&h->rp.epTerm, o, n, h->stream)); HIPCK(devGrow(&h->rp.epAgg, o * AGG_N, n * AGG_N, h->stream));
+  HIPCK(devGrow(&h->rp.posEid, o, n, h->stream)); HIPCK(devGrow(&h->rp.posPrefix, o + 1, n + 1, h->stream));
+  h->capEps = newCap; h->graphValid = false;
+  return HL_OK;
+}
+
+// contiguous slot range for a new episode: FIFO ring over [0, capSlots)
+int allocSlots(hl_learner* h, int N, long long* off) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (h->order.empty()) {
+      if (N <= h->capSlots) { *off = 0; h->ringHead = N; return HL_OK; }
+    } else {
+      const long long head = h->ringHead, tail = h->order.back().off;   // oldest live episode starts at tail
+      if (head > tail) {                       // live region [tail, head): free = [head, cap) and [0, tail)
+        if (head + N <= h->capSlots) { *off = head; h->ringHead = head + N; return HL_OK; }
+        if (N < tail) { *off = 0; h->ringHead = N; return HL_OK; }
+      } else if (head + N < tail) {            // wrapped: free = [head, tail)
+        *off = head; h->ringHead = head + N; return HL_OK;
+      }
+    }
+    int rc = growSlots(h, h->capSlots + std::max<long long>(N + 1, h->capSlots / 2));   // re-packs, un-wraps
+    if (rc) return rc;
+  }
+  return fail(h, HL_ERR_STATE, "replay slot allocation failed");
+}
+
+int uploadTable(hl_learner* h) {
+  const size_t nEp = h->order.size();
+  int rc = growEpisodes(h, (int)nEp + 1); if (rc) return rc;
+  const size_t bytes = nEp * sizeof(int) + (nEp + 1) * sizeof(long long) + 64;
+  rc = ensurePinned(h, bytes); if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));   // the pinned buffer may still feed an earlier copy
+  long long* pre = (long long*)h->pinned;
+  int* pe = (int*)(pre + nEp + 1);
+  long long acc = 0;
+  for (size_t p = 0; p < nEp; ++p) { pre[p] = acc; pe[p] = h->order[p].eid; acc += h->order[p].N - 1; }
+  pre[nEp] = acc;
+  HIPCK(hipMemcpyAsync(h->rp.posPrefix, pre, (nEp + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->rp.posEid, pe, nEp * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  h->tableDirty = false;
+  return HL_OK;
+}
+
+int runSweep(hl_learner* h, const int* dEids, int count, int recompute) {
+  if (count <= 0) return HL_OK;
+  const int nb = sweep_blocks(count);
+  if (recompute && nb > h->redCap) {
+    HIPCK(devGrow(&h->dRedNFar, 0, (size_t)nb, h->stream)); HIPCK(devGrow(&h->dRedMax, 0, (size_t)nb, h->stream));
+    h->redCap = nb;
+  }
+  EpisodeSweepArgs a{}; a.sc = h->sc; a.rp = h->rp; a.eids = dEids; a.count = count;
+  a.gamma = (float)h->cfg.gamma; a.lambda = (float)h->cfg.lambda; a.recompute = recompute;
+  a.redNFar = h->dRedNFar; a.redMaxAbs = h->dRedMax;
+  HIPCK(timed(h, recompute ? "episode_sweep_recompute" : "episode_sweep_retrace",
+              [&] { return launch_episode_sweep(a, nb, h->stream); }));
+  if (recompute) HIPCK(launch_sweep_finish(h->sc, h->dRedNFar, h->dRedMax, nb, h->stream));
+  return HL_OK;
+}
+
+// everything the host queued since the last step: table, counters, Retrace of new episodes
+int flushPending(hl_learner* h) {
+  if (h->tableDirty) { int rc = uploadTable(h); if (rc) return rc; }
+  if (h->countsDirty) {
+    HIPCK(launch_set_counts(h->sc, h->nTransitions, (long long)h->order.size(), h->nSeenEps, h->nSeenSteps, h->stream));
+    h->countsDirty = false;
+  }
+  if (!h->pendingRetrace.empty()) {
+    const int n = (int)h->pendingRetrace.size();
+    if (n > h->eidListCap) { HIPCK(devGrow(&h->dEidList, 0, (size_t)n * 2, h->stream)); h->eidListCap = n * 2; }
+    HIPCK(hipMemcpyAsync(h->dEidList, h->pendingRetrace.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    int rc = runSweep(h, h->dEidList, n, 0); if (rc) return rc;
+    h->pendingRetrace.clear();
+  }
+  return HL_OK;
+}
+
+// ---- gemm problem tables ---------------------------------------------------------------------
+void setTiles(GemmProblem& p, int& cursor) {
+  p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
+  if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 63) / 64; }
+  p.tileStart = cursor; cursor += p.tilesM * p.tilesN;
+}
+
+int buildProblems(hl_learner* h) {
+  std::vector<GemmProblem> P;
+  const int nH = h->nHidden, B = h->B;
+  h->fwdIdx.clear(); h->fwdBlocks.clear(); h->dxIdx.clear(); h->dxBlocks.clear();
+  // forward: one launch per hidden block
+  for (int j = 0; j < nH; ++j) {
+    const DevHidden& d = h->hid[j];
+    GemmProblem p{}; p.flavor = GEMM_F; p.epi = EPI_FWD; p.M = h->Mmax; p.N = d.size; p.K = d.nIn; p.dynRows = 1;
+    if (j == 0) { p.A = h->X0; p.lda = h->ldX0; }
+    else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
+    p.B = h->W + d.indW; p.ldb = d.ldW; p.bias = h->W + d.indB;
+    p.C = d.X; p.C2 = d.Y; p.C3 = d.hasRes ? d.Rr : nullptr; p.ldc = d.ldA; p.func = d.func;
+    if (d.hasRes) { p.resW = h->W + d.indWr; p.resB = h->W + d.indBr; p.resIn = p.A; p.ldRes = p.lda; p.resN = d.resW; }
+    int cur = 0; setTiles(p, cur);
+    h->fwdIdx.push_back((int)P.size()); h->fwdBlocks.push_back(cur); P.push_back(p);
+  }
+  // dX: for block j = nH-1 .. 1: Dres_{j-1} = D_j W_j^T + Dres_j[:, :res] * w_j ; D_{j-1} = Dres_{j-1} * act'
+  for (int j = nH - 1; j >= 1; --j) {
+    const DevHidden& d = h->hid[j]; const DevHidden& q = h->hid[j - 1];
+    GemmProblem p{}; p.flavor = GEMM_X; p.epi = EPI_DX; p.M = B; p.N = d.nIn; p.K = d.size;
+    p.A = d.D; p.lda = d.ldA; p.B = h->W + d.indW; p.ldb = d.ldW;
+    p.C = q.Dres; p.C2 = q.D; p.ldc = q.ldA;
+    if (d.hasRes) { p.resIn = d.Dres; p.ldRes = d.ldA; p.resW = h->W + d.indWr; p.resN = d.resW; }
+    p.actX = q.X; p.actY = q.Y; p.ldAct = q.ldA; p.func = q.func;
+    int cur = 0; setTiles(p, cur);
+    h->dxIdx.push_back((int)P.size()); h->dxBlocks.push_back(cur); P.push_back(p);
+  }
+  // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
+  h->dwIdx = (int)P.size(); int cur = 0;
+  for (int j = 0; j < nH; ++j) {
+    const DevHidden& d = h->hid[j];
+    GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = d.nIn + 1; p.N = d.size; p.K = B;
+    if (j == 0) { p.A = h->X0; p.lda = h->ldX0; }
+    else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
+    p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
+    setTiles(p, cur); P.push_back(p);
+    if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
+      GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
+      r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
+      setTiles(r, cur); P.push_back(r);
+      GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = d.resW; s.K = B;
+      s.A = d.Dres; s.lda = d.ldA; s.B = nullptr; s.C = h->G + d.indBr;
+      setTiles(s, cur); P.push_back(s);
+    }
+  }
+  { // output InnerProduct layer
+    const DevHidden& q = h->hid[nH - 1];
+    GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = q.size + 1; p.N = h->nDense; p.K = B;
+    p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; p.B = h->dOut; p.ldb = h->ldDo;
+    p.C = h->G + h->indWo; p.ldc = h->ldWo; p.biasOut = h->G + h->indBo;
+    setTiles(p, cur); P.push_back(p);
+    // ParamLayer::backward (Layers.h:522-546): bias gradient = column sums of the sigma-param deltas
+    GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
+    s.A = h->bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
+    setTiles(s, cur); P.push_back(s);
+  }
+  h->dwCount = (int)P.size() - h->dwIdx; h->dwBlocks = cur;
+  if (h->dProbs) hipFree(h->dProbs);
+  HIPCK(devAlloc(&h->dProbs, P.size()));
+  HIPCK(hipMemcpy(h->dProbs, P.data(), P.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
+  return HL_OK;
+}
+
+// ---- the launch sequence of one gradient step ------------------------------------------------
+struct StepOpts { const long long* dFlat; bool split; };   // split: stop before post(BETA) for exchanges
+
+int launchTrain(hl_learner* h, const long long* dFlat) {
+  SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
+  sa.X0 = h->X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
+  HIPCK(timed(h, "sample_kernel", [&] { return launch_sample(sa, h->stream); }));
+  for (int j = 0; j < h->nHidden; ++j)
+    HIPCK(timed(h, "gemm16_fwd", [&] { return launch_gemm(h->dProbs + h->fwdIdx[j], 1, h->fwdBlocks[j], h->sc, h->stream); }));
+  const DevHidden& q = h->hid[h->nHidden - 1];
+  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense;
+  ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
+  ha.func = q.func; ha.params = h->W; ha.indWo = h->indWo; ha.indBo = h->indBo; ha.indBp = h->indBp; ha.ldWo = h->ldWo;
+  ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA;
+  for (int i = 0; i < h->dA; ++i) ha.bounded[i] = h->cfg.bounded[i];
+  HIPCK(timed(h, "head_kernel", [&] { return launch_head(ha, h->Mmax, h->stream); }));
+  for (size_t i = 0; i < h->dxIdx.size(); ++i)
+    HIPCK(timed(h, "gemm16_dx", [&] { return launch_gemm(h->dProbs + h->dxIdx[i], 1, h->dxBlocks[i], h->sc, h->stream); }));
+  HIPCK(timed(h, "gemm16_dw", [&] { return launch_gemm(h->dProbs + h->dwIdx, h->dwCount, h->dwBlocks, h->sc, h->stream); }));
+  return HL_OK;
+}
+PostArgs postArgs(hl_learner* h, int mode) {
+  PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->bt; pa.B = h->B; pa.mode = mode;
+  pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
+  pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = h->cfg.n_ranks;
+  return pa;
+}
+int launchAdam(hl_learner* h) {
+  AdamArgs aa{}; aa.sc = h->sc; aa.W = h->W; aa.M1 = h->M1; aa.M2 = h->M2; aa.G = h->G; aa.n = h->nParams;
+  aa.eta0 = (float)h->cfg.learnrate; aa.lambda = (float)h->cfg.nnLambda; aa.fac = (float)(1.0 / h->Bglobal);
+  aa.epsAnneal = h->cfg.epsAnneal;
+  HIPCK(timed(h, "adam_kernel", [&] { return launch_adam(aa, h->stream); }));
+  return HL_OK;
+}
+int launchPost(hl_learner* h, int mode) {
+  PostArgs pa = postArgs(h, mode);
+  HIPCK(timed(h, "post_kernel", [&] { return launch_post(pa, h->stream); }));
+  return HL_OK;
+}
+
+// every 1000th step: Episode::updateCumulative + full Retrace sweep, then reward/state statistics
+int launchPeriodicSweep(hl_learner* h) {
+  return runSweep(h, nullptr, (int)h->order.size(), 1);
+}
+int launchMoments(hl_learner* h) {
+  const int nb = moments_blocks((int)h->order.size());
+  if (nb > h->momBlocksCap) {
+    HIPCK(devGrow(&h->dMomPartial, 0, (size_t)nb * 2 * (h->dS + 1), h->stream)); h->momBlocksCap = nb;
+  }
+  MomentsArgs ma{}; ma.sc = h->sc; ma.rp = h->rp; ma.dS = h->dS; ma.nEpisodes = (int)h->order.size();
+  ma.partial = h->dMomPartial; ma.nBlocks = nb; ma.moments = h->dMoments;
+  HIPCK(timed(h, "moments_kernel", [&] { return launch_moments(ma, h->stream); }));
+  return HL_OK;
+}
+int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
+  MomentsArgs ma{}; ma.sc = h->sc; ma.rp = h->rp; ma.dS = h->dS; ma.moments = h->dMoments;
+  ma.bInit = bInit ? 1 : 0; ma.learnrate = h->cfg.learnrate; ma.epsAnneal = h->cfg.epsAnneal; ma.rRateFac = rRateFac;
+  HIPCK(launch_moments_apply(ma, h->stream));
+  return HL_OK;
+}
+
+// FIFO removal (MemoryProcessing::applyEpisodesRemovalAlgo, "oldest"): host bookkeeping + device nFar
+int applyRemoval(hl_learner* h) {
+  bool any = false;
+  while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
+    const EpMeta e = h->order.back();
+    HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
+    h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
+  }
+  if (any) { h->tableDirty = true; h->countsDirty = true; h->graphValid = false; }
+  return HL_OK;
+}
+
+int allreduceGrad(hl_learner* h) {
+  if (h->cfg.n_ranks <= 1) return HL_OK;
+  if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
+  NCCLCK(ncclAllReduce(h->G, h->G, (size_t)h->nParams, ncclFloat, ncclSum, h->comm, h->stream));
+  return HL_OK;
+}
+int allreduceCounters(hl_learner* h) {
+  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
+  NCCLCK(ncclAllReduce(h->sc->cnt, h->sc->cnt, 4, ncclInt64, ncclSum, h->comm, h->stream));
+  return HL_OK;
+}
+int allreduceMoments(hl_learner* h) {
+  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
+  NCCLCK(ncclAllReduce(h->dMoments, h->dMoments, (size_t)(2 * h->dS + 3), ncclDouble, ncclSum, h->comm, h->stream));
+  return HL_OK;
+}
+
+// one full step, eager launches (also the body captured into the graph for the plain case)
+int stepEager(hl_learner* h, const long long* dFlat) {
+  const long long k = h->nGradSteps + 1;
+  const bool periodic = (k % 1000) == 0;
+  int rc = launchTrain(h, dFlat); if (rc) return rc;
+  rc = allreduceGrad(h); if (rc) return rc;
+  rc = launchAdam(h); if (rc) return rc;
+  const bool evict = !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
+  if (!periodic && !evict && h->cfg.n_ranks <= 1) return launchPost(h, POST_AGG | POST_BETA);
+  rc = launchPost(h, POST_AGG); if (rc) return rc;
+  if (periodic) {
+    rc = launchPeriodicSweep(h); if (rc) return rc;
+    rc = launchMoments(h); if (rc) return rc;
+    rc = allreduceMoments(h); if (rc) return rc;
+    rc = launchMomentsApply(h, false, 10); if (rc) return rc;
+  }
+  if (evict) { rc = applyRemoval(h); if (rc) return rc; rc = flushPending(h); if (rc) return rc; }
+  rc = allreduceCounters(h); if (rc) return rc;
+  return launchPost(h, POST_BETA);
+}
+
+int captureGraph(hl_learner* h) {
+  if (h->graphExec) { hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
+  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  HIPCK(hipStreamSynchronize(h->stream));
+  HIPCK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = launchTrain(h, nullptr);
+  if (!rc) rc = launchAdam(h);
+  if (!rc) rc = launchPost(h, POST_AGG | POST_BETA);
+  hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+  if (rc) return rc;
+  if (e != hipSuccess) return hipFail(h, e, "hipStreamEndCapture");
+  HIPCK(hipGraphInstantiate(&h->graphExec, h->graph, nullptr, nullptr, 0));
+  h->graphValid = true;
+  return HL_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int hl_version(void) { return 1; }
+const char* hl_status_string(int s) {
+  switch (s) { case HL_OK: return "HL_OK"; case HL_ERR_BAD_ARG: return "HL_ERR_BAD_ARG";
+    case HL_ERR_NO_DEVICE: return "HL_ERR_NO_DEVICE"; case HL_ERR_HIP: return "HL_ERR_HIP";
+    case HL_ERR_STATE: return "HL_ERR_STATE"; case HL_ERR_TOO_FEW_DATA: return "HL_ERR_TOO_FEW_DATA";
+    case HL_ERR_COMM: return "HL_ERR_COMM"; case HL_ERR_IO: return "HL_ERR_IO";
+    case HL_ERR_UNSUPPORTED: return "HL_ERR_UNSUPPORTED"; }
+  return "HL_ERR_?";
+}
+const char* hl_last_error(const hl_learner* h) { return h ? h->err.c_str() : "null handle"; }
+
+int hl_create(const hl_config* cfg, hl_learner** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
+  if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
+      cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
+  if (cfg->adv_kind != HL_ADV_ZERO) return HL_ERR_UNSUPPORTED;
+  if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
+      cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
+  if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return HL_ERR_NO_DEVICE;
+  hl_learner* h = new hl_learner();
+  h->cfg = *cfg;
+  h->dev = cfg->device_id >= 0 ? cfg->device_id : (cfg->rank % nDev);
+  *out = h;   // so that the caller can read hl_last_error and must hl_destroy
+  HIPCK(hipSetDevice(h->dev));
+  HIPCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->dS = cfg->dimS; h->dA = cfg->dimA;
+  const double nL = cfg->n_ranks;
+  h->Bglobal = cfg->batchSize > 1 ? (int)(std::ceil(cfg->batchSize / nL) * nL) : cfg->batchSize;
+  h->B = cfg->batchSize > 1 ? h->Bglobal / cfg->n_ranks : h->Bglobal;
+  if (h->B > 2048) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 2048");
+  h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);
+  h->maxObsLocal = h->maxObsGlobal / cfg->n_ranks;
+  long long minObs = cfg->minTotObsNum <= 0 ? cfg->maxTotObsNum : cfg->minTotObsNum;
+  minObs = std::min(minObs, (long long)cfg->maxTotObsNum);
+  minObs = (long long)(std::ceil(minObs / nL) * nL);
+  h->minObsLocal = minObs / cfg->n_ranks;
+  int rc = buildNet(h); if (rc) return rc;
+  const int B = h->B;
+  h->Mmax = (int)roundUp(2 * B, 16);
+  HIPCK(devAlloc(&h->W, (size_t)h->nParams)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams));
+  HIPCK(devAlloc(&h->M2, (size_t)h->nParams)); HIPCK(devAlloc(&h->G, (size_t)h->nParams));
+  HIPCK(devAlloc(&h->sc, 1));
+  h->ldX0 = (int)roundUp(h->dS, 16);
+  HIPCK(devAlloc(&h->X0, (size_t)h->Mmax * h->ldX0));
+  for (int j = 0; j < h->nHidden; ++j) {
+    DevHidden& d = h->hid[j];
+    const size_t n = (size_t)h->Mmax * d.ldA;
+    HIPCK(devAlloc(&d.X, n)); HIPCK(devAlloc(&d.Y, n));
+    if (d.hasRes) HIPCK(devAlloc(&d.Rr, n)); else d.Rr = nullptr;
+    HIPCK(devAlloc(&d.D, (size_t)B * d.ldA)); HIPCK(devAlloc(&d.Dres, (size_t)B * d.ldA));
+  }
+  h->ldDo = (int)roundUp(h->nDense, 16);
+  HIPCK(devAlloc(&h->dOut, (size_t)B * h->ldDo));
+  DevBatch& bt = h->bt;
+  HIPCK(devAlloc(&bt.flat, B)); HIPCK(devAlloc(&bt.pos, B)); HIPCK(devAlloc(&bt.eid, B)); HIPCK(devAlloc(&bt.t, B));
+  HIPCK(devAlloc(&bt.slot, B)); HIPCK(devAlloc(&bt.nextOf, B)); HIPCK(devAlloc(&bt.nextSrc, B));
+  HIPCK(devAlloc(&bt.O, (size_t)2 * B * h->nOut)); HIPCK(devAlloc(&bt.G, (size_t)B * h->nOut));
+  HIPCK(devAlloc(&bt.rho, B)); HIPCK(devAlloc(&bt.dkl, B)); HIPCK(devAlloc(&bt.dq, B)); HIPCK(devAlloc(&bt.far, B));
+  HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B));
+  HIPCK(devAlloc(&bt.oldDQ, B)); HIPCK(devAlloc(&bt.oldDKL, B)); HIPCK(devAlloc(&bt.oldW, B)); HIPCK(devAlloc(&bt.oldV, B));
+  HIPCK(devAlloc(&bt.oldADV, B)); HIPCK(devAlloc(&bt.nextV, B)); HIPCK(devAlloc(&bt.oldNextV, B));
+  HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * h->dA));
+  HIPCK(devAlloc(&h->dFlatGiven, B));
+  HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16));
+  HIPCK(devAlloc(&h->rp.stMean, h->dS)); HIPCK(devAlloc(&h->rp.stScale, h->dS)); HIPCK(devAlloc(&h->rp.stStd, h->dS));
+  rc = growSlots(h, h->maxObsLocal + h->maxObsLocal / 8 + 8192); if (rc) return rc;
+  rc = growEpisodes(h, 4096); if (rc) return rc;
+  // initial scalars (MemoryBuffer.h:41-44; Optimizer.h:96; ExecutionInfo.cpp:387,391)
+  DevScalars s0; std::memset(&s0, 0, sizeof(s0));
+  s0.beta = cfg->clipImpWeight <= 0 ? 1 : 1e-4; s0.alpha = 0.5;
+  s0.Cmax = 1 + cfg->clipImpWeight; s0.Cinv = 1 / cfg->clipImpWeight;
+  s0.adam_bt1 = 0.9; s0.adam_bt2 = 0.999; s0.rewMean = 0; s0.rewScale = 1; s0.rewStd = 1;
+  { HostMT g; uint32_t sd = (uint32_t)(cfg->randSeed + (uint64_t)cfg->rank); g.x[0] = sd;
+    for (uint32_t i = 1; i < 624; ++i) g.x[i] = 1812433253u * (g.x[i - 1] ^ (g.x[i - 1] >> 30)) + i;
+    std::memcpy(s0.rng, g.x, sizeof(g.x)); s0.rngPos = 624; }
+  HIPCK(hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice));
+  std::vector<float> ones(h->dS, 1.f);
+  HIPCK(hipMemcpy(h->rp.stScale, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
+  HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
+  rc = buildProblems(h); if (rc) return rc;
+  if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) h->useGraph = !(e[0] == '1');
+  return HL_OK;
+}
+
+int hl_destroy(hl_learner* h) {
+  if (!h) return HL_OK;
+  if (h->stream) hipStreamSynchronize(h->stream);
+  timerFlush(h);
+  if (h->graphExec) hipGraphExecDestroy(h->graphExec);
+  if (h->graph) hipGraphDestroy(h->graph);
+  if (h->comm) ncclCommDestroy(h->comm);
+  void* ptrs[] = {h->W, h->M1, h->M2, h->G, h->sc, h->X0, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
+    h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
+    h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
+    h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
+    h->rp.stStd, h->bt.flat, h->bt.pos, h->bt.eid, h->bt.t, h->bt.slot, h->bt.nextOf, h->bt.nextSrc, h->bt.O, h->bt.G,
+    h->bt.rho, h->bt.dkl, h->bt.dq, h->bt.far, h->bt.newDQ, h->bt.newDKL, h->bt.newW, h->bt.newV, h->bt.oldDQ,
+    h->bt.oldDKL, h->bt.oldW, h->bt.oldV, h->bt.oldADV, h->bt.nextV, h->bt.oldNextV, h->bt.oldNextADV, h->bt.gParam};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
+    for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
+  if (h->pinned) hipHostFree(h->pinned);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h; return HL_OK;
+}
+
+int64_t hl_num_params(const hl_learner* h) { return h ? h->nParams : -1; }
+int32_t hl_num_outputs(const hl_learner* h) { return h ? h->nOut : -1; }
+int32_t hl_num_layers(const hl_learner* h) { return h ? (int32_t)h->indW.size() : -1; }
+int hl_param_layout(const hl_learner* h, int64_t* indW, int64_t* nW, int64_t* indB, int64_t* nB) {
+  if (!h) return HL_ERR_BAD_ARG;
+  for (size_t l = 0; l < h->indW.size(); ++l) {
+    if (indW) indW[l] = h->indW[l];
+    if (nW) nW[l] = h->nW[l];
+    if (indB) indB[l] = h->indB[l];
+    if (nB) nB[l] = h->nB[l];
+  }
+  return HL_OK;
+}
+
+// Layer::initialize in build order (Builder.cpp:131-137; Layer_Base.h:115-141; Layers.h:395-400,548-553)
+int hl_init_weights(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  HostMT g; std::memcpy(g.x, s.rng, sizeof(g.x)); g.p = s.rngPos;
+  auto uni = [&](float a, float b) {
+    float r = (float)g.next() / 4294967296.0f;
+    if (r >= 1.0f) r = std::nextafter(1.0f, 0.0f);
+    return r * (b - a) + a;
+  };
+  auto initFactor = [&](int f, int inps, int outs) -> double {
+    switch (f) { case HL_FUNC_LINEAR: return std::sqrt(1. / inps); case HL_FUNC_TANH: return std::sqrt(6. / (inps + outs));
+      case HL_FUNC_SOFTSIGN: return std::sqrt(6.0 / (inps + outs)); case HL_FUNC_RELU: return std::sqrt(2. / inps); }
+    return 1;
+  };
+  std::vector<float> W((size_t)h->nParams, 0.f);
+  for (int j = 0; j < h->nHidden; ++j) {
+    const DevHidden& d = h->hid[j];
+    const float fac = 1; const float init = fac * initFactor(d.func, d.nIn, d.size);
+    for (int i = 0; i < d.nIn; ++i) for (int o = 0; o < d.size; ++o) W[d.indW + o + (long long)d.ldW * i] = uni(-init, init);
+    if (d.hasRes) for (int o = 0; o < d.size; ++o) { W[d.indWr + o] = 1.f; W[d.indBr + o] = 0.f; }
+  }
+  { const DevHidden& q = h->hid[h->nHidden - 1];
+    const double iFac = h->cfg.outWeightsPrefac; const float fac = (iFac > 0) ? iFac : 1;
+    const float init = fac * initFactor(HL_FUNC_LINEAR, q.size, h->nDense);
+    for (int i = 0; i < q.size; ++i) for (int o = 0; o < h->nDense; ++o) W[h->indWo + o + (long long)h->ldWo * i] = uni(-init, init);
+    double S = h->cfg.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
+    for (int o = 0; o < h->dA; ++o) W[h->indBp + o] = (float)((S * S - 0.25) / S);   // SoftPlus::_inv (Functions.h:564-568)
+  }
+  HIPCK(hipMemcpyAsync(h->W, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  std::memcpy(s.rng, g.x, sizeof(g.x)); s.rngPos = g.p;
+  HIPCK(hipMemcpyAsync(&h->sc->rng[0], s.rng, sizeof(s.rng), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(&h->sc->rngPos, &s.rngPos, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
+int hl_set_params(hl_learner* h, const float* w, const float* m1, const float* m2) {
+  if (!h) return HL_ERR_BAD_ARG;
+  const size_t n = (size_t)h->nParams * sizeof(float);
+  if (w) HIPCK(hipMemcpyAsync(h->W, w, n, hipMemcpyHostToDevice, h->stream));
+  if (m1) HIPCK(hipMemcpyAsync(h->M1, m1, n, hipMemcpyHostToDevice, h->stream));
+  if (m2) HIPCK(hipMemcpyAsync(h->M2, m2, n, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_get_params(hl_learner* h, float* w, float* m1, float* m2) {
+  if (!h) return HL_ERR_BAD_ARG;
+  const size_t n = (size_t)h->nParams * sizeof(float);
+  if (w) HIPCK(hipMemcpyAsync(w, h->W, n, hipMemcpyDeviceToHost, h->stream));
+  if (m1) HIPCK(hipMemcpyAsync(m1, h->M1, n, hipMemcpyDeviceToHost, h->stream));
+  if (m2) HIPCK(hipMemcpyAsync(m2, h->M2, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_set_rng_state(hl_learner* h, const uint32_t st[625]) {
+  if (!h || !st) return HL_ERR_BAD_ARG;
+  HIPCK(hipMemcpyAsync(&h->sc->rng[0], st, 624 * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(&h->sc->rngPos, st + 624, 4, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_get_rng_state(hl_learner* h, uint32_t st[625]) {
+  if (!h || !st) return HL_ERR_BAD_ARG;
+  DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  std::memcpy(st, s.rng, 624 * 4); st[624] = s.rngPos;
+  return HL_OK;
+}
+
+// MemoryBuffer::addEpisodeToTrainingSet + Episode::finalize + pushBackEpisode
+// (MemoryBuffer.cpp:131-170,479-520; Episode.cpp:244-274): host -> HBM, Retrace queued on the stream
+int hl_append_episode(hl_learner* h, int32_t N, const float* states, const double* actions, const double* mu,
+                      const double* rewards, const float* values, const float* advantages, int32_t terminated,
+                      int64_t tag) {
+  if (!h || !states || !actions || !mu || !rewards || !values) return HL_ERR_BAD_ARG;
+  if (N < 2) return fail(h, HL_ERR_BAD_ARG, "Episode must at least have s0 and sT");
+  const int dS = h->dS, dA = h->dA;
+  long long off = 0; int rc = allocSlots(h, N, &off); if (rc) return rc;
+  int eid;
+  if (!h->freeEids.empty()) { eid = h->freeEids.back(); h->freeEids.pop_back(); }
+  else { eid = h->nextEid++; rc = growEpisodes(h, eid + 1); if (rc) return rc; }
+  // stage the derived per-step arrays + episode record in pinned memory
+  const size_t nf = (size_t)N;
+  const size_t bytes = nf * 6 * sizeof(float) + AGG_N * sizeof(float) + 64;
+  rc = ensurePinned(h, bytes + 4096); if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  float* p = (float*)h->pinned;
+  float *pADV = p, *pRET = p + nf, *pDQ = p + 2 * nf, *pIMPW = p + 3 * nf, *pDKL = p + 4 * nf, *pAGG = p + 5 * nf;
+  const float maxError = (float)std::sqrt(std::max((double)FLT_EPSILON, h->lastAvgSqErr));
+  double totR = 0;
+  for (int t = 0; t < N; ++t) {
+    pADV[t] = advantages ? advantages[t] : 0.f; pRET[t] = 0.f; pDQ[t] = maxError; pIMPW[t] = 1.f; pDKL[t] = 0.f;
+    if (t) totR += rewards[t];
+  }
+  pIMPW[N - 1] = 0.f;
+  for (int i = 0; i < AGG_N; ++i) pAGG[i] = 0.f;
+  pAGG[AGG_TOTR] = (float)totR; pAGG[AGG_AVGSQERR] = maxError * maxError; pAGG[AGG_MAXABSERR] = maxError;
+  pAGG[AGG_MAXQ] = -1e9f; pAGG[AGG_MINQ] = 1e9f;
+  hipStream_t s = h->stream;
+  HIPCK(hipMemcpyAsync(h->rp.S + (size_t)off * dS, states, nf * dS * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.A + (size_t)off * dA, actions, nf * dA * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.MU + (size_t)off * 2 * dA, mu, nf * 2 * dA * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.R + off, rewards, nf * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.V + off, values, nf * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.ADV + off, pADV, nf * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.RET + off, pRET, nf * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.DQ + off, pDQ, nf * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.IMPW + off, pIMPW, nf * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.DKL + off, pDKL, nf * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.epAgg + (size_t)eid * AGG_N, pAGG, AGG_N * sizeof(float), hipMemcpyHostToDevice, s));
+  const long long off64 = off; const int n32 = N; const unsigned char term8 = terminated ? 1 : 0;
+  HIPCK(hipMemcpyAsync(h->rp.epOff + eid, &off64, sizeof(long long), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.epN + eid, &n32, sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.epTerm + eid, &term8, 1, hipMemcpyHostToDevice, s));
+  HIPCK(hipStreamSynchronize(s));     // caller-owned / stack buffers may go away after return
+  // counters: storeAction increments for t = 1..N-2, ID taken before the final increment (:110,:167,:484)
+  h->nSeenSteps += N - 2;
+  const long long locTrain = h->nGatheredB4Startup == INT64_MAX ? -1 : h->nSeenSteps - h->nGatheredB4Startup;
+  EpMeta e{eid, off, N, terminated != 0, tag, std::max(locTrain, (long long)0)};
+  h->nSeenSteps += 1; h->nSeenEps += 1;
+  h->order.push_front(e);
+  h->nTransitions += N - 1;
+  h->pendingRetrace.push_back(eid);
+  h->tableDirty = true; h->countsDirty = true; h->graphValid = false;
+  return HL_OK;
+}
+
+int hl_get_scaling(hl_learner* h, float* m, float* sc, float* r3) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (m) HIPCK(hipMemcpyAsync(m, h->rp.stMean, h->dS * 4, hipMemcpyDeviceToHost, h->stream));
+  if (sc) HIPCK(hipMemcpyAsync(sc, h->rp.stScale, h->dS * 4, hipMemcpyDeviceToHost, h->stream));
+  DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  if (r3) { r3[0] = s.rewMean; r3[1] = s.rewScale; r3[2] = s.rewStd; }
+  return HL_OK;
+}
+int hl_set_scaling(hl_learner* h, const float* m, const float* sc, const float* r3) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (m) HIPCK(hipMemcpyAsync(h->rp.stMean, m, h->dS * 4, hipMemcpyHostToDevice, h->stream));
+  if (sc) {
+    std::vector<float> sd(h->dS); for (int k = 0; k < h->dS; ++k) sd[k] = 1 / sc[k];
+    HIPCK(hipMemcpyAsync(h->rp.stScale, sc, h->dS * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipMemcpyAsync(h->rp.stStd, sd.data(), h->dS * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+  }
+  if (r3) {
+    HIPCK(hipMemcpyAsync(&h->sc->rewMean, &r3[0], 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipMemcpyAsync(&h->sc->rewScale, &r3[1], 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipMemcpyAsync(&h->sc->rewStd, &r3[2], 4, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_get_episode_info(hl_learner* h, int64_t pos, int64_t* tag, int32_t* nsteps, int32_t* term) {
+  if (!h || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  const EpMeta& e = h->order[(size_t)pos];
+  if (tag) *tag = e.tag;
+  if (nsteps) *nsteps = e.N;
+  if (term) *term = e.term;
+  return HL_OK;
+}
+int hl_get_episode_field(hl_learner* h, int64_t pos, int32_t field, float* dst, int32_t cap) {
+  if (!h || !dst || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  const EpMeta& e = h->order[(size_t)pos];
+  if (cap < e.N) return HL_ERR_BAD_ARG;
+  int rc = flushPending(h); if (rc) return rc;
+  const float* src = nullptr;
+  switch (field) { case HL_EP_RETURN: src = h->rp.RET; break; case HL_EP_VALUE: src = h->rp.V; break;
+    case HL_EP_ADVANTAGE: src = h->rp.ADV; break; case HL_EP_IMPW: src = h->rp.IMPW; break;
+    case HL_EP_DKL: src = h->rp.DKL; break; case HL_EP_DELTAQ: src = h->rp.DQ; break; default: return HL_ERR_BAD_ARG; }
+  HIPCK(hipMemcpyAsync(dst, src + e.off, (size_t)e.N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
+// Learner::initializeLearner (Learners/Learner.cpp:47-72)
+int hl_initialize(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (h->order.empty()) return fail(h, HL_ERR_TOO_FEW_DATA, "empty replay");
+  int rc = flushPending(h); if (rc) return rc;
+  if (h->cfg.n_ranks > 1 && !h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1: call hl_comm_init before hl_initialize");
+  rc = allreduceCounters(h); if (rc) return rc;
+  rc = launchPost(h, POST_INIT); if (rc) return rc;                  // updateCounters(bInit)
+  rc = launchMoments(h); if (rc) return rc;                          // updateRewardsStats(bInit)
+  rc = allreduceMoments(h); if (rc) return rc;
+  rc = launchMomentsApply(h, true, 1); if (rc) return rc;
+  h->nGatheredB4Startup = h->minObsLocal;
+  rc = runSweep(h, nullptr, (int)h->order.size(), 0); if (rc) return rc;   // rescaleAllReturnEstimator
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->initialized = true;
+  return HL_OK;
+}
+
+static int preStepChecks(hl_learner* h) {
+  if (!h->initialized) return fail(h, HL_ERR_STATE, "step before hl_initialize");
+  if (h->inStep) return fail(h, HL_ERR_STATE, "hl_step_begin called twice");
+  if (h->nTransitions < h->B) return fail(h, HL_ERR_TOO_FEW_DATA, "Parameter minTotObsNum is too low for given problem");
+  return flushPending(h);
+}
+
+int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
+  if (!h || n < 0) return HL_ERR_BAD_ARG;
+  for (int s = 0; s < n; ++s) {
+    int rc = preStepChecks(h); if (rc) return rc;
+    const long long k = h->nGradSteps + 1;
+    const bool evict = !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
+    const bool plain = !flat && (k % 1000) != 0 && !evict && h->cfg.n_ranks <= 1 && !h->timing && h->useGraph;
+    if (plain) {
+      if (!h->graphValid) { rc = captureGraph(h); if (rc) return rc; }
+      HIPCK(hipGraphLaunch(h->graphExec, h->stream));
+    } else {
+      const long long* dFlat = nullptr;
+      if (flat) {
+        HIPCK(hipMemcpyAsync(h->dFlatGiven, flat + (size_t)s * h->B, h->B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+        dFlat = h->dFlatGiven;
+      }
+      rc = stepEager(h, dFlat); if (rc) return rc;
+    }
+    h->nGradSteps += 1;
+  }
+  return HL_OK;
+}
+
+// split form (host-side exchange of gradient / counters / moments, e.g. over the existing MPI path)
+int hl_step_begin(hl_learner* h, const int64_t* flat) {
+  if (!h) return HL_ERR_BAD_ARG;
+  int rc = preStepChecks(h); if (rc) return rc;
+  const long long* dFlat = nullptr;
+  if (flat) {
+    HIPCK(hipMemcpyAsync(h->dFlatGiven, flat, h->B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    dFlat = h->dFlatGiven;
+  }
+  rc = launchTrain(h, dFlat); if (rc) return rc;
+  rc = launchPost(h, POST_AGG); if (rc) return rc;
+  h->momentsPending = false;
+  if (((h->nGradSteps + 1) % 1000) == 0) {
+    rc = launchPeriodicSweep(h); if (rc) return rc;
+    rc = launchMoments(h); if (rc) return rc;
+    h->momentsPending = true;
+  }
+  rc = applyRemoval(h); if (rc) return rc;
+  rc = flushPending(h); if (rc) return rc;
+  h->inStep = true;
+  return HL_OK;
+}
+int hl_grad_exchange(hl_learner* h, float* g, int32_t write_back) {
+  if (!h || !g) return HL_ERR_BAD_ARG;
+  const size_t n = (size_t)h->nParams * sizeof(float);
+  if (write_back) HIPCK(hipMemcpyAsync(h->G, g, n, hipMemcpyHostToDevice, h->stream));
+  else HIPCK(hipMemcpyAsync(g, h->G, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_counters_exchange(hl_learner* h, int64_t c[4], int32_t write_back) {
+  if (!h || !c) return HL_ERR_BAD_ARG;
+  if (write_back) HIPCK(hipMemcpyAsync(h->sc->cnt, c, 4 * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  else HIPCK(hipMemcpyAsync(c, h->sc->cnt, 4 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_moments_exchange(hl_learner* h, double* io, int32_t write_back) {
+  if (!h || !io) return HL_ERR_BAD_ARG;
+  if (!h->momentsPending) return fail(h, HL_ERR_STATE, "no reward/state moments pending this step");
+  const size_t n = (size_t)(2 * h->dS + 3) * sizeof(double);
+  if (write_back) HIPCK(hipMemcpyAsync(h->dMoments, io, n, hipMemcpyHostToDevice, h->stream));
+  else HIPCK(hipMemcpyAsync(io, h->dMoments, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+int hl_step_end(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (!h->inStep) return fail(h, HL_ERR_STATE, "hl_step_end without hl_step_begin");
+  int rc;
+  if (h->momentsPending) { rc = launchMomentsApply(h, false, 10); if (rc) return rc; h->momentsPending = false; }
+  rc = launchAdam(h); if (rc) return rc;
+  rc = launchPost(h, POST_BETA); if (rc) return rc;
+  h->nGradSteps += 1; h->inStep = false;
+  return HL_OK;
+}
+int hl_sync(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
+int hl_set_tap(hl_learner* h, int32_t) { return h ? HL_OK : HL_ERR_BAD_ARG; }   // taps are always recorded
+
+int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
+  if (!h || !dst) return HL_ERR_BAD_ARG;
+  const int B = h->B;
+  HIPCK(hipStreamSynchronize(h->stream));
+  auto copy = [&](const void* src, int64_t n) -> int {
+    if (bytes < n) return HL_ERR_BAD_ARG;
+    HIPCK(hipMemcpy(dst, src, (size_t)n, hipMemcpyDeviceToHost)); return HL_OK;
+  };
+  switch (what) {
+    case HL_TAP_FLAT: return copy(h->bt.flat, (int64_t)B * 8);
+    case HL_TAP_EPISODE: case HL_TAP_TSTEP: case HL_TAP_TAG: {
+      if (bytes < (int64_t)B * 8) return HL_ERR_BAD_ARG;
+      std::vector<int> tmp(B), tpos(B);
+      HIPCK(hipMemcpy(tmp.data(), what == HL_TAP_TSTEP ? h->bt.t : h->bt.pos, B * sizeof(int), hipMemcpyDeviceToHost));
+      int64_t* o = (int64_t*)dst;
+      for (int b = 0; b < B; ++b) {
+        if (what == HL_TAP_TAG) o[b] = (tmp[b] >= 0 && tmp[b] < (int)h->order.size()) ? h->order[tmp[b]].tag : -1;
+        else o[b] = tmp[b];
+      }
+      return HL_OK;
+    }
+    case HL_TAP_STATE: {
+      if (bytes < (int64_t)B * h->dS * 4) return HL_ERR_BAD_ARG;
+      HIPCK(hipMemcpy2D(dst, h->dS * 4, h->X0, h->ldX0 * 4, h->dS * 4, B, hipMemcpyDeviceToHost));
+      return HL_OK;
+    }
+    case HL_TAP_OUTPUT: return copy(h->bt.O, (int64_t)B * h->nOut * 8);
+    case HL_TAP_OUTGRAD: return copy(h->bt.G, (int64_t)B * h->nOut * 8);
+    case HL_TAP_RHO: return copy(h->bt.rho, (int64_t)B * 8);
+    case HL_TAP_DKL: return copy(h->bt.dkl, (int64_t)B * 8);
+    case HL_TAP_DELTAQ: return copy(h->bt.dq, (int64_t)B * 8);
+    case HL_TAP_FAR: return copy(h->bt.far, (int64_t)B);
+    case HL_TAP_GRADSUM: return copy(h->G, (int64_t)h->nParams * 4);
+  }
+  return HL_ERR_BAD_ARG;
+}
+
+int hl_get_scalars(hl_learner* h, hl_scalars* o) {
+  if (!h || !o) return HL_ERR_BAD_ARG;
+  int rc = flushPending(h); if (rc) return rc;
+  DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  o->beta = s.beta; o->alpha = s.alpha; o->CmaxRet = s.Cmax; o->CinvRet = s.Cinv;
+  o->nGradSteps = s.nGradSteps; o->nStoredSteps = h->nTransitions; o->nStoredEps = (int64_t)h->order.size();
+  o->nFarPolicySteps = s.nFarTotal; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
+  o->adam_beta_t_1 = s.adam_bt1; o->adam_beta_t_2 = s.adam_bt2; o->adam_nStep = s.nStep;
+  return HL_OK;
+}
+int hl_get_stats(hl_learner* h, hl_stats* o) {
+  if (!h || !o) return HL_ERR_BAD_ARG;
+  int rc = flushPending(h); if (rc) return rc;
+  HIPCK(launch_stats(h->sc, h->rp, (int)h->order.size(), h->dStatsOut, h->stream));
+  double out[16];
+  HIPCK(hipMemcpyAsync(out, h->dStatsOut, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  o->avgKLdivergence = out[0]; o->avgSquaredErr = out[1]; o->maxAbsError = out[2]; o->avgReturn = out[3];
+  o->avgQ = out[4]; o->stdevQ = out[5]; o->minQ = out[6]; o->maxQ = out[7]; o->nFarPolicySteps = (int64_t)out[8];
+  h->lastAvgSqErr = out[1];
+  return HL_OK;
+}
+
+// ---- RCCL over xGMI (C1-C4 of SURVEY.md 2.4) -------------------------------------------------------
+int hl_comm_unique_id(uint8_t id[128]) {
+  if (!id) return HL_ERR_BAD_ARG;
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return HL_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) <= 128, "unique id does not fit");
+  std::memset(id, 0, 128); std::memcpy(id, &u, sizeof(u));
+  return HL_OK;
+}
+int hl_comm_init(hl_learner* h, const uint8_t id[128]) {
+  if (!h || !id) return HL_ERR_BAD_ARG;
+  ncclUniqueId u; std::memcpy(&u, id, sizeof(u));
+  HIPCK(hipSetDevice(h->dev));
+  NCCLCK(ncclCommInitRank(&h->comm, h->cfg.n_ranks, u, h->cfg.rank));
+  // identical initial weights on every replica: MPI_Bcast from rank 0 (Network/Builder.cpp:143-144)
+  NCCLCK(ncclBroadcast(h->W, h->W, (size_t)h->nParams, ncclFloat, 0, h->comm, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
+// ---- timing taps (HIP events on the library's stream) ---------------------------------------------
+int hl_timing_enable(hl_learner* h, int32_t e) {
+  if (!h) return HL_ERR_BAD_ARG;
+  timerFlush(h);
+  h->timing = e != 0;
+  if (h->timing) { std::fill(h->tsum.begin(), h->tsum.end(), 0.0); std::fill(h->tcnt.begin(), h->tcnt.end(), 0); }
+  return HL_OK;
+}
+int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* launches) {
+  if (!h || !kernel) return HL_ERR_BAD_ARG;
+  timerFlush(h);
+  for (size_t i = 0; i < h->tnames.size(); ++i) if (h->tnames[i] == kernel) {
+    if (avg_ms) *avg_ms = h->tcnt[i] ? h->tsum[i] / h->tcnt[i] : 0.0;
+    if (launches) *launches = h->tcnt[i];
+    return HL_OK;
+  }
+  if (avg_ms) *avg_ms = 0;
+  if (launches) *launches = 0;
+  return HL_OK;
+}
+
+}  // extern "C"
