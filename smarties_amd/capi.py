@@ -8,8 +8,10 @@ missing or no HIP device is usable, loading / ``hl_create`` fail loudly.
 suite can drive the CPU oracle (``oracle/liboracle_port.so``, prefix ``ol_``)
 through the very same call sequence; nothing in this package loads the oracle.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -168,6 +170,17 @@ def _ptr(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 
 
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # destroy device state while the HIP runtime is still alive (python atexit runs before the
+    # runtime's own static destructors)
+    for L in list(_LIVE):
+        L.close()
+
+
 class Learner:
     """Thin object wrapper over one hl_learner handle (names follow include/smarties_hip.h)."""
 
@@ -176,7 +189,12 @@ class Learner:
         self.h = C.c_void_p()
         rc = api.fn("create")(C.byref(cfg), C.byref(self.h))
         if rc:
-            raise HlError(rc, "hl_create failed")
+            msg = (api.fn("last_error")(self.h) or b"").decode() if self.h else ""
+            if self.h:
+                api.fn("destroy")(self.h)
+                self.h = C.c_void_p()
+            raise HlError(rc, "hl_create failed: " + msg)
+        _LIVE.add(self)
         self.nParams = api.fn("num_params")(self.h)
         self.nOut = api.fn("num_outputs")(self.h)
         self.dS, self.dA = cfg.dimS, cfg.dimA
@@ -351,6 +369,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "libsmarties_hip.so")
 
 
+_hip_api = None
+
+
 def load_hip():
-    """The product library.  Raises if it has not been built (no CPU fallback)."""
-    return CApi(HIP_LIB, "hl_")
+    """The product library.  Raises if it has not been built (no CPU fallback).
+
+    PyTorch-ROCm bundles its own copy of the HIP runtime / RCCL with the same SONAMEs as the system
+    ROCm.  Whichever copy is mapped first serves the whole process, and torch breaks when it finds
+    the system copy already resident, so torch (when installed) is imported BEFORE the library is
+    dlopen-ed; libsmarties_hip.so then binds to the runtime torch brought in.
+    """
+    global _hip_api
+    if _hip_api is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _hip_api = CApi(HIP_LIB, "hl_")
+    return _hip_api

@@ -17,7 +17,8 @@ struct DevScalars {
   double maxAbsErrEMA;            // ReplayStats::maxAbsError
   long long nStep;                // AdamOptimizer::nStep (completed prepare_update calls)
   long long nGradSteps;
-  long long nFarTotal;            // ReplayStats::nFarPolicySteps (this replica)
+  long long nFarTotal;            // running sum over the episodes currently stored (this replica)
+  long long nFarStat;             // ReplayStats::nFarPolicySteps: value of the last statistics pass
   long long nTransitions;         // ReplayCounters::nTransitions (this replica)
   long long nEpisodes;
   long long cnt[4];               // {seenEps, seenSteps, nFar, nStored}: local, then all-reduced (C2)
@@ -45,6 +46,7 @@ struct DevReplay {
   long long* epOff;        // first slot
   int* epN;                // number of states
   unsigned char* epTerm;   // bReachedTermState
+  long long* epTag;        // caller-supplied episode tag
   float* epAgg;            // [nEpCap][AGG_N] running aggregates (Episode.h:99-103)
   // current episode order (position -> eid) and transition prefix (Sampling.cpp:26-47)
   int* posEid;             // [nEp]
@@ -65,6 +67,7 @@ struct DevBatch {
   long long* slot;     // [B] replay slot of the sampled state
   int* nextOf;         // [B] row index (>= B) holding s_{t+1} if truncated, else -1
   int* nextSrc;        // [B] for next row j: sample b it belongs to
+  long long* tag;      // [B] tag of the sampled episode
   // head outputs / write-back staging (old values are needed by the aggregate updates)
   double* O;           // [2B][nOut]
   double* G;           // [B][nOut]

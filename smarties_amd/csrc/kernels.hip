@@ -36,6 +36,14 @@ __device__ __forceinline__ float actDiff(int f, float in, float out) {
     default: return 1.f;
   }
 }
+// Far-policy steps an episode contributes to ReplayStats::nFarPolicySteps.  The reference adds
+// the float Nsteps*fracFarPolSteps to an integer counter with a truncation after every add
+// (MemoryProcessing.cpp:227): a product a few ulps below an integer still lands on that integer
+// because the float add rounds, a genuinely fractional product (N/(N-1) after a recompute) is
+// truncated.  floor(x + 1e-3) reproduces both cases independently of the summation order.
+__device__ __forceinline__ long long farSteps(float Nsteps, float fracFar) {
+  return (long long)floorf(Nsteps * fracFar + 1e-3f);
+}
 __device__ __forceinline__ double waveSum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.rp.posPrefix[mid] <= f) lo = mid; else hi = mid; }
     const int e = a.rp.posEid[lo];
     const int t = (int)(f - a.rp.posPrefix[lo]);
-    a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = e; a.bt.t[b] = t;
+    a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = e; a.bt.t[b] = t; a.bt.tag[b] = a.rp.epTag[e];
     a.bt.slot[b] = a.rp.epOff[e] + t;
     // Episode::isTruncated(t+1) (Episode.h:158-161)
     flags[b] = (t + 2 == a.rp.epN[e] && !a.rp.epTerm[e]) ? 1 : 0;
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
       float* ag = a.rp.epAgg + (size_t)e * AGG_N;
       const float Nf = (float)a.rp.epN[e];
       const float invN = 1 / Nf;
-      const long long before = (long long)(Nf * ag[AGG_FRACFAR]);
+      const long long before = farSteps(Nf, ag[AGG_FRACFAR]);
       for (int j = b; j < B && a.bt.eid[j] == e; ++j) {
         if (a.bt.nextOf[j] >= 0) {                         // setValues(t+1, Vnext) comes first
           const float Vn = a.bt.nextV[j];
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         const float Vf = a.bt.newV[j];
         aggValues(ag, a.bt.oldV[j], a.bt.oldADV[j], Vf, Vf);
       }
-      const long long after = (long long)(Nf * ag[AGG_FRACFAR]);
+      const long long after = farSteps(Nf, ag[AGG_FRACFAR]);
       if (after != before) atomicAdd((unsigned long long*)&sFarDelta, (unsigned long long)(after - before));
       atomicMax(&sMaxAbs, __float_as_uint(fmaxf(ag[AGG_MAXABSERR], 0.f)));
     }
@@ -616,13 +624,13 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
       sc->Cmax = 1 + a.clipImpWeight / (1 + (double)k * a.epsAnneal);
       sc->Cinv = 1 / sc->Cmax;
       if (sc->Cmax <= 1) sc->nFarTotal = 0;
-      sc->cnt[2] = sc->nFarTotal; sc->cnt[3] = sc->nTransitions;
+      sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
     }
     __syncthreads();
   }
   if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {
     // updateCounters (:46-92); with several replicas cnt[] holds the all-reduced counters
-    const long long nFar = a.nRanks > 1 ? sc->cnt[2] : sc->nFarTotal;
+    const long long nFar = a.nRanks > 1 ? sc->cnt[2] : sc->nFarStat;
     const long long nStored = a.nRanks > 1 ? sc->cnt[3] : sc->nTransitions;
     const double fracOffPol = (double)nFar / (double)(nStored > 1 ? nStored : 1);
     const double nDataSize = fmax(a.maxObsGlobal, (double)nStored);
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
       ag[AGG_FRACFAR] = invN * (float)nFarPol; ag[AGG_AVGSQERR] = invN * sumE2; ag[AGG_MAXABSERR] = maxAE;
       ag[AGG_SUMQ2] = sumQ2; ag[AGG_SUMQ] = sumQ1; ag[AGG_MAXQ] = maxQ; ag[AGG_MINQ] = minQ;
       ag[AGG_TOTR] = (float)totR; ag[AGG_AVGKL] = invN * sumKL;
-      myFar = (long long)((float)N * ag[AGG_FRACFAR]);
+      myFar = farSteps((float)N, ag[AGG_FRACFAR]);
       myMax = fmaxf(maxAE, 0.f);
     }
     const float gamma = a.gamma, lambda = a.lambda;
@@ -723,7 +731,7 @@ __global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, co
   for (int i = 0; i < n; ++i) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); }
   sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
   sc->maxAbsErrAll = m;
-  sc->cnt[2] = sc->nFarTotal; sc->cnt[3] = sc->nTransitions;
+  sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
 }
 hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(64), 0, s, sc, redNFar, redMaxAbs, nBlocks);
@@ -814,11 +822,11 @@ hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s) {
 
 __global__ void set_counts_kernel(DevScalars* sc, long long nT, long long nE, long long seenEps, long long seenSteps) {
   sc->nTransitions = nT; sc->nEpisodes = nE; sc->cnt[0] = seenEps; sc->cnt[1] = seenSteps;
-  sc->cnt[2] = sc->nFarTotal; sc->cnt[3] = nT;
+  sc->cnt[3] = nT;   // cnt[2] keeps the far-policy count of the last statistics pass
 }
 // removal of an episode (MemoryBuffer::removeBackEpisode): its far-policy steps leave the total
 __global__ void evict_kernel(DevScalars* sc, DevReplay rp, int eid) {
-  const long long c = (long long)((float)rp.epN[eid] * rp.epAgg[(size_t)eid * AGG_N + AGG_FRACFAR]);
+  const long long c = farSteps((float)rp.epN[eid], rp.epAgg[(size_t)eid * AGG_N + AGG_FRACFAR]);
   sc->nFarTotal -= c; if (sc->nFarTotal < 0) sc->nFarTotal = 0;
 }
 hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s) {
@@ -868,7 +876,7 @@ __global__ __launch_bounds__(256) void stats_kernel(DevScalars* sc, DevReplay rp
     out[4] = avgQ;
     out[5] = sqrt(fmax(sd[2][0] / nData - avgQ * avgQ, 1e-16));   // stdevQ
     out[6] = (double)sf[1][0]; out[7] = (double)sf[0][0];          // minQ, maxQ
-    out[8] = (double)sc->nFarTotal;
+    out[8] = (double)sc->nFarStat;
   }
 }
 hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out, hipStream_t s) {

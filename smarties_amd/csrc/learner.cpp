@@ -257,6 +257,7 @@ int growEpisodes(hl_learner* h, int need) {
   const size_t o = (size_t)h->capEps, n = (size_t)newCap;
   HIPCK(devGrow(&h->rp.epOff, o, n, h->stream)); HIPCK(devGrow(&h->rp.epN, o, n, h->stream));
   HIPCK(devGrow(&h->rp.epTerm, o, n, h->stream)); HIPCK(devGrow(&h->rp.epAgg, o * AGG_N, n * AGG_N, h->stream));
+  HIPCK(devGrow(&h->rp.epTag, o, n, h->stream));
   HIPCK(devGrow(&h->rp.posEid, o, n, h->stream)); HIPCK(devGrow(&h->rp.posPrefix, o + 1, n + 1, h->stream));
   h->capEps = newCap; h->graphValid = false;
   return HL_OK;
@@ -410,8 +411,11 @@ int launchTrain(hl_learner* h, const long long* dFlat) {
   SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
   sa.X0 = h->X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
   HIPCK(timed(h, "sample_kernel", [&] { return launch_sample(sa, h->stream); }));
-  for (int j = 0; j < h->nHidden; ++j)
-    HIPCK(timed(h, "gemm16_fwd", [&] { return launch_gemm(h->dProbs + h->fwdIdx[j], 1, h->fwdBlocks[j], h->sc, h->stream); }));
+  char nm[32];
+  for (int j = 0; j < h->nHidden; ++j) {
+    snprintf(nm, sizeof(nm), "gemm16_fwd%d", j);
+    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->fwdIdx[j], 1, h->fwdBlocks[j], h->sc, h->stream); }));
+  }
   const DevHidden& q = h->hid[h->nHidden - 1];
   HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense;
   ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
@@ -419,8 +423,10 @@ int launchTrain(hl_learner* h, const long long* dFlat) {
   ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA;
   for (int i = 0; i < h->dA; ++i) ha.bounded[i] = h->cfg.bounded[i];
   HIPCK(timed(h, "head_kernel", [&] { return launch_head(ha, h->Mmax, h->stream); }));
-  for (size_t i = 0; i < h->dxIdx.size(); ++i)
-    HIPCK(timed(h, "gemm16_dx", [&] { return launch_gemm(h->dProbs + h->dxIdx[i], 1, h->dxBlocks[i], h->sc, h->stream); }));
+  for (size_t i = 0; i < h->dxIdx.size(); ++i) {
+    snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
+    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->dxIdx[i], 1, h->dxBlocks[i], h->sc, h->stream); }));
+  }
   HIPCK(timed(h, "gemm16_dw", [&] { return launch_gemm(h->dProbs + h->dwIdx, h->dwCount, h->dwBlocks, h->sc, h->stream); }));
   return HL_OK;
 }
@@ -593,6 +599,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   DevBatch& bt = h->bt;
   HIPCK(devAlloc(&bt.flat, B)); HIPCK(devAlloc(&bt.pos, B)); HIPCK(devAlloc(&bt.eid, B)); HIPCK(devAlloc(&bt.t, B));
   HIPCK(devAlloc(&bt.slot, B)); HIPCK(devAlloc(&bt.nextOf, B)); HIPCK(devAlloc(&bt.nextSrc, B));
+  HIPCK(devAlloc(&bt.tag, B));
   HIPCK(devAlloc(&bt.O, (size_t)2 * B * h->nOut)); HIPCK(devAlloc(&bt.G, (size_t)B * h->nOut));
   HIPCK(devAlloc(&bt.rho, B)); HIPCK(devAlloc(&bt.dkl, B)); HIPCK(devAlloc(&bt.dq, B)); HIPCK(devAlloc(&bt.far, B));
   HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B));
@@ -632,7 +639,7 @@ int hl_destroy(hl_learner* h) {
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
-    h->rp.stStd, h->bt.flat, h->bt.pos, h->bt.eid, h->bt.t, h->bt.slot, h->bt.nextOf, h->bt.nextSrc, h->bt.O, h->bt.G,
+    h->rp.stStd, h->rp.epTag, h->bt.tag, h->bt.flat, h->bt.pos, h->bt.eid, h->bt.t, h->bt.slot, h->bt.nextOf, h->bt.nextSrc, h->bt.O, h->bt.G,
     h->bt.rho, h->bt.dkl, h->bt.dq, h->bt.far, h->bt.newDQ, h->bt.newDKL, h->bt.newW, h->bt.newV, h->bt.oldDQ,
     h->bt.oldDKL, h->bt.oldW, h->bt.oldV, h->bt.oldADV, h->bt.nextV, h->bt.oldNextV, h->bt.oldNextADV, h->bt.gParam};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -665,7 +672,7 @@ int hl_init_weights(hl_learner* h) {
   auto uni = [&](float a, float b) {
     float r = (float)g.next() / 4294967296.0f;
     if (r >= 1.0f) r = std::nextafter(1.0f, 0.0f);
-    return r * (b - a) + a;
+    return std::fmaf(r, b - a, a);   // the reference build contracts this into an FMA (-march with FMA)
   };
   auto initFactor = [&](int f, int inps, int outs) -> double {
     switch (f) { case HL_FUNC_LINEAR: return std::sqrt(1. / inps); case HL_FUNC_TANH: return std::sqrt(6. / (inps + outs));
@@ -771,6 +778,8 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
   HIPCK(hipMemcpyAsync(h->rp.epOff + eid, &off64, sizeof(long long), hipMemcpyHostToDevice, s));
   HIPCK(hipMemcpyAsync(h->rp.epN + eid, &n32, sizeof(int), hipMemcpyHostToDevice, s));
   HIPCK(hipMemcpyAsync(h->rp.epTerm + eid, &term8, 1, hipMemcpyHostToDevice, s));
+  const long long tag64 = tag;
+  HIPCK(hipMemcpyAsync(h->rp.epTag + eid, &tag64, sizeof(long long), hipMemcpyHostToDevice, s));
   HIPCK(hipStreamSynchronize(s));     // caller-owned / stack buffers may go away after return
   // counters: storeAction increments for t = 1..N-2, ID taken before the final increment (:110,:167,:484)
   h->nSeenSteps += N - 2;
@@ -955,15 +964,13 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
   };
   switch (what) {
     case HL_TAP_FLAT: return copy(h->bt.flat, (int64_t)B * 8);
-    case HL_TAP_EPISODE: case HL_TAP_TSTEP: case HL_TAP_TAG: {
+    case HL_TAP_TAG: return copy(h->bt.tag, (int64_t)B * 8);
+    case HL_TAP_EPISODE: case HL_TAP_TSTEP: {
       if (bytes < (int64_t)B * 8) return HL_ERR_BAD_ARG;
-      std::vector<int> tmp(B), tpos(B);
+      std::vector<int> tmp(B);
       HIPCK(hipMemcpy(tmp.data(), what == HL_TAP_TSTEP ? h->bt.t : h->bt.pos, B * sizeof(int), hipMemcpyDeviceToHost));
       int64_t* o = (int64_t*)dst;
-      for (int b = 0; b < B; ++b) {
-        if (what == HL_TAP_TAG) o[b] = (tmp[b] >= 0 && tmp[b] < (int)h->order.size()) ? h->order[tmp[b]].tag : -1;
-        else o[b] = tmp[b];
-      }
+      for (int b = 0; b < B; ++b) o[b] = tmp[b];
       return HL_OK;
     }
     case HL_TAP_STATE: {
@@ -988,7 +995,7 @@ int hl_get_scalars(hl_learner* h, hl_scalars* o) {
   DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   o->beta = s.beta; o->alpha = s.alpha; o->CmaxRet = s.Cmax; o->CinvRet = s.Cinv;
   o->nGradSteps = s.nGradSteps; o->nStoredSteps = h->nTransitions; o->nStoredEps = (int64_t)h->order.size();
-  o->nFarPolicySteps = s.nFarTotal; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
+  o->nFarPolicySteps = s.nFarStat; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
   o->adam_beta_t_1 = s.adam_bt1; o->adam_beta_t_2 = s.adam_bt2; o->adam_nStep = s.nStep;
   return HL_OK;
 }
