@@ -183,7 +183,7 @@ def main():
         L.timing_enable(True)
         L.step(args.roofline_steps)
         L.sync()
-        names = ["sample_kernel"] + ["gemm16_fwd%d" % j for j in range(len(CFG["hidden"]))] + ["head_kernel"] + \
+        names = ["step_tail_kernel"] + ["gemm16_fwd%d" % j for j in range(len(CFG["hidden"]))] + ["head_kernel"] + \
                 ["gemm16_dx%d" % j for j in range(1, len(CFG["hidden"]))] + ["gemm16_dw", "adam_kernel", "post_kernel"]
         times = {n: L.timing_get(n) for n in names}
         L.timing_enable(False)

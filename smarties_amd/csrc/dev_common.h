@@ -1,0 +1,76 @@
+// smarties_amd/csrc/dev_common.h -- device helpers shared by the gfx950 kernels
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include "kernels.h"
+
+namespace hl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float actEval(int f, float in) {   // Network/Layers/Functions.h
+  switch (f) {
+    case HL_FUNC_TANH:
+      if (in > 0) { const float e = expf(-2 * in); return (1 - e) / (1 + e); }
+      else        { const float e = expf( 2 * in); return (e - 1) / (1 + e); }
+    case HL_FUNC_SOFTSIGN: return in / (1 + fabsf(in));
+    case HL_FUNC_RELU: return in > 0 ? in : 0.f;
+    default: return in;
+  }
+}
+__device__ __forceinline__ float actDiff(int f, float in, float out) {
+  switch (f) {
+    case HL_FUNC_TANH: return 1 - out * out;
+    case HL_FUNC_SOFTSIGN: { const float d = 1 + fabsf(in); return 1 / (d * d); }
+    case HL_FUNC_RELU: return in > 0 ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}
+// Far-policy steps an episode contributes to ReplayStats::nFarPolicySteps.  The reference adds
+// the float Nsteps*fracFarPolSteps to an integer counter with a truncation after every add
+// (MemoryProcessing.cpp:227): a product a few ulps below an integer still lands on that integer
+// because the float add rounds, a genuinely fractional product (N/(N-1) after a recompute) is
+// truncated.  floor(x + 1e-3) reproduces both cases independently of the summation order.
+__device__ __forceinline__ long long farSteps(float Nsteps, float fracFar) {
+  return (long long)floorf(Nsteps * fracFar + 1e-3f);
+}
+__device__ __forceinline__ double waveSum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float waveSumF(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double scaleNet2V(double x) {   // Learners/RACER_common.cpp:23-27
+  return x > 0 ? 100 * (x + 51) - 100 * sqrt(2601 + 100 * x) : 100 * (x - 51) + 100 * sqrt(2601 - 100 * x);
+}
+__device__ __forceinline__ double scaleVdiff(double x) {   // Learners/RACER_common.cpp:28-32
+  return x > 0 ? 100 - 5000 / sqrt(2601 + 100 * x) : 100 - 5000 / sqrt(2601 - 100 * x);
+}
+
+// Adam::step (Network/Optimizer.cpp:61-108) with SMARTIES_NESTEROV_ADAM, SMARTIES_SAFE_ADAM,
+// SMARTIES_ADAMW (Settings/Bund.h); eta already carries the bias correction (Optimizer.cpp:66)
+struct AdamCoef { float eta, lambda, fac; };
+__device__ __forceinline__ AdamCoef adamCoef(const DevScalars* sc, float eta0, float lambda, float fac, double epsAnneal) {
+  const long long nStep = sc->nStep + 1;    // prepare_update incremented it before apply_update
+  const float _eta = (float)((double)eta0 / (1 + (double)(float)nStep * epsAnneal));
+  const float bt1 = (float)sc->adam_bt1, bt2 = (float)sc->adam_bt2;
+  AdamCoef c; c.eta = _eta * sqrtf(1 - bt2) / (1 - bt1); c.lambda = lambda; c.fac = fac;
+  return c;
+}
+__device__ __forceinline__ void adamStep(const AdamCoef& c, float g, float& w, float& m1, float& m2) {
+  const float B1 = 0.9f, B2 = 0.999f;
+  const float penal = -w * c.lambda;
+  const float DW = c.fac * g;
+  m1 = B1 * m1 + (1 - B1) * DW;
+  m2 = B2 * m2 + (1 - B2) * DW * DW;
+  const float numer = B1 * m1 + (1 - B1) * DW;
+  m2 = m2 < m1 * m1 ? m1 * m1 : m2;
+  const float ret = numer / (FLT_EPSILON + sqrtf(m2));
+  w = w + c.eta * (ret + penal);
+}
+
+}  // namespace hl

@@ -1,0 +1,204 @@
+// smarties_amd/csrc/gemm16.hip -- the MLP contractions of the learner update on fp32 MFMA.
+//
+// gemm16_kernel: one 16x16 output tile per 256-thread workgroup, the reduction dimension split
+// over the 4 wavefronts (one per SIMD), each issuing v_mfma_f32_16x16x4_f32 on two independent
+// accumulators.  The minibatch problems are tiny (M = batch = 256, N,K <= 256), so the kernel
+// is built for LATENCY, not for tile reuse: 256 tiles -> one workgroup per CU, every operand
+// byte is fetched by ONE round of 16-byte global loads per thread (all issued before the first
+// use), staged in LDS in layouts whose fragment reads (ds_read_b32) are bank-conflict free
+// (ROWS tile: leading dimension 258 == 2 mod 32; COLS tile: leading dimension 16), and the four
+// partial tiles are reduced through LDS before a fused epilogue:
+//   EPI_FWD  bias + activation (+ parametric residual)      BaseLayer::forward (Layer_Base.h:64-95),
+//                                                            ParametricResidualLayer::forward (Layers.h:347-361)
+//   EPI_DX   residual back-prop + activation derivative      Layer::backward dX (Layers.h:133-147),
+//                                                            ParametricResidualLayer::backward (:363-393)
+//   EPI_DW   weight/bias gradient (+ fused Adam update)      Layer::backward dW (Layers.h:164-187),
+//                                                            Adam::step (Optimizer.cpp:61-108)
+// One launch can carry several problems (table in device memory); all dW / bias / residual
+// parameter gradients of a step are ONE launch.
+#include "dev_common.h"
+
+namespace hl {
+
+#define KC 256
+#define LDR 258
+
+__device__ __forceinline__ void adamApply(const AdamCoef& c, float g, float* W, float* M1, float* M2, size_t i) {
+  float w = W[i], m1 = M1[i], m2 = M2[i];
+  adamStep(c, g, w, m1, m2);
+  W[i] = w; M1[i] = m1; M2[i] = m2;
+}
+
+__device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, float* red, const DevScalars* sc,
+                                            const AdamHyper& hyp) {
+  // out[j] = sum_m A[m][j] * (B ? B[m][j] : 1): 16 columns per workgroup, 16 row-partitions,
+  // 8 independent loads in flight per thread
+  const int tid = threadIdx.x, jj = tid & 15, part = tid >> 4;
+  const int j = tile * 16 + jj;
+  float acc = 0.f;
+  if (j < P.N) {
+    for (int m0 = part; m0 < P.K; m0 += 128) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + 16 * u;
+        av[u] = m < P.K ? P.A[(size_t)m * P.lda + j] : 0.f;
+        bv[u] = (P.B && m < P.K) ? P.B[(size_t)m * P.ldb + j] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += av[u] * bv[u];
+    }
+  }
+  red[part * 16 + jj] = acc;
+  __syncthreads();
+  if (part == 0 && j < P.N) {
+    float g = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g += red[q * 16 + jj];
+    P.C[j] = g;
+    if (P.adam) { const AdamCoef c = adamCoef(sc, hyp.eta0, hyp.lambda, hyp.fac, hyp.epsAnneal); adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
+                                                     const DevScalars* __restrict__ sc, AdamHyper hyp) {
+  __shared__ __attribute__((aligned(16))) float sA[16 * LDR];
+  __shared__ __attribute__((aligned(16))) float sB[16 * LDR];
+  __shared__ float red[4 * 256];
+  const int bid = blockIdx.x;
+  int p = 0;
+  for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
+  const GemmProblem P = probs[p];
+  const int tile = bid - P.tileStart;
+  if (P.flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
+
+  const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int Mvalid = P.dynRows ? sc->nRows : P.M;
+  if (m0 >= Mvalid) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lc = lane >> 4;
+  const bool aRows = (P.flavor != GEMM_W);   // A tile is 16 rows x k  (else k x 16)
+  const bool bRows = (P.flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < P.K; kb += KC) {
+    const int kc = min(KC, P.K - kb);
+    // k handled by each wave: power of two in {8,16,32,64}; staged chunk kcp = 4*kw in {32..256}
+    int kw = 8, sh = 3;                       // sh = log2(kcp / 4) = log2(kw)
+    while (4 * kw < kc) { kw <<= 1; ++sh; }
+    const int nf4 = kw;                       // float4 per 16-row-tile row (= kcp/4)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 va[4], vb[4];
+    // ---- issue every global load of this chunk (<= 8 x 16 B per thread) before any use ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      va[q] = z4; vb[q] = z4;
+      if (aRows) {
+        const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
+        if (idx < 16 * nf4 && m0 + r < Mvalid && c < kc && kb + c < P.lda)
+          va[q] = *reinterpret_cast<const float4*>(P.A + (size_t)(m0 + r) * P.lda + kb + c);
+      } else {   // GEMM_W: rows = reduction (batch), columns m0.. = input features, + the ones column
+        const int k = idx >> 2, c = m0 + (idx & 3) * 4;
+        if (idx < 16 * nf4 && k < kc) {
+          float4 v = z4;
+          if (c < P.lda) v = *reinterpret_cast<const float4*>(P.A + (size_t)(kb + k) * P.lda + c);
+          const int one = P.M - 1 - c;       // position of the ones column inside this float4
+          if (one == 0) v.x = 1.f; else if (one == 1) v.y = 1.f; else if (one == 2) v.z = 1.f; else if (one == 3) v.w = 1.f;
+          if (one < 0) v = z4;
+          else { if (one < 1) v.y = 0.f; if (one < 2) v.z = 0.f; if (one < 3) v.w = 0.f; }
+          va[q] = v;
+        }
+      }
+      if (bRows) {   // GEMM_X: weight rows n0.., reduction along the row
+        const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
+        if (idx < 16 * nf4 && n0 + r < P.N && c < kc && kb + c < P.ldb)
+          vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(n0 + r) * P.ldb + kb + c);
+      } else {
+        const int k = idx >> 2, c = n0 + (idx & 3) * 4;
+        if (idx < 16 * nf4 && k < kc && c < P.ldb && c < ((P.N + 3) & ~3))
+          vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(kb + k) * P.ldb + c);
+      }
+    }
+    // ---- stage into LDS ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < 16 * nf4) {
+        if (aRows) {
+          const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
+          float2* d = reinterpret_cast<float2*>(sA + r * LDR + c);
+          d[0] = make_float2(va[q].x, va[q].y); d[1] = make_float2(va[q].z, va[q].w);
+        } else {
+          *reinterpret_cast<float4*>(sA + idx * 4) = va[q];       // [k][16]
+        }
+        if (bRows) {
+          const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
+          float2* d = reinterpret_cast<float2*>(sB + r * LDR + c);
+          d[0] = make_float2(vb[q].x, vb[q].y); d[1] = make_float2(vb[q].z, vb[q].w);
+        } else {
+          *reinterpret_cast<float4*>(sB + idx * 4) = vb[q];
+        }
+      }
+    }
+    __syncthreads();
+    const int k0 = wave * kw;
+    for (int s = 0; s < kw; s += 8) {
+      const int ka = k0 + s + lc, kb2 = ka + 4;
+      const float a0 = aRows ? sA[li * LDR + ka] : sA[ka * 16 + li];
+      const float b0 = bRows ? sB[li * LDR + ka] : sB[ka * 16 + li];
+      const float a1 = aRows ? sA[li * LDR + kb2] : sA[kb2 * 16 + li];
+      const float b1 = bRows ? sB[li * LDR + kb2] : sB[kb2 * 16 + li];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- cross-wave reduction of the 4 partial tiles ----
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+  __syncthreads();
+  const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+  if (m >= Mvalid || n >= P.N) return;
+
+  if (P.epi == EPI_FWD) {
+    const float x = v + P.bias[n];
+    P.C[(size_t)m * P.ldc + n] = x;
+    const float y = actEval(P.func, x);
+    P.C2[(size_t)m * P.ldc + n] = y;
+    if (P.C3) {
+      float r = y;
+      if (n < P.resN) r += P.resIn[(size_t)m * P.ldRes + n] * P.resW[n] + P.resB[n];
+      P.C3[(size_t)m * P.ldc + n] = r;
+    }
+  } else if (P.epi == EPI_DX) {
+    float dres = v;
+    if (n < P.resN) dres += P.resIn[(size_t)m * P.ldRes + n] * P.resW[n];
+    P.C[(size_t)m * P.ldc + n] = dres;
+    P.C2[(size_t)m * P.ldc + n] =
+        dres * actDiff(P.func, P.actX[(size_t)m * P.ldAct + n], P.actY[(size_t)m * P.ldAct + n]);
+  } else if (P.epi == EPI_DW) {
+    if (m < P.M - 1) {
+      const size_t i = (size_t)m * P.ldc + n;
+      P.C[i] = v;
+      if (P.adam) { const AdamCoef c = adamCoef(sc, hyp.eta0, hyp.lambda, hyp.fac, hyp.epsAnneal); adamApply(c, v, P.adW, P.adM1, P.adM2, i); }
+    } else {
+      P.biasOut[n] = v;
+      if (P.adam) { const AdamCoef c = adamCoef(sc, hyp.eta0, hyp.lambda, hyp.fac, hyp.epsAnneal); adamApply(c, v, P.adbW, P.adbM1, P.adbM2, n); }
+    }
+  } else {
+    P.C[(size_t)m * P.ldc + n] = v;
+  }
+}
+
+hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
+                       const AdamHyper& hyp, hipStream_t s) {
+  if (nBlocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gemm16_kernel, dim3(nBlocks), dim3(256), 0, s, dProbs, nProbs, sc, hyp);
+  return hipGetLastError();
+}
+
+}  // namespace hl

@@ -1,0 +1,248 @@
+// smarties_amd/csrc/head.hip -- output layer + V-RACER / ReF-ER head, one wavefront per sample.
+//
+//   output InnerProduct layer (Linear, Layer_Base.h:64-95) + ParamLayer (Layers.h:510-520),
+//   RACER::Train for VRACER (Learners/RACER_train.cpp:14-67) in fp64 with Continuous_policy
+//   (Math/Continuous_policy.h:68-378, 569-738), write-backs MiniBatch::setMseDklImpw / setValues
+//   (MiniBatch.h:161-175) and the backward of the output layer into the last hidden block
+//   (Layers.h:123-160).
+//
+// The kernel is latency bound (a few KB per sample, ~1 kFLOP of fp64 transcendental math), so
+// it is written to expose ONE round of global-memory latency: every load a sample needs -- its
+// hidden activations, the whole output-layer weight matrix slice of the lane, action, behaviour
+// policy, Retrace target and the per-step values that are about to be overwritten -- is issued
+// up front; the weight slice stays in registers and is reused for the back-propagation.
+#include "dev_common.h"
+
+namespace hl {
+
+#define HEAD_MAXOUT 136
+
+// HQ = ceil(H / 64): hidden activations per lane.  nDense <= 8 (dimA <= 7) takes the register
+// path for the output layer; wider action spaces use the generic path below.
+template <int HQ>
+__global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a) {
+  __shared__ double sO[4][HEAD_MAXOUT];
+  __shared__ float sDelta[4][72];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const DevScalars* sc = a.sc;
+  if (row >= sc->nRows) return;
+  const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H;
+  const bool isNext = row >= B;
+  const int b = isNext ? a.bt.nextSrc[row - B] : row;
+  const long long slot = a.bt.slot[b];
+  const float* Wo = a.params + a.indWo;
+  const bool small = nDense <= 8;
+
+  // ---- every load, up front -------------------------------------------------------------------
+  float yv[HQ], xl[HQ], yl[HQ];
+  float4 w0[HQ], w1[HQ];
+#pragma unroll
+  for (int q = 0; q < HQ; ++q) {
+    const int k = lane + 64 * q;
+    const bool ok = k < H;
+    yv[q] = ok ? a.Yin[(size_t)row * a.ldY + k] : 0.f;
+    xl[q] = (ok && !isNext) ? a.Xlast[(size_t)row * a.ldD + k] : 0.f;
+    yl[q] = (ok && !isNext) ? a.Ylast[(size_t)row * a.ldD + k] : 0.f;
+    w0[q] = make_float4(0.f, 0.f, 0.f, 0.f); w1[q] = w0[q];
+    if (ok && small) {
+      w0[q] = *reinterpret_cast<const float4*>(Wo + (size_t)k * a.ldWo);
+      w1[q] = *reinterpret_cast<const float4*>(Wo + (size_t)k * a.ldWo + 4);
+    }
+  }
+  // hand the (episode, next-row) map of THIS minibatch to the bookkeeping pass, which runs while
+  // the sampler already overwrites bt.eid / bt.nextOf for the next step
+  if (!isNext && lane == 0) { a.bt.pEid[b] = a.bt.eid[b]; a.bt.pNextOf[b] = a.bt.nextOf[b]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sc->postPending = 1;
+  const float bo = lane < nDense ? a.params[a.indBo + lane] : 0.f;
+  const float bp = lane < dA ? a.params[a.indBp + lane] : 0.f;
+  double act = 0, bMean = 0, bStd = 1;
+  if (!isNext && lane < dA) {
+    act = a.rp.A[(size_t)slot * dA + lane];
+    bMean = a.rp.MU[(size_t)slot * 2 * dA + lane]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + lane];
+  }
+  // lanes 0..5 fetch RET, DQ, DKL, IMPW, V, ADV of the sampled step; lanes 6,7 V, ADV of t+1 (next rows)
+  float misc = 0.f;
+  {
+    const float* arr = nullptr; long long sl = slot;
+    if (!isNext) { arr = lane == 0 ? a.rp.RET : lane == 1 ? a.rp.DQ : lane == 2 ? a.rp.DKL : lane == 3 ? a.rp.IMPW :
+                         lane == 4 ? a.rp.V : lane == 5 ? a.rp.ADV : nullptr; }
+    else { arr = lane == 6 ? a.rp.V : lane == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
+    if (arr) misc = arr[sl];
+  }
+
+  // ---- output dense layer: O[o] = b[o] + sum_k y[k] W[k][o] -----------------------------------
+  if (small) {
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+      p[0] += yv[q] * w0[q].x; p[1] += yv[q] * w0[q].y; p[2] += yv[q] * w0[q].z; p[3] += yv[q] * w0[q].w;
+      p[4] += yv[q] * w1[q].x; p[5] += yv[q] * w1[q].y; p[6] += yv[q] * w1[q].z; p[7] += yv[q] * w1[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = waveSumF(p[q]);
+    float mine = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q == lane) mine = p[q];
+    if (lane < nDense) sO[wave][lane] = (double)(mine + bo);
+  } else {
+    const int nChunkOut = isNext ? 1 : nDense;
+    for (int o0 = 0; o0 < nChunkOut; o0 += 8) {
+      float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = lane; k < H; k += 64) {
+        const float yk = a.Yin[(size_t)row * a.ldY + k];
+        const float* w = Wo + (size_t)k * a.ldWo + o0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (o0 + q < nDense) p[q] += yk * w[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) p[q] = waveSumF(p[q]);
+      if (lane < 8 && o0 + lane < nDense) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q == lane) v = p[q];
+        sO[wave][o0 + lane] = (double)(v + a.params[a.indBo + o0 + lane]);
+      }
+    }
+  }
+  if (lane < dA) sO[wave][nDense + lane] = (double)bp;   // ParamLayer, Linear
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+
+  if (isNext) {   // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
+    const float oV = __shfl(misc, 6, 64), oA = __shfl(misc, 7, 64);
+    if (lane == 0) {
+      const float Vn = (float)scaleNet2V(sO[wave][0]);
+      a.bt.oldNextV[b] = oV; a.bt.oldNextADV[b] = oA;
+      a.rp.V[slot + 1] = Vn; a.rp.ADV[slot + 1] = 0.f; a.bt.nextV[b] = Vn;
+      a.bt.O[(size_t)row * a.nOut] = sO[wave][0];
+    }
+    return;
+  }
+
+  // ---- policy terms, one action component per lane (fp64) ---------------------------------------
+  const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
+  const double MAXM = 8.31776613503286, LOG2PI_2 = 9.1893853320467266954096885456237942e-01;
+  double lw = 0, kl = 0, mean = 0, stdev = 1, invStd = 1, dPos = 0;
+  bool bnd = false;
+  if (lane < dA) {
+    const int i = lane;
+    bnd = a.bounded[i] != 0;
+    mean = sO[wave][1 + i];
+    const double pp = sO[wave][nDense + i];
+    const double rt = sqrt(1 + pp * pp);
+    stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
+    const double bInv = 1 / bStd;
+    double lpPi, lpMu;
+    if (bnd) {
+      const double m = mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean);
+      const double sq = tanh(act), J = fmax(1 - sq * sq, (double)FLT_MIN);
+      const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
+      lpPi = -(u1 * u1) / 2 + log(invStd / J) - LOG2PI_2;
+      lpMu = -(u2 * u2) / 2 + log(bInv / J) - LOG2PI_2;
+    } else {
+      const double u1 = (act - mean) * invStd, u2 = (act - bMean) * bInv;
+      lpPi = -(u1 * u1) / 2 + log(invStd) - LOG2PI_2;
+      lpMu = -(u2 * u2) / 2 + log(bInv) - LOG2PI_2;
+    }
+    lw = lpPi - lpMu;
+    const double qq = stdev / bStd, CmuCpi = qq * qq, dm = (mean - bMean) / bStd;
+    kl = (CmuCpi - 1 + dm * dm - log(CmuCpi)) / 2;
+  }
+  const double logW = waveSum(lw), DKL = waveSum(kl);
+  const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
+  const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
+  const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
+  const double O0 = sO[wave][0];
+  const double V = scaleNet2V(O0);
+  const double Qret = (double)__shfl(misc, 0, 64);
+  const double A_RET = Qret - V, dQ = A_RET;                       // Zero_advantage
+  const double Ver = fmin(1.0, RHO) * dQ;
+  const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
+  const double coef = A_RET * fmin(Cmax, RHO);
+  if (lane < dA) {
+    const double dMean = mean - bMean, invVarMu = 1 / (bStd * bStd);
+    const double penalM = -1 * (dMean * invVarMu);
+    const double penalS = dPos * -1 * ((invVarMu - invStd * invStd) * stdev);
+    double polM = 0, polS = 0;
+    if (!far) {
+      if (bnd) {
+        const double dLogPdMean = (act - mean) * invStd * invStd;
+        const double m = mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean);
+        const double u = (act - m) * invStd;
+        polS = dPos * coef * ((u * u - 1) * invStd);
+        if (mean >= MAXM && coef * dLogPdMean > 0) polM = 0;
+        else if (mean <= -MAXM && coef * dLogPdMean < 0) polM = 0;
+        else polM = coef * dLogPdMean;
+      } else {
+        const double u = (act - mean) * invStd;
+        polM = coef * (u * invStd);
+        polS = dPos * coef * ((u * u - 1) * invStd);
+      }
+    }
+    const double gM = beta * polM + (1 - beta) * penalM;
+    const double gS = beta * polS + (1 - beta) * penalS;
+    // Activation::addOutputDelta: nnReal += Real (Activation.h:108-117)
+    sDelta[wave][1 + lane] = (float)gM;
+    a.bt.gParam[(size_t)b * dA + lane] = (float)gS;
+    a.bt.G[(size_t)b * a.nOut + 1 + lane] = (double)(float)gM;
+    a.bt.G[(size_t)b * a.nOut + nDense + lane] = (double)(float)gS;
+  }
+  {
+    const float oDQ = __shfl(misc, 1, 64), oDKL = __shfl(misc, 2, 64), oW = __shfl(misc, 3, 64);
+    const float oV = __shfl(misc, 4, 64), oADV = __shfl(misc, 5, 64);
+    if (lane == 0) {
+      sDelta[wave][0] = (float)g0;
+      a.bt.G[(size_t)b * a.nOut] = (double)(float)g0;
+      a.bt.rho[b] = RHO; a.bt.dkl[b] = DKL; a.bt.far[b] = far ? 1 : 0;
+      // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
+      const float E = (float)dQ, D = (float)DKL, Wn = (float)RHO, Vf = (float)V;
+      a.bt.oldDQ[b] = oDQ; a.bt.oldDKL[b] = oDKL; a.bt.oldW[b] = oW; a.bt.oldV[b] = oV; a.bt.oldADV[b] = oADV;
+      a.bt.newDQ[b] = E; a.bt.newDKL[b] = D; a.bt.newW[b] = Wn; a.bt.newV[b] = Vf;
+      a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = 0.f;
+      a.bt.dq[b] = (double)E;
+    }
+  }
+  for (int o = lane; o < a.nOut; o += 64) a.bt.O[(size_t)row * a.nOut + o] = sO[wave][o];
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  // ---- deltas of the output layer and back-propagation into the last hidden block ----------------
+  for (int o = lane; o < nDense; o += 64) a.dOut[(size_t)b * a.ldDo + o] = sDelta[wave][o];
+  if (small) {
+    float d[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) d[o] = o < nDense ? sDelta[wave][o] : 0.f;
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+      const int k = lane + 64 * q;
+      if (k < H) {
+        const float s = ((w0[q].x * d[0] + w0[q].y * d[1]) + (w0[q].z * d[2] + w0[q].w * d[3])) +
+                        ((w1[q].x * d[4] + w1[q].y * d[5]) + (w1[q].z * d[6] + w1[q].w * d[7]));
+        a.Dres[(size_t)b * a.ldD + k] = s;
+        a.D[(size_t)b * a.ldD + k] = s * actDiff(a.func, xl[q], yl[q]);
+      }
+    }
+  } else {
+    for (int k = lane; k < H; k += 64) {
+      const float* w = Wo + (size_t)k * a.ldWo;
+      float s = 0.f;
+      for (int o = 0; o < nDense; ++o) s += w[o] * sDelta[wave][o];
+      a.Dres[(size_t)b * a.ldD + k] = s;
+      a.D[(size_t)b * a.ldD + k] =
+          s * actDiff(a.func, a.Xlast[(size_t)row * a.ldD + k], a.Ylast[(size_t)row * a.ldD + k]);
+    }
+  }
+}
+
+hipError_t launch_head(const HeadArgs& a, int maxRows, hipStream_t s) {
+  const dim3 grid((maxRows + 3) / 4), block(256);
+  const int HQ = (a.H + 63) / 64;
+  if (HQ <= 1) hipLaunchKernelGGL(head_kernel_t<1>, grid, block, 0, s, a);
+  else if (HQ <= 2) hipLaunchKernelGGL(head_kernel_t<2>, grid, block, 0, s, a);
+  else if (HQ <= 4) hipLaunchKernelGGL(head_kernel_t<4>, grid, block, 0, s, a);
+  else if (HQ <= 8) hipLaunchKernelGGL(head_kernel_t<8>, grid, block, 0, s, a);
+  else return hipErrorInvalidValue;   // hidden width > 512: not supported by this kernel
+  return hipGetLastError();
+}
+
+}  // namespace hl

@@ -27,6 +27,7 @@ struct DevScalars {
   int nNext;                      // rows B..B+nNext-1 of the minibatch hold truncated next states
   int nRows;                      // B + nNext
   int errFlag;                    // sticky device-side error code (0 = ok)
+  int postPending;                // a trained step still needs its bookkeeping pass (post part)
   unsigned rngPos;
   unsigned rng[624];
 };
@@ -35,6 +36,16 @@ struct DevScalars {
 // Replay buffer in HBM: structure-of-arrays over "slots" (one slot per stored state,
 // Episode.h:66-82), episodes occupy contiguous slot ranges.
 // ---------------------------------------------------------------------------
+// everything the sampler needs about the episode at one position of the current order: the
+// flat-index prefix (Sampling.cpp:26-47), slot offset, length, terminal flag, storage id and tag
+struct PosRec {
+  long long prefix;        // transitions stored before this episode
+  long long off;           // first slot
+  long long tag;
+  int N;                   // number of states
+  int eidTerm;             // eid | (terminated << 31)
+};
+
 struct DevReplay {
   float* S;        // [cap][dS]      states (raw; standardized on gather, Episode.h:172-183)
   double* A;       // [cap][dA]      actions (f64 as in the reference, Episode.h:73)
@@ -51,6 +62,7 @@ struct DevReplay {
   // current episode order (position -> eid) and transition prefix (Sampling.cpp:26-47)
   int* posEid;             // [nEp]
   long long* posPrefix;    // [nEp+1]
+  struct PosRec* posRec;   // [nEp+1] the same table as one 32-byte record per position (sampler)
   float* stMean; float* stScale; float* stStd;   // [dS]
 };
 enum { AGG_TOTR = 0, AGG_AVGKL, AGG_FRACFAR, AGG_AVGSQERR, AGG_MAXABSERR, AGG_SUMQ2, AGG_SUMQ,
@@ -68,6 +80,8 @@ struct DevBatch {
   int* nextOf;         // [B] row index (>= B) holding s_{t+1} if truncated, else -1
   int* nextSrc;        // [B] for next row j: sample b it belongs to
   long long* tag;      // [B] tag of the sampled episode
+  int *pEid, *pNextOf; // [B] copies made by the head kernel for the bookkeeping pass (which runs
+                       //     concurrently with the sampling of the NEXT minibatch)
   // head outputs / write-back staging (old values are needed by the aggregate updates)
   double* O;           // [2B][nOut]
   double* G;           // [B][nOut]
@@ -113,7 +127,13 @@ struct GemmProblem {
   const float* resW; const float* resB; const float* resIn; int ldRes; int resN;  // residual
   const float* actX; const float* actY; int ldAct; int func;                        // EPI_DX
   float* biasOut;        // EPI_DW: row M-1 of the product (the ones row) goes here
+  // fused Adam (single replica): parameter / moment arrays laid out like C and like biasOut
+  int adam;
+  float *adW, *adM1, *adM2;
+  float *adbW, *adbM1, *adbM2;
   int tileStart, tilesM, tilesN;
 };
+
+struct AdamHyper { float eta0, lambda, fac; double epsAnneal; };
 
 }  // namespace hl

@@ -53,7 +53,11 @@ struct MomentsArgs {
 };
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
-hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc, hipStream_t s);
+// fused: bookkeeping of the previous step (if post != nullptr; postIfPending: only when the device
+// flag DevScalars::postPending is set) followed by the sampling of the next minibatch (if samp)
+hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, int postIfPending, hipStream_t s);
+hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
+                       const AdamHyper& hyp, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, int maxRows, hipStream_t s);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);

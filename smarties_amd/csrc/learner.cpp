@@ -51,7 +51,7 @@ struct hl_learner {
   long long indWo = 0, indBo = 0, indBp = 0; int ldWo = 0;
   // gemm problem tables (device) + launch geometry
   GemmProblem* dProbs = nullptr;           // all problems, contiguous
-  std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwCount = 0, dwBlocks = 0;
+  std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
   // replay bookkeeping (host)
   long long capSlots = 0; int capEps = 0;
   long long ringHead = 0;                  // next free slot
@@ -61,6 +61,7 @@ struct hl_learner {
   long long nTransitions = 0, nSeenSteps = 0, nSeenEps = 0, nGradSteps = 0;
   long long nGatheredB4Startup = INT64_MAX;
   bool tableDirty = true, countsDirty = true, initialized = false, inStep = false;
+  bool postPendingHost = false;            // a graph-replayed step still needs its post pass
   double lastAvgSqErr = 0;
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
@@ -70,6 +71,7 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // graph
   hipGraph_t graph = nullptr; hipGraphExec_t graphExec = nullptr; bool graphValid = false; bool useGraph = true;
+  hipGraph_t graphN = nullptr; hipGraphExec_t graphExecN = nullptr;   // GRAPH_UNROLL steps per replay
   // rccl
   ncclComm_t comm = nullptr;
   // moments exchange state
@@ -258,6 +260,7 @@ int growEpisodes(hl_learner* h, int need) {
   HIPCK(devGrow(&h->rp.epOff, o, n, h->stream)); HIPCK(devGrow(&h->rp.epN, o, n, h->stream));
   HIPCK(devGrow(&h->rp.epTerm, o, n, h->stream)); HIPCK(devGrow(&h->rp.epAgg, o * AGG_N, n * AGG_N, h->stream));
   HIPCK(devGrow(&h->rp.epTag, o, n, h->stream));
+  HIPCK(devGrow(&h->rp.posRec, o + 1, n + 1, h->stream));
   HIPCK(devGrow(&h->rp.posEid, o, n, h->stream)); HIPCK(devGrow(&h->rp.posPrefix, o + 1, n + 1, h->stream));
   h->capEps = newCap; h->graphValid = false;
   return HL_OK;
@@ -286,14 +289,23 @@ int allocSlots(hl_learner* h, int N, long long* off) {
 int uploadTable(hl_learner* h) {
   const size_t nEp = h->order.size();
   int rc = growEpisodes(h, (int)nEp + 1); if (rc) return rc;
-  const size_t bytes = nEp * sizeof(int) + (nEp + 1) * sizeof(long long) + 64;
+  const size_t bytes = (nEp + 1) * sizeof(PosRec) + (nEp + 1) * sizeof(long long) + nEp * sizeof(int) + 64;
   rc = ensurePinned(h, bytes); if (rc) return rc;
   HIPCK(hipStreamSynchronize(h->stream));   // the pinned buffer may still feed an earlier copy
-  long long* pre = (long long*)h->pinned;
+  PosRec* rec = (PosRec*)h->pinned;
+  long long* pre = (long long*)(rec + nEp + 1);
   int* pe = (int*)(pre + nEp + 1);
   long long acc = 0;
-  for (size_t p = 0; p < nEp; ++p) { pre[p] = acc; pe[p] = h->order[p].eid; acc += h->order[p].N - 1; }
+  for (size_t p = 0; p < nEp; ++p) {
+    const EpMeta& e = h->order[p];
+    pre[p] = acc; pe[p] = e.eid;
+    rec[p].prefix = acc; rec[p].off = e.off; rec[p].tag = e.tag; rec[p].N = e.N;
+    rec[p].eidTerm = e.eid | (e.term ? (int)0x80000000 : 0);
+    acc += e.N - 1;
+  }
   pre[nEp] = acc;
+  rec[nEp].prefix = acc; rec[nEp].off = 0; rec[nEp].tag = -1; rec[nEp].N = 0; rec[nEp].eidTerm = 0;
+  HIPCK(hipMemcpyAsync(h->rp.posRec, rec, (nEp + 1) * sizeof(PosRec), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->rp.posPrefix, pre, (nEp + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->rp.posEid, pe, nEp * sizeof(int), hipMemcpyHostToDevice, h->stream));
   h->tableDirty = false;
@@ -337,7 +349,7 @@ int flushPending(hl_learner* h) {
 // ---- gemm problem tables ---------------------------------------------------------------------
 void setTiles(GemmProblem& p, int& cursor) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
-  if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 63) / 64; }
+  if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
   p.tileStart = cursor; cursor += p.tilesM * p.tilesN;
 }
 
@@ -398,6 +410,17 @@ int buildProblems(hl_learner* h) {
     setTiles(s, cur); P.push_back(s);
   }
   h->dwCount = (int)P.size() - h->dwIdx; h->dwBlocks = cur;
+  // second copy of the dW table with the Adam update fused into the epilogue (single replica:
+  // every gradient element is final inside the workgroup that produced it)
+  h->dwAdamIdx = (int)P.size();
+  for (int i = 0; i < h->dwCount; ++i) {
+    GemmProblem p = P[h->dwIdx + i];
+    p.adam = 1;
+    const long long offC = p.C - h->G;
+    p.adW = h->W + offC; p.adM1 = h->M1 + offC; p.adM2 = h->M2 + offC;
+    if (p.biasOut) { const long long offB = p.biasOut - h->G; p.adbW = h->W + offB; p.adbM1 = h->M1 + offB; p.adbM2 = h->M2 + offB; }
+    P.push_back(p);
+  }
   if (h->dProbs) hipFree(h->dProbs);
   HIPCK(devAlloc(&h->dProbs, P.size()));
   HIPCK(hipMemcpy(h->dProbs, P.data(), P.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
@@ -407,14 +430,28 @@ int buildProblems(hl_learner* h) {
 // ---- the launch sequence of one gradient step ------------------------------------------------
 struct StepOpts { const long long* dFlat; bool split; };   // split: stop before post(BETA) for exchanges
 
-int launchTrain(hl_learner* h, const long long* dFlat) {
+AdamHyper adamHyper(const hl_learner* h) {
+  AdamHyper a; a.eta0 = (float)h->cfg.learnrate; a.lambda = (float)h->cfg.nnLambda; a.fac = (float)(1.0 / h->Bglobal);
+  a.epsAnneal = h->cfg.epsAnneal; return a;
+}
+// fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
+PostArgs postArgs(hl_learner* h, int mode);
+// postIfPending: the sampling kernel first runs the bookkeeping of the previous step when the
+// device flag DevScalars::postPending is set (step-tail fusion used by the replayed graph)
+int launchTrain(hl_learner* h, const long long* dFlat, bool fuseAdam, bool postIfPending = false) {
+  const AdamHyper hyp = adamHyper(h);
   SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
   sa.X0 = h->X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
-  HIPCK(timed(h, "sample_kernel", [&] { return launch_sample(sa, h->stream); }));
+  if (postIfPending) {
+    const PostArgs pa = postArgs(h, POST_AGG | POST_BETA);
+    HIPCK(timed(h, "step_tail_kernel", [&] { return launch_step_tail(&pa, &sa, 1, h->stream); }));
+  } else {
+    HIPCK(timed(h, "step_tail_kernel", [&] { return launch_sample(sa, h->stream); }));
+  }
   char nm[32];
   for (int j = 0; j < h->nHidden; ++j) {
     snprintf(nm, sizeof(nm), "gemm16_fwd%d", j);
-    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->fwdIdx[j], 1, h->fwdBlocks[j], h->sc, h->stream); }));
+    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->fwdIdx[j], 1, h->fwdBlocks[j], h->sc, hyp, h->stream); }));
   }
   const DevHidden& q = h->hid[h->nHidden - 1];
   HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense;
@@ -425,9 +462,9 @@ int launchTrain(hl_learner* h, const long long* dFlat) {
   HIPCK(timed(h, "head_kernel", [&] { return launch_head(ha, h->Mmax, h->stream); }));
   for (size_t i = 0; i < h->dxIdx.size(); ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
-    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->dxIdx[i], 1, h->dxBlocks[i], h->sc, h->stream); }));
+    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->dxIdx[i], 1, h->dxBlocks[i], h->sc, hyp, h->stream); }));
   }
-  HIPCK(timed(h, "gemm16_dw", [&] { return launch_gemm(h->dProbs + h->dwIdx, h->dwCount, h->dwBlocks, h->sc, h->stream); }));
+  HIPCK(timed(h, "gemm16_dw", [&] { return launch_gemm(h->dProbs + (fuseAdam ? h->dwAdamIdx : h->dwIdx), h->dwCount, h->dwBlocks, h->sc, hyp, h->stream); }));
   return HL_OK;
 }
 PostArgs postArgs(hl_learner* h, int mode) {
@@ -447,6 +484,12 @@ int launchPost(hl_learner* h, int mode) {
   PostArgs pa = postArgs(h, mode);
   HIPCK(timed(h, "post_kernel", [&] { return launch_post(pa, h->stream); }));
   return HL_OK;
+}
+// bookkeeping of the last graph-replayed step (the replayed graph defers it to the next step's tail)
+int flushPost(hl_learner* h) {
+  if (!h->postPendingHost) return HL_OK;
+  h->postPendingHost = false;
+  return launchPost(h, POST_AGG | POST_BETA);
 }
 
 // every 1000th step: Episode::updateCumulative + full Retrace sweep, then reward/state statistics
@@ -503,9 +546,9 @@ int allreduceMoments(hl_learner* h) {
 int stepEager(hl_learner* h, const long long* dFlat) {
   const long long k = h->nGradSteps + 1;
   const bool periodic = (k % 1000) == 0;
-  int rc = launchTrain(h, dFlat); if (rc) return rc;
-  rc = allreduceGrad(h); if (rc) return rc;
-  rc = launchAdam(h); if (rc) return rc;
+  const bool fuse = h->cfg.n_ranks <= 1;
+  int rc = launchTrain(h, dFlat, fuse); if (rc) return rc;
+  if (!fuse) { rc = allreduceGrad(h); if (rc) return rc; rc = launchAdam(h); if (rc) return rc; }
   const bool evict = !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
   if (!periodic && !evict && h->cfg.n_ranks <= 1) return launchPost(h, POST_AGG | POST_BETA);
   rc = launchPost(h, POST_AGG); if (rc) return rc;
@@ -520,18 +563,28 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   return launchPost(h, POST_BETA);
 }
 
-int captureGraph(hl_learner* h) {
-  if (h->graphExec) { hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
-  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+// Captures `nSteps` consecutive gradient steps into one executable graph.  Node sequence of a
+// step: [bookkeeping of the previous step (if pending) + sampling] -> forward GEMMs -> head ->
+// dX GEMMs -> dW GEMMs with fused Adam.  The bookkeeping of the LAST step of an hl_step() call
+// is flushed by an explicit post launch (flushPost).  A replay costs ~8 us of host/dispatch gap,
+// so long runs replay the GRAPH_UNROLL-step graph.
+constexpr int GRAPH_UNROLL = 20;
+int captureOne(hl_learner* h, int nSteps, hipGraph_t* g, hipGraphExec_t* ge) {
+  if (*ge) { hipGraphExecDestroy(*ge); *ge = nullptr; }
+  if (*g) { hipGraphDestroy(*g); *g = nullptr; }
   HIPCK(hipStreamSynchronize(h->stream));
   HIPCK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  int rc = launchTrain(h, nullptr);
-  if (!rc) rc = launchAdam(h);
-  if (!rc) rc = launchPost(h, POST_AGG | POST_BETA);
-  hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+  int rc = HL_OK;
+  for (int s = 0; s < nSteps && !rc; ++s) rc = launchTrain(h, nullptr, true, true);
+  hipError_t e = hipStreamEndCapture(h->stream, g);
   if (rc) return rc;
   if (e != hipSuccess) return hipFail(h, e, "hipStreamEndCapture");
-  HIPCK(hipGraphInstantiate(&h->graphExec, h->graph, nullptr, nullptr, 0));
+  HIPCK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+  return HL_OK;
+}
+int captureGraph(hl_learner* h) {
+  int rc = captureOne(h, 1, &h->graph, &h->graphExec); if (rc) return rc;
+  rc = captureOne(h, GRAPH_UNROLL, &h->graphN, &h->graphExecN); if (rc) return rc;
   h->graphValid = true;
   return HL_OK;
 }
@@ -572,7 +625,9 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   const double nL = cfg->n_ranks;
   h->Bglobal = cfg->batchSize > 1 ? (int)(std::ceil(cfg->batchSize / nL) * nL) : cfg->batchSize;
   h->B = cfg->batchSize > 1 ? h->Bglobal / cfg->n_ranks : h->Bglobal;
-  if (h->B > 2048) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 2048");
+  if (h->B > 1024) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024");
+  for (int j = 0; j < cfg->n_hidden; ++j)
+    if (cfg->hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
   h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);
   h->maxObsLocal = h->maxObsGlobal / cfg->n_ranks;
   long long minObs = cfg->minTotObsNum <= 0 ? cfg->maxTotObsNum : cfg->minTotObsNum;
@@ -599,7 +654,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   DevBatch& bt = h->bt;
   HIPCK(devAlloc(&bt.flat, B)); HIPCK(devAlloc(&bt.pos, B)); HIPCK(devAlloc(&bt.eid, B)); HIPCK(devAlloc(&bt.t, B));
   HIPCK(devAlloc(&bt.slot, B)); HIPCK(devAlloc(&bt.nextOf, B)); HIPCK(devAlloc(&bt.nextSrc, B));
-  HIPCK(devAlloc(&bt.tag, B));
+  HIPCK(devAlloc(&bt.tag, B)); HIPCK(devAlloc(&bt.pEid, B)); HIPCK(devAlloc(&bt.pNextOf, B));
   HIPCK(devAlloc(&bt.O, (size_t)2 * B * h->nOut)); HIPCK(devAlloc(&bt.G, (size_t)B * h->nOut));
   HIPCK(devAlloc(&bt.rho, B)); HIPCK(devAlloc(&bt.dkl, B)); HIPCK(devAlloc(&bt.dq, B)); HIPCK(devAlloc(&bt.far, B));
   HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B));
@@ -633,13 +688,15 @@ int hl_destroy(hl_learner* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   timerFlush(h);
   if (h->graphExec) hipGraphExecDestroy(h->graphExec);
+  if (h->graphExecN) hipGraphExecDestroy(h->graphExecN);
+  if (h->graphN) hipGraphDestroy(h->graphN);
   if (h->graph) hipGraphDestroy(h->graph);
   if (h->comm) ncclCommDestroy(h->comm);
   void* ptrs[] = {h->W, h->M1, h->M2, h->G, h->sc, h->X0, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
-    h->rp.stStd, h->rp.epTag, h->bt.tag, h->bt.flat, h->bt.pos, h->bt.eid, h->bt.t, h->bt.slot, h->bt.nextOf, h->bt.nextSrc, h->bt.O, h->bt.G,
+    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->bt.tag, h->bt.pEid, h->bt.pNextOf, h->bt.flat, h->bt.pos, h->bt.eid, h->bt.t, h->bt.slot, h->bt.nextOf, h->bt.nextSrc, h->bt.O, h->bt.G,
     h->bt.rho, h->bt.dkl, h->bt.dq, h->bt.far, h->bt.newDQ, h->bt.newDKL, h->bt.newW, h->bt.newV, h->bt.oldDQ,
     h->bt.oldDKL, h->bt.oldW, h->bt.oldV, h->bt.oldADV, h->bt.nextV, h->bt.oldNextV, h->bt.oldNextADV, h->bt.gParam};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -873,9 +930,19 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     const bool evict = !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
     const bool plain = !flat && (k % 1000) != 0 && !evict && h->cfg.n_ranks <= 1 && !h->timing && h->useGraph;
     if (plain) {
-      if (!h->graphValid) { rc = captureGraph(h); if (rc) return rc; }
+      if (!h->graphValid) { rc = flushPost(h); if (rc) return rc; rc = captureGraph(h); if (rc) return rc; }
+      // plain steps available before the next 1000-step sweep and within this call
+      const long long untilSweep = 999 - (h->nGradSteps % 1000);
+      if (n - s >= GRAPH_UNROLL && untilSweep >= GRAPH_UNROLL) {
+        HIPCK(hipGraphLaunch(h->graphExecN, h->stream));
+        h->postPendingHost = true;
+        h->nGradSteps += GRAPH_UNROLL; s += GRAPH_UNROLL - 1;
+        continue;
+      }
       HIPCK(hipGraphLaunch(h->graphExec, h->stream));
+      h->postPendingHost = true;
     } else {
+      rc = flushPost(h); if (rc) return rc;
       const long long* dFlat = nullptr;
       if (flat) {
         HIPCK(hipMemcpyAsync(h->dFlatGiven, flat + (size_t)s * h->B, h->B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
@@ -886,7 +953,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     }
     h->nGradSteps += 1;
   }
-  return HL_OK;
+  return flushPost(h);
 }
 
 // split form (host-side exchange of gradient / counters / moments, e.g. over the existing MPI path)
@@ -899,7 +966,7 @@ int hl_step_begin(hl_learner* h, const int64_t* flat) {
     HIPCK(hipStreamSynchronize(h->stream));
     dFlat = h->dFlatGiven;
   }
-  rc = launchTrain(h, dFlat); if (rc) return rc;
+  rc = launchTrain(h, dFlat, false); if (rc) return rc;
   rc = launchPost(h, POST_AGG); if (rc) return rc;
   h->momentsPending = false;
   if (((h->nGradSteps + 1) % 1000) == 0) {

@@ -1,0 +1,266 @@
+// smarties_amd/csrc/misc.hip -- Adam (multi-replica path), per-step bookkeeping, periodic
+// whole-buffer sweeps (Retrace, episode aggregates, reward/state moments) and statistics.
+#include "dev_common.h"
+
+namespace hl {
+
+// ---------------------------------------------------------------------------
+// adam_kernel: Adam::step + AdamOptimizer::apply_update (Network/Optimizer.cpp:61-108,122-160)
+// with SMARTIES_NESTEROV_ADAM, SMARTIES_SAFE_ADAM, SMARTIES_ADAMW (Settings/Bund.h).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  const DevScalars* sc = a.sc;
+  const long long nStep = sc->nStep + 1;    // prepare_update incremented it before apply_update
+  const float _eta = (float)((double)a.eta0 / (1 + (double)(float)nStep * a.epsAnneal));
+  const float bt1 = (float)sc->adam_bt1, bt2 = (float)sc->adam_bt2;
+  const float eta = _eta * sqrtf(1 - bt2) / (1 - bt1);
+  const float B1 = 0.9f, B2 = 0.999f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float w = a.W[i];
+    const float penal = -w * a.lambda;
+    const float DW = a.fac * a.G[i];
+    float m1 = B1 * a.M1[i] + (1 - B1) * DW;
+    float m2 = B2 * a.M2[i] + (1 - B2) * DW * DW;
+    const float numer = B1 * m1 + (1 - B1) * DW;
+    m2 = m2 < m1 * m1 ? m1 * m1 : m2;
+    const float ret = numer / (FLT_EPSILON + sqrtf(m2));
+    a.M1[i] = m1; a.M2[i] = m2;
+    a.W[i] = w + eta * (ret + penal);
+  }
+}
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
+  const int blocks = (int)((a.n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// episode_sweep_kernel: one thread per episode.
+//   recompute=1: Episode::updateCumulative (Episode.cpp:213-242)
+//   then computeRetrace backward scan (MemoryProcessing.cpp:23-44,391-400).
+// Used on insert (count=1), by initializeLearner and every 1000th step (whole buffer).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) {
+  __shared__ long long sFar[256];
+  __shared__ float sMax[256];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  long long myFar = 0; float myMax = 0.f;
+  if (idx < a.count) {
+    const int e = a.eids ? a.eids[idx] : a.rp.posEid[idx];
+    const long long off = a.rp.epOff[e];
+    const int N = a.rp.epN[e];
+    const bool term = a.rp.epTerm[e] != 0;
+    const DevScalars* sc = a.sc;
+    if (a.recompute) {
+      const float C = (float)sc->Cmax, invC = (float)sc->Cinv;
+      const int nd = N - 1;
+      const float invN = 1 / (float)nd;
+      long long nFarPol = 0;
+      float sumE2 = 0, maxAE = -1e9f, maxQ = -1e9f, sumQ2 = 0, minQ = 1e9f, sumQ1 = 0, sumKL = 0;
+      double totR = 0;
+      for (int t = 0; t < nd; ++t) {
+        const float w = a.rp.IMPW[off + t], dq = a.rp.DQ[off + t];
+        if (w > C || w < invC) ++nFarPol;
+        sumE2 += dq * dq; maxAE = fmaxf(maxAE, fabsf(dq));
+        const float Q = a.rp.ADV[off + t] + a.rp.V[off + t];
+        maxQ = fmaxf(maxQ, Q); minQ = fminf(minQ, Q); sumQ2 += Q * Q; sumQ1 += Q;
+      }
+      for (int t = 0; t < N; ++t) { totR += a.rp.R[off + t]; sumKL += a.rp.DKL[off + t]; }
+      float* ag = a.rp.epAgg + (size_t)e * AGG_N;
+      ag[AGG_FRACFAR] = invN * (float)nFarPol; ag[AGG_AVGSQERR] = invN * sumE2; ag[AGG_MAXABSERR] = maxAE;
+      ag[AGG_SUMQ2] = sumQ2; ag[AGG_SUMQ] = sumQ1; ag[AGG_MAXQ] = maxQ; ag[AGG_MINQ] = minQ;
+      ag[AGG_TOTR] = (float)totR; ag[AGG_AVGKL] = invN * sumKL;
+      myFar = farSteps((float)N, ag[AGG_FRACFAR]);
+      myMax = fmaxf(maxAE, 0.f);
+    }
+    const float gamma = a.gamma, lambda = a.lambda;
+    const float rM = sc->rewMean, rS = sc->rewScale;
+    float Q = term ? a.rp.RET[off + N - 1] : a.rp.V[off + N - 1];
+    if (!term) a.rp.RET[off + N - 1] = Q;
+    for (int t = N - 2; t >= 0; --t) {
+      const float R = (float)((a.rp.R[off + t + 1] - (double)rM) * (double)rS);
+      const float V = a.rp.V[off + t + 1], A = a.rp.ADV[off + t + 1];
+      const float iw = a.rp.IMPW[off + t + 1];
+      const float w = iw < 1.f ? iw : 1.f;
+      Q = R + gamma * (V + lambda * w * (Q - A - V));
+      a.rp.RET[off + t] = Q;
+    }
+  }
+  if (a.recompute) {
+    sFar[threadIdx.x] = myFar; sMax[threadIdx.x] = myMax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) { sFar[threadIdx.x] += sFar[threadIdx.x + s];
+        sMax[threadIdx.x] = fmaxf(sMax[threadIdx.x], sMax[threadIdx.x + s]); }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { a.redNFar[blockIdx.x] = sFar[0]; a.redMaxAbs[blockIdx.x] = sMax[0]; }
+  }
+}
+int sweep_blocks(int count) { return (count + 255) / 256; }
+hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s) {
+  if (nBlocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(episode_sweep_kernel, dim3(nBlocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+__global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long f = 0; float m = 0.f;
+  for (int i = 0; i < n; ++i) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); }
+  sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
+  sc->maxAbsErrAll = m;
+  sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
+}
+hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(64), 0, s, sc, redNFar, redMaxAbs, nBlocks);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// moments: MemoryProcessing::updateRewardsStats (MemoryProcessing.cpp:94-185).
+// One wavefront per episode (lanes stride over its transitions), fp64 accumulation
+// (the reference uses long double on the host), deterministic two-stage reduction.
+// ---------------------------------------------------------------------------
+// Thread layout: column c = tid % (dS+1) (c < dS: state component, c == dS: reward), row lane
+// r = tid / (dS+1); every thread owns one column, so sums are order-deterministic.
+__global__ __launch_bounds__(256) void moments_partial_kernel(MomentsArgs a) {
+  __shared__ double s1[256], s2[256];
+  const int dS = a.dS, CW = dS + 1, RL = 256 / CW, tid = threadIdx.x;
+  const int c = tid % CW, r = tid / CW;
+  const bool active = r < RL;
+  double sum = 0, sq = 0;
+  const float rMean = a.sc->rewMean;
+  const float sMean = (active && c < dS) ? a.rp.stMean[c] : 0.f;
+  if (active) for (int p = blockIdx.x; p < a.nEpisodes; p += gridDim.x) {
+    const int e = a.rp.posEid[p];
+    const long long off = a.rp.epOff[e];
+    const int nd = a.rp.epN[e] - 1;
+    for (int j = r; j < nd; j += RL) {
+      double d;
+      if (c < dS) d = (double)(a.rp.S[(size_t)(off + j) * dS + c] - sMean);   // float - float
+      else d = a.rp.R[off + j + 1] - (double)rMean;
+      sum += d; sq += d * d;
+    }
+  }
+  s1[tid] = sum; s2[tid] = sq;
+  __syncthreads();
+  if (tid < CW) {
+    double t1 = 0, t2 = 0;
+    for (int q = 0; q < RL; ++q) { t1 += s1[q * CW + tid]; t2 += s2[q * CW + tid]; }
+    a.partial[(size_t)blockIdx.x * 2 * CW + tid] = t1;
+    a.partial[(size_t)blockIdx.x * 2 * CW + CW + tid] = t2;
+  }
+}
+// moments layout (MemoryProcessing.cpp:139-150): [sum s (dS) | sum s^2 (dS) | count | sum r | sum r^2]
+__global__ __launch_bounds__(256) void moments_final_kernel(MomentsArgs a) {
+  const int dS = a.dS, CW = dS + 1;
+  for (int i = threadIdx.x; i < 2 * CW; i += 256) {
+    double s = 0;
+    for (int b = 0; b < a.nBlocks; ++b) s += a.partial[(size_t)b * 2 * CW + i];
+    const int c = i % CW; const bool second = i >= CW;
+    if (c < dS) a.moments[(second ? dS : 0) + c] = s;
+    else a.moments[2 * dS + (second ? 2 : 1)] = s;
+  }
+  if (threadIdx.x == 0) a.moments[2 * dS] = (double)a.sc->nTransitions;
+}
+__global__ void moments_apply_kernel(MomentsArgs a) {
+  DevScalars* sc = a.sc;
+  const int dS = a.dS;
+  const double learnR = a.learnrate / (1 + (double)sc->nGradSteps * a.epsAnneal);
+  const double annealLearnR = fmin(1.0, a.rRateFac * learnR);
+  const double Wt = a.bInit ? 1.0 : annealLearnR;
+  if (!(Wt > 0)) return;
+  const double count = a.moments[2 * dS];
+  for (int i = threadIdx.x; i <= dS; i += blockDim.x) {
+    const bool isRew = (i == dS);
+    const double Evar = (isRew ? a.moments[2 * dS + 1] : a.moments[i]) / count;
+    const double Evar2 = (isRew ? a.moments[2 * dS + 2] : a.moments[dS + i]) / count;
+    float mean = isRew ? sc->rewMean : a.rp.stMean[i];
+    float stdev = isRew ? sc->rewStd : a.rp.stStd[i];
+    mean = (float)((double)mean + Wt * Evar);
+    double variance = Evar2 - Evar * Evar * (2 * Wt - Wt * Wt);
+    variance = fmax(variance, (double)FLT_EPSILON);
+    stdev = (float)((double)stdev + Wt * (sqrt(variance) - (double)stdev));
+    const float inv = 1 / stdev;
+    if (isRew) { sc->rewMean = mean; sc->rewStd = stdev; sc->rewScale = inv; }
+    else { a.rp.stMean[i] = mean; a.rp.stStd[i] = stdev; a.rp.stScale[i] = inv; }
+  }
+}
+int moments_blocks(int nEpisodes) { int b = nEpisodes; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
+hipError_t launch_moments(const MomentsArgs& a, hipStream_t s) {
+  if (a.dS + 1 > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moments_partial_kernel, dim3(a.nBlocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(moments_apply_kernel, dim3(1), dim3(128), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ void set_counts_kernel(DevScalars* sc, long long nT, long long nE, long long seenEps, long long seenSteps) {
+  sc->nTransitions = nT; sc->nEpisodes = nE; sc->cnt[0] = seenEps; sc->cnt[1] = seenSteps;
+  sc->cnt[3] = nT;   // cnt[2] keeps the far-policy count of the last statistics pass
+}
+// removal of an episode (MemoryBuffer::removeBackEpisode): its far-policy steps leave the total
+__global__ void evict_kernel(DevScalars* sc, DevReplay rp, int eid) {
+  const long long c = farSteps((float)rp.epN[eid], rp.epAgg[(size_t)eid * AGG_N + AGG_FRACFAR]);
+  sc->nFarTotal -= c; if (sc->nFarTotal < 0) sc->nFarTotal = 0;
+}
+hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s) {
+  hipLaunchKernelGGL(evict_kernel, dim3(1), dim3(1), 0, s, sc, rp, eid);
+  return hipGetLastError();
+}
+hipError_t launch_set_counts(DevScalars* sc, long long nT, long long nE, long long seenEps, long long seenSteps, hipStream_t s) {
+  hipLaunchKernelGGL(set_counts_kernel, dim3(1), dim3(1), 0, s, sc, nT, nE, seenEps, seenSteps);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// stats_kernel (one workgroup): the reduction over all episodes of
+// MemoryProcessing::updateTrainingStatistics (:209-258), on demand (logging surface).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_kernel(DevScalars* sc, DevReplay rp, int nEp, double* out) {
+  __shared__ double sd[5][256];
+  __shared__ float sf[2][256];
+  const int tid = threadIdx.x;
+  double sumDKL = 0, sumE2 = 0, sumQ2 = 0, sumQ1 = 0, sumR = 0;
+  float maxQ = -1e9f, minQ = 1e9f;
+  for (int p = tid; p < nEp; p += 256) {
+    const int e = rp.posEid[p];
+    const float* ag = rp.epAgg + (size_t)e * AGG_N;
+    const float Nf = (float)rp.epN[e];
+    sumDKL += (double)(Nf * ag[AGG_AVGKL]); sumE2 += (double)(Nf * ag[AGG_AVGSQERR]);
+    sumQ2 += (double)ag[AGG_SUMQ2]; sumQ1 += (double)ag[AGG_SUMQ]; sumR += (double)ag[AGG_TOTR];
+    maxQ = fmaxf(maxQ, ag[AGG_MAXQ]); minQ = fminf(minQ, ag[AGG_MINQ]);
+  }
+  sd[0][tid] = sumDKL; sd[1][tid] = sumE2; sd[2][tid] = sumQ2; sd[3][tid] = sumQ1; sd[4][tid] = sumR;
+  sf[0][tid] = maxQ; sf[1][tid] = minQ;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      for (int q = 0; q < 5; ++q) sd[q][tid] += sd[q][tid + s];
+      sf[0][tid] = fmaxf(sf[0][tid], sf[0][tid + s]); sf[1][tid] = fminf(sf[1][tid], sf[1][tid + s]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double nData = (double)sc->nTransitions;
+    out[0] = sd[0][0] / nData;                 // avgKLdivergence
+    out[1] = sd[1][0] / nData;                 // avgSquaredErr
+    out[2] = sc->maxAbsErrEMA;                 // maxAbsError
+    out[3] = sd[4][0] / (double)nEp;           // avgReturn
+    const double avgQ = sd[3][0] / nData;
+    out[4] = avgQ;
+    out[5] = sqrt(fmax(sd[2][0] / nData - avgQ * avgQ, 1e-16));   // stdevQ
+    out[6] = (double)sf[1][0]; out[7] = (double)sf[0][0];          // minQ, maxQ
+    out[8] = (double)sc->nFarStat;
+  }
+}
+hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, sc, rp, nEpisodes, out);
+  return hipGetLastError();
+}
+
+}  // namespace hl
