@@ -54,12 +54,13 @@ __device__ __forceinline__ double scaleVdiff(double x) {   // Learners/RACER_com
 // Adam::step (Network/Optimizer.cpp:61-108) with SMARTIES_NESTEROV_ADAM, SMARTIES_SAFE_ADAM,
 // SMARTIES_ADAMW (Settings/Bund.h); eta already carries the bias correction (Optimizer.cpp:66)
 struct AdamCoef { float eta, lambda, fac; };
-__device__ __forceinline__ AdamCoef adamCoef(const DevScalars* sc, float eta0, float lambda, float fac, double epsAnneal) {
-  const long long nStep = sc->nStep + 1;    // prepare_update incremented it before apply_update
+// step size of the Adam step that follows `nStepDone` completed ones (Optimizer.cpp:66,132-135):
+// annealed learn rate times sqrt(1-beta2^t)/(1-beta1^t), all in nnReal as the reference does
+__device__ __forceinline__ float adamEtaEff(long long nStepDone, double bt1, double bt2, float eta0, double epsAnneal) {
+  const long long nStep = nStepDone + 1;    // prepare_update incremented it before apply_update
   const float _eta = (float)((double)eta0 / (1 + (double)(float)nStep * epsAnneal));
-  const float bt1 = (float)sc->adam_bt1, bt2 = (float)sc->adam_bt2;
-  AdamCoef c; c.eta = _eta * sqrtf(1 - bt2) / (1 - bt1); c.lambda = lambda; c.fac = fac;
-  return c;
+  const float b1 = (float)bt1, b2 = (float)bt2;
+  return _eta * sqrtf(1 - b2) / (1 - b1);
 }
 __device__ __forceinline__ void adamStep(const AdamCoef& c, float g, float& w, float& m1, float& m2) {
   const float B1 = 0.9f, B2 = 0.999f;

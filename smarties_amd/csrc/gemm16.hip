@@ -16,7 +16,7 @@
 //                                                            Adam::step (Optimizer.cpp:61-108)
 // One launch can carry several problems (table in device memory); all dW / bias / residual
 // parameter gradients of a step are ONE launch.
-#include "dev_common.h"
+#include "tail_dev.h"
 
 namespace hl {
 
@@ -56,16 +56,23 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
 #pragma unroll
     for (int q = 0; q < 16; ++q) g += red[q * 16 + jj];
     P.C[j] = g;
-    if (P.adam) { const AdamCoef c = adamCoef(sc, hyp.eta0, hyp.lambda, hyp.fac, hyp.epsAnneal); adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
+    if (P.adam) { AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac; adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
   }
 }
 
 __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
-                                                     const DevScalars* __restrict__ sc, AdamHyper hyp) {
-  __shared__ __attribute__((aligned(16))) float sA[16 * LDR];
-  __shared__ __attribute__((aligned(16))) float sB[16 * LDR];
-  __shared__ float red[4 * 256];
-  const int bid = blockIdx.x;
+                                                     const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
+  // one LDS block, used either by a GEMM tile (two operand tiles + the cross-wave reduction
+  // buffer) or by the tail code of the extra workgroup
+  constexpr int GEMM_LDS = (2 * 16 * LDR + 4 * 256) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
+  // horizontal fusion: workgroup 0 of the grid (dispatched first) runs a piece of the step tail
+  if (extra.role && blockIdx.x == 0) { runExtra(extra, smem); return; }
+  float* sA = reinterpret_cast<float*>(smem);
+  float* sB = sA + 16 * LDR;
+  float* red = sB + 16 * LDR;
+  const int bid = blockIdx.x - (extra.role ? 1 : 0);
+  const int nRowsDyn = sc->nRows[hyp.parity];   // issued together with the problem-table fetch
   int p = 0;
   for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
   const GemmProblem P = probs[p];
@@ -74,11 +81,30 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
 
   const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
   const int m0 = tm * 16, n0 = tn * 16;
-  const int Mvalid = P.dynRows ? sc->nRows : P.M;
+  const int Mvalid = P.dynRows ? nRowsDyn : P.M;
   if (m0 >= Mvalid) return;
+  if (hyp.variant & 8) return;              // ablation: launch + problem-table fetch only
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lc = lane >> 4;
+  // ---- prefetch the epilogue operands of this thread's output element (m, n) ----
+  const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+  const bool outOk = m < Mvalid && n < P.N;
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+  AdamCoef ac{};
+  if (outOk && !(hyp.variant & 4)) {        // ablation: no epilogue prefetch
+    if (P.epi == EPI_FWD) {
+      e0 = P.bias[n];
+      if (P.C3 && n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; e3 = P.resB[n]; }
+    } else if (P.epi == EPI_DX) {
+      if (n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; }
+      e0 = P.actX[(size_t)m * P.ldAct + n]; e3 = P.actY[(size_t)m * P.ldAct + n];
+    } else if (P.epi == EPI_DW && P.adam) {
+      ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
+      if (m < P.M - 1) { const size_t i = (size_t)m * P.ldc + n; e0 = P.adW[i]; e1 = P.adM1[i]; e2 = P.adM2[i]; }
+      else { e0 = P.adbW[n]; e1 = P.adbM1[n]; e2 = P.adbM2[n]; }
+    }
+  }
   const bool aRows = (P.flavor != GEMM_W);   // A tile is 16 rows x k  (else k x 16)
   const bool bRows = (P.flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
 
@@ -96,6 +122,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       va[q] = z4; vb[q] = z4;
+      if (hyp.variant & 1) continue;        // ablation: no operand loads
       if (aRows) {
         const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
         if (idx < 16 * nf4 && m0 + r < Mvalid && c < kc && kb + c < P.lda)
@@ -145,6 +172,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
     }
     __syncthreads();
     const int k0 = wave * kw;
+    if (!(hyp.variant & 2))                 // ablation: no MFMA loop
     for (int s = 0; s < kw; s += 8) {
       const int ka = k0 + s + lc, kb2 = ka + 4;
       const float a0 = aRows ? sA[li * LDR + ka] : sA[ka * 16 + li];
@@ -161,33 +189,31 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
   __syncthreads();
   const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-  const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
-  if (m >= Mvalid || n >= P.N) return;
+  if (!outOk) return;
 
   if (P.epi == EPI_FWD) {
-    const float x = v + P.bias[n];
+    const float x = v + e0;
     P.C[(size_t)m * P.ldc + n] = x;
     const float y = actEval(P.func, x);
     P.C2[(size_t)m * P.ldc + n] = y;
     if (P.C3) {
       float r = y;
-      if (n < P.resN) r += P.resIn[(size_t)m * P.ldRes + n] * P.resW[n] + P.resB[n];
+      if (n < P.resN) r += e1 * e2 + e3;
       P.C3[(size_t)m * P.ldc + n] = r;
     }
   } else if (P.epi == EPI_DX) {
     float dres = v;
-    if (n < P.resN) dres += P.resIn[(size_t)m * P.ldRes + n] * P.resW[n];
+    if (n < P.resN) dres += e1 * e2;
     P.C[(size_t)m * P.ldc + n] = dres;
-    P.C2[(size_t)m * P.ldc + n] =
-        dres * actDiff(P.func, P.actX[(size_t)m * P.ldAct + n], P.actY[(size_t)m * P.ldAct + n]);
+    P.C2[(size_t)m * P.ldc + n] = dres * actDiff(P.func, e0, e3);
   } else if (P.epi == EPI_DW) {
     if (m < P.M - 1) {
       const size_t i = (size_t)m * P.ldc + n;
       P.C[i] = v;
-      if (P.adam) { const AdamCoef c = adamCoef(sc, hyp.eta0, hyp.lambda, hyp.fac, hyp.epsAnneal); adamApply(c, v, P.adW, P.adM1, P.adM2, i); }
+      if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adW[i] = e0; P.adM1[i] = e1; P.adM2[i] = e2; }
     } else {
       P.biasOut[n] = v;
-      if (P.adam) { const AdamCoef c = adamCoef(sc, hyp.eta0, hyp.lambda, hyp.fac, hyp.epsAnneal); adamApply(c, v, P.adbW, P.adbM1, P.adbM2, n); }
+      if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adbW[n] = e0; P.adbM1[n] = e1; P.adbM2[n] = e2; }
     }
   } else {
     P.C[(size_t)m * P.ldc + n] = v;
@@ -195,9 +221,10 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
 }
 
 hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
-                       const AdamHyper& hyp, hipStream_t s) {
+                       const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
   if (nBlocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gemm16_kernel, dim3(nBlocks), dim3(256), 0, s, dProbs, nProbs, sc, hyp);
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  hipLaunchKernelGGL(gemm16_kernel, dim3(nBlocks + (ex.role ? 1 : 0)), dim3(256), 0, s, dProbs, nProbs, sc, hyp, ex);
   return hipGetLastError();
 }
 

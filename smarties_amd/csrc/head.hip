@@ -11,7 +11,7 @@
 // hidden activations, the whole output-layer weight matrix slice of the lane, action, behaviour
 // policy, Retrace target and the per-step values that are about to be overwritten -- is issued
 // up front; the weight slice stays in registers and is reused for the back-propagation.
-#include "dev_common.h"
+#include "tail_dev.h"
 
 namespace hl {
 
@@ -20,13 +20,17 @@ namespace hl {
 // HQ = ceil(H / 64): hidden activations per lane.  nDense <= 8 (dimA <= 7) takes the register
 // path for the output layer; wider action spaces use the generic path below.
 template <int HQ>
-__global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a) {
-  __shared__ double sO[4][HEAD_MAXOUT];
-  __shared__ float sDelta[4][72];
+__global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra) {
+  constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HEAD_LDS > TAIL_LDS_BYTES ? HEAD_LDS : TAIL_LDS_BYTES];
+  // horizontal fusion: workgroup 0 (dispatched first) runs sampler phase C of the next step
+  if (extra.role && blockIdx.x == 0) { runExtra(extra, smem); return; }
+  double (*sO)[HEAD_MAXOUT] = reinterpret_cast<double (*)[HEAD_MAXOUT]>(smem);
+  float (*sDelta)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
+  const int row = (blockIdx.x - (extra.role ? 1 : 0)) * 4 + wave;
   const DevScalars* sc = a.sc;
-  if (row >= sc->nRows) return;
+  if (row >= sc->nRows[a.parity]) return;
   const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H;
   const bool isNext = row >= B;
   const int b = isNext ? a.bt.nextSrc[row - B] : row;
@@ -53,7 +57,6 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a) {
   // hand the (episode, next-row) map of THIS minibatch to the bookkeeping pass, which runs while
   // the sampler already overwrites bt.eid / bt.nextOf for the next step
   if (!isNext && lane == 0) { a.bt.pEid[b] = a.bt.eid[b]; a.bt.pNextOf[b] = a.bt.nextOf[b]; }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.sc->postPending = 1;
   const float bo = lane < nDense ? a.params[a.indBo + lane] : 0.f;
   const float bp = lane < dA ? a.params[a.indBp + lane] : 0.f;
   double act = 0, bMean = 0, bStd = 1;
@@ -133,21 +136,17 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a) {
     const double rt = sqrt(1 + pp * pp);
     stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
     const double bInv = 1 / bStd;
-    double lpPi, lpMu;
-    if (bnd) {
-      const double m = mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean);
-      const double sq = tanh(act), J = fmax(1 - sq * sq, (double)FLT_MIN);
-      const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
-      lpPi = -(u1 * u1) / 2 + log(invStd / J) - LOG2PI_2;
-      lpMu = -(u2 * u2) / 2 + log(bInv / J) - LOG2PI_2;
-    } else {
-      const double u1 = (act - mean) * invStd, u2 = (act - bMean) * bInv;
-      lpPi = -(u1 * u1) / 2 + log(invStd) - LOG2PI_2;
-      lpMu = -(u2 * u2) / 2 + log(bInv) - LOG2PI_2;
-    }
-    lw = lpPi - lpMu;
-    const double qq = stdev / bStd, CmuCpi = qq * qq, dm = (mean - bMean) / bStd;
-    kl = (CmuCpi - 1 + dm * dm - log(CmuCpi)) / 2;
+    // log pi(a) - log mu(a): the tanh Jacobian J of SquashedNormalPolicy::logProb (:240-249) and
+    // the log(2 pi)/2 constants appear in both terms and cancel, log(invStd/J) - log(bInv/J) =
+    // -log(stdev/bStd); the same logarithm serves the KL divergence (log CmuCpi = 2 log(stdev/bStd)).
+    // One fp64 log per action component instead of three logs and a tanh (agrees with the
+    // reference's term-by-term evaluation to ~1e-16 relative).
+    const double m = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
+    const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
+    const double qq = stdev * bInv, lq = log(qq);
+    lw = (u2 * u2 - u1 * u1) / 2 - lq;
+    const double CmuCpi = qq * qq, dm = (mean - bMean) * bInv;
+    kl = (CmuCpi - 1 + dm * dm - 2 * lq) / 2;
   }
   const double logW = waveSum(lw), DKL = waveSum(kl);
   const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
@@ -234,13 +233,14 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a) {
   }
 }
 
-hipError_t launch_head(const HeadArgs& a, int maxRows, hipStream_t s) {
-  const dim3 grid((maxRows + 3) / 4), block(256);
+hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  const dim3 grid((maxRows + 3) / 4 + (ex.role ? 1 : 0)), block(256);
   const int HQ = (a.H + 63) / 64;
-  if (HQ <= 1) hipLaunchKernelGGL(head_kernel_t<1>, grid, block, 0, s, a);
-  else if (HQ <= 2) hipLaunchKernelGGL(head_kernel_t<2>, grid, block, 0, s, a);
-  else if (HQ <= 4) hipLaunchKernelGGL(head_kernel_t<4>, grid, block, 0, s, a);
-  else if (HQ <= 8) hipLaunchKernelGGL(head_kernel_t<8>, grid, block, 0, s, a);
+  if (HQ <= 1) hipLaunchKernelGGL(head_kernel_t<1>, grid, block, 0, s, a, ex);
+  else if (HQ <= 2) hipLaunchKernelGGL(head_kernel_t<2>, grid, block, 0, s, a, ex);
+  else if (HQ <= 4) hipLaunchKernelGGL(head_kernel_t<4>, grid, block, 0, s, a, ex);
+  else if (HQ <= 8) hipLaunchKernelGGL(head_kernel_t<8>, grid, block, 0, s, a, ex);
   else return hipErrorInvalidValue;   // hidden width > 512: not supported by this kernel
   return hipGetLastError();
 }

@@ -24,12 +24,14 @@ struct DevScalars {
   long long cnt[4];               // {seenEps, seenSteps, nFar, nStored}: local, then all-reduced (C2)
   float rewMean, rewScale, rewStd;
   float maxAbsErrAll;             // max over episodes of Episode::maxAbsError
-  int nNext;                      // rows B..B+nNext-1 of the minibatch hold truncated next states
-  int nRows;                      // B + nNext
+  // the minibatch workspace is double buffered (sampling of step k+1 overlaps the update of step k)
+  int nNext[2];                   // rows B..B+nNext-1 of the minibatch hold truncated next states
+  int nRows[2];                   // B + nNext
+  float etaEff[2];                // Adam step size incl. bias correction for the step using buffer p
   int errFlag;                    // sticky device-side error code (0 = ok)
-  int postPending;                // a trained step still needs its bookkeeping pass (post part)
   unsigned rngPos;
   unsigned rng[624];
+  long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };
 
 // ---------------------------------------------------------------------------
@@ -80,6 +82,7 @@ struct DevBatch {
   int* nextOf;         // [B] row index (>= B) holding s_{t+1} if truncated, else -1
   int* nextSrc;        // [B] for next row j: sample b it belongs to
   long long* tag;      // [B] tag of the sampled episode
+  unsigned* sVals;     // [B] candidate flat indices between the sampler phases (tail_dev.h)
   int *pEid, *pNextOf; // [B] copies made by the head kernel for the bookkeeping pass (which runs
                        //     concurrently with the sampling of the NEXT minibatch)
   // head outputs / write-back staging (old values are needed by the aggregate updates)
@@ -134,6 +137,7 @@ struct GemmProblem {
   int tileStart, tilesM, tilesN;
 };
 
-struct AdamHyper { float eta0, lambda, fac; double epsAnneal; };
+struct AdamHyper { float eta0, lambda, fac; double epsAnneal; int parity; /* minibatch buffer of this step */
+                   int variant; /* development ablation switches, 0 in production */ };
 
 }  // namespace hl

@@ -11,6 +11,9 @@ struct SampleArgs {
   float* X0;              // [Mmax][ldX0] standardized states (MiniBatch::S)
   const long long* flatGiven;  // != nullptr: use these indices instead of drawing
   int adamDraws;          // mt19937 draws consumed by the Adam step (Optimizer.cpp:139)
+  int parity;             // minibatch buffer written (bt / X0 passed here belong to it)
+  int computeEta;         // also derive DevScalars::etaEff[parity] (first step of a launch sequence)
+  float eta0; double epsAnneal;
 };
 
 struct HeadArgs {
@@ -23,6 +26,7 @@ struct HeadArgs {
   float* dOut; int ldDo;            // [B][ldDo] output-layer deltas (f32)
   float* Dres; float* D; int ldD;   // gradient wrt last hidden block output / after act'
   unsigned char bounded[HL_MAX_DIMA];
+  int parity;
 };
 
 struct PostArgs {
@@ -30,13 +34,20 @@ struct PostArgs {
   int B, mode;                       // mode bits: 1 aggregates, 2 beta+counters, 4 init (beta only)
   double clipImpWeight, epsAnneal, penalTol, maxObsGlobal, batchGlobal;
   int nRanks;
+  int parity;                        // buffer of the step being closed; etaEff[parity^1] is written
+  float eta0;
 };
 enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4 };
 
 struct AdamArgs {
   const DevScalars* sc; float* W; float* M1; float* M2; const float* G; long long n;
-  float eta0, lambda, fac; double epsAnneal;
+  float eta0, lambda, fac; double epsAnneal; int parity;
 };
+
+// extra workgroup appended to an MLP kernel's grid (tail_dev.h): role 0 none, 1 sampler phases
+// (PH_A/B/C mask) of the NEXT step's minibatch, 2 bookkeeping of the step just computed
+enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7 };
+struct ExtraArgs { int role; int phases; SampleArgs samp; PostArgs post; };
 
 struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
   DevScalars* sc; DevReplay rp;
@@ -53,12 +64,12 @@ struct MomentsArgs {
 };
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
-// fused: bookkeeping of the previous step (if post != nullptr; postIfPending: only when the device
-// flag DevScalars::postPending is set) followed by the sampling of the next minibatch (if samp)
-hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, int postIfPending, hipStream_t s);
+// one launch, two independent workgroups: bookkeeping of a finished step (post) and sampling of a
+// minibatch (samp); either may be nullptr
+hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStream_t s, int phases = PH_ALL);
 hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
-                       const AdamHyper& hyp, hipStream_t s);
-hipError_t launch_head(const HeadArgs& a, int maxRows, hipStream_t s);
+                       const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
+hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -29,6 +30,13 @@ struct EpMeta { int eid; long long off; int N; bool term; long long tag, ID; };
 
 struct TimeRec { int name; hipEvent_t a, b; };
 
+// one of the two minibatch workspaces + the indices of its GEMM problems in the device table
+struct StepBuf {
+  DevBatch bt{}; float* X0 = nullptr;
+  std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
+};
+struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int steps = 0; };
+
 }  // namespace
 
 struct hl_learner {
@@ -44,14 +52,13 @@ struct hl_learner {
   float *W = nullptr, *M1 = nullptr, *M2 = nullptr, *G = nullptr;
   DevScalars* sc = nullptr;
   DevReplay rp{};
-  DevBatch bt{};
-  float* X0 = nullptr; int ldX0 = 0;
+  StepBuf buf[2];                          // double-buffered minibatch workspace (see step_exec.h)
+  int ldX0 = 0; int lastParity = 0;        // buffer used by the last executed step (taps)
   DevHidden hid[HL_MAX_HIDDEN];
   float* dOut = nullptr; int ldDo = 0;
   long long indWo = 0, indBo = 0, indBp = 0; int ldWo = 0;
   // gemm problem tables (device) + launch geometry
-  GemmProblem* dProbs = nullptr;           // all problems, contiguous
-  std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
+  GemmProblem* dProbs = nullptr;           // all GEMM problems of both buffers, contiguous
   // replay bookkeeping (host)
   long long capSlots = 0; int capEps = 0;
   long long ringHead = 0;                  // next free slot
@@ -61,7 +68,6 @@ struct hl_learner {
   long long nTransitions = 0, nSeenSteps = 0, nSeenEps = 0, nGradSteps = 0;
   long long nGatheredB4Startup = INT64_MAX;
   bool tableDirty = true, countsDirty = true, initialized = false, inStep = false;
-  bool postPendingHost = false;            // a graph-replayed step still needs its post pass
   double lastAvgSqErr = 0;
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
@@ -69,9 +75,11 @@ struct hl_learner {
   long long* dRedNFar = nullptr; float* dRedMax = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
-  // graph
-  hipGraph_t graph = nullptr; hipGraphExec_t graphExec = nullptr; bool graphValid = false; bool useGraph = true;
-  hipGraph_t graphN = nullptr; hipGraphExec_t graphExecN = nullptr;   // GRAPH_UNROLL steps per replay
+  // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
+  GraphSlot graphs[3]; bool graphsStale = false, useGraph = true;
+  hipStream_t sSample = nullptr, sPost = nullptr;
+  std::vector<hipEvent_t> evPool; int evUsed = 0;
+  int dbgVariant = 0;
   // rccl
   ncclComm_t comm = nullptr;
   // moments exchange state
@@ -123,13 +131,13 @@ void timerFlush(hl_learner* h) {
   h->trecs.clear();
 }
 // run a launch, optionally bracketed by HIP events on the library's own stream
-template <typename F> hipError_t timed(hl_learner* h, const char* name, F&& f) {
+template <typename F> hipError_t timed(hl_learner* h, const char* name, hipStream_t st, F&& f) {
   if (!h->timing) return f();
   TimeRec r; r.name = timerId(h, name);
   hipEventCreate(&r.a); hipEventCreate(&r.b);
-  hipEventRecord(r.a, h->stream);
+  hipEventRecord(r.a, st);
   hipError_t e = f();
-  hipEventRecord(r.b, h->stream);
+  hipEventRecord(r.b, st);
   h->trecs.push_back(r);
   if (h->trecs.size() >= 4096) timerFlush(h);
   return e;
@@ -250,7 +258,7 @@ int growSlots(hl_learner* h, long long need) {
     HIPCK(hipMemcpyAsync(h->rp.epOff + it->eid, &it->off, sizeof(long long), hipMemcpyHostToDevice, s));
   }
   HIPCK(hipStreamSynchronize(s));
-  h->ringHead = off; h->capSlots = newCap; h->graphValid = false;
+  h->ringHead = off; h->capSlots = newCap; h->graphsStale = true;
   return HL_OK;
 }
 int growEpisodes(hl_learner* h, int need) {
@@ -262,7 +270,7 @@ int growEpisodes(hl_learner* h, int need) {
   HIPCK(devGrow(&h->rp.epTag, o, n, h->stream));
   HIPCK(devGrow(&h->rp.posRec, o + 1, n + 1, h->stream));
   HIPCK(devGrow(&h->rp.posEid, o, n, h->stream)); HIPCK(devGrow(&h->rp.posPrefix, o + 1, n + 1, h->stream));
-  h->capEps = newCap; h->graphValid = false;
+  h->capEps = newCap; h->graphsStale = true;
   return HL_OK;
 }
 
@@ -322,7 +330,7 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute) {
   EpisodeSweepArgs a{}; a.sc = h->sc; a.rp = h->rp; a.eids = dEids; a.count = count;
   a.gamma = (float)h->cfg.gamma; a.lambda = (float)h->cfg.lambda; a.recompute = recompute;
   a.redNFar = h->dRedNFar; a.redMaxAbs = h->dRedMax;
-  HIPCK(timed(h, recompute ? "episode_sweep_recompute" : "episode_sweep_retrace",
+  HIPCK(timed(h, recompute ? "episode_sweep_recompute" : "episode_sweep_retrace", h->stream,
               [&] { return launch_episode_sweep(a, nb, h->stream); }));
   if (recompute) HIPCK(launch_sweep_finish(h->sc, h->dRedNFar, h->dRedMax, nb, h->stream));
   return HL_OK;
@@ -346,250 +354,9 @@ int flushPending(hl_learner* h) {
   return HL_OK;
 }
 
-// ---- gemm problem tables ---------------------------------------------------------------------
-void setTiles(GemmProblem& p, int& cursor) {
-  p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
-  if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
-  p.tileStart = cursor; cursor += p.tilesM * p.tilesN;
-}
-
-int buildProblems(hl_learner* h) {
-  std::vector<GemmProblem> P;
-  const int nH = h->nHidden, B = h->B;
-  h->fwdIdx.clear(); h->fwdBlocks.clear(); h->dxIdx.clear(); h->dxBlocks.clear();
-  // forward: one launch per hidden block
-  for (int j = 0; j < nH; ++j) {
-    const DevHidden& d = h->hid[j];
-    GemmProblem p{}; p.flavor = GEMM_F; p.epi = EPI_FWD; p.M = h->Mmax; p.N = d.size; p.K = d.nIn; p.dynRows = 1;
-    if (j == 0) { p.A = h->X0; p.lda = h->ldX0; }
-    else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
-    p.B = h->W + d.indW; p.ldb = d.ldW; p.bias = h->W + d.indB;
-    p.C = d.X; p.C2 = d.Y; p.C3 = d.hasRes ? d.Rr : nullptr; p.ldc = d.ldA; p.func = d.func;
-    if (d.hasRes) { p.resW = h->W + d.indWr; p.resB = h->W + d.indBr; p.resIn = p.A; p.ldRes = p.lda; p.resN = d.resW; }
-    int cur = 0; setTiles(p, cur);
-    h->fwdIdx.push_back((int)P.size()); h->fwdBlocks.push_back(cur); P.push_back(p);
-  }
-  // dX: for block j = nH-1 .. 1: Dres_{j-1} = D_j W_j^T + Dres_j[:, :res] * w_j ; D_{j-1} = Dres_{j-1} * act'
-  for (int j = nH - 1; j >= 1; --j) {
-    const DevHidden& d = h->hid[j]; const DevHidden& q = h->hid[j - 1];
-    GemmProblem p{}; p.flavor = GEMM_X; p.epi = EPI_DX; p.M = B; p.N = d.nIn; p.K = d.size;
-    p.A = d.D; p.lda = d.ldA; p.B = h->W + d.indW; p.ldb = d.ldW;
-    p.C = q.Dres; p.C2 = q.D; p.ldc = q.ldA;
-    if (d.hasRes) { p.resIn = d.Dres; p.ldRes = d.ldA; p.resW = h->W + d.indWr; p.resN = d.resW; }
-    p.actX = q.X; p.actY = q.Y; p.ldAct = q.ldA; p.func = q.func;
-    int cur = 0; setTiles(p, cur);
-    h->dxIdx.push_back((int)P.size()); h->dxBlocks.push_back(cur); P.push_back(p);
-  }
-  // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
-  h->dwIdx = (int)P.size(); int cur = 0;
-  for (int j = 0; j < nH; ++j) {
-    const DevHidden& d = h->hid[j];
-    GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = d.nIn + 1; p.N = d.size; p.K = B;
-    if (j == 0) { p.A = h->X0; p.lda = h->ldX0; }
-    else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
-    p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
-    setTiles(p, cur); P.push_back(p);
-    if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
-      GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
-      r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
-      setTiles(r, cur); P.push_back(r);
-      GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = d.resW; s.K = B;
-      s.A = d.Dres; s.lda = d.ldA; s.B = nullptr; s.C = h->G + d.indBr;
-      setTiles(s, cur); P.push_back(s);
-    }
-  }
-  { // output InnerProduct layer
-    const DevHidden& q = h->hid[nH - 1];
-    GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = q.size + 1; p.N = h->nDense; p.K = B;
-    p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; p.B = h->dOut; p.ldb = h->ldDo;
-    p.C = h->G + h->indWo; p.ldc = h->ldWo; p.biasOut = h->G + h->indBo;
-    setTiles(p, cur); P.push_back(p);
-    // ParamLayer::backward (Layers.h:522-546): bias gradient = column sums of the sigma-param deltas
-    GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
-    s.A = h->bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
-    setTiles(s, cur); P.push_back(s);
-  }
-  h->dwCount = (int)P.size() - h->dwIdx; h->dwBlocks = cur;
-  // second copy of the dW table with the Adam update fused into the epilogue (single replica:
-  // every gradient element is final inside the workgroup that produced it)
-  h->dwAdamIdx = (int)P.size();
-  for (int i = 0; i < h->dwCount; ++i) {
-    GemmProblem p = P[h->dwIdx + i];
-    p.adam = 1;
-    const long long offC = p.C - h->G;
-    p.adW = h->W + offC; p.adM1 = h->M1 + offC; p.adM2 = h->M2 + offC;
-    if (p.biasOut) { const long long offB = p.biasOut - h->G; p.adbW = h->W + offB; p.adbM1 = h->M1 + offB; p.adbM2 = h->M2 + offB; }
-    P.push_back(p);
-  }
-  if (h->dProbs) hipFree(h->dProbs);
-  HIPCK(devAlloc(&h->dProbs, P.size()));
-  HIPCK(hipMemcpy(h->dProbs, P.data(), P.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
-  return HL_OK;
-}
-
-// ---- the launch sequence of one gradient step ------------------------------------------------
-struct StepOpts { const long long* dFlat; bool split; };   // split: stop before post(BETA) for exchanges
-
-AdamHyper adamHyper(const hl_learner* h) {
-  AdamHyper a; a.eta0 = (float)h->cfg.learnrate; a.lambda = (float)h->cfg.nnLambda; a.fac = (float)(1.0 / h->Bglobal);
-  a.epsAnneal = h->cfg.epsAnneal; return a;
-}
-// fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
-PostArgs postArgs(hl_learner* h, int mode);
-// postIfPending: the sampling kernel first runs the bookkeeping of the previous step when the
-// device flag DevScalars::postPending is set (step-tail fusion used by the replayed graph)
-int launchTrain(hl_learner* h, const long long* dFlat, bool fuseAdam, bool postIfPending = false) {
-  const AdamHyper hyp = adamHyper(h);
-  SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
-  sa.X0 = h->X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
-  if (postIfPending) {
-    const PostArgs pa = postArgs(h, POST_AGG | POST_BETA);
-    HIPCK(timed(h, "step_tail_kernel", [&] { return launch_step_tail(&pa, &sa, 1, h->stream); }));
-  } else {
-    HIPCK(timed(h, "step_tail_kernel", [&] { return launch_sample(sa, h->stream); }));
-  }
-  char nm[32];
-  for (int j = 0; j < h->nHidden; ++j) {
-    snprintf(nm, sizeof(nm), "gemm16_fwd%d", j);
-    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->fwdIdx[j], 1, h->fwdBlocks[j], h->sc, hyp, h->stream); }));
-  }
-  const DevHidden& q = h->hid[h->nHidden - 1];
-  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense;
-  ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
-  ha.func = q.func; ha.params = h->W; ha.indWo = h->indWo; ha.indBo = h->indBo; ha.indBp = h->indBp; ha.ldWo = h->ldWo;
-  ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA;
-  for (int i = 0; i < h->dA; ++i) ha.bounded[i] = h->cfg.bounded[i];
-  HIPCK(timed(h, "head_kernel", [&] { return launch_head(ha, h->Mmax, h->stream); }));
-  for (size_t i = 0; i < h->dxIdx.size(); ++i) {
-    snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
-    HIPCK(timed(h, nm, [&] { return launch_gemm(h->dProbs + h->dxIdx[i], 1, h->dxBlocks[i], h->sc, hyp, h->stream); }));
-  }
-  HIPCK(timed(h, "gemm16_dw", [&] { return launch_gemm(h->dProbs + (fuseAdam ? h->dwAdamIdx : h->dwIdx), h->dwCount, h->dwBlocks, h->sc, hyp, h->stream); }));
-  return HL_OK;
-}
-PostArgs postArgs(hl_learner* h, int mode) {
-  PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->bt; pa.B = h->B; pa.mode = mode;
-  pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
-  pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = h->cfg.n_ranks;
-  return pa;
-}
-int launchAdam(hl_learner* h) {
-  AdamArgs aa{}; aa.sc = h->sc; aa.W = h->W; aa.M1 = h->M1; aa.M2 = h->M2; aa.G = h->G; aa.n = h->nParams;
-  aa.eta0 = (float)h->cfg.learnrate; aa.lambda = (float)h->cfg.nnLambda; aa.fac = (float)(1.0 / h->Bglobal);
-  aa.epsAnneal = h->cfg.epsAnneal;
-  HIPCK(timed(h, "adam_kernel", [&] { return launch_adam(aa, h->stream); }));
-  return HL_OK;
-}
-int launchPost(hl_learner* h, int mode) {
-  PostArgs pa = postArgs(h, mode);
-  HIPCK(timed(h, "post_kernel", [&] { return launch_post(pa, h->stream); }));
-  return HL_OK;
-}
-// bookkeeping of the last graph-replayed step (the replayed graph defers it to the next step's tail)
-int flushPost(hl_learner* h) {
-  if (!h->postPendingHost) return HL_OK;
-  h->postPendingHost = false;
-  return launchPost(h, POST_AGG | POST_BETA);
-}
-
-// every 1000th step: Episode::updateCumulative + full Retrace sweep, then reward/state statistics
-int launchPeriodicSweep(hl_learner* h) {
-  return runSweep(h, nullptr, (int)h->order.size(), 1);
-}
-int launchMoments(hl_learner* h) {
-  const int nb = moments_blocks((int)h->order.size());
-  if (nb > h->momBlocksCap) {
-    HIPCK(devGrow(&h->dMomPartial, 0, (size_t)nb * 2 * (h->dS + 1), h->stream)); h->momBlocksCap = nb;
-  }
-  MomentsArgs ma{}; ma.sc = h->sc; ma.rp = h->rp; ma.dS = h->dS; ma.nEpisodes = (int)h->order.size();
-  ma.partial = h->dMomPartial; ma.nBlocks = nb; ma.moments = h->dMoments;
-  HIPCK(timed(h, "moments_kernel", [&] { return launch_moments(ma, h->stream); }));
-  return HL_OK;
-}
-int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
-  MomentsArgs ma{}; ma.sc = h->sc; ma.rp = h->rp; ma.dS = h->dS; ma.moments = h->dMoments;
-  ma.bInit = bInit ? 1 : 0; ma.learnrate = h->cfg.learnrate; ma.epsAnneal = h->cfg.epsAnneal; ma.rRateFac = rRateFac;
-  HIPCK(launch_moments_apply(ma, h->stream));
-  return HL_OK;
-}
-
-// FIFO removal (MemoryProcessing::applyEpisodesRemovalAlgo, "oldest"): host bookkeeping + device nFar
-int applyRemoval(hl_learner* h) {
-  bool any = false;
-  while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
-    const EpMeta e = h->order.back();
-    HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
-    h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
-  }
-  if (any) { h->tableDirty = true; h->countsDirty = true; h->graphValid = false; }
-  return HL_OK;
-}
-
-int allreduceGrad(hl_learner* h) {
-  if (h->cfg.n_ranks <= 1) return HL_OK;
-  if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
-  NCCLCK(ncclAllReduce(h->G, h->G, (size_t)h->nParams, ncclFloat, ncclSum, h->comm, h->stream));
-  return HL_OK;
-}
-int allreduceCounters(hl_learner* h) {
-  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
-  NCCLCK(ncclAllReduce(h->sc->cnt, h->sc->cnt, 4, ncclInt64, ncclSum, h->comm, h->stream));
-  return HL_OK;
-}
-int allreduceMoments(hl_learner* h) {
-  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
-  NCCLCK(ncclAllReduce(h->dMoments, h->dMoments, (size_t)(2 * h->dS + 3), ncclDouble, ncclSum, h->comm, h->stream));
-  return HL_OK;
-}
-
-// one full step, eager launches (also the body captured into the graph for the plain case)
-int stepEager(hl_learner* h, const long long* dFlat) {
-  const long long k = h->nGradSteps + 1;
-  const bool periodic = (k % 1000) == 0;
-  const bool fuse = h->cfg.n_ranks <= 1;
-  int rc = launchTrain(h, dFlat, fuse); if (rc) return rc;
-  if (!fuse) { rc = allreduceGrad(h); if (rc) return rc; rc = launchAdam(h); if (rc) return rc; }
-  const bool evict = !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
-  if (!periodic && !evict && h->cfg.n_ranks <= 1) return launchPost(h, POST_AGG | POST_BETA);
-  rc = launchPost(h, POST_AGG); if (rc) return rc;
-  if (periodic) {
-    rc = launchPeriodicSweep(h); if (rc) return rc;
-    rc = launchMoments(h); if (rc) return rc;
-    rc = allreduceMoments(h); if (rc) return rc;
-    rc = launchMomentsApply(h, false, 10); if (rc) return rc;
-  }
-  if (evict) { rc = applyRemoval(h); if (rc) return rc; rc = flushPending(h); if (rc) return rc; }
-  rc = allreduceCounters(h); if (rc) return rc;
-  return launchPost(h, POST_BETA);
-}
-
-// Captures `nSteps` consecutive gradient steps into one executable graph.  Node sequence of a
-// step: [bookkeeping of the previous step (if pending) + sampling] -> forward GEMMs -> head ->
-// dX GEMMs -> dW GEMMs with fused Adam.  The bookkeeping of the LAST step of an hl_step() call
-// is flushed by an explicit post launch (flushPost).  A replay costs ~8 us of host/dispatch gap,
-// so long runs replay the GRAPH_UNROLL-step graph.
-constexpr int GRAPH_UNROLL = 20;
-int captureOne(hl_learner* h, int nSteps, hipGraph_t* g, hipGraphExec_t* ge) {
-  if (*ge) { hipGraphExecDestroy(*ge); *ge = nullptr; }
-  if (*g) { hipGraphDestroy(*g); *g = nullptr; }
-  HIPCK(hipStreamSynchronize(h->stream));
-  HIPCK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  int rc = HL_OK;
-  for (int s = 0; s < nSteps && !rc; ++s) rc = launchTrain(h, nullptr, true, true);
-  hipError_t e = hipStreamEndCapture(h->stream, g);
-  if (rc) return rc;
-  if (e != hipSuccess) return hipFail(h, e, "hipStreamEndCapture");
-  HIPCK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
-  return HL_OK;
-}
-int captureGraph(hl_learner* h) {
-  int rc = captureOne(h, 1, &h->graph, &h->graphExec); if (rc) return rc;
-  rc = captureOne(h, GRAPH_UNROLL, &h->graphN, &h->graphExecN); if (rc) return rc;
-  h->graphValid = true;
-  return HL_OK;
-}
-
 }  // namespace
+
+#include "step_exec.h"
 
 // =================================================================================================
 extern "C" {
@@ -641,7 +408,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(devAlloc(&h->M2, (size_t)h->nParams)); HIPCK(devAlloc(&h->G, (size_t)h->nParams));
   HIPCK(devAlloc(&h->sc, 1));
   h->ldX0 = (int)roundUp(h->dS, 16);
-  HIPCK(devAlloc(&h->X0, (size_t)h->Mmax * h->ldX0));
   for (int j = 0; j < h->nHidden; ++j) {
     DevHidden& d = h->hid[j];
     const size_t n = (size_t)h->Mmax * d.ldA;
@@ -651,16 +417,22 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   }
   h->ldDo = (int)roundUp(h->nDense, 16);
   HIPCK(devAlloc(&h->dOut, (size_t)B * h->ldDo));
-  DevBatch& bt = h->bt;
-  HIPCK(devAlloc(&bt.flat, B)); HIPCK(devAlloc(&bt.pos, B)); HIPCK(devAlloc(&bt.eid, B)); HIPCK(devAlloc(&bt.t, B));
-  HIPCK(devAlloc(&bt.slot, B)); HIPCK(devAlloc(&bt.nextOf, B)); HIPCK(devAlloc(&bt.nextSrc, B));
-  HIPCK(devAlloc(&bt.tag, B)); HIPCK(devAlloc(&bt.pEid, B)); HIPCK(devAlloc(&bt.pNextOf, B));
-  HIPCK(devAlloc(&bt.O, (size_t)2 * B * h->nOut)); HIPCK(devAlloc(&bt.G, (size_t)B * h->nOut));
-  HIPCK(devAlloc(&bt.rho, B)); HIPCK(devAlloc(&bt.dkl, B)); HIPCK(devAlloc(&bt.dq, B)); HIPCK(devAlloc(&bt.far, B));
-  HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B));
-  HIPCK(devAlloc(&bt.oldDQ, B)); HIPCK(devAlloc(&bt.oldDKL, B)); HIPCK(devAlloc(&bt.oldW, B)); HIPCK(devAlloc(&bt.oldV, B));
-  HIPCK(devAlloc(&bt.oldADV, B)); HIPCK(devAlloc(&bt.nextV, B)); HIPCK(devAlloc(&bt.oldNextV, B));
-  HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * h->dA));
+  for (int pb = 0; pb < 2; ++pb) {
+    DevBatch& bt = h->buf[pb].bt;
+    HIPCK(devAlloc(&h->buf[pb].X0, (size_t)h->Mmax * h->ldX0));
+    HIPCK(devAlloc(&bt.flat, B)); HIPCK(devAlloc(&bt.pos, B)); HIPCK(devAlloc(&bt.eid, B)); HIPCK(devAlloc(&bt.t, B));
+    HIPCK(devAlloc(&bt.slot, B)); HIPCK(devAlloc(&bt.nextOf, B)); HIPCK(devAlloc(&bt.nextSrc, B));
+    HIPCK(devAlloc(&bt.tag, B)); HIPCK(devAlloc(&bt.pEid, B)); HIPCK(devAlloc(&bt.pNextOf, B));
+    HIPCK(devAlloc(&bt.sVals, (size_t)std::max(B, 256)));
+    HIPCK(devAlloc(&bt.O, (size_t)2 * B * h->nOut)); HIPCK(devAlloc(&bt.G, (size_t)B * h->nOut));
+    HIPCK(devAlloc(&bt.rho, B)); HIPCK(devAlloc(&bt.dkl, B)); HIPCK(devAlloc(&bt.dq, B)); HIPCK(devAlloc(&bt.far, B));
+    HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B));
+    HIPCK(devAlloc(&bt.oldDQ, B)); HIPCK(devAlloc(&bt.oldDKL, B)); HIPCK(devAlloc(&bt.oldW, B)); HIPCK(devAlloc(&bt.oldV, B));
+    HIPCK(devAlloc(&bt.oldADV, B)); HIPCK(devAlloc(&bt.nextV, B)); HIPCK(devAlloc(&bt.oldNextV, B));
+    HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * h->dA));
+  }
+  HIPCK(hipStreamCreateWithFlags(&h->sSample, hipStreamNonBlocking));
+  HIPCK(hipStreamCreateWithFlags(&h->sPost, hipStreamNonBlocking));
   HIPCK(devAlloc(&h->dFlatGiven, B));
   HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16));
   HIPCK(devAlloc(&h->rp.stMean, h->dS)); HIPCK(devAlloc(&h->rp.stScale, h->dS)); HIPCK(devAlloc(&h->rp.stStd, h->dS));
@@ -687,22 +459,29 @@ int hl_destroy(hl_learner* h) {
   if (!h) return HL_OK;
   if (h->stream) hipStreamSynchronize(h->stream);
   timerFlush(h);
-  if (h->graphExec) hipGraphExecDestroy(h->graphExec);
-  if (h->graphExecN) hipGraphExecDestroy(h->graphExecN);
-  if (h->graphN) hipGraphDestroy(h->graphN);
-  if (h->graph) hipGraphDestroy(h->graph);
+  if (h->sSample) hipStreamSynchronize(h->sSample);
+  if (h->sPost) hipStreamSynchronize(h->sPost);
+  invalidateGraphs(h);
+  for (hipEvent_t e : h->evPool) hipEventDestroy(e);
   if (h->comm) ncclCommDestroy(h->comm);
-  void* ptrs[] = {h->W, h->M1, h->M2, h->G, h->sc, h->X0, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
+  void* ptrs[] = {h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
-    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->bt.tag, h->bt.pEid, h->bt.pNextOf, h->bt.flat, h->bt.pos, h->bt.eid, h->bt.t, h->bt.slot, h->bt.nextOf, h->bt.nextSrc, h->bt.O, h->bt.G,
-    h->bt.rho, h->bt.dkl, h->bt.dq, h->bt.far, h->bt.newDQ, h->bt.newDKL, h->bt.newW, h->bt.newV, h->bt.oldDQ,
-    h->bt.oldDKL, h->bt.oldW, h->bt.oldV, h->bt.oldADV, h->bt.nextV, h->bt.oldNextV, h->bt.oldNextADV, h->bt.gParam};
+    h->rp.stStd, h->rp.epTag, h->rp.posRec};
+  for (int pb = 0; pb < 2; ++pb) {
+    DevBatch& bt = h->buf[pb].bt;
+    void* bp[] = {h->buf[pb].X0, bt.sVals, bt.tag, bt.pEid, bt.pNextOf, bt.flat, bt.pos, bt.eid, bt.t, bt.slot, bt.nextOf, bt.nextSrc,
+      bt.O, bt.G, bt.rho, bt.dkl, bt.dq, bt.far, bt.newDQ, bt.newDKL, bt.newW, bt.newV, bt.oldDQ, bt.oldDKL, bt.oldW,
+      bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam};
+    for (void* q : bp) if (q) hipFree(q);
+  }
   for (void* p : ptrs) if (p) hipFree(p);
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);
+  if (h->sSample) hipStreamDestroy(h->sSample);
+  if (h->sPost) hipStreamDestroy(h->sPost);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h; return HL_OK;
 }
@@ -846,7 +625,7 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
   h->order.push_front(e);
   h->nTransitions += N - 1;
   h->pendingRetrace.push_back(eid);
-  h->tableDirty = true; h->countsDirty = true; h->graphValid = false;
+  h->tableDirty = true; h->countsDirty = true;
   return HL_OK;
 }
 
@@ -904,7 +683,7 @@ int hl_initialize(hl_learner* h) {
   int rc = flushPending(h); if (rc) return rc;
   if (h->cfg.n_ranks > 1 && !h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1: call hl_comm_init before hl_initialize");
   rc = allreduceCounters(h); if (rc) return rc;
-  rc = launchPost(h, POST_INIT); if (rc) return rc;                  // updateCounters(bInit)
+  rc = launchPost(h, 0, POST_INIT, h->stream); if (rc) return rc;     // updateCounters(bInit)
   rc = launchMoments(h); if (rc) return rc;                          // updateRewardsStats(bInit)
   rc = allreduceMoments(h); if (rc) return rc;
   rc = launchMomentsApply(h, true, 1); if (rc) return rc;
@@ -924,36 +703,29 @@ static int preStepChecks(hl_learner* h) {
 
 int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
   if (!h || n < 0) return HL_ERR_BAD_ARG;
-  for (int s = 0; s < n; ++s) {
+  int s = 0;
+  while (s < n) {
     int rc = preStepChecks(h); if (rc) return rc;
     const long long k = h->nGradSteps + 1;
-    const bool evict = !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
-    const bool plain = !flat && (k % 1000) != 0 && !evict && h->cfg.n_ranks <= 1 && !h->timing && h->useGraph;
+    const bool plain = !flat && (k % 1000) != 0 && !evictionDue(h) && h->cfg.n_ranks <= 1 && !h->timing && h->useGraph;
     if (plain) {
-      if (!h->graphValid) { rc = flushPost(h); if (rc) return rc; rc = captureGraph(h); if (rc) return rc; }
+      if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
       // plain steps available before the next 1000-step sweep and within this call
-      const long long untilSweep = 999 - (h->nGradSteps % 1000);
-      if (n - s >= GRAPH_UNROLL && untilSweep >= GRAPH_UNROLL) {
-        HIPCK(hipGraphLaunch(h->graphExecN, h->stream));
-        h->postPendingHost = true;
-        h->nGradSteps += GRAPH_UNROLL; s += GRAPH_UNROLL - 1;
-        continue;
-      }
-      HIPCK(hipGraphLaunch(h->graphExec, h->stream));
-      h->postPendingHost = true;
-    } else {
-      rc = flushPost(h); if (rc) return rc;
-      const long long* dFlat = nullptr;
-      if (flat) {
-        HIPCK(hipMemcpyAsync(h->dFlatGiven, flat + (size_t)s * h->B, h->B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-        HIPCK(hipStreamSynchronize(h->stream));
-        dFlat = h->dFlatGiven;
-      }
-      rc = stepEager(h, dFlat); if (rc) return rc;
+      const long long avail = std::min<long long>(n - s, 999 - (h->nGradSteps % 1000));
+      int done = 0;
+      rc = replaySteps(h, avail, &done); if (rc) return rc;
+      if (done > 0) { h->nGradSteps += done; s += done; continue; }
     }
-    h->nGradSteps += 1;
+    const long long* dFlat = nullptr;
+    if (flat) {
+      HIPCK(hipMemcpyAsync(h->dFlatGiven, flat + (size_t)s * h->B, h->B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+      HIPCK(hipStreamSynchronize(h->stream));
+      dFlat = h->dFlatGiven;
+    }
+    rc = stepEager(h, dFlat); if (rc) return rc;
+    h->nGradSteps += 1; s += 1;
   }
-  return flushPost(h);
+  return HL_OK;
 }
 
 // split form (host-side exchange of gradient / counters / moments, e.g. over the existing MPI path)
@@ -966,8 +738,12 @@ int hl_step_begin(hl_learner* h, const int64_t* flat) {
     HIPCK(hipStreamSynchronize(h->stream));
     dFlat = h->dFlatGiven;
   }
-  rc = launchTrain(h, dFlat, false); if (rc) return rc;
-  rc = launchPost(h, POST_AGG); if (rc) return rc;
+  rc = launchSample(h, 0, dFlat, true, h->stream); if (rc) return rc;
+  rc = launchForward(h, 0, h->stream); if (rc) return rc;
+  rc = launchHead(h, 0, h->stream); if (rc) return rc;
+  rc = launchBackward(h, 0, false, h->stream); if (rc) return rc;
+  h->lastParity = 0;
+  rc = launchPost(h, 0, POST_AGG, h->stream); if (rc) return rc;
   h->momentsPending = false;
   if (((h->nGradSteps + 1) % 1000) == 0) {
     rc = launchPeriodicSweep(h); if (rc) return rc;
@@ -1008,8 +784,8 @@ int hl_step_end(hl_learner* h) {
   if (!h->inStep) return fail(h, HL_ERR_STATE, "hl_step_end without hl_step_begin");
   int rc;
   if (h->momentsPending) { rc = launchMomentsApply(h, false, 10); if (rc) return rc; h->momentsPending = false; }
-  rc = launchAdam(h); if (rc) return rc;
-  rc = launchPost(h, POST_BETA); if (rc) return rc;
+  rc = launchAdam(h, 0); if (rc) return rc;
+  rc = launchPost(h, 0, POST_BETA, h->stream); if (rc) return rc;
   h->nGradSteps += 1; h->inStep = false;
   return HL_OK;
 }
@@ -1025,32 +801,33 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
   if (!h || !dst) return HL_ERR_BAD_ARG;
   const int B = h->B;
   HIPCK(hipStreamSynchronize(h->stream));
+  const DevBatch& bt = h->buf[h->lastParity].bt;
   auto copy = [&](const void* src, int64_t n) -> int {
     if (bytes < n) return HL_ERR_BAD_ARG;
     HIPCK(hipMemcpy(dst, src, (size_t)n, hipMemcpyDeviceToHost)); return HL_OK;
   };
   switch (what) {
-    case HL_TAP_FLAT: return copy(h->bt.flat, (int64_t)B * 8);
-    case HL_TAP_TAG: return copy(h->bt.tag, (int64_t)B * 8);
+    case HL_TAP_FLAT: return copy(bt.flat, (int64_t)B * 8);
+    case HL_TAP_TAG: return copy(bt.tag, (int64_t)B * 8);
     case HL_TAP_EPISODE: case HL_TAP_TSTEP: {
       if (bytes < (int64_t)B * 8) return HL_ERR_BAD_ARG;
       std::vector<int> tmp(B);
-      HIPCK(hipMemcpy(tmp.data(), what == HL_TAP_TSTEP ? h->bt.t : h->bt.pos, B * sizeof(int), hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy(tmp.data(), what == HL_TAP_TSTEP ? bt.t : bt.pos, B * sizeof(int), hipMemcpyDeviceToHost));
       int64_t* o = (int64_t*)dst;
       for (int b = 0; b < B; ++b) o[b] = tmp[b];
       return HL_OK;
     }
     case HL_TAP_STATE: {
       if (bytes < (int64_t)B * h->dS * 4) return HL_ERR_BAD_ARG;
-      HIPCK(hipMemcpy2D(dst, h->dS * 4, h->X0, h->ldX0 * 4, h->dS * 4, B, hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy2D(dst, h->dS * 4, h->buf[h->lastParity].X0, h->ldX0 * 4, h->dS * 4, B, hipMemcpyDeviceToHost));
       return HL_OK;
     }
-    case HL_TAP_OUTPUT: return copy(h->bt.O, (int64_t)B * h->nOut * 8);
-    case HL_TAP_OUTGRAD: return copy(h->bt.G, (int64_t)B * h->nOut * 8);
-    case HL_TAP_RHO: return copy(h->bt.rho, (int64_t)B * 8);
-    case HL_TAP_DKL: return copy(h->bt.dkl, (int64_t)B * 8);
-    case HL_TAP_DELTAQ: return copy(h->bt.dq, (int64_t)B * 8);
-    case HL_TAP_FAR: return copy(h->bt.far, (int64_t)B);
+    case HL_TAP_OUTPUT: return copy(bt.O, (int64_t)B * h->nOut * 8);
+    case HL_TAP_OUTGRAD: return copy(bt.G, (int64_t)B * h->nOut * 8);
+    case HL_TAP_RHO: return copy(bt.rho, (int64_t)B * 8);
+    case HL_TAP_DKL: return copy(bt.dkl, (int64_t)B * 8);
+    case HL_TAP_DELTAQ: return copy(bt.dq, (int64_t)B * 8);
+    case HL_TAP_FAR: return copy(bt.far, (int64_t)B);
     case HL_TAP_GRADSUM: return copy(h->G, (int64_t)h->nParams * 4);
   }
   return HL_ERR_BAD_ARG;
@@ -1121,3 +898,59 @@ int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* la
 }
 
 }  // extern "C"
+
+// ---- development aid: wall-clock time of ONE kernel of the step, replayed `reps` times from a graph
+//      (which: 0 sample, 1 fwd0, 2 fwd(last), 3 head, 4 dx(last), 5 dw+adam, 6 post, 7 whole overlapped step) ----
+extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, int variant, double* us_per_launch) {
+  if (!h || !us_per_launch || reps <= 0) return HL_ERR_BAD_ARG;
+  int rc = flushPending(h); if (rc) return rc;
+  h->dbgVariant = variant;
+  GraphSlot slot;
+  if (which == 7) {
+    rc = captureSteps(h, reps, &slot); if (rc) { h->dbgVariant = 0; return rc; }
+  } else {
+    const AdamHyper hyp = adamHyper(h, 0);
+    const StepBuf& sb = h->buf[0];
+    HIPCK(hipStreamSynchronize(h->stream));
+    HIPCK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int r = 0; r < reps && !rc; ++r) {
+      hipError_t e = hipSuccess;
+      switch (which) {
+        case 0: rc = launchSample(h, 0, nullptr, true, h->stream); break;
+        case 1: e = launch_gemm(h->dProbs + sb.fwdIdx[0], 1, sb.fwdBlocks[0], h->sc, hyp, nullptr, h->stream); break;
+        case 2: e = launch_gemm(h->dProbs + sb.fwdIdx[h->nHidden - 1], 1, sb.fwdBlocks[h->nHidden - 1], h->sc, hyp, nullptr, h->stream); break;
+        case 3: rc = launchHead(h, 0, h->stream); break;
+        case 4: if (!sb.dxIdx.empty()) e = launch_gemm(h->dProbs + sb.dxIdx[0], 1, sb.dxBlocks[0], h->sc, hyp, nullptr, h->stream); break;
+        case 5: e = launch_gemm(h->dProbs + sb.dwIdx, sb.dwCount, sb.dwBlocks, h->sc, hyp, nullptr, h->stream); break;
+        case 6: rc = launchPost(h, 0, POST_AGG, h->stream); break;
+        case 8: case 9: case 10: { const SampleArgs sa = sampleArgs(h, 0, nullptr, false);
+          e = launch_step_tail(nullptr, &sa, h->stream, which == 8 ? PH_A : which == 9 ? PH_B : PH_C); break; }
+        case 11: rc = launchPost(h, 0, POST_AGG | POST_BETA, h->stream); break;
+        default: break;
+      }
+      if (e != hipSuccess) rc = hipFail(h, e, "debug launch");
+    }
+    hipError_t e = hipStreamEndCapture(h->stream, &slot.graph);
+    if (!rc && e != hipSuccess) rc = hipFail(h, e, "hipStreamEndCapture");
+    if (!rc && hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(h, HL_ERR_HIP, "instantiate");
+    if (rc) { h->dbgVariant = 0; return rc; }
+  }
+  h->dbgVariant = 0;
+  HIPCK(hipGraphLaunch(slot.exec, h->stream)); HIPCK(hipStreamSynchronize(h->stream));
+  const int iters = 20;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) HIPCK(hipGraphLaunch(slot.exec, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *us_per_launch = dt / ((double)iters * reps) * 1e6;
+  hipGraphExecDestroy(slot.exec); hipGraphDestroy(slot.graph);
+  if (which == 7) h->nGradSteps += (long long)(iters + 1) * reps;
+  return HL_OK;
+}
+
+extern "C" HL_API int hl_debug_stamps(hl_learner* h, long long out[32]) {
+  if (!h || !out) return HL_ERR_BAD_ARG;
+  DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  std::memcpy(out, s.dbgT, sizeof(s.dbgT));
+  return HL_OK;
+}

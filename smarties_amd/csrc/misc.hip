@@ -9,24 +9,12 @@ namespace hl {
 // with SMARTIES_NESTEROV_ADAM, SMARTIES_SAFE_ADAM, SMARTIES_ADAMW (Settings/Bund.h).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-  const DevScalars* sc = a.sc;
-  const long long nStep = sc->nStep + 1;    // prepare_update incremented it before apply_update
-  const float _eta = (float)((double)a.eta0 / (1 + (double)(float)nStep * a.epsAnneal));
-  const float bt1 = (float)sc->adam_bt1, bt2 = (float)sc->adam_bt2;
-  const float eta = _eta * sqrtf(1 - bt2) / (1 - bt1);
-  const float B1 = 0.9f, B2 = 0.999f;
+  AdamCoef c; c.eta = a.sc->etaEff[a.parity]; c.lambda = a.lambda; c.fac = a.fac;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
        i += (long long)gridDim.x * blockDim.x) {
-    const float w = a.W[i];
-    const float penal = -w * a.lambda;
-    const float DW = a.fac * a.G[i];
-    float m1 = B1 * a.M1[i] + (1 - B1) * DW;
-    float m2 = B2 * a.M2[i] + (1 - B2) * DW * DW;
-    const float numer = B1 * m1 + (1 - B1) * DW;
-    m2 = m2 < m1 * m1 ? m1 * m1 : m2;
-    const float ret = numer / (FLT_EPSILON + sqrtf(m2));
-    a.M1[i] = m1; a.M2[i] = m2;
-    a.W[i] = w + eta * (ret + penal);
+    float w = a.W[i], m1 = a.M1[i], m2 = a.M2[i];
+    adamStep(c, a.G[i], w, m1, m2);
+    a.W[i] = w; a.M1[i] = m1; a.M2[i] = m2;
   }
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {

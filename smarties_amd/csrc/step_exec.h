@@ -1,0 +1,330 @@
+// smarties_amd/csrc/step_exec.h -- launch sequences of the gradient step (included by learner.cpp).
+//
+// One step = sample -> forward GEMMs -> head -> dX GEMMs -> dW GEMMs (+Adam) -> bookkeeping.
+// The sampler and the bookkeeping pass are single-workgroup dependency chains (~15 us and ~5 us)
+// that do not touch what the MLP kernels touch.  In the replayed graph they are horizontally
+// fused into the MLP launches as one extra workgroup each (tail_dev.h):
+//
+//   fwd0(k)   + sampler phase A of step k+1        (draw + Lemire acceptance)
+//   fwd1(k)   + sampler phase B of step k+1        (sort / unique / redraw, Adam draws)
+//   head(k)   + sampler phase C of step k+1        (index -> episode/step, gather)
+//   dX(k)     + bookkeeping of step k              (aggregates, beta / C, Adam scalars)
+//   dW(k)     (Adam fused into the epilogue)
+//
+// Step k reads minibatch buffer k&1 while step k+1's is being written, so the minibatch
+// workspace (indices, standardized states, row counts, Adam step size) is double buffered;
+// everything else is single buffered.  (A multi-stream graph with the same overlap was measured
+// 1.5x SLOWER than the serial graph on this runtime: each cross-queue edge costs several us.)
+// Eager launches (parity tests, 1000-step sweeps, eviction, multi-replica) run the same kernels
+// back to back on the main stream with stand-alone tail launches.
+#pragma once
+
+namespace {
+
+constexpr int GRAPH_SIZES[] = {64, 8, 2};     // steps per replayed graph, tried in this order
+
+void setTiles(GemmProblem& p, int& cursor) {
+  p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
+  if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
+  p.tileStart = cursor; cursor += p.tilesM * p.tilesN;
+}
+
+// GEMM problem tables, one set per minibatch buffer (they differ in X0 / gParam only)
+int buildProblems(hl_learner* h) {
+  std::vector<GemmProblem> P;
+  const int nH = h->nHidden, B = h->B;
+  for (int pb = 0; pb < 2; ++pb) {
+    StepBuf& sb = h->buf[pb];
+    sb.fwdIdx.clear(); sb.fwdBlocks.clear(); sb.dxIdx.clear(); sb.dxBlocks.clear();
+    // forward: one launch per hidden block
+    for (int j = 0; j < nH; ++j) {
+      const DevHidden& d = h->hid[j];
+      GemmProblem p{}; p.flavor = GEMM_F; p.epi = EPI_FWD; p.M = h->Mmax; p.N = d.size; p.K = d.nIn; p.dynRows = 1;
+      if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
+      else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
+      p.B = h->W + d.indW; p.ldb = d.ldW; p.bias = h->W + d.indB;
+      p.C = d.X; p.C2 = d.Y; p.C3 = d.hasRes ? d.Rr : nullptr; p.ldc = d.ldA; p.func = d.func;
+      if (d.hasRes) { p.resW = h->W + d.indWr; p.resB = h->W + d.indBr; p.resIn = p.A; p.ldRes = p.lda; p.resN = d.resW; }
+      int cur = 0; setTiles(p, cur);
+      sb.fwdIdx.push_back((int)P.size()); sb.fwdBlocks.push_back(cur); P.push_back(p);
+    }
+    // dX: block j = nH-1 .. 1: Dres_{j-1} = D_j W_j^T + Dres_j[:, :res] * w_j ; D_{j-1} = Dres_{j-1} * act'
+    for (int j = nH - 1; j >= 1; --j) {
+      const DevHidden& d = h->hid[j]; const DevHidden& q = h->hid[j - 1];
+      GemmProblem p{}; p.flavor = GEMM_X; p.epi = EPI_DX; p.M = B; p.N = d.nIn; p.K = d.size;
+      p.A = d.D; p.lda = d.ldA; p.B = h->W + d.indW; p.ldb = d.ldW;
+      p.C = q.Dres; p.C2 = q.D; p.ldc = q.ldA;
+      if (d.hasRes) { p.resIn = d.Dres; p.ldRes = d.ldA; p.resW = h->W + d.indWr; p.resN = d.resW; }
+      p.actX = q.X; p.actY = q.Y; p.ldAct = q.ldA; p.func = q.func;
+      int cur = 0; setTiles(p, cur);
+      sb.dxIdx.push_back((int)P.size()); sb.dxBlocks.push_back(cur); P.push_back(p);
+    }
+    // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
+    sb.dwIdx = (int)P.size(); int cur = 0;
+    for (int j = 0; j < nH; ++j) {
+      const DevHidden& d = h->hid[j];
+      GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = d.nIn + 1; p.N = d.size; p.K = B;
+      if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
+      else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
+      p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
+      setTiles(p, cur); P.push_back(p);
+      if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
+        GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
+        r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
+        setTiles(r, cur); P.push_back(r);
+        GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = d.resW; s.K = B;
+        s.A = d.Dres; s.lda = d.ldA; s.B = nullptr; s.C = h->G + d.indBr;
+        setTiles(s, cur); P.push_back(s);
+      }
+    }
+    { // output InnerProduct layer
+      const DevHidden& q = h->hid[nH - 1];
+      GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = q.size + 1; p.N = h->nDense; p.K = B;
+      p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; p.B = h->dOut; p.ldb = h->ldDo;
+      p.C = h->G + h->indWo; p.ldc = h->ldWo; p.biasOut = h->G + h->indBo;
+      setTiles(p, cur); P.push_back(p);
+      // ParamLayer::backward (Layers.h:522-546): bias gradient = column sums of the sigma-param deltas
+      GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
+      s.A = sb.bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
+      setTiles(s, cur); P.push_back(s);
+    }
+    sb.dwCount = (int)P.size() - sb.dwIdx; sb.dwBlocks = cur;
+    // second copy of the dW table with the Adam update fused into the epilogue (single replica:
+    // every gradient element is final inside the workgroup that produced it)
+    sb.dwAdamIdx = (int)P.size();
+    for (int i = 0; i < sb.dwCount; ++i) {
+      GemmProblem p = P[sb.dwIdx + i];
+      p.adam = 1;
+      const long long offC = p.C - h->G;
+      p.adW = h->W + offC; p.adM1 = h->M1 + offC; p.adM2 = h->M2 + offC;
+      if (p.biasOut) { const long long offB = p.biasOut - h->G; p.adbW = h->W + offB; p.adbM1 = h->M1 + offB; p.adbM2 = h->M2 + offB; }
+      P.push_back(p);
+    }
+  }
+  if (h->dProbs) hipFree(h->dProbs);
+  h->dProbs = nullptr;
+  HIPCK(devAlloc(&h->dProbs, P.size()));
+  HIPCK(hipMemcpy(h->dProbs, P.data(), P.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
+  return HL_OK;
+}
+
+AdamHyper adamHyper(const hl_learner* h, int parity) {
+  AdamHyper a{}; a.eta0 = (float)h->cfg.learnrate; a.lambda = (float)h->cfg.nnLambda; a.fac = (float)(1.0 / h->Bglobal);
+  a.epsAnneal = h->cfg.epsAnneal; a.parity = parity; a.variant = h->dbgVariant;
+  return a;
+}
+SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool computeEta) {
+  SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->buf[parity].bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
+  sa.X0 = h->buf[parity].X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
+  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
+  return sa;
+}
+PostArgs postArgs(hl_learner* h, int parity, int mode) {
+  PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->buf[parity].bt; pa.B = h->B; pa.mode = mode;
+  pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
+  pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = h->cfg.n_ranks;
+  pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate;
+  return pa;
+}
+HeadArgs headArgs(hl_learner* h, int parity) {
+  const DevHidden& q = h->hid[h->nHidden - 1];
+  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->buf[parity].bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense;
+  ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
+  ha.func = q.func; ha.params = h->W; ha.indWo = h->indWo; ha.indBo = h->indBo; ha.indBp = h->indBp; ha.ldWo = h->ldWo;
+  ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA; ha.parity = parity;
+  for (int i = 0; i < h->dA; ++i) ha.bounded[i] = h->cfg.bounded[i];
+  return ha;
+}
+
+int launchSample(hl_learner* h, int parity, const long long* dFlat, bool computeEta, hipStream_t s) {
+  const SampleArgs sa = sampleArgs(h, parity, dFlat, computeEta);
+  HIPCK(timed(h, "step_tail_kernel", s, [&] { return launch_sample(sa, s); }));
+  return HL_OK;
+}
+// `nextSample`: sampler phases of the NEXT step (buffer parity^1) ride along as extra workgroups:
+// phase A with the first forward GEMM, phase B with the last one, phase C with the head kernel.
+// `fusePost`: the bookkeeping of THIS step rides along the first backward launch.
+ExtraArgs extraSample(hl_learner* h, int parityNext, int phases) {
+  ExtraArgs ex{}; ex.role = 1; ex.phases = phases; ex.samp = sampleArgs(h, parityNext, nullptr, false);
+  return ex;
+}
+int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
+  const AdamHyper hyp = adamHyper(h, parity);
+  const StepBuf& sb = h->buf[parity];
+  char nm[32];
+  for (int j = 0; j < h->nHidden; ++j) {
+    snprintf(nm, sizeof(nm), "gemm16_fwd%d", j);
+    ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+    if (nextSample) {
+      int ph = 0;
+      if (j == 0) ph |= PH_A;
+      if (j == h->nHidden - 1) ph |= PH_B;
+      if (ph) { ex = extraSample(h, parity ^ 1, ph); pex = &ex; }
+    }
+    HIPCK(timed(h, nm, s, [&] { return launch_gemm(h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
+  }
+  return HL_OK;
+}
+int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
+  const HeadArgs ha = headArgs(h, parity);
+  ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_C); pex = &ex; }
+  HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
+  return HL_OK;
+}
+// fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
+int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false) {
+  const AdamHyper hyp = adamHyper(h, parity);
+  const StepBuf& sb = h->buf[parity];
+  ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+  if (fusePost) { ex.role = 2; ex.post = postArgs(h, parity, POST_AGG | POST_BETA); pex = &ex; }
+  char nm[32];
+  for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
+    snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
+    HIPCK(timed(h, nm, s, [&] { return launch_gemm(h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
+  }
+  // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
+  // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.
+  const ExtraArgs* pexW = sb.dxIdx.empty() ? pex : nullptr;
+  HIPCK(timed(h, "gemm16_dw", s, [&] {
+    return launch_gemm(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s); }));
+  return HL_OK;
+}
+int launchAdam(hl_learner* h, int parity) {
+  AdamArgs aa{}; aa.sc = h->sc; aa.W = h->W; aa.M1 = h->M1; aa.M2 = h->M2; aa.G = h->G; aa.n = h->nParams;
+  aa.eta0 = (float)h->cfg.learnrate; aa.lambda = (float)h->cfg.nnLambda; aa.fac = (float)(1.0 / h->Bglobal);
+  aa.epsAnneal = h->cfg.epsAnneal; aa.parity = parity;
+  HIPCK(timed(h, "adam_kernel", h->stream, [&] { return launch_adam(aa, h->stream); }));
+  return HL_OK;
+}
+int launchPost(hl_learner* h, int parity, int mode, hipStream_t s) {
+  const PostArgs pa = postArgs(h, parity, mode);
+  HIPCK(timed(h, "post_kernel", s, [&] { return launch_post(pa, s); }));
+  return HL_OK;
+}
+
+// every 1000th step: Episode::updateCumulative + full Retrace sweep, then reward/state statistics
+int launchPeriodicSweep(hl_learner* h) { return runSweep(h, nullptr, (int)h->order.size(), 1); }
+int launchMoments(hl_learner* h) {
+  const int nb = moments_blocks((int)h->order.size());
+  if (nb > h->momBlocksCap) {
+    HIPCK(devGrow(&h->dMomPartial, 0, (size_t)nb * 2 * (h->dS + 1), h->stream)); h->momBlocksCap = nb;
+  }
+  MomentsArgs ma{}; ma.sc = h->sc; ma.rp = h->rp; ma.dS = h->dS; ma.nEpisodes = (int)h->order.size();
+  ma.partial = h->dMomPartial; ma.nBlocks = nb; ma.moments = h->dMoments;
+  HIPCK(timed(h, "moments_kernel", h->stream, [&] { return launch_moments(ma, h->stream); }));
+  return HL_OK;
+}
+int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
+  MomentsArgs ma{}; ma.sc = h->sc; ma.rp = h->rp; ma.dS = h->dS; ma.moments = h->dMoments;
+  ma.bInit = bInit ? 1 : 0; ma.learnrate = h->cfg.learnrate; ma.epsAnneal = h->cfg.epsAnneal; ma.rRateFac = rRateFac;
+  HIPCK(launch_moments_apply(ma, h->stream));
+  return HL_OK;
+}
+
+// FIFO removal (MemoryProcessing::applyEpisodesRemovalAlgo, "oldest"): host bookkeeping + device nFar
+int applyRemoval(hl_learner* h) {
+  bool any = false;
+  while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
+    const EpMeta e = h->order.back();
+    HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
+    h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
+  }
+  if (any) { h->tableDirty = true; h->countsDirty = true; }
+  return HL_OK;
+}
+
+int allreduceGrad(hl_learner* h) {
+  if (h->cfg.n_ranks <= 1) return HL_OK;
+  if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
+  NCCLCK(ncclAllReduce(h->G, h->G, (size_t)h->nParams, ncclFloat, ncclSum, h->comm, h->stream));
+  return HL_OK;
+}
+int allreduceCounters(hl_learner* h) {
+  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
+  NCCLCK(ncclAllReduce(h->sc->cnt, h->sc->cnt, 4, ncclInt64, ncclSum, h->comm, h->stream));
+  return HL_OK;
+}
+int allreduceMoments(hl_learner* h) {
+  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
+  NCCLCK(ncclAllReduce(h->dMoments, h->dMoments, (size_t)(2 * h->dS + 3), ncclDouble, ncclSum, h->comm, h->stream));
+  return HL_OK;
+}
+
+bool evictionDue(const hl_learner* h) {
+  return !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
+}
+
+// one full step, eager launches on the main stream, minibatch buffer 0
+int stepEager(hl_learner* h, const long long* dFlat) {
+  hipStream_t s = h->stream;
+  const long long k = h->nGradSteps + 1;
+  const bool periodic = (k % 1000) == 0;
+  const bool fuse = h->cfg.n_ranks <= 1;
+  int rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc;
+  rc = launchForward(h, 0, s); if (rc) return rc;
+  rc = launchHead(h, 0, s); if (rc) return rc;
+  rc = launchBackward(h, 0, fuse, s); if (rc) return rc;
+  if (!fuse) { rc = allreduceGrad(h); if (rc) return rc; rc = launchAdam(h, 0); if (rc) return rc; }
+  h->lastParity = 0;
+  const bool evict = evictionDue(h);
+  if (!periodic && !evict && h->cfg.n_ranks <= 1) return launchPost(h, 0, POST_AGG | POST_BETA, s);
+  rc = launchPost(h, 0, POST_AGG, s); if (rc) return rc;
+  if (periodic) {
+    rc = launchPeriodicSweep(h); if (rc) return rc;
+    rc = launchMoments(h); if (rc) return rc;
+    rc = allreduceMoments(h); if (rc) return rc;
+    rc = launchMomentsApply(h, false, 10); if (rc) return rc;
+  }
+  if (evict) { rc = applyRemoval(h); if (rc) return rc; rc = flushPending(h); if (rc) return rc; }
+  rc = allreduceCounters(h); if (rc) return rc;
+  return launchPost(h, 0, POST_BETA, s);
+}
+
+// ---- replayed graph: U steps on one stream, tail work horizontally fused into the MLP kernels ----
+int captureSteps(hl_learner* h, int U, GraphSlot* slot) {
+  if (slot->exec) { hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
+  if (slot->graph) { hipGraphDestroy(slot->graph); slot->graph = nullptr; }
+  hipStream_t s0 = h->stream;
+  HIPCK(hipStreamSynchronize(s0));
+  HIPCK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
+  int rc = launchSample(h, 0, nullptr, true, s0);       // first minibatch of the graph: its own launch
+  for (int j = 0; j < U && !rc; ++j) {
+    const int p = j & 1;
+    const bool more = j + 1 < U;                        // pre-sample step j+1 while step j computes
+    rc = launchForward(h, p, s0, more); if (rc) break;
+    rc = launchHead(h, p, s0, more); if (rc) break;
+    rc = launchBackward(h, p, true, s0, true); if (rc) break;
+  }
+  hipError_t e = hipStreamEndCapture(s0, &slot->graph);
+  if (rc) return rc;
+  if (e != hipSuccess) return hipFail(h, e, "hipStreamEndCapture");
+  HIPCK(hipGraphInstantiate(&slot->exec, slot->graph, nullptr, nullptr, 0));
+  slot->steps = U;
+  return HL_OK;
+}
+
+void invalidateGraphs(hl_learner* h) {
+  for (auto& g : h->graphs) {
+    if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    if (g.graph) { hipGraphDestroy(g.graph); g.graph = nullptr; }
+  }
+}
+
+// run as many plain steps as possible (<= avail) from one graph replay; returns steps done (0 = none)
+int replaySteps(hl_learner* h, long long avail, int* done) {
+  *done = 0;
+  for (size_t i = 0; i < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]); ++i) {
+    const int U = GRAPH_SIZES[i];
+    if (avail < U) continue;
+    GraphSlot& g = h->graphs[i];
+    if (!g.exec) { int rc = captureSteps(h, U, &g); if (rc) return rc; }
+    HIPCK(hipGraphLaunch(g.exec, h->stream));
+    h->lastParity = (U - 1) & 1;
+    *done = U;
+    return HL_OK;
+  }
+  return HL_OK;
+}
+
+}  // namespace

@@ -1,0 +1,450 @@
+// smarties_amd/csrc/tail_dev.h -- device code of the step tail: minibatch sampler and per-step
+// bookkeeping.  Both are single-workgroup dependency chains.  They can run as their own kernel
+// (sample.hip) or as ONE EXTRA WORKGROUP appended to the grid of an MLP kernel (gemm16.hip,
+// head.hip): the sampler of step k+1 is cut into three phases that ride along fwd0(k), fwd1(k)
+// and head(k), the bookkeeping of step k rides along dX(k) -- "horizontal fusion", which hides
+// ~20 us of serial work per step behind kernels that leave 255 CUs idle anyway, without the
+// cross-queue synchronisation a multi-stream graph costs on this runtime.
+//
+//   sampler     Sample_uniform::sample + Sampling::IDtoSeqStep (Sampling.cpp:26-47,82-96) over
+//               std::mt19937 generators[0] with libstdc++'s uniform_int_distribution (Lemire), the
+//               gather of MemoryBuffer::sampleMinibatch (MemoryBuffer.cpp:413-429) and the
+//               per-Adam-step generator draw (Optimizer.cpp:139).
+//   bookkeeping Episode::updateCumulative_atomic / updateValues_atomic (Episode.h:112-145) in
+//               minibatch order, MemoryProcessing::updateTrainingStatistics scalars (:187-259),
+//               updateCounters (:46-92), Adam beta_t bookkeeping (Optimizer.cpp:155-160), step
+//               counter (Learner.cpp:130-133)
+//
+// Organised to minimise workgroup barriers and exposed memory latency: ballot-based scans, a
+// bitonic sort whose strides < 64 run inside a wavefront on registers, an interpolation guess into
+// a one-record-per-position episode table (one 64-byte fetch resolves flat index -> episode, step,
+// slot, truncation for equal-length episodes; bounded binary search otherwise), and per-sample
+// slots kept in LDS for the gather.
+#pragma once
+#include "dev_common.h"
+
+namespace hl {
+
+// development time stamps (100 MHz constant clock), enabled with -DHL_TAIL_STAMPS
+#ifdef HL_TAIL_STAMPS
+#define TSTAMP(sc, i) do { if (threadIdx.x == 0) (sc)->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(sc, i) do { } while (0)
+#endif
+
+#define SMAXB 1024
+#define SMAXK (SMAXB / 256)
+
+// ---------------------------------------------------------------------------------------------
+// bookkeeping ("post") part
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aggValues(float* ag, float oldV, float oldADV, float V, float Q) {
+  const float oldQ = oldADV + oldV;
+  ag[AGG_SUMQ2] += Q * Q - oldQ * oldQ;
+  ag[AGG_SUMQ] += Q - oldQ;
+  ag[AGG_MAXQ] = fmaxf(ag[AGG_MAXQ], Q);
+  ag[AGG_MINQ] = fminf(ag[AGG_MINQ], Q);
+}
+
+__device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs) {
+  DevScalars* sc = a.sc;
+  const int tid = threadIdx.x, B = a.B;
+  // every scalar the pass needs, fetched once up front (uniform loads); thread 0 writes the
+  // results back at the end without any further dependent global read
+  const double Cmax0 = sc->Cmax, Cinv0 = sc->Cinv, beta0 = sc->beta, alpha0 = sc->alpha;
+  const double ema0 = sc->maxAbsErrEMA, bt1 = sc->adam_bt1, bt2 = sc->adam_bt2;
+  const long long nGrad0 = sc->nGradSteps, nFarTot0 = sc->nFarTotal, nFarStat0 = sc->nFarStat;
+  const long long nTrans = sc->nTransitions, cnt2 = sc->cnt[2], cnt3 = sc->cnt[3], nStep0 = sc->nStep;
+  const float maxAll0 = sc->maxAbsErrAll;
+  TSTAMP(sc, 16);
+  if (tid == 0) { *sFarDelta = 0; *sMaxAbs = 0u; }
+  __syncthreads();
+  TSTAMP(sc, 17);
+  long long nFarStat = nFarStat0; float maxAll = maxAll0;
+  if (a.mode & POST_AGG) {
+    const float C = (float)Cmax0, invC = (float)Cinv0;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+      const int b = b0 + tid;
+      const bool in = b < B;
+      // round 1: everything indexed by the sample (coalesced), unconditionally
+      const int e = in ? a.bt.pEid[b] : -1;
+      const int ePrev = (in && b > 0) ? a.bt.pEid[b - 1] : -2;
+      const int eNext = (in && b + 1 < B) ? a.bt.pEid[b + 1] : -3;
+      const int nxt0 = in ? a.bt.pNextOf[b] : -1;
+      float E0 = 0, D0 = 0, W0 = 0, V0 = 0, oW0 = 0, oE0 = 0, oD0 = 0, oV0 = 0, oA0 = 0, Vn0 = 0, oNV0 = 0, oNA0 = 0;
+      if (in) {
+        E0 = a.bt.newDQ[b]; D0 = a.bt.newDKL[b]; W0 = a.bt.newW[b]; V0 = a.bt.newV[b];
+        oW0 = a.bt.oldW[b]; oE0 = a.bt.oldDQ[b]; oD0 = a.bt.oldDKL[b]; oV0 = a.bt.oldV[b]; oA0 = a.bt.oldADV[b];
+        Vn0 = a.bt.nextV[b]; oNV0 = a.bt.oldNextV[b]; oNA0 = a.bt.oldNextADV[b];
+      }
+      if (!in || ePrev == e) continue;                    // not the leader of this episode's run
+      // round 2: the episode record
+      float* ag = a.rp.epAgg + (size_t)e * AGG_N;
+      const float Nf = (float)a.rp.epN[e];
+      float g[AGG_N];
+#pragma unroll
+      for (int q = 0; q < AGG_N; ++q) g[q] = ag[q];
+      const float invN = 1 / Nf;
+      const long long before = farSteps(Nf, g[AGG_FRACFAR]);
+      int j = b; bool more = true;
+      float E = E0, D = D0, W = W0, Vf = V0, oW = oW0, oE = oE0, oD = oD0, oV = oV0, oA = oA0, Vn = Vn0, oNV = oNV0, oNA = oNA0;
+      int nxt = nxt0;
+      while (more) {
+        if (nxt >= 0) aggValues(g, oNV, oNA, Vn, Vn);     // setValues(t+1, Vnext) comes first
+        const float wasFar = (oW > C || oW < invC) ? 1.f : 0.f;
+        const float isFar = (W > C || W < invC) ? 1.f : 0.f;
+        g[AGG_AVGKL] += invN * (D - oD);
+        g[AGG_FRACFAR] += invN * (isFar - wasFar);
+        g[AGG_AVGSQERR] += invN * (E * E - oE * oE);
+        g[AGG_MAXABSERR] = fmaxf(g[AGG_MAXABSERR], fabsf(E));
+        aggValues(g, oV, oA, Vf, Vf);
+        // further samples of the same episode (rare): fetched on demand, in minibatch order
+        const int en = (j == b) ? eNext : ((j + 1 < B) ? a.bt.pEid[j + 1] : -3);
+        more = (en == e);
+        if (more) {
+          ++j;
+          nxt = a.bt.pNextOf[j];
+          E = a.bt.newDQ[j]; D = a.bt.newDKL[j]; W = a.bt.newW[j]; Vf = a.bt.newV[j];
+          oW = a.bt.oldW[j]; oE = a.bt.oldDQ[j]; oD = a.bt.oldDKL[j]; oV = a.bt.oldV[j]; oA = a.bt.oldADV[j];
+          Vn = a.bt.nextV[j]; oNV = a.bt.oldNextV[j]; oNA = a.bt.oldNextADV[j];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < AGG_N; ++q) ag[q] = g[q];
+      const long long after = farSteps(Nf, g[AGG_FRACFAR]);
+      if (after != before) atomicAdd((unsigned long long*)sFarDelta, (unsigned long long)(after - before));
+      atomicMax(sMaxAbs, __float_as_uint(fmaxf(g[AGG_MAXABSERR], 0.f)));
+    }
+    TSTAMP(sc, 18);
+    __syncthreads();
+    TSTAMP(sc, 19);
+    if (tid == 0) {
+      long long nFarTot = nFarTot0 + *sFarDelta;
+      maxAll = fmaxf(maxAll0, __uint_as_float(*sMaxAbs));
+      // updateTrainingStatistics: ReF-ER clip annealing for the NEXT sampling (:193-196)
+      const double Cm = 1 + a.clipImpWeight / (1 + (double)(nGrad0 + 1) * a.epsAnneal);
+      if (Cm <= 1) nFarTot = 0;
+      nFarStat = nFarTot;
+      sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
+      sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
+    }
+  }
+  if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {
+    // updateCounters (:46-92); with several replicas cnt[] holds the all-reduced counters
+    const long long nFar = a.nRanks > 1 ? cnt2 : nFarStat;
+    const long long nStored = a.nRanks > 1 ? cnt3 : nTrans;
+    const double fracOffPol = (double)nFar / (double)(nStored > 1 ? nStored : 1);
+    const double nDataSize = fmax(a.maxObsGlobal, (double)nStored);
+    const double learnRefer = 0.1 * a.batchGlobal / nDataSize;
+    const bool dec = fracOffPol > a.penalTol;
+    sc->beta = dec ? (1 - fmin(learnRefer, beta0)) * beta0
+                   : (1 - fmin(learnRefer, beta0)) * beta0 + fmin(learnRefer, 1 - beta0);
+    const bool decA = fabs(a.penalTol - fracOffPol) < 1e-3;
+    sc->alpha = decA ? (1 - fmin(learnRefer, alpha0)) * alpha0
+                     : (1 - fmin(learnRefer, alpha0)) * alpha0 + fmin(learnRefer, 1 - alpha0);
+    if (a.mode & POST_BETA) {
+      // stats.maxAbsError EMA (:239-240) uses the replica-local data size
+      const double lrLoc = 0.1 * a.batchGlobal / fmax(a.maxObsGlobal, (double)nTrans);
+      sc->maxAbsErrEMA = ema0 + lrLoc * ((double)maxAll - ema0);
+      double nb1 = bt1 * 0.9; if (nb1 < (double)FLT_EPSILON) nb1 = 0;
+      double nb2 = bt2 * 0.999; if (nb2 < (double)FLT_EPSILON) nb2 = 0;
+      sc->adam_bt1 = nb1; sc->adam_bt2 = nb2;
+      sc->nStep = nStep0 + 1;
+      sc->nGradSteps = nGrad0 + 1;
+      // Adam step size of the NEXT step (read by its dW epilogue from the other buffer slot)
+      sc->etaEff[a.parity ^ 1] = adamEtaEff(nStep0 + 1, nb1, nb2, a.eta0, a.epsAnneal);
+    }
+  }
+  TSTAMP(sc, 20);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mt19937 (state in LDS)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mtTemper(unsigned z) {
+  z ^= (z >> 11); z ^= (z << 7) & 0x9d2c5680u; z ^= (z << 15) & 0xefc60000u; z ^= (z >> 18);
+  return z;
+}
+__device__ __forceinline__ unsigned mtF(unsigned a, unsigned b) {
+  const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ void mtTwist(unsigned* x, unsigned* xo) {
+  const int tid = threadIdx.x;
+  for (int k = tid; k < 624; k += 256) xo[k] = x[k];
+  __syncthreads();
+  if (tid < 227) x[tid] = xo[tid + 397] ^ mtF(xo[tid], xo[tid + 1]);
+  __syncthreads();
+  if (tid < 227) x[227 + tid] = x[tid] ^ mtF(xo[227 + tid], xo[228 + tid]);
+  __syncthreads();
+  if (tid < 169) x[454 + tid] = x[227 + tid] ^ mtF(xo[454 + tid], xo[455 + tid]);
+  __syncthreads();
+  if (tid == 0) x[623] = x[396] ^ mtF(xo[623], x[0]);
+  __syncthreads();
+}
+// append n raw tempered words to raw[0..n); *pPos lives in LDS; all threads call
+__device__ void mtDraw(unsigned* x, unsigned* xo, int* pPos, unsigned* raw, int n) {
+  int done = 0;
+  while (done < n) {
+    int pos = *pPos;
+    __syncthreads();
+    if (pos >= 624) { mtTwist(x, xo); pos = 0; }
+    const int take = min(n - done, 624 - pos);
+    for (int i = threadIdx.x; i < take; i += 256) raw[done + i] = mtTemper(x[pos + i]);
+    if (threadIdx.x == 0) *pPos = pos + take;
+    __syncthreads();
+    done += take;
+  }
+}
+
+// exclusive scan of one flag per element, element index e = r*256 + tid (r < K); returns the total.
+// Two barriers per row of 256 elements (wave ballot + 4 wave totals through LDS).
+__device__ int scanRows(int K, const bool* flag, int* excl, int* sWave /*[4]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;
+  for (int r = 0; r < K; ++r) {
+    const unsigned long long m = __ballot(flag[r]);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sWave[wave] = __popcll(m);
+    __syncthreads();
+    const int w0 = sWave[0], w1 = sWave[1], w2 = sWave[2], w3 = sWave[3];
+    excl[r] = base + within + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    base += w0 + w1 + w2 + w3;
+    __syncthreads();
+  }
+  return base;
+}
+
+// bitonic sort of vals[0..Bp) (u32, Bp = 256*K a power of two); strides < 64 inside a wavefront
+__device__ __forceinline__ unsigned cmpx(unsigned key, unsigned other, bool lower, bool up) {
+  const unsigned mn = min(key, other), mx = max(key, other);
+  return (lower == up) ? mn : mx;
+}
+__device__ void waveLocalRounds(unsigned* vals, int Bp, int k, int jStart) {
+  // every wave owns the 64-element blocks wave, wave+4, ...
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int blk = wave; blk * 64 < Bp; blk += 4) {
+    const int i = blk * 64 + lane;
+    unsigned key = vals[i];
+    if (k <= 64) {
+      for (int kk = 2; kk <= k; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1)
+          key = cmpx(key, (unsigned)__shfl_xor((int)key, j, 64), (i & j) == 0, (i & kk) == 0);
+    } else {
+      for (int j = jStart; j > 0; j >>= 1)
+        key = cmpx(key, (unsigned)__shfl_xor((int)key, j, 64), (i & j) == 0, (i & k) == 0);
+    }
+    vals[i] = key;
+  }
+}
+__device__ void bitonicSort(unsigned* vals, int Bp) {
+  __syncthreads();
+  waveLocalRounds(vals, Bp, 64, 32);              // all stages k = 2..64
+  for (int k = 128; k <= Bp; k <<= 1) {
+    for (int j = k >> 1; j >= 64; j >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < Bp / 2; t += 256) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
+        const unsigned a = vals[i], b = vals[i | j];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { vals[i] = b; vals[i | j] = a; }
+      }
+    }
+    __syncthreads();
+    waveLocalRounds(vals, Bp, k, 32);
+  }
+  __syncthreads();
+}
+
+// sampler phases: A = draw + Lemire acceptance, B = sort / unique / redraw + Adam draws,
+// C = index -> (episode, step), truncated-next rows, gather.  Between phases the candidate
+// indices live in bt.sVals (HBM) and the generator in DevScalars::rng.
+
+// draw accepted values into vals[from..B) (Lemire rejection, words consumed in order)
+__device__ void drawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* raw, unsigned* vals, int* sWave,
+                             int from, int B, int K, unsigned range, unsigned threshold) {
+  const int tid = threadIdx.x;
+  int filled = from;
+  while (filled < B) {
+    const int need = B - filled;
+    mtDraw(x, xo, sPos, raw, need);
+    bool fl[SMAXK]; int ex[SMAXK]; unsigned v[SMAXK];
+    for (int r = 0; r < K; ++r) {
+      const int i = r * 256 + tid;
+      fl[r] = false; v[r] = 0;
+      if (i < need) {
+        const unsigned long long prod = (unsigned long long)raw[i] * (unsigned long long)range;
+        fl[r] = (unsigned)prod >= threshold; v[r] = (unsigned)(prod >> 32);
+      }
+    }
+    const int acc = scanRows(K, fl, ex, sWave);
+    for (int r = 0; r < K; ++r) if (fl[r]) vals[filled + ex[r]] = v[r];
+    filled += acc;
+  }
+  __syncthreads();
+}
+// sort vals[0..B) and remove duplicates (std::sort + std::unique); returns the unique count
+__device__ int sortUnique(unsigned* vals, int* sWave, int B, int Bp, int K) {
+  const int tid = threadIdx.x;
+  for (int i = B + tid; i < Bp; i += 256) vals[i] = 0xFFFFFFFFu;
+  bitonicSort(vals, Bp);
+  bool fl[SMAXK]; int ex[SMAXK]; unsigned v[SMAXK];
+  for (int r = 0; r < K; ++r) {
+    const int i = r * 256 + tid;
+    v[r] = i < B ? vals[i] : 0u;
+    fl[r] = i < B && (i == 0 || v[r] != vals[i - 1]);
+  }
+  const int nu = scanRows(K, fl, ex, sWave);     // (barriers inside: all reads of vals are done)
+  for (int r = 0; r < K; ++r) if (fl[r]) vals[ex[r]] = v[r];
+  __syncthreads();
+  return nu;
+}
+
+// LDS footprint of the tail code (carved from the hosting kernel's LDS block, which the extra
+// workgroup does not otherwise use)
+#define TAIL_LDS_BYTES (8 * SMAXB + 4 * (624 + 624 + SMAXB + SMAXB + SMAXB) + 64)
+
+__device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* smem) {
+  long long* sSlot = reinterpret_cast<long long*>(smem);            // [SMAXB]   (8-byte aligned first)
+  unsigned* x = reinterpret_cast<unsigned*>(smem + 8 * SMAXB);      // [624]
+  unsigned* xo = x + 624;                                           // [624]
+  unsigned* raw = xo + 624;                                         // [SMAXB]
+  unsigned* vals = raw + SMAXB;                                     // [SMAXB]
+  int* sNextRow = reinterpret_cast<int*>(vals + SMAXB);             // [SMAXB]
+  int* sWave = sNextRow + SMAXB;                                    // [4]
+  int* sPos = sWave + 4;
+  const int tid = threadIdx.x;
+  DevScalars* sc = a.sc;
+  TSTAMP(sc, 0);
+  const int B = a.B;
+  int Bp = 256; while (Bp < B) Bp <<= 1;
+  const int K = Bp / 256;
+  const bool rngNeeded = (phases & (PH_A | PH_B)) != 0;
+  if (rngNeeded) {
+    for (int k = tid; k < 624; k += 256) x[k] = sc->rng[k];
+    if (tid == 0) *sPos = (int)sc->rngPos;
+  }
+  const unsigned long long nData = (unsigned long long)sc->nTransitions;
+  const int nEp = (int)sc->nEpisodes;
+  const unsigned range = (unsigned)nData;
+  const unsigned threshold = range ? (0u - range) % range : 0u;
+  if ((phases & (PH_B | PH_C)) && !(phases & PH_A))
+    for (int i = tid; i < B; i += 256) vals[i] = a.bt.sVals[i];
+  __syncthreads();
+  TSTAMP(sc, 1);
+
+  if (phases & PH_A) {
+    if (a.flatGiven) { for (int i = tid; i < B; i += 256) vals[i] = (unsigned)a.flatGiven[i]; __syncthreads(); }
+    else drawAccepted(x, xo, sPos, raw, vals, sWave, 0, B, K, range, threshold);
+  }
+  TSTAMP(sc, 2);
+  if (phases & PH_B) {
+    if (!a.flatGiven) {
+      int have = sortUnique(vals, sWave, B, Bp, K);
+      TSTAMP(sc, 3);
+      while (have < B) {                       // duplicates: redraw the tail (Sampling.cpp:86-93)
+        drawAccepted(x, xo, sPos, raw, vals, sWave, have, B, K, range, threshold);
+        have = sortUnique(vals, sWave, B, Bp, K);
+      }
+    }
+    // the generator draws of AdamOptimizer::apply_update (one per reference thread)
+    if (a.adamDraws > 0) mtDraw(x, xo, sPos, raw, a.adamDraws);
+  }
+  TSTAMP(sc, 4);
+  if (rngNeeded) {
+    for (int k = tid; k < 624; k += 256) sc->rng[k] = x[k];
+    if (tid == 0) sc->rngPos = (unsigned)*sPos;
+  }
+  if (!(phases & PH_C)) {
+    for (int i = tid; i < B; i += 256) a.bt.sVals[i] = vals[i];
+    return;
+  }
+
+  // ---- IDtoSeqStep: interpolation guess into the per-position table, then binary search ----
+  bool hasNext[SMAXK]; int nextIdx[SMAXK];
+  for (int r = 0; r < K; ++r) {
+    const int b = r * 256 + tid;
+    hasNext[r] = false;
+    if (b < B) {
+      const long long f = (long long)vals[b];
+      int k0 = (int)(((double)f * (double)nEp) / (double)nData);
+      k0 = min(max(k0, 0), nEp - 1);
+      PosRec rec = a.rp.posRec[k0];
+      const long long p1 = a.rp.posRec[k0 + 1].prefix;
+      int lo = k0;
+      if (f < rec.prefix || f >= p1) {
+        int l = f < rec.prefix ? 0 : k0 + 1, hgh = f < rec.prefix ? k0 : nEp;   // largest k in [l,hgh): prefix[k] <= f
+        while (hgh - l > 1) { const int mid = (l + hgh) >> 1; if (a.rp.posRec[mid].prefix <= f) l = mid; else hgh = mid; }
+        lo = l; rec = a.rp.posRec[lo];
+      }
+      const int t = (int)(f - rec.prefix);
+      const int e = rec.eidTerm & 0x7fffffff;
+      const bool term = rec.eidTerm < 0;
+      a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = e; a.bt.t[b] = t; a.bt.tag[b] = rec.tag;
+      a.bt.slot[b] = rec.off + t; sSlot[b] = rec.off + t;
+      hasNext[r] = (t + 2 == rec.N && !term);      // Episode::isTruncated(t+1) (Episode.h:158-161)
+    }
+  }
+  TSTAMP(sc, 5);
+  const int nNext = scanRows(K, hasNext, nextIdx, sWave);
+  TSTAMP(sc, 6);
+  for (int r = 0; r < K; ++r) {
+    const int b = r * 256 + tid;
+    if (b < B) {
+      if (hasNext[r]) { a.bt.nextOf[b] = B + nextIdx[r]; a.bt.nextSrc[nextIdx[r]] = b; sNextRow[b] = B + nextIdx[r]; }
+      else { a.bt.nextOf[b] = -1; sNextRow[b] = -1; }
+    }
+  }
+  if (tid == 0) {
+    sc->nNext[a.parity] = nNext; sc->nRows[a.parity] = B + nNext;
+    // first step of a launch sequence: derive this step's Adam step size from the canonical scalars
+    if (a.computeEta) sc->etaEff[a.parity] = adamEtaEff(sc->nStep, sc->adam_bt1, sc->adam_bt2, a.eta0, a.epsAnneal);
+  }
+  __syncthreads();
+  TSTAMP(sc, 7);
+  // ---- gather: Episode::standardizedState (Episode.h:172-183) for s_t and truncated s_{t+1} ----
+  // all loads of a thread are issued before its first store (one exposed HBM round trip); the
+  // per-component mean / scale come from LDS (staged at kernel start into raw[], free by now)
+  const int dS = a.dS, total = B * dS;
+  float* sMean = reinterpret_cast<float*>(raw);            // [dS]   (dS <= SMAXB / 2)
+  float* sScale = sMean + SMAXB / 2;
+  for (int i = tid; i < dS; i += 256) { sMean[i] = a.rp.stMean[i]; sScale[i] = a.rp.stScale[i]; }
+  __syncthreads();
+  constexpr int GU = 20;                                   // elements per thread per round
+  for (int e0 = tid; e0 < total; e0 += 256 * GU) {
+    float sv[GU], sn[GU]; int bb[GU], ii[GU], nr[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int e = e0 + 256 * u;
+      bb[u] = -1; sv[u] = 0.f; sn[u] = 0.f; ii[u] = 0; nr[u] = -1;
+      if (e < total) {
+        const int b = e / dS; bb[u] = b; ii[u] = e - b * dS;
+        const long long sl = sSlot[b];
+        sv[u] = a.rp.S[(size_t)sl * dS + ii[u]];
+        nr[u] = sNextRow[b];
+        if (nr[u] >= 0) sn[u] = a.rp.S[(size_t)(sl + 1) * dS + ii[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) if (bb[u] >= 0) {
+      const float mu = sMean[ii[u]], scl = sScale[ii[u]];
+      a.X0[(size_t)bb[u] * a.ldX0 + ii[u]] = (sv[u] - mu) * scl;
+      if (nr[u] >= 0) a.X0[(size_t)nr[u] * a.ldX0 + ii[u]] = (sn[u] - mu) * scl;
+    }
+  }
+  TSTAMP(sc, 8);
+}
+
+__device__ void postPhase(const PostArgs& a, unsigned char* smem) {
+  long long* sFarDelta = reinterpret_cast<long long*>(smem);
+  unsigned* sMaxAbs = reinterpret_cast<unsigned*>(smem + 8);
+  postPart(a, sFarDelta, sMaxAbs);
+}
+
+// the extra workgroup of an MLP kernel: role 1 = sampler phases (for the NEXT step), 2 = bookkeeping
+__device__ __forceinline__ void runExtra(const ExtraArgs& ex, unsigned char* smem) {
+  if (ex.role == 1) samplePhases(ex.samp, ex.phases, smem);
+  else if (ex.role == 2) postPhase(ex.post, smem);
+}
+
+}  // namespace hl
