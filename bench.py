@@ -14,7 +14,7 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the reference's mul
 (strong scaling), one fp32 gradient all-reduce (RCCL over xGMI) per step.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the library's
-stream around every launch of the dominant kernel (second, eager pass); `cpu_baseline` times the
+stream (hl_kernel_profile: graph-replayed launches of each kernel of the step); `cpu_baseline` times the
 compiled reference (oracle/_ref, kind "reference") -- or the single-threaded CPU oracle
 (kind "port") when the reference binary is absent -- on a bounded sample of the same workload.
 """
@@ -40,29 +40,47 @@ CFG = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=256,
            explNoise=0.4472135955, outWeightsPrefac=0.1, nnLambda=0.0, randSeed=42)
 
 
-def kernel_work(name, B, dS, dA, hidden, nParams):
-    """Algorithmic FLOPs / bytes of one launch of the named kernel (kernel table)."""
+def step_kernels(B, dS, dA, hidden, nParams):
+    """The five launches of one replayed step: (profile id, name in a kernel trace, bound, algorithmic
+    work per launch).  Work = FLOPs for the MFMA GEMMs, bytes for the HBM/latency-bound head
+    (kernel table, states the same figures)."""
     dims = [dS] + list(hidden)
+    H = dims[-1]
     nDense = 1 + dA
-    if name.startswith("gemm16_fwd"):
-        j = int(name[len("gemm16_fwd"):])
-        return "mfma", 2.0 * B * dims[j] * dims[j + 1]
-    if name.startswith("gemm16_dx"):
-        j = int(name[len("gemm16_dx"):])
-        return "mfma", 2.0 * B * dims[j + 1] * dims[j]
-    if name == "gemm16_dw":
-        fl = sum(2.0 * B * (dims[j] + 1) * dims[j + 1] for j in range(len(hidden)))
-        fl += 2.0 * B * (dims[-1] + 1) * nDense
-        return "mfma", fl
-    if name == "adam_kernel":
-        return "hbm", 7.0 * nParams * 4        # read W,M1,M2,G ; write W,M1,M2
-    if name == "head_kernel":
-        # per sample: read Y[H] + W_out[H*8] (L2 resident) + a,mu (f64) + write deltas 2x H
-        H = dims[-1]
-        return "hbm", B * (H * 4 + 3 * dA * 8 + 2 * H * 4 + 13 * 8 * 2)
-    if name == "sample_kernel":
-        return "hbm", B * (2 * dS * 4 + 8 * 6)
-    return "hbm", 0.0
+    nOut = nDense + dA
+    L = len(hidden)
+    dw_flops = sum(2.0 * B * (dims[j] + 1) * dims[j + 1] for j in range(L)) + 2.0 * B * (H + 1) * nDense
+    # head: read last hidden activations + output weights, the minibatch's action / mu / reward rows,
+    # write the two delta tiles (pre-residual and pre-activation) and the output gradients; the
+    # rider gathers the NEXT minibatch: 2 state rows per sample (row t and t+1) plus its scalars
+    head_bytes = B * (H * 4 + 2 * H * 4 + 2 * dA * 8 + 8 * 8 + nOut * 4) + H * 8 * 4 + \
+        B * (2 * dS * 4 + 2 * dA * 8 + 6 * 8)
+    ks = [(21, "gemm16_kernel<0>", "mfma", 2.0 * B * dims[0] * dims[1])]
+    if L > 1:
+        ks.append((22, "gemm16_kernel<1>", "mfma", 2.0 * B * dims[L - 1] * dims[L]))
+    ks.append((23, "head_kernel_t", "hbm", float(head_bytes)))
+    if L > 1:
+        ks.append((24, "gemm16_kernel<2>", "mfma", 2.0 * B * dims[L] * dims[L - 1]))
+    ks.append((25, "gemm16_kernel<3>", "mfma", dw_flops))
+    return ks
+
+
+def synthetic_episode(np, e, dS=17, dA=6, N=EP_STATES):
+    """Episode `e` of the synthetic replay: the distributions of oracle/synth.h (the generator the
+    CPU baseline's harness uses), drawn from a numpy Generator seeded by the episode index."""
+    g = np.random.default_rng(1000003 * 7 + e)
+    i = np.arange(dS)
+    S = (g.standard_normal((N, dS)) * (0.5 + 0.1 * i) + (0.2 * i - 1.0)).astype(np.float32)
+    R = g.standard_normal(N) + 0.1
+    R[0] = 0.0
+    mean = 0.5 * g.standard_normal((N, dA))
+    std = 0.3 + 0.4 * g.random((N, dA))
+    A = mean + std * g.standard_normal((N, dA))
+    MU = np.concatenate([mean, std], axis=1)
+    A[-1] = 0.0
+    MU[-1] = 0.0
+    V = (0.5 * g.standard_normal(N)).astype(np.float32)
+    return dict(states=S, actions=A, mu=MU, rewards=R, values=V, terminated=0, tag=e)
 
 
 def cpu_baseline(steps_budget_s=20.0):
@@ -113,7 +131,6 @@ def main():
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-steps", type=int, default=300)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,17 +150,15 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=n_ranks)
 
     from smarties_amd import capi, load_hip
-    from oracle_api import synth_cfg, synth_episode   # synthetic replay generator only (oracle/synth.h)
 
     api = load_hip()
     cfg = capi.make_config(n_ranks=n_ranks, rank=rank, device_id=local_rank, **CFG)
     L = capi.Learner(api, cfg)
     L.init_weights()
-    sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=EP_STATES, lenMax=EP_STATES, pTerm=0.0)
     per = N_EPISODES // n_ranks
     t_fill = time.time()
     for e in range(rank * per, (rank + 1) * per):
-        L.append_episode(**synth_episode(sc, e))
+        L.append_episode(**synthetic_episode(np, e))
     t_fill = time.time() - t_fill
     if n_ranks > 1:
         idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -177,31 +192,30 @@ def main():
     B_global = CFG["batchSize"]
     value = B_global * args.steps / dt
 
-    # ---- roofline of the dominant kernel: HIP events around every launch, eager pass ------------------
+    # ---- roofline of the dominant kernel ---------------------------------------------------------------
+    # hl_kernel_profile: `reps` launches of one kernel of the step (issued exactly as inside the
+    # replayed step, rider workgroup included) captured into a graph and replayed between two HIP
+    # events on the library's stream.  The empty-kernel profile shows how much of that is dispatch.
     roof = None
     if rank == 0:
-        L.timing_enable(True)
-        L.step(args.roofline_steps)
-        L.sync()
-        names = ["step_tail_kernel"] + ["gemm16_fwd%d" % j for j in range(len(CFG["hidden"]))] + ["head_kernel"] + \
-                ["gemm16_dx%d" % j for j in range(1, len(CFG["hidden"]))] + ["gemm16_dw", "adam_kernel", "post_kernel"]
-        times = {n: L.timing_get(n) for n in names}
-        L.timing_enable(False)
-        tot = {n: ms * cnt for n, (ms, cnt) in times.items()}
-        dom = max(tot, key=tot.get)
-        ms, cnt = times[dom]
-        kind, work = kernel_work(dom, L.B, 17, 6, CFG["hidden"], L.nParams)
-        if kind == "mfma":
-            achieved = work / (ms * 1e-3) / 1e12
-            roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
-        else:
-            achieved = work / (ms * 1e-3) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": None}
-        roof["avg_launch_us"] = ms * 1e3
-        roof["launches"] = cnt
-        roof["per_kernel_avg_us"] = {n: round(v[0] * 1e3, 3) for n, v in times.items()}
+        gap = L.kernel_profile(12, 400)
+        table = {}
+        for pid, name, bound, work in step_kernels(L.B, 17, 6, CFG["hidden"], L.nParams):
+            us = L.kernel_profile(pid, 200)
+            if bound == "mfma":
+                ach, peak, unit = work / (us * 1e-6) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = work / (us * 1e-6) / 1e9, PEAK_HBM_GBS, "GB/s"
+            table[name] = {"bound": bound, "launch_us": round(us, 3), "work_per_launch": work, "achieved": ach,
+                           "peak": peak, "unit": unit, "frac": ach / peak}
+        dom = max(table, key=lambda n: table[n]["launch_us"])
+        d = table[dom]
+        roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+                "frac": d["frac"], "traffic": None, "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
+                "step_kernels": table,
+                "note": "latency-bound step: 5 dependent launches of 16..512 workgroups; launch_us = HIP-event time "
+                        "per launch of graph-replayed back-to-back launches (dispatch included, as a kernel trace "
+                        "counts it); empty_launch_us = the same for an empty kernel"}
 
     out = None
     if rank == 0:

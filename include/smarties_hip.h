@@ -216,12 +216,34 @@ HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------- */
 HL_API int hl_comm_unique_id(uint8_t id[128]);             /* rank 0 creates, caller broadcasts */
 HL_API int hl_comm_init(hl_learner* h, const uint8_t id[128]);
+/* n_ranks > 1 WITHOUT hl_comm_init = host-exchange mode: the caller owns the communicator and
+ * drives hl_step_begin / hl_grad_exchange / hl_counters_exchange / hl_moments_exchange /
+ * hl_step_end itself (smarties_amd/dist_host.py); hl_initialize then takes the start-up reward /
+ * state statistics from the local shard, and hl_step returns HL_ERR_COMM. */
 
 /* ---- timing taps for bench.py ------------------------------------------------------ */
 /* average device time (ms) per launch of the named kernel over the launches since the
  * last hl_timing_reset, measured with HIP events on the library's own stream */
 HL_API int hl_timing_enable(hl_learner* h, int32_t enable);
 HL_API int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* launches);
+
+/* Isolated kernel profile: captures `reps` back-to-back launches of ONE kernel of the step into a
+ * graph on the library's stream, replays it 20 times between two HIP events and returns the
+ * average microseconds per launch (this includes the ~1.6 us graph-node dispatch gap; profile
+ * HL_PROF_EMPTY the same way to calibrate it).  The 2x launches are issued exactly as inside the
+ * replayed step, i.e. with the horizontally fused sampler / bookkeeping workgroup riding along.
+ * The call advances the sampler state and re-applies updates: profile AFTER the timed run. */
+enum {
+  HL_PROF_SAMPLE = 0,      /* stand-alone sampler (first minibatch of a replayed graph) */
+  HL_PROF_EMPTY = 12,      /* empty kernel node: dispatch-gap calibration */
+  HL_PROF_STEP_GRAPH = 7,  /* `reps` whole steps as one replayed graph */
+  HL_PROF_FWD0 = 21,       /* first forward GEMM   + sampler phase A of the next step */
+  HL_PROF_FWD_LAST = 22,   /* last forward GEMM    + sampler phase B */
+  HL_PROF_HEAD = 23,       /* V-RACER head         + sampler phase C (search + gather) */
+  HL_PROF_DX = 24,         /* first backward dX GEMM + ReF-ER bookkeeping of this step */
+  HL_PROF_DW = 25          /* all dW GEMMs + bias reductions + fused Adam */
+};
+HL_API int hl_kernel_profile(hl_learner* h, int32_t which, int32_t reps, double* us_per_launch);
 
 #ifdef __cplusplus
 }

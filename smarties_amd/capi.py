@@ -158,6 +158,7 @@ class CApi:
             "comm_init": (C.c_int, [P, C.POINTER(C.c_uint8)]),
             "timing_enable": (C.c_int, [P, I32]),
             "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
+            "kernel_profile": (C.c_int, [P, I32, I32, pd]),
             "status_string": (C.c_char_p, [C.c_int]),
             "version": (C.c_int, []),
         }.items():
@@ -363,6 +364,12 @@ class Learner:
         ms, n = C.c_double(), C.c_int64()
         self._ck(self.api.fn("timing_get")(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_profile(self, which, reps=200):
+        """Average microseconds per launch of one kernel of the step (see hl_kernel_profile)."""
+        us = C.c_double()
+        self._ck(self.api.fn("kernel_profile")(self.h, int(which), int(reps), C.byref(us)))
+        return us.value
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -60,6 +60,9 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
   }
 }
 
+// ROLE only names the instantiation (fwd0 / fwd / dx / dw) so that a kernel trace separates the four
+// launches of a step; the code is identical.
+template <int ROLE>
 __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
                                                      const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
   // one LDS block, used either by a GEMM tile (two operand tiles + the cross-wave reduction
@@ -76,8 +79,15 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   int p = 0;
   for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
   const GemmProblem P = probs[p];
-  const int tile = bid - P.tileStart;
+  int tile = bid - P.tileStart;
   if (P.flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
+  // Give XCD x the contiguous (row-major) tile range [x*nT/8, (x+1)*nT/8): the tiles of one XCD
+  // then share their A row-panels, and each L2 fetches 1/8 of A instead of all of it.
+  {
+    const int nT = P.tilesM * P.tilesN;
+    if ((nT & 7) == 0 && !(hyp.variant & 16) && !((hyp.variant >> 5) & (1 << ROLE))) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
+  }
 
   const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
   const int m0 = tm * 16, n0 = tn * 16;
@@ -220,11 +230,17 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   }
 }
 
-hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
+hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
   if (nBlocks <= 0) return hipSuccess;
   ExtraArgs ex{}; if (extra) ex = *extra;
-  hipLaunchKernelGGL(gemm16_kernel, dim3(nBlocks + (ex.role ? 1 : 0)), dim3(256), 0, s, dProbs, nProbs, sc, hyp, ex);
+  const dim3 grid(nBlocks + (ex.role ? 1 : 0)), block(256);
+  switch (role) {
+    case GEMM_ROLE_FWD0: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD0>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
+    case GEMM_ROLE_FWD: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
+    case GEMM_ROLE_DX: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_DX>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
+    default: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_DW>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
+  }
   return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ struct DevScalars {
   long long nTransitions;         // ReplayCounters::nTransitions (this replica)
   long long nEpisodes;
   long long cnt[4];               // {seenEps, seenSteps, nFar, nStored}: local, then all-reduced (C2)
+  long long seenLocal[2];         // this replica's seenEps / seenSteps (cnt[0..1] are reset from it each step)
   float rewMean, rewScale, rewStd;
   float maxAbsErrAll;             // max over episodes of Episode::maxAbsError
   // the minibatch workspace is double buffered (sampling of step k+1 overlaps the update of step k)

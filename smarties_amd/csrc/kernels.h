@@ -67,10 +67,12 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 // one launch, two independent workgroups: bookkeeping of a finished step (post) and sampling of a
 // minibatch (samp); either may be nullptr
 hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStream_t s, int phases = PH_ALL);
-hipError_t launch_gemm(const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
+enum { GEMM_ROLE_FWD0 = 0, GEMM_ROLE_FWD = 1, GEMM_ROLE_DX = 2, GEMM_ROLE_DW = 3 };
+hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
+hipError_t launch_empty(hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);
 hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s);

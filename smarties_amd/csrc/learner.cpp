@@ -681,7 +681,9 @@ int hl_initialize(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
   if (h->order.empty()) return fail(h, HL_ERR_TOO_FEW_DATA, "empty replay");
   int rc = flushPending(h); if (rc) return rc;
-  if (h->cfg.n_ranks > 1 && !h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1: call hl_comm_init before hl_initialize");
+  // n_ranks > 1 without hl_comm_init = host-exchange mode (hl_step_begin / hl_*_exchange /
+  // hl_step_end driven by the caller's own communicator): the start-up statistics then come from
+  // the local shard only; hl_step itself refuses to run (allreduceGrad).
   rc = allreduceCounters(h); if (rc) return rc;
   rc = launchPost(h, 0, POST_INIT, h->stream); if (rc) return rc;     // updateCounters(bInit)
   rc = launchMoments(h); if (rc) return rc;                          // updateRewardsStats(bInit)
@@ -707,7 +709,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
   while (s < n) {
     int rc = preStepChecks(h); if (rc) return rc;
     const long long k = h->nGradSteps + 1;
-    const bool plain = !flat && (k % 1000) != 0 && !evictionDue(h) && h->cfg.n_ranks <= 1 && !h->timing && h->useGraph;
+    const bool plain = !flat && (k % 1000) != 0 && !evictionDue(h) && !exchanging(h) && !h->timing && h->useGraph;
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
       // plain steps available before the next 1000-step sweep and within this call
@@ -917,15 +919,25 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
       hipError_t e = hipSuccess;
       switch (which) {
         case 0: rc = launchSample(h, 0, nullptr, true, h->stream); break;
-        case 1: e = launch_gemm(h->dProbs + sb.fwdIdx[0], 1, sb.fwdBlocks[0], h->sc, hyp, nullptr, h->stream); break;
-        case 2: e = launch_gemm(h->dProbs + sb.fwdIdx[h->nHidden - 1], 1, sb.fwdBlocks[h->nHidden - 1], h->sc, hyp, nullptr, h->stream); break;
+        case 1: e = launch_gemm(GEMM_ROLE_FWD0, h->dProbs + sb.fwdIdx[0], 1, sb.fwdBlocks[0], h->sc, hyp, nullptr, h->stream); break;
+        case 2: e = launch_gemm(GEMM_ROLE_FWD, h->dProbs + sb.fwdIdx[h->nHidden - 1], 1, sb.fwdBlocks[h->nHidden - 1], h->sc, hyp, nullptr, h->stream); break;
         case 3: rc = launchHead(h, 0, h->stream); break;
-        case 4: if (!sb.dxIdx.empty()) e = launch_gemm(h->dProbs + sb.dxIdx[0], 1, sb.dxBlocks[0], h->sc, hyp, nullptr, h->stream); break;
-        case 5: e = launch_gemm(h->dProbs + sb.dwIdx, sb.dwCount, sb.dwBlocks, h->sc, hyp, nullptr, h->stream); break;
+        case 4: if (!sb.dxIdx.empty()) e = launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[0], 1, sb.dxBlocks[0], h->sc, hyp, nullptr, h->stream); break;
+        case 5: e = launch_gemm(GEMM_ROLE_DW, h->dProbs + sb.dwAdamIdx, sb.dwCount, sb.dwBlocks, h->sc, hyp, nullptr, h->stream); break;
         case 6: rc = launchPost(h, 0, POST_AGG, h->stream); break;
         case 8: case 9: case 10: { const SampleArgs sa = sampleArgs(h, 0, nullptr, false);
           e = launch_step_tail(nullptr, &sa, h->stream, which == 8 ? PH_A : which == 9 ? PH_B : PH_C); break; }
         case 11: rc = launchPost(h, 0, POST_AGG | POST_BETA, h->stream); break;
+        case 12: e = launch_empty(h->stream); break;
+        // 21..25: the five launches of a replayed step exactly as captureSteps issues them (with riders)
+        case 21: { ExtraArgs ex = extraSample(h, 1, h->nHidden == 1 ? (PH_A | PH_B) : PH_A);
+          e = launch_gemm(GEMM_ROLE_FWD0, h->dProbs + sb.fwdIdx[0], 1, sb.fwdBlocks[0], h->sc, hyp, &ex, h->stream); break; }
+        case 22: { ExtraArgs ex = extraSample(h, 1, PH_B); const int j = h->nHidden - 1;
+          e = launch_gemm(GEMM_ROLE_FWD, h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, &ex, h->stream); break; }
+        case 23: rc = launchHead(h, 0, h->stream, true); break;
+        case 24: if (!sb.dxIdx.empty()) { ExtraArgs ex{}; ex.role = 2; ex.post = postArgs(h, 0, POST_AGG | POST_BETA);
+          e = launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[0], 1, sb.dxBlocks[0], h->sc, hyp, &ex, h->stream); } break;
+        case 25: e = launch_gemm(GEMM_ROLE_DW, h->dProbs + sb.dwAdamIdx, sb.dwCount, sb.dwBlocks, h->sc, hyp, nullptr, h->stream); break;
         default: break;
       }
       if (e != hipSuccess) rc = hipFail(h, e, "debug launch");
@@ -938,14 +950,22 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
   h->dbgVariant = 0;
   HIPCK(hipGraphLaunch(slot.exec, h->stream)); HIPCK(hipStreamSynchronize(h->stream));
   const int iters = 20;
-  const auto t0 = std::chrono::steady_clock::now();
+  hipEvent_t ev0, ev1;
+  HIPCK(hipEventCreate(&ev0)); HIPCK(hipEventCreate(&ev1));
+  HIPCK(hipEventRecord(ev0, h->stream));
   for (int i = 0; i < iters; ++i) HIPCK(hipGraphLaunch(slot.exec, h->stream));
+  HIPCK(hipEventRecord(ev1, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
-  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  *us_per_launch = dt / ((double)iters * reps) * 1e6;
+  float ms = 0.f; HIPCK(hipEventElapsedTime(&ms, ev0, ev1));
+  hipEventDestroy(ev0); hipEventDestroy(ev1);
+  *us_per_launch = (double)ms * 1e3 / ((double)iters * reps);
   hipGraphExecDestroy(slot.exec); hipGraphDestroy(slot.graph);
   if (which == 7) h->nGradSteps += (long long)(iters + 1) * reps;
   return HL_OK;
+}
+
+extern "C" HL_API int hl_kernel_profile(hl_learner* h, int which, int reps, double* us_per_launch) {
+  return hl_debug_kernel_time(h, which, reps, 0, us_per_launch);
 }
 
 extern "C" HL_API int hl_debug_stamps(hl_learner* h, long long out[32]) {

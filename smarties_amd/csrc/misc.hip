@@ -99,6 +99,7 @@ __global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, co
   sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
   sc->maxAbsErrAll = m;
   sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
+  sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1];
 }
 hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s) {
   hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(64), 0, s, sc, redNFar, redMaxAbs, nBlocks);
@@ -189,6 +190,7 @@ hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s) {
 
 __global__ void set_counts_kernel(DevScalars* sc, long long nT, long long nE, long long seenEps, long long seenSteps) {
   sc->nTransitions = nT; sc->nEpisodes = nE; sc->cnt[0] = seenEps; sc->cnt[1] = seenSteps;
+  sc->seenLocal[0] = seenEps; sc->seenLocal[1] = seenSteps;
   sc->cnt[3] = nT;   // cnt[2] keeps the far-policy count of the last statistics pass
 }
 // removal of an episode (MemoryBuffer::removeBackEpisode): its far-policy steps leave the total
@@ -250,5 +252,8 @@ hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, s, sc, rp, nEpisodes, out);
   return hipGetLastError();
 }
+
+__global__ void empty_kernel() {}
+hipError_t launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); return hipGetLastError(); }
 
 }  // namespace hl

@@ -119,10 +119,13 @@ SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool co
   sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
   return sa;
 }
+// replica exchanges are part of the step: several replicas, or a communicator was attached to a
+// single one (hl_comm_init with n_ranks == 1 runs the N > 1 sequence over a 1-rank RCCL communicator)
+bool exchanging(const hl_learner* h) { return h->cfg.n_ranks > 1 || h->comm != nullptr; }
 PostArgs postArgs(hl_learner* h, int parity, int mode) {
   PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->buf[parity].bt; pa.B = h->B; pa.mode = mode;
   pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
-  pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = h->cfg.n_ranks;
+  pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = exchanging(h) ? 2 : 1;   // > 1: use the exchanged counters
   pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate;
   return pa;
 }
@@ -161,7 +164,7 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       if (j == h->nHidden - 1) ph |= PH_B;
       if (ph) { ex = extraSample(h, parity ^ 1, ph); pex = &ex; }
     }
-    HIPCK(timed(h, nm, s, [&] { return launch_gemm(h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
+    HIPCK(timed(h, nm, s, [&] { return launch_gemm(j == 0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD, h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
   }
   return HL_OK;
 }
@@ -181,13 +184,13 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   char nm[32];
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
-    HIPCK(timed(h, nm, s, [&] { return launch_gemm(h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
+    HIPCK(timed(h, nm, s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
   // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.
   const ExtraArgs* pexW = sb.dxIdx.empty() ? pex : nullptr;
   HIPCK(timed(h, "gemm16_dw", s, [&] {
-    return launch_gemm(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s); }));
+    return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s); }));
   return HL_OK;
 }
 int launchAdam(hl_learner* h, int parity) {
@@ -235,18 +238,18 @@ int applyRemoval(hl_learner* h) {
 }
 
 int allreduceGrad(hl_learner* h) {
-  if (h->cfg.n_ranks <= 1) return HL_OK;
+  if (!exchanging(h)) return HL_OK;
   if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
   NCCLCK(ncclAllReduce(h->G, h->G, (size_t)h->nParams, ncclFloat, ncclSum, h->comm, h->stream));
   return HL_OK;
 }
 int allreduceCounters(hl_learner* h) {
-  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
+  if (!h->comm) return HL_OK;
   NCCLCK(ncclAllReduce(h->sc->cnt, h->sc->cnt, 4, ncclInt64, ncclSum, h->comm, h->stream));
   return HL_OK;
 }
 int allreduceMoments(hl_learner* h) {
-  if (h->cfg.n_ranks <= 1 || !h->comm) return HL_OK;
+  if (!h->comm) return HL_OK;
   NCCLCK(ncclAllReduce(h->dMoments, h->dMoments, (size_t)(2 * h->dS + 3), ncclDouble, ncclSum, h->comm, h->stream));
   return HL_OK;
 }
@@ -260,7 +263,7 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   hipStream_t s = h->stream;
   const long long k = h->nGradSteps + 1;
   const bool periodic = (k % 1000) == 0;
-  const bool fuse = h->cfg.n_ranks <= 1;
+  const bool fuse = !exchanging(h);
   int rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc;
   rc = launchForward(h, 0, s); if (rc) return rc;
   rc = launchHead(h, 0, s); if (rc) return rc;
@@ -268,7 +271,7 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   if (!fuse) { rc = allreduceGrad(h); if (rc) return rc; rc = launchAdam(h, 0); if (rc) return rc; }
   h->lastParity = 0;
   const bool evict = evictionDue(h);
-  if (!periodic && !evict && h->cfg.n_ranks <= 1) return launchPost(h, 0, POST_AGG | POST_BETA, s);
+  if (!periodic && !evict && !exchanging(h)) return launchPost(h, 0, POST_AGG | POST_BETA, s);
   rc = launchPost(h, 0, POST_AGG, s); if (rc) return rc;
   if (periodic) {
     rc = launchPeriodicSweep(h); if (rc) return rc;

@@ -127,6 +127,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       nFarStat = nFarTot;
       sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
       sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
+      if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce
     }
   }
   if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {

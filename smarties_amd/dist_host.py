@@ -1,0 +1,44 @@
+"""Host-side replica protocol for N > 1 learners (one process per GPU).
+
+Reference behaviour: with `nLearners` > 1 the global batch and the replay budget are
+split over the replicas (Settings/HyperParameters.cpp:186-197), every gradient step all-reduces the
+fp32 gradient sum (Core/Optimizer.cpp:104-133), the four replay counters
+(ReplayMemory/DataCoordinator / MemoryProcessing.cpp:100-118) and -- every 1000th step -- the
+2*dS+3 reward/state moments (MemoryProcessing.cpp:139-150).
+
+The product does those exchanges on the device with RCCL inside `hl_step` (learner.cpp,
+`hl_comm_init`).  This module is the SAME protocol driven from the host through the split-step
+entry points (`hl_step_begin` / `hl_*_exchange` / `hl_step_end`) and any `torch.distributed`
+backend; it exists so that an embedding which already owns an MPI / gloo communicator (the
+reference does) can keep it, and so that the N > 1 order of operations is covered by
+world_size-2 `gloo` tests on machines without a GPU.
+"""
+import numpy as np
+
+
+def init_replica_weights(L, dist, src=0):
+    """Replica 0's initial weights everywhere (reference: Network broadcast in
+    Learner_approximator::initializeApproximators -> Optimizer MPI_Bcast, Core/Optimizer.cpp:60-70)."""
+    import torch
+    w, m1, m2 = L.get_params()
+    t = torch.from_numpy(w)
+    dist.broadcast(t, src)
+    L.set_params(w, m1, m2)
+
+
+def step_host_exchange(L, dist, n_steps=1, flat=None):
+    """`n_steps` gradient steps of one replica; collectives through `dist` (torch.distributed)."""
+    import torch
+    for s in range(n_steps):
+        L.step_begin(None if flat is None else flat[s])
+        g = L.grad_fetch()
+        dist.all_reduce(torch.from_numpy(g), op=dist.ReduceOp.SUM)
+        L.grad_store(g)
+        m = L.moments_fetch()          # None unless this is a 1000th step (same on every replica)
+        if m is not None:
+            dist.all_reduce(torch.from_numpy(m), op=dist.ReduceOp.SUM)
+            L.moments_store(m)
+        c = np.asarray(L.counters_fetch(), dtype=np.int64)
+        dist.all_reduce(torch.from_numpy(c), op=dist.ReduceOp.SUM)
+        L.counters_store(c)
+        L.step_end()

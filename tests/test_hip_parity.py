@@ -216,6 +216,92 @@ def test_split_step_equals_fused_step(hip_api):
     assert A.scalars().beta == Bq.scalars().beta
 
 
+@pytest.mark.gpu
+def test_two_replica_protocol_matches_oracle_replicas(hip_api):
+    """n_ranks = 2 (batch and replay budget split): two HIP replicas on this GPU,
+    exchanges summed on the host, against two oracle replicas driven the same way -- over a
+    1000th-step sweep so that the moments exchange is part of it."""
+    from oracle_api import oracle_learner, synth_episode
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4096, randSeed=11)
+    sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+
+    def replicas(make):
+        Ls = []
+        for r in range(2):
+            L = make(capi.make_config(n_ranks=2, rank=r, **cfg_kw))
+            L.init_weights()
+            for e in range(r, 40, 2):
+                L.append_episode(**synth_episode(sc, e))
+            Ls.append(L)
+        w0 = Ls[0].get_params()[0]
+        for L in Ls:
+            w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2); L.initialize()
+        return Ls
+
+    def one_step(Ls):
+        for L in Ls:
+            L.step_begin()
+        gs = [L.grad_fetch() for L in Ls]
+        g = np.sum(gs, axis=0, dtype=np.float32)
+        ms = [L.moments_fetch() for L in Ls]
+        c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+        for L, m in zip(Ls, ms):
+            L.grad_store(g)
+            if m is not None:
+                L.moments_store(np.sum(ms, axis=0))
+            L.counters_store(c)
+            L.step_end()
+        return gs, c, ms
+
+    G = replicas(lambda cfg: hip_learner(hip_api, cfg))
+    O = replicas(oracle_learner)
+    assert G[0].B == 8 and O[0].B == 8
+    for k in range(1, 1004):
+        for L in G + O:
+            L.set_tap(k <= 3 or k >= 999)
+        gG, cG, mG = one_step(G)
+        gO, cO, mO = one_step(O)
+        if k <= 3 or k >= 999:
+            for r in range(2):
+                assert np.array_equal(G[r].readback(capi.TAP_FLAT), O[r].readback(capi.TAP_FLAT)), (k, r)
+                den = np.abs(gO[r]).max() + 1e-30
+                assert np.abs(gG[r] - gO[r]).max() / den < 1e-5, (k, r)     # north_star: 1e-5 rel, fp32
+            assert np.array_equal(cG[:2], cO[:2]) and cG[3] == cO[3]
+            assert abs(int(cG[2]) - int(cO[2])) <= 2                        # far-policy count: DESIGN.md, deviations
+        if k == 1000:
+            assert mG[0] is not None and mO[0] is not None
+            assert np.allclose(mG[0], mO[0], rtol=1e-12, atol=1e-9)
+    for r in range(2):
+        wG, wO = G[r].get_params()[0], O[r].get_params()[0]
+        assert np.abs(wG - wO).max() < 2e-4
+        assert abs(G[r].scalars().beta - O[r].scalars().beta) < 1e-3
+    assert np.array_equal(G[0].get_params()[0], G[1].get_params()[0])       # replicas stay identical
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_sequence_on_one_rank(hip_api):
+    """hl_comm_init on a single replica switches hl_step to the N > 1 sequence (gradient ->
+    ncclAllReduce -> separate Adam kernel -> counters ncclAllReduce -> beta update, moments
+    all-reduce on the 1000th step) over a 1-rank RCCL communicator: same results as the fused
+    single-replica step."""
+    import ctypes as C
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42)
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    A, _ = _pair(hip_api, cfg_kw, sc, 30)
+    Bq = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    Bq.init_weights(); fill_synth(Bq, sc, 30)
+    raw = (C.c_uint8 * 128)()
+    assert hip_api.fn("comm_unique_id")(raw) == 0
+    Bq.comm_init(bytes(raw))
+    Bq.initialize()
+    for n in (1, 7, 64, 931):                # 1003 steps: crosses the periodic sweep
+        A.step(n); Bq.step(n)
+        assert np.array_equal(A.get_params()[0], Bq.get_params()[0]), n
+        assert A.scalars().beta == Bq.scalars().beta
+        assert A.scalars().nFarPolicySteps == Bq.scalars().nFarPolicySteps
+    assert np.array_equal(A.get_rng_state(), Bq.get_rng_state())
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json size: 1M-transition replay, 17/6, 2x256, B=256
 # ---------------------------------------------------------------------------------------------
