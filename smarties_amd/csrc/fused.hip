@@ -1,0 +1,481 @@
+// smarties_amd/csrc/fused.hip -- forward + V-RACER head + input-gradient back-propagation of the
+// two-hidden-layer MLP as ONE kernel (the cfg-NS class of networks: dS <= 32, two hidden blocks of
+// equal width H in {16,32,64,128,256}, dA <= 7).
+//
+// Why: a gradient step is a chain of dependent kernels, each costing a dispatch gap (~1.6 us), a
+// cold L2 (every kernel boundary invalidates it) and a prologue.  fwd0 -> fwd1 -> head -> dX were
+// four such kernels for ~40 MFLOP.  Here a 16-row PANEL of the minibatch is owned by a group of
+// HT = H/16 workgroups (one 16-column tile each, all on one XCD because workgroups are dealt
+// round-robin to the 8 XCDs and the group shares blockIdx % 8); inside the group only ONE exchange
+// is needed:
+//
+//   every WG:  h1 = f(S W0 + b0) for the whole panel (17x256 weights: recomputed, not exchanged)
+//              its tile of x2 = h1 W1 + b1, y3 = f(x2) + w*h1 + b and f'(x2)
+//              -> global (agent-scope write-through stores)
+//   -- group barrier: a counter per panel, one atomic arrive per WG, no L2 flush / invalidate --
+//   every WG:  reads the panel's y3 and f'(x2) back (L2 hits), output layer + V-RACER head for the
+//              16 samples (fp64, one (sample, action dim) per lane), delta_y3 = delta_out Wout^T,
+//              delta_x2 = delta_y3 f'(x2) for the whole panel, its tile of
+//              delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1)
+//
+// The weight-gradient GEMMs need all rows and stay a second kernel (gemm16.hip, role DW).
+// Reference functions: BaseLayer::forward / ParametricResidualLayer::forward (Layer_Base.h:64-95,
+// Layers.h:347-361), RACER::Train (Learners/RACER_train.cpp:14-67), Continuous_policy
+// (Math/Continuous_policy.h:68-378, 569-738), MiniBatch::setMseDklImpw / setValues
+// (MiniBatch.h:161-175), Layer::backward (Layers.h:123-160, 363-393).
+#include "tail_dev.h"
+
+namespace hl {
+
+#define FLDR 258            // leading dimension of 16-row LDS tiles (== 2 mod 32: conflict-free MFMA operand reads)
+#define FLDS 34             // leading dimension of the 16 x dS state tile
+#define FMAXK4 8            // dS <= 32: at most 8 MFMA k-steps in the first layer
+
+__device__ __forceinline__ void st_agent(float* p, float v) {   // write-through to the agent coherence point
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float resOut(float y, float in, float w, float b) { return y + fmaf(in, w, b); }
+__device__ __forceinline__ double sum16(double v) {            // over the 16 lanes of one sample
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LDS carve-up (floats).  R1: h1 panel, later the W1 row tile of the dX contraction.  R2: W0
+// (k-major, leading dimension H+16), later the y3 panel.  R3: W1 column tile, later f'(x2) ->
+// delta_x2 panel.
+__host__ __device__ inline int fusedR2Floats(int dSp, int H) { const int a = dSp * (H + 16), b = 16 * FLDR; return a > b ? a : b; }
+__host__ __device__ inline int fusedR3Floats(int H) { const int a = H * 16, b = 16 * FLDR; return a > b ? a : b; }
+__host__ __device__ inline size_t fusedLdsBytes(int dS, int H) {
+  const int dSp = (dS + 3) & ~3;
+  const size_t fl = (size_t)16 * FLDR + fusedR2Floats(dSp, H) + fusedR3Floats(H) + (size_t)H * 8 /*Wout*/ + 16 * FLDS +
+                    1024 /*red*/ + 3 * (size_t)H /*b0, wres, bres*/ + 512 /*sO*/ + 128 /*sDo*/ + 256 /*own tile scratch*/ + 32 /*bo, bp*/;
+  const size_t bytes = fl * 4;
+  return bytes > TAIL_LDS_BYTES ? bytes : TAIL_LDS_BYTES;
+}
+
+// C[16x16] partial of one wave: sum over its k range of A[i][k] * B[k][j]; operands read from LDS
+// through the two index functors, ALL of them before the first MFMA (one exposed LDS latency)
+template <int NK, class FA, class FB>
+__device__ __forceinline__ f32x4 waveMma(FA fa, FB fb) {
+  float av[NK], bv[NK];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) { av[s] = fa(s); bv[s] = fb(s); }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc1, 0, 0, 0);
+    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc0, 0, 0, 0);
+  }
+  return acc0 + acc1;
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, ExtraArgs extra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // blocks 0..7: riders (tail work of the neighbouring steps); 8 of them keep blockIdx % 8 == XCD
+  if (blockIdx.x < 8) { if (blockIdx.x == 0 && extra.role) runExtra(extra, smem); return; }
+  constexpr int HT = H / 16, H4 = H / 4, LDW0 = H + 16;
+  constexpr int KW = H / 4;                      // reduction length per wave of the K-split contractions
+  constexpr int NK = KW / 4;                     // MFMA steps per wave
+  constexpr int TPW = HT >= 4 ? HT / 4 : 1;      // h1 column tiles per wave
+  constexpr int QP = (16 * H4 + 255) / 256;      // float4 per thread of a 16 x H panel
+  constexpr int QC = (H * 4 + 255) / 256;        // float4 per thread of the H x 16 column tile
+  constexpr int QO = (H * 2 + 255) / 256;        // float4 per thread of Wout [H][8]
+  const DevScalars* sc = a.sc;
+  const int dS = a.dS, dSp = (dS + 3) & ~3, B = a.B, dA = a.dA, nDense = a.nDense;
+  const int bid = blockIdx.x - 8, xcd = bid & 7, gi = bid >> 3;
+  const int panel = (gi / HT) * 8 + xcd, n = gi % HT;
+  const int m0 = panel * 16, n0 = n * 16;
+  const int nRows = sc->nRows[a.parity];
+  if (m0 >= nRows) return;
+
+  float* sY1 = reinterpret_cast<float*>(smem);                 // [16][FLDR]
+  float* sR2 = sY1 + 16 * FLDR;
+  float* sR3 = sR2 + fusedR2Floats(dSp, H);
+  float* sWo = sR3 + fusedR3Floats(H);                         // [H][8]
+  float* sS = sWo + H * 8;                                     // [16][FLDS]
+  float* red = sS + 16 * FLDS;                                 // [4][256]
+  float* sB0 = red + 1024;                                     // [H]
+  float* sWr = sB0 + H;                                        // [H] residual w
+  float* sBr = sWr + H;                                        // [H] residual b
+  double* sO = reinterpret_cast<double*>(sBr + H);             // [16][16]  (offset is a multiple of 8 bytes)
+  float* sDo = reinterpret_cast<float*>(sO + 256);             // [16][8]
+  float* sT = sDo + 128;                                       // [16][16] own-tile scratch (x1, later delta_y3)
+  float* sBo = sT + 256;                                       // [16] output bias, [16] ParamLayer bias
+  float* sBp = sBo + 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lc = lane >> 4;
+  const int em = tid >> 4, en = tid & 15;                      // the output element / (sample, dim) of this thread
+  const float* W = a.W;
+  const float* W0 = W + a.indW0; const float* W1 = W + a.indW1; const float* Wo = W + a.indWo;
+
+  // ---- every load that does not depend on the exchange, issued up front --------------------------
+  const int row = m0 + em;
+  const bool rowValid = row < nRows, isNext = rowValid && row >= B;
+  int bSrc = 0; long long slot = 0;
+  if (rowValid) { bSrc = isNext ? a.bt.nextSrc[row - B] : row; }
+  float sv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+    sv[q] = (c < dS && m0 + r < nRows) ? a.X0[(size_t)(m0 + r) * a.ldX0 + c] : 0.f;
+  }
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 w0v[FMAXK4], w1c[QC], w1r[QP], wov[QO];
+  const int nW0 = dSp * H4;
+#pragma unroll
+  for (int q = 0; q < FMAXK4; ++q) {
+    const int f = tid + 256 * q; w0v[q] = z4;
+    if (f < nW0) { const int k = f / H4, c4 = f % H4; if (k < dS) w0v[q] = *reinterpret_cast<const f32x4*>(W0 + (size_t)k * a.ldW0 + 4 * c4); }
+  }
+#pragma unroll
+  for (int q = 0; q < QC; ++q) {
+    const int f = tid + 256 * q; w1c[q] = z4;
+    if (f < H * 4) { const int k = f >> 2, c = n0 + (f & 3) * 4; w1c[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)k * a.ldW1 + c); }
+  }
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int f = tid + 256 * q; w1r[q] = z4;
+    if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w1r[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(n0 + r) * a.ldW1 + 4 * c4); }
+  }
+#pragma unroll
+  for (int q = 0; q < QO; ++q) { const int f = tid + 256 * q; wov[q] = f < H * 2 ? *reinterpret_cast<const f32x4*>(Wo + (size_t)f * 4) : z4; }
+  const float b0v = tid < H ? W[a.indB0 + tid] : 0.f;
+  const float wrv = tid < H ? W[a.indWr + tid] : 0.f, brv = tid < H ? W[a.indBr + tid] : 0.f;
+  const float b1e = W[a.indB1 + n0 + en];
+  const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
+  if (rowValid) slot = a.bt.slot[bSrc];
+  const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
+
+  // ---- stage: states, W0 (k-major), W1 column tile (k-major), Wout, vectors ------------------------
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31; sS[r * FLDS + c] = sv[q]; }
+#pragma unroll
+  for (int q = 0; q < FMAXK4; ++q) {
+    const int f = tid + 256 * q;
+    if (f < nW0) { const int k = f / H4, c4 = f % H4; *reinterpret_cast<f32x4*>(sR2 + k * LDW0 + 4 * c4) = w0v[q]; }
+  }
+#pragma unroll
+  for (int q = 0; q < QC; ++q) { const int f = tid + 256 * q; if (f < H * 4) *reinterpret_cast<f32x4*>(sR3 + (size_t)f * 4) = w1c[q]; }
+#pragma unroll
+  for (int q = 0; q < QO; ++q) { const int f = tid + 256 * q; if (f < H * 2) *reinterpret_cast<f32x4*>(sWo + (size_t)f * 4) = wov[q]; }
+  if (tid < H) { sB0[tid] = b0v; sWr[tid] = wrv; sBr[tid] = brv; }
+  if (tid < 16) { sBo[tid] = bov; sBp[tid] = bpv; }
+  __syncthreads();
+  if (a.variant == 1) return;
+
+  // the replay rows of the head (issued now, consumed after the exchange): one (sample, dim) per thread
+  double act = 0, bMean = 0, bStd = 1; float misc = 0.f;
+  if (rowValid && !isNext && en < dA) {
+    act = a.rp.A[(size_t)slot * dA + en];
+    bMean = a.rp.MU[(size_t)slot * 2 * dA + en]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + en];
+  }
+  if (rowValid) {   // lanes 0..5: RET, DQ, DKL, IMPW, V, ADV of the sampled step; next rows: lanes 6, 7: V, ADV of t+1
+    const float* arr = nullptr; long long sl = slot;
+    if (!isNext) arr = en == 0 ? a.rp.RET : en == 1 ? a.rp.DQ : en == 2 ? a.rp.DKL : en == 3 ? a.rp.IMPW : en == 4 ? a.rp.V : en == 5 ? a.rp.ADV : nullptr;
+    else { arr = en == 6 ? a.rp.V : en == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
+    if (arr) misc = arr[sl];
+  }
+
+  // ---- h1 = f(S W0 + b0), whole panel: wave w computes column tiles w, w+4, ... --------------------
+  {
+    float av[FMAXK4], bv[TPW][FMAXK4];
+#pragma unroll
+    for (int s = 0; s < FMAXK4; ++s) {
+      const int ka = 4 * s + lc;
+      av[s] = 4 * s < dSp ? sS[li * FLDS + ka] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) { const int nt = wave + 4 * t; bv[t][s] = (4 * s < dSp && nt < HT) ? sR2[ka * LDW0 + nt * 16 + li] : 0.f; }
+    }
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = z4;
+#pragma unroll
+    for (int s = 0; s < FMAXK4; ++s) {
+      if (4 * s < dSp) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[t][s], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int nt = wave + 4 * t;
+      if (nt < HT) {
+        const int c = nt * 16 + li;
+        const float bb = sB0[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lc * 4 + r;
+          const float x = acc[t][r] + bb;
+          sY1[i * FLDR + c] = actEval(a.func, x);
+          if (nt == n) sT[i * 16 + li] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float x1o = sT[em * 16 + en], y1o = sY1[em * FLDR + n0 + en];
+  if (a.variant == 2) return;
+  if (row < B) a.Y1[(size_t)row * a.ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
+
+  // ---- own tile of x2 = h1 W1 + b1: K split over the 4 waves ----------------------------------------
+  {
+    const int k0 = wave * KW + lc;
+    const f32x4 acc = waveMma<NK>([&](int s) { return sY1[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sR3[(k0 + 4 * s) * 16 + li]; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+  }
+  __syncthreads();
+  if (rowValid) {
+    const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    const float x2 = v + b1e;
+    const float y2 = actEval(a.func, x2);
+    const float y3 = (n0 + en < a.resN) ? resOut(y2, y1o, sWr[n0 + en], sBr[n0 + en]) : y2;
+    st_agent(a.R2 + (size_t)row * a.ldA1 + n0 + en, y3);                         // also the A operand of dWout
+    st_agent(a.X2 + (size_t)row * a.ldA1 + n0 + en, actDiff(a.func, x2, y2));   // f'(x2)
+  }
+  // ---- group barrier: all HT tiles of this panel are in memory ------------------------------------------
+  if (a.variant == 3) return;
+  __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the write-through stores are acknowledged
+  __syncthreads();
+  if (HT > 1 && tid == 0) {
+    unsigned* ctr = a.panelCtr + panel * 32;
+    const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (old / (unsigned)HT + 1u) * (unsigned)HT;
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { a.sc->errFlag = 77; break; }   // never hang the GPU on a lost workgroup
+    }
+  }
+  __syncthreads();
+
+  // ---- read the panel's y3 and f'(x2) back -----------------------------------------------------------------
+  if (a.variant == 4) return;
+  float* sY3 = sR2; float* sF2 = sR3; float* sBx = sY1;
+  {
+    f32x4 yv[QP], fv[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int f = tid + 256 * q; yv[q] = z4; fv[q] = z4;
+      if (f < 16 * H4) {
+        const int r = f / H4, c4 = f % H4;
+        if (m0 + r < nRows) {
+          yv[q] = *reinterpret_cast<const f32x4*>(a.R2 + (size_t)(m0 + r) * a.ldA1 + 4 * c4);
+          fv[q] = *reinterpret_cast<const f32x4*>(a.X2 + (size_t)(m0 + r) * a.ldA1 + 4 * c4);
+        }
+      }
+    }
+    // h1 is dead (own tile kept in registers): R1 takes the W1 row tile of the dX contraction
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int f = tid + 256 * q;
+      if (f < 16 * H4) {
+        const int r = f / H4, c = 4 * (f % H4);
+        float2* d = reinterpret_cast<float2*>(sBx + r * FLDR + c);
+        d[0] = make_float2(w1r[q][0], w1r[q][1]); d[1] = make_float2(w1r[q][2], w1r[q][3]);
+        float2* dy = reinterpret_cast<float2*>(sY3 + r * FLDR + c);
+        dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
+        float2* df = reinterpret_cast<float2*>(sF2 + r * FLDR + c);
+        df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
+      }
+    }
+  }
+  __syncthreads();
+  if (a.variant == 5) return;
+
+  // ---- output layer: O[16][nDense] = y3 Wout + bo (MFMA, columns >= 8 are zero) -----------------------
+  {
+    const int k0 = wave * KW + lc;
+    const f32x4 acc = waveMma<NK>([&](int s) { return sY3[li * FLDR + k0 + 4 * s]; },
+                                  [&](int s) { return li < 8 ? sWo[(k0 + 4 * s) * 8 + li] : 0.f; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+  }
+  __syncthreads();
+  {
+    const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    if (en < nDense) sO[em * 16 + en] = (double)(v + sBo[en]);
+    if (en < dA) sO[em * 16 + nDense + en] = (double)sBp[en];     // ParamLayer, Linear
+  }
+  __syncthreads();
+
+  // ---- V-RACER head: thread = (sample em, action component en), fp64 --------------------------------------
+  if (a.variant == 6) return;
+  const bool writer = (n == 0);
+  const int base = lane & ~15;
+  {
+    float g0f = 0.f, gMf = 0.f;
+    if (rowValid && isNext) {     // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
+      const float oV = __shfl(misc, base + 6, 64), oA = __shfl(misc, base + 7, 64);
+      if (writer && en == 0) {
+        const float Vn = (float)scaleNet2V(sO[em * 16]);
+        a.bt.oldNextV[bSrc] = oV; a.bt.oldNextADV[bSrc] = oA;
+        a.rp.V[slot + 1] = Vn; a.rp.ADV[slot + 1] = 0.f; a.bt.nextV[bSrc] = Vn;
+        a.bt.O[(size_t)row * a.nOut] = sO[em * 16];
+      }
+    }
+    const bool live = rowValid && !isNext;
+    const double MAXM = 8.31776613503286;
+    double lw = 0, kl = 0, mean = 0, stdev = 1, invStd = 1, dPos = 0;
+    bool bnd = false;
+    if (live && en < dA) {
+      bnd = a.bounded[en] != 0;
+      mean = sO[em * 16 + 1 + en];
+      const double pp = sO[em * 16 + nDense + en];
+      const double rt = sqrt(1 + pp * pp);
+      stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
+      const double bInv = 1 / bStd;
+      // log pi(a) - log mu(a) and D_KL(pi || mu) share one logarithm (see head.hip)
+      const double m = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
+      const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
+      const double qq = stdev * bInv, lq = log(qq);
+      lw = (u2 * u2 - u1 * u1) / 2 - lq;
+      const double CmuCpi = qq * qq, dm = (mean - bMean) * bInv;
+      kl = (CmuCpi - 1 + dm * dm - 2 * lq) / 2;
+    }
+    const double logW = sum16(lw), DKL = sum16(kl);
+    const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
+    const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
+    const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
+    const double O0 = sO[em * 16];
+    const double V = scaleNet2V(O0);
+    const double Qret = (double)__shfl(misc, base, 64);
+    const double A_RET = Qret - V, dQ = A_RET;                       // Zero_advantage
+    const double Ver = fmin(1.0, RHO) * dQ;
+    const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
+    const double coef = A_RET * fmin(Cmax, RHO);
+    if (live && en < dA) {
+      const double dMean = mean - bMean, invVarMu = 1 / (bStd * bStd);
+      const double penalM = -1 * (dMean * invVarMu);
+      const double penalS = dPos * -1 * ((invVarMu - invStd * invStd) * stdev);
+      double polM = 0, polS = 0;
+      if (!far) {
+        if (bnd) {
+          const double dLogPdMean = (act - mean) * invStd * invStd;
+          const double m = mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean);
+          const double u = (act - m) * invStd;
+          polS = dPos * coef * ((u * u - 1) * invStd);
+          if (mean >= MAXM && coef * dLogPdMean > 0) polM = 0;
+          else if (mean <= -MAXM && coef * dLogPdMean < 0) polM = 0;
+          else polM = coef * dLogPdMean;
+        } else {
+          const double u = (act - mean) * invStd;
+          polM = coef * (u * invStd);
+          polS = dPos * coef * ((u * u - 1) * invStd);
+        }
+      }
+      const double gM = beta * polM + (1 - beta) * penalM;
+      const double gS = beta * polS + (1 - beta) * penalS;
+      gMf = (float)gM;                                             // Activation::addOutputDelta: nnReal += Real
+      if (writer) {
+        a.bt.gParam[(size_t)bSrc * dA + en] = (float)gS;
+        a.bt.G[(size_t)bSrc * a.nOut + 1 + en] = (double)gMf;
+        a.bt.G[(size_t)bSrc * a.nOut + nDense + en] = (double)(float)gS;
+      }
+    }
+    if (live) g0f = (float)g0;
+    // output-layer deltas of the panel (zero for next / padding rows)
+    const float gPrev = __shfl(gMf, base + ((en + 15) & 15), 64);     // component en-1 of the same sample
+    if (en < 8) sDo[em * 8 + en] = en == 0 ? g0f : (en <= dA ? gPrev : 0.f);
+    if (live && writer) {
+      const float oDQ = __shfl(misc, base + 1, 64), oDKL = __shfl(misc, base + 2, 64), oW = __shfl(misc, base + 3, 64);
+      const float oV = __shfl(misc, base + 4, 64), oADV = __shfl(misc, base + 5, 64);
+      if (en == 0) {
+        a.bt.pEid[bSrc] = a.bt.eid[bSrc]; a.bt.pNextOf[bSrc] = a.bt.nextOf[bSrc];
+        a.bt.G[(size_t)bSrc * a.nOut] = (double)g0f;
+        a.bt.rho[bSrc] = RHO; a.bt.dkl[bSrc] = DKL; a.bt.far[bSrc] = far ? 1 : 0;
+        // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
+        const float E = (float)dQ, D = (float)DKL, Wn = (float)RHO, Vf = (float)V;
+        a.bt.oldDQ[bSrc] = oDQ; a.bt.oldDKL[bSrc] = oDKL; a.bt.oldW[bSrc] = oW; a.bt.oldV[bSrc] = oV; a.bt.oldADV[bSrc] = oADV;
+        a.bt.newDQ[bSrc] = E; a.bt.newDKL[bSrc] = D; a.bt.newW[bSrc] = Wn; a.bt.newV[bSrc] = Vf;
+        a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = 0.f;
+        a.bt.dq[bSrc] = (double)E;
+      }
+      if (en < a.nOut) a.bt.O[(size_t)row * a.nOut + en] = sO[em * 16 + en];
+    }
+  }
+  __syncthreads();
+  if (a.variant == 7) return;
+  if (writer && row < B && en < nDense) a.dOut[(size_t)row * a.ldDo + en] = sDo[em * 8 + en];
+
+  // ---- delta_y3 = delta_out Wout^T (MFMA, K = 8), delta_x2 = delta_y3 f'(x2): whole panel ----------------------
+  {
+    const float a0 = sDo[li * 8 + lc], a1 = sDo[li * 8 + 4 + lc];
+    float b0[TPW], b1[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int nt = wave + 4 * t;
+      b0[t] = nt < HT ? sWo[(nt * 16 + li) * 8 + lc] : 0.f; b1[t] = nt < HT ? sWo[(nt * 16 + li) * 8 + 4 + lc] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int nt = wave + 4 * t;
+      if (nt < HT) {
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], z4, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc, 0, 0, 0);
+        const int c = nt * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lc * 4 + r;
+          const float s = acc[r];
+          const float dx2 = s * sF2[i * FLDR + c];
+          sF2[i * FLDR + c] = dx2;
+          if (nt == n) {
+            sT[i * 16 + li] = s;
+            if (m0 + i < B) { a.Dres2[(size_t)(m0 + i) * a.ldA1 + c] = s; a.D2[(size_t)(m0 + i) * a.ldA1 + c] = dx2; }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.variant == 8) return;
+
+  // ---- own tile of delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1) ----------------------
+  {
+    const int k0 = wave * KW + lc;
+    const f32x4 acc = waveMma<NK>([&](int s) { return sF2[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sBx[li * FLDR + k0 + 4 * s]; });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+  }
+  __syncthreads();
+  if (row < B) {
+    const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    float dres = v;
+    if (n0 + en < a.resN) dres += sT[em * 16 + en] * sWr[n0 + en];
+    a.Dres1[(size_t)row * a.ldA0 + n0 + en] = dres;
+    a.D1[(size_t)row * a.ldA0 + n0 + en] = dres * actDiff(a.func, x1o, y1o);
+  }
+}
+
+template <int H>
+static hipError_t launchFusedT(const FusedArgs& a, int maxRows, const ExtraArgs& ex, hipStream_t s) {
+  const int HT = H / 16, panels = (maxRows + 15) / 16, pg = (panels + 7) / 8;
+  const size_t lds = fusedLdsBytes(a.dS, H);
+  static size_t attrSet = 0;
+  if (lds > attrSet) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attrSet = lds;
+  }
+  hipLaunchKernelGGL(fused_fwd_head_dx_kernel<H>, dim3(8 + 8 * HT * pg), dim3(256), lds, s, a, ex);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  switch (a.H) {
+    case 16: return launchFusedT<16>(a, maxRows, ex, s);
+    case 32: return launchFusedT<32>(a, maxRows, ex, s);
+    case 64: return launchFusedT<64>(a, maxRows, ex, s);
+    case 128: return launchFusedT<128>(a, maxRows, ex, s);
+    case 256: return launchFusedT<256>(a, maxRows, ex, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+size_t fused_lds_bytes(int dS, int H) { return fusedLdsBytes(dS, H); }
+
+}  // namespace hl

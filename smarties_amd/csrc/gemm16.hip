@@ -64,17 +64,18 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
 // launches of a step; the code is identical.
 template <int ROLE>
 __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
-                                                     const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
+                                                     const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra, ExtraArgs extra2) {
   // one LDS block, used either by a GEMM tile (two operand tiles + the cross-wave reduction
   // buffer) or by the tail code of the extra workgroup
   constexpr int GEMM_LDS = (2 * 16 * LDR + 4 * 256) * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
   // horizontal fusion: workgroup 0 of the grid (dispatched first) runs a piece of the step tail
-  if (extra.role && blockIdx.x == 0) { runExtra(extra, smem); return; }
+  const int nRiders = (extra.role ? 1 : 0) + (extra2.role ? 1 : 0);
+  if ((int)blockIdx.x < nRiders) { runExtra(blockIdx.x == 0 ? extra : extra2, smem); return; }
   float* sA = reinterpret_cast<float*>(smem);
   float* sB = sA + 16 * LDR;
   float* red = sB + 16 * LDR;
-  const int bid = blockIdx.x - (extra.role ? 1 : 0);
+  const int bid = blockIdx.x - nRiders;
   const int nRowsDyn = sc->nRows[hyp.parity];   // issued together with the problem-table fetch
   int p = 0;
   for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
@@ -231,15 +232,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
 }
 
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
-                       const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
+                       const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2) {
   if (nBlocks <= 0) return hipSuccess;
-  ExtraArgs ex{}; if (extra) ex = *extra;
-  const dim3 grid(nBlocks + (ex.role ? 1 : 0)), block(256);
+  ExtraArgs ex{}, ex2{}; if (extra) ex = *extra; if (extra2) ex2 = *extra2;
+  if (!ex.role && ex2.role) { ex = ex2; ex2 = ExtraArgs{}; }
+  const dim3 grid(nBlocks + (ex.role ? 1 : 0) + (ex2.role ? 1 : 0)), block(256);
   switch (role) {
-    case GEMM_ROLE_FWD0: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD0>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
-    case GEMM_ROLE_FWD: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
-    case GEMM_ROLE_DX: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_DX>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
-    default: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_DW>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex); break;
+    case GEMM_ROLE_FWD0: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD0>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex, ex2); break;
+    case GEMM_ROLE_FWD: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex, ex2); break;
+    case GEMM_ROLE_DX: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_DX>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex, ex2); break;
+    default: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_DW>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex, ex2); break;
   }
   return hipGetLastError();
 }

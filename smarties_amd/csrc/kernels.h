@@ -49,6 +49,21 @@ struct AdamArgs {
 enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7 };
 struct ExtraArgs { int role; int phases; SampleArgs samp; PostArgs post; };
 
+// fused forward + head + dX kernel of the two-hidden-layer MLP (fused.hip)
+struct FusedArgs {
+  DevScalars* sc; DevReplay rp; DevBatch bt;
+  int B, dS, dA, nDense, nOut, H, parity, func, resN;
+  const float* X0; int ldX0;              // standardized states of the minibatch [Mmax][ldX0]
+  const float* W;                         // weight blob
+  long long indW0, indB0, indW1, indB1, indWr, indBr, indWo, indBo, indBp; int ldW0, ldW1;
+  float* Y1; float* D1; float* Dres1; int ldA0;               // hidden block 0: activations, deltas
+  float* X2; float* R2; float* D2; float* Dres2; int ldA1;    // hidden block 1: pre-activations (exchange), y3, deltas
+  float* dOut; int ldDo;                  // output-layer deltas [B][ldDo]
+  unsigned* panelCtr;                     // [panels][32] arrive counters of the panel barrier (monotonic)
+  int variant;                            // development: stop after phase `variant` (0 = run everything)
+  unsigned char bounded[HL_MAX_DIMA];
+};
+
 struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
   DevScalars* sc; DevReplay rp;
   const int* eids; int count;        // eids == nullptr: all current positions (count = nEpisodes)
@@ -68,9 +83,12 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 // minibatch (samp); either may be nullptr
 hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStream_t s, int phases = PH_ALL);
 enum { GEMM_ROLE_FWD0 = 0, GEMM_ROLE_FWD = 1, GEMM_ROLE_DX = 2, GEMM_ROLE_DW = 3 };
+// up to two riders (extra, extra2) occupy workgroups 0 and 1 of the grid
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
-                       const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
+                       const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
+hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
+size_t fused_lds_bytes(int dS, int H);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);

@@ -77,6 +77,7 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
   GraphSlot graphs[3]; bool graphsStale = false, useGraph = true;
+  bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
   hipStream_t sSample = nullptr, sPost = nullptr;
   std::vector<hipEvent_t> evPool; int evUsed = 0;
   int dbgVariant = 0;
@@ -415,6 +416,21 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     if (d.hasRes) HIPCK(devAlloc(&d.Rr, n)); else d.Rr = nullptr;
     HIPCK(devAlloc(&d.D, (size_t)B * d.ldA)); HIPCK(devAlloc(&d.Dres, (size_t)B * d.ldA));
   }
+  {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces
+    const char* e = getenv("SMARTIES_HIP_NO_FUSED");
+    const bool off = e && e[0] == '1';
+    if (!off && h->nHidden == 2) {
+      const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
+      h->fusedOk = d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nDense <= 8 && h->ldWo == 8 &&
+                   !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
+                   fused_lds_bytes(h->dS, d1.size) <= 160 * 1024;
+    }
+    if (h->fusedOk) {
+      const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
+      HIPCK(devAlloc(&h->panelCtr, nCtr));
+      HIPCK(hipMemset(h->panelCtr, 0, nCtr * sizeof(unsigned)));
+    }
+  }
   h->ldDo = (int)roundUp(h->nDense, 16);
   HIPCK(devAlloc(&h->dOut, (size_t)B * h->ldDo));
   for (int pb = 0; pb < 2; ++pb) {
@@ -741,9 +757,7 @@ int hl_step_begin(hl_learner* h, const int64_t* flat) {
     dFlat = h->dFlatGiven;
   }
   rc = launchSample(h, 0, dFlat, true, h->stream); if (rc) return rc;
-  rc = launchForward(h, 0, h->stream); if (rc) return rc;
-  rc = launchHead(h, 0, h->stream); if (rc) return rc;
-  rc = launchBackward(h, 0, false, h->stream); if (rc) return rc;
+  rc = launchMlp(h, 0, false, h->stream); if (rc) return rc;
   h->lastParity = 0;
   rc = launchPost(h, 0, POST_AGG, h->stream); if (rc) return rc;
   h->momentsPending = false;
@@ -938,6 +952,12 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
         case 24: if (!sb.dxIdx.empty()) { ExtraArgs ex{}; ex.role = 2; ex.post = postArgs(h, 0, POST_AGG | POST_BETA);
           e = launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[0], 1, sb.dxBlocks[0], h->sc, hyp, &ex, h->stream); } break;
         case 25: e = launch_gemm(GEMM_ROLE_DW, h->dProbs + sb.dwAdamIdx, sb.dwCount, sb.dwBlocks, h->sc, hyp, nullptr, h->stream); break;
+        // fused path: 26 = forward+head+dX (+ sampler phases A,B), 27 = dW+Adam (+ phase C, bookkeeping),
+        // 28 / 29 = the same two kernels without riders
+        case 26: rc = h->fusedOk ? launchFused(h, 0, h->stream, true) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
+        case 27: rc = h->fusedOk ? launchWeightGrad(h, 0, true, h->stream, true, false) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
+        case 28: rc = h->fusedOk ? launchFused(h, 0, h->stream, false) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
+        case 29: rc = h->fusedOk ? launchWeightGrad(h, 0, true, h->stream, false, false) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
         default: break;
       }
       if (e != hipSuccess) rc = hipFail(h, e, "debug launch");

@@ -151,6 +151,29 @@ ExtraArgs extraSample(hl_learner* h, int parityNext, int phases) {
   ExtraArgs ex{}; ex.role = 1; ex.phases = phases; ex.samp = sampleArgs(h, parityNext, nullptr, false);
   return ex;
 }
+FusedArgs fusedArgs(hl_learner* h, int parity) {
+  const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
+  FusedArgs fa{}; fa.sc = h->sc; fa.rp = h->rp; fa.bt = h->buf[parity].bt;
+  fa.B = h->B; fa.dS = h->dS; fa.dA = h->dA; fa.nDense = h->nDense; fa.nOut = h->nOut; fa.H = d1.size; fa.parity = parity;
+  fa.func = d1.func; fa.resN = d1.resW;
+  fa.X0 = h->buf[parity].X0; fa.ldX0 = h->ldX0; fa.W = h->W;
+  fa.indW0 = d0.indW; fa.indB0 = d0.indB; fa.indW1 = d1.indW; fa.indB1 = d1.indB; fa.indWr = d1.indWr; fa.indBr = d1.indBr;
+  fa.indWo = h->indWo; fa.indBo = h->indBo; fa.indBp = h->indBp; fa.ldW0 = d0.ldW; fa.ldW1 = d1.ldW;
+  fa.Y1 = d0.Y; fa.D1 = d0.D; fa.Dres1 = d0.Dres; fa.ldA0 = d0.ldA;
+  fa.X2 = d1.X; fa.R2 = d1.Rr; fa.D2 = d1.D; fa.Dres2 = d1.Dres; fa.ldA1 = d1.ldA;
+  fa.dOut = h->dOut; fa.ldDo = h->ldDo; fa.panelCtr = h->panelCtr; fa.variant = h->dbgVariant;
+  for (int i = 0; i < h->dA; ++i) fa.bounded[i] = h->cfg.bounded[i];
+  return fa;
+}
+// forward + head + dX of the whole minibatch as one kernel (fused.hip); `nextSample`: sampler phases
+// A and B of the NEXT step ride along
+int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
+  const FusedArgs fa = fusedArgs(h, parity);
+  ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_ALL); pex = &ex; }
+  HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
+  return HL_OK;
+}
 int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
@@ -176,6 +199,19 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
   return HL_OK;
 }
 // fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
+// dW launch of the fused path: the dX contractions were done by the fused kernel; riders: the
+// bookkeeping of THIS step and sampler phase C of the NEXT one
+int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost, bool nextSampleC) {
+  const AdamHyper hyp = adamHyper(h, parity);
+  const StepBuf& sb = h->buf[parity];
+  ExtraArgs exP{}, exC{};
+  if (fusePost) { exP.role = 2; exP.post = postArgs(h, parity, POST_AGG | POST_BETA); }
+  if (nextSampleC) exC = extraSample(h, parity ^ 1, PH_C);
+  HIPCK(timed(h, "gemm16_dw", s, [&] {
+    return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp,
+                       nextSampleC ? &exC : nullptr, s, fusePost ? &exP : nullptr); }));
+  return HL_OK;
+}
 int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
@@ -258,6 +294,17 @@ bool evictionDue(const hl_learner* h) {
   return !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
 }
 
+// forward, head, backward (dX and dW) of buffer `parity`, eager, no riders
+int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
+  if (h->fusedOk) {
+    int rc = launchFused(h, parity, s); if (rc) return rc;
+    return launchWeightGrad(h, parity, fuseAdam, s, false, false);
+  }
+  int rc = launchForward(h, parity, s); if (rc) return rc;
+  rc = launchHead(h, parity, s); if (rc) return rc;
+  return launchBackward(h, parity, fuseAdam, s);
+}
+
 // one full step, eager launches on the main stream, minibatch buffer 0
 int stepEager(hl_learner* h, const long long* dFlat) {
   hipStream_t s = h->stream;
@@ -265,9 +312,7 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   const bool periodic = (k % 1000) == 0;
   const bool fuse = !exchanging(h);
   int rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc;
-  rc = launchForward(h, 0, s); if (rc) return rc;
-  rc = launchHead(h, 0, s); if (rc) return rc;
-  rc = launchBackward(h, 0, fuse, s); if (rc) return rc;
+  rc = launchMlp(h, 0, fuse, s); if (rc) return rc;
   if (!fuse) { rc = allreduceGrad(h); if (rc) return rc; rc = launchAdam(h, 0); if (rc) return rc; }
   h->lastParity = 0;
   const bool evict = evictionDue(h);
@@ -295,6 +340,11 @@ int captureSteps(hl_learner* h, int U, GraphSlot* slot) {
   for (int j = 0; j < U && !rc; ++j) {
     const int p = j & 1;
     const bool more = j + 1 < U;                        // pre-sample step j+1 while step j computes
+    if (h->fusedOk) {
+      rc = launchFused(h, p, s0, more); if (rc) break;
+      rc = launchWeightGrad(h, p, true, s0, true, false); if (rc) break;
+      continue;
+    }
     rc = launchForward(h, p, s0, more); if (rc) break;
     rc = launchHead(h, p, s0, more); if (rc) break;
     rc = launchBackward(h, p, true, s0, true); if (rc) break;
