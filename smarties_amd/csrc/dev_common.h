@@ -8,6 +8,7 @@
 namespace hl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float actEval(int f, float in) {   // Network/Layers/Functions.h
   switch (f) {

@@ -31,8 +31,45 @@ namespace hl {
 #define FLDS 34             // leading dimension of the 16 x dS state tile
 #define FMAXK4 8            // dS <= 32: at most 8 MFMA k-steps in the first layer
 
+// development time stamps of workgroup (panel 0, tile 1), 100 MHz clock: -DHL_TAIL_STAMPS
+#if defined(HL_TAIL_STAMPS) && !defined(HL_NO_FSTAMP)
+#define FSTAMP(i) do { if (threadIdx.x == 0 && panel == 0 && n == 1) a.sc->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void st_agent(float* p, float v) {   // write-through to the agent coherence point
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// activation evaluated with the function known at compile time; dispatchFunc() branches ONCE on the
+// (uniform) function id and runs the whole epilogue branch-free
+// n / d for d in [1, 2^60): reciprocal + Newton step + two residual corrections -- the IEEE division
+// expansion without its range scaling (v_div_scale / v_div_fmas serialise on VCC, so sixteen of
+// them per thread cannot overlap; these can)
+__device__ __forceinline__ float divNoScale(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  float q = n * r;
+  q = fmaf(fmaf(-d, q, n), r, q);
+  q = fmaf(fmaf(-d, q, n), r, q);
+  return q;
+}
+template <int F> __device__ __forceinline__ float actEvalT(float in) {
+  if constexpr (F == HL_FUNC_SOFTSIGN) return divNoScale(in, 1 + fabsf(in));
+  else return actEval(F, in);
+}
+template <int F> __device__ __forceinline__ float actDiffT(float in, float out) {
+  if constexpr (F == HL_FUNC_SOFTSIGN) { const float d = 1 + fabsf(in); return divNoScale(1.0f, d * d); }
+  else return actDiff(F, in, out);
+}
+template <int F> struct FuncTag { static constexpr int value = F; };
+// CF >= 0: the activation is a template parameter of the kernel (no other code is generated)
+template <int CF, class Body> __device__ __forceinline__ void dispatchFunc(int func, Body body) {
+  if constexpr (CF >= 0) body(FuncTag<CF>{});
+  else if (func == HL_FUNC_SOFTSIGN) body(FuncTag<HL_FUNC_SOFTSIGN>{});
+  else if (func == HL_FUNC_TANH) body(FuncTag<HL_FUNC_TANH>{});
+  else if (func == HL_FUNC_RELU) body(FuncTag<HL_FUNC_RELU>{});
+  else body(FuncTag<HL_FUNC_LINEAR>{});
 }
 __device__ __forceinline__ float resOut(float y, float in, float w, float b) { return y + fmaf(in, w, b); }
 __device__ __forceinline__ double sum16(double v) {            // over the 16 lanes of one sample
@@ -69,11 +106,16 @@ __device__ __forceinline__ f32x4 waveMma(FA fa, FB fb) {
   return acc0 + acc1;
 }
 
-template <int H>
+template <int H, int CF>
 __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, ExtraArgs extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // blocks 0..7: riders (tail work of the neighbouring steps); 8 of them keep blockIdx % 8 == XCD
-  if (blockIdx.x < 8) { if (blockIdx.x == 0 && extra.role) runExtra(extra, smem); return; }
+  if (blockIdx.x < 8) {
+    // the sampler runs in block 0; with PH_PUBLISH its gather is spread over blocks 1..7
+    if (blockIdx.x == 0) { if (extra.role) runExtra(extra, smem); }
+    else if (extra.role == 1 && (extra.phases & PH_PUBLISH)) gatherHelper(extra.samp, blockIdx.x - 1, 7, smem);
+    return;
+  }
   constexpr int HT = H / 16, H4 = H / 4, LDW0 = H + 16;
   constexpr int KW = H / 4;                      // reduction length per wave of the K-split contractions
   constexpr int NK = KW / 4;                     // MFMA steps per wave
@@ -83,11 +125,20 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   constexpr int QO = (H * 2 + 255) / 256;        // float4 per thread of Wout [H][8]
   const DevScalars* sc = a.sc;
   const int dS = a.dS, dSp = (dS + 3) & ~3, B = a.B, dA = a.dA, nDense = a.nDense;
+  // arguments used inside the hot loops, pinned in VGPRs: under SGPR pressure the compiler would
+  // otherwise re-load them from the kernarg segment at every use (~1 us per epilogue)
+  const int func = __builtin_amdgcn_readfirstlane(a.func);
+  int resN = a.resN, ldA0 = a.ldA0, ldA1 = a.ldA1;
+  asm volatile("" : "+v"(resN), "+v"(ldA0), "+v"(ldA1));
+  float* gR2 = a.R2; float* gX2 = a.X2; float* gD2 = a.D2; float* gDres2 = a.Dres2;
+  asm volatile("" : "+v"(gR2), "+v"(gX2), "+v"(gD2), "+v"(gDres2));
   const int bid = blockIdx.x - 8, xcd = bid & 7, gi = bid >> 3;
   const int panel = (gi / HT) * 8 + xcd, n = gi % HT;
   const int m0 = panel * 16, n0 = n * 16;
-  const int nRows = sc->nRows[a.parity];
-  if (m0 >= nRows) return;
+  // panels made of sampled rows only never wait for the row count of this minibatch
+  int nRows = a.B;
+  if (m0 + 16 > a.B) { nRows = sc->nRows[a.parity]; if (m0 >= nRows) return; }
+  FSTAMP(0);
 
   float* sY1 = reinterpret_cast<float*>(smem);                 // [16][FLDR]
   float* sR2 = sY1 + 16 * FLDR;
@@ -104,7 +155,8 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   float* sBo = sT + 256;                                       // [16] output bias, [16] ParamLayer bias
   float* sBp = sBo + 16;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on it
   const int li = lane & 15, lc = lane >> 4;
   const int em = tid >> 4, en = tid & 15;                      // the output element / (sample, dim) of this thread
   const float* W = a.W;
@@ -114,7 +166,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   const int row = m0 + em;
   const bool rowValid = row < nRows, isNext = rowValid && row >= B;
   int bSrc = 0; long long slot = 0;
-  if (rowValid) { bSrc = isNext ? a.bt.nextSrc[row - B] : row; }
+  if (rowValid) { bSrc = isNext ? a.bt.nextSrc[row - B] : row; slot = a.bt.slot[bSrc]; }   // oldest loads: the gathers hang off them
   float sv[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -145,8 +197,20 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   const float wrv = tid < H ? W[a.indWr + tid] : 0.f, brv = tid < H ? W[a.indBr + tid] : 0.f;
   const float b1e = W[a.indB1 + n0 + en];
   const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
-  if (rowValid) slot = a.bt.slot[bSrc];
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
+
+  // the replay rows of the head (issued now, consumed after the exchange): one (sample, dim) per thread
+  double act = 0, bMean = 0, bStd = 1; float misc = 0.f;
+  if (rowValid && !isNext && en < dA) {
+    act = a.rp.A[(size_t)slot * dA + en];
+    bMean = a.rp.MU[(size_t)slot * 2 * dA + en]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + en];
+  }
+  if (rowValid) {   // lanes 0..5: RET, DQ, DKL, IMPW, V, ADV of the sampled step; next rows: lanes 6, 7: V, ADV of t+1
+    const float* arr = nullptr; long long sl = slot;
+    if (!isNext) arr = en == 0 ? a.rp.RET : en == 1 ? a.rp.DQ : en == 2 ? a.rp.DKL : en == 3 ? a.rp.IMPW : en == 4 ? a.rp.V : en == 5 ? a.rp.ADV : nullptr;
+    else { arr = en == 6 ? a.rp.V : en == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
+    if (arr) misc = arr[sl];
+  }
 
   // ---- stage: states, W0 (k-major), W1 column tile (k-major), Wout, vectors ------------------------
 #pragma unroll
@@ -163,61 +227,57 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   if (tid < H) { sB0[tid] = b0v; sWr[tid] = wrv; sBr[tid] = brv; }
   if (tid < 16) { sBo[tid] = bov; sBp[tid] = bpv; }
   __syncthreads();
+  FSTAMP(1);
   if (a.variant == 1) return;
 
-  // the replay rows of the head (issued now, consumed after the exchange): one (sample, dim) per thread
-  double act = 0, bMean = 0, bStd = 1; float misc = 0.f;
-  if (rowValid && !isNext && en < dA) {
-    act = a.rp.A[(size_t)slot * dA + en];
-    bMean = a.rp.MU[(size_t)slot * 2 * dA + en]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + en];
-  }
-  if (rowValid) {   // lanes 0..5: RET, DQ, DKL, IMPW, V, ADV of the sampled step; next rows: lanes 6, 7: V, ADV of t+1
-    const float* arr = nullptr; long long sl = slot;
-    if (!isNext) arr = en == 0 ? a.rp.RET : en == 1 ? a.rp.DQ : en == 2 ? a.rp.DKL : en == 3 ? a.rp.IMPW : en == 4 ? a.rp.V : en == 5 ? a.rp.ADV : nullptr;
-    else { arr = en == 6 ? a.rp.V : en == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
-    if (arr) misc = arr[sl];
-  }
-
   // ---- h1 = f(S W0 + b0), whole panel: wave w computes column tiles w, w+4, ... --------------------
-  {
-    float av[FMAXK4], bv[TPW][FMAXK4];
-#pragma unroll
-    for (int s = 0; s < FMAXK4; ++s) {
-      const int ka = 4 * s + lc;
-      av[s] = 4 * s < dSp ? sS[li * FLDS + ka] : 0.f;
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) { const int nt = wave + 4 * t; bv[t][s] = (4 * s < dSp && nt < HT) ? sR2[ka * LDW0 + nt * 16 + li] : 0.f; }
-    }
+  if (wave < HT) {
     f32x4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = z4;
+    const int nk4 = dSp >> 2;
+    // operands of step s+1 are read while the MFMAs of step s run
+    float av = sS[li * FLDS + lc], bv[TPW];
 #pragma unroll
-    for (int s = 0; s < FMAXK4; ++s) {
-      if (4 * s < dSp) {
+    for (int t = 0; t < TPW; ++t) bv[t] = sR2[lc * LDW0 + (wave + 4 * t) * 16 + li];
+    for (int s = 0; s < nk4; ++s) {
+      const int kn = s + 1 < nk4 ? 4 * (s + 1) + lc : lc;
+      const float avn = sS[li * FLDS + kn];
+      float bvn[TPW];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[t][s], acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < TPW; ++t) bvn[t] = sR2[kn * LDW0 + (wave + 4 * t) * 16 + li];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+      av = avn;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) bv[t] = bvn[t];
     }
+    FSTAMP(14);
+    float bb[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int nt = wave + 4 * t;
-      if (nt < HT) {
+    for (int t = 0; t < TPW; ++t) bb[t] = sB0[(wave + 4 * t) * 16 + li];
+    dispatchFunc<CF>(func, [&](auto F) {
+      constexpr int FN = decltype(F)::value;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int nt = wave + 4 * t;
         const int c = nt * 16 + li;
-        const float bb = sB0[c];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = lc * 4 + r;
-          const float x = acc[t][r] + bb;
-          sY1[i * FLDR + c] = actEval(a.func, x);
+          const float x = acc[t][r] + bb[t];
+          sY1[i * FLDR + c] = actEvalT<FN>(x);
           if (nt == n) sT[i * 16 + li] = x;
         }
       }
-    }
+    });
   }
+  FSTAMP(15);
   __syncthreads();
   const float x1o = sT[em * 16 + en], y1o = sY1[em * FLDR + n0 + en];
+  FSTAMP(2);
   if (a.variant == 2) return;
-  if (row < B) a.Y1[(size_t)row * a.ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
+  if (row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
 
   // ---- own tile of x2 = h1 W1 + b1: K split over the 4 waves ----------------------------------------
   {
@@ -227,30 +287,53 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
   }
   __syncthreads();
+  FSTAMP(3);
   if (rowValid) {
     const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
     const float x2 = v + b1e;
-    const float y2 = actEval(a.func, x2);
-    const float y3 = (n0 + en < a.resN) ? resOut(y2, y1o, sWr[n0 + en], sBr[n0 + en]) : y2;
-    st_agent(a.R2 + (size_t)row * a.ldA1 + n0 + en, y3);                         // also the A operand of dWout
-    st_agent(a.X2 + (size_t)row * a.ldA1 + n0 + en, actDiff(a.func, x2, y2));   // f'(x2)
+    float y2 = 0.f, f2 = 0.f;
+    dispatchFunc<CF>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y2 = actEvalT<FN>(x2); f2 = actDiffT<FN>(x2, y2); });
+    const float y3 = (n0 + en < resN) ? resOut(y2, y1o, sWr[n0 + en], sBr[n0 + en]) : y2;
+    st_agent(gR2 + (size_t)row * ldA1 + n0 + en, y3);      // also the A operand of dWout
+    st_agent(gX2 + (size_t)row * ldA1 + n0 + en, f2);      // f'(x2)
+  }
+  FSTAMP(4);
+  // ---- head terms that do not depend on the network outputs of this step (the policy stdev comes
+  // from the ParamLayer bias alone): computed while the exchange stores drain / the barrier fills ------
+  const bool live = rowValid && !isNext;
+  const double MAXM = 8.31776613503286;
+  double stdev = 1, invStd = 1, dPos = 0, bInv = 1, invVarMu = 1, u2 = 0, lq = 0, CmuCpi = 1;
+  bool bnd = false;
+  asm volatile("" : "+v"(act), "+v"(bMean), "+v"(bStd));   // keep the fp64 work (and its wait on the gathers) here
+  if (live && en < dA) {
+    bnd = ((a.boundedMask >> en) & 1ull) != 0;
+    const double pp = (double)sBp[en];
+    const double rt = sqrt(1 + pp * pp);
+    stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
+    bInv = 1 / bStd; invVarMu = 1 / (bStd * bStd);
+    u2 = (act - bMean) * bInv;
+    const double qq = stdev * bInv;
+    lq = log(qq); CmuCpi = qq * qq;
   }
   // ---- group barrier: all HT tiles of this panel are in memory ------------------------------------------
-  if (a.variant == 3) return;
+  FSTAMP(5);
   __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the write-through stores are acknowledged
   __syncthreads();
+  if (a.variant == 3) return;
+  FSTAMP(6);
   if (HT > 1 && tid == 0) {
     unsigned* ctr = a.panelCtr + panel * 32;
     const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = (old / (unsigned)HT + 1u) * (unsigned)HT;
+    const unsigned barTarget = (old / (unsigned)HT + 1u) * (unsigned)HT;
     int spins = 0;
-    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - barTarget) < 0) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1 << 22)) { a.sc->errFlag = 77; break; }   // never hang the GPU on a lost workgroup
     }
   }
   __syncthreads();
 
+  FSTAMP(7);
   // ---- read the panel's y3 and f'(x2) back -----------------------------------------------------------------
   if (a.variant == 4) return;
   float* sY3 = sR2; float* sF2 = sR3; float* sBx = sY1;
@@ -262,8 +345,8 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
       if (f < 16 * H4) {
         const int r = f / H4, c4 = f % H4;
         if (m0 + r < nRows) {
-          yv[q] = *reinterpret_cast<const f32x4*>(a.R2 + (size_t)(m0 + r) * a.ldA1 + 4 * c4);
-          fv[q] = *reinterpret_cast<const f32x4*>(a.X2 + (size_t)(m0 + r) * a.ldA1 + 4 * c4);
+          yv[q] = *reinterpret_cast<const f32x4*>(gR2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
+          fv[q] = *reinterpret_cast<const f32x4*>(gX2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
         }
       }
     }
@@ -283,6 +366,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     }
   }
   __syncthreads();
+  FSTAMP(8);
   if (a.variant == 5) return;
 
   // ---- output layer: O[16][nDense] = y3 Wout + bo (MFMA, columns >= 8 are zero) -----------------------
@@ -294,52 +378,41 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
   }
   __syncthreads();
-  {
-    const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-    if (en < nDense) sO[em * 16 + en] = (double)(v + sBo[en]);
-    if (en < dA) sO[em * 16 + nDense + en] = (double)sBp[en];     // ParamLayer, Linear
-  }
-  __syncthreads();
+  FSTAMP(9);
+  // network outputs of sample em stay in registers: lane en holds O[em][en] (dense part); the
+  // ParamLayer part (Linear) is its bias
+  const int base = lane & ~15;
+  const float Oen = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]) + sBo[en];
+  const double O0 = (double)__shfl(Oen, base, 64);
+  const double mean = (double)__shfl(Oen, base + ((en + 1) & 15), 64);   // O[em][1 + en]
 
   // ---- V-RACER head: thread = (sample em, action component en), fp64 --------------------------------------
   if (a.variant == 6) return;
   const bool writer = (n == 0);
-  const int base = lane & ~15;
   {
     float g0f = 0.f, gMf = 0.f;
     if (rowValid && isNext) {     // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
       const float oV = __shfl(misc, base + 6, 64), oA = __shfl(misc, base + 7, 64);
       if (writer && en == 0) {
-        const float Vn = (float)scaleNet2V(sO[em * 16]);
+        const float Vn = (float)scaleNet2V(O0);
         a.bt.oldNextV[bSrc] = oV; a.bt.oldNextADV[bSrc] = oA;
         a.rp.V[slot + 1] = Vn; a.rp.ADV[slot + 1] = 0.f; a.bt.nextV[bSrc] = Vn;
-        a.bt.O[(size_t)row * a.nOut] = sO[em * 16];
+        a.bt.O[(size_t)row * a.nOut] = O0;
       }
     }
-    const bool live = rowValid && !isNext;
-    const double MAXM = 8.31776613503286;
-    double lw = 0, kl = 0, mean = 0, stdev = 1, invStd = 1, dPos = 0;
-    bool bnd = false;
+    double lw = 0, kl = 0;
     if (live && en < dA) {
-      bnd = a.bounded[en] != 0;
-      mean = sO[em * 16 + 1 + en];
-      const double pp = sO[em * 16 + nDense + en];
-      const double rt = sqrt(1 + pp * pp);
-      stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
-      const double bInv = 1 / bStd;
       // log pi(a) - log mu(a) and D_KL(pi || mu) share one logarithm (see head.hip)
       const double m = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
-      const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
-      const double qq = stdev * bInv, lq = log(qq);
+      const double u1 = (act - m) * invStd;
       lw = (u2 * u2 - u1 * u1) / 2 - lq;
-      const double CmuCpi = qq * qq, dm = (mean - bMean) * bInv;
+      const double dm = (mean - bMean) * bInv;
       kl = (CmuCpi - 1 + dm * dm - 2 * lq) / 2;
     }
     const double logW = sum16(lw), DKL = sum16(kl);
     const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
     const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
     const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
-    const double O0 = sO[em * 16];
     const double V = scaleNet2V(O0);
     const double Qret = (double)__shfl(misc, base, 64);
     const double A_RET = Qret - V, dQ = A_RET;                       // Zero_advantage
@@ -347,7 +420,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
     const double coef = A_RET * fmin(Cmax, RHO);
     if (live && en < dA) {
-      const double dMean = mean - bMean, invVarMu = 1 / (bStd * bStd);
+      const double dMean = mean - bMean;
       const double penalM = -1 * (dMean * invVarMu);
       const double penalS = dPos * -1 * ((invVarMu - invStd * invStd) * stdev);
       double polM = 0, polS = 0;
@@ -393,26 +466,30 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
         a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = 0.f;
         a.bt.dq[bSrc] = (double)E;
       }
-      if (en < a.nOut) a.bt.O[(size_t)row * a.nOut + en] = sO[em * 16 + en];
+      if (en < nDense) a.bt.O[(size_t)row * a.nOut + en] = (double)Oen;
+      if (en < dA) a.bt.O[(size_t)row * a.nOut + nDense + en] = (double)sBp[en];
     }
   }
   __syncthreads();
+  FSTAMP(10);
   if (a.variant == 7) return;
   if (writer && row < B && en < nDense) a.dOut[(size_t)row * a.ldDo + en] = sDo[em * 8 + en];
 
   // ---- delta_y3 = delta_out Wout^T (MFMA, K = 8), delta_x2 = delta_y3 f'(x2): whole panel ----------------------
   {
     const float a0 = sDo[li * 8 + lc], a1 = sDo[li * 8 + 4 + lc];
-    float b0[TPW], b1[TPW];
+    float b0[TPW], b1[TPW], f2v[TPW][4];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int nt = wave + 4 * t;
-      b0[t] = nt < HT ? sWo[(nt * 16 + li) * 8 + lc] : 0.f; b1[t] = nt < HT ? sWo[(nt * 16 + li) * 8 + 4 + lc] : 0.f;
+      const int nt = wave < HT ? wave + 4 * t : 0;
+      b0[t] = sWo[(nt * 16 + li) * 8 + lc]; b1[t] = sWo[(nt * 16 + li) * 8 + 4 + lc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f2v[t][r] = sF2[(lc * 4 + r) * FLDR + nt * 16 + li];
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int nt = wave + 4 * t;
-      if (nt < HT) {
+      if (wave < HT) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], z4, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc, 0, 0, 0);
         const int c = nt * 16 + li;
@@ -420,17 +497,18 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
         for (int r = 0; r < 4; ++r) {
           const int i = lc * 4 + r;
           const float s = acc[r];
-          const float dx2 = s * sF2[i * FLDR + c];
+          const float dx2 = s * f2v[t][r];
           sF2[i * FLDR + c] = dx2;
           if (nt == n) {
             sT[i * 16 + li] = s;
-            if (m0 + i < B) { a.Dres2[(size_t)(m0 + i) * a.ldA1 + c] = s; a.D2[(size_t)(m0 + i) * a.ldA1 + c] = dx2; }
+            if (m0 + i < B) { gDres2[(size_t)(m0 + i) * ldA1 + c] = s; gD2[(size_t)(m0 + i) * ldA1 + c] = dx2; }
           }
         }
       }
     }
   }
   __syncthreads();
+  FSTAMP(11);
   if (a.variant == 8) return;
 
   // ---- own tile of delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1) ----------------------
@@ -441,37 +519,49 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
   }
   __syncthreads();
+  FSTAMP(12);
   if (row < B) {
     const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
     float dres = v;
-    if (n0 + en < a.resN) dres += sT[em * 16 + en] * sWr[n0 + en];
-    a.Dres1[(size_t)row * a.ldA0 + n0 + en] = dres;
-    a.D1[(size_t)row * a.ldA0 + n0 + en] = dres * actDiff(a.func, x1o, y1o);
+    if (n0 + en < resN) dres += sT[em * 16 + en] * sWr[n0 + en];
+    a.Dres1[(size_t)row * ldA0 + n0 + en] = dres;
+    float f1 = 1.f;
+    dispatchFunc<CF>(func, [&](auto F) { f1 = actDiffT<decltype(F)::value>(x1o, y1o); });
+    a.D1[(size_t)row * ldA0 + n0 + en] = dres * f1;
   }
+  FSTAMP(13);
 }
 
-template <int H>
+template <int H, int CF>
 static hipError_t launchFusedT(const FusedArgs& a, int maxRows, const ExtraArgs& ex, hipStream_t s) {
   const int HT = H / 16, panels = (maxRows + 15) / 16, pg = (panels + 7) / 8;
   const size_t lds = fusedLdsBytes(a.dS, H);
   static size_t attrSet = 0;
   if (lds > attrSet) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attrSet = lds;
   }
-  hipLaunchKernelGGL(fused_fwd_head_dx_kernel<H>, dim3(8 + 8 * HT * pg), dim3(256), lds, s, a, ex);
+  hipLaunchKernelGGL((fused_fwd_head_dx_kernel<H, CF>), dim3(8 + 8 * HT * pg), dim3(256), lds, s, a, ex);
   return hipGetLastError();
+}
+// SoftSign (the reference's default for the shipped settings) and Tanh get their own instantiation;
+// every other activation takes the generic one (run-time dispatch inside the epilogues)
+template <int H>
+static hipError_t launchFusedH(const FusedArgs& a, int maxRows, const ExtraArgs& ex, hipStream_t s) {
+  if (a.func == HL_FUNC_SOFTSIGN) return launchFusedT<H, HL_FUNC_SOFTSIGN>(a, maxRows, ex, s);
+  if (a.func == HL_FUNC_TANH) return launchFusedT<H, HL_FUNC_TANH>(a, maxRows, ex, s);
+  return launchFusedT<H, -1>(a, maxRows, ex, s);
 }
 
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {
   ExtraArgs ex{}; if (extra) ex = *extra;
   switch (a.H) {
-    case 16: return launchFusedT<16>(a, maxRows, ex, s);
-    case 32: return launchFusedT<32>(a, maxRows, ex, s);
-    case 64: return launchFusedT<64>(a, maxRows, ex, s);
-    case 128: return launchFusedT<128>(a, maxRows, ex, s);
-    case 256: return launchFusedT<256>(a, maxRows, ex, s);
+    case 16: return launchFusedH<16>(a, maxRows, ex, s);
+    case 32: return launchFusedH<32>(a, maxRows, ex, s);
+    case 64: return launchFusedH<64>(a, maxRows, ex, s);
+    case 128: return launchFusedH<128>(a, maxRows, ex, s);
+    case 256: return launchFusedH<256>(a, maxRows, ex, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -60,27 +60,13 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
   }
 }
 
-// ROLE only names the instantiation (fwd0 / fwd / dx / dw) so that a kernel trace separates the four
-// launches of a step; the code is identical.
+// one 16x16 output tile (or 16 columns of a column reduction) of problem P
 template <int ROLE>
-__global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
-                                                     const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra, ExtraArgs extra2) {
-  // one LDS block, used either by a GEMM tile (two operand tiles + the cross-wave reduction
-  // buffer) or by the tail code of the extra workgroup
-  constexpr int GEMM_LDS = (2 * 16 * LDR + 4 * 256) * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
-  // horizontal fusion: workgroup 0 of the grid (dispatched first) runs a piece of the step tail
-  const int nRiders = (extra.role ? 1 : 0) + (extra2.role ? 1 : 0);
-  if ((int)blockIdx.x < nRiders) { runExtra(blockIdx.x == 0 ? extra : extra2, smem); return; }
+__device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* __restrict__ sc,
+                                         const AdamHyper& hyp, int nRowsDyn) {
   float* sA = reinterpret_cast<float*>(smem);
   float* sB = sA + 16 * LDR;
   float* red = sB + 16 * LDR;
-  const int bid = blockIdx.x - nRiders;
-  const int nRowsDyn = sc->nRows[hyp.parity];   // issued together with the problem-table fetch
-  int p = 0;
-  for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
-  const GemmProblem P = probs[p];
-  int tile = bid - P.tileStart;
   if (P.flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
   // Give XCD x the contiguous (row-major) tile range [x*nT/8, (x+1)*nT/8): the tiles of one XCD
@@ -229,6 +215,45 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   } else {
     P.C[(size_t)m * P.ldc + n] = v;
   }
+}
+
+// ROLE only names the instantiation (fwd0 / fwd / dx / dw) so that a kernel trace separates the four
+// launches of a step; the code is identical.
+constexpr int GEMM_LDS = (2 * 16 * LDR + 4 * 256) * 4;
+template <int ROLE>
+__global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
+                                                     const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra, ExtraArgs extra2) {
+  // one LDS block, used either by a GEMM tile (two operand tiles + the cross-wave reduction
+  // buffer) or by the tail code of the extra workgroup
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
+  // horizontal fusion: workgroup 0 of the grid (dispatched first) runs a piece of the step tail
+  const int nRiders = (extra.role ? 1 : 0) + (extra2.role ? 1 : 0);
+  if ((int)blockIdx.x < nRiders) { runExtra(blockIdx.x == 0 ? extra : extra2, smem); return; }
+  const int bid = blockIdx.x - nRiders;
+  const int nRowsDyn = sc->nRows[hyp.parity];   // issued together with the problem-table fetch
+  int p = 0;
+  for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
+  const GemmProblem P = probs[p];
+  gemmTile<ROLE>(P, bid - P.tileStart, smem, sc, hyp, nRowsDyn);
+}
+
+// the weight-gradient launch of the fused path: the problem table travels in the kernel arguments
+// (scalar loads from the kernarg segment instead of two dependent global round trips)
+__global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
+  const int nRiders = extra.role ? 1 : 0;
+  if ((int)blockIdx.x < nRiders) { runExtra(extra, smem); return; }
+  const int bid = blockIdx.x - nRiders;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < DW_TABLE_MAX; ++i) if (i < tbl.n && bid >= tbl.p[i].tileStart) p = i;
+  gemmTile<GEMM_ROLE_DW>(tbl.p[p], bid - tbl.p[p].tileStart, smem, sc, hyp, 0);
+}
+
+hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  hipLaunchKernelGGL(dw_table_kernel, dim3(nBlocks + (ex.role ? 1 : 0)), dim3(256), 0, s, tbl, sc, hyp, ex);
+  return hipGetLastError();
 }
 
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,

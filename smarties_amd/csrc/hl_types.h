@@ -30,6 +30,7 @@ struct DevScalars {
   int nRows[2];                   // B + nNext
   float etaEff[2];                // Adam step size incl. bias correction for the step using buffer p
   int errFlag;                    // sticky device-side error code (0 = ok)
+  long long gatherFlag[2];        // sampler -> gather-helper hand-off per minibatch buffer (value: nStep + 1)
   unsigned rngPos;
   unsigned rng[624];
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases

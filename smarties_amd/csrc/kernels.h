@@ -46,7 +46,9 @@ struct AdamArgs {
 
 // extra workgroup appended to an MLP kernel's grid (tail_dev.h): role 0 none, 1 sampler phases
 // (PH_A/B/C mask) of the NEXT step's minibatch, 2 bookkeeping of the step just computed
-enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7 };
+// PH_PUBLISH: phase C stops after the index -> (episode, step) search and hands the gather to helper
+// workgroups (gatherHelper) through DevScalars::gatherFlag
+enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7, PH_PUBLISH = 8 };
 struct ExtraArgs { int role; int phases; SampleArgs samp; PostArgs post; };
 
 // fused forward + head + dX kernel of the two-hidden-layer MLP (fused.hip)
@@ -61,7 +63,7 @@ struct FusedArgs {
   float* dOut; int ldDo;                  // output-layer deltas [B][ldDo]
   unsigned* panelCtr;                     // [panels][32] arrive counters of the panel barrier (monotonic)
   int variant;                            // development: stop after phase `variant` (0 = run everything)
-  unsigned char bounded[HL_MAX_DIMA];
+  unsigned long long boundedMask;         // bit i: action component i is bounded (dA <= 7 here)
 };
 
 struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
@@ -83,6 +85,9 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 // minibatch (samp); either may be nullptr
 hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStream_t s, int phases = PH_ALL);
 enum { GEMM_ROLE_FWD0 = 0, GEMM_ROLE_FWD = 1, GEMM_ROLE_DX = 2, GEMM_ROLE_DW = 3 };
+constexpr int DW_TABLE_MAX = 8;
+struct DwTable { GemmProblem p[DW_TABLE_MAX]; int n; };
+hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
 // up to two riders (extra, extra2) occupy workgroups 0 and 1 of the grid
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);

@@ -34,6 +34,7 @@ struct TimeRec { int name; hipEvent_t a, b; };
 struct StepBuf {
   DevBatch bt{}; float* X0 = nullptr;
   std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
+  DwTable dwTable{}, dwTableAdam{};        // the dW problems by value (kernel-argument table of dw_table_kernel)
 };
 struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int steps = 0; };
 

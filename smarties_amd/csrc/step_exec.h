@@ -100,6 +100,11 @@ int buildProblems(hl_learner* h) {
       if (p.biasOut) { const long long offB = p.biasOut - h->G; p.adbW = h->W + offB; p.adbM1 = h->M1 + offB; p.adbM2 = h->M2 + offB; }
       P.push_back(p);
     }
+    sb.dwTable = DwTable{}; sb.dwTableAdam = DwTable{};
+    if (sb.dwCount <= DW_TABLE_MAX) {
+      sb.dwTable.n = sb.dwTableAdam.n = sb.dwCount;
+      for (int i = 0; i < sb.dwCount; ++i) { sb.dwTable.p[i] = P[sb.dwIdx + i]; sb.dwTableAdam.p[i] = P[sb.dwAdamIdx + i]; }
+    }
   }
   if (h->dProbs) hipFree(h->dProbs);
   h->dProbs = nullptr;
@@ -162,7 +167,7 @@ FusedArgs fusedArgs(hl_learner* h, int parity) {
   fa.Y1 = d0.Y; fa.D1 = d0.D; fa.Dres1 = d0.Dres; fa.ldA0 = d0.ldA;
   fa.X2 = d1.X; fa.R2 = d1.Rr; fa.D2 = d1.D; fa.Dres2 = d1.Dres; fa.ldA1 = d1.ldA;
   fa.dOut = h->dOut; fa.ldDo = h->ldDo; fa.panelCtr = h->panelCtr; fa.variant = h->dbgVariant;
-  for (int i = 0; i < h->dA; ++i) fa.bounded[i] = h->cfg.bounded[i];
+  for (int i = 0; i < h->dA; ++i) if (h->cfg.bounded[i]) fa.boundedMask |= 1ull << i;
   return fa;
 }
 // forward + head + dX of the whole minibatch as one kernel (fused.hip); `nextSample`: sampler phases
@@ -170,7 +175,7 @@ FusedArgs fusedArgs(hl_learner* h, int parity) {
 int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
   const FusedArgs fa = fusedArgs(h, parity);
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
-  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_ALL); pex = &ex; }
+  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_ALL | PH_PUBLISH); pex = &ex; }
   HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
   return HL_OK;
 }
@@ -207,6 +212,11 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
   ExtraArgs exP{}, exC{};
   if (fusePost) { exP.role = 2; exP.post = postArgs(h, parity, POST_AGG | POST_BETA); }
   if (nextSampleC) exC = extraSample(h, parity ^ 1, PH_C);
+  if (sb.dwCount <= DW_TABLE_MAX && !nextSampleC) {   // problem table in the kernel arguments
+    const DwTable& tbl = fuseAdam ? sb.dwTableAdam : sb.dwTable;
+    HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s); }));
+    return HL_OK;
+  }
   HIPCK(timed(h, "gemm16_dw", s, [&] {
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp,
                        nextSampleC ? &exC : nullptr, s, fusePost ? &exP : nullptr); }));

@@ -382,7 +382,9 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
       const int e = rec.eidTerm & 0x7fffffff;
       const bool term = rec.eidTerm < 0;
       a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = e; a.bt.t[b] = t; a.bt.tag[b] = rec.tag;
-      a.bt.slot[b] = rec.off + t; sSlot[b] = rec.off + t;
+      if (phases & PH_PUBLISH) __hip_atomic_store(a.bt.slot + b, rec.off + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.bt.slot[b] = rec.off + t;
+      sSlot[b] = rec.off + t;
       hasNext[r] = (t + 2 == rec.N && !term);      // Episode::isTruncated(t+1) (Episode.h:158-161)
     }
   }
@@ -392,14 +394,24 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
   for (int r = 0; r < K; ++r) {
     const int b = r * 256 + tid;
     if (b < B) {
-      if (hasNext[r]) { a.bt.nextOf[b] = B + nextIdx[r]; a.bt.nextSrc[nextIdx[r]] = b; sNextRow[b] = B + nextIdx[r]; }
-      else { a.bt.nextOf[b] = -1; sNextRow[b] = -1; }
+      const int nr = hasNext[r] ? B + nextIdx[r] : -1;
+      if (hasNext[r]) a.bt.nextSrc[nextIdx[r]] = b;
+      if (phases & PH_PUBLISH) __hip_atomic_store(a.bt.nextOf + b, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.bt.nextOf[b] = nr;
+      sNextRow[b] = nr;
     }
   }
   if (tid == 0) {
     sc->nNext[a.parity] = nNext; sc->nRows[a.parity] = B + nNext;
     // first step of a launch sequence: derive this step's Adam step size from the canonical scalars
     if (a.computeEta) sc->etaEff[a.parity] = adamEtaEff(sc->nStep, sc->adam_bt1, sc->adam_bt2, a.eta0, a.epsAnneal);
+  }
+  if (phases & PH_PUBLISH) {   // the gather is done by the helper workgroups (gatherHelper)
+    __builtin_amdgcn_s_waitcnt(0);     // the agent-scope stores of slot / nextOf are acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(sc->gatherFlag + a.parity, sc->nStep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TSTAMP(sc, 9);
+    return;
   }
   __syncthreads();
   TSTAMP(sc, 7);
@@ -434,6 +446,59 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
     }
   }
   TSTAMP(sc, 8);
+}
+
+// helper workgroup `part` of `nParts`: waits for the sampler's hand-off, then gathers its share of
+// the minibatch (Episode::standardizedState, Episode.h:172-183).  A single workgroup can keep only
+// a few dozen HBM misses in flight; seven of them gather 256 x 17 floats in one round trip.
+__device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int nParts, unsigned char* smem) {
+  float* sMean = reinterpret_cast<float*>(smem);
+  float* sScale = sMean + SMAXB / 2;
+  const int tid = threadIdx.x, B = a.B, dS = a.dS;
+  DevScalars* sc = a.sc;
+  if (part == 0) TSTAMP(sc, 21);
+  for (int i = tid; i < dS; i += 256) { sMean[i] = a.rp.stMean[i]; sScale[i] = a.rp.stScale[i]; }
+  if (tid == 0) {
+    const long long want = sc->nStep + 1;
+    int spins = 0;
+    while (__hip_atomic_load(sc->gatherFlag + a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { sc->errFlag = 78; break; }
+    }
+  }
+  __syncthreads();
+  if (part == 0) TSTAMP(sc, 22);
+  const int per = (B + nParts - 1) / nParts, b0 = part * per, b1 = min(B, b0 + per);
+  const int total = max(0, b1 - b0) * dS;
+  constexpr int GU = 4;
+  for (int e0 = tid; e0 < total; e0 += 256 * GU) {
+    float sv[GU], sn[GU]; int bb[GU], ii[GU], nr[GU]; long long sl[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int e = e0 + 256 * u;
+      bb[u] = -1; nr[u] = -1; sl[u] = 0; ii[u] = 0;
+      if (e < total) {
+        const int b = b0 + e / dS; bb[u] = b; ii[u] = e - (b - b0) * dS;
+        sl[u] = __hip_atomic_load(a.bt.slot + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nr[u] = __hip_atomic_load(a.bt.nextOf + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      sv[u] = 0.f; sn[u] = 0.f;
+      if (bb[u] >= 0) {
+        sv[u] = a.rp.S[(size_t)sl[u] * dS + ii[u]];
+        if (nr[u] >= 0) sn[u] = a.rp.S[(size_t)(sl[u] + 1) * dS + ii[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) if (bb[u] >= 0) {
+      const float mu = sMean[ii[u]], scl = sScale[ii[u]];
+      a.X0[(size_t)bb[u] * a.ldX0 + ii[u]] = (sv[u] - mu) * scl;
+      if (nr[u] >= 0) a.X0[(size_t)nr[u] * a.ldX0 + ii[u]] = (sn[u] - mu) * scl;
+    }
+  }
+  if (part == 0) TSTAMP(sc, 23);
 }
 
 __device__ void postPhase(const PostArgs& a, unsigned char* smem) {
