@@ -40,8 +40,8 @@ CFG = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=256,
            explNoise=0.4472135955, outWeightsPrefac=0.1, nnLambda=0.0, randSeed=42)
 
 
-def step_kernels(B, dS, dA, hidden, nParams):
-    """The five launches of one replayed step: (profile id, name in a kernel trace, bound, algorithmic
+def step_kernels(B, dS, dA, hidden, nParams, fused):
+    """The launches of one replayed step: (profile id, name in a kernel trace, bound, algorithmic
     work per launch).  Work = FLOPs for the MFMA GEMMs, bytes for the HBM/latency-bound head
     (kernel table, states the same figures)."""
     dims = [dS] + list(hidden)
@@ -55,6 +55,11 @@ def step_kernels(B, dS, dA, hidden, nParams):
     # rider gathers the NEXT minibatch: 2 state rows per sample (row t and t+1) plus its scalars
     head_bytes = B * (H * 4 + 2 * H * 4 + 2 * dA * 8 + 8 * 8 + nOut * 4) + H * 8 * 4 + \
         B * (2 * dS * 4 + 2 * dA * 8 + 6 * 8)
+    if fused:
+        # two launches per step: forward + head + dX (one kernel, unique FLOPs counted once although
+        # the first layer is recomputed by every workgroup of a row panel), then dW + Adam
+        fl = 2.0 * B * dims[0] * dims[1] + 2.0 * B * dims[1] * dims[2] + 2 * (2.0 * B * H * nDense) + 2.0 * B * dims[2] * dims[1]
+        return [(26, "fused_fwd_head_dx_kernel", "mfma", fl), (27, "dw_table_kernel", "mfma", dw_flops)]
     ks = [(21, "gemm16_kernel<0>", "mfma", 2.0 * B * dims[0] * dims[1])]
     if L > 1:
         ks.append((22, "gemm16_kernel<1>", "mfma", 2.0 * B * dims[L - 1] * dims[L]))
@@ -200,7 +205,12 @@ def main():
     if rank == 0:
         gap = L.kernel_profile(12, 400)
         table = {}
-        for pid, name, bound, work in step_kernels(L.B, 17, 6, CFG["hidden"], L.nParams):
+        try:
+            L.kernel_profile(26, 8)          # the fused forward/head/dX kernel serves this network?
+            fused = True
+        except capi.HlError:
+            fused = False
+        for pid, name, bound, work in step_kernels(L.B, 17, 6, CFG["hidden"], L.nParams, fused):
             us = L.kernel_profile(pid, 200)
             if bound == "mfma":
                 ach, peak, unit = work / (us * 1e-6) / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
@@ -213,7 +223,7 @@ def main():
         roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                 "frac": d["frac"], "traffic": None, "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
                 "step_kernels": table,
-                "note": "latency-bound step: 5 dependent launches of 16..512 workgroups; launch_us = HIP-event time "
+                "note": "latency-bound step: dependent launches of a few hundred workgroups; launch_us = HIP-event time "
                         "per launch of graph-replayed back-to-back launches (dispatch included, as a kernel trace "
                         "counts it); empty_launch_us = the same for an empty kernel"}
 

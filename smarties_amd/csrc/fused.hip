@@ -30,6 +30,9 @@ namespace hl {
 #define FLDR 258            // leading dimension of 16-row LDS tiles (== 2 mod 32: conflict-free MFMA operand reads)
 #define FLDS 34             // leading dimension of the 16 x dS state tile
 #define FMAXK4 8            // dS <= 32: at most 8 MFMA k-steps in the first layer
+#ifndef FUSED_NT
+#define FUSED_NT 512        // threads per workgroup of the fused kernel
+#endif
 
 // development time stamps of workgroup (panel 0, tile 1), 100 MHz clock: -DHL_TAIL_STAMPS
 #if defined(HL_TAIL_STAMPS) && !defined(HL_NO_FSTAMP)
@@ -85,7 +88,7 @@ __host__ __device__ inline int fusedR3Floats(int H) { const int a = H * 16, b = 
 __host__ __device__ inline size_t fusedLdsBytes(int dS, int H) {
   const int dSp = (dS + 3) & ~3;
   const size_t fl = (size_t)16 * FLDR + fusedR2Floats(dSp, H) + fusedR3Floats(H) + (size_t)H * 8 /*Wout*/ + 16 * FLDS +
-                    1024 /*red*/ + 3 * (size_t)H /*b0, wres, bres*/ + 512 /*sO*/ + 128 /*sDo*/ + 256 /*own tile scratch*/ + 32 /*bo, bp*/;
+                    2048 /*red*/ + 3 * (size_t)H /*b0, wres, bres*/ + 512 /*sO*/ + 128 /*sDo*/ + 256 /*own tile scratch*/ + 32 /*bo, bp*/;
   const size_t bytes = fl * 4;
   return bytes > TAIL_LDS_BYTES ? bytes : TAIL_LDS_BYTES;
 }
@@ -106,23 +109,36 @@ __device__ __forceinline__ f32x4 waveMma(FA fa, FB fb) {
   return acc0 + acc1;
 }
 
-template <int H, int CF>
-__global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, ExtraArgs extra) {
+// NT threads per workgroup (256 or 512): threads 0..255 own one output element / one (sample, action
+// component) each; with 512 the panel-wide phases and the K-split contractions are spread over 8 waves
+// sum of the K-split partial tiles (fixed association: pairs, then pairs of pairs)
+template <int NP> __device__ __forceinline__ float redSum(const float* red, int tid) {
+  if constexpr (NP == 8) return ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) + ((red[1024 + tid] + red[1280 + tid]) + (red[1536 + tid] + red[1792 + tid]));
+  else return (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+}
+
+template <int H, int CF, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedArgs a, ExtraArgs extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // blocks 0..7: riders (tail work of the neighbouring steps); 8 of them keep blockIdx % 8 == XCD
   if (blockIdx.x < 8) {
+    if (threadIdx.x >= 256) return;            // the tail code is written for 256 threads
     // the sampler runs in block 0; with PH_PUBLISH its gather is spread over blocks 1..7
     if (blockIdx.x == 0) { if (extra.role) runExtra(extra, smem); }
     else if (extra.role == 1 && (extra.phases & PH_PUBLISH)) gatherHelper(extra.samp, blockIdx.x - 1, 7, smem);
     return;
   }
   constexpr int HT = H / 16, H4 = H / 4, LDW0 = H + 16;
-  constexpr int KW = H / 4;                      // reduction length per wave of the K-split contractions
+  constexpr int NW = NT / 64;                    // waves per workgroup
+  constexpr int KWAVES = (H / 4 >= NW) ? NW : 4; // waves sharing the reduction of the K-split contractions
+  constexpr int KW = H / KWAVES;                 // reduction length per wave
   constexpr int NK = KW / 4;                     // MFMA steps per wave
-  constexpr int TPW = HT >= 4 ? HT / 4 : 1;      // h1 column tiles per wave
-  constexpr int QP = (16 * H4 + 255) / 256;      // float4 per thread of a 16 x H panel
-  constexpr int QC = (H * 4 + 255) / 256;        // float4 per thread of the H x 16 column tile
-  constexpr int QO = (H * 2 + 255) / 256;        // float4 per thread of Wout [H][8]
+  constexpr int TPW = HT >= NW ? HT / NW : 1;    // h1 column tiles per wave
+  constexpr int QP = (16 * H4 + NT - 1) / NT;    // float4 per thread of a 16 x H panel
+  constexpr int QC = (H * 4 + NT - 1) / NT;      // float4 per thread of the H x 16 column tile
+  constexpr int QO = (H * 2 + NT - 1) / NT;      // float4 per thread of Wout [H][8]
+  constexpr int Q0 = (32 * H4 + NT - 1) / NT;    // float4 per thread of W0 (dS <= 32)
+  constexpr int QS = 512 / NT;                   // state-tile elements per thread
   const DevScalars* sc = a.sc;
   const int dS = a.dS, dSp = (dS + 3) & ~3, B = a.B, dA = a.dA, nDense = a.nDense;
   // arguments used inside the hot loops, pinned in VGPRs: under SGPR pressure the compiler would
@@ -145,8 +161,8 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   float* sR3 = sR2 + fusedR2Floats(dSp, H);
   float* sWo = sR3 + fusedR3Floats(H);                         // [H][8]
   float* sS = sWo + H * 8;                                     // [16][FLDS]
-  float* red = sS + 16 * FLDS;                                 // [4][256]
-  float* sB0 = red + 1024;                                     // [H]
+  float* red = sS + 16 * FLDS;                                 // [8][256]
+  float* sB0 = red + 2048;                                     // [H]
   float* sWr = sB0 + H;                                        // [H] residual w
   float* sBr = sWr + H;                                        // [H] residual b
   double* sO = reinterpret_cast<double*>(sBr + H);             // [16][16]  (offset is a multiple of 8 bytes)
@@ -158,44 +174,45 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on it
   const int li = lane & 15, lc = lane >> 4;
-  const int em = tid >> 4, en = tid & 15;                      // the output element / (sample, dim) of this thread
+  const bool eth = tid < 256;                                  // element thread: owns output element / (sample, dim) (em, en)
+  const int em = (tid >> 4) & 15, en = tid & 15;
   const float* W = a.W;
   const float* W0 = W + a.indW0; const float* W1 = W + a.indW1; const float* Wo = W + a.indWo;
 
   // ---- every load that does not depend on the exchange, issued up front --------------------------
   const int row = m0 + em;
-  const bool rowValid = row < nRows, isNext = rowValid && row >= B;
+  const bool rowValid = eth && row < nRows, isNext = rowValid && row >= B;
   int bSrc = 0; long long slot = 0;
   if (rowValid) { bSrc = isNext ? a.bt.nextSrc[row - B] : row; slot = a.bt.slot[bSrc]; }   // oldest loads: the gathers hang off them
-  float sv[2];
+  float sv[QS];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+  for (int q = 0; q < QS; ++q) {
+    const int idx = tid + NT * q, r = idx >> 5, c = idx & 31;
     sv[q] = (c < dS && m0 + r < nRows) ? a.X0[(size_t)(m0 + r) * a.ldX0 + c] : 0.f;
   }
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 w0v[FMAXK4], w1c[QC], w1r[QP], wov[QO];
+  f32x4 w0v[Q0], w1c[QC], w1r[QP], wov[QO];
   const int nW0 = dSp * H4;
 #pragma unroll
-  for (int q = 0; q < FMAXK4; ++q) {
-    const int f = tid + 256 * q; w0v[q] = z4;
+  for (int q = 0; q < Q0; ++q) {
+    const int f = tid + NT * q; w0v[q] = z4;
     if (f < nW0) { const int k = f / H4, c4 = f % H4; if (k < dS) w0v[q] = *reinterpret_cast<const f32x4*>(W0 + (size_t)k * a.ldW0 + 4 * c4); }
   }
 #pragma unroll
   for (int q = 0; q < QC; ++q) {
-    const int f = tid + 256 * q; w1c[q] = z4;
+    const int f = tid + NT * q; w1c[q] = z4;
     if (f < H * 4) { const int k = f >> 2, c = n0 + (f & 3) * 4; w1c[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)k * a.ldW1 + c); }
   }
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
-    const int f = tid + 256 * q; w1r[q] = z4;
+    const int f = tid + NT * q; w1r[q] = z4;
     if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w1r[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(n0 + r) * a.ldW1 + 4 * c4); }
   }
 #pragma unroll
-  for (int q = 0; q < QO; ++q) { const int f = tid + 256 * q; wov[q] = f < H * 2 ? *reinterpret_cast<const f32x4*>(Wo + (size_t)f * 4) : z4; }
+  for (int q = 0; q < QO; ++q) { const int f = tid + NT * q; wov[q] = f < H * 2 ? *reinterpret_cast<const f32x4*>(Wo + (size_t)f * 4) : z4; }
   const float b0v = tid < H ? W[a.indB0 + tid] : 0.f;
   const float wrv = tid < H ? W[a.indWr + tid] : 0.f, brv = tid < H ? W[a.indBr + tid] : 0.f;
-  const float b1e = W[a.indB1 + n0 + en];
+  const float b1e = eth ? W[a.indB1 + n0 + en] : 0.f;
   const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
 
@@ -214,16 +231,16 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
 
   // ---- stage: states, W0 (k-major), W1 column tile (k-major), Wout, vectors ------------------------
 #pragma unroll
-  for (int q = 0; q < 2; ++q) { const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31; sS[r * FLDS + c] = sv[q]; }
+  for (int q = 0; q < QS; ++q) { const int idx = tid + NT * q, r = idx >> 5, c = idx & 31; sS[r * FLDS + c] = sv[q]; }
 #pragma unroll
-  for (int q = 0; q < FMAXK4; ++q) {
-    const int f = tid + 256 * q;
+  for (int q = 0; q < Q0; ++q) {
+    const int f = tid + NT * q;
     if (f < nW0) { const int k = f / H4, c4 = f % H4; *reinterpret_cast<f32x4*>(sR2 + k * LDW0 + 4 * c4) = w0v[q]; }
   }
 #pragma unroll
-  for (int q = 0; q < QC; ++q) { const int f = tid + 256 * q; if (f < H * 4) *reinterpret_cast<f32x4*>(sR3 + (size_t)f * 4) = w1c[q]; }
+  for (int q = 0; q < QC; ++q) { const int f = tid + NT * q; if (f < H * 4) *reinterpret_cast<f32x4*>(sR3 + (size_t)f * 4) = w1c[q]; }
 #pragma unroll
-  for (int q = 0; q < QO; ++q) { const int f = tid + 256 * q; if (f < H * 2) *reinterpret_cast<f32x4*>(sWo + (size_t)f * 4) = wov[q]; }
+  for (int q = 0; q < QO; ++q) { const int f = tid + NT * q; if (f < H * 2) *reinterpret_cast<f32x4*>(sWo + (size_t)f * 4) = wov[q]; }
   if (tid < H) { sB0[tid] = b0v; sWr[tid] = wrv; sBr[tid] = brv; }
   if (tid < 16) { sBo[tid] = bov; sBp[tid] = bpv; }
   __syncthreads();
@@ -239,13 +256,13 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     // operands of step s+1 are read while the MFMAs of step s run
     float av = sS[li * FLDS + lc], bv[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) bv[t] = sR2[lc * LDW0 + (wave + 4 * t) * 16 + li];
+    for (int t = 0; t < TPW; ++t) bv[t] = sR2[lc * LDW0 + (wave + NW * t) * 16 + li];
     for (int s = 0; s < nk4; ++s) {
       const int kn = s + 1 < nk4 ? 4 * (s + 1) + lc : lc;
       const float avn = sS[li * FLDS + kn];
       float bvn[TPW];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) bvn[t] = sR2[kn * LDW0 + (wave + 4 * t) * 16 + li];
+      for (int t = 0; t < TPW; ++t) bvn[t] = sR2[kn * LDW0 + (wave + NW * t) * 16 + li];
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
       av = avn;
@@ -255,12 +272,12 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     FSTAMP(14);
     float bb[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) bb[t] = sB0[(wave + 4 * t) * 16 + li];
+    for (int t = 0; t < TPW; ++t) bb[t] = sB0[(wave + NW * t) * 16 + li];
     dispatchFunc<CF>(func, [&](auto F) {
       constexpr int FN = decltype(F)::value;
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const int nt = wave + 4 * t;
+        const int nt = wave + NW * t;
         const int c = nt * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -277,10 +294,10 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   const float x1o = sT[em * 16 + en], y1o = sY1[em * FLDR + n0 + en];
   FSTAMP(2);
   if (a.variant == 2) return;
-  if (row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
+  if (eth && row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
 
   // ---- own tile of x2 = h1 W1 + b1: K split over the 4 waves ----------------------------------------
-  {
+  if (wave < KWAVES) {
     const int k0 = wave * KW + lc;
     const f32x4 acc = waveMma<NK>([&](int s) { return sY1[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sR3[(k0 + 4 * s) * 16 + li]; });
 #pragma unroll
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   __syncthreads();
   FSTAMP(3);
   if (rowValid) {
-    const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    const float v = redSum<KWAVES>(red, tid);
     const float x2 = v + b1e;
     float y2 = 0.f, f2 = 0.f;
     dispatchFunc<CF>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y2 = actEvalT<FN>(x2); f2 = actDiffT<FN>(x2, y2); });
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     f32x4 yv[QP], fv[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
-      const int f = tid + 256 * q; yv[q] = z4; fv[q] = z4;
+      const int f = tid + NT * q; yv[q] = z4; fv[q] = z4;
       if (f < 16 * H4) {
         const int r = f / H4, c4 = f % H4;
         if (m0 + r < nRows) {
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     // h1 is dead (own tile kept in registers): R1 takes the W1 row tile of the dX contraction
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
-      const int f = tid + 256 * q;
+      const int f = tid + NT * q;
       if (f < 16 * H4) {
         const int r = f / H4, c = 4 * (f % H4);
         float2* d = reinterpret_cast<float2*>(sBx + r * FLDR + c);
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   if (a.variant == 5) return;
 
   // ---- output layer: O[16][nDense] = y3 Wout + bo (MFMA, columns >= 8 are zero) -----------------------
-  {
+  if (wave < KWAVES) {
     const int k0 = wave * KW + lc;
     const f32x4 acc = waveMma<NK>([&](int s) { return sY3[li * FLDR + k0 + 4 * s]; },
                                   [&](int s) { return li < 8 ? sWo[(k0 + 4 * s) * 8 + li] : 0.f; });
@@ -382,14 +399,14 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   // network outputs of sample em stay in registers: lane en holds O[em][en] (dense part); the
   // ParamLayer part (Linear) is its bias
   const int base = lane & ~15;
-  const float Oen = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]) + sBo[en];
+  const float Oen = eth ? redSum<KWAVES>(red, tid) + sBo[en] : 0.f;
   const double O0 = (double)__shfl(Oen, base, 64);
   const double mean = (double)__shfl(Oen, base + ((en + 1) & 15), 64);   // O[em][1 + en]
 
   // ---- V-RACER head: thread = (sample em, action component en), fp64 --------------------------------------
   if (a.variant == 6) return;
   const bool writer = (n == 0);
-  {
+  if (eth) {
     float g0f = 0.f, gMf = 0.f;
     if (rowValid && isNext) {     // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
       const float oV = __shfl(misc, base + 6, 64), oA = __shfl(misc, base + 7, 64);
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   __syncthreads();
   FSTAMP(10);
   if (a.variant == 7) return;
-  if (writer && row < B && en < nDense) a.dOut[(size_t)row * a.ldDo + en] = sDo[em * 8 + en];
+  if (eth && writer && row < B && en < nDense) a.dOut[(size_t)row * a.ldDo + en] = sDo[em * 8 + en];
 
   // ---- delta_y3 = delta_out Wout^T (MFMA, K = 8), delta_x2 = delta_y3 f'(x2): whole panel ----------------------
   {
@@ -481,14 +498,14 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
     float b0[TPW], b1[TPW], f2v[TPW][4];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int nt = wave < HT ? wave + 4 * t : 0;
+      const int nt = wave < HT ? wave + NW * t : 0;
       b0[t] = sWo[(nt * 16 + li) * 8 + lc]; b1[t] = sWo[(nt * 16 + li) * 8 + 4 + lc];
 #pragma unroll
       for (int r = 0; r < 4; ++r) f2v[t][r] = sF2[(lc * 4 + r) * FLDR + nt * 16 + li];
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int nt = wave + 4 * t;
+      const int nt = wave + NW * t;
       if (wave < HT) {
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], z4, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc, 0, 0, 0);
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   if (a.variant == 8) return;
 
   // ---- own tile of delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1) ----------------------
-  {
+  if (wave < KWAVES) {
     const int k0 = wave * KW + lc;
     const f32x4 acc = waveMma<NK>([&](int s) { return sF2[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sBx[li * FLDR + k0 + 4 * s]; });
 #pragma unroll
@@ -520,8 +537,8 @@ __global__ __launch_bounds__(256) void fused_fwd_head_dx_kernel(FusedArgs a, Ext
   }
   __syncthreads();
   FSTAMP(12);
-  if (row < B) {
-    const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  if (eth && row < B) {
+    const float v = redSum<KWAVES>(red, tid);
     float dres = v;
     if (n0 + en < resN) dres += sT[em * 16 + en] * sWr[n0 + en];
     a.Dres1[(size_t)row * ldA0 + n0 + en] = dres;
@@ -538,11 +555,11 @@ static hipError_t launchFusedT(const FusedArgs& a, int maxRows, const ExtraArgs&
   const size_t lds = fusedLdsBytes(a.dS, H);
   static size_t attrSet = 0;
   if (lds > attrSet) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H, CF, FUSED_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attrSet = lds;
   }
-  hipLaunchKernelGGL((fused_fwd_head_dx_kernel<H, CF>), dim3(8 + 8 * HT * pg), dim3(256), lds, s, a, ex);
+  hipLaunchKernelGGL((fused_fwd_head_dx_kernel<H, CF, FUSED_NT>), dim3(8 + 8 * HT * pg), dim3(FUSED_NT), lds, s, a, ex);
   return hipGetLastError();
 }
 // SoftSign (the reference's default for the shipped settings) and Tanh get their own instantiation;

@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int GRAPH_SIZES[] = {64, 8, 2};     // steps per replayed graph, tried in this order
+constexpr int GRAPH_SIZES[] = {256, 64, 8, 2};   // steps per replayed graph, tried in this order
 
 void setTiles(GemmProblem& p, int& cursor) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;

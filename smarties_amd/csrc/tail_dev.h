@@ -423,7 +423,7 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
   float* sScale = sMean + SMAXB / 2;
   for (int i = tid; i < dS; i += 256) { sMean[i] = a.rp.stMean[i]; sScale[i] = a.rp.stScale[i]; }
   __syncthreads();
-  constexpr int GU = 20;                                   // elements per thread per round
+  constexpr int GU = 9;                                    // elements per thread per round (two rounds at B = 256, dS = 17)
   for (int e0 = tid; e0 < total; e0 += 256 * GU) {
     float sv[GU], sn[GU]; int bb[GU], ii[GU], nr[GU];
 #pragma unroll
