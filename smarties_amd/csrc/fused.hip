@@ -215,6 +215,13 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const float b1e = eth ? W[a.indB1 + n0 + en] : 0.f;
   const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
+  // writer workgroup (tile 0): the aggregates of the sampled episode travel with the sample to the
+  // bookkeeping pass, which then needs no dependent gather (the store happens at the very end)
+  float aggv = 0.f;
+  if (n == 0 && rowValid && !isNext && en < AGG_N) {
+    const int eidv = a.bt.eid[bSrc];
+    aggv = en < AGG_USED ? a.rp.epAgg[(size_t)eidv * AGG_N + en] : (en == AGG_LEN ? (float)a.rp.epN[eidv] : 0.f);
+  }
 
   // the replay rows of the head (issued now, consumed after the exchange): one (sample, dim) per thread
   double act = 0, bMean = 0, bStd = 1; float misc = 0.f;
@@ -537,6 +544,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   }
   __syncthreads();
   FSTAMP(12);
+  if (n == 0 && rowValid && !isNext && en < AGG_N) a.bt.aggIn[(size_t)bSrc * AGG_N + en] = aggv;
   if (eth && row < B) {
     const float v = redSum<KWAVES>(red, tid);
     float dres = v;

@@ -23,6 +23,13 @@ namespace hl {
 #define KC 256
 #define LDR 258
 
+// development time stamps of one W1-gradient tile (-DHL_TAIL_STAMPS), DevScalars::dbgT[24..]
+#ifdef HL_TAIL_STAMPS
+#define GSTAMP(i) do { if (ROLE == GEMM_ROLE_DW && threadIdx.x == 0 && P.M > 200 && P.N > 200 && tile == 40) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void adamApply(const AdamCoef& c, float g, float* W, float* M1, float* M2, size_t i) {
   float w = W[i], m1 = M1[i], m2 = M2[i];
   adamStep(c, g, w, m1, m2);
@@ -82,6 +89,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   if (m0 >= Mvalid) return;
   if (hyp.variant & 8) return;              // ablation: launch + problem-table fetch only
 
+  GSTAMP(24);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lc = lane >> 4;
   // ---- prefetch the epilogue operands of this thread's output element (m, n) ----
@@ -168,6 +176,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
       }
     }
     __syncthreads();
+    GSTAMP(25);
     const int k0 = wave * kw;
     if (!(hyp.variant & 2))                 // ablation: no MFMA loop
     for (int s = 0; s < kw; s += 8) {
@@ -181,11 +190,13 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     }
     __syncthreads();
   }
+  GSTAMP(26);
   // ---- cross-wave reduction of the 4 partial tiles ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
   __syncthreads();
   const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  GSTAMP(27);
   if (!outOk) return;
 
   if (P.epi == EPI_FWD) {
@@ -215,6 +226,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   } else {
     P.C[(size_t)m * P.ldc + n] = v;
   }
+  GSTAMP(28);
 }
 
 // ROLE only names the instantiation (fwd0 / fwd / dx / dw) so that a kernel trace separates the four

@@ -70,7 +70,7 @@ struct DevReplay {
   float* stMean; float* stScale; float* stStd;   // [dS]
 };
 enum { AGG_TOTR = 0, AGG_AVGKL, AGG_FRACFAR, AGG_AVGSQERR, AGG_MAXABSERR, AGG_SUMQ2, AGG_SUMQ,
-       AGG_MAXQ, AGG_MINQ, AGG_N = 12 };
+       AGG_MAXQ, AGG_MINQ, AGG_USED, AGG_LEN = 9 /* staging only: episode length */, AGG_N = 12 };
 
 // ---------------------------------------------------------------------------
 // Minibatch workspace (MiniBatch.h) + taps
@@ -96,6 +96,8 @@ struct DevBatch {
   float *oldDQ, *oldDKL, *oldW, *oldV, *oldADV;   // [B]
   float *nextV, *oldNextV, *oldNextADV;           // [B] (indexed by sample b)
   float* gParam;       // [B][dA] gradient wrt the ParamLayer outputs
+  float* aggIn;        // [B][AGG_N] aggregates (+ length in slot AGG_LEN) of the sampled episode as of the
+                       //     start of the step, staged by the fused kernel for the bookkeeping pass
 };
 
 // one dense hidden block of the MLP (BaseLayer [+ ParametricResidualLayer])

@@ -36,6 +36,7 @@ struct PostArgs {
   int nRanks;
   int parity;                        // buffer of the step being closed; etaEff[parity^1] is written
   float eta0;
+  int aggStaged;                     // 1: bt.aggIn holds the episode aggregates (fused kernel), no gather needed
 };
 enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4 };
 

@@ -447,6 +447,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&bt.oldDQ, B)); HIPCK(devAlloc(&bt.oldDKL, B)); HIPCK(devAlloc(&bt.oldW, B)); HIPCK(devAlloc(&bt.oldV, B));
     HIPCK(devAlloc(&bt.oldADV, B)); HIPCK(devAlloc(&bt.nextV, B)); HIPCK(devAlloc(&bt.oldNextV, B));
     HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * h->dA));
+    HIPCK(devAlloc(&bt.aggIn, (size_t)B * AGG_N));
   }
   HIPCK(hipStreamCreateWithFlags(&h->sSample, hipStreamNonBlocking));
   HIPCK(hipStreamCreateWithFlags(&h->sPost, hipStreamNonBlocking));

@@ -40,6 +40,10 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
     const int N = a.rp.epN[e];
     const bool term = a.rp.epTerm[e] != 0;
     const DevScalars* sc = a.sc;
+    // Both passes walk the episode sequentially (the sums and the Retrace recursion keep the
+    // reference's order), but the loads of CH steps are issued together: one HBM round trip per
+    // chunk instead of one per step.
+    constexpr int CH = 16;
     if (a.recompute) {
       const float C = (float)sc->Cmax, invC = (float)sc->Cinv;
       const int nd = N - 1;
@@ -47,14 +51,29 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
       long long nFarPol = 0;
       float sumE2 = 0, maxAE = -1e9f, maxQ = -1e9f, sumQ2 = 0, minQ = 1e9f, sumQ1 = 0, sumKL = 0;
       double totR = 0;
-      for (int t = 0; t < nd; ++t) {
-        const float w = a.rp.IMPW[off + t], dq = a.rp.DQ[off + t];
-        if (w > C || w < invC) ++nFarPol;
-        sumE2 += dq * dq; maxAE = fmaxf(maxAE, fabsf(dq));
-        const float Q = a.rp.ADV[off + t] + a.rp.V[off + t];
-        maxQ = fmaxf(maxQ, Q); minQ = fminf(minQ, Q); sumQ2 += Q * Q; sumQ1 += Q;
+      for (int t0 = 0; t0 < nd; t0 += CH) {
+        float w[CH], dq[CH], ad[CH], vv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int t = t0 + u; const bool ok = t < nd;
+          w[u] = ok ? a.rp.IMPW[off + t] : 1.f; dq[u] = ok ? a.rp.DQ[off + t] : 0.f;
+          ad[u] = ok ? a.rp.ADV[off + t] : 0.f; vv[u] = ok ? a.rp.V[off + t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (t0 + u < nd) {
+          if (w[u] > C || w[u] < invC) ++nFarPol;
+          sumE2 += dq[u] * dq[u]; maxAE = fmaxf(maxAE, fabsf(dq[u]));
+          const float Q = ad[u] + vv[u];
+          maxQ = fmaxf(maxQ, Q); minQ = fminf(minQ, Q); sumQ2 += Q * Q; sumQ1 += Q;
+        }
       }
-      for (int t = 0; t < N; ++t) { totR += a.rp.R[off + t]; sumKL += a.rp.DKL[off + t]; }
+      for (int t0 = 0; t0 < N; t0 += CH) {
+        double rr[CH]; float kk[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { const int t = t0 + u; const bool ok = t < N; rr[u] = ok ? a.rp.R[off + t] : 0.0; kk[u] = ok ? a.rp.DKL[off + t] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) if (t0 + u < N) { totR += rr[u]; sumKL += kk[u]; }
+      }
       float* ag = a.rp.epAgg + (size_t)e * AGG_N;
       ag[AGG_FRACFAR] = invN * (float)nFarPol; ag[AGG_AVGSQERR] = invN * sumE2; ag[AGG_MAXABSERR] = maxAE;
       ag[AGG_SUMQ2] = sumQ2; ag[AGG_SUMQ] = sumQ1; ag[AGG_MAXQ] = maxQ; ag[AGG_MINQ] = minQ;
@@ -66,13 +85,21 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
     const float rM = sc->rewMean, rS = sc->rewScale;
     float Q = term ? a.rp.RET[off + N - 1] : a.rp.V[off + N - 1];
     if (!term) a.rp.RET[off + N - 1] = Q;
-    for (int t = N - 2; t >= 0; --t) {
-      const float R = (float)((a.rp.R[off + t + 1] - (double)rM) * (double)rS);
-      const float V = a.rp.V[off + t + 1], A = a.rp.ADV[off + t + 1];
-      const float iw = a.rp.IMPW[off + t + 1];
-      const float w = iw < 1.f ? iw : 1.f;
-      Q = R + gamma * (V + lambda * w * (Q - A - V));
-      a.rp.RET[off + t] = Q;
+    for (int t1 = N - 2; t1 >= 0; t1 -= CH) {      // chunk covers t = t1, t1-1, ..., t1-CH+1
+      double rr[CH]; float vv[CH], ad[CH], iw[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int t = t1 - u; const bool ok = t >= 0;
+        rr[u] = ok ? a.rp.R[off + t + 1] : 0.0; vv[u] = ok ? a.rp.V[off + t + 1] : 0.f;
+        ad[u] = ok ? a.rp.ADV[off + t + 1] : 0.f; iw[u] = ok ? a.rp.IMPW[off + t + 1] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) if (t1 - u >= 0) {
+        const float R = (float)((rr[u] - (double)rM) * (double)rS);
+        const float w = iw[u] < 1.f ? iw[u] : 1.f;
+        Q = R + gamma * (vv[u] + lambda * w * (Q - ad[u] - vv[u]));
+        a.rp.RET[off + t1 - u] = Q;
+      }
     }
   }
   if (a.recompute) {
@@ -142,16 +169,21 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(MomentsArgs a) {
   }
 }
 // moments layout (MemoryProcessing.cpp:139-150): [sum s (dS) | sum s^2 (dS) | count | sum r | sum r^2]
+// one wavefront per output: lanes stride over the per-block partials, then a butterfly sum
 __global__ __launch_bounds__(256) void moments_final_kernel(MomentsArgs a) {
   const int dS = a.dS, CW = dS + 1;
-  for (int i = threadIdx.x; i < 2 * CW; i += 256) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i < 2 * CW) {
     double s = 0;
-    for (int b = 0; b < a.nBlocks; ++b) s += a.partial[(size_t)b * 2 * CW + i];
-    const int c = i % CW; const bool second = i >= CW;
-    if (c < dS) a.moments[(second ? dS : 0) + c] = s;
-    else a.moments[2 * dS + (second ? 2 : 1)] = s;
+    for (int b = lane; b < a.nBlocks; b += 64) s += a.partial[(size_t)b * 2 * CW + i];
+    s = waveSum(s);
+    if (lane == 0) {
+      const int c = i % CW; const bool second = i >= CW;
+      if (c < dS) a.moments[(second ? dS : 0) + c] = s;
+      else a.moments[2 * dS + (second ? 2 : 1)] = s;
+    }
   }
-  if (threadIdx.x == 0) a.moments[2 * dS] = (double)a.sc->nTransitions;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.moments[2 * dS] = (double)a.sc->nTransitions;
 }
 __global__ void moments_apply_kernel(MomentsArgs a) {
   DevScalars* sc = a.sc;
@@ -180,7 +212,7 @@ int moments_blocks(int nEpisodes) { int b = nEpisodes; return b < 1 ? 1 : (b > 1
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s) {
   if (a.dS + 1 > 256) return hipErrorInvalidValue;
   hipLaunchKernelGGL(moments_partial_kernel, dim3(a.nBlocks), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(moments_final_kernel, dim3((2 * (a.dS + 1) + 3) / 4), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s) {

@@ -131,7 +131,7 @@ PostArgs postArgs(hl_learner* h, int parity, int mode) {
   PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->buf[parity].bt; pa.B = h->B; pa.mode = mode;
   pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
   pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = exchanging(h) ? 2 : 1;   // > 1: use the exchanged counters
-  pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate;
+  pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate; pa.aggStaged = h->fusedOk ? 1 : 0;
   return pa;
 }
 HeadArgs headArgs(hl_learner* h, int parity) {

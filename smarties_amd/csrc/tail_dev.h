@@ -77,13 +77,25 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
         oW0 = a.bt.oldW[b]; oE0 = a.bt.oldDQ[b]; oD0 = a.bt.oldDKL[b]; oV0 = a.bt.oldV[b]; oA0 = a.bt.oldADV[b];
         Vn0 = a.bt.nextV[b]; oNV0 = a.bt.oldNextV[b]; oNA0 = a.bt.oldNextADV[b];
       }
-      if (!in || ePrev == e) continue;                    // not the leader of this episode's run
-      // round 2: the episode record
+      // the episode record: staged per sample by the fused kernel (same round as the loads above) ...
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+      if (in && a.aggStaged) {
+        const f32x4* st = reinterpret_cast<const f32x4*>(a.bt.aggIn + (size_t)b * AGG_N);
+        s0 = st[0]; s1 = st[1]; s2 = st[2];
+      }
+      const bool leader = in && ePrev != e;               // first sample of this episode's run
+      float myMaxAbs = 0.f; long long myFarDelta = 0;
+      if (leader) {
       float* ag = a.rp.epAgg + (size_t)e * AGG_N;
-      const float Nf = (float)a.rp.epN[e];
-      float g[AGG_N];
+      float g[AGG_N]; float Nf;
+      if (a.aggStaged) {
+        g[0] = s0[0]; g[1] = s0[1]; g[2] = s0[2]; g[3] = s0[3]; g[4] = s1[0]; g[5] = s1[1]; g[6] = s1[2]; g[7] = s1[3];
+        g[8] = s2[0]; g[9] = 0.f; g[10] = 0.f; g[11] = 0.f; Nf = s2[1];
+      } else {   // ... or a second, dependent round: gather it here
+        Nf = (float)a.rp.epN[e];
 #pragma unroll
-      for (int q = 0; q < AGG_N; ++q) g[q] = ag[q];
+        for (int q = 0; q < AGG_N; ++q) g[q] = ag[q];
+      }
       const float invN = 1 / Nf;
       const long long before = farSteps(Nf, g[AGG_FRACFAR]);
       int j = b; bool more = true;
@@ -112,8 +124,18 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
 #pragma unroll
       for (int q = 0; q < AGG_N; ++q) ag[q] = g[q];
       const long long after = farSteps(Nf, g[AGG_FRACFAR]);
-      if (after != before) atomicAdd((unsigned long long*)sFarDelta, (unsigned long long)(after - before));
-      atomicMax(sMaxAbs, __float_as_uint(fmaxf(g[AGG_MAXABSERR], 0.f)));
+      myFarDelta = after - before;
+      myMaxAbs = fmaxf(g[AGG_MAXABSERR], 0.f);
+      }
+      // one LDS atomic per wavefront instead of one per episode (same-address LDS atomics serialise)
+      for (int o = 32; o > 0; o >>= 1) {
+        myMaxAbs = fmaxf(myMaxAbs, __shfl_xor(myMaxAbs, o, 64));
+        myFarDelta += __shfl_xor(myFarDelta, o, 64);
+      }
+      if ((tid & 63) == 0) {
+        if (myFarDelta != 0) atomicAdd((unsigned long long*)sFarDelta, (unsigned long long)myFarDelta);
+        atomicMax(sMaxAbs, __float_as_uint(myMaxAbs));
+      }
     }
     TSTAMP(sc, 18);
     __syncthreads();
