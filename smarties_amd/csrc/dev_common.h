@@ -64,6 +64,7 @@ __device__ __forceinline__ float adamEtaEff(long long nStepDone, double bt1, dou
   return _eta * sqrtf(1 - b2) / (1 - b1);
 }
 __device__ __forceinline__ void adamStep(const AdamCoef& c, float g, float& w, float& m1, float& m2) {
+#pragma clang fp contract(off)   // same rounding wherever this is inlined (dW epilogue, stand-alone Adam kernel)
   const float B1 = 0.9f, B2 = 0.999f;
   const float penal = -w * c.lambda;
   const float DW = c.fac * g;

@@ -215,10 +215,10 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const float b1e = eth ? W[a.indB1 + n0 + en] : 0.f;
   const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
-  // writer workgroup (tile 0): the aggregates of the sampled episode travel with the sample to the
+  // publishing workgroup of the sample: the aggregates of the sampled episode travel with it to the
   // bookkeeping pass, which then needs no dependent gather (the store happens at the very end)
   float aggv = 0.f;
-  if (n == 0 && rowValid && !isNext && en < AGG_N) {
+  if (((em & (HT - 1)) == n) && rowValid && !isNext && en < AGG_N) {
     const int eidv = a.bt.eid[bSrc];
     aggv = en < AGG_USED ? a.rp.epAgg[(size_t)eidv * AGG_N + en] : (en == AGG_LEN ? (float)a.rp.epN[eidv] : 0.f);
   }
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
 
   // ---- V-RACER head: thread = (sample em, action component en), fp64 --------------------------------------
   if (a.variant == 6) return;
-  const bool writer = (n == 0);
+  // every workgroup of the group holds the head results of all 16 samples: workgroup n publishes
+  // the samples em with em % HT == n, so no single workgroup carries all the stores
+  const bool writer = ((em & (HT - 1)) == n);
   if (eth) {
     float g0f = 0.f, gMf = 0.f;
     if (rowValid && isNext) {     // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   }
   __syncthreads();
   FSTAMP(12);
-  if (n == 0 && rowValid && !isNext && en < AGG_N) a.bt.aggIn[(size_t)bSrc * AGG_N + en] = aggv;
+  if (((em & (HT - 1)) == n) && rowValid && !isNext && en < AGG_N) a.bt.aggIn[(size_t)bSrc * AGG_N + en] = aggv;
   if (eth && row < B) {
     const float v = redSum<KWAVES>(red, tid);
     float dres = v;

@@ -68,50 +68,55 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
 }
 
 // one 16x16 output tile (or 16 columns of a column reduction) of problem P
-template <int ROLE>
+// FL >= 0: the flavor (and with it the epilogue kind) is known at compile time and the development
+// ablation switches are compiled out -- the operand loads then form one straight-line batch instead
+// of a chain of branches with a wait at every join
+template <int ROLE, int FL = -1>
 __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* __restrict__ sc,
                                          const AdamHyper& hyp, int nRowsDyn) {
+  const int flavor = FL >= 0 ? FL : P.flavor;
+  const int variant = FL >= 0 ? 0 : hyp.variant;
+  const int epi = FL == GEMM_W ? EPI_DW : P.epi;
   float* sA = reinterpret_cast<float*>(smem);
   float* sB = sA + 16 * LDR;
   float* red = sB + 16 * LDR;
-  if (P.flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
+  if (flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
   // Give XCD x the contiguous (row-major) tile range [x*nT/8, (x+1)*nT/8): the tiles of one XCD
   // then share their A row-panels, and each L2 fetches 1/8 of A instead of all of it.
   {
     const int nT = P.tilesM * P.tilesN;
-    if ((nT & 7) == 0 && !(hyp.variant & 16) && !((hyp.variant >> 5) & (1 << ROLE))) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
+    if ((nT & 7) == 0 && !(variant & 16) && !((variant >> 5) & (1 << ROLE))) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
   }
 
   const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
   const int m0 = tm * 16, n0 = tn * 16;
   const int Mvalid = P.dynRows ? nRowsDyn : P.M;
   if (m0 >= Mvalid) return;
-  if (hyp.variant & 8) return;              // ablation: launch + problem-table fetch only
+  if (variant & 8) return;              // ablation: launch + problem-table fetch only
 
   GSTAMP(24);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lc = lane >> 4;
-  // ---- prefetch the epilogue operands of this thread's output element (m, n) ----
   const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
   const bool outOk = m < Mvalid && n < P.N;
   float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
   AdamCoef ac{};
-  if (outOk && !(hyp.variant & 4)) {        // ablation: no epilogue prefetch
-    if (P.epi == EPI_FWD) {
+  if (outOk && !(variant & 4)) {        // ablation: no epilogue prefetch
+    if (epi == EPI_FWD) {
       e0 = P.bias[n];
       if (P.C3 && n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; e3 = P.resB[n]; }
-    } else if (P.epi == EPI_DX) {
+    } else if (epi == EPI_DX) {
       if (n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; }
       e0 = P.actX[(size_t)m * P.ldAct + n]; e3 = P.actY[(size_t)m * P.ldAct + n];
-    } else if (P.epi == EPI_DW && P.adam) {
+    } else if (epi == EPI_DW && P.adam) {
       ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
       if (m < P.M - 1) { const size_t i = (size_t)m * P.ldc + n; e0 = P.adW[i]; e1 = P.adM1[i]; e2 = P.adM2[i]; }
       else { e0 = P.adbW[n]; e1 = P.adbM1[n]; e2 = P.adbM2[n]; }
     }
   }
-  const bool aRows = (P.flavor != GEMM_W);   // A tile is 16 rows x k  (else k x 16)
-  const bool bRows = (P.flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
+  const bool aRows = (flavor != GEMM_W);   // A tile is 16 rows x k  (else k x 16)
+  const bool bRows = (flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int kb = 0; kb < P.K; kb += KC) {
@@ -127,22 +132,16 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       va[q] = z4; vb[q] = z4;
-      if (hyp.variant & 1) continue;        // ablation: no operand loads
+      if (variant & 1) continue;        // ablation: no operand loads
       if (aRows) {
         const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
         if (idx < 16 * nf4 && m0 + r < Mvalid && c < kc && kb + c < P.lda)
           va[q] = *reinterpret_cast<const float4*>(P.A + (size_t)(m0 + r) * P.lda + kb + c);
       } else {   // GEMM_W: rows = reduction (batch), columns m0.. = input features, + the ones column
         const int k = idx >> 2, c = m0 + (idx & 3) * 4;
-        if (idx < 16 * nf4 && k < kc) {
-          float4 v = z4;
-          if (c < P.lda) v = *reinterpret_cast<const float4*>(P.A + (size_t)(kb + k) * P.lda + c);
-          const int one = P.M - 1 - c;       // position of the ones column inside this float4
-          if (one == 0) v.x = 1.f; else if (one == 1) v.y = 1.f; else if (one == 2) v.z = 1.f; else if (one == 3) v.w = 1.f;
-          if (one < 0) v = z4;
-          else { if (one < 1) v.y = 0.f; if (one < 2) v.z = 0.f; if (one < 3) v.w = 0.f; }
-          va[q] = v;
-        }
+        // (the ones column is patched in at staging time: touching the value here would make the
+        // compiler wait for every load before issuing the next one)
+        if (idx < 16 * nf4 && k < kc && c < P.lda) va[q] = *reinterpret_cast<const float4*>(P.A + (size_t)(kb + k) * P.lda + c);
       }
       if (bRows) {   // GEMM_X: weight rows n0.., reduction along the row
         const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
@@ -154,6 +153,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
           vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(kb + k) * P.ldb + c);
       }
     }
+    GSTAMP(30);
     // ---- stage into LDS ----
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -164,7 +164,13 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
           float2* d = reinterpret_cast<float2*>(sA + r * LDR + c);
           d[0] = make_float2(va[q].x, va[q].y); d[1] = make_float2(va[q].z, va[q].w);
         } else {
-          *reinterpret_cast<float4*>(sA + idx * 4) = va[q];       // [k][16]
+          float4 v = va[q];
+          const int k = idx >> 2, c = m0 + (idx & 3) * 4;
+          const int one = P.M - 1 - c;       // position of the ones column inside this float4
+          if (k < kc) { if (one == 0) v.x = 1.f; else if (one == 1) v.y = 1.f; else if (one == 2) v.z = 1.f; else if (one == 3) v.w = 1.f; }
+          if (one < 0) v = z4;
+          else { if (one < 1) v.y = 0.f; if (one < 2) v.z = 0.f; if (one < 3) v.w = 0.f; }
+          *reinterpret_cast<float4*>(sA + idx * 4) = v;           // [k][16]
         }
         if (bRows) {
           const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
@@ -178,7 +184,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     __syncthreads();
     GSTAMP(25);
     const int k0 = wave * kw;
-    if (!(hyp.variant & 2))                 // ablation: no MFMA loop
+    if (!(variant & 2))                 // ablation: no MFMA loop
     for (int s = 0; s < kw; s += 8) {
       const int ka = k0 + s + lc, kb2 = ka + 4;
       const float a0 = aRows ? sA[li * LDR + ka] : sA[ka * 16 + li];
@@ -199,7 +205,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   GSTAMP(27);
   if (!outOk) return;
 
-  if (P.epi == EPI_FWD) {
+  if (epi == EPI_FWD) {
     const float x = v + e0;
     P.C[(size_t)m * P.ldc + n] = x;
     const float y = actEval(P.func, x);
@@ -209,12 +215,12 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
       if (n < P.resN) r += e1 * e2 + e3;
       P.C3[(size_t)m * P.ldc + n] = r;
     }
-  } else if (P.epi == EPI_DX) {
+  } else if (epi == EPI_DX) {
     float dres = v;
     if (n < P.resN) dres += e1 * e2;
     P.C[(size_t)m * P.ldc + n] = dres;
     P.C2[(size_t)m * P.ldc + n] = dres * actDiff(P.func, e0, e3);
-  } else if (P.epi == EPI_DW) {
+  } else if (epi == EPI_DW) {
     if (m < P.M - 1) {
       const size_t i = (size_t)m * P.ldc + n;
       P.C[i] = v;
@@ -253,13 +259,18 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
 // (scalar loads from the kernarg segment instead of two dependent global round trips)
 __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
+#ifdef HL_TAIL_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 73) const_cast<DevScalars*>(sc)->dbgT[29] = wall_clock64();
+#endif
   const int nRiders = extra.role ? 1 : 0;
   if ((int)blockIdx.x < nRiders) { runExtra(extra, smem); return; }
   const int bid = blockIdx.x - nRiders;
   int p = 0;
 #pragma unroll
   for (int i = 1; i < DW_TABLE_MAX; ++i) if (i < tbl.n && bid >= tbl.p[i].tileStart) p = i;
-  gemmTile<GEMM_ROLE_DW>(tbl.p[p], bid - tbl.p[p].tileStart, smem, sc, hyp, 0);
+  const GemmProblem P = tbl.p[p];      // by value: the whole record in one batch of scalar loads
+  if (P.flavor == GEMM_W) gemmTile<GEMM_ROLE_DW, GEMM_W>(P, bid - P.tileStart, smem, sc, hyp, 0);
+  else gemmTile<GEMM_ROLE_DW>(P, bid - P.tileStart, smem, sc, hyp, 0);
 }
 
 hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
