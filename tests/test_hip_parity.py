@@ -128,6 +128,18 @@ def _compare_step(G, O):
     (dict(dimS=33, dimA=17, bounded=[0] * 17, hidden=(96, 40), nnFunc="Relu", batchSize=48, maxTotObsNum=5000,
           randSeed=8),
      dict(seed=4, dimS=33, dimA=17, lenMin=20, lenMax=80, pTerm=0.1, muSpread=0.2), 60, 10),
+    # shapes served by the fused forward/head/dX kernel (fused.hip): one tile per panel (no panel
+    # barrier), odd batch, every episode truncated and short -> many next-state rows
+    (dict(dimS=3, dimA=1, bounded=[1], hidden=(16, 16), batchSize=5, maxTotObsNum=500, randSeed=3),
+     dict(seed=11, dimS=3, dimA=1, lenMin=3, lenMax=6, pTerm=0.0), 25, 30),
+    # widest state / action spaces of the fused kernel, Tanh instantiation, partial last panel
+    (dict(dimS=32, dimA=7, bounded=[1, 0, 1, 0, 1, 0, 1], hidden=(64, 64), nnFunc="Tanh", batchSize=40, maxTotObsNum=3000,
+          randSeed=12),
+     dict(seed=13, dimS=32, dimA=7, lenMin=3, lenMax=9, pTerm=0.0), 120, 15),
+    # run-time activation dispatch (neither SoftSign nor Tanh), 8 tiles per panel
+    (dict(dimS=20, dimA=4, bounded=[0, 1, 1, 0], hidden=(128, 128), nnFunc="Relu", batchSize=100, maxTotObsNum=20000,
+          randSeed=21, nnLambda=1e-5),
+     dict(seed=17, dimS=20, dimA=4, lenMin=30, lenMax=90, pTerm=0.3), 150, 10),
 ])
 def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
     """Device-side mt19937 sampler (Lemire + sort/unique/redraw), gather, MLP, head, ReF-ER
@@ -145,16 +157,28 @@ def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, s
     assert relinf(wg, wo) < TOL32 and relinf(m1g, m1o) < 5 * TOL32 and relinf(m2g, m2o) < 5 * TOL32
 
 
-def test_multi_step_graph_replay_matches_single_steps(hip_api):
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw,sc_kw,n_eps,n", [
+    (dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42),
+     dict(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5), 30, 64),
+    # 256-step graph + 64 + 8 + 2 + eager remainder; short truncated episodes: the riders (sampler with
+    # gather helpers, bookkeeping) handle next-state rows in every step
+    (dict(dimS=32, dimA=7, bounded=[1, 0, 1, 0, 1, 0, 1], hidden=(64, 64), nnFunc="Tanh", batchSize=40, maxTotObsNum=3000,
+          randSeed=12),
+     dict(seed=13, dimS=32, dimA=7, lenMin=3, lenMax=9, pTerm=0.0), 120, 331),
+    # layout not served by the fused kernel: generic five-launch graph
+    (dict(dimS=9, dimA=3, bounded=[0, 0, 0], hidden=(24, 16, 8), nnFunc="Tanh", batchSize=8, maxTotObsNum=1000, randSeed=5),
+     dict(seed=3, dimS=9, dimA=3, lenMin=3, lenMax=30, pTerm=0.3), 20, 70),
+])
+def test_multi_step_graph_replay_matches_single_steps(hip_api, cfg_kw, sc_kw, n_eps, n):
     """hl_step(n) (hipGraph replay of the launch sequence) == n x hl_step(1) == oracle."""
-    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42)
-    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
-    G, O = _pair(hip_api, cfg_kw, sc, 30)
-    G.step(64); O.step(64)
+    sc = synth_cfg(**sc_kw)
+    G, O = _pair(hip_api, cfg_kw, sc, n_eps)
+    G.step(n); O.step(n)
     _compare_step(G, O)
     assert np.array_equal(G.get_rng_state(), O.get_rng_state())
     assert relinf(G.get_params()[0], O.get_params()[0]) < TOL32
-    assert G.scalars().nGradSteps == 64
+    assert G.scalars().nGradSteps == n
 
 
 def test_thousand_step_sweep_matches_oracle(hip_api):
