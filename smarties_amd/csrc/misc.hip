@@ -24,105 +24,114 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// episode_sweep_kernel: one thread per episode.
+// episode_sweep_kernel: one WAVEFRONT per episode (grid-stride over the episodes).
 //   recompute=1: Episode::updateCumulative (Episode.cpp:213-242)
 //   then computeRetrace backward scan (MemoryProcessing.cpp:23-44,391-400).
-// Used on insert (count=1), by initializeLearner and every 1000th step (whole buffer).
+// Used on insert, by initializeLearner and every 1000th step (whole buffer).
+//
+// Both passes are sequential recurrences in fp32 whose order the reference fixes, so they cannot be
+// tree-reduced.  The 64 lanes load 64 consecutive steps with coalesced reads; the recurrence then
+// runs over the chunk with v_readlane broadcasts (every lane carries the same accumulator), and the
+// lane whose step it is keeps the value it has to store.  A thread per episode walked the arrays
+// with a stride of one episode: every 4-byte read pulled its own cache line 16 times (440 us for
+// 1M transitions); this is one coalesced pass (~10x less).
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float rlF(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+__device__ __forceinline__ double rlD(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, l), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) {
-  __shared__ long long sFar[256];
-  __shared__ float sMax[256];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ long long sFar[4];
+  __shared__ float sMax[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nWaves = gridDim.x * 4;
+  const DevScalars* sc = a.sc;
   long long myFar = 0; float myMax = 0.f;
-  if (idx < a.count) {
+  const float C = (float)sc->Cmax, invC = (float)sc->Cinv;
+  const float gamma = a.gamma, lambda = a.lambda;
+  const float rM = sc->rewMean, rS = sc->rewScale;
+  for (int idx = blockIdx.x * 4 + wave; idx < a.count; idx += nWaves) {
     const int e = a.eids ? a.eids[idx] : a.rp.posEid[idx];
     const long long off = a.rp.epOff[e];
     const int N = a.rp.epN[e];
     const bool term = a.rp.epTerm[e] != 0;
-    const DevScalars* sc = a.sc;
-    // Both passes walk the episode sequentially (the sums and the Retrace recursion keep the
-    // reference's order), but the loads of CH steps are issued together: one HBM round trip per
-    // chunk instead of one per step.
-    constexpr int CH = 16;
     if (a.recompute) {
-      const float C = (float)sc->Cmax, invC = (float)sc->Cinv;
       const int nd = N - 1;
       const float invN = 1 / (float)nd;
       long long nFarPol = 0;
       float sumE2 = 0, maxAE = -1e9f, maxQ = -1e9f, sumQ2 = 0, minQ = 1e9f, sumQ1 = 0, sumKL = 0;
       double totR = 0;
-      for (int t0 = 0; t0 < nd; t0 += CH) {
-        float w[CH], dq[CH], ad[CH], vv[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int t = t0 + u; const bool ok = t < nd;
-          w[u] = ok ? a.rp.IMPW[off + t] : 1.f; dq[u] = ok ? a.rp.DQ[off + t] : 0.f;
-          ad[u] = ok ? a.rp.ADV[off + t] : 0.f; vv[u] = ok ? a.rp.V[off + t] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) if (t0 + u < nd) {
-          if (w[u] > C || w[u] < invC) ++nFarPol;
-          sumE2 += dq[u] * dq[u]; maxAE = fmaxf(maxAE, fabsf(dq[u]));
-          const float Q = ad[u] + vv[u];
-          maxQ = fmaxf(maxQ, Q); minQ = fminf(minQ, Q); sumQ2 += Q * Q; sumQ1 += Q;
+      for (int t0 = 0; t0 < N; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < N;
+        const float w = ok ? a.rp.IMPW[off + t] : 1.f, dq = ok ? a.rp.DQ[off + t] : 0.f;
+        const float ad = ok ? a.rp.ADV[off + t] : 0.f, vv = ok ? a.rp.V[off + t] : 0.f;
+        const double rr = ok ? a.rp.R[off + t] : 0.0; const float kk = ok ? a.rp.DKL[off + t] : 0.f;
+        const int cnt = min(64, N - t0);
+#pragma unroll 8
+        for (int u = 0; u < cnt; ++u) {
+          const float wu = rlF(w, u), dqu = rlF(dq, u), Q = rlF(ad, u) + rlF(vv, u);
+          if (t0 + u < nd) {
+            if (wu > C || wu < invC) ++nFarPol;
+            sumE2 += dqu * dqu; maxAE = fmaxf(maxAE, fabsf(dqu));
+            maxQ = fmaxf(maxQ, Q); minQ = fminf(minQ, Q); sumQ2 += Q * Q; sumQ1 += Q;
+          }
+          totR += rlD(rr, u); sumKL += rlF(kk, u);
         }
       }
-      for (int t0 = 0; t0 < N; t0 += CH) {
-        double rr[CH]; float kk[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) { const int t = t0 + u; const bool ok = t < N; rr[u] = ok ? a.rp.R[off + t] : 0.0; kk[u] = ok ? a.rp.DKL[off + t] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) if (t0 + u < N) { totR += rr[u]; sumKL += kk[u]; }
+      if (lane == 0) {
+        float* ag = a.rp.epAgg + (size_t)e * AGG_N;
+        ag[AGG_FRACFAR] = invN * (float)nFarPol; ag[AGG_AVGSQERR] = invN * sumE2; ag[AGG_MAXABSERR] = maxAE;
+        ag[AGG_SUMQ2] = sumQ2; ag[AGG_SUMQ] = sumQ1; ag[AGG_MAXQ] = maxQ; ag[AGG_MINQ] = minQ;
+        ag[AGG_TOTR] = (float)totR; ag[AGG_AVGKL] = invN * sumKL;
       }
-      float* ag = a.rp.epAgg + (size_t)e * AGG_N;
-      ag[AGG_FRACFAR] = invN * (float)nFarPol; ag[AGG_AVGSQERR] = invN * sumE2; ag[AGG_MAXABSERR] = maxAE;
-      ag[AGG_SUMQ2] = sumQ2; ag[AGG_SUMQ] = sumQ1; ag[AGG_MAXQ] = maxQ; ag[AGG_MINQ] = minQ;
-      ag[AGG_TOTR] = (float)totR; ag[AGG_AVGKL] = invN * sumKL;
-      myFar = farSteps((float)N, ag[AGG_FRACFAR]);
-      myMax = fmaxf(maxAE, 0.f);
+      myFar += farSteps((float)N, invN * (float)nFarPol);
+      myMax = fmaxf(myMax, fmaxf(maxAE, 0.f));
     }
-    const float gamma = a.gamma, lambda = a.lambda;
-    const float rM = sc->rewMean, rS = sc->rewScale;
     float Q = term ? a.rp.RET[off + N - 1] : a.rp.V[off + N - 1];
-    if (!term) a.rp.RET[off + N - 1] = Q;
-    for (int t1 = N - 2; t1 >= 0; t1 -= CH) {      // chunk covers t = t1, t1-1, ..., t1-CH+1
-      double rr[CH]; float vv[CH], ad[CH], iw[CH];
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int t = t1 - u; const bool ok = t >= 0;
-        rr[u] = ok ? a.rp.R[off + t + 1] : 0.0; vv[u] = ok ? a.rp.V[off + t + 1] : 0.f;
-        ad[u] = ok ? a.rp.ADV[off + t + 1] : 0.f; iw[u] = ok ? a.rp.IMPW[off + t + 1] : 0.f;
+    if (!term && lane == 0) a.rp.RET[off + N - 1] = Q;
+    for (int t1 = N - 2; t1 >= 0; t1 -= 64) {      // chunk covers t = t1, t1-1, ..., t1-63
+      const int t = t1 - lane;
+      const bool ok = t >= 0;
+      const double rr = ok ? a.rp.R[off + t + 1] : 0.0;
+      const float vv = ok ? a.rp.V[off + t + 1] : 0.f, ad = ok ? a.rp.ADV[off + t + 1] : 0.f, iw = ok ? a.rp.IMPW[off + t + 1] : 0.f;
+      const float Rl = (float)((rr - (double)rM) * (double)rS);      // per lane, same expression as the reference
+      const float wl = iw < 1.f ? iw : 1.f;
+      const int cnt = min(64, t1 + 1);
+      float mine = 0.f;
+#pragma unroll 8
+      for (int u = 0; u < cnt; ++u) {
+        const float Vu = rlF(vv, u), Au = rlF(ad, u);
+        Q = rlF(Rl, u) + gamma * (Vu + lambda * rlF(wl, u) * (Q - Au - Vu));
+        if (lane == u) mine = Q;
       }
-#pragma unroll
-      for (int u = 0; u < CH; ++u) if (t1 - u >= 0) {
-        const float R = (float)((rr[u] - (double)rM) * (double)rS);
-        const float w = iw[u] < 1.f ? iw[u] : 1.f;
-        Q = R + gamma * (vv[u] + lambda * w * (Q - ad[u] - vv[u]));
-        a.rp.RET[off + t1 - u] = Q;
-      }
+      if (ok) a.rp.RET[off + t] = mine;
     }
   }
   if (a.recompute) {
-    sFar[threadIdx.x] = myFar; sMax[threadIdx.x] = myMax;
+    if (lane == 0) { sFar[wave] = myFar; sMax[wave] = myMax; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) { sFar[threadIdx.x] += sFar[threadIdx.x + s];
-        sMax[threadIdx.x] = fmaxf(sMax[threadIdx.x], sMax[threadIdx.x + s]); }
-      __syncthreads();
+    if (threadIdx.x == 0) {
+      a.redNFar[blockIdx.x] = sFar[0] + sFar[1] + sFar[2] + sFar[3];
+      a.redMaxAbs[blockIdx.x] = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
     }
-    if (threadIdx.x == 0) { a.redNFar[blockIdx.x] = sFar[0]; a.redMaxAbs[blockIdx.x] = sMax[0]; }
   }
 }
-int sweep_blocks(int count) { return (count + 255) / 256; }
+int sweep_blocks(int count) { const int b = (count + 3) / 4; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s) {
   if (nBlocks <= 0) return hipSuccess;
   hipLaunchKernelGGL(episode_sweep_kernel, dim3(nBlocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 __global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int n) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  long long f = 0; float m = 0.f;
-  for (int i = 0; i < n; ++i) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); }
+  if (blockIdx.x != 0) return;
+  long long f = 0; float m = 0.f;                       // integer sum / max: any order gives the same result
+  for (int i = threadIdx.x; i < n; i += 64) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); }
+  for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); m = fmaxf(m, __shfl_xor(m, o, 64)); }
+  if (threadIdx.x != 0) return;
   sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
   sc->maxAbsErrAll = m;
   sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
