@@ -77,7 +77,7 @@ struct hl_learner {
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
   // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
-  GraphSlot graphs[4]; bool graphsStale = false, useGraph = true;
+  GraphSlot graphs[5]; bool graphsStale = false, useGraph = true;
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
   hipStream_t sSample = nullptr, sPost = nullptr;
   std::vector<hipEvent_t> evPool; int evUsed = 0;

@@ -21,7 +21,8 @@
 
 namespace {
 
-constexpr int GRAPH_SIZES[] = {256, 64, 8, 2};   // steps per replayed graph, tried in this order
+// steps per replayed graph, tried in this order; 999 = everything between two 1000th-step sweeps
+constexpr int GRAPH_SIZES[] = {999, 256, 64, 8, 2};
 
 void setTiles(GemmProblem& p, int& cursor) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
@@ -381,7 +382,13 @@ int replaySteps(hl_learner* h, long long avail, int* done) {
     const int U = GRAPH_SIZES[i];
     if (avail < U) continue;
     GraphSlot& g = h->graphs[i];
-    if (!g.exec) { int rc = captureSteps(h, U, &g); if (rc) return rc; }
+    if (!g.exec) {
+      // first use: capture every size now (tens of ms, once per learner -- graphs survive appends
+      // and evictions, only a reallocation of the replay invalidates them), so that no later call
+      // pays for a capture in the middle of a training phase
+      for (size_t j = 0; j < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]); ++j)
+        if (!h->graphs[j].exec) { int rc = captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]); if (rc) return rc; }
+    }
     HIPCK(hipGraphLaunch(g.exec, h->stream));
     h->lastParity = (U - 1) & 1;
     *done = U;
