@@ -207,6 +207,15 @@ HL_API int hl_moments_exchange(hl_learner* h, double* io, int32_t write_back);
 HL_API int hl_step_end(hl_learner* h);
 HL_API int hl_sync(hl_learner* h);                         /* wait for all queued device work */
 
+/* ---- rollout inference (first row) --------------------------------------
+ * Network outputs for n raw (un-standardised) states with the CURRENT weights and state scaling:
+ * what Approximator::forward(agent) returns to RACER::selectAction / processTerminal
+ * (Learners/RACER.cpp:30-59; Network/Approximator.h:300-330): outputs[i] = [V_net, mean[dA],
+ * sigma_param[dA]] as doubles, nOut per state.  The caller builds the policy, draws the action
+ * with the agent's generator and applies scaleNet2V exactly as the reference does.  Call between
+ * steps, from the thread that owns the learner. */
+HL_API int hl_forward(hl_learner* h, int32_t n, const float* states /*[n][dimS]*/, double* outputs /*[n][nOut]*/);
+
 /* ---- inspection ---------------------------------------------------------------- */
 HL_API int hl_set_tap(hl_learner* h, int32_t enable);
 HL_API int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t dst_bytes);

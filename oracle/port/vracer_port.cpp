@@ -913,6 +913,19 @@ int ol_step(ol_learner* h, int32_t n, const int64_t* flat) {
   return HL_OK;
 }
 int ol_sync(ol_learner*) { return HL_OK; }
+// Approximator::forward(agent) (Network/Approximator.h:300-330) on standardised states
+// (Episode::standardizedState, Episode.h:172-183): the network outputs RACER::selectAction reads
+int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs) {
+  if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
+  const int dS = h->dS, nOut = h->nOut;
+  std::vector<nnReal> inp(dS);
+  for (int r = 0; r < n; ++r) {
+    for (int i = 0; i < dS; ++i) inp[i] = (states[(size_t)r * dS + i] - h->stMean[i]) * h->stScale[i];
+    forwardNet(h, inp.data(), h->X, h->Y);
+    getOutput(h, h->Y, outputs + (size_t)r * nOut);
+  }
+  return HL_OK;
+}
 int ol_set_tap(ol_learner* h, int32_t e) { if (!h) return HL_ERR_BAD_ARG; h->tap = e != 0; return HL_OK; }
 
 int ol_readback(ol_learner* h, int32_t what, void* dst, int64_t bytes) {

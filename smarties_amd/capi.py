@@ -159,6 +159,7 @@ class CApi:
             "timing_enable": (C.c_int, [P, I32]),
             "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
+            "forward": (C.c_int, [P, I32, pf, pd]),
             "status_string": (C.c_char_p, [C.c_int]),
             "version": (C.c_int, []),
         }.items():
@@ -322,6 +323,13 @@ class Learner:
     def moments_store(self, m):
         m = _f64(m)
         self._ck(self.api.fn("moments_exchange")(self.h, _ptr(m, C.c_double), 1))
+
+    def forward(self, states):
+        """Network outputs [n][nOut] (float64) for raw states [n][dimS] with the current weights."""
+        st = np.ascontiguousarray(states, dtype=np.float32).reshape(-1, self.dS)
+        out = np.zeros((st.shape[0], self.nOut), np.float64)
+        self._ck(self.api.fn("forward")(self.h, st.shape[0], _ptr(st, C.c_float), _ptr(out, C.c_double)))
+        return out
 
     def sync(self):
         self._ck(self.api.fn("sync")(self.h))

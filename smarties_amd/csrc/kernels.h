@@ -97,6 +97,9 @@ hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra,
 size_t fused_lds_bytes(int dS, int H);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);
+hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0, hipStream_t s);
+hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
+                             int nDense, int dA, int n, double* O, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);
 hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s);

@@ -73,6 +73,7 @@ struct hl_learner {
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
+  float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
   long long* dRedNFar = nullptr; float* dRedMax = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
@@ -807,6 +808,25 @@ int hl_step_end(hl_learner* h) {
   h->nGradSteps += 1; h->inStep = false;
   return HL_OK;
 }
+// rollout inference: Approximator::forward(agent) for n states (RACER.cpp:30-59)
+int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
+  if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
+  if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward between hl_step_begin and hl_step_end");
+  if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->Mmax * h->dS)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
+  const DevHidden& q = h->hid[h->nHidden - 1];
+  for (int r0 = 0; r0 < n; r0 += h->Mmax) {
+    const int m = std::min(h->Mmax, n - r0);
+    HIPCK(hipMemcpyAsync(h->dActS, states + (size_t)r0 * h->dS, (size_t)m * h->dS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, m, h->dS, h->buf[0].X0, h->ldX0, h->stream));
+    int rc = launchForward(h, 0, h->stream); if (rc) return rc;
+    HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->dA, m,
+                            h->dActO, h->stream));
+    HIPCK(hipMemcpyAsync(outputs + (size_t)r0 * h->nOut, h->dActO, (size_t)m * h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+  }
+  return HL_OK;
+}
+
 int hl_sync(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
   HIPCK(hipStreamSynchronize(h->stream));

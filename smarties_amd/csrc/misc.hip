@@ -294,6 +294,37 @@ hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// rollout inference (hl_forward): standardise raw states into the minibatch rows, run the forward
+// GEMMs of the training path on them, then the Linear output layer + ParamLayer as doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_standardize_kernel(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { sc->nRows[0] = n; sc->nNext[0] = 0; }     // rows the forward GEMMs of buffer 0 will process
+  if (i < n * dS) { const int r = i / dS, c = i - r * dS; X0[(size_t)r * ldX0 + c] = (S[i] - rp.stMean[c]) * rp.stScale[c]; }
+}
+__global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo,
+                                                         long long indBp, int ldWo, int nDense, int dA, int n, double* O) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, nOut = nDense + dA;
+  if (row >= n) return;
+  for (int o = 0; o < nDense; ++o) {
+    float p = 0.f;
+    for (int k = lane; k < H; k += 64) p += Y[(size_t)row * ldY + k] * W[indWo + (long long)k * ldWo + o];
+    p = waveSumF(p);
+    if (lane == 0) O[(size_t)row * nOut + o] = (double)(p + W[indBo + o]);
+  }
+  if (lane < dA) O[(size_t)row * nOut + nDense + lane] = (double)W[indBp + lane];
+}
+hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0, hipStream_t s) {
+  hipLaunchKernelGGL(act_standardize_kernel, dim3((n * dS + 255) / 256 + 1), dim3(256), 0, s, sc, rp, S, n, dS, X0, ldX0);
+  return hipGetLastError();
+}
+hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
+                             int nDense, int dA, int n, double* O, hipStream_t s) {
+  hipLaunchKernelGGL(act_output_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Y, ldY, H, W, indWo, indBo, indBp, ldWo, nDense, dA, n, O);
+  return hipGetLastError();
+}
+
 __global__ void empty_kernel() {}
 hipError_t launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); return hipGetLastError(); }
 

@@ -326,6 +326,31 @@ def test_rccl_exchange_sequence_on_one_rank(hip_api):
     assert np.array_equal(A.get_rng_state(), Bq.get_rng_state())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw,sc_kw", [
+    (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=64, maxTotObsNum=20000, randSeed=1),
+     dict(seed=9, dimS=17, dimA=6, lenMin=50, lenMax=90, pTerm=0.2)),
+    (dict(dimS=9, dimA=3, bounded=[0, 0, 0], hidden=(24, 16, 8), nnFunc="Tanh", batchSize=8, maxTotObsNum=1000, randSeed=5),
+     dict(seed=3, dimS=9, dimA=3, lenMin=3, lenMax=30, pTerm=0.3)),
+])
+def test_rollout_forward_matches_oracle(hip_api, cfg_kw, sc_kw):
+    """hl_forward (what RACER::selectAction reads, RACER.cpp:30-47): network outputs for raw states
+    with the current weights and state scaling, before and after training steps; more states than
+    minibatch rows (chunked) and a single state."""
+    sc = synth_cfg(**sc_kw)
+    G, O = _pair(hip_api, cfg_kw, sc, 40)
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 3 * cfg_kw["batchSize"] + 5):
+        st = rng.standard_normal((n, cfg_kw["dimS"])).astype(np.float32) * 2 + 0.3
+        og, oo = G.forward(st), O.forward(st)
+        assert og.shape == (n, G.nOut) and relinf(og, oo) < TOL32
+    G.step(20); O.step(20)
+    st = rng.standard_normal((33, cfg_kw["dimS"])).astype(np.float32)
+    assert relinf(G.forward(st), O.forward(st)) < TOL32
+    G.step(3); O.step(3)            # the forward pass in between leaves the training path untouched
+    _compare_step(G, O)
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json size: 1M-transition replay, 17/6, 2x256, B=256
 # ---------------------------------------------------------------------------------------------
