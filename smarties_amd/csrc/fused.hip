@@ -303,17 +303,44 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (a.variant == 2) return;
   if (eth && row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
 
-  // ---- own tile of x2 = h1 W1 + b1: K split over the 4 waves ----------------------------------------
-  if (wave < KWAVES) {
-    const int k0 = wave * KW + lc;
-    const f32x4 acc = waveMma<NK>([&](int s) { return sY1[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sR3[(k0 + 4 * s) * 16 + li]; });
+  // ---- head terms that do not depend on the network outputs of this step (the policy stdev comes
+  // from the ParamLayer bias alone).  With 8 waves the element threads (waves 0-3) compute them
+  // while waves 4-7 run the x2 contraction; with 4 waves they follow the exchange stores. ------------
+  const bool live = rowValid && !isNext;
+  const double MAXM = 8.31776613503286;
+  double stdev = 1, invStd = 1, dPos = 0, bInv = 1, invVarMu = 1, u2 = 0, lq = 0, CmuCpi = 1;
+  bool bnd = false;
+  auto headPrecompute = [&]() {
+    asm volatile("" : "+v"(act), "+v"(bMean), "+v"(bStd));   // keep the fp64 work (and its wait on the gathers) here
+    if (live && en < dA) {
+      bnd = ((a.boundedMask >> en) & 1ull) != 0;
+      const double pp = (double)sBp[en];
+      const double rt = sqrt(1 + pp * pp);
+      stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
+      bInv = 1 / bStd; invVarMu = 1 / (bStd * bStd);
+      u2 = (act - bMean) * bInv;
+      const double qq = stdev * bInv;
+      lq = log(qq); CmuCpi = qq * qq;
+    }
+  };
+  constexpr bool SPLITW = (NW == 8 && H >= 16);      // waves 4-7 contract, waves 0-3 do the fp64 terms
+  constexpr int XW = SPLITW ? 4 : KWAVES;            // waves sharing the x2 contraction
+  constexpr int XKW = H / XW, XNK = XKW / 4;
+
+  // ---- own tile of x2 = h1 W1 + b1: K split over XW waves ------------------------------------------------
+  {
+    const int xw = SPLITW ? wave - 4 : wave;
+    if (xw >= 0 && xw < XW) {
+      const int k0 = xw * XKW + lc;
+      const f32x4 acc = waveMma<XNK>([&](int s) { return sY1[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sR3[(k0 + 4 * s) * 16 + li]; });
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+      for (int r = 0; r < 4; ++r) red[xw * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+    } else if (SPLITW) headPrecompute();
   }
   __syncthreads();
   FSTAMP(3);
   if (rowValid) {
-    const float v = redSum<KWAVES>(red, tid);
+    const float v = redSum<XW>(red, tid);
     const float x2 = v + b1e;
     float y2 = 0.f, f2 = 0.f;
     dispatchFunc<CF>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y2 = actEvalT<FN>(x2); f2 = actDiffT<FN>(x2, y2); });
@@ -322,23 +349,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     st_agent(gX2 + (size_t)row * ldA1 + n0 + en, f2);      // f'(x2)
   }
   FSTAMP(4);
-  // ---- head terms that do not depend on the network outputs of this step (the policy stdev comes
-  // from the ParamLayer bias alone): computed while the exchange stores drain / the barrier fills ------
-  const bool live = rowValid && !isNext;
-  const double MAXM = 8.31776613503286;
-  double stdev = 1, invStd = 1, dPos = 0, bInv = 1, invVarMu = 1, u2 = 0, lq = 0, CmuCpi = 1;
-  bool bnd = false;
-  asm volatile("" : "+v"(act), "+v"(bMean), "+v"(bStd));   // keep the fp64 work (and its wait on the gathers) here
-  if (live && en < dA) {
-    bnd = ((a.boundedMask >> en) & 1ull) != 0;
-    const double pp = (double)sBp[en];
-    const double rt = sqrt(1 + pp * pp);
-    stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
-    bInv = 1 / bStd; invVarMu = 1 / (bStd * bStd);
-    u2 = (act - bMean) * bInv;
-    const double qq = stdev * bInv;
-    lq = log(qq); CmuCpi = qq * qq;
-  }
+  if (!SPLITW) headPrecompute();
   // ---- group barrier: all HT tiles of this panel are in memory ------------------------------------------
   FSTAMP(5);
   __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the write-through stores are acknowledged

@@ -213,6 +213,12 @@ struct HostMT {
 int syncScalarsToHost(hl_learner* h, DevScalars* out) {
   HIPCK(hipMemcpyAsync(out, h->sc, sizeof(DevScalars), hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
+  // sticky device-side error (a bounded in-kernel wait gave up: 77 = panel barrier of the fused
+  // kernel, 78 = sampler -> gather hand-off): the results since then are not trustworthy
+  if (out->errFlag != 0) {
+    char msg[96]; snprintf(msg, sizeof(msg), "device-side failure code %d (in-kernel wait timed out)", out->errFlag);
+    return fail(h, HL_ERR_HIP, msg);
+  }
   return HL_OK;
 }
 
