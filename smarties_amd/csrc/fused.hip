@@ -75,9 +75,27 @@ template <int CF, class Body> __device__ __forceinline__ void dispatchFunc(int f
   else body(FuncTag<HL_FUNC_LINEAR>{});
 }
 __device__ __forceinline__ float resOut(float y, float in, float w, float b) { return y + fmaf(in, w, b); }
-__device__ __forceinline__ double sum16(double v) {            // over the 16 lanes of one sample
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane traffic inside a 16-lane row (one sample) goes through DPP row rotations -- one VALU
+// instruction each -- instead of ds_bpermute round trips through the LDS crossbar.
+// rowRor<N>: lane i of a row receives the value of lane (i - N) mod 16 of the same row.
+template <int N> __device__ __forceinline__ int rowRorI(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false); }
+template <int N> __device__ __forceinline__ float rowRorF(float v) { return __int_as_float(rowRorI<N>(__float_as_int(v))); }
+template <int N> __device__ __forceinline__ double rowRorD(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)rowRorI<N>((int)(unsigned)b), hi = (unsigned)rowRorI<N>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the 16 lanes of one sample, every lane gets it.  Same pairing as an xor butterfly
+// (8, 4, 2, 1: the partial sums are periodic, so rotating or exchanging gives the same operands).
+__device__ __forceinline__ double sum16(double v) {
+  v += rowRorD<8>(v); v += rowRorD<4>(v); v += rowRorD<2>(v); v += rowRorD<1>(v);
   return v;
+}
+// value of lane 0 of the row in every lane (exact: the other lanes contribute +0)
+__device__ __forceinline__ float bcast0F(float v, int en) {
+  float x = en == 0 ? v : 0.f;
+  x += rowRorF<8>(x); x += rowRorF<4>(x); x += rowRorF<2>(x); x += rowRorF<1>(x);
+  return x;
 }
 
 // LDS carve-up (floats).  R1: h1 panel, later the W1 row tile of the dX contraction.  R2: W0
@@ -139,6 +157,9 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   constexpr int QO = (H * 2 + NT - 1) / NT;      // float4 per thread of Wout [H][8]
   constexpr int Q0 = (32 * H4 + NT - 1) / NT;    // float4 per thread of W0 (dS <= 32)
   constexpr int QS = 512 / NT;                   // state-tile elements per thread
+#if defined(HL_TAIL_STAMPS) && !defined(HL_NO_FSTAMP)
+  if (threadIdx.x == 0 && blockIdx.x == 8 + 8) a.sc->dbgT[31] = wall_clock64();   // (panel 0, tile 1): kernel entry
+#endif
   const DevScalars* sc = a.sc;
   const int dS = a.dS, dSp = (dS + 3) & ~3, B = a.B, dA = a.dA, nDense = a.nDense;
   // arguments used inside the hot loops, pinned in VGPRs: under SGPR pressure the compiler would
@@ -418,8 +439,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   // ParamLayer part (Linear) is its bias
   const int base = lane & ~15;
   const float Oen = eth ? redSum<KWAVES>(red, tid) + sBo[en] : 0.f;
-  const double O0 = (double)__shfl(Oen, base, 64);
-  const double mean = (double)__shfl(Oen, base + ((en + 1) & 15), 64);   // O[em][1 + en]
+  const double O0 = (double)bcast0F(Oen, en);
+  const double mean = (double)rowRorF<15>(Oen);                           // O[em][1 + en]: lane i reads lane i+1
 
   // ---- V-RACER head: thread = (sample em, action component en), fp64 --------------------------------------
   if (a.variant == 6) return;
@@ -429,7 +450,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (eth) {
     float g0f = 0.f, gMf = 0.f;
     if (rowValid && isNext) {     // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
-      const float oV = __shfl(misc, base + 6, 64), oA = __shfl(misc, base + 7, 64);
+      const float oV = rowRorF<10>(misc), oA = rowRorF<9>(misc);      // lane 0 reads lanes 6 and 7
       if (writer && en == 0) {
         const float Vn = (float)scaleNet2V(O0);
         a.bt.oldNextV[bSrc] = oV; a.bt.oldNextADV[bSrc] = oA;
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
     const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
     const double V = scaleNet2V(O0);
-    const double Qret = (double)__shfl(misc, base, 64);
+    const double Qret = (double)bcast0F(misc, en);
     const double A_RET = Qret - V, dQ = A_RET;                       // Zero_advantage
     const double Ver = fmin(1.0, RHO) * dQ;
     const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
@@ -487,11 +508,12 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     }
     if (live) g0f = (float)g0;
     // output-layer deltas of the panel (zero for next / padding rows)
-    const float gPrev = __shfl(gMf, base + ((en + 15) & 15), 64);     // component en-1 of the same sample
+    const float gPrev = rowRorF<1>(gMf);                               // component en-1 of the same sample
     if (en < 8) sDo[em * 8 + en] = en == 0 ? g0f : (en <= dA ? gPrev : 0.f);
     if (live && writer) {
-      const float oDQ = __shfl(misc, base + 1, 64), oDKL = __shfl(misc, base + 2, 64), oW = __shfl(misc, base + 3, 64);
-      const float oV = __shfl(misc, base + 4, 64), oADV = __shfl(misc, base + 5, 64);
+      // lane 0 (the one that stores them) reads lanes 1..5
+      const float oDQ = rowRorF<15>(misc), oDKL = rowRorF<14>(misc), oW = rowRorF<13>(misc);
+      const float oV = rowRorF<12>(misc), oADV = rowRorF<11>(misc);
       if (en == 0) {
         a.bt.pEid[bSrc] = a.bt.eid[bSrc]; a.bt.pNextOf[bSrc] = a.bt.nextOf[bSrc];
         a.bt.G[(size_t)bSrc * a.nOut] = (double)g0f;
