@@ -109,11 +109,18 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     } else if (epi == EPI_DX) {
       if (n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; }
       e0 = P.actX[(size_t)m * P.ldAct + n]; e3 = P.actY[(size_t)m * P.ldAct + n];
-    } else if (epi == EPI_DW && P.adam) {
+    } else if (epi == EPI_DW && P.adam && FL < 0) {
       ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
       if (m < P.M - 1) { const size_t i = (size_t)m * P.ldc + n; e0 = P.adW[i]; e1 = P.adM1[i]; e2 = P.adM2[i]; }
       else { e0 = P.adbW[n]; e1 = P.adbM1[n]; e2 = P.adbM2[n]; }
     }
+  }
+  if (FL == GEMM_W && P.adam) {   // branch-free variant: a divergent if/else here ends in a wait for its loads
+    ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
+    const bool isW = m < P.M - 1;
+    const size_t iw = outOk ? (isW ? (size_t)m * P.ldc + n : (size_t)n) : 0;
+    const float* pw = isW ? P.adW : P.adbW; const float* p1 = isW ? P.adM1 : P.adbM1; const float* p2 = isW ? P.adM2 : P.adbM2;
+    e0 = pw[iw]; e1 = p1[iw]; e2 = p2[iw];
   }
   const bool aRows = (flavor != GEMM_W);   // A tile is 16 rows x k  (else k x 16)
   const bool bRows = (flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
