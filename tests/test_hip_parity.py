@@ -327,6 +327,50 @@ def test_rccl_exchange_sequence_on_one_rank(hip_api):
 
 
 @pytest.mark.gpu
+def test_sampler_collisions_and_redraw_match_oracle(hip_api):
+    """Replay barely larger than the batch: most draws collide, so Sample_uniform's
+    sort / unique / redraw-the-tail loop (Sampling.cpp:75-93) runs several rounds per step.  Indices,
+    generator state and updates stay bit-exact / within tolerance; episodes of the minimal length
+    (2 states) and terminated ones are part of the mix."""
+    cfg_kw = dict(dimS=4, dimA=2, bounded=[1, 1], hidden=(16, 16), batchSize=32, maxTotObsNum=200, randSeed=77)
+    sc = synth_cfg(seed=5, dimS=4, dimA=2, lenMin=2, lenMax=5, pTerm=0.5)
+    G, O = _pair(hip_api, cfg_kw, sc, 16)
+    nT = G.scalars().nStoredSteps
+    assert 32 <= nT <= 64, nT                      # > 25 % duplicates expected per draw of 32
+    for k in range(25):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state()), k
+    G.step(70); O.step(70)                         # the same through replayed graphs
+    _compare_step(G, O)
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+
+
+@pytest.mark.gpu
+def test_error_paths_fail_loudly(hip_api):
+    """Call-sequence and size errors come back as status codes, never as silent work
+    (reference: die() in Learner_approximator.cpp:38-41 for a too small replay)."""
+    cfg = capi.make_config(dimS=4, dimA=2, bounded=[1, 1], hidden=(16, 16), batchSize=32, maxTotObsNum=200, randSeed=1)
+    L = hip_learner(hip_api, cfg)
+    L.init_weights()
+    with pytest.raises(capi.HlError) as e:
+        L.initialize()                             # empty replay
+    assert e.value.status == 5                     # HL_ERR_TOO_FEW_DATA
+    sc = synth_cfg(seed=5, dimS=4, dimA=2, lenMin=3, lenMax=3, pTerm=0.0)
+    fill_synth(L, sc, 4)                           # 8 transitions < batch 32
+    with pytest.raises(capi.HlError) as e:
+        L.step(1)                                  # step before initialize
+    assert e.value.status == 4                     # HL_ERR_STATE
+    L.initialize()
+    with pytest.raises(capi.HlError) as e:
+        L.step(1)
+    assert e.value.status == 5 and "minTotObsNum" in str(e.value)
+    with pytest.raises(capi.HlError) as e:
+        L.step_end()                               # without step_begin
+    assert e.value.status == 4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg_kw,sc_kw", [
     (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=64, maxTotObsNum=20000, randSeed=1),
      dict(seed=9, dimS=17, dimA=6, lenMin=50, lenMax=90, pTerm=0.2)),
