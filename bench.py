@@ -220,8 +220,17 @@ def main():
                            "peak": peak, "unit": unit, "frac": ach / peak}
         dom = max(table, key=lambda n: table[n]["launch_us"])
         d = table[dom]
+        # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process;
+        # the committed rocprofv3 --pmc passes (profiles/r01_pmc.json: commands, corrections) are quoted
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+                traffic = json.load(f)["kernels"][dom.split("<")[0]]["traffic_bytes"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": None, "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
+                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r01_pmc.json)",
+                "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
                 "step_kernels": table,
                 "note": "latency-bound step: dependent launches of a few hundred workgroups; launch_us = HIP-event time "
                         "per launch of graph-replayed back-to-back launches (dispatch included, as a kernel trace "
