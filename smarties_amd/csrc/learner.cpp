@@ -79,6 +79,7 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
   GraphSlot graphs[5]; bool graphsStale = false, useGraph = true;
+  bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
   hipStream_t sSample = nullptr, sPost = nullptr;
   std::vector<hipEvent_t> evPool; int evUsed = 0;
@@ -477,6 +478,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   rc = buildProblems(h); if (rc) return rc;
   if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) h->useGraph = !(e[0] == '1');
+  if (const char* e = getenv("SMARTIES_HIP_NO_EXCH_GRAPH")) h->exchGraph = !(e[0] == '1');   // replicas: eager exchanges only
   return HL_OK;
 }
 
@@ -734,7 +736,8 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
   while (s < n) {
     int rc = preStepChecks(h); if (rc) return rc;
     const long long k = h->nGradSteps + 1;
-    const bool plain = !flat && (k % 1000) != 0 && !evictionDue(h) && !exchanging(h) && !h->timing && h->useGraph;
+    const bool plain = !flat && (k % 1000) != 0 && !evictionDue(h) && !h->timing && h->useGraph &&
+                       (!exchanging(h) || (h->fusedOk && h->exchGraph && h->comm));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
       // plain steps available before the next 1000-step sweep and within this call

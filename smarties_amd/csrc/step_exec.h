@@ -207,11 +207,12 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
 // fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
 // dW launch of the fused path: the dX contractions were done by the fused kernel; riders: the
 // bookkeeping of THIS step and sampler phase C of the NEXT one
-int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost, bool nextSampleC) {
+int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost, bool nextSampleC,
+                     int postMode = POST_AGG | POST_BETA) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   ExtraArgs exP{}, exC{};
-  if (fusePost) { exP.role = 2; exP.post = postArgs(h, parity, POST_AGG | POST_BETA); }
+  if (fusePost) { exP.role = 2; exP.post = postArgs(h, parity, postMode); }
   if (nextSampleC) exC = extraSample(h, parity ^ 1, PH_C);
   if (sb.dwCount <= DW_TABLE_MAX && !nextSampleC) {   // problem table in the kernel arguments
     const DwTable& tbl = fuseAdam ? sb.dwTableAdam : sb.dwTable;
@@ -353,7 +354,14 @@ int captureSteps(hl_learner* h, int U, GraphSlot* slot) {
     const bool more = j + 1 < U;                        // pre-sample step j+1 while step j computes
     if (h->fusedOk) {
       rc = launchFused(h, p, s0, more); if (rc) break;
-      rc = launchWeightGrad(h, p, true, s0, true, false); if (rc) break;
+      if (!exchanging(h)) { rc = launchWeightGrad(h, p, true, s0, true, false); if (rc) break; continue; }
+      // replicas: the exchanges are part of the replayed graph (RCCL calls are captured like kernels).
+      // Same collective order as the eager sequence: gradient sum, then the four counters.
+      rc = launchWeightGrad(h, p, false, s0, true, false, POST_AGG); if (rc) break;
+      rc = allreduceGrad(h); if (rc) break;
+      rc = allreduceCounters(h); if (rc) break;
+      rc = launchAdam(h, p); if (rc) break;
+      rc = launchPost(h, p, POST_BETA, s0); if (rc) break;
       continue;
     }
     rc = launchForward(h, p, s0, more); if (rc) break;
@@ -382,6 +390,15 @@ int replaySteps(hl_learner* h, long long avail, int* done) {
     const int U = GRAPH_SIZES[i];
     if (avail < U) continue;
     GraphSlot& g = h->graphs[i];
+    if (!g.exec && exchanging(h)) {
+      // a communicator is attached: if RCCL cannot be captured on this system, fall back to eager
+      // launches for good (the graph is only an optimisation)
+      for (size_t j = 0; j < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]) && h->exchGraph; ++j)
+        if (!h->graphs[j].exec && captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]) != HL_OK) {
+          h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
+        }
+      if (!h->exchGraph) return HL_OK;
+    }
     if (!g.exec) {
       // first use: capture every size now (tens of ms, once per learner -- graphs survive appends
       // and evictions, only a reallocation of the replay invalidates them), so that no later call
