@@ -495,12 +495,12 @@ int hl_destroy(hl_learner* h) {
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
-    h->rp.stStd, h->rp.epTag, h->rp.posRec};
+    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->panelCtr, h->dActS, h->dActO};
   for (int pb = 0; pb < 2; ++pb) {
     DevBatch& bt = h->buf[pb].bt;
     void* bp[] = {h->buf[pb].X0, bt.sVals, bt.tag, bt.pEid, bt.pNextOf, bt.flat, bt.pos, bt.eid, bt.t, bt.slot, bt.nextOf, bt.nextSrc,
       bt.O, bt.G, bt.rho, bt.dkl, bt.dq, bt.far, bt.newDQ, bt.newDKL, bt.newW, bt.newV, bt.oldDQ, bt.oldDKL, bt.oldW,
-      bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam};
+      bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam, bt.aggIn};
     for (void* q : bp) if (q) hipFree(q);
   }
   for (void* p : ptrs) if (p) hipFree(p);
