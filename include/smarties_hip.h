@@ -216,6 +216,17 @@ HL_API int hl_sync(hl_learner* h);                         /* wait for all queue
  * steps, from the thread that owns the learner. */
 HL_API int hl_forward(hl_learner* h, int32_t n, const float* states /*[n][dimS]*/, double* outputs /*[n][nOut]*/);
 
+/* ---- checkpoint in the reference's file format (second row) ----------------
+ * Approximator::save -> AdamOptimizer::save -> Network::save (Network/Approximator.cpp:282-297,
+ * Network/Optimizer.cpp:180-214, Network/Network.cpp:22-68): three raw fp32 files
+ * <base>_weights.raw, <base>_1stMom.raw, <base>_2ndMom.raw, layer by layer WITHOUT the SIMD padding
+ * of the in-memory blob (dense: W[in][out] then bias; parametric residual: w then b; ParamLayer:
+ * bias).  The binding passes base = "<agent>_net" ("agent_00_net").  hl_restart needs the weights
+ * file (HL_ERR_IO if it is missing or has the wrong size); missing moment files are ignored, as in
+ * AdamOptimizer::restart. */
+HL_API int hl_save(hl_learner* h, const char* base);
+HL_API int hl_restart(hl_learner* h, const char* base);
+
 /* ---- inspection ---------------------------------------------------------------- */
 HL_API int hl_set_tap(hl_learner* h, int32_t enable);
 HL_API int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t dst_bytes);

@@ -912,6 +912,73 @@ int ol_step(ol_learner* h, int32_t n, const int64_t* flat) {
   }
   return HL_OK;
 }
+// Network::save / restart (Network/Network.cpp:22-68) over Layer::save of each type
+// (Layer_Base.h:143-166, Layers.h:401-420, 554-567): compact fp32, no SIMD padding
+static size_t packedSize(const ol_learner* h) {
+  size_t n = 0;
+  for (const Layer& l : h->layers) {
+    if (l.type == L_DENSE) n += (size_t)l.size * (l.nIn + 1);
+    else if (l.type == L_PARAMRES) n += 2 * (size_t)l.size;
+    else if (l.type == L_PARAM) n += (size_t)l.size;
+  }
+  return n;
+}
+static void packBlob(const ol_learner* h, const std::vector<nnReal>& P, std::vector<float>& out) {
+  out.clear();
+  for (const Layer& l : h->layers) {
+    const nnReal* W = P.data() + l.indW; const nnReal* Bv = P.data() + l.indB;
+    if (l.type == L_DENSE) {
+      for (int i = 0; i < l.nIn; ++i) for (int o = 0; o < l.size; ++o) out.push_back((float)W[o + (int64_t)l.nOutSimd * i]);
+      for (int o = 0; o < l.size; ++o) out.push_back((float)Bv[o]);
+    } else if (l.type == L_PARAMRES) {
+      for (int o = 0; o < l.size; ++o) out.push_back((float)W[o]);
+      for (int o = 0; o < l.size; ++o) out.push_back((float)Bv[o]);
+    } else if (l.type == L_PARAM) for (int o = 0; o < l.size; ++o) out.push_back((float)Bv[o]);
+  }
+}
+static void unpackBlob(const ol_learner* h, const std::vector<float>& in, std::vector<nnReal>& P) {
+  size_t k = 0;
+  for (const Layer& l : h->layers) {
+    nnReal* W = P.data() + l.indW; nnReal* Bv = P.data() + l.indB;
+    if (l.type == L_DENSE) {
+      for (int i = 0; i < l.nIn; ++i) for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = (nnReal)in[k++];
+      for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)in[k++];
+    } else if (l.type == L_PARAMRES) {
+      for (int o = 0; o < l.size; ++o) W[o] = (nnReal)in[k++];
+      for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)in[k++];
+    } else if (l.type == L_PARAM) for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)in[k++];
+  }
+}
+int ol_save(ol_learner* h, const char* base) {
+  if (!h || !base) return HL_ERR_BAD_ARG;
+  const std::vector<nnReal>* blobs[3] = {&h->W, &h->M1, &h->M2};
+  const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
+  std::vector<float> buf;
+  for (int b = 0; b < 3; ++b) {
+    packBlob(h, *blobs[b], buf);
+    const std::string name = std::string(base) + suf[b] + ".raw";
+    FILE* f = fopen(name.c_str(), "wb");
+    if (!f) return fail(h, HL_ERR_IO, "cannot write checkpoint file");
+    fwrite(buf.data(), sizeof(float), buf.size(), f); fclose(f);
+  }
+  return HL_OK;
+}
+int ol_restart(ol_learner* h, const char* base) {
+  if (!h || !base) return HL_ERR_BAD_ARG;
+  std::vector<nnReal>* blobs[3] = {&h->W, &h->M1, &h->M2};
+  const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
+  const size_t n = packedSize(h);
+  for (int b = 0; b < 3; ++b) {
+    const std::string name = std::string(base) + suf[b] + ".raw";
+    FILE* f = fopen(name.c_str(), "rb");
+    if (!f) { if (b == 0) return fail(h, HL_ERR_IO, "Parameters restart file not found"); continue; }
+    std::vector<float> buf(n + 1);
+    const size_t got = fread(buf.data(), sizeof(float), n + 1, f); fclose(f);
+    if (got != n) return fail(h, HL_ERR_IO, "Mismatch in restarted file");
+    buf.resize(n); unpackBlob(h, buf, *blobs[b]);
+  }
+  return HL_OK;
+}
 int ol_sync(ol_learner*) { return HL_OK; }
 // Approximator::forward(agent) (Network/Approximator.h:300-330) on standardised states
 // (Episode::standardizedState, Episode.h:172-183): the network outputs RACER::selectAction reads

@@ -46,6 +46,8 @@ HL_API int ol_counters_exchange(ol_learner* h, int64_t counters_io[4], int32_t w
 HL_API int ol_moments_exchange(ol_learner* h, double* io, int32_t write_back);
 HL_API int ol_step_end(ol_learner* h);
 HL_API int ol_sync(ol_learner* h);
+HL_API int ol_save(ol_learner* h, const char* base);
+HL_API int ol_restart(ol_learner* h, const char* base);
 HL_API int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs);
 HL_API int ol_set_tap(ol_learner* h, int32_t enable);
 HL_API int ol_readback(ol_learner* h, int32_t what, void* dst, int64_t dst_bytes);

@@ -332,6 +332,19 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   W.f64("traj_beta", traj_beta); W.f64("traj_cmax", traj_cmax);
   W.i64("traj_nfar", traj_nfar); W.f64("traj_wnorm", traj_wnorm);
   W.f32("Wfinal", paramsOf(PW));
+  W.f32("M1final", paramsOf(OPT->_1stMom.get())); W.f32("M2final", paramsOf(OPT->_2ndMom.get()));
+  {   // the reference's own checkpoint of this state (Approximator::save -> AdamOptimizer::save -> Network::save)
+    const std::string ck = A.s("ckpt", "");
+    if (!ck.empty()) {
+      NET.save(ck, false);
+      for (const char* suf : {"_net_weights", "_net_1stMom", "_net_2ndMom"}) {
+        FILE* f = fopen((ck + suf + ".raw").c_str(), "rb");
+        std::vector<uint8_t> bytes;
+        if (f) { int c; while ((c = fgetc(f)) != EOF) bytes.push_back((uint8_t)c); fclose(f); }
+        W.u8(std::string("ckpt") + suf, bytes);
+      }
+    }
+  }
   {
     const ReplayStats& st = L.data->stats;
     std::vector<double> s = {(double)st.avgKLdivergence, (double)st.avgSquaredErr, (double)st.maxAbsError,

@@ -160,6 +160,8 @@ class CApi:
             "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
             "forward": (C.c_int, [P, I32, pf, pd]),
+            "save": (C.c_int, [P, C.c_char_p]),
+            "restart": (C.c_int, [P, C.c_char_p]),
             "status_string": (C.c_char_p, [C.c_int]),
             "version": (C.c_int, []),
         }.items():
@@ -323,6 +325,13 @@ class Learner:
     def moments_store(self, m):
         m = _f64(m)
         self._ck(self.api.fn("moments_exchange")(self.h, _ptr(m, C.c_double), 1))
+
+    def save(self, base):
+        """Checkpoint in the reference's format: <base>_weights.raw, _1stMom.raw, _2ndMom.raw."""
+        self._ck(self.api.fn("save")(self.h, str(base).encode()))
+
+    def restart(self, base):
+        self._ck(self.api.fn("restart")(self.h, str(base).encode()))
 
     def forward(self, states):
         """Network outputs [n][nOut] (float64) for raw states [n][dimS] with the current weights."""

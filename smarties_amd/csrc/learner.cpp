@@ -79,6 +79,8 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
   GraphSlot graphs[5]; bool graphsStale = false, useGraph = true;
+  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer
+  std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
   hipStream_t sSample = nullptr, sPost = nullptr;
@@ -189,6 +191,13 @@ int buildNet(hl_learner* h) {
   }
   h->indWo = h->indW[outLayer]; h->indBo = h->indB[outLayer]; h->ldWo = (int)roundUp(h->nDense, 8);
   h->indBp = h->indB[paramLayer];
+  h->lay.clear();
+  for (int j = 0; j < nH; ++j) {
+    h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    if (hs[j].hasRes) h->lay.push_back({2, 0, hs[j].size, 0, h->indW[hs[j].resLayer], h->indB[hs[j].resLayer]});
+  }
+  h->lay.push_back({1, prev, h->nDense, h->ldWo, h->indWo, h->indBo});
+  h->lay.push_back({3, 0, c.dimA, 0, 0, h->indBp});
   return HL_OK;
 }
 
@@ -817,6 +826,72 @@ int hl_step_end(hl_learner* h) {
   h->nGradSteps += 1; h->inStep = false;
   return HL_OK;
 }
+// ---- checkpoint in the reference's format (Network::save / restart, Network/Network.cpp:22-68) ----
+static void packBlob(const hl_learner* h, const std::vector<float>& P, std::vector<float>& out) {
+  out.clear();
+  for (const auto& l : h->lay) {
+    const float* W = P.data() + l.indW; const float* Bv = P.data() + l.indB;
+    if (l.type == 1) {
+      for (int i = 0; i < l.nIn; ++i) for (int o = 0; o < l.size; ++o) out.push_back(W[o + (long long)l.ld * i]);
+      for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
+    } else if (l.type == 2) {
+      for (int o = 0; o < l.size; ++o) out.push_back(W[o]);
+      for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
+    } else for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
+  }
+}
+static void unpackBlob(const hl_learner* h, const std::vector<float>& in, std::vector<float>& P) {
+  size_t k = 0;
+  for (const auto& l : h->lay) {
+    float* W = P.data() + l.indW; float* Bv = P.data() + l.indB;
+    if (l.type == 1) {
+      for (int i = 0; i < l.nIn; ++i) for (int o = 0; o < l.size; ++o) W[o + (long long)l.ld * i] = in[k++];
+      for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
+    } else if (l.type == 2) {
+      for (int o = 0; o < l.size; ++o) W[o] = in[k++];
+      for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
+    } else for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
+  }
+}
+int hl_save(hl_learner* h, const char* base) {
+  if (!h || !base) return HL_ERR_BAD_ARG;
+  std::vector<float> P[3]; for (auto& v : P) v.resize((size_t)h->nParams);
+  int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
+  const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
+  std::vector<float> buf;
+  for (int b = 0; b < 3; ++b) {
+    packBlob(h, P[b], buf);
+    // like Network::save: write <name>_backup.raw first, then copy it over <name>.raw
+    const std::string name = std::string(base) + suf[b] + ".raw", back = std::string(base) + suf[b] + "_backup.raw";
+    for (const std::string& fn : {back, name}) {
+      FILE* f = fopen(fn.c_str(), "wb");
+      if (!f) return fail(h, HL_ERR_IO, "Unable to save into file " + fn);
+      const size_t w = fwrite(buf.data(), sizeof(float), buf.size(), f);
+      fclose(f);
+      if (w != buf.size()) return fail(h, HL_ERR_IO, "short write to " + fn);
+    }
+  }
+  return HL_OK;
+}
+int hl_restart(hl_learner* h, const char* base) {
+  if (!h || !base) return HL_ERR_BAD_ARG;
+  std::vector<float> P[3]; for (auto& v : P) v.resize((size_t)h->nParams);
+  int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
+  size_t n = 0;
+  for (const auto& l : h->lay) n += l.type == 1 ? (size_t)l.size * (l.nIn + 1) : (l.type == 2 ? 2 * (size_t)l.size : (size_t)l.size);
+  const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
+  for (int b = 0; b < 3; ++b) {
+    const std::string name = std::string(base) + suf[b] + ".raw";
+    FILE* f = fopen(name.c_str(), "rb");
+    if (!f) { if (b == 0) return fail(h, HL_ERR_IO, "Parameters restart file " + name + " not found."); continue; }
+    std::vector<float> buf(n + 1);
+    const size_t got = fread(buf.data(), sizeof(float), n + 1, f); fclose(f);
+    if (got != n) return fail(h, HL_ERR_IO, "Mismatch in restarted file " + name);
+    buf.resize(n); unpackBlob(h, buf, P[b]);
+  }
+  return hl_set_params(h, P[0].data(), P[1].data(), P[2].data());
+}
+
 // rollout inference: Approximator::forward(agent) for n states (RACER.cpp:30-59)
 int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;

@@ -13,14 +13,14 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
 
 # G-small: mixed bounded/unbounded actions, terminated + truncated episodes, every tap
 "$DRV" fixture "$HERE/small_mixed.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
-   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_small"
 # G-traj: 1200 steps across the 1000-step recompute / Retrace sweep / reward-stat update
 "$DRV" fixture "$HERE/traj_1200.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=999,1000,1200 \
    maxObs=2000 minObs=500 epsAnneal=5e-7
 # G-deep: three hidden layers of unequal width (parametric residual with min() width), Tanh, unbounded
 "$DRV" fixture "$HERE/deep_tanh.bin" dimS=9 dimA=3 bounded=000 layers=24,16,8 nnFunc=Tanh batch=8 nEps=20 \
-   lenMin=3 lenMax=30 pTerm=0.3 nSteps=6 gradSteps=1,6 maxObs=1000 minObs=100 nnLambda=1e-4 learnrate=1e-3
+   lenMin=3 lenMax=30 pTerm=0.3 nSteps=6 gradSteps=1,6 maxObs=1000 minObs=100 nnLambda=1e-4 learnrate=1e-3 ckpt="$TMP/ck_deep"
 # G-ns: the north-star network/batch shape (17/6, 2x256 SoftSign, B=256) on a 300-episode replay
 "$DRV" fixture "$HERE/ns_shape.bin" dimS=17 dimA=6 layers=256,256 batch=256 nEps=300 \
    lenMin=150 lenMax=250 pTerm=0.2 nSteps=4 gradSteps=1 maxObs=100000 minObs=1000

@@ -327,6 +327,31 @@ def test_rccl_exchange_sequence_on_one_rank(hip_api):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin"])
+def test_checkpoint_files_match_reference(hip_api, name, tmp_path):
+    """hl_save == the reference's own checkpoint files (Network::save, Network.cpp:22-38) for the
+    same weights / moments; hl_restart of the reference's files restores the device blobs; a
+    truncated file is refused."""
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    L.set_params(fx["Wfinal"], fx["M1final"], fx["M2final"])
+    base = str(tmp_path / "agent_00_net")
+    L.save(base)
+    for suf in ("_weights", "_1stMom", "_2ndMom"):
+        assert open(base + suf + ".raw", "rb").read() == bytes(bytearray(fx["ckpt_net" + suf])), suf
+    L2 = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    L2.init_weights()
+    L2.restart(base)
+    w, m1, m2 = L2.get_params()
+    assert np.array_equal(w, fx["Wfinal"]) and np.array_equal(m1, fx["M1final"]) and np.array_equal(m2, fx["M2final"])
+    data = open(base + "_weights.raw", "rb").read()
+    open(base + "_weights.raw", "wb").write(data[:-8])
+    with pytest.raises(capi.HlError) as e:
+        L2.restart(base)
+    assert e.value.status == 7                      # HL_ERR_IO
+
+
+@pytest.mark.gpu
 def test_sampler_collisions_and_redraw_match_oracle(hip_api):
     """Replay barely larger than the batch: most draws collide, so Sample_uniform's
     sort / unique / redraw-the-tail loop (Sampling.cpp:75-93) runs several rounds per step.  Indices,

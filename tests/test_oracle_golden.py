@@ -131,3 +131,26 @@ def test_long_trajectory_crosses_1000_step_sweep():
     mine = [st.avgKLdivergence, st.avgSquaredErr, st.maxAbsError, st.avgReturn, st.avgQ, st.stdevQ, st.minQ, st.maxQ]
     assert np.allclose(mine, ref[:8], rtol=1e-4, atol=1e-6)
     assert st.nFarPolicySteps == int(ref[8])
+
+
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin"])
+def test_checkpoint_files_match_reference(name, tmp_path):
+    """ol_save writes byte-for-byte the files Approximator::save wrote for the same weights and
+    moments (Network.cpp:22-38); ol_restart of the reference's files restores the padded blobs."""
+    fx = load_fixture(name)
+    L = oracle_learner(fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    L.set_params(fx["Wfinal"], fx["M1final"], fx["M2final"])
+    base = str(tmp_path / "agent_00_net")
+    L.save(base)
+    for suf in ("_weights", "_1stMom", "_2ndMom"):
+        assert open(base + suf + ".raw", "rb").read() == bytes(bytearray(fx["ckpt_net" + suf])), suf
+    ref = str(tmp_path / "ref_net")
+    for suf in ("_weights", "_1stMom", "_2ndMom"):
+        open(ref + suf + ".raw", "wb").write(bytes(bytearray(fx["ckpt_net" + suf])))
+    L2 = oracle_learner(fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    L2.init_weights()
+    L2.restart(ref)
+    w, m1, m2 = L2.get_params()
+    assert np.array_equal(w, fx["Wfinal"]) and np.array_equal(m1, fx["M1final"]) and np.array_equal(m2, fx["M2final"])
+    with pytest.raises(Exception):
+        L2.restart(str(tmp_path / "missing"))
