@@ -225,11 +225,6 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     if (f < H * 4) { const int k = f >> 2, c = n0 + (f & 3) * 4; w1c[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)k * a.ldW1 + c); }
   }
 #pragma unroll
-  for (int q = 0; q < QP; ++q) {
-    const int f = tid + NT * q; w1r[q] = z4;
-    if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w1r[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(n0 + r) * a.ldW1 + 4 * c4); }
-  }
-#pragma unroll
   for (int q = 0; q < QO; ++q) { const int f = tid + NT * q; wov[q] = f < H * 2 ? *reinterpret_cast<const f32x4*>(Wo + (size_t)f * 4) : z4; }
   const float b0v = tid < H ? W[a.indB0 + tid] : 0.f;
   const float wrv = tid < H ? W[a.indWr + tid] : 0.f, brv = tid < H ? W[a.indBr + tid] : 0.f;
@@ -274,6 +269,12 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   __syncthreads();
   FSTAMP(1);
   if (a.variant == 1) return;
+  // the W1 row tile is needed only by the dX contraction: fetched now, behind the critical first batch
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int f = tid + NT * q; w1r[q] = z4;
+    if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w1r[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(n0 + r) * a.ldW1 + 4 * c4); }
+  }
 
   // ---- h1 = f(S W0 + b0), whole panel: wave w computes column tiles w, w+4, ... --------------------
   if (wave < HT) {
