@@ -535,46 +535,31 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (a.variant == 7) return;
   if (eth && writer && row < B && en < nDense) a.dOut[(size_t)row * a.ldDo + en] = sDo[em * 8 + en];
 
-  // ---- delta_y3 = delta_out Wout^T (MFMA, K = 8), delta_x2 = delta_y3 f'(x2): whole panel ----------------------
-  {
-    const float a0 = sDo[li * 8 + lc], a1 = sDo[li * 8 + 4 + lc];
-    float b0[TPW], b1[TPW], f2v[TPW][4];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int nt = wave < HT ? wave + NW * t : 0;
-      b0[t] = sWo[(nt * 16 + li) * 8 + lc]; b1[t] = sWo[(nt * 16 + li) * 8 + 4 + lc];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) f2v[t][r] = sF2[(lc * 4 + r) * FLDR + nt * 16 + li];
-    }
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int nt = wave + NW * t;
-      if (wave < HT) {
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], z4, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc, 0, 0, 0);
-        const int c = nt * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = lc * 4 + r;
-          const float s = acc[r];
-          const float dx2 = s * f2v[t][r];
-          sF2[i * FLDR + c] = dx2;
-          if (nt == n) {
-            sT[i * 16 + li] = s;
-            if (m0 + i < B) { gDres2[(size_t)(m0 + i) * ldA1 + c] = s; gD2[(size_t)(m0 + i) * ldA1 + c] = dx2; }
-          }
-        }
-      }
-    }
+  // ---- delta_y3 = delta_out Wout^T and delta_x2 = delta_y3 f'(x2) are formed directly as the A operand
+  // of the dX contraction (8 fused multiply-adds per element; no panel-wide pass, no extra barrier);
+  // the element threads compute the same expression for their own element, which goes to global memory ----
+  auto deltaY3 = [&](int rowL, int c) {      // sum_o delta_out[rowL][o] * Wout[c][o], fixed association
+    const f32x4 wa = *reinterpret_cast<const f32x4*>(sWo + c * 8), wb = *reinterpret_cast<const f32x4*>(sWo + c * 8 + 4);
+    const f32x4 da = *reinterpret_cast<const f32x4*>(sDo + rowL * 8), db = *reinterpret_cast<const f32x4*>(sDo + rowL * 8 + 4);
+    float s = wa[0] * da[0];
+    s = fmaf(wa[1], da[1], s); s = fmaf(wa[2], da[2], s); s = fmaf(wa[3], da[3], s);
+    s = fmaf(wb[0], db[0], s); s = fmaf(wb[1], db[1], s); s = fmaf(wb[2], db[2], s); s = fmaf(wb[3], db[3], s);
+    return s;
+  };
+  float dy3own = 0.f;
+  if (eth && rowValid) {
+    const int c = n0 + en;
+    dy3own = deltaY3(em, c);
+    if (row < B) { gDres2[(size_t)row * ldA1 + c] = dy3own; gD2[(size_t)row * ldA1 + c] = dy3own * sF2[em * FLDR + c]; }
   }
-  __syncthreads();
   FSTAMP(11);
   if (a.variant == 8) return;
 
   // ---- own tile of delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1) ----------------------
   if (wave < KWAVES) {
     const int k0 = wave * KW + lc;
-    const f32x4 acc = waveMma<NK>([&](int s) { return sF2[li * FLDR + k0 + 4 * s]; }, [&](int s) { return sBx[li * FLDR + k0 + 4 * s]; });
+    const f32x4 acc = waveMma<NK>([&](int s) { const int c = k0 + 4 * s; return deltaY3(li, c) * sF2[li * FLDR + c]; },
+                                  [&](int s) { return sBx[li * FLDR + k0 + 4 * s]; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
   }
@@ -584,7 +569,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (eth && row < B) {
     const float v = redSum<KWAVES>(red, tid);
     float dres = v;
-    if (n0 + en < resN) dres += sT[em * 16 + en] * sWr[n0 + en];
+    if (n0 + en < resN) dres += dy3own * sWr[n0 + en];
     a.Dres1[(size_t)row * ldA0 + n0 + en] = dres;
     float f1 = 1.f;
     dispatchFunc<CF>(func, [&](auto F) { f1 = actDiffT<decltype(F)::value>(x1o, y1o); });
