@@ -394,8 +394,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   // ---- read the panel's y3 and f'(x2) back -----------------------------------------------------------------
   if (a.variant == 4) return;
   float* sY3 = sR2; float* sF2 = sR3; float* sBx = sY1;
+  f32x4 yv[QP], fv[QP];
   {
-    f32x4 yv[QP], fv[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
       const int f = tid + NT * q; yv[q] = z4; fv[q] = z4;
@@ -407,18 +407,14 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
         }
       }
     }
-    // h1 is dead (own tile kept in registers): R1 takes the W1 row tile of the dX contraction
+    // only y3 is needed by the next contraction: f'(x2) and the W1 row tile are staged after it
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
       const int f = tid + NT * q;
       if (f < 16 * H4) {
         const int r = f / H4, c = 4 * (f % H4);
-        float2* d = reinterpret_cast<float2*>(sBx + r * FLDR + c);
-        d[0] = make_float2(w1r[q][0], w1r[q][1]); d[1] = make_float2(w1r[q][2], w1r[q][3]);
         float2* dy = reinterpret_cast<float2*>(sY3 + r * FLDR + c);
         dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
-        float2* df = reinterpret_cast<float2*>(sF2 + r * FLDR + c);
-        df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
       }
     }
   }
@@ -433,6 +429,18 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
                                   [&](int s) { return li < 8 ? sWo[(k0 + 4 * s) * 8 + li] : 0.f; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+  }
+  // h1 is dead (own tile kept in registers): R1 takes the W1 row tile of the dX contraction, R3 f'(x2)
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int f = tid + NT * q;
+    if (f < 16 * H4) {
+      const int r = f / H4, c = 4 * (f % H4);
+      float2* d = reinterpret_cast<float2*>(sBx + r * FLDR + c);
+      d[0] = make_float2(w1r[q][0], w1r[q][1]); d[1] = make_float2(w1r[q][2], w1r[q][3]);
+      float2* df = reinterpret_cast<float2*>(sF2 + r * FLDR + c);
+      df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
+    }
   }
   __syncthreads();
   FSTAMP(9);
