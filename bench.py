@@ -110,8 +110,8 @@ def cpu_baseline(steps_budget_s=20.0):
         if best is not None:
             return {"value": best["transitions_per_s"], "unit": "transitions/s", "cores": int(best["threads"]),
                     "kind": "reference",
-                    "sample": "compiled reference (oracle/_ref, -O3 -ffast-math, OpenMP), same 1M-transition "
-                              "synthetic replay, 400 gradient steps after 20 warm-up; best of threads=%s on %d host CPUs"
+                    "sample": "compiled reference (oracle/_ref, -O3 -ffast-math, OpenMP) on a 1M-transition synthetic replay of "
+                              "the same shape and distributions, 400 gradient steps after 20 warm-up; best of threads=%s on %d host CPUs"
                               % ([t for t, _ in tried], ncpu),
                     "tried": tried}
     # fallback: single-threaded CPU oracle (port)
