@@ -1,22 +1,25 @@
 // smarties_amd/csrc/step_exec.h -- launch sequences of the gradient step (included by learner.cpp).
 //
-// One step = sample -> forward GEMMs -> head -> dX GEMMs -> dW GEMMs (+Adam) -> bookkeeping.
-// The sampler and the bookkeeping pass are single-workgroup dependency chains (~15 us and ~5 us)
-// that do not touch what the MLP kernels touch.  In the replayed graph they are horizontally
-// fused into the MLP launches as one extra workgroup each (tail_dev.h):
+// One step = sample -> forward -> head -> dX -> dW (+Adam) -> bookkeeping.  The sampler and the
+// bookkeeping pass are single-workgroup dependency chains (~10 us and ~3.5 us) that do not touch
+// what the MLP kernels touch; in the replayed graph they ride along the MLP kernels as extra
+// workgroups (tail_dev.h).
 //
-//   fwd0(k)   + sampler phase A of step k+1        (draw + Lemire acceptance)
-//   fwd1(k)   + sampler phase B of step k+1        (sort / unique / redraw, Adam draws)
-//   head(k)   + sampler phase C of step k+1        (index -> episode/step, gather)
-//   dX(k)     + bookkeeping of step k              (aggregates, beta / C, Adam scalars)
-//   dW(k)     (Adam fused into the epilogue)
+// Networks with two equal hidden blocks (fusedOk) take two launches per step:
+//   K1 fused_fwd_head_dx(k)  + block 0: sampler of step k+1 (draw, sort/unique, search),
+//                              blocks 1..7: its gather                           (fused.hip)
+//   K2 dw_table(k) + Adam    + block 0: bookkeeping of step k (aggregates, beta/C, Adam scalars)
+// every other layout the generic five:
+//   fwd0(k) + sampler phase A | fwd_last(k) + phase B | head(k) + phase C | dX(k) + bookkeeping | dW(k)
+// With a communicator attached (replicas) K2 leaves Adam out and is followed by
+//   allreduce(G), allreduce(counters), adam, bookkeeping(beta)   -- RCCL calls captured like kernels.
 //
 // Step k reads minibatch buffer k&1 while step k+1's is being written, so the minibatch
 // workspace (indices, standardized states, row counts, Adam step size) is double buffered;
 // everything else is single buffered.  (A multi-stream graph with the same overlap was measured
 // 1.5x SLOWER than the serial graph on this runtime: each cross-queue edge costs several us.)
-// Eager launches (parity tests, 1000-step sweeps, eviction, multi-replica) run the same kernels
-// back to back on the main stream with stand-alone tail launches.
+// Eager launches (parity tests, 1000-step sweeps, eviction) run the same kernels back to back on
+// the main stream with stand-alone tail launches.
 #pragma once
 
 namespace {
