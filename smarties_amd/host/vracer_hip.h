@@ -1,0 +1,212 @@
+// smarties_amd/host/vracer_hip.h -- C++ host side above the C-ABI (include/smarties_hip.h).
+//
+// A header-only mirror of the part of the reference's Learner interface that drives the hot path,
+// with the reference's names, argument meaning and error behaviour, so that a maintainer can lift
+// it into `Learners/RACER_HIP.{h,cpp}` and so that the C++ parity test
+// (tests/cpp/host_parity.cpp) reads like a smarties test:
+//
+//   Learner::select                 Learners/Learner.cpp:30-45
+//   RACER::selectAction             Learners/RACER.cpp:30-47
+//   RACER::processTerminal          Learners/RACER.cpp:49-59
+//   Learner::initializeLearner      Learners/Learner.cpp:47-72
+//   RACER::setupTasks (train step)  Learners/RACER.cpp:62-110
+//   Approximator::save / restart    Network/Approximator.cpp:282-297
+//   Continuous_policy::selectAction Math/Continuous_policy.h:777-789 (per-dimension Normal /
+//   SquashedNormal sample with sampleClippedGaussian, :183-197, 347-363)
+//
+// The reference `die()`s on errors (Utils/Warnings.h:34-44: message + abort); here `die` throws
+// std::runtime_error with the library's message so that a test can observe it.
+//
+// Not reproduced here: the smarties::Communicator / Worker machinery that produces `Agent`s, and
+// action rescaling to the environment's bounds (ActionInfo::action2scaledAction) -- both stay the
+// reference's; `Agent` below carries only what Learner::select reads and writes.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/smarties_hip.h"
+
+namespace smarties_amd {
+
+using Real = double;
+using Fval = float;
+using Uint = std::size_t;
+using Rvec = std::vector<Real>;
+using Fvec = std::vector<Fval>;
+
+enum episodeStatus { INIT = 0, CONT, LAST, TERM, FAIL };   // Core/Agent.h:23
+
+// Core/StateAction.h:57-112 (the fields the learner reads)
+struct MDPdescriptor {
+  Uint dimStateObserved = 0, dimAction = 0;
+  std::vector<bool> bActionSpaceBounded;
+};
+
+// Settings/HyperParameters.h:42-72 (same names, same defaults where they do not depend on the MDP)
+struct HyperParameters {
+  Real explNoise = std::sqrt(0.2), gamma = 0.995, lambda = 1, clipImpWeight = 4, penalTol = 0.1;
+  Real epsAnneal = 5e-7, nnLambda = 0, learnrate = 1e-4, outWeightsPrefac = 1e-3;
+  Uint minTotObsNum = 0, maxTotObsNum = 1 << 20, batchSize = 256;
+  std::vector<Uint> nnLayerSizes = {128, 128};
+  std::string nnFunc = "Tanh";
+  Uint randSeed = 0;
+};
+
+// Core/Agent.h (subset): what Learner::select reads (state, reward, status) and writes (action, policy)
+struct Agent {
+  Uint ID = 0;
+  episodeStatus agentStatus = INIT;
+  Fvec state;                 // observed state, raw
+  Real reward = 0;
+  Rvec action, policyVector;  // policy-space action a_t and behaviour policy mu_t = [mean, stdev]
+  std::mt19937 generator;
+  explicit Agent(Uint id = 0, Uint seed = 0) : ID(id), generator((unsigned)(seed + 1000 * id)) {}
+};
+
+[[noreturn]] inline void die(const std::string& msg) { throw std::runtime_error(msg); }
+
+class VRACER {
+  hl_learner* H = nullptr;
+  MDPdescriptor MDP;
+  HyperParameters S;
+  bool bTrain = true, bInit = false;
+  int nOut = 0, nDense = 0;
+  // one in-progress episode per agent: MemoryBuffer::inProgress (ReplayMemory/MemoryBuffer.h)
+  struct InProgress { Fvec states; Rvec actions, policies, rewards; Fvec values; int64_t tag = 0; };
+  std::vector<InProgress> inProgress;
+  int64_t nSeenEpisodes = 0;
+
+  void ck(int rc) const { if (rc) die(std::string(hl_status_string(rc)) + ": " + hl_last_error(H)); }
+  static int funcId(const std::string& f) {
+    if (f == "Tanh") return HL_FUNC_TANH;
+    if (f == "SoftSign") return HL_FUNC_SOFTSIGN;
+    if (f == "Relu") return HL_FUNC_RELU;
+    if (f == "Linear") return HL_FUNC_LINEAR;
+    die("nnFunc " + f + " is not supported by the HIP learner");
+  }
+  InProgress& episodeOf(const Agent& a) { if (a.ID >= inProgress.size()) inProgress.resize(a.ID + 1); return inProgress[a.ID]; }
+
+ public:
+  // Learners/RACER_common.cpp:23-27
+  static Real scaleNet2V(const Real x) {
+    return x > 0 ? 100 * (x + 51) - 100 * std::sqrt(2601 + 100 * x) : 100 * (x - 51) + 100 * std::sqrt(2601 - 100 * x);
+  }
+  // Math/Continuous_policy.h:183-190
+  static Real sampleClippedGaussian(std::mt19937& gen) {
+    constexpr Real NORMDIST_MAX = 3;   // Settings/Bund.h:51
+    std::normal_distribution<Real> dist(0, 1);
+    std::uniform_real_distribution<Real> safety(-NORMDIST_MAX, NORMDIST_MAX);
+    const Real noise = dist(gen);
+    if (noise > NORMDIST_MAX || noise < -NORMDIST_MAX) return safety(gen);
+    return noise;
+  }
+
+  VRACER(const MDPdescriptor& M, const HyperParameters& hp, int deviceID = 0, int nLearners = 1, int learnerRank = 0)
+      : MDP(M), S(hp) {
+    if (M.dimAction > HL_MAX_DIMA || hp.nnLayerSizes.size() > HL_MAX_HIDDEN) die("problem too large for hl_config");
+    hl_config c{}; c.struct_size = sizeof(c);
+    c.dimS = (int32_t)M.dimStateObserved; c.dimA = (int32_t)M.dimAction;
+    for (Uint i = 0; i < M.dimAction; ++i) c.bounded[i] = i < M.bActionSpaceBounded.size() && M.bActionSpaceBounded[i];
+    c.n_hidden = (int32_t)hp.nnLayerSizes.size();
+    for (Uint i = 0; i < hp.nnLayerSizes.size(); ++i) c.hidden[i] = (int32_t)hp.nnLayerSizes[i];
+    c.nnFunc = funcId(hp.nnFunc); c.adv_kind = HL_ADV_ZERO;
+    c.batchSize = (int32_t)hp.batchSize; c.maxTotObsNum = (int64_t)hp.maxTotObsNum; c.minTotObsNum = (int64_t)hp.minTotObsNum;
+    c.gamma = hp.gamma; c.lambda = hp.lambda; c.clipImpWeight = hp.clipImpWeight; c.penalTol = hp.penalTol;
+    c.epsAnneal = hp.epsAnneal; c.learnrate = hp.learnrate; c.nnLambda = hp.nnLambda; c.explNoise = hp.explNoise;
+    c.outWeightsPrefac = hp.outWeightsPrefac; c.randSeed = hp.randSeed;
+    c.n_ranks = nLearners; c.rank = learnerRank; c.device_id = deviceID; c.ref_threads = 1;
+    const int rc = hl_create(&c, &H);
+    if (rc) die(std::string("hl_create: ") + hl_status_string(rc) + ": " + hl_last_error(nullptr));
+    ck(hl_init_weights(H));
+    nOut = hl_num_outputs(H); nDense = 1 + (int)M.dimAction;
+  }
+  ~VRACER() { if (H) hl_destroy(H); }
+  VRACER(const VRACER&) = delete;
+  VRACER& operator=(const VRACER&) = delete;
+
+  hl_learner* handle() const { return H; }
+  void setTrain(bool b) { bTrain = b; }
+
+  // Approximator::forward(agent): network outputs for the agent's current state
+  Rvec forward(const Agent& agent) const {
+    if (agent.state.size() != MDP.dimStateObserved) die("Agent state has the wrong size");
+    Rvec out((Uint)nOut);
+    const int rc = hl_forward(H, 1, agent.state.data(), out.data());
+    if (rc) die(std::string(hl_status_string(rc)) + ": " + hl_last_error(H));
+    return out;
+  }
+
+  // Learner::select (Learner.cpp:30-45): storeState; then act, or close the episode
+  void select(Agent& agent) {
+    InProgress& EP = episodeOf(agent);
+    const Uint dS = MDP.dimStateObserved, dA = MDP.dimAction;
+    if (agent.agentStatus == INIT) { EP = InProgress(); EP.tag = nSeenEpisodes++; }
+    // MemoryBuffer::storeState (MemoryBuffer.cpp:79-129): the reward of the first state is 0
+    EP.states.insert(EP.states.end(), agent.state.begin(), agent.state.end());
+    EP.rewards.push_back(agent.agentStatus == INIT ? 0.0 : agent.reward);
+    if (agent.agentStatus < LAST) {
+      // RACER::selectAction (RACER.cpp:30-47)
+      const Rvec output = forward(agent);
+      Rvec mean(dA), stdev(dA), act(dA);
+      for (Uint i = 0; i < dA; ++i) {
+        const Real p = output[(Uint)nDense + i];
+        mean[i] = output[1 + i]; stdev[i] = (p + std::sqrt(1 + p * p)) / 2;         // SoftPlus (Functions.h:541-584)
+        if (!bTrain) { act[i] = mean[i]; continue; }                                 // Continuous_policy.h:779
+        const Real a = mean[i] + stdev[i] * sampleClippedGaussian(agent.generator);
+        constexpr Real MAX = 8.31776613503286;                                       // SquashedNormalPolicy::sample (:356-360)
+        act[i] = c_bounded(i) ? (a > MAX ? MAX : (a < -MAX ? -MAX : a)) : a;
+      }
+      const Real V = scaleNet2V(output[0]);
+      EP.values.push_back((Fval)V);                                                  // MB.appendValues(V, V + 0): Zero_advantage
+      agent.action = act;
+      agent.policyVector = mean; agent.policyVector.insert(agent.policyVector.end(), stdev.begin(), stdev.end());
+      // MemoryBuffer::storeAction (MemoryBuffer.cpp:131-170 region): a_t and mu_t next to s_t
+      EP.actions.insert(EP.actions.end(), act.begin(), act.end());
+      EP.policies.insert(EP.policies.end(), agent.policyVector.begin(), agent.policyVector.end());
+    } else {
+      // RACER::processTerminal (RACER.cpp:49-59): value of a truncated last state from the network, 0 if terminal
+      EP.values.push_back(agent.agentStatus == LAST ? (Fval)scaleNet2V(forward(agent)[0]) : (Fval)0);
+      EP.actions.insert(EP.actions.end(), dA, 0.0);                                  // dummy last action / policy
+      EP.policies.insert(EP.policies.end(), 2 * dA, 0.0);
+      // MemoryBuffer::terminateCurrentEpisode -> pushBackEpisode
+      pushBackEpisode((int)(EP.states.size() / dS), EP.states, EP.actions, EP.policies, EP.rewards, EP.values,
+                      agent.agentStatus == TERM, EP.tag);
+      EP = InProgress();
+    }
+  }
+  bool c_bounded(Uint i) const { return i < MDP.bActionSpaceBounded.size() && MDP.bActionSpaceBounded[i]; }
+
+  // MemoryBuffer::pushBackEpisode: a finished episode enters the training set
+  void pushBackEpisode(int nStates, const Fvec& states, const Rvec& actions, const Rvec& policies, const Rvec& rewards,
+                       const Fvec& values, bool bReachedTermState, int64_t ID) {
+    ck(hl_append_episode(H, nStates, states.data(), actions.data(), policies.data(), rewards.data(), values.data(), nullptr,
+                         bReachedTermState ? 1 : 0, ID));
+  }
+
+  // Learner::initializeLearner (Learner.cpp:47-72)
+  void initializeLearner() { ck(hl_initialize(H)); bInit = true; }
+
+  // RACER::setupTasks stepMain + stepComplete, n gradient steps (RACER.cpp:81-108)
+  void trainStep(int n = 1) { if (!bInit) die("trainStep before initializeLearner"); ck(hl_step(H, n, nullptr)); }
+
+  long nGradSteps() const { hl_scalars s; ck(hl_get_scalars(H, &s)); return (long)s.nGradSteps; }
+  Real beta() const { hl_scalars s; ck(hl_get_scalars(H, &s)); return s.beta; }
+  long nStoredSteps() const { hl_scalars s; ck(hl_get_scalars(H, &s)); return (long)s.nStoredSteps; }
+
+  // Learner::getMetrics (the ReplayStats / ReF-ER columns of agent_00_stats.txt)
+  void getMetrics(std::ostringstream& buf) const {
+    hl_stats st; hl_scalars s; ck(hl_get_stats(H, &st)); ck(hl_get_scalars(H, &s));
+    buf << " " << st.avgKLdivergence << " " << st.avgSquaredErr << " " << st.maxAbsError << " " << st.avgQ << " " << st.stdevQ
+        << " " << st.minQ << " " << st.maxQ << " " << st.nFarPolicySteps << " " << s.beta << " " << s.CmaxRet;
+  }
+
+  // Approximator::save / restart: "<base>_net_weights.raw", "_1stMom.raw", "_2ndMom.raw"
+  void save(const std::string& base) const { ck(hl_save(H, (base + "_net").c_str())); }
+  void restart(const std::string& base) { ck(hl_restart(H, (base + "_net").c_str())); }
+};
+
+}  // namespace smarties_amd

@@ -1,0 +1,125 @@
+// tests/cpp/host_parity.cpp -- C++ parity test of the host side (smarties_amd/host/vracer_hip.h) against
+// the CPU oracle (oracle/port, ol_* C API).  Reads like a smarties learner test: build the MDP and the
+// settings, create the learner, push episodes, initializeLearner, train, compare.
+// Built by __graft_entry__.build(); run on an MI355X by tests/test_host_cpp.py (-m gpu).
+#include <cassert>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include "../../smarties_amd/host/vracer_hip.h"
+#include "../../oracle/port/vracer_port.h"   // test infrastructure: the checker
+#include "../../oracle/synth.h"
+
+using namespace smarties_amd;
+
+static int failures = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+static double relinf(const std::vector<float>& a, const std::vector<float>& b) {
+  double num = 0, den = 1e-30;
+  for (size_t i = 0; i < a.size(); ++i) { num = std::max(num, (double)std::fabs(a[i] - b[i])); den = std::max(den, (double)std::fabs(b[i])); }
+  return num / den;
+}
+
+int main() {
+  // ---- problem: the north-star shape on a small replay -------------------------------------------------
+  MDPdescriptor MDP; MDP.dimStateObserved = 17; MDP.dimAction = 6; MDP.bActionSpaceBounded.assign(6, true);
+  HyperParameters HP; HP.nnLayerSizes = {256, 256}; HP.nnFunc = "SoftSign"; HP.batchSize = 64; HP.maxTotObsNum = 20000;
+  HP.clipImpWeight = 4; HP.epsAnneal = 0; HP.explNoise = 0.4472135955; HP.outWeightsPrefac = 0.1; HP.randSeed = 42;
+  VRACER L(MDP, HP, /*deviceID*/0);
+
+  hl_config c{}; c.struct_size = sizeof(c); c.dimS = 17; c.dimA = 6; for (int i = 0; i < 6; ++i) c.bounded[i] = 1;
+  c.n_hidden = 2; c.hidden[0] = c.hidden[1] = 256; c.nnFunc = HL_FUNC_SOFTSIGN; c.adv_kind = HL_ADV_ZERO;
+  c.batchSize = 64; c.maxTotObsNum = 20000; c.gamma = HP.gamma; c.lambda = HP.lambda; c.clipImpWeight = 4; c.penalTol = HP.penalTol;
+  c.epsAnneal = 0; c.learnrate = HP.learnrate; c.nnLambda = HP.nnLambda; c.explNoise = HP.explNoise; c.outWeightsPrefac = 0.1;
+  c.randSeed = 42; c.n_ranks = 1; c.ref_threads = 1;
+  ol_learner* O = nullptr;
+  CHECK(ol_create(&c, &O) == 0, "ol_create");
+  CHECK(ol_init_weights(O) == 0, "ol_init_weights");
+  const int64_t nP = hl_num_params(L.handle());
+  std::vector<float> wG(nP), wO(nP), m1(nP), m2(nP);
+  hl_get_params(L.handle(), wG.data(), m1.data(), m2.data()); ol_get_params(O, wO.data(), m1.data(), m2.data());
+  CHECK(wG == wO, "initial weights differ (Layer::initialize draw order)");
+
+  // ---- replay: the same synthetic episodes into both ----------------------------------------------------
+  synth_cfg sc{7, 17, 6, 30, 90, 0.3, 0.5, 1.0};
+  for (uint64_t e = 0; e < 80; ++e) {
+    int term = 0; const int N = synth_episode_len(&sc, e, &term);
+    Fvec S((size_t)N * 17), V(N); Rvec A((size_t)N * 6), MU((size_t)N * 12), R(N);
+    synth_episode(&sc, e, S.data(), A.data(), MU.data(), R.data(), V.data());
+    L.pushBackEpisode(N, S, A, MU, R, V, term != 0, (int64_t)e);
+    CHECK(ol_append_episode(O, N, S.data(), A.data(), MU.data(), R.data(), V.data(), nullptr, term, (int64_t)e) == 0, "ol_append_episode");
+  }
+  bool threw = false;
+  try { L.trainStep(1); } catch (const std::runtime_error&) { threw = true; }
+  CHECK(threw, "trainStep before initializeLearner must die");
+  L.initializeLearner(); CHECK(ol_initialize(O) == 0, "ol_initialize");
+
+  // ---- training: sampled indices bit-exact, weights / beta within the fp32 tolerance ---------------------
+  const int B = 64;
+  std::vector<int64_t> fG(B), fO(B);
+  for (int k = 1; k <= 30; ++k) {
+    L.trainStep(1); CHECK(ol_step(O, 1, nullptr) == 0, "ol_step");
+    hl_readback(L.handle(), HL_TAP_FLAT, fG.data(), B * 8); ol_readback(O, HL_TAP_FLAT, fO.data(), B * 8);
+    CHECK(fG == fO, "step %d: sampled indices differ", k);
+  }
+  L.trainStep(170); CHECK(ol_step(O, 170, nullptr) == 0, "ol_step(170)");   // replayed graphs on the device side
+  hl_get_params(L.handle(), wG.data(), m1.data(), m2.data()); ol_get_params(O, wO.data(), m1.data(), m2.data());
+  CHECK(relinf(wG, wO) < 1e-4, "weights after 200 steps: rel err %.3g", relinf(wG, wO));
+  hl_scalars sO; ol_get_scalars(O, &sO);
+  CHECK(std::fabs(L.beta() - sO.beta) <= 1e-9 * sO.beta, "beta %.17g vs %.17g", L.beta(), sO.beta);
+  CHECK(L.nGradSteps() == 200, "nGradSteps %ld", L.nGradSteps());
+  uint32_t rG[625], rO[625]; hl_get_rng_state(L.handle(), rG); ol_get_rng_state(O, rO);
+  CHECK(std::memcmp(rG, rO, sizeof(rG)) == 0, "generator state differs after 200 steps");
+
+  // ---- acting: Learner::select on a live agent -----------------------------------------------------------
+  {
+    Agent agent(0, 123);
+    const long before = L.nStoredSteps();
+    const int T = 12;
+    for (int t = 0; t <= T; ++t) {
+      agent.agentStatus = t == 0 ? INIT : (t == T ? LAST : CONT);
+      agent.state.resize(17); for (int i = 0; i < 17; ++i) agent.state[i] = 0.1f * (float)std::sin(0.7 * t + i);
+      agent.reward = 0.5 + 0.01 * t;
+      std::mt19937 genCopy = agent.generator;
+      L.select(agent);
+      if (t < T) {
+        std::vector<double> out(13);
+        CHECK(ol_forward(O, 1, agent.state.data(), out.data()) == 0, "ol_forward");
+        for (int i = 0; i < 6; ++i) {
+          const double p = out[7 + i], sd = (p + std::sqrt(1 + p * p)) / 2;
+          CHECK(std::fabs(agent.policyVector[i] - out[1 + i]) <= 1e-5 * (1 + std::fabs(out[1 + i])), "policy mean %d at t=%d", i, t);
+          CHECK(std::fabs(agent.policyVector[6 + i] - sd) <= 1e-12 * sd, "policy stdev %d", i);
+          double a = agent.policyVector[i] + agent.policyVector[6 + i] * VRACER::sampleClippedGaussian(genCopy);
+          a = std::min(8.31776613503286, std::max(-8.31776613503286, a));
+          CHECK(agent.action[i] == a, "action %d at t=%d: generator draw order", i, t);
+        }
+      }
+    }
+    CHECK(L.nStoredSteps() == before + T, "episode of %d transitions entered the replay (%ld -> %ld)", T, before, L.nStoredSteps());
+    L.trainStep(3);                                   // the appended episode is sampled from now on
+    CHECK(L.nGradSteps() == 203, "nGradSteps after appended episode");
+  }
+
+  // ---- checkpoint round trip through the reference's file format --------------------------------------------
+  {
+    char tmpl[] = "/tmp/smarties_hip_XXXXXX"; const char* dir = mkdtemp(tmpl);
+    CHECK(dir != nullptr, "mkdtemp");
+    const std::string base = std::string(dir) + "/agent_00";
+    L.save(base);
+    VRACER L2(MDP, HP, 0);
+    L2.restart(base);
+    std::vector<float> w2(nP), a1(nP), a2(nP), b1(nP), b2(nP);
+    hl_get_params(L.handle(), wG.data(), a1.data(), a2.data()); hl_get_params(L2.handle(), w2.data(), b1.data(), b2.data());
+    CHECK(wG == w2 && a1 == b1 && a2 == b2, "checkpoint round trip");
+    bool missing = false;
+    try { L2.restart(std::string(dir) + "/nothing_here"); } catch (const std::runtime_error&) { missing = true; }
+    CHECK(missing, "restart from a missing file must die");
+    std::ostringstream m; L.getMetrics(m); CHECK(!m.str().empty(), "getMetrics");
+  }
+  ol_destroy(O);
+  std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: OK\n", failures);
+  return failures ? 1 : 0;
+}
