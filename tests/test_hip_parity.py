@@ -136,6 +136,10 @@ def _compare_step(G, O):
     (dict(dimS=32, dimA=7, bounded=[1, 0, 1, 0, 1, 0, 1], hidden=(64, 64), nnFunc="Tanh", batchSize=40, maxTotObsNum=3000,
           randSeed=12),
      dict(seed=13, dimS=32, dimA=7, lenMin=3, lenMax=9, pTerm=0.0), 120, 15),
+    # batch 1024: 2000+ workgroups of the fused kernel, four times what the GPU holds at once -- the panel
+    # groups must complete wave after wave (no group may wait for workgroups that cannot become resident)
+    (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=100000, randSeed=2),
+     dict(seed=19, dimS=17, dimA=6, lenMin=100, lenMax=200, pTerm=0.1), 200, 4),
     # run-time activation dispatch (neither SoftSign nor Tanh), 8 tiles per panel
     (dict(dimS=20, dimA=4, bounded=[0, 1, 1, 0], hidden=(128, 128), nnFunc="Relu", batchSize=100, maxTotObsNum=20000,
           randSeed=21, nnLambda=1e-5),
@@ -166,6 +170,9 @@ def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, s
     (dict(dimS=32, dimA=7, bounded=[1, 0, 1, 0, 1, 0, 1], hidden=(64, 64), nnFunc="Tanh", batchSize=40, maxTotObsNum=3000,
           randSeed=12),
      dict(seed=13, dimS=32, dimA=7, lenMin=3, lenMax=9, pTerm=0.0), 120, 331),
+    # batch 512 on the fused path: more workgroups than the GPU holds at once, riders included
+    (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=512, maxTotObsNum=100000, randSeed=2),
+     dict(seed=19, dimS=17, dimA=6, lenMin=100, lenMax=200, pTerm=0.1), 120, 12),
     # layout not served by the fused kernel: generic five-launch graph
     (dict(dimS=9, dimA=3, bounded=[0, 0, 0], hidden=(24, 16, 8), nnFunc="Tanh", batchSize=8, maxTotObsNum=1000, randSeed=5),
      dict(seed=3, dimS=9, dimA=3, lenMin=3, lenMax=30, pTerm=0.3), 20, 70),
