@@ -392,12 +392,16 @@ int replaySteps(hl_learner* h, long long avail, int* done) {
   for (size_t i = 0; i < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]); ++i) {
     const int U = GRAPH_SIZES[i];
     if (avail < U) continue;
+    // with a communicator attached the graphs stay short (<= 64 steps, 128 captured collectives):
+    // a 3 ms replay already amortises the launch, and nothing here depends on how many collective
+    // nodes the installed RCCL is comfortable with in one graph
+    if (exchanging(h) && U > 64) continue;
     GraphSlot& g = h->graphs[i];
     if (!g.exec && exchanging(h)) {
-      // a communicator is attached: if RCCL cannot be captured on this system, fall back to eager
-      // launches for good (the graph is only an optimisation)
+      // if RCCL cannot be captured on this system, fall back to eager launches for good (the graph
+      // is only an optimisation)
       for (size_t j = 0; j < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]) && h->exchGraph; ++j)
-        if (!h->graphs[j].exec && captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]) != HL_OK) {
+        if (GRAPH_SIZES[j] <= 64 && !h->graphs[j].exec && captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]) != HL_OK) {
           h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
         }
       if (!h->exchGraph) return HL_OK;
@@ -407,7 +411,8 @@ int replaySteps(hl_learner* h, long long avail, int* done) {
       // and evictions, only a reallocation of the replay invalidates them), so that no later call
       // pays for a capture in the middle of a training phase
       for (size_t j = 0; j < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]); ++j)
-        if (!h->graphs[j].exec) { int rc = captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]); if (rc) return rc; }
+        if (!h->graphs[j].exec && !(exchanging(h) && GRAPH_SIZES[j] > 64)) {
+          int rc = captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]); if (rc) return rc; }
     }
     HIPCK(hipGraphLaunch(g.exec, h->stream));
     h->lastParity = (U - 1) & 1;
