@@ -359,6 +359,25 @@ def test_checkpoint_files_match_reference(hip_api, name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_long_replayed_runs_are_deterministic(hip_api):
+    """Two learners, same seed, 6000 steps each through the replayed graphs (sampler and gather riders,
+    in-kernel panel barriers, bookkeeping rider, 1000-step sweeps): weights, moments, beta, far-policy count
+    and generator state bit-identical, no device-side wait ever timed out (get_scalars would raise)."""
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=200000, randSeed=3)
+    sc = synth_cfg(seed=23, dimS=17, dimA=6, lenMin=100, lenMax=200, pTerm=0.2)
+    out = []
+    for run in range(2):
+        L = hip_learner(hip_api, capi.make_config(**cfg_kw))
+        L.init_weights(); fill_synth(L, sc, 400); L.initialize()
+        L.step(6000)
+        w, m1, m2 = L.get_params(); s = L.scalars()
+        out.append((w, m1, m2, s.beta, s.nFarPolicySteps, L.get_rng_state()))
+        assert np.isfinite(w).all() and s.nGradSteps == 6000
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_sampler_collisions_and_redraw_match_oracle(hip_api):
     """Replay barely larger than the batch: most draws collide, so Sample_uniform's
     sort / unique / redraw-the-tail loop (Sampling.cpp:75-93) runs several rounds per step.  Indices,
