@@ -133,8 +133,8 @@ def cpu_baseline(steps_budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
