@@ -216,6 +216,19 @@ HL_API int hl_sync(hl_learner* h);                         /* wait for all queue
  * steps, from the thread that owns the learner. */
 HL_API int hl_forward(hl_learner* h, int32_t n, const float* states /*[n][dimS]*/, double* outputs /*[n][nOut]*/);
 
+/* ---- episodes in the reference's wire format (second row) --------------------
+ * Episode::packEpisode / unpackEpisode (ReplayMemory/Episode.cpp:24-130): the fp32 record a worker
+ * sends to the learner and MemoryBuffer::save writes per episode.  nsteps * (dimS + 1 + dimA +
+ * 2 dimA + 6) floats -- per step [state | reward | action | policy], then returnEstimator,
+ * actionAdvantage, stateValue, deltaValue, offPolicImpW, KullbLeibDiv -- plus 10 floats holding
+ * {bool bReachedTermState, Sint ID, Sint just_sampled, Sint agentID} byte-packed (Episode.h:211-219).
+ * hl_append_packed_episode = unpackEpisode + the hl_append_episode path (actions, policies and
+ * rewards come back from fp32 exactly as the reference reads them; ID becomes the episode tag).
+ * hl_pack_episode packs a STORED episode with its current derived fields. */
+HL_API int64_t hl_packed_episode_size(const hl_learner* h, int32_t nsteps);
+HL_API int hl_append_packed_episode(hl_learner* h, const float* data, int64_t n_floats);
+HL_API int hl_pack_episode(hl_learner* h, int64_t episode_pos, float* dst, int64_t cap_floats);
+
 /* ---- checkpoint in the reference's file format (second row) ----------------
  * Approximator::save -> AdamOptimizer::save -> Network::save (Network/Approximator.cpp:282-297,
  * Network/Optimizer.cpp:180-214, Network/Network.cpp:22-68): three raw fp32 files

@@ -912,6 +912,57 @@ int ol_step(ol_learner* h, int32_t n, const int64_t* flat) {
   }
   return HL_OK;
 }
+// Episode::packEpisode / unpackEpisode (ReplayMemory/Episode.cpp:24-130, sizes Episode.h:211-228)
+int64_t ol_packed_episode_size(const ol_learner* h, int32_t N) {
+  if (!h || N < 0) return -1;
+  return (int64_t)(h->dS + h->dA + 2 * h->dA + 1 + 6) * N + 10;
+}
+int ol_append_packed_episode(ol_learner* h, const float* data, int64_t n) {
+  if (!h || !data) return HL_ERR_BAD_ARG;
+  const int dS = h->dS, dA = h->dA, tup = dS + 1 + dA + 2 * dA;
+  const int64_t N = (n - 10) / (tup + 6);
+  if (N < 2 || ol_packed_episode_size(h, (int32_t)N) != n) return fail(h, HL_ERR_BAD_ARG, "packed episode has the wrong size");
+  std::vector<float> S((size_t)N * dS), V(N), ADV(N);
+  std::vector<double> A((size_t)N * dA), MU((size_t)N * 2 * dA), R(N);
+  const float* buf = data;
+  for (int64_t i = 0; i < N; ++i) {
+    std::copy(buf, buf + dS, S.begin() + i * dS); R[i] = buf[dS]; buf += dS + 1;
+    for (int j = 0; j < dA; ++j) A[i * dA + j] = buf[j]; buf += dA;
+    for (int j = 0; j < 2 * dA; ++j) MU[i * 2 * dA + j] = buf[j]; buf += 2 * dA;
+  }
+  buf += N;                                            // returnEstimator: recomputed on insertion
+  std::copy(buf, buf + N, ADV.begin()); buf += N;      // actionAdvantage
+  std::copy(buf, buf + N, V.begin()); buf += N;        // stateValue
+  buf += 3 * N;                                        // deltaValue, offPolicImpW, KullbLeibDiv: reset on insertion
+  const char* cp = reinterpret_cast<const char*>(buf);
+  bool term; int64_t ID; std::memcpy(&term, cp, sizeof(bool)); std::memcpy(&ID, cp + sizeof(bool), sizeof(int64_t));
+  return ol_append_episode(h, (int32_t)N, S.data(), A.data(), MU.data(), R.data(), V.data(), ADV.data(), term ? 1 : 0, ID);
+}
+int ol_pack_episode(ol_learner* h, int64_t pos, float* dst, int64_t cap) {
+  if (!h || !dst || pos < 0 || pos >= (int64_t)h->episodes.size()) return HL_ERR_BAD_ARG;
+  const Episode& EP = *h->episodes[(size_t)pos];
+  const int dS = h->dS, dA = h->dA; const int64_t N = EP.N;
+  if (cap < ol_packed_episode_size(h, (int32_t)N)) return HL_ERR_BAD_ARG;
+  std::fill(dst, dst + ol_packed_episode_size(h, (int32_t)N), 0.f);
+  float* buf = dst;
+  for (int64_t i = 0; i < N; ++i) {
+    std::copy(EP.S.begin() + i * dS, EP.S.begin() + (i + 1) * dS, buf); buf[dS] = (float)EP.R[i]; buf += dS + 1;
+    for (int j = 0; j < dA; ++j) buf[j] = (float)EP.A[i * dA + j]; buf += dA;
+    for (int j = 0; j < 2 * dA; ++j) buf[j] = (float)EP.MU[i * 2 * dA + j]; buf += 2 * dA;
+  }
+  for (int64_t i = 0; i < N; ++i) buf[i] = EP.RET[i]; buf += N;
+  for (int64_t i = 0; i < N; ++i) buf[i] = EP.ADV[i]; buf += N;
+  for (int64_t i = 0; i < N; ++i) buf[i] = EP.V[i]; buf += N;
+  for (int64_t i = 0; i < N; ++i) buf[i] = EP.DQ[i]; buf += N;
+  for (int64_t i = 0; i < N; ++i) buf[i] = EP.IMPW[i]; buf += N;
+  for (int64_t i = 0; i < N; ++i) buf[i] = EP.DKL[i]; buf += N;
+  char* cp = reinterpret_cast<char*>(buf);
+  const bool term = EP.term; const int64_t ID = EP.tag, sampled = -1, agentID = 0;
+  std::memcpy(cp, &term, sizeof(bool)); cp += sizeof(bool);
+  std::memcpy(cp, &ID, 8); cp += 8; std::memcpy(cp, &sampled, 8); cp += 8; std::memcpy(cp, &agentID, 8);
+  return HL_OK;
+}
+
 // Network::save / restart (Network/Network.cpp:22-68) over Layer::save of each type
 // (Layer_Base.h:143-166, Layers.h:401-420, 554-567): compact fp32, no SIMD padding
 static size_t packedSize(const ol_learner* h) {

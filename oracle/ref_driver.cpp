@@ -259,6 +259,17 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   // stepInit (RACER.cpp:69-79): Learner::initializeLearner
   L.initializeLearner(); L.algoSubStepID = 0; L.profiler->start("DATA");
   W.u32("rng0", rngState(info.generators[0]));
+  if (A.l("pack", 0)) {   // Episode::packEpisode (ReplayMemory/Episode.cpp:24-86) of the first stored episodes: the
+    // worker -> learner wire format and the per-episode record of MemoryBuffer::save
+    const long nPack = std::min<long>(A.l("pack", 0), (long)L.data->nStoredEps());
+    std::vector<int64_t> ids;
+    for (long k = 0; k < nPack; ++k) {
+      Episode& EP = L.data->get(k);
+      ids.push_back((int64_t)EP.agentID);                       // the harness keeps the synthetic episode number here
+      W.f32("pack_" + std::to_string(k), EP.packEpisode());
+    }
+    W.i64("pack_tags", ids);
+  }
   W.scalar_d("beta0", L.data->beta); W.scalar_d("cmax0", L.data->CmaxRet);
   {
     std::vector<float> sc;

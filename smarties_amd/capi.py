@@ -161,6 +161,9 @@ class CApi:
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
             "forward": (C.c_int, [P, I32, pf, pd]),
             "save": (C.c_int, [P, C.c_char_p]),
+            "packed_episode_size": (C.c_int64, [P, I32]),
+            "append_packed_episode": (C.c_int, [P, pf, I64]),
+            "pack_episode": (C.c_int, [P, I64, pf, I64]),
             "restart": (C.c_int, [P, C.c_char_p]),
             "status_string": (C.c_char_p, [C.c_int]),
             "version": (C.c_int, []),
@@ -325,6 +328,17 @@ class Learner:
     def moments_store(self, m):
         m = _f64(m)
         self._ck(self.api.fn("moments_exchange")(self.h, _ptr(m, C.c_double), 1))
+
+    def append_packed_episode(self, data):
+        """Episode in the reference's wire format (Episode::packEpisode)."""
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        self._ck(self.api.fn("append_packed_episode")(self.h, _ptr(d, C.c_float), d.size))
+
+    def pack_episode(self, pos):
+        _, n, _ = self.episode_info(pos)
+        out = np.zeros(int(self.api.fn("packed_episode_size")(self.h, n)), np.float32)
+        self._ck(self.api.fn("pack_episode")(self.h, pos, _ptr(out, C.c_float), out.size))
+        return out
 
     def save(self, base):
         """Checkpoint in the reference's format: <base>_weights.raw, _1stMom.raw, _2ndMom.raw."""

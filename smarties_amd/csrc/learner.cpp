@@ -826,6 +826,66 @@ int hl_step_end(hl_learner* h) {
   h->nGradSteps += 1; h->inStep = false;
   return HL_OK;
 }
+// ---- episodes in the reference's wire format (Episode::packEpisode / unpackEpisode, Episode.cpp:24-130) ----
+int64_t hl_packed_episode_size(const hl_learner* h, int32_t N) {
+  if (!h || N < 0) return -1;
+  return (int64_t)(h->dS + h->dA + 2 * h->dA + 1 + 6) * N + 10;      // Episode::computeTotalEpisodeSize (Episode.h:211-219)
+}
+int hl_append_packed_episode(hl_learner* h, const float* data, int64_t n) {
+  if (!h || !data) return HL_ERR_BAD_ARG;
+  const int dS = h->dS, dA = h->dA, tup = dS + 1 + dA + 2 * dA;
+  const int64_t N = (n - 10) / (tup + 6);
+  if (N < 2 || hl_packed_episode_size(h, (int32_t)N) != n) return fail(h, HL_ERR_BAD_ARG, "packed episode has the wrong size");
+  std::vector<float> S((size_t)N * dS), V(N), ADV(N);
+  std::vector<double> A((size_t)N * dA), MU((size_t)N * 2 * dA), R(N);
+  const float* buf = data;
+  for (int64_t i = 0; i < N; ++i) {      // Episode::unpackEpisode: fp32 -> Fvec states, Real reward, Rvec action / policy
+    std::copy(buf, buf + dS, S.begin() + i * dS); R[i] = buf[dS]; buf += dS + 1;
+    for (int j = 0; j < dA; ++j) A[i * dA + j] = buf[j];
+    buf += dA;
+    for (int j = 0; j < 2 * dA; ++j) MU[i * 2 * dA + j] = buf[j];
+    buf += 2 * dA;
+  }
+  buf += N;                                            // returnEstimator: recomputed on insertion
+  std::copy(buf, buf + N, ADV.begin()); buf += N;      // actionAdvantage
+  std::copy(buf, buf + N, V.begin()); buf += N;        // stateValue
+  buf += 3 * N;                                        // deltaValue, offPolicImpW, KullbLeibDiv: reset on insertion
+  const char* cp = reinterpret_cast<const char*>(buf);
+  bool term; int64_t ID; std::memcpy(&term, cp, sizeof(bool)); std::memcpy(&ID, cp + sizeof(bool), sizeof(int64_t));
+  return hl_append_episode(h, (int32_t)N, S.data(), A.data(), MU.data(), R.data(), V.data(), ADV.data(), term ? 1 : 0, ID);
+}
+int hl_pack_episode(hl_learner* h, int64_t pos, float* dst, int64_t cap) {
+  if (!h || !dst || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  const EpMeta e = h->order[(size_t)pos];
+  const int dS = h->dS, dA = h->dA; const int64_t N = e.N, total = hl_packed_episode_size(h, e.N);
+  if (cap < total) return fail(h, HL_ERR_BAD_ARG, "hl_pack_episode: destination too small");
+  int rc = flushPending(h); if (rc) return rc;
+  std::vector<float> S((size_t)N * dS), F((size_t)6 * N);
+  std::vector<double> A((size_t)N * dA), MU((size_t)N * 2 * dA), R(N);
+  HIPCK(hipMemcpyAsync(S.data(), h->rp.S + (size_t)e.off * dS, S.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpyAsync(A.data(), h->rp.A + (size_t)e.off * dA, A.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpyAsync(MU.data(), h->rp.MU + (size_t)e.off * 2 * dA, MU.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpyAsync(R.data(), h->rp.R + e.off, R.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  const float* src[6] = {h->rp.RET, h->rp.ADV, h->rp.V, h->rp.DQ, h->rp.IMPW, h->rp.DKL};   // order of Episode.cpp:48-72
+  for (int k = 0; k < 6; ++k) HIPCK(hipMemcpyAsync(F.data() + (size_t)k * N, src[k] + e.off, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  std::fill(dst, dst + total, 0.f);
+  float* buf = dst;
+  for (int64_t i = 0; i < N; ++i) {
+    std::copy(S.begin() + i * dS, S.begin() + (i + 1) * dS, buf); buf[dS] = (float)R[i]; buf += dS + 1;
+    for (int j = 0; j < dA; ++j) buf[j] = (float)A[i * dA + j];
+    buf += dA;
+    for (int j = 0; j < 2 * dA; ++j) buf[j] = (float)MU[i * 2 * dA + j];
+    buf += 2 * dA;
+  }
+  std::copy(F.begin(), F.end(), buf); buf += 6 * N;
+  char* cp = reinterpret_cast<char*>(buf);
+  const bool term = e.term; const int64_t ID = e.tag, sampled = -1, agentID = 0;
+  std::memcpy(cp, &term, sizeof(bool)); cp += sizeof(bool);
+  std::memcpy(cp, &ID, 8); cp += 8; std::memcpy(cp, &sampled, 8); cp += 8; std::memcpy(cp, &agentID, 8);
+  return HL_OK;
+}
+
 // ---- checkpoint in the reference's format (Network::save / restart, Network/Network.cpp:22-68) ----
 static void packBlob(const hl_learner* h, const std::vector<float>& P, std::vector<float>& out) {
   out.clear();

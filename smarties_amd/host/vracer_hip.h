@@ -187,6 +187,16 @@ class VRACER {
                          bReachedTermState ? 1 : 0, ID));
   }
 
+  // the same from the wire format a worker sends (Episode::packEpisode / unpackEpisode, Episode.cpp:24-130)
+  void pushBackEpisode(const Fvec& packed) { ck(hl_append_packed_episode(H, packed.data(), (int64_t)packed.size())); }
+  // Episode::packEpisode of the stored episode at position `pos` (what MemoryBuffer::save writes per episode)
+  Fvec packEpisode(long pos) const {
+    int64_t tag; int32_t n, term; ck(hl_get_episode_info(H, pos, &tag, &n, &term));
+    Fvec out((Uint)hl_packed_episode_size(H, n));
+    ck(hl_pack_episode(H, pos, out.data(), (int64_t)out.size()));
+    return out;
+  }
+
   // Learner::initializeLearner (Learner.cpp:47-72)
   void initializeLearner() { ck(hl_initialize(H)); bInit = true; }
 

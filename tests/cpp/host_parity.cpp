@@ -103,6 +103,19 @@ int main() {
     CHECK(L.nGradSteps() == 203, "nGradSteps after appended episode");
   }
 
+  // ---- wire format: a stored episode packed and pushed into a second learner --------------------------------
+  {
+    const Fvec packed = L.packEpisode(3);
+    VRACER L3(MDP, HP, 0);
+    L3.pushBackEpisode(packed);
+    L3.pushBackEpisode(L.packEpisode(5));
+    L3.initializeLearner();
+    const Fvec again = L3.packEpisode(1);          // newest first: position 1 is the first one pushed
+    const size_t nfl = packed.size() - 10, N = nfl / (17 + 1 + 6 + 12 + 6), tup = 17 + 1 + 6 + 12;
+    CHECK(again.size() == packed.size(), "packed size");
+    CHECK(std::memcmp(again.data(), packed.data(), N * tup * sizeof(float)) == 0, "states / rewards / actions / policies survive the wire format");
+  }
+
   // ---- checkpoint round trip through the reference's file format --------------------------------------------
   {
     char tmpl[] = "/tmp/smarties_hip_XXXXXX"; const char* dir = mkdtemp(tmpl);

@@ -70,3 +70,41 @@ def fixture_arrays_by_tag(fx, tags_key, arr_key, lens):
         out[int(tag)] = fx[arr_key][o:o + n]
         o += n
     return out
+
+import pytest  # noqa: E402
+
+def check_packed_roundtrip(make_learner, fx):
+    """Episodes in the reference's wire format (Episode::packEpisode, Episode.cpp:24-86), as packed by the
+    compiled reference right after Learner::initializeLearner."""
+    from oracle_api import synth_episode
+    cfg = fixture_config(fx)
+    sc = fixture_synth(fx)
+    tags = [int(t) for t in fx["pack_tags"]]
+    packs = [np.asarray(fx["pack_%d" % k], np.float32) for k in range(len(tags))]
+    # (1) same learner state as the reference had: the library's own pack == the reference's pack
+    L = make_learner(cfg)
+    setup_from_fixture(L, fx)                      # pushes the synthetic episodes, initialize
+    pos_of = {L.episode_info(p)[0]: p for p in range(int(fx["cfg"][3]))}
+    for tag, ref in zip(tags, packs):
+        mine = L.pack_episode(pos_of[tag])
+        assert mine.size == ref.size
+        nfl = ref.size - 10
+        assert np.array_equal(mine[:nfl], ref[:nfl]), tag     # states, rewards, actions, policies, RET, ADV, V, dQ, impW, KL
+        assert mine[nfl:].view(np.uint8)[0] == ref[nfl:].view(np.uint8)[0]   # bReachedTermState
+    # (2) unpack: appending the packed record == appending the original arrays rounded through fp32
+    A = make_learner(cfg); A.init_weights()
+    Bq = make_learner(cfg); Bq.init_weights()
+    for tag, ref in zip(tags, packs):
+        A.append_packed_episode(ref)
+        ep = synth_episode(sc, tag)
+        ep["actions"] = ep["actions"].astype(np.float32).astype(np.float64)
+        ep["mu"] = ep["mu"].astype(np.float32).astype(np.float64)
+        ep["rewards"] = ep["rewards"].astype(np.float32).astype(np.float64)
+        ep["tag"] = int(np.frombuffer(ref[ref.size - 10:].tobytes()[1:9], np.int64)[0])   # the reference's episode ID
+        Bq.append_episode(**ep)
+    A.initialize(); Bq.initialize()
+    for p in range(len(tags)):
+        assert A.episode_info(p) == Bq.episode_info(p)
+        assert A.pack_episode(p).tobytes() == Bq.pack_episode(p).tobytes()      # (the trailer bytes read as NaN floats)
+    with pytest.raises(Exception):
+        A.append_packed_episode(packs[0][:-3])         # wrong size

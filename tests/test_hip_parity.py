@@ -359,6 +359,12 @@ def test_checkpoint_files_match_reference(hip_api, name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_packed_episode_wire_format_matches_reference(hip_api):
+    from parity import check_packed_roundtrip
+    check_packed_roundtrip(lambda cfg: hip_learner(hip_api, cfg), load_fixture("small_mixed.bin"))
+
+
+@pytest.mark.gpu
 def test_long_replayed_runs_are_deterministic(hip_api):
     """Two learners, same seed, 6000 steps each through the replayed graphs (sampler and gather riders,
     in-kernel panel barriers, bookkeeping rider, 1000-step sweeps): weights, moments, beta, far-policy count

@@ -154,3 +154,8 @@ def test_checkpoint_files_match_reference(name, tmp_path):
     assert np.array_equal(w, fx["Wfinal"]) and np.array_equal(m1, fx["M1final"]) and np.array_equal(m2, fx["M2final"])
     with pytest.raises(Exception):
         L2.restart(str(tmp_path / "missing"))
+
+
+def test_packed_episode_wire_format_matches_reference():
+    from parity import check_packed_roundtrip
+    check_packed_roundtrip(oracle_learner, load_fixture("small_mixed.bin"))
