@@ -240,6 +240,18 @@ HL_API int hl_pack_episode(hl_learner* h, int64_t episode_pos, float* dst, int64
 HL_API int hl_save(hl_learner* h, const char* base);
 HL_API int hl_restart(hl_learner* h, const char* base);
 
+/* Replay memory + ReF-ER state in the reference's files (MemoryBuffer::save / restart,
+ * ReplayMemory/MemoryBuffer.cpp:172-324): <base>_scaling.raw (doubles: state mean | scale | stdev,
+ * reward stdev, scale, mean), <base>_rank_RRR_learner_status.raw (text: nStoredEps, nStoredObs,
+ * nLocalSeenEps, nLocalSeenObs, nInitialData, nGradSteps, CmaxReFER, beta) and
+ * <base>_rank_RRR_learner_data.raw (per episode: Uint length + Episode::packEpisode record, with every
+ * derived per-step field).  hl_restart_memory restores the per-step fields as stored, recomputes the
+ * per-episode aggregates (Episode::updateCumulative) and -- like the reference, which skips
+ * Learner::initializeLearner for a restarted learner -- leaves the learner ready to step.
+ * Missing files: HL_ERR_IO (the reference prints a notice and continues with an empty memory). */
+HL_API int hl_save_memory(hl_learner* h, const char* base, int32_t rank);
+HL_API int hl_restart_memory(hl_learner* h, const char* base, int32_t rank);
+
 /* ---- inspection ---------------------------------------------------------------- */
 HL_API int hl_set_tap(hl_learner* h, int32_t enable);
 HL_API int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t dst_bytes);

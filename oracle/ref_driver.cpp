@@ -356,6 +356,18 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       }
     }
   }
+  {   // the reference's own replay-memory checkpoint of this state (MemoryBuffer::save, MemoryBuffer.cpp:274-324)
+    const std::string mk = A.s("memck", "");
+    if (!mk.empty()) {
+      L.data->save(mk);
+      for (const char* suf : {"_scaling", "_rank_000_learner_status", "_rank_000_learner_data"}) {
+        FILE* f = fopen((mk + suf + ".raw").c_str(), "rb");
+        std::vector<uint8_t> bytes;
+        if (f) { int c; while ((c = fgetc(f)) != EOF) bytes.push_back((uint8_t)c); fclose(f); }
+        W.u8(std::string("memck") + suf, bytes);
+      }
+    }
+  }
   {
     const ReplayStats& st = L.data->stats;
     std::vector<double> s = {(double)st.avgKLdivergence, (double)st.avgSquaredErr, (double)st.maxAbsError,

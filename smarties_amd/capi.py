@@ -161,6 +161,8 @@ class CApi:
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
             "forward": (C.c_int, [P, I32, pf, pd]),
             "save": (C.c_int, [P, C.c_char_p]),
+            "save_memory": (C.c_int, [P, C.c_char_p, I32]),
+            "restart_memory": (C.c_int, [P, C.c_char_p, I32]),
             "packed_episode_size": (C.c_int64, [P, I32]),
             "append_packed_episode": (C.c_int, [P, pf, I64]),
             "pack_episode": (C.c_int, [P, I64, pf, I64]),
@@ -339,6 +341,13 @@ class Learner:
         out = np.zeros(int(self.api.fn("packed_episode_size")(self.h, n)), np.float32)
         self._ck(self.api.fn("pack_episode")(self.h, pos, _ptr(out, C.c_float), out.size))
         return out
+
+    def save_memory(self, base, rank=0):
+        """Replay memory + ReF-ER state in the reference's files (MemoryBuffer::save)."""
+        self._ck(self.api.fn("save_memory")(self.h, str(base).encode(), rank))
+
+    def restart_memory(self, base, rank=0):
+        self._ck(self.api.fn("restart_memory")(self.h, str(base).encode(), rank))
 
     def save(self, base):
         """Checkpoint in the reference's format: <base>_weights.raw, _1stMom.raw, _2ndMom.raw."""

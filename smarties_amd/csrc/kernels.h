@@ -71,6 +71,7 @@ struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
   DevScalars* sc; DevReplay rp;
   const int* eids; int count;        // eids == nullptr: all current positions (count = nEpisodes)
   float gamma, lambda; int recompute; // recompute=1: Episode::updateCumulative first
+  int skipRetrace;                   // 1: aggregates only (restart from a checkpoint keeps the stored estimates)
   long long* redNFar; float* redMaxAbs;   // per-block partials (recompute only)
 };
 

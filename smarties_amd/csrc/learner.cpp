@@ -26,7 +26,7 @@ namespace {
 
 inline long long roundUp(long long n, long long m) { return (n + m - 1) / m * m; }
 
-struct EpMeta { int eid; long long off; int N; bool term; long long tag, ID; };
+struct EpMeta { int eid; long long off; int N; bool term; long long tag, ID; long long sampled = -1, agentID = 0; /* wire-format trailer, kept for byte-exact re-packing */ };
 
 struct TimeRec { int name; hipEvent_t a, b; };
 
@@ -339,7 +339,7 @@ int uploadTable(hl_learner* h) {
   return HL_OK;
 }
 
-int runSweep(hl_learner* h, const int* dEids, int count, int recompute) {
+int runSweep(hl_learner* h, const int* dEids, int count, int recompute, int skipRetrace = 0) {
   if (count <= 0) return HL_OK;
   const int nb = sweep_blocks(count);
   if (recompute && nb > h->redCap) {
@@ -347,7 +347,7 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute) {
     h->redCap = nb;
   }
   EpisodeSweepArgs a{}; a.sc = h->sc; a.rp = h->rp; a.eids = dEids; a.count = count;
-  a.gamma = (float)h->cfg.gamma; a.lambda = (float)h->cfg.lambda; a.recompute = recompute;
+  a.gamma = (float)h->cfg.gamma; a.lambda = (float)h->cfg.lambda; a.recompute = recompute; a.skipRetrace = skipRetrace;
   a.redNFar = h->dRedNFar; a.redMaxAbs = h->dRedMax;
   HIPCK(timed(h, recompute ? "episode_sweep_recompute" : "episode_sweep_retrace", h->stream,
               [&] { return launch_episode_sweep(a, nb, h->stream); }));
@@ -880,9 +880,142 @@ int hl_pack_episode(hl_learner* h, int64_t pos, float* dst, int64_t cap) {
   }
   std::copy(F.begin(), F.end(), buf); buf += 6 * N;
   char* cp = reinterpret_cast<char*>(buf);
-  const bool term = e.term; const int64_t ID = e.tag, sampled = -1, agentID = 0;
+  const bool term = e.term; const int64_t ID = e.tag, sampled = e.sampled, agentID = e.agentID;
   std::memcpy(cp, &term, sizeof(bool)); cp += sizeof(bool);
   std::memcpy(cp, &ID, 8); cp += 8; std::memcpy(cp, &sampled, 8); cp += 8; std::memcpy(cp, &agentID, 8);
+  return HL_OK;
+}
+
+// ---- replay memory + ReF-ER state (MemoryBuffer::save / restart, MemoryBuffer.cpp:172-324) ----
+static bool copyFile(const std::string& from, const std::string& to) {
+  FILE* a = fopen(from.c_str(), "rb"); if (!a) return false;
+  FILE* b = fopen(to.c_str(), "wb"); if (!b) { fclose(a); return false; }
+  char buf[1 << 16]; size_t n;
+  while ((n = fread(buf, 1, sizeof(buf), a)) > 0) fwrite(buf, 1, n, b);
+  fclose(a); fclose(b); return true;
+}
+int hl_save_memory(hl_learner* h, const char* base, int32_t rank) {
+  if (!h || !base) return HL_ERR_BAD_ARG;
+  int rc = flushPending(h); if (rc) return rc;
+  DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;
+  const int dS = h->dS;
+  std::vector<float> mean(dS), scale(dS), stdv(dS);
+  HIPCK(hipMemcpy(mean.data(), h->rp.stMean, dS * 4, hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(scale.data(), h->rp.stScale, dS * 4, hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(stdv.data(), h->rp.stStd, dS * 4, hipMemcpyDeviceToHost));
+  const std::string B(base);
+  {
+    const std::string back = B + "_scaling_backup.raw";
+    FILE* f = fopen(back.c_str(), "wb"); if (!f) return fail(h, HL_ERR_IO, "Unable to save into file " + back);
+    std::vector<double> V(mean.begin(), mean.end()); fwrite(V.data(), 8, V.size(), f);
+    V.assign(scale.begin(), scale.end()); fwrite(V.data(), 8, V.size(), f);
+    V.assign(stdv.begin(), stdv.end()); fwrite(V.data(), 8, V.size(), f);
+    const double r3[3] = {(double)sc.rewStd, (double)sc.rewScale, (double)sc.rewMean};
+    fwrite(r3, 8, 3, f); fclose(f);
+    copyFile(back, B + "_scaling.raw");
+  }
+  char rk[64]; snprintf(rk, sizeof(rk), "_rank_%03u_learner_", (unsigned)rank);
+  const std::string fName = B + rk;
+  {
+    FILE* f = fopen((fName + "status_backup.raw").c_str(), "w"); if (!f) return fail(h, HL_ERR_IO, "Unable to save into file " + fName);
+    fprintf(f, "nStoredEps: %lu\n", (unsigned long)h->order.size());
+    fprintf(f, "nStoredObs: %lu\n", (unsigned long)h->nTransitions);
+    fprintf(f, "nLocalSeenEps: %lu\n", (unsigned long)h->nSeenEps);
+    fprintf(f, "nLocalSeenObs: %lu\n", (unsigned long)h->nSeenSteps);
+    fprintf(f, "nInitialData: %ld\n", (long)h->nGatheredB4Startup);
+    fprintf(f, "nGradSteps: %ld\n", (long)(h->nGradSteps + 1));           // the reference writes counters.nGradSteps + 1
+    fprintf(f, "CmaxReFER: %le\n", sc.Cmax);
+    fprintf(f, "beta: %le\n", sc.beta);
+    fclose(f);
+  }
+  {
+    FILE* f = fopen((fName + "data_backup.raw").c_str(), "wb"); if (!f) return fail(h, HL_ERR_IO, "Unable to save into file " + fName);
+    std::vector<float> buf;
+    for (long long p = (long long)h->order.size() - 1; p >= 0; --p) {      // oldest first: re-appending restores the order
+      const unsigned long N = (unsigned long)h->order[(size_t)p].N;
+      buf.resize((size_t)hl_packed_episode_size(h, (int32_t)N));
+      rc = hl_pack_episode(h, p, buf.data(), (int64_t)buf.size()); if (rc) { fclose(f); return rc; }
+      fwrite(&N, sizeof(unsigned long), 1, f); fwrite(buf.data(), 4, buf.size(), f);
+    }
+    fclose(f);
+  }
+  copyFile(fName + "status_backup.raw", fName + "status.raw");
+  copyFile(fName + "data_backup.raw", fName + "data.raw");
+  return HL_OK;
+}
+int hl_restart_memory(hl_learner* h, const char* base, int32_t rank) {
+  if (!h || !base) return HL_ERR_BAD_ARG;
+  if (!h->order.empty()) return fail(h, HL_ERR_STATE, "hl_restart_memory needs an empty replay");
+  const int dS = h->dS, dA = h->dA;
+  const std::string B(base);
+  {
+    FILE* f = fopen((B + "_scaling.raw").c_str(), "rb");
+    if (!f) return fail(h, HL_ERR_IO, "Parameters restart file " + B + "_scaling.raw not found.");
+    std::vector<double> V((size_t)3 * dS + 3);
+    const size_t got = fread(V.data(), 8, V.size(), f); fclose(f);
+    if (got != V.size()) return fail(h, HL_ERR_IO, "Mismatch in restarted file " + B + "_scaling.raw");
+    std::vector<float> m(dS), s(dS), d(dS);
+    for (int i = 0; i < dS; ++i) { m[i] = (float)V[i]; s[i] = (float)V[dS + i]; d[i] = (float)V[2 * dS + i]; }
+    HIPCK(hipMemcpy(h->rp.stMean, m.data(), dS * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->rp.stScale, s.data(), dS * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->rp.stStd, d.data(), dS * 4, hipMemcpyHostToDevice));
+    const float r3[3] = {(float)V[3 * dS + 2], (float)V[3 * dS + 1], (float)V[3 * dS]};   // mean, scale, std
+    HIPCK(hipMemcpy(&h->sc->rewMean, &r3[0], 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(&h->sc->rewScale, &r3[1], 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(&h->sc->rewStd, &r3[2], 4, hipMemcpyHostToDevice));
+  }
+  char rk[64]; snprintf(rk, sizeof(rk), "_rank_%03u_learner_", (unsigned)rank);
+  const std::string fName = B + rk;
+  FILE* fs = fopen((fName + "status.raw").c_str(), "r");
+  FILE* fd = fopen((fName + "data.raw").c_str(), "rb");
+  if (!fs || !fd) { if (fs) fclose(fs); if (fd) fclose(fd); return fail(h, HL_ERR_IO, "Learner status / data restart file " + fName + "*.raw not found"); }
+  unsigned long nEps = 0, nObs = 0, seenE = 0, seenO = 0; long nInit = 0, doneGrad = 0; double Cmax = 0, beta = 0;
+  int pass = 1;
+  pass = pass && 1 == fscanf(fs, "nStoredEps: %lu\n", &nEps);
+  pass = pass && 1 == fscanf(fs, "nStoredObs: %lu\n", &nObs);
+  pass = pass && 1 == fscanf(fs, "nLocalSeenEps: %lu\n", &seenE);
+  pass = pass && 1 == fscanf(fs, "nLocalSeenObs: %lu\n", &seenO);
+  pass = pass && 1 == fscanf(fs, "nInitialData: %ld\n", &nInit);
+  pass = pass && 1 == fscanf(fs, "nGradSteps: %ld\n", &doneGrad);
+  pass = pass && 1 == fscanf(fs, "CmaxReFER: %le\n", &Cmax);
+  pass = pass && 1 == fscanf(fs, "beta: %le\n", &beta);
+  fclose(fs);
+  if (!pass || doneGrad < 0) { fclose(fd); return fail(h, HL_ERR_IO, "Mismatch in restarted file " + fName + "status.raw"); }
+  // episodes: unpack, append (same path as fresh ones), then put the stored per-step fields back
+  struct Stored { std::vector<float> f6; int N; };
+  std::vector<Stored> stored; stored.reserve(nEps);
+  const int tup = dS + 1 + dA + 2 * dA;
+  for (unsigned long i = 0; i < nEps; ++i) {
+    unsigned long N = 0;
+    if (fread(&N, sizeof(unsigned long), 1, fd) != 1 || N < 2) { fclose(fd); return fail(h, HL_ERR_IO, "Unable to find sequence in " + fName + "data.raw"); }
+    std::vector<float> buf((size_t)hl_packed_episode_size(h, (int32_t)N));
+    if (fread(buf.data(), 4, buf.size(), fd) != buf.size()) { fclose(fd); return fail(h, HL_ERR_IO, "Truncated " + fName + "data.raw"); }
+    int rc = hl_append_packed_episode(h, buf.data(), (int64_t)buf.size()); if (rc) { fclose(fd); return rc; }
+    Stored st; st.N = (int)N; st.f6.assign(buf.begin() + (size_t)N * tup, buf.begin() + (size_t)N * (tup + 6));
+    stored.push_back(std::move(st));
+    const char* cp = reinterpret_cast<const char*>(buf.data() + (size_t)N * (tup + 6)) + sizeof(bool) + 8;
+    std::memcpy(&h->order.front().sampled, cp, 8); std::memcpy(&h->order.front().agentID, cp + 8, 8);
+  }
+  fclose(fd);
+  int rc = flushPending(h); if (rc) return rc;            // tables, counters, insertion-time Retrace
+  float* dst[6] = {h->rp.RET, h->rp.ADV, h->rp.V, h->rp.DQ, h->rp.IMPW, h->rp.DKL};
+  for (size_t i = 0; i < stored.size(); ++i) {           // episode i of the file sits at position nEps-1-i
+    const EpMeta& e = h->order[stored.size() - 1 - i];
+    for (int k = 0; k < 6; ++k)
+      HIPCK(hipMemcpyAsync(dst[k] + e.off, stored[i].f6.data() + (size_t)k * e.N, (size_t)e.N * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  // counters and ReF-ER state, then Episode::updateCumulative for every episode (MemoryBuffer.cpp:266)
+  h->nSeenEps = (long long)seenE; h->nSeenSteps = (long long)seenO; h->nGatheredB4Startup = nInit; h->nGradSteps = doneGrad;
+  h->countsDirty = true;
+  rc = flushPending(h); if (rc) return rc;
+  DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;
+  sc.Cmax = Cmax; sc.Cinv = 1 / Cmax; sc.beta = beta; sc.nGradSteps = doneGrad;
+  HIPCK(hipMemcpy(h->sc, &sc, sizeof(DevScalars), hipMemcpyHostToDevice));
+  rc = runSweep(h, nullptr, (int)h->order.size(), 1, /*skipRetrace*/1); if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  if ((unsigned long)h->nTransitions != nObs) return fail(h, HL_ERR_IO, "nStoredObs of the status file does not match the data file");
+  h->initialized = true;      // Learner::initializeLearner is skipped for a restarted learner (Learner.cpp:51-54)
   return HL_OK;
 }
 

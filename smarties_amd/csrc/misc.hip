@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
       myFar += farSteps((float)N, invN * (float)nFarPol);
       myMax = fmaxf(myMax, fmaxf(maxAE, 0.f));
     }
+    if (a.skipRetrace) continue;
     float Q = term ? a.rp.RET[off + N - 1] : a.rp.V[off + N - 1];
     if (!term && lane == 0) a.rp.RET[off + N - 1] = Q;
     for (int t1 = N - 2; t1 >= 0; t1 -= 64) {      // chunk covers t = t1, t1-1, ..., t1-63

@@ -214,9 +214,16 @@ class VRACER {
         << " " << st.minQ << " " << st.maxQ << " " << st.nFarPolicySteps << " " << s.beta << " " << s.CmaxRet;
   }
 
-  // Approximator::save / restart: "<base>_net_weights.raw", "_1stMom.raw", "_2ndMom.raw"
-  void save(const std::string& base) const { ck(hl_save(H, (base + "_net").c_str())); }
+  // Learner::save / restart: the networks ("<base>_net_weights.raw", "_1stMom.raw", "_2ndMom.raw",
+  // Approximator.cpp:282-297) and the replay memory ("<base>_scaling.raw", "<base>_rank_RRR_learner_status.raw",
+  // "..._data.raw", MemoryBuffer.cpp:172-324)
+  void save(const std::string& base, int learnerRank = 0) const {
+    ck(hl_save(H, (base + "_net").c_str()));
+    ck(hl_save_memory(H, base.c_str(), learnerRank));
+  }
+  // networks only (a replay memory is restarted only when its files exist, as in the reference)
   void restart(const std::string& base) { ck(hl_restart(H, (base + "_net").c_str())); }
+  void restartMemory(const std::string& base, int learnerRank = 0) { ck(hl_restart_memory(H, base.c_str(), learnerRank)); bInit = true; }
 };
 
 }  // namespace smarties_amd

@@ -13,7 +13,7 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
 
 # G-small: mixed bounded/unbounded actions, terminated + truncated episodes, every tap
 "$DRV" fixture "$HERE/small_mixed.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
-   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_small" pack=4
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_small" pack=4 memck="$TMP/mem_small"
 # G-traj: 1200 steps across the 1000-step recompute / Retrace sweep / reward-stat update
 "$DRV" fixture "$HERE/traj_1200.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=999,1000,1200 \

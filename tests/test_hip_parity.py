@@ -365,6 +365,73 @@ def test_packed_episode_wire_format_matches_reference(hip_api):
 
 
 @pytest.mark.gpu
+def test_memory_checkpoint_files_of_the_reference(hip_api, tmp_path):
+    """hl_restart_memory reads the replay-memory checkpoint the COMPILED REFERENCE wrote after 12 gradient
+    steps (MemoryBuffer::save, MemoryBuffer.cpp:274-324): scaling, counters, ReF-ER state and every per-step
+    field of every episode come back exactly; hl_save_memory of that state reproduces the three files byte
+    for byte."""
+    fx = load_fixture("small_mixed.bin")
+    base = str(tmp_path / "agent_00")
+    names = ("_scaling", "_rank_000_learner_status", "_rank_000_learner_data")
+    for suf in names:
+        open(base + suf + ".raw", "wb").write(bytes(bytearray(fx["memck" + suf])))
+    L = hip_learner(hip_api, fixture_config(fx))
+    L.init_weights()
+    L.restart_memory(base)
+    s = L.scalars()
+    assert (s.nStoredEps, s.nStoredSteps, s.nGradSteps) == (30, 659, 13)
+    assert s.CmaxRet == 5.0 and abs(s.beta - 1.044926e-02) < 1e-8
+    scal = np.frombuffer(bytes(bytearray(fx["memck_scaling"])), np.float64)
+    m, sc_, r3 = L.get_scaling()
+    assert np.array_equal(m, scal[0:5].astype(np.float32)) and np.array_equal(sc_, scal[5:10].astype(np.float32))
+    assert np.array_equal(np.asarray(r3, np.float32), scal[[17, 16, 15]].astype(np.float32))    # file: std, scale, mean
+    data = bytes(bytearray(fx["memck_rank_000_learner_data"]))
+    off = 0
+    for i in range(30):                                  # file order = oldest first = position 29 - i
+        n = int(np.frombuffer(data[off:off + 8], np.uint64)[0]); off += 8
+        size = (5 + 1 + 2 + 4 + 6) * n + 10
+        rec = data[off:off + 4 * size]; off += 4 * size
+        assert L.pack_episode(29 - i).tobytes() == rec, i
+    assert off == len(data)
+    out = str(tmp_path / "copy")
+    L.save_memory(out)
+    for suf in names:
+        mine, ref = open(out + suf + ".raw", "rb").read(), bytes(bytearray(fx["memck" + suf]))
+        if suf.endswith("status"):
+            # the reference writes counters.nGradSteps + 1 and restarts into counters.nGradSteps without
+            # taking the 1 back (MemoryBuffer.cpp:303, 250-251): every save / restart cycle adds one
+            assert mine == ref.replace(b"nGradSteps: 13", b"nGradSteps: 14")
+        else:
+            assert mine == ref, suf
+    L.step(5)                                            # restarted learners step without initializeLearner
+    assert L.scalars().nGradSteps == 18
+
+
+@pytest.mark.gpu
+def test_memory_and_network_checkpoint_round_trip_continues_identically(hip_api, tmp_path):
+    """Save network + memory after 40 steps, restart both into a fresh learner (plus the generator
+    state, which the reference does not checkpoint), continue both for 30 steps: identical."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42)
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    A = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    A.init_weights(); fill_synth(A, sc, 30); A.initialize(); A.step(40)
+    base = str(tmp_path / "agent_00")
+    A.save(base + "_net"); A.save_memory(base)
+    Bq = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    Bq.init_weights(); Bq.restart(base + "_net"); Bq.restart_memory(base)
+    Bq.set_rng_state(A.get_rng_state())
+    for p in range(30):
+        assert A.pack_episode(p).tobytes() == Bq.pack_episode(p).tobytes()      # (packing rounds to fp32 on both sides)
+    # the status file is text: beta and CmaxReFER carry 7 significant digits (%le), as in the reference
+    assert abs(Bq.scalars().beta - A.scalars().beta) <= 1e-6 * A.scalars().beta
+    A.step(1); Bq.step(1)
+    assert np.array_equal(A.readback(capi.TAP_FLAT), Bq.readback(capi.TAP_FLAT))
+    assert np.array_equal(A.readback(capi.TAP_OUTPUT), Bq.readback(capi.TAP_OUTPUT))
+    # actions and behaviour policies travel as fp32 in the episode records (Episode.cpp:38-40)
+    assert relinf(A.readback(capi.TAP_RHO), Bq.readback(capi.TAP_RHO)) < 1e-5
+
+
+@pytest.mark.gpu
 def test_long_replayed_runs_are_deterministic(hip_api):
     """Two learners, same seed, 6000 steps each through the replayed graphs (sampler and gather riders,
     in-kernel panel barriers, bookkeeping rider, 1000-step sweeps): weights, moments, beta, far-policy count
