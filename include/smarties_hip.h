@@ -258,6 +258,13 @@ HL_API int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t dst_bytes
 HL_API int hl_get_scalars(hl_learner* h, hl_scalars* out);
 HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
 
+/* ---- statistics surface (third row) ---------------------------------------
+ * The column header and the line Learner::logStats appends to <learner>_stats.txt
+ * (Learners/Learner.cpp:155-195): MemoryBuffer::getHeaders / getMetrics (MemoryBuffer.cpp:522-575),
+ * then the network's AdamOptimizer::getHeaders / getMetrics (Optimizer.cpp:216-226), formatted with
+ * Utilities::real2SS (Utils/SstreamUtilities.h:51-63).  Either buffer may be NULL. */
+HL_API int hl_metrics(hl_learner* h, char* header, int32_t header_cap, char* line, int32_t line_cap);
+
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------- */
 HL_API int hl_comm_unique_id(uint8_t id[128]);             /* rank 0 creates, caller broadcasts */
 HL_API int hl_comm_init(hl_learner* h, const uint8_t id[128]);

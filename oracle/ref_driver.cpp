@@ -368,6 +368,18 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       }
     }
   }
+  {   // the statistics line and header of agent_00_stats.txt for this state (Learner::logStats, Learner.cpp:155-195)
+    const ReplayStats& st0 = L.data->stats;
+    std::vector<double> s0 = {(double)st0.avgKLdivergence, (double)st0.avgSquaredErr, (double)st0.maxAbsError,
+        (double)st0.avgReturn, (double)st0.avgQ, (double)st0.stdevQ, (double)st0.minQ, (double)st0.maxQ, (double)st0.nFarPolicySteps};
+    W.f64("stats_before_metrics", s0);
+    std::ostringstream buf, head;
+    L.data->getMetrics(buf); L.getMetrics(buf);
+    L.data->getHeaders(head); L.getHeaders(head);
+    const std::string sb = buf.str(), sh = head.str();
+    W.u8("metrics_line", std::vector<uint8_t>(sb.begin(), sb.end()));
+    W.u8("metrics_head", std::vector<uint8_t>(sh.begin(), sh.end()));
+  }
   {
     const ReplayStats& st = L.data->stats;
     std::vector<double> s = {(double)st.avgKLdivergence, (double)st.avgSquaredErr, (double)st.maxAbsError,

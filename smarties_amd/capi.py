@@ -161,6 +161,7 @@ class CApi:
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
             "forward": (C.c_int, [P, I32, pf, pd]),
             "save": (C.c_int, [P, C.c_char_p]),
+            "metrics": (C.c_int, [P, C.c_char_p, I32, C.c_char_p, I32]),
             "save_memory": (C.c_int, [P, C.c_char_p, I32]),
             "restart_memory": (C.c_int, [P, C.c_char_p, I32]),
             "packed_episode_size": (C.c_int64, [P, I32]),
@@ -341,6 +342,12 @@ class Learner:
         out = np.zeros(int(self.api.fn("packed_episode_size")(self.h, n)), np.float32)
         self._ck(self.api.fn("pack_episode")(self.h, pos, _ptr(out, C.c_float), out.size))
         return out
+
+    def metrics(self):
+        """(header, line) of <learner>_stats.txt as Learner::logStats formats them."""
+        hd, ln = C.create_string_buffer(1024), C.create_string_buffer(1024)
+        self._ck(self.api.fn("metrics")(self.h, hd, 1024, ln, 1024))
+        return hd.value.decode(), ln.value.decode()
 
     def save_memory(self, base, rank=0):
         """Replay memory + ReF-ER state in the reference's files (MemoryBuffer::save)."""

@@ -16,6 +16,9 @@
 #include <deque>
 #include <map>
 #include <string>
+#include <sstream>
+#include <iomanip>
+#include <limits>
 #include <vector>
 
 #include "kernels.h"
@@ -883,6 +886,59 @@ int hl_pack_episode(hl_learner* h, int64_t pos, float* dst, int64_t cap) {
   const bool term = e.term; const int64_t ID = e.tag, sampled = e.sampled, agentID = e.agentID;
   std::memcpy(cp, &term, sizeof(bool)); cp += sizeof(bool);
   std::memcpy(cp, &ID, 8); cp += 8; std::memcpy(cp, &sampled, 8); cp += 8; std::memcpy(cp, &agentID, 8);
+  return HL_OK;
+}
+
+// ---- statistics line (Learner::logStats: MemoryBuffer::getMetrics + AdamOptimizer::getMetrics) ----
+static void real2SS(std::ostringstream& B, const double V, const int W, const bool bPos) {   // SstreamUtilities.h:51-63
+  B << " " << std::setw(W);
+  if (std::fabs(V) >= 1e4) B << std::setprecision(std::max(W - 7 + bPos, 0));
+  else if (std::fabs(V) >= 1e3) B << std::setprecision(std::max(W - 6 + bPos, 0));
+  else if (std::fabs(V) >= 1e2) B << std::setprecision(std::max(W - 5 + bPos, 0));
+  else if (std::fabs(V) >= 1e1) B << std::setprecision(std::max(W - 4 + bPos, 0));
+  else B << std::setprecision(std::max(W - 3 + bPos, 0));
+  B << std::fixed << V;
+}
+int hl_metrics(hl_learner* h, char* header, int32_t headerCap, char* line, int32_t lineCap) {
+  if (!h) return HL_ERR_BAD_ARG;
+  hl_stats st; int rc = hl_get_stats(h, &st); if (rc) return rc;
+  DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;
+  const bool qStats = st.minQ < st.maxQ;
+  if (line) {
+    std::ostringstream buff;
+    real2SS(buff, st.avgReturn, 9, 0); real2SS(buff, (double)sc.rewMean, 6, 0); real2SS(buff, (double)sc.rewStd, 6, 1);
+    real2SS(buff, st.avgKLdivergence, 5, 1);
+    if (qStats) {
+      const double EPS = std::numeric_limits<float>::epsilon();
+      real2SS(buff, std::sqrt(std::max(EPS, st.avgSquaredErr)), 6, 1); real2SS(buff, st.maxAbsError, 6, 1);
+      real2SS(buff, st.stdevQ, 6, 1); real2SS(buff, st.avgQ, 6, 0); real2SS(buff, st.minQ, 6, 0); real2SS(buff, st.maxQ, 6, 0);
+    }
+    buff << " " << std::setw(5) << (long)h->order.size();
+    buff << " " << std::setw(7) << (long)h->nTransitions;
+    buff << " " << std::setw(7) << (long)h->nSeenEps;
+    buff << " " << std::setw(8) << (long)h->nSeenSteps;
+    buff << " " << std::setw(7) << (long)st.nFarPolicySteps;
+    if (sc.Cmax > 1) real2SS(buff, sc.beta, 6, 1);
+    // AdamOptimizer::getMetrics: L2 norm of the whole (padded) weight blob in long double
+    std::vector<float> w((size_t)h->nParams);
+    rc = hl_get_params(h, w.data(), nullptr, nullptr); if (rc) return rc;
+    long double sum = 0; for (float x : w) sum += (long double)x * (long double)x;
+    real2SS(buff, (double)std::sqrt(sum), 7, 1);
+    const std::string sLine = buff.str();
+    if ((int)sLine.size() + 1 > lineCap) return fail(h, HL_ERR_BAD_ARG, "hl_metrics: line buffer too small");
+    std::memcpy(line, sLine.c_str(), sLine.size() + 1);
+  }
+  if (header) {
+    std::ostringstream buff;
+    buff << "|  avgR  | avgr | stdr | DKL ";
+    if (qStats) buff << "| RMSE |maxErr| stdQ | avgQ | minQ | maxQ ";
+    buff << "| nEp |  nObs | totEp | totObs | nFarP ";
+    if (sc.Cmax > 1) buff << "| beta ";
+    buff << std::left << std::setfill(' ') << "| " << std::setw(6) << "net";
+    const std::string sHead = buff.str();
+    if ((int)sHead.size() + 1 > headerCap) return fail(h, HL_ERR_BAD_ARG, "hl_metrics: header buffer too small");
+    std::memcpy(header, sHead.c_str(), sHead.size() + 1);
+  }
   return HL_OK;
 }
 

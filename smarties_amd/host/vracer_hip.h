@@ -207,11 +207,20 @@ class VRACER {
   Real beta() const { hl_scalars s; ck(hl_get_scalars(H, &s)); return s.beta; }
   long nStoredSteps() const { hl_scalars s; ck(hl_get_scalars(H, &s)); return (long)s.nStoredSteps; }
 
-  // Learner::getMetrics (the ReplayStats / ReF-ER columns of agent_00_stats.txt)
-  void getMetrics(std::ostringstream& buf) const {
-    hl_stats st; hl_scalars s; ck(hl_get_stats(H, &st)); ck(hl_get_scalars(H, &s));
-    buf << " " << st.avgKLdivergence << " " << st.avgSquaredErr << " " << st.maxAbsError << " " << st.avgQ << " " << st.stdevQ
-        << " " << st.minQ << " " << st.maxQ << " " << st.nFarPolicySteps << " " << s.beta << " " << s.CmaxRet;
+  // Learner::getMetrics / getHeaders (Learner.cpp:203-215): the replay-memory columns followed by the network's,
+  // formatted as the reference writes them into agent_00_stats.txt (hl_metrics)
+  void getMetrics(std::ostringstream& buf) const { char head[1024], line[1024]; ck(hl_metrics(H, head, 1024, line, 1024)); buf << line; }
+  void getHeaders(std::ostringstream& buf) const { char head[1024], line[1024]; ck(hl_metrics(H, head, 1024, line, 1024)); buf << head; }
+  // Learner::processStats (Learner.cpp:158-196): one line "<learnID> <step/freqPrint><columns>" appended to
+  // <learner>_stats.txt; the header goes to the file once, at the first print
+  void processStats(const std::string& learnerName, const bool bPrintHeader, const unsigned freqPrint = 1000, const unsigned learnID = 0) const {
+    const unsigned currStep = (unsigned)nGradSteps() + 1, tStamp = currStep / freqPrint;
+    std::ostringstream buf, head; getMetrics(buf);
+    FILE* fout = std::fopen((learnerName + "_stats.txt").c_str(), "a");
+    if (!fout) die("unable to open " + learnerName + "_stats.txt");
+    if (bPrintHeader) { getHeaders(head); if (currStep == freqPrint) std::fprintf(fout, "ID #/T   %s\n", head.str().c_str()); }
+    std::fprintf(fout, "%02u %05u%s\n", learnID, tStamp, buf.str().c_str());
+    std::fclose(fout);
   }
 
   // Learner::save / restart: the networks ("<base>_net_weights.raw", "_1stMom.raw", "_2ndMom.raw",

@@ -130,7 +130,22 @@ int main() {
     bool missing = false;
     try { L2.restart(std::string(dir) + "/nothing_here"); } catch (const std::runtime_error&) { missing = true; }
     CHECK(missing, "restart from a missing file must die");
-    std::ostringstream m; L.getMetrics(m); CHECK(!m.str().empty(), "getMetrics");
+    std::ostringstream m, hd; L.getMetrics(m); L.getHeaders(hd);
+    CHECK(hd.str().rfind("|  avgR  | avgr | stdr | DKL ", 0) == 0 && hd.str().find("| net") != std::string::npos, "getHeaders");
+    {   // one number per header column
+      std::istringstream is(m.str()); double v; int nNum = 0; while (is >> v) ++nNum;
+      int nCol = 0; for (char c : hd.str()) nCol += c == '|';
+      CHECK(nNum == nCol && nNum >= 10, "getMetrics columns");
+    }
+    L.processStats(base, true, (unsigned)L.nGradSteps() + 1);
+    L.processStats(base, false, (unsigned)L.nGradSteps() + 1);
+    FILE* sf = std::fopen((base + "_stats.txt").c_str(), "r"); CHECK(sf != nullptr, "stats file");
+    if (sf) {
+      char row[2048]; int nRows = 0; std::string first;
+      while (std::fgets(row, sizeof(row), sf)) { if (!nRows) first = row; ++nRows; }
+      std::fclose(sf);
+      CHECK(nRows == 3 && first.rfind("ID #/T   |  avgR", 0) == 0, "stats file: header once, then one line per call");
+    }
   }
   ol_destroy(O);
   std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: OK\n", failures);

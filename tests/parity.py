@@ -108,3 +108,40 @@ def check_packed_roundtrip(make_learner, fx):
         assert A.pack_episode(p).tobytes() == Bq.pack_episode(p).tobytes()      # (the trailer bytes read as NaN floats)
     with pytest.raises(Exception):
         A.append_packed_episode(packs[0][:-3])         # wrong size
+
+
+def real2ss(v, w, bpos):
+    """Utilities::real2SS (Utils/SstreamUtilities.h:51-63): ' ' + fixed, width w, precision by magnitude."""
+    a = abs(v)
+    drop = 7 if a >= 1e4 else 6 if a >= 1e3 else 5 if a >= 1e2 else 4 if a >= 10 else 3
+    return " %*.*f" % (w, max(w - drop + bpos, 0), v)
+
+
+def stats_line(L):
+    """The line Learner::logStats writes (MemoryBuffer::getMetrics, MemoryBuffer.cpp:522-548, then
+    AdamOptimizer::getMetrics, Optimizer.cpp:216-220), rebuilt from a learner's read-back state."""
+    st, sc = L.stats(), L.scalars()
+    rew = L.get_scaling()[2]
+    out = real2ss(st.avgReturn, 9, 0) + real2ss(float(rew[0]), 6, 0) + real2ss(float(rew[2]), 6, 1)
+    out += real2ss(st.avgKLdivergence, 5, 1)
+    if st.minQ < st.maxQ:
+        eps = float(np.finfo(np.float32).eps)
+        out += real2ss(np.sqrt(max(eps, st.avgSquaredErr)), 6, 1) + real2ss(st.maxAbsError, 6, 1)
+        out += real2ss(st.stdevQ, 6, 1) + real2ss(st.avgQ, 6, 0) + real2ss(st.minQ, 6, 0) + real2ss(st.maxQ, 6, 0)
+    out += " %5d %7d %7d %8d %7d" % (sc.nStoredEps, sc.nStoredSteps, sc.nSeenEps, sc.nSeenSteps, st.nFarPolicySteps)
+    if sc.CmaxRet > 1:
+        out += real2ss(sc.beta, 6, 1)
+    w = L.get_params()[0].astype(np.longdouble)
+    return out + real2ss(float(np.sqrt((w * w).sum())), 7, 1)
+
+
+def lines_agree(mine, ref, head, rel=0.0):
+    """Same layout; each number equal at the printed precision (2 units of the last digit, or rel)."""
+    if len(mine) != len(ref):
+        return False
+    names = head.replace("|", " ").split()
+    for name, a, b in zip(names, mine.split(), ref.split()):
+        ulp = 10.0 ** -len(b.split(".")[1]) if "." in b else 1.0
+        if abs(float(a) - float(b)) > max(2 * ulp, rel * abs(float(b))):
+            return False
+    return True

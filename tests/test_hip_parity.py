@@ -8,7 +8,7 @@ import pytest
 
 from oracle_api import oracle_learner, fill_synth, synth_cfg, synth_episode
 from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
-                    episode_arrays_by_tag, fixture_arrays_by_tag)
+                    episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree)
 from smarties_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -405,6 +405,38 @@ def test_memory_checkpoint_files_of_the_reference(hip_api, tmp_path):
             assert mine == ref, suf
     L.step(5)                                            # restarted learners step without initializeLearner
     assert L.scalars().nGradSteps == 18
+
+
+@pytest.mark.gpu
+def test_stats_line_matches_reference_log(hip_api):
+    """Replay the 12 steps the reference took (same sampled pairs), then print the statistics line: same
+    header and -- number by number, at the printed precision -- the same line as the reference's own
+    Learner::logStats wrote for that state (MemoryBuffer::getMetrics + AdamOptimizer::getMetrics)."""
+    fx = load_fixture("small_mixed.bin")
+    L = hip_learner(hip_api, fixture_config(fx))
+    setup_from_fixture(L, fx)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        L.step(1, flat=np.sort(our_flat_for(L, fx["s%d_tag" % k], fx["s%d_t" % k]), kind="stable"))
+    head, line = L.metrics()
+    ref_head = bytes(bytearray(fx["metrics_head"])).decode()
+    assert head == ref_head
+    assert lines_agree(line, bytes(bytearray(fx["metrics_line"])).decode(), head), line
+    assert lines_agree(line, stats_line(L), head)
+
+
+@pytest.mark.gpu
+def test_stats_line_after_the_thousand_step_sweep_matches_oracle(hip_api):
+    """1200 free-running steps of the traj_1200 configuration (larger numbers: other precision branches of
+    real2SS, Q statistics present, beta column): the library's line against the line rebuilt from the
+    oracle's state (tests/parity.stats_line, itself pinned to the reference's line in the CPU suite)."""
+    fx = load_fixture("traj_1200.bin")
+    G, O = hip_learner(hip_api, fixture_config(fx)), oracle_learner(fixture_config(fx))
+    for L in (G, O):
+        setup_from_fixture(L, fx)
+        L.step(1200)
+    head, line = G.metrics()
+    assert head == bytes(bytearray(fx["metrics_head"])).decode()
+    assert lines_agree(line, stats_line(O), head, rel=1e-3), (line, stats_line(O))
 
 
 @pytest.mark.gpu

@@ -5,7 +5,7 @@ import pytest
 
 from oracle_api import oracle_learner, synth_episode
 from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
-                    episode_arrays_by_tag, fixture_arrays_by_tag)
+                    episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree)
 from smarties_amd import capi
 
 FUNC_OF = {"deep_tanh.bin": "Tanh"}
@@ -131,6 +131,9 @@ def test_long_trajectory_crosses_1000_step_sweep():
     mine = [st.avgKLdivergence, st.avgSquaredErr, st.maxAbsError, st.avgReturn, st.avgQ, st.stdevQ, st.minQ, st.maxQ]
     assert np.allclose(mine, ref[:8], rtol=1e-4, atol=1e-6)
     assert st.nFarPolicySteps == int(ref[8])
+    # the statistics line of agent_00_stats.txt for this state, as the reference itself printed it
+    head = bytes(bytearray(fx["metrics_head"])).decode()
+    assert lines_agree(stats_line(L), bytes(bytearray(fx["metrics_line"])).decode(), head)
 
 
 @pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin"])
