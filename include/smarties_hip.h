@@ -84,7 +84,7 @@ enum { HL_ORDER_STABLE = 0,     /* stable sort by ID, newest first (product sema
                                    (oracle only: reproduces the reference's permutation) */
 
 /*
- * Learner configuration = the settings/*.json Learner surface
+ * Learner configuration = the settings/<name>.json Learner surface
  * (Settings/HyperParameters.cpp:132-171) + the MDP descriptor fields the hot
  * path reads (Core/StateAction.h:57-112) + process layout.
  */
@@ -264,6 +264,15 @@ HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
  * then the network's AdamOptimizer::getHeaders / getMetrics (Optimizer.cpp:216-226), formatted with
  * Utilities::real2SS (Utils/SstreamUtilities.h:51-63).  Either buffer may be NULL. */
 HL_API int hl_metrics(hl_learner* h, char* header, int32_t header_cap, char* line, int32_t line_cap);
+
+/* Output-gradient statistics (Utils/StatsTracker.cpp:28-107, fed by Approximator::setGradient,
+ * Network/Approximator.h:197): mean and root-mean-square over the last minibatch of each network
+ * output's gradient (nOutputs values each).  hl_set_log_base(h, "<learner_name>") makes hl_step /
+ * hl_step_end append them to <learner_name>_net_outGrad_stats.raw for the steps with
+ * nGradSteps % 1000 == 0, in the reference's format (first a float nOutputs + 0.1, then 2*nOutputs floats
+ * per record; rank 0 only), as Learner_approximator.cpp:89 does.  NULL / "" switches the file off. */
+HL_API int hl_grad_stats(hl_learner* h, double* mean, double* rms);
+HL_API int hl_set_log_base(hl_learner* h, const char* base);
 
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------- */
 HL_API int hl_comm_unique_id(uint8_t id[128]);             /* rank 0 creates, caller broadcasts */

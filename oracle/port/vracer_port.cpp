@@ -204,6 +204,10 @@ struct ol_learner {
   std::vector<int64_t> bFlat, bEp, bT, bTag;
   std::vector<float> tState; std::vector<double> tO, tG, tRho, tDkl, tDq; std::vector<uint8_t> tFar;
   std::vector<nnReal> tGradSum;
+  // Utils/StatsTracker.cpp: sums of the output gradients over the minibatch, mean / RMS of the last one
+  std::vector<long double> gsSum, gsSq; std::vector<double> gsMean, gsRms;
+  int64_t gsCalls = 0;           // StatsTracker::nStep
+  std::string logBase;           // "<learner_name>": <logBase>_net_outGrad_stats.raw
 };
 
 namespace {
@@ -830,6 +834,7 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     h->tRho.assign(B, 0); h->tDkl.assign(B, 0); h->tDq.assign(B, 0); h->tFar.assign(B, 0); }
   std::vector<nnReal> inp(dS); std::vector<Real> O(nOut), On(nOut), grad(nOut);
   const size_t outDense = h->layers.size() - 2, outParam = h->layers.size() - 1;
+  h->gsSum.assign(nOut, 0); h->gsSq.assign(nOut, 0);
   for (int b = 0; b < B; ++b) {
     Episode& EP = *h->episodes[h->bEp[b]]; const int t = (int)h->bT[b];
     h->bTag[b] = EP.tag;
@@ -847,6 +852,7 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     Real rho, dkl, dq, V; int far;
     ol_head_vracer(dA, h->cfg.bounded, O.data(), &EP.A[(size_t)t * dA], &EP.MU[(size_t)t * 2 * dA],
                    (Real)EP.RET[t], h->beta, h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V);
+    for (int o = 0; o < nOut; ++o) { h->gsSum[o] += grad[o]; h->gsSq[o] += grad[o] * grad[o]; }   // StatsTracker::track_vector (Approximator.h:197)
     // Approximator::setGradient -> Activation::addOutputDelta (Approximator.h:190-204, Activation.h:108-117)
     for (auto& e : h->E) std::fill(e.begin(), e.end(), 0);
     for (int o = 0; o < 1 + dA; ++o) h->E[outDense][o] += grad[o];
@@ -862,6 +868,20 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     backwardNet(h);
   }
   if (h->tap) h->tGradSum = h->G;
+  {   // StatsTracker::reduce_stats (StatsTracker.cpp:100-107) as called by Learner_approximator.cpp:89 with iter = nGradSteps
+    h->gsMean.resize(nOut); h->gsRms.resize(nOut);
+    const long double cnt = std::max((long double)2.2e-16, (long double)B);
+    for (int o = 0; o < nOut; ++o) { h->gsMean[o] = (Real)(h->gsSum[o] / cnt); h->gsRms[o] = (Real)std::sqrt((Real)(h->gsSq[o] / cnt)); }
+    if (!h->logBase.empty() && h->nGradSteps % 1000 == 0 && h->cfg.rank == 0) {
+      FILE* f = fopen((h->logBase + "_net_outGrad_stats.raw").c_str(), h->gsCalls ? "ab" : "wb");
+      if (!f) return fail(h, HL_ERR_IO, "unable to open " + h->logBase + "_net_outGrad_stats.raw");
+      if (!h->gsCalls) { const float hd = nOut + .1; fwrite(&hd, sizeof(float), 1, f); }
+      std::vector<float> v(2 * (size_t)nOut);
+      for (int o = 0; o < nOut; ++o) { v[o] = (float)h->gsMean[o]; v[o + nOut] = (float)h->gsRms[o]; }
+      fwrite(v.data(), sizeof(float), v.size(), f); fclose(f);
+    }
+    h->gsCalls++;
+  }
   h->nStep++;   // AdamOptimizer::prepare_update (Optimizer.cpp:119)
   // Learner::processMemoryBuffer (Learner.cpp:74-100) up to the counters all-reduce; none of
   // it reads the (possibly still in flight) gradient sum, so doing it here keeps the order
@@ -1044,6 +1064,13 @@ int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs) {
   }
   return HL_OK;
 }
+int ol_grad_stats(ol_learner* h, double* mean, double* rms) {
+  if (!h || !mean || !rms) return HL_ERR_BAD_ARG;
+  if (h->gsMean.empty()) return fail(h, HL_ERR_STATE, "no gradient step yet");
+  std::copy(h->gsMean.begin(), h->gsMean.end(), mean); std::copy(h->gsRms.begin(), h->gsRms.end(), rms);
+  return HL_OK;
+}
+int ol_set_log_base(ol_learner* h, const char* base) { if (!h) return HL_ERR_BAD_ARG; h->logBase = base ? base : ""; return HL_OK; }
 int ol_set_tap(ol_learner* h, int32_t e) { if (!h) return HL_ERR_BAD_ARG; h->tap = e != 0; return HL_OK; }
 
 int ol_readback(ol_learner* h, int32_t what, void* dst, int64_t bytes) {

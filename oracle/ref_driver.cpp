@@ -380,6 +380,18 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     W.u8("metrics_line", std::vector<uint8_t>(sb.begin(), sb.end()));
     W.u8("metrics_head", std::vector<uint8_t>(sh.begin(), sh.end()));
   }
+  {   // output-gradient statistics (Utils/StatsTracker.cpp): the file the run wrote at iter % 1000 == 0 and the
+      // mean / RMS over the last minibatch
+    FILE* f = fopen((L.learner_name + "_net_outGrad_stats.raw").c_str(), "rb");
+    std::vector<uint8_t> bytes;
+    if (f) { int c; while ((c = fgetc(f)) != EOF) bytes.push_back((uint8_t)c); fclose(f); }
+    W.u8("outgrad_stats_file", bytes);
+    const StatsTracker* T = NET.gradStats;
+    std::vector<double> inst;
+    for (Uint i = 0; i < T->n_stats; ++i) inst.push_back((double)T->instMean[i]);
+    for (Uint i = 0; i < T->n_stats; ++i) inst.push_back((double)T->instStdv[i]);
+    W.f64("outgrad_stats_last", inst);
+  }
   {
     const ReplayStats& st = L.data->stats;
     std::vector<double> s = {(double)st.avgKLdivergence, (double)st.avgSquaredErr, (double)st.maxAbsError,

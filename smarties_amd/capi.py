@@ -162,6 +162,8 @@ class CApi:
             "forward": (C.c_int, [P, I32, pf, pd]),
             "save": (C.c_int, [P, C.c_char_p]),
             "metrics": (C.c_int, [P, C.c_char_p, I32, C.c_char_p, I32]),
+            "grad_stats": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+            "set_log_base": (C.c_int, [P, C.c_char_p]),
             "save_memory": (C.c_int, [P, C.c_char_p, I32]),
             "restart_memory": (C.c_int, [P, C.c_char_p, I32]),
             "packed_episode_size": (C.c_int64, [P, I32]),
@@ -348,6 +350,15 @@ class Learner:
         hd, ln = C.create_string_buffer(1024), C.create_string_buffer(1024)
         self._ck(self.api.fn("metrics")(self.h, hd, 1024, ln, 1024))
         return hd.value.decode(), ln.value.decode()
+
+    def grad_stats(self):
+        """mean, RMS of every network output's gradient over the last minibatch (StatsTracker)."""
+        m, r = np.zeros(self.nOut, np.float64), np.zeros(self.nOut, np.float64)
+        self._ck(self.api.fn("grad_stats")(self.h, _ptr(m, C.c_double), _ptr(r, C.c_double)))
+        return m, r
+
+    def set_log_base(self, base):
+        self._ck(self.api.fn("set_log_base")(self.h, base.encode() if base else None))
 
     def save_memory(self, base, rank=0):
         """Replay memory + ReF-ER state in the reference's files (MemoryBuffer::save)."""

@@ -60,6 +60,7 @@ struct hl_learner {
   int ldX0 = 0; int lastParity = 0;        // buffer used by the last executed step (taps)
   DevHidden hid[HL_MAX_HIDDEN];
   float* dOut = nullptr; int ldDo = 0;
+  std::string logBase; long long gsCalls = 0;     // StatsTracker file (<logBase>_net_outGrad_stats.raw) and its nStep
   long long indWo = 0, indBo = 0, indBp = 0; int ldWo = 0;
   // gemm problem tables (device) + launch geometry
   GemmProblem* dProbs = nullptr;           // all GEMM problems of both buffers, contiguous
@@ -415,6 +416,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->Bglobal = cfg->batchSize > 1 ? (int)(std::ceil(cfg->batchSize / nL) * nL) : cfg->batchSize;
   h->B = cfg->batchSize > 1 ? h->Bglobal / cfg->n_ranks : h->Bglobal;
   if (h->B > 1024) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024");
+  if (h->dS > 512) return fail(h, HL_ERR_UNSUPPORTED, "more than 512 observed state components");   // gather staging (tail_dev.h)
   for (int j = 0; j < cfg->n_hidden; ++j)
     if (cfg->hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
   h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);
@@ -742,13 +744,48 @@ static int preStepChecks(hl_learner* h) {
   return flushPending(h);
 }
 
+// StatsTracker (Utils/StatsTracker.cpp:28-107): mean / RMS of the output gradients of the last minibatch
+static int gradStatsOfLastBatch(hl_learner* h, double* mean, double* rms) {
+  const int B = h->B, nOut = h->nOut;
+  std::vector<double> G((size_t)B * nOut);
+  HIPCK(hipStreamSynchronize(h->stream));
+  HIPCK(hipMemcpy(G.data(), h->buf[h->lastParity].bt.G, G.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const long double cnt = std::max((long double)2.2e-16, (long double)B);
+  for (int o = 0; o < nOut; ++o) {
+    long double a = 0, q = 0;
+    for (int b = 0; b < B; ++b) { const long double g = G[(size_t)b * nOut + o]; a += g; q += g * g; }
+    mean[o] = (double)(a / cnt); rms[o] = std::sqrt((double)(q / cnt));
+  }
+  return HL_OK;
+}
+int hl_grad_stats(hl_learner* h, double* mean, double* rms) {
+  if (!h || !mean || !rms) return HL_ERR_BAD_ARG;
+  if (h->gsCalls == 0 && !h->inStep) return fail(h, HL_ERR_STATE, "no gradient step yet");
+  return gradStatsOfLastBatch(h, mean, rms);
+}
+int hl_set_log_base(hl_learner* h, const char* base) { if (!h) return HL_ERR_BAD_ARG; h->logBase = base ? base : ""; return HL_OK; }
+static int appendGradStats(hl_learner* h) {      // StatsTracker::printToFile (StatsTracker.cpp:65-85)
+  if (h->cfg.rank != 0) return HL_OK;
+  std::vector<double> m((size_t)h->nOut), r((size_t)h->nOut);
+  int rc = gradStatsOfLastBatch(h, m.data(), r.data()); if (rc) return rc;
+  const std::string name = h->logBase + "_net_outGrad_stats.raw";
+  FILE* f = std::fopen(name.c_str(), h->gsCalls ? "ab" : "wb");
+  if (!f) return fail(h, HL_ERR_IO, "unable to open " + name);
+  if (!h->gsCalls) { const float hd = h->nOut + .1; std::fwrite(&hd, sizeof(float), 1, f); }
+  std::vector<float> v(2 * (size_t)h->nOut);
+  for (int o = 0; o < h->nOut; ++o) { v[o] = (float)m[o]; v[o + h->nOut] = (float)r[o]; }
+  std::fwrite(v.data(), sizeof(float), v.size(), f); std::fclose(f);
+  return HL_OK;
+}
+
 int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
   if (!h || n < 0) return HL_ERR_BAD_ARG;
   int s = 0;
   while (s < n) {
     int rc = preStepChecks(h); if (rc) return rc;
     const long long k = h->nGradSteps + 1;
-    const bool plain = !flat && (k % 1000) != 0 && !evictionDue(h) && !h->timing && h->useGraph &&
+    const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
+    const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
                        (!exchanging(h) || (h->fusedOk && h->exchGraph && h->comm));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
@@ -756,7 +793,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
       const long long avail = std::min<long long>(n - s, 999 - (h->nGradSteps % 1000));
       int done = 0;
       rc = replaySteps(h, avail, &done); if (rc) return rc;
-      if (done > 0) { h->nGradSteps += done; s += done; continue; }
+      if (done > 0) { h->nGradSteps += done; h->gsCalls += done; s += done; continue; }
     }
     const long long* dFlat = nullptr;
     if (flat) {
@@ -765,6 +802,8 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
       dFlat = h->dFlatGiven;
     }
     rc = stepEager(h, dFlat); if (rc) return rc;
+    if (logStep) { rc = appendGradStats(h); if (rc) return rc; }
+    h->gsCalls += 1;
     h->nGradSteps += 1; s += 1;
   }
   return HL_OK;
@@ -826,6 +865,8 @@ int hl_step_end(hl_learner* h) {
   if (h->momentsPending) { rc = launchMomentsApply(h, false, 10); if (rc) return rc; h->momentsPending = false; }
   rc = launchAdam(h, 0); if (rc) return rc;
   rc = launchPost(h, 0, POST_BETA, h->stream); if (rc) return rc;
+  if (!h->logBase.empty() && (h->nGradSteps % 1000) == 0) { rc = appendGradStats(h); if (rc) return rc; }
+  h->gsCalls += 1;
   h->nGradSteps += 1; h->inStep = false;
   return HL_OK;
 }

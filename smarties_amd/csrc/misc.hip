@@ -152,8 +152,9 @@ hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const f
 // r = tid / (dS+1); every thread owns one column, so sums are order-deterministic.
 __global__ __launch_bounds__(256) void moments_partial_kernel(MomentsArgs a) {
   __shared__ double s1[256], s2[256];
-  const int dS = a.dS, CW = dS + 1, RL = 256 / CW, tid = threadIdx.x;
-  const int c = tid % CW, r = tid / CW;
+  // wide states (dS + 1 > 256, e.g. Humanoid's 257): blockIdx.y selects a chunk of 256 columns
+  const int dS = a.dS, CW = dS + 1, c0 = blockIdx.y * 256, CC = min(CW - c0, 256), RL = 256 / CC, tid = threadIdx.x;
+  const int cl = tid % CC, c = c0 + cl, r = tid / CC;
   const bool active = r < RL;
   double sum = 0, sq = 0;
   const float rMean = a.sc->rewMean;
@@ -171,11 +172,11 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(MomentsArgs a) {
   }
   s1[tid] = sum; s2[tid] = sq;
   __syncthreads();
-  if (tid < CW) {
+  if (tid < CC) {
     double t1 = 0, t2 = 0;
-    for (int q = 0; q < RL; ++q) { t1 += s1[q * CW + tid]; t2 += s2[q * CW + tid]; }
-    a.partial[(size_t)blockIdx.x * 2 * CW + tid] = t1;
-    a.partial[(size_t)blockIdx.x * 2 * CW + CW + tid] = t2;
+    for (int q = 0; q < RL; ++q) { t1 += s1[q * CC + tid]; t2 += s2[q * CC + tid]; }
+    a.partial[(size_t)blockIdx.x * 2 * CW + c0 + tid] = t1;
+    a.partial[(size_t)blockIdx.x * 2 * CW + CW + c0 + tid] = t2;
   }
 }
 // moments layout (MemoryProcessing.cpp:139-150): [sum s (dS) | sum s^2 (dS) | count | sum r | sum r^2]
@@ -220,8 +221,7 @@ __global__ void moments_apply_kernel(MomentsArgs a) {
 }
 int moments_blocks(int nEpisodes) { int b = nEpisodes; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s) {
-  if (a.dS + 1 > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(moments_partial_kernel, dim3(a.nBlocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(moments_partial_kernel, dim3(a.nBlocks, (a.dS + 1 + 255) / 256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(moments_final_kernel, dim3((2 * (a.dS + 1) + 3) / 4), dim3(256), 0, s, a);
   return hipGetLastError();
 }

@@ -146,7 +146,10 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       // updateTrainingStatistics: ReF-ER clip annealing for the NEXT sampling (:193-196)
       const double Cm = 1 + a.clipImpWeight / (1 + (double)(nGrad0 + 1) * a.epsAnneal);
       if (Cm <= 1) nFarTot = 0;
-      nFarStat = nFarTot;
+      // the reported count is unsigned in the reference (ReplayStats::nFarPolicySteps); the running total may dip
+      // below zero right after the start when clipImpWeight < 1 (MemoryBuffer.h:44 starts CinvRet at 1/C0 > 1, so
+      // never-sampled steps count as "were far") -- it stays exact, the statistic is clamped
+      nFarStat = nFarTot > 0 ? nFarTot : 0;
       sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
       sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
       if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce

@@ -211,6 +211,12 @@ class VRACER {
   // formatted as the reference writes them into agent_00_stats.txt (hl_metrics)
   void getMetrics(std::ostringstream& buf) const { char head[1024], line[1024]; ck(hl_metrics(H, head, 1024, line, 1024)); buf << line; }
   void getHeaders(std::ostringstream& buf) const { char head[1024], line[1024]; ck(hl_metrics(H, head, 1024, line, 1024)); buf << head; }
+  // Approximator::updateGradStats (Approximator.h:65-68): <learnerName>_net_outGrad_stats.raw, written by the
+  // library at the steps with nGradSteps % 1000 == 0 once the name is set; gradStats() = last minibatch
+  void setLearnerName(const std::string& learnerName) { ck(hl_set_log_base(H, learnerName.c_str())); }
+  void gradStats(std::vector<Real>& mean, std::vector<Real>& rms) const {
+    mean.resize((size_t)nOut); rms.resize((size_t)nOut); ck(hl_grad_stats(H, mean.data(), rms.data()));
+  }
   // Learner::processStats (Learner.cpp:158-196): one line "<learnID> <step/freqPrint><columns>" appended to
   // <learner>_stats.txt; the header goes to the file once, at the first print
   void processStats(const std::string& learnerName, const bool bPrintHeader, const unsigned freqPrint = 1000, const unsigned learnID = 0) const {

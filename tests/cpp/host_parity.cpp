@@ -137,6 +137,7 @@ int main() {
       int nCol = 0; for (char c : hd.str()) nCol += c == '|';
       CHECK(nNum == nCol && nNum >= 10, "getMetrics columns");
     }
+    { std::vector<double> gm, gr; L.gradStats(gm, gr); CHECK(gm.size() == gr.size() && !gm.empty() && gr[0] >= std::fabs(gm[0]), "gradStats"); }
     L.processStats(base, true, (unsigned)L.nGradSteps() + 1);
     L.processStats(base, false, (unsigned)L.nGradSteps() + 1);
     FILE* sf = std::fopen((base + "_stats.txt").c_str(), "r"); CHECK(sf != nullptr, "stats file");

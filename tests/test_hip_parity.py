@@ -144,6 +144,17 @@ def _compare_step(G, O):
     (dict(dimS=20, dimA=4, bounded=[0, 1, 1, 0], hidden=(128, 128), nnFunc="Relu", batchSize=100, maxTotObsNum=20000,
           randSeed=21, nnLambda=1e-5),
      dict(seed=17, dimS=20, dimA=4, lenMin=30, lenMax=90, pTerm=0.3), 150, 10),
+    # BASELINE.json configs[0]: cart_pole_cpp + settings/VRACER.json with the code defaults of
+    # Settings/HyperParameters.h:42-72 (observed state 5, one action bounded, 2x128 Tanh, batch 256,
+    # C = sqrt(dA/2), replay 2^14 sqrt(dA+dS))
+    (dict(dimS=5, dimA=1, bounded=[1], hidden=(128, 128), nnFunc="Tanh", batchSize=256, maxTotObsNum=40131,
+          clipImpWeight=0.5 ** 0.5, gamma=0.995, learnrate=1e-4, explNoise=0.2 ** 0.5, randSeed=31),
+     dict(seed=23, dimS=5, dimA=1, lenMin=20, lenMax=200, pTerm=0.9), 60, 10),
+    # BASELINE.json configs[2]: Humanoid-v2 through apps/OpenAI_gym/HumanoidWrapper.py (257 observed states,
+    # 17 unbounded actions, 2x256), the share of ONE of its 8 replicas: local batch 32 (generic five-launch path)
+    (dict(dimS=257, dimA=17, bounded=[0] * 17, hidden=(256, 256), batchSize=32, maxTotObsNum=60000,
+          clipImpWeight=(17 / 2.0) ** 0.5, randSeed=33),
+     dict(seed=29, dimS=257, dimA=17, lenMin=20, lenMax=120, pTerm=0.5, muSpread=0.2), 40, 8),
 ])
 def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
     """Device-side mt19937 sampler (Lemire + sort/unique/redraw), gather, MLP, head, ReF-ER
@@ -422,6 +433,42 @@ def test_stats_line_matches_reference_log(hip_api):
     assert head == ref_head
     assert lines_agree(line, bytes(bytearray(fx["metrics_line"])).decode(), head), line
     assert lines_agree(line, stats_line(L), head)
+
+
+@pytest.mark.gpu
+def test_output_gradient_statistics_file_matches_reference(hip_api, tmp_path):
+    """StatsTracker (Utils/StatsTracker.cpp): <learner>_net_outGrad_stats.raw as the compiled reference wrote
+    it for the same 12 steps (one record, at step 0), and the mean / RMS over the last minibatch."""
+    fx = load_fixture("small_mixed.bin")
+    L = hip_learner(hip_api, fixture_config(fx))
+    setup_from_fixture(L, fx)
+    L.set_log_base(str(tmp_path / "agent_00"))
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        L.step(1, flat=np.sort(our_flat_for(L, fx["s%d_tag" % k], fx["s%d_t" % k]), kind="stable"))
+    ref_file = np.frombuffer(bytes(bytearray(fx["outgrad_stats_file"])), np.float32)
+    mine_file = np.fromfile(str(tmp_path / "agent_00_net_outGrad_stats.raw"), np.float32)
+    assert mine_file.size == ref_file.size == 1 + 2 * L.nOut and mine_file[0] == ref_file[0]
+    assert relinf(mine_file[1:], ref_file[1:]) < TOL32
+    m, r = L.grad_stats()
+    assert relinf(np.concatenate([m, r]), fx["outgrad_stats_last"]) < TOL32
+
+
+@pytest.mark.gpu
+def test_output_gradient_statistics_across_graph_replays_match_oracle(hip_api, tmp_path):
+    """2100 free-running steps with the log switched on: records at steps 0, 1000 and 2000 (the library has to
+    leave its graphs for exactly those steps), equal to the oracle's file."""
+    fx = load_fixture("traj_1200.bin")
+    G, O = hip_learner(hip_api, fixture_config(fx)), oracle_learner(fixture_config(fx))
+    for L, nm in ((G, "g"), (O, "o")):
+        setup_from_fixture(L, fx)
+        L.set_log_base(str(tmp_path / nm))
+        L.step(700); L.step(1400)
+    fg = np.fromfile(str(tmp_path / "g_net_outGrad_stats.raw"), np.float32)
+    fo = np.fromfile(str(tmp_path / "o_net_outGrad_stats.raw"), np.float32)
+    assert fg.size == fo.size == 1 + 3 * 2 * G.nOut and fg[0] == fo[0]
+    assert np.allclose(fg, fo, rtol=1e-3, atol=1e-6)
+    assert G.scalars().nGradSteps == O.scalars().nGradSteps == 2100
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
 
 
 @pytest.mark.gpu

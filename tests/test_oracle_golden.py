@@ -101,11 +101,12 @@ def test_far_policy_masks_are_exercised():
     assert 0 < far.sum() < far.size
 
 
-def test_long_trajectory_crosses_1000_step_sweep():
+def test_long_trajectory_crosses_1000_step_sweep(tmp_path):
     """1200 steps: beta / CmaxRet / nFarPolicySteps trajectories, the 1000-step
     Episode::updateCumulative + full Retrace sweep and the reward/state statistics EMA."""
     fx, L = make("traj_1200.bin")
     setup_from_fixture(L, fx)
+    L.set_log_base(str(tmp_path / "agent_00"))
     lens = {e: synth_episode(fixture_synth(fx), e)["rewards"].size for e in range(int(fx["cfg"][3]))}
     for k in range(1, 1201):
         L.step(1)
@@ -131,6 +132,14 @@ def test_long_trajectory_crosses_1000_step_sweep():
     mine = [st.avgKLdivergence, st.avgSquaredErr, st.maxAbsError, st.avgReturn, st.avgQ, st.stdevQ, st.minQ, st.maxQ]
     assert np.allclose(mine, ref[:8], rtol=1e-4, atol=1e-6)
     assert st.nFarPolicySteps == int(ref[8])
+    # StatsTracker: the output-gradient statistics file the reference wrote at steps 0 and 1000, and the
+    # mean / RMS over its last minibatch
+    ref_file = np.frombuffer(bytes(bytearray(fx["outgrad_stats_file"])), np.float32)
+    mine_file = np.fromfile(str(tmp_path / "agent_00_net_outGrad_stats.raw"), np.float32)
+    assert mine_file.size == ref_file.size == 1 + 2 * 2 * L.nOut and mine_file[0] == ref_file[0]
+    assert np.allclose(mine_file, ref_file, rtol=2e-5, atol=1e-7)
+    m, r = L.grad_stats()
+    assert np.allclose(np.concatenate([m, r]), fx["outgrad_stats_last"], rtol=2e-5, atol=1e-7)
     # the statistics line of agent_00_stats.txt for this state, as the reference itself printed it
     head = bytes(bytearray(fx["metrics_head"])).decode()
     assert lines_agree(stats_line(L), bytes(bytearray(fx["metrics_line"])).decode(), head)
