@@ -41,9 +41,6 @@ namespace hl {
 #define FSTAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ void st_agent(float* p, float v) {   // write-through to the agent coherence point
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // activation evaluated with the function known at compile time; dispatchFunc() branches ONCE on the
 // (uniform) function id and runs the whole epilogue branch-free
 // n / d for d in [1, 2^60): reciprocal + Newton step + two residual corrections -- the IEEE division
@@ -193,6 +190,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   float* sBp = sBo + 16;
 
   const int tid = threadIdx.x, lane = tid & 63;
+  __builtin_assume(tid >= 0 && tid < NT);      // lets the `tid + NT * q < count` guards of full chunks fold away
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches on it
   const int li = lane & 15, lc = lane >> 4;
   const bool eth = tid < 256;                                  // element thread: owns output element / (sample, dim) (em, en)
@@ -205,6 +203,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const bool rowValid = eth && row < nRows, isNext = rowValid && row >= B;
   int bSrc = 0; long long slot = 0;
   if (rowValid) { bSrc = isNext ? a.bt.nextSrc[row - B] : row; slot = a.bt.slot[bSrc]; }   // oldest loads: the gathers hang off them
+  int eidv = 0;
+  if (rowValid && !isNext) eidv = a.bt.eid[row];
   float sv[QS];
 #pragma unroll
   for (int q = 0; q < QS; ++q) {
@@ -216,8 +216,10 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const int nW0 = dSp * H4;
 #pragma unroll
   for (int q = 0; q < Q0; ++q) {
-    const int f = tid + NT * q; w0v[q] = z4;
-    if (f < nW0) { const int k = f / H4, c4 = f % H4; if (k < dS) w0v[q] = *reinterpret_cast<const f32x4*>(W0 + (size_t)k * a.ldW0 + 4 * c4); }
+    // no guards: rows >= dS read row dS-1 again (finite weights) and meet state columns that are zero, so they add
+    // exactly 0; a guarded load would make the compiler wait for it at the join, ahead of all the loads below
+    const int f = tid + NT * q, k = f / H4, c4 = f % H4;
+    w0v[q] = *reinterpret_cast<const f32x4*>(W0 + (size_t)(k < dS ? k : dS - 1) * a.ldW0 + 4 * c4);
   }
 #pragma unroll
   for (int q = 0; q < QC; ++q) {
@@ -231,27 +233,6 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const float b1e = eth ? W[a.indB1 + n0 + en] : 0.f;
   const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
-  // publishing workgroup of the sample: the aggregates of the sampled episode travel with it to the
-  // bookkeeping pass, which then needs no dependent gather (the store happens at the very end)
-  float aggv = 0.f;
-  if (((em & (HT - 1)) == n) && rowValid && !isNext && en < AGG_N) {
-    const int eidv = a.bt.eid[bSrc];
-    aggv = en < AGG_USED ? a.rp.epAgg[(size_t)eidv * AGG_N + en] : (en == AGG_LEN ? (float)a.rp.epN[eidv] : 0.f);
-  }
-
-  // the replay rows of the head (issued now, consumed after the exchange): one (sample, dim) per thread
-  double act = 0, bMean = 0, bStd = 1; float misc = 0.f;
-  if (rowValid && !isNext && en < dA) {
-    act = a.rp.A[(size_t)slot * dA + en];
-    bMean = a.rp.MU[(size_t)slot * 2 * dA + en]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + en];
-  }
-  if (rowValid) {   // lanes 0..5: RET, DQ, DKL, IMPW, V, ADV of the sampled step; next rows: lanes 6, 7: V, ADV of t+1
-    const float* arr = nullptr; long long sl = slot;
-    if (!isNext) arr = en == 0 ? a.rp.RET : en == 1 ? a.rp.DQ : en == 2 ? a.rp.DKL : en == 3 ? a.rp.IMPW : en == 4 ? a.rp.V : en == 5 ? a.rp.ADV : nullptr;
-    else { arr = en == 6 ? a.rp.V : en == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
-    if (arr) misc = arr[sl];
-  }
-
   // ---- stage: states, W0 (k-major), W1 column tile (k-major), Wout, vectors ------------------------
 #pragma unroll
   for (int q = 0; q < QS; ++q) { const int idx = tid + NT * q, r = idx >> 5, c = idx & 31; sS[r * FLDS + c] = sv[q]; }
@@ -275,6 +256,25 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     const int f = tid + NT * q; w1r[q] = z4;
     if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w1r[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(n0 + r) * a.ldW1 + 4 * c4); }
   }
+  // publishing workgroup of the sample: the aggregates of the sampled episode travel with it to the
+  // bookkeeping pass, which then needs no dependent gather (the store happens at the very end)
+  // (issued here, behind the first batch and its barrier: they hang off `slot` / `eid`, and a dependent load in the
+  // prologue makes everything after it wait for a second HBM round trip)
+  const bool aggOwner = ((em & (HT - 1)) == n) && rowValid && !isNext && en < AGG_N;
+
+  // the replay rows of the head (issued now, consumed after the exchange): one (sample, dim) per thread
+  double act = 0, bMean = 0, bStd = 1; float misc = 0.f;
+  if (rowValid && !isNext && en < dA) {
+    act = a.rp.A[(size_t)slot * dA + en];
+    bMean = a.rp.MU[(size_t)slot * 2 * dA + en]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + en];
+  }
+  if (rowValid) {   // lanes 0..5: RET, DQ, DKL, IMPW, V, ADV of the sampled step; next rows: lanes 6, 7: V, ADV of t+1
+    const float* arr = nullptr; long long sl = slot;
+    if (!isNext) arr = en == 0 ? a.rp.RET : en == 1 ? a.rp.DQ : en == 2 ? a.rp.DKL : en == 3 ? a.rp.IMPW : en == 4 ? a.rp.V : en == 5 ? a.rp.ADV : nullptr;
+    else { arr = en == 6 ? a.rp.V : en == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
+    if (arr) misc = arr[sl];
+  }
+
 
   // ---- h1 = f(S W0 + b0), whole panel: wave w computes column tiles w, w+4, ... --------------------
   if (wave < HT) {
@@ -324,6 +324,9 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   FSTAMP(2);
   if (a.variant == 2) return;
   if (eth && row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
+  float aggv = 0.f;
+  asm volatile("" : "+v"(eidv));      // keeps the index arithmetic (and the wait for the load) from being hoisted into the prologue
+  if (aggOwner) aggv = en < AGG_USED ? a.rp.epAgg[(size_t)eidv * AGG_N + en] : (en == AGG_LEN ? (float)a.rp.epN[eidv] : 0.f);
 
   // ---- head terms that do not depend on the network outputs of this step (the policy stdev comes
   // from the ParamLayer bias alone).  With 8 waves the element threads (waves 0-3) compute them
@@ -367,14 +370,17 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     float y2 = 0.f, f2 = 0.f;
     dispatchFunc<CF>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y2 = actEvalT<FN>(x2); f2 = actDiffT<FN>(x2, y2); });
     const float y3 = (n0 + en < resN) ? resOut(y2, y1o, sWr[n0 + en], sBr[n0 + en]) : y2;
-    st_agent(gR2 + (size_t)row * ldA1 + n0 + en, y3);      // also the A operand of dWout
-    st_agent(gX2 + (size_t)row * ldA1 + n0 + en, f2);      // f'(x2)
+    // plain stores: the consumers are the workgroups of this panel, which share this XCD's L2 (the vector L1 is
+    // write-through); other XCDs see y3 after the kernel boundary.  Agent-scope (write-through) stores made the
+    // acknowledgement wait below ~1 us longer.
+    gR2[(size_t)row * ldA1 + n0 + en] = y3;                // also the A operand of dWout
+    gX2[(size_t)row * ldA1 + n0 + en] = f2;                // f'(x2)
   }
   FSTAMP(4);
   if (!SPLITW) headPrecompute();
   // ---- group barrier: all HT tiles of this panel are in memory ------------------------------------------
   FSTAMP(5);
-  __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the write-through stores are acknowledged
+  __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the stores are acknowledged by the L2
   __syncthreads();
   if (a.variant == 3) return;
   FSTAMP(6);
