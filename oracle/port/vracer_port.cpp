@@ -197,6 +197,7 @@ struct ol_learner {
   hl_stats stats{};
   // adam (Network/Optimizer.h:38-47,96)
   Real beta_t_1 = 0.9, beta_t_2 = 0.999; int64_t nStep = 0;
+  int nAdv = 0;                 // advantage outputs between V and the policy mean (0 = VRACER)
   bool initialized = false, inStep = false, tap = false;
   // activations workspace: per layer X, Y, E for current and next step
   std::vector<std::vector<nnReal>> X, Y, E, Xn, Yn;
@@ -231,10 +232,19 @@ void buildNet(ol_learner* h) {
     // skip connection except after the first layer (Builder.cpp:89-95)
     if (ID != 1) { Layer r; r.type = L_PARAMRES; r.size = d.size; L.push_back(r); }
   }
-  const int nDense = 1 + c.dimA;  // VRACER: [V, mean x dA]; sigma is a ParamLayer
+  // VRACER: [V, mean x dA]; RACER with the Gaussian advantage: [V, coef, L+ x dA, L- x dA, mean x dA]
+  // (RACER_common.cpp:172-186, Gaus_advantage.h:20-22); sigma is a ParamLayer (RACER_simpleSigma)
+  const int nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * c.dimA : 0;
+  const int nDense = 1 + nAdv + c.dimA;
+  h->nAdv = nAdv;
   { const int ID = (int)L.size();
     Layer o; o.type = L_DENSE; o.size = nDense; o.nIn = L[ID - 1].size;
-    o.nOutSimd = (int)roundUp8(o.size); o.func = HL_FUNC_LINEAR; o.bOutput = true; L.push_back(o); }
+    o.nOutSimd = (int)roundUp8(o.size); o.func = HL_FUNC_LINEAR; o.bOutput = true;
+    if (nAdv) {   // Builder::setLastLayersBias(biases): Gaussian_advantage::setInitial (Gaus_advantage.h:31-34)
+      o.biasInit.assign(nDense, 0); o.biasInit[1] = -1;
+      for (int e = 2; e < 1 + nAdv; ++e) o.biasInit[e] = 1;
+    }
+    L.push_back(o); }
   { Layer p; p.type = L_PARAM; p.size = c.dimA; p.func = HL_FUNC_LINEAR; p.bOutput = true;
     // Continuous_policy::initial_Stdev -> SoftPlus::_inv(explNoise) (Continuous_policy.h:603-617,192-194)
     Real S = c.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
@@ -275,7 +285,7 @@ void initWeights(ol_learner* h) {
       const Real initializationFac = l.bOutput ? c.outWeightsPrefac : 1;
       const nnReal fac = (initializationFac > 0) ? initializationFac : 1;
       const nnReal init = fac * fInitFactor(l.func, l.nIn, l.size);
-      for (int o = 0; o < l.size; ++o) Bv[o] = 0;  // output bias init values are all 0 -> Linear inverse
+      for (int o = 0; o < l.size; ++o) Bv[o] = l.biasInit.size() == (size_t)l.size ? (nnReal)l.biasInit[o] : 0;  // Linear inverse of the init values (Layer_Base.h:122-125)
       for (int i = 0; i < l.nIn; ++i)
         for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = uniformFloat(h->gen, -init, init);
     } else if (l.type == L_PARAMRES) {
@@ -384,14 +394,25 @@ extern "C" void ol_head_vracer(int dA, const uint8_t* bounded, const double* O, 
                                const double* mu, double Qret, double beta, double Cmax, double Cinv,
                                double* grad, double* rho, double* dkl, double* deltaQ, int* isFar,
                                double* Vval) {
+  double Q;
+  ol_head_racer(dA, 0, bounded, O, act, mu, Qret, beta, Cmax, Cinv, grad, rho, dkl, deltaQ, isFar, Vval, &Q);
+}
+// nAdv = 0: Zero_advantage (VRACER); nAdv = 1 + 2 dA: Gaussian_advantage (Math/Gaus_advantage.h:17-127).
+// Output layout [V | advantage nAdv | mean dA | sigma parameter dA].
+extern "C" void ol_head_racer(int dA, int nAdv, const uint8_t* bounded, const double* O, const double* act,
+                              const double* mu, double Qret, double beta, double Cmax, double Cinv,
+                              double* grad, double* rho, double* dkl, double* deltaQ, int* isFar,
+                              double* Vval, double* Qval) {
+  const int pM = 1 + nAdv, pS = 1 + nAdv + dA;      // policy mean / sigma-parameter offsets
+  for (int o = 0; o < pS + dA; ++o) grad[o] = 0;
   constexpr Real MAXM = 8.31776613503286;
   constexpr Real LOG2PI_2 = 9.1893853320467266954096885456237942e-01;
   constexpr Real FMIN = FLT_MIN;
   Real logW = 0, kl = 0;
   std::vector<Real> mean(dA), stdev(dA), invStd(dA), dPos(dA);
   for (int i = 0; i < dA; ++i) {
-    mean[i] = O[1 + i];
-    const Real p = O[1 + dA + i];
+    mean[i] = O[pM + i];
+    const Real p = O[pS + i];
     stdev[i] = spEval(p); invStd[i] = 1 / stdev[i]; dPos[i] = spDiff(p);
     const Real bMean = mu[i], bStd = mu[dA + i];
     Real lpPi, lpMu;
@@ -415,8 +436,27 @@ extern "C" void ol_head_vracer(int dA, const uint8_t* bounded, const double* O, 
   const Real RHO = std::exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
   const bool far = isFarPolicy((Fval)RHO, (Fval)Cmax, (Fval)Cinv);
   const Real V = scaleNet2V(O[0]);
-  const Real A_RET = Qret - V, dQ = A_RET - 0;          // Zero_advantage: A == 0
+  // Gaussian_advantage::computeAdvantage (:76-81): coef (exp(-1/2 sum (a-m)^2 / L) - mixture ratio), L = L+ above the
+  // mean, L- below; mean and variance are the policy's (getMean(): clipped for squashed components)
+  Real Aval = 0, advCoef = 0, advOrig = 0, advRatio = 1;
+  std::vector<Real> mat(2 * (size_t)dA, 1), pmean(dA);
+  if (nAdv) {
+    advCoef = spEval(O[1]);
+    for (int i = 0; i < 2 * dA; ++i) mat[i] = spEval(O[2 + i]);
+    Real quad = 0;
+    for (int i = 0; i < dA; ++i) {
+      pmean[i] = bounded[i] ? (mean[i] > MAXM ? MAXM : (mean[i] < -MAXM ? -MAXM : mean[i])) : mean[i];
+      const int matind = act[i] > pmean[i] ? i : i + dA;                                   // diagInvMul (:118-128)
+      quad += std::pow(act[i] - pmean[i], 2) / mat[matind];
+      const Real S = stdev[i] * stdev[i];
+      advRatio *= std::sqrt(mat[i] / (mat[i] + S)) / 2 + std::sqrt(mat[i + dA] / (mat[i + dA] + S)) / 2;   // coefMixRatio
+    }
+    advOrig = std::exp(-quad / 2);
+    Aval = advCoef * (advOrig - advRatio);
+  }
+  const Real A_RET = Qret - V, dQ = A_RET - Aval;       // Zero_advantage: A == 0
   const Real Ver = std::min((Real)1, RHO) * dQ;
+  const Real Aer = std::min(Cmax, RHO) * dQ;
   grad[0] = far ? 0 : Ver * beta * scaleVdiff(O[0]);     // RACER_train.cpp:51
   const Real coef = A_RET * std::min(Cmax, RHO);
   for (int i = 0; i < dA; ++i) {
@@ -444,10 +484,26 @@ extern "C" void ol_head_vracer(int dA, const uint8_t* bounded, const double* O, 
       }
     }
     // Utilities::penalizeReFER (Utils/FunctionUtilities.h:221-228) + makeNetworkGrad (:727-738)
-    grad[1 + i] = beta * polM + (1 - beta) * penalM;
-    grad[1 + dA + i] = beta * polS + (1 - beta) * penalS;
+    grad[pM + i] = beta * polM + (1 - beta) * penalM;
+    grad[pS + i] = beta * polS + (1 - beta) * penalS;
   }
-  *rho = RHO; *dkl = kl; *deltaQ = dQ; *isFar = far ? 1 : 0; *Vval = V;
+  if (nAdv) {   // Gaussian_advantage::grad (:91-116) with Qer = far ? 0 : beta * Aer (RACER_train.cpp:56)
+    const Real Qer = far ? 0 : beta * Aer, expect = -advRatio;
+    grad[1] += advOrig + expect;
+    for (int i = 0; i < dA; ++i) {
+      const Real m = pmean[i], p1 = mat[i], p2 = mat[i + dA];
+      grad[2 + i] = act[i] > m ? advOrig * advCoef * std::pow((act[i] - m) / p1, 2) / 2 : 0;
+      grad[2 + dA + i] = act[i] < m ? advOrig * advCoef * std::pow((act[i] - m) / p2, 2) / 2 : 0;
+      const Real S = stdev[i] * stdev[i];
+      const Real F = 2 / (std::sqrt(p1 / (p1 + S)) + std::sqrt(p2 / (p2 + S)));
+      const Real diff1 = S / std::sqrt(p1 * std::pow(p1 + S, 3)) / 4;
+      const Real diff2 = S / std::sqrt(p2 * std::pow(p2 + S, 3)) / 4;
+      grad[2 + i] += F * expect * advCoef * diff1;
+      grad[2 + dA + i] += F * expect * advCoef * diff2;
+    }
+    for (int e = 0; e < nAdv; ++e) grad[1 + e] *= Qer * spDiff(O[1 + e]);                  // grad_matrix (:69-74)
+  }
+  *rho = RHO; *dkl = kl; *deltaQ = dQ; *isFar = far ? 1 : 0; *Vval = V; *Qval = Aval + V;
 }
 
 namespace {
@@ -677,7 +733,7 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
   if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
-  if (cfg->adv_kind != HL_ADV_ZERO) return HL_ERR_UNSUPPORTED;
+  if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN) return HL_ERR_UNSUPPORTED;
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   auto* h = new ol_learner(); h->cfg = *cfg;
@@ -849,21 +905,22 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
       const Fval Vn = (Fval)scaleNet2V(On[0]);
       epUpdateValues(EP, t + 1, Vn, Vn);
     }
-    Real rho, dkl, dq, V; int far;
-    ol_head_vracer(dA, h->cfg.bounded, O.data(), &EP.A[(size_t)t * dA], &EP.MU[(size_t)t * 2 * dA],
-                   (Real)EP.RET[t], h->beta, h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V);
+    Real rho, dkl, dq, V, Q; int far;
+    const int nAdv = h->nAdv, nDn = 1 + nAdv + dA;
+    ol_head_racer(dA, nAdv, h->cfg.bounded, O.data(), &EP.A[(size_t)t * dA], &EP.MU[(size_t)t * 2 * dA],
+                  (Real)EP.RET[t], h->beta, h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V, &Q);
     for (int o = 0; o < nOut; ++o) { h->gsSum[o] += grad[o]; h->gsSq[o] += grad[o] * grad[o]; }   // StatsTracker::track_vector (Approximator.h:197)
     // Approximator::setGradient -> Activation::addOutputDelta (Approximator.h:190-204, Activation.h:108-117)
     for (auto& e : h->E) std::fill(e.begin(), e.end(), 0);
-    for (int o = 0; o < 1 + dA; ++o) h->E[outDense][o] += grad[o];
-    for (int o = 0; o < dA; ++o) h->E[outParam][o] += grad[1 + dA + o];
+    for (int o = 0; o < nDn; ++o) h->E[outDense][o] += grad[o];
+    for (int o = 0; o < dA; ++o) h->E[outParam][o] += grad[nDn + o];
     if (h->tap) { for (int o = 0; o < nOut; ++o) { h->tO[(size_t)b * nOut + o] = O[o]; }
-      for (int o = 0; o < 1 + dA; ++o) h->tG[(size_t)b * nOut + o] = h->E[outDense][o];
-      for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + 1 + dA + o] = h->E[outParam][o];
+      for (int o = 0; o < nDn; ++o) h->tG[(size_t)b * nOut + o] = h->E[outDense][o];
+      for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + nDn + o] = h->E[outParam][o];
       h->tRho[b] = rho; h->tDkl[b] = dkl; h->tFar[b] = (uint8_t)far; }
     // MiniBatch::setMseDklImpw / setValues (RACER_train.cpp:59-60; MiniBatch.h:161-175)
     epUpdateCumulative(EP, t, (Fval)dq, (Fval)dkl, (Fval)rho, (Fval)h->CmaxRet, (Fval)h->CinvRet);
-    epUpdateValues(EP, t, (Fval)V, (Fval)V);
+    epUpdateValues(EP, t, (Fval)V, (Fval)Q);
     if (h->tap) h->tDq[b] = EP.DQ[t];
     backwardNet(h);
   }

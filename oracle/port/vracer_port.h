@@ -68,6 +68,10 @@ HL_API void ol_head_vracer(int dA, const uint8_t* bounded, const double* O, cons
                            const double* mu, double Qret, double beta, double Cmax, double Cinv,
                            double* grad /*1+2dA*/, double* rho, double* dkl, double* deltaQ, int* isFar,
                            double* Vval);
+HL_API void ol_head_racer(int dA, int nAdv, const uint8_t* bounded, const double* O, const double* act,
+                          const double* mu, double Qret, double beta, double Cmax, double Cinv,
+                          double* grad /*1+nAdv+2dA*/, double* rho, double* dkl, double* deltaQ, int* isFar,
+                          double* Vval, double* Qval);
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@
 #define private public
 #include "smarties/Learners/RACER.h"
 #include "smarties/Math/Zero_advantage.h"
+#include "smarties/Math/Gaus_advantage.h"
 #include "smarties/Math/Continuous_policy.h"
 #include "smarties/Network/Approximator.h"
 #include "smarties/Network/Optimizer.h"
@@ -71,7 +72,17 @@ static std::vector<uint32_t> rngState(const std::mt19937& g) {
   return r;  // 624 state words + position
 }
 
+// -DREF_GAUSS_ADV builds the same harness around RACER with the Gaussian advantage head
+// (RACER<Param_advantage = Gaussian_advantage, Continuous_policy, Rvec>, Learners/AlgoFactory.cpp:124)
+#ifdef REF_GAUSS_ADV
+using VRACER = RACER<Gaussian_advantage, Continuous_policy, Rvec>;
+static const char* kLearner = "RACER";
+static const int64_t kAdvKind = 1;
+#else
 using VRACER = RACER<Zero_advantage, Continuous_policy, Rvec>;
+static const char* kLearner = "VRACER";
+static const int64_t kAdvKind = 0;
+#endif
 
 struct Harness {
   ExecutionInfo& info;
@@ -96,7 +107,7 @@ struct Harness {
     MDP.synchronize([](void*, size_t) {});
     MDP.policyVecDim = 2 * dA;
     HP = std::make_unique<HyperParameters>(dS, dA);
-    HP->learner = "VRACER"; HP->returnsEstimator = "retrace";
+    HP->learner = kLearner; HP->returnsEstimator = "retrace";
     HP->nnLayerSizes = parseList(A.s("layers", "256,256"));
     HP->nnFunc = A.s("nnFunc", "SoftSign");
     HP->batchSize = A.l("batch", 256);
@@ -238,7 +249,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   {
     std::vector<int64_t> cfg = {(int64_t)H.MDP.dimStateObserved, (int64_t)H.MDP.dimAction,
         (int64_t)H.HP->batchSize, nEps, nSteps, (int64_t)PW->nParams, (int64_t)NET.nOutputs(),
-        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax};
+        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind};
     W.i64("cfg", cfg);
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

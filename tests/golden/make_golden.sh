@@ -24,6 +24,9 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
 # G-ns: the north-star network/batch shape (17/6, 2x256 SoftSign, B=256) on a 300-episode replay
 "$DRV" fixture "$HERE/ns_shape.bin" dimS=17 dimA=6 layers=256,256 batch=256 nEps=300 \
    lenMin=150 lenMax=250 pTerm=0.2 nSteps=4 gradSteps=1 maxObs=100000 minObs=1000
+# G-racer: RACER with the Gaussian advantage head (Math/Gaus_advantage.h), same replay as G-small
+"$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/racer_gauss.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
 # official-vs-manual cross check of the harness itself (weights must be bit-identical)
 "$DRV" fixture "$TMP/off.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 maxObs=2000 minObs=500 path=official
