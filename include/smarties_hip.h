@@ -75,6 +75,9 @@ enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU 
        HL_FUNC_EXPPLUS = 8, HL_FUNC_EXP = 9 };
 
 /* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
+/* advantage head (Learners/AlgoFactory.cpp:109-152): Math/Zero_advantage.h (VRACER), Math/Gaus_advantage.h (RACER,
+ * continuous actions: network outputs [V | coef, L+ x dA, L- x dA | mean x dA | sigma parameter x dA]);
+ * HL_ADV_DISCRETE is declared for the reference's third variant and answers HL_ERR_UNSUPPORTED */
 enum { HL_ADV_ZERO = 0 /* VRACER */, HL_ADV_GAUSSIAN = 1 /* RACER continuous */,
        HL_ADV_DISCRETE = 2 /* RACER discrete */ };
 

@@ -1,8 +1,9 @@
 // smarties_amd/csrc/head.hip -- output layer + V-RACER / ReF-ER head, one wavefront per sample.
 //
 //   output InnerProduct layer (Linear, Layer_Base.h:64-95) + ParamLayer (Layers.h:510-520),
-//   RACER::Train for VRACER (Learners/RACER_train.cpp:14-67) in fp64 with Continuous_policy
-//   (Math/Continuous_policy.h:68-378, 569-738), write-backs MiniBatch::setMseDklImpw / setValues
+//   RACER::Train (Learners/RACER_train.cpp:14-67) in fp64 with Continuous_policy
+//   (Math/Continuous_policy.h:68-378, 569-738) and Zero_advantage (VRACER) or Gaussian_advantage
+//   (Math/Gaus_advantage.h:17-127; outputs [V | coef, L+ x dA, L- x dA | mean x dA | sigma parameter x dA]), write-backs MiniBatch::setMseDklImpw / setValues
 //   (MiniBatch.h:161-175) and the backward of the output layer into the last hidden block
 //   (Layers.h:123-160).
 //
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   const int row = (blockIdx.x - (extra.role ? 1 : 0)) * 4 + wave;
   const DevScalars* sc = a.sc;
   if (row >= sc->nRows[a.parity]) return;
-  const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H;
+  const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H, nAdv = a.nAdv, pM = 1 + nAdv;
   const bool isNext = row >= B;
   const int b = isNext ? a.bt.nextSrc[row - B] : row;
   const long long slot = a.bt.slot[b];
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   if (lane < dA) {
     const int i = lane;
     bnd = a.bounded[i] != 0;
-    mean = sO[wave][1 + i];
+    mean = sO[wave][pM + i];
     const double pp = sO[wave][nDense + i];
     const double rt = sqrt(1 + pp * pp);
     stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
@@ -155,8 +156,28 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   const double O0 = sO[wave][0];
   const double V = scaleNet2V(O0);
   const double Qret = (double)__shfl(misc, 0, 64);
-  const double A_RET = Qret - V, dQ = A_RET;                       // Zero_advantage
+  // Gaussian_advantage::computeAdvantage (Gaus_advantage.h:76-88): A = coef (exp(-1/2 sum (a-m)^2 / L) - ratio),
+  // L = L+ above the policy mean, L- below; sums and products in the reference's component order
+  double Aval = 0, advCoef = 0, advOrig = 0, advRatio = 1, p1 = 1, p2 = 1, pm = 0;
+  auto sp = [](double x) { return (x + sqrt(1 + x * x)) / 2; };                 // SoftPlus::_eval (Functions.h:541-584)
+  auto spD = [](double x) { return (1 + x / sqrt(1 + x * x)) / 2; };
+  if (nAdv) {
+    double quadI = 0, rI = 1;
+    if (lane < dA) {
+      p1 = sp(sO[wave][2 + lane]); p2 = sp(sO[wave][2 + dA + lane]);
+      pm = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
+      const double d = act - pm, S = stdev * stdev;
+      quadI = d * d / (act > pm ? p1 : p2);
+      rI = sqrt(p1 / (p1 + S)) / 2 + sqrt(p2 / (p2 + S)) / 2;
+    }
+    double quad = 0;
+    for (int i = 0; i < dA; ++i) { quad += __shfl(quadI, i, 64); advRatio *= __shfl(rI, i, 64); }
+    advCoef = sp(sO[wave][1]); advOrig = exp(-quad / 2);
+    Aval = advCoef * (advOrig - advRatio);
+  }
+  const double A_RET = Qret - V, dQ = A_RET - Aval;                // Zero_advantage: A = 0
   const double Ver = fmin(1.0, RHO) * dQ;
+  const double Qer = far ? 0.0 : beta * (fmin(Cmax, RHO) * dQ);    // RACER_train.cpp:42,56
   const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
   const double coef = A_RET * fmin(Cmax, RHO);
   if (lane < dA) {
@@ -182,10 +203,23 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     const double gM = beta * polM + (1 - beta) * penalM;
     const double gS = beta * polS + (1 - beta) * penalS;
     // Activation::addOutputDelta: nnReal += Real (Activation.h:108-117)
-    sDelta[wave][1 + lane] = (float)gM;
+    sDelta[wave][pM + lane] = (float)gM;
     a.bt.gParam[(size_t)b * dA + lane] = (float)gS;
-    a.bt.G[(size_t)b * a.nOut + 1 + lane] = (double)(float)gM;
+    a.bt.G[(size_t)b * a.nOut + pM + lane] = (double)(float)gM;
     a.bt.G[(size_t)b * a.nOut + nDense + lane] = (double)(float)gS;
+    if (nAdv) {   // Gaussian_advantage::grad (Gaus_advantage.h:91-116) for the two precisions of this component
+      const double expect = -advRatio, S = stdev * stdev, d = act - pm;
+      double g1 = act > pm ? advOrig * advCoef * ((d / p1) * (d / p1)) / 2 : 0;
+      double g2 = act < pm ? advOrig * advCoef * ((d / p2) * (d / p2)) / 2 : 0;
+      const double F = 2 / (sqrt(p1 / (p1 + S)) + sqrt(p2 / (p2 + S)));
+      const double q1 = p1 + S, q2 = p2 + S;
+      g1 += F * expect * advCoef * (S / sqrt(p1 * (q1 * q1 * q1)) / 4);
+      g2 += F * expect * advCoef * (S / sqrt(p2 * (q2 * q2 * q2)) / 4);
+      g1 *= Qer * spD(sO[wave][2 + lane]); g2 *= Qer * spD(sO[wave][2 + dA + lane]);          // grad_matrix (:69-74)
+      sDelta[wave][2 + lane] = (float)g1; sDelta[wave][2 + dA + lane] = (float)g2;
+      a.bt.G[(size_t)b * a.nOut + 2 + lane] = (double)(float)g1;
+      a.bt.G[(size_t)b * a.nOut + 2 + dA + lane] = (double)(float)g2;
+    }
   }
   {
     const float oDQ = __shfl(misc, 1, 64), oDKL = __shfl(misc, 2, 64), oW = __shfl(misc, 3, 64);
@@ -193,12 +227,18 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     if (lane == 0) {
       sDelta[wave][0] = (float)g0;
       a.bt.G[(size_t)b * a.nOut] = (double)(float)g0;
+      if (nAdv) {
+        const double gc = (advOrig - advRatio) * (Qer * spD(sO[wave][1]));
+        sDelta[wave][1] = (float)gc; a.bt.G[(size_t)b * a.nOut + 1] = (double)(float)gc;
+      }
       a.bt.rho[b] = RHO; a.bt.dkl[b] = DKL; a.bt.far[b] = far ? 1 : 0;
       // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
       const float E = (float)dQ, D = (float)DKL, Wn = (float)RHO, Vf = (float)V;
       a.bt.oldDQ[b] = oDQ; a.bt.oldDKL[b] = oDKL; a.bt.oldW[b] = oW; a.bt.oldV[b] = oV; a.bt.oldADV[b] = oADV;
       a.bt.newDQ[b] = E; a.bt.newDKL[b] = D; a.bt.newW[b] = Wn; a.bt.newV[b] = Vf;
-      a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = 0.f;
+      const float Qf = (float)(Aval + V);                   // Episode::updateValues_atomic(t, V, Q): advantage = Q - V in Fval
+      a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = nAdv ? Qf - Vf : 0.f;
+      a.bt.newQ[b] = nAdv ? Qf : Vf;
       a.bt.dq[b] = (double)E;
     }
   }

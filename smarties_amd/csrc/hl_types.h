@@ -93,6 +93,7 @@ struct DevBatch {
   double *rho, *dkl, *dq;        // [B]
   unsigned char* far;            // [B]
   float *newDQ, *newDKL, *newW, *newV;   // [B] values written to the replay (Fval casts)
+  float* newQ;                           // [B] Q = V + A of the sampled step (heads with an advantage; VRACER: Q = V)
   float *oldDQ, *oldDKL, *oldW, *oldV, *oldADV;   // [B]
   float *nextV, *oldNextV, *oldNextADV;           // [B] (indexed by sample b)
   float* gParam;       // [B][dA] gradient wrt the ParamLayer outputs

@@ -19,6 +19,7 @@ struct SampleArgs {
 struct HeadArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
   int B, dA, nDense, nOut, H;       // H = width of the last hidden block
+  int nAdv;                         // advantage outputs between V and the policy mean: 0 (VRACER) or 1 + 2 dA (Gaussian)
   const float* Yin; int ldY;        // input of the output layer [Mmax][ldY]
   const float* Xlast; const float* Ylast; int func;   // last hidden block pre/post activation (for act')
   const float* params;              // weight blob
@@ -37,6 +38,7 @@ struct PostArgs {
   int parity;                        // buffer of the step being closed; etaEff[parity^1] is written
   float eta0;
   int aggStaged;                     // 1: bt.aggIn holds the episode aggregates (fused kernel), no gather needed
+  int hasAdv;                        // 1: Q = bt.newQ (head with an advantage), 0: Q = V
 };
 enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4 };
 

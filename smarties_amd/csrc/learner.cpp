@@ -48,7 +48,7 @@ struct hl_learner {
   std::string err;
   int dev = 0;
   hipStream_t stream = nullptr;
-  int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nHidden = 0, Mmax = 0;
+  int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nAdv = 0, nHidden = 0, Mmax = 0;
   long long maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
   // parameter blob layout (Parameters::_computeNParams, Layers/Parameters.h:159-176)
   std::vector<long long> indW, nW, indB, nB;
@@ -174,7 +174,9 @@ int buildNet(hl_learner* h) {
   }
   if (nH < 1) return HL_ERR_BAD_ARG;
   h->nHidden = nH;
-  h->nDense = 1 + c.dimA; h->nOut = h->nDense + c.dimA;
+  // VRACER: [V, mean]; RACER with the Gaussian advantage: [V, coef, L+, L-, mean] (RACER_common.cpp:172-186)
+  h->nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * c.dimA : 0;
+  h->nDense = 1 + h->nAdv + c.dimA; h->nOut = h->nDense + c.dimA;
   const int outLayer = (int)lw.size();
   lw.push_back(roundUp(h->nDense, 8) * prev); lb.push_back(h->nDense);
   const int paramLayer = (int)lw.size();
@@ -399,7 +401,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
   if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
-  if (cfg->adv_kind != HL_ADV_ZERO) return HL_ERR_UNSUPPORTED;
+  if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN) return HL_ERR_UNSUPPORTED;
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
@@ -444,7 +446,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     const bool off = e && e[0] == '1';
     if (!off && h->nHidden == 2) {
       const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
-      h->fusedOk = d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nDense <= 8 && h->ldWo == 8 &&
+      h->fusedOk = d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nAdv == 0 && h->nDense <= 8 && h->ldWo == 8 &&
                    !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
                    fused_lds_bytes(h->dS, d1.size) <= 160 * 1024;
     }
@@ -465,7 +467,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&bt.sVals, (size_t)std::max(B, 256)));
     HIPCK(devAlloc(&bt.O, (size_t)2 * B * h->nOut)); HIPCK(devAlloc(&bt.G, (size_t)B * h->nOut));
     HIPCK(devAlloc(&bt.rho, B)); HIPCK(devAlloc(&bt.dkl, B)); HIPCK(devAlloc(&bt.dq, B)); HIPCK(devAlloc(&bt.far, B));
-    HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B));
+    HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B)); HIPCK(devAlloc(&bt.newQ, B));
     HIPCK(devAlloc(&bt.oldDQ, B)); HIPCK(devAlloc(&bt.oldDKL, B)); HIPCK(devAlloc(&bt.oldW, B)); HIPCK(devAlloc(&bt.oldV, B));
     HIPCK(devAlloc(&bt.oldADV, B)); HIPCK(devAlloc(&bt.nextV, B)); HIPCK(devAlloc(&bt.oldNextV, B));
     HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * h->dA));
@@ -513,7 +515,7 @@ int hl_destroy(hl_learner* h) {
   for (int pb = 0; pb < 2; ++pb) {
     DevBatch& bt = h->buf[pb].bt;
     void* bp[] = {h->buf[pb].X0, bt.sVals, bt.tag, bt.pEid, bt.pNextOf, bt.flat, bt.pos, bt.eid, bt.t, bt.slot, bt.nextOf, bt.nextSrc,
-      bt.O, bt.G, bt.rho, bt.dkl, bt.dq, bt.far, bt.newDQ, bt.newDKL, bt.newW, bt.newV, bt.oldDQ, bt.oldDKL, bt.oldW,
+      bt.O, bt.G, bt.rho, bt.dkl, bt.dq, bt.far, bt.newDQ, bt.newDKL, bt.newW, bt.newV, bt.newQ, bt.oldDQ, bt.oldDKL, bt.oldW,
       bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam, bt.aggIn};
     for (void* q : bp) if (q) hipFree(q);
   }
@@ -566,6 +568,8 @@ int hl_init_weights(hl_learner* h) {
   { const DevHidden& q = h->hid[h->nHidden - 1];
     const double iFac = h->cfg.outWeightsPrefac; const float fac = (iFac > 0) ? iFac : 1;
     const float init = fac * initFactor(HL_FUNC_LINEAR, q.size, h->nDense);
+    // Builder::setLastLayersBias: Gaussian_advantage::setInitial (Gaus_advantage.h:31-34), Linear inverse = identity
+    if (h->nAdv) { W[h->indBo + 1] = -1.f; for (int e = 2; e < 1 + h->nAdv; ++e) W[h->indBo + e] = 1.f; }
     for (int i = 0; i < q.size; ++i) for (int o = 0; o < h->nDense; ++o) W[h->indWo + o + (long long)h->ldWo * i] = uni(-init, init);
     double S = h->cfg.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
     for (int o = 0; o < h->dA; ++o) W[h->indBp + o] = (float)((S * S - 0.25) / S);   // SoftPlus::_inv (Functions.h:564-568)

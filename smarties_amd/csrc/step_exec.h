@@ -135,12 +135,12 @@ PostArgs postArgs(hl_learner* h, int parity, int mode) {
   PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->buf[parity].bt; pa.B = h->B; pa.mode = mode;
   pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
   pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = exchanging(h) ? 2 : 1;   // > 1: use the exchanged counters
-  pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate; pa.aggStaged = h->fusedOk ? 1 : 0;
+  pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate; pa.aggStaged = h->fusedOk ? 1 : 0; pa.hasAdv = h->nAdv > 0 ? 1 : 0;
   return pa;
 }
 HeadArgs headArgs(hl_learner* h, int parity) {
   const DevHidden& q = h->hid[h->nHidden - 1];
-  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->buf[parity].bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense;
+  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->buf[parity].bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense; ha.nAdv = h->nAdv;
   ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
   ha.func = q.func; ha.params = h->W; ha.indWo = h->indWo; ha.indBo = h->indBo; ha.indBp = h->indBp; ha.ldWo = h->ldWo;
   ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA; ha.parity = parity;

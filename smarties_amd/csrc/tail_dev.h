@@ -71,11 +71,12 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       const int ePrev = (in && b > 0) ? a.bt.pEid[b - 1] : -2;
       const int eNext = (in && b + 1 < B) ? a.bt.pEid[b + 1] : -3;
       const int nxt0 = in ? a.bt.pNextOf[b] : -1;
-      float E0 = 0, D0 = 0, W0 = 0, V0 = 0, oW0 = 0, oE0 = 0, oD0 = 0, oV0 = 0, oA0 = 0, Vn0 = 0, oNV0 = 0, oNA0 = 0;
+      float Q0 = 0, E0 = 0, D0 = 0, W0 = 0, V0 = 0, oW0 = 0, oE0 = 0, oD0 = 0, oV0 = 0, oA0 = 0, Vn0 = 0, oNV0 = 0, oNA0 = 0;
       if (in) {
         E0 = a.bt.newDQ[b]; D0 = a.bt.newDKL[b]; W0 = a.bt.newW[b]; V0 = a.bt.newV[b];
         oW0 = a.bt.oldW[b]; oE0 = a.bt.oldDQ[b]; oD0 = a.bt.oldDKL[b]; oV0 = a.bt.oldV[b]; oA0 = a.bt.oldADV[b];
         Vn0 = a.bt.nextV[b]; oNV0 = a.bt.oldNextV[b]; oNA0 = a.bt.oldNextADV[b];
+        Q0 = a.hasAdv ? a.bt.newQ[b] : V0;          // VRACER: Q = V (no extra load on the hot path)
       }
       // the episode record: staged per sample by the fused kernel (same round as the loads above) ...
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
@@ -99,7 +100,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       const float invN = 1 / Nf;
       const long long before = farSteps(Nf, g[AGG_FRACFAR]);
       int j = b; bool more = true;
-      float E = E0, D = D0, W = W0, Vf = V0, oW = oW0, oE = oE0, oD = oD0, oV = oV0, oA = oA0, Vn = Vn0, oNV = oNV0, oNA = oNA0;
+      float Qf = Q0, E = E0, D = D0, W = W0, Vf = V0, oW = oW0, oE = oE0, oD = oD0, oV = oV0, oA = oA0, Vn = Vn0, oNV = oNV0, oNA = oNA0;
       int nxt = nxt0;
       while (more) {
         if (nxt >= 0) aggValues(g, oNV, oNA, Vn, Vn);     // setValues(t+1, Vnext) comes first
@@ -109,7 +110,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
         g[AGG_FRACFAR] += invN * (isFar - wasFar);
         g[AGG_AVGSQERR] += invN * (E * E - oE * oE);
         g[AGG_MAXABSERR] = fmaxf(g[AGG_MAXABSERR], fabsf(E));
-        aggValues(g, oV, oA, Vf, Vf);
+        aggValues(g, oV, oA, Vf, Qf);
         // further samples of the same episode (rare): fetched on demand, in minibatch order
         const int en = (j == b) ? eNext : ((j + 1 < B) ? a.bt.pEid[j + 1] : -3);
         more = (en == e);
@@ -119,6 +120,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
           E = a.bt.newDQ[j]; D = a.bt.newDKL[j]; W = a.bt.newW[j]; Vf = a.bt.newV[j];
           oW = a.bt.oldW[j]; oE = a.bt.oldDQ[j]; oD = a.bt.oldDKL[j]; oV = a.bt.oldV[j]; oA = a.bt.oldADV[j];
           Vn = a.bt.nextV[j]; oNV = a.bt.oldNextV[j]; oNA = a.bt.oldNextADV[j];
+          Qf = a.hasAdv ? a.bt.newQ[j] : Vf;
         }
       }
 #pragma unroll

@@ -33,7 +33,7 @@ def our_flat_for(L, tags, ts):
     return np.array([prefix[int(g)] + int(t) for g, t in zip(tags, ts)], np.int64)
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin"])
 def test_init_weights_and_initialize_match_reference(hip_api, name):
     fx = load_fixture(name)
     L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
@@ -57,7 +57,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin"])
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
@@ -155,6 +155,10 @@ def _compare_step(G, O):
     (dict(dimS=257, dimA=17, bounded=[0] * 17, hidden=(256, 256), batchSize=32, maxTotObsNum=60000,
           clipImpWeight=(17 / 2.0) ** 0.5, randSeed=33),
      dict(seed=29, dimS=257, dimA=17, lenMin=20, lenMax=120, pTerm=0.5, muSpread=0.2), 40, 8),
+    # RACER with the Gaussian advantage head (Math/Gaus_advantage.h): 6 actions -> 13 advantage outputs, 26 in all
+    (dict(dimS=17, dimA=6, bounded=[1, 0, 1, 0, 1, 1], hidden=(64, 64), batchSize=64, maxTotObsNum=20000, randSeed=41,
+          adv_kind=capi.ADV_GAUSSIAN),
+     dict(seed=37, dimS=17, dimA=6, lenMin=20, lenMax=80, pTerm=0.4), 80, 12),
 ])
 def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
     """Device-side mt19937 sampler (Lemire + sort/unique/redraw), gather, MLP, head, ReF-ER
@@ -170,6 +174,14 @@ def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, s
         assert np.array_equal(G.get_rng_state(), O.get_rng_state())
     wg, m1g, m2g = G.get_params(); wo, m1o, m2o = O.get_params()
     assert relinf(wg, wo) < TOL32 and relinf(m1g, m1o) < 5 * TOL32 and relinf(m2g, m2o) < 5 * TOL32
+    # what the steps wrote back into the replay (V, advantage = Q - V, importance weights) and the Q statistics
+    for field in (capi.EP_VALUE, capi.EP_ADVANTAGE, capi.EP_IMPW, capi.EP_DKL, capi.EP_DELTAQ):
+        mg, mo = episode_arrays_by_tag(G, field), episode_arrays_by_tag(O, field)
+        for tag in mo:
+            assert np.allclose(mg[tag], mo[tag], rtol=1e-4, atol=1e-5), (field, tag)
+    stg, sto = G.stats(), O.stats()
+    for f in ("avgKLdivergence", "avgSquaredErr", "avgReturn", "avgQ", "stdevQ", "minQ", "maxQ"):
+        assert np.isclose(getattr(stg, f), getattr(sto, f), rtol=1e-3, atol=1e-5), f
 
 
 @pytest.mark.gpu
