@@ -53,6 +53,7 @@ struct HyperParameters {
   Uint minTotObsNum = 0, maxTotObsNum = 1 << 20, batchSize = 256;
   std::vector<Uint> nnLayerSizes = {128, 128};
   std::string nnFunc = "Tanh";
+  std::string learner = "VRACER";   // "VRACER" (Zero_advantage) or "RACER" (Gaussian_advantage), AlgoFactory.cpp:109-152
   Uint randSeed = 0;
 };
 
@@ -74,9 +75,9 @@ class VRACER {
   MDPdescriptor MDP;
   HyperParameters S;
   bool bTrain = true, bInit = false;
-  int nOut = 0, nDense = 0;
+  int nOut = 0, nDense = 0, nAdv = 0;      // nAdv: advantage outputs between V and the policy mean
   // one in-progress episode per agent: MemoryBuffer::inProgress (ReplayMemory/MemoryBuffer.h)
-  struct InProgress { Fvec states; Rvec actions, policies, rewards; Fvec values; int64_t tag = 0; };
+  struct InProgress { Fvec states; Rvec actions, policies, rewards; Fvec values, advantages; int64_t tag = 0; };
   std::vector<InProgress> inProgress;
   int64_t nSeenEpisodes = 0;
 
@@ -113,7 +114,11 @@ class VRACER {
     for (Uint i = 0; i < M.dimAction; ++i) c.bounded[i] = i < M.bActionSpaceBounded.size() && M.bActionSpaceBounded[i];
     c.n_hidden = (int32_t)hp.nnLayerSizes.size();
     for (Uint i = 0; i < hp.nnLayerSizes.size(); ++i) c.hidden[i] = (int32_t)hp.nnLayerSizes[i];
-    c.nnFunc = funcId(hp.nnFunc); c.adv_kind = HL_ADV_ZERO;
+    c.nnFunc = funcId(hp.nnFunc);
+    if (hp.learner == "VRACER") c.adv_kind = HL_ADV_ZERO;
+    else if (hp.learner == "RACER") c.adv_kind = HL_ADV_GAUSSIAN;
+    else die("learner " + hp.learner + " is not served by the HIP library");
+    nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * (int)M.dimAction : 0;
     c.batchSize = (int32_t)hp.batchSize; c.maxTotObsNum = (int64_t)hp.maxTotObsNum; c.minTotObsNum = (int64_t)hp.minTotObsNum;
     c.gamma = hp.gamma; c.lambda = hp.lambda; c.clipImpWeight = hp.clipImpWeight; c.penalTol = hp.penalTol;
     c.epsAnneal = hp.epsAnneal; c.learnrate = hp.learnrate; c.nnLambda = hp.nnLambda; c.explNoise = hp.explNoise;
@@ -122,7 +127,7 @@ class VRACER {
     const int rc = hl_create(&c, &H);
     if (rc) die(std::string("hl_create: ") + hl_status_string(rc) + ": " + hl_last_error(nullptr));
     ck(hl_init_weights(H));
-    nOut = hl_num_outputs(H); nDense = 1 + (int)M.dimAction;
+    nOut = hl_num_outputs(H); nDense = 1 + nAdv + (int)M.dimAction;
   }
   ~VRACER() { if (H) hl_destroy(H); }
   VRACER(const VRACER&) = delete;
@@ -154,14 +159,29 @@ class VRACER {
       Rvec mean(dA), stdev(dA), act(dA);
       for (Uint i = 0; i < dA; ++i) {
         const Real p = output[(Uint)nDense + i];
-        mean[i] = output[1 + i]; stdev[i] = (p + std::sqrt(1 + p * p)) / 2;         // SoftPlus (Functions.h:541-584)
+        mean[i] = output[(Uint)(1 + nAdv) + i]; stdev[i] = (p + std::sqrt(1 + p * p)) / 2;         // SoftPlus (Functions.h:541-584)
         if (!bTrain) { act[i] = mean[i]; continue; }                                 // Continuous_policy.h:779
         const Real a = mean[i] + stdev[i] * sampleClippedGaussian(agent.generator);
         constexpr Real MAX = 8.31776613503286;                                       // SquashedNormalPolicy::sample (:356-360)
         act[i] = c_bounded(i) ? (a > MAX ? MAX : (a < -MAX ? -MAX : a)) : a;
       }
       const Real V = scaleNet2V(output[0]);
-      EP.values.push_back((Fval)V);                                                  // MB.appendValues(V, V + 0): Zero_advantage
+      // MB.appendValues(V, V + adv.computeAdvantage(action)) (RACER.cpp:44-46): Zero_advantage, or
+      // Gaussian_advantage::computeAdvantage (Gaus_advantage.h:76-88) with the policy's clipped mean and variance
+      Real A = 0;
+      if (nAdv) {
+        auto sp = [](Real x) { return (x + std::sqrt(1 + x * x)) / 2; };
+        constexpr Real MAX = 8.31776613503286;
+        Real quad = 0, ratio = 1;
+        for (Uint i = 0; i < dA; ++i) {
+          const Real m = c_bounded(i) ? (mean[i] > MAX ? MAX : (mean[i] < -MAX ? -MAX : mean[i])) : mean[i];
+          const Real p1 = sp(output[2 + i]), p2 = sp(output[2 + dA + i]), Sv = stdev[i] * stdev[i];
+          quad += (act[i] - m) * (act[i] - m) / (act[i] > m ? p1 : p2);
+          ratio *= std::sqrt(p1 / (p1 + Sv)) / 2 + std::sqrt(p2 / (p2 + Sv)) / 2;
+        }
+        A = sp(output[1]) * (std::exp(-quad / 2) - ratio);
+      }
+      EP.values.push_back((Fval)V); EP.advantages.push_back((Fval)((Fval)(V + A) - (Fval)V));
       agent.action = act;
       agent.policyVector = mean; agent.policyVector.insert(agent.policyVector.end(), stdev.begin(), stdev.end());
       // MemoryBuffer::storeAction (MemoryBuffer.cpp:131-170 region): a_t and mu_t next to s_t
@@ -170,11 +190,12 @@ class VRACER {
     } else {
       // RACER::processTerminal (RACER.cpp:49-59): value of a truncated last state from the network, 0 if terminal
       EP.values.push_back(agent.agentStatus == LAST ? (Fval)scaleNet2V(forward(agent)[0]) : (Fval)0);
+      EP.advantages.push_back(0);
       EP.actions.insert(EP.actions.end(), dA, 0.0);                                  // dummy last action / policy
       EP.policies.insert(EP.policies.end(), 2 * dA, 0.0);
       // MemoryBuffer::terminateCurrentEpisode -> pushBackEpisode
       pushBackEpisode((int)(EP.states.size() / dS), EP.states, EP.actions, EP.policies, EP.rewards, EP.values,
-                      agent.agentStatus == TERM, EP.tag);
+                      agent.agentStatus == TERM, EP.tag, &EP.advantages);
       EP = InProgress();
     }
   }
@@ -182,9 +203,9 @@ class VRACER {
 
   // MemoryBuffer::pushBackEpisode: a finished episode enters the training set
   void pushBackEpisode(int nStates, const Fvec& states, const Rvec& actions, const Rvec& policies, const Rvec& rewards,
-                       const Fvec& values, bool bReachedTermState, int64_t ID) {
-    ck(hl_append_episode(H, nStates, states.data(), actions.data(), policies.data(), rewards.data(), values.data(), nullptr,
-                         bReachedTermState ? 1 : 0, ID));
+                       const Fvec& values, bool bReachedTermState, int64_t ID, const Fvec* advantages = nullptr) {
+    ck(hl_append_episode(H, nStates, states.data(), actions.data(), policies.data(), rewards.data(), values.data(),
+                         advantages ? advantages->data() : nullptr, bReachedTermState ? 1 : 0, ID));
   }
 
   // the same from the wire format a worker sends (Episode::packEpisode / unpackEpisode, Episode.cpp:24-130)

@@ -148,6 +148,52 @@ int main() {
       CHECK(nRows == 3 && first.rfind("ID #/T   |  avgR", 0) == 0, "stats file: header once, then one line per call");
     }
   }
+  // ---- RACER (Gaussian advantage head): acting stores V and the advantage of the drawn action, training follows the oracle ----
+  {
+    MDPdescriptor M2; M2.dimStateObserved = 9; M2.dimAction = 3; M2.bActionSpaceBounded = {true, false, true};
+    HyperParameters H2; H2.learner = "RACER"; H2.nnLayerSizes = {64, 64}; H2.nnFunc = "Tanh"; H2.batchSize = 32; H2.maxTotObsNum = 5000;
+    H2.clipImpWeight = 4; H2.epsAnneal = 0; H2.explNoise = 0.5; H2.outWeightsPrefac = 0.1; H2.randSeed = 77;
+    VRACER R(M2, H2, 0);
+    hl_config c2{}; c2.struct_size = sizeof(c2); c2.dimS = 9; c2.dimA = 3; c2.bounded[0] = 1; c2.bounded[2] = 1;
+    c2.n_hidden = 2; c2.hidden[0] = c2.hidden[1] = 64; c2.nnFunc = HL_FUNC_TANH; c2.adv_kind = HL_ADV_GAUSSIAN;
+    c2.batchSize = 32; c2.maxTotObsNum = 5000; c2.gamma = H2.gamma; c2.lambda = H2.lambda; c2.clipImpWeight = 4; c2.penalTol = H2.penalTol;
+    c2.epsAnneal = 0; c2.learnrate = H2.learnrate; c2.nnLambda = H2.nnLambda; c2.explNoise = 0.5; c2.outWeightsPrefac = 0.1;
+    c2.randSeed = 77; c2.n_ranks = 1; c2.ref_threads = 1;
+    ol_learner* O2 = nullptr;
+    CHECK(ol_create(&c2, &O2) == 0 && ol_init_weights(O2) == 0, "RACER oracle");
+    // acting: 40 episodes of 25 steps through select(); the oracle gets the very same episodes (packed form)
+    for (int e = 0; e < 40; ++e) {
+      Agent agent(0, 1000 + e);
+      for (int t = 0; t <= 25; ++t) {
+        agent.agentStatus = t == 0 ? INIT : (t == 25 ? (e % 3 ? LAST : TERM) : CONT);
+        agent.state.resize(9); for (int i = 0; i < 9; ++i) agent.state[i] = 0.3f * (float)std::sin(0.37 * t + i + e);
+        agent.reward = 0.1 * std::cos(0.2 * t + e);
+        R.select(agent);
+      }
+      const Fvec packed = R.packEpisode(0);
+      CHECK(ol_append_packed_episode(O2, packed.data(), (int64_t)packed.size()) == 0, "oracle takes the packed episode");
+    }
+    {   // the stored advantage of a drawn action is not zero for this head, and equals the oracle's network view
+      const Fvec packed = R.packEpisode(0);
+      const size_t N = 26, tup = 9 + 1 + 3 + 6;
+      double amax = 0; for (size_t t = 0; t + 1 < N; ++t) amax = std::max(amax, (double)std::fabs(packed[N * tup + 2 * N + t]));
+      CHECK(amax > 0, "stored advantages are all zero");
+    }
+    R.initializeLearner(); CHECK(ol_initialize(O2) == 0, "RACER ol_initialize");
+    std::vector<int64_t> f1(32), f2(32);
+    for (int k = 1; k <= 20; ++k) {
+      R.trainStep(1); CHECK(ol_step(O2, 1, nullptr) == 0, "RACER ol_step");
+      hl_readback(R.handle(), HL_TAP_FLAT, f1.data(), 32 * 8); ol_readback(O2, HL_TAP_FLAT, f2.data(), 32 * 8);
+      CHECK(f1 == f2, "RACER step %d: sampled indices differ", k);
+    }
+    const int64_t n2 = hl_num_params(R.handle());
+    std::vector<float> a(n2), b(n2), t1(n2), t2(n2);
+    hl_get_params(R.handle(), a.data(), t1.data(), t2.data()); ol_get_params(O2, b.data(), t1.data(), t2.data());
+    CHECK(relinf(a, b) < 1e-4, "RACER weights after 20 steps: rel err %.3g", relinf(a, b));
+    hl_scalars s2; ol_get_scalars(O2, &s2);
+    CHECK(std::fabs(R.beta() - s2.beta) <= 1e-9 * s2.beta, "RACER beta");
+    ol_destroy(O2);
+  }
   ol_destroy(O);
   std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: OK\n", failures);
   return failures ? 1 : 0;
