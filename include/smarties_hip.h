@@ -77,7 +77,8 @@ enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU 
 /* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
 /* advantage head (Learners/AlgoFactory.cpp:109-152): Math/Zero_advantage.h (VRACER), Math/Gaus_advantage.h (RACER,
  * continuous actions: network outputs [V | coef, L+ x dA, L- x dA | mean x dA | sigma parameter x dA]);
- * HL_ADV_DISCRETE is declared for the reference's third variant and answers HL_ERR_UNSUPPORTED */
+ * Math/Discrete_advantage.h + Math/Discrete_policy.h (RACER, discrete actions: outputs [V | A x nOptions |
+ * policy logits x nOptions], no sigma layer; per-step policy vectors have nOptions entries instead of 2 dimA) */
 enum { HL_ADV_ZERO = 0 /* VRACER */, HL_ADV_GAUSSIAN = 1 /* RACER continuous */,
        HL_ADV_DISCRETE = 2 /* RACER discrete */ };
 
@@ -118,7 +119,10 @@ typedef struct hl_config {
   int32_t ref_threads;               /* OMP threads of the reference being mirrored: one
                                         mt19937 draw per thread per Adam step
                                         (Network/Optimizer.cpp:139); default 1            */
-  int32_t reserved[7];
+  int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..64) of the ONE
+                                        discrete action variable (dimA = 1; actions hold label + 0.1 as in
+                                        Core/StateAction.h:322-341, policies the nOptions probabilities); else 0 */
+  int32_t reserved[6];
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */

@@ -198,6 +198,8 @@ struct ol_learner {
   // adam (Network/Optimizer.h:38-47,96)
   Real beta_t_1 = 0.9, beta_t_2 = 0.999; int64_t nStep = 0;
   int nAdv = 0;                 // advantage outputs between V and the policy mean (0 = VRACER)
+  int nOpt = 0;                 // discrete head: number of options (0 = continuous)
+  int polDim = 0;               // entries of a stored behaviour policy: 2 dA (mean | stdev) or nOpt probabilities
   bool initialized = false, inStep = false, tap = false;
   // activations workspace: per layer X, Y, E for current and next step
   std::vector<std::vector<nnReal>> X, Y, E, Xn, Yn;
@@ -234,18 +236,20 @@ void buildNet(ol_learner* h) {
   }
   // VRACER: [V, mean x dA]; RACER with the Gaussian advantage: [V, coef, L+ x dA, L- x dA, mean x dA]
   // (RACER_common.cpp:172-186, Gaus_advantage.h:20-22); sigma is a ParamLayer (RACER_simpleSigma)
-  const int nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * c.dimA : 0;
-  const int nDense = 1 + nAdv + c.dimA;
-  h->nAdv = nAdv;
+  // RACER discrete: [V, A x nOpt, logits x nOpt], no sigma layer (RACER_common.cpp:119-134)
+  const bool discrete = c.adv_kind == HL_ADV_DISCRETE;
+  const int nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * c.dimA : (discrete ? c.n_options : 0);
+  const int nDense = 1 + nAdv + (discrete ? c.n_options : c.dimA);
+  h->nAdv = nAdv; h->nOpt = discrete ? c.n_options : 0; h->polDim = discrete ? c.n_options : 2 * c.dimA;
   { const int ID = (int)L.size();
     Layer o; o.type = L_DENSE; o.size = nDense; o.nIn = L[ID - 1].size;
     o.nOutSimd = (int)roundUp8(o.size); o.func = HL_FUNC_LINEAR; o.bOutput = true;
-    if (nAdv) {   // Builder::setLastLayersBias(biases): Gaussian_advantage::setInitial (Gaus_advantage.h:31-34)
+    if (c.adv_kind == HL_ADV_GAUSSIAN) {   // Builder::setLastLayersBias(biases): Gaussian_advantage::setInitial (Gaus_advantage.h:31-34)
       o.biasInit.assign(nDense, 0); o.biasInit[1] = -1;
       for (int e = 2; e < 1 + nAdv; ++e) o.biasInit[e] = 1;
     }
     L.push_back(o); }
-  { Layer p; p.type = L_PARAM; p.size = c.dimA; p.func = HL_FUNC_LINEAR; p.bOutput = true;
+  if (!discrete) { Layer p; p.type = L_PARAM; p.size = c.dimA; p.func = HL_FUNC_LINEAR; p.bOutput = true;
     // Continuous_policy::initial_Stdev -> SoftPlus::_inv(explNoise) (Continuous_policy.h:603-617,192-194)
     Real S = c.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
     p.biasInit.assign(c.dimA, spInv(S)); L.push_back(p); }
@@ -264,7 +268,7 @@ void buildNet(ol_learner* h) {
     l.indB = tot; tot += roundUp8(l.nB);
   }
   h->nParams = tot;
-  h->nOut = nDense + c.dimA;
+  h->nOut = nDense + (discrete ? 0 : c.dimA);
   h->W.assign(tot, 0); h->M1.assign(tot, 0); h->M2.assign(tot, 0); h->G.assign(tot, 0);
   const size_t nl = L.size();
   h->X.resize(nl); h->Y.resize(nl); h->E.resize(nl); h->Xn.resize(nl); h->Yn.resize(nl);
@@ -505,6 +509,46 @@ extern "C" void ol_head_racer(int dA, int nAdv, const uint8_t* bounded, const do
   }
   *rho = RHO; *dkl = kl; *deltaQ = dQ; *isFar = far ? 1 : 0; *Vval = V; *Qval = Aval + V;
 }
+// RACER::Train with Discrete_policy (Math/Discrete_policy.h:17-208: SoftPlus-normalised probabilities) and
+// Discrete_advantage (Math/Discrete_advantage.h:17-100).  Output layout [V | A x nOpt | logits x nOpt].
+extern "C" void ol_head_discrete(int nOpt, const double* O, double actMsg, const double* mu, double Qret, double beta,
+                                 double Cmax, double Cinv, double* grad, double* rho, double* dkl, double* deltaQ,
+                                 int* isFar, double* Vval, double* Qval) {
+  const int pA = 1, pP = 1 + nOpt;
+  const int act = (int)std::floor(actMsg);                         // ActionInfo::actionMessage2label (StateAction.h:300-320)
+  std::vector<Real> unnorm(nOpt), probs(nOpt);
+  Real norm = 0;
+  for (int j = 0; j < nOpt; ++j) { unnorm[j] = spEval(O[pP + j]); norm += unnorm[j]; }
+  norm = std::max(norm, std::numeric_limits<Real>::epsilon());
+  for (int j = 0; j < nOpt; ++j) probs[j] = unnorm[j] / norm;
+  const Real RHO = probs[act] / mu[act];                           // importanceWeight (:84-91)
+  Real kl = 0;
+  for (int i = 0; i < nOpt; ++i) kl += probs[i] * std::log(probs[i] / mu[i]);   // KLDivergence (:126-130)
+  const bool far = isFarPolicy((Fval)RHO, (Fval)Cmax, (Fval)Cinv);
+  Real expA = 0;
+  for (int j = 0; j < nOpt; ++j) expA += probs[j] * O[pA + j];
+  const Real Aval = O[pA + act] - expA;                            // computeAdvantage (:64-70)
+  const Real V = scaleNet2V(O[0]);
+  const Real A_RET = Qret - V, dQ = A_RET - Aval;
+  const Real Ver = std::min((Real)1, RHO) * dQ, Aer = std::min(Cmax, RHO) * dQ;
+  grad[0] = far ? 0 : Ver * beta * scaleVdiff(O[0]);
+  // penalG = KLDivGradient(mu, -1) (:152-162), polG = policyGradient(act, A_RET min(Cmax, rho)) (:136-144) or zeros
+  std::vector<Real> penalG(nOpt, 0), polG(nOpt, 0);
+  for (int j = 0; j < nOpt; ++j) {
+    const Real tmp = -1 * (1 + std::log(probs[j] / mu[j])) / norm;
+    for (int i = 0; i < nOpt; ++i) penalG[i] += tmp * ((i == j) - probs[j]);
+  }
+  for (int j = 0; j < nOpt; ++j) penalG[j] *= spDiff(O[pP + j]);
+  if (!far) {
+    const Real factor = A_RET * std::min(Cmax, RHO);
+    polG[act] = factor / unnorm[act];
+    for (int i = 0; i < nOpt; ++i) { polG[i] -= factor / norm; polG[i] *= spDiff(O[pP + i]); }
+  }
+  for (int j = 0; j < nOpt; ++j) grad[pP + j] = beta * polG[j] + (1 - beta) * penalG[j];   // penalizeReFER + makeNetworkGrad
+  const Real Qer = far ? 0 : beta * Aer;
+  for (int j = 0; j < nOpt; ++j) grad[pA + j] = Qer * ((j == act ? 1 : 0) - probs[j]);     // Discrete_advantage::grad (:51-58)
+  *rho = RHO; *dkl = kl; *deltaQ = dQ; *isFar = far ? 1 : 0; *Vval = V; *Qval = Aval + V;
+}
 
 namespace {
 
@@ -733,7 +777,8 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
   if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
-  if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN) return HL_ERR_UNSUPPORTED;
+  if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
+  if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 64)) return HL_ERR_BAD_ARG;
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   auto* h = new ol_learner(); h->cfg = *cfg;
@@ -804,7 +849,7 @@ int ol_append_episode(ol_learner* h, int32_t N, const float* states, const doubl
   EP->N = N; EP->term = terminated != 0; EP->tag = tag;
   EP->S.assign(states, states + (size_t)N * dS);
   EP->A.assign(actions, actions + (size_t)N * dA);
-  EP->MU.assign(mu, mu + (size_t)N * 2 * dA);
+  EP->MU.assign(mu, mu + (size_t)N * h->polDim);
   EP->R.assign(rewards, rewards + N);
   EP->V.assign(values, values + N);
   if (advantages) EP->ADV.assign(advantages, advantages + N); else EP->ADV.assign(N, 0);
@@ -889,7 +934,7 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
   if (h->tap) { h->tState.assign((size_t)B * dS, 0); h->tO.assign((size_t)B * nOut, 0); h->tG.assign((size_t)B * nOut, 0);
     h->tRho.assign(B, 0); h->tDkl.assign(B, 0); h->tDq.assign(B, 0); h->tFar.assign(B, 0); }
   std::vector<nnReal> inp(dS); std::vector<Real> O(nOut), On(nOut), grad(nOut);
-  const size_t outDense = h->layers.size() - 2, outParam = h->layers.size() - 1;
+  const size_t outParam = h->layers.size() - 1, outDense = h->nOpt ? outParam : outParam - 1;   // discrete: no sigma layer
   h->gsSum.assign(nOut, 0); h->gsSq.assign(nOut, 0);
   for (int b = 0; b < B; ++b) {
     Episode& EP = *h->episodes[h->bEp[b]]; const int t = (int)h->bT[b];
@@ -906,17 +951,19 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
       epUpdateValues(EP, t + 1, Vn, Vn);
     }
     Real rho, dkl, dq, V, Q; int far;
-    const int nAdv = h->nAdv, nDn = 1 + nAdv + dA;
-    ol_head_racer(dA, nAdv, h->cfg.bounded, O.data(), &EP.A[(size_t)t * dA], &EP.MU[(size_t)t * 2 * dA],
+    const int nAdv = h->nAdv, nDn = h->nOpt ? 1 + 2 * h->nOpt : 1 + nAdv + dA;
+    if (h->nOpt) ol_head_discrete(h->nOpt, O.data(), EP.A[(size_t)t * dA], &EP.MU[(size_t)t * h->polDim], (Real)EP.RET[t], h->beta,
+                                  h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V, &Q);
+    else ol_head_racer(dA, nAdv, h->cfg.bounded, O.data(), &EP.A[(size_t)t * dA], &EP.MU[(size_t)t * h->polDim],
                   (Real)EP.RET[t], h->beta, h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V, &Q);
     for (int o = 0; o < nOut; ++o) { h->gsSum[o] += grad[o]; h->gsSq[o] += grad[o] * grad[o]; }   // StatsTracker::track_vector (Approximator.h:197)
     // Approximator::setGradient -> Activation::addOutputDelta (Approximator.h:190-204, Activation.h:108-117)
     for (auto& e : h->E) std::fill(e.begin(), e.end(), 0);
     for (int o = 0; o < nDn; ++o) h->E[outDense][o] += grad[o];
-    for (int o = 0; o < dA; ++o) h->E[outParam][o] += grad[nDn + o];
+    if (!h->nOpt) for (int o = 0; o < dA; ++o) h->E[outParam][o] += grad[nDn + o];
     if (h->tap) { for (int o = 0; o < nOut; ++o) { h->tO[(size_t)b * nOut + o] = O[o]; }
       for (int o = 0; o < nDn; ++o) h->tG[(size_t)b * nOut + o] = h->E[outDense][o];
-      for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + nDn + o] = h->E[outParam][o];
+      if (!h->nOpt) for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + nDn + o] = h->E[outParam][o];
       h->tRho[b] = rho; h->tDkl[b] = dkl; h->tFar[b] = (uint8_t)far; }
     // MiniBatch::setMseDklImpw / setValues (RACER_train.cpp:59-60; MiniBatch.h:161-175)
     epUpdateCumulative(EP, t, (Fval)dq, (Fval)dkl, (Fval)rho, (Fval)h->CmaxRet, (Fval)h->CinvRet);
@@ -992,20 +1039,20 @@ int ol_step(ol_learner* h, int32_t n, const int64_t* flat) {
 // Episode::packEpisode / unpackEpisode (ReplayMemory/Episode.cpp:24-130, sizes Episode.h:211-228)
 int64_t ol_packed_episode_size(const ol_learner* h, int32_t N) {
   if (!h || N < 0) return -1;
-  return (int64_t)(h->dS + h->dA + 2 * h->dA + 1 + 6) * N + 10;
+  return (int64_t)(h->dS + h->dA + h->polDim + 1 + 6) * N + 10;
 }
 int ol_append_packed_episode(ol_learner* h, const float* data, int64_t n) {
   if (!h || !data) return HL_ERR_BAD_ARG;
-  const int dS = h->dS, dA = h->dA, tup = dS + 1 + dA + 2 * dA;
+  const int dS = h->dS, dA = h->dA, pD = h->polDim, tup = dS + 1 + dA + pD;
   const int64_t N = (n - 10) / (tup + 6);
   if (N < 2 || ol_packed_episode_size(h, (int32_t)N) != n) return fail(h, HL_ERR_BAD_ARG, "packed episode has the wrong size");
   std::vector<float> S((size_t)N * dS), V(N), ADV(N);
-  std::vector<double> A((size_t)N * dA), MU((size_t)N * 2 * dA), R(N);
+  std::vector<double> A((size_t)N * dA), MU((size_t)N * pD), R(N);
   const float* buf = data;
   for (int64_t i = 0; i < N; ++i) {
     std::copy(buf, buf + dS, S.begin() + i * dS); R[i] = buf[dS]; buf += dS + 1;
     for (int j = 0; j < dA; ++j) A[i * dA + j] = buf[j]; buf += dA;
-    for (int j = 0; j < 2 * dA; ++j) MU[i * 2 * dA + j] = buf[j]; buf += 2 * dA;
+    for (int j = 0; j < pD; ++j) MU[i * pD + j] = buf[j]; buf += pD;
   }
   buf += N;                                            // returnEstimator: recomputed on insertion
   std::copy(buf, buf + N, ADV.begin()); buf += N;      // actionAdvantage
@@ -1025,7 +1072,7 @@ int ol_pack_episode(ol_learner* h, int64_t pos, float* dst, int64_t cap) {
   for (int64_t i = 0; i < N; ++i) {
     std::copy(EP.S.begin() + i * dS, EP.S.begin() + (i + 1) * dS, buf); buf[dS] = (float)EP.R[i]; buf += dS + 1;
     for (int j = 0; j < dA; ++j) buf[j] = (float)EP.A[i * dA + j]; buf += dA;
-    for (int j = 0; j < 2 * dA; ++j) buf[j] = (float)EP.MU[i * 2 * dA + j]; buf += 2 * dA;
+    for (int j = 0; j < h->polDim; ++j) buf[j] = (float)EP.MU[i * h->polDim + j]; buf += h->polDim;
   }
   for (int64_t i = 0; i < N; ++i) buf[i] = EP.RET[i]; buf += N;
   for (int64_t i = 0; i < N; ++i) buf[i] = EP.ADV[i]; buf += N;
@@ -1165,6 +1212,9 @@ int ol_get_stats(ol_learner* h, hl_stats* o) { if (!h || !o) return HL_ERR_BAD_A
 int ol_synth_episode_len(const synth_cfg* c, uint64_t e, int* term) { return synth_episode_len(c, e, term); }
 void ol_synth_episode(const synth_cfg* c, uint64_t e, float* s, double* a, double* mu, double* r, float* v) {
   synth_episode(c, e, s, a, mu, r, v);
+}
+void ol_synth_episode_discrete(const synth_cfg* c, int nOpt, uint64_t e, float* s, double* a, double* mu, double* r, float* v) {
+  synth_episode_discrete(c, nOpt, e, s, a, mu, r, v);
 }
 
 }  // extern "C"

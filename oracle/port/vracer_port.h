@@ -72,6 +72,11 @@ HL_API void ol_head_racer(int dA, int nAdv, const uint8_t* bounded, const double
                           const double* mu, double Qret, double beta, double Cmax, double Cinv,
                           double* grad /*1+nAdv+2dA*/, double* rho, double* dkl, double* deltaQ, int* isFar,
                           double* Vval, double* Qval);
+HL_API void ol_head_discrete(int nOpt, const double* O, double actMsg, const double* mu, double Qret, double beta,
+                             double Cmax, double Cinv, double* grad /*1+2nOpt*/, double* rho, double* dkl, double* deltaQ,
+                             int* isFar, double* Vval, double* Qval);
+HL_API void ol_synth_episode_discrete(const synth_cfg* c, int nOpt, uint64_t e, float* states, double* actions,
+                                      double* mu, double* rewards, float* values);
 #ifdef __cplusplus
 }
 #endif

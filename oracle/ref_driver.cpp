@@ -25,6 +25,8 @@
 #include "smarties/Learners/RACER.h"
 #include "smarties/Math/Zero_advantage.h"
 #include "smarties/Math/Gaus_advantage.h"
+#include "smarties/Math/Discrete_policy.h"
+#include "smarties/Math/Discrete_advantage.h"
 #include "smarties/Math/Continuous_policy.h"
 #include "smarties/Network/Approximator.h"
 #include "smarties/Network/Optimizer.h"
@@ -74,12 +76,21 @@ static std::vector<uint32_t> rngState(const std::mt19937& g) {
 
 // -DREF_GAUSS_ADV builds the same harness around RACER with the Gaussian advantage head
 // (RACER<Param_advantage = Gaussian_advantage, Continuous_policy, Rvec>, Learners/AlgoFactory.cpp:124)
-#ifdef REF_GAUSS_ADV
+#if defined(REF_DISCRETE)
+// -DREF_DISCRETE: RACER<Discrete_advantage, Discrete_policy, Uint> (Learners/AlgoFactory.cpp:109), one action
+// variable with `nOpt` options
+using VRACER = RACER<Discrete_advantage, Discrete_policy, Uint>;
+using POLICY = Discrete_policy;
+static const char* kLearner = "RACER";
+static const int64_t kAdvKind = 2;
+#elif defined(REF_GAUSS_ADV)
 using VRACER = RACER<Gaussian_advantage, Continuous_policy, Rvec>;
+using POLICY = Continuous_policy;
 static const char* kLearner = "RACER";
 static const int64_t kAdvKind = 1;
 #else
 using VRACER = RACER<Zero_advantage, Continuous_policy, Rvec>;
+using POLICY = Continuous_policy;
 static const char* kLearner = "VRACER";
 static const int64_t kAdvKind = 0;
 #endif
@@ -91,6 +102,7 @@ struct Harness {
   std::unique_ptr<VRACER> L;
   std::unique_ptr<TaskQueue> algo, dataQ;
   synth_cfg SC;
+  int nOpt = 0;     // discrete harness: number of action options
 
   Harness(ExecutionInfo& I, const Args& A) : info(I) {
     const int nThr = (int)A.l("threads", 1);
@@ -104,8 +116,17 @@ struct Harness {
     const std::string bnd = A.s("bounded", std::string(dA, '1'));
     MDP.bActionSpaceBounded = std::vector<bool>(dA, false);
     for (Uint i = 0; i < dA && i < bnd.size(); ++i) MDP.bActionSpaceBounded[i] = bnd[i] == '1';
+#ifdef REF_DISCRETE
+    nOpt = (int)A.l("nOpt", 4);
+    if (dA != 1) { fprintf(stderr, "discrete harness: dimA must be 1\n"); exit(2); }
+    MDP.discreteActionValues = std::vector<Uint>(1, (Uint)nOpt);
+#endif
     MDP.synchronize([](void*, size_t) {});
+#ifdef REF_DISCRETE
+    MDP.policyVecDim = nOpt;
+#else
     MDP.policyVecDim = 2 * dA;
+#endif
     HP = std::make_unique<HyperParameters>(dS, dA);
     HP->learner = kLearner; HP->returnsEstimator = "retrace";
     HP->nnLayerSizes = parseList(A.s("layers", "256,256"));
@@ -141,15 +162,22 @@ struct Harness {
     int term = 0; const int N = synth_episode_len(&SC, e, &term);
     const int dS = SC.dimS, dA = SC.dimA;
     std::vector<float> S((size_t)N * dS), V(N);
-    std::vector<double> Act((size_t)N * dA), Mu((size_t)N * 2 * dA), R(N);
+#ifdef REF_DISCRETE
+    const int pD = nOpt;
+    std::vector<double> Act((size_t)N * dA), Mu((size_t)N * pD), R(N);
+    synth_episode_discrete(&SC, nOpt, e, S.data(), Act.data(), Mu.data(), R.data(), V.data());
+#else
+    const int pD = 2 * dA;
+    std::vector<double> Act((size_t)N * dA), Mu((size_t)N * pD), R(N);
     synth_episode(&SC, e, S.data(), Act.data(), Mu.data(), R.data(), V.data());
+#endif
     auto EP = std::make_unique<Episode>(MDP);
     EP->bReachedTermState = term; EP->agentID = (Sint)e;  // agentID doubles as content tag
     for (int t = 0; t < N; ++t) {
       EP->states.push_back(Fvec(S.begin() + (size_t)t * dS, S.begin() + (size_t)(t + 1) * dS));
       EP->latent_states.push_back(Fvec());
       EP->actions.push_back(Rvec(Act.begin() + (size_t)t * dA, Act.begin() + (size_t)(t + 1) * dA));
-      EP->policies.push_back(Rvec(Mu.begin() + (size_t)t * 2 * dA, Mu.begin() + (size_t)(t + 1) * 2 * dA));
+      EP->policies.push_back(Rvec(Mu.begin() + (size_t)t * pD, Mu.begin() + (size_t)(t + 1) * pD));
       EP->rewards.push_back(R[t]);
       if (t) EP->totR += R[t];
       EP->stateValue.push_back(V[t]);
@@ -208,7 +236,7 @@ static void manualStep(Harness& H, StepTap* tap) {
       const Rvec O = A->getOutput();
       const NNvec G = A->getOutputDelta();
       for (Uint o = 0; o < nOut; ++o) { tap->O[b * nOut + o] = O[o]; tap->G[b * nOut + o] = G[o]; }
-      const Continuous_policy POL(L.pol_start, L.aInfo, O);
+      const POLICY POL(L.pol_start, L.aInfo, O);
       const Real RHO = POL.importanceWeight(MB.action(b, t), MB.mu(b, t));
       tap->rho[b] = RHO; tap->dkl[b] = POL.KLDivergence(MB.mu(b, t));
       tap->dq[b] = MB.episodes[b]->deltaValue[t];
@@ -249,7 +277,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   {
     std::vector<int64_t> cfg = {(int64_t)H.MDP.dimStateObserved, (int64_t)H.MDP.dimAction,
         (int64_t)H.HP->batchSize, nEps, nSteps, (int64_t)PW->nParams, (int64_t)NET.nOutputs(),
-        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind};
+        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind, (int64_t)H.nOpt};
     W.i64("cfg", cfg);
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

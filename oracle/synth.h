@@ -94,6 +94,33 @@ static inline void synth_episode(const synth_cfg* c, uint64_t e,
   }
 }
 
+/* Discrete-action variant (RACER<Discrete_advantage, Discrete_policy, Uint>): one action variable with nOpt options.
+ * actions f64[N] hold the action message label + 0.1 (Core/StateAction.h:322-341), mu f64[N*nOpt] the behaviour
+ * probabilities; divisions are IEEE-exact, no libm, so every translation unit produces the same bits. */
+static inline void synth_episode_discrete(const synth_cfg* c, int nOpt, uint64_t e, float* states /*N*dS*/,
+                                          double* actions /*N*/, double* mu /*N*nOpt*/, double* rewards /*N*/,
+                                          float* values /*N*/) {
+  int term = 0;
+  const int N = synth_episode_len(c, e, &term);
+  synth_rng g; g.s = c->seed * 0xA0761D6478BD642Full + e * 0xE7037ED1A0B428DBull + 11;
+  const int dS = c->dimS;
+  for (int t = 0; t < N; ++t) {
+    for (int i = 0; i < dS; ++i)
+      states[(size_t)t * dS + i] = (float)(synth_normal(&g) * (0.5 + 0.1 * i) + (0.2 * i - 1.0));
+    rewards[t] = t == 0 ? 0.0 : synth_normal(&g) + 0.1;
+    const int last = (t == N - 1);
+    double w[64], tot = 0;
+    for (int j = 0; j < nOpt; ++j) { w[j] = synth_u01(&g) + c->muSpread * 0.2; tot += w[j]; }
+    const double r = synth_u01(&g) * tot;
+    double acc = 0; int label = nOpt - 1;
+    for (int j = 0; j < nOpt; ++j) { acc += w[j]; if (r < acc) { label = j; break; } }
+    for (int j = 0; j < nOpt; ++j) mu[(size_t)t * nOpt + j] = last ? 0.0 : w[j] / tot;
+    actions[t] = last ? 0.0 : (double)label + 0.1;
+    const double v = 0.5 * synth_normal(&g);
+    values[t] = (last && term) ? 0.0f : (float)v;
+  }
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,7 +42,7 @@ class HlConfig(C.Structure):
         ("nnLambda", C.c_double), ("explNoise", C.c_double), ("outWeightsPrefac", C.c_double),
         ("randSeed", C.c_uint64), ("n_ranks", C.c_int32), ("rank", C.c_int32),
         ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("n_options", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -65,7 +65,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
                 maxTotObsNum=1000000, minTotObsNum=0, gamma=0.995, lambda_=1.0, clipImpWeight=4.0,
                 penalTol=0.1, epsAnneal=0.0, learnrate=1e-4, nnLambda=0.0, explNoise=0.4472135955,
                 outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
-                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO):
+                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0):
     """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
     c = HlConfig()
     c.struct_size = C.sizeof(HlConfig)
@@ -78,6 +78,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
         c.hidden[i] = int(hsz)
     c.nnFunc = FUNC[nnFunc] if isinstance(nnFunc, str) else int(nnFunc)
     c.adv_kind = adv_kind
+    c.n_options = n_options if adv_kind == ADV_DISCRETE else 0
     c.batchSize = batchSize
     c.maxTotObsNum, c.minTotObsNum = int(maxTotObsNum), int(minTotObsNum)
     c.gamma, c.lambda_, c.clipImpWeight, c.penalTol = gamma, lambda_, clipImpWeight, penalTol
@@ -210,6 +211,8 @@ class Learner:
         self.nParams = api.fn("num_params")(self.h)
         self.nOut = api.fn("num_outputs")(self.h)
         self.dS, self.dA = cfg.dimS, cfg.dimA
+        self.nOptions = cfg.n_options                      # discrete head: options of the one action variable
+        self.polDim = cfg.n_options if cfg.n_options else 2 * cfg.dimA
         self.B = max(1, cfg.batchSize // cfg.n_ranks) if cfg.batchSize > 1 else cfg.batchSize
 
     def close(self):
@@ -263,7 +266,7 @@ class Learner:
         states, values = _f32(states), _f32(values)
         actions, mu, rewards = _f64(actions), _f64(mu), _f64(rewards)
         n = rewards.size
-        assert states.size == n * self.dS and actions.size == n * self.dA and mu.size == 2 * n * self.dA
+        assert states.size == n * self.dS and actions.size == n * self.dA and mu.size == n * self.polDim
         adv = None if advantages is None else _f32(advantages)
         self._ck(self.api.fn("append_episode")(
             self.h, n, _ptr(states, C.c_float), _ptr(actions, C.c_double), _ptr(mu, C.c_double),

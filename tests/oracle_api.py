@@ -30,6 +30,9 @@ def oracle_api():
         lib = _api.lib
         lib.ol_synth_episode_len.restype = C.c_int
         lib.ol_synth_episode_len.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.POINTER(C.c_int)]
+        lib.ol_synth_episode_discrete.restype = None
+        lib.ol_synth_episode_discrete.argtypes = [C.POINTER(SynthCfg), C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ol_synth_episode.restype = None
         lib.ol_synth_episode.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
@@ -48,24 +51,29 @@ def synth_cfg(seed=7, dimS=17, dimA=6, lenMin=201, lenMax=201, pTerm=0.0, muSpre
     return SynthCfg(seed, dimS, dimA, lenMin, lenMax, pTerm, muSpread, actNoise)
 
 
-def synth_episode(sc, e):
-    """Episode `e` of the deterministic synthetic replay (oracle/synth.h)."""
+def synth_episode(sc, e, n_options=0):
+    """Episode `e` of the deterministic synthetic replay (oracle/synth.h); n_options > 0: the discrete-action variant
+    (actions = label + 0.1, behaviour policies = n_options probabilities)."""
     lib = oracle_api().lib
     term = C.c_int()
     n = lib.ol_synth_episode_len(C.byref(sc), e, C.byref(term))
     S = np.zeros((n, sc.dimS), np.float32)
     A = np.zeros((n, sc.dimA), np.float64)
-    MU = np.zeros((n, 2 * sc.dimA), np.float64)
+    MU = np.zeros((n, n_options if n_options else 2 * sc.dimA), np.float64)
     R = np.zeros(n, np.float64)
     V = np.zeros(n, np.float32)
-    lib.ol_synth_episode(C.byref(sc), e, S.ctypes.data, A.ctypes.data, MU.ctypes.data, R.ctypes.data,
-                         V.ctypes.data)
+    if n_options:
+        lib.ol_synth_episode_discrete(C.byref(sc), n_options, e, S.ctypes.data, A.ctypes.data, MU.ctypes.data,
+                                      R.ctypes.data, V.ctypes.data)
+    else:
+        lib.ol_synth_episode(C.byref(sc), e, S.ctypes.data, A.ctypes.data, MU.ctypes.data, R.ctypes.data,
+                             V.ctypes.data)
     return dict(states=S, actions=A, mu=MU, rewards=R, values=V, terminated=term.value, tag=e)
 
 
 def fill_synth(learner, sc, n_eps):
     for e in range(n_eps):
-        ep = synth_episode(sc, e)
+        ep = synth_episode(sc, e, getattr(learner, "nOptions", 0))
         learner.append_episode(**ep)
 
 
