@@ -119,7 +119,7 @@ typedef struct hl_config {
   int32_t ref_threads;               /* OMP threads of the reference being mirrored: one
                                         mt19937 draw per thread per Adam step
                                         (Network/Optimizer.cpp:139); default 1            */
-  int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..64) of the ONE
+  int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..32) of the ONE
                                         discrete action variable (dimA = 1; actions hold label + 0.1 as in
                                         Core/StateAction.h:322-341, policies the nOptions probabilities); else 0 */
   int32_t reserved[6];

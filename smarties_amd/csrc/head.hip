@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   const DevScalars* sc = a.sc;
   if (row >= sc->nRows[a.parity]) return;
   const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H, nAdv = a.nAdv, pM = 1 + nAdv;
+  const bool hasAdv = nAdv > 0 || a.nOpt > 0;
   const bool isNext = row >= B;
   const int b = isNext ? a.bt.nextSrc[row - B] : row;
   const long long slot = a.bt.slot[b];
@@ -59,9 +60,12 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   // the sampler already overwrites bt.eid / bt.nextOf for the next step
   if (!isNext && lane == 0) { a.bt.pEid[b] = a.bt.eid[b]; a.bt.pNextOf[b] = a.bt.nextOf[b]; }
   const float bo = lane < nDense ? a.params[a.indBo + lane] : 0.f;
-  const float bp = lane < dA ? a.params[a.indBp + lane] : 0.f;
+  const float bp = lane < a.nSig ? a.params[a.indBp + lane] : 0.f;
   double act = 0, bMean = 0, bStd = 1;
-  if (!isNext && lane < dA) {
+  if (!isNext && a.nOpt) {     // discrete head: lane 0 holds the action message, lane j the behaviour probability of option j
+    if (lane == 0) act = a.rp.A[slot];
+    if (lane < a.nOpt) bMean = a.rp.MU[(size_t)slot * a.nOpt + lane];
+  } else if (!isNext && lane < dA) {
     act = a.rp.A[(size_t)slot * dA + lane];
     bMean = a.rp.MU[(size_t)slot * 2 * dA + lane]; bStd = a.rp.MU[(size_t)slot * 2 * dA + dA + lane];
   }
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       }
     }
   }
-  if (lane < dA) sO[wave][nDense + lane] = (double)bp;   // ParamLayer, Linear
+  if (lane < a.nSig) sO[wave][nDense + lane] = (double)bp;   // ParamLayer, Linear (absent for the discrete head)
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
 
@@ -124,121 +128,164 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     return;
   }
 
-  // ---- policy terms, one action component per lane (fp64) ---------------------------------------
+  // ---- head: results shared by the write-back / back-propagation tail -------------------------------------
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
-  const double MAXM = 8.31776613503286, LOG2PI_2 = 9.1893853320467266954096885456237942e-01;
-  double lw = 0, kl = 0, mean = 0, stdev = 1, invStd = 1, dPos = 0;
-  bool bnd = false;
-  if (lane < dA) {
-    const int i = lane;
-    bnd = a.bounded[i] != 0;
-    mean = sO[wave][pM + i];
-    const double pp = sO[wave][nDense + i];
-    const double rt = sqrt(1 + pp * pp);
-    stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
-    const double bInv = 1 / bStd;
-    // log pi(a) - log mu(a): the tanh Jacobian J of SquashedNormalPolicy::logProb (:240-249) and
-    // the log(2 pi)/2 constants appear in both terms and cancel, log(invStd/J) - log(bInv/J) =
-    // -log(stdev/bStd); the same logarithm serves the KL divergence (log CmuCpi = 2 log(stdev/bStd)).
-    // One fp64 log per action component instead of three logs and a tanh (agrees with the
-    // reference's term-by-term evaluation to ~1e-16 relative).
-    const double m = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
-    const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
-    const double qq = stdev * bInv, lq = log(qq);
-    lw = (u2 * u2 - u1 * u1) / 2 - lq;
-    const double CmuCpi = qq * qq, dm = (mean - bMean) * bInv;
-    kl = (CmuCpi - 1 + dm * dm - 2 * lq) / 2;
-  }
-  const double logW = waveSum(lw), DKL = waveSum(kl);
-  const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
-  const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
-  const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
-  const double O0 = sO[wave][0];
-  const double V = scaleNet2V(O0);
-  const double Qret = (double)__shfl(misc, 0, 64);
-  // Gaussian_advantage::computeAdvantage (Gaus_advantage.h:76-88): A = coef (exp(-1/2 sum (a-m)^2 / L) - ratio),
-  // L = L+ above the policy mean, L- below; sums and products in the reference's component order
-  double Aval = 0, advCoef = 0, advOrig = 0, advRatio = 1, p1 = 1, p2 = 1, pm = 0;
-  auto sp = [](double x) { return (x + sqrt(1 + x * x)) / 2; };                 // SoftPlus::_eval (Functions.h:541-584)
-  auto spD = [](double x) { return (1 + x / sqrt(1 + x * x)) / 2; };
-  if (nAdv) {
-    double quadI = 0, rI = 1;
-    if (lane < dA) {
-      p1 = sp(sO[wave][2 + lane]); p2 = sp(sO[wave][2 + dA + lane]);
-      pm = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
-      const double d = act - pm, S = stdev * stdev;
-      quadI = d * d / (act > pm ? p1 : p2);
-      rI = sqrt(p1 / (p1 + S)) / 2 + sqrt(p2 / (p2 + S)) / 2;
+  double xRHO = 1, xDKL = 0, xV = 0, xdQ = 0, xAval = 0; bool xfar = false; double xg0 = 0;
+  if (a.nOpt) {
+    // ---- discrete actions: Discrete_policy (Math/Discrete_policy.h:17-208, SoftPlus-normalised probabilities) and
+    // Discrete_advantage (Math/Discrete_advantage.h:17-100); outputs [V | A x nOpt | logits x nOpt], one option per lane
+    const int nOpt = a.nOpt, pA = 1, pP = 1 + nOpt;
+    auto sp = [](double x) { return (x + sqrt(1 + x * x)) / 2; };
+    auto spD = [](double x) { return (1 + x / sqrt(1 + x * x)) / 2; };
+    const bool on = lane < nOpt;
+    const int label = (int)floor(__shfl(act, 0, 64));                      // ActionInfo::actionMessage2label
+    const double logit = on ? sO[wave][pP + lane] : 0.0, advJ = on ? sO[wave][pA + lane] : 0.0;
+    const double unnorm = on ? sp(logit) : 0.0;
+    const double norm = fmax(waveSum(unnorm), 2.220446049250313e-16);
+    const double pj = unnorm / norm, mj = on ? bMean : 1.0;                 // bMean carries mu_j for this head
+    const double lr = on ? log(pj / mj) : 0.0;
+    const double RHO = __shfl(pj, label, 64) / __shfl(mj, label, 64);       // importanceWeight (:84-91), no clipping
+    const double DKL = waveSum(on ? pj * lr : 0.0);                         // KLDivergence (:126-130)
+    const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
+    const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);
+    const double expA = waveSum(on ? pj * advJ : 0.0);
+    const double Aval = __shfl(advJ, label, 64) - expA;                     // computeAdvantage (:64-70)
+    const double O0 = sO[wave][0], V = scaleNet2V(O0);
+    const double Qret = (double)__shfl(misc, 0, 64);
+    const double A_RET = Qret - V, dQ = A_RET - Aval;
+    const double g0 = far ? 0.0 : fmin(1.0, RHO) * dQ * beta * scaleVdiff(O0);
+    const double Qer = far ? 0.0 : beta * (fmin(Cmax, RHO) * dQ);
+    // KLDivGradient(mu, -1) (:152-162): sum_j tmp_j ((i == j) - p_j) = tmp_i - sum_j tmp_j p_j
+    const double tmp = on ? -(1 + lr) / norm : 0.0;
+    const double tp = waveSum(on ? tmp * pj : 0.0);
+    if (on) {
+      const double dpos = spD(logit);
+      const double penal = (tmp - tp) * dpos;
+      double pol = 0;
+      if (!far) { const double factor = A_RET * fmin(Cmax, RHO); pol = ((lane == label ? factor / unnorm : 0.0) - factor / norm) * dpos; }   // policyGradient (:136-144)
+      const double gP = beta * pol + (1 - beta) * penal;                    // penalizeReFER + makeNetworkGrad
+      const double gA = Qer * ((lane == label ? 1.0 : 0.0) - pj);           // Discrete_advantage::grad (:51-58)
+      sDelta[wave][pP + lane] = (float)gP; sDelta[wave][pA + lane] = (float)gA;
+      a.bt.G[(size_t)b * a.nOut + pP + lane] = (double)(float)gP;
+      a.bt.G[(size_t)b * a.nOut + pA + lane] = (double)(float)gA;
     }
-    double quad = 0;
-    for (int i = 0; i < dA; ++i) { quad += __shfl(quadI, i, 64); advRatio *= __shfl(rI, i, 64); }
-    advCoef = sp(sO[wave][1]); advOrig = exp(-quad / 2);
-    Aval = advCoef * (advOrig - advRatio);
-  }
-  const double A_RET = Qret - V, dQ = A_RET - Aval;                // Zero_advantage: A = 0
-  const double Ver = fmin(1.0, RHO) * dQ;
-  const double Qer = far ? 0.0 : beta * (fmin(Cmax, RHO) * dQ);    // RACER_train.cpp:42,56
-  const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
-  const double coef = A_RET * fmin(Cmax, RHO);
-  if (lane < dA) {
-    const double dMean = mean - bMean, invVarMu = 1 / (bStd * bStd);
-    const double penalM = -1 * (dMean * invVarMu);
-    const double penalS = dPos * -1 * ((invVarMu - invStd * invStd) * stdev);
-    double polM = 0, polS = 0;
-    if (!far) {
-      if (bnd) {
-        const double dLogPdMean = (act - mean) * invStd * invStd;
-        const double m = mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean);
-        const double u = (act - m) * invStd;
-        polS = dPos * coef * ((u * u - 1) * invStd);
-        if (mean >= MAXM && coef * dLogPdMean > 0) polM = 0;
-        else if (mean <= -MAXM && coef * dLogPdMean < 0) polM = 0;
-        else polM = coef * dLogPdMean;
-      } else {
-        const double u = (act - mean) * invStd;
-        polM = coef * (u * invStd);
-        polS = dPos * coef * ((u * u - 1) * invStd);
+    xRHO = RHO; xDKL = DKL; xV = V; xdQ = dQ; xAval = Aval; xfar = far; xg0 = g0;
+  } else {
+    const double MAXM = 8.31776613503286, LOG2PI_2 = 9.1893853320467266954096885456237942e-01;
+    double lw = 0, kl = 0, mean = 0, stdev = 1, invStd = 1, dPos = 0;
+    bool bnd = false;
+    if (lane < dA) {
+      const int i = lane;
+      bnd = a.bounded[i] != 0;
+      mean = sO[wave][pM + i];
+      const double pp = sO[wave][nDense + i];
+      const double rt = sqrt(1 + pp * pp);
+      stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
+      const double bInv = 1 / bStd;
+      // log pi(a) - log mu(a): the tanh Jacobian J of SquashedNormalPolicy::logProb (:240-249) and
+      // the log(2 pi)/2 constants appear in both terms and cancel, log(invStd/J) - log(bInv/J) =
+      // -log(stdev/bStd); the same logarithm serves the KL divergence (log CmuCpi = 2 log(stdev/bStd)).
+      // One fp64 log per action component instead of three logs and a tanh (agrees with the
+      // reference's term-by-term evaluation to ~1e-16 relative).
+      const double m = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
+      const double u1 = (act - m) * invStd, u2 = (act - bMean) * bInv;
+      const double qq = stdev * bInv, lq = log(qq);
+      lw = (u2 * u2 - u1 * u1) / 2 - lq;
+      const double CmuCpi = qq * qq, dm = (mean - bMean) * bInv;
+      kl = (CmuCpi - 1 + dm * dm - 2 * lq) / 2;
+    }
+    const double logW = waveSum(lw), DKL = waveSum(kl);
+    const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
+    const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
+    const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
+    const double O0 = sO[wave][0];
+    const double V = scaleNet2V(O0);
+    const double Qret = (double)__shfl(misc, 0, 64);
+    // Gaussian_advantage::computeAdvantage (Gaus_advantage.h:76-88): A = coef (exp(-1/2 sum (a-m)^2 / L) - ratio),
+    // L = L+ above the policy mean, L- below; sums and products in the reference's component order
+    double Aval = 0, advCoef = 0, advOrig = 0, advRatio = 1, p1 = 1, p2 = 1, pm = 0;
+    auto sp = [](double x) { return (x + sqrt(1 + x * x)) / 2; };                 // SoftPlus::_eval (Functions.h:541-584)
+    auto spD = [](double x) { return (1 + x / sqrt(1 + x * x)) / 2; };
+    if (nAdv) {
+      double quadI = 0, rI = 1;
+      if (lane < dA) {
+        p1 = sp(sO[wave][2 + lane]); p2 = sp(sO[wave][2 + dA + lane]);
+        pm = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
+        const double d = act - pm, S = stdev * stdev;
+        quadI = d * d / (act > pm ? p1 : p2);
+        rI = sqrt(p1 / (p1 + S)) / 2 + sqrt(p2 / (p2 + S)) / 2;
+      }
+      double quad = 0;
+      for (int i = 0; i < dA; ++i) { quad += __shfl(quadI, i, 64); advRatio *= __shfl(rI, i, 64); }
+      advCoef = sp(sO[wave][1]); advOrig = exp(-quad / 2);
+      Aval = advCoef * (advOrig - advRatio);
+    }
+    const double A_RET = Qret - V, dQ = A_RET - Aval;                // Zero_advantage: A = 0
+    const double Ver = fmin(1.0, RHO) * dQ;
+    const double Qer = far ? 0.0 : beta * (fmin(Cmax, RHO) * dQ);    // RACER_train.cpp:42,56
+    const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
+    const double coef = A_RET * fmin(Cmax, RHO);
+    if (lane < dA) {
+      const double dMean = mean - bMean, invVarMu = 1 / (bStd * bStd);
+      const double penalM = -1 * (dMean * invVarMu);
+      const double penalS = dPos * -1 * ((invVarMu - invStd * invStd) * stdev);
+      double polM = 0, polS = 0;
+      if (!far) {
+        if (bnd) {
+          const double dLogPdMean = (act - mean) * invStd * invStd;
+          const double m = mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean);
+          const double u = (act - m) * invStd;
+          polS = dPos * coef * ((u * u - 1) * invStd);
+          if (mean >= MAXM && coef * dLogPdMean > 0) polM = 0;
+          else if (mean <= -MAXM && coef * dLogPdMean < 0) polM = 0;
+          else polM = coef * dLogPdMean;
+        } else {
+          const double u = (act - mean) * invStd;
+          polM = coef * (u * invStd);
+          polS = dPos * coef * ((u * u - 1) * invStd);
+        }
+      }
+      const double gM = beta * polM + (1 - beta) * penalM;
+      const double gS = beta * polS + (1 - beta) * penalS;
+      // Activation::addOutputDelta: nnReal += Real (Activation.h:108-117)
+      sDelta[wave][pM + lane] = (float)gM;
+      a.bt.gParam[(size_t)b * dA + lane] = (float)gS;
+      a.bt.G[(size_t)b * a.nOut + pM + lane] = (double)(float)gM;
+      a.bt.G[(size_t)b * a.nOut + nDense + lane] = (double)(float)gS;
+      if (nAdv) {   // Gaussian_advantage::grad (Gaus_advantage.h:91-116) for the two precisions of this component
+        const double expect = -advRatio, S = stdev * stdev, d = act - pm;
+        double g1 = act > pm ? advOrig * advCoef * ((d / p1) * (d / p1)) / 2 : 0;
+        double g2 = act < pm ? advOrig * advCoef * ((d / p2) * (d / p2)) / 2 : 0;
+        const double F = 2 / (sqrt(p1 / (p1 + S)) + sqrt(p2 / (p2 + S)));
+        const double q1 = p1 + S, q2 = p2 + S;
+        g1 += F * expect * advCoef * (S / sqrt(p1 * (q1 * q1 * q1)) / 4);
+        g2 += F * expect * advCoef * (S / sqrt(p2 * (q2 * q2 * q2)) / 4);
+        g1 *= Qer * spD(sO[wave][2 + lane]); g2 *= Qer * spD(sO[wave][2 + dA + lane]);          // grad_matrix (:69-74)
+        sDelta[wave][2 + lane] = (float)g1; sDelta[wave][2 + dA + lane] = (float)g2;
+        a.bt.G[(size_t)b * a.nOut + 2 + lane] = (double)(float)g1;
+        a.bt.G[(size_t)b * a.nOut + 2 + dA + lane] = (double)(float)g2;
       }
     }
-    const double gM = beta * polM + (1 - beta) * penalM;
-    const double gS = beta * polS + (1 - beta) * penalS;
-    // Activation::addOutputDelta: nnReal += Real (Activation.h:108-117)
-    sDelta[wave][pM + lane] = (float)gM;
-    a.bt.gParam[(size_t)b * dA + lane] = (float)gS;
-    a.bt.G[(size_t)b * a.nOut + pM + lane] = (double)(float)gM;
-    a.bt.G[(size_t)b * a.nOut + nDense + lane] = (double)(float)gS;
-    if (nAdv) {   // Gaussian_advantage::grad (Gaus_advantage.h:91-116) for the two precisions of this component
-      const double expect = -advRatio, S = stdev * stdev, d = act - pm;
-      double g1 = act > pm ? advOrig * advCoef * ((d / p1) * (d / p1)) / 2 : 0;
-      double g2 = act < pm ? advOrig * advCoef * ((d / p2) * (d / p2)) / 2 : 0;
-      const double F = 2 / (sqrt(p1 / (p1 + S)) + sqrt(p2 / (p2 + S)));
-      const double q1 = p1 + S, q2 = p2 + S;
-      g1 += F * expect * advCoef * (S / sqrt(p1 * (q1 * q1 * q1)) / 4);
-      g2 += F * expect * advCoef * (S / sqrt(p2 * (q2 * q2 * q2)) / 4);
-      g1 *= Qer * spD(sO[wave][2 + lane]); g2 *= Qer * spD(sO[wave][2 + dA + lane]);          // grad_matrix (:69-74)
-      sDelta[wave][2 + lane] = (float)g1; sDelta[wave][2 + dA + lane] = (float)g2;
-      a.bt.G[(size_t)b * a.nOut + 2 + lane] = (double)(float)g1;
-      a.bt.G[(size_t)b * a.nOut + 2 + dA + lane] = (double)(float)g2;
+    if (nAdv && lane == 0) {   // coefficient output of the Gaussian advantage
+      const double gc = (advOrig - advRatio) * (Qer * spD(sO[wave][1]));
+      sDelta[wave][1] = (float)gc; a.bt.G[(size_t)b * a.nOut + 1] = (double)(float)gc;
     }
+    xRHO = RHO; xDKL = DKL; xV = V; xdQ = dQ; xAval = Aval; xfar = far; xg0 = g0;
   }
   {
     const float oDQ = __shfl(misc, 1, 64), oDKL = __shfl(misc, 2, 64), oW = __shfl(misc, 3, 64);
     const float oV = __shfl(misc, 4, 64), oADV = __shfl(misc, 5, 64);
     if (lane == 0) {
-      sDelta[wave][0] = (float)g0;
-      a.bt.G[(size_t)b * a.nOut] = (double)(float)g0;
-      if (nAdv) {
-        const double gc = (advOrig - advRatio) * (Qer * spD(sO[wave][1]));
-        sDelta[wave][1] = (float)gc; a.bt.G[(size_t)b * a.nOut + 1] = (double)(float)gc;
-      }
-      a.bt.rho[b] = RHO; a.bt.dkl[b] = DKL; a.bt.far[b] = far ? 1 : 0;
+      sDelta[wave][0] = (float)xg0;
+      a.bt.G[(size_t)b * a.nOut] = (double)(float)xg0;
+      a.bt.rho[b] = xRHO; a.bt.dkl[b] = xDKL; a.bt.far[b] = xfar ? 1 : 0;
       // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
-      const float E = (float)dQ, D = (float)DKL, Wn = (float)RHO, Vf = (float)V;
+      const float E = (float)xdQ, D = (float)xDKL, Wn = (float)xRHO, Vf = (float)xV;
       a.bt.oldDQ[b] = oDQ; a.bt.oldDKL[b] = oDKL; a.bt.oldW[b] = oW; a.bt.oldV[b] = oV; a.bt.oldADV[b] = oADV;
       a.bt.newDQ[b] = E; a.bt.newDKL[b] = D; a.bt.newW[b] = Wn; a.bt.newV[b] = Vf;
-      const float Qf = (float)(Aval + V);                   // Episode::updateValues_atomic(t, V, Q): advantage = Q - V in Fval
-      a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = nAdv ? Qf - Vf : 0.f;
-      a.bt.newQ[b] = nAdv ? Qf : Vf;
+      const float Qf = (float)(xAval + xV);                   // Episode::updateValues_atomic(t, V, Q): advantage = Q - V in Fval
+      a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = hasAdv ? Qf - Vf : 0.f;
+      a.bt.newQ[b] = hasAdv ? Qf : Vf;
       a.bt.dq[b] = (double)E;
     }
   }

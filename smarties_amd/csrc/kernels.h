@@ -20,6 +20,7 @@ struct HeadArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
   int B, dA, nDense, nOut, H;       // H = width of the last hidden block
   int nAdv;                         // advantage outputs between V and the policy mean: 0 (VRACER) or 1 + 2 dA (Gaussian)
+  int nOpt, nSig;                   // discrete head: number of options (else 0); size of the sigma ParamLayer (dA or 0)
   const float* Yin; int ldY;        // input of the output layer [Mmax][ldY]
   const float* Xlast; const float* Ylast; int func;   // last hidden block pre/post activation (for act')
   const float* params;              // weight blob

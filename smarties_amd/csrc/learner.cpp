@@ -49,6 +49,7 @@ struct hl_learner {
   int dev = 0;
   hipStream_t stream = nullptr;
   int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nAdv = 0, nHidden = 0, Mmax = 0;
+  int nOpt = 0, polDim = 0, nSig = 0;      // discrete head: options; entries of a stored policy (2 dA | nOpt); sigma ParamLayer size (dA | 0)
   long long maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
   // parameter blob layout (Parameters::_computeNParams, Layers/Parameters.h:159-176)
   std::vector<long long> indW, nW, indB, nB;
@@ -175,12 +176,15 @@ int buildNet(hl_learner* h) {
   if (nH < 1) return HL_ERR_BAD_ARG;
   h->nHidden = nH;
   // VRACER: [V, mean]; RACER with the Gaussian advantage: [V, coef, L+, L-, mean] (RACER_common.cpp:172-186)
-  h->nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * c.dimA : 0;
-  h->nDense = 1 + h->nAdv + c.dimA; h->nOut = h->nDense + c.dimA;
+  // RACER discrete: [V, A x nOpt, logits x nOpt], no sigma layer (RACER_common.cpp:119-134)
+  const bool discrete = c.adv_kind == HL_ADV_DISCRETE;
+  h->nOpt = discrete ? c.n_options : 0; h->polDim = discrete ? c.n_options : 2 * c.dimA; h->nSig = discrete ? 0 : c.dimA;
+  h->nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * c.dimA : (discrete ? c.n_options : 0);
+  h->nDense = 1 + h->nAdv + (discrete ? c.n_options : c.dimA); h->nOut = h->nDense + h->nSig;
   const int outLayer = (int)lw.size();
   lw.push_back(roundUp(h->nDense, 8) * prev); lb.push_back(h->nDense);
-  const int paramLayer = (int)lw.size();
-  lw.push_back(0); lb.push_back(c.dimA);
+  const int paramLayer = h->nSig ? (int)lw.size() : -1;
+  if (h->nSig) { lw.push_back(0); lb.push_back(h->nSig); }       // sigma ParamLayer (none behind a discrete policy)
   long long tot = 0;
   for (size_t l = 0; l < lw.size(); ++l) {
     h->indW.push_back(tot); h->nW.push_back(lw[l]); tot += roundUp(lw[l], 8);
@@ -196,14 +200,14 @@ int buildNet(hl_learner* h) {
     d.ldA = (int)roundUp(d.size, 16);
   }
   h->indWo = h->indW[outLayer]; h->indBo = h->indB[outLayer]; h->ldWo = (int)roundUp(h->nDense, 8);
-  h->indBp = h->indB[paramLayer];
+  h->indBp = paramLayer >= 0 ? h->indB[paramLayer] : 0;
   h->lay.clear();
   for (int j = 0; j < nH; ++j) {
     h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     if (hs[j].hasRes) h->lay.push_back({2, 0, hs[j].size, 0, h->indW[hs[j].resLayer], h->indB[hs[j].resLayer]});
   }
   h->lay.push_back({1, prev, h->nDense, h->ldWo, h->indWo, h->indBo});
-  h->lay.push_back({3, 0, c.dimA, 0, 0, h->indBp});
+  if (h->nSig) h->lay.push_back({3, 0, c.dimA, 0, 0, h->indBp});
   return HL_OK;
 }
 
@@ -273,7 +277,7 @@ int growSlots(hl_learner* h, long long need) {
   const long long newCap = std::max(need, h->capSlots + h->capSlots / 2 + 4096);
   const int dS = h->dS, dA = h->dA; hipStream_t s = h->stream;
   HIPCK(repack(&h->rp.S, dS, newCap, h->order, s)); HIPCK(repack(&h->rp.A, dA, newCap, h->order, s));
-  HIPCK(repack(&h->rp.MU, 2 * dA, newCap, h->order, s)); HIPCK(repack(&h->rp.R, 1, newCap, h->order, s));
+  HIPCK(repack(&h->rp.MU, h->polDim, newCap, h->order, s)); HIPCK(repack(&h->rp.R, 1, newCap, h->order, s));
   HIPCK(repack(&h->rp.V, 1, newCap, h->order, s)); HIPCK(repack(&h->rp.ADV, 1, newCap, h->order, s));
   HIPCK(repack(&h->rp.RET, 1, newCap, h->order, s)); HIPCK(repack(&h->rp.DQ, 1, newCap, h->order, s));
   HIPCK(repack(&h->rp.IMPW, 1, newCap, h->order, s)); HIPCK(repack(&h->rp.DKL, 1, newCap, h->order, s));
@@ -401,7 +405,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
   if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
-  if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN) return HL_ERR_UNSUPPORTED;
+  if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
+  if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;   // head kernel: one option per lane, deltas staged in 72 floats
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
@@ -470,7 +475,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&bt.newDQ, B)); HIPCK(devAlloc(&bt.newDKL, B)); HIPCK(devAlloc(&bt.newW, B)); HIPCK(devAlloc(&bt.newV, B)); HIPCK(devAlloc(&bt.newQ, B));
     HIPCK(devAlloc(&bt.oldDQ, B)); HIPCK(devAlloc(&bt.oldDKL, B)); HIPCK(devAlloc(&bt.oldW, B)); HIPCK(devAlloc(&bt.oldV, B));
     HIPCK(devAlloc(&bt.oldADV, B)); HIPCK(devAlloc(&bt.nextV, B)); HIPCK(devAlloc(&bt.oldNextV, B));
-    HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * h->dA));
+    HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * std::max(h->nSig, 1)));
     HIPCK(devAlloc(&bt.aggIn, (size_t)B * AGG_N));
   }
   HIPCK(hipStreamCreateWithFlags(&h->sSample, hipStreamNonBlocking));
@@ -569,10 +574,10 @@ int hl_init_weights(hl_learner* h) {
     const double iFac = h->cfg.outWeightsPrefac; const float fac = (iFac > 0) ? iFac : 1;
     const float init = fac * initFactor(HL_FUNC_LINEAR, q.size, h->nDense);
     // Builder::setLastLayersBias: Gaussian_advantage::setInitial (Gaus_advantage.h:31-34), Linear inverse = identity
-    if (h->nAdv) { W[h->indBo + 1] = -1.f; for (int e = 2; e < 1 + h->nAdv; ++e) W[h->indBo + e] = 1.f; }
+    if (h->cfg.adv_kind == HL_ADV_GAUSSIAN) { W[h->indBo + 1] = -1.f; for (int e = 2; e < 1 + h->nAdv; ++e) W[h->indBo + e] = 1.f; }
     for (int i = 0; i < q.size; ++i) for (int o = 0; o < h->nDense; ++o) W[h->indWo + o + (long long)h->ldWo * i] = uni(-init, init);
     double S = h->cfg.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
-    for (int o = 0; o < h->dA; ++o) W[h->indBp + o] = (float)((S * S - 0.25) / S);   // SoftPlus::_inv (Functions.h:564-568)
+    for (int o = 0; o < h->nSig; ++o) W[h->indBp + o] = (float)((S * S - 0.25) / S);   // SoftPlus::_inv (Functions.h:564-568)
   }
   HIPCK(hipMemcpyAsync(h->W, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
   std::memcpy(s.rng, g.x, sizeof(g.x)); s.rngPos = g.p;
@@ -646,7 +651,7 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
   hipStream_t s = h->stream;
   HIPCK(hipMemcpyAsync(h->rp.S + (size_t)off * dS, states, nf * dS * sizeof(float), hipMemcpyHostToDevice, s));
   HIPCK(hipMemcpyAsync(h->rp.A + (size_t)off * dA, actions, nf * dA * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.MU + (size_t)off * 2 * dA, mu, nf * 2 * dA * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCK(hipMemcpyAsync(h->rp.MU + (size_t)off * h->polDim, mu, nf * h->polDim * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCK(hipMemcpyAsync(h->rp.R + off, rewards, nf * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCK(hipMemcpyAsync(h->rp.V + off, values, nf * sizeof(float), hipMemcpyHostToDevice, s));
   HIPCK(hipMemcpyAsync(h->rp.ADV + off, pADV, nf * sizeof(float), hipMemcpyHostToDevice, s));
@@ -877,22 +882,22 @@ int hl_step_end(hl_learner* h) {
 // ---- episodes in the reference's wire format (Episode::packEpisode / unpackEpisode, Episode.cpp:24-130) ----
 int64_t hl_packed_episode_size(const hl_learner* h, int32_t N) {
   if (!h || N < 0) return -1;
-  return (int64_t)(h->dS + h->dA + 2 * h->dA + 1 + 6) * N + 10;      // Episode::computeTotalEpisodeSize (Episode.h:211-219)
+  return (int64_t)(h->dS + h->dA + h->polDim + 1 + 6) * N + 10;      // Episode::computeTotalEpisodeSize (Episode.h:211-219)
 }
 int hl_append_packed_episode(hl_learner* h, const float* data, int64_t n) {
   if (!h || !data) return HL_ERR_BAD_ARG;
-  const int dS = h->dS, dA = h->dA, tup = dS + 1 + dA + 2 * dA;
+  const int dS = h->dS, dA = h->dA, pD = h->polDim, tup = dS + 1 + dA + pD;
   const int64_t N = (n - 10) / (tup + 6);
   if (N < 2 || hl_packed_episode_size(h, (int32_t)N) != n) return fail(h, HL_ERR_BAD_ARG, "packed episode has the wrong size");
   std::vector<float> S((size_t)N * dS), V(N), ADV(N);
-  std::vector<double> A((size_t)N * dA), MU((size_t)N * 2 * dA), R(N);
+  std::vector<double> A((size_t)N * dA), MU((size_t)N * pD), R(N);
   const float* buf = data;
   for (int64_t i = 0; i < N; ++i) {      // Episode::unpackEpisode: fp32 -> Fvec states, Real reward, Rvec action / policy
     std::copy(buf, buf + dS, S.begin() + i * dS); R[i] = buf[dS]; buf += dS + 1;
     for (int j = 0; j < dA; ++j) A[i * dA + j] = buf[j];
     buf += dA;
-    for (int j = 0; j < 2 * dA; ++j) MU[i * 2 * dA + j] = buf[j];
-    buf += 2 * dA;
+    for (int j = 0; j < pD; ++j) MU[i * pD + j] = buf[j];
+    buf += pD;
   }
   buf += N;                                            // returnEstimator: recomputed on insertion
   std::copy(buf, buf + N, ADV.begin()); buf += N;      // actionAdvantage
@@ -905,14 +910,14 @@ int hl_append_packed_episode(hl_learner* h, const float* data, int64_t n) {
 int hl_pack_episode(hl_learner* h, int64_t pos, float* dst, int64_t cap) {
   if (!h || !dst || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
   const EpMeta e = h->order[(size_t)pos];
-  const int dS = h->dS, dA = h->dA; const int64_t N = e.N, total = hl_packed_episode_size(h, e.N);
+  const int dS = h->dS, dA = h->dA, pD = h->polDim; const int64_t N = e.N, total = hl_packed_episode_size(h, e.N);
   if (cap < total) return fail(h, HL_ERR_BAD_ARG, "hl_pack_episode: destination too small");
   int rc = flushPending(h); if (rc) return rc;
   std::vector<float> S((size_t)N * dS), F((size_t)6 * N);
-  std::vector<double> A((size_t)N * dA), MU((size_t)N * 2 * dA), R(N);
+  std::vector<double> A((size_t)N * dA), MU((size_t)N * pD), R(N);
   HIPCK(hipMemcpyAsync(S.data(), h->rp.S + (size_t)e.off * dS, S.size() * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipMemcpyAsync(A.data(), h->rp.A + (size_t)e.off * dA, A.size() * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCK(hipMemcpyAsync(MU.data(), h->rp.MU + (size_t)e.off * 2 * dA, MU.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpyAsync(MU.data(), h->rp.MU + (size_t)e.off * pD, MU.size() * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipMemcpyAsync(R.data(), h->rp.R + e.off, R.size() * 8, hipMemcpyDeviceToHost, h->stream));
   const float* src[6] = {h->rp.RET, h->rp.ADV, h->rp.V, h->rp.DQ, h->rp.IMPW, h->rp.DKL};   // order of Episode.cpp:48-72
   for (int k = 0; k < 6; ++k) HIPCK(hipMemcpyAsync(F.data() + (size_t)k * N, src[k] + e.off, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
@@ -923,8 +928,8 @@ int hl_pack_episode(hl_learner* h, int64_t pos, float* dst, int64_t cap) {
     std::copy(S.begin() + i * dS, S.begin() + (i + 1) * dS, buf); buf[dS] = (float)R[i]; buf += dS + 1;
     for (int j = 0; j < dA; ++j) buf[j] = (float)A[i * dA + j];
     buf += dA;
-    for (int j = 0; j < 2 * dA; ++j) buf[j] = (float)MU[i * 2 * dA + j];
-    buf += 2 * dA;
+    for (int j = 0; j < pD; ++j) buf[j] = (float)MU[i * pD + j];
+    buf += pD;
   }
   std::copy(F.begin(), F.end(), buf); buf += 6 * N;
   char* cp = reinterpret_cast<char*>(buf);
@@ -1085,7 +1090,7 @@ int hl_restart_memory(hl_learner* h, const char* base, int32_t rank) {
   // episodes: unpack, append (same path as fresh ones), then put the stored per-step fields back
   struct Stored { std::vector<float> f6; int N; };
   std::vector<Stored> stored; stored.reserve(nEps);
-  const int tup = dS + 1 + dA + 2 * dA;
+  const int tup = dS + 1 + dA + h->polDim;
   for (unsigned long i = 0; i < nEps; ++i) {
     unsigned long N = 0;
     if (fread(&N, sizeof(unsigned long), 1, fd) != 1 || N < 2) { fclose(fd); return fail(h, HL_ERR_IO, "Unable to find sequence in " + fName + "data.raw"); }
@@ -1197,7 +1202,7 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
     HIPCK(hipMemcpyAsync(h->dActS, states + (size_t)r0 * h->dS, (size_t)m * h->dS * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, m, h->dS, h->buf[0].X0, h->ldX0, h->stream));
     int rc = launchForward(h, 0, h->stream); if (rc) return rc;
-    HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->dA, m,
+    HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, m,
                             h->dActO, h->stream));
     HIPCK(hipMemcpyAsync(outputs + (size_t)r0 * h->nOut, h->dActO, (size_t)m * h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));

@@ -88,9 +88,11 @@ int buildProblems(hl_learner* h) {
       p.C = h->G + h->indWo; p.ldc = h->ldWo; p.biasOut = h->G + h->indBo;
       setTiles(p, cur); P.push_back(p);
       // ParamLayer::backward (Layers.h:522-546): bias gradient = column sums of the sigma-param deltas
-      GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
-      s.A = sb.bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
-      setTiles(s, cur); P.push_back(s);
+      if (h->nSig) {      // (no sigma layer behind a discrete policy)
+        GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
+        s.A = sb.bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
+        setTiles(s, cur); P.push_back(s);
+      }
     }
     sb.dwCount = (int)P.size() - sb.dwIdx; sb.dwBlocks = cur;
     // second copy of the dW table with the Adam update fused into the epilogue (single replica:
@@ -140,7 +142,7 @@ PostArgs postArgs(hl_learner* h, int parity, int mode) {
 }
 HeadArgs headArgs(hl_learner* h, int parity) {
   const DevHidden& q = h->hid[h->nHidden - 1];
-  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->buf[parity].bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense; ha.nAdv = h->nAdv;
+  HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->buf[parity].bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense; ha.nAdv = h->cfg.adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0; ha.nOpt = h->nOpt; ha.nSig = h->nSig;
   ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
   ha.func = q.func; ha.params = h->W; ha.indWo = h->indWo; ha.indBo = h->indBo; ha.indBp = h->indBp; ha.ldWo = h->ldWo;
   ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA; ha.parity = parity;
