@@ -28,6 +28,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <limits>
 #include "../../include/smarties_hip.h"
 
 namespace smarties_amd {
@@ -44,6 +46,8 @@ enum episodeStatus { INIT = 0, CONT, LAST, TERM, FAIL };   // Core/Agent.h:23
 struct MDPdescriptor {
   Uint dimStateObserved = 0, dimAction = 0;
   std::vector<bool> bActionSpaceBounded;
+  std::vector<Uint> discreteActionValues;     // non-empty: discrete actions (one variable is served), options per variable
+  bool bDiscreteActions() const { return discreteActionValues.size() > 0; }
 };
 
 // Settings/HyperParameters.h:42-72 (same names, same defaults where they do not depend on the MDP)
@@ -75,7 +79,7 @@ class VRACER {
   MDPdescriptor MDP;
   HyperParameters S;
   bool bTrain = true, bInit = false;
-  int nOut = 0, nDense = 0, nAdv = 0;      // nAdv: advantage outputs between V and the policy mean
+  int nOut = 0, nDense = 0, nAdv = 0, nOpt = 0;      // nAdv: advantage outputs between V and the policy; nOpt: discrete options
   // one in-progress episode per agent: MemoryBuffer::inProgress (ReplayMemory/MemoryBuffer.h)
   struct InProgress { Fvec states; Rvec actions, policies, rewards; Fvec values, advantages; int64_t tag = 0; };
   std::vector<InProgress> inProgress;
@@ -115,10 +119,14 @@ class VRACER {
     c.n_hidden = (int32_t)hp.nnLayerSizes.size();
     for (Uint i = 0; i < hp.nnLayerSizes.size(); ++i) c.hidden[i] = (int32_t)hp.nnLayerSizes[i];
     c.nnFunc = funcId(hp.nnFunc);
-    if (hp.learner == "VRACER") c.adv_kind = HL_ADV_ZERO;
+    // AlgoFactory.cpp:78-152: discrete action spaces always get RACER<Discrete_advantage, Discrete_policy, Uint>
+    if (M.bDiscreteActions()) {
+      if (M.dimAction != 1 || M.discreteActionValues.size() != 1) die("one discrete action variable is served");
+      c.adv_kind = HL_ADV_DISCRETE; c.n_options = (int32_t)M.discreteActionValues[0]; nOpt = c.n_options;
+    } else if (hp.learner == "VRACER") c.adv_kind = HL_ADV_ZERO;
     else if (hp.learner == "RACER") c.adv_kind = HL_ADV_GAUSSIAN;
     else die("learner " + hp.learner + " is not served by the HIP library");
-    nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * (int)M.dimAction : 0;
+    nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * (int)M.dimAction : nOpt;
     c.batchSize = (int32_t)hp.batchSize; c.maxTotObsNum = (int64_t)hp.maxTotObsNum; c.minTotObsNum = (int64_t)hp.minTotObsNum;
     c.gamma = hp.gamma; c.lambda = hp.lambda; c.clipImpWeight = hp.clipImpWeight; c.penalTol = hp.penalTol;
     c.epsAnneal = hp.epsAnneal; c.learnrate = hp.learnrate; c.nnLambda = hp.nnLambda; c.explNoise = hp.explNoise;
@@ -127,7 +135,7 @@ class VRACER {
     const int rc = hl_create(&c, &H);
     if (rc) die(std::string("hl_create: ") + hl_status_string(rc) + ": " + hl_last_error(nullptr));
     ck(hl_init_weights(H));
-    nOut = hl_num_outputs(H); nDense = 1 + nAdv + (int)M.dimAction;
+    nOut = hl_num_outputs(H); nDense = nOpt ? 1 + 2 * nOpt : 1 + nAdv + (int)M.dimAction;
   }
   ~VRACER() { if (H) hl_destroy(H); }
   VRACER(const VRACER&) = delete;
@@ -156,6 +164,23 @@ class VRACER {
     if (agent.agentStatus < LAST) {
       // RACER::selectAction (RACER.cpp:30-47)
       const Rvec output = forward(agent);
+      if (nOpt) {     // Discrete_policy (Math/Discrete_policy.h:63-83, 190-200) + Discrete_advantage (:64-70)
+        Rvec probs((Uint)nOpt); Real norm = 0;
+        for (int j = 0; j < nOpt; ++j) { const Real x = output[(Uint)(1 + nOpt + j)]; probs[j] = (x + std::sqrt(1 + x * x)) / 2; norm += probs[j]; }
+        norm = std::max(norm, std::numeric_limits<Real>::epsilon());
+        for (int j = 0; j < nOpt; ++j) probs[j] /= norm;
+        Uint label;
+        if (bTrain) { std::discrete_distribution<Uint> dist(probs.begin(), probs.end()); label = dist(agent.generator); }
+        else label = (Uint)(std::max_element(probs.begin(), probs.end()) - probs.begin());      // Utilities::maxInd
+        Real expA = 0; for (int j = 0; j < nOpt; ++j) expA += probs[j] * output[(Uint)(1 + j)];
+        const Real V = scaleNet2V(output[0]), A = output[1 + label] - expA;
+        EP.values.push_back((Fval)V); EP.advantages.push_back((Fval)((Fval)(V + A) - (Fval)V));
+        agent.action = Rvec(1, (Real)label + 0.1);                                              // label2actionMessage (StateAction.h:327-341)
+        agent.policyVector = probs;
+        EP.actions.push_back(agent.action[0]);
+        EP.policies.insert(EP.policies.end(), probs.begin(), probs.end());
+        return;
+      }
       Rvec mean(dA), stdev(dA), act(dA);
       for (Uint i = 0; i < dA; ++i) {
         const Real p = output[(Uint)nDense + i];
@@ -192,7 +217,7 @@ class VRACER {
       EP.values.push_back(agent.agentStatus == LAST ? (Fval)scaleNet2V(forward(agent)[0]) : (Fval)0);
       EP.advantages.push_back(0);
       EP.actions.insert(EP.actions.end(), dA, 0.0);                                  // dummy last action / policy
-      EP.policies.insert(EP.policies.end(), 2 * dA, 0.0);
+      EP.policies.insert(EP.policies.end(), nOpt ? (size_t)nOpt : 2 * dA, 0.0);
       // MemoryBuffer::terminateCurrentEpisode -> pushBackEpisode
       pushBackEpisode((int)(EP.states.size() / dS), EP.states, EP.actions, EP.policies, EP.rewards, EP.values,
                       agent.agentStatus == TERM, EP.tag, &EP.advantages);

@@ -194,6 +194,52 @@ int main() {
     CHECK(std::fabs(R.beta() - s2.beta) <= 1e-9 * s2.beta, "RACER beta");
     ol_destroy(O2);
   }
+  // ---- RACER on a discrete action space: acting draws labels from the SoftPlus-normalised policy, training follows the oracle ----
+  {
+    MDPdescriptor M3; M3.dimStateObserved = 7; M3.dimAction = 1; M3.discreteActionValues = {5};
+    HyperParameters H3; H3.learner = "RACER"; H3.nnLayerSizes = {32, 32}; H3.nnFunc = "SoftSign"; H3.batchSize = 32; H3.maxTotObsNum = 5000;
+    H3.clipImpWeight = 4; H3.epsAnneal = 0; H3.outWeightsPrefac = 0.1; H3.randSeed = 99;
+    VRACER D(M3, H3, 0);
+    hl_config c3{}; c3.struct_size = sizeof(c3); c3.dimS = 7; c3.dimA = 1; c3.n_options = 5;
+    c3.n_hidden = 2; c3.hidden[0] = c3.hidden[1] = 32; c3.nnFunc = HL_FUNC_SOFTSIGN; c3.adv_kind = HL_ADV_DISCRETE;
+    c3.batchSize = 32; c3.maxTotObsNum = 5000; c3.gamma = H3.gamma; c3.lambda = H3.lambda; c3.clipImpWeight = 4; c3.penalTol = H3.penalTol;
+    c3.epsAnneal = 0; c3.learnrate = H3.learnrate; c3.nnLambda = H3.nnLambda; c3.explNoise = H3.explNoise; c3.outWeightsPrefac = 0.1;
+    c3.randSeed = 99; c3.n_ranks = 1; c3.ref_threads = 1;
+    ol_learner* O3 = nullptr;
+    CHECK(ol_create(&c3, &O3) == 0 && ol_init_weights(O3) == 0, "discrete oracle");
+    int counts[5] = {0, 0, 0, 0, 0};
+    for (int e = 0; e < 40; ++e) {
+      Agent agent(0, 2000 + e);
+      for (int t = 0; t <= 20; ++t) {
+        agent.agentStatus = t == 0 ? INIT : (t == 20 ? (e % 2 ? LAST : TERM) : CONT);
+        agent.state.resize(7); for (int i = 0; i < 7; ++i) agent.state[i] = 0.4f * (float)std::cos(0.23 * t + i - e);
+        agent.reward = 0.2 * std::sin(0.3 * t + e);
+        D.select(agent);
+        if (t < 20) {
+          const int label = (int)std::floor(agent.action[0]);
+          CHECK(label >= 0 && label < 5 && agent.policyVector.size() == 5, "discrete action message");
+          if (label >= 0 && label < 5) counts[label]++;
+          double tot = 0; for (double p : agent.policyVector) tot += p;
+          CHECK(std::fabs(tot - 1) < 1e-12, "policy vector sums to one");
+        }
+      }
+      const Fvec packed = D.packEpisode(0);
+      CHECK(ol_append_packed_episode(O3, packed.data(), (int64_t)packed.size()) == 0, "oracle takes the packed discrete episode");
+    }
+    CHECK(counts[0] > 0 && counts[1] > 0 && counts[2] > 0 && counts[3] > 0 && counts[4] > 0, "every option is drawn by a fresh policy");
+    D.initializeLearner(); CHECK(ol_initialize(O3) == 0, "discrete ol_initialize");
+    std::vector<int64_t> f1(32), f2(32);
+    for (int k = 1; k <= 20; ++k) {
+      D.trainStep(1); CHECK(ol_step(O3, 1, nullptr) == 0, "discrete ol_step");
+      hl_readback(D.handle(), HL_TAP_FLAT, f1.data(), 32 * 8); ol_readback(O3, HL_TAP_FLAT, f2.data(), 32 * 8);
+      CHECK(f1 == f2, "discrete step %d: sampled indices differ", k);
+    }
+    const int64_t n3 = hl_num_params(D.handle());
+    std::vector<float> a(n3), b(n3), t1(n3), t2(n3);
+    hl_get_params(D.handle(), a.data(), t1.data(), t2.data()); ol_get_params(O3, b.data(), t1.data(), t2.data());
+    CHECK(relinf(a, b) < 1e-4, "discrete weights after 20 steps: rel err %.3g", relinf(a, b));
+    ol_destroy(O3);
+  }
   ol_destroy(O);
   std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: OK\n", failures);
   return failures ? 1 : 0;
