@@ -27,6 +27,10 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
 # G-racer: RACER with the Gaussian advantage head (Math/Gaus_advantage.h), same replay as G-small
 "$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/racer_gauss.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+# G-racer-traj: the same head across the 1000-step sweep (Retrace with non-zero stored advantages)
+"$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/racer_traj_1200.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=999,1000,1200 \
+   maxObs=2000 minObs=500 epsAnneal=5e-7
 # G-discrete: RACER with Discrete_policy / Discrete_advantage (one action variable, 4 options)
 "$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/racer_discrete.bin" dimS=5 dimA=1 nOpt=4 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500

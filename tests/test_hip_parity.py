@@ -215,16 +215,23 @@ def test_multi_step_graph_replay_matches_single_steps(hip_api, cfg_kw, sc_kw, n_
     assert G.scalars().nGradSteps == n
 
 
-def test_thousand_step_sweep_matches_oracle(hip_api):
-    """Crosses step 1000: Episode::updateCumulative + whole-buffer Retrace + reward/state EMA."""
+@pytest.mark.parametrize("head", ["vracer", "racer_gaussian", "racer_discrete"])
+def test_thousand_step_sweep_matches_oracle(hip_api, head):
+    """Crosses step 1000: Episode::updateCumulative + whole-buffer Retrace + reward/state EMA -- for the three
+    advantage heads (stored advantages are non-zero for the two RACER ones)."""
     cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42,
                   epsAnneal=5e-7)
-    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    if head == "racer_gaussian":
+        cfg_kw.update(adv_kind=capi.ADV_GAUSSIAN)
+    if head == "racer_discrete":
+        cfg_kw.update(adv_kind=capi.ADV_DISCRETE, n_options=6, dimA=1, bounded=[0])
+    sc = synth_cfg(seed=7, dimS=5, dimA=cfg_kw["dimA"], lenMin=5, lenMax=40, pTerm=0.5)
     G, O = _pair(hip_api, cfg_kw, sc, 30)
     G.step(999); O.step(999)
     assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
     G.step(1); O.step(1)
-    for field, tol in ((capi.EP_RETURN, 1e-4), (capi.EP_VALUE, 1e-4), (capi.EP_IMPW, 1e-4), (capi.EP_DKL, 1e-4)):
+    for field, tol in ((capi.EP_RETURN, 1e-4), (capi.EP_VALUE, 1e-4), (capi.EP_ADVANTAGE, 1e-4), (capi.EP_IMPW, 1e-4),
+                       (capi.EP_DKL, 1e-4)):
         mg, mo = episode_arrays_by_tag(G, field), episode_arrays_by_tag(O, field)
         for tag in mo:
             assert np.allclose(mg[tag], mo[tag], rtol=tol, atol=tol), (field, tag)

@@ -101,10 +101,11 @@ def test_far_policy_masks_are_exercised():
     assert 0 < far.sum() < far.size
 
 
-def test_long_trajectory_crosses_1000_step_sweep(tmp_path):
+@pytest.mark.parametrize("name", ["traj_1200.bin", "racer_traj_1200.bin"])
+def test_long_trajectory_crosses_1000_step_sweep(tmp_path, name):
     """1200 steps: beta / CmaxRet / nFarPolicySteps trajectories, the 1000-step
     Episode::updateCumulative + full Retrace sweep and the reward/state statistics EMA."""
-    fx, L = make("traj_1200.bin")
+    fx, L = make(name)
     setup_from_fixture(L, fx)
     L.set_log_base(str(tmp_path / "agent_00"))
     lens = {e: synth_episode(fixture_synth(fx), e)["rewards"].size for e in range(int(fx["cfg"][3]))}
