@@ -75,6 +75,10 @@ enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU 
        HL_FUNC_EXPPLUS = 8, HL_FUNC_EXP = 9 };
 
 /* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
+/* hidden layer type (Network/Builder.cpp:48-117): dense, or LSTM (Network/Layers/Layer_LSTM.h; BASELINE config 4).
+ * HL_NN_LSTM is restated by the oracle (pinned by a reference fixture); the library answers HL_ERR_UNSUPPORTED. */
+enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1 };
+
 /* advantage head (Learners/AlgoFactory.cpp:109-152): Math/Zero_advantage.h (VRACER), Math/Gaus_advantage.h (RACER,
  * continuous actions: network outputs [V | coef, L+ x dA, L- x dA | mean x dA | sigma parameter x dA]);
  * Math/Discrete_advantage.h + Math/Discrete_policy.h (RACER, discrete actions: outputs [V | A x nOptions |
@@ -122,7 +126,9 @@ typedef struct hl_config {
   int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..32) of the ONE
                                         discrete action variable (dimA = 1; actions hold label + 0.1 as in
                                         Core/StateAction.h:322-341, policies the nOptions probabilities); else 0 */
-  int32_t reserved[6];
+  int32_t nn_type;                   /* HL_NN_*: settings nnType of the hidden layers                  */
+  int32_t nnBPTTseq;                 /* recurrent nets: steps of truncated BPTT (0 = the default, 16)   */
+  int32_t reserved[4];
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */

@@ -154,13 +154,17 @@ inline bool isFarPolicy(Fval W, Fval C, Fval invC) {
 // ---------------------------------------------------------------------------
 // network description (Network/Builder.cpp:48-117, Layers/*.h)
 // ---------------------------------------------------------------------------
-enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM };
+enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM };
 struct Layer {
   LType type; int size = 0, nIn = 0, nOutSimd = 0, func = HL_FUNC_LINEAR;
   bool bOutput = false, skipInpGrad = false;
   int64_t indW = 0, nW = 0, indB = 0, nB = 0;
   std::vector<Real> biasInit;  // ParamLayer initial values
 };
+
+// work memory of one time step (Network/Layers/Activation.h): pre-activations, outputs, errors per layer; an LSTM
+// layer uses 4 x nCells entries of each (Layer_LSTM.h:29-48)
+struct Act { std::vector<std::vector<nnReal>> X, Y, E; };
 
 struct Episode {  // ReplayMemory/Episode.h:40-108
   int64_t tag = -1, ID = -1, seq = 0; int N = 0; bool term = false;
@@ -228,7 +232,7 @@ void buildNet(ol_learner* h) {
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     const int ID = (int)L.size();
-    Layer d; d.type = L_DENSE; d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
+    Layer d; d.type = c.nn_type == HL_NN_LSTM ? L_LSTM : L_DENSE; d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
     d.nOutSimd = (int)roundUp8(d.size); d.func = c.nnFunc;
     L.push_back(d);
     // skip connection except after the first layer (Builder.cpp:89-95)
@@ -263,6 +267,7 @@ void buildNet(ol_learner* h) {
       case L_DENSE: l.nW = (int64_t)l.nOutSimd * l.nIn; l.nB = l.size; break;   // Layer_Base.h:24-28
       case L_PARAMRES: l.nW = l.size; l.nB = l.size; break;                    // Layers.h:334-338
       case L_PARAM: l.nW = 0; l.nB = l.size; break;                            // Layers.h:494-497
+      case L_LSTM: l.nW = (int64_t)4 * l.size * (l.nIn + l.size); l.nB = 4 * l.size; break;   // Layer_LSTM.h:24-29
     }
     l.indW = tot; tot += roundUp8(l.nW);
     l.indB = tot; tot += roundUp8(l.nB);
@@ -273,7 +278,7 @@ void buildNet(ol_learner* h) {
   const size_t nl = L.size();
   h->X.resize(nl); h->Y.resize(nl); h->E.resize(nl); h->Xn.resize(nl); h->Yn.resize(nl);
   for (size_t i = 0; i < nl; ++i) {
-    const size_t n = (size_t)roundUp8(L[i].size);
+    const size_t n = (size_t)roundUp8(L[i].type == L_LSTM ? 4 * L[i].size : L[i].size);
     h->X[i].assign(n, 0); h->Y[i].assign(n, 0); h->E[i].assign(n, 0);
     h->Xn[i].assign(n, 0); h->Yn[i].assign(n, 0);
   }
@@ -292,6 +297,11 @@ void initWeights(ol_learner* h) {
       for (int o = 0; o < l.size; ++o) Bv[o] = l.biasInit.size() == (size_t)l.size ? (nnReal)l.biasInit[o] : 0;  // Linear inverse of the init values (Layer_Base.h:122-125)
       for (int i = 0; i < l.nIn; ++i)
         for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = uniformFloat(h->gen, -init, init);
+    } else if (l.type == L_LSTM) {   // Layer_LSTM.h:167-185: forget gate starts open, input / output gates closed (LSTM_PRIME_FAC = 1)
+      const nnReal init = fInitFactor(l.func, l.nIn, l.size);
+      const int nC = l.size;
+      for (int o = 0; o < nC; ++o) { Bv[o] = 0; Bv[nC + o] = -1; Bv[2 * nC + o] = 1; Bv[3 * nC + o] = -1; }
+      for (int64_t w = 0; w < (int64_t)4 * nC * (l.nIn + nC); ++w) W[w] = uniformFloat(h->gen, -init, init);
     } else if (l.type == L_PARAMRES) {
       for (int o = 0; o < l.size; ++o) { Bv[o] = 0; W[o] = 1; }
     } else if (l.type == L_PARAM) {
@@ -301,8 +311,14 @@ void initWeights(ol_learner* h) {
 }
 
 // Network::forward (Network/Network.h:102-113) over Layer::forward of each type
+inline int actSize(const Layer& l) { return l.type == L_LSTM ? 4 * l.size : l.size; }   // Activation::sizes
+inline nnReal sigmEval(nnReal in) {   // Sigm::_eval (Functions.h:158-165), safeExp cut at 8 for fp32 (Definitions.h:43)
+  const auto safeExp = [](nnReal v) { return std::exp(std::min((nnReal)8, std::max(-(nnReal)8, v))); };
+  if (in > 0) return 1 / (1 + safeExp(-in));
+  const nnReal ex = safeExp(in); return ex / (1 + ex);
+}
 void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vector<nnReal>>& X,
-                std::vector<std::vector<nnReal>>& Y) {
+                std::vector<std::vector<nnReal>>& Y, const std::vector<std::vector<nnReal>>* prevY = nullptr) {
   const auto& L = h->layers;
   std::copy(input, input + L[0].size, Y[0].begin());
   for (size_t ID = 1; ID < L.size(); ++ID) {
@@ -321,8 +337,28 @@ void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vecto
       nnReal* ret = Y[ID].data();
       std::memcpy(ret, Y[ID - 1].data(), l.size * sizeof(nnReal));
       const nnReal* inp = Y[ID - 2].data();
-      const int sizeInp = std::min(L[ID - 2].size, l.size);
+      const int sizeInp = std::min(actSize(L[ID - 2]), l.size);
       for (int j = 0; j < sizeInp; ++j) ret[j] += inp[j] * W[j] + Bv[j];
+    } else if (l.type == L_LSTM) {   // Layer_LSTM.h:78-125
+      const int nC = l.size;
+      nnReal* suminp = X[ID].data();
+      std::memcpy(suminp, Bv, 4 * nC * sizeof(nnReal));
+      { const nnReal* inputs = Y[ID - 1].data();
+        for (int i = 0; i < l.nIn; ++i) { const nnReal* Wi = W + (int64_t)4 * nC * i; for (int o = 0; o < 4 * nC; ++o) suminp[o] += inputs[i] * Wi[o]; } }
+      if (prevY) {
+        const nnReal* inputs = (*prevY)[ID].data(); const nnReal* Wr = W + (int64_t)4 * nC * l.nIn;
+        for (int i = 0; i < nC; ++i) { const nnReal* Wi = Wr + (int64_t)4 * nC * i; for (int o = 0; o < 4 * nC; ++o) suminp[o] += inputs[i] * Wi[o]; }
+      }
+      for (int o = nC; o < 4 * nC; ++o) suminp[o] = sigmEval(suminp[o]);      // gates overwrite their inputs
+      const nnReal* prevSt = prevY ? (*prevY)[ID].data() + nC : nullptr;
+      nnReal* output = Y[ID].data(); nnReal* currSt = output + nC; nnReal* cellOp = output + 2 * nC;
+      const nnReal* inputG = suminp + nC; const nnReal* forgtG = suminp + 2 * nC; const nnReal* outptG = suminp + 3 * nC;
+      for (int o = 0; o < nC; ++o) {
+        const nnReal oldStatePass = prevSt ? prevSt[o] * forgtG[o] : 0;
+        currSt[o] = suminp[o] * inputG[o] + oldStatePass;
+        cellOp[o] = fEval(HL_FUNC_TANH, currSt[o]);
+        output[o] = outptG[o] * cellOp[o];
+      }
     } else if (l.type == L_PARAM) {  // Layers.h:510-520
       for (int n = 0; n < l.size; ++n) { X[ID][n] = Bv[n]; Y[ID][n] = fEval(l.func, Bv[n]); }
     }
@@ -382,6 +418,63 @@ void backwardNet(ol_learner* h) {
         gradInp[j] += delta[j] * W[j];
         gW[j] += delta[j] * inp[j];
         gB[j] += delta[j];
+      }
+    }
+  }
+}
+
+// Network::backProp over a time series (Network/Network.h:155-193): layers from the top down, for each layer the
+// steps from the last one with an error (T) back to 0; recurrent layers pass errors to the previous step's E
+void backwardSeries(ol_learner* h, std::vector<Act>& series, int T) {
+  const auto& L = h->layers;
+  for (int ID = (int)L.size() - 1; ID >= 1; --ID) {
+    const Layer& l = L[ID];
+    const nnReal* W = h->W.data() + l.indW;
+    nnReal* gW = h->G.data() + l.indW; nnReal* gB = h->G.data() + l.indB;
+    for (int k = T; k >= 0; --k) {
+      Act& cur = series[k]; Act* prev = k > 0 ? &series[k - 1] : nullptr; Act* next = k < T ? &series[k + 1] : nullptr;
+      if (l.type == L_PARAM) {
+        nnReal* deltas = cur.E[ID].data();
+        for (int o = 0; o < l.size; ++o) { deltas[o] *= fDiff(l.func, cur.X[ID][o], cur.Y[ID][o]); gB[o] += deltas[o]; }
+      } else if (l.type == L_DENSE) {
+        nnReal* deltas = cur.E[ID].data();
+        for (int o = 0; o < l.size; ++o) deltas[o] *= fDiff(l.func, cur.X[ID][o], cur.Y[ID][o]);
+        if (!l.skipInpGrad) gemvOmp(l.size, l.nIn, l.nOutSimd, W, deltas, cur.E[ID - 1].data());
+        for (int o = 0; o < l.size; ++o) gB[o] += deltas[o];
+        const nnReal* inputs = cur.Y[ID - 1].data();
+        for (int i = 0; i < l.nIn; ++i) { nnReal* Gi = gW + (int64_t)l.nOutSimd * i; for (int o = 0; o < l.size; ++o) Gi[o] += inputs[i] * deltas[o]; }
+      } else if (l.type == L_PARAMRES) {
+        const nnReal* delta = cur.E[ID].data();
+        std::memcpy(cur.E[ID - 1].data(), delta, l.size * sizeof(nnReal));
+        nnReal* gradInp = cur.E[ID - 2].data(); const nnReal* inp = cur.Y[ID - 2].data();
+        const int sizeInp = std::min(actSize(L[ID - 2]), l.size);
+        for (int j = 0; j < sizeInp; ++j) { gradInp[j] += delta[j] * W[j]; gW[j] += delta[j] * inp[j]; gB[j] += delta[j]; }
+      } else if (l.type == L_LSTM) {   // Layer_LSTM.h:127-165, then Layer::backward (Layers.h:123-188) with NO = 4 nC, NR = nC
+        const int nC = l.size;
+        nnReal* deltas = cur.E[ID].data();
+        const nnReal* cellOutput = cur.Y[ID].data() + 2 * nC; nnReal* stateDelta = cur.Y[ID].data() + 3 * nC;
+        const nnReal* cellInpt = cur.X[ID].data(); const nnReal* IGate = cellInpt + nC; const nnReal* FGate = cellInpt + 2 * nC;
+        const nnReal* OGate = cellInpt + 3 * nC;
+        const nnReal* prvState = prev ? prev->Y[ID].data() + nC : nullptr;
+        const nnReal* nxtStErr = next ? next->Y[ID].data() + 3 * nC : nullptr;
+        const nnReal* nxtFGate = next ? next->X[ID].data() + 2 * nC : nullptr;
+        for (int o = 0; o < nC; ++o) {
+          const nnReal D = deltas[o];
+          const nnReal diff = (1 - cellOutput[o] * cellOutput[o]) * deltas[o];
+          stateDelta[o] = diff * OGate[o] + (next ? nxtStErr[o] * nxtFGate[o] : 0);
+          deltas[o] = IGate[o] * stateDelta[o];
+          deltas[o + nC] = IGate[o] * (1 - IGate[o]) * cellInpt[o] * stateDelta[o];
+          deltas[o + 2 * nC] = prev ? FGate[o] * (1 - FGate[o]) * prvState[o] * stateDelta[o] : 0;
+          deltas[o + 3 * nC] = OGate[o] * (1 - OGate[o]) * D * cellOutput[o];
+        }
+        const int NO = 4 * nC;
+        if (!l.skipInpGrad) gemvOmp(NO, l.nIn, NO, W, deltas, cur.E[ID - 1].data());
+        if (prev) gemvOmp(NO, nC, NO, W + (int64_t)NO * l.nIn, deltas, prev->E[ID].data());
+        for (int o = 0; o < NO; ++o) gB[o] += deltas[o];
+        { const nnReal* inputs = cur.Y[ID - 1].data();
+          for (int i = 0; i < l.nIn; ++i) { nnReal* Gi = gW + (int64_t)NO * i; for (int o = 0; o < NO; ++o) Gi[o] += inputs[i] * deltas[o]; } }
+        if (prev) { const nnReal* inputs = prev->Y[ID].data(); nnReal* gR = gW + (int64_t)NO * l.nIn;
+          for (int i = 0; i < nC; ++i) { nnReal* Gi = gR + (int64_t)NO * i; for (int o = 0; o < NO; ++o) Gi[o] += inputs[i] * deltas[o]; } }
       }
     }
   }
@@ -942,11 +1035,27 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     // MemoryBuffer::sampleMinibatch gather: Episode::standardizedState (Episode.h:172-183)
     for (int i = 0; i < dS; ++i) inp[i] = (EP.S[(size_t)t * dS + i] - h->stMean[i]) * h->stScale[i];
     if (h->tap) std::copy(inp.begin(), inp.end(), h->tState.begin() + (size_t)b * dS);
-    forwardNet(h, inp.data(), h->X, h->Y); getOutput(h, h->Y, O.data());
+    // recurrent nets: the window of MemoryBuffer::sampleMinibatch (:391-402), min(nnBPTTseq, t) steps before t; every
+    // step is forwarded with the previous one as recurrent input (Approximator::forward, Approximator.h:116-173)
+    const bool recurrent = h->cfg.nn_type == HL_NN_LSTM;
+    std::vector<Act> series; int T = 0;
+    if (recurrent) {
+      const int nBPTT = h->cfg.nnBPTTseq > 0 ? h->cfg.nnBPTTseq : 16;
+      const int beg = t - std::min(nBPTT, t); T = t - beg;
+      series.resize((size_t)T + 2);
+      for (auto& a : series) { a.X = h->X; a.Y = h->Y; a.E = h->E; for (auto& e : a.E) std::fill(e.begin(), e.end(), 0); }
+      std::vector<nnReal> in2(dS);
+      for (int k = 0; k <= T; ++k) {
+        for (int i = 0; i < dS; ++i) in2[i] = (EP.S[(size_t)(beg + k) * dS + i] - h->stMean[i]) * h->stScale[i];
+        forwardNet(h, in2.data(), series[k].X, series[k].Y, k ? &series[k - 1].Y : nullptr);
+      }
+      getOutput(h, series[T].Y, O.data());
+    } else { forwardNet(h, inp.data(), h->X, h->Y); getOutput(h, h->Y, O.data()); }
     if (EP.isTruncated(t + 1)) {   // RACER_train.cpp:23-27
       std::vector<nnReal> inpn(dS);
       for (int i = 0; i < dS; ++i) inpn[i] = (EP.S[(size_t)(t + 1) * dS + i] - h->stMean[i]) * h->stScale[i];
-      forwardNet(h, inpn.data(), h->Xn, h->Yn); getOutput(h, h->Yn, On.data());
+      if (recurrent) { forwardNet(h, inpn.data(), series[T + 1].X, series[T + 1].Y, &series[T].Y); getOutput(h, series[T + 1].Y, On.data()); }
+      else { forwardNet(h, inpn.data(), h->Xn, h->Yn); getOutput(h, h->Yn, On.data()); }
       const Fval Vn = (Fval)scaleNet2V(On[0]);
       epUpdateValues(EP, t + 1, Vn, Vn);
     }
@@ -958,18 +1067,19 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
                   (Real)EP.RET[t], h->beta, h->CmaxRet, h->CinvRet, grad.data(), &rho, &dkl, &dq, &far, &V, &Q);
     for (int o = 0; o < nOut; ++o) { h->gsSum[o] += grad[o]; h->gsSq[o] += grad[o] * grad[o]; }   // StatsTracker::track_vector (Approximator.h:197)
     // Approximator::setGradient -> Activation::addOutputDelta (Approximator.h:190-204, Activation.h:108-117)
+    auto& Eout = recurrent ? series[T].E : h->E;
     for (auto& e : h->E) std::fill(e.begin(), e.end(), 0);
-    for (int o = 0; o < nDn; ++o) h->E[outDense][o] += grad[o];
-    if (!h->nOpt) for (int o = 0; o < dA; ++o) h->E[outParam][o] += grad[nDn + o];
+    for (int o = 0; o < nDn; ++o) Eout[outDense][o] += grad[o];
+    if (!h->nOpt) for (int o = 0; o < dA; ++o) Eout[outParam][o] += grad[nDn + o];
     if (h->tap) { for (int o = 0; o < nOut; ++o) { h->tO[(size_t)b * nOut + o] = O[o]; }
-      for (int o = 0; o < nDn; ++o) h->tG[(size_t)b * nOut + o] = h->E[outDense][o];
-      if (!h->nOpt) for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + nDn + o] = h->E[outParam][o];
+      for (int o = 0; o < nDn; ++o) h->tG[(size_t)b * nOut + o] = Eout[outDense][o];
+      if (!h->nOpt) for (int o = 0; o < dA; ++o) h->tG[(size_t)b * nOut + nDn + o] = Eout[outParam][o];
       h->tRho[b] = rho; h->tDkl[b] = dkl; h->tFar[b] = (uint8_t)far; }
     // MiniBatch::setMseDklImpw / setValues (RACER_train.cpp:59-60; MiniBatch.h:161-175)
     epUpdateCumulative(EP, t, (Fval)dq, (Fval)dkl, (Fval)rho, (Fval)h->CmaxRet, (Fval)h->CinvRet);
     epUpdateValues(EP, t, (Fval)V, (Fval)Q);
     if (h->tap) h->tDq[b] = EP.DQ[t];
-    backwardNet(h);
+    if (recurrent) backwardSeries(h, series, T); else backwardNet(h);
   }
   if (h->tap) h->tGradSum = h->G;
   {   // StatsTracker::reduce_stats (StatsTracker.cpp:100-107) as called by Learner_approximator.cpp:89 with iter = nGradSteps
@@ -1159,6 +1269,7 @@ int ol_sync(ol_learner*) { return HL_OK; }
 // (Episode::standardizedState, Episode.h:172-183): the network outputs RACER::selectAction reads
 int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
+  if (h->cfg.nn_type != HL_NN_FFNN) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
   const int dS = h->dS, nOut = h->nOut;
   std::vector<nnReal> inp(dS);
   for (int r = 0; r < n; ++r) {

@@ -131,6 +131,7 @@ struct Harness {
     HP->learner = kLearner; HP->returnsEstimator = "retrace";
     HP->nnLayerSizes = parseList(A.s("layers", "256,256"));
     HP->nnFunc = A.s("nnFunc", "SoftSign");
+    HP->nnType = A.s("nnType", "FFNN"); HP->nnBPTTseq = (Uint)A.l("bptt", 16);   // "LSTM": recurrent hidden layers
     HP->batchSize = A.l("batch", 256);
     HP->maxTotObsNum = A.l("maxObs", 1000000);
     HP->minTotObsNum = A.l("minObs", HP->maxTotObsNum);
@@ -277,7 +278,8 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   {
     std::vector<int64_t> cfg = {(int64_t)H.MDP.dimStateObserved, (int64_t)H.MDP.dimAction,
         (int64_t)H.HP->batchSize, nEps, nSteps, (int64_t)PW->nParams, (int64_t)NET.nOutputs(),
-        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind, (int64_t)H.nOpt};
+        (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind, (int64_t)H.nOpt,
+        (int64_t)(H.HP->nnType == "LSTM" ? 1 : 0), (int64_t)H.HP->nnBPTTseq};
     W.i64("cfg", cfg);
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

@@ -21,6 +21,7 @@ HL_MAX_HIDDEN = 8
 FUNC = {"Linear": 0, "Tanh": 1, "SoftSign": 2, "Relu": 3, "LRelu": 4, "Sigm": 5, "HardSign": 6,
         "SoftPlus": 7, "ExpPlus": 8, "Exp": 9}
 ADV_ZERO, ADV_GAUSSIAN, ADV_DISCRETE = 0, 1, 2
+NN_FFNN, NN_LSTM = 0, 1
 ORDER_STABLE, ORDER_REFERENCE = 0, 1
 
 (TAP_FLAT, TAP_EPISODE, TAP_TSTEP, TAP_TAG, TAP_STATE, TAP_OUTPUT, TAP_OUTGRAD, TAP_RHO, TAP_DKL,
@@ -42,7 +43,7 @@ class HlConfig(C.Structure):
         ("nnLambda", C.c_double), ("explNoise", C.c_double), ("outWeightsPrefac", C.c_double),
         ("randSeed", C.c_uint64), ("n_ranks", C.c_int32), ("rank", C.c_int32),
         ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
-        ("n_options", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("n_options", C.c_int32), ("nn_type", C.c_int32), ("nnBPTTseq", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -65,7 +66,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
                 maxTotObsNum=1000000, minTotObsNum=0, gamma=0.995, lambda_=1.0, clipImpWeight=4.0,
                 penalTol=0.1, epsAnneal=0.0, learnrate=1e-4, nnLambda=0.0, explNoise=0.4472135955,
                 outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
-                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0):
+                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0, nn_type=0, nnBPTTseq=0):
     """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
     c = HlConfig()
     c.struct_size = C.sizeof(HlConfig)
@@ -79,6 +80,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
     c.nnFunc = FUNC[nnFunc] if isinstance(nnFunc, str) else int(nnFunc)
     c.adv_kind = adv_kind
     c.n_options = n_options if adv_kind == ADV_DISCRETE else 0
+    c.nn_type, c.nnBPTTseq = nn_type, nnBPTTseq
     c.batchSize = batchSize
     c.maxTotObsNum, c.minTotObsNum = int(maxTotObsNum), int(minTotObsNum)
     c.gamma, c.lambda_, c.clipImpWeight, c.penalTol = gamma, lambda_, clipImpWeight, penalTol

@@ -410,6 +410,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
+  if (cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;             // recurrent layers: restated by the oracle only (next on the device)
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return HL_ERR_NO_DEVICE;
   hl_learner* h = new hl_learner();

@@ -21,7 +21,9 @@ def fixture_config(fx, **over):
     func = over.pop("nnFunc", None)
     adv = int(fx["cfg"][11]) if len(fx["cfg"]) > 11 else 0     # 0 = VRACER, 1 = RACER with the Gaussian advantage
     nopt = int(fx["cfg"][12]) if len(fx["cfg"]) > 12 else 0    # discrete head: options of the action variable
-    kw = dict(adv_kind=adv, n_options=nopt, dimS=dS, dimA=dA, bounded=fx["bounded"], hidden=[int(x) for x in fx["layers"]], batchSize=B,
+    nnt = int(fx["cfg"][13]) if len(fx["cfg"]) > 13 else 0     # hidden layer type: 0 dense, 1 LSTM
+    bptt = int(fx["cfg"][14]) if len(fx["cfg"]) > 14 else 0
+    kw = dict(adv_kind=adv, n_options=nopt, nn_type=nnt, nnBPTTseq=bptt, dimS=dS, dimA=dA, bounded=fx["bounded"], hidden=[int(x) for x in fx["layers"]], batchSize=B,
               maxTotObsNum=int(hp[12]), clipImpWeight=hp[0], penalTol=hp[1], epsAnneal=hp[2], gamma=hp[3],
               lambda_=hp[4], learnrate=hp[5], explNoise=hp[6], outWeightsPrefac=hp[7], nnLambda=hp[8],
               randSeed=42, nnFunc=func or "SoftSign")
