@@ -107,6 +107,7 @@ struct DevHidden {
   int func;
   long long indW, indB;          // dense weights / bias offsets in the blob
   int hasRes, resW;              // resW = min(nIn, size) (Layers.h:357)
+  int lstm;                      // 1: LSTM layer of `size` cells (Layer_LSTM.h): W is [(nIn + size)][4 size], ldW = 4 size, bias 4 size
   long long indWr, indBr;        // residual w / b offsets
   float *X, *Y, *Rr;             // pre-activation, activation, residual output  [Mmax][ldA]
   float *D, *Dres;               // delta after act', gradient wrt block output  [B][ldA]

@@ -31,6 +31,26 @@ struct HeadArgs {
   int parity;
 };
 
+// recurrent (LSTM) hidden layers, rec.hip: per (sample, step) rows r = b * K + k, K = nnBPTTseq + 1
+struct RecLayer {
+  int nIn, nC, hasRes, resW;
+  long long indW, indB, indWr, indBr;
+  float* A; int ldA;       // [R][ldA]   [input of the step (nIn) | previous output (nC)]: A operand of the dW contraction
+  float* X; float* Y;      // [R][4 nC]  cell input + gates / output, state, pre-gate cell output
+  float* D;                // [R][4 nC]  deltas of cell input and gates: B operand of the dW contraction
+  float* Rd; int ldR;      // [R][ldR]   delta at the residual output (hasRes)
+};
+struct RecArgs {
+  DevScalars* sc; DevReplay rp; DevBatch bt;
+  int B, dS, nL, K, nBPTT;
+  const float* W;
+  RecLayer L[HL_MAX_HIDDEN];
+  float* Yout; int ldY;            // output of the last block at the sampled step (rows < B) and at t+1 (next rows): input of the head
+  const float* Dres; int ldD;      // head: gradient w.r.t. Yout, rows < B
+};
+hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
+hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);
+
 struct PostArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
   int B, mode;                       // mode bits: 1 aggregates, 2 beta+counters, 4 init (beta only)

@@ -49,6 +49,8 @@ struct hl_learner {
   int dev = 0;
   hipStream_t stream = nullptr;
   int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nAdv = 0, nHidden = 0, Mmax = 0;
+  bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
+  RecLayer rec[HL_MAX_HIDDEN]{};
   int nOpt = 0, polDim = 0, nSig = 0;      // discrete head: options; entries of a stored policy (2 dA | nOpt); sigma ParamLayer size (dA | 0)
   long long maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
   // parameter blob layout (Parameters::_computeNParams, Layers/Parameters.h:159-176)
@@ -84,7 +86,7 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
   GraphSlot graphs[5]; bool graphsStale = false, useGraph = true;
-  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer
+  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM
   std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
@@ -167,7 +169,8 @@ int buildNet(hl_learner* h) {
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
-    lw.push_back(roundUp(t.size, 8) * t.nIn); lb.push_back(t.size);
+    if (c.nn_type == HL_NN_LSTM) { lw.push_back((long long)4 * t.size * (t.nIn + t.size)); lb.push_back(4 * t.size); }   // Layer_LSTM.h:24-29
+    else { lw.push_back(roundUp(t.size, 8) * t.nIn); lb.push_back(t.size); }
     t.hasRes = (t.denseLayer != 1);        // no skip connection after the first layer (Builder.cpp:89-95)
     t.resLayer = -1;
     if (t.hasRes) { t.resLayer = (int)lw.size(); lw.push_back(t.size); lb.push_back(t.size); }
@@ -193,9 +196,11 @@ int buildNet(hl_learner* h) {
   h->nParams = tot;
   for (int j = 0; j < nH; ++j) {
     DevHidden& d = h->hid[j];
-    d.nIn = hs[j].nIn; d.size = hs[j].size; d.ldW = (int)roundUp(d.size, 8); d.func = c.nnFunc;
+    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 1 : 0;
+    d.ldW = d.lstm ? 4 * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
     d.indW = h->indW[hs[j].denseLayer]; d.indB = h->indB[hs[j].denseLayer];
     d.hasRes = hs[j].hasRes; d.resW = std::min(d.nIn, d.size);
+    if (d.lstm && d.hasRes && d.nIn < d.size) return HL_ERR_UNSUPPORTED;   // (the reference's residual would read LSTM cell states there, Layers.h:357)
     d.indWr = d.hasRes ? h->indW[hs[j].resLayer] : 0; d.indBr = d.hasRes ? h->indB[hs[j].resLayer] : 0;
     d.ldA = (int)roundUp(d.size, 16);
   }
@@ -203,7 +208,8 @@ int buildNet(hl_learner* h) {
   h->indBp = paramLayer >= 0 ? h->indB[paramLayer] : 0;
   h->lay.clear();
   for (int j = 0; j < nH; ++j) {
-    h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    if (c.nn_type == HL_NN_LSTM) h->lay.push_back({4, hs[j].nIn, hs[j].size, 4 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    else h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     if (hs[j].hasRes) h->lay.push_back({2, 0, hs[j].size, 0, h->indW[hs[j].resLayer], h->indB[hs[j].resLayer]});
   }
   h->lay.push_back({1, prev, h->nDense, h->ldWo, h->indWo, h->indBo});
@@ -410,7 +416,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
-  if (cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;             // recurrent layers: restated by the oracle only (next on the device)
+  if (cfg->nn_type != HL_NN_FFNN && cfg->nn_type != HL_NN_LSTM) return HL_ERR_UNSUPPORTED;
+  if (cfg->nn_type == HL_NN_LSTM) {   // rec.hip: one gate per thread of a 256-thread workgroup
+    if (cfg->dimS > 256) return HL_ERR_UNSUPPORTED;
+    for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
+  }
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return HL_ERR_NO_DEVICE;
   hl_learner* h = new hl_learner();
@@ -447,10 +457,23 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     if (d.hasRes) HIPCK(devAlloc(&d.Rr, n)); else d.Rr = nullptr;
     HIPCK(devAlloc(&d.D, (size_t)B * d.ldA)); HIPCK(devAlloc(&d.Dres, (size_t)B * d.ldA));
   }
+  h->recurrent = cfg->nn_type == HL_NN_LSTM;
+  if (h->recurrent) {
+    h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
+    const size_t R = (size_t)B * h->recK;
+    for (int j = 0; j < h->nHidden; ++j) {
+      const DevHidden& d = h->hid[j]; RecLayer& L = h->rec[j];
+      L.nIn = d.nIn; L.nC = d.size; L.hasRes = d.hasRes; L.resW = d.resW; L.indW = d.indW; L.indB = d.indB; L.indWr = d.indWr; L.indBr = d.indBr;
+      L.ldA = (int)roundUp(d.nIn + d.size, 16); L.ldR = (int)roundUp(d.size, 16);
+      HIPCK(devAlloc(&L.A, R * L.ldA)); HIPCK(devAlloc(&L.X, R * 4 * d.size)); HIPCK(devAlloc(&L.Y, R * 4 * d.size));
+      HIPCK(devAlloc(&L.D, R * 4 * d.size));
+      if (d.hasRes) HIPCK(devAlloc(&L.Rd, R * L.ldR));
+    }
+  }
   {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces
     const char* e = getenv("SMARTIES_HIP_NO_FUSED");
     const bool off = e && e[0] == '1';
-    if (!off && h->nHidden == 2) {
+    if (!off && h->nHidden == 2 && !h->recurrent) {
       const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
       h->fusedOk = d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nAdv == 0 && h->nDense <= 8 && h->ldWo == 8 &&
                    !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
@@ -525,6 +548,7 @@ int hl_destroy(hl_learner* h) {
       bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam, bt.aggIn};
     for (void* q : bp) if (q) hipFree(q);
   }
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd}) if (q) hipFree(q);
   for (void* p : ptrs) if (p) hipFree(p);
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
@@ -568,6 +592,11 @@ int hl_init_weights(hl_learner* h) {
   for (int j = 0; j < h->nHidden; ++j) {
     const DevHidden& d = h->hid[j];
     const float fac = 1; const float init = fac * initFactor(d.func, d.nIn, d.size);
+    if (d.lstm) {   // Layer_LSTM.h:167-185: forget gates start open, input / output gates closed; weights in memory order
+      const int nC = d.size;
+      for (int o = 0; o < nC; ++o) { W[d.indB + o] = 0.f; W[d.indB + nC + o] = -1.f; W[d.indB + 2 * nC + o] = 1.f; W[d.indB + 3 * nC + o] = -1.f; }
+      for (long long w = 0; w < (long long)4 * nC * (d.nIn + nC); ++w) W[d.indW + w] = uni(-init, init);
+    } else
     for (int i = 0; i < d.nIn; ++i) for (int o = 0; o < d.size; ++o) W[d.indW + o + (long long)d.ldW * i] = uni(-init, init);
     if (d.hasRes) for (int o = 0; o < d.size; ++o) { W[d.indWr + o] = 1.f; W[d.indBr + o] = 0.f; }
   }
@@ -795,7 +824,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     int rc = preStepChecks(h); if (rc) return rc;
     const long long k = h->nGradSteps + 1;
     const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
-    const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
+    const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph && !h->recurrent &&
                        (!exchanging(h) || (h->fusedOk && h->exchGraph && h->comm));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
@@ -1137,6 +1166,9 @@ static void packBlob(const hl_learner* h, const std::vector<float>& P, std::vect
     } else if (l.type == 2) {
       for (int o = 0; o < l.size; ++o) out.push_back(W[o]);
       for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
+    } else if (l.type == 4) {     // LSTMLayer::save (Layer_LSTM.h:186-197): weights, then biases, as they lie
+      for (long long w = 0; w < (long long)4 * l.size * (l.nIn + l.size); ++w) out.push_back(W[w]);
+      for (int o = 0; o < 4 * l.size; ++o) out.push_back(Bv[o]);
     } else for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
   }
 }
@@ -1150,6 +1182,9 @@ static void unpackBlob(const hl_learner* h, const std::vector<float>& in, std::v
     } else if (l.type == 2) {
       for (int o = 0; o < l.size; ++o) W[o] = in[k++];
       for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
+    } else if (l.type == 4) {
+      for (long long w = 0; w < (long long)4 * l.size * (l.nIn + l.size); ++w) W[w] = in[k++];
+      for (int o = 0; o < 4 * l.size; ++o) Bv[o] = in[k++];
     } else for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
   }
 }
@@ -1178,7 +1213,8 @@ int hl_restart(hl_learner* h, const char* base) {
   std::vector<float> P[3]; for (auto& v : P) v.resize((size_t)h->nParams);
   int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
   size_t n = 0;
-  for (const auto& l : h->lay) n += l.type == 1 ? (size_t)l.size * (l.nIn + 1) : (l.type == 2 ? 2 * (size_t)l.size : (size_t)l.size);
+  for (const auto& l : h->lay) n += l.type == 1 ? (size_t)l.size * (l.nIn + 1) : (l.type == 2 ? 2 * (size_t)l.size :
+                                  (l.type == 4 ? (size_t)4 * l.size * (l.nIn + l.size + 1) : (size_t)l.size));
   const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
   for (int b = 0; b < 3; ++b) {
     const std::string name = std::string(base) + suf[b] + ".raw";
@@ -1196,6 +1232,7 @@ int hl_restart(hl_learner* h, const char* base) {
 int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward between hl_step_begin and hl_step_end");
+  if (h->recurrent) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
   if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->Mmax * h->dS)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
   const DevHidden& q = h->hid[h->nHidden - 1];
   for (int r0 = 0; r0 < n; r0 += h->Mmax) {

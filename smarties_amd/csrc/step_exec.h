@@ -40,8 +40,8 @@ int buildProblems(hl_learner* h) {
   for (int pb = 0; pb < 2; ++pb) {
     StepBuf& sb = h->buf[pb];
     sb.fwdIdx.clear(); sb.fwdBlocks.clear(); sb.dxIdx.clear(); sb.dxBlocks.clear();
-    // forward: one launch per hidden block
-    for (int j = 0; j < nH; ++j) {
+    // forward: one launch per hidden block (dense layers; LSTM layers have their own kernels, rec.hip)
+    for (int j = 0; j < nH && !h->recurrent; ++j) {
       const DevHidden& d = h->hid[j];
       GemmProblem p{}; p.flavor = GEMM_F; p.epi = EPI_FWD; p.M = h->Mmax; p.N = d.size; p.K = d.nIn; p.dynRows = 1;
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
@@ -53,7 +53,7 @@ int buildProblems(hl_learner* h) {
       sb.fwdIdx.push_back((int)P.size()); sb.fwdBlocks.push_back(cur); P.push_back(p);
     }
     // dX: block j = nH-1 .. 1: Dres_{j-1} = D_j W_j^T + Dres_j[:, :res] * w_j ; D_{j-1} = Dres_{j-1} * act'
-    for (int j = nH - 1; j >= 1; --j) {
+    for (int j = nH - 1; j >= 1 && !h->recurrent; --j) {
       const DevHidden& d = h->hid[j]; const DevHidden& q = h->hid[j - 1];
       GemmProblem p{}; p.flavor = GEMM_X; p.epi = EPI_DX; p.M = B; p.N = d.nIn; p.K = d.size;
       p.A = d.D; p.lda = d.ldA; p.B = h->W + d.indW; p.ldb = d.ldW;
@@ -65,7 +65,23 @@ int buildProblems(hl_learner* h) {
     }
     // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
     sb.dwIdx = (int)P.size(); int cur = 0;
-    for (int j = 0; j < nH; ++j) {
+    for (int j = 0; j < nH && h->recurrent; ++j) {
+      // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
+      // sample does not have carry zero deltas (rec_backward_kernel)
+      const RecLayer& L = h->rec[j]; const int R = B * h->recK;
+      GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = 4 * L.nC; p.K = R;
+      p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 4 * L.nC; p.C = h->G + L.indW; p.ldc = 4 * L.nC; p.biasOut = h->G + L.indB;
+      setTiles(p, cur); P.push_back(p);
+      if (L.hasRes) {
+        GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = L.resW; r.K = R;
+        r.A = L.Rd; r.lda = L.ldR; r.B = L.A; r.ldb = L.ldA; r.C = h->G + L.indWr;
+        setTiles(r, cur); P.push_back(r);
+        GemmProblem s2{}; s2.flavor = RED_COL; s2.epi = EPI_NONE; s2.N = L.resW; s2.K = R;
+        s2.A = L.Rd; s2.lda = L.ldR; s2.B = nullptr; s2.C = h->G + L.indBr;
+        setTiles(s2, cur); P.push_back(s2);
+      }
+    }
+    for (int j = 0; j < nH && !h->recurrent; ++j) {
       const DevHidden& d = h->hid[j];
       GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = d.nIn + 1; p.N = d.size; p.K = B;
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
@@ -311,11 +327,26 @@ bool evictionDue(const hl_learner* h) {
   return !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
 }
 
+RecArgs recArgs(hl_learner* h, int parity) {
+  const DevHidden& q = h->hid[h->nHidden - 1];
+  RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS; ra.nL = h->nHidden;
+  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W;
+  for (int j = 0; j < h->nHidden; ++j) ra.L[j] = h->rec[j];
+  ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA;
+  return ra;
+}
 // forward, head, backward (dX and dW) of buffer `parity`, eager, no riders
 int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
   if (h->fusedOk) {
     int rc = launchFused(h, parity, s); if (rc) return rc;
     return launchWeightGrad(h, parity, fuseAdam, s, false, false);
+  }
+  if (h->recurrent) {      // LSTM layers: window forward, head, back-propagation through time, then the common dW (+ Adam) launch
+    const RecArgs ra = recArgs(h, parity);
+    HIPCK(timed(h, "rec_forward", s, [&] { return launch_rec_forward(ra, s); }));
+    int rc = launchHead(h, parity, s); if (rc) return rc;
+    HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));
+    return launchBackward(h, parity, fuseAdam, s);       // no dX problems for this layout: the dW launch only
   }
   int rc = launchForward(h, parity, s); if (rc) return rc;
   rc = launchHead(h, parity, s); if (rc) return rc;

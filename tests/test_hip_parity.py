@@ -13,7 +13,7 @@ from smarties_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-FUNC_OF = {"deep_tanh.bin": "Tanh"}
+FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh"}
 TOL32 = 1e-5     # north_star: 1e-5 relative fp32
 TOL64 = 1e-9
 
@@ -33,7 +33,7 @@ def our_flat_for(L, tags, ts):
     return np.array([prefix[int(g)] + int(t) for g, t in zip(tags, ts)], np.int64)
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin"])
 def test_init_weights_and_initialize_match_reference(hip_api, name):
     fx = load_fixture(name)
     L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
@@ -57,7 +57,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin"])
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
@@ -163,6 +163,11 @@ def _compare_step(G, O):
     (dict(dimS=24, dimA=1, hidden=(128, 128), batchSize=64, maxTotObsNum=20000, randSeed=43,
           adv_kind=capi.ADV_DISCRETE, n_options=18),
      dict(seed=39, dimS=24, dimA=1, lenMin=20, lenMax=80, pTerm=0.4), 80, 12),
+    # RACER on two LSTM layers (RACER_RNN.json family, BASELINE config 4): truncated BPTT over up to 16 steps, short and
+    # long windows, truncated episode ends (t+1 forwarded through the recurrence)
+    (dict(dimS=6, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=32, maxTotObsNum=20000, randSeed=47, gamma=0.99,
+          adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1),
+     dict(seed=41, dimS=6, dimA=1, lenMin=3, lenMax=60, pTerm=0.4), 80, 12),
 ])
 def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
     """Device-side mt19937 sampler (Lemire + sort/unique/redraw), gather, MLP, head, ReF-ER
