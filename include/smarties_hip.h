@@ -250,6 +250,11 @@ HL_API int hl_pack_episode(hl_learner* h, int64_t episode_pos, float* dst, int64
  * bias).  The binding passes base = "<agent>_net" ("agent_00_net").  hl_restart needs the weights
  * file (HL_ERR_IO if it is missing or has the wrong size); missing moment files are ignored, as in
  * AdamOptimizer::restart. */
+/* Acting with recurrent layers (MemoryBuffer::agentToMinibatch, MemoryBuffer.cpp:440-467 + Approximator::forward(agent)):
+ * `states` = the agent's last n_steps raw observed states, oldest first, n_steps = min(nnBPTTseq, t) + 1; every one is
+ * forwarded from a zero recurrent state, `outputs` (nOutputs doubles) are those of the last.  Dense nets: only the last
+ * state matters (same result as hl_forward on it). */
+HL_API int hl_forward_sequence(hl_learner* h, int32_t n_steps, const float* states, double* outputs);
 HL_API int hl_save(hl_learner* h, const char* base);
 HL_API int hl_restart(hl_learner* h, const char* base);
 

@@ -1279,6 +1279,21 @@ int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs) {
   }
   return HL_OK;
 }
+// MemoryBuffer::agentToMinibatch (:440-467) + Approximator::forward(agent): the last steps from a zero recurrent state
+int ol_forward_sequence(ol_learner* h, int32_t nSteps, const float* states, double* outputs) {
+  if (!h || nSteps < 1 || !states || !outputs) return HL_ERR_BAD_ARG;
+  const int dS = h->dS;
+  if (h->cfg.nn_type == HL_NN_FFNN) return ol_forward(h, 1, states + (size_t)(nSteps - 1) * dS, outputs);
+  std::vector<Act> series((size_t)nSteps);
+  std::vector<nnReal> inp(dS);
+  for (int k = 0; k < nSteps; ++k) {
+    series[k].X = h->X; series[k].Y = h->Y;
+    for (int i = 0; i < dS; ++i) inp[i] = (states[(size_t)k * dS + i] - h->stMean[i]) * h->stScale[i];
+    forwardNet(h, inp.data(), series[k].X, series[k].Y, k ? &series[k - 1].Y : nullptr);
+  }
+  getOutput(h, series[nSteps - 1].Y, outputs);
+  return HL_OK;
+}
 int ol_grad_stats(ol_learner* h, double* mean, double* rms) {
   if (!h || !mean || !rms) return HL_ERR_BAD_ARG;
   if (h->gsMean.empty()) return fail(h, HL_ERR_STATE, "no gradient step yet");

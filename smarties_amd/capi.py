@@ -163,6 +163,7 @@ class CApi:
             "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
             "forward": (C.c_int, [P, I32, pf, pd]),
+            "forward_sequence": (C.c_int, [P, I32, pf, pd]),
             "save": (C.c_int, [P, C.c_char_p]),
             "metrics": (C.c_int, [P, C.c_char_p, I32, C.c_char_p, I32]),
             "grad_stats": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -348,6 +349,13 @@ class Learner:
         _, n, _ = self.episode_info(pos)
         out = np.zeros(int(self.api.fn("packed_episode_size")(self.h, n)), np.float32)
         self._ck(self.api.fn("pack_episode")(self.h, pos, _ptr(out, C.c_float), out.size))
+        return out
+
+    def forward_sequence(self, states):
+        """network outputs for the last of the given consecutive raw states (recurrent nets: forwarded from a zero state)"""
+        states = _f32(states).reshape(-1, self.dS)
+        out = np.zeros(self.nOut, np.float64)
+        self._ck(self.api.fn("forward_sequence")(self.h, states.shape[0], _ptr(states, C.c_float), _ptr(out, C.c_double)))
         return out
 
     def metrics(self):

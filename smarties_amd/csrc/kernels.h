@@ -47,6 +47,7 @@ struct RecArgs {
   RecLayer L[HL_MAX_HIDDEN];
   float* Yout; int ldY;            // output of the last block at the sampled step (rows < B) and at t+1 (next rows): input of the head
   const float* Dres; int ldD;      // head: gradient w.r.t. Yout, rows < B
+  const float* actStates; int actSteps;   // acting (hl_forward_sequence): raw states of the agent's last steps instead of a minibatch
 };
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);

@@ -1248,6 +1248,23 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   return HL_OK;
 }
 
+int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, double* outputs) {
+  if (!h || nSteps < 1 || !states || !outputs) return HL_ERR_BAD_ARG;
+  if (!h->recurrent) return hl_forward(h, 1, states + (size_t)(nSteps - 1) * h->dS, outputs);
+  if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
+  if (nSteps > h->recK) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1");
+  if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)std::max(h->Mmax, h->recK) * h->dS)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
+  const DevHidden& q = h->hid[h->nHidden - 1];
+  HIPCK(hipMemcpyAsync(h->dActS, states, (size_t)nSteps * h->dS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = h->dActS; ra.actSteps = nSteps;
+  HIPCK(launch_rec_forward(ra, h->stream));
+  HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
+                          h->dActO, h->stream));
+  HIPCK(hipMemcpyAsync(outputs, h->dActO, (size_t)h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
 int hl_sync(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
   HIPCK(hipStreamSynchronize(h->stream));

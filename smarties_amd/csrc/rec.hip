@@ -28,16 +28,21 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC], sPrevSt[HL_MAX_HIDDEN][REC_MAXC];
   __shared__ float sX[4 * REC_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
-  const int T = min(a.nBPTT, t);
-  const int nextRow = a.bt.nextOf[b];
+  // acting (MemoryBuffer::agentToMinibatch, MemoryBuffer.cpp:440-467): the agent's last steps, from a zero recurrent state
+  const bool acting = a.actStates != nullptr;
+  const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
+  const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
+  const int nextRow = acting ? -1 : a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
   for (int k = 0; k < nSteps; ++k) {
-    const bool store = k <= T;
+    const bool store = !acting && k <= T;
     const long long r = (long long)b * a.K + k;
     const long long sl = slot - T + k;
-    if (tid < a.dS) sBuf[0][tid] = (a.rp.S[(size_t)sl * a.dS + tid] - a.rp.stMean[tid]) * a.rp.stScale[tid];   // Episode::standardizedState
+    if (tid < a.dS) {
+      const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)sl * a.dS + tid];
+      sBuf[0][tid] = (raw - a.rp.stMean[tid]) * a.rp.stScale[tid];                                   // Episode::standardizedState
+    }
     __syncthreads();
     int cur = 0;
     for (int j = 0; j < a.nL; ++j) {

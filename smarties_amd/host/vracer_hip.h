@@ -57,6 +57,8 @@ struct HyperParameters {
   Uint minTotObsNum = 0, maxTotObsNum = 1 << 20, batchSize = 256;
   std::vector<Uint> nnLayerSizes = {128, 128};
   std::string nnFunc = "Tanh";
+  std::string nnType = "FFNN";      // "FFNN" or "LSTM" (Network/Builder.cpp:48-117); nnBPTTseq: steps of truncated BPTT
+  Uint nnBPTTseq = 16;
   std::string learner = "VRACER";   // "VRACER" (Zero_advantage) or "RACER" (Gaussian_advantage), AlgoFactory.cpp:109-152
   Uint randSeed = 0;
 };
@@ -79,6 +81,7 @@ class VRACER {
   MDPdescriptor MDP;
   HyperParameters S;
   bool bTrain = true, bInit = false;
+  bool recurrent = false;
   int nOut = 0, nDense = 0, nAdv = 0, nOpt = 0;      // nAdv: advantage outputs between V and the policy; nOpt: discrete options
   // one in-progress episode per agent: MemoryBuffer::inProgress (ReplayMemory/MemoryBuffer.h)
   struct InProgress { Fvec states; Rvec actions, policies, rewards; Fvec values, advantages; int64_t tag = 0; };
@@ -119,6 +122,8 @@ class VRACER {
     c.n_hidden = (int32_t)hp.nnLayerSizes.size();
     for (Uint i = 0; i < hp.nnLayerSizes.size(); ++i) c.hidden[i] = (int32_t)hp.nnLayerSizes[i];
     c.nnFunc = funcId(hp.nnFunc);
+    if (hp.nnType == "LSTM") { c.nn_type = HL_NN_LSTM; c.nnBPTTseq = (int32_t)hp.nnBPTTseq; recurrent = true; }
+    else if (hp.nnType != "FFNN") die("nnType " + hp.nnType + " is not served by the HIP library");
     // AlgoFactory.cpp:78-152: discrete action spaces always get RACER<Discrete_advantage, Discrete_policy, Uint>
     if (M.bDiscreteActions()) {
       if (M.dimAction != 1 || M.discreteActionValues.size() != 1) die("one discrete action variable is served");
@@ -148,6 +153,14 @@ class VRACER {
   Rvec forward(const Agent& agent) const {
     if (agent.state.size() != MDP.dimStateObserved) die("Agent state has the wrong size");
     Rvec out((Uint)nOut);
+    if (recurrent) {   // MemoryBuffer::agentToMinibatch (:440-467): the last min(nnBPTTseq, t) + 1 states of the episode in progress
+      const InProgress& EP = inProgress.at(agent.ID);
+      const Uint dS = MDP.dimStateObserved, nS = (Uint)(EP.states.size() / dS), n = std::min<Uint>(S.nnBPTTseq + 1, nS);
+      if (n == 0) die("forward(agent) before the agent's state was stored");
+      const int rcs = hl_forward_sequence(H, (int32_t)n, EP.states.data() + (size_t)(nS - n) * dS, out.data());
+      if (rcs) die(std::string(hl_status_string(rcs)) + ": " + hl_last_error(H));
+      return out;
+    }
     const int rc = hl_forward(H, 1, agent.state.data(), out.data());
     if (rc) die(std::string(hl_status_string(rc)) + ": " + hl_last_error(H));
     return out;

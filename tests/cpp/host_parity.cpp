@@ -240,6 +240,52 @@ int main() {
     CHECK(relinf(a, b) < 1e-4, "discrete weights after 20 steps: rel err %.3g", relinf(a, b));
     ol_destroy(O3);
   }
+  // ---- RACER on LSTM layers (RACER_RNN.json family): acting carries the episode's history, training follows the oracle ----
+  {
+    MDPdescriptor M4; M4.dimStateObserved = 4; M4.dimAction = 1; M4.bActionSpaceBounded = {true};
+    HyperParameters H4; H4.learner = "RACER"; H4.nnType = "LSTM"; H4.nnBPTTseq = 6; H4.nnLayerSizes = {32, 32}; H4.nnFunc = "Tanh";
+    H4.batchSize = 16; H4.maxTotObsNum = 5000; H4.clipImpWeight = 4; H4.epsAnneal = 0; H4.explNoise = 0.1; H4.outWeightsPrefac = 0.1;
+    H4.gamma = 0.99; H4.nnLambda = 1e-6; H4.randSeed = 123;
+    VRACER Rn(M4, H4, 0);
+    hl_config c4{}; c4.struct_size = sizeof(c4); c4.dimS = 4; c4.dimA = 1; c4.bounded[0] = 1; c4.nn_type = HL_NN_LSTM; c4.nnBPTTseq = 6;
+    c4.n_hidden = 2; c4.hidden[0] = c4.hidden[1] = 32; c4.nnFunc = HL_FUNC_TANH; c4.adv_kind = HL_ADV_GAUSSIAN;
+    c4.batchSize = 16; c4.maxTotObsNum = 5000; c4.gamma = 0.99; c4.lambda = H4.lambda; c4.clipImpWeight = 4; c4.penalTol = H4.penalTol;
+    c4.epsAnneal = 0; c4.learnrate = H4.learnrate; c4.nnLambda = 1e-6; c4.explNoise = 0.1; c4.outWeightsPrefac = 0.1;
+    c4.randSeed = 123; c4.n_ranks = 1; c4.ref_threads = 1;
+    ol_learner* O4 = nullptr;
+    CHECK(ol_create(&c4, &O4) == 0 && ol_init_weights(O4) == 0, "LSTM oracle");
+    for (int e = 0; e < 30; ++e) {
+      Agent agent(0, 3000 + e);
+      std::vector<float> hist;
+      for (int t = 0; t <= 15; ++t) {
+        agent.agentStatus = t == 0 ? INIT : (t == 15 ? (e % 2 ? LAST : TERM) : CONT);
+        agent.state.resize(4); for (int i = 0; i < 4; ++i) agent.state[i] = 0.5f * (float)std::sin(0.41 * t + 1.3 * i + e);
+        agent.reward = 0.1 * t;
+        hist.insert(hist.end(), agent.state.begin(), agent.state.end());
+        Rn.select(agent);
+        if (t < 15 && e == 0) {      // the policy mean the agent acted on = the oracle's output for the same history window
+          const int n = std::min(7, t + 1);
+          std::vector<double> out(8);
+          CHECK(ol_forward_sequence(O4, n, hist.data() + (size_t)(t + 1 - n) * 4, out.data()) == 0, "ol_forward_sequence");
+          CHECK(std::fabs(agent.policyVector[0] - out[4]) <= 1e-5 * (1 + std::fabs(out[4])), "recurrent policy mean at t=%d: %.9g vs %.9g", t, agent.policyVector[0], out[4]);
+        }
+      }
+      const Fvec packed = Rn.packEpisode(0);
+      CHECK(ol_append_packed_episode(O4, packed.data(), (int64_t)packed.size()) == 0, "oracle takes the packed episode");
+    }
+    Rn.initializeLearner(); CHECK(ol_initialize(O4) == 0, "LSTM ol_initialize");
+    std::vector<int64_t> f1(16), f2(16);
+    for (int k = 1; k <= 20; ++k) {
+      Rn.trainStep(1); CHECK(ol_step(O4, 1, nullptr) == 0, "LSTM ol_step");
+      hl_readback(Rn.handle(), HL_TAP_FLAT, f1.data(), 16 * 8); ol_readback(O4, HL_TAP_FLAT, f2.data(), 16 * 8);
+      CHECK(f1 == f2, "LSTM step %d: sampled indices differ", k);
+    }
+    const int64_t n4 = hl_num_params(Rn.handle());
+    std::vector<float> a(n4), b(n4), t1(n4), t2(n4);
+    hl_get_params(Rn.handle(), a.data(), t1.data(), t2.data()); ol_get_params(O4, b.data(), t1.data(), t2.data());
+    CHECK(relinf(a, b) < 1e-4, "LSTM weights after 20 steps: rel err %.3g", relinf(a, b));
+    ol_destroy(O4);
+  }
   ol_destroy(O);
   std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: OK\n", failures);
   return failures ? 1 : 0;

@@ -629,6 +629,25 @@ def test_rollout_forward_matches_oracle(hip_api, cfg_kw, sc_kw):
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json size: 1M-transition replay, 17/6, 2x256, B=256
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_recurrent_acting_matches_oracle(hip_api):
+    """hl_forward_sequence: the agent's last min(nnBPTTseq, t) + 1 states forwarded from a zero recurrent state
+    (MemoryBuffer::agentToMinibatch + Approximator::forward(agent)), after some training, windows of every length."""
+    cfg_kw = dict(dimS=6, dimA=2, bounded=[1, 0], hidden=(32, 32), nnFunc="Tanh", batchSize=16, maxTotObsNum=5000, randSeed=51,
+                  adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnBPTTseq=8)
+    G, O = _pair(hip_api, cfg_kw, synth_cfg(seed=43, dimS=6, dimA=2, lenMin=5, lenMax=40, pTerm=0.5), 40)
+    G.step(5); O.step(5)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 5, 9):
+        S = rng.normal(size=(n, 6)).astype(np.float32)
+        og, oo = G.forward_sequence(S), O.forward_sequence(S)
+        assert relinf(og, oo) < TOL32, (n, og, oo)
+    with pytest.raises(capi.HlError):
+        G.forward_sequence(rng.normal(size=(10, 6)).astype(np.float32))      # more than nnBPTTseq + 1 steps
+    with pytest.raises(capi.HlError):
+        G.forward(rng.normal(size=(1, 6)).astype(np.float32))                # stateless forward of a recurrent net
+
+
 @pytest.fixture(scope="module")
 def full_size(hip_api):
     cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=1000000, randSeed=42)
