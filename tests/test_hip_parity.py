@@ -272,9 +272,10 @@ def test_eviction_and_append_during_training(hip_api):
     assert relinf(G.get_params()[0], O.get_params()[0]) < TOL32
 
 
-def test_split_step_equals_fused_step(hip_api):
-    """hl_step_begin / exchanges / hl_step_end (host-side all-reduce hook) == hl_step."""
-    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42)
+@pytest.mark.parametrize("extra", [{}, dict(adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnFunc="Tanh", nnBPTTseq=6)])
+def test_split_step_equals_fused_step(hip_api, extra):
+    """hl_step_begin / exchanges / hl_step_end (host-side all-reduce hook) == hl_step (dense and recurrent layers)."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42, **extra)
     sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
     A, _ = _pair(hip_api, cfg_kw, sc, 30)
     Bq = hip_learner(hip_api, capi.make_config(**cfg_kw))
