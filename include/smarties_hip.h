@@ -77,7 +77,7 @@ enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU 
 /* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
 /* hidden layer type (Network/Builder.cpp:48-117): dense, or LSTM (Network/Layers/Layer_LSTM.h; BASELINE config 4).
  * HL_NN_LSTM: rec.hip (one workgroup per sample walks the BPTT window; cells <= 64 per layer, eager launches). */
-enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1 };
+enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1, HL_NN_MGU = 2 /* Layer_GRU.h: what a partially observable MDP gets when nnType is left FFNN (Approximator.cpp:221-223) */ };
 
 /* advantage head (Learners/AlgoFactory.cpp:109-152): Math/Zero_advantage.h (VRACER), Math/Gaus_advantage.h (RACER,
  * continuous actions: network outputs [V | coef, L+ x dA, L- x dA | mean x dA | sigma parameter x dA]);

@@ -154,7 +154,7 @@ inline bool isFarPolicy(Fval W, Fval C, Fval invC) {
 // ---------------------------------------------------------------------------
 // network description (Network/Builder.cpp:48-117, Layers/*.h)
 // ---------------------------------------------------------------------------
-enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM };
+enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM, L_MGU };
 struct Layer {
   LType type; int size = 0, nIn = 0, nOutSimd = 0, func = HL_FUNC_LINEAR;
   bool bOutput = false, skipInpGrad = false;
@@ -165,6 +165,8 @@ struct Layer {
 // work memory of one time step (Network/Layers/Activation.h): pre-activations, outputs, errors per layer; an LSTM
 // layer uses 4 x nCells entries of each (Layer_LSTM.h:29-48)
 struct Act { std::vector<std::vector<nnReal>> X, Y, E; };
+
+inline int actSize(const Layer& l) { return l.type == L_LSTM ? 4 * l.size : (l.type == L_MGU ? 2 * l.size : l.size); }   // Activation::sizes
 
 struct Episode {  // ReplayMemory/Episode.h:40-108
   int64_t tag = -1, ID = -1, seq = 0; int N = 0; bool term = false;
@@ -232,7 +234,7 @@ void buildNet(ol_learner* h) {
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     const int ID = (int)L.size();
-    Layer d; d.type = c.nn_type == HL_NN_LSTM ? L_LSTM : L_DENSE; d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
+    Layer d; d.type = c.nn_type == HL_NN_LSTM ? L_LSTM : (c.nn_type == HL_NN_MGU ? L_MGU : L_DENSE); d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
     d.nOutSimd = (int)roundUp8(d.size); d.func = c.nnFunc;
     L.push_back(d);
     // skip connection except after the first layer (Builder.cpp:89-95)
@@ -268,6 +270,7 @@ void buildNet(ol_learner* h) {
       case L_PARAMRES: l.nW = l.size; l.nB = l.size; break;                    // Layers.h:334-338
       case L_PARAM: l.nW = 0; l.nB = l.size; break;                            // Layers.h:494-497
       case L_LSTM: l.nW = (int64_t)4 * l.size * (l.nIn + l.size); l.nB = 4 * l.size; break;   // Layer_LSTM.h:24-29
+      case L_MGU: l.nW = (int64_t)2 * l.size * (l.nIn + l.size); l.nB = 2 * l.size; break;    // Layer_GRU.h:29-34
     }
     l.indW = tot; tot += roundUp8(l.nW);
     l.indB = tot; tot += roundUp8(l.nB);
@@ -278,7 +281,7 @@ void buildNet(ol_learner* h) {
   const size_t nl = L.size();
   h->X.resize(nl); h->Y.resize(nl); h->E.resize(nl); h->Xn.resize(nl); h->Yn.resize(nl);
   for (size_t i = 0; i < nl; ++i) {
-    const size_t n = (size_t)roundUp8(L[i].type == L_LSTM ? 4 * L[i].size : L[i].size);
+    const size_t n = (size_t)roundUp8(actSize(L[i]));
     h->X[i].assign(n, 0); h->Y[i].assign(n, 0); h->E[i].assign(n, 0);
     h->Xn[i].assign(n, 0); h->Yn[i].assign(n, 0);
   }
@@ -302,6 +305,11 @@ void initWeights(ol_learner* h) {
       const int nC = l.size;
       for (int o = 0; o < nC; ++o) { Bv[o] = 0; Bv[nC + o] = -1; Bv[2 * nC + o] = 1; Bv[3 * nC + o] = -1; }
       for (int64_t w = 0; w < (int64_t)4 * nC * (l.nIn + nC); ++w) W[w] = uniformFloat(h->gen, -init, init);
+    } else if (l.type == L_MGU) {    // Layer_GRU.h:232-246: forget gate starts open
+      const nnReal init = fInitFactor(l.func, l.nIn, l.size);
+      const int nC = l.size;
+      for (int o = 0; o < nC; ++o) { Bv[o] = 1; Bv[nC + o] = 0; }
+      for (int64_t w = 0; w < (int64_t)2 * nC * (l.nIn + nC); ++w) W[w] = uniformFloat(h->gen, -init, init);
     } else if (l.type == L_PARAMRES) {
       for (int o = 0; o < l.size; ++o) { Bv[o] = 0; W[o] = 1; }
     } else if (l.type == L_PARAM) {
@@ -311,7 +319,6 @@ void initWeights(ol_learner* h) {
 }
 
 // Network::forward (Network/Network.h:102-113) over Layer::forward of each type
-inline int actSize(const Layer& l) { return l.type == L_LSTM ? 4 * l.size : l.size; }   // Activation::sizes
 inline nnReal sigmEval(nnReal in) {   // Sigm::_eval (Functions.h:158-165), safeExp cut at 8 for fp32 (Definitions.h:43)
   const auto safeExp = [](nnReal v) { return std::exp(std::min((nnReal)8, std::max(-(nnReal)8, v))); };
   if (in > 0) return 1 / (1 + safeExp(-in));
@@ -358,6 +365,24 @@ void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vecto
         currSt[o] = suminp[o] * inputG[o] + oldStatePass;
         cellOp[o] = fEval(HL_FUNC_TANH, currSt[o]);
         output[o] = outptG[o] * cellOp[o];
+      }
+    } else if (l.type == L_MGU) {    // Layer_GRU.h:66-118: forget = sigm(Wff in + Wfr prevOut + bf), state = tanh(Wsf in + Wsr (forget*prevOut) + bs)
+      const int nC = l.size;
+      nnReal* forget = X[ID].data(); nnReal* state = forget + nC; nnReal* output = Y[ID].data();
+      std::memcpy(forget, Bv, 2 * nC * sizeof(nnReal));
+      { const nnReal* inputs = Y[ID - 1].data();
+        for (int i = 0; i < l.nIn; ++i) { const nnReal* Wi = W + (int64_t)2 * nC * i; for (int o = 0; o < 2 * nC; ++o) forget[o] += inputs[i] * Wi[o]; } }
+      if (prevY) {
+        const nnReal* inputs = (*prevY)[ID].data(); const nnReal* Wr = W + (int64_t)2 * nC * l.nIn;
+        for (int i = 0; i < nC; ++i) { const nnReal* Wfr = Wr + (int64_t)2 * nC * i; for (int o = 0; o < nC; ++o) forget[o] += Wfr[o] * inputs[i]; }
+        for (int o = 0; o < nC; ++o) forget[o] = sigmEval(forget[o]);
+        for (int i = 0; i < nC; ++i) { const nnReal* Wsr = Wr + (int64_t)2 * nC * i + nC; for (int o = 0; o < nC; ++o) state[o] += Wsr[o] * inputs[i] * forget[i]; }
+        for (int o = 0; o < nC; ++o) state[o] = fEval(HL_FUNC_TANH, state[o]);
+        for (int o = 0; o < nC; ++o) output[o] = forget[o] * state[o] + (1 - forget[o]) * inputs[o];
+      } else {
+        for (int o = 0; o < nC; ++o) forget[o] = sigmEval(forget[o]);
+        for (int o = 0; o < nC; ++o) state[o] = fEval(HL_FUNC_TANH, state[o]);
+        for (int o = 0; o < nC; ++o) output[o] = forget[o] * state[o];
       }
     } else if (l.type == L_PARAM) {  // Layers.h:510-520
       for (int n = 0; n < l.size; ++n) { X[ID][n] = Bv[n]; Y[ID][n] = fEval(l.func, Bv[n]); }
@@ -449,6 +474,32 @@ void backwardSeries(ol_learner* h, std::vector<Act>& series, int T) {
         nnReal* gradInp = cur.E[ID - 2].data(); const nnReal* inp = cur.Y[ID - 2].data();
         const int sizeInp = std::min(actSize(L[ID - 2]), l.size);
         for (int j = 0; j < sizeInp; ++j) { gradInp[j] += delta[j] * W[j]; gW[j] += delta[j] * inp[j]; gB[j] += delta[j]; }
+      } else if (l.type == L_MGU) {    // Layer_GRU.h:120-229
+        const int nC = l.size;
+        const nnReal* forget = cur.X[ID].data(); const nnReal* state = forget + nC;
+        const nnReal* dLdO = cur.E[ID].data(); nnReal* dLdF = cur.E[ID].data() + nC; nnReal* dLdS = cur.Y[ID].data() + nC;
+        std::vector<nnReal> zeros(nC, 0), dLdFprevOut(nC, 0);
+        const nnReal* prevOut = prev ? prev->Y[ID].data() : zeros.data();
+        nnReal* dLdprevOut = prev ? prev->E[ID].data() : nullptr;
+        for (int o = 0; o < nC; ++o) dLdS[o] = dLdO[o] * forget[o] * (1 - state[o] * state[o]);
+        const nnReal* Wr = W + (int64_t)2 * nC * l.nIn;
+        if (prev) gemvOmp(nC, nC, 2 * nC, Wr + nC, dLdS, dLdFprevOut.data());
+        for (int o = 0; o < nC; ++o) dLdF[o] = ((state[o] - prevOut[o]) * dLdO[o] + dLdFprevOut[o] * prevOut[o]) * forget[o] * (1 - forget[o]);
+        if (prev) {
+          for (int o = 0; o < nC; ++o) dLdprevOut[o] += (1 - forget[o]) * dLdO[o] + forget[o] * dLdFprevOut[o];
+          gemvOmp(nC, nC, 2 * nC, Wr, dLdF, dLdprevOut);
+        }
+        if (!l.skipInpGrad) {
+          gemvOmp(nC, l.nIn, 2 * nC, W, dLdF, cur.E[ID - 1].data());
+          gemvOmp(nC, l.nIn, 2 * nC, W + nC, dLdS, cur.E[ID - 1].data());
+        }
+        for (int o = 0; o < nC; ++o) { gB[o] += dLdF[o]; gB[o + nC] += dLdS[o]; }
+        { const nnReal* inputs = cur.Y[ID - 1].data();
+          for (int i = 0; i < l.nIn; ++i) { nnReal* Gi = gW + (int64_t)2 * nC * i; for (int o = 0; o < nC; ++o) { Gi[o] += inputs[i] * dLdF[o]; Gi[o + nC] += inputs[i] * dLdS[o]; } } }
+        if (prev) for (int i = 0; i < nC; ++i) {
+          nnReal* Gi = gW + (int64_t)2 * nC * (l.nIn + i);
+          for (int o = 0; o < nC; ++o) { Gi[o] += prevOut[i] * dLdF[o]; Gi[o + nC] += prevOut[i] * dLdS[o] * forget[i]; }
+        }
       } else if (l.type == L_LSTM) {   // Layer_LSTM.h:127-165, then Layer::backward (Layers.h:123-188) with NO = 4 nC, NR = nC
         const int nC = l.size;
         nnReal* deltas = cur.E[ID].data();
@@ -1037,7 +1088,7 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     if (h->tap) std::copy(inp.begin(), inp.end(), h->tState.begin() + (size_t)b * dS);
     // recurrent nets: the window of MemoryBuffer::sampleMinibatch (:391-402), min(nnBPTTseq, t) steps before t; every
     // step is forwarded with the previous one as recurrent input (Approximator::forward, Approximator.h:116-173)
-    const bool recurrent = h->cfg.nn_type == HL_NN_LSTM;
+    const bool recurrent = h->cfg.nn_type == HL_NN_LSTM || h->cfg.nn_type == HL_NN_MGU;
     std::vector<Act> series; int T = 0;
     if (recurrent) {
       const int nBPTT = h->cfg.nnBPTTseq > 0 ? h->cfg.nnBPTTseq : 16;

@@ -279,7 +279,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     std::vector<int64_t> cfg = {(int64_t)H.MDP.dimStateObserved, (int64_t)H.MDP.dimAction,
         (int64_t)H.HP->batchSize, nEps, nSteps, (int64_t)PW->nParams, (int64_t)NET.nOutputs(),
         (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind, (int64_t)H.nOpt,
-        (int64_t)(H.HP->nnType == "LSTM" ? 1 : 0), (int64_t)H.HP->nnBPTTseq};
+        (int64_t)(H.HP->nnType == "LSTM" ? 1 : (H.HP->nnType == "MGU" ? 2 : 0)), (int64_t)H.HP->nnBPTTseq};
     W.i64("cfg", cfg);
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

@@ -21,7 +21,7 @@ HL_MAX_HIDDEN = 8
 FUNC = {"Linear": 0, "Tanh": 1, "SoftSign": 2, "Relu": 3, "LRelu": 4, "Sigm": 5, "HardSign": 6,
         "SoftPlus": 7, "ExpPlus": 8, "Exp": 9}
 ADV_ZERO, ADV_GAUSSIAN, ADV_DISCRETE = 0, 1, 2
-NN_FFNN, NN_LSTM = 0, 1
+NN_FFNN, NN_LSTM, NN_MGU = 0, 1, 2
 ORDER_STABLE, ORDER_REFERENCE = 0, 1
 
 (TAP_FLAT, TAP_EPISODE, TAP_TSTEP, TAP_TAG, TAP_STATE, TAP_OUTPUT, TAP_OUTGRAD, TAP_RHO, TAP_DKL,
