@@ -39,10 +39,12 @@ struct RecLayer {
   float* X; float* Y;      // [R][4 nC]  cell input + gates / output, state, pre-gate cell output
   float* D;                // [R][4 nC]  deltas of cell input and gates: B operand of the dW contraction
   float* Rd; int ldR;      // [R][ldR]   delta at the residual output (hasRes)
+  float* A2; int ldA2;     // [R][ldA2]  MGU: previous output x forget gate (A operand of the recurrent state weights)
 };
 struct RecArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
   int B, dS, nL, K, nBPTT;
+  int gates;                       // 4: LSTM (cell input, input / forget / output gate), 2: MGU (forget gate, state)
   const float* W;
   RecLayer L[HL_MAX_HIDDEN];
   float* Yout; int ldY;            // output of the last block at the sampled step (rows < B) and at t+1 (next rows): input of the head

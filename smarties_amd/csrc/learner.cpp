@@ -34,6 +34,7 @@ struct EpMeta { int eid; long long off; int N; bool term; long long tag, ID; lon
 struct TimeRec { int name; hipEvent_t a, b; };
 
 // one of the two minibatch workspaces + the indices of its GEMM problems in the device table
+constexpr int PARAM_TAIL = 256;
 struct StepBuf {
   DevBatch bt{}; float* X0 = nullptr;
   std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
@@ -86,7 +87,7 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
   GraphSlot graphs[5]; bool graphsStale = false, useGraph = true;
-  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM
+  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM, 5 MGU (ld = gates x cells)
   std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
@@ -169,7 +170,8 @@ int buildNet(hl_learner* h) {
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
-    if (c.nn_type == HL_NN_LSTM) { lw.push_back((long long)4 * t.size * (t.nIn + t.size)); lb.push_back(4 * t.size); }   // Layer_LSTM.h:24-29
+    const int gates = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : 0);     // Layer_LSTM.h:24-29, Layer_GRU.h:29-34
+    if (gates) { lw.push_back((long long)gates * t.size * (t.nIn + t.size)); lb.push_back(gates * t.size); }
     else { lw.push_back(roundUp(t.size, 8) * t.nIn); lb.push_back(t.size); }
     t.hasRes = (t.denseLayer != 1);        // no skip connection after the first layer (Builder.cpp:89-95)
     t.resLayer = -1;
@@ -196,8 +198,8 @@ int buildNet(hl_learner* h) {
   h->nParams = tot;
   for (int j = 0; j < nH; ++j) {
     DevHidden& d = h->hid[j];
-    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 1 : 0;
-    d.ldW = d.lstm ? 4 * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
+    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : 0);   // gates per cell (0: dense)
+    d.ldW = d.lstm ? d.lstm * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
     d.indW = h->indW[hs[j].denseLayer]; d.indB = h->indB[hs[j].denseLayer];
     d.hasRes = hs[j].hasRes; d.resW = std::min(d.nIn, d.size);
     if (d.lstm && d.hasRes && d.nIn < d.size) return HL_ERR_UNSUPPORTED;   // (the reference's residual would read LSTM cell states there, Layers.h:357)
@@ -209,6 +211,7 @@ int buildNet(hl_learner* h) {
   h->lay.clear();
   for (int j = 0; j < nH; ++j) {
     if (c.nn_type == HL_NN_LSTM) h->lay.push_back({4, hs[j].nIn, hs[j].size, 4 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    else if (c.nn_type == HL_NN_MGU) h->lay.push_back({5, hs[j].nIn, hs[j].size, 2 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     else h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     if (hs[j].hasRes) h->lay.push_back({2, 0, hs[j].size, 0, h->indW[hs[j].resLayer], h->indB[hs[j].resLayer]});
   }
@@ -416,8 +419,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
-  if (cfg->nn_type != HL_NN_FFNN && cfg->nn_type != HL_NN_LSTM) return HL_ERR_UNSUPPORTED;
-  if (cfg->nn_type == HL_NN_LSTM) {   // rec.hip: one gate per thread of a 256-thread workgroup
+  if (cfg->nn_type != HL_NN_FFNN && cfg->nn_type != HL_NN_LSTM && cfg->nn_type != HL_NN_MGU) return HL_ERR_UNSUPPORTED;
+  if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: one gate per thread of a 256-thread workgroup
     if (cfg->dimS > 256) return HL_ERR_UNSUPPORTED;
     for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
   }
@@ -446,8 +449,9 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   int rc = buildNet(h); if (rc) return rc;
   const int B = h->B;
   h->Mmax = (int)roundUp(2 * B, 16);
-  HIPCK(devAlloc(&h->W, (size_t)h->nParams)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams));
-  HIPCK(devAlloc(&h->M2, (size_t)h->nParams)); HIPCK(devAlloc(&h->G, (size_t)h->nParams));
+  // (+ PARAM_TAIL unused floats: scratch "bias" rows of weight-gradient problems that have no bias, step_exec.h)
+  HIPCK(devAlloc(&h->W, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams + PARAM_TAIL));
+  HIPCK(devAlloc(&h->M2, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->G, (size_t)h->nParams + PARAM_TAIL));
   HIPCK(devAlloc(&h->sc, 1));
   h->ldX0 = (int)roundUp(h->dS, 16);
   for (int j = 0; j < h->nHidden; ++j) {
@@ -457,17 +461,19 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     if (d.hasRes) HIPCK(devAlloc(&d.Rr, n)); else d.Rr = nullptr;
     HIPCK(devAlloc(&d.D, (size_t)B * d.ldA)); HIPCK(devAlloc(&d.Dres, (size_t)B * d.ldA));
   }
-  h->recurrent = cfg->nn_type == HL_NN_LSTM;
+  h->recurrent = cfg->nn_type != HL_NN_FFNN;
   if (h->recurrent) {
     h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
     const size_t R = (size_t)B * h->recK;
     for (int j = 0; j < h->nHidden; ++j) {
       const DevHidden& d = h->hid[j]; RecLayer& L = h->rec[j];
       L.nIn = d.nIn; L.nC = d.size; L.hasRes = d.hasRes; L.resW = d.resW; L.indW = d.indW; L.indB = d.indB; L.indWr = d.indWr; L.indBr = d.indBr;
-      L.ldA = (int)roundUp(d.nIn + d.size, 16); L.ldR = (int)roundUp(d.size, 16);
-      HIPCK(devAlloc(&L.A, R * L.ldA)); HIPCK(devAlloc(&L.X, R * 4 * d.size)); HIPCK(devAlloc(&L.Y, R * 4 * d.size));
-      HIPCK(devAlloc(&L.D, R * 4 * d.size));
+      const size_t g = (size_t)d.lstm;         // gates per cell
+      L.ldA = (int)roundUp(d.nIn + d.size + 1, 16); L.ldR = (int)roundUp(d.size, 16); L.ldA2 = (int)roundUp(d.size + 1, 16);
+      HIPCK(devAlloc(&L.A, R * L.ldA)); HIPCK(devAlloc(&L.X, R * g * d.size)); HIPCK(devAlloc(&L.Y, R * g * d.size));
+      HIPCK(devAlloc(&L.D, R * g * d.size));
       if (d.hasRes) HIPCK(devAlloc(&L.Rd, R * L.ldR));
+      if (d.lstm == 2) HIPCK(devAlloc(&L.A2, R * L.ldA2 + 16));
     }
   }
   {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces
@@ -548,7 +554,7 @@ int hl_destroy(hl_learner* h) {
       bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam, bt.aggIn};
     for (void* q : bp) if (q) hipFree(q);
   }
-  for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd}) if (q) hipFree(q);
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd, h->rec[j].A2}) if (q) hipFree(q);
   for (void* p : ptrs) if (p) hipFree(p);
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
@@ -592,10 +598,11 @@ int hl_init_weights(hl_learner* h) {
   for (int j = 0; j < h->nHidden; ++j) {
     const DevHidden& d = h->hid[j];
     const float fac = 1; const float init = fac * initFactor(d.func, d.nIn, d.size);
-    if (d.lstm) {   // Layer_LSTM.h:167-185: forget gates start open, input / output gates closed; weights in memory order
+    if (d.lstm) {   // Layer_LSTM.h:167-185 / Layer_GRU.h:232-246: forget gates start open, input / output gates closed; weights in memory order
       const int nC = d.size;
-      for (int o = 0; o < nC; ++o) { W[d.indB + o] = 0.f; W[d.indB + nC + o] = -1.f; W[d.indB + 2 * nC + o] = 1.f; W[d.indB + 3 * nC + o] = -1.f; }
-      for (long long w = 0; w < (long long)4 * nC * (d.nIn + nC); ++w) W[d.indW + w] = uni(-init, init);
+      if (d.lstm == 4) for (int o = 0; o < nC; ++o) { W[d.indB + o] = 0.f; W[d.indB + nC + o] = -1.f; W[d.indB + 2 * nC + o] = 1.f; W[d.indB + 3 * nC + o] = -1.f; }
+      else for (int o = 0; o < nC; ++o) { W[d.indB + o] = 1.f; W[d.indB + nC + o] = 0.f; }
+      for (long long w = 0; w < (long long)d.lstm * nC * (d.nIn + nC); ++w) W[d.indW + w] = uni(-init, init);
     } else
     for (int i = 0; i < d.nIn; ++i) for (int o = 0; o < d.size; ++o) W[d.indW + o + (long long)d.ldW * i] = uni(-init, init);
     if (d.hasRes) for (int o = 0; o < d.size; ++o) { W[d.indWr + o] = 1.f; W[d.indBr + o] = 0.f; }
@@ -1166,9 +1173,9 @@ static void packBlob(const hl_learner* h, const std::vector<float>& P, std::vect
     } else if (l.type == 2) {
       for (int o = 0; o < l.size; ++o) out.push_back(W[o]);
       for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
-    } else if (l.type == 4) {     // LSTMLayer::save (Layer_LSTM.h:186-197): weights, then biases, as they lie
-      for (long long w = 0; w < (long long)4 * l.size * (l.nIn + l.size); ++w) out.push_back(W[w]);
-      for (int o = 0; o < 4 * l.size; ++o) out.push_back(Bv[o]);
+    } else if (l.type == 4 || l.type == 5) {     // LSTMLayer::save / MGULayer::save (Layer_LSTM.h:186-197, Layer_GRU.h:248-258): weights, then biases, as they lie
+      for (long long w = 0; w < (long long)l.ld * (l.nIn + l.size); ++w) out.push_back(W[w]);
+      for (int o = 0; o < l.ld; ++o) out.push_back(Bv[o]);
     } else for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
   }
 }
@@ -1182,9 +1189,9 @@ static void unpackBlob(const hl_learner* h, const std::vector<float>& in, std::v
     } else if (l.type == 2) {
       for (int o = 0; o < l.size; ++o) W[o] = in[k++];
       for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
-    } else if (l.type == 4) {
-      for (long long w = 0; w < (long long)4 * l.size * (l.nIn + l.size); ++w) W[w] = in[k++];
-      for (int o = 0; o < 4 * l.size; ++o) Bv[o] = in[k++];
+    } else if (l.type == 4 || l.type == 5) {
+      for (long long w = 0; w < (long long)l.ld * (l.nIn + l.size); ++w) W[w] = in[k++];
+      for (int o = 0; o < l.ld; ++o) Bv[o] = in[k++];
     } else for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
   }
 }
@@ -1214,7 +1221,7 @@ int hl_restart(hl_learner* h, const char* base) {
   int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
   size_t n = 0;
   for (const auto& l : h->lay) n += l.type == 1 ? (size_t)l.size * (l.nIn + 1) : (l.type == 2 ? 2 * (size_t)l.size :
-                                  (l.type == 4 ? (size_t)4 * l.size * (l.nIn + l.size + 1) : (size_t)l.size));
+                                  (l.type == 4 || l.type == 5 ? (size_t)l.ld * (l.nIn + l.size + 1) : (size_t)l.size));
   const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
   for (int b = 0; b < 3; ++b) {
     const std::string name = std::string(base) + suf[b] + ".raw";

@@ -34,7 +34,7 @@ __device__ __forceinline__ void recStageWeights(const RecArgs& a, float* sW, int
   int off = 0;
   for (int j = 0; j < a.nL; ++j) {
     const RecLayer& L = a.L[j];
-    const int NO = 4 * L.nC, rows = L.nIn + L.nC;
+    const int NO = a.gates * L.nC, rows = L.nIn + L.nC;
     const float* src = a.W + L.indW;
     // eight loads in flight per thread (a rolled loop pays one L2 / HBM round trip per element: 50 in a row at 32 cells)
     const int total = rows * NO;
@@ -51,7 +51,7 @@ __device__ __forceinline__ void recStageWeights(const RecArgs& a, float* sW, int
 // offset of layer j's weights inside the LDS copy
 __device__ __forceinline__ int recLdsOffset(const RecArgs& a, int j) {
   int off = 0;
-  for (int q = 0; q < j; ++q) off += (a.L[q].nIn + a.L[q].nC) * (4 * a.L[q].nC + 1);
+  for (int q = 0; q < j; ++q) off += (a.L[q].nIn + a.L[q].nC) * (a.gates * a.L[q].nC + 1);
   return off;
 }
 
@@ -237,9 +237,199 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
   }
 }
 
+// ---- MGU layers (Network/Layers/Layer_GRU.h): forget = sigm(Wff in + Wfr prevOut + bf), state = tanh(Wsf in + Wsr (forget * prevOut)
+// + bs), output = forget * state + (1 - forget) * prevOut.  Same structure as the LSTM kernels: one workgroup per sample. ----
+template <bool LDSW>
+__global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  __shared__ float sBuf[2][REC_MAXIN];
+  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC];
+  __shared__ float sF[REC_MAXC], sS[REC_MAXC];
+  __shared__ float sStates[REC_STATES];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool acting = a.actStates != nullptr;
+  const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
+  const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
+  const int nextRow = acting ? -1 : a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  if constexpr (LDSW) recStageWeights(a, sW, tid);
+  float bias[HL_MAX_HIDDEN], wr[HL_MAX_HIDDEN], br[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) {
+    bias[j] = 0.f; wr[j] = 0.f; br[j] = 0.f;
+    if (j < a.nL) {
+      const RecLayer& L = a.L[j];
+      if (tid < 2 * L.nC) bias[j] = W[L.indB + tid];
+      if (L.hasRes && tid < L.resW) { wr[j] = W[L.indWr + tid]; br[j] = W[L.indBr + tid]; }
+    }
+  }
+  const bool preload = nSteps * a.dS <= REC_STATES;
+  if (preload) for (int e = tid; e < nSteps * a.dS; e += 256) {
+    const int kk = e / a.dS, i = e - kk * a.dS;
+    const float raw = acting ? a.actStates[e] : a.rp.S[(size_t)(slot - T + kk) * a.dS + i];
+    sStates[e] = (raw - a.rp.stMean[i]) * a.rp.stScale[i];
+  }
+  const float sMean = tid < a.dS ? a.rp.stMean[tid] : 0.f, sScale = tid < a.dS ? a.rp.stScale[tid] : 1.f;
+  ldsBarrier();
+  for (int k = 0; k < nSteps; ++k) {
+    const bool store = !acting && k <= T;
+    const long long r = (long long)b * a.K + k;
+    if (tid < a.dS) {
+      if (preload) sBuf[0][tid] = sStates[k * a.dS + tid];
+      else { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)(slot - T + k) * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
+    }
+    ldsBarrier();
+    int cur = 0;
+#pragma unroll
+    for (int j = 0; j < HL_MAX_HIDDEN; ++j) if (j < a.nL) {
+      const RecLayer& L = a.L[j];
+      const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
+      const float* in = sBuf[cur];
+      const int ldw = LDSW ? NO + 1 : NO, wOff = LDSW ? recLdsOffset(a, j) : 0;
+      const float* gWj = W + L.indW;
+      auto wAt = [&](int i, int o) -> float { if constexpr (LDSW) return sW[wOff + i * ldw + o]; else return gWj[(size_t)i * ldw + o]; };
+      if (store) {
+        for (int i = tid; i < nIn; i += 256) L.A[r * L.ldA + i] = in[i];
+        if (tid < nC) L.A[r * L.ldA + nIn + tid] = k > 0 ? sPrevOut[j][tid] : 0.f;
+      }
+      float acc = 0.f;
+      if (tid < NO) {
+        acc = bias[j];
+#pragma unroll 8
+        for (int i = 0; i < nIn; ++i) acc += in[i] * wAt(i, tid);
+        if (tid < nC) {          // forget gate
+          if (k > 0) {
+#pragma unroll 8
+            for (int i = 0; i < nC; ++i) acc += wAt(nIn + i, tid) * sPrevOut[j][i];
+          }
+          acc = recSigm(acc);
+          sF[tid] = acc;
+          if (store) L.X[r * NO + tid] = acc;
+        }
+      }
+      ldsBarrier();
+      if (tid >= nC && tid < NO) {   // cell state
+        if (k > 0) {
+#pragma unroll 8
+          for (int i = 0; i < nC; ++i) acc += wAt(nIn + i, tid) * sPrevOut[j][i] * sF[i];
+        }
+        acc = actEval(HL_FUNC_TANH, acc);
+        sS[tid - nC] = acc;
+        if (store) L.X[r * NO + tid] = acc;
+      }
+      ldsBarrier();
+      float out = 0.f;
+      if (tid < nC) {
+        const float f = sF[tid], st = sS[tid], po = k > 0 ? sPrevOut[j][tid] : 0.f;
+        out = k > 0 ? f * st + (1.f - f) * po : f * st;
+        if (store) { L.Y[r * NO + tid] = out; L.A2[r * L.ldA2 + tid] = po * f; }
+        float blk = out;
+        if (L.hasRes && tid < L.resW) blk += in[tid] * wr[j] + br[j];
+        sBuf[cur ^ 1][tid] = blk;
+      }
+      ldsBarrier();
+      if (tid < nC) sPrevOut[j][tid] = out;
+      cur ^= 1;
+    }
+    const int nCl = a.L[a.nL - 1].nC;
+    if (k == T && tid < nCl) a.Yout[(size_t)b * a.ldY + tid] = sBuf[cur][tid];
+    if (k == T + 1 && tid < nCl) a.Yout[(size_t)nextRow * a.ldY + tid] = sBuf[cur][tid];
+    ldsBarrier();
+  }
+}
+
+template <bool LDSW>
+__global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  __shared__ float sTop[2][REC_MAXIN];
+  __shared__ float sRec[HL_MAX_HIDDEN][REC_MAXC];          // dLdprevOut handed from step k+1 to step k
+  __shared__ float sDF[REC_MAXC], sDS[REC_MAXC], sFP[REC_MAXC], sRes[REC_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = a.bt.t[b];
+  const int T = min(a.nBPTT, t);
+  const float* W = a.W;
+  if constexpr (LDSW) recStageWeights(a, sW, tid);
+  float wr[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) { wr[j] = 0.f; if (j < a.nL && a.L[j].hasRes && tid < a.L[j].resW) wr[j] = W[a.L[j].indWr + tid]; }
+  ldsBarrier();
+  for (int k = T + 1; k < a.K; ++k) {
+    const long long r = (long long)b * a.K + k;
+    for (int j = 0; j < a.nL; ++j) {
+      const RecLayer& L = a.L[j];
+      if (tid < 2 * L.nC) L.D[r * 2 * L.nC + tid] = 0.f;
+      if (L.hasRes && tid < L.nC) L.Rd[r * L.ldR + tid] = 0.f;
+    }
+  }
+  for (int k = T; k >= 0; --k) {
+    const long long r = (long long)b * a.K + k;
+    int cur = 0;
+    const int nCl = a.L[a.nL - 1].nC;
+    if (tid < nCl) sTop[0][tid] = k == T ? a.Dres[(size_t)b * a.ldD + tid] : 0.f;
+    float vF[HL_MAX_HIDDEN], vS[HL_MAX_HIDDEN], vP[HL_MAX_HIDDEN];
+#pragma unroll
+    for (int j = 0; j < HL_MAX_HIDDEN; ++j) {
+      vF[j] = vS[j] = vP[j] = 0.f;
+      if (j < a.nL && tid < a.L[j].nC) {
+        const RecLayer& L = a.L[j]; const int nC = L.nC, NO = 2 * nC;
+        vF[j] = L.X[r * NO + tid]; vS[j] = L.X[r * NO + nC + tid];
+        if (k > 0) vP[j] = L.Y[(r - 1) * NO + tid];
+      }
+    }
+    ldsBarrier();
+#pragma unroll
+    for (int j = HL_MAX_HIDDEN - 1; j >= 0; --j) if (j < a.nL) {
+      const RecLayer& L = a.L[j];
+      const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
+      const int ldw = LDSW ? NO + 1 : NO, wOff = LDSW ? recLdsOffset(a, j) : 0;
+      const float* gWj = W + L.indW;
+      auto wAt = [&](int i, int o) -> float { if constexpr (LDSW) return sW[wOff + i * ldw + o]; else return gWj[(size_t)i * ldw + o]; };
+      float dLdO = 0.f;
+      if (tid < nC) {
+        const float eTop = sTop[cur][tid];
+        if (L.hasRes) { L.Rd[r * L.ldR + tid] = eTop; sRes[tid] = tid < L.resW ? eTop * wr[j] : 0.f; }
+        dLdO = eTop + (k < T ? sRec[j][tid] : 0.f);
+        sDS[tid] = dLdO * vF[j] * (1.f - vS[j] * vS[j]);                         // 1) dLdS
+      }
+      ldsBarrier();
+      float fp = 0.f;
+      if (tid < nC && k > 0) {                                                   // 2) dLdFprevOut = Wsr dLdS
+#pragma unroll 8
+        for (int o = 0; o < nC; ++o) fp += wAt(nIn + tid, nC + o) * sDS[o];
+      }
+      if (tid < nC) {
+        sFP[tid] = fp;
+        sDF[tid] = ((vS[j] - vP[j]) * dLdO + fp * vP[j]) * vF[j] * (1.f - vF[j]);   // 3) dLdF
+        L.D[r * NO + tid] = sDF[tid]; L.D[r * NO + nC + tid] = sDS[tid];
+      }
+      ldsBarrier();
+      // backprop to the block input: Wff dLdF + Wsf dLdS (+ the residual path); not below the first layer
+      if (j > 0) for (int i = tid; i < nIn; i += 256) {
+        float e1 = 0.f, e2 = 0.f;
+#pragma unroll 8
+        for (int o = 0; o < nC; ++o) { e1 += wAt(i, o) * sDF[o]; e2 += wAt(i, nC + o) * sDS[o]; }
+        sTop[cur ^ 1][i] = ((L.hasRes && i < L.resW ? sRes[i] : 0.f) + e1) + e2;
+      }
+      float rec = 0.f;
+      if (k > 0 && tid < nC) {                                                   // 4) dLdprevOut
+        rec = (1.f - vF[j]) * dLdO + vF[j] * sFP[tid];
+        float g = 0.f;
+#pragma unroll 8
+        for (int o = 0; o < nC; ++o) g += wAt(nIn + tid, o) * sDF[o];
+        rec += g;
+      }
+      ldsBarrier();
+      if (tid < nC) sRec[j][tid] = rec;
+      cur ^= 1;
+    }
+    ldsBarrier();
+  }
+}
+
 static size_t recLdsBytes(const RecArgs& a) {
   size_t fl = 0;
-  for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (4 * a.L[j].nC + 1);
+  for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (a.gates * a.L[j].nC + 1);
   return fl * sizeof(float);
 }
 template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_t lds, size_t* attr, hipStream_t s) {
@@ -253,14 +443,14 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 }
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
-  static size_t attr = 0; const size_t lds = recLdsBytes(a);
-  if (lds <= 120 * 1024) return recLaunch(rec_forward_kernel<true>, a, lds, &attr, s);
-  static size_t attr0 = 0; return recLaunch(rec_forward_kernel<false>, a, 0, &attr0, s);
+  static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
+  if (a.gates == 2) return fit ? recLaunch(mgu_forward_kernel<true>, a, lds, &attr[0], s) : recLaunch(mgu_forward_kernel<false>, a, 0, &attr[1], s);
+  return fit ? recLaunch(rec_forward_kernel<true>, a, lds, &attr[2], s) : recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
-  static size_t attr = 0; const size_t lds = recLdsBytes(a);
-  if (lds <= 120 * 1024) return recLaunch(rec_backward_kernel<true>, a, lds, &attr, s);
-  static size_t attr0 = 0; return recLaunch(rec_backward_kernel<false>, a, 0, &attr0, s);
+  static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
+  if (a.gates == 2) return fit ? recLaunch(mgu_backward_kernel<true>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false>, a, 0, &attr[1], s);
+  return fit ? recLaunch(rec_backward_kernel<true>, a, lds, &attr[2], s) : recLaunch(rec_backward_kernel<false>, a, 0, &attr[3], s);
 }
 
 }  // namespace hl

@@ -69,9 +69,27 @@ int buildProblems(hl_learner* h) {
       // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
       // sample does not have carry zero deltas (rec_backward_kernel)
       const RecLayer& L = h->rec[j]; const int R = B * h->recK;
-      GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = 4 * L.nC; p.K = R;
-      p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 4 * L.nC; p.C = h->G + L.indW; p.ldc = 4 * L.nC; p.biasOut = h->G + L.indB;
-      setTiles(p, cur); P.push_back(p);
+      if (h->hid[j].lstm == 4) {
+        GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = 4 * L.nC; p.K = R;
+        p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 4 * L.nC; p.C = h->G + L.indW; p.ldc = 4 * L.nC; p.biasOut = h->G + L.indB;
+        setTiles(p, cur); P.push_back(p);
+      } else {
+        // MGU (Layer_GRU.h:196-229): [Wff Wsf] and the biases from the inputs; Wfr from the previous output and dLdF; Wsr from
+        // (previous output x forget) and dLdS.  The two recurrent blocks have no bias: their bias row goes to the unused tail
+        // of the parameter arrays.
+        const int nC = L.nC;
+        GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + 1; p.N = 2 * nC; p.K = R;
+        p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 2 * nC; p.C = h->G + L.indW; p.ldc = 2 * nC; p.biasOut = h->G + L.indB;
+        setTiles(p, cur); P.push_back(p);
+        GemmProblem f{}; f.flavor = GEMM_W; f.epi = EPI_DW; f.M = nC + 1; f.N = nC; f.K = R;
+        f.A = L.A + L.nIn; f.lda = L.ldA; f.B = L.D; f.ldb = 2 * nC; f.C = h->G + L.indW + (long long)2 * nC * L.nIn; f.ldc = 2 * nC;
+        f.biasOut = h->G + h->nParams;
+        setTiles(f, cur); P.push_back(f);
+        GemmProblem q{}; q.flavor = GEMM_W; q.epi = EPI_DW; q.M = nC + 1; q.N = nC; q.K = R;
+        q.A = L.A2; q.lda = L.ldA2; q.B = L.D + nC; q.ldb = 2 * nC; q.C = h->G + L.indW + (long long)2 * nC * L.nIn + nC; q.ldc = 2 * nC;
+        q.biasOut = h->G + h->nParams + 64;
+        setTiles(q, cur); P.push_back(q);
+      }
       if (L.hasRes) {
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = L.resW; r.K = R;
         r.A = L.Rd; r.lda = L.ldR; r.B = L.A; r.ldb = L.ldA; r.C = h->G + L.indWr;
@@ -330,7 +348,7 @@ bool evictionDue(const hl_learner* h) {
 RecArgs recArgs(hl_learner* h, int parity) {
   const DevHidden& q = h->hid[h->nHidden - 1];
   RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS; ra.nL = h->nHidden;
-  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W;
+  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[0].lstm;
   for (int j = 0; j < h->nHidden; ++j) ra.L[j] = h->rec[j];
   ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA;
   return ra;

@@ -57,7 +57,7 @@ struct HyperParameters {
   Uint minTotObsNum = 0, maxTotObsNum = 1 << 20, batchSize = 256;
   std::vector<Uint> nnLayerSizes = {128, 128};
   std::string nnFunc = "Tanh";
-  std::string nnType = "FFNN";      // "FFNN" or "LSTM" (Network/Builder.cpp:48-117); nnBPTTseq: steps of truncated BPTT
+  std::string nnType = "FFNN";      // "FFNN", "LSTM" or "MGU" (Network/Builder.cpp:48-117); nnBPTTseq: steps of truncated BPTT
   Uint nnBPTTseq = 16;
   std::string learner = "VRACER";   // "VRACER" (Zero_advantage) or "RACER" (Gaussian_advantage), AlgoFactory.cpp:109-152
   Uint randSeed = 0;
@@ -123,6 +123,7 @@ class VRACER {
     for (Uint i = 0; i < hp.nnLayerSizes.size(); ++i) c.hidden[i] = (int32_t)hp.nnLayerSizes[i];
     c.nnFunc = funcId(hp.nnFunc);
     if (hp.nnType == "LSTM") { c.nn_type = HL_NN_LSTM; c.nnBPTTseq = (int32_t)hp.nnBPTTseq; recurrent = true; }
+    else if (hp.nnType == "MGU" || hp.nnType == "GRU") { c.nn_type = HL_NN_MGU; c.nnBPTTseq = (int32_t)hp.nnBPTTseq; recurrent = true; }   // Builder.cpp:68-73
     else if (hp.nnType != "FFNN") die("nnType " + hp.nnType + " is not served by the HIP library");
     // AlgoFactory.cpp:78-152: discrete action spaces always get RACER<Discrete_advantage, Discrete_policy, Uint>
     if (M.bDiscreteActions()) {

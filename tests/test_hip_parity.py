@@ -13,7 +13,7 @@ from smarties_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh"}
+FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh"}
 TOL32 = 1e-5     # north_star: 1e-5 relative fp32
 TOL64 = 1e-9
 
@@ -33,7 +33,7 @@ def our_flat_for(L, tags, ts):
     return np.array([prefix[int(g)] + int(t) for g, t in zip(tags, ts)], np.int64)
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])
 def test_init_weights_and_initialize_match_reference(hip_api, name):
     fx = load_fixture(name)
     L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
@@ -57,7 +57,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
@@ -168,6 +168,10 @@ def _compare_step(G, O):
     (dict(dimS=6, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=32, maxTotObsNum=20000, randSeed=47, gamma=0.99,
           adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1),
      dict(seed=41, dimS=6, dimA=1, lenMin=3, lenMax=60, pTerm=0.4), 80, 12),
+    # V-RACER on MGU layers (Layer_GRU.h; what a partially observable MDP gets with the default nnType), unequal widths
+    (dict(dimS=7, dimA=2, bounded=[0, 1], hidden=(48, 32), nnFunc="Tanh", batchSize=24, maxTotObsNum=20000, randSeed=53,
+          nn_type=capi.NN_MGU, nnBPTTseq=10),
+     dict(seed=45, dimS=7, dimA=2, lenMin=3, lenMax=50, pTerm=0.4), 80, 12),
 ])
 def test_device_sampler_and_update_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
     """Device-side mt19937 sampler (Lemire + sort/unique/redraw), gather, MLP, head, ReF-ER
