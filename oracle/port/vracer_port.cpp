@@ -1256,6 +1256,7 @@ static size_t packedSize(const ol_learner* h) {
     if (l.type == L_DENSE) n += (size_t)l.size * (l.nIn + 1);
     else if (l.type == L_PARAMRES) n += 2 * (size_t)l.size;
     else if (l.type == L_PARAM) n += (size_t)l.size;
+    else if (l.type == L_LSTM || l.type == L_MGU) n += (size_t)actSize(l) * (l.nIn + l.size + 1);   // Layer_LSTM.h:186-197, Layer_GRU.h:248-258
   }
   return n;
 }
@@ -1270,6 +1271,10 @@ static void packBlob(const ol_learner* h, const std::vector<nnReal>& P, std::vec
       for (int o = 0; o < l.size; ++o) out.push_back((float)W[o]);
       for (int o = 0; o < l.size; ++o) out.push_back((float)Bv[o]);
     } else if (l.type == L_PARAM) for (int o = 0; o < l.size; ++o) out.push_back((float)Bv[o]);
+    else if (l.type == L_LSTM || l.type == L_MGU) {   // weights, then biases, as they lie
+      for (int64_t w = 0; w < (int64_t)actSize(l) * (l.nIn + l.size); ++w) out.push_back((float)W[w]);
+      for (int o = 0; o < actSize(l); ++o) out.push_back((float)Bv[o]);
+    }
   }
 }
 static void unpackBlob(const ol_learner* h, const std::vector<float>& in, std::vector<nnReal>& P) {
@@ -1283,6 +1288,10 @@ static void unpackBlob(const ol_learner* h, const std::vector<float>& in, std::v
       for (int o = 0; o < l.size; ++o) W[o] = (nnReal)in[k++];
       for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)in[k++];
     } else if (l.type == L_PARAM) for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)in[k++];
+    else if (l.type == L_LSTM || l.type == L_MGU) {
+      for (int64_t w = 0; w < (int64_t)actSize(l) * (l.nIn + l.size); ++w) W[w] = (nnReal)in[k++];
+      for (int o = 0; o < actSize(l); ++o) Bv[o] = (nnReal)in[k++];
+    }
   }
 }
 int ol_save(ol_learner* h, const char* base) {

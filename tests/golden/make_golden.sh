@@ -33,13 +33,13 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
    maxObs=2000 minObs=500 epsAnneal=5e-7
 # G-lstm: RACER (Gaussian advantage) on two LSTM layers, truncated BPTT over 8 steps (the RACER_RNN.json family, BASELINE config 4)
 "$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/racer_lstm.bin" dimS=5 dimA=2 bounded=10 layers=32,32 nnType=LSTM nnFunc=Tanh bptt=8 \
-   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_lstm"
 # G-mgu: V-RACER on two MGU layers (what a partially observable MDP gets with the default nnType, Approximator.cpp:221-223)
 "$DRV" fixture "$HERE/vracer_mgu.bin" dimS=5 dimA=2 bounded=10 layers=32,32 nnType=MGU nnFunc=Tanh bptt=8 \
-   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_mgu"
 # G-discrete: RACER with Discrete_policy / Discrete_advantage (one action variable, 4 options)
 "$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/racer_discrete.bin" dimS=5 dimA=1 nOpt=4 layers=32,32 batch=16 nEps=30 \
-   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_disc" pack=4 memck="$TMP/mem_disc"
 # official-vs-manual cross check of the harness itself (weights must be bit-identical)
 "$DRV" fixture "$TMP/off.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 maxObs=2000 minObs=500 path=official

@@ -83,6 +83,7 @@ def check_packed_roundtrip(make_learner, fx):
     from oracle_api import synth_episode
     cfg = fixture_config(fx)
     sc = fixture_synth(fx)
+    nopt = int(fx["cfg"][12]) if len(fx["cfg"]) > 12 else 0     # discrete head: policies are n_options probabilities
     tags = [int(t) for t in fx["pack_tags"]]
     packs = [np.asarray(fx["pack_%d" % k], np.float32) for k in range(len(tags))]
     # (1) same learner state as the reference had: the library's own pack == the reference's pack
@@ -100,7 +101,7 @@ def check_packed_roundtrip(make_learner, fx):
     Bq = make_learner(cfg); Bq.init_weights()
     for tag, ref in zip(tags, packs):
         A.append_packed_episode(ref)
-        ep = synth_episode(sc, tag)
+        ep = synth_episode(sc, tag, nopt)
         ep["actions"] = ep["actions"].astype(np.float32).astype(np.float64)
         ep["mu"] = ep["mu"].astype(np.float32).astype(np.float64)
         ep["rewards"] = ep["rewards"].astype(np.float32).astype(np.float64)

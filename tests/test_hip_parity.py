@@ -378,7 +378,7 @@ def test_rccl_exchange_sequence_on_one_rank(hip_api):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "racer_lstm.bin", "vracer_mgu.bin", "racer_discrete.bin"])
 def test_checkpoint_files_match_reference(hip_api, name, tmp_path):
     """hl_save == the reference's own checkpoint files (Network::save, Network.cpp:22-38) for the
     same weights / moments; hl_restart of the reference's files restores the device blobs; a
@@ -403,9 +403,10 @@ def test_checkpoint_files_match_reference(hip_api, name, tmp_path):
 
 
 @pytest.mark.gpu
-def test_packed_episode_wire_format_matches_reference(hip_api):
+@pytest.mark.parametrize("name", ["small_mixed.bin", "racer_discrete.bin"])
+def test_packed_episode_wire_format_matches_reference(hip_api, name):
     from parity import check_packed_roundtrip
-    check_packed_roundtrip(lambda cfg: hip_learner(hip_api, cfg), load_fixture("small_mixed.bin"))
+    check_packed_roundtrip(lambda cfg: hip_learner(hip_api, cfg), load_fixture(name))
 
 
 @pytest.mark.gpu

@@ -146,7 +146,7 @@ def test_long_trajectory_crosses_1000_step_sweep(tmp_path, name):
     assert lines_agree(stats_line(L), bytes(bytearray(fx["metrics_line"])).decode(), head)
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "racer_lstm.bin", "vracer_mgu.bin", "racer_discrete.bin"])
 def test_checkpoint_files_match_reference(name, tmp_path):
     """ol_save writes byte-for-byte the files Approximator::save wrote for the same weights and
     moments (Network.cpp:22-38); ol_restart of the reference's files restores the padded blobs."""
@@ -169,6 +169,7 @@ def test_checkpoint_files_match_reference(name, tmp_path):
         L2.restart(str(tmp_path / "missing"))
 
 
-def test_packed_episode_wire_format_matches_reference():
+@pytest.mark.parametrize("name", ["small_mixed.bin", "racer_discrete.bin"])
+def test_packed_episode_wire_format_matches_reference(name):
     from parity import check_packed_roundtrip
-    check_packed_roundtrip(oracle_learner, load_fixture("small_mixed.bin"))
+    check_packed_roundtrip(oracle_learner, load_fixture(name))
