@@ -63,6 +63,8 @@ struct PostArgs {
   float eta0;
   int aggStaged;                     // 1: bt.aggIn holds the episode aggregates (fused kernel), no gather needed
   int hasAdv;                        // 1: Q = bt.newQ (head with an advantage), 0: Q = V
+  float* cntMsg;                     // != nullptr: the four replica counters travel inside the gradient message (12 floats, three
+                                     // 20-bit chunks each: exact in fp32 for up to 16 replicas) instead of a collective of their own
 };
 enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4 };
 

@@ -50,6 +50,7 @@ struct hl_learner {
   int dev = 0;
   hipStream_t stream = nullptr;
   int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nAdv = 0, nHidden = 0, Mmax = 0;
+  bool foldCounters = false;               // while capturing exchange graphs: counters ride in the gradient message (step_exec.h)
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
   RecLayer rec[HL_MAX_HIDDEN]{};
   int nOpt = 0, polDim = 0, nSig = 0;      // discrete head: options; entries of a stored policy (2 dA | nOpt); sigma ParamLayer size (dA | 0)

@@ -26,6 +26,7 @@ namespace {
 
 // steps per replayed graph, tried in this order; 999 = everything between two 1000th-step sweeps
 constexpr int GRAPH_SIZES[] = {999, 256, 64, 8, 2};
+constexpr int CNT_MSG_OFFSET = 128;    // counters message inside the PARAM_TAIL floats behind the gradient (learner.cpp)
 
 void setTiles(GemmProblem& p, int& cursor) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
@@ -172,6 +173,7 @@ PostArgs postArgs(hl_learner* h, int parity, int mode) {
   pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
   pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = exchanging(h) ? 2 : 1;   // > 1: use the exchanged counters
   pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate; pa.aggStaged = h->fusedOk ? 1 : 0; pa.hasAdv = h->nAdv > 0 ? 1 : 0;
+  pa.cntMsg = h->foldCounters ? h->G + h->nParams + CNT_MSG_OFFSET : nullptr;
   return pa;
 }
 HeadArgs headArgs(hl_learner* h, int parity) {
@@ -324,10 +326,12 @@ int applyRemoval(hl_learner* h) {
   return HL_OK;
 }
 
+// with `foldCounters` the message also carries the parameter tail up to the 12 counter chunks (postPart, cntMsg)
 int allreduceGrad(hl_learner* h) {
   if (!exchanging(h)) return HL_OK;
   if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
-  NCCLCK(ncclAllReduce(h->G, h->G, (size_t)h->nParams, ncclFloat, ncclSum, h->comm, h->stream));
+  const size_t n = (size_t)h->nParams + (h->foldCounters ? CNT_MSG_OFFSET + 12 : 0);
+  NCCLCK(ncclAllReduce(h->G, h->G, n, ncclFloat, ncclSum, h->comm, h->stream));
   return HL_OK;
 }
 int allreduceCounters(hl_learner* h) {
@@ -409,13 +413,17 @@ int captureSteps(hl_learner* h, int U, GraphSlot* slot) {
     if (h->fusedOk) {
       rc = launchFused(h, p, s0, more); if (rc) break;
       if (!exchanging(h)) { rc = launchWeightGrad(h, p, true, s0, true, false); if (rc) break; continue; }
-      // replicas: the exchanges are part of the replayed graph (RCCL calls are captured like kernels).
-      // Same collective order as the eager sequence: gradient sum, then the four counters.
-      rc = launchWeightGrad(h, p, false, s0, true, false, POST_AGG); if (rc) break;
-      rc = allreduceGrad(h); if (rc) break;
-      rc = allreduceCounters(h); if (rc) break;
-      rc = launchAdam(h, p); if (rc) break;
-      rc = launchPost(h, p, POST_BETA, s0); if (rc) break;
+      // replicas: the exchange is part of the replayed graph (RCCL calls are captured like kernels).  ONE collective per
+      // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (three exact 20-bit
+      // chunks each), the pass after Adam decodes their sums -- the eager sequence keeps its separate counter all-reduce
+      // because there the gradient is exchanged before the bookkeeping runs.
+      h->foldCounters = true;
+      rc = launchWeightGrad(h, p, false, s0, true, false, POST_AGG);
+      if (!rc) rc = allreduceGrad(h);
+      if (!rc) rc = launchAdam(h, p);
+      if (!rc) rc = launchPost(h, p, POST_BETA, s0);
+      h->foldCounters = false;
+      if (rc) break;
       continue;
     }
     rc = launchForward(h, p, s0, more); if (rc) break;

@@ -155,12 +155,24 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
       sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
       if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce
+      if (a.cntMsg) {       // counters ride in the tail of the gradient buffer: one all-reduce per step instead of two
+        const long long c4[4] = {sc->seenLocal[0], sc->seenLocal[1], nFarStat, nTrans};
+        for (int c = 0; c < 4; ++c) for (int q = 0; q < 3; ++q) a.cntMsg[3 * c + q] = (float)((c4[c] >> (20 * q)) & 0xFFFFF);
+      }
     }
   }
   if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {
     // updateCounters (:46-92); with several replicas cnt[] holds the all-reduced counters
-    const long long nFar = a.nRanks > 1 ? cnt2 : nFarStat;
-    const long long nStored = a.nRanks > 1 ? cnt3 : nTrans;
+    long long cntR[4] = {sc->cnt[0], sc->cnt[1], cnt2, cnt3};
+    if (a.cntMsg) {         // decode the summed chunks (each sum < 2^24: exact)
+      for (int c = 0; c < 4; ++c) {
+        long long v = 0;
+        for (int q = 0; q < 3; ++q) v += (long long)(a.cntMsg[3 * c + q] + 0.5f) << (20 * q);
+        cntR[c] = v; sc->cnt[c] = v;
+      }
+    }
+    const long long nFar = a.nRanks > 1 ? cntR[2] : nFarStat;
+    const long long nStored = a.nRanks > 1 ? cntR[3] : nTrans;
     const double fracOffPol = (double)nFar / (double)(nStored > 1 ? nStored : 1);
     const double nDataSize = fmax(a.maxObsGlobal, (double)nStored);
     const double learnRefer = 0.1 * a.batchGlobal / nDataSize;
