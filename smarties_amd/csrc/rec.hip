@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   const int nextRow = acting ? -1 : a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
+  // layer descriptors copied out of the kernel-argument segment once (inside the step loops every field access was a scalar
+  // load of its own)
+  RecLayer LL[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
   if constexpr (LDSW) recStageWeights(a, sW, tid);
   float bias[HL_MAX_HIDDEN], wr[HL_MAX_HIDDEN], br[HL_MAX_HIDDEN];      // this thread's gate bias / residual parameters per layer
 #pragma unroll
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
     int cur = 0;
 #pragma unroll
     for (int j = 0; j < HL_MAX_HIDDEN; ++j) if (j < a.nL) {
-      const RecLayer& L = a.L[j];
+      const RecLayer& L = LL[j];
       const int nIn = L.nIn, nC = L.nC, NO = 4 * nC;
       const float* in = sBuf[cur];
       // element (i, o) of [W_in; W_rec] of this layer: LDS copy (padded rows) or global memory, decided at compile time
@@ -159,6 +164,11 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
   const int t = a.bt.t[b];
   const int T = min(a.nBPTT, t);
   const float* W = a.W;
+  // layer descriptors copied out of the kernel-argument segment once (inside the step loops every field access was a scalar
+  // load of its own)
+  RecLayer LL[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
   if constexpr (LDSW) recStageWeights(a, sW, tid);
   float wr[HL_MAX_HIDDEN];
 #pragma unroll
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
     ldsBarrier();
 #pragma unroll
     for (int j = HL_MAX_HIDDEN - 1; j >= 0; --j) if (j < a.nL) {
-      const RecLayer& L = a.L[j];
+      const RecLayer& L = LL[j];
       const int nIn = L.nIn, nC = L.nC, NO = 4 * nC;
       const int ldw = LDSW ? NO + 1 : NO, wOff = LDSW ? recLdsOffset(a, j) : 0;
       const float* gWj = W + L.indW;
@@ -253,6 +263,11 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
   const int nextRow = acting ? -1 : a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
+  // layer descriptors copied out of the kernel-argument segment once (inside the step loops every field access was a scalar
+  // load of its own)
+  RecLayer LL[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
   if constexpr (LDSW) recStageWeights(a, sW, tid);
   float bias[HL_MAX_HIDDEN], wr[HL_MAX_HIDDEN], br[HL_MAX_HIDDEN];
 #pragma unroll
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
     int cur = 0;
 #pragma unroll
     for (int j = 0; j < HL_MAX_HIDDEN; ++j) if (j < a.nL) {
-      const RecLayer& L = a.L[j];
+      const RecLayer& L = LL[j];
       const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
       const float* in = sBuf[cur];
       const int ldw = LDSW ? NO + 1 : NO, wOff = LDSW ? recLdsOffset(a, j) : 0;
@@ -349,6 +364,11 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
   const int t = a.bt.t[b];
   const int T = min(a.nBPTT, t);
   const float* W = a.W;
+  // layer descriptors copied out of the kernel-argument segment once (inside the step loops every field access was a scalar
+  // load of its own)
+  RecLayer LL[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
   if constexpr (LDSW) recStageWeights(a, sW, tid);
   float wr[HL_MAX_HIDDEN];
 #pragma unroll
@@ -380,7 +400,7 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
     ldsBarrier();
 #pragma unroll
     for (int j = HL_MAX_HIDDEN - 1; j >= 0; --j) if (j < a.nL) {
-      const RecLayer& L = a.L[j];
+      const RecLayer& L = LL[j];
       const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
       const int ldw = LDSW ? NO + 1 : NO, wOff = LDSW ? recLdsOffset(a, j) : 0;
       const float* gWj = W + L.indW;
