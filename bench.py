@@ -107,12 +107,22 @@ def cpu_baseline(steps_budget_s=20.0):
                         best = r
                 except Exception as e:  # noqa: BLE001
                     tried.append((thr, "failed: %s" % e))
+            if best is not None:      # the quoted value: a longer run at the best thread count (the 400-step probes are noisy)
+                thr = int(best["threads"])
+                env = dict(os.environ, OMP_NUM_THREADS=str(thr), OMP_PROC_BIND="close", OMP_PLACES="cores")
+                try:
+                    out = subprocess.run([ref, "bench", "threads=%d" % thr, "nObs=1000000", "nSteps=6000", "warmup=100"],
+                                         cwd=td, env=env, capture_output=True, text=True, timeout=300).stdout
+                    best = json.loads([l for l in out.splitlines() if l.startswith("{\"kind\"")][-1])
+                    long_run = True
+                except Exception:  # noqa: BLE001
+                    long_run = False
         if best is not None:
             return {"value": best["transitions_per_s"], "unit": "transitions/s", "cores": int(best["threads"]),
                     "kind": "reference",
                     "sample": "compiled reference (oracle/_ref, -O3 -ffast-math, OpenMP) on a 1M-transition synthetic replay of "
-                              "the same shape and distributions, 400 gradient steps after 20 warm-up; best of threads=%s on %d host CPUs"
-                              % ([t for t, _ in tried], ncpu),
+                              "the same shape and distributions: 400-step probes at threads=%s on %d host CPUs, then %s at the best count"
+                              % ([t for t, _ in tried], ncpu, "6000 gradient steps after 100 warm-up" if long_run else "(long run failed) the probe"),
                     "tried": tried}
     # fallback: single-threaded CPU oracle (port)
     from oracle_api import oracle_learner, fill_synth, synth_cfg
