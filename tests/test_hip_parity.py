@@ -584,6 +584,31 @@ def test_sampler_collisions_and_redraw_match_oracle(hip_api):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw,sc_kw,n_eps", [
+    # every episode is the shortest possible one (two states = one transition, all truncated: every sample has a next row)
+    (dict(dimS=3, dimA=1, bounded=[0], hidden=(16, 16), batchSize=8, maxTotObsNum=100, randSeed=3),
+     dict(seed=61, dimS=3, dimA=1, lenMin=2, lenMax=2, pTerm=0.0), 40),
+    # the replay holds exactly one minibatch: the sampler has to return every transition, each step
+    (dict(dimS=4, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=24, maxTotObsNum=100, randSeed=4),
+     dict(seed=62, dimS=4, dimA=2, lenMin=4, lenMax=4, pTerm=1.0), 8),
+    # batch of one (settings allow it; HyperParameters.cpp:186 leaves batchSize 1 unsplit), ragged episode lengths
+    (dict(dimS=4, dimA=2, bounded=[1, 1], hidden=(16, 16), batchSize=1, maxTotObsNum=500, randSeed=5),
+     dict(seed=63, dimS=4, dimA=2, lenMin=2, lenMax=17, pTerm=0.5), 12),
+])
+def test_edge_shapes_match_oracle(hip_api, cfg_kw, sc_kw, n_eps):
+    G, O = _pair(hip_api, cfg_kw, synth_cfg(**sc_kw), n_eps)
+    for k in range(6):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+        assert G.scalars().beta == pytest.approx(O.scalars().beta, rel=1e-12)
+    G.step(20); O.step(20)                                   # replayed graphs
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 10 * TOL32
+    if cfg_kw["batchSize"] == 24:
+        assert np.array_equal(G.readback(capi.TAP_FLAT), np.arange(24))
+
+
+@pytest.mark.gpu
 def test_error_paths_fail_loudly(hip_api):
     """Call-sequence and size errors come back as status codes, never as silent work
     (reference: die() in Learner_approximator.cpp:38-41 for a too small replay)."""
