@@ -168,6 +168,10 @@ def _compare_step(G, O):
     (dict(dimS=6, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=32, maxTotObsNum=20000, randSeed=47, gamma=0.99,
           adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1),
      dict(seed=41, dimS=6, dimA=1, lenMin=3, lenMax=60, pTerm=0.4), 80, 12),
+    # LSTM layers of an odd width, short BPTT window, V-RACER head
+    (dict(dimS=6, dimA=2, bounded=[1, 0], hidden=(24, 24), nnFunc="Tanh", batchSize=20, maxTotObsNum=20000, randSeed=57,
+          nn_type=capi.NN_LSTM, nnBPTTseq=5),
+     dict(seed=49, dimS=6, dimA=2, lenMin=3, lenMax=30, pTerm=0.4), 60, 10),
     # V-RACER on MGU layers (Layer_GRU.h; what a partially observable MDP gets with the default nnType), unequal widths
     (dict(dimS=7, dimA=2, bounded=[0, 1], hidden=(48, 32), nnFunc="Tanh", batchSize=24, maxTotObsNum=20000, randSeed=53,
           nn_type=capi.NN_MGU, nnBPTTseq=10),
