@@ -414,12 +414,14 @@ def test_packed_episode_wire_format_matches_reference(hip_api, name):
 
 
 @pytest.mark.gpu
-def test_memory_checkpoint_files_of_the_reference(hip_api, tmp_path):
+@pytest.mark.parametrize("name", ["small_mixed.bin", "racer_discrete.bin"])
+def test_memory_checkpoint_files_of_the_reference(hip_api, tmp_path, name):
     """hl_restart_memory reads the replay-memory checkpoint the COMPILED REFERENCE wrote after 12 gradient
     steps (MemoryBuffer::save, MemoryBuffer.cpp:274-324): scaling, counters, ReF-ER state and every per-step
     field of every episode come back exactly; hl_save_memory of that state reproduces the three files byte
     for byte."""
-    fx = load_fixture("small_mixed.bin")
+    fx = load_fixture(name)
+    dA, polDim = int(fx["cfg"][1]), (int(fx["cfg"][12]) if len(fx["cfg"]) > 12 and fx["cfg"][12] else 2 * int(fx["cfg"][1]))
     base = str(tmp_path / "agent_00")
     names = ("_scaling", "_rank_000_learner_status", "_rank_000_learner_data")
     for suf in names:
@@ -438,7 +440,7 @@ def test_memory_checkpoint_files_of_the_reference(hip_api, tmp_path):
     off = 0
     for i in range(30):                                  # file order = oldest first = position 29 - i
         n = int(np.frombuffer(data[off:off + 8], np.uint64)[0]); off += 8
-        size = (5 + 1 + 2 + 4 + 6) * n + 10
+        size = (5 + 1 + dA + polDim + 6) * n + 10
         rec = data[off:off + 4 * size]; off += 4 * size
         assert L.pack_episode(29 - i).tobytes() == rec, i
     assert off == len(data)
