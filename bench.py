@@ -159,32 +159,62 @@ def main():
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+    # SMARTIES_BENCH_EXCHANGE=host: replicas exchange through the host (gloo + the split-step entry points) instead of RCCL
+    # inside the library -- the slow but dependency-free protocol, also the automatic fall-back if the communicator cannot be set up
+    host_exchange = os.environ.get("SMARTIES_BENCH_EXCHANGE", "") == "host"
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    host_group = None
     if n_ranks > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=n_ranks)
+        dist.init_process_group(backend="gloo" if host_exchange else "nccl", rank=rank, world_size=n_ranks)
 
     from smarties_amd import capi, load_hip
 
     api = load_hip()
-    cfg = capi.make_config(n_ranks=n_ranks, rank=rank, device_id=local_rank, **CFG)
-    L = capi.Learner(api, cfg)
-    L.init_weights()
+    cfg = capi.make_config(n_ranks=n_ranks, rank=rank, device_id=local_rank % ndev, **CFG)
     per = N_EPISODES // n_ranks
-    t_fill = time.time()
-    for e in range(rank * per, (rank + 1) * per):
-        L.append_episode(**synthetic_episode(np, e))
-    t_fill = time.time() - t_fill
-    if n_ranks > 1:
-        idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            import ctypes as C
-            raw = (C.c_uint8 * 128)()
-            assert api.fn("comm_unique_id")(raw) == 0
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
-        dist.broadcast(idbuf, 0)
-        L.comm_init(bytes(idbuf.cpu().tolist()))
+
+    def make_learner():
+        L_ = capi.Learner(api, cfg)
+        L_.init_weights()
+        t_ = time.time()
+        for e in range(rank * per, (rank + 1) * per):
+            L_.append_episode(**synthetic_episode(np, e))
+        return L_, time.time() - t_
+
+    L, t_fill = make_learner()
+    if n_ranks > 1 and not host_exchange:
+        ok = 1
+        try:
+            idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                import ctypes as C
+                raw = (C.c_uint8 * 128)()
+                assert api.fn("comm_unique_id")(raw) == 0
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
+            dist.broadcast(idbuf, 0)
+            L.comm_init(bytes(idbuf.cpu().tolist()))
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print("rank %d: RCCL communicator of the library failed (%s): host exchange instead" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            host_exchange = True
+            host_group = dist.new_group(backend="gloo")
+            L.close()
+            L, t_fill = make_learner()
+    if n_ranks > 1 and host_exchange:
+        from smarties_amd import dist_host
+        dist_host.init_replica_weights(L, dist, group=host_group)
     L.initialize()
+
+    def run(n):
+        if n_ranks > 1 and host_exchange:
+            dist_host.step_host_exchange(L, dist, n, group=host_group)
+        else:
+            L.step(n)
 
     def barrier():
         if n_ranks > 1:
@@ -192,15 +222,15 @@ def main():
         torch.cuda.synchronize()
         L.sync()
 
-    L.step(args.warmup)
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    L.step(args.steps)
+    run(args.steps)
     L.sync()
     barrier()
     dt = time.perf_counter() - t0
     if n_ranks > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -257,7 +287,9 @@ def main():
                                    "(state_dim 17, act_dim 6 bounded), 2x256 SoftSign MLP (72976 padded fp32 params), "
                                    "global batch 256 split over %d replica(s), replay split likewise, "
                                    "device-side mt19937 sampler" % n_ranks,
-                       "global_batch": B_global, "replay_transitions": 1000000, "parallelism": "dp%d" % n_ranks},
+                       "global_batch": B_global, "replay_transitions": 1000000, "parallelism": "dp%d" % n_ranks,
+                       "exchange": "single replica" if n_ranks == 1 else ("host (gloo, split-step entry points)" if host_exchange
+                                                                          else "RCCL inside the library (captured in the replayed graphs)")},
             "roofline": roof,
             "fill_seconds": t_fill,
         }

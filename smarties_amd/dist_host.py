@@ -16,29 +16,30 @@ world_size-2 `gloo` tests on machines without a GPU.
 import numpy as np
 
 
-def init_replica_weights(L, dist, src=0):
+def init_replica_weights(L, dist, src=0, group=None):
     """Replica 0's initial weights everywhere (reference: Network broadcast in
     Learner_approximator::initializeApproximators -> Optimizer MPI_Bcast, Core/Optimizer.cpp:60-70)."""
     import torch
     w, m1, m2 = L.get_params()
     t = torch.from_numpy(w)
-    dist.broadcast(t, src)
+    dist.broadcast(t, src, group=group)
     L.set_params(w, m1, m2)
 
 
-def step_host_exchange(L, dist, n_steps=1, flat=None):
-    """`n_steps` gradient steps of one replica; collectives through `dist` (torch.distributed)."""
+def step_host_exchange(L, dist, n_steps=1, flat=None, group=None):
+    """`n_steps` gradient steps of one replica; collectives through `dist` (torch.distributed; `group`: a process group
+    that takes host tensors, e.g. a gloo group next to an nccl default group)."""
     import torch
     for s in range(n_steps):
         L.step_begin(None if flat is None else flat[s])
         g = L.grad_fetch()
-        dist.all_reduce(torch.from_numpy(g), op=dist.ReduceOp.SUM)
+        dist.all_reduce(torch.from_numpy(g), op=dist.ReduceOp.SUM, group=group)
         L.grad_store(g)
         m = L.moments_fetch()          # None unless this is a 1000th step (same on every replica)
         if m is not None:
-            dist.all_reduce(torch.from_numpy(m), op=dist.ReduceOp.SUM)
+            dist.all_reduce(torch.from_numpy(m), op=dist.ReduceOp.SUM, group=group)
             L.moments_store(m)
         c = np.asarray(L.counters_fetch(), dtype=np.int64)
-        dist.all_reduce(torch.from_numpy(c), op=dist.ReduceOp.SUM)
+        dist.all_reduce(torch.from_numpy(c), op=dist.ReduceOp.SUM, group=group)
         L.counters_store(c)
         L.step_end()
