@@ -614,6 +614,53 @@ def test_edge_shapes_match_oracle(hip_api, cfg_kw, sc_kw, n_eps):
         assert np.array_equal(G.readback(capi.TAP_FLAT), np.arange(24))
 
 
+def _random_config(rng):
+    """A small learner configuration drawn at random: layer type, head, widths, batch, state / action sizes."""
+    nn = [capi.NN_FFNN, capi.NN_FFNN, capi.NN_LSTM, capi.NN_MGU][int(rng.integers(4))]
+    head = [capi.ADV_ZERO, capi.ADV_GAUSSIAN, capi.ADV_DISCRETE][int(rng.integers(3))]
+    n_layers = int(rng.integers(1, 4))
+    if nn == capi.NN_FFNN:
+        hidden = [int(rng.integers(5, 72)) for _ in range(n_layers)]
+    else:                                   # recurrent layers behind a residual must not widen (hl_create refuses that)
+        w0 = 8 * int(rng.integers(1, 8))
+        hidden = [w0] + [8 * int(rng.integers(1, w0 // 8 + 1)) for _ in range(n_layers - 1)]
+        hidden = sorted(hidden, reverse=True)
+    dimS = int(rng.integers(1, 40))
+    kw = dict(dimS=dimS, hidden=tuple(hidden), nnFunc=["SoftSign", "Tanh", "Relu"][int(rng.integers(3))], nn_type=nn,
+              batchSize=int(rng.integers(1, 70)), maxTotObsNum=4000, randSeed=int(rng.integers(1, 1000)), adv_kind=head,
+              nnBPTTseq=int(rng.integers(1, 12)), nnLambda=float(rng.choice([0.0, 1e-5])),
+              clipImpWeight=float(rng.choice([0.7, 2.0, 4.0])), gamma=float(rng.choice([0.9, 0.995])))
+    if head == capi.ADV_DISCRETE:
+        kw.update(dimA=1, bounded=[0], n_options=int(rng.integers(2, 20)))
+    else:
+        dA = int(rng.integers(1, 8 if head == capi.ADV_ZERO else 6))
+        kw.update(dimA=dA, bounded=[int(b) for b in rng.integers(0, 2, dA)])
+    sc = dict(seed=int(rng.integers(1, 1000)), dimS=dimS, dimA=kw["dimA"], lenMin=2, lenMax=int(rng.integers(3, 40)),
+              pTerm=float(rng.choice([0.0, 0.5, 1.0])))
+    return kw, sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(28))
+def test_random_configurations_match_oracle(hip_api, seed):
+    """Randomly drawn configurations (dense / LSTM / MGU layers x the three heads x odd sizes): the library against the
+    oracle over a few single steps and a replayed stretch."""
+    kw, sc = _random_config(np.random.default_rng(1000 + seed))
+    n_eps = 40
+    try:
+        G, O = _pair(hip_api, kw, synth_cfg(**sc), n_eps)
+    except capi.HlError as e:                # too few transitions for the batch: both sides must say so
+        assert e.status == 5, (kw, sc, str(e))
+        return
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(12); O.step(12)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT)), (kw, sc)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 20 * TOL32, (kw, sc)
+    assert abs(G.scalars().beta - O.scalars().beta) <= 1e-9 * O.scalars().beta
+
+
 @pytest.mark.gpu
 def test_error_paths_fail_loudly(hip_api):
     """Call-sequence and size errors come back as status codes, never as silent work
