@@ -662,6 +662,32 @@ def test_random_configurations_match_oracle(hip_api, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_random_fused_kernel_shapes_match_oracle(hip_api, seed):
+    """Shapes served by the fused forward / head / dX kernel, drawn at random: width 16..256, 1..32 state components, 1..7
+    actions with mixed bounds, batches 1..300 (partial panels, many next-state rows with short truncated episodes)."""
+    rng = np.random.default_rng(3000 + seed)
+    H = int(rng.choice([16, 32, 64, 128, 256]))
+    dS, dA = int(rng.integers(1, 33)), int(rng.integers(1, 8))
+    kw = dict(dimS=dS, dimA=dA, bounded=[int(b) for b in rng.integers(0, 2, dA)], hidden=(H, H),
+              nnFunc=["SoftSign", "Tanh", "Relu"][int(rng.integers(3))], batchSize=int(rng.integers(1, 300)),
+              maxTotObsNum=20000, randSeed=int(rng.integers(1, 1000)), clipImpWeight=float(rng.choice([0.7, 2.0, 4.0])))
+    sc = dict(seed=int(rng.integers(1, 1000)), dimS=dS, dimA=dA, lenMin=2, lenMax=int(rng.integers(3, 60)),
+              pTerm=float(rng.choice([0.0, 0.5, 1.0])))
+    try:
+        G, O = _pair(hip_api, kw, synth_cfg(**sc), 120)
+    except capi.HlError as e:
+        assert e.status == 5, (kw, sc, str(e))
+        return
+    for _ in range(2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(9); O.step(9)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT)), (kw, sc)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 20 * TOL32, (kw, sc)
+
+
+@pytest.mark.gpu
 def test_error_paths_fail_loudly(hip_api):
     """Call-sequence and size errors come back as status codes, never as silent work
     (reference: die() in Learner_approximator.cpp:38-41 for a too small replay)."""
