@@ -262,18 +262,27 @@ def test_thousand_step_sweep_matches_oracle(hip_api, head):
         assert np.isclose(getattr(stg, f), getattr(sto, f), rtol=1e-3, atol=1e-5), f
 
 
-def test_eviction_and_append_during_training(hip_api):
+VARIANTS = {
+    "vracer": {},
+    "racer_gaussian_lstm": dict(adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnFunc="Tanh", nnBPTTseq=6),
+    "racer_discrete_mgu": dict(adv_kind=capi.ADV_DISCRETE, n_options=5, dimA=1, bounded=[0], nn_type=capi.NN_MGU, nnFunc="Tanh", nnBPTTseq=4),
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_eviction_and_append_during_training(hip_api, variant):
     """FIFO removal (applyEpisodesRemovalAlgo, 'oldest') and episodes appended between steps."""
     cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 1], hidden=(32, 32), batchSize=16, maxTotObsNum=600, minTotObsNum=300,
                   randSeed=2)
-    sc = synth_cfg(seed=21, dimS=5, dimA=2, lenMin=10, lenMax=40, pTerm=0.4)
+    cfg_kw.update(VARIANTS[variant])
+    sc = synth_cfg(seed=21, dimS=5, dimA=cfg_kw["dimA"], lenMin=10, lenMax=40, pTerm=0.4)
     G, O = _pair(hip_api, cfg_kw, sc, 24)
     e = 24
     for k in range(30):
         G.step(1); O.step(1)
         _compare_step(G, O)
         for L in (G, O):
-            L.append_episode(**synth_episode(sc, e))
+            L.append_episode(**synth_episode(sc, e, cfg_kw.get("n_options", 0)))
         e += 1
         sg, so = G.scalars(), O.scalars()
         assert sg.nStoredSteps == so.nStoredSteps and sg.nStoredEps == so.nStoredEps
@@ -527,11 +536,13 @@ def test_stats_line_after_the_thousand_step_sweep_matches_oracle(hip_api):
 
 
 @pytest.mark.gpu
-def test_memory_and_network_checkpoint_round_trip_continues_identically(hip_api, tmp_path):
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_memory_and_network_checkpoint_round_trip_continues_identically(hip_api, tmp_path, variant):
     """Save network + memory after 40 steps, restart both into a fresh learner (plus the generator
     state, which the reference does not checkpoint), continue both for 30 steps: identical."""
     cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=2000, randSeed=42)
-    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    cfg_kw.update(VARIANTS[variant])
+    sc = synth_cfg(seed=7, dimS=5, dimA=cfg_kw["dimA"], lenMin=5, lenMax=40, pTerm=0.5)
     A = hip_learner(hip_api, capi.make_config(**cfg_kw))
     A.init_weights(); fill_synth(A, sc, 30); A.initialize(); A.step(40)
     base = str(tmp_path / "agent_00")
