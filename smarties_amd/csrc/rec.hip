@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
   __shared__ float sTop[2][REC_MAXIN];                    // error w.r.t. the output of the current block (from above, same step)
   __shared__ float sRec[HL_MAX_HIDDEN][REC_MAXC];          // error w.r.t. this step's LSTM output coming from step k+1
   __shared__ float sNxtSt[HL_MAX_HIDDEN][REC_MAXC], sNxtF[HL_MAX_HIDDEN][REC_MAXC];
-  __shared__ float sD[4 * REC_MAXC], sRes[REC_MAXC];
+  __shared__ float sD[4 * REC_MAXC], sRes[REC_MAXC], sRecNew[REC_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = a.bt.t[b];
   const int T = min(a.nBPTT, t);
@@ -228,19 +228,26 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
       }
       ldsBarrier();
       // Layer::backward (Layers.h:123-188): errors to the block below (not below the first layer) and to the previous step
-      if (j > 0) for (int i = tid; i < nIn; i += 256) {
-        float e = 0.f;
+      // one row of [W_in; W_rec] per group of four lanes (quarter sums joined by two shuffles): rows 0..nIn-1 give the error
+      // of the block below (skipped under the first layer), rows nIn.. the error handed to the previous step
+      {
+        const int part = tid & 3, row0 = j > 0 ? 0 : nIn, nRow = nIn + (k > 0 ? nC : 0);
+        for (int i0 = row0; i0 < nRow; i0 += 64) {
+          const int i = i0 + (tid >> 2);
+          float e = 0.f;
+          if (i < nRow) {
 #pragma unroll 8
-        for (int o = 0; o < NO; ++o) e += wAt(i, o) * sD[o];
-        sTop[cur ^ 1][i] = (L.hasRes && i < L.resW ? sRes[i] : 0.f) + e;
-      }
-      float rec = 0.f;
-      if (k > 0 && tid < nC) {
-#pragma unroll 8
-        for (int o = 0; o < NO; ++o) rec += wAt(nIn + tid, o) * sD[o];
+            for (int u = 0; u < NO / 4; ++u) { const int o = 4 * u + part; e += wAt(i, o) * sD[o]; }
+          }
+          e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64);
+          if (part == 0 && i < nRow) {
+            if (i < nIn) sTop[cur ^ 1][i] = (L.hasRes && i < L.resW ? sRes[i] : 0.f) + e;
+            else sRecNew[i - nIn] = e;
+          }
+        }
       }
       ldsBarrier();
-      if (tid < nC) sRec[j][tid] = rec;
+      if (tid < nC) sRec[j][tid] = k > 0 ? sRecNew[tid] : 0.f;
       cur ^= 1;
     }
     ldsBarrier();
