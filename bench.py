@@ -35,6 +35,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32,
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 N_EPISODES, EP_STATES = 5000, 201
+PROBE_SECONDS = int(os.environ.get("SMARTIES_BENCH_PROBE_SECONDS", "300"))
 CFG = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=256, maxTotObsNum=1000000,
            clipImpWeight=4.0, penalTol=0.1, epsAnneal=0.0, gamma=0.995, lambda_=1.0, learnrate=1e-4,
            explNoise=0.4472135955, outWeightsPrefac=0.1, nnLambda=0.0, randSeed=42)
@@ -165,9 +166,35 @@ def main():
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % ndev)
     host_group = None
+    dog = None
+    if n_ranks > 1 and not host_exchange:
+        # The RCCL exchange (communicator set-up, the collective inside the replayed graph) is the one path this
+        # repository could never run on more than one device before the scaling bench itself.  Set-up and a two-step
+        # probe run under a watchdog: if anything wedges, every rank starts over in the host-exchange protocol
+        # (exercised by the gloo tests) rather than losing the whole measurement.
+        import threading
+
+        def start_over():
+            print("rank %d: RCCL exchange did not come up within %ds: restarting with the host exchange" % (
+                rank, PROBE_SECONDS), file=sys.stderr, flush=True)
+            env = dict(os.environ, SMARTIES_BENCH_EXCHANGE="host", SMARTIES_BENCH_REEXEC="1")
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # (else every rank of the second life is a store client)
+            os.execve(sys.executable, [sys.executable] + sys.argv, env)
+
+        dog = threading.Timer(PROBE_SECONDS, start_over)
+        dog.daemon = True
+        dog.start()
+        if os.environ.get("SMARTIES_BENCH_TEST_HANG"):     # (proves that the second life works, see tools/README.md)
+            time.sleep(10 * PROBE_SECONDS)
     if n_ranks > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo" if host_exchange else "nccl", rank=rank, world_size=n_ranks)
+        if os.environ.get("SMARTIES_BENCH_REEXEC"):
+            # second life after the watchdog below fired: the launcher's store still holds the first life's keys,
+            # so rank 0 opens a store of its own next to it
+            dist.init_process_group(backend="gloo", rank=rank, world_size=n_ranks, init_method="tcp://127.0.0.1:%d" % (
+                int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        else:
+            dist.init_process_group(backend="gloo" if host_exchange else "nccl", rank=rank, world_size=n_ranks)
 
     from smarties_amd import capi, load_hip
 
@@ -221,6 +248,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         L.sync()
+
+    if dog is not None:
+        run(2)
+        barrier()
+        dog.cancel()
 
     run(args.warmup)
     barrier()
