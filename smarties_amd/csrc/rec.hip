@@ -23,10 +23,15 @@ namespace hl {
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float recSigm(float in) {     // Sigm::_eval (Functions.h:158-165), safeExp cut at 8 (Definitions.h:43)
-  if (in > 0.f) return 1.f / (1.f + expf(fminf(8.f, fmaxf(-8.f, -in))));
-  const float ex = expf(fminf(8.f, fmaxf(-8.f, in)));
-  return ex / (1.f + ex);
+  // (one exponential for both branches of the reference: the argument is -|in| cut at -8 either way)
+  const float ex = expf(fmaxf(-8.f, -fabsf(in)));
+  return in > 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
 }
+// End of a kernel prologue: every global load issued so far has landed.  Values fetched once before the step loops (biases,
+// residual parameters, state scales) otherwise look "possibly in flight" at the loop head, and the compiler guards each use
+// inside the loop with s_waitcnt vmcnt(0) -- which also waits for every row store of the previous layer-step to be acknowledged.
+__device__ __forceinline__ void vmDrain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+
 
 // weights of all LSTM layers staged in LDS with a padded row stride (4 nC + 1: the forward pass reads columns, the backward
 // pass rows, both conflict-free); nets that do not fit read them through the L2 (ldsW = 0)
@@ -55,6 +60,12 @@ __device__ __forceinline__ int recLdsOffset(const RecArgs& a, int j) {
   return off;
 }
 
+#ifdef REC_STAMPS
+__device__ unsigned long long recStamps[256];
+#define RSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 256) recStamps[i] = wall_clock64(); } while (0)
+#else
+#define RSTAMP(i) do {} while (0)
+#endif
 template <bool LDSW>
 __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
@@ -62,6 +73,7 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC], sPrevSt[HL_MAX_HIDDEN][REC_MAXC];
   __shared__ float sX[4 * REC_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x;
+  RSTAMP(0);
   // acting (MemoryBuffer::agentToMinibatch, MemoryBuffer.cpp:440-467): the agent's last steps, from a zero recurrent state
   const bool acting = a.actStates != nullptr;
   const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
@@ -74,7 +86,9 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   RecLayer LL[HL_MAX_HIDDEN];
 #pragma unroll
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
+  RSTAMP(1);
   if constexpr (LDSW) recStageWeights(a, sW, tid);
+  RSTAMP(2);
   float bias[HL_MAX_HIDDEN], wr[HL_MAX_HIDDEN], br[HL_MAX_HIDDEN];      // this thread's gate bias / residual parameters per layer
 #pragma unroll
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) {
@@ -94,7 +108,8 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
     sStates[e] = (raw - a.rp.stMean[i]) * a.rp.stScale[i];
   }
   const float sMean = tid < a.dS ? a.rp.stMean[tid] : 0.f, sScale = tid < a.dS ? a.rp.stScale[tid] : 1.f;
-  ldsBarrier();
+  vmDrain(); ldsBarrier();
+  RSTAMP(3);
   for (int k = 0; k < nSteps; ++k) {
     const bool store = !acting && k <= T;
     const long long r = (long long)b * a.K + k;
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
       else { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)sl * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
     }
     ldsBarrier();
+    RSTAMP(4 + k * 5);
     int cur = 0;
 #pragma unroll
     for (int j = 0; j < HL_MAX_HIDDEN; ++j) if (j < a.nL) {
@@ -132,6 +148,7 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
         if (store) L.X[r * NO + tid] = acc;
       }
       ldsBarrier();
+      if (j < 2) RSTAMP(4 + k * 5 + 1 + 2 * j);
       float out = 0.f, st = 0.f;
       if (tid < nC) {
         st = sX[tid] * sX[nC + tid] + (k > 0 ? sPrevSt[j][tid] * sX[2 * nC + tid] : 0.f);
@@ -143,6 +160,7 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
         sBuf[cur ^ 1][tid] = blk;
       }
       ldsBarrier();
+      if (j < 2) RSTAMP(4 + k * 5 + 2 + 2 * j);
       if (tid < nC) { sPrevOut[j][tid] = out; sPrevSt[j][tid] = st; }
       cur ^= 1;
     }
@@ -151,6 +169,181 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
     if (k == T + 1 && tid < nCl) a.Yout[(size_t)nextRow * a.ldY + tid] = sBuf[cur][tid];
     ldsBarrier();
   }
+  RSTAMP(250);
+}
+
+// ---- LSTM forward, weights resident in LDS: the version the step uses whenever they fit --------------------------------
+// Measured on the kernel above (device time stamps, 2 x 32 cells): a layer-step cost 1.1-1.3 us for the gate sums -- one
+// thread per gate walking 36 / 64 terms, eight LDS reads in flight at a time, 0.11 us per batch of eight -- 0.4 us for the
+// cell update behind a barrier of its own, and 0.5 us of per-step barriers.  Here
+//   * the weights sit TRANSPOSED in LDS, one row per gate: [W_in column (padded to 4) | W_rec column (padded to 4) | bias,0,0,0]
+//     with a row pitch whose quarter is odd, so that ds_read_b128 of 16 neighbouring gates touch all 64 banks once;
+//   * the operand is ONE vector per layer, [input | previous output | 1,0,0,0], double-buffered over the steps (this step's
+//     output goes into the other copy), which is also exactly the row stored for the weight-gradient contraction;
+//   * P = 8 / 4 / 2 / 1 lanes share a gate (<= 8 / 16 / 32 / 64 cells), each lane reads four 16-byte chunks per round with all
+//     eight reads in flight, partial sums joined by shuffles;
+//   * the four gates of a cell sit in neighbouring lanes, so the cell update gathers them by shuffles instead of LDS + barrier:
+//     ONE barrier per layer-step, none per step (the next step's state is written into the idle copy during the step).
+// Sums are formed in a different order than in the oracle (four partial sums per lane, bias last): 1e-7-level differences.
+struct LstmGeo { int inPad, recPad, nT, ld; };
+__host__ __device__ __forceinline__ LstmGeo lstmGeo(int nIn, int nC) {
+  LstmGeo g; g.inPad = (nIn + 3) & ~3; g.recPad = (nC + 3) & ~3; g.nT = g.inPad + g.recPad + 4;
+  g.ld = ((g.nT >> 2) & 1) ? g.nT : g.nT + 4;
+  return g;
+}
+#define LSTM_VEC (REC_MAXIN + REC_MAXC + 8)
+// NL / NC: number of layers / cells of every layer known at compile time (0: read from the arguments) -- with the general
+// eight-layer body the loop invariants alone are 450 spilled scalars and each layer-step some 600 instructions
+template <int NL, int NC>
+__global__ __launch_bounds__(256) void lstm_forward_lds_kernel(RecArgs a) {
+  constexpr int MAXL = NL ? NL : HL_MAX_HIDDEN;
+  const int nL = NL ? NL : a.nL;
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  __shared__ __attribute__((aligned(16))) float sA[HL_MAX_HIDDEN][2][LSTM_VEC];
+  __shared__ float sStates[REC_STATES];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  RSTAMP(0);
+  const bool acting = a.actStates != nullptr;
+  const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
+  const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
+  const int nextRow = acting ? -1 : a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  RecLayer LL[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) LL[j] = a.L[j];
+  RSTAMP(1);
+  // weights, transposed (coalesced 16-byte global reads along the gates of one input row, scattered LDS writes)
+  {
+    int off = 0;
+    for (int j = 0; j < nL; ++j) {
+      const RecLayer& L = a.L[j];
+      const int nIn = L.nIn, nC = NC ? NC : L.nC, NO = 4 * nC, rows = nIn + nC, q4 = nC;          // q4: float4 per row (NO / 4)
+      const LstmGeo g = lstmGeo(nIn, nC);
+      const float4* src = reinterpret_cast<const float4*>(W + L.indW);                  // (indW is a multiple of 4: checked by the launcher)
+      const int total = rows * q4;
+      for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; v[u] = src[e < total ? e : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + 256 * u;
+          if (e < total) {
+            const int i = e / q4, o = 4 * (e - i * q4), ti = i < nIn ? i : g.inPad + (i - nIn);
+            float* d = sW + off + o * g.ld + ti;
+            d[0] = v[u].x; d[g.ld] = v[u].y; d[2 * g.ld] = v[u].z; d[3 * g.ld] = v[u].w;
+          }
+        }
+      }
+      for (int o = tid; o < NO; o += 256) {
+        float* d = sW + off + o * g.ld;
+        for (int i = nIn; i < g.inPad; ++i) d[i] = 0.f;
+        for (int i = g.inPad + nC; i < g.inPad + g.recPad; ++i) d[i] = 0.f;
+        d[g.nT - 4] = W[L.indB + o]; d[g.nT - 3] = 0.f; d[g.nT - 2] = 0.f; d[g.nT - 1] = 0.f;
+      }
+      for (int i = tid; i < 2 * LSTM_VEC; i += 256) {                                  // operand vectors: zero, then the constant 1
+        const int c = i / LSTM_VEC, e = i - c * LSTM_VEC;
+        sA[j][c][e] = e == g.nT - 4 ? 1.f : 0.f;
+      }
+      off += NO * g.ld;
+    }
+  }
+  RSTAMP(2);
+  // this thread's role per layer: cell, gate, part; the parameters of its cell
+  float wr[MAXL], br[MAXL], prevSt[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) {
+    wr[j] = 0.f; br[j] = 0.f; prevSt[j] = 0.f;
+    if (j < nL) {
+      const RecLayer& L = a.L[j];
+      const int nCj = NC ? NC : L.nC;
+      const int P = nCj <= 8 ? 8 : (nCj <= 16 ? 4 : (nCj <= 32 ? 2 : 1)), c = tid / (4 * P);
+      if (L.hasRes && c < L.resW && c < nCj) { wr[j] = W[L.indWr + c]; br[j] = W[L.indBr + c]; }
+    }
+  }
+  const bool preload = nSteps * a.dS <= REC_STATES;
+  if (preload) for (int e = tid; e < nSteps * a.dS; e += 256) {
+    const int kk = e / a.dS, i = e - kk * a.dS;
+    const float raw = acting ? a.actStates[e] : a.rp.S[(size_t)(slot - T + kk) * a.dS + i];
+    sStates[e] = (raw - a.rp.stMean[i]) * a.rp.stScale[i];
+  }
+  const float sMean = tid < a.dS ? a.rp.stMean[tid] : 0.f, sScale = tid < a.dS ? a.rp.stScale[tid] : 1.f;
+  auto stateOf = [&](int k) -> float {     // standardised state component `tid` of step k (Episode::standardizedState, Episode.h:172-183)
+    if (preload) return sStates[k * a.dS + tid];
+    const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)(slot - T + k) * a.dS + tid];
+    return (raw - sMean) * sScale;
+  };
+  vmDrain(); ldsBarrier();
+  if (tid < a.dS) sA[0][0][tid] = stateOf(0);
+  ldsBarrier();
+  RSTAMP(3);
+  for (int k = 0; k < nSteps; ++k) {
+    const bool store = !acting && k <= T;
+    const long long r = (long long)b * a.K + k;
+    const int cb = k & 1;
+    if (k + 1 < nSteps && tid < a.dS) sA[0][cb ^ 1][tid] = stateOf(k + 1);             // (that copy was last read a step ago)
+    RSTAMP(4 + k * 5);
+    int off = 0;
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) if (j < nL) {
+      const RecLayer& L = LL[j];
+      const int nIn = (NC && j > 0) ? NC : L.nIn, nC = NC ? NC : L.nC, NO = 4 * nC;
+      const LstmGeo g = lstmGeo(nIn, nC);
+      const int P = nC <= 8 ? 8 : (nC <= 16 ? 4 : (nC <= 32 ? 2 : 1)), G = 4 * P;
+      const int c = tid / G, gate = (tid & (G - 1)) / P, part = tid & (P - 1), o = gate * nC + c;
+      const float* vec = sA[j][cb];
+      if (store) {
+        if (tid < nIn + nC) L.A[r * L.ldA + tid] = vec[tid < nIn ? tid : g.inPad + (tid - nIn)];   // (nIn + nC <= 256 + 64: second round below)
+        if (tid + 256 < nIn + nC) L.A[r * L.ldA + tid + 256] = vec[tid + 256 < nIn ? tid + 256 : g.inPad + (tid + 256 - nIn)];
+      }
+      float acc = 0.f;
+      if (c < nC) {
+        const float4* row4 = reinterpret_cast<const float4*>(sW + off + o * g.ld);
+        const float4* vec4 = reinterpret_cast<const float4*>(vec);
+        const int nCh = g.nT >> 2;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        for (int c0 = part; c0 < nCh; c0 += 4 * P) {
+          float4 w[4], x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ch = c0 + u * P, cc = ch < nCh ? ch : part;
+            w[u] = row4[cc]; x[u] = vec4[cc];
+            if (ch >= nCh) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { p0 += w[u].x * x[u].x; p1 += w[u].y * x[u].y; p2 += w[u].z * x[u].z; p3 += w[u].w * x[u].w; }
+        }
+        acc = (p0 + p1) + (p2 + p3);
+      }
+      if (P > 1) acc += __shfl_xor(acc, 1, 64);
+      if (P > 2) acc += __shfl_xor(acc, 2, 64);
+      if (P > 4) acc += __shfl_xor(acc, 4, 64);
+      if (gate > 0) acc = recSigm(acc);                    // the gates overwrite their inputs
+      if (store && part == 0 && c < nC) L.X[r * NO + o] = acc;
+      const int base = (tid & 63) & ~(G - 1);
+      const float x0 = __shfl(acc, base, 64), x1 = __shfl(acc, base + P, 64), x2 = __shfl(acc, base + 2 * P, 64), x3 = __shfl(acc, base + 3 * P, 64);
+      if ((tid & (G - 1)) == 0 && c < nC) {
+        const float st = x0 * x1 + prevSt[j] * x2;          // (prevSt is 0 at the first step of the window)
+        const float co = actEval(HL_FUNC_TANH, st);
+        const float out = x3 * co;
+        prevSt[j] = st;
+        if (store) { L.Y[r * NO + c] = out; L.Y[r * NO + nC + c] = st; L.Y[r * NO + 2 * nC + c] = co; }
+        float blk = out;                                   // ParametricResidualLayer::forward (Layers.h:347-361)
+        if (L.hasRes && c < L.resW) blk += vec[c] * wr[j] + br[j];
+        sA[j][cb ^ 1][g.inPad + c] = out;                  // recurrent input of the next step
+        if (j + 1 < nL) sA[j + 1][cb][c] = blk;
+        else {
+          if (k == T) a.Yout[(size_t)b * a.ldY + c] = blk;
+          if (k == T + 1) a.Yout[(size_t)nextRow * a.ldY + c] = blk;
+        }
+      }
+      ldsBarrier();
+      if (j < 2) RSTAMP(4 + k * 5 + 2 + 2 * j);
+      off += NO * g.ld;
+    }
+  }
+  RSTAMP(250);
 }
 
 template <bool LDSW>
@@ -173,7 +366,7 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
   float wr[HL_MAX_HIDDEN];
 #pragma unroll
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) { wr[j] = 0.f; if (j < a.nL && a.L[j].hasRes && tid < a.L[j].resW) wr[j] = W[a.L[j].indWr + tid]; }
-  ldsBarrier();
+  vmDrain(); ldsBarrier();
   // rows of the steps this sample does not have: zero deltas (their stale inputs then add nothing to the gradients)
   for (int k = T + 1; k < a.K; ++k) {
     const long long r = (long long)b * a.K + k;
@@ -293,7 +486,7 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
     sStates[e] = (raw - a.rp.stMean[i]) * a.rp.stScale[i];
   }
   const float sMean = tid < a.dS ? a.rp.stMean[tid] : 0.f, sScale = tid < a.dS ? a.rp.stScale[tid] : 1.f;
-  ldsBarrier();
+  vmDrain(); ldsBarrier();
   for (int k = 0; k < nSteps; ++k) {
     const bool store = !acting && k <= T;
     const long long r = (long long)b * a.K + k;
@@ -380,7 +573,7 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
   float wr[HL_MAX_HIDDEN];
 #pragma unroll
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) { wr[j] = 0.f; if (j < a.nL && a.L[j].hasRes && tid < a.L[j].resW) wr[j] = W[a.L[j].indWr + tid]; }
-  ldsBarrier();
+  vmDrain(); ldsBarrier();
   for (int k = T + 1; k < a.K; ++k) {
     const long long r = (long long)b * a.K + k;
     for (int j = 0; j < a.nL; ++j) {
@@ -472,7 +665,17 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
   if (a.gates == 2) return fit ? recLaunch(mgu_forward_kernel<true>, a, lds, &attr[0], s) : recLaunch(mgu_forward_kernel<false>, a, 0, &attr[1], s);
-  return fit ? recLaunch(rec_forward_kernel<true>, a, lds, &attr[2], s) : recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
+  size_t fl = 0; bool al = true;
+  for (int j = 0; j < a.nL; ++j) { fl += (size_t)4 * a.L[j].nC * lstmGeo(a.L[j].nIn, a.L[j].nC).ld; al = al && a.L[j].indW % 4 == 0 && a.L[j].nIn <= REC_MAXIN; }
+  if (al && fl * sizeof(float) <= 120 * 1024) {
+    // (hidden layers above the first take the block below as input; the specialised bodies rely on nIn == cells there)
+    bool same = true;
+    for (int j = 0; j < a.nL; ++j) same = same && a.L[j].nC == a.L[0].nC && (j == 0 || a.L[j].nIn == a.L[0].nC);
+    static size_t attrS[4] = {0, 0, 0, 0};
+    if (same && a.nL == 2 && a.L[0].nC == 32) return recLaunch(lstm_forward_lds_kernel<2, 32>, a, fl * sizeof(float), &attrS[0], s);
+    return recLaunch(lstm_forward_lds_kernel<0, 0>, a, fl * sizeof(float), &attr[2], s);
+  }
+  return recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
@@ -481,3 +684,9 @@ hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
 }
 
 }  // namespace hl
+
+#ifdef REC_STAMPS
+extern "C" int hl_debug_rec_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hl::recStamps), sizeof(unsigned long long) * 256);
+}
+#endif
