@@ -449,6 +449,155 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
 
 // ---- MGU layers (Network/Layers/Layer_GRU.h): forget = sigm(Wff in + Wfr prevOut + bf), state = tanh(Wsf in + Wsr (forget * prevOut)
 // + bs), output = forget * state + (1 - forget) * prevOut.  Same structure as the LSTM kernels: one workgroup per sample. ----
+// ---- LSTM back-propagation through the window, weights AND the window's stored activations resident in LDS ----------------
+// Same findings as for the forward kernel; in addition the per-step reads of the stored gates sat behind the acknowledgement
+// of the previous step's delta stores (one in-order memory counter).  Here the gates and states of the whole window are
+// fetched once into LDS, so the step loop only stores; [W_in; W_rec] rows have a pitch of 16 (mod 64) floats so that the
+// 16-byte reads of four rows x four lanes touch every bank once; two barriers per layer-step instead of three.
+__host__ __device__ __forceinline__ int lstmBwdPitch(int NO) { return NO + ((16 - NO % 64) + 64) % 64; }
+template <int NL>
+__global__ __launch_bounds__(256) void lstm_backward_lds_kernel(RecArgs a) {
+  constexpr int MAXL = NL ? NL : HL_MAX_HIDDEN;
+  const int nL = NL ? NL : a.nL;
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  __shared__ float sTop[2][REC_MAXIN];                    // error w.r.t. the output of the current block (from above, same step)
+  __shared__ float sRec[MAXL][REC_MAXC];                   // error w.r.t. this step's LSTM output coming from step k+1
+  __shared__ float sNxtSt[MAXL][REC_MAXC], sNxtF[MAXL][REC_MAXC];
+  __shared__ __attribute__((aligned(16))) float sD[4 * REC_MAXC];
+  __shared__ float sRes[REC_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = a.bt.t[b];
+  const int T = min(a.nBPTT, t);
+  const float* W = a.W;
+  RecLayer LL[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) LL[j] = a.L[j];
+  // weights: rows of [W_in; W_rec] as in global memory, padded pitch
+  int wOffs[MAXL], aOffs[MAXL];
+  int off = 0, actPitch = 0;
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) {
+    wOffs[j] = off; aOffs[j] = actPitch;
+    if (j < nL) {
+      const RecLayer& L = LL[j];
+      const int nC = L.nC, NO = 4 * nC, rows = L.nIn + nC, ldb = lstmBwdPitch(NO), total = rows * nC;
+      const float4* src = reinterpret_cast<const float4*>(W + L.indW);
+      for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; v[u] = src[e < total ? e : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + 256 * u;
+          if (e < total) { const int i = e / nC, q = e - i * nC; *reinterpret_cast<float4*>(sW + off + i * ldb + 4 * q) = v[u]; }
+        }
+      }
+      off += rows * ldb; actPitch += 6 * nC;
+    }
+  }
+  // stored activations of the window, per (step, layer): [cell input | input, forget, output gate | state | tanh(state)]
+  float* sAct = sW + off;
+  {
+    const int total = (T + 1) * actPitch;
+    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u, ee = e < total ? e : 0, k = ee / actPitch, q = ee - k * actPitch;
+        const long long r = (long long)b * a.K + k;
+        const float* p = nullptr;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) if (j < nL && q >= aOffs[j] && q < aOffs[j] + 6 * LL[j].nC) {
+          const int x = q - aOffs[j], nC = LL[j].nC;
+          p = x < 4 * nC ? LL[j].X + r * 4 * nC + x : LL[j].Y + r * 4 * nC + nC + (x - 4 * nC);
+        }
+        v[u] = *p;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < total) sAct[e] = v[u]; }
+    }
+  }
+  float wr[MAXL];
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) { wr[j] = 0.f; if (j < nL && LL[j].hasRes && tid < LL[j].resW) wr[j] = W[LL[j].indWr + tid]; }
+  const int nCl = LL[nL - 1].nC;
+  const float dres = tid < nCl ? a.Dres[(size_t)b * a.ldD + tid] : 0.f;
+  vmDrain(); ldsBarrier();
+  // rows of the steps this sample does not have: zero deltas (their stale inputs then add nothing to the gradients)
+  for (int k = T + 1; k < a.K; ++k) {
+    const long long r = (long long)b * a.K + k;
+    for (int j = 0; j < nL; ++j) {
+      const RecLayer& L = a.L[j];
+      if (tid < 4 * L.nC) L.D[r * 4 * L.nC + tid] = 0.f;
+      if (L.hasRes && tid < L.nC) L.Rd[r * L.ldR + tid] = 0.f;
+    }
+  }
+  for (int k = T; k >= 0; --k) {
+    const long long r = (long long)b * a.K + k;
+    int cur = 0;
+    if (tid < nCl) sTop[0][tid] = k == T ? dres : 0.f;
+    ldsBarrier();
+#pragma unroll
+    for (int j = MAXL - 1; j >= 0; --j) if (j < nL) {
+      const RecLayer& L = LL[j];
+      const int nIn = L.nIn, nC = L.nC, NO = 4 * nC, ldb = lstmBwdPitch(NO);
+      if (tid < nC) {
+        const float* act = sAct + k * actPitch + aOffs[j];
+        const float eTop = sTop[cur][tid];
+        // ParametricResidualLayer::backward (Layers.h:363-393): the delta passes to the LSTM output, and through w to the block input
+        if (L.hasRes) { L.Rd[r * L.ldR + tid] = eTop; sRes[tid] = tid < L.resW ? eTop * wr[j] : 0.f; }
+        const float D = eTop + (k < T ? sRec[j][tid] : 0.f);
+        // LSTMLayer::backward (Layer_LSTM.h:127-165)
+        const float cellInpt = act[tid], IG = act[nC + tid], FG = act[2 * nC + tid], OG = act[3 * nC + tid], co = act[5 * nC + tid];
+        const float prevSt = k > 0 ? (act - actPitch)[4 * nC + tid] : 0.f;
+        const float diff = (1.f - co * co) * D;
+        const float sd = diff * OG + (k < T ? sNxtSt[j][tid] * sNxtF[j][tid] : 0.f);
+        const float d0 = IG * sd;
+        const float d1 = IG * (1.f - IG) * cellInpt * sd;
+        const float d2 = k > 0 ? FG * (1.f - FG) * prevSt * sd : 0.f;
+        const float d3 = OG * (1.f - OG) * D * co;
+        sD[tid] = d0; sD[nC + tid] = d1; sD[2 * nC + tid] = d2; sD[3 * nC + tid] = d3;
+        L.D[r * NO + tid] = d0; L.D[r * NO + nC + tid] = d1; L.D[r * NO + 2 * nC + tid] = d2; L.D[r * NO + 3 * nC + tid] = d3;
+        sNxtSt[j][tid] = sd; sNxtF[j][tid] = FG;
+      }
+      ldsBarrier();
+      // Layer::backward (Layers.h:123-188): one row of [W_in; W_rec] per group of four lanes, 16-byte chunks of the row and of
+      // the deltas, eight of each in flight per lane; rows 0..nIn-1 give the error of the block below (skipped under the first
+      // layer), rows nIn.. the error handed to the previous step
+      {
+        const int part = tid & 3, row0 = j > 0 ? 0 : nIn, nRow = nIn + (k > 0 ? nC : 0), nCh = nC;
+        const float4* d4 = reinterpret_cast<const float4*>(sD);
+        for (int i0 = row0; i0 < nRow; i0 += 64) {
+          const int i = i0 + (tid >> 2);
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+          if (i < nRow) {
+            const float4* row4 = reinterpret_cast<const float4*>(sW + wOffs[j] + i * ldb);
+            for (int u0 = 0; u0 < nCh; u0 += 32) {
+              float4 w[8], d[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int ch = u0 + part + 4 * u, cc = ch < nCh ? ch : part;
+                w[u] = row4[cc]; d[u] = d4[cc];
+                if (ch >= nCh) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) { p0 += w[u].x * d[u].x; p1 += w[u].y * d[u].y; p2 += w[u].z * d[u].z; p3 += w[u].w * d[u].w; }
+            }
+          }
+          float e = (p0 + p1) + (p2 + p3);
+          e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64);
+          if (part == 0 && i < nRow) {
+            if (i < nIn) sTop[cur ^ 1][i] = (L.hasRes && i < L.resW ? sRes[i] : 0.f) + e;
+            else sRec[j][i - nIn] = e;                       // (read above, before the barrier; not used at k == 0)
+          }
+        }
+      }
+      ldsBarrier();
+      cur ^= 1;
+    }
+  }
+}
+
 template <bool LDSW>
 __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
@@ -672,7 +821,10 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
     bool same = true;
     for (int j = 0; j < a.nL; ++j) same = same && a.L[j].nC == a.L[0].nC && (j == 0 || a.L[j].nIn == a.L[0].nC);
     static size_t attrS[4] = {0, 0, 0, 0};
-    if (same && a.nL == 2 && a.L[0].nC == 32) return recLaunch(lstm_forward_lds_kernel<2, 32>, a, fl * sizeof(float), &attrS[0], s);
+    if (same && a.nL == 2 && a.L[0].nC == 32) return recLaunch(lstm_forward_lds_kernel<2, 32>, a, fl * sizeof(float), &attrS[0], s);   // RACER_RNN.json
+    if (a.nL == 1) return recLaunch(lstm_forward_lds_kernel<1, 0>, a, fl * sizeof(float), &attrS[1], s);
+    if (a.nL == 2) return recLaunch(lstm_forward_lds_kernel<2, 0>, a, fl * sizeof(float), &attrS[2], s);
+    if (a.nL == 3) return recLaunch(lstm_forward_lds_kernel<3, 0>, a, fl * sizeof(float), &attrS[3], s);
     return recLaunch(lstm_forward_lds_kernel<0, 0>, a, fl * sizeof(float), &attr[2], s);
   }
   return recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
@@ -680,6 +832,18 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
   if (a.gates == 2) return fit ? recLaunch(mgu_backward_kernel<true>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false>, a, 0, &attr[1], s);
+  size_t fl = 0; bool al = true;
+  for (int j = 0; j < a.nL; ++j) {
+    fl += (size_t)(a.L[j].nIn + a.L[j].nC) * lstmBwdPitch(4 * a.L[j].nC) + (size_t)a.K * 6 * a.L[j].nC;
+    al = al && a.L[j].indW % 4 == 0 && a.L[j].nIn <= REC_MAXIN;
+  }
+  if (al && fl * sizeof(float) <= 120 * 1024) {
+    static size_t attrS[4] = {0, 0, 0, 0};
+    if (a.nL == 1) return recLaunch(lstm_backward_lds_kernel<1>, a, fl * sizeof(float), &attrS[1], s);
+    if (a.nL == 2) return recLaunch(lstm_backward_lds_kernel<2>, a, fl * sizeof(float), &attrS[2], s);
+    if (a.nL == 3) return recLaunch(lstm_backward_lds_kernel<3>, a, fl * sizeof(float), &attrS[3], s);
+    return recLaunch(lstm_backward_lds_kernel<0>, a, fl * sizeof(float), &attrS[0], s);
+  }
   return fit ? recLaunch(rec_backward_kernel<true>, a, lds, &attr[2], s) : recLaunch(rec_backward_kernel<false>, a, 0, &attr[3], s);
 }
 
