@@ -598,11 +598,13 @@ __global__ __launch_bounds__(256) void lstm_backward_lds_kernel(RecArgs a) {
   }
 }
 
-template <bool LDSW>
+template <bool LDSW, int NL>
 __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
+  constexpr int MAXL = NL ? NL : HL_MAX_HIDDEN;
+  const int nL = NL ? NL : a.nL;
   extern __shared__ __attribute__((aligned(16))) float sW[];
   __shared__ float sBuf[2][REC_MAXIN];
-  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC];
+  __shared__ float sPrevOut[MAXL][REC_MAXC];
   __shared__ float sF[REC_MAXC], sS[REC_MAXC];
   __shared__ float sStates[REC_STATES];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -614,15 +616,15 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
   const float* W = a.W;
   // layer descriptors copied out of the kernel-argument segment once (inside the step loops every field access was a scalar
   // load of its own)
-  RecLayer LL[HL_MAX_HIDDEN];
+  RecLayer LL[MAXL];
 #pragma unroll
-  for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
+  for (int j = 0; j < MAXL; ++j) LL[j] = a.L[j];
   if constexpr (LDSW) recStageWeights(a, sW, tid);
-  float bias[HL_MAX_HIDDEN], wr[HL_MAX_HIDDEN], br[HL_MAX_HIDDEN];
+  float bias[MAXL], wr[MAXL], br[MAXL];
 #pragma unroll
-  for (int j = 0; j < HL_MAX_HIDDEN; ++j) {
+  for (int j = 0; j < MAXL; ++j) {
     bias[j] = 0.f; wr[j] = 0.f; br[j] = 0.f;
-    if (j < a.nL) {
+    if (j < nL) {
       const RecLayer& L = a.L[j];
       if (tid < 2 * L.nC) bias[j] = W[L.indB + tid];
       if (L.hasRes && tid < L.resW) { wr[j] = W[L.indWr + tid]; br[j] = W[L.indBr + tid]; }
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
     ldsBarrier();
     int cur = 0;
 #pragma unroll
-    for (int j = 0; j < HL_MAX_HIDDEN; ++j) if (j < a.nL) {
+    for (int j = 0; j < MAXL; ++j) if (j < nL) {
       const RecLayer& L = LL[j];
       const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
       const float* in = sBuf[cur];
@@ -696,18 +698,20 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
       if (tid < nC) sPrevOut[j][tid] = out;
       cur ^= 1;
     }
-    const int nCl = a.L[a.nL - 1].nC;
+    const int nCl = a.L[nL - 1].nC;
     if (k == T && tid < nCl) a.Yout[(size_t)b * a.ldY + tid] = sBuf[cur][tid];
     if (k == T + 1 && tid < nCl) a.Yout[(size_t)nextRow * a.ldY + tid] = sBuf[cur][tid];
     ldsBarrier();
   }
 }
 
-template <bool LDSW>
+template <bool LDSW, int NL>
 __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
+  constexpr int MAXL = NL ? NL : HL_MAX_HIDDEN;
+  const int nL = NL ? NL : a.nL;
   extern __shared__ __attribute__((aligned(16))) float sW[];
   __shared__ float sTop[2][REC_MAXIN];
-  __shared__ float sRec[HL_MAX_HIDDEN][REC_MAXC];          // dLdprevOut handed from step k+1 to step k
+  __shared__ float sRec[MAXL][REC_MAXC];          // dLdprevOut handed from step k+1 to step k
   __shared__ float sDF[REC_MAXC], sDS[REC_MAXC], sFP[REC_MAXC], sRes[REC_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = a.bt.t[b];
@@ -715,17 +719,17 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
   const float* W = a.W;
   // layer descriptors copied out of the kernel-argument segment once (inside the step loops every field access was a scalar
   // load of its own)
-  RecLayer LL[HL_MAX_HIDDEN];
+  RecLayer LL[MAXL];
 #pragma unroll
-  for (int j = 0; j < HL_MAX_HIDDEN; ++j) LL[j] = a.L[j];
+  for (int j = 0; j < MAXL; ++j) LL[j] = a.L[j];
   if constexpr (LDSW) recStageWeights(a, sW, tid);
-  float wr[HL_MAX_HIDDEN];
+  float wr[MAXL];
 #pragma unroll
-  for (int j = 0; j < HL_MAX_HIDDEN; ++j) { wr[j] = 0.f; if (j < a.nL && a.L[j].hasRes && tid < a.L[j].resW) wr[j] = W[a.L[j].indWr + tid]; }
+  for (int j = 0; j < MAXL; ++j) { wr[j] = 0.f; if (j < nL && a.L[j].hasRes && tid < a.L[j].resW) wr[j] = W[a.L[j].indWr + tid]; }
   vmDrain(); ldsBarrier();
   for (int k = T + 1; k < a.K; ++k) {
     const long long r = (long long)b * a.K + k;
-    for (int j = 0; j < a.nL; ++j) {
+    for (int j = 0; j < nL; ++j) {
       const RecLayer& L = a.L[j];
       if (tid < 2 * L.nC) L.D[r * 2 * L.nC + tid] = 0.f;
       if (L.hasRes && tid < L.nC) L.Rd[r * L.ldR + tid] = 0.f;
@@ -734,13 +738,13 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
   for (int k = T; k >= 0; --k) {
     const long long r = (long long)b * a.K + k;
     int cur = 0;
-    const int nCl = a.L[a.nL - 1].nC;
+    const int nCl = a.L[nL - 1].nC;
     if (tid < nCl) sTop[0][tid] = k == T ? a.Dres[(size_t)b * a.ldD + tid] : 0.f;
-    float vF[HL_MAX_HIDDEN], vS[HL_MAX_HIDDEN], vP[HL_MAX_HIDDEN];
+    float vF[MAXL], vS[MAXL], vP[MAXL];
 #pragma unroll
-    for (int j = 0; j < HL_MAX_HIDDEN; ++j) {
+    for (int j = 0; j < MAXL; ++j) {
       vF[j] = vS[j] = vP[j] = 0.f;
-      if (j < a.nL && tid < a.L[j].nC) {
+      if (j < nL && tid < a.L[j].nC) {
         const RecLayer& L = a.L[j]; const int nC = L.nC, NO = 2 * nC;
         vF[j] = L.X[r * NO + tid]; vS[j] = L.X[r * NO + nC + tid];
         if (k > 0) vP[j] = L.Y[(r - 1) * NO + tid];
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
     }
     ldsBarrier();
 #pragma unroll
-    for (int j = HL_MAX_HIDDEN - 1; j >= 0; --j) if (j < a.nL) {
+    for (int j = MAXL - 1; j >= 0; --j) if (j < nL) {
       const RecLayer& L = LL[j];
       const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
       const int ldw = LDSW ? NO + 1 : NO, wOff = LDSW ? recLdsOffset(a, j) : 0;
@@ -813,7 +817,12 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
-  if (a.gates == 2) return fit ? recLaunch(mgu_forward_kernel<true>, a, lds, &attr[0], s) : recLaunch(mgu_forward_kernel<false>, a, 0, &attr[1], s);
+  if (a.gates == 2) {
+    static size_t attrM[4] = {0, 0, 0, 0};
+    if (fit && a.nL == 1) return recLaunch(mgu_forward_kernel<true, 1>, a, lds, &attrM[1], s);
+    if (fit && a.nL == 2) return recLaunch(mgu_forward_kernel<true, 2>, a, lds, &attrM[2], s);
+    return fit ? recLaunch(mgu_forward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_forward_kernel<false, 0>, a, 0, &attr[1], s);
+  }
   size_t fl = 0; bool al = true;
   for (int j = 0; j < a.nL; ++j) { fl += (size_t)4 * a.L[j].nC * lstmGeo(a.L[j].nIn, a.L[j].nC).ld; al = al && a.L[j].indW % 4 == 0 && a.L[j].nIn <= REC_MAXIN; }
   if (al && fl * sizeof(float) <= 120 * 1024) {
@@ -831,7 +840,12 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
-  if (a.gates == 2) return fit ? recLaunch(mgu_backward_kernel<true>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false>, a, 0, &attr[1], s);
+  if (a.gates == 2) {
+    static size_t attrM[4] = {0, 0, 0, 0};
+    if (fit && a.nL == 1) return recLaunch(mgu_backward_kernel<true, 1>, a, lds, &attrM[1], s);
+    if (fit && a.nL == 2) return recLaunch(mgu_backward_kernel<true, 2>, a, lds, &attrM[2], s);
+    return fit ? recLaunch(mgu_backward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false, 0>, a, 0, &attr[1], s);
+  }
   size_t fl = 0; bool al = true;
   for (int j = 0; j < a.nL; ++j) {
     fl += (size_t)(a.L[j].nIn + a.L[j].nC) * lstmBwdPitch(4 * a.L[j].nC) + (size_t)a.K * 6 * a.L[j].nC;
