@@ -672,6 +672,37 @@ def test_random_configurations_match_oracle(hip_api, seed):
     assert abs(G.scalars().beta - O.scalars().beta) <= 1e-9 * O.scalars().beta
 
 
+REC_SHAPES = [  # (layer type, hidden, dimS, bptt, batch): every instantiation / fall-back of the recurrent kernels
+    ("lstm", (13,), 3, 5, 9),               # one layer, cells not a multiple of 4 (padded chunks, 4 lanes per gate)
+    ("lstm", (5, 5, 5), 1, 3, 17),          # three layers, 8 lanes per gate
+    ("lstm", (24, 16, 8, 8), 7, 6, 12),     # four layers: the general (runtime layer count) bodies
+    ("lstm", (32, 32), 4, 16, 33),          # the RACER_RNN.json shape: cells known at compile time
+    ("lstm", (64, 64), 30, 4, 8),           # one lane per gate
+    ("lstm", (64, 64), 200, 3, 6),          # weights too large for LDS: the one-thread-per-gate kernels
+    ("lstm", (48, 40), 130, 11, 5),         # BPTT window + weights beyond the LDS budget of the BPTT kernel only
+    ("mgu", (24, 16, 8, 8), 7, 6, 12),
+    ("mgu", (13,), 3, 5, 9),
+    ("mgu", (64, 64), 200, 3, 6),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", REC_SHAPES, ids=lambda sh: "%s-%s-dS%d" % (sh[0], "x".join(map(str, sh[1])), sh[2]))
+def test_recurrent_kernel_variants_match_oracle(hip_api, shape):
+    """The recurrent kernels are instantiated per layer count / cell count and fall back to slower bodies when weights or the
+    window's activations do not fit in LDS: one configuration per variant, against the oracle."""
+    kind, hidden, dS, bptt, batch = shape
+    kw = dict(dimS=dS, dimA=2, bounded=[1, 0], hidden=hidden, nnFunc="Tanh", batchSize=batch, maxTotObsNum=8000, randSeed=5,
+              nn_type=capi.NN_LSTM if kind == "lstm" else capi.NN_MGU, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=bptt)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=21, dimS=dS, dimA=2, lenMin=2, lenMax=30, pTerm=0.5), 60)
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(10); O.step(10)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 20 * TOL32
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(16))
 def test_random_fused_kernel_shapes_match_oracle(hip_api, seed):
