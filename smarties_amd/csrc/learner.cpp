@@ -116,6 +116,10 @@ int hipFail(hl_learner* h, hipError_t e, const char* what) {
 template <typename T> hipError_t devAlloc(T** p, size_t n) {
   hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
   if (e == hipSuccess) e = hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T));
+  // hipMemset of device memory returns before the fill has run (null stream), and the library's streams are non-blocking:
+  // without this wait the zeros could land on top of what the first kernels on h->stream had already written
+  // (seen as a 9 % flake of tests/cpp/host_parity: initializeLearner() followed at once by the first step)
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   return e;
 }
 template <typename T> hipError_t devGrow(T** p, size_t oldN, size_t newN, hipStream_t s) {
@@ -490,6 +494,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
       HIPCK(devAlloc(&h->panelCtr, nCtr));
       HIPCK(hipMemset(h->panelCtr, 0, nCtr * sizeof(unsigned)));
+      HIPCK(hipStreamSynchronize(nullptr));
     }
   }
   h->ldDo = (int)roundUp(h->nDense, 16);

@@ -233,10 +233,23 @@ int main() {
       D.trainStep(1); CHECK(ol_step(O3, 1, nullptr) == 0, "discrete ol_step");
       hl_readback(D.handle(), HL_TAP_FLAT, f1.data(), 32 * 8); ol_readback(O3, HL_TAP_FLAT, f2.data(), 32 * 8);
       CHECK(f1 == f2, "discrete step %d: sampled indices differ", k);
+      if (getenv("HOST_PARITY_VERBOSE") && getenv("HOST_PARITY_VERBOSE")[0] == '2') {
+        const int64_t nn = hl_num_params(D.handle());
+        std::vector<float> wa(nn), wb(nn), m1a(nn), m1b(nn), m2a(nn), m2b(nn);
+        hl_get_params(D.handle(), wa.data(), m1a.data(), m2a.data()); ol_get_params(O3, wb.data(), m1b.data(), m2b.data());
+        int64_t worst = 0; double wd = 0;
+        for (int64_t i = 0; i < nn; ++i) { const double d = std::fabs((double)wa[i] - wb[i]); if (d > wd) { wd = d; worst = i; } }
+        std::printf("  step %d: W rel %.3g M1 rel %.3g M2 rel %.3g  worst W idx %lld of %lld (%.8g vs %.8g)\n", k, relinf(wa, wb), relinf(m1a, m1b),
+                    relinf(m2a, m2b), (long long)worst, (long long)nn, wa[worst], wb[worst]);
+      }
     }
     const int64_t n3 = hl_num_params(D.handle());
     std::vector<float> a(n3), b(n3), t1(n3), t2(n3);
     hl_get_params(D.handle(), a.data(), t1.data(), t2.data()); ol_get_params(O3, b.data(), t1.data(), t2.data());
+    if (getenv("HOST_PARITY_VERBOSE")) {
+      double sa = 0, sb = 0; for (int64_t i = 0; i < n3; ++i) { sa += (double)a[i] * (1 + i % 7); sb += (double)b[i] * (1 + i % 7); }
+      std::printf("discrete weights after 20 steps: rel err %.3g  device sum %.12f oracle sum %.12f\n", relinf(a, b), sa, sb);
+    }
     CHECK(relinf(a, b) < 1e-4, "discrete weights after 20 steps: rel err %.3g", relinf(a, b));
     ol_destroy(O3);
   }
