@@ -301,18 +301,20 @@ __global__ __launch_bounds__(256) void lstm_forward_lds_kernel(RecArgs a) {
       if (c < nC) {
         const float4* row4 = reinterpret_cast<const float4*>(sW + off + o * g.ld);
         const float4* vec4 = reinterpret_cast<const float4*>(vec);
-        const int nCh = g.nT >> 2;
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        for (int c0 = part; c0 < nCh; c0 += 4 * P) {
-          float4 w[4], x[4];
+        // the bias chunk [b,0,0,0] x [1,0,0,0] is taken as one scalar (lane part 0), so that 64 terms are exactly eight chunks
+        // per lane at two lanes per gate: ONE round of sixteen 16-byte reads in flight
+        const int nCh = (g.nT >> 2) - 1;
+        float p0 = part == 0 ? (sW + off + o * g.ld)[g.nT - 4] : 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        for (int c0 = part; c0 < nCh; c0 += 8 * P) {
+          float4 w[8], x[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 8; ++u) {
             const int ch = c0 + u * P, cc = ch < nCh ? ch : part;
             w[u] = row4[cc]; x[u] = vec4[cc];
             if (ch >= nCh) w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { p0 += w[u].x * x[u].x; p1 += w[u].y * x[u].y; p2 += w[u].z * x[u].z; p3 += w[u].w * x[u].w; }
+          for (int u = 0; u < 8; ++u) { p0 += w[u].x * x[u].x; p1 += w[u].y * x[u].y; p2 += w[u].z * x[u].z; p3 += w[u].w * x[u].w; }
         }
         acc = (p0 + p1) + (p2 + p3);
       }
