@@ -126,15 +126,15 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   const bool bRows = (flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  for (int kb = 0; kb < P.K; kb += KC) {
-    const int kc = min(KC, P.K - kb);
-    // k handled by each wave: power of two in {8,16,32,64}; staged chunk kcp = 4*kw in {32..256}
-    int kw = 8, sh = 3;                       // sh = log2(kcp / 4) = log2(kw)
-    while (4 * kw < kc) { kw <<= 1; ++sh; }
-    const int nf4 = kw;                       // float4 per 16-row-tile row (= kcp/4)
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 va[4], vb[4];
-    // ---- issue every global load of this chunk (<= 8 x 16 B per thread) before any use ----
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 va[4], vb[4];
+  // k handled by each wave: power of two in {8,16,32,64}; staged chunk kcp = 4*kw in {32..256}
+  auto chunkGeo = [&](int kb, int& kc, int& kw, int& sh) { kc = min(KC, P.K - kb); kw = 8; sh = 3; while (4 * kw < kc) { kw <<= 1; ++sh; } };
+  // every global load of one chunk (<= 8 x 16 B per thread), issued before any use.  With more than one chunk (weight gradients
+  // over batch x BPTT rows) the loads of chunk i+1 are issued right after chunk i is staged, so they fly during its MFMA loop.
+  auto loadChunk = [&](int kb) {
+    int kc, kw, sh; chunkGeo(kb, kc, kw, sh);
+    const int nf4 = kw;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
@@ -160,6 +160,11 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
           vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(kb + k) * P.ldb + c);
       }
     }
+  };
+  loadChunk(0);
+  for (int kb = 0; kb < P.K; kb += KC) {
+    int kc, kw, sh; chunkGeo(kb, kc, kw, sh);
+    const int nf4 = kw;                       // float4 per 16-row-tile row (= kcp/4)
     GSTAMP(30);
     // ---- stage into LDS ----
 #pragma unroll
@@ -190,6 +195,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     }
     __syncthreads();
     GSTAMP(25);
+    if (kb + KC < P.K) loadChunk(kb + KC);
     const int k0 = wave * kw;
     if (!(variant & 2))                 // ablation: no MFMA loop
     for (int s = 0; s < kw; s += 8) {
