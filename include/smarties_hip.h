@@ -55,6 +55,7 @@ extern "C" {
 
 #define HL_MAX_DIMA   64
 #define HL_MAX_HIDDEN 8
+#define HL_MAX_RANKS  256   /* replica counters travel as 16-bit chunks inside the fp32 gradient all-reduce */
 
 /* status codes */
 enum {
@@ -320,7 +321,12 @@ enum {
   HL_PROF_FWD_LAST = 22,   /* last forward GEMM    + sampler phase B */
   HL_PROF_HEAD = 23,       /* V-RACER head         + sampler phase C (search + gather) */
   HL_PROF_DX = 24,         /* first backward dX GEMM + ReF-ER bookkeeping of this step */
-  HL_PROF_DW = 25          /* all dW GEMMs + bias reductions + fused Adam */
+  HL_PROF_DW = 25,         /* all dW GEMMs + bias reductions + fused Adam */
+  /* networks served by the fused kernel (two equal hidden blocks): the two launches of a replayed step */
+  HL_PROF_FUSED = 26,          /* forward + head + dX, sampler of the next step riding along */
+  HL_PROF_FUSED_DW = 27,       /* all weight gradients + Adam, bookkeeping of the step riding along */
+  HL_PROF_FUSED_BARE = 28,     /* 26 without its rider */
+  HL_PROF_FUSED_DW_BARE = 29   /* 27 without its rider */
 };
 HL_API int hl_kernel_profile(hl_learner* h, int32_t which, int32_t reps, double* us_per_launch);
 

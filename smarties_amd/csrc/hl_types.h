@@ -33,6 +33,10 @@ struct DevScalars {
   long long gatherFlag[2];        // sampler -> gather-helper hand-off per minibatch buffer (value: nStep + 1)
   unsigned rngPos;
   unsigned rng[624];
+  // generator state before the draws of the LAST pre-sampled minibatch (the sampler of step k+1 rides along step k;
+  // if the host has to discard that minibatch -- new episodes, an eviction, explicit indices -- it puts this state back)
+  unsigned rngBakPos;
+  unsigned rngBak[624];
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };
 

@@ -13,6 +13,7 @@ struct SampleArgs {
   int adamDraws;          // mt19937 draws consumed by the Adam step (Optimizer.cpp:139)
   int parity;             // minibatch buffer written (bt / X0 passed here belong to it)
   int computeEta;         // also derive DevScalars::etaEff[parity] (first step of a launch sequence)
+  int backupRng;          // keep the generator state as of before the draws in DevScalars::rngBak (pre-sampling riders)
   float eta0; double epsAnneal;
 };
 
@@ -63,10 +64,10 @@ struct PostArgs {
   float eta0;
   int aggStaged;                     // 1: bt.aggIn holds the episode aggregates (fused kernel), no gather needed
   int hasAdv;                        // 1: Q = bt.newQ (head with an advantage), 0: Q = V
-  float* cntMsg;                     // != nullptr: the four replica counters travel inside the gradient message (12 floats, three
-                                     // 20-bit chunks each: exact in fp32 for up to 16 replicas) instead of a collective of their own
+  float* cntMsg;                     // != nullptr: the four replica counters travel inside the gradient message (16 floats, four
+                                     // 16-bit chunks each: exact in fp32 for up to 256 replicas) instead of a collective of their own
 };
-enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4 };
+enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4, POST_ENCODE = 8 /* write the counters message only */ };
 
 struct AdamArgs {
   const DevScalars* sc; float* W; float* M1; float* M2; const float* G; long long n;
@@ -126,6 +127,7 @@ hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra,
 size_t fused_lds_bytes(int dS, int H);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);
+hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0, hipStream_t s);
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
                              int nDense, int dA, int n, double* O, hipStream_t s);

@@ -50,7 +50,6 @@ struct hl_learner {
   int dev = 0;
   hipStream_t stream = nullptr;
   int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nAdv = 0, nHidden = 0, Mmax = 0;
-  bool foldCounters = false;               // while capturing exchange graphs: counters ride in the gradient message (step_exec.h)
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
   RecLayer rec[HL_MAX_HIDDEN]{};
   int nOpt = 0, polDim = 0, nSig = 0;      // discrete head: options; entries of a stored policy (2 dA | nOpt); sigma ParamLayer size (dA | 0)
@@ -86,8 +85,13 @@ struct hl_learner {
   long long* dRedNFar = nullptr; float* dRedMax = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
-  // replayed graphs (one per entry of GRAPH_SIZES), side streams and fork/join events
-  GraphSlot graphs[5]; bool graphsStale = false, useGraph = true;
+  // replayed graphs: one per entry of GRAPH_SIZES and starting minibatch buffer (step_exec.h)
+  GraphSlot graphs[16][2]; bool graphsStale = false, useGraph = true;
+  // the sampler of step k+1 rides along step k, also along the LAST step of a replayed graph: the next call finds its
+  // minibatch ready in buffer preParity.  Whatever changes what a sampler sees (new episodes, evictions, explicit
+  // indices, a generator read-out) first puts the generator back (dropPresample)
+  bool preValid = false; int preParity = 0;
+  long long nCollectives = 0;              // RCCL calls issued or captured so far (tests: every path speaks the same wire protocol)
   struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM, 5 MGU (ld = gates x cells)
   std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
@@ -379,8 +383,13 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute, int skip
   return HL_OK;
 }
 
+int dropPresample(hl_learner* h);      // step_exec.h
+
 // everything the host queued since the last step: table, counters, Retrace of new episodes
 int flushPending(hl_learner* h) {
+  if (h->tableDirty || h->countsDirty || !h->pendingRetrace.empty()) {   // a minibatch drawn ahead saw the old table
+    int rc = dropPresample(h); if (rc) return rc;
+  }
   if (h->tableDirty) { int rc = uploadTable(h); if (rc) return rc; }
   if (h->countsDirty) {
     HIPCK(launch_set_counts(h->sc, h->nTransitions, (long long)h->order.size(), h->nSeenEps, h->nSeenSteps, h->stream));
@@ -419,6 +428,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (!cfg || !out || cfg->struct_size != sizeof(hl_config)) return HL_ERR_BAD_ARG;
   if (cfg->dimS <= 0 || cfg->dimA <= 0 || cfg->dimA > HL_MAX_DIMA || cfg->n_hidden < 1 ||
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
+  if (cfg->n_ranks > 256) return HL_ERR_UNSUPPORTED;   // the replica counters travel as 16-bit chunks in fp32 (tail_dev.h: encodeCounters)
   if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;   // head kernel: one option per lane, deltas staged in 72 floats
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
@@ -475,8 +485,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       L.nIn = d.nIn; L.nC = d.size; L.hasRes = d.hasRes; L.resW = d.resW; L.indW = d.indW; L.indB = d.indB; L.indWr = d.indWr; L.indBr = d.indBr;
       const size_t g = (size_t)d.lstm;         // gates per cell
       L.ldA = (int)roundUp(d.nIn + d.size + 1, 16); L.ldR = (int)roundUp(d.size, 16); L.ldA2 = (int)roundUp(d.size + 1, 16);
-      HIPCK(devAlloc(&L.A, R * L.ldA)); HIPCK(devAlloc(&L.X, R * g * d.size)); HIPCK(devAlloc(&L.Y, R * g * d.size));
-      HIPCK(devAlloc(&L.D, R * g * d.size));
+      // (+16: the float4 loads of the weight-gradient kernel start at column offsets inside a row -- MGU recurrent blocks,
+      //  step_exec.h -- and may run past the end of the last row; the values are masked, the reads must stay in bounds)
+      HIPCK(devAlloc(&L.A, R * L.ldA + 16)); HIPCK(devAlloc(&L.X, R * g * d.size)); HIPCK(devAlloc(&L.Y, R * g * d.size));
+      HIPCK(devAlloc(&L.D, R * g * d.size + 16));
       if (d.hasRes) HIPCK(devAlloc(&L.Rd, R * L.ldR));
       if (d.lstm == 2) HIPCK(devAlloc(&L.A2, R * L.ldA2 + 16));
     }
@@ -588,7 +600,8 @@ int hl_param_layout(const hl_learner* h, int64_t* indW, int64_t* nW, int64_t* in
 // Layer::initialize in build order (Builder.cpp:131-137; Layer_Base.h:115-141; Layers.h:395-400,548-553)
 int hl_init_weights(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
-  DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  int rc = dropPresample(h); if (rc) return rc;
+  DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   HostMT g; std::memcpy(g.x, s.rng, sizeof(g.x)); g.p = s.rngPos;
   auto uni = [&](float a, float b) {
     float r = (float)g.next() / 4294967296.0f;
@@ -650,6 +663,7 @@ int hl_get_params(hl_learner* h, float* w, float* m1, float* m2) {
 }
 int hl_set_rng_state(hl_learner* h, const uint32_t st[625]) {
   if (!h || !st) return HL_ERR_BAD_ARG;
+  { int rc = dropPresample(h); if (rc) return rc; }
   HIPCK(hipMemcpyAsync(&h->sc->rng[0], st, 624 * 4, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(&h->sc->rngPos, st + 624, 4, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -657,7 +671,8 @@ int hl_set_rng_state(hl_learner* h, const uint32_t st[625]) {
 }
 int hl_get_rng_state(hl_learner* h, uint32_t st[625]) {
   if (!h || !st) return HL_ERR_BAD_ARG;
-  DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
+  int rc = dropPresample(h); if (rc) return rc;      // the state as of after the last executed step
+  DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   std::memcpy(st, s.rng, 624 * 4); st[624] = s.rngPos;
   return HL_OK;
 }
@@ -865,6 +880,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
 int hl_step_begin(hl_learner* h, const int64_t* flat) {
   if (!h) return HL_ERR_BAD_ARG;
   int rc = preStepChecks(h); if (rc) return rc;
+  rc = dropPresample(h); if (rc) return rc;
   const long long* dFlat = nullptr;
   if (flat) {
     HIPCK(hipMemcpyAsync(h->dFlatGiven, flat, h->B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
@@ -1246,6 +1262,7 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward between hl_step_begin and hl_step_end");
   if (h->recurrent) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
+  { int rc = dropPresample(h); if (rc) return rc; }      // the forward pass borrows minibatch buffer 0
   if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->Mmax * h->dS)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
   const DevHidden& q = h->hid[h->nHidden - 1];
   for (int r0 = 0; r0 < n; r0 += h->Mmax) {
@@ -1393,10 +1410,12 @@ int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* la
 extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, int variant, double* us_per_launch) {
   if (!h || !us_per_launch || reps <= 0) return HL_ERR_BAD_ARG;
   int rc = flushPending(h); if (rc) return rc;
+  rc = dropPresample(h); if (rc) return rc;
   h->dbgVariant = variant;
   GraphSlot slot;
   if (which == 7) {
-    rc = captureSteps(h, reps, &slot); if (rc) { h->dbgVariant = 0; return rc; }
+    rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc;
+    rc = captureSteps(h, reps & ~1, 0, &slot); if (rc) { h->dbgVariant = 0; return rc; }   // (even: every replay starts with buffer 0)
   } else {
     const AdamHyper hyp = adamHyper(h, 0);
     const StepBuf& sb = h->buf[0];
@@ -1451,15 +1470,18 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
   HIPCK(hipStreamSynchronize(h->stream));
   float ms = 0.f; HIPCK(hipEventElapsedTime(&ms, ev0, ev1));
   hipEventDestroy(ev0); hipEventDestroy(ev1);
-  *us_per_launch = (double)ms * 1e3 / ((double)iters * reps);
+  *us_per_launch = (double)ms * 1e3 / ((double)iters * (which == 7 ? (reps & ~1) : reps));
   hipGraphExecDestroy(slot.exec); hipGraphDestroy(slot.graph);
-  if (which == 7) h->nGradSteps += (long long)(iters + 1) * reps;
+  if (which == 7) h->nGradSteps += (long long)(iters + 1) * (reps & ~1);
   return HL_OK;
 }
 
 extern "C" HL_API int hl_kernel_profile(hl_learner* h, int which, int reps, double* us_per_launch) {
   return hl_debug_kernel_time(h, which, reps, 0, us_per_launch);
 }
+
+// RCCL calls issued or captured so far (tests: eager and replayed steps speak the same wire protocol)
+extern "C" HL_API int64_t hl_debug_collectives(const hl_learner* h) { return h ? h->nCollectives : -1; }
 
 extern "C" HL_API int hl_debug_stamps(hl_learner* h, long long out[32]) {
   if (!h || !out) return HL_ERR_BAD_ARG;

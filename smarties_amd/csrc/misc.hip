@@ -326,6 +326,12 @@ hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, lon
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void rng_restore_kernel(DevScalars* sc) {
+  for (int k = threadIdx.x; k < 624; k += 256) sc->rng[k] = sc->rngBak[k];
+  if (threadIdx.x == 0) sc->rngPos = sc->rngBakPos;
+}
+hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s) { hipLaunchKernelGGL(rng_restore_kernel, dim3(1), dim3(256), 0, s, sc); return hipGetLastError(); }
+
 __global__ void empty_kernel() {}
 hipError_t launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); return hipGetLastError(); }
 

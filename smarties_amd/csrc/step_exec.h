@@ -24,8 +24,10 @@
 
 namespace {
 
-// steps per replayed graph, tried in this order; 999 = everything between two 1000th-step sweeps
-constexpr int GRAPH_SIZES[] = {999, 256, 64, 8, 2};
+// steps per replayed graph, tried in this order (a call of n steps is served greedily: 20 = 16 + 4);
+// 999 = everything between two 1000th-step sweeps
+constexpr int GRAPH_SIZES[] = {999, 256, 128, 64, 32, 16, 8, 4, 2, 1};
+constexpr int CNT_MSG_FLOATS = 16;     // four counters x four 16-bit chunks (tail_dev.h: postPart)
 constexpr int CNT_MSG_OFFSET = 128;    // counters message inside the PARAM_TAIL floats behind the gradient (learner.cpp)
 
 void setTiles(GemmProblem& p, int& cursor) {
@@ -162,7 +164,7 @@ AdamHyper adamHyper(const hl_learner* h, int parity) {
 SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool computeEta) {
   SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->buf[parity].bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
   sa.X0 = h->buf[parity].X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
-  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
+  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.backupRng = 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
   return sa;
 }
 // replica exchanges are part of the step: several replicas, or a communicator was attached to a
@@ -173,7 +175,7 @@ PostArgs postArgs(hl_learner* h, int parity, int mode) {
   pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
   pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = exchanging(h) ? 2 : 1;   // > 1: use the exchanged counters
   pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate; pa.aggStaged = h->fusedOk ? 1 : 0; pa.hasAdv = h->nAdv > 0 ? 1 : 0;
-  pa.cntMsg = h->foldCounters ? h->G + h->nParams + CNT_MSG_OFFSET : nullptr;
+  pa.cntMsg = h->comm ? h->G + h->nParams + CNT_MSG_OFFSET : nullptr;
   return pa;
 }
 HeadArgs headArgs(hl_learner* h, int parity) {
@@ -196,6 +198,7 @@ int launchSample(hl_learner* h, int parity, const long long* dFlat, bool compute
 // `fusePost`: the bookkeeping of THIS step rides along the first backward launch.
 ExtraArgs extraSample(hl_learner* h, int parityNext, int phases) {
   ExtraArgs ex{}; ex.role = 1; ex.phases = phases; ex.samp = sampleArgs(h, parityNext, nullptr, false);
+  ex.samp.backupRng = 1;       // the minibatch drawn here may have to be discarded (dropPresample)
   return ex;
 }
 FusedArgs fusedArgs(hl_learner* h, int parity) {
@@ -326,22 +329,25 @@ int applyRemoval(hl_learner* h) {
   return HL_OK;
 }
 
-// with `foldCounters` the message also carries the parameter tail up to the 12 counter chunks (postPart, cntMsg)
+// the message also carries the parameter tail up to the counter chunks (postPart, cntMsg): one collective per step
 int allreduceGrad(hl_learner* h) {
   if (!exchanging(h)) return HL_OK;
   if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
-  const size_t n = (size_t)h->nParams + (h->foldCounters ? CNT_MSG_OFFSET + 12 : 0);
+  const size_t n = (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS;
   NCCLCK(ncclAllReduce(h->G, h->G, n, ncclFloat, ncclSum, h->comm, h->stream));
+  h->nCollectives += 1;
   return HL_OK;
 }
-int allreduceCounters(hl_learner* h) {
+int allreduceCounters(hl_learner* h) {      // start-up only (hl_initialize); steps carry the counters in the gradient message
   if (!h->comm) return HL_OK;
   NCCLCK(ncclAllReduce(h->sc->cnt, h->sc->cnt, 4, ncclInt64, ncclSum, h->comm, h->stream));
+  h->nCollectives += 1;
   return HL_OK;
 }
 int allreduceMoments(hl_learner* h) {
   if (!h->comm) return HL_OK;
   NCCLCK(ncclAllReduce(h->dMoments, h->dMoments, (size_t)(2 * h->dS + 3), ncclDouble, ncclSum, h->comm, h->stream));
+  h->nCollectives += 1;
   return HL_OK;
 }
 
@@ -375,19 +381,31 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
   return launchBackward(h, parity, fuseAdam, s);
 }
 
-// one full step, eager launches on the main stream, minibatch buffer 0
+// A pre-sampled minibatch is discarded: the generator goes back to where it was before that minibatch was drawn.
+int dropPresample(hl_learner* h) {
+  if (!h->preValid) return HL_OK;
+  h->preValid = false;
+  HIPCK(launch_rng_restore(h->sc, h->stream));
+  return HL_OK;
+}
+
+// one full step, eager launches on the main stream.  The order is the reference's (RACER::setupTasks, RACER.cpp:81-108):
+// train -> processMemoryBuffer (statistics, every 1000th step the whole-buffer passes, removal, counters) -> gradient
+// exchange -> Adam -> beta.  With a communicator every step -- eager or replayed -- issues exactly ONE all-reduce
+// (gradient || counters), plus one of the 2 dS + 3 moments on every 1000th step, so replicas may mix the two paths freely.
 int stepEager(hl_learner* h, const long long* dFlat) {
   hipStream_t s = h->stream;
   const long long k = h->nGradSteps + 1;
   const bool periodic = (k % 1000) == 0;
-  const bool fuse = !exchanging(h);
-  int rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc;
-  rc = launchMlp(h, 0, fuse, s); if (rc) return rc;
-  if (!fuse) { rc = allreduceGrad(h); if (rc) return rc; rc = launchAdam(h, 0); if (rc) return rc; }
-  h->lastParity = 0;
+  const bool exch = exchanging(h);
+  int p = 0, rc;
+  if (h->preValid && !dFlat) { p = h->preParity; h->preValid = false; }     // drawn by the rider of the previous step
+  else { rc = dropPresample(h); if (rc) return rc; rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc; }
+  rc = launchMlp(h, p, !exch, s); if (rc) return rc;
+  h->lastParity = p;
   const bool evict = evictionDue(h);
-  if (!periodic && !evict && !exchanging(h)) return launchPost(h, 0, POST_AGG | POST_BETA, s);
-  rc = launchPost(h, 0, POST_AGG, s); if (rc) return rc;
+  if (!periodic && !evict && !exch) return launchPost(h, p, POST_AGG | POST_BETA, s);
+  rc = launchPost(h, p, POST_AGG, s); if (rc) return rc;
   if (periodic) {
     rc = launchPeriodicSweep(h); if (rc) return rc;
     rc = launchMoments(h); if (rc) return rc;
@@ -395,42 +413,46 @@ int stepEager(hl_learner* h, const long long* dFlat) {
     rc = launchMomentsApply(h, false, 10); if (rc) return rc;
   }
   if (evict) { rc = applyRemoval(h); if (rc) return rc; rc = flushPending(h); if (rc) return rc; }
-  rc = allreduceCounters(h); if (rc) return rc;
-  return launchPost(h, 0, POST_BETA, s);
+  if (exch) {
+    if (h->comm) { rc = launchPost(h, p, POST_ENCODE, s); if (rc) return rc; }   // counters as of after the removal
+    rc = allreduceGrad(h); if (rc) return rc;
+    rc = launchAdam(h, p); if (rc) return rc;
+  }
+  return launchPost(h, p, POST_BETA, s);
 }
 
-// ---- replayed graph: U steps on one stream, tail work horizontally fused into the MLP kernels ----
-int captureSteps(hl_learner* h, int U, GraphSlot* slot) {
+// ---- replayed graph: U steps on one stream, tail work horizontally fused into the MLP kernels.  The graph starts
+//      with the minibatch of its first step already in buffer `p0` and leaves the one of the step after its last in
+//      buffer (p0 + U) & 1 ----
+int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
   if (slot->exec) { hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
   if (slot->graph) { hipGraphDestroy(slot->graph); slot->graph = nullptr; }
   hipStream_t s0 = h->stream;
   HIPCK(hipStreamSynchronize(s0));
   HIPCK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
-  int rc = launchSample(h, 0, nullptr, true, s0);       // first minibatch of the graph: its own launch
+  int rc = HL_OK;
+  const long long nColl0 = h->nCollectives;      // captured calls are counted when the graph is replayed
   for (int j = 0; j < U && !rc; ++j) {
-    const int p = j & 1;
-    const bool more = j + 1 < U;                        // pre-sample step j+1 while step j computes
+    const int p = (p0 + j) & 1;
     if (h->fusedOk) {
-      rc = launchFused(h, p, s0, more); if (rc) break;
+      rc = launchFused(h, p, s0, true); if (rc) break;
       if (!exchanging(h)) { rc = launchWeightGrad(h, p, true, s0, true, false); if (rc) break; continue; }
       // replicas: the exchange is part of the replayed graph (RCCL calls are captured like kernels).  ONE collective per
-      // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (three exact 20-bit
-      // chunks each), the pass after Adam decodes their sums -- the eager sequence keeps its separate counter all-reduce
-      // because there the gradient is exchanged before the bookkeeping runs.
-      h->foldCounters = true;
+      // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (four exact 16-bit
+      // chunks each), the pass after Adam decodes their sums.
       rc = launchWeightGrad(h, p, false, s0, true, false, POST_AGG);
       if (!rc) rc = allreduceGrad(h);
       if (!rc) rc = launchAdam(h, p);
       if (!rc) rc = launchPost(h, p, POST_BETA, s0);
-      h->foldCounters = false;
       if (rc) break;
       continue;
     }
-    rc = launchForward(h, p, s0, more); if (rc) break;
-    rc = launchHead(h, p, s0, more); if (rc) break;
+    rc = launchForward(h, p, s0, true); if (rc) break;
+    rc = launchHead(h, p, s0, true); if (rc) break;
     rc = launchBackward(h, p, true, s0, true); if (rc) break;
   }
   hipError_t e = hipStreamEndCapture(s0, &slot->graph);
+  h->nCollectives = nColl0;
   if (rc) return rc;
   if (e != hipSuccess) return hipFail(h, e, "hipStreamEndCapture");
   HIPCK(hipGraphInstantiate(&slot->exec, slot->graph, nullptr, nullptr, 0));
@@ -439,42 +461,50 @@ int captureSteps(hl_learner* h, int U, GraphSlot* slot) {
 }
 
 void invalidateGraphs(hl_learner* h) {
-  for (auto& g : h->graphs) {
+  for (auto& gp : h->graphs) for (auto& g : gp) {
     if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (g.graph) { hipGraphDestroy(g.graph); g.graph = nullptr; }
   }
 }
 
+// sizes usable by this learner: with a communicator attached the graphs stay short (<= 64 steps, i.e. 64 captured
+// collectives: a 2 ms replay already amortises the launch, and nothing here depends on how many collective nodes the
+// installed RCCL is comfortable with in one graph); the 999-step graph only ever starts right after a 1000th-step
+// sweep, i.e. with buffer 0
+bool graphUsable(const hl_learner* h, int U, int p0) {
+  if (exchanging(h) && U > 64) return false;
+  if (U == 999 && p0 != 0) return false;
+  return true;
+}
+
 // run as many plain steps as possible (<= avail) from one graph replay; returns steps done (0 = none)
 int replaySteps(hl_learner* h, long long avail, int* done) {
   *done = 0;
-  for (size_t i = 0; i < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]); ++i) {
+  constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
+  static_assert(NS <= 16, "hl_learner::graphs is too small");
+  if (!h->graphs[NS - 1][0].exec) {
+    // first use: capture every size and starting buffer now (once per learner -- graphs survive appends and
+    // evictions, only a reallocation of the replay invalidates them), so that no later call pays for a capture
+    // in the middle of a training phase.  If RCCL cannot be captured on this system, fall back to eager launches
+    // for good (the graph is only an optimisation).
+    for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
+      if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
+      const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);
+      if (rc == HL_OK) continue;
+      if (!exchanging(h)) return rc;
+      h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
+      return HL_OK;
+    }
+  }
+  const int p0 = h->preValid ? h->preParity : 0;
+  for (int i = 0; i < NS; ++i) {
     const int U = GRAPH_SIZES[i];
-    if (avail < U) continue;
-    // with a communicator attached the graphs stay short (<= 64 steps, 128 captured collectives):
-    // a 3 ms replay already amortises the launch, and nothing here depends on how many collective
-    // nodes the installed RCCL is comfortable with in one graph
-    if (exchanging(h) && U > 64) continue;
-    GraphSlot& g = h->graphs[i];
-    if (!g.exec && exchanging(h)) {
-      // if RCCL cannot be captured on this system, fall back to eager launches for good (the graph
-      // is only an optimisation)
-      for (size_t j = 0; j < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]) && h->exchGraph; ++j)
-        if (GRAPH_SIZES[j] <= 64 && !h->graphs[j].exec && captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]) != HL_OK) {
-          h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
-        }
-      if (!h->exchGraph) return HL_OK;
-    }
-    if (!g.exec) {
-      // first use: capture every size now (tens of ms, once per learner -- graphs survive appends
-      // and evictions, only a reallocation of the replay invalidates them), so that no later call
-      // pays for a capture in the middle of a training phase
-      for (size_t j = 0; j < sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]); ++j)
-        if (!h->graphs[j].exec && !(exchanging(h) && GRAPH_SIZES[j] > 64)) {
-          int rc = captureSteps(h, GRAPH_SIZES[j], &h->graphs[j]); if (rc) return rc; }
-    }
-    HIPCK(hipGraphLaunch(g.exec, h->stream));
-    h->lastParity = (U - 1) & 1;
+    if (avail < U || !graphUsable(h, U, p0)) continue;
+    if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }   // first minibatch: its own launch
+    HIPCK(hipGraphLaunch(h->graphs[i][p0].exec, h->stream));
+    h->lastParity = (p0 + U - 1) & 1;
+    h->preValid = true; h->preParity = (p0 + U) & 1;
+    if (h->comm) h->nCollectives += U;
     *done = U;
     return HL_OK;
   }

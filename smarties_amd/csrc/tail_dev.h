@@ -46,6 +46,12 @@ __device__ __forceinline__ void aggValues(float* ag, float oldV, float oldADV, f
   ag[AGG_MINQ] = fminf(ag[AGG_MINQ], Q);
 }
 
+// the four replica counters as 16 floats: four 16-bit chunks each, so that an fp32 SUM all-reduce over up to 256
+// replicas returns them exactly (every chunk sum stays below 2^24)
+__device__ __forceinline__ void encodeCounters(float* msg, const long long c4[4]) {
+  for (int c = 0; c < 4; ++c) for (int q = 0; q < 4; ++q) msg[4 * c + q] = (float)((c4[c] >> (16 * q)) & 0xFFFF);
+}
+
 __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs) {
   DevScalars* sc = a.sc;
   const int tid = threadIdx.x, B = a.B;
@@ -157,17 +163,21 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce
       if (a.cntMsg) {       // counters ride in the tail of the gradient buffer: one all-reduce per step instead of two
         const long long c4[4] = {sc->seenLocal[0], sc->seenLocal[1], nFarStat, nTrans};
-        for (int c = 0; c < 4; ++c) for (int q = 0; q < 3; ++q) a.cntMsg[3 * c + q] = (float)((c4[c] >> (20 * q)) & 0xFFFFF);
+        encodeCounters(a.cntMsg, c4);
       }
     }
+  }
+  if ((a.mode & POST_ENCODE) && a.cntMsg && tid == 0) {   // eager steps: the counters as they stand after the removal pass
+    const long long c4[4] = {sc->seenLocal[0], sc->seenLocal[1], sc->cnt[2], sc->cnt[3]};
+    encodeCounters(a.cntMsg, c4);
   }
   if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {
     // updateCounters (:46-92); with several replicas cnt[] holds the all-reduced counters
     long long cntR[4] = {sc->cnt[0], sc->cnt[1], cnt2, cnt3};
-    if (a.cntMsg) {         // decode the summed chunks (each sum < 2^24: exact)
+    if (a.cntMsg && (a.mode & POST_BETA)) {         // decode the summed chunks (each sum < 2^24: exact)
       for (int c = 0; c < 4; ++c) {
         long long v = 0;
-        for (int q = 0; q < 3; ++q) v += (long long)(a.cntMsg[3 * c + q] + 0.5f) << (20 * q);
+        for (int q = 0; q < 4; ++q) v += (long long)(a.cntMsg[4 * c + q] + 0.5f) << (16 * q);
         cntR[c] = v; sc->cnt[c] = v;
       }
     }
@@ -361,8 +371,9 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
   const int K = Bp / 256;
   const bool rngNeeded = (phases & (PH_A | PH_B)) != 0;
   if (rngNeeded) {
-    for (int k = tid; k < 624; k += 256) x[k] = sc->rng[k];
-    if (tid == 0) *sPos = (int)sc->rngPos;
+    const bool bak = a.backupRng && (phases & PH_A);
+    for (int k = tid; k < 624; k += 256) { const unsigned v = sc->rng[k]; x[k] = v; if (bak) sc->rngBak[k] = v; }
+    if (tid == 0) { const unsigned p0 = sc->rngPos; *sPos = (int)p0; if (bak) sc->rngBakPos = p0; }
   }
   const unsigned long long nData = (unsigned long long)sc->nTransitions;
   const int nEp = (int)sc->nEpisodes;

@@ -71,8 +71,8 @@ def synth_episode(sc, e, n_options=0):
     return dict(states=S, actions=A, mu=MU, rewards=R, values=V, terminated=term.value, tag=e)
 
 
-def fill_synth(learner, sc, n_eps):
-    for e in range(n_eps):
+def fill_synth(learner, sc, n_eps, first=0):
+    for e in range(first, first + n_eps):
         ep = synth_episode(sc, e, getattr(learner, "nOptions", 0))
         learner.append_episode(**ep)
 

@@ -800,6 +800,79 @@ def test_recurrent_acting_matches_oracle(hip_api):
         G.forward(rng.normal(size=(1, 6)).astype(np.float32))                # stateless forward of a recurrent net
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw,sc_kw,n_eps", [
+    (dict(dimS=17, dimA=6, hidden=(64, 64), batchSize=32, maxTotObsNum=3000, randSeed=8),          # fused path
+     dict(seed=21, dimS=17, dimA=6, lenMin=5, lenMax=30, pTerm=0.3), 60),
+    (dict(dimS=9, dimA=3, bounded=[0, 1, 0], hidden=(24, 16), nnFunc="Tanh", batchSize=8, maxTotObsNum=1500, randSeed=5),   # five launches
+     dict(seed=3, dimS=9, dimA=3, lenMin=3, lenMax=30, pTerm=0.3), 40),
+])
+def test_chained_replays_carry_the_next_minibatch_across_calls(hip_api, cfg_kw, sc_kw, n_eps):
+    """Every replayed step draws the minibatch of the step after it, also the last one of a call: the next call starts from
+    it (odd and even call lengths alternate the buffer), and whatever invalidates it -- a generator read-out, new episodes,
+    explicit indices, a rollout forward -- puts the generator back first.  Same trajectory as the oracle throughout."""
+    sc = synth_cfg(**sc_kw)
+    G, O = _pair(hip_api, cfg_kw, sc, n_eps)
+    nxt = n_eps
+    for i, n in enumerate([1, 1, 1, 2, 5, 20, 3, 1, 7, 16, 1, 33]):
+        G.step(n); O.step(n)
+        if i % 4 == 3:       # generator read-out: the minibatch drawn ahead is discarded, the state is the oracle's
+            assert np.array_equal(G.get_rng_state(), O.get_rng_state()), i
+        if i == 5:           # new episodes between two calls
+            for L in (G, O):
+                fill_synth(L, sc, 3, first=nxt)
+            nxt += 3
+        if i == 8:           # rollout inference borrows a minibatch buffer
+            st = np.random.default_rng(0).normal(size=(4, cfg_kw["dimS"])).astype(np.float32)
+            assert relinf(G.forward(st), O.forward(st)) < TOL32
+        if i == 9:           # explicit indices
+            flat = np.sort(np.random.default_rng(1).choice(int(G.scalars().nStoredSteps), G.B, replace=False)).astype(np.int64)
+            G.step(1, flat=flat); O.step(1, flat=flat)
+    _compare_step(G, O)
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < TOL32
+    assert G.scalars().nGradSteps == O.scalars().nGradSteps
+    assert abs(G.scalars().beta - O.scalars().beta) < 1e-9
+
+
+@pytest.mark.gpu
+def test_replicas_speak_one_wire_protocol_on_every_path(hip_api):
+    """With a communicator attached every step -- replayed or eager, with or without an eviction, with explicit indices --
+    issues exactly ONE all-reduce (gradient || counters), the 1000th step one more (moments): replicas that take different
+    paths (their replays fill differently) still pair their collectives one to one."""
+    import ctypes as C
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=600, randSeed=42)
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    A, _ = _pair(hip_api, cfg_kw, sc, 30)
+    Bq = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    Bq.init_weights(); fill_synth(Bq, sc, 30)
+    raw = (C.c_uint8 * 128)()
+    assert hip_api.fn("comm_unique_id")(raw) == 0
+    Bq.comm_init(bytes(raw))
+    Bq.initialize()
+    coll = hip_api.lib.hl_debug_collectives
+    coll.restype = C.c_int64; coll.argtypes = [C.c_void_p]
+    c0 = coll(Bq.h)
+    done = 0
+    nxt = 30
+    for n in (1, 20, 3, 64, 7):
+        A.step(n); Bq.step(n); done += n
+        assert coll(Bq.h) - c0 == done, n
+        for L in (A, Bq):                      # appended episodes push the replay over its budget: eager steps with evictions
+            fill_synth(L, sc, 4, first=nxt)
+        nxt += 4
+        assert np.array_equal(A.get_params()[0], Bq.get_params()[0]), n
+    flat = np.sort(np.random.default_rng(1).choice(int(A.scalars().nStoredSteps), A.B, replace=False)).astype(np.int64)
+    A.step(1, flat=flat); Bq.step(1, flat=flat); done += 1
+    assert coll(Bq.h) - c0 == done
+    rest = 1000 - done
+    A.step(rest); Bq.step(rest)                # ends on the 1000th step: + the moments all-reduce
+    assert coll(Bq.h) - c0 == 1000 + 1
+    assert np.array_equal(A.get_params()[0], Bq.get_params()[0])
+    assert A.scalars().beta == Bq.scalars().beta and A.scalars().nFarPolicySteps == Bq.scalars().nFarPolicySteps
+    assert np.array_equal(A.get_rng_state(), Bq.get_rng_state())
+
+
 @pytest.fixture(scope="module")
 def full_size(hip_api):
     cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=1000000, randSeed=42)
@@ -848,13 +921,20 @@ def test_full_size_retrace_round_trip(full_size):
         tag, N, term = G.episode_info(pos)
         R = synth_episode(synth_cfg(seed=7, dimS=17, dimA=6, lenMin=201, lenMax=201, pTerm=0.0), tag)["rewards"]
         assert np.allclose(Q, O.episode_field(pos, capi.EP_RETURN), rtol=1e-4, atol=1e-4)
-        # the sweep ran at initialize(); sampled steps since then changed V / rho of a few entries,
-        # so check the recursion only where nothing was touched (rho == 1, the insert-time value)
+        # the sweep ran at initialize(); steps sampled since then changed V / rho of a few entries (their stored Q_t stays
+        # as it was until the next sweep), so the recursion is asserted exactly where nothing was touched: rho_{t+1} still
+        # at its insert-time value 1 -- for the last transition, whose successor is the truncated end state (rho = 0,
+        # Q = V), the sampled step itself untouched
         rs = ((R - np.float64(r3[0])) * np.float64(r3[1])).astype(np.float32)
+        g = np.float32(0.995)
+        checked = 0
         for t in range(N - 2, -1, -1):
-            if W[t + 1] == 1.0 and (t + 2 >= N or W[t + 2] == 1.0 or True):
-                rhs = rs[t + 1] + np.float32(0.995) * (V[t + 1] + np.float32(1.0) * min(np.float32(1), W[t + 1]) * (Q[t + 1] - V[t + 1]))
-                if abs(Q[t] - rhs) > 1e-3 * max(1.0, abs(rhs)):
-                    # a later-updated V/rho invalidates the stored Q_t until the next sweep; tolerate few
-                    pass
+            untouched = (W[t + 1] == 1.0) if t + 1 < N - 1 else (W[t] == 1.0 and W[t + 1] == 0.0)
+            if not untouched:
+                continue
+            w = min(np.float32(1), W[t + 1])
+            rhs = rs[t + 1] + g * (V[t + 1] + w * (Q[t + 1] - V[t + 1]))
+            assert abs(Q[t] - rhs) <= 2e-5 * max(1.0, abs(rhs)), (pos, t, Q[t], rhs)
+            checked += 1
+        assert checked > N // 2
         assert np.isfinite(Q).all()
