@@ -55,6 +55,7 @@ extern "C" {
 
 #define HL_MAX_DIMA   64
 #define HL_MAX_HIDDEN 8
+#define HL_MAX_CONV   8
 #define HL_MAX_RANKS  256   /* replica counters travel as 16-bit chunks inside the fp32 gradient all-reduce */
 
 /* status codes */
@@ -91,6 +92,15 @@ enum { HL_ADV_ZERO = 0 /* VRACER */, HL_ADV_GAUSSIAN = 1 /* RACER continuous */,
 enum { HL_ORDER_STABLE = 0,     /* stable sort by ID, newest first (product semantics)  */
        HL_ORDER_REFERENCE = 1 };/* std::sort each step exactly as MemoryProcessing.cpp:336
                                    (oracle only: reproduces the reference's permutation) */
+
+/* Convolutional preprocessing layer as the environment declares it (Conv2D_Descriptor, Core/StateAction.h;
+ * Communicator::setPreprocessingConv2d, Communicator.cpp:136-162): image [inpFeatures][inpY][inpX] -> SoftSign
+ * convolution -> [outFeatures][outY][outX], filter [outFeatures][inpFeatures][filtery][filterx], one bias per OUTPUT
+ * ELEMENT (Network/Layers/Layer_Conv2D.h:37-40).  The reference instantiates seven shapes (Network/Builder.cpp:189-203);
+ * the library takes any stride / filter with zero padding. */
+typedef struct hl_conv2d {
+  int32_t inpFeatures, inpY, inpX, outFeatures, outY, outX, filterx, filtery, stridex, stridey, paddinx, paddiny;
+} hl_conv2d;
 
 /*
  * Learner configuration = the settings/<name>.json Learner surface
@@ -129,7 +139,13 @@ typedef struct hl_config {
                                         Core/StateAction.h:322-341, policies the nOptions probabilities); else 0 */
   int32_t nn_type;                   /* HL_NN_*: settings nnType of the hidden layers                  */
   int32_t nnBPTTseq;                 /* recurrent nets: steps of truncated BPTT (0 = the default, 16)   */
-  int32_t reserved[4];
+  int32_t nAppendedObs;              /* MDP.nAppendedObs (Communicator::setNumAppendedPastObservations): the network input is the
+                                        observed state of step t followed by those of t-1 .. t-nAppendedObs
+                                        (Episode::standardizedState, Episode.h:172-183; steps before the first: the first) */
+  int32_t n_conv;                    /* MDP.conv2dDescriptors: convolutional layers ahead of nnLayerSizes
+                                        (Approximator::buildPreprocessing, Approximator.cpp:231-271; BASELINE config 5) */
+  hl_conv2d conv[HL_MAX_CONV];
+  int32_t reserved[2];
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */

@@ -154,9 +154,10 @@ inline bool isFarPolicy(Fval W, Fval C, Fval invC) {
 // ---------------------------------------------------------------------------
 // network description (Network/Builder.cpp:48-117, Layers/*.h)
 // ---------------------------------------------------------------------------
-enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM, L_MGU };
+enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM, L_MGU, L_CONV };
 struct Layer {
   LType type; int size = 0, nIn = 0, nOutSimd = 0, func = HL_FUNC_LINEAR;
+  hl_conv2d cv{};                     // L_CONV: Conv2DLayer<SoftSign, ...> (Network/Layers/Layer_Conv2D.h:29-232)
   bool bOutput = false, skipInpGrad = false;
   int64_t indW = 0, nW = 0, indB = 0, nB = 0;
   std::vector<Real> biasInit;  // ParamLayer initial values
@@ -230,7 +231,16 @@ void buildNet(ol_learner* h) {
   const hl_config& c = h->cfg;
   std::vector<Layer>& L = h->layers;
   L.clear();
-  { Layer in; in.type = L_INPUT; in.size = c.dimS; L.push_back(in); }
+  // input: the observed state followed by the nAppendedObs previous ones (Approximator.cpp:208-209, 242-243)
+  { Layer in; in.type = L_INPUT; in.size = c.dimS * (1 + c.nAppendedObs); L.push_back(in); }
+  // Approximator::buildPreprocessing (Approximator.cpp:231-271) -> Builder::addConv2d (Builder.cpp:172-215): SoftSign
+  // convolutions, no skip connections between them
+  for (int j = 0; j < c.n_conv; ++j) {
+    const hl_conv2d& d = c.conv[j];
+    Layer cl; cl.type = L_CONV; cl.cv = d; cl.func = HL_FUNC_SOFTSIGN;
+    cl.size = d.outFeatures * d.outY * d.outX; cl.nIn = d.inpFeatures * d.inpY * d.inpX;
+    L.push_back(cl);
+  }
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     const int ID = (int)L.size();
@@ -271,6 +281,7 @@ void buildNet(ol_learner* h) {
       case L_PARAM: l.nW = 0; l.nB = l.size; break;                            // Layers.h:494-497
       case L_LSTM: l.nW = (int64_t)4 * l.size * (l.nIn + l.size); l.nB = 4 * l.size; break;   // Layer_LSTM.h:24-29
       case L_MGU: l.nW = (int64_t)2 * l.size * (l.nIn + l.size); l.nB = 2 * l.size; break;    // Layer_GRU.h:29-34
+      case L_CONV: l.nW = (int64_t)l.cv.outFeatures * l.cv.inpFeatures * l.cv.filtery * l.cv.filterx; l.nB = l.size; break;   // Layer_Conv2D.h:37-40
     }
     l.indW = tot; tot += roundUp8(l.nW);
     l.indB = tot; tot += roundUp8(l.nB);
@@ -314,7 +325,44 @@ void initWeights(ol_learner* h) {
       for (int o = 0; o < l.size; ++o) { Bv[o] = 0; W[o] = 1; }
     } else if (l.type == L_PARAM) {
       for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)l.biasInit[o];
+    } else if (l.type == L_CONV) {   // Layer_Conv2D.h:198-213: fan-in InC KnX KnY, fan-out KnC; biases zero, weights in memory order
+      const nnReal init = fInitFactor(l.func, l.cv.inpFeatures * l.cv.filterx * l.cv.filtery, l.cv.outFeatures);
+      for (int o = 0; o < l.size; ++o) Bv[o] = 0;
+      for (int64_t w = 0; w < l.nW; ++w) W[w] = uniformFloat(h->gen, -init, init);
     }
+  }
+}
+
+// Conv2DLayer::forward / backward, the direct loops of the build without BLAS (Layer_Conv2D.h:83-139): image [C][Y][X],
+// filter K[KnC][InC][KnY][KnX], the reference's loop nest (so every output element sums its terms in the same order)
+void convForward(const Layer& l, const nnReal* K, const nnReal* Bv, const nnReal* INP, nnReal* OUT, nnReal* Yout) {
+  const hl_conv2d& d = l.cv;
+  const int InC = d.inpFeatures, InY = d.inpY, InX = d.inpX, KnC = d.outFeatures, KnY = d.filtery, KnX = d.filterx;
+  const int OpY = d.outY, OpX = d.outX, Sx = d.stridex, Sy = d.stridey, Px = d.paddinx, Py = d.paddiny;
+  std::memcpy(OUT, Bv, (size_t)l.size * sizeof(nnReal));
+  for (int fc = 0; fc < KnC; ++fc) for (int ic = 0; ic < InC; ++ic)
+  for (int oy = 0; oy < OpY; ++oy) for (int fy = 0; fy < KnY; ++fy)
+  for (int ox = 0; ox < OpX; ++ox) for (int fx = 0; fx < KnX; ++fx) {
+    const int ix = ox * Sx - Px + fx, iy = oy * Sy - Py + fy;
+    if (ix < 0 || ix >= InX || iy < 0 || iy >= InY) continue;
+    OUT[(fc * OpY + oy) * OpX + ox] += K[((fc * InC + ic) * KnY + fy) * KnX + fx] * INP[(ic * InY + iy) * InX + ix];
+  }
+  for (int o = 0; o < l.size; ++o) Yout[o] = fEval(l.func, OUT[o]);
+}
+void convBackward(const Layer& l, const nnReal* K, const nnReal* INP, const nnReal* Xl, const nnReal* Yl, nnReal* dOUT,
+                  nnReal* dINP /*nullptr: first layer*/, nnReal* gK, nnReal* gB) {
+  const hl_conv2d& d = l.cv;
+  const int InC = d.inpFeatures, InY = d.inpY, InX = d.inpX, KnC = d.outFeatures, KnY = d.filtery, KnX = d.filterx;
+  const int OpY = d.outY, OpX = d.outX, Sx = d.stridex, Sy = d.stridey, Px = d.paddinx, Py = d.paddiny;
+  for (int o = 0; o < l.size; ++o) { dOUT[o] *= fDiff(l.func, Xl[o], Yl[o]); gB[o] += dOUT[o]; }   // backward_bias (:68-78)
+  for (int fc = 0; fc < KnC; ++fc) for (int ic = 0; ic < InC; ++ic)
+  for (int oy = 0; oy < OpY; ++oy) for (int fy = 0; fy < KnY; ++fy)
+  for (int ox = 0; ox < OpX; ++ox) for (int fx = 0; fx < KnX; ++fx) {
+    const int ix = ox * Sx - Px + fx, iy = oy * Sy - Py + fy;
+    if (ix < 0 || ix >= InX || iy < 0 || iy >= InY) continue;
+    const nnReal dO = dOUT[(fc * OpY + oy) * OpX + ox];
+    gK[((fc * InC + ic) * KnY + fy) * KnX + fx] += dO * INP[(ic * InY + iy) * InX + ix];
+    if (dINP) dINP[(ic * InY + iy) * InX + ix] += dO * K[((fc * InC + ic) * KnY + fy) * KnX + fx];
   }
 }
 
@@ -386,6 +434,8 @@ void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vecto
       }
     } else if (l.type == L_PARAM) {  // Layers.h:510-520
       for (int n = 0; n < l.size; ++n) { X[ID][n] = Bv[n]; Y[ID][n] = fEval(l.func, Bv[n]); }
+    } else if (l.type == L_CONV) {
+      convForward(l, W, Bv, Y[ID - 1].data(), X[ID].data(), Y[ID].data());
     }
   }
 }
@@ -444,6 +494,8 @@ void backwardNet(ol_learner* h) {
         gW[j] += delta[j] * inp[j];
         gB[j] += delta[j];
       }
+    } else if (l.type == L_CONV) {
+      convBackward(l, W, Y[ID - 1].data(), X[ID].data(), Y[ID].data(), E[ID].data(), ID > 1 ? E[ID - 1].data() : nullptr, gW, gB);
     }
   }
 }
@@ -925,6 +977,15 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;
   if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
       cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
+  if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
+  if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
+  for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
+    const hl_conv2d& d = cfg->conv[j];
+    const int inSize = d.inpFeatures * d.inpY * d.inpX;
+    const int prev = j == 0 ? cfg->dimS * (1 + cfg->nAppendedObs) : cfg->conv[j - 1].outFeatures * cfg->conv[j - 1].outY * cfg->conv[j - 1].outX;
+    if (inSize != prev || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.stridey < 1) return HL_ERR_BAD_ARG;
+    if (d.outY != (d.inpY - d.filtery + 2 * d.paddiny) / d.stridey + 1 || d.outX != (d.inpX - d.filterx + 2 * d.paddinx) / d.stridex + 1) return HL_ERR_BAD_ARG;
+  }
   auto* h = new ol_learner(); h->cfg = *cfg;
   h->dS = cfg->dimS; h->dA = cfg->dimA;
   // HyperParameters::defineDistributedLearning (Settings/HyperParameters.cpp:177-205)
@@ -1065,13 +1126,25 @@ int ol_initialize(ol_learner* h) {
 }
 
 // Learner_approximator::spawnTrainTasks (Learner_approximator.cpp:36-92), nThreads = 1
+// Episode::standardizedState (Episode.h:172-183): the observed state of step t followed by the nAppendedObs previous ones,
+// each (s - mean) * scale.  The reference indexes the appended steps with std::max((Uint) samp - j, (Uint) 0), which wraps
+// for samp < j (an out-of-bounds read there); the evident intent -- steps before the first repeat the first -- is what
+// both the library and this restatement do, and the fixtures of the compiled reference only sample t >= nAppendedObs.
+static void standardizedState(const ol_learner* h, const Episode& EP, int t, nnReal* ret) {
+  const int dS = h->dS, nApp = h->cfg.nAppendedObs;
+  for (int j = 0, k = 0; j <= nApp; ++j) {
+    const int tt = std::max(t - j, 0);
+    for (int i = 0; i < dS; ++i, ++k) ret[k] = (EP.S[(size_t)tt * dS + i] - h->stMean[i]) * h->stScale[i];
+  }
+}
+
 int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
   if (!h) return HL_ERR_BAD_ARG;
   if (!h->initialized) return fail(h, HL_ERR_STATE, "step before initialize");
   if (h->inStep) return fail(h, HL_ERR_STATE, "step_begin twice");
   if (h->minObsLocal < h->cfg.batchSize && false) return HL_ERR_TOO_FEW_DATA;
   if (h->nTransitions < h->B) return fail(h, HL_ERR_TOO_FEW_DATA, "Parameter minTotObsNum is too low for given problem");
-  const int B = h->B, dS = h->dS, dA = h->dA, nOut = h->nOut;
+  const int B = h->B, dS = h->dS * (1 + h->cfg.nAppendedObs), dA = h->dA, nOut = h->nOut;      // dS: network input size
   if (flat_in) h->bFlat.assign(flat_in, flat_in + B); else sampleUniform(h, h->bFlat);
   idToSeqStep(h, h->bFlat, h->bEp, h->bT);
   h->bTag.resize(B);
@@ -1084,7 +1157,7 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     Episode& EP = *h->episodes[h->bEp[b]]; const int t = (int)h->bT[b];
     h->bTag[b] = EP.tag;
     // MemoryBuffer::sampleMinibatch gather: Episode::standardizedState (Episode.h:172-183)
-    for (int i = 0; i < dS; ++i) inp[i] = (EP.S[(size_t)t * dS + i] - h->stMean[i]) * h->stScale[i];
+    standardizedState(h, EP, t, inp.data());
     if (h->tap) std::copy(inp.begin(), inp.end(), h->tState.begin() + (size_t)b * dS);
     // recurrent nets: the window of MemoryBuffer::sampleMinibatch (:391-402), min(nnBPTTseq, t) steps before t; every
     // step is forwarded with the previous one as recurrent input (Approximator::forward, Approximator.h:116-173)
@@ -1097,14 +1170,14 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
       for (auto& a : series) { a.X = h->X; a.Y = h->Y; a.E = h->E; for (auto& e : a.E) std::fill(e.begin(), e.end(), 0); }
       std::vector<nnReal> in2(dS);
       for (int k = 0; k <= T; ++k) {
-        for (int i = 0; i < dS; ++i) in2[i] = (EP.S[(size_t)(beg + k) * dS + i] - h->stMean[i]) * h->stScale[i];
+        standardizedState(h, EP, beg + k, in2.data());
         forwardNet(h, in2.data(), series[k].X, series[k].Y, k ? &series[k - 1].Y : nullptr);
       }
       getOutput(h, series[T].Y, O.data());
     } else { forwardNet(h, inp.data(), h->X, h->Y); getOutput(h, h->Y, O.data()); }
     if (EP.isTruncated(t + 1)) {   // RACER_train.cpp:23-27
       std::vector<nnReal> inpn(dS);
-      for (int i = 0; i < dS; ++i) inpn[i] = (EP.S[(size_t)(t + 1) * dS + i] - h->stMean[i]) * h->stScale[i];
+      standardizedState(h, EP, t + 1, inpn.data());
       if (recurrent) { forwardNet(h, inpn.data(), series[T + 1].X, series[T + 1].Y, &series[T].Y); getOutput(h, series[T + 1].Y, On.data()); }
       else { forwardNet(h, inpn.data(), h->Xn, h->Yn); getOutput(h, h->Yn, On.data()); }
       const Fval Vn = (Fval)scaleNet2V(On[0]);
@@ -1257,6 +1330,7 @@ static size_t packedSize(const ol_learner* h) {
     else if (l.type == L_PARAMRES) n += 2 * (size_t)l.size;
     else if (l.type == L_PARAM) n += (size_t)l.size;
     else if (l.type == L_LSTM || l.type == L_MGU) n += (size_t)actSize(l) * (l.nIn + l.size + 1);   // Layer_LSTM.h:186-197, Layer_GRU.h:248-258
+    else if (l.type == L_CONV) n += (size_t)(l.nW + l.nB);                                          // Layer_Conv2D.h:215-231
   }
   return n;
 }
@@ -1274,6 +1348,9 @@ static void packBlob(const ol_learner* h, const std::vector<nnReal>& P, std::vec
     else if (l.type == L_LSTM || l.type == L_MGU) {   // weights, then biases, as they lie
       for (int64_t w = 0; w < (int64_t)actSize(l) * (l.nIn + l.size); ++w) out.push_back((float)W[w]);
       for (int o = 0; o < actSize(l); ++o) out.push_back((float)Bv[o]);
+    } else if (l.type == L_CONV) {                    // weights, then biases, as they lie
+      for (int64_t w = 0; w < l.nW; ++w) out.push_back((float)W[w]);
+      for (int64_t o = 0; o < l.nB; ++o) out.push_back((float)Bv[o]);
     }
   }
 }
@@ -1291,6 +1368,9 @@ static void unpackBlob(const ol_learner* h, const std::vector<float>& in, std::v
     else if (l.type == L_LSTM || l.type == L_MGU) {
       for (int64_t w = 0; w < (int64_t)actSize(l) * (l.nIn + l.size); ++w) W[w] = (nnReal)in[k++];
       for (int o = 0; o < actSize(l); ++o) Bv[o] = (nnReal)in[k++];
+    } else if (l.type == L_CONV) {
+      for (int64_t w = 0; w < l.nW; ++w) W[w] = (nnReal)in[k++];
+      for (int64_t o = 0; o < l.nB; ++o) Bv[o] = (nnReal)in[k++];
     }
   }
 }
@@ -1330,10 +1410,11 @@ int ol_sync(ol_learner*) { return HL_OK; }
 int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
   if (h->cfg.nn_type != HL_NN_FFNN) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
-  const int dS = h->dS, nOut = h->nOut;
+  // with appended observations `states` holds, per row, the raw state of step t followed by those of t-1 .. t-nAppendedObs
+  const int dS1 = h->dS, dS = dS1 * (1 + h->cfg.nAppendedObs), nOut = h->nOut;
   std::vector<nnReal> inp(dS);
   for (int r = 0; r < n; ++r) {
-    for (int i = 0; i < dS; ++i) inp[i] = (states[(size_t)r * dS + i] - h->stMean[i]) * h->stScale[i];
+    for (int i = 0; i < dS; ++i) inp[i] = (states[(size_t)r * dS + i] - h->stMean[i % dS1]) * h->stScale[i % dS1];
     forwardNet(h, inp.data(), h->X, h->Y);
     getOutput(h, h->Y, outputs + (size_t)r * nOut);
   }

@@ -42,6 +42,7 @@
 #include <chrono>
 #include <cstdio>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 
@@ -64,6 +65,52 @@ static std::vector<Uint> parseList(const std::string& s) {
   std::vector<Uint> r; std::stringstream ss(s); std::string tok;
   while (std::getline(ss, tok, ',')) if (tok.size()) r.push_back((Uint)atol(tok.c_str()));
   return r;
+}
+
+// conv=W,H,C,K,F,S;...: the arguments of Communicator::setPreprocessingConv2d (Communicator.cpp:136-162), one group per layer
+static std::vector<Conv2D_Descriptor> parseConv(const std::string& s) {
+  std::vector<Conv2D_Descriptor> r; std::stringstream ss(s); std::string grp;
+  while (std::getline(ss, grp, ';')) {
+    const std::vector<Uint> v = parseList(grp);
+    if (v.size() != 6) continue;
+    Conv2D_Descriptor d;
+    d.inpX = v[0]; d.inpY = v[1]; d.inpFeatures = v[2]; d.outFeatures = v[3];
+    d.filterx = d.filtery = v[4]; d.stridex = d.stridey = v[5]; d.paddinx = d.paddiny = 0;
+    d.outY = (d.inpY - d.filterx + 2 * d.paddinx) / d.stridex + 1;
+    d.outX = (d.inpX - d.filtery + 2 * d.paddiny) / d.stridey + 1;
+    r.push_back(d);
+  }
+  return r;
+}
+
+// Sampler of the harness for MDPs with appended observations: Episode::standardizedState (Episode.h:172-183) reads
+// states[samp - j] through an unsigned subtraction, i.e. out of bounds for samp < nAppendedObs, so the fixtures draw
+// (episode, step >= minT) pairs only -- from a generator of the harness, the learner's own is left to the Adam draws.
+// Output sorted by (episode, step) and unique, like Sample_uniform's (Sampling.cpp:82-96).
+struct RestrictedSampler : public Sampling {
+  std::mt19937 g; Uint minT;
+  RestrictedSampler(std::vector<std::mt19937>& G, MemoryBuffer* R, Uint minT_, unsigned seed) : Sampling(G, R, false), g(seed), minT(minT_) {}
+  void sample(std::vector<Uint>& seq, std::vector<Uint>& obs) override {
+    std::set<std::pair<Uint, Uint>> S;
+    const Uint nE = episodes.size();
+    while (S.size() < seq.size()) {
+      const Uint e = g() % nE, nd = episodes[e]->ndata();
+      if (nd <= minT) continue;
+      S.insert({e, minT + (Uint)(g() % (nd - minT))});
+    }
+    Uint i = 0; for (const auto& p : S) { seq[i] = p.first; obs[i] = p.second; ++i; }
+  }
+  void prepare() override {}
+  bool requireImportanceWeights() override { return false; }
+};
+
+// large parameter vectors in "lean" fixtures: every 53rd element, plus the sum and the sum of squares in double
+static bool gLean = false;
+static void writeParams(BlobWriter& W, const std::string& name, const std::vector<float>& v) {
+  if (!gLean || name == "s1_gradSum") { W.f32(name, v); return; }      // (the first gradient stays whole)
+  std::vector<float> sub; double s1 = 0, s2 = 0;
+  for (size_t i = 0; i < v.size(); ++i) { if (i % 53 == 0) sub.push_back(v[i]); s1 += v[i]; s2 += (double)v[i] * v[i]; }
+  W.f32(name + "_sub", sub); W.f64(name + "_sums", std::vector<double>{s1, s2, (double)v.size()});
 }
 
 static std::vector<uint32_t> rngState(const std::mt19937& g) {
@@ -121,6 +168,8 @@ struct Harness {
     if (dA != 1) { fprintf(stderr, "discrete harness: dimA must be 1\n"); exit(2); }
     MDP.discreteActionValues = std::vector<Uint>(1, (Uint)nOpt);
 #endif
+    MDP.nAppendedObs = (Uint)A.l("nApp", 0);
+    MDP.conv2dDescriptors = parseConv(A.s("conv", ""));
     MDP.synchronize([](void*, size_t) {});
 #ifdef REF_DISCRETE
     MDP.policyVecDim = nOpt;
@@ -152,6 +201,7 @@ struct Harness {
     algo = std::make_unique<TaskQueue>([]() { return false; });
     dataQ = std::make_unique<TaskQueue>([]() { return false; });
     L->setupTasks(*algo); L->setupDataCollectionTasks(*dataQ);
+    if (MDP.nAppendedObs > 0) const_cast<std::unique_ptr<Sampling>&>(L->data->sampler) = std::make_unique<RestrictedSampler>(info.generators, L->data.get(), MDP.nAppendedObs, (unsigned)A.l("sampleSeed", 99));
     SC.seed = (uint64_t)A.l("synthSeed", 7); SC.dimS = (int)dS; SC.dimA = (int)dA;
     SC.lenMin = (int)A.l("lenMin", 201); SC.lenMax = (int)A.l("lenMax", 201);
     SC.pTerminated = A.d("pTerm", 0.0); SC.muSpread = A.d("muSpread", 0.5);
@@ -265,6 +315,7 @@ static std::vector<float> paramsOf(const Parameters* P) {
 static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& out) {
   Harness H(info, A);
   VRACER& L = *H.L;
+  gLean = A.l("lean", 0) != 0;
   const long nEps = A.l("nEps", 40), nSteps = A.l("nSteps", 10), tapSteps = A.l("tapSteps", nSteps);
   const std::vector<Uint> gradSteps = parseList(A.s("gradSteps", "1,2"));
   const std::vector<Uint> retSteps = parseList(A.s("retSteps", ""));
@@ -281,6 +332,11 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
         (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind, (int64_t)H.nOpt,
         (int64_t)(H.HP->nnType == "LSTM" ? 1 : (H.HP->nnType == "MGU" ? 2 : 0)), (int64_t)H.HP->nnBPTTseq};
     W.i64("cfg", cfg);
+    {   // MDP preprocessing: appended observations and the convolutional layers (W, H, C, K, F, S per layer)
+      std::vector<int64_t> pre = {(int64_t)H.MDP.nAppendedObs};
+      for (const auto& d : H.MDP.conv2dDescriptors) for (int64_t v : {(int64_t)d.inpX, (int64_t)d.inpY, (int64_t)d.inpFeatures, (int64_t)d.outFeatures, (int64_t)d.filterx, (int64_t)d.stridex}) pre.push_back(v);
+      W.i64("preproc", pre);
+    }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);
     std::vector<uint8_t> bnd; for (Uint i = 0; i < H.MDP.dimAction; ++i) bnd.push_back(H.MDP.bActionSpaceBounded[i]);
@@ -294,7 +350,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       nw.push_back(PW->nWeights[l]); nb.push_back(PW->nBiases[l]); }
     W.i64("indWeights", iw); W.i64("indBiases", ib); W.i64("nWeights", nw); W.i64("nBiases", nb);
   }
-  W.f32("W0", paramsOf(PW));
+  writeParams(W, "W0", paramsOf(PW));
   W.u32("rng_before_init", rngState(info.generators[0]));
 
   // stepInit (RACER.cpp:69-79): Learner::initializeLearner
@@ -351,12 +407,12 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
         W.f64(sk + "rho", tap.rho); W.f64(sk + "dkl", tap.dkl); W.f64(sk + "dq", tap.dq);
         W.u8(sk + "far", tap.far);
       }
-      for (auto g : gradSteps) if ((long)g == k) W.f32(sk + "gradSum", paramsOf(OPT->gradSum.get()));
+      for (auto g : gradSteps) if ((long)g == k) writeParams(W, sk + "gradSum", paramsOf(OPT->gradSum.get()));
       finishStep(H);
     }
     for (auto g : gradSteps) if ((long)g == k) {
-      W.f32(sk + "W", paramsOf(PW));
-      W.f32(sk + "M1", paramsOf(OPT->_1stMom.get())); W.f32(sk + "M2", paramsOf(OPT->_2ndMom.get()));
+      writeParams(W, sk + "W", paramsOf(PW));
+      writeParams(W, sk + "M1", paramsOf(OPT->_1stMom.get())); writeParams(W, sk + "M2", paramsOf(OPT->_2ndMom.get()));
     }
     for (auto g : retSteps) if ((long)g == k) {
       std::vector<int64_t> tags; std::vector<float> ret, val, impw, dkl, dq;
@@ -383,8 +439,8 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   }
   W.f64("traj_beta", traj_beta); W.f64("traj_cmax", traj_cmax);
   W.i64("traj_nfar", traj_nfar); W.f64("traj_wnorm", traj_wnorm);
-  W.f32("Wfinal", paramsOf(PW));
-  W.f32("M1final", paramsOf(OPT->_1stMom.get())); W.f32("M2final", paramsOf(OPT->_2ndMom.get()));
+  writeParams(W, "Wfinal", paramsOf(PW));
+  writeParams(W, "M1final", paramsOf(OPT->_1stMom.get())); writeParams(W, "M2final", paramsOf(OPT->_2ndMom.get()));
   {   // the reference's own checkpoint of this state (Approximator::save -> AdamOptimizer::save -> Network::save)
     const std::string ck = A.s("ckpt", "");
     if (!ck.empty()) {

@@ -32,6 +32,14 @@ STATUS = {0: "HL_OK", 1: "HL_ERR_BAD_ARG", 2: "HL_ERR_NO_DEVICE", 3: "HL_ERR_HIP
           5: "HL_ERR_TOO_FEW_DATA", 6: "HL_ERR_COMM", 7: "HL_ERR_IO", 8: "HL_ERR_UNSUPPORTED"}
 
 
+class HlConv2d(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("inpFeatures", "inpY", "inpX", "outFeatures", "outY", "outX", "filterx", "filtery",
+                                         "stridex", "stridey", "paddinx", "paddiny")]
+
+
+HL_MAX_CONV = 8
+
+
 class HlConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("dimS", C.c_int32), ("dimA", C.c_int32),
@@ -43,7 +51,8 @@ class HlConfig(C.Structure):
         ("nnLambda", C.c_double), ("explNoise", C.c_double), ("outWeightsPrefac", C.c_double),
         ("randSeed", C.c_uint64), ("n_ranks", C.c_int32), ("rank", C.c_int32),
         ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
-        ("n_options", C.c_int32), ("nn_type", C.c_int32), ("nnBPTTseq", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("n_options", C.c_int32), ("nn_type", C.c_int32), ("nnBPTTseq", C.c_int32),
+        ("nAppendedObs", C.c_int32), ("n_conv", C.c_int32), ("conv", HlConv2d * HL_MAX_CONV), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -66,7 +75,8 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
                 maxTotObsNum=1000000, minTotObsNum=0, gamma=0.995, lambda_=1.0, clipImpWeight=4.0,
                 penalTol=0.1, epsAnneal=0.0, learnrate=1e-4, nnLambda=0.0, explNoise=0.4472135955,
                 outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
-                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0, nn_type=0, nnBPTTseq=0):
+                episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0, nn_type=0, nnBPTTseq=0,
+                nAppendedObs=0, conv=()):
     """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
     c = HlConfig()
     c.struct_size = C.sizeof(HlConfig)
@@ -81,6 +91,17 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
     c.adv_kind = adv_kind
     c.n_options = n_options if adv_kind == ADV_DISCRETE else 0
     c.nn_type, c.nnBPTTseq = nn_type, nnBPTTseq
+    # conv: (input_width, input_height, input_features, kernels_num, filters_size, stride) as passed to
+    # Communicator::setPreprocessingConv2d (Communicator.cpp:136-162)
+    c.nAppendedObs, c.n_conv = nAppendedObs, len(conv)
+    for i, (iw, ih, ic, kn, fs, st) in enumerate(conv):
+        d = c.conv[i]
+        d.inpFeatures, d.inpY, d.inpX, d.outFeatures = ic, ih, iw, kn
+        d.filterx = d.filtery = fs
+        d.stridex = d.stridey = st
+        d.paddinx = d.paddiny = 0
+        d.outY = (d.inpY - d.filterx + 2 * d.paddinx) // d.stridex + 1
+        d.outX = (d.inpX - d.filtery + 2 * d.paddiny) // d.stridey + 1
     c.batchSize = batchSize
     c.maxTotObsNum, c.minTotObsNum = int(maxTotObsNum), int(minTotObsNum)
     c.gamma, c.lambda_, c.clipImpWeight, c.penalTol = gamma, lambda_, clipImpWeight, penalTol
@@ -214,6 +235,7 @@ class Learner:
         self.nParams = api.fn("num_params")(self.h)
         self.nOut = api.fn("num_outputs")(self.h)
         self.dS, self.dA = cfg.dimS, cfg.dimA
+        self.dIn = cfg.dimS * (1 + cfg.nAppendedObs)      # network input: the observed state and the appended past ones
         self.nOptions = cfg.n_options                      # discrete head: options of the one action variable
         self.polDim = cfg.n_options if cfg.n_options else 2 * cfg.dimA
         self.B = max(1, cfg.batchSize // cfg.n_ranks) if cfg.batchSize > 1 else cfg.batchSize
@@ -389,7 +411,7 @@ class Learner:
 
     def forward(self, states):
         """Network outputs [n][nOut] (float64) for raw states [n][dimS] with the current weights."""
-        st = np.ascontiguousarray(states, dtype=np.float32).reshape(-1, self.dS)
+        st = np.ascontiguousarray(states, dtype=np.float32).reshape(-1, self.dIn)
         out = np.zeros((st.shape[0], self.nOut), np.float64)
         self._ck(self.api.fn("forward")(self.h, st.shape[0], _ptr(st, C.c_float), _ptr(out, C.c_double)))
         return out
@@ -405,7 +427,7 @@ class Learner:
         B, nO = self.B, self.nOut
         shape, dt = {
             TAP_FLAT: ((B,), np.int64), TAP_EPISODE: ((B,), np.int64), TAP_TSTEP: ((B,), np.int64),
-            TAP_TAG: ((B,), np.int64), TAP_STATE: ((B, self.dS), np.float32),
+            TAP_TAG: ((B,), np.int64), TAP_STATE: ((B, self.dIn), np.float32),
             TAP_OUTPUT: ((B, nO), np.float64), TAP_OUTGRAD: ((B, nO), np.float64),
             TAP_RHO: ((B,), np.float64), TAP_DKL: ((B,), np.float64), TAP_DELTAQ: ((B,), np.float64),
             TAP_FAR: ((B,), np.uint8), TAP_GRADSUM: ((self.nParams,), np.float32)}[what]

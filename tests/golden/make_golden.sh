@@ -40,6 +40,17 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
 # G-discrete: RACER with Discrete_policy / Discrete_advantage (one action variable, 4 options)
 "$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/racer_discrete.bin" dimS=5 dimA=1 nOpt=4 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_disc" pack=4 memck="$TMP/mem_disc"
+# G-conv-small: discrete RACER behind two convolutional layers (8x8x16 -> k4 -> 5x5x32 -> k3 -> 3x3x64; shapes 6 and 7 of
+# Network/Builder.cpp:189-203) on states of 1 + 3 appended observations; (episode, t >= 3) pairs from the harness' sampler;
+# "lean": parameter-sized vectors as every 53rd element + sums, the first gradient whole
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/conv_small.bin" dimS=256 dimA=1 nOpt=4 nApp=3 "conv=8,8,16,32,4,1;5,5,32,64,3,1" \
+   layers=64 nnFunc=Tanh batch=16 nEps=30 lenMin=6 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 \
+   lean=1 ckpt="$TMP/ck_conv"
+# G-atari: the RACER_atari.json shape (BASELINE config 5): 84x84 frames x (1 + 3), four SoftSign convolutions, dense 576 -> 512 (Tanh,
+# the code default: the settings file names no nnFunc) + parametric residual, 6 options (Pong), batch 128
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/racer_atari.bin" dimS=7056 dimA=1 nOpt=6 nApp=3 \
+   "conv=84,84,4,8,8,4;20,20,8,16,6,2;8,8,16,32,4,1;5,5,32,64,3,1" layers=512 nnFunc=Tanh batch=128 nEps=24 lenMin=8 lenMax=18 pTerm=0.5 \
+   nSteps=3 gradSteps=1,3 maxObs=262144 minObs=131072 gamma=0.99 explNoise=0.05 lean=1
 # official-vs-manual cross check of the harness itself (weights must be bit-identical)
 "$DRV" fixture "$TMP/off.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 maxObs=2000 minObs=500 path=official

@@ -27,6 +27,10 @@ def fixture_config(fx, **over):
               maxTotObsNum=int(hp[12]), clipImpWeight=hp[0], penalTol=hp[1], epsAnneal=hp[2], gamma=hp[3],
               lambda_=hp[4], learnrate=hp[5], explNoise=hp[6], outWeightsPrefac=hp[7], nnLambda=hp[8],
               randSeed=42, nnFunc=func or "SoftSign")
+    if "preproc" in fx:      # appended observations and convolutional layers (W, H, C, K, F, S per layer) of the MDP
+        pre = [int(x) for x in fx["preproc"]]
+        kw["nAppendedObs"] = pre[0]
+        kw["conv"] = [tuple(pre[1 + 6 * i:7 + 6 * i]) for i in range((len(pre) - 1) // 6)]
     kw.update(over)
     return capi.make_config(**kw)
 
@@ -41,6 +45,31 @@ def fixture_synth(fx):
 def relinf(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def fx_vec_dev(fx, key, mine):
+    """Deviation of a parameter-sized vector from the fixture's: the whole vector, or -- "lean" fixtures of large
+    networks (oracle/ref_driver.cpp: writeParams) -- every 53rd element plus the sum and the sum of squares."""
+    m = np.asarray(mine, np.float64)
+    if key in fx:
+        return relinf(m, fx[key])
+    sub, (s1, s2, n) = np.asarray(fx[key + "_sub"], np.float64), fx[key + "_sums"]
+    assert int(n) == m.size, (key, n, m.size)
+    scale = max(np.abs(m).max(), 1e-300)
+    d = np.abs(m[::53] - sub).max() / scale
+    d = max(d, abs(m.sum() - s1) / max(np.abs(m).sum(), 1e-300), abs((m * m).sum() - s2) / max(2 * s2, 1e-300))
+    return float(d)
+
+
+def flat_for(L, tags, ts):
+    """flat indices (in the learner's own episode order) selecting the given (tag, t) pairs"""
+    n = L.scalars().nStoredEps
+    prefix, acc = {}, 0
+    for k in range(n):
+        tag, N, _ = L.episode_info(k)
+        prefix[tag] = acc
+        acc += N - 1
+    return np.array([prefix[int(g)] + int(t) for g, t in zip(tags, ts)], np.int64)
 
 
 def setup_from_fixture(L, fx, use_fixture_weights=False):

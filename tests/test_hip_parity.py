@@ -8,7 +8,7 @@ import pytest
 
 from oracle_api import oracle_learner, fill_synth, synth_cfg, synth_episode
 from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
-                    episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree)
+                    episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree, fx_vec_dev, flat_for)
 from smarties_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -22,15 +22,7 @@ def hip_learner(hip_api, cfg):
     return capi.Learner(hip_api, cfg)
 
 
-def our_flat_for(L, tags, ts):
-    """flat indices (in the library's own episode order) selecting the given (tag, t) pairs"""
-    n = L.scalars().nStoredEps
-    prefix, acc = {}, 0
-    for k in range(n):
-        tag, N, _ = L.episode_info(k)
-        prefix[tag] = acc
-        acc += N - 1
-    return np.array([prefix[int(g)] + int(t) for g, t in zip(tags, ts)], np.int64)
+our_flat_for = flat_for
 
 
 @pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])

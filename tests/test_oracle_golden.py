@@ -5,7 +5,7 @@ import pytest
 
 from oracle_api import oracle_learner, synth_episode
 from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
-                    episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree)
+                    episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree, fx_vec_dev, flat_for)
 from smarties_amd import capi
 
 FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh"}
@@ -92,6 +92,80 @@ def test_steps_match_reference(name):
         assert sca.nFarPolicySteps == fx["traj_nfar"][k - 1]
     w, _, _ = L.get_params()
     assert relinf(w, fx["Wfinal"]) < 1e-6
+
+
+CONV_FIXTURES = ["conv_small.bin", "racer_atari.bin"]
+CONV_FUNC = {"conv_small.bin": "Tanh", "racer_atari.bin": "Tanh"}      # (settings/RACER_atari.json leaves nnFunc at its default)
+
+
+@pytest.mark.parametrize("name", CONV_FIXTURES)
+def test_conv_layout_init_and_initialize_match_reference(name):
+    """Convolutional preprocessing (Approximator::buildPreprocessing -> Builder::addConv2d -> Conv2DLayer): blob layout with one
+    bias per output element, Conv2DLayer::initialize draw order, checkpoint packing, then initializeLearner on states of
+    (1 + nAppendedObs) frames."""
+    fx = load_fixture(name)
+    L = oracle_learner(fixture_config(fx, nnFunc=CONV_FUNC[name], episode_order=capi.ORDER_REFERENCE))
+    assert L.nParams == int(fx["cfg"][5]) and L.nOut == int(fx["cfg"][6])
+    lay = L.layout()
+    assert np.array_equal(lay["indW"], fx["indWeights"]) and np.array_equal(lay["indB"], fx["indBiases"])
+    assert np.array_equal(lay["nW"], fx["nWeights"]) and np.array_equal(lay["nB"], fx["nBiases"])
+    L.init_weights()
+    w0 = L.get_params()[0]
+    assert fx_vec_dev(fx, "W0", w0) < 1e-12 and ("W0" in fx or np.array_equal(w0[::53], fx["W0_sub"]))   # (sums: summation order only)
+    assert np.array_equal(L.get_rng_state(), fx["rng_before_init"])
+    L = oracle_learner(fixture_config(fx, nnFunc=CONV_FUNC[name], episode_order=capi.ORDER_REFERENCE))
+    setup_from_fixture(L, fx)
+    s = L.scalars()
+    assert s.nStoredSteps == int(fx["cfg"][7]) and s.beta == fx["beta0"][0] and s.CmaxRet == fx["cmax0"][0]
+    m, sc, r = L.get_scaling()
+    assert np.array_equal(np.concatenate([m, sc, r]), fx["scaling0"])
+    assert np.array_equal(L.get_rng_state(), fx["rng0"])
+
+
+@pytest.mark.parametrize("name", CONV_FIXTURES)
+def test_conv_steps_match_reference(name, tmp_path):
+    """Steps on the (episode, t >= nAppendedObs) pairs the harness drew (oracle/ref_driver.cpp: RestrictedSampler): stacked
+    standardised frames -> SoftSign convolutions -> dense + parametric residual over the first conv outputs -> discrete RACER
+    head; outputs, rho, D_KL, gradients, Adam update against the compiled reference."""
+    fx = load_fixture(name)
+    L = oracle_learner(fixture_config(fx, nnFunc=CONV_FUNC[name], episode_order=capi.ORDER_REFERENCE))
+    setup_from_fixture(L, fx)
+    L.set_tap(True)
+    nSteps = int(fx["cfg"][4])
+    for k in range(1, nSteps + 1):
+        sk = "s%d_" % k
+        assert np.array_equal(L.get_rng_state(), fx[sk + "rng"]), k      # only the Adam draws advance the learner's generator
+        flat = flat_for(L, fx[sk + "tag"], fx[sk + "t"])
+        assert np.all(np.diff(flat) > 0)
+        L.step(1, flat=flat)
+        assert np.array_equal(L.readback(capi.TAP_TAG), fx[sk + "tag"]) and np.array_equal(L.readback(capi.TAP_TSTEP), fx[sk + "t"])
+        assert relinf(L.readback(capi.TAP_OUTPUT), fx[sk + "O"]) < 2e-6
+        assert relinf(L.readback(capi.TAP_RHO), fx[sk + "rho"]) < 2e-6
+        assert relinf(L.readback(capi.TAP_DKL), fx[sk + "dkl"]) < 2e-6
+        assert relinf(L.readback(capi.TAP_DELTAQ), fx[sk + "dq"]) < 2e-6
+        assert relinf(L.readback(capi.TAP_OUTGRAD), fx[sk + "G"]) < 2e-6
+        assert np.array_equal(L.readback(capi.TAP_FAR), fx[sk + "far"])
+        if sk + "gradSum" in fx or sk + "gradSum_sub" in fx:
+            assert fx_vec_dev(fx, sk + "gradSum", L.readback(capi.TAP_GRADSUM)) < 1e-5
+        if sk + "W" in fx or sk + "W_sub" in fx:
+            w, m1, m2 = L.get_params()
+            assert fx_vec_dev(fx, sk + "W", w) < 1e-6
+            assert fx_vec_dev(fx, sk + "M1", m1) < 1e-5 and fx_vec_dev(fx, sk + "M2", m2) < 1e-5
+        sca = L.scalars()
+        assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-14 * abs(sca.beta)
+        assert sca.nFarPolicySteps == fx["traj_nfar"][k - 1]
+    w, m1, m2 = L.get_params()
+    assert fx_vec_dev(fx, "Wfinal", w) < 1e-6
+    if "ckpt_net_weights" in fx:      # Conv2DLayer::save (Layer_Conv2D.h:215-231): filters, then biases, as they lie
+        ref = np.frombuffer(bytes(bytearray(fx["ckpt_net_weights"])), np.float32)
+        base = str(tmp_path / "agent_00_net")
+        L.save(base)
+        mine = np.fromfile(base + "_weights.raw", np.float32)
+        assert mine.size == ref.size and relinf(mine, ref) < 1e-6
+        L2 = oracle_learner(fixture_config(fx, nnFunc=CONV_FUNC[name]))
+        open(str(tmp_path / "ref_net_weights.raw"), "wb").write(ref.tobytes())
+        L2.init_weights(); L2.restart(str(tmp_path / "ref_net")); L2.save(str(tmp_path / "again"))
+        assert np.array_equal(np.fromfile(str(tmp_path / "again_weights.raw"), np.float32), ref)
 
 
 def test_far_policy_masks_are_exercised():
