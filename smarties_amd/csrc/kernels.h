@@ -13,6 +13,8 @@ struct SampleArgs {
   int adamDraws;          // mt19937 draws consumed by the Adam step (Optimizer.cpp:139)
   int parity;             // minibatch buffer written (bt / X0 passed here belong to it)
   int computeEta;         // also derive DevScalars::etaEff[parity] (first step of a launch sequence)
+  int noGather;           // phase C stops after the index -> (episode, step) search: the states are gathered by
+                          // stack_gather_kernel (appended observations / convolutional input, conv.hip)
   int backupRng;          // keep the generator state as of before the draws in DevScalars::rngBak (pre-sampling riders)
   float eta0; double epsAnneal;
 };
@@ -54,6 +56,31 @@ struct RecArgs {
 };
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);
+
+// convolutional preprocessing (conv.hip): one layer's geometry and buffers
+struct ConvGeo {
+  int InC, InY, InX, KnC, KnY, KnX, S, OpY, OpX;
+  int K, P;                  // InC KnY KnX (patch size), OpY OpX (output positions)
+  int ldIn, ldOut;           // row pitch of the input / output activation arrays
+  long long indW, indB;      // filter [KnC][InC][KnY][KnX] and bias [KnC][OpY][OpX] in the parameter blob
+  const float* in;           // [rows][ldIn]  input images (first layer: the standardised stacked states)
+  float* X; float* Y;        // [rows][ldOut] pre-activation / output, [c][oy][ox] per row
+  float* D;                  // [B][ldOut]    dL/dX of this layer
+  float* part;               // [nChunks][KnC K] partial filter gradients
+  int nChunks, chunkRows, dwBlock0;   // reduction chunks of the filter gradient; first workgroup of this layer in the dW launch
+};
+struct ConvArgs {
+  DevScalars* sc; int parity, B, nL;
+  const float* W; float* Wrw; float* M1; float* M2; float* G;
+  ConvGeo L[HL_MAX_CONV];
+};
+struct StackGatherArgs { DevScalars* sc; DevReplay rp; DevBatch bt; int B, dS, nApp, parity; float* X0; int ldX0; };
+struct AdamHyper;
+hipError_t launch_stack_gather(const StackGatherArgs& a, int maxRows, hipStream_t s);
+hipError_t launch_conv_forward(const ConvArgs& a, int l, int maxRows, hipStream_t s);
+hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s);       // D of layer l-1 from D of layer l
+hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);
+hipError_t launch_conv_reduce_adam(const ConvArgs& a, const AdamHyper& hyp, int fuseAdam, hipStream_t s);
 
 struct PostArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
@@ -128,7 +155,7 @@ size_t fused_lds_bytes(int dS, int H);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
-hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0, hipStream_t s);
+hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s);
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
                              int nDense, int dA, int n, double* O, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);

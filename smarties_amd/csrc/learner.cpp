@@ -50,6 +50,11 @@ struct hl_learner {
   int dev = 0;
   hipStream_t stream = nullptr;
   int dS = 0, dA = 0, B = 0, Bglobal = 0, nOut = 0, nDense = 0, nAdv = 0, nHidden = 0, Mmax = 0;
+  // appended past observations / convolutional preprocessing (conv.hip): the network input is dIn = dS (1 + nApp) wide and
+  // gathered by its own kernel; with convolutions hid[0] stands for the last convolutional layer (its X, Y, D, Dres are that
+  // layer's), hid[1..] are the dense blocks behind it
+  bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
+  ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
   RecLayer rec[HL_MAX_HIDDEN]{};
   int nOpt = 0, polDim = 0, nSig = 0;      // discrete head: options; entries of a stored policy (2 dA | nOpt); sigma ParamLayer size (dA | 0)
@@ -92,7 +97,7 @@ struct hl_learner {
   // indices, a generator read-out) first puts the generator back (dropPresample)
   bool preValid = false; int preParity = 0;
   long long nCollectives = 0;              // RCCL calls issued or captured so far (tests: every path speaks the same wire protocol)
-  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM, 5 MGU (ld = gates x cells)
+  struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM, 5 MGU (ld = gates x cells), 6 convolution (nIn = filter floats, size = biases)
   std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
@@ -173,9 +178,18 @@ int buildNet(hl_learner* h) {
   h->indW.clear(); h->nW.clear(); h->indB.clear(); h->nB.clear();
   std::vector<long long> lw, lb;          // per layer requested sizes
   lw.push_back(0); lb.push_back(0);       // input layer
-  int prev = c.dimS, nH = 0;
+  int prev = c.dimS * (1 + c.nAppendedObs), nH = 0;
   struct Tmp { int nIn, size, hasRes; int denseLayer, resLayer; };
   std::vector<Tmp> hs;
+  // Approximator::buildPreprocessing -> Builder::addConv2d (Approximator.cpp:231-271, Builder.cpp:172-215): SoftSign
+  // convolutions right behind the input, no skip connections; filter KnC InC KnY KnX floats, one bias per output element
+  std::vector<int> convLayer;
+  for (int j = 0; j < c.n_conv; ++j) {
+    const hl_conv2d& d = c.conv[j];
+    convLayer.push_back((int)lw.size());
+    lw.push_back((long long)d.outFeatures * d.inpFeatures * d.filtery * d.filterx); lb.push_back((long long)d.outFeatures * d.outY * d.outX);
+    prev = d.outFeatures * d.outY * d.outX;
+  }
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
@@ -188,7 +202,9 @@ int buildNet(hl_learner* h) {
     hs.push_back(t); prev = t.size; ++nH;
   }
   if (nH < 1) return HL_ERR_BAD_ARG;
-  h->nHidden = nH;
+  const int hOff = c.n_conv > 0 ? 1 : 0;      // hid[0] = the last convolutional layer
+  if (nH + hOff > HL_MAX_HIDDEN) return HL_ERR_UNSUPPORTED;
+  h->nHidden = nH + hOff;
   // VRACER: [V, mean]; RACER with the Gaussian advantage: [V, coef, L+, L-, mean] (RACER_common.cpp:172-186)
   // RACER discrete: [V, A x nOpt, logits x nOpt], no sigma layer (RACER_common.cpp:119-134)
   const bool discrete = c.adv_kind == HL_ADV_DISCRETE;
@@ -205,8 +221,22 @@ int buildNet(hl_learner* h) {
     h->indB.push_back(tot); h->nB.push_back(lb[l]); tot += roundUp(lb[l], 8);
   }
   h->nParams = tot;
+  h->nConv = c.n_conv;
+  for (int j = 0; j < c.n_conv; ++j) {
+    const hl_conv2d& d = c.conv[j]; ConvGeo& g = h->cg[j];
+    g = ConvGeo{};
+    g.InC = d.inpFeatures; g.InY = d.inpY; g.InX = d.inpX; g.KnC = d.outFeatures; g.KnY = d.filtery; g.KnX = d.filterx;
+    g.S = d.stridex; g.OpY = d.outY; g.OpX = d.outX; g.K = g.InC * g.KnY * g.KnX; g.P = g.OpY * g.OpX;
+    g.indW = h->indW[convLayer[j]]; g.indB = h->indB[convLayer[j]];
+  }
+  if (hOff) {
+    const ConvGeo& g = h->cg[c.n_conv - 1];
+    DevHidden& d = h->hid[0]; d = DevHidden{};
+    d.nIn = g.K; d.size = g.KnC * g.P; d.ldW = 0; d.func = HL_FUNC_SOFTSIGN; d.hasRes = 0; d.resW = 0; d.lstm = 0;
+    d.ldA = (int)roundUp(d.size, 16);
+  }
   for (int j = 0; j < nH; ++j) {
-    DevHidden& d = h->hid[j];
+    DevHidden& d = h->hid[j + hOff];
     d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : 0);   // gates per cell (0: dense)
     d.ldW = d.lstm ? d.lstm * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
     d.indW = h->indW[hs[j].denseLayer]; d.indB = h->indB[hs[j].denseLayer];
@@ -218,6 +248,7 @@ int buildNet(hl_learner* h) {
   h->indWo = h->indW[outLayer]; h->indBo = h->indB[outLayer]; h->ldWo = (int)roundUp(h->nDense, 8);
   h->indBp = paramLayer >= 0 ? h->indB[paramLayer] : 0;
   h->lay.clear();
+  for (int j = 0; j < c.n_conv; ++j) h->lay.push_back({6, (int)lw[convLayer[j]], (int)lb[convLayer[j]], 0, h->indW[convLayer[j]], h->indB[convLayer[j]]});
   for (int j = 0; j < nH; ++j) {
     if (c.nn_type == HL_NN_LSTM) h->lay.push_back({4, hs[j].nIn, hs[j].size, 4 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     else if (c.nn_type == HL_NN_MGU) h->lay.push_back({5, hs[j].nIn, hs[j].size, 2 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
@@ -439,6 +470,19 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     if (cfg->dimS > 256) return HL_ERR_UNSUPPORTED;
     for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
   }
+  if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
+  if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
+  for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
+    const hl_conv2d& d = cfg->conv[j];
+    const long long inSize = (long long)d.inpFeatures * d.inpY * d.inpX;
+    const long long prev = j == 0 ? (long long)cfg->dimS * (1 + cfg->nAppendedObs)
+                                  : (long long)cfg->conv[j - 1].outFeatures * cfg->conv[j - 1].outY * cfg->conv[j - 1].outX;
+    if (inSize != prev || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.filterx < 1 || d.filtery < 1) return HL_ERR_BAD_ARG;
+    if (d.outY != (d.inpY - d.filtery + 2 * d.paddiny) / d.stridey + 1 || d.outX != (d.inpX - d.filterx + 2 * d.paddinx) / d.stridex + 1) return HL_ERR_BAD_ARG;
+    // conv.hip: zero padding, one power-of-two stride, <= 64 channels per layer, filters <= 32 wide
+    if (d.paddinx || d.paddiny || d.stridex != d.stridey || (d.stridex & (d.stridex - 1)) || d.stridex > 8) return HL_ERR_UNSUPPORTED;
+    if (d.outFeatures > 64 || d.inpFeatures > 64 || d.filterx > 31 || d.filtery > 63 || (long long)d.outFeatures * d.outY * d.outX >= (1 << 20)) return HL_ERR_UNSUPPORTED;
+  }
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return HL_ERR_NO_DEVICE;
   hl_learner* h = new hl_learner();
@@ -452,7 +496,9 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->Bglobal = cfg->batchSize > 1 ? (int)(std::ceil(cfg->batchSize / nL) * nL) : cfg->batchSize;
   h->B = cfg->batchSize > 1 ? h->Bglobal / cfg->n_ranks : h->Bglobal;
   if (h->B > 1024) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024");
-  if (h->dS > 512) return fail(h, HL_ERR_UNSUPPORTED, "more than 512 observed state components");   // gather staging (tail_dev.h)
+  h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);
+  h->preproc = h->nApp > 0 || cfg->n_conv > 0;       // the states are gathered by stack_gather_kernel (conv.hip)
+  if (!h->preproc && h->dS > 512) return fail(h, HL_ERR_UNSUPPORTED, "more than 512 observed state components");   // gather staging (tail_dev.h)
   for (int j = 0; j < cfg->n_hidden; ++j)
     if (cfg->hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
   h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);
@@ -468,13 +514,31 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(devAlloc(&h->W, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams + PARAM_TAIL));
   HIPCK(devAlloc(&h->M2, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->G, (size_t)h->nParams + PARAM_TAIL));
   HIPCK(devAlloc(&h->sc, 1));
-  h->ldX0 = (int)roundUp(h->dS, 16);
+  h->ldX0 = (int)roundUp(h->dIn, 16);
   for (int j = 0; j < h->nHidden; ++j) {
     DevHidden& d = h->hid[j];
     const size_t n = (size_t)h->Mmax * d.ldA;
     HIPCK(devAlloc(&d.X, n)); HIPCK(devAlloc(&d.Y, n));
     if (d.hasRes) HIPCK(devAlloc(&d.Rr, n)); else d.Rr = nullptr;
     HIPCK(devAlloc(&d.D, (size_t)B * d.ldA)); HIPCK(devAlloc(&d.Dres, (size_t)B * d.ldA));
+  }
+  {   // convolutional layers: activations per layer (the last one's are hid[0]'s), chunking of the filter-gradient reduction
+    int blk = 0;
+    for (int l = 0; l < h->nConv; ++l) {
+      ConvGeo& g = h->cg[l];
+      g.ldIn = l == 0 ? h->ldX0 : h->cg[l - 1].ldOut;
+      g.ldOut = (int)roundUp((long long)g.KnC * g.P, 16);
+      if (l == h->nConv - 1) { g.X = h->hid[0].X; g.Y = h->hid[0].Y; g.D = h->hid[0].D; }
+      else { HIPCK(devAlloc(&g.X, (size_t)h->Mmax * g.ldOut)); HIPCK(devAlloc(&g.Y, (size_t)h->Mmax * g.ldOut)); HIPCK(devAlloc(&g.D, (size_t)B * g.ldOut)); }
+      const long long R = (long long)B * g.P;                    // rows of the filter-gradient reduction
+      const int tiles = ((g.K + 15) / 16) * ((g.KnC + 15) / 16);
+      long long rowsPer = std::max<long long>(64, (R * tiles + 1023) / 1024);   // about a thousand workgroups per layer
+      rowsPer = std::min<long long>(roundUp(rowsPer, 16), 2048);
+      g.chunkRows = (int)rowsPer; g.nChunks = (int)((R + rowsPer - 1) / rowsPer);
+      g.dwBlock0 = blk; blk += g.nChunks * tiles;
+      HIPCK(devAlloc(&g.part, (size_t)g.nChunks * g.KnC * g.K));
+    }
+    h->convDwBlocks = blk;
   }
   h->recurrent = cfg->nn_type != HL_NN_FFNN;
   if (h->recurrent) {
@@ -496,7 +560,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces
     const char* e = getenv("SMARTIES_HIP_NO_FUSED");
     const bool off = e && e[0] == '1';
-    if (!off && h->nHidden == 2 && !h->recurrent) {
+    if (!off && h->nHidden == 2 && !h->recurrent && !h->preproc) {
       const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
       h->fusedOk = d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nAdv == 0 && h->nDense <= 8 && h->ldWo == 8 &&
                    !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
@@ -531,7 +595,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(devAlloc(&h->dFlatGiven, B));
   HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16));
   HIPCK(devAlloc(&h->rp.stMean, h->dS)); HIPCK(devAlloc(&h->rp.stScale, h->dS)); HIPCK(devAlloc(&h->rp.stStd, h->dS));
-  rc = growSlots(h, h->maxObsLocal + h->maxObsLocal / 8 + 8192); if (rc) return rc;
+  {   // ring slack: an eighth of the budget plus room for the episodes in flight (bounded in bytes for image-sized states)
+    const long long slack = std::max<long long>(512, std::min<long long>(8192, (64ll << 20) / ((long long)h->dS * 4)));
+    rc = growSlots(h, h->maxObsLocal + h->maxObsLocal / 8 + slack); if (rc) return rc;
+  }
   rc = growEpisodes(h, 4096); if (rc) return rc;
   // initial scalars (MemoryBuffer.h:41-44; Optimizer.h:96; ExecutionInfo.cpp:387,391)
   DevScalars s0; std::memset(&s0, 0, sizeof(s0));
@@ -574,6 +641,9 @@ int hl_destroy(hl_learner* h) {
   }
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd, h->rec[j].A2}) if (q) hipFree(q);
   for (void* p : ptrs) if (p) hipFree(p);
+  for (int l = 0; l < h->nConv; ++l) { ConvGeo& g = h->cg[l];
+    if (l != h->nConv - 1) for (float* p : {g.X, g.Y, g.D}) if (p) hipFree(p);
+    if (g.part) hipFree(g.part); }
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);
@@ -614,7 +684,12 @@ int hl_init_weights(hl_learner* h) {
     return 1;
   };
   std::vector<float> W((size_t)h->nParams, 0.f);
-  for (int j = 0; j < h->nHidden; ++j) {
+  for (int l = 0; l < h->nConv; ++l) {     // Conv2DLayer::initialize (Layer_Conv2D.h:198-213): fan-in InC KnX KnY, fan-out KnC, biases zero
+    const ConvGeo& g = h->cg[l];
+    const float init = (float)initFactor(HL_FUNC_SOFTSIGN, g.K, g.KnC);
+    for (long long w = 0; w < (long long)g.KnC * g.K; ++w) W[g.indW + w] = uni(-init, init);
+  }
+  for (int j = h->nConv > 0 ? 1 : 0; j < h->nHidden; ++j) {
     const DevHidden& d = h->hid[j];
     const float fac = 1; const float init = fac * initFactor(d.func, d.nIn, d.size);
     if (d.lstm) {   // Layer_LSTM.h:167-185 / Layer_GRU.h:232-246: forget gates start open, input / output gates closed; weights in memory order
@@ -1198,6 +1273,9 @@ static void packBlob(const hl_learner* h, const std::vector<float>& P, std::vect
     } else if (l.type == 4 || l.type == 5) {     // LSTMLayer::save / MGULayer::save (Layer_LSTM.h:186-197, Layer_GRU.h:248-258): weights, then biases, as they lie
       for (long long w = 0; w < (long long)l.ld * (l.nIn + l.size); ++w) out.push_back(W[w]);
       for (int o = 0; o < l.ld; ++o) out.push_back(Bv[o]);
+    } else if (l.type == 6) {                    // Conv2DLayer::save (Layer_Conv2D.h:215-231): filters, then biases, as they lie
+      for (int w = 0; w < l.nIn; ++w) out.push_back(W[w]);
+      for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
     } else for (int o = 0; o < l.size; ++o) out.push_back(Bv[o]);
   }
 }
@@ -1214,6 +1292,9 @@ static void unpackBlob(const hl_learner* h, const std::vector<float>& in, std::v
     } else if (l.type == 4 || l.type == 5) {
       for (long long w = 0; w < (long long)l.ld * (l.nIn + l.size); ++w) W[w] = in[k++];
       for (int o = 0; o < l.ld; ++o) Bv[o] = in[k++];
+    } else if (l.type == 6) {
+      for (int w = 0; w < l.nIn; ++w) W[w] = in[k++];
+      for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
     } else for (int o = 0; o < l.size; ++o) Bv[o] = in[k++];
   }
 }
@@ -1243,7 +1324,8 @@ int hl_restart(hl_learner* h, const char* base) {
   int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
   size_t n = 0;
   for (const auto& l : h->lay) n += l.type == 1 ? (size_t)l.size * (l.nIn + 1) : (l.type == 2 ? 2 * (size_t)l.size :
-                                  (l.type == 4 || l.type == 5 ? (size_t)l.ld * (l.nIn + l.size + 1) : (size_t)l.size));
+                                  (l.type == 4 || l.type == 5 ? (size_t)l.ld * (l.nIn + l.size + 1) :
+                                   (l.type == 6 ? (size_t)l.nIn + l.size : (size_t)l.size)));
   const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
   for (int b = 0; b < 3; ++b) {
     const std::string name = std::string(base) + suf[b] + ".raw";
@@ -1263,13 +1345,14 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward between hl_step_begin and hl_step_end");
   if (h->recurrent) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
   { int rc = dropPresample(h); if (rc) return rc; }      // the forward pass borrows minibatch buffer 0
-  if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->Mmax * h->dS)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
+  // (with appended observations a row holds the raw state of step t followed by those of t-1 .. t-nAppendedObs)
+  if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->Mmax * h->dIn)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
   const DevHidden& q = h->hid[h->nHidden - 1];
   for (int r0 = 0; r0 < n; r0 += h->Mmax) {
     const int m = std::min(h->Mmax, n - r0);
-    HIPCK(hipMemcpyAsync(h->dActS, states + (size_t)r0 * h->dS, (size_t)m * h->dS * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, m, h->dS, h->buf[0].X0, h->ldX0, h->stream));
-    int rc = launchForward(h, 0, h->stream); if (rc) return rc;
+    HIPCK(hipMemcpyAsync(h->dActS, states + (size_t)r0 * h->dIn, (size_t)m * h->dIn * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, m, h->dS, h->dIn, h->buf[0].X0, h->ldX0, h->stream));
+    int rc = launchForward(h, 0, h->stream, false, /*gather*/false); if (rc) return rc;
     HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, m,
                             h->dActO, h->stream));
     HIPCK(hipMemcpyAsync(outputs + (size_t)r0 * h->nOut, h->dActO, (size_t)m * h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1324,8 +1407,8 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
       return HL_OK;
     }
     case HL_TAP_STATE: {
-      if (bytes < (int64_t)B * h->dS * 4) return HL_ERR_BAD_ARG;
-      HIPCK(hipMemcpy2D(dst, h->dS * 4, h->buf[h->lastParity].X0, h->ldX0 * 4, h->dS * 4, B, hipMemcpyDeviceToHost));
+      if (bytes < (int64_t)B * h->dIn * 4) return HL_ERR_BAD_ARG;
+      HIPCK(hipMemcpy2D(dst, (size_t)h->dIn * 4, h->buf[h->lastParity].X0, (size_t)h->ldX0 * 4, (size_t)h->dIn * 4, B, hipMemcpyDeviceToHost));
       return HL_OK;
     }
     case HL_TAP_OUTPUT: return copy(bt.O, (int64_t)B * h->nOut * 8);

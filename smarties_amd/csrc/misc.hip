@@ -299,10 +299,13 @@ hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out
 // rollout inference (hl_forward): standardise raw states into the minibatch rows, run the forward
 // GEMMs of the training path on them, then the Linear output layer + ParamLayer as doubles
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void act_standardize_kernel(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// dIn = dS (1 + nAppendedObs): a row holds the raw state of step t followed by the appended past ones, each standardised
+// with the per-component mean / scale (Episode::standardizedState, Episode.h:172-183)
+__global__ __launch_bounds__(256) void act_standardize_kernel(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i == 0) { sc->nRows[0] = n; sc->nNext[0] = 0; }     // rows the forward GEMMs of buffer 0 will process
-  if (i < n * dS) { const int r = i / dS, c = i - r * dS; X0[(size_t)r * ldX0 + c] = (S[i] - rp.stMean[c]) * rp.stScale[c]; }
+  if (i < (long long)n * dIn) { const int r = (int)(i / dIn), c = (int)(i - (long long)r * dIn), k = c % dS;
+    X0[(size_t)r * ldX0 + c] = (S[i] - rp.stMean[k]) * rp.stScale[k]; }
 }
 __global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo,
                                                          long long indBp, int ldWo, int nDense, int dA, int n, double* O) {
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY
   }
   if (lane < dA) O[(size_t)row * nOut + nDense + lane] = (double)W[indBp + lane];
 }
-hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, float* X0, int ldX0, hipStream_t s) {
-  hipLaunchKernelGGL(act_standardize_kernel, dim3((n * dS + 255) / 256 + 1), dim3(256), 0, s, sc, rp, S, n, dS, X0, ldX0);
+hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s) {
+  hipLaunchKernelGGL(act_standardize_kernel, dim3((unsigned)(((long long)n * dIn + 255) / 256 + 1)), dim3(256), 0, s, sc, rp, S, n, dS, dIn, X0, ldX0);
   return hipGetLastError();
 }
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,

@@ -43,8 +43,11 @@ int buildProblems(hl_learner* h) {
   for (int pb = 0; pb < 2; ++pb) {
     StepBuf& sb = h->buf[pb];
     sb.fwdIdx.clear(); sb.fwdBlocks.clear(); sb.dxIdx.clear(); sb.dxBlocks.clear();
-    // forward: one launch per hidden block (dense layers; LSTM layers have their own kernels, rec.hip)
-    for (int j = 0; j < nH && !h->recurrent; ++j) {
+    // forward: one launch per hidden block (dense layers; LSTM layers have their own kernels, rec.hip; with convolutional
+    // preprocessing hid[0] is the last convolution, computed by conv.hip)
+    const int j0 = h->nConv > 0 ? 1 : 0;
+    if (j0) { sb.fwdIdx.push_back(-1); sb.fwdBlocks.push_back(0); }
+    for (int j = j0; j < nH && !h->recurrent; ++j) {
       const DevHidden& d = h->hid[j];
       GemmProblem p{}; p.flavor = GEMM_F; p.epi = EPI_FWD; p.M = h->Mmax; p.N = d.size; p.K = d.nIn; p.dynRows = 1;
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
@@ -102,7 +105,13 @@ int buildProblems(hl_learner* h) {
         setTiles(s2, cur); P.push_back(s2);
       }
     }
-    for (int j = 0; j < nH && !h->recurrent; ++j) {
+    for (int l = 0; l < h->nConv; ++l) {   // convolution biases (one per output element): column sums of the layer's deltas
+      const ConvGeo& g = h->cg[l];
+      GemmProblem s2{}; s2.flavor = RED_COL; s2.epi = EPI_NONE; s2.N = g.KnC * g.P; s2.K = B;
+      s2.A = g.D; s2.lda = g.ldOut; s2.B = nullptr; s2.C = h->G + g.indB;
+      setTiles(s2, cur); P.push_back(s2);
+    }
+    for (int j = j0; j < nH && !h->recurrent; ++j) {
       const DevHidden& d = h->hid[j];
       GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = d.nIn + 1; p.N = d.size; p.K = B;
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
@@ -164,7 +173,7 @@ AdamHyper adamHyper(const hl_learner* h, int parity) {
 SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool computeEta) {
   SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->buf[parity].bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
   sa.X0 = h->buf[parity].X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
-  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.backupRng = 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
+  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.backupRng = 0; sa.noGather = h->preproc ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
   return sa;
 }
 // replica exchanges are part of the step: several replicas, or a communicator was attached to a
@@ -224,20 +233,41 @@ int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = fals
   HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
   return HL_OK;
 }
-int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
+ConvArgs convArgs(hl_learner* h, int parity) {
+  ConvArgs ca{}; ca.sc = h->sc; ca.parity = parity; ca.B = h->B; ca.nL = h->nConv;
+  ca.W = h->W; ca.Wrw = h->W; ca.M1 = h->M1; ca.M2 = h->M2; ca.G = h->G;
+  for (int l = 0; l < h->nConv; ++l) { ca.L[l] = h->cg[l]; ca.L[l].in = l == 0 ? h->buf[parity].X0 : h->cg[l - 1].Y; }
+  return ca;
+}
+// `gather`: states with appended observations / convolutional input are assembled here, from the sampled slots
+// (rollout inference writes the standardised rows itself)
+int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   char nm[32];
-  for (int j = 0; j < h->nHidden; ++j) {
+  if (h->preproc && gather) {
+    StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = h->buf[parity].bt; ga.B = h->B; ga.dS = h->dS; ga.nApp = h->nApp;
+    ga.parity = parity; ga.X0 = h->buf[parity].X0; ga.ldX0 = h->ldX0;
+    HIPCK(timed(h, "stack_gather", s, [&] { return launch_stack_gather(ga, h->Mmax, s); }));
+  }
+  const int j0 = h->nConv > 0 ? 1 : 0;
+  if (j0) {
+    const ConvArgs ca = convArgs(h, parity);
+    for (int l = 0; l < h->nConv; ++l) {
+      snprintf(nm, sizeof(nm), "conv_fwd%d", l);
+      HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
+    }
+  }
+  for (int j = j0; j < h->nHidden; ++j) {
     snprintf(nm, sizeof(nm), "gemm16_fwd%d", j);
     ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
     if (nextSample) {
       int ph = 0;
-      if (j == 0) ph |= PH_A;
+      if (j == j0) ph |= PH_A;
       if (j == h->nHidden - 1) ph |= PH_B;
       if (ph) { ex = extraSample(h, parity ^ 1, ph); pex = &ex; }
     }
-    HIPCK(timed(h, nm, s, [&] { return launch_gemm(j == 0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD, h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
+    HIPCK(timed(h, nm, s, [&] { return launch_gemm(j == j0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD, h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
   }
   return HL_OK;
 }
@@ -277,6 +307,15 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
     HIPCK(timed(h, nm, s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
+  }
+  if (h->nConv > 0) {   // convolutional layers: input gradients from the last one down, then every filter gradient (+ Adam)
+    const ConvArgs ca = convArgs(h, parity);
+    for (int l = h->nConv - 1; l >= 1; --l) {
+      snprintf(nm, sizeof(nm), "conv_dx%d", l);
+      HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s); }));
+    }
+    HIPCK(timed(h, "conv_dw", s, [&] { return launch_conv_dw(ca, h->convDwBlocks, s); }));
+    HIPCK(timed(h, "conv_reduce_adam", s, [&] { return launch_conv_reduce_adam(ca, hyp, fuseAdam ? 1 : 0, s); }));
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
   // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.

@@ -456,6 +456,7 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
     // first step of a launch sequence: derive this step's Adam step size from the canonical scalars
     if (a.computeEta) sc->etaEff[a.parity] = adamEtaEff(sc->nStep, sc->adam_bt1, sc->adam_bt2, a.eta0, a.epsAnneal);
   }
+  if (a.noGather) return;      // the states are gathered by stack_gather_kernel (conv.hip)
   if (phases & PH_PUBLISH) {   // the gather is done by the helper workgroups (gatherHelper)
     __builtin_amdgcn_s_waitcnt(0);     // the agent-scope stores of slot / nextOf are acknowledged
     __syncthreads();

@@ -792,6 +792,79 @@ def test_recurrent_acting_matches_oracle(hip_api):
         G.forward(rng.normal(size=(1, 6)).astype(np.float32))                # stateless forward of a recurrent net
 
 
+CONV_ATARI = [(84, 84, 4, 8, 8, 4), (20, 20, 8, 16, 6, 2), (8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)]     # apps/OpenAI_gym_atari/exec.py:114-117
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["conv_small.bin", "racer_atari.bin"])
+def test_conv_steps_follow_reference_fixture(hip_api, name):
+    """BASELINE config 5 (RACER_atari.json: 84x84 frames x (1 + 3 appended), four SoftSign convolutions, dense 512 + parametric
+    residual, discrete RACER head, batch 128) and a two-layer variant: the (episode, t >= nAppendedObs) pairs of the compiled
+    reference's harness through the device path -- stacked gather, implicit-GEMM convolutions forward / dX / dW on MFMA,
+    Adam -- against the reference's own taps."""
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc="Tanh"))
+    assert L.nParams == int(fx["cfg"][5]) and L.nOut == int(fx["cfg"][6])
+    setup_from_fixture(L, fx)
+    w0 = L.get_params()[0]
+    assert fx_vec_dev(fx, "W0", w0) < 1e-12 and np.array_equal(w0[::53], fx["W0_sub"])      # Conv2DLayer::initialize draw order
+    m, sc, r = L.get_scaling()
+    assert np.allclose(np.concatenate([m, sc, r]), fx["scaling0"], rtol=2e-7, atol=1e-7)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        flat = flat_for(L, fx[sk + "tag"], fx[sk + "t"])
+        order = np.argsort(flat, kind="stable")
+        L.step(1, flat=flat[order])
+        assert np.array_equal(L.readback(capi.TAP_TAG), fx[sk + "tag"][order]) and np.array_equal(L.readback(capi.TAP_TSTEP), fx[sk + "t"][order])
+        assert relinf(L.readback(capi.TAP_OUTPUT), fx[sk + "O"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_RHO), fx[sk + "rho"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_DKL), fx[sk + "dkl"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_OUTGRAD), fx[sk + "G"][order]) < TOL32
+        assert np.array_equal(L.readback(capi.TAP_FAR), fx[sk + "far"][order])
+        if sk + "gradSum" in fx or sk + "gradSum_sub" in fx:
+            assert fx_vec_dev(fx, sk + "gradSum", L.readback(capi.TAP_GRADSUM)) < TOL32
+        if sk + "W_sub" in fx:
+            w, m1, m2 = L.get_params()
+            assert fx_vec_dev(fx, sk + "W", w) < TOL32
+            assert fx_vec_dev(fx, sk + "M1", m1) < 2 * TOL32 and fx_vec_dev(fx, sk + "M2", m2) < 2 * TOL32
+        assert L.scalars().nFarPolicySteps == fx["traj_nfar"][k - 1]
+    assert fx_vec_dev(fx, "Wfinal", L.get_params()[0]) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw,sc_kw,n_eps,steps", [
+    # two convolutions behind 1 + 3 stacked observations; short episodes: steps t < 3 (first frame repeated) and
+    # truncated next states (rows >= B) are sampled
+    (dict(dimS=256, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=5, nAppendedObs=3, conv=[(8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)],
+          hidden=(48,), nnFunc="Tanh", batchSize=24, maxTotObsNum=2000, randSeed=3),
+     dict(seed=5, dimS=256, dimA=1, lenMin=3, lenMax=9, pTerm=0.3), 60, 6),
+    # stride-2 layer with 8 -> 16 channels (the second RACER_atari layer), continuous V-RACER head, two dense layers
+    (dict(dimS=800, dimA=2, bounded=[1, 0], nAppendedObs=3, conv=[(20, 20, 8, 16, 6, 2)], hidden=(40, 24), batchSize=16,
+          maxTotObsNum=1500, randSeed=4),
+     dict(seed=6, dimS=800, dimA=2, lenMin=4, lenMax=20, pTerm=0.5), 30, 5),
+    # odd geometry: 3 input channels, 5 filters, 7x9 image, stride 1, filter 3 (channel and position tiles partly empty)
+    (dict(dimS=189, dimA=2, nAppendedObs=0, conv=[(9, 7, 3, 5, 3, 1)], hidden=(32,), nnFunc="SoftSign", batchSize=10,
+          maxTotObsNum=800, randSeed=6),
+     dict(seed=8, dimS=189, dimA=2, lenMin=3, lenMax=12, pTerm=0.4), 25, 5),
+    # appended observations without convolutions: dense layers on the stacked state
+    (dict(dimS=6, dimA=2, nAppendedObs=2, hidden=(32, 32), batchSize=16, maxTotObsNum=900, randSeed=9),
+     dict(seed=2, dimS=6, dimA=2, lenMin=2, lenMax=15, pTerm=0.5), 40, 8),
+])
+def test_conv_and_appended_observations_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
+    sc = synth_cfg(**sc_kw)
+    G, O = _pair(hip_api, cfg_kw, sc, n_eps)
+    for _ in range(steps):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    assert (G.readback(capi.TAP_TSTEP) >= 0).all()
+    G.step(21); O.step(21)                      # replayed graphs (16 + 4 + 1), riders draw the next minibatch
+    _compare_step(G, O)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 4 * TOL32
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    st = np.random.default_rng(0).normal(size=(3, G.dIn)).astype(np.float32)      # rollout inference on stacked raw states
+    assert relinf(G.forward(st), O.forward(st)) < TOL32
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_kw,sc_kw,n_eps", [
     (dict(dimS=17, dimA=6, hidden=(64, 64), batchSize=32, maxTotObsNum=3000, randSeed=8),          # fused path
