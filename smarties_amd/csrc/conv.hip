@@ -36,31 +36,90 @@ __global__ __launch_bounds__(256) void stack_gather_kernel(StackGatherArgs a) {
   const long long slot = a.bt.slot[b] + (row < a.B ? 0 : 1);
   const int t = a.bt.t[b] + (row < a.B ? 0 : 1);
   const int dS = a.dS, dIn = dS * (1 + a.nApp);
+  if ((dS & 3) == 0) {                                        // 16-byte path (frames of 84 x 84: 7056 floats)
+    const int q4 = dS >> 2;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < (dIn >> 2); idx += gridDim.x * 256) {
+      const int j = idx / q4, i = idx - j * q4;
+      const int back = j < t ? j : t;                         // steps before the first repeat the first
+      const f32x4 v = reinterpret_cast<const f32x4*>(a.rp.S + (size_t)(slot - back) * dS)[i];
+      const f32x4 m = reinterpret_cast<const f32x4*>(a.rp.stMean)[i], sc4 = reinterpret_cast<const f32x4*>(a.rp.stScale)[i];
+      f32x4 o; o[0] = (v[0] - m[0]) * sc4[0]; o[1] = (v[1] - m[1]) * sc4[1]; o[2] = (v[2] - m[2]) * sc4[2]; o[3] = (v[3] - m[3]) * sc4[3];
+      reinterpret_cast<f32x4*>(a.X0 + (size_t)row * a.ldX0)[idx] = o;
+    }
+    return;
+  }
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < dIn; idx += gridDim.x * 256) {
     const int j = idx / dS, i = idx - j * dS;
-    const int back = j < t ? j : t;                           // steps before the first repeat the first
+    const int back = j < t ? j : t;
     a.X0[(size_t)row * a.ldX0 + idx] = (a.rp.S[(size_t)(slot - back) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
   }
 }
 hipError_t launch_stack_gather(const StackGatherArgs& a, int maxRows, hipStream_t s) {
   const int dIn = a.dS * (1 + a.nApp);
-  int bx = (dIn + 255) / 256; if (bx > 64) bx = 64;
+  int bx = (dIn / 4 + 255) / 256; if (bx > 32) bx = 32; if (bx < 1) bx = 1;
   hipLaunchKernelGGL(stack_gather_kernel, dim3(bx, maxRows), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward
+// forward.  A workgroup = 4 wavefronts = (4 / CT) tiles of 16 output positions x CT tiles of 16 channels, one
+// (position tile, channel tile) per wavefront.  These layers are small (0.2 - 0.8 MFLOP per sample), so the kernels are
+// built for latency: NK > 0 = the number of MFMA steps is known at compile time and EVERY gathered patch element of the
+// wavefront is requested before the first MFMA (one exposed memory round trip instead of one per few steps); NK = 0 is
+// the generic loop for other shapes.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int CONV_PT = 2;     // 16-position tiles per wavefront
-
 __host__ __device__ inline int convPad4(int k) { return (k + 3) & ~3; }
 __host__ __device__ inline size_t convFwdLds(const ConvGeo& g, int CT) {
   const int Kp = convPad4(g.K);
   return (size_t)CT * 16 * (Kp + 4) * 4 + (size_t)Kp * 4;
 }
 
-template <int CT>     // 16-channel tiles
+// Filters in the layouts the kernels stage into LDS, written once per step (the weights change only in the Adam pass):
+//   Wf[l]: [CT 16][Kp + 4]   filter rows, zero padded (forward: A operand rows = output channels)
+//   Wx[l]: [IT 16][KKp + 4]  Wx[ic][(c, fy, fx)] = K[c][ic][fy][fx], zero padded (dX: A operand rows = input channels)
+// so that a workgroup's staging is a flat 16-byte copy with every load in flight at once.
+__host__ __device__ inline int convWfFloats(const ConvGeo& g) { return ((g.KnC + 15) & ~15) * (convPad4(g.K) + 4); }
+__host__ __device__ inline int convWxFloats(const ConvGeo& g) { return ((g.InC + 15) & ~15) * (convPad4(g.KnC * g.KnY * g.KnX) + 4); }
+__global__ __launch_bounds__(256) void conv_prep_kernel(ConvArgs a) {
+  int l = 0, i = blockIdx.x * 256 + threadIdx.x;
+  for (; l < a.nL; ++l) { const int n = convWfFloats(a.L[l]) + (l > 0 ? convWxFloats(a.L[l]) : 0); if (i < n) break; i -= n; }
+  if (l >= a.nL) return;
+  const ConvGeo& g = a.L[l];
+  const float* Wl = a.W + g.indW;
+  const int nf = convWfFloats(g);
+  if (i < nf) {
+    const int ldK = convPad4(g.K) + 4, c = i / ldK, k = i - c * ldK;
+    g.Wf[i] = (c < g.KnC && k < g.K) ? Wl[(size_t)c * g.K + k] : 0.f;
+  } else {
+    i -= nf;
+    const int fsz = g.KnY * g.KnX, KK = g.KnC * fsz, ldKK = convPad4(KK) + 4, ic = i / ldKK, kk = i - ic * ldKK;
+    float w = 0.f;
+    if (ic < g.InC && kk < KK) { const int c = kk / fsz, f = kk - c * fsz; w = Wl[((size_t)c * g.InC + ic) * fsz + f]; }
+    g.Wx[i] = w;
+  }
+}
+hipError_t launch_conv_prep(const ConvArgs& a, hipStream_t s) {
+  long long n = 0;
+  for (int l = 0; l < a.nL; ++l) n += convWfFloats(a.L[l]) + (l > 0 ? convWxFloats(a.L[l]) : 0);
+  hipLaunchKernelGGL(conv_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+long long conv_prep_floats(const ConvGeo& g, int which) { return which == 0 ? convWfFloats(g) : convWxFloats(g); }
+
+// flat 16-byte copy global -> LDS, every load of the thread issued before its first store
+template <int MAXQ> __device__ __forceinline__ void stageFlat(float* dst, const float* src, int nFloats) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src); f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+  const int n4 = nFloats >> 2;
+  for (int q0 = 0; q0 < n4; q0 += 256 * MAXQ) {
+    f32x4 v[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) { const int i = q0 + threadIdx.x + 256 * q; v[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) { const int i = q0 + threadIdx.x + 256 * q; if (i < n4) d4[i] = v[q]; }
+  }
+}
+
+template <int CT, int NK>     // channel tiles per workgroup (1, 2, 4); MFMA steps (0: run-time)
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvGeo g = a.L[l];
@@ -68,15 +127,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   float* Ws = reinterpret_cast<float*>(smem);                         // [CT*16][ldK]
   int* kOff = reinterpret_cast<int*>(Ws + (size_t)CT * 16 * ldK);     // [Kp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  constexpr int PW = 4 / CT;                                           // position tiles per workgroup
   const int nRows = a.sc->nRows[a.parity];
-  const long long R = (long long)nRows * P;
-  const long long tile0 = ((long long)blockIdx.x * 4 + wave) * CONV_PT;
-  if ((long long)blockIdx.x * 4 * CONV_PT * 16 >= R) return;         // whole workgroup beyond the minibatch
-  const float* Wl = a.W + g.indW;
-  for (int i = tid; i < CT * 16 * ldK; i += 256) {
-    const int c = i / ldK, k = i - c * ldK;
-    Ws[i] = (c < g.KnC && k < K) ? Wl[(size_t)c * K + k] : 0.f;
-  }
+  const unsigned R = (unsigned)nRows * (unsigned)P;                   // (rows x positions < 2^31, checked at creation)
+  if (blockIdx.x * PW * 16u >= R) return;                             // whole workgroup beyond the minibatch
+  stageFlat<(NK > 0 ? (CT * 16 * (NK + 1) + 255) / 256 : 5)>(Ws, g.Wf, CT * 16 * ldK);     // one batch of loads when the shape is known
+  const int ct = wave % CT;
+  const unsigned tile = blockIdx.x * PW + wave / CT;
+  // this lane's output position and the origin of its patch in the input image (the index arithmetic overlaps the
+  // weight fetch)
+  const unsigned r = tile * 16 + li;
+  const bool ok = r < R;
+  const unsigned rr = ok ? r : 0;
+  const int bb = (int)(rr / (unsigned)P), pp = (int)(rr - (unsigned)bb * (unsigned)P);
+  const int oy = pp / g.OpX, ox = pp - oy * g.OpX;
+  const float* inRow = g.in + (long long)bb * g.ldIn + (long long)oy * g.S * g.InX + ox * g.S;
   for (int k = tid; k < Kp; k += 256) {
     int off = 0;
     if (k < K) { const int ic = k / (g.KnY * g.KnX), f = k - ic * g.KnY * g.KnX, fy = f / g.KnX, fx = f - fy * g.KnX;
@@ -84,82 +149,84 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
     kOff[k] = off;
   }
   __syncthreads();
-  long long rowBase[CONV_PT]; int bb[CONV_PT], pp[CONV_PT]; bool ok[CONV_PT];
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* wRow = Ws + (ct * 16 + li) * ldK + lc;
+  if constexpr (NK > 0) {
+    float bv[NK];
 #pragma unroll
-  for (int t = 0; t < CONV_PT; ++t) {
-    const long long r = (tile0 + t) * 16 + li;
-    ok[t] = r < R;
-    const long long rr = ok[t] ? r : 0;
-    bb[t] = (int)(rr / P); pp[t] = (int)(rr - (long long)bb[t] * P);
-    const int oy = pp[t] / g.OpX, ox = pp[t] - oy * g.OpX;
-    rowBase[t] = (long long)bb[t] * g.ldIn + (long long)oy * g.S * g.InX + ox * g.S;
-  }
-  f32x4 acc[CT][CONV_PT];
+    for (int s = 0; s < NK; ++s) bv[s] = inRow[kOff[4 * s + lc]];
+    __builtin_amdgcn_sched_barrier(0);          // all gathers are in flight before the first MFMA
 #pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int t = 0; t < CONV_PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* in = g.in;
-  constexpr int UN = 4;                       // MFMA steps whose operands are fetched together
-  for (int s0 = 0; s0 < Kp / 4; s0 += UN) {
-    float av[UN][CT], bv[UN][CONV_PT];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int kk = 4 * (s0 + u) + lc;
-      const bool kin = kk < Kp;
-      const int ko = kin ? kOff[kk] : 0;
-#pragma unroll
-      for (int c = 0; c < CT; ++c) av[u][c] = kin ? Ws[(c * 16 + li) * ldK + kk] : 0.f;
-#pragma unroll
-      for (int t = 0; t < CONV_PT; ++t) bv[u][t] = in[rowBase[t] + ko];
+    for (int s = 0; s < NK; ++s) {
+      const float av = wRow[4 * s];
+      if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc0, 0, 0, 0);
     }
+  } else {
+    constexpr int UN = 8;
+    for (int s0 = 0; s0 < Kp / 4; s0 += UN) {
+      float av[UN], bv[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u)
+      for (int u = 0; u < UN; ++u) {
+        const int s = s0 + u; const bool kin = 4 * s < Kp;
+        av[u] = kin ? wRow[4 * s] : 0.f;
+        bv[u] = kin ? inRow[kOff[4 * s + lc]] : 0.f;
+      }
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int t = 0; t < CONV_PT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][t], acc[c][t], 0, 0, 0);
+      for (int u = 0; u < UN; ++u) {
+        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
+      }
+    }
   }
+  if (!ok) return;
   const float* Bl = a.W + g.indB;
 #pragma unroll
-  for (int t = 0; t < CONV_PT; ++t) {
-    if (!ok[t]) continue;
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ch = c * 16 + lc * 4 + r;
-        if (ch < g.KnC) {
-          const float x = acc[c][t][r] + Bl[(size_t)ch * P + pp[t]];
-          const size_t o = (size_t)bb[t] * g.ldOut + (size_t)ch * P + pp[t];
-          g.X[o] = x; g.Y[o] = softsignEval(x);
-        }
-      }
+  for (int q = 0; q < 4; ++q) {
+    const int ch = ct * 16 + lc * 4 + q;
+    if (ch < g.KnC) {
+      const float x = (acc0[q] + acc1[q]) + Bl[(size_t)ch * P + pp];
+      const size_t o = (size_t)bb * g.ldOut + (size_t)ch * P + pp;
+      g.X[o] = x; g.Y[o] = softsignEval(x);
+    }
   }
 }
 
-template <int CT> static hipError_t launchConvFwdT(const ConvArgs& a, int l, int blocks, hipStream_t s) {
+template <int CT, int NK> static hipError_t launchConvFwdT(const ConvArgs& a, int l, long long R, hipStream_t s) {
   const size_t lds = convFwdLds(a.L[l], CT);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr int PW = 4 / CT;
+  const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<CT, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(conv_fwd_kernel<CT>, dim3(blocks), dim3(256), lds, s, a, l);
+  hipLaunchKernelGGL((conv_fwd_kernel<CT, NK>), dim3(blocks), dim3(256), lds, s, a, l);
   return hipGetLastError();
+}
+template <int CT> static hipError_t launchConvFwdC(const ConvArgs& a, int l, long long R, hipStream_t s) {
+  const int nk = convPad4(a.L[l].K) / 4;
+  if (nk == 64) return launchConvFwdT<CT, 64>(a, l, R, s);       // 4 x 8 x 8, 16 x 4 x 4 patches
+  if (nk == 72) return launchConvFwdT<CT, 72>(a, l, R, s);       // 8 x 6 x 6, 32 x 3 x 3
+  return launchConvFwdT<CT, 0>(a, l, R, s);
 }
 hipError_t launch_conv_forward(const ConvArgs& a, int l, int maxRows, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const long long R = (long long)maxRows * g.P;
-  const int blocks = (int)((R + 16 * 4 * CONV_PT - 1) / (16 * 4 * CONV_PT));
   const int CT = (g.KnC + 15) / 16;
-  if (CT == 1) return launchConvFwdT<1>(a, l, blocks, s);
-  if (CT == 2) return launchConvFwdT<2>(a, l, blocks, s);
-  if (CT <= 4) return launchConvFwdT<4>(a, l, blocks, s);
+  if (CT == 1) return launchConvFwdC<1>(a, l, R, s);
+  if (CT == 2) return launchConvFwdC<2>(a, l, R, s);
+  if (CT <= 4) return launchConvFwdC<4>(a, l, R, s);
   return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// dX: gradient w.r.t. the input image of layer l, times act' of the layer below -> D of layer l - 1
+// dX: gradient w.r.t. the input image of layer l, times act' of the layer below -> D of layer l - 1.  Same workgroup
+// shape as the forward kernel: one (16 input positions, 16 input channels) tile per wavefront, every gathered delta
+// requested before the first MFMA when the number of steps is a compile-time constant.
 // ---------------------------------------------------------------------------------------------------------------
-template <int IT>     // 16-input-channel tiles
+__host__ __device__ inline size_t convDxLds(const ConvGeo& g, int IT) {
+  const int KKp = convPad4(g.KnC * g.KnY * g.KnX);
+  return (size_t)IT * 16 * (KKp + 4) * 4 + (size_t)KKp * 4;
+}
+template <int IT, int NK>     // input-channel tiles per workgroup; MFMA steps (0: run-time)
 __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvGeo g = a.L[l];
@@ -168,99 +235,96 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
   float* Wx = reinterpret_cast<float*>(smem);                          // [IT*16][ldKK]   Wx[ic][(c, fy, fx)]
   int* kTab = reinterpret_cast<int*>(Wx + (size_t)IT * 16 * ldKK);     // [KKp]   c * P | fy << 20 | fx << 26   (-1: padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  const long long R = (long long)a.B * Pin;
-  const long long tile0 = ((long long)blockIdx.x * 4 + wave) * CONV_PT;
-  const float* Wl = a.W + g.indW;
+  constexpr int PW = 4 / IT;
+  const unsigned R = (unsigned)a.B * (unsigned)Pin;
+  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx, IT * 16 * ldKK);
+  const int it = wave % IT;
+  const unsigned tile = blockIdx.x * PW + wave / IT;
+  const unsigned r = tile * 16 + li;
+  const bool ok = r < R;
+  const unsigned rr = ok ? r : 0;
+  const int bb = (int)(rr / (unsigned)Pin), qq = (int)(rr - (unsigned)bb * (unsigned)Pin);
+  const int iy = qq / g.InX, ix = qq - iy * g.InX;
+  const float* dRow = g.D + (long long)bb * g.ldOut;
   const int fsz = g.KnY * g.KnX;
-  for (int i = tid; i < IT * 16 * ldKK; i += 256) {
-    const int ic = i / ldKK, kk = i - ic * ldKK;
-    float w = 0.f;
-    if (ic < g.InC && kk < KK) { const int c = kk / fsz, f = kk - c * fsz; w = Wl[((size_t)c * g.InC + ic) * fsz + f]; }
-    Wx[i] = w;
-  }
   for (int kk = tid; kk < KKp; kk += 256) {
     int v = -1;
     if (kk < KK) { const int c = kk / fsz, f = kk - c * fsz, fy = f / g.KnX, fx = f - fy * g.KnX; v = (c * P) | (fy << 20) | (fx << 26); }
     kTab[kk] = v;
   }
   __syncthreads();
-  int bb[CONV_PT], qq[CONV_PT], iy[CONV_PT], ix[CONV_PT]; bool ok[CONV_PT]; long long dRow[CONV_PT];
-#pragma unroll
-  for (int t = 0; t < CONV_PT; ++t) {
-    const long long r = (tile0 + t) * 16 + li;
-    ok[t] = r < R;
-    const long long rr = ok[t] ? r : 0;
-    bb[t] = (int)(rr / Pin); qq[t] = (int)(rr - (long long)bb[t] * Pin);
-    iy[t] = qq[t] / g.InX; ix[t] = qq[t] - iy[t] * g.InX;
-    dRow[t] = (long long)bb[t] * g.ldOut;
-  }
   const int S = g.S, sh = S == 1 ? 0 : (S == 2 ? 1 : (S == 4 ? 2 : 3));
-  f32x4 acc[IT][CONV_PT];
+  auto gatherD = [&](int kk) -> float {       // D[(b, c, (q - f) / S)] where that output position exists, else 0
+    const int tab = kTab[kk];
+    const int offC = tab & 0xFFFFF, fy = (tab >> 20) & 63, fx = (tab >> 26) & 31;
+    const int oyS = iy - fy, oxS = ix - fx;
+    const int oy = oyS >> sh, ox = oxS >> sh;
+    const bool v = tab >= 0 && ok && oyS >= 0 && oxS >= 0 && ((oyS | oxS) & (S - 1)) == 0 && oy < g.OpY && ox < g.OpX;
+    return v ? dRow[offC + oy * g.OpX + ox] : 0.f;
+  };
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* wRow = Wx + (it * 16 + li) * ldKK + lc;
+  if constexpr (NK > 0) {
+    float bv[NK];
 #pragma unroll
-  for (int c = 0; c < IT; ++c)
+    for (int s = 0; s < NK; ++s) bv[s] = gatherD(4 * s + lc);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < CONV_PT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* D = g.D;
-  constexpr int UN = 4;
-  for (int s0 = 0; s0 < KKp / 4; s0 += UN) {
-    float av[UN][IT], bv[UN][CONV_PT];
+    for (int s = 0; s < NK; ++s) {
+      const float av = wRow[4 * s];
+      if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc0, 0, 0, 0);
+    }
+  } else {
+    constexpr int UN = 8;
+    for (int s0 = 0; s0 < KKp / 4; s0 += UN) {
+      float av[UN], bv[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int kk = 4 * (s0 + u) + lc;
-      const bool kin = kk < KKp;
-      const int tab = kin ? kTab[kk] : -1;
-      const int offC = tab & 0xFFFFF, fy = (tab >> 20) & 63, fx = (tab >> 26) & 31;
+      for (int u = 0; u < UN; ++u) {
+        const int s = s0 + u; const bool kin = 4 * s < KKp;
+        av[u] = kin ? wRow[4 * s] : 0.f;
+        bv[u] = kin ? gatherD(4 * s + lc) : 0.f;
+      }
 #pragma unroll
-      for (int c = 0; c < IT; ++c) av[u][c] = kin ? Wx[(c * 16 + li) * ldKK + kk] : 0.f;
-#pragma unroll
-      for (int t = 0; t < CONV_PT; ++t) {
-        const int oyS = iy[t] - fy, oxS = ix[t] - fx;
-        const int oy = oyS >> sh, ox = oxS >> sh;
-        const bool v = tab >= 0 && ok[t] && oyS >= 0 && oxS >= 0 && ((oyS | oxS) & (S - 1)) == 0 && oy < g.OpY && ox < g.OpX;
-        bv[u][t] = v ? D[dRow[t] + offC + oy * g.OpX + ox] : 0.f;
+      for (int u = 0; u < UN; ++u) {
+        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int u = 0; u < UN; ++u)
-#pragma unroll
-      for (int c = 0; c < IT; ++c)
-#pragma unroll
-        for (int t = 0; t < CONV_PT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][c], bv[u][t], acc[c][t], 0, 0, 0);
   }
+  if (!ok) return;
 #pragma unroll
-  for (int t = 0; t < CONV_PT; ++t) {
-    if (!ok[t]) continue;
-#pragma unroll
-    for (int c = 0; c < IT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ic = c * 16 + lc * 4 + r;
-        if (ic < g.InC) {
-          const size_t o = (size_t)bb[t] * gp.ldOut + (size_t)ic * Pin + qq[t];
-          gp.D[o] = acc[c][t][r] * softsignDiff(gp.X[o]);
-        }
-      }
+  for (int q = 0; q < 4; ++q) {
+    const int ic = it * 16 + lc * 4 + q;
+    if (ic < g.InC) {
+      const size_t o = (size_t)bb * gp.ldOut + (size_t)ic * Pin + qq;
+      gp.D[o] = (acc0[q] + acc1[q]) * softsignDiff(gp.X[o]);
+    }
   }
 }
-__host__ __device__ inline size_t convDxLds(const ConvGeo& g, int IT) {
-  const int KKp = convPad4(g.KnC * g.KnY * g.KnX);
-  return (size_t)IT * 16 * (KKp + 4) * 4 + (size_t)KKp * 4;
-}
-template <int IT> static hipError_t launchConvDxT(const ConvArgs& a, int l, int blocks, hipStream_t s) {
+template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, hipStream_t s) {
   const size_t lds = convDxLds(a.L[l], IT);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dx_kernel<IT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr int PW = 4 / IT;
+  const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dx_kernel<IT, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(conv_dx_kernel<IT>, dim3(blocks), dim3(256), lds, s, a, l);
+  hipLaunchKernelGGL((conv_dx_kernel<IT, NK>), dim3(blocks), dim3(256), lds, s, a, l);
   return hipGetLastError();
+}
+template <int IT> static hipError_t launchConvDxC(const ConvArgs& a, int l, long long R, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  const int nk = convPad4(g.KnC * g.KnY * g.KnX) / 4;
+  if (nk == 128) return launchConvDxT<IT, 128>(a, l, R, s);      // 32 filters of 4 x 4
+  if (nk == 144) return launchConvDxT<IT, 144>(a, l, R, s);      // 16 of 6 x 6, 64 of 3 x 3
+  return launchConvDxT<IT, 0>(a, l, R, s);
 }
 hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const long long R = (long long)a.B * g.InY * g.InX;
-  const int blocks = (int)((R + 16 * 4 * CONV_PT - 1) / (16 * 4 * CONV_PT));
   const int IT = (g.InC + 15) / 16;
-  if (IT == 1) return launchConvDxT<1>(a, l, blocks, s);
-  if (IT == 2) return launchConvDxT<2>(a, l, blocks, s);
-  if (IT <= 4) return launchConvDxT<4>(a, l, blocks, s);
+  if (IT == 1) return launchConvDxC<1>(a, l, R, s);
+  if (IT == 2) return launchConvDxC<2>(a, l, R, s);
+  if (IT <= 4) return launchConvDxC<4>(a, l, R, s);
   return hipErrorInvalidValue;
 }
 
@@ -280,12 +344,12 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(ConvArgs a) {
   const int chunk = local / (tilesK * tilesC), tile = local - chunk * tilesK * tilesC;
   const int ct = tile / tilesK, kt = tile - ct * tilesK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  const long long R = (long long)a.B * P;
-  const long long r0 = (long long)chunk * g.chunkRows;
-  const int nr = (int)(R - r0 < g.chunkRows ? R - r0 : g.chunkRows);
+  const int R = a.B * P;
+  const int r0 = chunk * g.chunkRows;
+  const int nr = R - r0 < g.chunkRows ? R - r0 : g.chunkRows;
   for (int i = tid; i < nr; i += 256) {
-    const long long r = r0 + i;
-    const int b = (int)(r / P), p = (int)(r - (long long)b * P), oy = p / g.OpX, ox = p - oy * g.OpX;
+    const unsigned r = (unsigned)(r0 + i);
+    const int b = (int)(r / (unsigned)P), p = (int)(r - (unsigned)b * (unsigned)P), oy = p / g.OpX, ox = p - oy * g.OpX;
     sIn[i] = (long long)b * g.ldIn + (long long)oy * g.S * g.InX + ox * g.S;
     sD[i] = b * g.ldOut + p;
   }
@@ -300,7 +364,7 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(ConvArgs a) {
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* in = g.in; const float* D = g.D;
   const int nGroups = (nr + 3) / 4;                      // groups of 4 rows = one MFMA step; wave w takes groups w, w+4, ...
-  constexpr int UN = 4;
+  constexpr int UN = 16;                                 // operands of 16 steps in flight
   for (int g0 = wave; g0 < nGroups; g0 += 4 * UN) {
     float av[UN], bv[UN];
 #pragma unroll
@@ -337,7 +401,13 @@ __global__ __launch_bounds__(256) void conv_reduce_adam_kernel(ConvArgs a, AdamH
   const ConvGeo& g = a.L[l];
   const size_t n = (size_t)g.KnC * g.K;
   float s = 0.f;
-  for (int ch = 0; ch < g.nChunks; ++ch) s += g.part[(size_t)ch * n + i];
+  for (int c0 = 0; c0 < g.nChunks; c0 += 8) {       // eight partials in flight, summed in chunk order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c0 + u < g.nChunks ? g.part[(size_t)(c0 + u) * n + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
   a.G[g.indW + i] = s;
   if (fuseAdam) {
     AdamCoef c; c.eta = a.sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac;

@@ -67,6 +67,7 @@ struct ConvGeo {
   float* X; float* Y;        // [rows][ldOut] pre-activation / output, [c][oy][ox] per row
   float* D;                  // [B][ldOut]    dL/dX of this layer
   float* part;               // [nChunks][KnC K] partial filter gradients
+  float* Wf; float* Wx;      // the filters in the kernels' LDS layouts (conv.hip: conv_prep_kernel)
   int nChunks, chunkRows, dwBlock0;   // reduction chunks of the filter gradient; first workgroup of this layer in the dW launch
 };
 struct ConvArgs {
@@ -77,6 +78,8 @@ struct ConvArgs {
 struct StackGatherArgs { DevScalars* sc; DevReplay rp; DevBatch bt; int B, dS, nApp, parity; float* X0; int ldX0; };
 struct AdamHyper;
 hipError_t launch_stack_gather(const StackGatherArgs& a, int maxRows, hipStream_t s);
+hipError_t launch_conv_prep(const ConvArgs& a, hipStream_t s);              // filters -> LDS layouts (once per step)
+long long conv_prep_floats(const ConvGeo& g, int which);                   // floats of Wf (0) / Wx (1)
 hipError_t launch_conv_forward(const ConvArgs& a, int l, int maxRows, hipStream_t s);
 hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s);       // D of layer l-1 from D of layer l
 hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);

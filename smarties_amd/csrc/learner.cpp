@@ -537,6 +537,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       g.chunkRows = (int)rowsPer; g.nChunks = (int)((R + rowsPer - 1) / rowsPer);
       g.dwBlock0 = blk; blk += g.nChunks * tiles;
       HIPCK(devAlloc(&g.part, (size_t)g.nChunks * g.KnC * g.K));
+      HIPCK(devAlloc(&g.Wf, (size_t)conv_prep_floats(g, 0))); HIPCK(devAlloc(&g.Wx, (size_t)conv_prep_floats(g, 1)));
+      if ((long long)h->Mmax * g.P >= (1ll << 31) || (long long)h->Mmax * g.InY * g.InX >= (1ll << 31)) return fail(h, HL_ERR_UNSUPPORTED, "convolution: rows x positions >= 2^31");
     }
     h->convDwBlocks = blk;
   }
@@ -643,7 +645,7 @@ int hl_destroy(hl_learner* h) {
   for (void* p : ptrs) if (p) hipFree(p);
   for (int l = 0; l < h->nConv; ++l) { ConvGeo& g = h->cg[l];
     if (l != h->nConv - 1) for (float* p : {g.X, g.Y, g.D}) if (p) hipFree(p);
-    if (g.part) hipFree(g.part); }
+    for (float* p : {g.part, g.Wf, g.Wx}) if (p) hipFree(p); }
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);

@@ -253,6 +253,7 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
   const int j0 = h->nConv > 0 ? 1 : 0;
   if (j0) {
     const ConvArgs ca = convArgs(h, parity);
+    HIPCK(timed(h, "conv_prep", s, [&] { return launch_conv_prep(ca, s); }));
     for (int l = 0; l < h->nConv; ++l) {
       snprintf(nm, sizeof(nm), "conv_fwd%d", l);
       HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
