@@ -96,13 +96,12 @@ struct hl_learner {
   // minibatch ready in buffer preParity.  Whatever changes what a sampler sees (new episodes, evictions, explicit
   // indices, a generator read-out) first puts the generator back (dropPresample)
   bool preValid = false; int preParity = 0;
+  int eagerChain = 3;                      // calls of up to this many plain steps are launched directly instead of as graphs
   long long nCollectives = 0;              // RCCL calls issued or captured so far (tests: every path speaks the same wire protocol)
   struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM, 5 MGU (ld = gates x cells), 6 convolution (nIn = filter floats, size = biases)
   std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
-  hipStream_t sSample = nullptr, sPost = nullptr;
-  std::vector<hipEvent_t> evPool; int evUsed = 0;
   int dbgVariant = 0;
   // rccl
   ncclComm_t comm = nullptr;
@@ -592,8 +591,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&bt.oldNextADV, B)); HIPCK(devAlloc(&bt.gParam, (size_t)B * std::max(h->nSig, 1)));
     HIPCK(devAlloc(&bt.aggIn, (size_t)B * AGG_N));
   }
-  HIPCK(hipStreamCreateWithFlags(&h->sSample, hipStreamNonBlocking));
-  HIPCK(hipStreamCreateWithFlags(&h->sPost, hipStreamNonBlocking));
   HIPCK(devAlloc(&h->dFlatGiven, B));
   HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16));
   HIPCK(devAlloc(&h->rp.stMean, h->dS)); HIPCK(devAlloc(&h->rp.stScale, h->dS)); HIPCK(devAlloc(&h->rp.stStd, h->dS));
@@ -616,6 +613,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   rc = buildProblems(h); if (rc) return rc;
   if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) h->useGraph = !(e[0] == '1');
+  if (const char* e = getenv("SMARTIES_HIP_EAGER_CHAIN")) h->eagerChain = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_NO_EXCH_GRAPH")) h->exchGraph = !(e[0] == '1');   // replicas: eager exchanges only
   return HL_OK;
 }
@@ -624,10 +622,7 @@ int hl_destroy(hl_learner* h) {
   if (!h) return HL_OK;
   if (h->stream) hipStreamSynchronize(h->stream);
   timerFlush(h);
-  if (h->sSample) hipStreamSynchronize(h->sSample);
-  if (h->sPost) hipStreamSynchronize(h->sPost);
   invalidateGraphs(h);
-  for (hipEvent_t e : h->evPool) hipEventDestroy(e);
   if (h->comm) ncclCommDestroy(h->comm);
   void* ptrs[] = {h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
@@ -649,8 +644,6 @@ int hl_destroy(hl_learner* h) {
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);
-  if (h->sSample) hipStreamDestroy(h->sSample);
-  if (h->sPost) hipStreamDestroy(h->sPost);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h; return HL_OK;
 }
@@ -878,7 +871,8 @@ int hl_initialize(hl_learner* h) {
   rc = runSweep(h, nullptr, (int)h->order.size(), 0); if (rc) return rc;   // rescaleAllReturnEstimator
   HIPCK(hipStreamSynchronize(h->stream));
   h->initialized = true;
-  return HL_OK;
+  if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
+  return captureAllGraphs(h);      // one-off costs belong here, not in the first training step
 }
 
 static int preStepChecks(hl_learner* h) {

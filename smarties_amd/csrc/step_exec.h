@@ -496,6 +496,9 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
   if (rc) return rc;
   if (e != hipSuccess) return hipFail(h, e, "hipStreamEndCapture");
   HIPCK(hipGraphInstantiate(&slot->exec, slot->graph, nullptr, nullptr, 0));
+  // the first launch of an executable graph otherwise pays for its upload (~40 us seen on a 20-step call right after the
+  // capture); a failure here only means the first launch is slower
+  if (hipGraphUpload(slot->exec, s0) != hipSuccess) (void)hipGetLastError();
   slot->steps = U;
   return HL_OK;
 }
@@ -517,26 +520,45 @@ bool graphUsable(const hl_learner* h, int U, int p0) {
   return true;
 }
 
+// Every size and starting buffer is captured at once -- by hl_initialize, or by the first replay after something
+// invalidated the graphs (they survive appends and evictions, only a reallocation of the replay invalidates them) -- so
+// that no later call pays for a capture in the middle of a training phase.  If RCCL cannot be captured on this system,
+// replicas fall back to eager launches for good (the graph is only an optimisation).
+int captureAllGraphs(hl_learner* h) {
+  constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
+  static_assert(NS <= 16, "hl_learner::graphs is too small");
+  if (!h->useGraph || h->recurrent || (exchanging(h) && !(h->fusedOk && h->exchGraph && h->comm))) return HL_OK;
+  for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
+    if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
+    const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);
+    if (rc == HL_OK) continue;
+    if (!exchanging(h)) return rc;
+    h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
+    return HL_OK;
+  }
+  return HL_OK;
+}
+
 // run as many plain steps as possible (<= avail) from one graph replay; returns steps done (0 = none)
 int replaySteps(hl_learner* h, long long avail, int* done) {
   *done = 0;
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
-  static_assert(NS <= 16, "hl_learner::graphs is too small");
-  if (!h->graphs[NS - 1][0].exec) {
-    // first use: capture every size and starting buffer now (once per learner -- graphs survive appends and
-    // evictions, only a reallocation of the replay invalidates them), so that no later call pays for a capture
-    // in the middle of a training phase.  If RCCL cannot be captured on this system, fall back to eager launches
-    // for good (the graph is only an optimisation).
-    for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
-      if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
-      const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);
-      if (rc == HL_OK) continue;
-      if (!exchanging(h)) return rc;
-      h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
-      return HL_OK;
-    }
-  }
+  if (!h->graphs[NS - 1][0].exec) { int rc = captureAllGraphs(h); if (rc) return rc; if (!h->graphs[NS - 1][0].exec) return HL_OK; }
   const int p0 = h->preValid ? h->preParity : 0;
+  if (h->eagerChain > 0 && avail <= h->eagerChain && h->fusedOk && !exchanging(h)) {
+    // short calls: the same two launches per step (riders included) issued directly -- no graph launch latency, no
+    // first-launch cost of a graph that has not run yet
+    if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
+    const int U = (int)avail;
+    for (int j = 0; j < U; ++j) {
+      const int p = (p0 + j) & 1;
+      int rc = launchFused(h, p, h->stream, true); if (rc) return rc;
+      rc = launchWeightGrad(h, p, true, h->stream, true, false); if (rc) return rc;
+    }
+    h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;
+    *done = U;
+    return HL_OK;
+  }
   for (int i = 0; i < NS; ++i) {
     const int U = GRAPH_SIZES[i];
     if (avail < U || !graphUsable(h, U, p0)) continue;
