@@ -196,7 +196,7 @@ template <int CT, int NK> static hipError_t launchConvFwdT(const ConvArgs& a, in
   const size_t lds = convFwdLds(a.L[l], CT);
   constexpr int PW = 4 / CT;
   const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<CT, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_fwd_kernel<CT, NK>), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((conv_fwd_kernel<CT, NK>), dim3(blocks), dim3(256), lds, s, a, l);
   return hipGetLastError();
@@ -306,7 +306,7 @@ template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int
   const size_t lds = convDxLds(a.L[l], IT);
   constexpr int PW = 4 / IT;
   const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dx_kernel<IT, NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dx_kernel<IT, NK>), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((conv_dx_kernel<IT, NK>), dim3(blocks), dim3(256), lds, s, a, l);
   return hipGetLastError();

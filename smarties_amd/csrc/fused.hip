@@ -596,12 +596,7 @@ template <int H, int CF>
 static hipError_t launchFusedT(const FusedArgs& a, int maxRows, const ExtraArgs& ex, hipStream_t s) {
   const int HT = H / 16, panels = (maxRows + 15) / 16, pg = (panels + 7) / 8;
   const size_t lds = fusedLdsBytes(a.dS, H);
-  static size_t attrSet = 0;
-  if (lds > attrSet) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H, CF, FUSED_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attrSet = lds;
-  }
+  { hipError_t e = ensureDynLds(reinterpret_cast<const void*>(fused_fwd_head_dx_kernel<H, CF, FUSED_NT>), lds); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL((fused_fwd_head_dx_kernel<H, CF, FUSED_NT>), dim3(8 + 8 * HT * pg), dim3(FUSED_NT), lds, s, a, ex);
   return hipGetLastError();
 }

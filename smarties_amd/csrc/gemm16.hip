@@ -81,6 +81,8 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   float* sB = sA + 16 * LDR;
   float* red = sB + 16 * LDR;
   if (flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
+  int ks = 0;                                  // chunk of the reduction (split problems only)
+  if (FL < 0 && P.nSplit > 1) { const int nT0 = P.tilesM * P.tilesN; ks = tile / nT0; tile -= ks * nT0; }
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
   // Give XCD x the contiguous (row-major) tile range [x*nT/8, (x+1)*nT/8): the tiles of one XCD
   // then share their A row-panels, and each L2 fetches 1/8 of A instead of all of it.
@@ -161,8 +163,9 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
       }
     }
   };
-  loadChunk(0);
-  for (int kb = 0; kb < P.K; kb += KC) {
+  const int kBeg = ks * KC, kEnd = (FL < 0 && P.nSplit > 1) ? min(P.K, kBeg + KC) : P.K;
+  loadChunk(kBeg);
+  for (int kb = kBeg; kb < kEnd; kb += KC) {
     int kc, kw, sh; chunkGeo(kb, kc, kw, sh);
     const int nf4 = kw;                       // float4 per 16-row-tile row (= kcp/4)
     GSTAMP(30);
@@ -195,7 +198,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     }
     __syncthreads();
     GSTAMP(25);
-    if (kb + KC < P.K) loadChunk(kb + KC);
+    if (kb + KC < kEnd) loadChunk(kb + KC);
     const int k0 = wave * kw;
     if (!(variant & 2))                 // ablation: no MFMA loop
     for (int s = 0; s < kw; s += 8) {
@@ -233,6 +236,8 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     if (n < P.resN) dres += e1 * e2;
     P.C[(size_t)m * P.ldc + n] = dres;
     P.C2[(size_t)m * P.ldc + n] = dres * actDiff(P.func, e0, e3);
+  } else if (epi == EPI_DW && FL < 0 && P.nSplit > 1) {
+    P.part[((size_t)ks * P.M + m) * P.N + n] = v;
   } else if (epi == EPI_DW) {
     if (m < P.M - 1) {
       const size_t i = (size_t)m * P.ldc + n;
@@ -284,6 +289,36 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
   const GemmProblem P = tbl.p[p];      // by value: the whole record in one batch of scalar loads
   if (P.flavor == GEMM_W) gemmTile<GEMM_ROLE_DW, GEMM_W>(P, bid - P.tileStart, smem, sc, hyp, 0);
   else gemmTile<GEMM_ROLE_DW>(P, bid - P.tileStart, smem, sc, hyp, 0);
+}
+
+// sum of the chunk partials of the split weight-gradient problems, in chunk order, + Adam
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* __restrict__ probs, const DevScalars* __restrict__ sc, AdamHyper hyp) {
+  const GemmProblem P = probs[blockIdx.y];
+  if (P.nSplit <= 1) return;
+  const int i = blockIdx.x * 256 + threadIdx.x, MN = P.M * P.N;
+  if (i >= MN) return;
+  float s = 0.f;
+  for (int c0 = 0; c0 < P.nSplit; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c0 + u < P.nSplit ? P.part[(size_t)(c0 + u) * MN + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  const int m = i / P.N, n = i - m * P.N;
+  AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac;
+  if (m < P.M - 1) {
+    const size_t o = (size_t)m * P.ldc + n;
+    P.C[o] = s;
+    if (P.adamRed) adamApply(c, s, P.adW, P.adM1, P.adM2, o);
+  } else {
+    P.biasOut[n] = s;
+    if (P.adamRed) adamApply(c, s, P.adbW, P.adbM1, P.adbM2, n);
+  }
+}
+hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s) {
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((maxMN + 255) / 256, nProbs), dim3(256), 0, s, dProbs, sc, hyp);
+  return hipGetLastError();
 }
 
 hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {

@@ -145,6 +145,11 @@ struct GemmProblem {
   float *adW, *adM1, *adM2;
   float *adbW, *adbM1, *adbM2;
   int tileStart, tilesM, tilesN;
+  // GEMM_W over many rows (recurrent nets: batch x BPTT steps): the reduction is cut into nSplit chunks of 256 rows, one
+  // workgroup per (tile, chunk); partial tiles go to part[chunk][M][N] and are summed in chunk order -- with the Adam
+  // update, adamRed -- by splitk_reduce_kernel (gemm16.hip)
+  int nSplit, adamRed;
+  float* part;
 };
 
 struct AdamHyper { float eta0, lambda, fac; double epsAnneal; int parity; /* minibatch buffer of this step */

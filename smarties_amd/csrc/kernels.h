@@ -1,9 +1,25 @@
 // smarties_amd/csrc/kernels.h -- launchers of the gfx950 kernels (kernels.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "hl_types.h"
 
 namespace hl {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: raise it once per (device, kernel)
+// and size, from whatever thread launches first (learners on different devices may live in one process)
+inline hipError_t ensureDynLds(const void* kernel, size_t bytes) {
+  static std::mutex m; static std::map<std::pair<int, const void*>, size_t> done;
+  int dev = 0; (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(m);
+  size_t& have = done[std::make_pair(dev, kernel)];
+  if (bytes <= have) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
 
 struct SampleArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
@@ -152,6 +168,7 @@ hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc
 // up to two riders (extra, extra2) occupy workgroups 0 and 1 of the grid
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);
+hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 size_t fused_lds_bytes(int dS, int H);

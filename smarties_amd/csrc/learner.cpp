@@ -38,6 +38,7 @@ constexpr int PARAM_TAIL = 256;
 struct StepBuf {
   DevBatch bt{}; float* X0 = nullptr;
   std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
+  int splitMaxMN = 0;                      // > 0: some weight-gradient problems are split over the rows (largest M x N among them)
   DwTable dwTable{}, dwTableAdam{};        // the dW problems by value (kernel-argument table of dw_table_kernel)
 };
 struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int steps = 0; };
@@ -73,6 +74,7 @@ struct hl_learner {
   long long indWo = 0, indBo = 0, indBp = 0; int ldWo = 0;
   // gemm problem tables (device) + launch geometry
   GemmProblem* dProbs = nullptr;           // all GEMM problems of both buffers, contiguous
+  float* splitPart = nullptr; size_t splitPartFloats = 0;   // partial tiles of the split weight-gradient problems
   // replay bookkeeping (host)
   long long capSlots = 0; int capEps = 0;
   long long ringHead = 0;                  // next free slot
@@ -624,7 +626,7 @@ int hl_destroy(hl_learner* h) {
   timerFlush(h);
   invalidateGraphs(h);
   if (h->comm) ncclCommDestroy(h->comm);
-  void* ptrs[] = {h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
+  void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
@@ -923,7 +925,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     int rc = preStepChecks(h); if (rc) return rc;
     const long long k = h->nGradSteps + 1;
     const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
-    const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph && !h->recurrent &&
+    const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
                        (!exchanging(h) || (h->fusedOk && h->exchGraph && h->comm));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
@@ -1404,6 +1406,11 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
     }
     case HL_TAP_STATE: {
       if (bytes < (int64_t)B * h->dIn * 4) return HL_ERR_BAD_ARG;
+      if (h->recurrent) {   // recurrent layers read their windows straight from the replay: the rows are assembled on demand
+        StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = bt; ga.B = B; ga.dS = h->dS; ga.nApp = 0; ga.parity = h->lastParity;
+        ga.X0 = h->buf[h->lastParity].X0; ga.ldX0 = h->ldX0;
+        HIPCK(launch_stack_gather(ga, h->Mmax, h->stream)); HIPCK(hipStreamSynchronize(h->stream));
+      }
       HIPCK(hipMemcpy2D(dst, (size_t)h->dIn * 4, h->buf[h->lastParity].X0, (size_t)h->ldX0 * 4, (size_t)h->dIn * 4, B, hipMemcpyDeviceToHost));
       return HL_OK;
     }

@@ -807,12 +807,8 @@ static size_t recLdsBytes(const RecArgs& a) {
   for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (a.gates * a.L[j].nC + 1);
   return fl * sizeof(float);
 }
-template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_t lds, size_t* attr, hipStream_t s) {
-  if (lds > *attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    *attr = lds;
-  }
+template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_t lds, size_t*, hipStream_t s) {
+  if (lds > 0) { hipError_t e = ensureDynLds(reinterpret_cast<const void*>(kernel), lds); if (e != hipSuccess) return e; }
   hipLaunchKernelGGL(kernel, dim3(a.B), dim3(256), lds, s, a);
   return hipGetLastError();
 }

@@ -30,10 +30,12 @@ constexpr int GRAPH_SIZES[] = {999, 256, 128, 64, 32, 16, 8, 4, 2, 1};
 constexpr int CNT_MSG_FLOATS = 16;     // four counters x four 16-bit chunks (tail_dev.h: postPart)
 constexpr int CNT_MSG_OFFSET = 128;    // counters message inside the PARAM_TAIL floats behind the gradient (learner.cpp)
 
-void setTiles(GemmProblem& p, int& cursor) {
+void setTiles(GemmProblem& p, int& cursor, bool maySplit = false) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
   if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
-  p.tileStart = cursor; cursor += p.tilesM * p.tilesN;
+  // weight gradients over >= 1024 rows (recurrent nets: batch x BPTT steps): one workgroup per (tile, 256-row chunk)
+  p.nSplit = (maySplit && p.flavor == GEMM_W && p.K >= 1024) ? (p.K + 255) / 256 : 1;
+  p.tileStart = cursor; cursor += p.tilesM * p.tilesN * p.nSplit;
 }
 
 // GEMM problem tables, one set per minibatch buffer (they differ in X0 / gParam only)
@@ -78,7 +80,7 @@ int buildProblems(hl_learner* h) {
       if (h->hid[j].lstm == 4) {
         GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = 4 * L.nC; p.K = R;
         p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 4 * L.nC; p.C = h->G + L.indW; p.ldc = 4 * L.nC; p.biasOut = h->G + L.indB;
-        setTiles(p, cur); P.push_back(p);
+        setTiles(p, cur, true); P.push_back(p);
       } else {
         // MGU (Layer_GRU.h:196-229): [Wff Wsf] and the biases from the inputs; Wfr from the previous output and dLdF; Wsr from
         // (previous output x forget) and dLdS.  The two recurrent blocks have no bias: their bias row goes to the unused tail
@@ -86,15 +88,15 @@ int buildProblems(hl_learner* h) {
         const int nC = L.nC;
         GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + 1; p.N = 2 * nC; p.K = R;
         p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 2 * nC; p.C = h->G + L.indW; p.ldc = 2 * nC; p.biasOut = h->G + L.indB;
-        setTiles(p, cur); P.push_back(p);
+        setTiles(p, cur, true); P.push_back(p);
         GemmProblem f{}; f.flavor = GEMM_W; f.epi = EPI_DW; f.M = nC + 1; f.N = nC; f.K = R;
         f.A = L.A + L.nIn; f.lda = L.ldA; f.B = L.D; f.ldb = 2 * nC; f.C = h->G + L.indW + (long long)2 * nC * L.nIn; f.ldc = 2 * nC;
         f.biasOut = h->G + h->nParams;
-        setTiles(f, cur); P.push_back(f);
+        setTiles(f, cur, true); P.push_back(f);
         GemmProblem q{}; q.flavor = GEMM_W; q.epi = EPI_DW; q.M = nC + 1; q.N = nC; q.K = R;
         q.A = L.A2; q.lda = L.ldA2; q.B = L.D + nC; q.ldb = 2 * nC; q.C = h->G + L.indW + (long long)2 * nC * L.nIn + nC; q.ldc = 2 * nC;
         q.biasOut = h->G + h->nParams + 64;
-        setTiles(q, cur); P.push_back(q);
+        setTiles(q, cur, true); P.push_back(q);
       }
       if (L.hasRes) {
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = L.resW; r.K = R;
@@ -141,12 +143,19 @@ int buildProblems(hl_learner* h) {
       }
     }
     sb.dwCount = (int)P.size() - sb.dwIdx; sb.dwBlocks = cur;
+    {   // scratch of the split problems (shared by both minibatch buffers: steps are sequential)
+      size_t need = 0; sb.splitMaxMN = 0;
+      for (int i = 0; i < sb.dwCount; ++i) { const GemmProblem& q = P[sb.dwIdx + i]; if (q.nSplit > 1) { need += (size_t)q.nSplit * q.M * q.N; sb.splitMaxMN = std::max(sb.splitMaxMN, q.M * q.N); } }
+      if (need > h->splitPartFloats) { if (h->splitPart) hipFree(h->splitPart); h->splitPart = nullptr; HIPCK(devAlloc(&h->splitPart, need)); h->splitPartFloats = need; }
+      size_t off = 0;
+      for (int i = 0; i < sb.dwCount; ++i) { GemmProblem& q = P[sb.dwIdx + i]; if (q.nSplit > 1) { q.part = h->splitPart + off; off += (size_t)q.nSplit * q.M * q.N; } }
+    }
     // second copy of the dW table with the Adam update fused into the epilogue (single replica:
     // every gradient element is final inside the workgroup that produced it)
     sb.dwAdamIdx = (int)P.size();
     for (int i = 0; i < sb.dwCount; ++i) {
       GemmProblem p = P[sb.dwIdx + i];
-      p.adam = 1;
+      p.adam = p.nSplit > 1 ? 0 : 1; p.adamRed = p.nSplit > 1 ? 1 : 0;
       const long long offC = p.C - h->G;
       p.adW = h->W + offC; p.adM1 = h->M1 + offC; p.adM2 = h->M2 + offC;
       if (p.biasOut) { const long long offB = p.biasOut - h->G; p.adbW = h->W + offB; p.adbM1 = h->M1 + offB; p.adbM2 = h->M2 + offB; }
@@ -173,7 +182,8 @@ AdamHyper adamHyper(const hl_learner* h, int parity) {
 SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool computeEta) {
   SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->buf[parity].bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
   sa.X0 = h->buf[parity].X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
-  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.backupRng = 0; sa.noGather = h->preproc ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
+  // (recurrent layers read the raw states of their window straight from the replay: no gathered rows either)
+  sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.backupRng = 0; sa.noGather = (h->preproc || h->recurrent) ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
   return sa;
 }
 // replica exchanges are part of the step: several replicas, or a communicator was attached to a
@@ -275,7 +285,8 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
 int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
   const HeadArgs ha = headArgs(h, parity);
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
-  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_C); pex = &ex; }
+  // (recurrent nets have no forward GEMM launches: the whole sampler of the next step rides along the head kernel)
+  if (nextSample) { ex = extraSample(h, parity ^ 1, h->recurrent ? PH_ALL : PH_C); pex = &ex; }
   HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
   return HL_OK;
 }
@@ -323,6 +334,9 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   const ExtraArgs* pexW = sb.dxIdx.empty() ? pex : nullptr;
   HIPCK(timed(h, "gemm16_dw", s, [&] {
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s); }));
+  if (sb.splitMaxMN > 0)
+    HIPCK(timed(h, "splitk_reduce", s, [&] {
+      return launch_splitk_reduce(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.splitMaxMN, h->sc, hyp, s); }));
   return HL_OK;
 }
 int launchAdam(hl_learner* h, int parity) {
@@ -487,6 +501,14 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
       if (rc) break;
       continue;
     }
+    if (h->recurrent) {      // window forward, head (+ the sampler of the next step), BPTT, weight gradients (+ bookkeeping)
+      const RecArgs ra = recArgs(h, p);
+      if (launch_rec_forward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_forward"); break; }
+      rc = launchHead(h, p, s0, true); if (rc) break;
+      if (launch_rec_backward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_backward"); break; }
+      rc = launchBackward(h, p, true, s0, true); if (rc) break;
+      continue;
+    }
     rc = launchForward(h, p, s0, true); if (rc) break;
     rc = launchHead(h, p, s0, true); if (rc) break;
     rc = launchBackward(h, p, true, s0, true); if (rc) break;
@@ -527,7 +549,7 @@ bool graphUsable(const hl_learner* h, int U, int p0) {
 int captureAllGraphs(hl_learner* h) {
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
   static_assert(NS <= 16, "hl_learner::graphs is too small");
-  if (!h->useGraph || h->recurrent || (exchanging(h) && !(h->fusedOk && h->exchGraph && h->comm))) return HL_OK;
+  if (!h->useGraph || (exchanging(h) && !(h->fusedOk && h->exchGraph && h->comm))) return HL_OK;
   for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
     if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
     const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);

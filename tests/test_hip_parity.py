@@ -672,6 +672,8 @@ REC_SHAPES = [  # (layer type, hidden, dimS, bptt, batch): every instantiation /
     ("lstm", (64, 64), 30, 4, 8),           # one lane per gate
     ("lstm", (64, 64), 200, 3, 6),          # weights too large for LDS: the one-thread-per-gate kernels
     ("lstm", (48, 40), 130, 11, 5),         # BPTT window + weights beyond the LDS budget of the BPTT kernel only
+    ("lstm", (32, 32), 4, 16, 64),          # 64 x 17 = 1088 rows: the weight gradients are split over the rows (splitk_reduce_kernel)
+    ("mgu", (24, 16), 6, 15, 70),           # the same for the three weight-gradient problems of an MGU layer
     ("mgu", (24, 16, 8, 8), 7, 6, 12),
     ("mgu", (13,), 3, 5, 9),
     ("mgu", (64, 64), 200, 3, 6),
@@ -690,8 +692,9 @@ def test_recurrent_kernel_variants_match_oracle(hip_api, shape):
     for _ in range(3):
         G.step(1); O.step(1)
         _compare_step(G, O)
-    G.step(10); O.step(10)
+    G.step(10); O.step(10)                      # replayed: the sampler of the next step rides along the head kernel
     assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
     assert relinf(G.get_params()[0], O.get_params()[0]) < 20 * TOL32
 
 
