@@ -102,6 +102,8 @@ inline float uniformFloat(MT19937& g, float a, float b) {
 // ---------------------------------------------------------------------------
 // activation functions (Network/Layers/Functions.h)
 // ---------------------------------------------------------------------------
+// Utilities::safeExp (Utils/FunctionUtilities.h:51-54) with SMARTIES_EXP_CUT = 8 of the single-precision build (Definitions.h:43)
+inline nnReal nnSafeExp(nnReal v) { return std::exp(std::min((nnReal)8, std::max(-(nnReal)8, v))); }
 inline nnReal fEval(int f, nnReal in) {
   switch (f) {
     case HL_FUNC_LINEAR: return in;                                   // :40-82
@@ -110,6 +112,14 @@ inline nnReal fEval(int f, nnReal in) {
       else        { const nnReal e = std::exp( 2 * in); return (e - 1) / (1 + e); }
     case HL_FUNC_SOFTSIGN: return in / (1 + std::fabs(in));           // :328-331
     case HL_FUNC_RELU: return in > 0 ? in : 0;                        // :415-418
+    case HL_FUNC_LRELU: return in > 0 ? in : (nnReal)0.1 * in;         // :461-464 (PRELU_FAC = 0.1, :16-18)
+    case HL_FUNC_SIGM:                                                // :158-165
+      if (in > 0) return 1 / (1 + nnSafeExp(-in));
+      else { const nnReal ex = nnSafeExp(in); return ex / (1 + ex); }
+    case HL_FUNC_HARDSIGN: return in / std::sqrt(1 + in * in);         // :220-223
+    case HL_FUNC_SOFTPLUS: return (in + std::sqrt(1 + in * in)) / 2;   // :552-555
+    case HL_FUNC_EXPPLUS: return std::log(1 + nnSafeExp(in));          // :507-510
+    case HL_FUNC_EXP: return nnSafeExp(in);                            // :604-607
   }
   return in;
 }
@@ -119,6 +129,12 @@ inline nnReal fDiff(int f, nnReal in, nnReal out) {
     case HL_FUNC_TANH: return 1 - out * out;                          // :119-122
     case HL_FUNC_SOFTSIGN: { const nnReal d = 1 + std::fabs(in); return 1 / (d * d); }  // :333-337
     case HL_FUNC_RELU: return in > 0 ? 1 : 0;
+    case HL_FUNC_LRELU: return in > 0 ? 1 : (nnReal)0.1;                 // :465-468
+    case HL_FUNC_SIGM: return out * (1 - out);                          // :179-182
+    case HL_FUNC_HARDSIGN: { const nnReal d = std::sqrt(1 + in * in); return 1 / (d * d * d); }   // :225-229
+    case HL_FUNC_SOFTPLUS: return (1 + in / std::sqrt(1 + in * in)) / 2;  // :560-563
+    case HL_FUNC_EXPPLUS: return 1 / (1 + nnSafeExp(-in));              // :515-518
+    case HL_FUNC_EXP: return out;                                       // :614-617
   }
   return 1;
 }
@@ -128,6 +144,9 @@ inline Real fInitFactor(int f, int inps, int outs) {
     case HL_FUNC_TANH: return std::sqrt(6. / (inps + outs));          // :94-97
     case HL_FUNC_SOFTSIGN: return std::sqrt(6.0 / (inps + outs));     // :318-321
     case HL_FUNC_RELU: return std::sqrt(2. / inps);                   // :404-407
+    case HL_FUNC_LRELU: return std::sqrt(1.0 / inps);                 // :453-460
+    case HL_FUNC_SIGM: case HL_FUNC_HARDSIGN: return std::sqrt(6. / (inps + outs));   // :148-156, :210-218
+    case HL_FUNC_SOFTPLUS: case HL_FUNC_EXPPLUS: case HL_FUNC_EXP: return std::sqrt(2. / inps);   // :544-551, :496-501, :589-597
   }
   return 1;
 }
@@ -975,8 +994,7 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
   if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;
-  if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
-      cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
+  if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input

@@ -10,6 +10,8 @@ namespace hl {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Utilities::safeExp (Utils/FunctionUtilities.h:51-54), SMARTIES_EXP_CUT = 8 in the single-precision build (Definitions.h:43)
+__device__ __forceinline__ float nnSafeExp(float v) { return expf(fminf(8.f, fmaxf(-8.f, v))); }
 __device__ __forceinline__ float actEval(int f, float in) {   // Network/Layers/Functions.h
   switch (f) {
     case HL_FUNC_TANH:
@@ -17,6 +19,12 @@ __device__ __forceinline__ float actEval(int f, float in) {   // Network/Layers/
       else        { const float e = expf( 2 * in); return (e - 1) / (1 + e); }
     case HL_FUNC_SOFTSIGN: return in / (1 + fabsf(in));
     case HL_FUNC_RELU: return in > 0 ? in : 0.f;
+    case HL_FUNC_LRELU: return in > 0 ? in : 0.1f * in;                       // PRELU_FAC (Functions.h:16-18)
+    case HL_FUNC_SIGM: { if (in > 0) return 1 / (1 + nnSafeExp(-in)); const float ex = nnSafeExp(in); return ex / (1 + ex); }
+    case HL_FUNC_HARDSIGN: return in / sqrtf(1 + in * in);
+    case HL_FUNC_SOFTPLUS: return (in + sqrtf(1 + in * in)) / 2;
+    case HL_FUNC_EXPPLUS: return logf(1 + nnSafeExp(in));
+    case HL_FUNC_EXP: return nnSafeExp(in);
     default: return in;
   }
 }
@@ -25,6 +33,12 @@ __device__ __forceinline__ float actDiff(int f, float in, float out) {
     case HL_FUNC_TANH: return 1 - out * out;
     case HL_FUNC_SOFTSIGN: { const float d = 1 + fabsf(in); return 1 / (d * d); }
     case HL_FUNC_RELU: return in > 0 ? 1.f : 0.f;
+    case HL_FUNC_LRELU: return in > 0 ? 1.f : 0.1f;
+    case HL_FUNC_SIGM: return out * (1 - out);
+    case HL_FUNC_HARDSIGN: { const float d = sqrtf(1 + in * in); return 1 / (d * d * d); }
+    case HL_FUNC_SOFTPLUS: return (1 + in / sqrtf(1 + in * in)) / 2;
+    case HL_FUNC_EXPPLUS: return 1 / (1 + nnSafeExp(-in));
+    case HL_FUNC_EXP: return out;
     default: return 1.f;
   }
 }

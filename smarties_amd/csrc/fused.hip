@@ -69,6 +69,12 @@ template <int CF, class Body> __device__ __forceinline__ void dispatchFunc(int f
   else if (func == HL_FUNC_SOFTSIGN) body(FuncTag<HL_FUNC_SOFTSIGN>{});
   else if (func == HL_FUNC_TANH) body(FuncTag<HL_FUNC_TANH>{});
   else if (func == HL_FUNC_RELU) body(FuncTag<HL_FUNC_RELU>{});
+  else if (func == HL_FUNC_LRELU) body(FuncTag<HL_FUNC_LRELU>{});
+  else if (func == HL_FUNC_SIGM) body(FuncTag<HL_FUNC_SIGM>{});
+  else if (func == HL_FUNC_HARDSIGN) body(FuncTag<HL_FUNC_HARDSIGN>{});
+  else if (func == HL_FUNC_SOFTPLUS) body(FuncTag<HL_FUNC_SOFTPLUS>{});
+  else if (func == HL_FUNC_EXPPLUS) body(FuncTag<HL_FUNC_EXPPLUS>{});
+  else if (func == HL_FUNC_EXP) body(FuncTag<HL_FUNC_EXP>{});
   else body(FuncTag<HL_FUNC_LINEAR>{});
 }
 __device__ __forceinline__ float resOut(float y, float in, float w, float b) { return y + fmaf(in, w, b); }

@@ -37,20 +37,22 @@ __device__ __forceinline__ void adamApply(const AdamCoef& c, float g, float* W, 
 }
 
 __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, float* red, const DevScalars* sc,
-                                            const AdamHyper& hyp) {
+                                            const AdamHyper& hyp, int ks) {
   // out[j] = sum_m A[m][j] * (B ? B[m][j] : 1): 16 columns per workgroup, 16 row-partitions,
   // 8 independent loads in flight per thread
   const int tid = threadIdx.x, jj = tid & 15, part = tid >> 4;
   const int j = tile * 16 + jj;
   float acc = 0.f;
+  // split problems (many rows: batch x BPTT steps): this workgroup sums the 256 rows of chunk ks only
+  const int mBeg = P.nSplit > 1 ? ks * KC : 0, mEnd = P.nSplit > 1 ? min(P.K, mBeg + KC) : P.K;
   if (j < P.N) {
-    for (int m0 = part; m0 < P.K; m0 += 128) {
+    for (int m0 = mBeg + part; m0 < mEnd; m0 += 128) {
       float av[8], bv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int m = m0 + 16 * u;
-        av[u] = m < P.K ? P.A[(size_t)m * P.lda + j] : 0.f;
-        bv[u] = (P.B && m < P.K) ? P.B[(size_t)m * P.ldb + j] : 1.f;
+        av[u] = m < mEnd ? P.A[(size_t)m * P.lda + j] : 0.f;
+        bv[u] = (P.B && m < mEnd) ? P.B[(size_t)m * P.ldb + j] : 1.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += av[u] * bv[u];
@@ -62,6 +64,7 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
     float g = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) g += red[q * 16 + jj];
+    if (P.nSplit > 1) { P.part[(size_t)ks * P.N + j] = g; return; }
     P.C[j] = g;
     if (P.adam) { AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac; adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
   }
@@ -80,9 +83,9 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   float* sA = reinterpret_cast<float*>(smem);
   float* sB = sA + 16 * LDR;
   float* red = sB + 16 * LDR;
-  if (flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp); return; }
   int ks = 0;                                  // chunk of the reduction (split problems only)
   if (FL < 0 && P.nSplit > 1) { const int nT0 = P.tilesM * P.tilesN; ks = tile / nT0; tile -= ks * nT0; }
+  if (flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp, ks); return; }
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
   // Give XCD x the contiguous (row-major) tile range [x*nT/8, (x+1)*nT/8): the tiles of one XCD
   // then share their A row-panels, and each L2 fetches 1/8 of A instead of all of it.
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* __restrict__ probs, const DevScalars* __restrict__ sc, AdamHyper hyp) {
   const GemmProblem P = probs[blockIdx.y];
   if (P.nSplit <= 1) return;
-  const int i = blockIdx.x * 256 + threadIdx.x, MN = P.M * P.N;
+  const bool col = P.flavor == RED_COL;         // column sums: one row of N values
+  const int i = blockIdx.x * 256 + threadIdx.x, MN = col ? P.N : P.M * P.N;
   if (i >= MN) return;
   float s = 0.f;
   for (int c0 = 0; c0 < P.nSplit; c0 += 8) {
@@ -307,7 +311,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* _
   }
   const int m = i / P.N, n = i - m * P.N;
   AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac;
-  if (m < P.M - 1) {
+  if (col) {
+    P.C[i] = s;
+    if (P.adamRed) adamApply(c, s, P.adW, P.adM1, P.adM2, i);
+  } else if (m < P.M - 1) {
     const size_t o = (size_t)m * P.ldc + n;
     P.C[o] = s;
     if (P.adamRed) adamApply(c, s, P.adW, P.adM1, P.adM2, o);

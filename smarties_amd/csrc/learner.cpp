@@ -463,8 +463,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->n_ranks > 256) return HL_ERR_UNSUPPORTED;   // the replica counters travel as 16-bit chunks in fp32 (tail_dev.h: encodeCounters)
   if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;   // head kernel: one option per lane, deltas staged in 72 floats
-  if (cfg->nnFunc != HL_FUNC_LINEAR && cfg->nnFunc != HL_FUNC_TANH && cfg->nnFunc != HL_FUNC_SOFTSIGN &&
-      cfg->nnFunc != HL_FUNC_RELU) return HL_ERR_UNSUPPORTED;
+  if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;   // the ten names of makeFunction (Functions.h:643-668)
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
   if (cfg->nn_type != HL_NN_FFNN && cfg->nn_type != HL_NN_LSTM && cfg->nn_type != HL_NN_MGU) return HL_ERR_UNSUPPORTED;
   if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: one gate per thread of a 256-thread workgroup
@@ -677,7 +676,9 @@ int hl_init_weights(hl_learner* h) {
   };
   auto initFactor = [&](int f, int inps, int outs) -> double {
     switch (f) { case HL_FUNC_LINEAR: return std::sqrt(1. / inps); case HL_FUNC_TANH: return std::sqrt(6. / (inps + outs));
-      case HL_FUNC_SOFTSIGN: return std::sqrt(6.0 / (inps + outs)); case HL_FUNC_RELU: return std::sqrt(2. / inps); }
+      case HL_FUNC_SOFTSIGN: return std::sqrt(6.0 / (inps + outs)); case HL_FUNC_RELU: return std::sqrt(2. / inps);
+      case HL_FUNC_LRELU: return std::sqrt(1.0 / inps); case HL_FUNC_SIGM: case HL_FUNC_HARDSIGN: return std::sqrt(6. / (inps + outs));
+      case HL_FUNC_SOFTPLUS: case HL_FUNC_EXPPLUS: case HL_FUNC_EXP: return std::sqrt(2. / inps); }
     return 1;
   };
   std::vector<float> W((size_t)h->nParams, 0.f);

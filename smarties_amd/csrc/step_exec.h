@@ -34,7 +34,7 @@ void setTiles(GemmProblem& p, int& cursor, bool maySplit = false) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
   if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
   // weight gradients over >= 1024 rows (recurrent nets: batch x BPTT steps): one workgroup per (tile, 256-row chunk)
-  p.nSplit = (maySplit && p.flavor == GEMM_W && p.K >= 1024) ? (p.K + 255) / 256 : 1;
+  p.nSplit = (maySplit && (p.flavor == GEMM_W || p.flavor == RED_COL) && p.K >= 1024) ? (p.K + 255) / 256 : 1;
   p.tileStart = cursor; cursor += p.tilesM * p.tilesN * p.nSplit;
 }
 
@@ -101,10 +101,10 @@ int buildProblems(hl_learner* h) {
       if (L.hasRes) {
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = L.resW; r.K = R;
         r.A = L.Rd; r.lda = L.ldR; r.B = L.A; r.ldb = L.ldA; r.C = h->G + L.indWr;
-        setTiles(r, cur); P.push_back(r);
+        setTiles(r, cur, true); P.push_back(r);
         GemmProblem s2{}; s2.flavor = RED_COL; s2.epi = EPI_NONE; s2.N = L.resW; s2.K = R;
         s2.A = L.Rd; s2.lda = L.ldR; s2.B = nullptr; s2.C = h->G + L.indBr;
-        setTiles(s2, cur); P.push_back(s2);
+        setTiles(s2, cur, true); P.push_back(s2);
       }
     }
     for (int l = 0; l < h->nConv; ++l) {   // convolution biases (one per output element): column sums of the layer's deltas
@@ -145,10 +145,10 @@ int buildProblems(hl_learner* h) {
     sb.dwCount = (int)P.size() - sb.dwIdx; sb.dwBlocks = cur;
     {   // scratch of the split problems (shared by both minibatch buffers: steps are sequential)
       size_t need = 0; sb.splitMaxMN = 0;
-      for (int i = 0; i < sb.dwCount; ++i) { const GemmProblem& q = P[sb.dwIdx + i]; if (q.nSplit > 1) { need += (size_t)q.nSplit * q.M * q.N; sb.splitMaxMN = std::max(sb.splitMaxMN, q.M * q.N); } }
+      for (int i = 0; i < sb.dwCount; ++i) { const GemmProblem& q = P[sb.dwIdx + i]; if (q.nSplit > 1) { const int mn = q.flavor == RED_COL ? q.N : q.M * q.N; need += (size_t)q.nSplit * mn; sb.splitMaxMN = std::max(sb.splitMaxMN, mn); } }
       if (need > h->splitPartFloats) { if (h->splitPart) hipFree(h->splitPart); h->splitPart = nullptr; HIPCK(devAlloc(&h->splitPart, need)); h->splitPartFloats = need; }
       size_t off = 0;
-      for (int i = 0; i < sb.dwCount; ++i) { GemmProblem& q = P[sb.dwIdx + i]; if (q.nSplit > 1) { q.part = h->splitPart + off; off += (size_t)q.nSplit * q.M * q.N; } }
+      for (int i = 0; i < sb.dwCount; ++i) { GemmProblem& q = P[sb.dwIdx + i]; if (q.nSplit > 1) { q.part = h->splitPart + off; off += (size_t)q.nSplit * (q.flavor == RED_COL ? q.N : q.M * q.N); } }
     }
     // second copy of the dW table with the Adam update fused into the epilogue (single replica:
     // every gradient element is final inside the workgroup that produced it)

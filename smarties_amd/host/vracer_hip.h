@@ -94,7 +94,13 @@ class VRACER {
     if (f == "SoftSign") return HL_FUNC_SOFTSIGN;
     if (f == "Relu") return HL_FUNC_RELU;
     if (f == "Linear") return HL_FUNC_LINEAR;
-    die("nnFunc " + f + " is not supported by the HIP learner");
+    if (f == "LRelu") return HL_FUNC_LRELU;
+    if (f == "Sigm") return HL_FUNC_SIGM;
+    if (f == "HardSign") return HL_FUNC_HARDSIGN;
+    if (f == "SoftPlus") return HL_FUNC_SOFTPLUS;
+    if (f == "ExpPlus") return HL_FUNC_EXPPLUS;
+    if (f == "Exp") return HL_FUNC_EXP;
+    die("Activation function not recognized");      // makeFunction (Network/Layers/Functions.h:643-668)
   }
   InProgress& episodeOf(const Agent& a) { if (a.ID >= inProgress.size()) inProgress.resize(a.ID + 1); return inProgress[a.ID]; }
 

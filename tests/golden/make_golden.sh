@@ -51,6 +51,11 @@ TMP="$(mktemp -d)"; cd "$TMP"   # the reference writes agent_00_* log files into
 "$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/racer_atari.bin" dimS=7056 dimA=1 nOpt=6 nApp=3 \
    "conv=84,84,4,8,8,4;20,20,8,16,6,2;8,8,16,32,4,1;5,5,32,64,3,1" layers=512 nnFunc=Tanh batch=128 nEps=24 lenMin=8 lenMax=18 pTerm=0.5 \
    nSteps=3 gradSteps=1,3 maxObs=262144 minObs=131072 gamma=0.99 explNoise=0.05 lean=1
+# G-act-*: the other six activation functions of makeFunction (Network/Layers/Functions.h:643-668), one small fixture each
+for F in LRelu Sigm HardSign SoftPlus ExpPlus Exp; do
+  "$DRV" fixture "$HERE/act_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 nnFunc=$F batch=8 nEps=12 lenMin=5 lenMax=20 pTerm=0.5 \
+     nSteps=4 gradSteps=1,4 maxObs=600 minObs=100
+done
 # official-vs-manual cross check of the harness itself (weights must be bit-identical)
 "$DRV" fixture "$TMP/off.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 maxObs=2000 minObs=500 path=official

@@ -13,7 +13,8 @@ from smarties_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh"}
+ACT_FIXTURES = ["act_%s.bin" % f for f in ("LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp")]     # the other names of makeFunction (Functions.h:643-668)
+FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
 TOL32 = 1e-5     # north_star: 1e-5 relative fp32
 TOL64 = 1e-9
 
@@ -49,7 +50,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"] + ACT_FIXTURES)
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
@@ -641,6 +642,25 @@ def _random_config(rng):
     sc = dict(seed=int(rng.integers(1, 1000)), dimS=dimS, dimA=kw["dimA"], lenMin=2, lenMax=int(rng.integers(3, 40)),
               pTerm=float(rng.choice([0.0, 0.5, 1.0])))
     return kw, sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("func", ["LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp"])
+def test_other_activation_functions_on_the_generic_path(hip_api, func):
+    """The six remaining names of makeFunction (Functions.h:643-668) on a layout the fused kernel does not serve (three unequal
+    layers: five launches, run-time dispatch in the GEMM epilogues) and as the weight-initialisation rule of recurrent layers."""
+    kw = dict(dimS=9, dimA=3, bounded=[0, 1, 0], hidden=(24, 16, 8), nnFunc=func, batchSize=12, maxTotObsNum=1500, randSeed=5)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=3, dimS=9, dimA=3, lenMin=3, lenMax=30, pTerm=0.3), 30)
+    for _ in range(4):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(17); O.step(17)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 4 * TOL32
+    kw = dict(dimS=6, dimA=2, hidden=(16, 16), nnFunc=func, batchSize=8, maxTotObsNum=1500, randSeed=5, nn_type=capi.NN_LSTM, nnBPTTseq=4)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=3, dimS=6, dimA=2, lenMin=3, lenMax=30, pTerm=0.3), 30)
+    assert np.array_equal(G.get_params()[0], O.get_params()[0])          # Layer::initialize with this function's fan-in / fan-out rule
+    G.step(3); O.step(3)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 4 * TOL32
 
 
 @pytest.mark.gpu

@@ -8,7 +8,8 @@ from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixt
                     episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree, fx_vec_dev, flat_for)
 from smarties_amd import capi
 
-FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh"}
+ACT_FIXTURES = ["act_%s.bin" % f for f in ("LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp")]     # the other names of makeFunction (Functions.h:643-668)
+FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
 
 
 def make(name):
@@ -18,7 +19,7 @@ def make(name):
     return fx, L
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"] + ACT_FIXTURES)
 def test_layout_init_and_rng_match_reference(name):
     """Parameters blob layout (Parameters.h:159-176), Layer::initialize draw order and the
     libstdc++ uniform_real_distribution<float> restatement: weights and RNG state bit-exact."""
@@ -53,7 +54,7 @@ def test_initialize_matches_reference(name):
     assert np.array_equal(L.get_rng_state(), fx["rng0"])
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"] + ACT_FIXTURES)
 def test_steps_match_reference(name):
     """Every tapped step: sampled flat indices / (episode, t) bit-exact (mt19937 + Lemire
     uniform_int + sort/unique/redraw + the reference's std::sort episode permutation); network
