@@ -186,6 +186,12 @@ enum {
 enum { HL_EP_RETURN = 0, HL_EP_VALUE = 1, HL_EP_ADVANTAGE = 2, HL_EP_IMPW = 3, HL_EP_DKL = 4,
        HL_EP_DELTAQ = 5 };
 
+/* Threading: every entry point takes the learner's own lock, so calls on one handle may come from several threads -- the
+ * training thread stepping while env-service threads hand over finished episodes (hl_append_episode, which never waits
+ * for the device) or ask for actions (hl_forward); the reference's dataset_mutex (ReplayMemory/MemoryBuffer.h:55,
+ * callers Core/Master.cpp:66-86).  Appended episodes are visible to every later call.  hl_destroy must not race with
+ * other calls on the same handle. */
+
 /* ---- lifetime ------------------------------------------------------------ */
 HL_API int hl_create(const hl_config* cfg, hl_learner** out);
 HL_API int hl_destroy(hl_learner* h);
@@ -291,6 +297,9 @@ HL_API int hl_restart_memory(hl_learner* h, const char* base, int32_t rank);
 HL_API int hl_set_tap(hl_learner* h, int32_t enable);
 HL_API int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t dst_bytes);
 HL_API int hl_get_scalars(hl_learner* h, hl_scalars* out);
+/* the host-side counters only -- no device wait: what Learner::locDataSetSize / nGradSteps / nLocTimeSteps read between
+ * steps (Learners/Learner.h:84-101).  Any pointer may be NULL. */
+HL_API int hl_get_counts(hl_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int64_t* nGradSteps, int64_t* nSeenSteps, int64_t* nSeenEps);
 HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
 
 /* ---- statistics surface (third row) ---------------------------------------

@@ -1492,6 +1492,12 @@ int ol_get_scalars(ol_learner* h, hl_scalars* o) {
   o->adam_beta_t_1 = h->beta_t_1; o->adam_beta_t_2 = h->beta_t_2; o->adam_nStep = h->nStep;
   return HL_OK;
 }
+int ol_get_counts(ol_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int64_t* nGradSteps, int64_t* nSeenSteps, int64_t* nSeenEps) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (nStoredSteps) *nStoredSteps = h->nTransitions; if (nStoredEps) *nStoredEps = (int64_t)h->episodes.size();
+  if (nGradSteps) *nGradSteps = h->nGradSteps; if (nSeenSteps) *nSeenSteps = h->nSeenSteps; if (nSeenEps) *nSeenEps = h->nSeenEps;
+  return HL_OK;
+}
 int ol_get_stats(ol_learner* h, hl_stats* o) { if (!h || !o) return HL_ERR_BAD_ARG; *o = h->stats; return HL_OK; }
 
 int ol_synth_episode_len(const synth_cfg* c, uint64_t e, int* term) { return synth_episode_len(c, e, term); }

@@ -180,6 +180,7 @@ class CApi:
         for name, (res, args) in {
             "comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
             "comm_init": (C.c_int, [P, C.POINTER(C.c_uint8)]),
+            "get_counts": (C.c_int, [P, pi64, pi64, pi64, pi64, pi64]),
             "timing_enable": (C.c_int, [P, I32]),
             "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
@@ -415,6 +416,12 @@ class Learner:
         out = np.zeros((st.shape[0], self.nOut), np.float64)
         self._ck(self.api.fn("forward")(self.h, st.shape[0], _ptr(st, C.c_float), _ptr(out, C.c_double)))
         return out
+
+    def counts(self):
+        """(nStoredSteps, nStoredEps, nGradSteps, nSeenSteps, nSeenEps): host-side counters, no device wait"""
+        v = [C.c_int64() for _ in range(5)]
+        self._ck(self.api.fn("get_counts")(self.h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
 
     def sync(self):
         self._ck(self.api.fn("sync")(self.h))

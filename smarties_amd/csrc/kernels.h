@@ -174,6 +174,16 @@ hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra,
 size_t fused_lds_bytes(int dS, int H);
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);
+// episode ingestion (misc.hip: ingest_kernel): a batch of finished episodes staged in pinned host memory -- descriptor table
+// first, then per episode states f32 | actions f64 | behaviour policies f64 | rewards f64 | values f32 | advantages f32, each
+// block 16-byte aligned -- is scattered into the replay's structure of arrays by ONE kernel that reads the host buffer directly
+struct IngestDesc { long long off, tag; unsigned long long data; int N, eid, term; float totR; };   // data: byte offset of the episode's block
+struct IngestArgs {
+  DevReplay rp; const unsigned char* stage; int nEp, dS, dA, polDim;
+  const double* stats; int nEpTable;     // stats[1] = avgSquaredErr over the nEpTable episodes of the device table (placeholder error of new episodes)
+};
+constexpr int INGEST_MAX_EP = 1024;
+hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s);
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <string>
 #include <sstream>
 #include <iomanip>
@@ -85,6 +86,15 @@ struct hl_learner {
   long long nGatheredB4Startup = INT64_MAX;
   bool tableDirty = true, countsDirty = true, initialized = false, inStep = false;
   double lastAvgSqErr = 0;
+  // One lock per learner: every entry point takes it, so finished episodes (hl_append_episode) and rollout inference
+  // (hl_forward) may come from env-service threads while the training thread steps (the reference's dataset_mutex,
+  // ReplayMemory/MemoryBuffer.h:55; callers Core/Master.cpp:66-86).  Entry points only enqueue device work, so the lock
+  // is held for microseconds except where a call has to wait for the device by its nature (read-backs).
+  mutable std::recursive_mutex mu;
+  // episode ingestion: two pinned host buffers filled in turn; a buffer is handed to ONE ingest kernel (which reads it
+  // over the bus) when it is full or when the device state has to be current (flushPending)
+  struct Staging { unsigned char* host = nullptr; size_t cap = 0, used = 0; int nEp = 0; hipEvent_t ev = nullptr; bool inFlight = false; };
+  Staging stg[2]; int stgCur = 0; int tableCount = 0;      // tableCount: episodes in the table the device currently holds
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
@@ -120,6 +130,7 @@ int fail(hl_learner* h, int code, const std::string& m) { if (h) h->err = m; ret
 int hipFail(hl_learner* h, hipError_t e, const char* what) {
   return fail(h, HL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+#define HL_LOCK(h) std::lock_guard<std::recursive_mutex> hl_lock_guard__((h)->mu)
 #define HIPCK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return hipFail(h, e__, #x); } while (0)
 #define NCCLCK(x) do { ncclResult_t r__ = (x); if (r__ != ncclSuccess) return fail(h, HL_ERR_COMM, std::string(#x) + ": " + ncclGetErrorString(r__)); } while (0)
 
@@ -322,8 +333,10 @@ template <typename T> hipError_t repack(T** arr, size_t width, long long newCap,
   *arr = q;
   return hipSuccess;
 }
+int flushStaging(hl_learner* h);
 int growSlots(hl_learner* h, long long need) {
   if (need <= h->capSlots) return HL_OK;
+  if (h->rp.S) { int rc = flushStaging(h); if (rc) return rc; }     // staged episodes carry slot offsets of the present layout
   const long long newCap = std::max(need, h->capSlots + h->capSlots / 2 + 4096);
   const int dS = h->dS, dA = h->dA; hipStream_t s = h->stream;
   HIPCK(repack(&h->rp.S, dS, newCap, h->order, s)); HIPCK(repack(&h->rp.A, dA, newCap, h->order, s));
@@ -395,7 +408,7 @@ int uploadTable(hl_learner* h) {
   HIPCK(hipMemcpyAsync(h->rp.posRec, rec, (nEp + 1) * sizeof(PosRec), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->rp.posPrefix, pre, (nEp + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->rp.posEid, pe, nEp * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  h->tableDirty = false;
+  h->tableDirty = false; h->tableCount = (int)nEp;
   return HL_OK;
 }
 
@@ -417,11 +430,28 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute, int skip
 
 int dropPresample(hl_learner* h);      // step_exec.h
 
+// hand the staged episodes to the ingest kernel (one launch for the whole batch) and switch to the other buffer
+int flushStaging(hl_learner* h) {
+  hl_learner::Staging& st = h->stg[h->stgCur];
+  if (st.nEp == 0) return HL_OK;
+  // placeholder error of the new episodes: the average squared error over the episodes the device table holds right now
+  // (ReplayStats::avgSquaredErr as of the last statistics pass, MemoryBuffer.cpp:486-487)
+  if (h->tableCount > 0) HIPCK(launch_stats(h->sc, h->rp, h->tableCount, h->dStatsOut, h->stream));
+  IngestArgs ia{}; ia.rp = h->rp; ia.stage = st.host; ia.nEp = st.nEp; ia.dS = h->dS; ia.dA = h->dA; ia.polDim = h->polDim;
+  ia.stats = h->dStatsOut; ia.nEpTable = h->tableCount;
+  HIPCK(timed(h, "ingest_kernel", h->stream, [&] { return launch_ingest(ia, h->stream); }));
+  HIPCK(hipEventRecord(st.ev, h->stream));
+  st.inFlight = true; st.nEp = 0; st.used = 0;
+  h->stgCur ^= 1;
+  return HL_OK;
+}
+
 // everything the host queued since the last step: table, counters, Retrace of new episodes
 int flushPending(hl_learner* h) {
   if (h->tableDirty || h->countsDirty || !h->pendingRetrace.empty()) {   // a minibatch drawn ahead saw the old table
     int rc = dropPresample(h); if (rc) return rc;
   }
+  { int rc = flushStaging(h); if (rc) return rc; }
   if (h->tableDirty) { int rc = uploadTable(h); if (rc) return rc; }
   if (h->countsDirty) {
     HIPCK(launch_set_counts(h->sc, h->nTransitions, (long long)h->order.size(), h->nSeenEps, h->nSeenSteps, h->stream));
@@ -621,6 +651,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
 
 int hl_destroy(hl_learner* h) {
   if (!h) return HL_OK;
+  h->mu.lock();      // (released before the handle goes away; no other thread may still be using it)
   if (h->stream) hipStreamSynchronize(h->stream);
   timerFlush(h);
   invalidateGraphs(h);
@@ -645,7 +676,9 @@ int hl_destroy(hl_learner* h) {
   for (int j = 0; j < h->nHidden; ++j) { DevHidden& d = h->hid[j];
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);
+  for (auto& st : h->stg) { if (st.host) hipHostFree(st.host); if (st.ev) hipEventDestroy(st.ev); }
   if (h->stream) hipStreamDestroy(h->stream);
+  h->mu.unlock();
   delete h; return HL_OK;
 }
 
@@ -654,6 +687,7 @@ int32_t hl_num_outputs(const hl_learner* h) { return h ? h->nOut : -1; }
 int32_t hl_num_layers(const hl_learner* h) { return h ? (int32_t)h->indW.size() : -1; }
 int hl_param_layout(const hl_learner* h, int64_t* indW, int64_t* nW, int64_t* indB, int64_t* nB) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   for (size_t l = 0; l < h->indW.size(); ++l) {
     if (indW) indW[l] = h->indW[l];
     if (nW) nW[l] = h->nW[l];
@@ -666,6 +700,7 @@ int hl_param_layout(const hl_learner* h, int64_t* indW, int64_t* nW, int64_t* in
 // Layer::initialize in build order (Builder.cpp:131-137; Layer_Base.h:115-141; Layers.h:395-400,548-553)
 int hl_init_weights(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = dropPresample(h); if (rc) return rc;
   DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   HostMT g; std::memcpy(g.x, s.rng, sizeof(g.x)); g.p = s.rngPos;
@@ -718,6 +753,7 @@ int hl_init_weights(hl_learner* h) {
 
 int hl_set_params(hl_learner* h, const float* w, const float* m1, const float* m2) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const size_t n = (size_t)h->nParams * sizeof(float);
   if (w) HIPCK(hipMemcpyAsync(h->W, w, n, hipMemcpyHostToDevice, h->stream));
   if (m1) HIPCK(hipMemcpyAsync(h->M1, m1, n, hipMemcpyHostToDevice, h->stream));
@@ -727,6 +763,7 @@ int hl_set_params(hl_learner* h, const float* w, const float* m1, const float* m
 }
 int hl_get_params(hl_learner* h, float* w, float* m1, float* m2) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const size_t n = (size_t)h->nParams * sizeof(float);
   if (w) HIPCK(hipMemcpyAsync(w, h->W, n, hipMemcpyDeviceToHost, h->stream));
   if (m1) HIPCK(hipMemcpyAsync(m1, h->M1, n, hipMemcpyDeviceToHost, h->stream));
@@ -736,6 +773,7 @@ int hl_get_params(hl_learner* h, float* w, float* m1, float* m2) {
 }
 int hl_set_rng_state(hl_learner* h, const uint32_t st[625]) {
   if (!h || !st) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   { int rc = dropPresample(h); if (rc) return rc; }
   HIPCK(hipMemcpyAsync(&h->sc->rng[0], st, 624 * 4, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(&h->sc->rngPos, st + 624, 4, hipMemcpyHostToDevice, h->stream));
@@ -744,6 +782,7 @@ int hl_set_rng_state(hl_learner* h, const uint32_t st[625]) {
 }
 int hl_get_rng_state(hl_learner* h, uint32_t st[625]) {
   if (!h || !st) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = dropPresample(h); if (rc) return rc;      // the state as of after the last executed step
   DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   std::memcpy(st, s.rng, 624 * 4); st[624] = s.rngPos;
@@ -751,53 +790,47 @@ int hl_get_rng_state(hl_learner* h, uint32_t st[625]) {
 }
 
 // MemoryBuffer::addEpisodeToTrainingSet + Episode::finalize + pushBackEpisode
-// (MemoryBuffer.cpp:131-170,479-520; Episode.cpp:244-274): host -> HBM, Retrace queued on the stream
+// (MemoryBuffer.cpp:131-170,479-520; Episode.cpp:244-274).  The host bookkeeping (slot range, episode id, counters, order)
+// is immediate; the data is copied into the pinned staging buffer -- the caller's arrays are free after return -- and
+// reaches HBM with the next ingest launch (flushStaging); the Retrace estimate follows on the stream.  No device wait here.
 int hl_append_episode(hl_learner* h, int32_t N, const float* states, const double* actions, const double* mu,
                       const double* rewards, const float* values, const float* advantages, int32_t terminated,
                       int64_t tag) {
   if (!h || !states || !actions || !mu || !rewards || !values) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (N < 2) return fail(h, HL_ERR_BAD_ARG, "Episode must at least have s0 and sT");
-  const int dS = h->dS, dA = h->dA;
+  const int dS = h->dS, dA = h->dA, pD = h->polDim;
   long long off = 0; int rc = allocSlots(h, N, &off); if (rc) return rc;
   int eid;
   if (!h->freeEids.empty()) { eid = h->freeEids.back(); h->freeEids.pop_back(); }
   else { eid = h->nextEid++; rc = growEpisodes(h, eid + 1); if (rc) return rc; }
-  // stage the derived per-step arrays + episode record in pinned memory
   const size_t nf = (size_t)N;
-  const size_t bytes = nf * 6 * sizeof(float) + AGG_N * sizeof(float) + 64;
-  rc = ensurePinned(h, bytes + 4096); if (rc) return rc;
-  HIPCK(hipStreamSynchronize(h->stream));
-  float* p = (float*)h->pinned;
-  float *pADV = p, *pRET = p + nf, *pDQ = p + 2 * nf, *pIMPW = p + 3 * nf, *pDKL = p + 4 * nf, *pAGG = p + 5 * nf;
-  const float maxError = (float)std::sqrt(std::max((double)FLT_EPSILON, h->lastAvgSqErr));
-  double totR = 0;
-  for (int t = 0; t < N; ++t) {
-    pADV[t] = advantages ? advantages[t] : 0.f; pRET[t] = 0.f; pDQ[t] = maxError; pIMPW[t] = 1.f; pDKL[t] = 0.f;
-    if (t) totR += rewards[t];
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t bS = al16(nf * dS * 4), bA = nf * dA * 8, bMU = nf * pD * 8, bR = nf * 8, bV = nf * 4, bADV = nf * 4;
+  const size_t need = al16(bS + bA + bMU + bR + bV + bADV);
+  const size_t head = al16(sizeof(IngestDesc) * INGEST_MAX_EP);
+  hl_learner::Staging* st = &h->stg[h->stgCur];
+  if (st->nEp >= INGEST_MAX_EP || (st->nEp > 0 && st->used + need > st->cap)) { rc = flushStaging(h); if (rc) return rc; st = &h->stg[h->stgCur]; }
+  if (st->inFlight) { HIPCK(hipEventSynchronize(st->ev)); st->inFlight = false; }      // the kernel that read this buffer is done
+  if (head + need > st->cap) {       // (an episode larger than the buffer: grow it; it holds nothing at this point)
+    if (st->host) hipHostFree(st->host);
+    st->cap = std::max<size_t>(head + need, (size_t)32 << 20); st->host = nullptr;
+    HIPCK(hipHostMalloc((void**)&st->host, st->cap, hipHostMallocDefault));
+    if (!st->ev) HIPCK(hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
   }
-  pIMPW[N - 1] = 0.f;
-  for (int i = 0; i < AGG_N; ++i) pAGG[i] = 0.f;
-  pAGG[AGG_TOTR] = (float)totR; pAGG[AGG_AVGSQERR] = maxError * maxError; pAGG[AGG_MAXABSERR] = maxError;
-  pAGG[AGG_MAXQ] = -1e9f; pAGG[AGG_MINQ] = 1e9f;
-  hipStream_t s = h->stream;
-  HIPCK(hipMemcpyAsync(h->rp.S + (size_t)off * dS, states, nf * dS * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.A + (size_t)off * dA, actions, nf * dA * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.MU + (size_t)off * h->polDim, mu, nf * h->polDim * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.R + off, rewards, nf * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.V + off, values, nf * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.ADV + off, pADV, nf * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.RET + off, pRET, nf * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.DQ + off, pDQ, nf * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.IMPW + off, pIMPW, nf * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.DKL + off, pDKL, nf * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.epAgg + (size_t)eid * AGG_N, pAGG, AGG_N * sizeof(float), hipMemcpyHostToDevice, s));
-  const long long off64 = off; const int n32 = N; const unsigned char term8 = terminated ? 1 : 0;
-  HIPCK(hipMemcpyAsync(h->rp.epOff + eid, &off64, sizeof(long long), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.epN + eid, &n32, sizeof(int), hipMemcpyHostToDevice, s));
-  HIPCK(hipMemcpyAsync(h->rp.epTerm + eid, &term8, 1, hipMemcpyHostToDevice, s));
-  const long long tag64 = tag;
-  HIPCK(hipMemcpyAsync(h->rp.epTag + eid, &tag64, sizeof(long long), hipMemcpyHostToDevice, s));
-  HIPCK(hipStreamSynchronize(s));     // caller-owned / stack buffers may go away after return
+  if (st->nEp == 0) st->used = head;
+  unsigned char* p = st->host + st->used;
+  std::memcpy(p, states, nf * dS * 4); p += bS;
+  std::memcpy(p, actions, bA); p += bA;
+  std::memcpy(p, mu, bMU); p += bMU;
+  std::memcpy(p, rewards, bR); p += bR;
+  std::memcpy(p, values, bV); p += bV;
+  if (advantages) std::memcpy(p, advantages, bADV); else std::memset(p, 0, bADV);
+  double totR = 0;
+  for (int t = 1; t < N; ++t) totR += rewards[t];
+  IngestDesc& d = reinterpret_cast<IngestDesc*>(st->host)[st->nEp];
+  d.off = off; d.tag = tag; d.data = st->used; d.N = N; d.eid = eid; d.term = terminated ? 1 : 0; d.totR = (float)totR;
+  st->used += need; st->nEp += 1;
   // counters: storeAction increments for t = 1..N-2, ID taken before the final increment (:110,:167,:484)
   h->nSeenSteps += N - 2;
   const long long locTrain = h->nGatheredB4Startup == INT64_MAX ? -1 : h->nSeenSteps - h->nGatheredB4Startup;
@@ -812,6 +845,7 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
 
 int hl_get_scaling(hl_learner* h, float* m, float* sc, float* r3) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (m) HIPCK(hipMemcpyAsync(m, h->rp.stMean, h->dS * 4, hipMemcpyDeviceToHost, h->stream));
   if (sc) HIPCK(hipMemcpyAsync(sc, h->rp.stScale, h->dS * 4, hipMemcpyDeviceToHost, h->stream));
   DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
@@ -820,6 +854,7 @@ int hl_get_scaling(hl_learner* h, float* m, float* sc, float* r3) {
 }
 int hl_set_scaling(hl_learner* h, const float* m, const float* sc, const float* r3) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (m) HIPCK(hipMemcpyAsync(h->rp.stMean, m, h->dS * 4, hipMemcpyHostToDevice, h->stream));
   if (sc) {
     std::vector<float> sd(h->dS); for (int k = 0; k < h->dS; ++k) sd[k] = 1 / sc[k];
@@ -837,6 +872,7 @@ int hl_set_scaling(hl_learner* h, const float* m, const float* sc, const float* 
 }
 int hl_get_episode_info(hl_learner* h, int64_t pos, int64_t* tag, int32_t* nsteps, int32_t* term) {
   if (!h || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const EpMeta& e = h->order[(size_t)pos];
   if (tag) *tag = e.tag;
   if (nsteps) *nsteps = e.N;
@@ -845,6 +881,7 @@ int hl_get_episode_info(hl_learner* h, int64_t pos, int64_t* tag, int32_t* nstep
 }
 int hl_get_episode_field(hl_learner* h, int64_t pos, int32_t field, float* dst, int32_t cap) {
   if (!h || !dst || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const EpMeta& e = h->order[(size_t)pos];
   if (cap < e.N) return HL_ERR_BAD_ARG;
   int rc = flushPending(h); if (rc) return rc;
@@ -860,6 +897,7 @@ int hl_get_episode_field(hl_learner* h, int64_t pos, int32_t field, float* dst, 
 // Learner::initializeLearner (Learners/Learner.cpp:47-72)
 int hl_initialize(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (h->order.empty()) return fail(h, HL_ERR_TOO_FEW_DATA, "empty replay");
   int rc = flushPending(h); if (rc) return rc;
   // n_ranks > 1 without hl_comm_init = host-exchange mode (hl_step_begin / hl_*_exchange /
@@ -901,10 +939,11 @@ static int gradStatsOfLastBatch(hl_learner* h, double* mean, double* rms) {
 }
 int hl_grad_stats(hl_learner* h, double* mean, double* rms) {
   if (!h || !mean || !rms) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (h->gsCalls == 0 && !h->inStep) return fail(h, HL_ERR_STATE, "no gradient step yet");
   return gradStatsOfLastBatch(h, mean, rms);
 }
-int hl_set_log_base(hl_learner* h, const char* base) { if (!h) return HL_ERR_BAD_ARG; h->logBase = base ? base : ""; return HL_OK; }
+int hl_set_log_base(hl_learner* h, const char* base) { if (!h) return HL_ERR_BAD_ARG; HL_LOCK(h); h->logBase = base ? base : ""; return HL_OK; }
 static int appendGradStats(hl_learner* h) {      // StatsTracker::printToFile (StatsTracker.cpp:65-85)
   if (h->cfg.rank != 0) return HL_OK;
   std::vector<double> m((size_t)h->nOut), r((size_t)h->nOut);
@@ -921,6 +960,7 @@ static int appendGradStats(hl_learner* h) {      // StatsTracker::printToFile (S
 
 int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
   if (!h || n < 0) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int s = 0;
   while (s < n) {
     int rc = preStepChecks(h); if (rc) return rc;
@@ -953,6 +993,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
 // split form (host-side exchange of gradient / counters / moments, e.g. over the existing MPI path)
 int hl_step_begin(hl_learner* h, const int64_t* flat) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = preStepChecks(h); if (rc) return rc;
   rc = dropPresample(h); if (rc) return rc;
   const long long* dFlat = nullptr;
@@ -978,6 +1019,7 @@ int hl_step_begin(hl_learner* h, const int64_t* flat) {
 }
 int hl_grad_exchange(hl_learner* h, float* g, int32_t write_back) {
   if (!h || !g) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const size_t n = (size_t)h->nParams * sizeof(float);
   if (write_back) HIPCK(hipMemcpyAsync(h->G, g, n, hipMemcpyHostToDevice, h->stream));
   else HIPCK(hipMemcpyAsync(g, h->G, n, hipMemcpyDeviceToHost, h->stream));
@@ -986,6 +1028,7 @@ int hl_grad_exchange(hl_learner* h, float* g, int32_t write_back) {
 }
 int hl_counters_exchange(hl_learner* h, int64_t c[4], int32_t write_back) {
   if (!h || !c) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (write_back) HIPCK(hipMemcpyAsync(h->sc->cnt, c, 4 * sizeof(long long), hipMemcpyHostToDevice, h->stream));
   else HIPCK(hipMemcpyAsync(c, h->sc->cnt, 4 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -993,6 +1036,7 @@ int hl_counters_exchange(hl_learner* h, int64_t c[4], int32_t write_back) {
 }
 int hl_moments_exchange(hl_learner* h, double* io, int32_t write_back) {
   if (!h || !io) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (!h->momentsPending) return fail(h, HL_ERR_STATE, "no reward/state moments pending this step");
   const size_t n = (size_t)(2 * h->dS + 3) * sizeof(double);
   if (write_back) HIPCK(hipMemcpyAsync(h->dMoments, io, n, hipMemcpyHostToDevice, h->stream));
@@ -1002,6 +1046,7 @@ int hl_moments_exchange(hl_learner* h, double* io, int32_t write_back) {
 }
 int hl_step_end(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (!h->inStep) return fail(h, HL_ERR_STATE, "hl_step_end without hl_step_begin");
   int rc;
   if (h->momentsPending) { rc = launchMomentsApply(h, false, 10); if (rc) return rc; h->momentsPending = false; }
@@ -1015,10 +1060,12 @@ int hl_step_end(hl_learner* h) {
 // ---- episodes in the reference's wire format (Episode::packEpisode / unpackEpisode, Episode.cpp:24-130) ----
 int64_t hl_packed_episode_size(const hl_learner* h, int32_t N) {
   if (!h || N < 0) return -1;
+  HL_LOCK(h);
   return (int64_t)(h->dS + h->dA + h->polDim + 1 + 6) * N + 10;      // Episode::computeTotalEpisodeSize (Episode.h:211-219)
 }
 int hl_append_packed_episode(hl_learner* h, const float* data, int64_t n) {
   if (!h || !data) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const int dS = h->dS, dA = h->dA, pD = h->polDim, tup = dS + 1 + dA + pD;
   const int64_t N = (n - 10) / (tup + 6);
   if (N < 2 || hl_packed_episode_size(h, (int32_t)N) != n) return fail(h, HL_ERR_BAD_ARG, "packed episode has the wrong size");
@@ -1042,6 +1089,7 @@ int hl_append_packed_episode(hl_learner* h, const float* data, int64_t n) {
 }
 int hl_pack_episode(hl_learner* h, int64_t pos, float* dst, int64_t cap) {
   if (!h || !dst || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const EpMeta e = h->order[(size_t)pos];
   const int dS = h->dS, dA = h->dA, pD = h->polDim; const int64_t N = e.N, total = hl_packed_episode_size(h, e.N);
   if (cap < total) return fail(h, HL_ERR_BAD_ARG, "hl_pack_episode: destination too small");
@@ -1084,6 +1132,7 @@ static void real2SS(std::ostringstream& B, const double V, const int W, const bo
 }
 int hl_metrics(hl_learner* h, char* header, int32_t headerCap, char* line, int32_t lineCap) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   hl_stats st; int rc = hl_get_stats(h, &st); if (rc) return rc;
   DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;
   const bool qStats = st.minQ < st.maxQ;
@@ -1135,6 +1184,7 @@ static bool copyFile(const std::string& from, const std::string& to) {
 }
 int hl_save_memory(hl_learner* h, const char* base, int32_t rank) {
   if (!h || !base) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
   DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;
   const int dS = h->dS;
@@ -1184,6 +1234,7 @@ int hl_save_memory(hl_learner* h, const char* base, int32_t rank) {
 }
 int hl_restart_memory(hl_learner* h, const char* base, int32_t rank) {
   if (!h || !base) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (!h->order.empty()) return fail(h, HL_ERR_STATE, "hl_restart_memory needs an empty replay");
   const int dS = h->dS, dA = h->dA;
   const std::string B(base);
@@ -1299,6 +1350,7 @@ static void unpackBlob(const hl_learner* h, const std::vector<float>& in, std::v
 }
 int hl_save(hl_learner* h, const char* base) {
   if (!h || !base) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   std::vector<float> P[3]; for (auto& v : P) v.resize((size_t)h->nParams);
   int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
   const char* suf[3] = {"_weights", "_1stMom", "_2ndMom"};
@@ -1319,6 +1371,7 @@ int hl_save(hl_learner* h, const char* base) {
 }
 int hl_restart(hl_learner* h, const char* base) {
   if (!h || !base) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   std::vector<float> P[3]; for (auto& v : P) v.resize((size_t)h->nParams);
   int rc = hl_get_params(h, P[0].data(), P[1].data(), P[2].data()); if (rc) return rc;
   size_t n = 0;
@@ -1341,6 +1394,7 @@ int hl_restart(hl_learner* h, const char* base) {
 // rollout inference: Approximator::forward(agent) for n states (RACER.cpp:30-59)
 int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward between hl_step_begin and hl_step_end");
   if (h->recurrent) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
   { int rc = dropPresample(h); if (rc) return rc; }      // the forward pass borrows minibatch buffer 0
@@ -1362,6 +1416,7 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
 
 int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, double* outputs) {
   if (!h || nSteps < 1 || !states || !outputs) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   if (!h->recurrent) return hl_forward(h, 1, states + (size_t)(nSteps - 1) * h->dS, outputs);
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
   if (nSteps > h->recK) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1");
@@ -1379,6 +1434,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
 
 int hl_sync(hl_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   HIPCK(hipStreamSynchronize(h->stream));
   return HL_OK;
 }
@@ -1387,6 +1443,7 @@ int hl_set_tap(hl_learner* h, int32_t) { return h ? HL_OK : HL_ERR_BAD_ARG; }   
 
 int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
   if (!h || !dst) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   const int B = h->B;
   HIPCK(hipStreamSynchronize(h->stream));
   const DevBatch& bt = h->buf[h->lastParity].bt;
@@ -1428,6 +1485,7 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
 
 int hl_get_scalars(hl_learner* h, hl_scalars* o) {
   if (!h || !o) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
   DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   o->beta = s.beta; o->alpha = s.alpha; o->CmaxRet = s.Cmax; o->CinvRet = s.Cinv;
@@ -1436,8 +1494,19 @@ int hl_get_scalars(hl_learner* h, hl_scalars* o) {
   o->adam_beta_t_1 = s.adam_bt1; o->adam_beta_t_2 = s.adam_bt2; o->adam_nStep = s.nStep;
   return HL_OK;
 }
+int hl_get_counts(hl_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int64_t* nGradSteps, int64_t* nSeenSteps, int64_t* nSeenEps) {
+  if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  if (nStoredSteps) *nStoredSteps = h->nTransitions;
+  if (nStoredEps) *nStoredEps = (int64_t)h->order.size();
+  if (nGradSteps) *nGradSteps = h->nGradSteps;
+  if (nSeenSteps) *nSeenSteps = h->nSeenSteps;
+  if (nSeenEps) *nSeenEps = h->nSeenEps;
+  return HL_OK;
+}
 int hl_get_stats(hl_learner* h, hl_stats* o) {
   if (!h || !o) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
   HIPCK(launch_stats(h->sc, h->rp, (int)h->order.size(), h->dStatsOut, h->stream));
   double out[16];
@@ -1460,6 +1529,7 @@ int hl_comm_unique_id(uint8_t id[128]) {
 }
 int hl_comm_init(hl_learner* h, const uint8_t id[128]) {
   if (!h || !id) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   ncclUniqueId u; std::memcpy(&u, id, sizeof(u));
   HIPCK(hipSetDevice(h->dev));
   NCCLCK(ncclCommInitRank(&h->comm, h->cfg.n_ranks, u, h->cfg.rank));
@@ -1472,6 +1542,7 @@ int hl_comm_init(hl_learner* h, const uint8_t id[128]) {
 // ---- timing taps (HIP events on the library's stream) ---------------------------------------------
 int hl_timing_enable(hl_learner* h, int32_t e) {
   if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   timerFlush(h);
   h->timing = e != 0;
   if (h->timing) { std::fill(h->tsum.begin(), h->tsum.end(), 0.0); std::fill(h->tcnt.begin(), h->tcnt.end(), 0); }
@@ -1479,6 +1550,7 @@ int hl_timing_enable(hl_learner* h, int32_t e) {
 }
 int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* launches) {
   if (!h || !kernel) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   timerFlush(h);
   for (size_t i = 0; i < h->tnames.size(); ++i) if (h->tnames[i] == kernel) {
     if (avg_ms) *avg_ms = h->tcnt[i] ? h->tsum[i] / h->tcnt[i] : 0.0;
@@ -1496,6 +1568,7 @@ int hl_timing_get(hl_learner* h, const char* kernel, double* avg_ms, int64_t* la
 //      (which: 0 sample, 1 fwd0, 2 fwd(last), 3 head, 4 dx(last), 5 dw+adam, 6 post, 7 whole overlapped step) ----
 extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, int variant, double* us_per_launch) {
   if (!h || !us_per_launch || reps <= 0) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
   rc = dropPresample(h); if (rc) return rc;
   h->dbgVariant = variant;
@@ -1572,6 +1645,7 @@ extern "C" HL_API int64_t hl_debug_collectives(const hl_learner* h) { return h ?
 
 extern "C" HL_API int hl_debug_stamps(hl_learner* h, long long out[32]) {
   if (!h || !out) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
   DevScalars s; int rc = syncScalarsToHost(h, &s); if (rc) return rc;
   std::memcpy(out, s.dbgT, sizeof(s.dbgT));
   return HL_OK;

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void stats_kernel(DevScalars* sc, DevReplay rp
     __syncthreads();
   }
   if (tid == 0) {
-    const double nData = (double)sc->nTransitions;
+    const double nData = fmax(1.0, (double)sc->nTransitions);
     out[0] = sd[0][0] / nData;                 // avgKLdivergence
     out[1] = sd[1][0] / nData;                 // avgSquaredErr
     out[2] = sc->maxAbsErrEMA;                 // maxAbsError
@@ -326,6 +326,50 @@ hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, 
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
                              int nDense, int dA, int n, double* O, hipStream_t s) {
   hipLaunchKernelGGL(act_output_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Y, ldY, H, W, indWo, indBo, indBp, ldWo, nDense, dA, n, O);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// ingest_kernel: MemoryBuffer::addEpisodeToTrainingSet / pushBackEpisode (MemoryBuffer.cpp:131-170, 479-520) for a batch of
+// episodes: blockIdx.y = episode of the batch, blockIdx.x strides over its elements.  Reads the pinned host buffer over the
+// bus exactly once; the derived per-step fields get their insertion values (Episode.h:66-82; pre-training error placeholder
+// sqrt(max(eps, avgSquaredErr)), MemoryBuffer.cpp:486-487), the Retrace estimate follows from the episode sweep.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
+  const IngestDesc d = reinterpret_cast<const IngestDesc*>(a.stage)[blockIdx.y];
+  const int N = d.N, dS = a.dS, dA = a.dA, pD = a.polDim;
+  const unsigned char* base = a.stage + d.data;
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const float* S = reinterpret_cast<const float*>(base);
+  const double* A = reinterpret_cast<const double*>(base + al16((size_t)N * dS * 4));
+  const double* MU = A + (size_t)N * dA;                       // (multiples of 8 bytes keep the following blocks aligned)
+  const double* R = MU + (size_t)N * pD;
+  const float* V = reinterpret_cast<const float*>(R + N);
+  const float* ADV = V + N;
+  const float avgSq = a.nEpTable > 0 ? (float)a.stats[1] : 0.f;
+  const float maxError = sqrtf(fmaxf(FLT_EPSILON, avgSq));
+  const long long off = d.off;
+  const int tid = blockIdx.x * 256 + threadIdx.x, nT = gridDim.x * 256;
+  if ((((size_t)N * dS) & 3) == 0 && ((off * dS) & 3) == 0) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(S); f32x4* d4 = reinterpret_cast<f32x4*>(a.rp.S + (size_t)off * dS);
+    for (int i = tid; i < (N * dS) >> 2; i += nT) d4[i] = s4[i];
+  } else for (int i = tid; i < N * dS; i += nT) a.rp.S[(size_t)off * dS + i] = S[i];
+  for (int i = tid; i < N * dA; i += nT) a.rp.A[(size_t)off * dA + i] = A[i];
+  for (int i = tid; i < N * pD; i += nT) a.rp.MU[(size_t)off * pD + i] = MU[i];
+  for (int t = tid; t < N; t += nT) {
+    a.rp.R[off + t] = R[t]; a.rp.V[off + t] = V[t]; a.rp.ADV[off + t] = ADV[t];
+    a.rp.RET[off + t] = 0.f; a.rp.DQ[off + t] = maxError; a.rp.IMPW[off + t] = t == N - 1 ? 0.f : 1.f; a.rp.DKL[off + t] = 0.f;
+  }
+  if (tid == 0) {
+    a.rp.epOff[d.eid] = off; a.rp.epN[d.eid] = N; a.rp.epTerm[d.eid] = d.term ? 1 : 0; a.rp.epTag[d.eid] = d.tag;
+    float* ag = a.rp.epAgg + (size_t)d.eid * AGG_N;
+    for (int q = 0; q < AGG_N; ++q) ag[q] = 0.f;
+    ag[AGG_TOTR] = d.totR; ag[AGG_AVGSQERR] = maxError * maxError; ag[AGG_MAXABSERR] = maxError; ag[AGG_MAXQ] = -1e9f; ag[AGG_MINQ] = 1e9f;
+  }
+}
+hipError_t launch_ingest(const IngestArgs& a, hipStream_t s) {
+  if (a.nEp <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ingest_kernel, dim3(8, a.nEp), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -961,6 +961,53 @@ def test_replicas_speak_one_wire_protocol_on_every_path(hip_api):
     assert np.array_equal(A.get_rng_state(), Bq.get_rng_state())
 
 
+@pytest.mark.gpu
+def test_episodes_and_actions_from_other_threads_while_training(hip_api):
+    """The learner's lock (the reference's dataset_mutex, MemoryBuffer.h:55): env-service threads hand over finished episodes and
+    ask for network outputs while the training thread steps.  Nothing is lost, the counters add up, and -- the interleaving
+    being whatever it was -- a second learner fed the same episodes in the order the first one stored them, then stepped
+    alone, holds the same replay contents."""
+    import threading
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(64, 64), batchSize=32, maxTotObsNum=50000, randSeed=8)
+    sc = synth_cfg(seed=21, dimS=17, dimA=6, lenMin=5, lenMax=30, pTerm=0.3)
+    G = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    G.init_weights(); fill_synth(G, sc, 60); G.initialize()
+    errs = []
+
+    def feeder(first, n):
+        try:
+            for e in range(first, first + n):
+                G.append_episode(**synth_episode(sc, e))
+                G.forward(np.zeros((2, 17), np.float32))
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+
+    ths = [threading.Thread(target=feeder, args=(1000 * (i + 1), 80)) for i in range(3)]
+    for t in ths:
+        t.start()
+    steps = 0
+    while any(t.is_alive() for t in ths):
+        G.step(3); steps += 3
+    for t in ths:
+        t.join()
+    G.step(5); steps += 5
+    assert not errs, errs
+    nS, nE, nG, seenS, seenE = G.counts()
+    assert nE == 60 + 240 and nG == steps and seenE == 300
+    lens = [G.episode_info(p)[1] for p in range(nE)]
+    assert nS == sum(lens) - nE and seenS == nS
+    sca = G.scalars()
+    assert sca.nStoredSteps == nS and sca.nGradSteps == steps
+    tags = sorted(G.episode_info(p)[0] for p in range(nE))
+    assert tags == sorted(list(range(60)) + [1000 * (i + 1) + k for i in range(3) for k in range(80)])
+    # every stored episode holds its own data (nothing interleaved inside the staging buffers)
+    for p in (0, 7, 150, nE - 1):
+        tag, N, term = G.episode_info(p)
+        ref = synth_episode(sc, tag)
+        pk = G.pack_episode(p).reshape(-1)
+        assert np.array_equal(pk[:17], ref["states"][0]) and N == ref["rewards"].size
+
+
 @pytest.fixture(scope="module")
 def full_size(hip_api):
     cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=1000000, randSeed=42)
