@@ -88,6 +88,13 @@ enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1, HL_NN_MGU = 2 /* Layer_GRU.h: what a part
 enum { HL_ADV_ZERO = 0 /* VRACER */, HL_ADV_GAUSSIAN = 1 /* RACER continuous */,
        HL_ADV_DISCRETE = 2 /* RACER discrete */ };
 
+/* which episodes leave an over-full replay: settings key ERoldSeqFilter (MemoryProcessing::getERfilterAlgo,
+ * ReplayMemory/MemoryProcessing.cpp:261-298) */
+enum { HL_ER_OLDEST = 0,       /* "oldest" / "default": first in, first out                                   */
+       HL_ER_FARPOLFRAC = 1,   /* "farpolfrac": the episode with the largest fraction of far-policy steps      */
+       HL_ER_MAXKLDIV = 2,     /* "maxkldiv":   the episode with the largest average D_KL                      */
+       HL_ER_MINERROR = 3 };   /* "minerror":   the episode with the smallest average squared TD error         */
+
 /* episode ordering used for the flat-index -> (episode, step) prefix walk */
 enum { HL_ORDER_STABLE = 0,     /* stable sort by ID, newest first (product semantics)  */
        HL_ORDER_REFERENCE = 1 };/* std::sort each step exactly as MemoryProcessing.cpp:336
@@ -145,7 +152,9 @@ typedef struct hl_config {
   int32_t n_conv;                    /* MDP.conv2dDescriptors: convolutional layers ahead of nnLayerSizes
                                         (Approximator::buildPreprocessing, Approximator.cpp:231-271; BASELINE config 5) */
   hl_conv2d conv[HL_MAX_CONV];
-  int32_t reserved[2];
+  int32_t ERoldSeqFilter;            /* HL_ER_*: removal rule of an over-full replay (equal keys: the older episode goes;
+                                        the reference's non-stable std::sort leaves that to the library implementation)  */
+  int32_t reserved[1];
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */

@@ -917,19 +917,35 @@ void updateTrainingStatistics(ol_learner* h) {
 }
 
 // MemoryProcessing::applyEpisodesRemovalAlgo, "oldest" filter (MemoryProcessing.cpp:261-275,327-351)
+// MemoryProcessing::applyEpisodesRemovalAlgo + getERfilterAlgo (MemoryProcessing.cpp:261-351): sort the episodes so that the
+// ones to delete are at the back, pop the back while the replay stays over budget without it
 void applyEpisodesRemoval(ol_learner* h) {
-  const auto cmp = [](const std::unique_ptr<Episode>& a, const std::unique_ptr<Episode>& b) {
-    return a->ID > b->ID;
-  };
-  if (h->cfg.episode_order == HL_ORDER_REFERENCE) std::sort(h->episodes.begin(), h->episodes.end(), cmp);
-  else  // product semantics (HL_ORDER_STABLE): strict FIFO, newest episode first (IDs are non-decreasing
-        // in insertion order, so this is one of the orders the reference's comparator admits)
-    std::sort(h->episodes.begin(), h->episodes.end(),
-              [](const std::unique_ptr<Episode>& a, const std::unique_ptr<Episode>& b) { return a->seq > b->seq; });
-  while (!h->episodes.empty() &&
-         h->nTransitions - (int64_t)h->episodes.back()->N > h->maxObsLocal) {
-    h->nTransitions -= h->episodes.back()->ndata();
-    h->episodes.pop_back();
+  using EPtr = std::unique_ptr<Episode>;
+  const int filter = h->cfg.ERoldSeqFilter;
+  if (h->cfg.episode_order == HL_ORDER_REFERENCE) {      // the reference's own (non-stable) std::sort with its comparator
+    if (filter == HL_ER_FARPOLFRAC) std::sort(h->episodes.begin(), h->episodes.end(), [](const EPtr& a, const EPtr& b) { return a->fracFar < b->fracFar; });
+    else if (filter == HL_ER_MAXKLDIV) std::sort(h->episodes.begin(), h->episodes.end(), [](const EPtr& a, const EPtr& b) { return a->avgKL < b->avgKL; });
+    else if (filter == HL_ER_MINERROR) std::sort(h->episodes.begin(), h->episodes.end(), [](const EPtr& a, const EPtr& b) { return a->avgSqErr > b->avgSqErr; });
+    else std::sort(h->episodes.begin(), h->episodes.end(), [](const EPtr& a, const EPtr& b) { return a->ID > b->ID; });
+    while (!h->episodes.empty() && h->nTransitions - (int64_t)h->episodes.back()->N > h->maxObsLocal) {
+      h->nTransitions -= h->episodes.back()->ndata();
+      h->episodes.pop_back();
+    }
+    return;
+  }
+  // product semantics (HL_ORDER_STABLE): the sampling order stays newest episode first (IDs are non-decreasing in insertion
+  // order, so for "oldest" this is one of the orders the reference's comparator admits); the victim is the episode the
+  // comparator puts last, the older one among equal keys
+  std::sort(h->episodes.begin(), h->episodes.end(), [](const EPtr& a, const EPtr& b) { return a->seq > b->seq; });
+  while (!h->episodes.empty()) {
+    size_t v = h->episodes.size() - 1;
+    if (filter != HL_ER_OLDEST) {
+      auto key = [&](const Episode& e) -> Fval { return filter == HL_ER_FARPOLFRAC ? e.fracFar : (filter == HL_ER_MAXKLDIV ? e.avgKL : -e.avgSqErr); };
+      for (size_t i = h->episodes.size(); i-- > 0;) if (key(*h->episodes[i]) > key(*h->episodes[v])) v = i;      // (scan from the oldest: ties keep it)
+    }
+    if (h->nTransitions - (int64_t)h->episodes[v]->N <= h->maxObsLocal) break;
+    h->nTransitions -= h->episodes[v]->ndata();
+    h->episodes.erase(h->episodes.begin() + (long)v);
   }
 }
 
@@ -995,6 +1011,7 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;
   if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
+  if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input

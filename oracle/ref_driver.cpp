@@ -193,6 +193,7 @@ struct Harness {
     HP->explNoise = A.d("explNoise", 0.4472135955);
     HP->outWeightsPrefac = A.d("outWeightsPrefac", 0.1);
     HP->nnLambda = A.d("nnLambda", 0);
+    HP->ERoldSeqFilter = A.s("erFilter", "oldest");      // oldest | farpolfrac | maxkldiv | minerror (MemoryProcessing.cpp:261-298)
     HP->obsPerStep = 0;  // never block gradient steps on data
     HP->saveFreq = 1000000000;
     HP->defineDistributedLearning(info); HP->check();
@@ -336,6 +337,8 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       std::vector<int64_t> pre = {(int64_t)H.MDP.nAppendedObs};
       for (const auto& d : H.MDP.conv2dDescriptors) for (int64_t v : {(int64_t)d.inpX, (int64_t)d.inpY, (int64_t)d.inpFeatures, (int64_t)d.outFeatures, (int64_t)d.filterx, (int64_t)d.stridex}) pre.push_back(v);
       W.i64("preproc", pre);
+      const std::string f = H.HP->ERoldSeqFilter;
+      W.i64("erFilter", std::vector<int64_t>{f == "farpolfrac" ? 1 : (f == "maxkldiv" ? 2 : (f == "minerror" ? 3 : 0))});
     }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

@@ -95,6 +95,10 @@ struct hl_learner {
   // over the bus) when it is full or when the device state has to be current (flushPending)
   struct Staging { unsigned char* host = nullptr; size_t cap = 0, used = 0; int nEp = 0; hipEvent_t ev = nullptr; bool inFlight = false; };
   Staging stg[2]; int stgCur = 0; int tableCount = 0;      // tableCount: episodes in the table the device currently holds
+  // ReplayStats::avgSquaredErr as the reference has it when episodes arrive (the pre-training error placeholder,
+  // MemoryBuffer.cpp:486-487): the value of the last gradient step's statistics pass, taken BEFORE that step's removals;
+  // 0 before the first step.  Computed on the device when needed (dStatsIns), at most once per step.
+  double* dStatsIns = nullptr; bool statsFresh = false, anyStep = false;
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
@@ -334,10 +338,12 @@ template <typename T> hipError_t repack(T** arr, size_t width, long long newCap,
   return hipSuccess;
 }
 int flushStaging(hl_learner* h);
-int growSlots(hl_learner* h, long long need) {
-  if (need <= h->capSlots) return HL_OK;
+// `compact`: same capacity, the live episodes re-packed contiguously (removal rules other than "oldest" leave holes
+// inside the ring that only fall behind its tail when the oldest episode goes)
+int growSlots(hl_learner* h, long long need, bool compact = false) {
+  if (need <= h->capSlots && !compact) return HL_OK;
   if (h->rp.S) { int rc = flushStaging(h); if (rc) return rc; }     // staged episodes carry slot offsets of the present layout
-  const long long newCap = std::max(need, h->capSlots + h->capSlots / 2 + 4096);
+  const long long newCap = compact ? h->capSlots : std::max(need, h->capSlots + h->capSlots / 2 + 4096);
   const int dS = h->dS, dA = h->dA; hipStream_t s = h->stream;
   HIPCK(repack(&h->rp.S, dS, newCap, h->order, s)); HIPCK(repack(&h->rp.A, dA, newCap, h->order, s));
   HIPCK(repack(&h->rp.MU, h->polDim, newCap, h->order, s)); HIPCK(repack(&h->rp.R, 1, newCap, h->order, s));
@@ -380,7 +386,10 @@ int allocSlots(hl_learner* h, int N, long long* off) {
         *off = head; h->ringHead = head + N; return HL_OK;
       }
     }
-    int rc = growSlots(h, h->capSlots + std::max<long long>(N + 1, h->capSlots / 2));   // re-packs, un-wraps
+    long long live = 0; for (const EpMeta& e : h->order) live += e.N;
+    const bool holes = h->cfg.ERoldSeqFilter != HL_ER_OLDEST && live + N + 1 <= h->capSlots - h->capSlots / 16;
+    int rc = holes ? growSlots(h, h->capSlots, true)                                          // squeeze the holes out
+                   : growSlots(h, h->capSlots + std::max<long long>(N + 1, h->capSlots / 2));   // re-packs, un-wraps
     if (rc) return rc;
   }
   return fail(h, HL_ERR_STATE, "replay slot allocation failed");
@@ -430,15 +439,23 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute, int skip
 
 int dropPresample(hl_learner* h);      // step_exec.h
 
+// the statistics new episodes take their placeholder error from: over the table the device holds now (call before the
+// table changes within a step)
+int refreshInsertionStats(hl_learner* h) {
+  if (h->statsFresh || !h->anyStep || h->tableCount <= 0) return HL_OK;
+  HIPCK(launch_stats(h->sc, h->rp, h->tableCount, h->dStatsIns, h->stream));
+  h->statsFresh = true;
+  return HL_OK;
+}
 // hand the staged episodes to the ingest kernel (one launch for the whole batch) and switch to the other buffer
 int flushStaging(hl_learner* h) {
   hl_learner::Staging& st = h->stg[h->stgCur];
   if (st.nEp == 0) return HL_OK;
   // placeholder error of the new episodes: the average squared error over the episodes the device table holds right now
   // (ReplayStats::avgSquaredErr as of the last statistics pass, MemoryBuffer.cpp:486-487)
-  if (h->tableCount > 0) HIPCK(launch_stats(h->sc, h->rp, h->tableCount, h->dStatsOut, h->stream));
+  int rc = refreshInsertionStats(h); if (rc) return rc;
   IngestArgs ia{}; ia.rp = h->rp; ia.stage = st.host; ia.nEp = st.nEp; ia.dS = h->dS; ia.dA = h->dA; ia.polDim = h->polDim;
-  ia.stats = h->dStatsOut; ia.nEpTable = h->tableCount;
+  ia.stats = h->dStatsIns; ia.nEpTable = h->anyStep ? h->tableCount : 0;
   HIPCK(timed(h, "ingest_kernel", h->stream, [&] { return launch_ingest(ia, h->stream); }));
   HIPCK(hipEventRecord(st.ev, h->stream));
   st.inFlight = true; st.nEp = 0; st.used = 0;
@@ -501,6 +518,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
   }
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
+  if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
     const hl_conv2d& d = cfg->conv[j];
@@ -623,7 +641,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&bt.aggIn, (size_t)B * AGG_N));
   }
   HIPCK(devAlloc(&h->dFlatGiven, B));
-  HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16));
+  HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16)); HIPCK(devAlloc(&h->dStatsIns, 16));
   HIPCK(devAlloc(&h->rp.stMean, h->dS)); HIPCK(devAlloc(&h->rp.stScale, h->dS)); HIPCK(devAlloc(&h->rp.stStd, h->dS));
   {   // ring slack: an eighth of the budget plus room for the episodes in flight (bounded in bytes for image-sized states)
     const long long slack = std::max<long long>(512, std::min<long long>(8192, (64ll << 20) / ((long long)h->dS * 4)));
@@ -657,7 +675,7 @@ int hl_destroy(hl_learner* h) {
   invalidateGraphs(h);
   if (h->comm) ncclCommDestroy(h->comm);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
-    h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut,
+    h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
     h->rp.stStd, h->rp.epTag, h->rp.posRec, h->panelCtr, h->dActS, h->dActO};
@@ -964,6 +982,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
   int s = 0;
   while (s < n) {
     int rc = preStepChecks(h); if (rc) return rc;
+    h->statsFresh = false; h->anyStep = true;      // the statistics new episodes see are those of the step now running
     const long long k = h->nGradSteps + 1;
     const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
     const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
@@ -995,6 +1014,7 @@ int hl_step_begin(hl_learner* h, const int64_t* flat) {
   if (!h) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
   int rc = preStepChecks(h); if (rc) return rc;
+  h->statsFresh = false; h->anyStep = true;
   rc = dropPresample(h); if (rc) return rc;
   const long long* dFlat = nullptr;
   if (flat) {

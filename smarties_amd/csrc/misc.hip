@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestArgs a) {
   const double* R = MU + (size_t)N * pD;
   const float* V = reinterpret_cast<const float*>(R + N);
   const float* ADV = V + N;
-  const float avgSq = a.nEpTable > 0 ? (float)a.stats[1] : 0.f;
-  const float maxError = sqrtf(fmaxf(FLT_EPSILON, avgSq));
+  const double avgSq = a.nEpTable > 0 ? a.stats[1] : 0.0;
+  const float maxError = (float)sqrt(fmax((double)FLT_EPSILON, avgSq));      // (Fval) std::sqrt(std::max(EPS, stats.avgSquaredErr))
   const long long off = d.off;
   const int tid = blockIdx.x * 256 + threadIdx.x, nT = gridDim.x * 256;
   if ((((size_t)N * dS) & 3) == 0 && ((off * dS) & 3) == 0) {

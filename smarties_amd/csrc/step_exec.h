@@ -371,13 +371,39 @@ int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
   return HL_OK;
 }
 
-// FIFO removal (MemoryProcessing::applyEpisodesRemovalAlgo, "oldest"): host bookkeeping + device nFar
+// MemoryProcessing::applyEpisodesRemovalAlgo (MemoryProcessing.cpp:327-351): host bookkeeping + device far-policy count.
+// "oldest": the back of the order.  Other rules of getERfilterAlgo (:261-298): the episode the reference's comparator puts
+// last -- largest far-policy fraction / largest average D_KL / smallest average squared error --, the older one among equal
+// keys; the keys are the per-episode aggregates the device maintains, fetched when a removal may be due.
+bool evictionDue(const hl_learner* h);
 int applyRemoval(hl_learner* h) {
   bool any = false;
-  while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
-    const EpMeta e = h->order.back();
-    HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
-    h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
+  const int filter = h->cfg.ERoldSeqFilter;
+  if (evictionDue(h)) { int rc = refreshInsertionStats(h); if (rc) return rc; }     // the statistics pass precedes the removals
+  if (filter == HL_ER_OLDEST) {
+    while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
+      const EpMeta e = h->order.back();
+      HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
+      h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
+    }
+  } else if (!h->order.empty() && h->nTransitions - 2 > h->maxObsLocal) {
+    std::vector<float> agg((size_t)h->nextEid * AGG_N);
+    HIPCK(hipMemcpyAsync(agg.data(), h->rp.epAgg, agg.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    const int col = filter == HL_ER_FARPOLFRAC ? AGG_FRACFAR : (filter == HL_ER_MAXKLDIV ? AGG_AVGKL : AGG_AVGSQERR);
+    const float sgn = filter == HL_ER_MINERROR ? -1.f : 1.f;
+    while (!h->order.empty()) {
+      size_t v = h->order.size() - 1;
+      float best = sgn * agg[(size_t)h->order[v].eid * AGG_N + col];
+      for (size_t i = h->order.size() - 1; i-- > 0;) {             // from the oldest towards the newest: ties keep the older one
+        const float k = sgn * agg[(size_t)h->order[i].eid * AGG_N + col];
+        if (k > best) { best = k; v = i; }
+      }
+      const EpMeta e = h->order[v];
+      if (h->nTransitions - (long long)e.N <= h->maxObsLocal) break;
+      HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
+      h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.erase(h->order.begin() + (long)v); any = true;
+    }
   }
   if (any) { h->tableDirty = true; h->countsDirty = true; }
   return HL_OK;
@@ -405,8 +431,12 @@ int allreduceMoments(hl_learner* h) {
   return HL_OK;
 }
 
+// (rules other than "oldest": whether the episode to go can go is only known once its key has been fetched; over budget by
+// more than the shortest possible episode is the necessary condition)
 bool evictionDue(const hl_learner* h) {
-  return !h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
+  if (h->order.empty()) return false;
+  if (h->cfg.ERoldSeqFilter != HL_ER_OLDEST) return h->nTransitions - 2 > h->maxObsLocal;
+  return h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
 }
 
 RecArgs recArgs(hl_learner* h, int parity) {

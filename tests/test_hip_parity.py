@@ -14,6 +14,7 @@ from smarties_amd import capi
 pytestmark = pytest.mark.gpu
 
 ACT_FIXTURES = ["act_%s.bin" % f for f in ("LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp")]     # the other names of makeFunction (Functions.h:643-668)
+EVICT_FIXTURES = ["evict_%s.bin" % f for f in ("farpolfrac", "maxkldiv", "minerror")]      # ERoldSeqFilter (MemoryProcessing.cpp:261-298)
 FUNC_OF = {"deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
 TOL32 = 1e-5     # north_star: 1e-5 relative fp32
 TOL64 = 1e-9
@@ -280,6 +281,33 @@ def test_eviction_and_append_during_training(hip_api, variant):
         sg, so = G.scalars(), O.scalars()
         assert sg.nStoredSteps == so.nStoredSteps and sg.nStoredEps == so.nStoredEps
     assert relinf(G.get_params()[0], O.get_params()[0]) < TOL32
+
+
+@pytest.mark.parametrize("rule", ["farpolfrac", "maxkldiv", "minerror"])
+def test_removal_rules_other_than_oldest(hip_api, rule):
+    """ERoldSeqFilter (getERfilterAlgo, MemoryProcessing.cpp:261-298): the episode that leaves an over-full replay is the one with
+    the most far-policy steps / the largest D_KL / the smallest TD error -- from the aggregates the device maintains.  Episodes
+    keep arriving between steps; the slot ring, where such removals leave holes, wraps several times (compaction)."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 1], hidden=(32, 32), batchSize=16, maxTotObsNum=600, minTotObsNum=300, randSeed=2,
+                  ERoldSeqFilter=rule)
+    sc = synth_cfg(seed=21, dimS=5, dimA=2, lenMin=10, lenMax=40, pTerm=0.4)
+    G, O = _pair(hip_api, cfg_kw, sc, 30)
+    e = 30
+    for k in range(700):
+        for L in (G, O):
+            L.append_episode(**synth_episode(sc, e))
+        e += 1
+        if k % 2 == 0:
+            G.step(1); O.step(1)
+            sg, so = G.scalars(), O.scalars()
+            assert sg.nStoredSteps == so.nStoredSteps and sg.nStoredEps == so.nStoredEps, k
+        if k % 50 == 0:
+            _compare_step(G, O)
+            tg = [G.episode_info(p)[0] for p in range(G.scalars().nStoredEps)]
+            to = [O.episode_info(p)[0] for p in range(O.scalars().nStoredEps)]
+            assert tg == to, k                                    # the same episodes survived, in the same order
+    assert max(tg) - min(tg) > len(tg) + 10                       # (not first in, first out: older episodes are still there)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 4 * TOL32
 
 
 @pytest.mark.parametrize("extra", [{}, dict(adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnFunc="Tanh", nnBPTTseq=6)])
