@@ -318,6 +318,14 @@ HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
  * Utilities::real2SS (Utils/SstreamUtilities.h:51-63).  Either buffer may be NULL. */
 HL_API int hl_metrics(hl_learner* h, char* header, int32_t header_cap, char* line, int32_t line_cap);
 
+/* The histogram of the off-policy importance weights Learner::logStats prints with the profiler every freqPrint x
+ * PRFL_DMPFRQ steps (MemoryProcessing::histogramImportanceWeights, ReplayMemory/MemoryProcessing.cpp:353-389; caller
+ * Learners/Learner.cpp:139-144): 81 bins over the stored transitions' pi/mu -- [0, 1e-3), 79 log-spaced bins up to 50,
+ * [50, max) --, counted on the device.  `text` (may be NULL) receives the block exactly as the reference prints it,
+ * `counts` (may be NULL) the 81 bin counts. */
+#define HL_IMPW_BINS 81
+HL_API int hl_impweight_histogram(hl_learner* h, char* text, int32_t text_cap, int64_t counts[HL_IMPW_BINS]);
+
 /* Output-gradient statistics (Utils/StatsTracker.cpp:28-107, fed by Approximator::setGradient,
  * Network/Approximator.h:197): mean and root-mean-square over the last minibatch of each network
  * output's gradient (nOutputs values each).  hl_set_log_base(h, "<learner_name>") makes hl_step /

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <iomanip>
+#include <sstream>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -1507,6 +1509,45 @@ int ol_get_scalars(ol_learner* h, hl_scalars* o) {
   o->nGradSteps = h->nGradSteps; o->nStoredSteps = h->nTransitions; o->nStoredEps = h->episodes.size();
   o->nFarPolicySteps = h->stats.nFarPolicySteps; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
   o->adam_beta_t_1 = h->beta_t_1; o->adam_beta_t_2 = h->beta_t_2; o->adam_nStep = h->nStep;
+  return HL_OK;
+}
+// MemoryProcessing::histogramImportanceWeights (MemoryProcessing.cpp:353-389) with Utilities::real2SS (SstreamUtilities.h:51-63)
+static void realToSS(std::ostringstream& B, const double V, const int W, const bool bPos) {
+  B << " " << std::setw(W);
+  if (std::fabs(V) >= 1e4) B << std::setprecision(std::max(W - 7 + bPos, 0));
+  else if (std::fabs(V) >= 1e3) B << std::setprecision(std::max(W - 6 + bPos, 0));
+  else if (std::fabs(V) >= 1e2) B << std::setprecision(std::max(W - 5 + bPos, 0));
+  else if (std::fabs(V) >= 1e1) B << std::setprecision(std::max(W - 4 + bPos, 0));
+  else B << std::setprecision(std::max(W - 3 + bPos, 0));
+  B << std::fixed << V;
+}
+int ol_impweight_histogram(ol_learner* h, char* text, int32_t cap, int64_t counts[HL_IMPW_BINS]) {
+  if (!h) return HL_ERR_BAD_ARG;
+  constexpr int nBins = 81;
+  const Real beg = std::log(1e-3), end = std::log(50.0);
+  Fval bounds[nBins + 1] = {0}; int64_t cnt[nBins] = {0};
+  for (int i = 1; i < nBins; ++i) bounds[i] = std::exp(beg + (end - beg) * (i - 1.0) / (nBins - 2.0));
+  bounds[nBins] = std::numeric_limits<Fval>::max() - 1e2;
+  for (const auto& ep : h->episodes) for (int j = 0; j < ep->ndata(); ++j) {
+    const Fval rho = ep->IMPW[j];
+    for (int b = 0; b < nBins; ++b) if (rho >= bounds[b] && rho < bounds[b + 1]) cnt[b]++;
+  }
+  if (counts) std::memcpy(counts, cnt, sizeof(cnt));
+  if (text) {
+    std::ostringstream buff;
+    buff << "_____________________________________________________________________";
+    buff << "\nOFF-POLICY IMP WEIGHTS HISTOGRAMS\n";
+    buff << "weight pi/mu (harmonic mean of histogram's bounds):\n";
+    for (int b = 0; b < nBins; ++b) { const Fval x = bounds[b], y = bounds[b + 1]; realToSS(buff, 2 * x * (y / (x + y)), 6, 1); }
+    buff << "\nfraction of dataset:\n";
+    const Real dataSize = (Real)h->nTransitions;
+    for (int b = 0; b < nBins; ++b) realToSS(buff, cnt[b] / dataSize, 6, 1);
+    buff << "\n";
+    buff << "_____________________________________________________________________";
+    const std::string t = buff.str();
+    if ((int)t.size() + 1 > cap) return fail(h, HL_ERR_BAD_ARG, "text buffer too small");
+    std::memcpy(text, t.c_str(), t.size() + 1);
+  }
   return HL_OK;
 }
 int ol_get_counts(ol_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int64_t* nGradSteps, int64_t* nSeenSteps, int64_t* nSeenEps) {

@@ -40,6 +40,7 @@
 #include "blobio.h"
 
 #include <chrono>
+#include <unistd.h>
 #include <cstdio>
 #include <map>
 #include <set>
@@ -491,6 +492,19 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     for (Uint i = 0; i < T->n_stats; ++i) inst.push_back((double)T->instMean[i]);
     for (Uint i = 0; i < T->n_stats; ++i) inst.push_back((double)T->instStdv[i]);
     W.f64("outgrad_stats_last", inst);
+  }
+  if (A.l("hist", 0)) {   // the importance-weight histogram Learner::logStats prints with the profiler (Learner.cpp:139-144):
+    // MemoryProcessing::histogramImportanceWeights writes to stdout only, which is pointed at a file for the call
+    fflush(stdout);
+    const std::string tmp = out + ".hist.txt";
+    const int saved = dup(fileno(stdout));
+    FILE* f = fopen(tmp.c_str(), "w"); dup2(fileno(f), fileno(stdout));
+    MemoryProcessing::histogramImportanceWeights(*L.data);
+    fflush(stdout); dup2(saved, fileno(stdout)); close(saved); fclose(f);
+    std::vector<uint8_t> bytes; FILE* g = fopen(tmp.c_str(), "rb");
+    if (g) { int c; while ((c = fgetc(g)) != EOF) bytes.push_back((uint8_t)c); fclose(g); }
+    remove(tmp.c_str());
+    W.u8("impw_histogram", bytes);
   }
   {
     const ReplayStats& st = L.data->stats;

@@ -182,6 +182,7 @@ class CApi:
             "comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
             "comm_init": (C.c_int, [P, C.POINTER(C.c_uint8)]),
             "get_counts": (C.c_int, [P, pi64, pi64, pi64, pi64, pi64]),
+            "impweight_histogram": (C.c_int, [P, C.c_char_p, I32, pi64]),
             "timing_enable": (C.c_int, [P, I32]),
             "timing_get": (C.c_int, [P, C.c_char_p, pd, pi64]),
             "kernel_profile": (C.c_int, [P, I32, I32, pd]),
@@ -417,6 +418,13 @@ class Learner:
         out = np.zeros((st.shape[0], self.nOut), np.float64)
         self._ck(self.api.fn("forward")(self.h, st.shape[0], _ptr(st, C.c_float), _ptr(out, C.c_double)))
         return out
+
+    def impweight_histogram(self):
+        """(text block as Learner::logStats prints it, 81 bin counts) of the stored importance weights"""
+        buf = C.create_string_buffer(8192)
+        cnt = np.zeros(81, np.int64)
+        self._ck(self.api.fn("impweight_histogram")(self.h, buf, 8192, _ptr(cnt, C.c_int64)))
+        return buf.value.decode(), cnt
 
     def counts(self):
         """(nStoredSteps, nStoredEps, nGradSteps, nSeenSteps, nSeenEps): host-side counters, no device wait"""

@@ -197,6 +197,8 @@ hipError_t launch_set_counts(DevScalars* sc, long long nTransitions, long long n
                              long long seenEps, long long seenSteps, hipStream_t s);
 hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s);
 hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out /*16 doubles*/, hipStream_t s);
+struct HistArgs { DevReplay rp; int nEpisodes; float bounds[82]; unsigned long long* counts; };
+hipError_t launch_impw_hist(const HistArgs& a, hipStream_t s);
 int sweep_blocks(int count);
 int moments_blocks(int nEpisodes);
 

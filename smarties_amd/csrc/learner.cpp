@@ -1194,6 +1194,50 @@ int hl_metrics(hl_learner* h, char* header, int32_t headerCap, char* line, int32
   return HL_OK;
 }
 
+
+// the bounds and the text block of MemoryProcessing::histogramImportanceWeights (MemoryProcessing.cpp:353-389)
+static void impwBounds(float bounds[82]) {
+  const int nBins = 81;
+  const double beg = std::log(1e-3), end = std::log(50.0);
+  bounds[0] = 0;
+  for (int i = 1; i < nBins; ++i) bounds[i] = (float)std::exp(beg + (end - beg) * (i - 1.0) / (nBins - 2.0));
+  bounds[nBins] = std::numeric_limits<float>::max() - 1e2;
+}
+static std::string impwText(const float bounds[82], const int64_t counts[81], double dataSize) {
+  std::ostringstream buff;
+  buff << "_____________________________________________________________________";
+  buff << "\nOFF-POLICY IMP WEIGHTS HISTOGRAMS\n";
+  buff << "weight pi/mu (harmonic mean of histogram's bounds):\n";
+  for (int b = 0; b < 81; ++b) { const float x = bounds[b], y = bounds[b + 1]; real2SS(buff, 2 * x * (y / (x + y)), 6, 1); }
+  buff << "\nfraction of dataset:\n";
+  for (int b = 0; b < 81; ++b) real2SS(buff, counts[b] / dataSize, 6, 1);
+  buff << "\n";
+  buff << "_____________________________________________________________________";
+  return buff.str();
+}
+int hl_impweight_histogram(hl_learner* h, char* text, int32_t cap, int64_t counts[HL_IMPW_BINS]) {
+  if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  int rc = flushPending(h); if (rc) return rc;
+  HistArgs ha{}; ha.rp = h->rp; ha.nEpisodes = (int)h->order.size(); impwBounds(ha.bounds);
+  unsigned long long* dCnt = nullptr;
+  HIPCK(devAlloc(&dCnt, 81));
+  ha.counts = dCnt;
+  HIPCK(launch_impw_hist(ha, h->stream));
+  unsigned long long hc[81];
+  HIPCK(hipMemcpyAsync(hc, dCnt, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  hipFree(dCnt);
+  int64_t c64[81]; for (int b = 0; b < 81; ++b) c64[b] = (int64_t)hc[b];
+  if (counts) std::memcpy(counts, c64, sizeof(c64));
+  if (text) {
+    const std::string t = impwText(ha.bounds, c64, (double)h->nTransitions);
+    if ((int)t.size() + 1 > cap) return fail(h, HL_ERR_BAD_ARG, "hl_impweight_histogram: text buffer too small");
+    std::memcpy(text, t.c_str(), t.size() + 1);
+  }
+  return HL_OK;
+}
+
 // ---- replay memory + ReF-ER state (MemoryBuffer::save / restart, MemoryBuffer.cpp:172-324) ----
 static bool copyFile(const std::string& from, const std::string& to) {
   FILE* a = fopen(from.c_str(), "rb"); if (!a) return false;

@@ -330,6 +330,38 @@ hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, lon
 }
 
 // ---------------------------------------------------------------------------
+// impw_hist_kernel: MemoryProcessing::histogramImportanceWeights (MemoryProcessing.cpp:353-389): one wavefront per
+// episode, lanes over its transitions, bins found by bisection of the (monotonic) bounds, block histogram in LDS
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void impw_hist_kernel(HistArgs a) {
+  __shared__ unsigned sCnt[81];
+  __shared__ float sB[82];
+  for (int i = threadIdx.x; i < 82; i += 256) { sB[i] = a.bounds[i]; if (i < 81) sCnt[i] = 0u; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = blockIdx.x * 4 + wave; p < a.nEpisodes; p += gridDim.x * 4) {
+    const int e = a.rp.posEid[p];
+    const long long off = a.rp.epOff[e];
+    const int nd = a.rp.epN[e] - 1;
+    for (int j = lane; j < nd; j += 64) {
+      const float rho = a.rp.IMPW[off + j];
+      if (rho >= sB[0] && rho < sB[81]) {
+        int lo = 0, hi = 81;                       // largest b with bounds[b] <= rho
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sB[mid] <= rho) lo = mid; else hi = mid; }
+        atomicAdd(&sCnt[lo], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 81; i += 256) if (sCnt[i]) atomicAdd(&a.counts[i], (unsigned long long)sCnt[i]);
+}
+hipError_t launch_impw_hist(const HistArgs& a, hipStream_t s) {
+  int nb = (a.nEpisodes + 3) / 4; if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(impw_hist_kernel, dim3(nb), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // ingest_kernel: MemoryBuffer::addEpisodeToTrainingSet / pushBackEpisode (MemoryBuffer.cpp:131-170, 479-520) for a batch of
 // episodes: blockIdx.y = episode of the batch, blockIdx.x strides over its elements.  Reads the pinned host buffer over the
 // bus exactly once; the derived per-step fields get their insertion values (Episode.h:66-82; pre-training error placeholder

@@ -56,6 +56,15 @@ for F in LRelu Sigm HardSign SoftPlus ExpPlus Exp; do
   "$DRV" fixture "$HERE/act_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 nnFunc=$F batch=8 nEps=12 lenMin=5 lenMax=20 pTerm=0.5 \
      nSteps=4 gradSteps=1,4 maxObs=600 minObs=100
 done
+# G-evict-*: removal rules other than "oldest" (ERoldSeqFilter; getERfilterAlgo, MemoryProcessing.cpp:261-298): more data than
+# maxObs before the first step, so the first steps remove episodes by the rule
+for F in farpolfrac maxkldiv minerror; do
+  "$DRV" fixture "$HERE/evict_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=40 lenMin=5 lenMax=40 pTerm=0.5 \
+     nSteps=30 gradSteps=1,30 maxObs=500 minObs=200 erFilter=$F
+done
+# G-hist: the importance-weight histogram the reference prints (MemoryProcessing::histogramImportanceWeights), captured from stdout
+"$DRV" fixture "$HERE/hist_small.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=40 tapSteps=2 gradSteps=40 maxObs=2000 minObs=300 muSpread=0.8 hist=1
 # official-vs-manual cross check of the harness itself (weights must be bit-identical)
 "$DRV" fixture "$TMP/off.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 \
    lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 maxObs=2000 minObs=500 path=official

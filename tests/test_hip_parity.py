@@ -1036,6 +1036,28 @@ def test_episodes_and_actions_from_other_threads_while_training(hip_api):
         assert np.array_equal(pk[:17], ref["states"][0]) and N == ref["rewards"].size
 
 
+@pytest.mark.gpu
+def test_importance_weight_histogram(hip_api):
+    """hl_impweight_histogram (MemoryProcessing::histogramImportanceWeights, MemoryProcessing.cpp:353-389) on the fixture state
+    of the compiled reference, and against the oracle on a larger replay."""
+    fx = load_fixture("hist_small.bin")
+    L = hip_learner(hip_api, fixture_config(fx))
+    setup_from_fixture(L, fx)
+    for k in range(1, 3):      # the reference's samples of the tapped steps, its own afterwards
+        flat = flat_for(L, fx["s%d_tag" % k], fx["s%d_t" % k])
+        L.step(1, flat=np.sort(flat))
+    text, cnt = L.impweight_histogram()
+    assert cnt.sum() == L.scalars().nStoredSteps
+    assert text.splitlines()[:4] == bytes(bytearray(fx["impw_histogram"])).decode().splitlines()[:4]     # header + bin centres
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(64, 64), batchSize=64, maxTotObsNum=20000, randSeed=8)
+    G, O = _pair(hip_api, cfg_kw, synth_cfg(seed=21, dimS=17, dimA=6, lenMin=5, lenMax=60, pTerm=0.3, muSpread=0.8), 300)
+    G.step(200); O.step(200)
+    tg, cg = G.impweight_histogram(); to, co = O.impweight_histogram()
+    assert cg.sum() == co.sum() == G.scalars().nStoredSteps
+    assert np.abs(cg - co).sum() <= 4 and (cg[1:80] > 0).sum() > 20      # (a weight within 1e-6 of a bin edge may change bins)
+    assert tg.splitlines()[3] == to.splitlines()[3]
+
+
 @pytest.fixture(scope="module")
 def full_size(hip_api):
     cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=1000000, randSeed=42)

@@ -170,6 +170,19 @@ def test_conv_steps_match_reference(name, tmp_path):
         assert np.array_equal(np.fromfile(str(tmp_path / "again_weights.raw"), np.float32), ref)
 
 
+def test_importance_weight_histogram_matches_reference_printout():
+    """MemoryProcessing::histogramImportanceWeights (MemoryProcessing.cpp:353-389) after 40 steps: the block the compiled
+    reference printed, character for character."""
+    fx, L = make("hist_small.bin")
+    setup_from_fixture(L, fx)
+    L.step(40)
+    assert relinf(L.get_params()[0], fx["Wfinal"]) < 1e-6
+    text, cnt = L.impweight_histogram()
+    ref = bytes(bytearray(fx["impw_histogram"])).decode().rstrip("\n")
+    assert cnt.sum() == L.scalars().nStoredSteps and cnt[0] > 0 and (cnt[40:60] > 0).any()
+    assert text == ref
+
+
 def test_far_policy_masks_are_exercised():
     """The fixtures must contain both accepted and rejected (far-policy) samples."""
     fx = load_fixture("small_mixed.bin")
