@@ -326,6 +326,13 @@ HL_API int hl_metrics(hl_learner* h, char* header, int32_t header_cap, char* lin
 #define HL_IMPW_BINS 81
 HL_API int hl_impweight_histogram(hl_learner* h, char* text, int32_t text_cap, int64_t counts[HL_IMPW_BINS]);
 
+/* <runDir>/agent_XX_rank_RRR_cumulative_rewards.dat (MemoryBuffer::pushBackEpisode, ReplayMemory/MemoryBuffer.cpp:481-507,
+ * with --logAllSamples): one line "nGradSteps timeStamp agentID nSteps cumulativeReward" per episode that enters the
+ * training set, appended to `path` (NULL / "" switches it off).  The companion _obs.raw holds environment-scaled actions
+ * and latent state variables (Episode::logToFile): that one is written where those are known -- the reference's own
+ * MemoryBuffer in the compiled binding (bindings/smarties/RACER_HIP.h keeps it as the episode collector). */
+HL_API int hl_set_episode_log(hl_learner* h, const char* path);
+
 /* Output-gradient statistics (Utils/StatsTracker.cpp:28-107, fed by Approximator::setGradient,
  * Network/Approximator.h:197): mean and root-mean-square over the last minibatch of each network
  * output's gradient (nOutputs values each).  hl_set_log_base(h, "<learner_name>") makes hl_step /

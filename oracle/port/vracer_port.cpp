@@ -239,6 +239,7 @@ struct ol_learner {
   std::vector<long double> gsSum, gsSq; std::vector<double> gsMean, gsRms;
   int64_t gsCalls = 0;           // StatsTracker::nStep
   std::string logBase;           // "<learner_name>": <logBase>_net_outGrad_stats.raw
+  std::string episodeLog;        // cumulative_rewards.dat (MemoryBuffer.cpp:481-507)
 };
 
 namespace {
@@ -1108,6 +1109,9 @@ int ol_append_episode(ol_learner* h, int32_t N, const float* states, const doubl
   EP->avgSqErr = maxError * maxError; EP->maxAbsErr = maxError;
   const int64_t locTrain = h->nGatheredB4Startup == INT64_MAX ? -1 : h->nSeenSteps - h->nGatheredB4Startup;
   EP->ID = std::max(locTrain, (int64_t)0);
+  if (!h->episodeLog.empty()) {    // MemoryBuffer.cpp:492-503: nGradSteps, time stamp, agent, steps, total reward
+    if (FILE* f = fopen(h->episodeLog.c_str(), "a")) { fprintf(f, "%ld %ld %d %u %f\n", (long)h->nGradSteps, (long)EP->ID, 0, (unsigned)N, EP->totR); fclose(f); }
+  }
   h->nSeenSteps += 1;                                            // :167
   EP->seq = h->nSeenEps;
   h->nTransitions += EP->ndata();
@@ -1478,6 +1482,7 @@ int ol_grad_stats(ol_learner* h, double* mean, double* rms) {
   std::copy(h->gsMean.begin(), h->gsMean.end(), mean); std::copy(h->gsRms.begin(), h->gsRms.end(), rms);
   return HL_OK;
 }
+int ol_set_episode_log(ol_learner* h, const char* path) { if (!h) return HL_ERR_BAD_ARG; h->episodeLog = path ? path : ""; return HL_OK; }
 int ol_set_log_base(ol_learner* h, const char* base) { if (!h) return HL_ERR_BAD_ARG; h->logBase = base ? base : ""; return HL_OK; }
 int ol_set_tap(ol_learner* h, int32_t e) { if (!h) return HL_ERR_BAD_ARG; h->tap = e != 0; return HL_OK; }
 

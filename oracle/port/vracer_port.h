@@ -54,6 +54,7 @@ HL_API int ol_restart(ol_learner* h, const char* base);
 HL_API int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs);
 HL_API int ol_grad_stats(ol_learner* h, double* mean, double* rms);
 HL_API int ol_set_log_base(ol_learner* h, const char* base);
+HL_API int ol_set_episode_log(ol_learner* h, const char* path);
 HL_API int ol_forward_sequence(ol_learner* h, int32_t n_steps, const float* states, double* outputs);
 HL_API int ol_set_tap(ol_learner* h, int32_t enable);
 HL_API int ol_readback(ol_learner* h, int32_t what, void* dst, int64_t dst_bytes);

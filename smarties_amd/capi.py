@@ -192,6 +192,7 @@ class CApi:
             "metrics": (C.c_int, [P, C.c_char_p, I32, C.c_char_p, I32]),
             "grad_stats": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "set_log_base": (C.c_int, [P, C.c_char_p]),
+            "set_episode_log": (C.c_int, [P, C.c_char_p]),
             "save_memory": (C.c_int, [P, C.c_char_p, I32]),
             "restart_memory": (C.c_int, [P, C.c_char_p, I32]),
             "packed_episode_size": (C.c_int64, [P, I32]),
@@ -418,6 +419,9 @@ class Learner:
         out = np.zeros((st.shape[0], self.nOut), np.float64)
         self._ck(self.api.fn("forward")(self.h, st.shape[0], _ptr(st, C.c_float), _ptr(out, C.c_double)))
         return out
+
+    def set_episode_log(self, path):
+        self._ck(self.api.fn("set_episode_log")(self.h, str(path).encode() if path else None))
 
     def impweight_histogram(self):
         """(text block as Learner::logStats prints it, 81 bin counts) of the stored importance weights"""

@@ -41,6 +41,13 @@ namespace hl {
 #define FSTAMP(i) do { } while (0)
 #endif
 
+// development: stop after phase n (tools/ktime4.py; library built with HL_EXTRA_FLAGS=-DHL_DEV) -- compiled out otherwise
+#ifdef HL_DEV
+#define FVARIANT_STOP(n) do { if (a.variant == (n)) return; } while (0)
+#else
+#define FVARIANT_STOP(n) do { } while (0)
+#endif
+
 // activation evaluated with the function known at compile time; dispatchFunc() branches ONCE on the
 // (uniform) function id and runs the whole epilogue branch-free
 // n / d for d in [1, 2^60): reciprocal + Newton step + two residual corrections -- the IEEE division
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (tid < 16) { sBo[tid] = bov; sBp[tid] = bpv; }
   __syncthreads();
   FSTAMP(1);
-  if (a.variant == 1) return;
+  FVARIANT_STOP(1);
   // the W1 row tile is needed only by the dX contraction: fetched now, behind the critical first batch
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   __syncthreads();
   const float x1o = sT[em * 16 + en], y1o = sY1[em * FLDR + n0 + en];
   FSTAMP(2);
-  if (a.variant == 2) return;
+  FVARIANT_STOP(2);
   if (eth && row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;     // A operand of the dW1 contraction
   float aggv = 0.f;
   asm volatile("" : "+v"(eidv));      // keeps the index arithmetic (and the wait for the load) from being hoisted into the prologue
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   FSTAMP(5);
   __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the stores are acknowledged by the L2
   __syncthreads();
-  if (a.variant == 3) return;
+  FVARIANT_STOP(3);
   FSTAMP(6);
   if (HT > 1 && tid == 0) {
     unsigned* ctr = a.panelCtr + panel * 32;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
 
   FSTAMP(7);
   // ---- read the panel's y3 and f'(x2) back -----------------------------------------------------------------
-  if (a.variant == 4) return;
+  FVARIANT_STOP(4);
   float* sY3 = sR2; float* sF2 = sR3; float* sBx = sY1;
   f32x4 yv[QP], fv[QP];
   {
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   }
   __syncthreads();
   FSTAMP(8);
-  if (a.variant == 5) return;
+  FVARIANT_STOP(5);
 
   // ---- output layer: O[16][nDense] = y3 Wout + bo (MFMA, columns >= 8 are zero) -----------------------
   if (wave < KWAVES) {
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const double mean = (double)rowRorF<15>(Oen);                           // O[em][1 + en]: lane i reads lane i+1
 
   // ---- V-RACER head: thread = (sample em, action component en), fp64 --------------------------------------
-  if (a.variant == 6) return;
+  FVARIANT_STOP(6);
   // every workgroup of the group holds the head results of all 16 samples: workgroup n publishes
   // the samples em with em % HT == n, so no single workgroup carries all the stores
   const bool writer = ((em & (HT - 1)) == n);
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   }
   __syncthreads();
   FSTAMP(10);
-  if (a.variant == 7) return;
+  FVARIANT_STOP(7);
   if (eth && writer && row < B && en < nDense) a.dOut[(size_t)row * a.ldDo + en] = sDo[em * 8 + en];
 
   // ---- delta_y3 = delta_out Wout^T and delta_x2 = delta_y3 f'(x2) are formed directly as the A operand
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     if (row < B) { gDres2[(size_t)row * ldA1 + c] = dy3own; gD2[(size_t)row * ldA1 + c] = dy3own * sF2[em * FLDR + c]; }
   }
   FSTAMP(11);
-  if (a.variant == 8) return;
+  FVARIANT_STOP(8);
 
   // ---- own tile of delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1) ----------------------
   if (wave < KWAVES) {

@@ -78,7 +78,11 @@ template <int ROLE, int FL = -1>
 __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* __restrict__ sc,
                                          const AdamHyper& hyp, int nRowsDyn) {
   const int flavor = FL >= 0 ? FL : P.flavor;
-  const int variant = FL >= 0 ? 0 : hyp.variant;
+#ifdef HL_DEV
+  const int variant = FL >= 0 ? 0 : hyp.variant;      // development ablation switches (HL_EXTRA_FLAGS=-DHL_DEV)
+#else
+  constexpr int variant = 0;
+#endif
   const int epi = FL == GEMM_W ? EPI_DW : P.epi;
   float* sA = reinterpret_cast<float*>(smem);
   float* sB = sA + 16 * LDR;

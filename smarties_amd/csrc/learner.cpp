@@ -71,6 +71,7 @@ struct hl_learner {
   int ldX0 = 0; int lastParity = 0;        // buffer used by the last executed step (taps)
   DevHidden hid[HL_MAX_HIDDEN];
   float* dOut = nullptr; int ldDo = 0;
+  std::string episodeLog;                  // cumulative_rewards.dat of MemoryBuffer::pushBackEpisode (hl_set_episode_log)
   std::string logBase; long long gsCalls = 0;     // StatsTracker file (<logBase>_net_outGrad_stats.raw) and its nStep
   long long indWo = 0, indBo = 0, indBp = 0; int ldWo = 0;
   // gemm problem tables (device) + launch geometry
@@ -853,6 +854,11 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
   h->nSeenSteps += N - 2;
   const long long locTrain = h->nGatheredB4Startup == INT64_MAX ? -1 : h->nSeenSteps - h->nGatheredB4Startup;
   EpMeta e{eid, off, N, terminated != 0, tag, std::max(locTrain, (long long)0)};
+  if (!h->episodeLog.empty()) {      // MemoryBuffer.cpp:492-503: "%ld %ld %d %u %f" = nGradSteps, time stamp, agent, steps, total reward (Fval)
+    float totRf = 0; for (int t = 1; t < N; ++t) totRf = (float)((double)totRf + rewards[t]);      // Fval totR += Real reward (:95-96)
+    if (FILE* f = std::fopen(h->episodeLog.c_str(), "a")) { std::fprintf(f, "%ld %ld %d %u %f\n", (long)h->nGradSteps, (long)e.ID, 0, (unsigned)N, totRf); std::fclose(f); }
+    else return fail(h, HL_ERR_IO, "unable to open " + h->episodeLog);
+  }
   h->nSeenSteps += 1; h->nSeenEps += 1;
   h->order.push_front(e);
   h->nTransitions += N - 1;
@@ -961,6 +967,7 @@ int hl_grad_stats(hl_learner* h, double* mean, double* rms) {
   if (h->gsCalls == 0 && !h->inStep) return fail(h, HL_ERR_STATE, "no gradient step yet");
   return gradStatsOfLastBatch(h, mean, rms);
 }
+int hl_set_episode_log(hl_learner* h, const char* path) { if (!h) return HL_ERR_BAD_ARG; HL_LOCK(h); h->episodeLog = path ? path : ""; return HL_OK; }
 int hl_set_log_base(hl_learner* h, const char* base) { if (!h) return HL_ERR_BAD_ARG; HL_LOCK(h); h->logBase = base ? base : ""; return HL_OK; }
 static int appendGradStats(hl_learner* h) {      // StatsTracker::printToFile (StatsTracker.cpp:65-85)
   if (h->cfg.rank != 0) return HL_OK;

@@ -264,13 +264,15 @@ VARIANTS = {
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_eviction_and_append_during_training(hip_api, variant):
-    """FIFO removal (applyEpisodesRemovalAlgo, 'oldest') and episodes appended between steps."""
+def test_eviction_and_append_during_training(hip_api, variant, tmp_path):
+    """FIFO removal (applyEpisodesRemovalAlgo, 'oldest') and episodes appended between steps; the cumulative_rewards.dat
+    lines MemoryBuffer::pushBackEpisode writes for them (MemoryBuffer.cpp:481-507)."""
     cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 1], hidden=(32, 32), batchSize=16, maxTotObsNum=600, minTotObsNum=300,
                   randSeed=2)
     cfg_kw.update(VARIANTS[variant])
     sc = synth_cfg(seed=21, dimS=5, dimA=cfg_kw["dimA"], lenMin=10, lenMax=40, pTerm=0.4)
     G, O = _pair(hip_api, cfg_kw, sc, 24)
+    G.set_episode_log(tmp_path / "g_rewards.dat"); O.set_episode_log(tmp_path / "o_rewards.dat")
     e = 24
     for k in range(30):
         G.step(1); O.step(1)
@@ -281,6 +283,8 @@ def test_eviction_and_append_during_training(hip_api, variant):
         sg, so = G.scalars(), O.scalars()
         assert sg.nStoredSteps == so.nStoredSteps and sg.nStoredEps == so.nStoredEps
     assert relinf(G.get_params()[0], O.get_params()[0]) < TOL32
+    lg, lo = open(tmp_path / "g_rewards.dat").read().split("\n"), open(tmp_path / "o_rewards.dat").read().split("\n")
+    assert len(lg) == len(lo) == 31 and lg == lo and lg[3].split()[0] == "4"      # "nGradSteps timeStamp agent nSteps totalReward"
 
 
 @pytest.mark.parametrize("rule", ["farpolfrac", "maxkldiv", "minerror"])
