@@ -89,6 +89,52 @@ def synthetic_episode(np, e, dS=17, dA=6, N=EP_STATES):
     return dict(states=S, actions=A, mu=MU, rewards=R, values=V, terminated=0, tag=e)
 
 
+def other_configs(api, steps=1000):
+    """us per gradient step of the other BASELINE.json configurations (parity-tested shapes, not the bench workload): small
+    synthetic replays resident in HBM, `steps` replayed steps after a warm-up.  Reported next to the bench line."""
+    import numpy as np
+    from smarties_amd import capi
+    conv = [(84, 84, 4, 8, 8, 4), (20, 20, 8, 16, 6, 2), (8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)]
+    cases = {
+        "cfg1_cart_pole_vracer_2x128_b256": (dict(dimS=5, dimA=1, bounded=[1], hidden=(128, 128), nnFunc="Tanh", batchSize=256, maxTotObsNum=40131,
+                                                  clipImpWeight=0.5 ** 0.5, explNoise=0.2 ** 0.5), 300, 120, steps),
+        "cfg3_humanoid_replica_2x256_b32": (dict(dimS=257, dimA=17, bounded=[0] * 17, hidden=(256, 256), batchSize=32, maxTotObsNum=131072,
+                                                 clipImpWeight=(17 / 2.0) ** 0.5), 300, 200, steps),
+        "cfg4_racer_rnn_lstm_2x32_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
+                                                      gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
+        "cfg4_mgu_2x32_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
+                                           gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
+        "cfg5_racer_atari_conv4_512_b128": (dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3, conv=conv, hidden=(512,),
+                                                 nnFunc="Tanh", batchSize=128, maxTotObsNum=20000, gamma=0.99, explNoise=0.05), 120, 60, max(100, steps // 5)),
+    }
+    res = {}
+    for name, (kw, nEp, N, n) in cases.items():
+        g = np.random.default_rng(5)
+        L = capi.Learner(api, capi.make_config(randSeed=7, **kw))
+        L.init_weights()
+        dS, dA = kw["dimS"], kw["dimA"]
+        nopt = kw.get("n_options", 0)
+        for e in range(nEp):
+            S = g.standard_normal((N, dS)).astype(np.float32)
+            if nopt:
+                A = g.integers(0, nopt, size=(N, 1)).astype(np.float64) + 0.1
+                MU = g.random((N, nopt)) + 0.2
+                MU /= MU.sum(1, keepdims=True)
+            else:
+                mean = 0.5 * g.standard_normal((N, dA)); std = 0.3 + 0.4 * g.random((N, dA))
+                A = mean + std * g.standard_normal((N, dA)); MU = np.concatenate([mean, std], axis=1)
+            R = g.standard_normal(N); R[0] = 0
+            A[-1] = 0; MU[-1] = 0
+            L.append_episode(states=S, actions=A, mu=MU, rewards=R, values=(0.5 * g.standard_normal(N)).astype(np.float32),
+                             terminated=int(e % 3 == 0), tag=e)
+        L.initialize()
+        L.step(64); L.sync()
+        t0 = time.perf_counter(); L.step(n); L.sync(); dt = time.perf_counter() - t0
+        res[name] = {"us_per_step": round(dt / n * 1e6, 2), "transitions_per_s": round(kw["batchSize"] * n / dt), "steps": n}
+        L.close()
+    return res
+
+
 def cpu_baseline(steps_budget_s=20.0):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver_fast")
     ncpu = os.cpu_count() or 1
@@ -147,6 +193,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the us/step of the other BASELINE configurations")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -325,6 +372,11 @@ def main():
             "roofline": roof,
             "fill_seconds": t_fill,
         }
+        if not args.no_other_configs and n_ranks == 1:
+            try:
+                out["other_configs"] = other_configs(api, steps=1000)
+            except Exception as e:  # noqa: BLE001
+                out["other_configs"] = {"error": str(e)}
         if not args.no_cpu_baseline and n_ranks == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline()
