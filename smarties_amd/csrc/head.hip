@@ -79,39 +79,37 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     if (arr) misc = arr[sl];
   }
 
-  // ---- output dense layer: O[o] = b[o] + sum_k y[k] W[k][o] -----------------------------------
-  if (small) {
+  // ---- output dense layer: O[o] = b[o] + sum_k y[k] W[k][o], eight outputs at a time; the weight rows of a chunk are
+  // fetched as two 16-byte loads per hidden unit, all of them in flight before the first use (the first chunk was
+  // requested up front, next to the activations) ------------------------------------------------------------------
+  const int nChunkOut = isNext ? 1 : (nDense + 7) / 8;
+  for (int c = 0; c < nChunkOut; ++c) {
+    float4 wa[HQ], wb[HQ];
+    if (c == 0 && small) {
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) { wa[q] = w0[q]; wb[q] = w1[q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        const int k = lane + 64 * q; const bool ok = k < H;
+        const float* wr = Wo + (size_t)(ok ? k : 0) * a.ldWo + 8 * c;
+        wa[q] = *reinterpret_cast<const float4*>(wr); wb[q] = *reinterpret_cast<const float4*>(wr + 4);
+        if (!ok) { wa[q] = make_float4(0.f, 0.f, 0.f, 0.f); wb[q] = wa[q]; }
+      }
+    }
     float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
-      p[0] += yv[q] * w0[q].x; p[1] += yv[q] * w0[q].y; p[2] += yv[q] * w0[q].z; p[3] += yv[q] * w0[q].w;
-      p[4] += yv[q] * w1[q].x; p[5] += yv[q] * w1[q].y; p[6] += yv[q] * w1[q].z; p[7] += yv[q] * w1[q].w;
+      p[0] += yv[q] * wa[q].x; p[1] += yv[q] * wa[q].y; p[2] += yv[q] * wa[q].z; p[3] += yv[q] * wa[q].w;
+      p[4] += yv[q] * wb[q].x; p[5] += yv[q] * wb[q].y; p[6] += yv[q] * wb[q].z; p[7] += yv[q] * wb[q].w;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) p[q] = waveSumF(p[q]);
     float mine = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q == lane) mine = p[q];
-    if (lane < nDense) sO[wave][lane] = (double)(mine + bo);
-  } else {
-    const int nChunkOut = isNext ? 1 : nDense;
-    for (int o0 = 0; o0 < nChunkOut; o0 += 8) {
-      float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int k = lane; k < H; k += 64) {
-        const float yk = a.Yin[(size_t)row * a.ldY + k];
-        const float* w = Wo + (size_t)k * a.ldWo + o0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (o0 + q < nDense) p[q] += yk * w[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) p[q] = waveSumF(p[q]);
-      if (lane < 8 && o0 + lane < nDense) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (q == lane) v = p[q];
-        sO[wave][o0 + lane] = (double)(v + a.params[a.indBo + o0 + lane]);
-      }
-    }
+    const int o = 8 * c + lane;
+    if (lane < 8 && o < nDense) sO[wave][o] = (double)(mine + (c == 0 ? bo : a.params[a.indBo + o]));
   }
   if (lane < a.nSig) sO[wave][nDense + lane] = (double)bp;   // ParamLayer, Linear (absent for the discrete head)
   __builtin_amdgcn_wave_barrier();
@@ -294,28 +292,39 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   __threadfence_block();
   // ---- deltas of the output layer and back-propagation into the last hidden block ----------------
   for (int o = lane; o < nDense; o += 64) a.dOut[(size_t)b * a.ldDo + o] = sDelta[wave][o];
-  if (small) {
-    float d[8];
+  {
+    float acc[HQ];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) d[o] = o < nDense ? sDelta[wave][o] : 0.f;
+    for (int q = 0; q < HQ; ++q) acc[q] = 0.f;
+    const int nCh = (nDense + 7) / 8;
+    for (int c = 0; c < nCh; ++c) {
+      float4 wa[HQ], wb[HQ];
+      if (c == 0 && small) {
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) { wa[q] = w0[q]; wb[q] = w1[q]; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+          const int k = lane + 64 * q;
+          const float* wr = Wo + (size_t)(k < H ? k : 0) * a.ldWo + 8 * c;
+          wa[q] = *reinterpret_cast<const float4*>(wr); wb[q] = *reinterpret_cast<const float4*>(wr + 4);
+        }
+      }
+      float d[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) d[o] = 8 * c + o < nDense ? sDelta[wave][8 * c + o] : 0.f;
+#pragma unroll
+      for (int q = 0; q < HQ; ++q)
+        acc[q] += ((wa[q].x * d[0] + wa[q].y * d[1]) + (wa[q].z * d[2] + wa[q].w * d[3])) +
+                  ((wb[q].x * d[4] + wb[q].y * d[5]) + (wb[q].z * d[6] + wb[q].w * d[7]));
+    }
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
       const int k = lane + 64 * q;
       if (k < H) {
-        const float s = ((w0[q].x * d[0] + w0[q].y * d[1]) + (w0[q].z * d[2] + w0[q].w * d[3])) +
-                        ((w1[q].x * d[4] + w1[q].y * d[5]) + (w1[q].z * d[6] + w1[q].w * d[7]));
-        a.Dres[(size_t)b * a.ldD + k] = s;
-        a.D[(size_t)b * a.ldD + k] = s * actDiff(a.func, xl[q], yl[q]);
+        a.Dres[(size_t)b * a.ldD + k] = acc[q];
+        a.D[(size_t)b * a.ldD + k] = acc[q] * actDiff(a.func, xl[q], yl[q]);
       }
-    }
-  } else {
-    for (int k = lane; k < H; k += 64) {
-      const float* w = Wo + (size_t)k * a.ldWo;
-      float s = 0.f;
-      for (int o = 0; o < nDense; ++o) s += w[o] * sDelta[wave][o];
-      a.Dres[(size_t)b * a.ldD + k] = s;
-      a.D[(size_t)b * a.ldD + k] =
-          s * actDiff(a.func, a.Xlast[(size_t)row * a.ldD + k], a.Ylast[(size_t)row * a.ldD + k]);
     }
   }
 }
