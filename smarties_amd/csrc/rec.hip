@@ -802,6 +802,227 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
   }
 }
 
+// ---- LSTM, two layers of 32 cells (settings/RACER_RNN.json): ONE WAVEFRONT PER (SAMPLE, LAYER), weights in registers ----------
+// The kernels above spend a layer-step (128 gates x 64 terms = 8 k multiply-adds) mostly on LDS round trips for weights and
+// operand, cross-lane joins and workgroup barriers: ~1.1 us, 38 + 41 us per window forward + BPTT.  Here a workgroup of two
+// wavefronts owns a sample, one wavefront per layer:
+//   forward   lane l of a layer's wavefront holds the two gate columns l and l + 64 of [W_in; W_rec] in registers; the operand
+//             [input | previous output] lives in LDS and is read as broadcast 16-byte chunks; the two dot products of a lane
+//             run as packed fp32 FMAs on four independent accumulators, no cross-lane join; the four gates of a cell meet
+//             through one 32-lane shuffle.  Layer 0 never depends on layer 1, so its wavefront runs one step AHEAD: at
+//             iteration i the first works on step i, the second on step i - 1 (software pipeline, one barrier per iteration).
+//   backward  lane i holds ROW i of [W_in; W_rec] (128 values), the 128 gate deltas of the layer-step are broadcast from LDS.
+//             Here the TOP layer never depends on the one below, so its wavefront runs one step ahead (k = T - i).
+// Sigmoid / tanh use the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32 + one Newton step: ~1e-7 relative, inside
+// the tolerance these layers are tested to); the kernels above keep libm's.  Rows written for the weight-gradient launch
+// are the same as those of the kernels above.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pairBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float fastRcp(float d) { float r = __builtin_amdgcn_rcpf(d); return fmaf(fmaf(-d, r, 1.0f), r, r); }
+__device__ __forceinline__ float fastSigm(float in) {      // Sigm::_eval with safeExp cut at 8, one exponential for both branches
+  const float ex = __expf(fmaxf(-8.f, -fabsf(in))), r = fastRcp(1.f + ex);
+  return in > 0.f ? r : ex * r;
+}
+__device__ __forceinline__ float fastTanh(float in) {      // Tanh::_eval (Functions.h:104-113)
+  const float e = __expf(-2.f * fabsf(in)), y = (1.f - e) * fastRcp(1.f + e);
+  return in > 0.f ? y : -y;
+}
+
+// one layer-step: the two gates of this lane (NT terms each, operand broadcast from LDS), cell update on lanes 0..31, the
+// rows kept for the backward pass / the weight gradients
+template <int NT>
+__device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (&w)[NT], f32x2 bias, const float* vec, int inPad, int nInL,
+                                                float& prevSt, float wr, float br, float* hNext, float& blkOut, bool store, long long r, int lane) {
+  constexpr int NC = 32, NO = 128;
+  f32x2 a0 = bias, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+  const f32x4* v4 = reinterpret_cast<const f32x4*>(vec);
+#pragma unroll
+  for (int q = 0; q < NT / 4; ++q) {
+    const f32x4 v = v4[q];
+    a0 += w[4 * q] * f32x2{v[0], v[0]}; a1 += w[4 * q + 1] * f32x2{v[1], v[1]};
+    a2 += w[4 * q + 2] * f32x2{v[2], v[2]}; a3 += w[4 * q + 3] * f32x2{v[3], v[3]};
+  }
+  const f32x2 acc = (a0 + a1) + (a2 + a3);
+  // lanes 0..31: acc = (cell input, forget gate); lanes 32..63: (input gate, output gate)
+  const float g0 = lane < 32 ? acc[0] : fastSigm(acc[0]), g1 = fastSigm(acc[1]);
+  if (store) { L.X[r * NO + lane] = g0; L.X[r * NO + lane + 64] = g1; }
+  const float ig = __shfl(g0, lane + 32, 64), og = __shfl(g1, lane + 32, 64);
+  if (store) {         // the operand row: A operand of the weight-gradient contraction
+    if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
+    if (lane < NC) L.A[r * L.ldA + nInL + lane] = vec[inPad + lane];
+  }
+  if (lane < NC) {
+    const float st = g0 * ig + prevSt * g1;            // (prevSt is 0 at the first step of the window)
+    const float co = fastTanh(st);
+    const float out = og * co;
+    prevSt = st;
+    if (store) { L.Y[r * NO + lane] = out; L.Y[r * NO + NC + lane] = st; L.Y[r * NO + 2 * NC + lane] = co; }
+    float blk = out;                                   // ParametricResidualLayer::forward (Layers.h:347-361)
+    if (L.hasRes && lane < L.resW) blk += vec[lane] * wr + br;
+    hNext[lane] = out;
+    blkOut = blk;
+  }
+}
+
+template <int IN0>     // inputs of the first layer, padded to a multiple of 4 (<= 32)
+__global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
+  constexpr int NC = 32, NO = 128;
+  constexpr int NTMAX = (IN0 + NC) > 2 * NC ? (IN0 + NC) : 2 * NC;    // terms per gate as the unrolled loop walks them (zero weights behind the layer's own)
+  __shared__ __attribute__((aligned(16))) float sV0[2][NTMAX];         // layer 0 operand [x_k | h0_{k-1} | 0 ...], double-buffered over the steps
+  __shared__ __attribute__((aligned(16))) float sV1[2][2 * NC];        // layer 1 operand [block-0 output of step k | h1_{k-1}]
+  __shared__ float sStates[18 * 32];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int layer = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform
+  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
+  const int T = min(a.nBPTT, t);
+  const int nextRow = a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  const RecLayer L = a.L[layer];
+  const int nIn = a.L[0].nIn, dS = a.dS;
+  // this lane's gate columns of its layer: o = lane (cell input | input gate) and lane + 64 (forget | output gate)
+  f32x2 w[NTMAX];
+  {
+    const float* Wl = W + L.indW;
+#pragma unroll
+    for (int i = 0; i < NTMAX; ++i) {
+      int row;
+      if (layer == 0) row = i < IN0 ? (i < nIn ? i : -1) : (i < IN0 + NC ? nIn + (i - IN0) : -1);
+      else row = i < 2 * NC ? i : -1;
+      w[i] = row >= 0 ? f32x2{Wl[(size_t)row * NO + lane], Wl[(size_t)row * NO + lane + 64]} : f32x2{0.f, 0.f};
+    }
+  }
+  const f32x2 bias = {W[L.indB + lane], W[L.indB + lane + 64]};
+  const int c = lane & 31;
+  float wr = 0.f, br = 0.f;
+  if (L.hasRes && c < L.resW) { wr = W[L.indWr + c]; br = W[L.indBr + c]; }
+  for (int e = tid; e < nSteps * dS; e += 128) {
+    const int kk = e / dS, i = e - kk * dS;
+    sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
+  }
+  for (int i = tid; i < 2 * NTMAX; i += 128) (&sV0[0][0])[i] = 0.f;
+  for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
+  vmDrain(); pairBarrier();
+  if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
+  pairBarrier();
+  float prevSt = 0.f;
+  for (int it = 0; it <= nSteps; ++it) {
+    if (layer == 0) {
+      const int k = it;
+      if (k < nSteps) {
+        const int cb = k & 1;
+        if (k + 1 < nSteps && lane < dS) sV0[cb ^ 1][lane] = sStates[(k + 1) * dS + lane];       // (that copy was last read a step ago)
+        float blk = 0.f;
+        lstm32LayerStep<NTMAX>(L, w, bias, sV0[cb], IN0, nIn, prevSt, wr, br, &sV0[cb ^ 1][IN0], blk, k <= T, (long long)b * a.K + k, lane);
+        if (lane < NC) sV1[cb][lane] = blk;
+      }
+    } else {
+      const int k = it - 1;
+      if (k >= 0) {
+        const int cb = k & 1;
+        float blk = 0.f;
+        lstm32LayerStep<NTMAX>(L, w, bias, sV1[cb], NC, NC, prevSt, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane);
+        if (lane < NC) {
+          if (k == T) a.Yout[(size_t)b * a.ldY + lane] = blk;
+          if (k == T + 1) a.Yout[(size_t)nextRow * a.ldY + lane] = blk;
+        }
+      }
+    }
+    pairBarrier();
+  }
+}
+
+template <int IN0>
+__global__ __launch_bounds__(128) void lstm32_backward_wave_kernel(RecArgs a) {
+  constexpr int NC = 32, NO = 128, ACT = 6 * NC;           // per (step, layer): [cell input | I | F | O | state | tanh(state)]
+  __shared__ __attribute__((aligned(16))) float sD[2][NO]; // gate deltas of the layer-step, per layer
+  __shared__ float sAct[2][17 * ACT];
+  __shared__ float sTop[2][NC];                            // error w.r.t. block 0's output at step k (ring over k & 1), from the top layer
+  __shared__ float sRec[2][NC];                            // error w.r.t. this step's LSTM output coming from step k + 1, per layer
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = 1 - wv;                                    // wavefront 0 = the top layer (one step ahead), wavefront 1 = layer 0
+  const int t = a.bt.t[b];
+  const int T = min(a.nBPTT, t);
+  const float* W = a.W;
+  const RecLayer L = a.L[j];
+  const int nIn0 = a.L[0].nIn;
+  // this lane's row of [W_in; W_rec]: top layer row `lane` (0..31 input, 32..63 recurrent); layer 0 row nIn + lane (recurrent
+  // part only: nothing is propagated to the network input)
+  f32x4 wq[NO / 4];
+  {
+    const f32x4* rw = reinterpret_cast<const f32x4*>(W + L.indW + (size_t)(j == 1 ? lane : nIn0 + (lane & 31)) * NO);
+#pragma unroll
+    for (int q = 0; q < NO / 4; ++q) wq[q] = rw[q];
+  }
+  {   // stored activations of this layer over the window
+    const int total = (T + 1) * ACT;
+    for (int e = lane; e < total; e += 64) {
+      const int k = e / ACT, x = e - k * ACT;
+      const long long r = (long long)b * a.K + k;
+      sAct[j][e] = x < 4 * NC ? L.X[r * NO + x] : L.Y[r * NO + NC + (x - 4 * NC)];
+    }
+  }
+  const float wr = (L.hasRes && lane < L.resW) ? W[L.indWr + lane] : 0.f;
+  const float dres = (j == 1 && lane < NC) ? a.Dres[(size_t)b * a.ldD + lane] : 0.f;
+  // rows of the steps this sample does not have: zero deltas
+  for (int k = T + 1; k < a.K; ++k) {
+    const long long r = (long long)b * a.K + k;
+    L.D[r * NO + lane] = 0.f; L.D[r * NO + lane + 64] = 0.f;
+    if (L.hasRes && lane < NC) L.Rd[r * L.ldR + lane] = 0.f;
+  }
+  vmDrain(); pairBarrier();
+  float nxtSt = 0.f, nxtF = 0.f;                           // state error / forget gate of step k + 1 (lanes 0..31)
+  for (int it = 0; it <= T + 1; ++it) {
+    const int k = T - it + (j == 1 ? 0 : 1);               // the top layer is one step ahead
+    if (k >= 0 && k <= T) {
+      const long long r = (long long)b * a.K + k;
+      // gate deltas on lanes 0..31 (LSTMLayer::backward, Layer_LSTM.h:127-165)
+      float res = 0.f;
+      if (lane < NC) {
+        const float eTop = j == 1 ? (k == T ? dres : 0.f) : sTop[k & 1][lane];
+        const float* act = sAct[j] + k * ACT;
+        if (L.hasRes) { L.Rd[r * L.ldR + lane] = eTop; res = lane < L.resW ? eTop * wr : 0.f; }
+        const float D = eTop + (k < T ? sRec[j][lane] : 0.f);
+        const float cellInpt = act[lane], IG = act[NC + lane], FG = act[2 * NC + lane], OG = act[3 * NC + lane], co = act[5 * NC + lane];
+        const float prevSt = k > 0 ? (act - ACT)[4 * NC + lane] : 0.f;
+        const float diff = (1.f - co * co) * D;
+        const float sd = diff * OG + (k < T ? nxtSt * nxtF : 0.f);
+        const float d0 = IG * sd;
+        const float d1 = IG * (1.f - IG) * cellInpt * sd;
+        const float d2 = k > 0 ? FG * (1.f - FG) * prevSt * sd : 0.f;
+        const float d3 = OG * (1.f - OG) * D * co;
+        sD[j][lane] = d0; sD[j][NC + lane] = d1; sD[j][2 * NC + lane] = d2; sD[j][3 * NC + lane] = d3;
+        L.D[r * NO + lane] = d0; L.D[r * NO + NC + lane] = d1; L.D[r * NO + 2 * NC + lane] = d2; L.D[r * NO + 3 * NC + lane] = d3;
+        nxtSt = sd; nxtF = FG;
+      }
+      __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier();    // this wavefront's deltas are in LDS
+      if (j == 1 || k > 0) {
+        // e_i = sum_o W[i][o] delta[o] for this lane's row (Layer::backward, Layers.h:123-188)
+        const f32x4* d4 = reinterpret_cast<const f32x4*>(sD[j]);
+        f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NO / 4; q += 2) {
+          const f32x4 da = d4[q], db = d4[q + 1];
+          p0 += f32x2{wq[q][0], wq[q][1]} * f32x2{da[0], da[1]}; p1 += f32x2{wq[q][2], wq[q][3]} * f32x2{da[2], da[3]};
+          p2 += f32x2{wq[q + 1][0], wq[q + 1][1]} * f32x2{db[0], db[1]}; p3 += f32x2{wq[q + 1][2], wq[q + 1][3]} * f32x2{db[2], db[3]};
+        }
+        const f32x2 ps = (p0 + p1) + (p2 + p3);
+        const float e = ps[0] + ps[1];
+        if (j == 1) {   // rows 0..31: error of block 0's output (+ the residual path of this layer); rows 32..63: handed to step k - 1
+          if (lane < NC) sTop[k & 1][lane] = res + e; else sRec[1][lane - NC] = e;
+        } else if (lane < NC) sRec[0][lane] = e;
+      }
+    }
+    pairBarrier();
+  }
+}
+
+// the wave-per-sample kernels serve the training pass of two LSTM layers of 32 cells each over up to 32 inputs and 17 steps
+static bool lstm32Wave(const RecArgs& a) {
+  return a.gates == 4 && a.actStates == nullptr && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
+         a.L[0].nIn <= 32 && a.dS == a.L[0].nIn && a.K <= 17 && a.L[0].indW % 4 == 0 && a.L[1].indW % 4 == 0 && !a.L[0].hasRes;
+}
 static size_t recLdsBytes(const RecArgs& a) {
   size_t fl = 0;
   for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (a.gates * a.L[j].nC + 1);
@@ -820,6 +1041,14 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
     if (fit && a.nL == 1) return recLaunch(mgu_forward_kernel<true, 1>, a, lds, &attrM[1], s);
     if (fit && a.nL == 2) return recLaunch(mgu_forward_kernel<true, 2>, a, lds, &attrM[2], s);
     return fit ? recLaunch(mgu_forward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_forward_kernel<false, 0>, a, 0, &attr[1], s);
+  }
+  if (lstm32Wave(a)) {      // two layers of 32 cells, training pass: one wavefront per sample, weights in registers
+    const int in0 = (a.L[0].nIn + 3) & ~3;
+    if (in0 <= 4) hipLaunchKernelGGL(lstm32_forward_wave_kernel<4>, dim3(a.B), dim3(128), 0, s, a);
+    else if (in0 <= 8) hipLaunchKernelGGL(lstm32_forward_wave_kernel<8>, dim3(a.B), dim3(128), 0, s, a);
+    else if (in0 <= 16) hipLaunchKernelGGL(lstm32_forward_wave_kernel<16>, dim3(a.B), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(lstm32_forward_wave_kernel<32>, dim3(a.B), dim3(128), 0, s, a);
+    return hipGetLastError();
   }
   size_t fl = 0; bool al = true;
   for (int j = 0; j < a.nL; ++j) { fl += (size_t)4 * a.L[j].nC * lstmGeo(a.L[j].nIn, a.L[j].nC).ld; al = al && a.L[j].indW % 4 == 0 && a.L[j].nIn <= REC_MAXIN; }
@@ -843,6 +1072,14 @@ hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
     if (fit && a.nL == 1) return recLaunch(mgu_backward_kernel<true, 1>, a, lds, &attrM[1], s);
     if (fit && a.nL == 2) return recLaunch(mgu_backward_kernel<true, 2>, a, lds, &attrM[2], s);
     return fit ? recLaunch(mgu_backward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false, 0>, a, 0, &attr[1], s);
+  }
+  if (lstm32Wave(a)) {
+    const int in0 = (a.L[0].nIn + 3) & ~3;
+    if (in0 <= 4) hipLaunchKernelGGL(lstm32_backward_wave_kernel<4>, dim3(a.B), dim3(128), 0, s, a);
+    else if (in0 <= 8) hipLaunchKernelGGL(lstm32_backward_wave_kernel<8>, dim3(a.B), dim3(128), 0, s, a);
+    else if (in0 <= 16) hipLaunchKernelGGL(lstm32_backward_wave_kernel<16>, dim3(a.B), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(lstm32_backward_wave_kernel<32>, dim3(a.B), dim3(128), 0, s, a);
+    return hipGetLastError();
   }
   size_t fl = 0; bool al = true;
   for (int j = 0; j < a.nL; ++j) {
