@@ -95,6 +95,12 @@ enum { HL_ER_OLDEST = 0,       /* "oldest" / "default": first in, first out     
        HL_ER_MAXKLDIV = 2,     /* "maxkldiv":   the episode with the largest average D_KL                      */
        HL_ER_MINERROR = 3 };   /* "minerror":   the episode with the smallest average squared TD error         */
 
+/* minibatch sampler: settings key dataSamplingAlgo (Sampling::prepareSampler, ReplayMemory/Sampling.cpp:298-340) */
+enum { HL_SAMPLE_UNIFORM = 0,  /* "uniform":  Sample_uniform (:50-97)                                                     */
+       HL_SAMPLE_PERRANK = 1,  /* "PERrank":  TSample_impRank (:101-170): probability 1 / sqrt(sqrt(rank of the squared TD error)) */
+       HL_SAMPLE_PERERR = 2,   /* "PERerr":   TSample_impErr (:173-230): probability (delta^2 + eps)^(1/4)                  */
+       HL_SAMPLE_PERSEQ = 3 }; /* "PERseq":   Sample_impSeq (:234-296): episodes by (avg squared error + eps)^(1/4) x length, step uniform */
+
 /* episode ordering used for the flat-index -> (episode, step) prefix walk */
 enum { HL_ORDER_STABLE = 0,     /* stable sort by ID, newest first (product semantics)  */
        HL_ORDER_REFERENCE = 1 };/* std::sort each step exactly as MemoryProcessing.cpp:336
@@ -154,7 +160,11 @@ typedef struct hl_config {
   hl_conv2d conv[HL_MAX_CONV];
   int32_t ERoldSeqFilter;            /* HL_ER_*: removal rule of an over-full replay (equal keys: the older episode goes;
                                         the reference's non-stable std::sort leaves that to the library implementation)  */
-  int32_t reserved[1];
+  int32_t dataSamplingAlgo;          /* HL_SAMPLE_*.  The prioritised samplers rebuild a std::discrete_distribution over all
+                                        stored transitions (episodes) before every minibatch, as the reference does: its
+                                        normalisation and cumulative table are sequential double-precision passes, kept
+                                        sequential on the device so that the drawn indices are the reference's (PERerr, PERseq;
+                                        PERrank ranks equal errors in storage order where the reference's non-stable sort leaves it open) */
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */

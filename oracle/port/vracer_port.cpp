@@ -26,6 +26,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <tuple>
+#include <limits>
 #include <vector>
 
 namespace {
@@ -963,6 +965,81 @@ void sampleUniform(ol_learner* h, std::vector<int64_t>& flat) {
     it = std::unique(flat.begin(), flat.end()) - flat.begin();
   }
 }
+// ---- prioritised samplers (ReplayMemory/Sampling.cpp:101-296) over libstdc++'s std::discrete_distribution<Uint>, restated:
+//   param_type::_M_initialize   sum = accumulate(p, 0.0); p /= sum; cp = partial_sum(p); cp.back() = 1   (all sequential, double)
+//   operator()                  lower_bound(cp, generate_canonical<double, 53>(urng)) - cp.begin()
+//   generate_canonical<double,53> over mt19937: (w0 + w1 * 2^32) / 2^64 from two words, nextafter(1, 0) if it rounds to 1
+struct DiscreteDist {
+  std::vector<double> cp;
+  void init(const std::vector<float>& p) {
+    cp.clear();
+    if (p.size() < 2) return;
+    std::vector<double> q(p.begin(), p.end());
+    double sum = 0.0; for (double v : q) sum += v;
+    for (double& v : q) v /= sum;
+    cp.resize(q.size()); double acc = 0; bool first = true;
+    for (size_t i = 0; i < q.size(); ++i) { acc = first ? q[i] : acc + q[i]; first = false; cp[i] = acc; }
+    cp.back() = 1.0;
+  }
+  size_t draw(MT19937& g) const {
+    if (cp.empty()) return 0;
+    double sum = 0, tmp = 1;
+    for (int k = 0; k < 2; ++k) { sum += (double)g.next() * tmp; tmp *= 4294967296.0; }
+    double r = sum / tmp; if (r >= 1.0) r = std::nextafter(1.0, 0.0);
+    return (size_t)(std::lower_bound(cp.begin(), cp.end(), r) - cp.begin());
+  }
+};
+void perPrepare(ol_learner* h, DiscreteDist& dist) {
+  const float EPS = std::numeric_limits<float>::epsilon();
+  const int algo = h->cfg.dataSamplingAlgo;
+  std::vector<float> probs;
+  if (algo == HL_SAMPLE_PERSEQ) {          // Sample_impSeq::prepare (:234-258)
+    for (const auto& ep : h->episodes) probs.push_back(std::sqrt(std::sqrt(ep->avgSqErr + EPS)) * (float)(size_t)ep->ndata());
+  } else if (algo == HL_SAMPLE_PERERR) {   // TSample_impErr::prepare (:173-205)
+    for (const auto& ep : h->episodes) for (int j = 0; j < ep->ndata(); ++j) { const float d2 = ep->DQ[j] * ep->DQ[j]; probs.push_back(std::sqrt(std::sqrt(d2 + EPS))); }
+  } else {                                  // TSample_impRank::prepare (:102-149)
+    using Tup = std::tuple<float, unsigned, unsigned>;
+    std::vector<Tup> errors; std::vector<size_t> prefixes; size_t prefix = 0;
+    for (size_t i = 0; i < h->episodes.size(); ++i) {
+      prefixes.push_back(prefix); prefix += (size_t)h->episodes[i]->ndata();
+      for (int j = 0; j < h->episodes[i]->ndata(); ++j) errors.emplace_back(h->episodes[i]->DQ[j] * h->episodes[i]->DQ[j], (unsigned)i, (unsigned)j);
+    }
+    const auto before = [](const Tup& a, const Tup& b) { return std::get<0>(a) > std::get<0>(b); };
+    if (h->cfg.episode_order == HL_ORDER_REFERENCE) std::sort(errors.begin(), errors.end(), before);      // the reference's non-stable sort
+    else std::stable_sort(errors.begin(), errors.end(), before);                                         // product: equal errors in storage order
+    probs.assign(errors.size(), 1.f);
+    for (unsigned i = 0; i < errors.size(); ++i) {
+      const float P = std::get<0>(errors[i]) > 0 ? 1 / std::sqrt(std::sqrt(i + 1)) : 1;                   // (integer argument: double square roots, :141)
+      probs[prefixes[std::get<1>(errors[i])] + std::get<2>(errors[i])] = P;
+    }
+  }
+  dist.init(probs);
+}
+// TSample_impRank / TSample_impErr::sample (:151-170, 207-230) and Sample_impSeq::sample, transitions (:270-294)
+void samplePER(ol_learner* h, std::vector<int64_t>& flat) {
+  DiscreteDist dist; perPrepare(h, dist);
+  const int B = h->B; flat.resize(B);
+  size_t it = 0;
+  if (h->cfg.dataSamplingAlgo == HL_SAMPLE_PERSEQ) {
+    std::vector<int64_t> prefix; int64_t acc = 0;
+    for (const auto& ep : h->episodes) { prefix.push_back(acc); acc += ep->ndata(); }
+    while (it != (size_t)B) {
+      for (size_t i = it; i < (size_t)B; ++i) {
+        const size_t s = dist.draw(h->gen);
+        const size_t t = (size_t)(uniformFloat(h->gen, 0.f, 1.f) * (float)(size_t)h->episodes[s]->ndata());
+        flat[i] = prefix[s] + (int64_t)t;        // (sorting / uniquing (episode, step) pairs == sorting / uniquing these)
+      }
+      std::sort(flat.begin(), flat.end());
+      it = std::unique(flat.begin(), flat.end()) - flat.begin();
+    }
+    return;
+  }
+  while (it != (size_t)B) {
+    for (size_t i = it; i < (size_t)B; ++i) flat[i] = (int64_t)dist.draw(h->gen);
+    std::sort(flat.begin(), flat.end());
+    it = std::unique(flat.begin(), flat.end()) - flat.begin();
+  }
+}
 void idToSeqStep(ol_learner* h, const std::vector<int64_t>& flat, std::vector<int64_t>& seq,
                  std::vector<int64_t>& obs) {
   const size_t B = flat.size(); seq.assign(B, 0); obs.assign(B, 0);
@@ -1015,6 +1092,7 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;
   if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
+  if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
@@ -1186,7 +1264,9 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
   if (h->minObsLocal < h->cfg.batchSize && false) return HL_ERR_TOO_FEW_DATA;
   if (h->nTransitions < h->B) return fail(h, HL_ERR_TOO_FEW_DATA, "Parameter minTotObsNum is too low for given problem");
   const int B = h->B, dS = h->dS * (1 + h->cfg.nAppendedObs), dA = h->dA, nOut = h->nOut;      // dS: network input size
-  if (flat_in) h->bFlat.assign(flat_in, flat_in + B); else sampleUniform(h, h->bFlat);
+  if (flat_in) h->bFlat.assign(flat_in, flat_in + B);
+  else if (h->cfg.dataSamplingAlgo == HL_SAMPLE_UNIFORM) sampleUniform(h, h->bFlat);
+  else samplePER(h, h->bFlat);
   idToSeqStep(h, h->bFlat, h->bEp, h->bT);
   h->bTag.resize(B);
   if (h->tap) { h->tState.assign((size_t)B * dS, 0); h->tO.assign((size_t)B * nOut, 0); h->tG.assign((size_t)B * nOut, 0);

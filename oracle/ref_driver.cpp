@@ -194,6 +194,7 @@ struct Harness {
     HP->explNoise = A.d("explNoise", 0.4472135955);
     HP->outWeightsPrefac = A.d("outWeightsPrefac", 0.1);
     HP->nnLambda = A.d("nnLambda", 0);
+    HP->dataSamplingAlgo = A.s("sampling", "uniform");   // uniform | PERrank | PERerr | PERseq (Sampling.cpp:298-340)
     HP->ERoldSeqFilter = A.s("erFilter", "oldest");      // oldest | farpolfrac | maxkldiv | minerror (MemoryProcessing.cpp:261-298)
     HP->obsPerStep = 0;  // never block gradient steps on data
     HP->saveFreq = 1000000000;
@@ -340,6 +341,8 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       W.i64("preproc", pre);
       const std::string f = H.HP->ERoldSeqFilter;
       W.i64("erFilter", std::vector<int64_t>{f == "farpolfrac" ? 1 : (f == "maxkldiv" ? 2 : (f == "minerror" ? 3 : 0))});
+      const std::string sa = H.HP->dataSamplingAlgo;
+      W.i64("sampling", std::vector<int64_t>{sa == "PERrank" ? 1 : (sa == "PERerr" ? 2 : (sa == "PERseq" ? 3 : 0))});
     }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

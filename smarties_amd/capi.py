@@ -52,7 +52,7 @@ class HlConfig(C.Structure):
         ("randSeed", C.c_uint64), ("n_ranks", C.c_int32), ("rank", C.c_int32),
         ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
         ("n_options", C.c_int32), ("nn_type", C.c_int32), ("nnBPTTseq", C.c_int32),
-        ("nAppendedObs", C.c_int32), ("n_conv", C.c_int32), ("conv", HlConv2d * HL_MAX_CONV), ("ERoldSeqFilter", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("nAppendedObs", C.c_int32), ("n_conv", C.c_int32), ("conv", HlConv2d * HL_MAX_CONV), ("ERoldSeqFilter", C.c_int32), ("dataSamplingAlgo", C.c_int32),
     ]
 
 
@@ -76,7 +76,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
                 penalTol=0.1, epsAnneal=0.0, learnrate=1e-4, nnLambda=0.0, explNoise=0.4472135955,
                 outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
                 episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0, nn_type=0, nnBPTTseq=0,
-                nAppendedObs=0, conv=(), ERoldSeqFilter="oldest"):
+                nAppendedObs=0, conv=(), ERoldSeqFilter="oldest", dataSamplingAlgo="uniform"):
     """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
     c = HlConfig()
     c.struct_size = C.sizeof(HlConfig)
@@ -94,6 +94,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
     # conv: (input_width, input_height, input_features, kernels_num, filters_size, stride) as passed to
     # Communicator::setPreprocessingConv2d (Communicator.cpp:136-162)
     c.ERoldSeqFilter = {"oldest": 0, "default": 0, "farpolfrac": 1, "maxkldiv": 2, "minerror": 3}[ERoldSeqFilter] if isinstance(ERoldSeqFilter, str) else int(ERoldSeqFilter)
+    c.dataSamplingAlgo = {"uniform": 0, "PERrank": 1, "PERerr": 2, "PERseq": 3}[dataSamplingAlgo] if isinstance(dataSamplingAlgo, str) else int(dataSamplingAlgo)
     c.nAppendedObs, c.n_conv = nAppendedObs, len(conv)
     for i, (iw, ih, ic, kn, fs, st) in enumerate(conv):
         d = c.conv[i]

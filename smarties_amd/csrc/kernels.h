@@ -29,6 +29,8 @@ struct SampleArgs {
   int adamDraws;          // mt19937 draws consumed by the Adam step (Optimizer.cpp:139)
   int parity;             // minibatch buffer written (bt / X0 passed here belong to it)
   int computeEta;         // also derive DevScalars::etaEff[parity] (first step of a launch sequence)
+  int perAlgo;            // HL_SAMPLE_*: the prioritised samplers draw through the cumulative table `perCp` (per.hip)
+  const double* perCp; long long perN;   // cumulative probabilities of the perN transitions (PERrank, PERerr) or episodes (PERseq); perN < 2: always 0
   int noGather;           // phase C stops after the index -> (episode, step) search: the states are gathered by
                           // stack_gather_kernel (appended observations / convolutional input, conv.hip)
   int backupRng;          // keep the generator state as of before the draws in DevScalars::rngBak (pre-sampling riders)
@@ -197,6 +199,15 @@ hipError_t launch_set_counts(DevScalars* sc, long long nTransitions, long long n
                              long long seenEps, long long seenSteps, hipStream_t s);
 hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s);
 hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out /*16 doubles*/, hipStream_t s);
+// prioritised samplers (per.hip): probabilities, ranking and the sequential normalisation / cumulative table
+struct PerArgs {
+  DevReplay rp; int nEpisodes, algo;
+  float* prob; double* cp;                                   // [capSlots] (PERseq: [episodes])
+  float *key, *keySorted; unsigned *idx, *idxSorted;         // PERrank: squared errors and flat indices, sorted descending (stable)
+  void* temp; size_t tempBytes;
+};
+hipError_t launch_per_prepare(const PerArgs& a, long long nTransitions, hipStream_t s);
+size_t per_sort_temp_bytes(long long n);
 struct HistArgs { DevReplay rp; int nEpisodes; float bounds[82]; unsigned long long* counts; };
 hipError_t launch_impw_hist(const HistArgs& a, hipStream_t s);
 int sweep_blocks(int count);

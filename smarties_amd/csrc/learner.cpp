@@ -100,6 +100,9 @@ struct hl_learner {
   // MemoryBuffer.cpp:486-487): the value of the last gradient step's statistics pass, taken BEFORE that step's removals;
   // 0 before the first step.  Computed on the device when needed (dStatsIns), at most once per step.
   double* dStatsIns = nullptr; bool statsFresh = false, anyStep = false;
+  // prioritised samplers (per.hip): probabilities / cumulative table of the stored transitions, rebuilt before every minibatch
+  float *perProb = nullptr, *perKey = nullptr, *perKeyS = nullptr; double* perCp = nullptr; unsigned *perIdx = nullptr, *perIdxS = nullptr;
+  void* perTemp = nullptr; size_t perTempBytes = 0; long long perCap = 0;
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
@@ -520,6 +523,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   }
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
+  if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
   if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
     const hl_conv2d& d = cfg->conv[j];
@@ -696,6 +700,7 @@ int hl_destroy(hl_learner* h) {
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);
   for (auto& st : h->stg) { if (st.host) hipHostFree(st.host); if (st.ev) hipEventDestroy(st.ev); }
+  for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp}) if (q) hipFree(q);
   if (h->stream) hipStreamDestroy(h->stream);
   h->mu.unlock();
   delete h; return HL_OK;
@@ -993,6 +998,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     const long long k = h->nGradSteps + 1;
     const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
     const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
+                       h->cfg.dataSamplingAlgo == HL_SAMPLE_UNIFORM &&      // (the prioritised samplers rebuild their table before every minibatch)
                        (!exchanging(h) || (h->fusedOk && h->exchGraph && h->comm));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
@@ -1714,6 +1720,18 @@ extern "C" HL_API int hl_kernel_profile(hl_learner* h, int which, int reps, doub
 // RCCL calls issued or captured so far (tests: eager and replayed steps speak the same wire protocol)
 extern "C" HL_API int64_t hl_debug_collectives(const hl_learner* h) { return h ? h->nCollectives : -1; }
 
+// the prioritised samplers' tables as the last step built them (tests: sequential normalisation / partial_sum)
+extern "C" HL_API int64_t hl_debug_per_table(hl_learner* h, float* prob, double* cp, int64_t cap) {
+  if (!h) return -1;
+  HL_LOCK(h);
+  if (!h->perProb) return 0;
+  const int64_t n = h->cfg.dataSamplingAlgo == HL_SAMPLE_PERSEQ ? (int64_t)h->order.size() : (int64_t)h->nTransitions;
+  if (n > cap) return -n;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+  if (prob && hipMemcpy(prob, h->perProb, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (cp && hipMemcpy(cp, h->perCp, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
 extern "C" HL_API int hl_debug_stamps(hl_learner* h, long long out[32]) {
   if (!h || !out) return HL_ERR_BAD_ARG;
   HL_LOCK(h);

@@ -207,8 +207,35 @@ HeadArgs headArgs(hl_learner* h, int parity) {
   return ha;
 }
 
+// prioritised samplers: Sampling::prepare() of the reference runs at the end of every step (updateSampler,
+// MemoryProcessing.cpp:350) on the errors that step left behind -- here right before the draw, on the same data
+int launchPerPrepare(hl_learner* h, hipStream_t s) {
+  const long long n = std::max<long long>(h->nTransitions, (long long)h->order.size());
+  if (n > h->perCap) {
+    HIPCK(hipStreamSynchronize(s));
+    for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp}) if (q) hipFree(q);
+    const size_t cap = (size_t)n + (size_t)n / 4 + 1024;
+    HIPCK(devAlloc(&h->perProb, cap)); HIPCK(devAlloc(&h->perCp, cap));
+    if (h->cfg.dataSamplingAlgo == HL_SAMPLE_PERRANK) {
+      HIPCK(devAlloc(&h->perKey, cap)); HIPCK(devAlloc(&h->perKeyS, cap)); HIPCK(devAlloc(&h->perIdx, cap)); HIPCK(devAlloc(&h->perIdxS, cap));
+      h->perTempBytes = per_sort_temp_bytes((long long)cap);
+      unsigned char* t = nullptr; HIPCK(devAlloc(&t, h->perTempBytes)); h->perTemp = t;
+    }
+    h->perCap = (long long)cap;
+  }
+  PerArgs pa{}; pa.rp = h->rp; pa.nEpisodes = (int)h->order.size(); pa.algo = h->cfg.dataSamplingAlgo;
+  pa.prob = h->perProb; pa.cp = h->perCp; pa.key = h->perKey; pa.keySorted = h->perKeyS; pa.idx = h->perIdx; pa.idxSorted = h->perIdxS;
+  pa.temp = h->perTemp; pa.tempBytes = h->perTempBytes;
+  HIPCK(timed(h, "per_prepare", s, [&] { return launch_per_prepare(pa, h->nTransitions, s); }));
+  return HL_OK;
+}
 int launchSample(hl_learner* h, int parity, const long long* dFlat, bool computeEta, hipStream_t s) {
-  const SampleArgs sa = sampleArgs(h, parity, dFlat, computeEta);
+  SampleArgs sa = sampleArgs(h, parity, dFlat, computeEta);
+  if (h->cfg.dataSamplingAlgo != HL_SAMPLE_UNIFORM && !dFlat) {
+    int rc = launchPerPrepare(h, s); if (rc) return rc;
+    sa.perAlgo = h->cfg.dataSamplingAlgo; sa.perCp = h->perCp;
+    sa.perN = h->cfg.dataSamplingAlgo == HL_SAMPLE_PERSEQ ? (long long)h->order.size() : h->nTransitions;
+  }
   HIPCK(timed(h, "step_tail_kernel", s, [&] { return launch_sample(sa, s); }));
   return HL_OK;
 }

@@ -333,6 +333,36 @@ __device__ void drawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* raw
   }
   __syncthreads();
 }
+// TSample_impRank / TSample_impErr / Sample_impSeq::sample (Sampling.cpp:151-170, 207-230, 270-294): values for vals[from..B)
+// through std::discrete_distribution -- generate_canonical<double, 53> from two generator words, lower_bound over the
+// cumulative table -- and, for PERseq, a step drawn with uniform_real_distribution<float> (one more word) times the episode's
+// length.  No rejection: every value consumes its two (three) words in order.
+__device__ void drawPER(const SampleArgs& a, unsigned* x, unsigned* xo, int* sPos, unsigned* raw, unsigned* vals, int from, int B) {
+  const int tid = threadIdx.x, Wn = a.perAlgo == HL_SAMPLE_PERSEQ ? 3 : 2;
+  for (int c0 = from; c0 < B; c0 += 256) {
+    const int n = min(256, B - c0);
+    mtDraw(x, xo, sPos, raw, n * Wn);
+    if (tid < n) {
+      const unsigned w0 = raw[Wn * tid], w1 = raw[Wn * tid + 1];
+      double p = ((double)w0 + (double)w1 * 4294967296.0) / 18446744073709551616.0;
+      if (p >= 1.0) p = 0.99999999999999988898;                  // nextafter(1, 0)
+      long long lo = 0;
+      if (a.perN >= 2) {                                          // std::lower_bound: first entry not less than p
+        long long len = a.perN;
+        while (len > 0) { const long long half = len >> 1; if (a.perCp[lo + half] < p) { lo += half + 1; len -= half + 1; } else len = half; }
+      }
+      unsigned v = (unsigned)lo;
+      if (a.perAlgo == HL_SAMPLE_PERSEQ) {
+        float u = (float)raw[Wn * tid + 2] / 4294967296.0f;
+        if (u >= 1.0f) u = 0.99999994f;                           // nextafterf(1, 0)
+        const PosRec rec = a.rp.posRec[lo];
+        v = (unsigned)(rec.prefix + (long long)(unsigned long long)(u * (float)(unsigned long long)(rec.N - 1)));
+      }
+      vals[c0 + tid] = v;
+    }
+    __syncthreads();
+  }
+}
 // sort vals[0..B) and remove duplicates (std::sort + std::unique); returns the unique count
 __device__ int sortUnique(unsigned* vals, int* sWave, int B, int Bp, int K) {
   const int tid = threadIdx.x;
@@ -386,6 +416,7 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
 
   if (phases & PH_A) {
     if (a.flatGiven) { for (int i = tid; i < B; i += 256) vals[i] = (unsigned)a.flatGiven[i]; __syncthreads(); }
+    else if (a.perAlgo) drawPER(a, x, xo, sPos, raw, vals, 0, B);
     else drawAccepted(x, xo, sPos, raw, vals, sWave, 0, B, K, range, threshold);
   }
   TSTAMP(sc, 2);
@@ -394,7 +425,8 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
       int have = sortUnique(vals, sWave, B, Bp, K);
       TSTAMP(sc, 3);
       while (have < B) {                       // duplicates: redraw the tail (Sampling.cpp:86-93)
-        drawAccepted(x, xo, sPos, raw, vals, sWave, have, B, K, range, threshold);
+        if (a.perAlgo) drawPER(a, x, xo, sPos, raw, vals, have, B);
+        else drawAccepted(x, xo, sPos, raw, vals, sWave, have, B, K, range, threshold);
         have = sortUnique(vals, sWave, B, Bp, K);
       }
     }

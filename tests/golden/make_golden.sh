@@ -62,6 +62,12 @@ for F in farpolfrac maxkldiv minerror; do
   "$DRV" fixture "$HERE/evict_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=40 lenMin=5 lenMax=40 pTerm=0.5 \
      nSteps=30 gradSteps=1,30 maxObs=500 minObs=200 erFilter=$F
 done
+# G-sample-*: the prioritised samplers (dataSamplingAlgo PERrank / PERerr / PERseq; ReplayMemory/Sampling.cpp:101-296): the
+# std::discrete_distribution over all stored transitions (episodes) is rebuilt before every one of the 30 tapped minibatches
+for F in PERrank PERerr PERseq; do
+  "$DRV" fixture "$HERE/sample_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+     nSteps=30 gradSteps=1,30 maxObs=2000 minObs=300 sampling=$F
+done
 # G-hist: the importance-weight histogram the reference prints (MemoryProcessing::histogramImportanceWeights), captured from stdout
 "$DRV" fixture "$HERE/hist_small.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
    nSteps=40 tapSteps=2 gradSteps=40 maxObs=2000 minObs=300 muSpread=0.8 hist=1

@@ -31,6 +31,8 @@ def fixture_config(fx, **over):
         pre = [int(x) for x in fx["preproc"]]
         kw["nAppendedObs"] = pre[0]
         kw["conv"] = [tuple(pre[1 + 6 * i:7 + 6 * i]) for i in range((len(pre) - 1) // 6)]
+    if "sampling" in fx:
+        kw["dataSamplingAlgo"] = int(fx["sampling"][0])
     if "erFilter" in fx:
         kw["ERoldSeqFilter"] = int(fx["erFilter"][0])
     kw.update(over)

@@ -3,6 +3,7 @@
   (2) the CPU oracle on the same seeded inputs (bit-exact sample indices and ReF-ER masks,
       fp32 quantities to 1e-5 of the infinity norm, fp64 head quantities to 1e-9),
 plus size-independent properties at the BASELINE.json replay size (1M transitions)."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -85,6 +86,82 @@ def test_steps_follow_reference_fixture(hip_api, name):
         assert sca.CmaxRet == fx["traj_cmax"][k - 1]
         # the reference's count depends on its float-add/truncate summation order
         assert abs(sca.nFarPolicySteps - fx["traj_nfar"][k - 1]) <= 2
+
+
+PER_FIXTURES = ["sample_%s.bin" % f for f in ("PERrank", "PERerr", "PERseq")]      # dataSamplingAlgo (Sampling.cpp:101-296)
+
+
+@pytest.mark.parametrize("algo", ["PERrank", "PERerr", "PERseq"])
+def test_prioritised_sampler_tables(hip_api, algo):
+    """The discrete distribution behind dataSamplingAlgo PERrank / PERerr / PERseq on ~60 000 stored transitions (the
+    one-wavefront chain crosses many 1024-value blocks): probabilities as Sampling.cpp:137-146 / 192-196 / 247-249 define them
+    from the errors in the replay, and the cumulative table bit for bit what libstdc++'s discrete_distribution builds --
+    sequential double sum, division, sequential partial_sum, last entry 1.
+    (The reference's own minibatches, tests/golden/sample_PER*.bin, are reproduced by the oracle in its reference-order mode --
+    test_oracle_golden.py; they cannot be fed to the library: the drawn flat indices mean (episode, step) pairs through the
+    STORAGE order, where the reference's is an artefact of its non-stable per-step std::sort (as is its ranking of equal errors
+    for PERrank) and the library's is newest-first / stable.  Next test: library == oracle in that mode, bit for bit.)"""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=256, maxTotObsNum=100000, randSeed=4, dataSamplingAlgo=algo)
+    sc = synth_cfg(seed=13, dimS=5, dimA=2, lenMin=150, lenMax=250, pTerm=0.4)
+    G = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    G.init_weights(); fill_synth(G, sc, 300); G.initialize()
+    f = hip_api.lib.hl_debug_per_table; f.restype = C.c_int64; f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    G.step(40)                                                     # errors of ~10 000 transitions are now their own
+    nEp = G.scalars().nStoredEps
+    dq = [G.episode_field(p, capi.EP_DELTAQ) for p in range(nEp)]      # (N values per episode, the last one unused)
+    G.step(1)                                                      # the table this step drew from was built on `dq`
+    n = int(G.scalars().nStoredSteps) if algo != "PERseq" else nEp
+    prob, cp = np.zeros(n, np.float32), np.zeros(n, np.float64)
+    assert f(G.h, prob.ctypes.data, cp.ctypes.data, n) == n
+    eps = np.float32(np.finfo(np.float32).eps)
+    if algo == "PERseq":
+        want = None                                                # (from the running per-episode average: next test)
+    else:
+        d2 = np.concatenate([d[:-1] * d[:-1] for d in dq]).astype(np.float32)
+        if algo == "PERerr":
+            want = np.sqrt(np.sqrt(d2 + eps))
+        else:
+            order = np.argsort(-d2.astype(np.float64), kind="stable")       # decreasing error, equal errors in storage order
+            want = np.ones(n, np.float32)
+            want[order] = np.where(d2[order] > 0, (1 / np.sqrt(np.sqrt(np.arange(1, n + 1, dtype=np.float64)))).astype(np.float32), np.float32(1))
+    if want is not None:
+        assert np.array_equal(prob, want.astype(np.float32))
+    assert (prob > 0).all()
+    total = np.cumsum(prob.astype(np.float64))[-1]                 # (np.cumsum adds in sequence, as std::accumulate does)
+    ref = np.cumsum(prob.astype(np.float64) / total); ref[-1] = 1.0
+    assert np.array_equal(cp, ref)
+
+
+@pytest.mark.parametrize("algo,extra", [("PERrank", {}), ("PERerr", {}), ("PERseq", {}),
+                                        ("PERerr", dict(nn_type=capi.NN_LSTM, nnFunc="Tanh", nnBPTTseq=6)),                  # recurrent path
+                                        ("PERseq", dict(adv_kind=capi.ADV_GAUSSIAN)), ("PERrank", dict(adv_kind=capi.ADV_DISCRETE, n_options=4, dimA=1, bounded=[0]))],   # RACER heads
+                         ids=lambda v: v if isinstance(v, str) else "-".join(v) or "vracer")
+def test_prioritised_samplers_follow_the_oracle_while_episodes_arrive(hip_api, algo, extra):
+    """The same samplers against the oracle on a replay that grows and evicts between steps (the table is rebuilt over the
+    current contents each time), batch 64 over ~1500 transitions: duplicates are redrawn as the reference does.  Calls of
+    several steps take the eager route (the distribution is rebuilt before every minibatch)."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=64, maxTotObsNum=1500, minTotObsNum=500, randSeed=4,
+                  dataSamplingAlgo=algo)
+    cfg_kw.update(extra)
+    sc = synth_cfg(seed=13, dimS=5, dimA=cfg_kw["dimA"], lenMin=10, lenMax=60, pTerm=0.4)
+    G, O = _pair(hip_api, cfg_kw, sc, 40)
+    e = 40
+    for k in range(25):
+        n = 1 if k % 3 else 3
+        G.step(n); O.step(n)
+        _compare_step(G, O)
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+        for L in (G, O):
+            L.append_episode(**synth_episode(sc, e, cfg_kw.get("n_options", 0)))
+        e += 1
+    assert relinf(G.get_params()[0], O.get_params()[0]) < TOL32
+
+
+def test_unknown_sampler_is_rejected(hip_api):
+    cfg = capi.make_config(dimS=5, dimA=2, hidden=(16,), batchSize=8)
+    cfg.dataSamplingAlgo = 7
+    with pytest.raises(RuntimeError):
+        capi.Learner(hip_api, cfg)
 
 
 def _pair(hip_api, cfg_kw, sc, n_eps):
