@@ -1018,6 +1018,193 @@ __global__ __launch_bounds__(128) void lstm32_backward_wave_kernel(RecArgs a) {
   }
 }
 
+// ---- MGU, two layers of 32 cells: the same arrangement ---------------------------------------------------------------------
+// A layer-step has 64 gate columns -- forget gates on lanes 0..31, candidate states on lanes 32..63 (MGULayer::forward,
+// Layer_GRU.h:64-124) -- and two dependent halves: the candidate's recurrent operand is prevOut * forget.  Lane o keeps column o
+// of [W_in; W_rec] in registers; the forget lanes publish prevOut * f through LDS, the candidate lanes then add their 32
+// recurrent terms.  Layer 0's wavefront runs one step ahead of layer 1's, as above.
+template <int IN>
+__device__ __forceinline__ float dotIn(const float (&w)[32], const float* vec) {
+  const f32x4* v4 = reinterpret_cast<const f32x4*>(vec);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int q = 0; q < IN / 4; ++q) { const f32x4 v = v4[q]; a0 += w[4 * q] * v[0]; a1 += w[4 * q + 1] * v[1]; a2 += w[4 * q + 2] * v[2]; a3 += w[4 * q + 3] * v[3]; }
+  return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ void waveLdsSync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
+
+template <int IN>      // IN: operand length of the input part as the unrolled loop walks it (zero weights behind the layer's own inputs)
+__device__ __forceinline__ void mgu32LayerStep(const RecLayer& L, const float (&win)[32], const float (&wrec)[32], float bias, const float* vec,
+                                               float* hf, int nInL, float wr, float br, float* hNext, float& blkOut, bool store, long long r, int lane) {
+  constexpr int NC = 32, NO = 64;
+  const float* hPrev = vec + IN;
+  const float accIn = bias + dotIn<IN>(win, vec);
+  const float po = lane < NC ? hPrev[lane] : 0.f;
+  const float f = fastSigm(accIn + dotIn<NC>(wrec, hPrev));            // (meaningful on the forget lanes)
+  if (lane < NC) hf[lane] = po * f;
+  waveLdsSync();
+  const float sc = fastTanh(accIn + dotIn<NC>(wrec, hf));              // (meaningful on the candidate lanes)
+  if (store) {
+    L.X[r * NO + lane] = lane < NC ? f : sc;
+    if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
+    if (lane < NC) L.A[r * L.ldA + nInL + lane] = po;
+  }
+  const float st = __shfl(sc, lane + 32, 64);
+  if (lane < NC) {
+    const float out = f * st + (1.f - f) * po;                           // (po is 0 at the first step of the window)
+    if (store) { L.Y[r * NO + lane] = out; L.A2[r * L.ldA2 + lane] = po * f; }
+    float blk = out;
+    if (L.hasRes && lane < L.resW) blk += vec[lane] * wr + br;
+    hNext[lane] = out;
+    blkOut = blk;
+  }
+}
+
+template <int IN0>
+__global__ __launch_bounds__(128) void mgu32_forward_wave_kernel(RecArgs a) {
+  constexpr int NC = 32, NO = 64;
+  __shared__ __attribute__((aligned(16))) float sV0[2][IN0 + NC];      // layer 0 operand [x_k | h0_{k-1}], double-buffered over the steps
+  __shared__ __attribute__((aligned(16))) float sV1[2][2 * NC];        // layer 1 operand [block-0 output of step k | h1_{k-1}]
+  __shared__ __attribute__((aligned(16))) float sHF[2][NC];            // prevOut * forget, per layer
+  __shared__ float sStates[18 * 32];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int layer = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
+  const int T = min(a.nBPTT, t);
+  const int nextRow = a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  const RecLayer L = a.L[layer];
+  const int nIn = a.L[0].nIn, dS = a.dS;
+  float win[32], wrec[32];
+  {
+    const float* Wl = W + L.indW;
+    const int nInL = layer == 0 ? nIn : NC;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      win[i] = i < nInL ? Wl[(size_t)i * NO + lane] : 0.f;
+      wrec[i] = Wl[(size_t)(nInL + i) * NO + lane];
+    }
+  }
+  const float bias = W[L.indB + lane];
+  const int c = lane & 31;
+  float wr = 0.f, br = 0.f;
+  if (L.hasRes && c < L.resW) { wr = W[L.indWr + c]; br = W[L.indBr + c]; }
+  for (int e = tid; e < nSteps * dS; e += 128) {
+    const int kk = e / dS, i = e - kk * dS;
+    sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
+  }
+  for (int i = tid; i < 2 * (IN0 + NC); i += 128) (&sV0[0][0])[i] = 0.f;
+  for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
+  vmDrain(); pairBarrier();
+  if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
+  pairBarrier();
+  for (int it = 0; it <= nSteps; ++it) {
+    if (layer == 0) {
+      const int k = it;
+      if (k < nSteps) {
+        const int cb = k & 1;
+        if (k + 1 < nSteps && lane < dS) sV0[cb ^ 1][lane] = sStates[(k + 1) * dS + lane];
+        float blk = 0.f;
+        mgu32LayerStep<IN0>(L, win, wrec, bias, sV0[cb], sHF[0], nIn, wr, br, &sV0[cb ^ 1][IN0], blk, k <= T, (long long)b * a.K + k, lane);
+        if (lane < NC) sV1[cb][lane] = blk;
+      }
+    } else {
+      const int k = it - 1;
+      if (k >= 0) {
+        const int cb = k & 1;
+        float blk = 0.f;
+        mgu32LayerStep<NC>(L, win, wrec, bias, sV1[cb], sHF[1], NC, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane);
+        if (lane < NC) {
+          if (k == T) a.Yout[(size_t)b * a.ldY + lane] = blk;
+          if (k == T + 1) a.Yout[(size_t)nextRow * a.ldY + lane] = blk;
+        }
+      }
+    }
+    pairBarrier();
+  }
+}
+
+// backward (MGULayer::backward, Layer_GRU.h:126-231): lane i holds ROW i of [W_in; W_rec] (32 forget + 32 candidate columns); the
+// top layer's lanes 0..31 are its input rows, 32..63 its recurrent rows; layer 0 needs its recurrent rows only (lanes 0..31)
+template <int IN0>
+__global__ __launch_bounds__(128) void mgu32_backward_wave_kernel(RecArgs a) {
+  constexpr int NC = 32, NO = 64, ACT = 3 * NC;            // per (step, layer): [forget | candidate | output]
+  __shared__ __attribute__((aligned(16))) float sDS[2][NC], sDF[2][NC];
+  __shared__ float sAct[2][17 * ACT];
+  __shared__ float sTop[2][NC];
+  __shared__ float sRec[2][NC];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = 1 - wv;                                    // wavefront 0 = the top layer (one step ahead), wavefront 1 = layer 0
+  const int t = a.bt.t[b];
+  const int T = min(a.nBPTT, t);
+  const float* W = a.W;
+  const RecLayer L = a.L[j];
+  const int nIn0 = a.L[0].nIn;
+  float wf[32], ws[32];                                    // this lane's row: forget columns, candidate columns
+  {
+    const f32x4* rw = reinterpret_cast<const f32x4*>(W + L.indW + (size_t)(j == 1 ? lane : nIn0 + (lane & 31)) * NO);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f32x4 u = rw[q], v = rw[8 + q]; wf[4 * q] = u[0]; wf[4 * q + 1] = u[1]; wf[4 * q + 2] = u[2]; wf[4 * q + 3] = u[3];
+                                  ws[4 * q] = v[0]; ws[4 * q + 1] = v[1]; ws[4 * q + 2] = v[2]; ws[4 * q + 3] = v[3]; }
+  }
+  {
+    const int total = (T + 1) * ACT;
+    for (int e = lane; e < total; e += 64) {
+      const int k = e / ACT, x = e - k * ACT;
+      const long long r = (long long)b * a.K + k;
+      sAct[j][e] = x < NO ? L.X[r * NO + x] : L.Y[r * NO + (x - NO)];
+    }
+  }
+  const float wr = (L.hasRes && lane < L.resW) ? W[L.indWr + lane] : 0.f;
+  const float dres = (j == 1 && lane < NC) ? a.Dres[(size_t)b * a.ldD + lane] : 0.f;
+  for (int k = T + 1; k < a.K; ++k) {
+    const long long r = (long long)b * a.K + k;
+    L.D[r * NO + lane] = 0.f;
+    if (L.hasRes && lane < NC) L.Rd[r * L.ldR + lane] = 0.f;
+  }
+  vmDrain(); pairBarrier();
+  for (int it = 0; it <= T + 1; ++it) {
+    const int k = T - it + (j == 1 ? 0 : 1);
+    if (k >= 0 && k <= T) {
+      const long long r = (long long)b * a.K + k;
+      float res = 0.f, dLdO = 0.f, f = 0.f, sc = 0.f, po = 0.f, dS_ = 0.f;
+      if (lane < NC) {
+        const float eTop = j == 1 ? (k == T ? dres : 0.f) : sTop[k & 1][lane];
+        const float* act = sAct[j] + k * ACT;
+        if (L.hasRes) { L.Rd[r * L.ldR + lane] = eTop; res = lane < L.resW ? eTop * wr : 0.f; }
+        dLdO = eTop + (k < T ? sRec[j][lane] : 0.f);
+        f = act[lane]; sc = act[NC + lane]; po = k > 0 ? (act - ACT)[2 * NC + lane] : 0.f;
+        dS_ = dLdO * f * (1.f - sc * sc);                                         // 1) dLdS
+        sDS[j][lane] = dS_;
+      }
+      waveLdsSync();
+      const float viaS = dotIn<NC>(ws, sDS[j]);                                    // row i: sum_o W[i][nC + o] dLdS[o]
+      // 2) dLdFprevOut of cell c = the recurrent row nIn + c
+      float fp = j == 1 ? __shfl(viaS, lane + 32, 64) : viaS;
+      if (k == 0) fp = 0.f;
+      if (lane < NC) {
+        const float dF = ((sc - po) * dLdO + fp * po) * f * (1.f - f);             // 3) dLdF
+        sDF[j][lane] = dF;
+        L.D[r * NO + lane] = dF; L.D[r * NO + NC + lane] = dS_;
+      }
+      waveLdsSync();
+      const float viaF = dotIn<NC>(wf, sDF[j]);                                    // row i: sum_o W[i][o] dLdF[o]
+      const float g = j == 1 ? __shfl(viaF, lane + 32, 64) : viaF;
+      if (lane < NC) {
+        if (j == 1) sTop[k & 1][lane] = (res + viaF) + viaS;                       // error of block 0's output (+ the residual path)
+        if (k > 0) sRec[j][lane] = ((1.f - f) * dLdO + f * fp) + g;                // 4) dLdprevOut
+      }
+    }
+    pairBarrier();
+  }
+}
+
+static bool mgu32Wave(const RecArgs& a) {
+  return a.gates == 2 && a.actStates == nullptr && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
+         a.L[0].nIn <= 32 && a.dS == a.L[0].nIn && a.K <= 17 && a.L[0].indW % 4 == 0 && a.L[1].indW % 4 == 0 && !a.L[0].hasRes;
+}
 // the wave-per-sample kernels serve the training pass of two LSTM layers of 32 cells each over up to 32 inputs and 17 steps
 static bool lstm32Wave(const RecArgs& a) {
   return a.gates == 4 && a.actStates == nullptr && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
@@ -1036,6 +1223,14 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
+  if (mgu32Wave(a)) {        // two layers of 32 cells, training pass: one wavefront per (sample, layer), weights in registers
+    const int in0 = (a.L[0].nIn + 3) & ~3;
+    if (in0 <= 4) hipLaunchKernelGGL(mgu32_forward_wave_kernel<4>, dim3(a.B), dim3(128), 0, s, a);
+    else if (in0 <= 8) hipLaunchKernelGGL(mgu32_forward_wave_kernel<8>, dim3(a.B), dim3(128), 0, s, a);
+    else if (in0 <= 16) hipLaunchKernelGGL(mgu32_forward_wave_kernel<16>, dim3(a.B), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(mgu32_forward_wave_kernel<32>, dim3(a.B), dim3(128), 0, s, a);
+    return hipGetLastError();
+  }
   if (a.gates == 2) {
     static size_t attrM[4] = {0, 0, 0, 0};
     if (fit && a.nL == 1) return recLaunch(mgu_forward_kernel<true, 1>, a, lds, &attrM[1], s);
@@ -1069,6 +1264,7 @@ hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
   if (a.gates == 2) {
     static size_t attrM[4] = {0, 0, 0, 0};
+    if (mgu32Wave(a)) { hipLaunchKernelGGL(mgu32_backward_wave_kernel<32>, dim3(a.B), dim3(128), 0, s, a); return hipGetLastError(); }
     if (fit && a.nL == 1) return recLaunch(mgu_backward_kernel<true, 1>, a, lds, &attrM[1], s);
     if (fit && a.nL == 2) return recLaunch(mgu_backward_kernel<true, 2>, a, lds, &attrM[2], s);
     return fit ? recLaunch(mgu_backward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false, 0>, a, 0, &attr[1], s);

@@ -804,6 +804,9 @@ REC_SHAPES = [  # (layer type, hidden, dimS, bptt, batch): every instantiation /
     ("lstm", (32, 32), 4, 16, 64),          # 64 x 17 = 1088 rows: the weight gradients are split over the rows (splitk_reduce_kernel)
     ("mgu", (24, 16), 6, 15, 70),           # the same for the three weight-gradient problems of an MGU layer
     ("mgu", (24, 16, 8, 8), 7, 6, 12),
+    ("mgu", (32, 32), 4, 16, 33),           # two layers of 32 cells: one wavefront per (sample, layer), as for the LSTM
+    ("mgu", (32, 32), 13, 16, 64),          # ... inputs padded to 16, split weight gradients
+    ("mgu", (32, 32), 32, 5, 20),
     ("mgu", (13,), 3, 5, 9),
     ("mgu", (64, 64), 200, 3, 6),
 ]
