@@ -320,15 +320,15 @@ def main():
         dom = max(table, key=lambda n: table[n]["launch_us"])
         d = table[dom]
         # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process;
-        # the committed rocprofv3 --pmc passes (profiles/r01_pmc.json: commands, corrections) are quoted
+        # the committed rocprofv3 --pmc passes (profiles/r02_pmc.json: commands, corrections) are quoted
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
                 traffic = json.load(f)["kernels"][dom.split("<")[0]]["traffic_bytes"]
         except Exception:  # noqa: BLE001
             traffic = None
         roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r01_pmc.json)",
+                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r02_pmc.json)",
                 "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
                 "step_kernels": table,
                 "note": "latency-bound step: dependent launches of a few hundred workgroups; launch_us = HIP-event time "
