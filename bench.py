@@ -242,7 +242,9 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=n_ranks, init_method="tcp://127.0.0.1:%d" % (
                 int(os.environ.get("MASTER_PORT", "29500")) + 17))
         else:
-            dist.init_process_group(backend="gloo" if host_exchange else "nccl", rank=rank, world_size=n_ranks)
+            # (SMARTIES_BENCH_PG=gloo: handles and flags travel over gloo -- two ranks on ONE device, as on the 1-GPU test box)
+            dist.init_process_group(backend="gloo" if (host_exchange or os.environ.get("SMARTIES_BENCH_PG") == "gloo") else "nccl",
+                                    rank=rank, world_size=n_ranks)
 
     from smarties_amd import capi, load_hip
 
@@ -259,27 +261,61 @@ def main():
         return L_, time.time() - t_
 
     L, t_fill = make_learner()
+    transport = "single replica"
     if n_ranks > 1 and not host_exchange:
-        ok = 1
-        try:
-            idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                import ctypes as C
-                raw = (C.c_uint8 * 128)()
-                assert api.fn("comm_unique_id")(raw) == 0
-                idbuf = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
-            dist.broadcast(idbuf, 0)
-            L.comm_init(bytes(idbuf.cpu().tolist()))
-        except Exception as e:  # noqa: BLE001
-            ok = 0
-            print("rank %d: RCCL communicator of the library failed (%s): host exchange instead" % (rank, e), file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            host_exchange = True
-            host_group = dist.new_group(backend="gloo")
-            L.close()
-            L, t_fill = make_learner()
+        # 1st choice: the library's own one-kernel exchange through peer-mapped windows (xchg.hip; handles travel through the
+        # process group); 2nd: its RCCL communicator; 3rd: sums on the host (gloo).  Every decision is taken by ALL ranks.
+        pg_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=pg_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        want = os.environ.get("SMARTIES_BENCH_EXCHANGE", "")
+        done = False
+        if want in ("", "xchg"):
+            hd = None
+            try:
+                hd = L.xchg_export()
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: hl_xchg_export failed (%s)" % (rank, e), file=sys.stderr)
+            hs = [None] * n_ranks
+            dist.all_gather_object(hs, hd)
+            ok = all(h is not None for h in hs)
+            if ok:
+                try:
+                    L.xchg_connect(hs)
+                except Exception as e:  # noqa: BLE001
+                    ok = False
+                    print("rank %d: hl_xchg_connect failed (%s)" % (rank, e), file=sys.stderr)
+            done = all_ok(ok)
+            if done:
+                transport = "one-kernel exchange through peer-mapped windows over xGMI (xchg.hip), a node of the replayed graphs"
+            elif ok:                       # (connected here, not everywhere: start over with a clean learner)
+                L.close()
+                L, t_fill = make_learner()
+        if not done:
+            ok = True
+            try:
+                idbuf = torch.zeros(128, dtype=torch.uint8, device=pg_dev)
+                if rank == 0:
+                    import ctypes as C
+                    raw = (C.c_uint8 * 128)()
+                    assert api.fn("comm_unique_id")(raw) == 0
+                    idbuf = torch.tensor(list(raw), dtype=torch.uint8, device=pg_dev)
+                dist.broadcast(idbuf, 0)
+                L.comm_init(bytes(idbuf.cpu().tolist()))
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                print("rank %d: RCCL communicator of the library failed (%s): host exchange instead" % (rank, e), file=sys.stderr)
+            if all_ok(ok):
+                transport = "RCCL inside the library (captured in the replayed graphs)"
+            else:
+                host_exchange = True
+                host_group = dist.new_group(backend="gloo")
+                L.close()
+                L, t_fill = make_learner()
     if n_ranks > 1 and host_exchange:
         from smarties_amd import dist_host
         dist_host.init_replica_weights(L, dist, group=host_group)
@@ -382,8 +418,7 @@ def main():
                                    "global batch 256 split over %d replica(s), replay split likewise, "
                                    "device-side mt19937 sampler" % n_ranks,
                        "global_batch": B_global, "replay_transitions": 1000000, "parallelism": "dp%d" % n_ranks,
-                       "exchange": "single replica" if n_ranks == 1 else ("host (gloo, split-step entry points)" if host_exchange
-                                                                          else "RCCL inside the library (captured in the replayed graphs)")},
+                       "exchange": "host (gloo, split-step entry points)" if (n_ranks > 1 and host_exchange) else transport},
             "roofline": roof,
             "fill_seconds": t_fill,
         }

@@ -355,7 +355,20 @@ HL_API int hl_set_log_base(hl_learner* h, const char* base);
 /* ---- multi-GPU (RCCL over xGMI) -------------------------------------------------- */
 HL_API int hl_comm_unique_id(uint8_t id[128]);             /* rank 0 creates, caller broadcasts */
 HL_API int hl_comm_init(hl_learner* h, const uint8_t id[128]);
-/* n_ranks > 1 WITHOUT hl_comm_init = host-exchange mode: the caller owns the communicator and
+/* The same sums without RCCL (2..16 replicas of one node): every replica owns a window in its HBM into which each peer writes
+ * its message directly over xGMI; ONE kernel per collective stores the local message into all peers' windows, waits for theirs
+ * and sums in rank order (bit-identical replicas) -- replacing the reference's MPI_Iallreduce of the gradient
+ * (Network/Optimizer.cpp:110-132) and of the counters / moments (Utils/DelayedReductor.cpp:53-83).  hl_xchg_export creates the
+ * window and returns its handle; the caller gathers all replicas' handles IN RANK ORDER with its own communicator (the
+ * reference's learners have MPI: one MPI_Allgather of HL_XCHG_HANDLE_BYTES bytes) and hands them to hl_xchg_connect, which maps
+ * the peers' windows (hipIpc between processes, plain pointers between learners of one process), copies rank 0's weights to
+ * every replica like hl_comm_init and makes hl_initialize / hl_step use this exchange (it takes precedence over a
+ * communicator of hl_comm_init).  A peer that does not answer within SMARTIES_HIP_XCHG_TIMEOUT_MS (default 5000) raises the
+ * learner's device error instead of hanging the GPU. */
+#define HL_XCHG_HANDLE_BYTES 96
+HL_API int hl_xchg_export(hl_learner* h, uint8_t handle[HL_XCHG_HANDLE_BYTES]);
+HL_API int hl_xchg_connect(hl_learner* h, const uint8_t* handles /* n_ranks x HL_XCHG_HANDLE_BYTES */);
+/* n_ranks > 1 WITHOUT hl_xchg_connect / hl_comm_init = host-exchange mode: the caller owns the communicator and
  * drives hl_step_begin / hl_grad_exchange / hl_counters_exchange / hl_moments_exchange /
  * hl_step_end itself (smarties_amd/dist_host.py); hl_initialize then takes the start-up reward /
  * state statistics from the local shard, and hl_step returns HL_ERR_COMM. */

@@ -26,6 +26,7 @@ ORDER_STABLE, ORDER_REFERENCE = 0, 1
 
 (TAP_FLAT, TAP_EPISODE, TAP_TSTEP, TAP_TAG, TAP_STATE, TAP_OUTPUT, TAP_OUTGRAD, TAP_RHO, TAP_DKL,
  TAP_DELTAQ, TAP_FAR, TAP_GRADSUM) = range(12)
+XCHG_HANDLE_BYTES = 96
 EP_RETURN, EP_VALUE, EP_ADVANTAGE, EP_IMPW, EP_DKL, EP_DELTAQ = range(6)
 
 STATUS = {0: "HL_OK", 1: "HL_ERR_BAD_ARG", 2: "HL_ERR_NO_DEVICE", 3: "HL_ERR_HIP", 4: "HL_ERR_STATE",
@@ -182,6 +183,8 @@ class CApi:
         for name, (res, args) in {
             "comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
             "comm_init": (C.c_int, [P, C.POINTER(C.c_uint8)]),
+            "xchg_export": (C.c_int, [P, C.POINTER(C.c_uint8)]),
+            "xchg_connect": (C.c_int, [P, C.POINTER(C.c_uint8)]),
             "get_counts": (C.c_int, [P, pi64, pi64, pi64, pi64, pi64]),
             "impweight_histogram": (C.c_int, [P, C.c_char_p, I32, pi64]),
             "timing_enable": (C.c_int, [P, I32]),
@@ -470,6 +473,17 @@ class Learner:
     def comm_init(self, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._ck(self.api.fn("comm_init")(self.h, buf))
+
+    def xchg_export(self):
+        """Handle (XCHG_HANDLE_BYTES bytes) of this replica's exchange window: gather all replicas' in rank order."""
+        buf = (C.c_uint8 * XCHG_HANDLE_BYTES)()
+        self._ck(self.api.fn("xchg_export")(self.h, buf))
+        return bytes(buf)
+
+    def xchg_connect(self, handles):
+        raw = b"".join(bytes(hd) for hd in handles)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        self._ck(self.api.fn("xchg_connect")(self.h, buf))
 
     def timing_enable(self, on=True):
         self._ck(self.api.fn("timing_enable")(self.h, int(on)))

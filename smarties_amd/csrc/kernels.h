@@ -122,6 +122,20 @@ struct AdamArgs {
   float eta0, lambda, fac; double epsAnneal; int parity;
 };
 
+// one-kernel sum over the replicas' windows (xchg.hip)
+constexpr int XCHG_CHUNKS = 64;         // workgroups (= independently flagged chunks) of one collective, at most
+constexpr int XCHG_MAX_RANKS = 16;
+struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int pad; };
+struct XchgArgs {
+  void* msg; long long n;                       // local message, summed in place
+  int nRanks, rank;
+  unsigned char* const* peers;                  // [nRanks] windows as this device addresses them (device array; [rank] = the own one)
+  size_t slotsOffset, slotBytes;
+  XchgCtl* ctl; DevScalars* sc;
+  long long timeoutTicks;                       // wall_clock64 ticks (100 MHz) a workgroup waits for a peer's stamp
+  int fuse; AdamArgs adam; PostArgs post;      // fuse != 0 (float messages): Adam on the summed chunk, then the bookkeeping pass
+};
+hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype /* 0 float, 1 double, 2 int64 */, hipStream_t s);
 // extra workgroup appended to an MLP kernel's grid (tail_dev.h): role 0 none, 1 sampler phases
 // (PH_A/B/C mask) of the NEXT step's minibatch, 2 bookkeeping of the step just computed
 // PH_PUBLISH: phase C stops after the index -> (episode, step) search and hands the gather to helper

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <unistd.h>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -125,6 +126,14 @@ struct hl_learner {
   int dbgVariant = 0;
   // rccl
   ncclComm_t comm = nullptr;
+  // one-kernel exchange through peer-mapped windows (xchg.hip)
+  struct Xchg {
+    bool on = false;
+    unsigned char* win = nullptr; size_t winBytes = 0, slotsOffset = 0, slotBytes = 0;
+    unsigned char** dPeers = nullptr; XchgCtl* ctl = nullptr;
+    std::vector<void*> opened;               // windows opened through hipIpc (closed by hl_destroy)
+  } xchg;
+  long long xchgTimeoutTicks = 500000000LL;   // 5 s at 100 MHz (SMARTIES_HIP_XCHG_TIMEOUT_MS)
   // moments exchange state
   bool momentsPending = false;
   // timing
@@ -668,6 +677,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   rc = buildProblems(h); if (rc) return rc;
   if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) h->useGraph = !(e[0] == '1');
   if (const char* e = getenv("SMARTIES_HIP_EAGER_CHAIN")) h->eagerChain = atoi(e);
+  if (const char* e = getenv("SMARTIES_HIP_XCHG_TIMEOUT_MS")) h->xchgTimeoutTicks = std::max(1LL, atoll(e)) * 100000LL;
   if (const char* e = getenv("SMARTIES_HIP_NO_EXCH_GRAPH")) h->exchGraph = !(e[0] == '1');   // replicas: eager exchanges only
   return HL_OK;
 }
@@ -679,6 +689,8 @@ int hl_destroy(hl_learner* h) {
   timerFlush(h);
   invalidateGraphs(h);
   if (h->comm) ncclCommDestroy(h->comm);
+  for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
+  for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
@@ -999,7 +1011,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
     const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
                        h->cfg.dataSamplingAlgo == HL_SAMPLE_UNIFORM &&      // (the prioritised samplers rebuild their table before every minibatch)
-                       (!exchanging(h) || (h->fusedOk && h->exchGraph && h->comm));
+                       (!exchanging(h) || (h->fusedOk && h->exchGraph && wired(h)));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
       // plain steps available before the next 1000-step sweep and within this call
@@ -1613,6 +1625,88 @@ int hl_comm_init(hl_learner* h, const uint8_t id[128]) {
   // identical initial weights on every replica: MPI_Bcast from rank 0 (Network/Builder.cpp:143-144)
   NCCLCK(ncclBroadcast(h->W, h->W, (size_t)h->nParams, ncclFloat, 0, h->comm, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
+  return HL_OK;
+}
+
+// ---- the same sums without RCCL: peer-mapped windows, one kernel per collective (xchg.hip) --------
+// handle: [0,64) hipIpcMemHandle_t | [64,72) the window's address in the exporting process | [72,76) its pid | [76,80) its
+// device | [80,88) window bytes
+namespace {
+size_t xchgMsgBytes(const hl_learner* h) {
+  size_t b = ((size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS) * sizeof(float);
+  b = std::max(b, (size_t)(2 * h->dS + 3) * sizeof(double));
+  return (std::max(b, (size_t)64) + 255) & ~(size_t)255;
+}
+}  // namespace
+int hl_xchg_export(hl_learner* h, uint8_t out[HL_XCHG_HANDLE_BYTES]) {
+  if (!h || !out) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  if (h->cfg.n_ranks < 2 || h->cfg.n_ranks > XCHG_MAX_RANKS) return fail(h, HL_ERR_BAD_ARG, "hl_xchg_export: 2..16 replicas");
+  HIPCK(hipSetDevice(h->dev));
+  auto& x = h->xchg;
+  if (!x.win) {
+    const size_t R = (size_t)h->cfg.n_ranks;
+    x.slotBytes = xchgMsgBytes(h);
+    x.slotsOffset = (2 * R * XCHG_CHUNKS * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    x.winBytes = x.slotsOffset + 2 * R * x.slotBytes;
+    // uncached: the peers' stores land in HBM behind this device's L2, the owner's loads must not be served from it
+    HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&x.win), x.winBytes, hipDeviceMallocUncached));
+    HIPCK(hipMemset(x.win, 0, x.winBytes));
+    HIPCK(devAlloc(&x.ctl, 1));
+    HIPCK(devAlloc(&x.dPeers, R));
+    HIPCK(hipDeviceSynchronize());
+  }
+  std::memset(out, 0, HL_XCHG_HANDLE_BYTES);
+  hipIpcMemHandle_t hd;
+  if (hipIpcGetMemHandle(&hd, x.win) == hipSuccess) std::memcpy(out, &hd, sizeof(hd));
+  else (void)hipGetLastError();              // (same-process peers do not need it; others fail in hl_xchg_connect)
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ipc handle does not fit");
+  const unsigned long long addr = (unsigned long long)(uintptr_t)x.win, bytes = x.winBytes;
+  const int pid = (int)getpid(), dev = h->dev;
+  std::memcpy(out + 64, &addr, 8); std::memcpy(out + 72, &pid, 4); std::memcpy(out + 76, &dev, 4); std::memcpy(out + 80, &bytes, 8);
+  return HL_OK;
+}
+int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
+  if (!h || !handles) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  auto& x = h->xchg;
+  if (!x.win) return fail(h, HL_ERR_BAD_ARG, "hl_xchg_connect before hl_xchg_export");
+  HIPCK(hipSetDevice(h->dev));
+  const int R = h->cfg.n_ranks;
+  std::vector<unsigned char*> peers((size_t)R, nullptr);
+  for (int r = 0; r < R; ++r) {
+    const uint8_t* e = handles + (size_t)r * HL_XCHG_HANDLE_BYTES;
+    unsigned long long addr, bytes; int pid, dev;
+    std::memcpy(&addr, e + 64, 8); std::memcpy(&pid, e + 72, 4); std::memcpy(&dev, e + 76, 4); std::memcpy(&bytes, e + 80, 8);
+    if (bytes != x.winBytes) return fail(h, HL_ERR_BAD_ARG, "hl_xchg_connect: the replicas' windows differ in size (different networks?)");
+    if (r == h->cfg.rank) {
+      if (addr != (unsigned long long)(uintptr_t)x.win || pid != (int)getpid()) return fail(h, HL_ERR_BAD_ARG, "hl_xchg_connect: entry [rank] is not this learner's handle");
+      peers[(size_t)r] = x.win;
+    } else if (pid == (int)getpid()) {        // a learner of this process: its pointer as it is
+      if (dev != h->dev) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(dev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return hipFail(h, pe, "hipDeviceEnablePeerAccess");
+        (void)hipGetLastError();
+      }
+      peers[(size_t)r] = reinterpret_cast<unsigned char*>((uintptr_t)addr);
+    } else {
+      hipIpcMemHandle_t hd; std::memcpy(&hd, e, sizeof(hd));
+      void* q = nullptr;
+      HIPCK(hipIpcOpenMemHandle(&q, hd, hipIpcMemLazyEnablePeerAccess));
+      x.opened.push_back(q);
+      peers[(size_t)r] = static_cast<unsigned char*>(q);
+    }
+  }
+  HIPCK(hipMemcpy(x.dPeers, peers.data(), (size_t)R * sizeof(unsigned char*), hipMemcpyHostToDevice));
+  x.on = true;
+  h->graphsStale = true;
+  // identical initial weights on every replica: MPI_Bcast from rank 0 (Network/Builder.cpp:143-144) as a sum with zeros
+  if (h->cfg.rank == 0) HIPCK(hipMemcpyAsync(h->G, h->W, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  else HIPCK(hipMemsetAsync(h->G, 0, (size_t)h->nParams * sizeof(float), h->stream));
+  int rc = xchgAllreduce(h, h->G, (size_t)h->nParams, 0); if (rc) return rc;
+  HIPCK(hipMemcpyAsync(h->W, h->G, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;       // (a peer that never showed up: the wait timed out)
   return HL_OK;
 }
 

@@ -189,12 +189,13 @@ SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool co
 // replica exchanges are part of the step: several replicas, or a communicator was attached to a
 // single one (hl_comm_init with n_ranks == 1 runs the N > 1 sequence over a 1-rank RCCL communicator)
 bool exchanging(const hl_learner* h) { return h->cfg.n_ranks > 1 || h->comm != nullptr; }
+bool wired(const hl_learner* h) { return h->comm != nullptr || h->xchg.on; }      // the library itself exchanges (RCCL or xchg.hip)
 PostArgs postArgs(hl_learner* h, int parity, int mode) {
   PostArgs pa{}; pa.sc = h->sc; pa.rp = h->rp; pa.bt = h->buf[parity].bt; pa.B = h->B; pa.mode = mode;
   pa.clipImpWeight = h->cfg.clipImpWeight; pa.epsAnneal = h->cfg.epsAnneal; pa.penalTol = h->cfg.penalTol;
   pa.maxObsGlobal = (double)h->maxObsGlobal; pa.batchGlobal = (double)h->Bglobal; pa.nRanks = exchanging(h) ? 2 : 1;   // > 1: use the exchanged counters
   pa.parity = parity; pa.eta0 = (float)h->cfg.learnrate; pa.aggStaged = h->fusedOk ? 1 : 0; pa.hasAdv = h->nAdv > 0 ? 1 : 0;
-  pa.cntMsg = h->comm ? h->G + h->nParams + CNT_MSG_OFFSET : nullptr;
+  pa.cntMsg = wired(h) ? h->G + h->nParams + CNT_MSG_OFFSET : nullptr;
   return pa;
 }
 HeadArgs headArgs(hl_learner* h, int parity) {
@@ -437,21 +438,41 @@ int applyRemoval(hl_learner* h) {
 }
 
 // the message also carries the parameter tail up to the counter chunks (postPart, cntMsg): one collective per step
+// peer windows (hl_xchg_connect) take precedence over the RCCL communicator
+int xchgAllreduce(hl_learner* h, void* buf, size_t n, int dtype, int fuseParity = -1) {
+  XchgArgs xa{};
+  if (fuseParity >= 0) {        // the gradient message of a step: Adam and the counters' bookkeeping inside the same kernel
+    xa.fuse = 1;
+    xa.adam.sc = h->sc; xa.adam.W = h->W; xa.adam.M1 = h->M1; xa.adam.M2 = h->M2; xa.adam.G = h->G; xa.adam.n = h->nParams;
+    xa.adam.eta0 = (float)h->cfg.learnrate; xa.adam.lambda = (float)h->cfg.nnLambda; xa.adam.fac = (float)(1.0 / h->Bglobal);
+    xa.adam.epsAnneal = h->cfg.epsAnneal; xa.adam.parity = fuseParity;
+    xa.post = postArgs(h, fuseParity, POST_BETA);
+  } xa.msg = buf; xa.n = (long long)n; xa.nRanks = h->cfg.n_ranks; xa.rank = h->cfg.rank; xa.peers = h->xchg.dPeers;
+  xa.slotsOffset = h->xchg.slotsOffset; xa.slotBytes = h->xchg.slotBytes; xa.ctl = h->xchg.ctl; xa.sc = h->sc;
+  xa.timeoutTicks = h->xchgTimeoutTicks;
+  if (n * (dtype == 0 ? 4 : 8) > h->xchg.slotBytes) return fail(h, HL_ERR_COMM, "exchange message larger than the window slot");
+  HIPCK(timed(h, "xchg_allreduce", h->stream, [&] { return launch_xchg_allreduce(xa, dtype, h->stream); }));
+  h->nCollectives += 1;
+  return HL_OK;
+}
 int allreduceGrad(hl_learner* h) {
   if (!exchanging(h)) return HL_OK;
-  if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but hl_comm_init was not called");
   const size_t n = (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS;
+  if (h->xchg.on) return xchgAllreduce(h, h->G, n, 0);
+  if (!h->comm) return fail(h, HL_ERR_COMM, "n_ranks > 1 but neither hl_xchg_connect nor hl_comm_init was called");
   NCCLCK(ncclAllReduce(h->G, h->G, n, ncclFloat, ncclSum, h->comm, h->stream));
   h->nCollectives += 1;
   return HL_OK;
 }
 int allreduceCounters(hl_learner* h) {      // start-up only (hl_initialize); steps carry the counters in the gradient message
+  if (h->xchg.on) return xchgAllreduce(h, h->sc->cnt, 4, 2);
   if (!h->comm) return HL_OK;
   NCCLCK(ncclAllReduce(h->sc->cnt, h->sc->cnt, 4, ncclInt64, ncclSum, h->comm, h->stream));
   h->nCollectives += 1;
   return HL_OK;
 }
 int allreduceMoments(hl_learner* h) {
+  if (h->xchg.on) return xchgAllreduce(h, h->dMoments, (size_t)(2 * h->dS + 3), 1);
   if (!h->comm) return HL_OK;
   NCCLCK(ncclAllReduce(h->dMoments, h->dMoments, (size_t)(2 * h->dS + 3), ncclDouble, ncclSum, h->comm, h->stream));
   h->nCollectives += 1;
@@ -525,7 +546,8 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   }
   if (evict) { rc = applyRemoval(h); if (rc) return rc; rc = flushPending(h); if (rc) return rc; }
   if (exch) {
-    if (h->comm) { rc = launchPost(h, p, POST_ENCODE, s); if (rc) return rc; }   // counters as of after the removal
+    if (wired(h)) { rc = launchPost(h, p, POST_ENCODE, s); if (rc) return rc; }   // counters as of after the removal
+    if (h->xchg.on) return xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p);   // + Adam + beta
     rc = allreduceGrad(h); if (rc) return rc;
     rc = launchAdam(h, p); if (rc) return rc;
   }
@@ -552,6 +574,7 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
       // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (four exact 16-bit
       // chunks each), the pass after Adam decodes their sums.
       rc = launchWeightGrad(h, p, false, s0, true, false, POST_AGG);
+      if (!rc && h->xchg.on) { rc = xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p); if (rc) break; continue; }
       if (!rc) rc = allreduceGrad(h);
       if (!rc) rc = launchAdam(h, p);
       if (!rc) rc = launchPost(h, p, POST_BETA, s0);
@@ -606,7 +629,7 @@ bool graphUsable(const hl_learner* h, int U, int p0) {
 int captureAllGraphs(hl_learner* h) {
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
   static_assert(NS <= 16, "hl_learner::graphs is too small");
-  if (!h->useGraph || (exchanging(h) && !(h->fusedOk && h->exchGraph && h->comm))) return HL_OK;
+  if (!h->useGraph || (exchanging(h) && !(h->fusedOk && h->exchGraph && wired(h)))) return HL_OK;
   for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
     if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
     const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);
@@ -645,7 +668,7 @@ int replaySteps(hl_learner* h, long long avail, int* done) {
     HIPCK(hipGraphLaunch(h->graphs[i][p0].exec, h->stream));
     h->lastParity = (p0 + U - 1) & 1;
     h->preValid = true; h->preParity = (p0 + U) & 1;
-    if (h->comm) h->nCollectives += U;
+    if (wired(h)) h->nCollectives += U;
     *done = U;
     return HL_OK;
   }

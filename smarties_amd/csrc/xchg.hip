@@ -1,0 +1,128 @@
+// smarties_amd/csrc/xchg.hip -- the replicas' sum over xGMI as ONE kernel (the reference: MPI_Iallreduce of the gradient,
+// Network/Optimizer.cpp:110-132; of the counters and moments, Utils/DelayedReductor.cpp:53-83).
+//
+// A 292 KB message on 8 GPUs is latency: a ring or tree all-reduce pays its hop count, the direct xGMI links of a node let every
+// replica WRITE its message straight into a window in each peer's HBM instead.  Per replica one window (uncached device memory,
+// peer-mapped through hipIpc handles or, inside one process, plain pointers):
+//     flags [2][nRanks][XCHG_CHUNKS]   64-bit arrival stamps (sequence number + 1) per sender and chunk of the message
+//     slots [2][nRanks][slotBytes]     the senders' messages
+// double-buffered over the parity of the sequence number: a replica can be at most one collective ahead of the slowest one
+// (it needs everybody's message of collective s before it can issue s + 1), so the buffer of s - 1 is free when s + 1 writes it.
+// Workgroup c owns chunk c of the message: it stores its chunk into all peers' windows, fences at system scope, stamps the
+// peers' flags, waits for the peers' stamps on ITS chunk only (no device-wide barrier), and sums the nRanks contributions in
+// rank order -- the own one from the local buffer -- so that every replica gets the same bits.  The waits are bounded: a lost
+// peer raises the learner's sticky device error (hl_sync then returns HL_ERR_HIP) instead of hanging the GPU.
+#include "tail_dev.h"
+
+namespace hl {
+
+template <typename T> struct Vec16 { T v[16 / sizeof(T)]; };
+
+__device__ __forceinline__ unsigned long long ldSys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void stSys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// FUSE (the gradient message of a step): the workgroup that summed a chunk applies Adam to it (AdamOptimizer::apply_update,
+// Network/Optimizer.cpp:122-160) and the last workgroup to finish runs the bookkeeping that needs the summed counters
+// (MemoryProcessing::updateCounters ... beta, the next step's Adam scalars) -- a replica's step is then three launches.
+template <typename T, bool FUSE>
+__global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
+  __shared__ unsigned long long sSeq;
+  __shared__ int sLast;
+  __shared__ long long sFarDelta; __shared__ unsigned sMaxAbs;
+  const int tid = threadIdx.x, chunk = blockIdx.x, nCh = gridDim.x, R = a.nRanks, me = a.rank;
+  if (tid == 0) sSeq = __hip_atomic_load(&a.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned long long seq = sSeq, tag = seq + 1;
+  const int par = (int)(seq & 1);
+  // 16-byte units of the message; the last one may be partial (handled element-wise)
+  const long long bytes = a.n * (long long)sizeof(T), full = bytes >> 4;
+  const long long per = (full + nCh - 1) / nCh, v0 = per * chunk, v1 = min(full, v0 + per);
+  typedef Vec16<T> V;
+  V* msg = reinterpret_cast<V*>(a.msg);
+  const size_t slotOff = a.slotsOffset + ((size_t)par * R + me) * a.slotBytes;
+  // ---- push: this chunk into every peer's window ----
+  for (long long v = v0 + tid; v < v1; v += 256) {
+    const V x = msg[v];
+    for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<V*>(a.peers[p] + slotOff)[v] = x;
+  }
+  const long long tail0 = full * (16 / (long long)sizeof(T));          // elements behind the last full unit: chunk 0 carries them
+  if (chunk == 0 && tid < (int)(a.n - tail0)) {
+    const T x = reinterpret_cast<const T*>(a.msg)[tail0 + tid];
+    for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<T*>(a.peers[p] + slotOff)[tail0 + tid] = x;
+  }
+  __threadfence_system();
+  __syncthreads();
+  unsigned long long* myFlags = reinterpret_cast<unsigned long long*>(a.peers[me]) + (size_t)par * R * XCHG_CHUNKS;
+  if (tid < R && tid != me) {
+    stSys(reinterpret_cast<unsigned long long*>(a.peers[tid]) + ((size_t)par * R + me) * XCHG_CHUNKS + chunk, tag);
+    // ---- wait for the same chunk of every peer ----
+    const unsigned long long* f = myFlags + (size_t)tid * XCHG_CHUNKS + chunk;
+    const long long t0 = wall_clock64();
+    while (ldSys(f) < tag) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > a.timeoutTicks) { a.sc->errFlag = 79; break; }
+    }
+  }
+  __syncthreads();
+  // ---- sum in rank order ----
+  const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
+  for (long long v = v0 + tid; v < v1; v += 256) {
+    V acc;
+    for (int r = 0; r < R; ++r) {
+      const V x = r == me ? msg[v] : reinterpret_cast<const V*>(mine + (size_t)r * a.slotBytes)[v];
+      if (r == 0) acc = x;
+      else {
+#pragma unroll
+        for (int q = 0; q < (int)(16 / sizeof(T)); ++q) acc.v[q] += x.v[q];
+      }
+    }
+    msg[v] = acc;
+    if constexpr (FUSE) {
+      AdamCoef c; c.eta = a.adam.sc->etaEff[a.adam.parity]; c.lambda = a.adam.lambda; c.fac = a.adam.fac;
+#pragma unroll
+      for (int q = 0; q < (int)(16 / sizeof(T)); ++q) {
+        const long long i = v * (long long)(16 / sizeof(T)) + q;
+        if (i < a.adam.n) {
+          float w = a.adam.W[i], m1 = a.adam.M1[i], m2 = a.adam.M2[i];
+          adamStep(c, (float)acc.v[q], w, m1, m2);
+          a.adam.W[i] = w; a.adam.M1[i] = m1; a.adam.M2[i] = m2;
+        }
+      }
+    }
+  }
+  if (chunk == 0 && tid < (int)(a.n - tail0)) {
+    T acc = 0;
+    for (int r = 0; r < R; ++r) {
+      const T x = r == me ? reinterpret_cast<const T*>(a.msg)[tail0 + tid] : reinterpret_cast<const T*>(mine + (size_t)r * a.slotBytes)[tail0 + tid];
+      acc = r == 0 ? x : acc + x;
+    }
+    reinterpret_cast<T*>(a.msg)[tail0 + tid] = acc;
+  }
+  // ---- the last workgroup to get here closes the collective: every workgroup has read `seq` by then ----
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const bool last = atomicAdd(&a.ctl->done, 1u) == (unsigned)nCh - 1;
+    sLast = last ? 1 : 0;
+    if (last) {
+      a.ctl->done = 0;
+      __hip_atomic_store(&a.ctl->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if constexpr (FUSE) {
+    __syncthreads();
+    if (sLast) { __threadfence(); postPart(a.post, &sFarDelta, &sMaxAbs); }      // (all chunks are summed and visible)
+  }
+}
+
+hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype, hipStream_t s) {
+  const long long bytes = a.n * (dtype == 0 ? 4 : 8);
+  int nCh = (int)((bytes + 4095) / 4096); if (nCh < 1) nCh = 1; if (nCh > XCHG_CHUNKS) nCh = XCHG_CHUNKS;
+  if (a.fuse && dtype == 0) hipLaunchKernelGGL((xchg_allreduce_kernel<float, true>), dim3(nCh), dim3(256), 0, s, a);
+  else if (dtype == 0) hipLaunchKernelGGL((xchg_allreduce_kernel<float, false>), dim3(nCh), dim3(256), 0, s, a);
+  else if (dtype == 1) hipLaunchKernelGGL((xchg_allreduce_kernel<double, false>), dim3(nCh), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((xchg_allreduce_kernel<long long, false>), dim3(nCh), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace hl

@@ -406,6 +406,142 @@ def test_split_step_equals_fused_step(hip_api, extra):
     assert A.scalars().beta == Bq.scalars().beta
 
 
+def _xchg_replicas(hip_api, cfg_kw, sc, connect):
+    """Two HIP replicas on this GPU; connect=True: exchanging through each other's windows (one thread per replica, as the
+    collectives wait for the peer), else to be driven through the host-exchange entry points."""
+    import threading
+    from oracle_api import synth_episode
+    Ls = []
+    for r in range(2):
+        L = hip_learner(hip_api, capi.make_config(n_ranks=2, rank=r, **cfg_kw))
+        L.init_weights()
+        for e in range(r, 40, 2):
+            L.append_episode(**synth_episode(sc, e))
+        Ls.append(L)
+    if connect == "before":                   # the start-up statistics are then sums over both shards (hl_initialize exchanges them)
+        handles = [L.xchg_export() for L in Ls]
+        _both(Ls, lambda L: (L.xchg_connect(handles), L.initialize()))
+        return Ls
+    w0 = Ls[0].get_params()[0]
+    for L in Ls:                              # host-exchange mode: statistics of the local shard
+        w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2); L.initialize()
+    if connect == "after":
+        handles = [L.xchg_export() for L in Ls]
+        _both(Ls, lambda L: L.xchg_connect(handles))
+    return Ls
+
+
+def _both(Ls, fn):
+    import threading
+    errs = []
+
+    def run(L):
+        try:
+            fn(L)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=run, args=(L,)) for L in Ls]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
+def _host_sum_step(Ls):
+    for L in Ls:
+        L.step_begin()
+    g = np.sum([L.grad_fetch() for L in Ls], axis=0, dtype=np.float32)
+    ms = [L.moments_fetch() for L in Ls]
+    c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+    for L, m in zip(Ls, ms):
+        L.grad_store(g)
+        if m is not None:
+            L.moments_store(np.sum(ms, axis=0))
+        L.counters_store(c)
+        L.step_end()
+
+
+def test_one_kernel_exchange_between_two_replicas(hip_api):
+    """hl_xchg_export / hl_xchg_connect (xchg.hip): each replica writes its gradient-and-counters message straight into the
+    other's window and sums in rank order -- against the same two replicas with the sums formed on the host: weights, Adam
+    moments, beta and the generator bit for bit after eager calls, replayed graphs (the exchange kernel is a graph node) and
+    the 1000th-step sweep with its moments exchange; both replicas identical throughout."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4096, randSeed=11)
+    sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+    X = _xchg_replicas(hip_api, cfg_kw, sc, "after")      # (same start as H: initialised on the local shards, then connected)
+    H = _xchg_replicas(hip_api, cfg_kw, sc, None)
+    assert X[0].B == 8
+    done = 0
+    for n in (1, 1, 3, 20, 70, 900, 10):
+        _both(X, lambda L: (L.step(n), L.sync()))
+        for _ in range(n):
+            _host_sum_step(H)
+        done += n
+        for r in range(2):
+            for a, b in zip(X[r].get_params(), H[r].get_params()):
+                assert np.array_equal(a, b), (done, r)
+            assert X[r].scalars().beta == H[r].scalars().beta and np.array_equal(X[r].get_rng_state(), H[r].get_rng_state())
+        assert np.array_equal(X[0].get_params()[0], X[1].get_params()[0])
+    coll = hip_api.lib.hl_debug_collectives
+    coll.restype = C.c_int64; coll.argtypes = [C.c_void_p]
+    assert coll(X[0].h) == coll(X[1].h) >= 1005
+
+
+def test_one_kernel_exchange_at_start_up(hip_api):
+    """Connected BEFORE hl_initialize: rank 0's weights reach rank 1, the start-up counters and reward / state moments are summed
+    over both shards (Learner::initializeLearner with several learners) -- the scaling equals that of ONE learner holding all
+    episodes -- and the replicas stay identical over the following steps."""
+    from oracle_api import synth_episode
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4096, randSeed=11)
+    sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+    Y = _xchg_replicas(hip_api, cfg_kw, sc, "before")
+    S = hip_learner(hip_api, capi.make_config(**cfg_kw)); S.init_weights()
+    for e in range(40):
+        S.append_episode(**synth_episode(sc, e))
+    S.initialize()
+    ref = np.concatenate(S.get_scaling())
+    for r in range(2):
+        got = np.concatenate(Y[r].get_scaling())
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-7), r
+    assert all(np.array_equal(a, b) for a, b in zip(Y[0].get_scaling(), Y[1].get_scaling()))
+    assert np.array_equal(Y[0].get_params()[0], Y[1].get_params()[0])
+    c0, c1 = Y[0].counts(), Y[1].counts()
+    _both(Y, lambda L: (L.step(30), L.sync()))
+    assert np.array_equal(Y[0].get_params()[0], Y[1].get_params()[0]) and Y[0].scalars().beta == Y[1].scalars().beta
+
+
+def test_one_kernel_exchange_between_two_processes():
+    """The same exchange between two PROCESSES sharing this GPU, windows mapped through hipIpc handles that travel over gloo
+    (tests/xchg_ipc_worker.py): replicas identical and equal to the host-summed run, bit for bit, after 1005 steps."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMARTIES_HIP_XCHG_TIMEOUT_MS="20000")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", os.path.join(here, "xchg_ipc_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert "XCHG_IPC_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_exchange_times_out_instead_of_hanging(hip_api):
+    """A peer that never issues its collective: the waiting replica's kernel gives up after SMARTIES_HIP_XCHG_TIMEOUT_MS and the
+    learner reports a device error; the GPU stays usable."""
+    import subprocess, sys, os
+    code = (
+        "import os, sys; sys.path[:0] = [%r, %r]\n"
+        "from smarties_amd import capi, load_hip; from oracle_api import synth_cfg, synth_episode\n"
+        "api = load_hip(); sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)\n"
+        "Ls = [capi.Learner(api, capi.make_config(n_ranks=2, rank=r, dimS=5, dimA=2, hidden=(32, 32), batchSize=16)) for r in range(2)]\n"
+        "hs = [L.xchg_export() for L in Ls]\n"
+        "try:\n    Ls[0].xchg_connect(hs); print('NO_ERROR')\n"
+        "except capi.HlError as e:\n    print('TIMED_OUT', e)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMARTIES_HIP_XCHG_TIMEOUT_MS="200"), capture_output=True, text=True, timeout=300)
+    assert "TIMED_OUT" in out.stdout, out.stdout + out.stderr[-2000:]
+    L = hip_learner(hip_api, capi.make_config(dimS=5, dimA=2, hidden=(16,), batchSize=8))     # the device still works
+    L.init_weights()
+
+
 @pytest.mark.gpu
 def test_two_replica_protocol_matches_oracle_replicas(hip_api):
     """n_ranks = 2 (batch and replay budget split): two HIP replicas on this GPU,
