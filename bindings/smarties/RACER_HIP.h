@@ -141,7 +141,15 @@ class RACER_HIP : public Learner
     const int rc = hl_create(&c, &H);
     if (rc) { const std::string msg = H ? hl_last_error(H) : hl_status_string(rc); if (H) hl_destroy(H); H = nullptr; die(msg.c_str()); }
     ck(hl_init_weights(H));
-    if (learn_size > 1) {                              // RCCL id over the learners' MPI communicator (Optimizer.h:24)
+    if (learn_size > 1 && learn_size <= 16 && getenv("SMARTIES_HIP_RCCL") == nullptr) {
+      // learners of one node: every replica's exchange window is mapped by its peers (xGMI); the 96-byte handles travel over
+      // the learners' MPI communicator (Optimizer.h:24), the sums themselves never touch MPI or the host
+      uint8_t mine[HL_XCHG_HANDLE_BYTES];
+      std::vector<uint8_t> all((size_t) learn_size * HL_XCHG_HANDLE_BYTES);
+      ck(hl_xchg_export(H, mine));
+      MPI_Allgather(mine, HL_XCHG_HANDLE_BYTES, MPI_BYTE, all.data(), HL_XCHG_HANDLE_BYTES, MPI_BYTE, learnersComm);
+      ck(hl_xchg_connect(H, all.data()));
+    } else if (learn_size > 1) {                       // RCCL id over the same communicator
       uint8_t id[128] = {0};
       if (learn_rank == 0) ck(hl_comm_unique_id(id));
       MPI_Bcast(id, 128, MPI_BYTE, 0, learnersComm);

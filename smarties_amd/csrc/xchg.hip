@@ -18,7 +18,8 @@ namespace hl {
 
 template <typename T> struct Vec16 { T v[16 / sizeof(T)]; };
 
-__device__ __forceinline__ unsigned long long ldSys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// (relaxed: the window is uncached memory, every load goes to HBM; an acquire load would invalidate this XCD's L2 at every poll)
+__device__ __forceinline__ unsigned long long ldSys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void stSys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // FUSE (the gradient message of a step): the workgroup that summed a chunk applies Adam to it (AdamOptimizer::apply_update,
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > a.timeoutTicks) { a.sc->errFlag = 79; break; }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
   }
   __syncthreads();
   // ---- sum in rank order ----
