@@ -383,8 +383,13 @@ def main():
         roof = roofline(P)                   # (P is closed after the timed region: freeing 300 MB idles the device for milliseconds)
 
     if dog is not None:
-        run(2)
-        barrier()
+        try:
+            run(2)
+            barrier()
+        except Exception as e:  # noqa: BLE001  (e.g. a peer's message never arrived: the exchange kernel's bounded wait)
+            print("rank %d: the two-step probe of the exchange failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+            dog.cancel()
+            start_over()
         dog.cancel()
 
     run(args.warmup)
