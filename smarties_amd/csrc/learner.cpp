@@ -87,7 +87,6 @@ struct hl_learner {
   long long nTransitions = 0, nSeenSteps = 0, nSeenEps = 0, nGradSteps = 0;
   long long nGatheredB4Startup = INT64_MAX;
   bool tableDirty = true, countsDirty = true, initialized = false, inStep = false;
-  double lastAvgSqErr = 0;
   // One lock per learner: every entry point takes it, so finished episodes (hl_append_episode) and rollout inference
   // (hl_forward) may come from env-service threads while the training thread steps (the reference's dataset_mutex,
   // ReplayMemory/MemoryBuffer.h:55; callers Core/Master.cpp:66-86).  Entry points only enqueue device work, so the lock
@@ -1603,7 +1602,6 @@ int hl_get_stats(hl_learner* h, hl_stats* o) {
   HIPCK(hipStreamSynchronize(h->stream));
   o->avgKLdivergence = out[0]; o->avgSquaredErr = out[1]; o->maxAbsError = out[2]; o->avgReturn = out[3];
   o->avgQ = out[4]; o->stdevQ = out[5]; o->minQ = out[6]; o->maxQ = out[7]; o->nFarPolicySteps = (int64_t)out[8];
-  h->lastAvgSqErr = out[1];
   return HL_OK;
 }
 
@@ -1742,6 +1740,8 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
   HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
   rc = dropPresample(h); if (rc) return rc;
+  if ((which == 1 || which == 21) && (h->buf[0].fwdIdx.empty() || h->buf[0].fwdIdx[0] < 0)) return fail(h, HL_ERR_UNSUPPORTED, "no dense first layer to profile (convolutional preprocessing)");
+  if ((which == 2 || which == 22 || which == 4 || which == 24) && (h->recurrent || h->buf[0].fwdIdx.empty())) return fail(h, HL_ERR_UNSUPPORTED, "dense-layer profiles do not apply to recurrent networks");
   h->dbgVariant = variant;
   GraphSlot slot;
   if (which == 7) {

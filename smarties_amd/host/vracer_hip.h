@@ -145,8 +145,12 @@ class VRACER {
     c.outWeightsPrefac = hp.outWeightsPrefac; c.randSeed = hp.randSeed;
     c.n_ranks = nLearners; c.rank = learnerRank; c.device_id = deviceID; c.ref_threads = 1;
     const int rc = hl_create(&c, &H);
-    if (rc) die(std::string("hl_create: ") + hl_status_string(rc) + ": " + hl_last_error(nullptr));
-    ck(hl_init_weights(H));
+    if (rc) {       // (hl_create may hand back a handle that only carries the message)
+      const std::string msg = std::string("hl_create: ") + hl_status_string(rc) + ": " + hl_last_error(H);
+      if (H) { hl_destroy(H); H = nullptr; }
+      die(msg);
+    }
+    if (hl_init_weights(H) != HL_OK) { const std::string msg = hl_last_error(H); hl_destroy(H); H = nullptr; die(msg); }
     nOut = hl_num_outputs(H); nDense = nOpt ? 1 + 2 * nOpt : 1 + nAdv + (int)M.dimAction;
   }
   ~VRACER() { if (H) hl_destroy(H); }
