@@ -25,11 +25,15 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[HEAD_LDS > TAIL_LDS_BYTES ? HEAD_LDS : TAIL_LDS_BYTES];
   // horizontal fusion: workgroup 0 (dispatched first) runs sampler phase C of the next step
+  // ... and, for wide states, workgroups 1..helpers gather the minibatch it found (one workgroup keeps only a few dozen HBM
+  // misses in flight: 2 x 256 rows of 257 floats took 60 us that way)
+  const int nExtra = extra.role ? 1 + extra.helpers : 0;
   if (extra.role && blockIdx.x == 0) { runExtra(extra, smem); return; }
+  if ((int)blockIdx.x < nExtra) { gatherHelper(extra.samp, blockIdx.x - 1, extra.helpers, smem); return; }
   double (*sO)[HEAD_MAXOUT] = reinterpret_cast<double (*)[HEAD_MAXOUT]>(smem);
   float (*sDelta)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = (blockIdx.x - (extra.role ? 1 : 0)) * 4 + wave;
+  const int row = (blockIdx.x - nExtra) * 4 + wave;
   const DevScalars* sc = a.sc;
   if (row >= sc->nRows[a.parity]) return;
   const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H, nAdv = a.nAdv, pM = 1 + nAdv;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
 
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {
   ExtraArgs ex{}; if (extra) ex = *extra;
-  const dim3 grid((maxRows + 3) / 4 + (ex.role ? 1 : 0)), block(256);
+  const dim3 grid((maxRows + 3) / 4 + (ex.role ? 1 + ex.helpers : 0)), block(256);
   const int HQ = (a.H + 63) / 64;
   if (HQ <= 1) hipLaunchKernelGGL(head_kernel_t<1>, grid, block, 0, s, a, ex);
   else if (HQ <= 2) hipLaunchKernelGGL(head_kernel_t<2>, grid, block, 0, s, a, ex);

@@ -141,7 +141,7 @@ hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype /* 0 float, 1 doub
 // PH_PUBLISH: phase C stops after the index -> (episode, step) search and hands the gather to helper
 // workgroups (gatherHelper) through DevScalars::gatherFlag
 enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7, PH_PUBLISH = 8 };
-struct ExtraArgs { int role; int phases; SampleArgs samp; PostArgs post; };
+struct ExtraArgs { int role; int phases; SampleArgs samp; PostArgs post; int helpers; /* head kernel: gather helper workgroups behind the rider (PH_PUBLISH) */ };
 
 // fused forward + head + dX kernel of the two-hidden-layer MLP (fused.hip)
 struct FusedArgs {

@@ -314,7 +314,14 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
   const HeadArgs ha = headArgs(h, parity);
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
   // (recurrent nets have no forward GEMM launches: the whole sampler of the next step rides along the head kernel)
-  if (nextSample) { ex = extraSample(h, parity ^ 1, h->recurrent ? PH_ALL : PH_C); pex = &ex; }
+  if (nextSample) {
+    ex = extraSample(h, parity ^ 1, h->recurrent ? PH_ALL : PH_C); pex = &ex;
+    if (!ex.samp.noGather) {      // the gather of 2 B rows of dS floats: ~1024 floats per helper workgroup, at most 31 of them
+      const long long fl = 2LL * h->B * h->dS;
+      ex.helpers = (int)std::min<long long>(31, fl / 1024);
+      if (ex.helpers > 0) ex.phases |= PH_PUBLISH;
+    }
+  }
   HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
   return HL_OK;
 }
