@@ -79,7 +79,15 @@ __host__ __device__ inline size_t convFwdLds(const ConvGeo& g, int CT) {
 //   Wx[l]: [IT 16][KKp + 4]  Wx[ic][(c, fy, fx)] = K[c][ic][fy][fx], zero padded (dX: A operand rows = input channels)
 // so that a workgroup's staging is a flat 16-byte copy with every load in flight at once.
 __host__ __device__ inline int convWfFloats(const ConvGeo& g) { return ((g.KnC + 15) & ~15) * (convPad4(g.K) + 4); }
-__host__ __device__ inline int convWxFloats(const ConvGeo& g) { return ((g.InC + 15) & ~15) * (convPad4(g.KnC * g.KnY * g.KnX) + 4); }
+// strided layers whose filter and input sizes are multiples of the stride: dX runs per PARITY CLASS of the input position
+// (iy mod S, ix mod S) -- only the filter taps fy = iy (mod S), fx = ix (mod S) reach such a position, 1 / S^2 of them
+__host__ __device__ inline bool convStrided(const ConvGeo& g) { return g.S > 1 && g.KnY % g.S == 0 && g.KnX % g.S == 0 && g.InY % g.S == 0 && g.InX % g.S == 0; }
+__host__ __device__ inline int convClassK(const ConvGeo& g) { return g.KnC * (g.KnY / g.S) * (g.KnX / g.S); }
+__host__ __device__ inline int convWxFloats(const ConvGeo& g) {
+  const int rows = (g.InC + 15) & ~15;
+  if (convStrided(g)) return g.S * g.S * rows * (convPad4(convClassK(g)) + 4);      // Wx[class][ic][(c, ty, tx)]
+  return rows * (convPad4(g.KnC * g.KnY * g.KnX) + 4);
+}
 __global__ __launch_bounds__(256) void conv_prep_kernel(ConvArgs a) {
   int l = 0, i = blockIdx.x * 256 + threadIdx.x;
   for (; l < a.nL; ++l) { const int n = convWfFloats(a.L[l]) + (l > 0 ? convWxFloats(a.L[l]) : 0); if (i < n) break; i -= n; }
@@ -92,6 +100,18 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(ConvArgs a) {
     g.Wf[i] = (c < g.KnC && k < g.K) ? Wl[(size_t)c * g.K + k] : 0.f;
   } else {
     i -= nf;
+    if (convStrided(g)) {
+      const int S = g.S, TY = g.KnY / S, TX = g.KnX / S, KKc = g.KnC * TY * TX, ld = convPad4(KKc) + 4, rows = (g.InC + 15) & ~15;
+      const int cls = i / (rows * ld), rem = i - cls * rows * ld, ic = rem / ld, kc = rem - ic * ld;
+      float w = 0.f;
+      if (ic < g.InC && kc < KKc) {
+        const int c = kc / (TY * TX), t = kc - c * TY * TX, ty = t / TX, tx = t - ty * TX;
+        const int fy = cls / S + S * ty, fx = cls % S + S * tx;
+        w = Wl[(((size_t)c * g.InC + ic) * g.KnY + fy) * g.KnX + fx];
+      }
+      g.Wx[i] = w;
+      return;
+    }
     const int fsz = g.KnY * g.KnX, KK = g.KnC * fsz, ldKK = convPad4(KK) + 4, ic = i / ldKK, kk = i - ic * ldKK;
     float w = 0.f;
     if (ic < g.InC && kk < KK) { const int c = kk / fsz, f = kk - c * fsz; w = Wl[((size_t)c * g.InC + ic) * fsz + f]; }
@@ -302,6 +322,102 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
     }
   }
 }
+// the same for a strided layer, one parity class of input positions per workgroup: tiles are laid out class-major
+// (class, sample, position inside the class), NK = KnC (KnY / S)(KnX / S) / 4 steps instead of KnC KnY KnX / 4
+template <int IT, int NK>
+__global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsigned tilesPerClass) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvGeo g = a.L[l];
+  const ConvGeo gp = a.L[l - 1];
+  const int S = g.S, TY = g.KnY / S, TX = g.KnX / S, KKc = g.KnC * TY * TX, KKp = convPad4(KKc), ld = KKp + 4, P = g.P;
+  const int CX = g.InX / S, Pc = (g.InY / S) * CX, Pin = g.InY * g.InX;
+  float* Wx = reinterpret_cast<float*>(smem);                          // [IT*16][ld]   this class's Wx[ic][(c, ty, tx)]
+  int* kTab = reinterpret_cast<int*>(Wx + (size_t)IT * 16 * ld);       // [KKp]   c * P | ty << 20 | tx << 26   (-1: padding)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  constexpr int PW = 4 / IT;
+  const unsigned Rc = (unsigned)a.B * (unsigned)Pc;
+  const unsigned tile = blockIdx.x * PW + wave / IT;
+  const int cls = (int)(tile / tilesPerClass);                         // uniform over the workgroup (tilesPerClass is a multiple of PW)
+  const unsigned tIn = tile - (unsigned)cls * tilesPerClass;
+  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx + (size_t)cls * IT * 16 * ld, IT * 16 * ld);
+  const int it = wave % IT;
+  const unsigned r = tIn * 16 + li;
+  const bool ok = r < Rc;
+  const unsigned rr = ok ? r : 0;
+  const int bb = (int)(rr / (unsigned)Pc), j = (int)(rr - (unsigned)bb * (unsigned)Pc);
+  const int jy = j / CX, jx = j - jy * CX;
+  const int qq = (cls / S + S * jy) * g.InX + (cls % S + S * jx);
+  const float* dRow = g.D + (long long)bb * g.ldOut;
+  for (int kc = tid; kc < KKp; kc += 256) {
+    int v = -1;
+    if (kc < KKc) { const int c = kc / (TY * TX), t = kc - c * TY * TX, ty = t / TX, tx = t - ty * TX; v = (c * P) | (ty << 20) | (tx << 26); }
+    kTab[kc] = v;
+  }
+  __syncthreads();
+  auto gatherD = [&](int kc) -> float {       // D[(b, c, (jy - ty, jx - tx))] where that output position exists, else 0
+    const int tab = kTab[kc];
+    const int offC = tab & 0xFFFFF, oy = jy - ((tab >> 20) & 63), ox = jx - ((tab >> 26) & 31);
+    const bool v = tab >= 0 && ok && (unsigned)oy < (unsigned)g.OpY && (unsigned)ox < (unsigned)g.OpX;
+    return v ? dRow[offC + oy * g.OpX + ox] : 0.f;
+  };
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* wRow = Wx + (it * 16 + li) * ld + lc;
+  if constexpr (NK > 0) {
+    float bv[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) bv[s] = gatherD(4 * s + lc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      const float av = wRow[4 * s];
+      if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc0, 0, 0, 0);
+    }
+  } else {
+    constexpr int UN = 8;
+    for (int s0 = 0; s0 < KKp / 4; s0 += UN) {
+      float av[UN], bv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int s = s0 + u; const bool kin = 4 * s < KKp;
+        av[u] = kin ? wRow[4 * s] : 0.f;
+        bv[u] = kin ? gatherD(4 * s + lc) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
+      }
+    }
+  }
+  if (!ok) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ic = it * 16 + lc * 4 + q;
+    if (ic < g.InC) {
+      const size_t o = (size_t)bb * gp.ldOut + (size_t)ic * Pin + qq;
+      gp.D[o] = (acc0[q] + acc1[q]) * softsignDiff(gp.X[o]);
+    }
+  }
+}
+template <int IT, int NK> static hipError_t launchConvDxsT(const ConvArgs& a, int l, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  const int KKp = convPad4(convClassK(g));
+  const size_t lds = (size_t)IT * 16 * (KKp + 4) * 4 + (size_t)KKp * 4;
+  constexpr int PW = 4 / IT;
+  const long long Rc = (long long)a.B * (g.InY / g.S) * (g.InX / g.S);
+  unsigned tpc = (unsigned)((Rc + 15) / 16); tpc = (tpc + PW - 1) / PW * PW;
+  const int blocks = (int)((long long)g.S * g.S * tpc / PW);
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dxs_kernel<IT, NK>), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((conv_dxs_kernel<IT, NK>), dim3(blocks), dim3(256), lds, s, a, l, tpc);
+  return hipGetLastError();
+}
+template <int IT> static hipError_t launchConvDxsC(const ConvArgs& a, int l, hipStream_t s) {
+  const int nk = convPad4(convClassK(a.L[l])) / 4;
+  if (nk == 36) return launchConvDxsT<IT, 36>(a, l, s);         // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
+  return launchConvDxsT<IT, 0>(a, l, s);
+}
 template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, hipStream_t s) {
   const size_t lds = convDxLds(a.L[l], IT);
   constexpr int PW = 4 / IT;
@@ -322,6 +438,12 @@ hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const long long R = (long long)a.B * g.InY * g.InX;
   const int IT = (g.InC + 15) / 16;
+  if (convStrided(g)) {
+    if (IT == 1) return launchConvDxsC<1>(a, l, s);
+    if (IT == 2) return launchConvDxsC<2>(a, l, s);
+    if (IT <= 4) return launchConvDxsC<4>(a, l, s);
+    return hipErrorInvalidValue;
+  }
   if (IT == 1) return launchConvDxC<1>(a, l, R, s);
   if (IT == 2) return launchConvDxC<2>(a, l, R, s);
   if (IT <= 4) return launchConvDxC<4>(a, l, R, s);

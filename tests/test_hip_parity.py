@@ -1113,6 +1113,15 @@ def test_conv_steps_follow_reference_fixture(hip_api, name):
     (dict(dimS=800, dimA=2, bounded=[1, 0], nAppendedObs=3, conv=[(20, 20, 8, 16, 6, 2)], hidden=(40, 24), batchSize=16,
           maxTotObsNum=1500, randSeed=4),
      dict(seed=6, dimS=800, dimA=2, lenMin=4, lenMax=20, pTerm=0.5), 30, 5),
+    # a strided layer BEHIND another one: its input gradient runs per parity class of the input position (filter and image sizes
+    # multiples of the stride) ...
+    (dict(dimS=576, dimA=2, nAppendedObs=0, conv=[(12, 12, 4, 8, 3, 1), (10, 10, 8, 16, 4, 2)], hidden=(32,), nnFunc="Tanh", batchSize=12,
+          maxTotObsNum=900, randSeed=2),
+     dict(seed=4, dimS=576, dimA=2, lenMin=3, lenMax=12, pTerm=0.4), 25, 5),
+    # ... or, when they are not (11 x 11 image, filter 3, stride 2), through the all-taps kernel
+    (dict(dimS=507, dimA=2, nAppendedObs=0, conv=[(13, 13, 3, 8, 3, 1), (11, 11, 8, 12, 3, 2)], hidden=(32,), nnFunc="Tanh", batchSize=12,
+          maxTotObsNum=900, randSeed=2),
+     dict(seed=4, dimS=507, dimA=2, lenMin=3, lenMax=12, pTerm=0.4), 25, 5),
     # odd geometry: 3 input channels, 5 filters, 7x9 image, stride 1, filter 3 (channel and position tiles partly empty)
     (dict(dimS=189, dimA=2, nAppendedObs=0, conv=[(9, 7, 3, 5, 3, 1)], hidden=(32,), nnFunc="SoftSign", batchSize=10,
           maxTotObsNum=800, randSeed=6),
