@@ -246,8 +246,13 @@ __host__ __device__ inline size_t convDxLds(const ConvGeo& g, int IT) {
   const int KKp = convPad4(g.KnC * g.KnY * g.KnX);
   return (size_t)IT * 16 * (KKp + 4) * 4 + (size_t)KKp * 4;
 }
-template <int IT, int NK>     // input-channel tiles per workgroup; MFMA steps (0: run-time)
+// KS waves share the reduction of one tile (NK > 0): the chain per wavefront is NK / KS steps, partial tiles meet in LDS in wave
+// order (fixed summation order), the first wave of a tile applies act' and stores
+template <int IT, int NK>     // input-channel tiles per workgroup (NK > 0: 1, the tile of blockIdx.y); MFMA steps (0: run-time)
 __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
+  constexpr int KS = NK > 0 ? 4 / IT : 1;      // waves per tile
+  const int itBase = NK > 0 ? blockIdx.y : 0;
+  __shared__ float sRed[4][256];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvGeo g = a.L[l];
   const ConvGeo gp = a.L[l - 1];                    // the layer whose outputs are this layer's inputs
@@ -255,11 +260,11 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
   float* Wx = reinterpret_cast<float*>(smem);                          // [IT*16][ldKK]   Wx[ic][(c, fy, fx)]
   int* kTab = reinterpret_cast<int*>(Wx + (size_t)IT * 16 * ldKK);     // [KKp]   c * P | fy << 20 | fx << 26   (-1: padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  constexpr int PW = 4 / IT;
+  constexpr int PW = 4 / (IT * KS);
   const unsigned R = (unsigned)a.B * (unsigned)Pin;
-  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx, IT * 16 * ldKK);
-  const int it = wave % IT;
-  const unsigned tile = blockIdx.x * PW + wave / IT;
+  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx + (size_t)itBase * 16 * ldKK, IT * 16 * ldKK);
+  const int it = wave % IT, ks = (wave / IT) % KS;
+  const unsigned tile = blockIdx.x * PW + wave / (IT * KS);
   const unsigned r = tile * 16 + li;
   const bool ok = r < R;
   const unsigned rr = ok ? r : 0;
@@ -285,15 +290,30 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* wRow = Wx + (it * 16 + li) * ldKK + lc;
   if constexpr (NK > 0) {
-    float bv[NK];
+    constexpr int NS = NK / KS;
+    static_assert(NK % KS == 0, "steps divide over the waves");
+    float bv[NS];
 #pragma unroll
-    for (int s = 0; s < NK; ++s) bv[s] = gatherD(4 * s + lc);
+    for (int s = 0; s < NS; ++s) bv[s] = gatherD(4 * (ks * NS + s) + lc);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < NK; ++s) {
-      const float av = wRow[4 * s];
+    for (int s = 0; s < NS; ++s) {
+      const float av = wRow[4 * (ks * NS + s)];
       if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc1, 0, 0, 0);
       else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc0, 0, 0, 0);
+    }
+    if constexpr (KS > 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sRed[wave][q * 64 + lane] = acc0[q] + acc1[q];
+      __syncthreads();
+      if (ks != 0) return;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = sRed[wave][q * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < KS; ++w) v += sRed[wave + w * IT][q * 64 + lane];
+        acc0[q] = v; acc1[q] = 0.f;
+      }
     }
   } else {
     constexpr int UN = 8;
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
   if (!ok) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int ic = it * 16 + lc * 4 + q;
+    const int ic = (itBase + it) * 16 + lc * 4 + q;
     if (ic < g.InC) {
       const size_t o = (size_t)bb * gp.ldOut + (size_t)ic * Pin + qq;
       gp.D[o] = (acc0[q] + acc1[q]) * softsignDiff(gp.X[o]);
@@ -326,6 +346,10 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
 // (class, sample, position inside the class), NK = KnC (KnY / S)(KnX / S) / 4 steps instead of KnC KnY KnX / 4
 template <int IT, int NK>
 __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsigned tilesPerClass) {
+  constexpr int KS = NK > 0 ? 4 / IT : 1;
+  __shared__ float sRed[4][256];
+  const int itBase = NK > 0 ? blockIdx.y : 0;
+  const int rowsAll = (a.L[l].InC + 15) & ~15;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvGeo g = a.L[l];
   const ConvGeo gp = a.L[l - 1];
@@ -334,13 +358,13 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
   float* Wx = reinterpret_cast<float*>(smem);                          // [IT*16][ld]   this class's Wx[ic][(c, ty, tx)]
   int* kTab = reinterpret_cast<int*>(Wx + (size_t)IT * 16 * ld);       // [KKp]   c * P | ty << 20 | tx << 26   (-1: padding)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  constexpr int PW = 4 / IT;
+  constexpr int PW = 4 / (IT * KS);
   const unsigned Rc = (unsigned)a.B * (unsigned)Pc;
-  const unsigned tile = blockIdx.x * PW + wave / IT;
+  const unsigned tile = blockIdx.x * PW + wave / (IT * KS);
   const int cls = (int)(tile / tilesPerClass);                         // uniform over the workgroup (tilesPerClass is a multiple of PW)
   const unsigned tIn = tile - (unsigned)cls * tilesPerClass;
-  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx + (size_t)cls * IT * 16 * ld, IT * 16 * ld);
-  const int it = wave % IT;
+  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx + ((size_t)cls * rowsAll + (size_t)itBase * 16) * ld, IT * 16 * ld);
+  const int it = wave % IT, ks = (wave / IT) % KS;
   const unsigned r = tIn * 16 + li;
   const bool ok = r < Rc;
   const unsigned rr = ok ? r : 0;
@@ -363,15 +387,30 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* wRow = Wx + (it * 16 + li) * ld + lc;
   if constexpr (NK > 0) {
-    float bv[NK];
+    constexpr int NS = NK / KS;
+    static_assert(NK % KS == 0, "steps divide over the waves");
+    float bv[NS];
 #pragma unroll
-    for (int s = 0; s < NK; ++s) bv[s] = gatherD(4 * s + lc);
+    for (int s = 0; s < NS; ++s) bv[s] = gatherD(4 * (ks * NS + s) + lc);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < NK; ++s) {
-      const float av = wRow[4 * s];
+    for (int s = 0; s < NS; ++s) {
+      const float av = wRow[4 * (ks * NS + s)];
       if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc1, 0, 0, 0);
       else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc0, 0, 0, 0);
+    }
+    if constexpr (KS > 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sRed[wave][q * 64 + lane] = acc0[q] + acc1[q];
+      __syncthreads();
+      if (ks != 0) return;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = sRed[wave][q * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < KS; ++w) v += sRed[wave + w * IT][q * 64 + lane];
+        acc0[q] = v; acc1[q] = 0.f;
+      }
     }
   } else {
     constexpr int UN = 8;
@@ -393,46 +432,46 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
   if (!ok) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int ic = it * 16 + lc * 4 + q;
+    const int ic = (itBase + it) * 16 + lc * 4 + q;
     if (ic < g.InC) {
       const size_t o = (size_t)bb * gp.ldOut + (size_t)ic * Pin + qq;
       gp.D[o] = (acc0[q] + acc1[q]) * softsignDiff(gp.X[o]);
     }
   }
 }
-template <int IT, int NK> static hipError_t launchConvDxsT(const ConvArgs& a, int l, hipStream_t s) {
+template <int IT, int NK> static hipError_t launchConvDxsT(const ConvArgs& a, int l, int ity, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const int KKp = convPad4(convClassK(g));
   const size_t lds = (size_t)IT * 16 * (KKp + 4) * 4 + (size_t)KKp * 4;
-  constexpr int PW = 4 / IT;
+  constexpr int PW = NK > 0 ? 1 : 4 / IT;
   const long long Rc = (long long)a.B * (g.InY / g.S) * (g.InX / g.S);
   unsigned tpc = (unsigned)((Rc + 15) / 16); tpc = (tpc + PW - 1) / PW * PW;
   const int blocks = (int)((long long)g.S * g.S * tpc / PW);
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dxs_kernel<IT, NK>), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((conv_dxs_kernel<IT, NK>), dim3(blocks), dim3(256), lds, s, a, l, tpc);
+  hipLaunchKernelGGL((conv_dxs_kernel<IT, NK>), dim3(blocks, ity), dim3(256), lds, s, a, l, tpc);
   return hipGetLastError();
 }
 template <int IT> static hipError_t launchConvDxsC(const ConvArgs& a, int l, hipStream_t s) {
   const int nk = convPad4(convClassK(a.L[l])) / 4;
-  if (nk == 36) return launchConvDxsT<IT, 36>(a, l, s);         // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
-  return launchConvDxsT<IT, 0>(a, l, s);
+  if (nk == 36) return launchConvDxsT<1, 36>(a, l, IT, s);         // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
+  return launchConvDxsT<IT, 0>(a, l, 1, s);
 }
-template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, hipStream_t s) {
+template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, int ity, hipStream_t s) {
   const size_t lds = convDxLds(a.L[l], IT);
-  constexpr int PW = 4 / IT;
+  constexpr int PW = NK > 0 ? 1 : 4 / IT;       // (NK > 0: the four waves of a workgroup share one tile's reduction)
   const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dx_kernel<IT, NK>), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((conv_dx_kernel<IT, NK>), dim3(blocks), dim3(256), lds, s, a, l);
+  hipLaunchKernelGGL((conv_dx_kernel<IT, NK>), dim3(blocks, ity), dim3(256), lds, s, a, l);
   return hipGetLastError();
 }
 template <int IT> static hipError_t launchConvDxC(const ConvArgs& a, int l, long long R, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const int nk = convPad4(g.KnC * g.KnY * g.KnX) / 4;
-  if (nk == 128) return launchConvDxT<IT, 128>(a, l, R, s);      // 32 filters of 4 x 4
-  if (nk == 144) return launchConvDxT<IT, 144>(a, l, R, s);      // 16 of 6 x 6, 64 of 3 x 3
-  return launchConvDxT<IT, 0>(a, l, R, s);
+  if (nk == 128) return launchConvDxT<1, 128>(a, l, R, IT, s);      // 32 filters of 4 x 4
+  if (nk == 144) return launchConvDxT<1, 144>(a, l, R, IT, s);      // 16 of 6 x 6, 64 of 3 x 3
+  return launchConvDxT<IT, 0>(a, l, R, 1, s);
 }
 hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s) {
   const ConvGeo& g = a.L[l];
