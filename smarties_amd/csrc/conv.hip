@@ -139,21 +139,26 @@ template <int MAXQ> __device__ __forceinline__ void stageFlat(float* dst, const 
   }
 }
 
-template <int CT, int NK>     // channel tiles per workgroup (1, 2, 4); MFMA steps (0: run-time)
+// KS = 4 (small layers: few position tiles): the four wavefronts share ONE tile's reduction, the channel tile comes from
+// blockIdx.y -- four times the workgroups, a quarter of the chain per wavefront; partial tiles meet in LDS in wave order
+template <int CT, int NK, int KS = 1>     // channel tiles per workgroup (1, 2, 4); MFMA steps (0: run-time); waves per tile
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
+  static_assert(KS == 1 || (CT == 1 && NK > 0 && NK % KS == 0), "split tiles: one channel tile per workgroup");
+  __shared__ float sRed[KS > 1 ? 4 : 1][256];
+  const int ctBase = KS > 1 ? blockIdx.y : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvGeo g = a.L[l];
   const int K = g.K, Kp = convPad4(K), ldK = Kp + 4, P = g.P;
   float* Ws = reinterpret_cast<float*>(smem);                         // [CT*16][ldK]
   int* kOff = reinterpret_cast<int*>(Ws + (size_t)CT * 16 * ldK);     // [Kp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  constexpr int PW = 4 / CT;                                           // position tiles per workgroup
+  constexpr int PW = 4 / (CT * KS);                                    // position tiles per workgroup
   const int nRows = a.sc->nRows[a.parity];
   const unsigned R = (unsigned)nRows * (unsigned)P;                   // (rows x positions < 2^31, checked at creation)
   if (blockIdx.x * PW * 16u >= R) return;                             // whole workgroup beyond the minibatch
-  stageFlat<(NK > 0 ? (CT * 16 * (NK + 1) + 255) / 256 : 5)>(Ws, g.Wf, CT * 16 * ldK);     // one batch of loads when the shape is known
-  const int ct = wave % CT;
-  const unsigned tile = blockIdx.x * PW + wave / CT;
+  stageFlat<(NK > 0 ? (CT * 16 * (NK + 1) + 255) / 256 : 5)>(Ws, g.Wf + (size_t)ctBase * 16 * ldK, CT * 16 * ldK);     // one batch of loads when the shape is known
+  const int ct = wave % CT, ks = (wave / CT) % KS;
+  const unsigned tile = blockIdx.x * PW + wave / (CT * KS);
   // this lane's output position and the origin of its patch in the input image (the index arithmetic overlaps the
   // weight fetch)
   const unsigned r = tile * 16 + li;
@@ -172,15 +177,29 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* wRow = Ws + (ct * 16 + li) * ldK + lc;
   if constexpr (NK > 0) {
-    float bv[NK];
+    constexpr int NS = NK / KS;
+    float bv[NS];
 #pragma unroll
-    for (int s = 0; s < NK; ++s) bv[s] = inRow[kOff[4 * s + lc]];
+    for (int s = 0; s < NS; ++s) bv[s] = inRow[kOff[4 * (ks * NS + s) + lc]];
     __builtin_amdgcn_sched_barrier(0);          // all gathers are in flight before the first MFMA
 #pragma unroll
-    for (int s = 0; s < NK; ++s) {
-      const float av = wRow[4 * s];
+    for (int s = 0; s < NS; ++s) {
+      const float av = wRow[4 * (ks * NS + s)];
       if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc1, 0, 0, 0);
       else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc0, 0, 0, 0);
+    }
+    if constexpr (KS > 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sRed[wave][q * 64 + lane] = acc0[q] + acc1[q];
+      __syncthreads();
+      if (ks != 0) return;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = sRed[0][q * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < KS; ++w) v += sRed[w][q * 64 + lane];
+        acc0[q] = v; acc1[q] = 0.f;
+      }
     }
   } else {
     constexpr int UN = 8;
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   const float* Bl = a.W + g.indB;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int ch = ct * 16 + lc * 4 + q;
+    const int ch = (ctBase + ct) * 16 + lc * 4 + q;
     if (ch < g.KnC) {
       const float x = (acc0[q] + acc1[q]) + Bl[(size_t)ch * P + pp];
       const size_t o = (size_t)bb * g.ldOut + (size_t)ch * P + pp;
@@ -213,6 +232,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
 }
 
 template <int CT, int NK> static hipError_t launchConvFwdT(const ConvArgs& a, int l, long long R, hipStream_t s) {
+  if constexpr (NK > 0) {
+    if (R <= 16 * 1024) {          // few position tiles: split every tile's reduction over the four wavefronts
+      const size_t lds1 = convFwdLds(a.L[l], 1);
+      hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_fwd_kernel<1, NK, 4>), lds1);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((conv_fwd_kernel<1, NK, 4>), dim3((unsigned)((R + 15) / 16), (a.L[l].KnC + 15) / 16), dim3(256), lds1, s, a, l);
+      return hipGetLastError();
+    }
+  }
   const size_t lds = convFwdLds(a.L[l], CT);
   constexpr int PW = 4 / CT;
   const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
