@@ -44,6 +44,3 @@ for nm in ("step_tail_kernel", "stack_gather", "conv_prep", "conv_fwd0", "conv_f
     print("  %-18s %8.2f us  x%d" % (nm, ms.value * 1e3, n.value)); tot += ms.value * 1e3
 print("  sum %.1f us" % tot)
 api.fn("timing_enable")(L.h, 0)
-for pid, nm in ((3, "head, no rider"), (23, "head + sampler rider"), (12, "empty")):
-    try: print("  profile %-22s %.2f us" % (nm, L.kernel_profile(pid, 100)))
-    except Exception as e: print("  profile", nm, "n/a", e)
