@@ -248,6 +248,8 @@ def main():
 
     from smarties_amd import capi, load_hip
 
+    # replicas reach their first collectives seconds apart (set-up, graph capture): a generous bound for the exchange kernel's wait
+    os.environ.setdefault("SMARTIES_HIP_XCHG_TIMEOUT_MS", "60000")
     api = load_hip()
     cfg = capi.make_config(n_ranks=n_ranks, rank=rank, device_id=local_rank % ndev, **CFG)
     per = N_EPISODES // n_ranks
