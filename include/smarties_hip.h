@@ -364,7 +364,9 @@ HL_API int hl_comm_init(hl_learner* h, const uint8_t id[128]);
  * the peers' windows (hipIpc between processes, plain pointers between learners of one process), copies rank 0's weights to
  * every replica like hl_comm_init and makes hl_initialize / hl_step use this exchange (it takes precedence over a
  * communicator of hl_comm_init).  A peer that does not answer within SMARTIES_HIP_XCHG_TIMEOUT_MS (default 5000) raises the
- * learner's device error instead of hanging the GPU. */
+ * learner's device error instead of hanging the GPU.  Replicas of ONE process wait for each other inside kernels, so each needs a
+ * hardware queue of its own: HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) queues -- raise it for more replicas per
+ * process; one process per GPU, the usual layout, is not affected. */
 #define HL_XCHG_HANDLE_BYTES 96
 HL_API int hl_xchg_export(hl_learner* h, uint8_t handle[HL_XCHG_HANDLE_BYTES]);
 HL_API int hl_xchg_connect(hl_learner* h, const uint8_t* handles /* n_ranks x HL_XCHG_HANDLE_BYTES */);

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# several replicas of ONE process that wait for each other inside kernels (test_one_kernel_exchange_among_several_replicas) need a
+# hardware queue each: HIP maps streams onto 4 by default, a fifth stream shares one -- and a waiting kernel then blocks its peer
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -489,6 +489,66 @@ def test_one_kernel_exchange_between_two_replicas(hip_api):
     assert coll(X[0].h) == coll(X[1].h) >= 1005
 
 
+@pytest.mark.parametrize("n_ranks", [3, 4])
+def test_one_kernel_exchange_among_several_replicas(hip_api, n_ranks):
+    """The exchange among 3 and 4 replicas (one thread each, all on this GPU): every replica sums the contributions in rank order, so
+    all end bit-identical; against host-formed sums in the same order -- ((g0 + g1) + g2) + g3 in fp32 -- over eager calls, replayed
+    graphs and a 1000th-step sweep.  (Batch 24 splits 3 x 8 and 4 x 6.)"""
+    from oracle_api import synth_episode
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=24, maxTotObsNum=6000, randSeed=11)
+    sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+
+    def replicas(connect):
+        Ls = []
+        for r in range(n_ranks):
+            L = hip_learner(hip_api, capi.make_config(n_ranks=n_ranks, rank=r, **cfg_kw))
+            L.init_weights()
+            for e in range(r, 60, n_ranks):
+                L.append_episode(**synth_episode(sc, e))
+            Ls.append(L)
+        w0 = Ls[0].get_params()[0]
+        for L in Ls:
+            w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2); L.initialize()
+        if connect:
+            handles = [L.xchg_export() for L in Ls]
+            _both(Ls, lambda L: L.xchg_connect(handles))
+        return Ls
+
+    def host_step(Ls):
+        for L in Ls:
+            L.step_begin()
+        gs = [L.grad_fetch() for L in Ls]
+        g = gs[0].copy()
+        for q in gs[1:]:
+            g = (g + q).astype(np.float32)                    # rank order, fp32
+        ms = [L.moments_fetch() for L in Ls]
+        c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+        m = None
+        if ms[0] is not None:
+            m = ms[0].copy()
+            for q in ms[1:]:
+                m = m + q
+        for L in Ls:
+            L.grad_store(g)
+            if m is not None:
+                L.moments_store(m)
+            L.counters_store(c)
+            L.step_end()
+
+    X, H = replicas(True), replicas(False)
+    assert X[0].B == 24 // n_ranks
+    for n in (1, 2, 20, 70, 900, 12):
+        _both(X, lambda L: (L.step(n), L.sync()))
+        for _ in range(n):
+            host_step(H)
+        for r in range(n_ranks):
+            for a, b in zip(X[r].get_params(), H[r].get_params()):
+                assert np.array_equal(a, b), (n, r)
+            assert X[r].scalars().beta == H[r].scalars().beta
+        for r in range(1, n_ranks):
+            assert np.array_equal(X[0].get_params()[0], X[r].get_params()[0])
+
+
 def test_one_kernel_exchange_at_start_up(hip_api):
     """Connected BEFORE hl_initialize: rank 0's weights reach rank 1, the start-up counters and reward / state moments are summed
     over both shards (Learner::initializeLearner with several learners) -- the scaling equals that of ONE learner holding all
