@@ -1740,6 +1740,7 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
   HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
   rc = dropPresample(h); if (rc) return rc;
+  if (h->cfg.dataSamplingAlgo != HL_SAMPLE_UNIFORM) return fail(h, HL_ERR_UNSUPPORTED, "kernel profiles replay captured launches: not with the prioritised samplers (their table is rebuilt per minibatch)");
   if ((which == 1 || which == 21) && (h->buf[0].fwdIdx.empty() || h->buf[0].fwdIdx[0] < 0)) return fail(h, HL_ERR_UNSUPPORTED, "no dense first layer to profile (convolutional preprocessing)");
   if ((which == 2 || which == 22 || which == 4 || which == 24) && (h->recurrent || h->buf[0].fwdIdx.empty())) return fail(h, HL_ERR_UNSUPPORTED, "dense-layer profiles do not apply to recurrent networks");
   h->dbgVariant = variant;
