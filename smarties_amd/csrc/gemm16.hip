@@ -282,13 +282,23 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
 
 // the weight-gradient launch of the fused path: the problem table travels in the kernel arguments
 // (scalar loads from the kernarg segment instead of two dependent global round trips)
-__global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
+// (the two riders' arguments travel unpacked: two whole ExtraArgs records would push the kernel-argument segment past 4 KB)
+__global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevScalars* __restrict__ sc, AdamHyper hyp, int postOn, PostArgs post,
+                                                       int sampPhases, int helpers, SampleArgs samp) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
 #ifdef HL_TAIL_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 73) const_cast<DevScalars*>(sc)->dbgT[29] = wall_clock64();
 #endif
-  const int nRiders = extra.role ? 1 : 0;
-  if ((int)blockIdx.x < nRiders) { runExtra(extra, smem); return; }
+  // riders: the bookkeeping of this step, then the index -> (episode, step) search of the NEXT minibatch (drawn and sorted by the
+  // rider of the fused kernel) and the workgroups that gather it -- the sampler's dependency chain is split over both kernels
+  const int r1 = postOn ? 1 : 0, r2 = sampPhases ? 1 + helpers : 0, nRiders = r1 + r2;
+  if ((int)blockIdx.x < nRiders) {
+    const int b = blockIdx.x;
+    if (b < r1) postPhase(post, smem);
+    else if (b == r1) samplePhases(samp, sampPhases, smem);
+    else gatherHelper(samp, b - r1 - 1, helpers, smem);
+    return;
+  }
   const int bid = blockIdx.x - nRiders;
   int p = 0;
 #pragma unroll
@@ -332,9 +342,12 @@ hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN
   return hipGetLastError();
 }
 
-hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
-  ExtraArgs ex{}; if (extra) ex = *extra;
-  hipLaunchKernelGGL(dw_table_kernel, dim3(nBlocks + (ex.role ? 1 : 0)), dim3(256), 0, s, tbl, sc, hyp, ex);
+hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s,
+                           const ExtraArgs* extra2) {
+  PostArgs post{}; SampleArgs samp{}; int postOn = 0, phases = 0, helpers = 0;
+  if (extra && extra->role == 2) { post = extra->post; postOn = 1; }
+  if (extra2 && extra2->role == 1) { samp = extra2->samp; phases = extra2->phases; helpers = extra2->helpers; }
+  hipLaunchKernelGGL(dw_table_kernel, dim3(nBlocks + postOn + (phases ? 1 + helpers : 0)), dim3(256), 0, s, tbl, sc, hyp, postOn, post, phases, helpers, samp);
   return hipGetLastError();
 }
 

@@ -37,6 +37,7 @@ struct DevScalars {
   // if the host has to discard that minibatch -- new episodes, an eviction, explicit indices -- it puts this state back)
   unsigned rngBakPos;
   unsigned rngBak[624];
+  long long sampleSeq;            // minibatches drawn so far (sampler phase A): hand-off tag when the gather rides along the dW kernel
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };
 

@@ -31,6 +31,8 @@ struct SampleArgs {
   int computeEta;         // also derive DevScalars::etaEff[parity] (first step of a launch sequence)
   int perAlgo;            // HL_SAMPLE_*: the prioritised samplers draw through the cumulative table `perCp` (per.hip)
   const double* perCp; long long perN;   // cumulative probabilities of the perN transitions (PERrank, PERerr) or episodes (PERseq); perN < 2: always 0
+  int tagSeq;             // gather hand-off tag: 0 = nStep + 1 (nothing in the publishing kernel changes nStep), 1 = sampleSeq (the dW kernel:
+                          // its bookkeeping rider advances nStep while the sampler's phase C and the gather helpers run)
   int noGather;           // phase C stops after the index -> (episode, step) search: the states are gathered by
                           // stack_gather_kernel (appended observations / convolutional input, conv.hip)
   int backupRng;          // keep the generator state as of before the draws in DevScalars::rngBak (pre-sampling riders)
@@ -180,7 +182,10 @@ hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStr
 enum { GEMM_ROLE_FWD0 = 0, GEMM_ROLE_FWD = 1, GEMM_ROLE_DX = 2, GEMM_ROLE_DW = 3 };
 constexpr int DW_TABLE_MAX = 8;
 struct DwTable { GemmProblem p[DW_TABLE_MAX]; int n; };
-hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
+// riders: `extra` (bookkeeping of this step) in workgroup 0, `extra2` (sampler phase C of the next minibatch, PH_PUBLISH) behind it,
+// followed by extra2->helpers gather workgroups
+hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s,
+                           const ExtraArgs* extra2 = nullptr);
 // up to two riders (extra, extra2) occupy workgroups 0 and 1 of the grid
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);

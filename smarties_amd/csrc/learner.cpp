@@ -1779,7 +1779,7 @@ extern "C" HL_API int hl_debug_kernel_time(hl_learner* h, int which, int reps, i
         // fused path: 26 = forward+head+dX (+ sampler phases A,B), 27 = dW+Adam (+ phase C, bookkeeping),
         // 28 / 29 = the same two kernels without riders
         case 26: rc = h->fusedOk ? launchFused(h, 0, h->stream, true) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
-        case 27: rc = h->fusedOk ? launchWeightGrad(h, 0, true, h->stream, true, false) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
+        case 27: rc = h->fusedOk ? launchWeightGrad(h, 0, true, h->stream, true, true) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
         case 28: rc = h->fusedOk ? launchFused(h, 0, h->stream, false) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
         case 29: rc = h->fusedOk ? launchWeightGrad(h, 0, true, h->stream, false, false) : fail(h, HL_ERR_UNSUPPORTED, "fused kernel not used for this network"); break;
         default: break;

@@ -267,7 +267,8 @@ FusedArgs fusedArgs(hl_learner* h, int parity) {
 int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
   const FusedArgs fa = fusedArgs(h, parity);
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
-  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_ALL | PH_PUBLISH); pex = &ex; }
+  // (draws, sort, redraws of the next minibatch here; its search and gather ride along the dW kernel: launchWeightGrad)
+  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
   HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
   return HL_OK;
 }
@@ -335,9 +336,10 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
   ExtraArgs exP{}, exC{};
   if (fusePost) { exP.role = 2; exP.post = postArgs(h, parity, postMode); }
   if (nextSampleC) exC = extraSample(h, parity ^ 1, PH_C);
-  if (sb.dwCount <= DW_TABLE_MAX && !nextSampleC) {   // problem table in the kernel arguments
+  if (sb.dwCount <= DW_TABLE_MAX) {   // problem table in the kernel arguments
     const DwTable& tbl = fuseAdam ? sb.dwTableAdam : sb.dwTable;
-    HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s); }));
+    if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; }
+    HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s, nextSampleC ? &exC : nullptr); }));
     return HL_OK;
   }
   HIPCK(timed(h, "gemm16_dw", s, [&] {
@@ -576,11 +578,11 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
     const int p = (p0 + j) & 1;
     if (h->fusedOk) {
       rc = launchFused(h, p, s0, true); if (rc) break;
-      if (!exchanging(h)) { rc = launchWeightGrad(h, p, true, s0, true, false); if (rc) break; continue; }
+      if (!exchanging(h)) { rc = launchWeightGrad(h, p, true, s0, true, true); if (rc) break; continue; }
       // replicas: the exchange is part of the replayed graph (RCCL calls are captured like kernels).  ONE collective per
       // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (four exact 16-bit
       // chunks each), the pass after Adam decodes their sums.
-      rc = launchWeightGrad(h, p, false, s0, true, false, POST_AGG);
+      rc = launchWeightGrad(h, p, false, s0, true, true, POST_AGG);
       if (!rc && h->xchg.on) { rc = xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p); if (rc) break; continue; }
       if (!rc) rc = allreduceGrad(h);
       if (!rc) rc = launchAdam(h, p);
@@ -662,7 +664,7 @@ int replaySteps(hl_learner* h, long long avail, int* done) {
     for (int j = 0; j < U; ++j) {
       const int p = (p0 + j) & 1;
       int rc = launchFused(h, p, h->stream, true); if (rc) return rc;
-      rc = launchWeightGrad(h, p, true, h->stream, true, false); if (rc) return rc;
+      rc = launchWeightGrad(h, p, true, h->stream, true, true); if (rc) return rc;
     }
     h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;
     *done = U;

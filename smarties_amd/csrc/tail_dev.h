@@ -403,7 +403,7 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
   if (rngNeeded) {
     const bool bak = a.backupRng && (phases & PH_A);
     for (int k = tid; k < 624; k += 256) { const unsigned v = sc->rng[k]; x[k] = v; if (bak) sc->rngBak[k] = v; }
-    if (tid == 0) { const unsigned p0 = sc->rngPos; *sPos = (int)p0; if (bak) sc->rngBakPos = p0; }
+    if (tid == 0) { const unsigned p0 = sc->rngPos; *sPos = (int)p0; if (bak) sc->rngBakPos = p0; if (phases & PH_A) sc->sampleSeq += 1; }
   }
   const unsigned long long nData = (unsigned long long)sc->nTransitions;
   const int nEp = (int)sc->nEpisodes;
@@ -492,7 +492,7 @@ __device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* sme
   if (phases & PH_PUBLISH) {   // the gather is done by the helper workgroups (gatherHelper)
     __builtin_amdgcn_s_waitcnt(0);     // the agent-scope stores of slot / nextOf are acknowledged
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(sc->gatherFlag + a.parity, sc->nStep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(sc->gatherFlag + a.parity, a.tagSeq ? -sc->sampleSeq : sc->nStep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TSTAMP(sc, 9);
     return;
   }
@@ -542,7 +542,7 @@ __device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int 
   if (part == 0) TSTAMP(sc, 21);
   for (int i = tid; i < dS; i += 256) { sMean[i] = a.rp.stMean[i]; sScale[i] = a.rp.stScale[i]; }
   if (tid == 0) {
-    const long long want = sc->nStep + 1;
+    const long long want = a.tagSeq ? -sc->sampleSeq : sc->nStep + 1;       // (negative: never equal to a tag of the other kind)
     int spins = 0;
     while (__hip_atomic_load(sc->gatherFlag + a.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
       __builtin_amdgcn_s_sleep(2);
