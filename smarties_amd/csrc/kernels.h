@@ -210,6 +210,17 @@ hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, 
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
                              int nDense, int dA, int n, double* O, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+// rollout inference for a few agents (misc.hip: act_forward_kernel): the whole dense network for one raw state per workgroup, states
+// read from and outputs written to pinned host memory, completion stamped per row
+constexpr int ACT_MAXW = 1024, ACT_MAXROWS = 64;
+struct ActLayer { int nIn, size, ldW, func, hasRes, resW; long long indW, indB, indWr, indBr; };
+struct ActArgs {
+  const float* W; const float* stMean; const float* stScale;
+  const float* in; double* out; volatile unsigned* done; unsigned tag;      // pinned host memory (device-mapped)
+  int dS, dIn, nL, nDense, nSig, nOut, ldWo; long long indWo, indBo, indBp;
+  ActLayer L[HL_MAX_HIDDEN];
+};
+hipError_t launch_act_forward(const ActArgs& a, int n, hipStream_t s);
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);
 hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s);
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);          // partial sums + final sum

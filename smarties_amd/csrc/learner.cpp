@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <atomic>
 #include <unistd.h>
 #include <cstring>
 #include <deque>
@@ -100,6 +101,7 @@ struct hl_learner {
   // MemoryBuffer.cpp:486-487): the value of the last gradient step's statistics pass, taken BEFORE that step's removals;
   // 0 before the first step.  Computed on the device when needed (dStatsIns), at most once per step.
   double* dStatsIns = nullptr; bool statsFresh = false, anyStep = false;
+  unsigned char* actPin = nullptr; unsigned actTag = 0; bool actFastOk = false;     // rollout inference of a few agents (hl_forward)
   // prioritised samplers (per.hip): probabilities / cumulative table of the stored transitions, rebuilt before every minibatch
   float *perProb = nullptr, *perKey = nullptr, *perKeyS = nullptr; double* perCp = nullptr; unsigned *perIdx = nullptr, *perIdxS = nullptr;
   void* perTemp = nullptr; size_t perTempBytes = 0; long long perCap = 0;
@@ -604,6 +606,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     h->convDwBlocks = blk;
   }
   h->recurrent = cfg->nn_type != HL_NN_FFNN;
+  h->actFastOk = !h->recurrent && h->nConv == 0 && getenv("SMARTIES_HIP_NO_ACT_KERNEL") == nullptr;
+  for (int j = 0; j < h->nHidden; ++j) if (h->hid[j].size > ACT_MAXW || h->hid[j].nIn > ACT_MAXW) h->actFastOk = false;
   if (h->recurrent) {
     h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
     const size_t R = (size_t)B * h->recK;
@@ -688,6 +692,7 @@ int hl_destroy(hl_learner* h) {
   timerFlush(h);
   invalidateGraphs(h);
   if (h->comm) ncclCommDestroy(h->comm);
+  if (h->actPin) hipHostFree(h->actPin);
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
   for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
@@ -1485,6 +1490,35 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   HL_LOCK(h);
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward between hl_step_begin and hl_step_end");
   if (h->recurrent) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
+  // a few agents, dense network: one kernel, states and outputs through pinned host memory (misc.hip: act_forward_kernel)
+  if (n > 0 && n <= ACT_MAXROWS && h->nConv == 0 && h->dIn <= ACT_MAXW && h->actFastOk) {
+    if (!h->actPin) {
+      const size_t bytes = (size_t)ACT_MAXROWS * (h->dIn * sizeof(float) + h->nOut * sizeof(double) + sizeof(unsigned)) + 256;
+      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->actPin), bytes, hipHostMallocMapped));
+      std::memset(h->actPin, 0, bytes);
+    }
+    double* pOut = reinterpret_cast<double*>(h->actPin);
+    float* pIn = reinterpret_cast<float*>(pOut + (size_t)ACT_MAXROWS * h->nOut);
+    volatile unsigned* pDone = reinterpret_cast<volatile unsigned*>(pIn + (size_t)ACT_MAXROWS * h->dIn);
+    std::memcpy(pIn, states, (size_t)n * h->dIn * sizeof(float));
+    ActArgs aa{}; aa.W = h->W; aa.stMean = h->rp.stMean; aa.stScale = h->rp.stScale; aa.in = pIn; aa.out = pOut; aa.done = pDone;
+    aa.tag = ++h->actTag; if (aa.tag == 0) aa.tag = ++h->actTag;
+    aa.dS = h->dS; aa.dIn = h->dIn; aa.nL = h->nHidden; aa.nDense = h->nDense; aa.nSig = h->nSig; aa.nOut = h->nOut; aa.ldWo = h->ldWo;
+    aa.indWo = h->indWo; aa.indBo = h->indBo; aa.indBp = h->indBp;
+    for (int j = 0; j < h->nHidden; ++j) { const DevHidden& d = h->hid[j];
+      aa.L[j] = ActLayer{d.nIn, d.size, d.ldW, d.func, d.hasRes, d.resW, d.indW, d.indB, d.indWr, d.indBr}; }
+    HIPCK(launch_act_forward(aa, n, h->stream));
+    // the kernel stamps every row once its outputs are in host memory: poll the stamps (a stream synchronisation costs ~10 us
+    // more), give up after 2 s and fall back to it
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < n; ++r)
+      while (pDone[r] != aa.tag) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCK(hipStreamSynchronize(h->stream)); break; }
+      }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    std::memcpy(outputs, pOut, (size_t)n * h->nOut * sizeof(double));
+    return HL_OK;
+  }
   { int rc = dropPresample(h); if (rc) return rc; }      // the forward pass borrows minibatch buffer 0
   // (with appended observations a row holds the raw state of step t followed by those of t-1 .. t-nAppendedObs)
   if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->Mmax * h->dIn)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }

@@ -319,6 +319,56 @@ __global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY
   }
   if (lane < dA) O[(size_t)row * nOut + nDense + lane] = (double)W[indBp + lane];
 }
+// The network for ONE raw state per workgroup: what an environment thread needs per agent step (RACER::selectAction,
+// Learners/RACER.cpp:30-59 -> Approximator::forward(agent)).  The batched path above costs five launches and two staged copies
+// (47 us per call); here the state comes straight from pinned host memory, every layer is a per-thread dot product over the
+// previous layer's outputs in LDS (weights row-major: thread j reads W[k][j], coalesced), the outputs go back to pinned host
+// memory and a per-row stamp tells the waiting host thread that they are there.
+__global__ __launch_bounds__(256) void act_forward_kernel(ActArgs a) {
+  __shared__ float sA[ACT_MAXW], sB[ACT_MAXW];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* W = a.W;
+  for (int c = tid; c < a.dIn; c += 256) { const int k = c % a.dS; sA[c] = (a.in[(size_t)row * a.dIn + c] - a.stMean[k]) * a.stScale[k]; }
+  __syncthreads();
+  float* in = sA; float* out = sB;
+  for (int l = 0; l < a.nL; ++l) {
+    const ActLayer L = a.L[l];
+    for (int j = tid; j < L.size; j += 256) {
+      const float* w = W + L.indW + j;
+      float acc0 = W[L.indB + j], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      int k = 0;
+      for (; k + 8 <= L.nIn; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w[(size_t)(k + u) * L.ldW];
+        acc0 = fmaf(in[k], v[0], acc0); acc1 = fmaf(in[k + 1], v[1], acc1); acc2 = fmaf(in[k + 2], v[2], acc2); acc3 = fmaf(in[k + 3], v[3], acc3);
+        acc0 = fmaf(in[k + 4], v[4], acc0); acc1 = fmaf(in[k + 5], v[5], acc1); acc2 = fmaf(in[k + 6], v[6], acc2); acc3 = fmaf(in[k + 7], v[7], acc3);
+      }
+      for (; k < L.nIn; ++k) acc0 = fmaf(in[k], w[(size_t)k * L.ldW], acc0);
+      float y = actEval(L.func, (acc0 + acc1) + (acc2 + acc3));
+      if (L.hasRes && j < L.resW) y += in[j] * W[L.indWr + j] + W[L.indBr + j];       // ParametricResidualLayer::forward (Layers.h:347-361)
+      out[j] = y;
+    }
+    __syncthreads();
+    float* t = in; in = out; out = t;
+  }
+  // output layer (Linear) + ParamLayer: one output per wavefront at a time, lanes over the hidden units
+  const int H = a.L[a.nL - 1].size;
+  for (int o = wave; o < a.nDense; o += 4) {
+    float p = 0.f;
+    for (int k = lane; k < H; k += 64) p = fmaf(in[k], W[a.indWo + (long long)k * a.ldWo + o], p);
+    p = waveSumF(p);
+    if (lane == 0) a.out[(size_t)row * a.nOut + o] = (double)(p + W[a.indBo + o]);
+  }
+  if (tid < a.nSig) a.out[(size_t)row * a.nOut + a.nDense + tid] = (double)W[a.indBp + tid];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(const_cast<unsigned*>(a.done) + row, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_act_forward(const ActArgs& a, int n, hipStream_t s) {
+  hipLaunchKernelGGL(act_forward_kernel, dim3(n), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s) {
   hipLaunchKernelGGL(act_standardize_kernel, dim3((unsigned)(((long long)n * dIn + 255) / 256 + 1)), dim3(256), 0, s, sc, rp, S, n, dS, dIn, X0, ldX0);
   return hipGetLastError();
