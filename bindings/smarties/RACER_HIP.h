@@ -124,6 +124,14 @@ class RACER_HIP : public Learner
     bRecurrent = c.nn_type != HL_NN_FFNN; c.nnBPTTseq = (int32_t) S.nnBPTTseq;
     c.adv_kind = bDiscrete ? HL_ADV_DISCRETE : (bGaussAdv ? HL_ADV_GAUSSIAN : HL_ADV_ZERO);
     c.n_options = bDiscrete ? (int32_t) nA : 0;
+    // removal rule of an over-full replay and minibatch sampler (getERfilterAlgo, MemoryProcessing.cpp:261-298;
+    // Sampling::prepareSampler, Sampling.cpp:298-340)
+    c.ERoldSeqFilter = S.ERoldSeqFilter == "oldest" ? HL_ER_OLDEST : S.ERoldSeqFilter == "farpolfrac" ? HL_ER_FARPOLFRAC :
+                       S.ERoldSeqFilter == "maxkldiv" ? HL_ER_MAXKLDIV : S.ERoldSeqFilter == "minerror" ? HL_ER_MINERROR : -1;
+    if (c.ERoldSeqFilter < 0) die("ERoldSeqFilter setting not recognized.");
+    c.dataSamplingAlgo = S.dataSamplingAlgo == "uniform" ? HL_SAMPLE_UNIFORM : S.dataSamplingAlgo == "PERrank" ? HL_SAMPLE_PERRANK :
+                         S.dataSamplingAlgo == "PERerr" ? HL_SAMPLE_PERERR : S.dataSamplingAlgo == "PERseq" ? HL_SAMPLE_PERSEQ : -1;
+    if (c.dataSamplingAlgo < 0) die("Setting dataSamplingAlgo not recognized.");
     c.nAppendedObs = (int32_t) M.nAppendedObs;
     c.n_conv = (int32_t) M.conv2dDescriptors.size();
     if (c.n_conv > HL_MAX_CONV) die("too many convolutional layers for hl_config");

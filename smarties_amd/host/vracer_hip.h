@@ -60,6 +60,8 @@ struct HyperParameters {
   std::string nnType = "FFNN";      // "FFNN", "LSTM" or "MGU" (Network/Builder.cpp:48-117); nnBPTTseq: steps of truncated BPTT
   Uint nnBPTTseq = 16;
   std::string learner = "VRACER";   // "VRACER" (Zero_advantage) or "RACER" (Gaussian_advantage), AlgoFactory.cpp:109-152
+  std::string ERoldSeqFilter = "oldest";        // "oldest", "farpolfrac", "maxkldiv", "minerror" (MemoryProcessing.cpp:261-298)
+  std::string dataSamplingAlgo = "uniform";     // "uniform", "PERrank", "PERerr", "PERseq" (Sampling.cpp:298-340)
   Uint randSeed = 0;
 };
 
@@ -139,6 +141,12 @@ class VRACER {
     else if (hp.learner == "RACER") c.adv_kind = HL_ADV_GAUSSIAN;
     else die("learner " + hp.learner + " is not served by the HIP library");
     nAdv = c.adv_kind == HL_ADV_GAUSSIAN ? 1 + 2 * (int)M.dimAction : nOpt;
+    c.ERoldSeqFilter = hp.ERoldSeqFilter == "oldest" ? HL_ER_OLDEST : hp.ERoldSeqFilter == "farpolfrac" ? HL_ER_FARPOLFRAC :
+                       hp.ERoldSeqFilter == "maxkldiv" ? HL_ER_MAXKLDIV : hp.ERoldSeqFilter == "minerror" ? HL_ER_MINERROR : -1;
+    if (c.ERoldSeqFilter < 0) die("ERoldSeqFilter setting not recognized.");
+    c.dataSamplingAlgo = hp.dataSamplingAlgo == "uniform" ? HL_SAMPLE_UNIFORM : hp.dataSamplingAlgo == "PERrank" ? HL_SAMPLE_PERRANK :
+                         hp.dataSamplingAlgo == "PERerr" ? HL_SAMPLE_PERERR : hp.dataSamplingAlgo == "PERseq" ? HL_SAMPLE_PERSEQ : -1;
+    if (c.dataSamplingAlgo < 0) die("Setting dataSamplingAlgo not recognized.");
     c.batchSize = (int32_t)hp.batchSize; c.maxTotObsNum = (int64_t)hp.maxTotObsNum; c.minTotObsNum = (int64_t)hp.minTotObsNum;
     c.gamma = hp.gamma; c.lambda = hp.lambda; c.clipImpWeight = hp.clipImpWeight; c.penalTol = hp.penalTol;
     c.epsAnneal = hp.epsAnneal; c.learnrate = hp.learnrate; c.nnLambda = hp.nnLambda; c.explNoise = hp.explNoise;
