@@ -34,8 +34,9 @@ namespace hl {
 #define FUSED_NT 512        // threads per workgroup of the fused kernel
 #endif
 
-// development time stamps of workgroup (panel 0, tile 1), 100 MHz clock: -DHL_TAIL_STAMPS
-#if defined(HL_TAIL_STAMPS) && !defined(HL_NO_FSTAMP)
+// development time stamps of workgroup (panel 0, tile 1), 100 MHz clock: -DHL_FSTAMPS (its own flag: the tail stamps of
+// -DHL_TAIL_STAMPS use the same slots of DevScalars::dbgT)
+#if defined(HL_FSTAMPS)
 #define FSTAMP(i) do { if (threadIdx.x == 0 && panel == 0 && n == 1) a.sc->dbgT[i] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   constexpr int QO = (H * 2 + NT - 1) / NT;      // float4 per thread of Wout [H][8]
   constexpr int Q0 = (32 * H4 + NT - 1) / NT;    // float4 per thread of W0 (dS <= 32)
   constexpr int QS = 512 / NT;                   // state-tile elements per thread
-#if defined(HL_TAIL_STAMPS) && !defined(HL_NO_FSTAMP)
+#if defined(HL_FSTAMPS)
   if (threadIdx.x == 0 && blockIdx.x == 8 + 8) a.sc->dbgT[31] = wall_clock64();   // (panel 0, tile 1): kernel entry
 #endif
   const DevScalars* sc = a.sc;
