@@ -208,7 +208,7 @@ hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s);
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
-                             int nDense, int dA, int n, double* O, hipStream_t s);
+                             int nDense, int dA, int n, double* O, hipStream_t s, unsigned* done = nullptr, unsigned tag = 0);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 // rollout inference for a few agents (misc.hip: act_forward_kernel): the whole dense network for one raw state per workgroup, states
 // read from and outputs written to pinned host memory, completion stamped per row

@@ -1485,6 +1485,26 @@ int hl_restart(hl_learner* h, const char* base) {
 }
 
 // rollout inference: Approximator::forward(agent) for n states (RACER.cpp:30-59)
+// pinned, device-mapped staging of rollout inference: outputs [ACT_MAXROWS][nOut] f64 | states f32 | completion stamps
+static size_t actPinFloats(const hl_learner* h) { return std::max((size_t)ACT_MAXROWS * h->dIn, (size_t)std::max(h->recK, 1) * h->dS); }
+static int actPinEnsure(hl_learner* h) {
+  if (h->actPin) return HL_OK;
+  const size_t bytes = (size_t)ACT_MAXROWS * (h->nOut * sizeof(double) + sizeof(unsigned)) + actPinFloats(h) * sizeof(float) + 256;
+  HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->actPin), bytes, hipHostMallocMapped));
+  std::memset(h->actPin, 0, bytes);
+  return HL_OK;
+}
+// the kernel stamps a row once its outputs are in host memory: poll the stamps (a stream synchronisation costs ~10 us more),
+// give up after 2 s and fall back to it
+static int actWait(hl_learner* h, volatile unsigned* pDone, int n, unsigned tag) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < n; ++r)
+    while (pDone[r] != tag) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCK(hipStreamSynchronize(h->stream)); break; }
+    }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return HL_OK;
+}
 int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (!h || n < 0 || (n > 0 && (!states || !outputs))) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
@@ -1492,14 +1512,10 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   if (h->recurrent) return fail(h, HL_ERR_UNSUPPORTED, "forward of a recurrent net needs the agent's history");
   // a few agents, dense network: one kernel, states and outputs through pinned host memory (misc.hip: act_forward_kernel)
   if (n > 0 && n <= ACT_MAXROWS && h->nConv == 0 && h->dIn <= ACT_MAXW && h->actFastOk) {
-    if (!h->actPin) {
-      const size_t bytes = (size_t)ACT_MAXROWS * (h->dIn * sizeof(float) + h->nOut * sizeof(double) + sizeof(unsigned)) + 256;
-      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->actPin), bytes, hipHostMallocMapped));
-      std::memset(h->actPin, 0, bytes);
-    }
+    { int rc = actPinEnsure(h); if (rc) return rc; }
     double* pOut = reinterpret_cast<double*>(h->actPin);
     float* pIn = reinterpret_cast<float*>(pOut + (size_t)ACT_MAXROWS * h->nOut);
-    volatile unsigned* pDone = reinterpret_cast<volatile unsigned*>(pIn + (size_t)ACT_MAXROWS * h->dIn);
+    volatile unsigned* pDone = reinterpret_cast<volatile unsigned*>(pIn + actPinFloats(h));
     std::memcpy(pIn, states, (size_t)n * h->dIn * sizeof(float));
     ActArgs aa{}; aa.W = h->W; aa.stMean = h->rp.stMean; aa.stScale = h->rp.stScale; aa.in = pIn; aa.out = pOut; aa.done = pDone;
     aa.tag = ++h->actTag; if (aa.tag == 0) aa.tag = ++h->actTag;
@@ -1508,14 +1524,7 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
     for (int j = 0; j < h->nHidden; ++j) { const DevHidden& d = h->hid[j];
       aa.L[j] = ActLayer{d.nIn, d.size, d.ldW, d.func, d.hasRes, d.resW, d.indW, d.indB, d.indWr, d.indBr}; }
     HIPCK(launch_act_forward(aa, n, h->stream));
-    // the kernel stamps every row once its outputs are in host memory: poll the stamps (a stream synchronisation costs ~10 us
-    // more), give up after 2 s and fall back to it
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < n; ++r)
-      while (pDone[r] != aa.tag) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCK(hipStreamSynchronize(h->stream)); break; }
-      }
-    std::atomic_thread_fence(std::memory_order_acquire);
+    { int rc = actWait(h, pDone, n, aa.tag); if (rc) return rc; }
     std::memcpy(outputs, pOut, (size_t)n * h->nOut * sizeof(double));
     return HL_OK;
   }
@@ -1542,15 +1551,20 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
   if (!h->recurrent) return hl_forward(h, 1, states + (size_t)(nSteps - 1) * h->dS, outputs);
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
   if (nSteps > h->recK) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1");
-  if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)std::max(h->Mmax, h->recK) * h->dS)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
+  // states and outputs through pinned host memory, completion by stamp (as hl_forward): two launches, no staged copies
+  { int rc = actPinEnsure(h); if (rc) return rc; }
+  double* pOut = reinterpret_cast<double*>(h->actPin);
+  float* pIn = reinterpret_cast<float*>(pOut + (size_t)ACT_MAXROWS * h->nOut);
+  volatile unsigned* pDone = reinterpret_cast<volatile unsigned*>(pIn + actPinFloats(h));
+  std::memcpy(pIn, states, (size_t)nSteps * h->dS * sizeof(float));
+  unsigned tag = ++h->actTag; if (tag == 0) tag = ++h->actTag;
   const DevHidden& q = h->hid[h->nHidden - 1];
-  HIPCK(hipMemcpyAsync(h->dActS, states, (size_t)nSteps * h->dS * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = h->dActS; ra.actSteps = nSteps;
+  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = pIn; ra.actSteps = nSteps;
   HIPCK(launch_rec_forward(ra, h->stream));
   HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
-                          h->dActO, h->stream));
-  HIPCK(hipMemcpyAsync(outputs, h->dActO, (size_t)h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCK(hipStreamSynchronize(h->stream));
+                          pOut, h->stream, const_cast<unsigned*>(pDone), tag));
+  { int rc = actWait(h, pDone, 1, tag); if (rc) return rc; }
+  std::memcpy(outputs, pOut, (size_t)h->nOut * sizeof(double));
   return HL_OK;
 }
 

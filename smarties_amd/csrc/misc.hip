@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void act_standardize_kernel(DevScalars* sc, De
   if (i < (long long)n * dIn) { const int r = (int)(i / dIn), c = (int)(i - (long long)r * dIn), k = c % dS;
     X0[(size_t)r * ldX0 + c] = (S[i] - rp.stMean[k]) * rp.stScale[k]; }
 }
+// done != nullptr (one row, outputs in pinned host memory): the row is stamped once its outputs are visible to the host
 __global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo,
-                                                         long long indBp, int ldWo, int nDense, int dA, int n, double* O) {
+                                                         long long indBp, int ldWo, int nDense, int dA, int n, double* O, unsigned* done, unsigned tag) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, nOut = nDense + dA;
   if (row >= n) return;
   for (int o = 0; o < nDense; ++o) {
@@ -318,6 +319,11 @@ __global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY
     if (lane == 0) O[(size_t)row * nOut + o] = (double)(p + W[indBo + o]);
   }
   if (lane < dA) O[(size_t)row * nOut + nDense + lane] = (double)W[indBp + lane];
+  if (done) {
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(done + row, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 // The network for ONE raw state per workgroup: what an environment thread needs per agent step (RACER::selectAction,
 // Learners/RACER.cpp:30-59 -> Approximator::forward(agent)).  The batched path above costs five launches and two staged copies
@@ -374,8 +380,8 @@ hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, 
   return hipGetLastError();
 }
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
-                             int nDense, int dA, int n, double* O, hipStream_t s) {
-  hipLaunchKernelGGL(act_output_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Y, ldY, H, W, indWo, indBo, indBp, ldWo, nDense, dA, n, O);
+                             int nDense, int dA, int n, double* O, hipStream_t s, unsigned* done, unsigned tag) {
+  hipLaunchKernelGGL(act_output_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Y, ldY, H, W, indWo, indBo, indBp, ldWo, nDense, dA, n, O, done, tag);
   return hipGetLastError();
 }
 

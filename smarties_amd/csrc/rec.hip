@@ -873,9 +873,10 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
   __shared__ float sStates[18 * 32];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int layer = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform
-  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
-  const int T = min(a.nBPTT, t);
-  const int nextRow = a.bt.nextOf[b];
+  const bool acting = a.actStates != nullptr;                          // rollout inference: the agent's last states, nothing stored
+  const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
+  const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
+  const int nextRow = acting ? -1 : a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
   const RecLayer L = a.L[layer];
@@ -898,7 +899,8 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
   if (L.hasRes && c < L.resW) { wr = W[L.indWr + c]; br = W[L.indBr + c]; }
   for (int e = tid; e < nSteps * dS; e += 128) {
     const int kk = e / dS, i = e - kk * dS;
-    sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
+    const float raw = acting ? a.actStates[e] : a.rp.S[(size_t)(slot - T + kk) * dS + i];
+    sStates[e] = (raw - a.rp.stMean[i]) * a.rp.stScale[i];
   }
   for (int i = tid; i < 2 * NTMAX; i += 128) (&sV0[0][0])[i] = 0.f;
   for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
         const int cb = k & 1;
         if (k + 1 < nSteps && lane < dS) sV0[cb ^ 1][lane] = sStates[(k + 1) * dS + lane];       // (that copy was last read a step ago)
         float blk = 0.f;
-        lstm32LayerStep<NTMAX>(L, w, bias, sV0[cb], IN0, nIn, prevSt, wr, br, &sV0[cb ^ 1][IN0], blk, k <= T, (long long)b * a.K + k, lane);
+        lstm32LayerStep<NTMAX>(L, w, bias, sV0[cb], IN0, nIn, prevSt, wr, br, &sV0[cb ^ 1][IN0], blk, !acting && k <= T, (long long)b * a.K + k, lane);
         if (lane < NC) sV1[cb][lane] = blk;
       }
     } else {
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
       if (k >= 0) {
         const int cb = k & 1;
         float blk = 0.f;
-        lstm32LayerStep<NTMAX>(L, w, bias, sV1[cb], NC, NC, prevSt, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane);
+        lstm32LayerStep<NTMAX>(L, w, bias, sV1[cb], NC, NC, prevSt, wr, br, &sV1[cb ^ 1][NC], blk, !acting && k <= T, (long long)b * a.K + k, lane);
         if (lane < NC) {
           if (k == T) a.Yout[(size_t)b * a.ldY + lane] = blk;
           if (k == T + 1) a.Yout[(size_t)nextRow * a.ldY + lane] = blk;
@@ -1069,9 +1071,10 @@ __global__ __launch_bounds__(128) void mgu32_forward_wave_kernel(RecArgs a) {
   __shared__ float sStates[18 * 32];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int layer = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
-  const int T = min(a.nBPTT, t);
-  const int nextRow = a.bt.nextOf[b];
+  const bool acting = a.actStates != nullptr;                          // rollout inference: the agent's last states, nothing stored
+  const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
+  const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
+  const int nextRow = acting ? -1 : a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
   const RecLayer L = a.L[layer];
@@ -1092,7 +1095,8 @@ __global__ __launch_bounds__(128) void mgu32_forward_wave_kernel(RecArgs a) {
   if (L.hasRes && c < L.resW) { wr = W[L.indWr + c]; br = W[L.indBr + c]; }
   for (int e = tid; e < nSteps * dS; e += 128) {
     const int kk = e / dS, i = e - kk * dS;
-    sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
+    const float raw = acting ? a.actStates[e] : a.rp.S[(size_t)(slot - T + kk) * dS + i];
+    sStates[e] = (raw - a.rp.stMean[i]) * a.rp.stScale[i];
   }
   for (int i = tid; i < 2 * (IN0 + NC); i += 128) (&sV0[0][0])[i] = 0.f;
   for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(128) void mgu32_forward_wave_kernel(RecArgs a) {
         const int cb = k & 1;
         if (k + 1 < nSteps && lane < dS) sV0[cb ^ 1][lane] = sStates[(k + 1) * dS + lane];
         float blk = 0.f;
-        mgu32LayerStep<IN0>(L, win, wrec, bias, sV0[cb], sHF[0], nIn, wr, br, &sV0[cb ^ 1][IN0], blk, k <= T, (long long)b * a.K + k, lane);
+        mgu32LayerStep<IN0>(L, win, wrec, bias, sV0[cb], sHF[0], nIn, wr, br, &sV0[cb ^ 1][IN0], blk, !acting && k <= T, (long long)b * a.K + k, lane);
         if (lane < NC) sV1[cb][lane] = blk;
       }
     } else {
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(128) void mgu32_forward_wave_kernel(RecArgs a) {
       if (k >= 0) {
         const int cb = k & 1;
         float blk = 0.f;
-        mgu32LayerStep<NC>(L, win, wrec, bias, sV1[cb], sHF[1], NC, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane);
+        mgu32LayerStep<NC>(L, win, wrec, bias, sV1[cb], sHF[1], NC, wr, br, &sV1[cb ^ 1][NC], blk, !acting && k <= T, (long long)b * a.K + k, lane);
         if (lane < NC) {
           if (k == T) a.Yout[(size_t)b * a.ldY + lane] = blk;
           if (k == T + 1) a.Yout[(size_t)nextRow * a.ldY + lane] = blk;
@@ -1202,12 +1206,12 @@ __global__ __launch_bounds__(128) void mgu32_backward_wave_kernel(RecArgs a) {
 }
 
 static bool mgu32Wave(const RecArgs& a) {
-  return a.gates == 2 && a.actStates == nullptr && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
+  return a.gates == 2 && (a.actStates == nullptr || a.actSteps <= 17) && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
          a.L[0].nIn <= 32 && a.dS == a.L[0].nIn && a.K <= 17 && a.L[0].indW % 4 == 0 && a.L[1].indW % 4 == 0 && !a.L[0].hasRes;
 }
 // the wave-per-sample kernels serve the training pass of two LSTM layers of 32 cells each over up to 32 inputs and 17 steps
-static bool lstm32Wave(const RecArgs& a) {
-  return a.gates == 4 && a.actStates == nullptr && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
+static bool lstm32Wave(const RecArgs& a) {      // (forward: training windows and rollout inference; backward: training only)
+  return a.gates == 4 && (a.actStates == nullptr || a.actSteps <= 17) && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
          a.L[0].nIn <= 32 && a.dS == a.L[0].nIn && a.K <= 17 && a.L[0].indW % 4 == 0 && a.L[1].indW % 4 == 0 && !a.L[0].hasRes;
 }
 static size_t recLdsBytes(const RecArgs& a) {

@@ -1105,11 +1105,14 @@ def test_rollout_forward_matches_oracle(hip_api, cfg_kw, sc_kw):
 # BASELINE.json size: 1M-transition replay, 17/6, 2x256, B=256
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-def test_recurrent_acting_matches_oracle(hip_api):
+@pytest.mark.parametrize("kind,hidden", [(capi.NN_LSTM, (32, 32)), (capi.NN_MGU, (32, 32)),      # one wavefront per layer (weights in registers)
+                                         (capi.NN_LSTM, (24, 16)), (capi.NN_MGU, (24, 16, 8))],   # the general kernels
+                         ids=["lstm-2x32", "mgu-2x32", "lstm-24x16", "mgu-24x16x8"])
+def test_recurrent_acting_matches_oracle(hip_api, kind, hidden):
     """hl_forward_sequence: the agent's last min(nnBPTTseq, t) + 1 states forwarded from a zero recurrent state
     (MemoryBuffer::agentToMinibatch + Approximator::forward(agent)), after some training, windows of every length."""
-    cfg_kw = dict(dimS=6, dimA=2, bounded=[1, 0], hidden=(32, 32), nnFunc="Tanh", batchSize=16, maxTotObsNum=5000, randSeed=51,
-                  adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnBPTTseq=8)
+    cfg_kw = dict(dimS=6, dimA=2, bounded=[1, 0], hidden=hidden, nnFunc="Tanh", batchSize=16, maxTotObsNum=5000, randSeed=51,
+                  adv_kind=capi.ADV_GAUSSIAN, nn_type=kind, nnBPTTseq=8)
     G, O = _pair(hip_api, cfg_kw, synth_cfg(seed=43, dimS=6, dimA=2, lenMin=5, lenMax=40, pTerm=0.5), 40)
     G.step(5); O.step(5)
     rng = np.random.default_rng(5)
