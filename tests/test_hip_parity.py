@@ -1387,6 +1387,23 @@ def test_full_size_steps_match_oracle(full_size):
     assert np.allclose(np.concatenate([mG, sG, rG]), np.concatenate([mO, sO, rO]), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("algo", ["PERerr", "PERrank"])
+def test_full_size_prioritised_sampler(hip_api, algo):
+    """The prioritised samplers on the 1M-transition replay: the sequential normalisation / cumulative table runs over a million
+    values (977 blocks of the one-wavefront chain), the ranking over a million keys -- minibatches, generator and the errors the
+    steps write back equal the oracle's; sample indices sorted, unique and inside the buffer."""
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=1000000, randSeed=42, dataSamplingAlgo=algo)
+    sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=201, lenMax=201, pTerm=0.0)
+    G, O = _pair(hip_api, cfg_kw, sc, 5000)
+    for k in range(4):
+        G.step(1); O.step(1)
+        flat = G.readback(capi.TAP_FLAT)
+        assert np.array_equal(flat, O.readback(capi.TAP_FLAT)), k
+        assert flat.min() >= 0 and flat.max() < 1000000 and np.all(np.diff(flat) > 0)
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    _compare_step(G, O)
+
+
 def test_full_size_retrace_round_trip(full_size):
     """Property at full size: Retrace of a truncated episode satisfies its own recursion
     Q_t = r_{t+1} + gamma (V_{t+1} + min(1, rho_{t+1}) (Q_{t+1} - V_{t+1})) on the values the GPU holds."""
