@@ -2,7 +2,7 @@
 // ReplayMemory/Sampling.cpp:101-296): before every minibatch the reference rebuilds a std::discrete_distribution<Uint>
 // over all stored transitions (episodes).  libstdc++ normalises it with a SEQUENTIAL double-precision accumulate, divides,
 // and builds the cumulative table with a SEQUENTIAL partial_sum; the drawn indices depend on every rounding of those two
-// chains, so they are kept sequential here -- one wavefront walks the million values -- and cost what they cost the
+// chains, so they are kept sequential here -- one lane walks the million values -- and cost about what they cost the
 // reference: milliseconds per step (the samplers are not selected by any shipped settings file, and the importance weights
 // they define are not applied in this version of the reference, Approximator.h:196).  The draws themselves
 // (generate_canonical<double, 53> + lower_bound, sort / unique / redraw) run in the sampler kernel (tail_dev.h).
@@ -38,39 +38,57 @@ __global__ __launch_bounds__(256) void per_rank_kernel(PerArgs a, long long n) {
   a.prob[a.idxSorted[i]] = P;
 }
 
-__device__ __forceinline__ double readlaneD(double v, int l) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, l), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), l);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 // discrete_distribution::param_type::_M_initialize: sum = accumulate(p, 0.0); p /= sum; cp = partial_sum(p); cp.back() = 1.
-// One wavefront: every lane fetches 16 consecutive values (coalesced), the chain then visits them lane by lane through
-// v_readlane -- all lanes carry the same accumulator --, the lane whose value it was keeps the running sum it has to store.
+// One wavefront: its 64 lanes move blocks of 4096 values between global memory and LDS (coalesced), lane 0 walks a block
+// sequentially, sixteen LDS reads ahead of the dependent additions: 23 ms per step on a million transitions -- the chain of
+// two million dependent fp64 additions of a lone wavefront (11 ns each; overlapping the LDS reads with the additions changes
+// nothing; a first version passed the values lane to lane through v_readlane: 29 ms).  The CPU does the same chain in ~4 ms.
+constexpr int PER_BLK = 4096;
 __global__ __launch_bounds__(64) void per_scan_kernel(const float* __restrict__ prob, double* __restrict__ cp, long long n) {
+  __shared__ double sh[PER_BLK];
+  __shared__ double sSum;
   if (n < 2) return;                                   // (the distribution then always returns 0: nothing to build)
   const int lane = threadIdx.x;
-  constexpr int U = 16;
+  auto sync = [] { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); };      // one wavefront: LDS traffic settled
   double s = 0.0;
-  for (long long base = 0; base < n; base += 64 * U) {
-    double x[U];
+  for (long long base = 0; base < n; base += PER_BLK) {
+#pragma unroll 8
+    for (int j = lane; j < PER_BLK; j += 64) sh[j] = base + j < n ? (double)prob[base + j] : 0.0;    // (+ 0.0 behind the end: exact)
+    sync();
+    if (lane == 0) {
+      for (int j = 0; j < PER_BLK; j += 16) {
+        double v[16];
 #pragma unroll
-    for (int j = 0; j < U; ++j) { const long long e = base + (long long)lane * U + j; x[j] = e < n ? (double)prob[e] : 0.0; }
-    for (int l = 0; l < 64; ++l) {
+        for (int u = 0; u < 16; ++u) v[u] = sh[j + u];
 #pragma unroll
-      for (int j = 0; j < U; ++j) s += readlaneD(x[j], l);        // (+ 0.0 behind the end: exact)
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
     }
+    sync();
   }
+  if (lane == 0) sSum = s;
+  sync();
+  s = sSum;
   double acc = 0.0;
-  for (long long base = 0; base < n; base += 64 * U) {
-    double q[U], mine[U];
+  for (long long base = 0; base < n; base += PER_BLK) {
+#pragma unroll 8
+    for (int j = lane; j < PER_BLK; j += 64) sh[j] = base + j < n ? (double)prob[base + j] / s : 0.0;
+    sync();
+    if (lane == 0) {
+      for (int j = 0; j < PER_BLK; j += 16) {
+        double v[16];
 #pragma unroll
-    for (int j = 0; j < U; ++j) { const long long e = base + (long long)lane * U + j; q[j] = e < n ? (double)prob[e] / s : 0.0; mine[j] = 0.0; }
-    for (int l = 0; l < 64; ++l) {
+        for (int u = 0; u < 16; ++u) v[u] = sh[j + u];
 #pragma unroll
-      for (int j = 0; j < U; ++j) { acc += readlaneD(q[j], l); if (lane == l) mine[j] = acc; }
+        for (int u = 0; u < 16; ++u) { acc += v[u]; v[u] = acc; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sh[j + u] = v[u];
+      }
     }
-#pragma unroll
-    for (int j = 0; j < U; ++j) { const long long e = base + (long long)lane * U + j; if (e < n) cp[e] = e == n - 1 ? 1.0 : mine[j]; }
+    sync();
+#pragma unroll 8
+    for (int j = lane; j < PER_BLK; j += 64) { const long long e = base + j; if (e < n) cp[e] = e == n - 1 ? 1.0 : sh[j]; }
+    sync();
   }
 }
 
