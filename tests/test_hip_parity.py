@@ -416,7 +416,7 @@ def _xchg_replicas(hip_api, cfg_kw, sc, connect):
         L = hip_learner(hip_api, capi.make_config(n_ranks=2, rank=r, **cfg_kw))
         L.init_weights()
         for e in range(r, 40, 2):
-            L.append_episode(**synth_episode(sc, e))
+            L.append_episode(**synth_episode(sc, e, cfg_kw.get("n_options", 0)))
         Ls.append(L)
     if connect == "before":                   # the start-up statistics are then sums over both shards (hl_initialize exchanges them)
         handles = [L.xchg_export() for L in Ls]
@@ -463,13 +463,18 @@ def _host_sum_step(Ls):
         L.step_end()
 
 
-def test_one_kernel_exchange_between_two_replicas(hip_api):
+@pytest.mark.parametrize("extra", [{}, dict(hidden=(24, 16, 8), nnFunc="Tanh"), dict(hidden=(16, 16), nnFunc="Tanh", nn_type=capi.NN_LSTM, nnBPTTseq=4),
+                                   dict(adv_kind=capi.ADV_DISCRETE, n_options=4, dimA=1, bounded=[0])],
+                         ids=["fused-2x32", "generic-24x16x8", "lstm-2x16", "discrete-head"])
+def test_one_kernel_exchange_between_two_replicas(hip_api, extra):
     """hl_xchg_export / hl_xchg_connect (xchg.hip): each replica writes its gradient-and-counters message straight into the
     other's window and sums in rank order -- against the same two replicas with the sums formed on the host: weights, Adam
-    moments, beta and the generator bit for bit after eager calls, replayed graphs (the exchange kernel is a graph node) and
-    the 1000th-step sweep with its moments exchange; both replicas identical throughout."""
+    moments, beta and the generator bit for bit after eager calls, replayed graphs (the exchange kernel is a graph node; networks
+    the fused kernel does not serve step eagerly) and the 1000th-step sweep with its moments exchange; both replicas identical
+    throughout."""
     cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4096, randSeed=11)
-    sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+    cfg_kw.update(extra)
+    sc = synth_cfg(seed=3, dimS=5, dimA=cfg_kw["dimA"], lenMin=8, lenMax=30, pTerm=0.5)
     X = _xchg_replicas(hip_api, cfg_kw, sc, "after")      # (same start as H: initialised on the local shards, then connected)
     H = _xchg_replicas(hip_api, cfg_kw, sc, None)
     assert X[0].B == 8
