@@ -1015,7 +1015,7 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     const bool logStep = !h->logBase.empty() && (h->nGradSteps % 1000) == 0;   // StatsTracker::printToFile turn
     const bool plain = !flat && (k % 1000) != 0 && !logStep && !evictionDue(h) && !h->timing && h->useGraph &&
                        h->cfg.dataSamplingAlgo == HL_SAMPLE_UNIFORM &&      // (the prioritised samplers rebuild their table before every minibatch)
-                       (!exchanging(h) || (h->fusedOk && h->exchGraph && wired(h)));
+                       (!exchanging(h) || (h->exchGraph && wired(h)));
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
       // plain steps available before the next 1000-step sweep and within this call

@@ -347,11 +347,11 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
                        nextSampleC ? &exC : nullptr, s, fusePost ? &exP : nullptr); }));
   return HL_OK;
 }
-int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false) {
+int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
-  if (fusePost) { ex.role = 2; ex.post = postArgs(h, parity, POST_AGG | POST_BETA); pex = &ex; }
+  if (fusePost) { ex.role = 2; ex.post = postArgs(h, parity, postMode); pex = &ex; }
   char nm[32];
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
@@ -590,17 +590,26 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
       if (rc) break;
       continue;
     }
+    // networks off the fused path; replicas: the weight-gradient launches leave the gradient (bookkeeping rider: aggregates and
+    // the counters message only), then the exchange with Adam and the rest of the bookkeeping -- as in the fused branch
+    const bool exch = exchanging(h);
     if (h->recurrent) {      // window forward, head (+ the sampler of the next step), BPTT, weight gradients (+ bookkeeping)
       const RecArgs ra = recArgs(h, p);
       if (launch_rec_forward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_forward"); break; }
       rc = launchHead(h, p, s0, true); if (rc) break;
       if (launch_rec_backward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_backward"); break; }
-      rc = launchBackward(h, p, true, s0, true); if (rc) break;
-      continue;
+    } else {
+      rc = launchForward(h, p, s0, true); if (rc) break;
+      rc = launchHead(h, p, s0, true); if (rc) break;
     }
-    rc = launchForward(h, p, s0, true); if (rc) break;
-    rc = launchHead(h, p, s0, true); if (rc) break;
-    rc = launchBackward(h, p, true, s0, true); if (rc) break;
+    rc = launchBackward(h, p, !exch, s0, true, exch ? POST_AGG : (POST_AGG | POST_BETA)); if (rc) break;
+    if (exch) {
+      if (h->xchg.on) { rc = xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p); if (rc) break; continue; }
+      rc = allreduceGrad(h);
+      if (!rc) rc = launchAdam(h, p);
+      if (!rc) rc = launchPost(h, p, POST_BETA, s0);
+      if (rc) break;
+    }
   }
   hipError_t e = hipStreamEndCapture(s0, &slot->graph);
   h->nCollectives = nColl0;
@@ -638,7 +647,7 @@ bool graphUsable(const hl_learner* h, int U, int p0) {
 int captureAllGraphs(hl_learner* h) {
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
   static_assert(NS <= 16, "hl_learner::graphs is too small");
-  if (!h->useGraph || (exchanging(h) && !(h->fusedOk && h->exchGraph && wired(h)))) return HL_OK;
+  if (!h->useGraph || (exchanging(h) && !(h->exchGraph && wired(h)))) return HL_OK;
   for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
     if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
     const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);

@@ -1249,12 +1249,16 @@ def test_chained_replays_carry_the_next_minibatch_across_calls(hip_api, cfg_kw, 
 
 
 @pytest.mark.gpu
-def test_replicas_speak_one_wire_protocol_on_every_path(hip_api):
+@pytest.mark.parametrize("extra", [{}, dict(hidden=(24, 16, 8), nnFunc="Tanh"), dict(hidden=(16, 16), nnFunc="Tanh", nn_type=capi.NN_MGU, nnBPTTseq=4)],
+                         ids=["fused-2x32", "generic-24x16x8", "mgu-2x16"])
+def test_replicas_speak_one_wire_protocol_on_every_path(hip_api, extra):
     """With a communicator attached every step -- replayed or eager, with or without an eviction, with explicit indices --
     issues exactly ONE all-reduce (gradient || counters), the 1000th step one more (moments): replicas that take different
-    paths (their replays fill differently) still pair their collectives one to one."""
+    paths (their replays fill differently) still pair their collectives one to one.  (Networks off the fused path replay as
+    graphs with the captured collective too.)"""
     import ctypes as C
     cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=600, randSeed=42)
+    cfg_kw.update(extra)
     sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
     A, _ = _pair(hip_api, cfg_kw, sc, 30)
     Bq = hip_learner(hip_api, capi.make_config(**cfg_kw))
