@@ -144,9 +144,10 @@ typedef struct hl_config {
   int32_t n_ranks, rank;             /* learner replicas on this node                      */
   int32_t device_id;                 /* HIP device ordinal; -1 = rank % device count       */
   int32_t episode_order;             /* HL_ORDER_*                                         */
-  int32_t ref_threads;               /* OMP threads of the reference being mirrored: one
-                                        mt19937 draw per thread per Adam step
-                                        (Network/Optimizer.cpp:139); default 1            */
+  int32_t ref_threads;               /* OMP threads T of the reference run being mirrored (default 1): it seeds T - 1 further
+                                        generators from the main one (ExecutionInfo.cpp:392-393), which shifts the stream all
+                                        samples and weights are drawn from by T - 1 draws; per Adam step the main generator
+                                        gives one draw whatever T is (thread 0's, Network/Optimizer.cpp:139) */
   int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..32) of the ONE
                                         discrete action variable (dimA = 1; actions hold label + 0.1 as in
                                         Core/StateAction.h:322-341, policies the nOptions probabilities); else 0 */

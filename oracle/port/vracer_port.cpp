@@ -1057,7 +1057,7 @@ void adamApply(ol_learner* h) {
   // Optimizer.h:52-53: nnReal eta = eta_init; annealRate<nnReal>(eta, nStep, epsAnneal)
   const nnReal eta0 = (nnReal)h->cfg.learnrate;
   const nnReal _eta = (nnReal)(eta0 / (1 + (nnReal)h->nStep * h->cfg.epsAnneal));
-  for (int t = 0; t < std::max(1, h->cfg.ref_threads); ++t) (void)h->gen.next();  // Saru seed draw (:139)
+  (void)h->gen.next();  // Saru seed draw of thread 0 (:139): the other threads draw from generators of their own
   const nnReal betat1 = (nnReal)h->beta_t_1, betat2 = (nnReal)h->beta_t_2;
   const nnReal eta = _eta * std::sqrt(1 - betat2) / (1 - betat1);
   const nnReal B1 = (nnReal)0.9, B2 = (nnReal)0.999, lambda = (nnReal)h->cfg.nnLambda, fac = (nnReal)factor;
@@ -1116,6 +1116,7 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   h->minObsLocal = minObs / cfg->n_ranks;
   buildNet(h);
   h->gen.seed((uint32_t)(cfg->randSeed + (uint64_t)cfg->rank));   // ExecutionInfo.cpp:387,391
+  for (int t = 1; t < cfg->ref_threads; ++t) (void)h->gen.next();   // ... :392-393: T - 1 generators of the other threads seeded from it
   h->stMean.assign(h->dS, 0); h->stStd.assign(h->dS, 1); h->stScale.assign(h->dS, 1);
   h->beta = cfg->clipImpWeight <= 0 ? 1 : 1e-4;                     // MemoryBuffer.h:41-44
   h->CmaxRet = 1 + cfg->clipImpWeight; h->CinvRet = 1 / cfg->clipImpWeight;

@@ -343,6 +343,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       W.i64("erFilter", std::vector<int64_t>{f == "farpolfrac" ? 1 : (f == "maxkldiv" ? 2 : (f == "minerror" ? 3 : 0))});
       const std::string sa = H.HP->dataSamplingAlgo;
       W.i64("sampling", std::vector<int64_t>{sa == "PERrank" ? 1 : (sa == "PERerr" ? 2 : (sa == "PERseq" ? 3 : 0))});
+      W.i64("threads", std::vector<int64_t>{(int64_t)H.info.nThreads});
     }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

@@ -672,7 +672,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   s0.adam_bt1 = 0.9; s0.adam_bt2 = 0.999; s0.rewMean = 0; s0.rewScale = 1; s0.rewStd = 1;
   { HostMT g; uint32_t sd = (uint32_t)(cfg->randSeed + (uint64_t)cfg->rank); g.x[0] = sd;
     for (uint32_t i = 1; i < 624; ++i) g.x[i] = 1812433253u * (g.x[i - 1] ^ (g.x[i - 1] >> 30)) + i;
-    std::memcpy(s0.rng, g.x, sizeof(g.x)); s0.rngPos = 624; }
+    g.p = 624;
+    // a reference run with T OpenMP threads seeds T - 1 further generators from this one (ExecutionInfo.cpp:392-393): they feed
+    // only the other threads' Adam noise seeds, but the T - 1 draws shift the stream every sample is drawn from
+    for (int t = 1; t < cfg->ref_threads; ++t) (void)g.next();
+    std::memcpy(s0.rng, g.x, sizeof(g.x)); s0.rngPos = g.p; }
   HIPCK(hipMemcpy(h->sc, &s0, sizeof(s0), hipMemcpyHostToDevice));
   std::vector<float> ones(h->dS, 1.f);
   HIPCK(hipMemcpy(h->rp.stScale, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));

@@ -181,7 +181,7 @@ AdamHyper adamHyper(const hl_learner* h, int parity) {
 }
 SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool computeEta) {
   SampleArgs sa{}; sa.sc = h->sc; sa.rp = h->rp; sa.bt = h->buf[parity].bt; sa.B = h->B; sa.dS = h->dS; sa.ldX0 = h->ldX0;
-  sa.X0 = h->buf[parity].X0; sa.flatGiven = dFlat; sa.adamDraws = std::max(1, h->cfg.ref_threads);
+  sa.X0 = h->buf[parity].X0; sa.flatGiven = dFlat; sa.adamDraws = 1;      // thread 0's Saru seed: the only per-step draw from this generator (Optimizer.cpp:139, generators[thrID])
   // (recurrent layers read the raw states of their window straight from the replay: no gathered rows either)
   sa.parity = parity; sa.computeEta = computeEta ? 1 : 0; sa.backupRng = 0; sa.noGather = (h->preproc || h->recurrent) ? 1 : 0; sa.eta0 = (float)h->cfg.learnrate; sa.epsAnneal = h->cfg.epsAnneal;
   return sa;

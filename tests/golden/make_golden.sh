@@ -68,6 +68,10 @@ for F in PERrank PERerr PERseq; do
   "$DRV" fixture "$HERE/sample_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
      nSteps=30 gradSteps=1,30 maxObs=2000 minObs=300 sampling=$F
 done
+# G-threads: the reference run with THREE OpenMP threads: two more generators are seeded from the main one (ExecutionInfo.cpp:392-393:
+# the stream of weights and samples is shifted by two draws), the per-thread gradients are summed by reduceThreadsGrad
+"$DRV" fixture "$HERE/threads3.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=20 lenMin=5 lenMax=30 pTerm=0.5 \
+   nSteps=12 gradSteps=1,12 maxObs=1000 minObs=200 threads=3
 # G-hist: the importance-weight histogram the reference prints (MemoryProcessing::histogramImportanceWeights), captured from stdout
 "$DRV" fixture "$HERE/hist_small.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
    nSteps=40 tapSteps=2 gradSteps=40 maxObs=2000 minObs=300 muSpread=0.8 hist=1

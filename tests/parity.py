@@ -35,6 +35,8 @@ def fixture_config(fx, **over):
         kw["dataSamplingAlgo"] = int(fx["sampling"][0])
     if "erFilter" in fx:
         kw["ERoldSeqFilter"] = int(fx["erFilter"][0])
+    if "threads" in fx:          # OpenMP threads of the reference run that recorded the fixture
+        kw["ref_threads"] = int(fx["threads"][0])
     kw.update(over)
     return capi.make_config(**kw)
 

@@ -28,7 +28,7 @@ def hip_learner(hip_api, cfg):
 our_flat_for = flat_for
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin"])
 def test_init_weights_and_initialize_match_reference(hip_api, name):
     fx = load_fixture(name)
     L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
@@ -52,7 +52,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin"] + ACT_FIXTURES)
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin"] + ACT_FIXTURES)
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
@@ -162,6 +162,28 @@ def test_unknown_sampler_is_rejected(hip_api):
     cfg.dataSamplingAlgo = 7
     with pytest.raises(RuntimeError):
         capi.Learner(hip_api, cfg)
+
+
+def test_generator_stream_of_a_reference_run_with_three_threads(hip_api):
+    """ref_threads = 3 (tests/golden/threads3.bin, recorded with three OpenMP threads): the reference seeds two more generators from
+    the main one, so weights and every minibatch come from a stream shifted by two draws, and each Adam step takes ONE draw from
+    it whatever the thread count.  The library sampling on its own walks exactly that stream (the drawn flat indices too; which
+    transitions they denote depends on the storage order)."""
+    fx = load_fixture("threads3.bin")
+    assert int(fx["threads"][0]) == 3
+    L = hip_learner(hip_api, fixture_config(fx))
+    setup_from_fixture(L, fx)
+    assert np.array_equal(L.get_params()[0], fx["W0"]) and np.array_equal(L.get_rng_state(), fx["rng0"])
+    L.set_tap(True)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        if sk + "rng" in fx:
+            assert np.array_equal(L.get_rng_state(), fx[sk + "rng"]), k
+        L.step(1)
+        if sk + "flat" in fx:
+            assert np.array_equal(L.readback(capi.TAP_FLAT), fx[sk + "flat"]), k
+    one = hip_learner(hip_api, fixture_config(fx, ref_threads=1)); one.init_weights()
+    assert not np.array_equal(one.get_params()[0], fx["W0"])               # (one thread: another stream)
 
 
 def _pair(hip_api, cfg_kw, sc, n_eps):
