@@ -68,6 +68,13 @@ for F in PERrank PERerr PERseq; do
   "$DRV" fixture "$HERE/sample_$F.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
      nSteps=30 gradSteps=1,30 maxObs=2000 minObs=300 sampling=$F
 done
+# G-hp-*: hyper-parameters away from the shipped defaults (Retrace lambda < 1, other clip / tolerance / discount / annealing /
+# learning rate / exploration / output-weight / weight-decay values; clipImpWeight < 1 with its first-steps quirk)
+"$DRV" fixture "$HERE/hp_odd.bin" dimS=7 dimA=3 bounded=101 layers=24,24 nnFunc=Tanh batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.4 \
+   nSteps=40 gradSteps=1,40 maxObs=2000 minObs=300 clip=2 penalTol=0.2 gamma=0.9 lambda=0.8 epsAnneal=1e-4 learnrate=3e-4 \
+   explNoise=0.2 outWeightsPrefac=0.01 nnLambda=1e-5
+"$DRV" fixture "$HERE/hp_lowclip.bin" dimS=5 dimA=2 bounded=01 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.6 \
+   nSteps=40 gradSteps=1,40 maxObs=2000 minObs=300 clip=0.7 penalTol=0.05 gamma=0.99 lambda=0.95 epsAnneal=5e-3
 # G-threads: the reference run with THREE OpenMP threads: two more generators are seeded from the main one (ExecutionInfo.cpp:392-393:
 # the stream of weights and samples is shifted by two draws), the per-thread gradients are summed by reduceThreadsGrad
 "$DRV" fixture "$HERE/threads3.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=20 lenMin=5 lenMax=30 pTerm=0.5 \
