@@ -75,6 +75,17 @@ done
    explNoise=0.2 outWeightsPrefac=0.01 nnLambda=1e-5
 "$DRV" fixture "$HERE/hp_lowclip.bin" dimS=5 dimA=2 bounded=01 layers=16,16 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.6 \
    nSteps=40 gradSteps=1,40 maxObs=2000 minObs=300 clip=0.7 penalTol=0.05 gamma=0.99 lambda=0.95 epsAnneal=5e-3
+# G-combos: combinations the other fixtures do not hold: discrete head on LSTM layers (BPTT 5), Gaussian advantage on MGU layers
+# (BPTT 3, episodes shorter than the window), one hidden layer of 48 Relu units with four mixed-bound actions, two appended
+# observations in front of dense layers (no convolution)
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/discrete_lstm.bin" dimS=6 dimA=1 nOpt=5 layers=24,24 nnType=LSTM nnFunc=Tanh bptt=5 \
+   batch=12 nEps=30 lenMin=3 lenMax=25 pTerm=0.5 nSteps=20 gradSteps=1,20 maxObs=2000 minObs=200
+"$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/gauss_mgu.bin" dimS=6 dimA=2 bounded=01 layers=16,16 nnType=MGU nnFunc=Tanh bptt=3 \
+   batch=12 nEps=30 lenMin=2 lenMax=12 pTerm=0.5 nSteps=20 gradSteps=1,20 maxObs=2000 minObs=100
+"$DRV" fixture "$HERE/one_layer_relu.bin" dimS=9 dimA=4 bounded=0110 layers=48 nnFunc=Relu batch=20 nEps=30 lenMin=4 lenMax=25 pTerm=0.5 \
+   nSteps=20 gradSteps=1,20 maxObs=2000 minObs=200
+"$DRV" fixture "$HERE/appended_dense.bin" dimS=6 dimA=2 bounded=10 nApp=2 layers=32,32 batch=16 nEps=30 lenMin=4 lenMax=25 pTerm=0.5 \
+   nSteps=20 gradSteps=1,20 maxObs=2000 minObs=200
 # G-threads: the reference run with THREE OpenMP threads: two more generators are seeded from the main one (ExecutionInfo.cpp:392-393:
 # the stream of weights and samples is shifted by two draws), the per-thread gradients are summed by reduceThreadsGrad
 "$DRV" fixture "$HERE/threads3.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=20 lenMin=5 lenMax=30 pTerm=0.5 \

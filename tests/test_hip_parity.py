@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 ACT_FIXTURES = ["act_%s.bin" % f for f in ("LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp")]     # the other names of makeFunction (Functions.h:643-668)
 EVICT_FIXTURES = ["evict_%s.bin" % f for f in ("farpolfrac", "maxkldiv", "minerror")]      # ERoldSeqFilter (MemoryProcessing.cpp:261-298)
-FUNC_OF = {"hp_odd.bin": "Tanh", "deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
+FUNC_OF = {"hp_odd.bin": "Tanh", "discrete_lstm.bin": "Tanh", "gauss_mgu.bin": "Tanh", "one_layer_relu.bin": "Relu", "deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
 TOL32 = 1e-5     # north_star: 1e-5 relative fp32
 TOL64 = 1e-9
 
@@ -28,7 +28,7 @@ def hip_learner(hip_api, cfg):
 our_flat_for = flat_for
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "appended_dense.bin"])
 def test_init_weights_and_initialize_match_reference(hip_api, name):
     fx = load_fixture(name)
     L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
@@ -52,7 +52,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin"] + ACT_FIXTURES)
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "appended_dense.bin"] + ACT_FIXTURES)
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
