@@ -319,7 +319,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   Harness H(info, A);
   VRACER& L = *H.L;
   gLean = A.l("lean", 0) != 0;
-  const long nEps = A.l("nEps", 40), nSteps = A.l("nSteps", 10), tapSteps = A.l("tapSteps", nSteps);
+  const long nEps = A.l("nEps", 40), nSteps = A.l("nSteps", 10), tapSteps = A.l("tapSteps", nSteps), addEvery = A.l("addEvery", 0);
   const std::vector<Uint> gradSteps = parseList(A.s("gradSteps", "1,2"));
   const std::vector<Uint> retSteps = parseList(A.s("retSteps", ""));
   const bool official = A.s("path", "manual") == "official";
@@ -344,6 +344,8 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       const std::string sa = H.HP->dataSamplingAlgo;
       W.i64("sampling", std::vector<int64_t>{sa == "PERrank" ? 1 : (sa == "PERerr" ? 2 : (sa == "PERseq" ? 3 : 0))});
       W.i64("threads", std::vector<int64_t>{(int64_t)H.info.nThreads});
+      W.i64("addEvery", std::vector<int64_t>{(int64_t)A.l("addEvery", 0)});
+      W.i64("minObs", std::vector<int64_t>{(int64_t)H.HP->minTotObsNum});
     }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);
@@ -418,6 +420,9 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       for (auto g : gradSteps) if ((long)g == k) writeParams(W, sk + "gradSum", paramsOf(OPT->gradSum.get()));
       finishStep(H);
     }
+    // episodes that arrive while the learner trains (addEvery = n: one more synthetic episode behind every n-th step, as the
+    // data-collection tasks of a run would deliver them): time stamps, placeholder errors and removals of a replay in motion
+    if (addEvery > 0 && k % addEvery == 0) H.pushSynthEpisode((uint64_t)(nEps + k / addEvery - 1));
     for (auto g : gradSteps) if ((long)g == k) {
       writeParams(W, sk + "W", paramsOf(PW));
       writeParams(W, sk + "M1", paramsOf(OPT->_1stMom.get())); writeParams(W, sk + "M2", paramsOf(OPT->_2ndMom.get()));

@@ -35,10 +35,18 @@ def fixture_config(fx, **over):
         kw["dataSamplingAlgo"] = int(fx["sampling"][0])
     if "erFilter" in fx:
         kw["ERoldSeqFilter"] = int(fx["erFilter"][0])
+    if "minObs" in fx:           # (matters once episodes arrive during training: time stamps count from this many observations)
+        kw["minTotObsNum"] = int(fx["minObs"][0])
     if "threads" in fx:          # OpenMP threads of the reference run that recorded the fixture
         kw["ref_threads"] = int(fx["threads"][0])
     kw.update(over)
     return capi.make_config(**kw)
+
+
+def fixture_arrival(fx, k):
+    """Tag of the synthetic episode the recording run appended behind gradient step k (ref_driver addEvery=n), or None."""
+    n = int(fx["addEvery"][0]) if "addEvery" in fx else 0
+    return int(fx["cfg"][3]) + k // n - 1 if n > 0 and k % n == 0 else None
 
 
 def fixture_synth(fx):

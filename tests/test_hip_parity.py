@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle_api import oracle_learner, fill_synth, synth_cfg, synth_episode
-from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
+from parity import (load_fixture, fixture_config, fixture_synth, fixture_arrival, setup_from_fixture, relinf,
                     episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree, fx_vec_dev, flat_for)
 from smarties_amd import capi
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle_api import oracle_learner, synth_episode
-from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf,
+from parity import (load_fixture, fixture_config, fixture_synth, fixture_arrival, setup_from_fixture, relinf,
                     episode_arrays_by_tag, fixture_arrays_by_tag, stats_line, lines_agree, fx_vec_dev, flat_for)
 from smarties_amd import capi
 
@@ -56,7 +56,7 @@ def test_initialize_matches_reference(name):
     assert np.array_equal(L.get_rng_state(), fx["rng0"])
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin"] + ACT_FIXTURES + EVICT_FIXTURES + PER_FIXTURES)
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "moving_replay.bin"] + ACT_FIXTURES + EVICT_FIXTURES + PER_FIXTURES)
 def test_steps_match_reference(name):
     """Every tapped step: sampled flat indices / (episode, t) bit-exact (mt19937 + Lemire
     uniform_int + sort/unique/redraw + the reference's std::sort episode permutation); network
@@ -93,6 +93,9 @@ def test_steps_match_reference(name):
         assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-14 * abs(sca.beta)
         assert sca.CmaxRet == fx["traj_cmax"][k - 1]
         assert sca.nFarPolicySteps == fx["traj_nfar"][k - 1]
+        e = fixture_arrival(fx, k)
+        if e is not None:
+            L.append_episode(**synth_episode(fixture_synth(fx), e, getattr(L, "nOptions", 0)))
     w, _, _ = L.get_params()
     assert relinf(w, fx["Wfinal"]) < 1e-6
 
