@@ -158,7 +158,10 @@ struct Harness {
     info.randSeed = A.l("seed", 42); info.initialze();
     info.learners_train_comm = MPI_COMM_SELF; info.bIsMaster = true;
     info.nAgents = 1; info.nOwnedEnvironments = 1; info.nEnvironments = 1;
-    info.logAllSamples = 0; info.learnersOnWorkers = false; info.restart = "none";
+    info.logAllSamples = (int)A.l("rewlog", 0); info.learnersOnWorkers = false; info.restart = "none";
+    if (info.logAllSamples) {     // cumulative_rewards.dat / obs.raw of MemoryBuffer::pushBackEpisode go to a scratch directory
+      snprintf(info.initial_runDir, sizeof(info.initial_runDir), "%s", A.s("rewdir", "/tmp").c_str());
+    }
     const Uint dS = A.l("dimS", 17), dA = A.l("dimA", 6);
     MDP.dimState = dS; MDP.dimAction = dA;
     const std::string bnd = A.s("bounded", std::string(dA, '1'));
@@ -501,6 +504,14 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     for (Uint i = 0; i < T->n_stats; ++i) inst.push_back((double)T->instMean[i]);
     for (Uint i = 0; i < T->n_stats; ++i) inst.push_back((double)T->instStdv[i]);
     W.f64("outgrad_stats_last", inst);
+  }
+  if (A.l("rewlog", 0)) {   // what the reference wrote for every episode that entered the training set (MemoryBuffer.cpp:491-513)
+    const std::string dir = A.s("rewdir", "/tmp");
+    const std::string fr = dir + "/agent_00_rank_000_cumulative_rewards.dat", fo = dir + "/agent_00_rank_000_obs.raw";
+    std::vector<uint8_t> bytes; FILE* g = fopen(fr.c_str(), "rb");
+    if (g) { int c; while ((c = fgetc(g)) != EOF) bytes.push_back((uint8_t)c); fclose(g); }
+    remove(fr.c_str()); remove(fo.c_str());
+    W.u8("rewards_log", bytes);
   }
   if (A.l("hist", 0)) {   // the importance-weight histogram Learner::logStats prints with the profiler (Learner.cpp:139-144):
     // MemoryProcessing::histogramImportanceWeights writes to stdout only, which is pointed at a file for the call

@@ -89,7 +89,7 @@ done
 # G-moving: a replay in motion -- one more episode behind every second gradient step (time stamps counted from minTotObsNum
 # observations, placeholder errors from the running statistics) with the budget exceeded, so the oldest episodes leave all along
 "$DRV" fixture "$HERE/moving_replay.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=25 lenMin=5 lenMax=40 pTerm=0.5 \
-   nSteps=60 gradSteps=1,60 maxObs=600 minObs=200 addEvery=2
+   nSteps=60 gradSteps=1,60 maxObs=600 minObs=200 addEvery=2 rewlog=1 rewdir="$TMP"
 # G-threads: the reference run with THREE OpenMP threads: two more generators are seeded from the main one (ExecutionInfo.cpp:392-393:
 # the stream of weights and samples is shifted by two draws), the per-thread gradients are summed by reduceThreadsGrad
 "$DRV" fixture "$HERE/threads3.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=20 lenMin=5 lenMax=30 pTerm=0.5 \

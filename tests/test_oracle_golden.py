@@ -266,3 +266,26 @@ def test_checkpoint_files_match_reference(name, tmp_path):
 def test_packed_episode_wire_format_matches_reference(name):
     from parity import check_packed_roundtrip
     check_packed_roundtrip(oracle_learner, load_fixture(name))
+
+
+def test_episode_log_of_a_replay_in_motion_matches_reference(tmp_path):
+    """cumulative_rewards.dat (MemoryBuffer::pushBackEpisode, MemoryBuffer.cpp:491-513; --logAllSamples): one line
+    "nGradSteps timeStamp agentID nSteps totalReward" per episode entering the training set -- the file the compiled reference wrote
+    while moving_replay.bin was recorded (25 episodes before training, 30 behind every second gradient step: gradient-step counts and
+    time stamps from minTotObsNum observations on) against the oracle's, line by line.  (The harness uses the agent id as the
+    episode's content tag; the library's callers log agent 0.)"""
+    fx, L = make("moving_replay.bin")
+    L.set_episode_log(tmp_path / "rewards.dat")
+    setup_from_fixture(L, fx)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        L.step(1)
+        e = fixture_arrival(fx, k)
+        if e is not None:
+            L.append_episode(**synth_episode(fixture_synth(fx), e))
+    ref = bytes(fx["rewards_log"]).decode().splitlines()
+    mine = open(tmp_path / "rewards.dat").read().splitlines()
+    assert len(ref) == len(mine) == 55
+    for a, b in zip(ref, mine):
+        a, b = a.split(), b.split()
+        assert [a[0], a[1], a[3], a[4]] == [b[0], b[1], b[3], b[4]], (a, b)
+    assert ref[-1].split()[1] == "910"
