@@ -175,7 +175,9 @@ typedef struct hl_scalars {
   double beta, alpha, CmaxRet, CinvRet;            /* MemoryBuffer.h:41-44                 */
   int64_t nGradSteps, nStoredSteps, nStoredEps;
   int64_t nFarPolicySteps;                         /* ReplayStats::nFarPolicySteps          */
-  int64_t nSeenSteps, nSeenEps;
+  int64_t nSeenSteps, nSeenEps;                    /* ReplayCounters::nSeenTransitions / nSeenEpisodes: summed over the replicas, as of the
+                                                      last updateCounters (MemoryProcessing.cpp:60-61) -- what MemoryBuffer::getMetrics
+                                                      prints; this replica's live counters: hl_get_counts (the reference's *_loc) */
   double adam_beta_t_1, adam_beta_t_2;             /* Optimizer.h:96                        */
   int64_t adam_nStep;
 } hl_scalars;

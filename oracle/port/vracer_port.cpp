@@ -220,6 +220,9 @@ struct ol_learner {
   std::vector<nnReal> stMean, stStd, stScale; nnReal rewMean = 0, rewStd = 1, rewScale = 1;
   Real beta = 1e-4, alpha = 0.5, CmaxRet = 5, CinvRet = 0.25;
   int64_t nGradSteps = 0, nTransitions = 0, nSeenSteps = 0, nSeenEps = 0;
+  // ReplayCounters::nSeenEpisodes / nSeenTransitions: the (summed) counters as of the last updateCounters (MemoryProcessing.cpp:60-61)
+  // -- what nSeenEps() / nSeenSteps() return and the stats line prints; the live ones above are the reference's *_loc
+  int64_t seenEpsUpd = 0, seenStepsUpd = 0, seenEpsGlobal = 0, seenStepsGlobal = 0;
   int64_t nGatheredB4Startup = INT64_MAX;
   int64_t nFarGlobal = 0, nStoredGlobal = 0;  // result of counters reduction
   bool countersReduced = false, momentsPending = false;
@@ -829,7 +832,8 @@ void retraceEpisode(const ol_learner* h, Episode& EP) {
 // MemoryProcessing::updateCounters (MemoryProcessing.cpp:46-92)
 void updateCounters(ol_learner* h, bool /*bInit*/) {
   int64_t nFar = h->stats.nFarPolicySteps, nStored = h->nTransitions;
-  if (h->cfg.n_ranks > 1 && h->countersReduced) { nFar = h->nFarGlobal; nStored = h->nStoredGlobal; }
+  h->seenEpsUpd = h->nSeenEps; h->seenStepsUpd = h->nSeenSteps;
+  if (h->cfg.n_ranks > 1 && h->countersReduced) { nFar = h->nFarGlobal; nStored = h->nStoredGlobal; h->seenEpsUpd = h->seenEpsGlobal; h->seenStepsUpd = h->seenStepsGlobal; }
   h->countersReduced = false;
   const Real fracOffPol = nFar / (Real)std::max(nStored, (int64_t)1);
   const Real maxN = (Real)h->maxObsGlobal, BS = h->Bglobal;
@@ -1371,7 +1375,7 @@ int ol_grad_exchange(ol_learner* h, float* grad_io, int32_t write_back) {
 }
 int ol_counters_exchange(ol_learner* h, int64_t c[4], int32_t write_back) {
   if (!h || !c) return HL_ERR_BAD_ARG;
-  if (write_back) { h->nFarGlobal = c[2]; h->nStoredGlobal = c[3]; h->countersReduced = true; }
+  if (write_back) { h->seenEpsGlobal = c[0]; h->seenStepsGlobal = c[1]; h->nFarGlobal = c[2]; h->nStoredGlobal = c[3]; h->countersReduced = true; }
   else { c[0] = h->nSeenEps; c[1] = h->nSeenSteps; c[2] = h->stats.nFarPolicySteps; c[3] = h->nTransitions; }
   return HL_OK;
 }
@@ -1593,7 +1597,7 @@ int ol_get_scalars(ol_learner* h, hl_scalars* o) {
   if (!h || !o) return HL_ERR_BAD_ARG;
   o->beta = h->beta; o->alpha = h->alpha; o->CmaxRet = h->CmaxRet; o->CinvRet = h->CinvRet;
   o->nGradSteps = h->nGradSteps; o->nStoredSteps = h->nTransitions; o->nStoredEps = h->episodes.size();
-  o->nFarPolicySteps = h->stats.nFarPolicySteps; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
+  o->nFarPolicySteps = h->stats.nFarPolicySteps; o->nSeenSteps = h->seenStepsUpd; o->nSeenEps = h->seenEpsUpd;
   o->adam_beta_t_1 = h->beta_t_1; o->adam_beta_t_2 = h->beta_t_2; o->adam_nStep = h->nStep;
   return HL_OK;
 }

@@ -37,6 +37,8 @@ struct DevScalars {
   // if the host has to discard that minibatch -- new episodes, an eviction, explicit indices -- it puts this state back)
   unsigned rngBakPos;
   unsigned rngBak[624];
+  long long seenUpd[2];           // seen episodes / steps (summed over the replicas) as of the last updateCounters: ReplayCounters::nSeenEpisodes,
+                                  // nSeenTransitions (MemoryProcessing.cpp:60-61) -- what the stats line prints
   long long sampleSeq;            // minibatches drawn so far (sampler phase A): hand-off tag when the gather rides along the dW kernel
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };

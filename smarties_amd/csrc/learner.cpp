@@ -1200,8 +1200,8 @@ int hl_metrics(hl_learner* h, char* header, int32_t headerCap, char* line, int32
     }
     buff << " " << std::setw(5) << (long)h->order.size();
     buff << " " << std::setw(7) << (long)h->nTransitions;
-    buff << " " << std::setw(7) << (long)h->nSeenEps;
-    buff << " " << std::setw(8) << (long)h->nSeenSteps;
+    buff << " " << std::setw(7) << (long)sc.seenUpd[0];       // nSeenEps() / nSeenSteps(): as of the last updateCounters
+    buff << " " << std::setw(8) << (long)sc.seenUpd[1];
     buff << " " << std::setw(7) << (long)st.nFarPolicySteps;
     if (sc.Cmax > 1) real2SS(buff, sc.beta, 6, 1);
     // AdamOptimizer::getMetrics: L2 norm of the whole (padded) weight blob in long double
@@ -1630,7 +1630,7 @@ int hl_get_scalars(hl_learner* h, hl_scalars* o) {
   DevScalars s; rc = syncScalarsToHost(h, &s); if (rc) return rc;
   o->beta = s.beta; o->alpha = s.alpha; o->CmaxRet = s.Cmax; o->CinvRet = s.Cinv;
   o->nGradSteps = s.nGradSteps; o->nStoredSteps = h->nTransitions; o->nStoredEps = (int64_t)h->order.size();
-  o->nFarPolicySteps = s.nFarStat; o->nSeenSteps = h->nSeenSteps; o->nSeenEps = h->nSeenEps;
+  o->nFarPolicySteps = s.nFarStat; o->nSeenSteps = s.seenUpd[1]; o->nSeenEps = s.seenUpd[0];
   o->adam_beta_t_1 = s.adam_bt1; o->adam_beta_t_2 = s.adam_bt2; o->adam_nStep = s.nStep;
   return HL_OK;
 }
@@ -1648,9 +1648,14 @@ int hl_get_stats(hl_learner* h, hl_stats* o) {
   if (!h || !o) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
   int rc = flushPending(h); if (rc) return rc;
-  HIPCK(launch_stats(h->sc, h->rp, (int)h->order.size(), h->dStatsOut, h->stream));
+  // ReplayStats as of the last step's statistics pass (MemoryProcessing::updateTrainingStatistics): episodes that arrived since do
+  // not enter yet -- the snapshot taken before they were ingested (refreshInsertionStats) is that state; with no arrivals since
+  // the last step the aggregates the device holds now are
+  const double* src = h->dStatsOut;
+  if (h->statsFresh && h->anyStep) src = h->dStatsIns;
+  else HIPCK(launch_stats(h->sc, h->rp, (int)h->order.size(), h->dStatsOut, h->stream));
   double out[16];
-  HIPCK(hipMemcpyAsync(out, h->dStatsOut, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpyAsync(out, src, sizeof(out), hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
   o->avgKLdivergence = out[0]; o->avgSquaredErr = out[1]; o->maxAbsError = out[2]; o->avgReturn = out[3];
   o->avgQ = out[4]; o->stdevQ = out[5]; o->minQ = out[6]; o->maxQ = out[7]; o->nFarPolicySteps = (int64_t)out[8];

@@ -181,6 +181,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
         cntR[c] = v; sc->cnt[c] = v;
       }
     }
+    sc->seenUpd[0] = cntR[0]; sc->seenUpd[1] = cntR[1];
     const long long nFar = a.nRanks > 1 ? cntR[2] : nFarStat;
     const long long nStored = a.nRanks > 1 ? cntR[3] : nTrans;
     const double fracOffPol = (double)nFar / (double)(nStored > 1 ? nStored : 1);

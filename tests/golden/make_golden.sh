@@ -90,6 +90,10 @@ done
 # observations, placeholder errors from the running statistics) with the budget exceeded, so the oldest episodes leave all along
 "$DRV" fixture "$HERE/moving_replay.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=25 lenMin=5 lenMax=40 pTerm=0.5 \
    nSteps=60 gradSteps=1,60 maxObs=600 minObs=200 addEvery=2 rewlog=1 rewdir="$TMP"
+# ... and 1200 steps of it across the 1000-step sweep (400 arrivals: the replay turns over several times); its statistics line shows
+# that totEp / totObs are the counters as of the last step's update, not the instant's
+"$DRV" fixture "$HERE/moving_traj_1200.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=1000,1200 maxObs=1200 minObs=400 epsAnneal=5e-7 addEvery=3
 # G-threads: the reference run with THREE OpenMP threads: two more generators are seeded from the main one (ExecutionInfo.cpp:392-393:
 # the stream of weights and samples is shifted by two draws), the per-thread gradients are summed by reduceThreadsGrad
 "$DRV" fixture "$HERE/threads3.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=20 lenMin=5 lenMax=30 pTerm=0.5 \

@@ -810,6 +810,29 @@ def test_stats_line_matches_reference_log(hip_api):
 
 
 @pytest.mark.gpu
+def test_stats_line_with_episodes_arriving_between_steps(hip_api):
+    """totEp / totObs of the statistics line are the seen counters AS OF THE LAST updateCounters (ReplayCounters::nSeenEpisodes,
+    MemoryProcessing.cpp:60-61), not this instant's: episodes appended since the last step do not show yet (nEp / nObs, the stored
+    ones, do).  The oracle prints the compiled reference's line in that situation (moving_traj_1200.bin); the library prints the
+    oracle's."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=1200, minTotObsNum=400, randSeed=42)
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    G, O = _pair(hip_api, cfg_kw, sc, 30)
+    e = 30
+    for k in range(1, 43):
+        G.step(1); O.step(1)
+        if k % 3 == 0:
+            for L in (G, O):
+                L.append_episode(**synth_episode(sc, e))
+            e += 1
+    head, line = G.metrics()
+    assert lines_agree(line, stats_line(O), head, rel=2e-5), (line, stats_line(O))
+    seen = int(line.split()[head.replace("|", " ").split().index("totEp")])
+    assert seen == e - 1 == G.counts()[4] - 1                    # the episode appended behind step 39 shows, the one behind step 42 not yet
+    assert G.scalars().nSeenEps == O.scalars().nSeenEps == seen
+
+
+@pytest.mark.gpu
 def test_output_gradient_statistics_file_matches_reference(hip_api, tmp_path):
     """StatsTracker (Utils/StatsTracker.cpp): <learner>_net_outGrad_stats.raw as the compiled reference wrote
     it for the same 12 steps (one record, at step 0), and the mean / RMS over the last minibatch."""

@@ -194,16 +194,19 @@ def test_far_policy_masks_are_exercised():
     assert 0 < far.sum() < far.size
 
 
-@pytest.mark.parametrize("name", ["traj_1200.bin", "racer_traj_1200.bin"])
+@pytest.mark.parametrize("name", ["traj_1200.bin", "racer_traj_1200.bin", "moving_traj_1200.bin"])
 def test_long_trajectory_crosses_1000_step_sweep(tmp_path, name):
     """1200 steps: beta / CmaxRet / nFarPolicySteps trajectories, the 1000-step
-    Episode::updateCumulative + full Retrace sweep and the reward/state statistics EMA."""
+    Episode::updateCumulative + full Retrace sweep and the reward/state statistics EMA.  moving_traj_1200: with an episode
+    arriving behind every third step and the oldest ones leaving (400 arrivals, the replay turned over several times)."""
     fx, L = make(name)
     setup_from_fixture(L, fx)
     L.set_log_base(str(tmp_path / "agent_00"))
-    lens = {e: synth_episode(fixture_synth(fx), e)["rewards"].size for e in range(int(fx["cfg"][3]))}
+    lens = {e: synth_episode(fixture_synth(fx), e)["rewards"].size for e in range(int(fx["cfg"][3]) + 400)}
     for k in range(1, 1201):
         L.step(1)
+        if fixture_arrival(fx, k) is not None:          # (the recording run appended it right behind the step, before its dumps)
+            L.append_episode(**synth_episode(fixture_synth(fx), fixture_arrival(fx, k)))
         sca = L.scalars()
         assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-12 * abs(sca.beta), k
         assert sca.nFarPolicySteps == fx["traj_nfar"][k - 1], k
