@@ -327,6 +327,15 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   const std::vector<Uint> retSteps = parseList(A.s("retSteps", ""));
   const bool official = A.s("path", "manual") == "official";
   for (long e = 0; e < nEps; ++e) H.pushSynthEpisode((uint64_t)e);
+  // resume=<prefix>: instead of (or on top of) a synthetic fill, what Learner_approximator::restart does (Learner_approximator.cpp:
+  // 118-131) with the files an earlier run of this harness wrote through ckpt=<prefix> memck=<prefix>: network and Adam moments,
+  // replay memory with its counters and scaling, the optimizer's step count
+  const std::string resume = A.s("resume", "");
+  if (!resume.empty()) {
+    for (const auto& net : L.networks) net->restart(resume);
+    L.data->restart(resume);
+    for (const auto& net : L.networks) net->setNgradSteps(L.nGradSteps());
+  }
 
   BlobWriter W(out);
   Approximator& NET = *L.networks[0];

@@ -94,6 +94,12 @@ done
 # that totEp / totObs are the counters as of the last step's update, not the instant's
 "$DRV" fixture "$HERE/moving_traj_1200.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
    nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=1000,1200 maxObs=1200 minObs=400 epsAnneal=5e-7 addEvery=3
+# G-resume: one run writes its network and replay-memory checkpoints after 40 steps, a SECOND reference process restarts from them
+# (Learner_approximator::restart; initializeLearner is skipped for a restarted learner) and trains 20 more steps with taps
+"$DRV" fixture "$HERE/resume_first.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=40 gradSteps=1,40 maxObs=2000 minObs=500 ckpt="$TMP/resume_ck" memck="$TMP/resume_ck"
+"$DRV" fixture "$HERE/resume_second.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=0 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=20 gradSteps=1,20 maxObs=2000 minObs=500 resume="$TMP/resume_ck"
 # G-threads: the reference run with THREE OpenMP threads: two more generators are seeded from the main one (ExecutionInfo.cpp:392-393:
 # the stream of weights and samples is shifted by two draws), the per-thread gradients are summed by reduceThreadsGrad
 "$DRV" fixture "$HERE/threads3.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=16 nEps=20 lenMin=5 lenMax=30 pTerm=0.5 \

@@ -810,6 +810,51 @@ def test_stats_line_matches_reference_log(hip_api):
 
 
 @pytest.mark.gpu
+def test_resumed_run_follows_the_reference_after_its_own_restart(hip_api, tmp_path):
+    """Resume as the reference resumes (Learner_approximator::restart, Learner_approximator.cpp:118-131): one run of the compiled
+    reference trained 40 steps and wrote its network and replay-memory checkpoints (resume_first.bin carries the files), a SECOND
+    reference process restarted from them -- skipping initializeLearner, Learner.cpp:51-54 -- and trained 20 more steps with taps
+    (resume_second.bin).  The library restarted from the same files follows that second run: generator state before its first step,
+    outputs, importance weights, gradients, weights and Adam moments, beta.  (What the checkpoint does not hold restarts as in the
+    reference: Adam's running bias-correction factors begin again at beta_1, beta_2 while the step count continues.)"""
+    fa, fr = load_fixture("resume_first.bin"), load_fixture("resume_second.bin")
+    base = str(tmp_path / "ck")
+    for suf in ("_net_weights", "_net_1stMom", "_net_2ndMom"):
+        open(base + suf + ".raw", "wb").write(bytes(bytearray(fa["ckpt" + suf])))
+    for suf in ("_scaling", "_rank_000_learner_status", "_rank_000_learner_data"):
+        open(base + suf + ".raw", "wb").write(bytes(bytearray(fa["memck" + suf])))
+    L = hip_learner(hip_api, fixture_config(fr))
+    L.init_weights()                                  # (the restarted process builds and initialises its network first, too)
+    L.restart(base + "_net"); L.restart_memory(base)
+    assert np.array_equal(L.get_params()[0], fa["Wfinal"])
+    assert L.scalars().nGradSteps == 41 and L.scalars().nStoredSteps == int(fr["cfg"][7])     # (MemoryBuffer::save writes nGradSteps + 1)
+    assert np.array_equal(L.get_rng_state(), fr["s1_rng"])
+    assert abs(L.scalars().beta - fr["s1_beta"][0]) <= 1e-6 * fr["s1_beta"][0]       # (the status file holds 7 digits)
+    # the harness names episodes by agentID; restored episodes keep it in their wire record (trailer: terminated flag, ID, sampled
+    # count, agentID -- Episode.cpp:78-81), from which the (episode, t) pairs of the reference are mapped to this replay's indices
+    prefix, acc = {}, 0
+    for p in range(L.scalars().nStoredEps):
+        rec = L.pack_episode(p).tobytes()
+        prefix[int.from_bytes(rec[-40:][17:25], "little", signed=True)] = acc
+        acc += L.episode_info(p)[1] - 1
+    assert len(prefix) == 30
+    for k in range(1, int(fr["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        flat = np.array([prefix[int(g)] + int(t) for g, t in zip(fr[sk + "tag"], fr[sk + "t"])], np.int64)
+        order = np.argsort(flat, kind="stable")
+        L.step(1, flat=flat[order])
+        assert relinf(L.readback(capi.TAP_OUTPUT), fr[sk + "O"][order]) < TOL32, k
+        assert relinf(L.readback(capi.TAP_RHO), fr[sk + "rho"][order]) < TOL32, k
+        assert relinf(L.readback(capi.TAP_OUTGRAD), fr[sk + "G"][order]) < TOL32, k
+        assert np.array_equal(L.readback(capi.TAP_FAR), fr[sk + "far"][order]), k
+        if sk + "W" in fr:
+            w, m1, m2 = L.get_params()
+            assert relinf(w, fr[sk + "W"]) < TOL32 and relinf(m1, fr[sk + "M1"]) < TOL32 and relinf(m2, fr[sk + "M2"]) < 2 * TOL32, k
+        assert abs(L.scalars().beta - fr["traj_beta"][k - 1]) <= 2e-6 * fr["traj_beta"][k - 1], k
+    assert relinf(L.get_params()[0], fr["Wfinal"]) < TOL32
+
+
+@pytest.mark.gpu
 def test_stats_line_with_episodes_arriving_between_steps(hip_api):
     """totEp / totObs of the statistics line are the seen counters AS OF THE LAST updateCounters (ReplayCounters::nSeenEpisodes,
     MemoryProcessing.cpp:60-61), not this instant's: episodes appended since the last step do not show yet (nEp / nObs, the stored
