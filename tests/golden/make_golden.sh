@@ -94,6 +94,10 @@ done
 # that totEp / totObs are the counters as of the last step's update, not the instant's
 "$DRV" fixture "$HERE/moving_traj_1200.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
    nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=1000,1200 maxObs=1200 minObs=400 epsAnneal=5e-7 addEvery=3
+# G-crowded: batch 64 out of 93 stored transitions -- most draws collide, the sort / unique / redraw loop of Sample_uniform runs many
+# rounds per minibatch
+"$DRV" fixture "$HERE/crowded_sampler.bin" dimS=5 dimA=2 bounded=10 layers=16,16 batch=64 nEps=6 lenMin=12 lenMax=20 pTerm=0.5 \
+   nSteps=25 gradSteps=1,25 maxObs=600 minObs=64
 # G-resume: one run writes its network and replay-memory checkpoints after 40 steps, a SECOND reference process restarts from them
 # (Learner_approximator::restart; initializeLearner is skipped for a restarted learner) and trains 20 more steps with taps
 "$DRV" fixture "$HERE/resume_first.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \

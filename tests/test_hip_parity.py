@@ -28,7 +28,7 @@ def hip_learner(hip_api, cfg):
 our_flat_for = flat_for
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "appended_dense.bin"])
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "crowded_sampler.bin", "appended_dense.bin"])
 def test_init_weights_and_initialize_match_reference(hip_api, name):
     fx = load_fixture(name)
     L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
@@ -52,7 +52,7 @@ def test_init_weights_and_initialize_match_reference(hip_api, name):
         assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "appended_dense.bin"] + ACT_FIXTURES)
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "crowded_sampler.bin", "appended_dense.bin"] + ACT_FIXTURES)
 def test_steps_follow_reference_fixture(hip_api, name):
     """Feed the (episode, t) pairs the reference sampled at each tapped step and compare every
     per-sample quantity and the summed gradient / Adam update with the reference's own values."""
@@ -162,6 +162,23 @@ def test_unknown_sampler_is_rejected(hip_api):
     cfg.dataSamplingAlgo = 7
     with pytest.raises(RuntimeError):
         capi.Learner(hip_api, cfg)
+
+
+def test_device_sampler_on_the_reference_s_crowded_minibatches(hip_api):
+    """Batch 64 out of 93 stored transitions (tests/golden/crowded_sampler.bin): most draws collide, Sample_uniform's sort / unique /
+    redraw loop (Sampling.cpp:69-93) runs many rounds per minibatch -- about 105 generator draws for 64 indices.  The device
+    sampler, drawing on its own, produces the compiled reference's flat indices and generator states for all 25 steps."""
+    fx = load_fixture("crowded_sampler.bin")
+    L = hip_learner(hip_api, fixture_config(fx))
+    setup_from_fixture(L, fx)
+    L.set_tap(True)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        assert np.array_equal(L.get_rng_state(), fx[sk + "rng"]), k
+        L.step(1)
+        assert np.array_equal(L.readback(capi.TAP_FLAT), fx[sk + "flat"]), k
+    draws = [(int(fx["s%d_rng" % (k + 1)][-1]) - int(fx["s%d_rng" % k][-1])) % 624 for k in range(1, 25)]
+    assert min(draws) > 64 + 1                     # (every minibatch needed redraws; + 1: the optimizer's draw)
 
 
 def test_generator_stream_of_a_reference_run_with_three_threads(hip_api):

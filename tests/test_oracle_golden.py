@@ -56,7 +56,7 @@ def test_initialize_matches_reference(name):
     assert np.array_equal(L.get_rng_state(), fx["rng0"])
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "moving_replay.bin"] + ACT_FIXTURES + EVICT_FIXTURES + PER_FIXTURES)
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "crowded_sampler.bin", "moving_replay.bin"] + ACT_FIXTURES + EVICT_FIXTURES + PER_FIXTURES)
 def test_steps_match_reference(name):
     """Every tapped step: sampled flat indices / (episode, t) bit-exact (mt19937 + Lemire
     uniform_int + sort/unique/redraw + the reference's std::sort episode permutation); network
