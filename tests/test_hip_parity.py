@@ -872,6 +872,30 @@ def test_resumed_run_follows_the_reference_after_its_own_restart(hip_api, tmp_pa
 
 
 @pytest.mark.gpu
+def test_episode_log_equals_the_file_the_reference_wrote(hip_api, tmp_path):
+    """cumulative_rewards.dat (MemoryBuffer::pushBackEpisode, MemoryBuffer.cpp:491-513): the file the compiled reference wrote while
+    moving_replay.bin was recorded -- 25 episodes before training, 30 more behind every second gradient step -- against the
+    library's hl_set_episode_log for the same arrivals: gradient-step count, time stamp (observations since minTotObsNum), length
+    and total reward of every line.  (The harness logs its content tag as the agent id; the library's callers log agent 0.)"""
+    fx = load_fixture("moving_replay.bin")
+    L = hip_learner(hip_api, fixture_config(fx))
+    L.set_episode_log(tmp_path / "rewards.dat")
+    setup_from_fixture(L, fx)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        L.step(1)
+        e = fixture_arrival(fx, k)
+        if e is not None:
+            L.append_episode(**synth_episode(fixture_synth(fx), e))
+    L.sync()
+    ref = bytes(fx["rewards_log"]).decode().splitlines()
+    mine = open(tmp_path / "rewards.dat").read().splitlines()
+    assert len(ref) == len(mine) == 55
+    for a, b in zip(ref, mine):
+        a, b = a.split(), b.split()
+        assert [a[0], a[1], a[3], a[4]] == [b[0], b[1], b[3], b[4]], (a, b)
+
+
+@pytest.mark.gpu
 def test_stats_line_with_episodes_arriving_between_steps(hip_api):
     """totEp / totObs of the statistics line are the seen counters AS OF THE LAST updateCounters (ReplayCounters::nSeenEpisodes,
     MemoryProcessing.cpp:60-61), not this instant's: episodes appended since the last step do not show yet (nEp / nObs, the stored
