@@ -2,8 +2,8 @@
 
 Reference behaviour: with `nLearners` > 1 the global batch and the replay budget are
 split over the replicas (Settings/HyperParameters.cpp:186-197), every gradient step all-reduces the
-fp32 gradient sum (Core/Optimizer.cpp:104-133), the four replay counters
-(ReplayMemory/DataCoordinator / MemoryProcessing.cpp:100-118) and -- every 1000th step -- the
+fp32 gradient sum (Network/Optimizer.cpp:110-132), the four replay counters
+(Utils/DelayedReductor.cpp:53-83, read by MemoryProcessing.cpp:46-92) and -- every 1000th step -- the
 2*dS+3 reward/state moments (MemoryProcessing.cpp:139-150).
 
 The product does those exchanges on the device with RCCL inside `hl_step` (learner.cpp,
