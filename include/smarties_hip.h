@@ -264,6 +264,12 @@ HL_API int hl_counters_exchange(hl_learner* h, int64_t counters_io[4], int32_t w
 HL_API int hl_moments_exchange(hl_learner* h, double* io, int32_t write_back);
 HL_API int hl_step_end(hl_learner* h);
 HL_API int hl_sync(hl_learner* h);                         /* wait for all queued device work */
+/* A caller that steps n gradient steps per hl_step call -- the reference's training task does one per turn
+ * (Learners/RACER.cpp:81-108), a throughput loop many -- may announce n once after hl_initialize: the replayed graph of exactly
+ * n steps is built here instead of being assembled from the stock sizes (20 = 16 + 4), and its last node stamps a pinned host
+ * word that hl_sync polls.  Purely an optimisation: results are bit-identical with or without it; call sizes seen three
+ * times in a row are prepared automatically. */
+HL_API int hl_prepare_steps(hl_learner* h, int32_t n_steps);
 
 /* ---- rollout inference (first row) --------------------------------------
  * Network outputs for n raw (un-standardised) states with the CURRENT weights and state scaling:

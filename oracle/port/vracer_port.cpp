@@ -1531,6 +1531,7 @@ int ol_restart(ol_learner* h, const char* base) {
   return HL_OK;
 }
 int ol_sync(ol_learner*) { return HL_OK; }
+int ol_prepare_steps(ol_learner* h, int32_t n) { return (h && n >= 1) ? HL_OK : HL_ERR_BAD_ARG; }   // (a launch-shape hint of the device library)
 // Approximator::forward(agent) (Network/Approximator.h:300-330) on standardised states
 // (Episode::standardizedState, Episode.h:172-183): the network outputs RACER::selectAction reads
 int ol_forward(ol_learner* h, int32_t n, const float* states, double* outputs) {

@@ -46,6 +46,7 @@ HL_API int ol_counters_exchange(ol_learner* h, int64_t counters_io[4], int32_t w
 HL_API int ol_moments_exchange(ol_learner* h, double* io, int32_t write_back);
 HL_API int ol_step_end(ol_learner* h);
 HL_API int ol_sync(ol_learner* h);
+HL_API int ol_prepare_steps(ol_learner* h, int32_t n_steps);
 HL_API int64_t ol_packed_episode_size(const ol_learner* h, int32_t nsteps);
 HL_API int ol_append_packed_episode(ol_learner* h, const float* data, int64_t n_floats);
 HL_API int ol_pack_episode(ol_learner* h, int64_t episode_pos, float* dst, int64_t cap_floats);

@@ -172,6 +172,7 @@ class CApi:
             "moments_exchange": (C.c_int, [P, pd, I32]),
             "step_end": (C.c_int, [P]),
             "sync": (C.c_int, [P]),
+            "prepare_steps": (C.c_int, [P, I32]),
             "set_tap": (C.c_int, [P, I32]),
             "readback": (C.c_int, [P, I32, C.c_void_p, I64]),
             "get_scalars": (C.c_int, [P, C.POINTER(HlScalars)]),
@@ -442,6 +443,10 @@ class Learner:
 
     def sync(self):
         self._ck(self.api.fn("sync")(self.h))
+
+    def prepare_steps(self, n):
+        """announce calls of n steps (hl_prepare_steps): the graph of exactly n steps is captured now"""
+        self._ck(self.api.fn("prepare_steps")(self.h, int(n)))
 
     # -- inspection -----------------------------------------------------------------
     def set_tap(self, on=True):

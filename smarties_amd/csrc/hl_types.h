@@ -40,6 +40,7 @@ struct DevScalars {
   long long seenUpd[2];           // seen episodes / steps (summed over the replicas) as of the last updateCounters: ReplayCounters::nSeenEpisodes,
                                   // nSeenTransitions (MemoryProcessing.cpp:60-61) -- what the stats line prints
   long long sampleSeq;            // minibatches drawn so far (sampler phase A): hand-off tag when the gather rides along the dW kernel
+  unsigned notifySeq;             // exact-size graphs replayed so far (their last node stores it into pinned host memory: hl_sync)
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };
 

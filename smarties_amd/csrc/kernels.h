@@ -205,6 +205,9 @@ struct IngestArgs {
 };
 constexpr int INGEST_MAX_EP = 1024;
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
+struct TouchArgs { const void* ptr[16]; long long bytes[16]; int n; float* sink; };
+hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)
+hipError_t launch_notify(DevScalars* sc, unsigned* hostWord, hipStream_t s);   // ++sc->notifySeq -> pinned host word (completion stamp polled by hl_sync)
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s);
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,

@@ -467,6 +467,29 @@ __global__ __launch_bounds__(256) void rng_restore_kernel(DevScalars* sc) {
 }
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s) { hipLaunchKernelGGL(rng_restore_kernel, dim3(1), dim3(256), 0, s, sc); return hipGetLastError(); }
 
+// Completion stamp of a replayed call: the last node of an exact-size graph stores the count of such graphs run so far
+// into pinned host memory; hl_sync polls that word instead of asking the runtime for a stream marker
+// (tools/call_bench.hip: 7.5 us from the last workgroup to the host against 18.7 us through hipStreamSynchronize).
+__global__ void notify_kernel(DevScalars* sc, unsigned* hostWord) {
+  const unsigned s = ++sc->notifySeq;
+  __hip_atomic_store(hostWord, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_notify(DevScalars* sc, unsigned* hostWord, hipStream_t s) { hipLaunchKernelGGL(notify_kernel, dim3(1), dim3(1), 0, s, sc, hostWord); return hipGetLastError(); }
+
+// One word per 4 KB of every replay array: the address translations of the whole replay are resident before a timed
+// stepping phase starts (hl_prepare_steps).  A minibatch touches ~2000 random rows of a few hundred MB; a freshly filled
+// replay otherwise pays its page walks over the first few dozen steps (tools/first_call3.py).
+__global__ __launch_bounds__(256) void touch_kernel(TouchArgs a) {
+  float acc = 0.f;
+  for (int k = 0; k < a.n; ++k) {
+    const char* base = (const char*)a.ptr[k];
+    for (long long off = ((long long)blockIdx.x * 256 + threadIdx.x) * 4096; off < a.bytes[k]; off += (long long)gridDim.x * 256 * 4096)
+      acc += *(const volatile float*)(base + off);
+  }
+  if (acc == 1.2345e-30f) *a.sink = acc;
+}
+hipError_t launch_touch(const TouchArgs& a, hipStream_t s) { hipLaunchKernelGGL(touch_kernel, dim3(256), dim3(256), 0, s, a); return hipGetLastError(); }
+
 __global__ void empty_kernel() {}
 hipError_t launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); return hipGetLastError(); }
 

@@ -413,6 +413,8 @@ int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
 // last -- largest far-policy fraction / largest average D_KL / smallest average squared error --, the older one among equal
 // keys; the keys are the per-episode aggregates the device maintains, fetched when a removal may be due.
 bool evictionDue(const hl_learner* h);
+int prepareExact(hl_learner* h, int n);
+int touchReplay(hl_learner* h);
 int applyRemoval(hl_learner* h) {
   bool any = false;
   const int filter = h->cfg.ERoldSeqFilter;
@@ -566,7 +568,7 @@ int stepEager(hl_learner* h, const long long* dFlat) {
 // ---- replayed graph: U steps on one stream, tail work horizontally fused into the MLP kernels.  The graph starts
 //      with the minibatch of its first step already in buffer `p0` and leaves the one of the step after its last in
 //      buffer (p0 + U) & 1 ----
-int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
+int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = false) {
   if (slot->exec) { hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
   if (slot->graph) { hipGraphDestroy(slot->graph); slot->graph = nullptr; }
   hipStream_t s0 = h->stream;
@@ -611,6 +613,7 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
       if (rc) break;
     }
   }
+  if (!rc && notify && launch_notify(h->sc, h->notifyPin, s0) != hipSuccess) rc = fail(h, HL_ERR_HIP, "notify");
   hipError_t e = hipStreamEndCapture(s0, &slot->graph);
   h->nCollectives = nColl0;
   if (rc) return rc;
@@ -624,16 +627,49 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot) {
 }
 
 void invalidateGraphs(hl_learner* h) {
-  for (auto& gp : h->graphs) for (auto& g : gp) {
+  auto drop = [](GraphSlot& g) {
     if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (g.graph) { hipGraphDestroy(g.graph); g.graph = nullptr; }
-  }
+  };
+  for (auto& gp : h->graphs) for (auto& g : gp) drop(g);
+  for (auto& kv : h->exactGraphs) for (auto& g : kv.second) drop(g);      // (the sizes stay: captureAllGraphs re-captures them)
 }
 
 // sizes usable by this learner: with a communicator attached the graphs stay short (<= 64 steps, i.e. 64 captured
 // collectives: a 2 ms replay already amortises the launch, and nothing here depends on how many collective nodes the
 // installed RCCL is comfortable with in one graph); the 999-step graph only ever starts right after a 1000th-step
 // sweep, i.e. with buffer 0
+// the address translations of the whole replay and of the parameter arrays resident before a stepping phase (touch_kernel)
+int touchReplay(hl_learner* h) {
+  TouchArgs ta{}; const long long cap = h->capSlots;
+  auto add = [&](const void* p, long long bytes) { if (p && ta.n < 16) { ta.ptr[ta.n] = p; ta.bytes[ta.n] = bytes; ++ta.n; } };
+  add(h->rp.S, cap * h->dS * 4); add(h->rp.A, cap * h->dA * 8); add(h->rp.MU, cap * h->polDim * 8); add(h->rp.R, cap * 8);
+  add(h->rp.V, cap * 4); add(h->rp.ADV, cap * 4); add(h->rp.RET, cap * 4); add(h->rp.DQ, cap * 4); add(h->rp.IMPW, cap * 4); add(h->rp.DKL, cap * 4);
+  add(h->W, h->nParams * 4); add(h->M1, h->nParams * 4); add(h->M2, h->nParams * 4); add(h->G, h->nParams * 4);
+  ta.sink = h->G + h->nParams + 200;
+  HIPCK(launch_touch(ta, h->stream));
+  return HL_OK;
+}
+
+// graph of exactly n steps for both starting buffers, last node = the completion stamp (hl_prepare_steps)
+int prepareExact(hl_learner* h, int n) {
+  if (!h->useGraph || n >= 1000 || (exchanging(h) && (!(h->exchGraph && wired(h)) || n > 64)) || h->cfg.dataSamplingAlgo != HL_SAMPLE_UNIFORM) return HL_OK;
+  if (!h->notifyPin) { HIPCK(hipHostMalloc((void**)&h->notifyPin, 64, hipHostMallocDefault)); *h->notifyPin = 0; }
+  if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
+  if (h->exactGraphs.size() >= 8 && !h->exactGraphs.count(n)) {      // a handful of call sizes at most
+    auto victim = h->exactGraphs.begin();
+    for (auto& g : victim->second) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
+    h->exactGraphs.erase(victim);
+  }
+  auto& slots = h->exactGraphs[n];
+  for (int p0 = 0; p0 < 2; ++p0) {
+    if (slots[p0].exec) continue;
+    const int rc = captureSteps(h, n, p0, &slots[p0], true);
+    if (rc) { h->exactGraphs.erase(n); if (!exchanging(h)) return rc; h->err.clear(); (void)hipGetLastError(); return HL_OK; }
+  }
+  return HL_OK;
+}
+
 bool graphUsable(const hl_learner* h, int U, int p0) {
   if (exchanging(h) && U > 64) return false;
   if (U == 999 && p0 != 0) return false;
@@ -656,15 +692,30 @@ int captureAllGraphs(hl_learner* h) {
     h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
     return HL_OK;
   }
+  std::vector<int> sizes; for (auto& kv : h->exactGraphs) if (!kv.second[0].exec) sizes.push_back(kv.first);
+  for (int n : sizes) { const int rc = prepareExact(h, n); if (rc) return rc; }
   return HL_OK;
 }
 
 // run as many plain steps as possible (<= avail) from one graph replay; returns steps done (0 = none)
-int replaySteps(hl_learner* h, long long avail, int* done) {
+int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = false) {
   *done = 0;
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
   if (!h->graphs[NS - 1][0].exec) { int rc = captureAllGraphs(h); if (rc) return rc; if (!h->graphs[NS - 1][0].exec) return HL_OK; }
   const int p0 = h->preValid ? h->preParity : 0;
+  if (wholeCall) {      // the whole call as one launch, completion stamp behind it
+    auto it = h->exactGraphs.find((int)avail);
+    if (it != h->exactGraphs.end() && it->second[p0].exec) {
+      const int U = (int)avail;
+      if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
+      HIPCK(hipGraphLaunch(it->second[p0].exec, h->stream));
+      h->notifyIssued += 1; h->tailNotify = true;
+      h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;
+      if (wired(h)) h->nCollectives += U;
+      *done = U;
+      return HL_OK;
+    }
+  }
   if (h->eagerChain > 0 && avail <= h->eagerChain && h->fusedOk && !exchanging(h)) {
     // short calls: the same two launches per step (riders included) issued directly -- no graph launch latency, no
     // first-launch cost of a graph that has not run yet

@@ -1380,6 +1380,40 @@ def test_chained_replays_carry_the_next_minibatch_across_calls(hip_api, cfg_kw, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [{}, dict(hidden=(24, 16, 8), nnFunc="Tanh")], ids=["fused-2x32", "generic-24x16x8"])
+def test_announced_call_sizes_replay_as_one_graph_with_a_completion_stamp(hip_api, extra):
+    """hl_prepare_steps(n): a call of n steps is ONE graph whose last node stamps a pinned host word that hl_sync polls.
+    Bit-identical to the same calls served from the stock graph sizes; the stamp path survives new episodes, a 1000th-step
+    sweep inside a call (served piecewise), interleaved other calls, and call sizes that prepare themselves after three calls."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=3000, randSeed=42)
+    cfg_kw.update(extra)
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    A, O = _pair(hip_api, cfg_kw, sc, 60)
+    B, _ = _pair(hip_api, cfg_kw, sc, 60)
+    A.prepare_steps(20); A.prepare_steps(7)
+    nxt = 60
+    for i, n in enumerate([5, 20, 20, 7, 20, 3, 20, 11, 11, 11, 11, 11, 20]):
+        A.step(n); B.step(n); O.step(n)
+        A.sync(); B.sync()
+        if i % 3 == 1:
+            assert np.array_equal(A.get_params()[0], B.get_params()[0]), i
+        if i == 4:
+            for L in (A, B, O):
+                fill_synth(L, sc, 2, first=nxt)
+            nxt += 2
+    for _ in range(42):      # across the 1000th step
+        A.step(20); B.step(20); O.step(20)
+    A.sync(); B.sync()
+    assert A.scalars().nGradSteps == B.scalars().nGradSteps == O.scalars().nGradSteps
+    for a, b in zip(A.get_params(), B.get_params()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(A.get_rng_state(), B.get_rng_state())
+    assert np.array_equal(A.get_rng_state(), O.get_rng_state())
+    assert A.scalars().beta == B.scalars().beta
+    assert relinf(A.get_params()[0], O.get_params()[0]) < 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [{}, dict(hidden=(24, 16, 8), nnFunc="Tanh"), dict(hidden=(16, 16), nnFunc="Tanh", nn_type=capi.NN_MGU, nnBPTTseq=4)],
                          ids=["fused-2x32", "generic-24x16x8", "mgu-2x16"])
 def test_replicas_speak_one_wire_protocol_on_every_path(hip_api, extra):
