@@ -115,13 +115,31 @@ class RACER_HIP : public Learner
     c.dimS = (int32_t) M.dimStateObserved; c.dimA = (int32_t) aInfo.dim();
     for (Uint i = 0; i < aInfo.dim() && !bDiscrete; ++i) c.bounded[i] = aInfo.isBounded(i);
     c.n_hidden = (int32_t) S.nnLayerSizes.size();
-    if (c.n_hidden > HL_MAX_HIDDEN) die("too many hidden layers for hl_config");
+    // Learner_approximator::createEncoder (:149-166): the encoder's dense layers head the same network (zero entries dropped there)
+    c.n_encoder = (int32_t) S.encoderLayerSizes.size();
+    if (c.n_hidden + c.n_encoder > HL_MAX_HIDDEN) die("too many hidden layers for hl_config");
     for (Uint i = 0; i < S.nnLayerSizes.size(); ++i) c.hidden[i] = (int32_t) S.nnLayerSizes[i];
+    for (Uint i = 0; i < S.encoderLayerSizes.size(); ++i) c.encoder[i] = (int32_t) S.encoderLayerSizes[i];
     c.nnFunc = hlFunc(S.nnFunc);
+    c.nnOutputFunc = hlFunc(S.nnOutputFunc);                                      // Approximator.cpp:193,228
     // what Approximator::buildFromSettings makes of nnType (Approximator.cpp:218-226)
     const std::string netType = M.isPartiallyObservable && S.bRecurrent == false ? "MGU" : S.nnType;
-    c.nn_type = netType == "LSTM" ? HL_NN_LSTM : (netType == "MGU" || netType == "GRU" ? HL_NN_MGU : HL_NN_FFNN);
+    c.nn_type = netType == "LSTM" ? HL_NN_LSTM : (netType == "MGU" || netType == "GRU") ? HL_NN_MGU :
+                netType == "RNN" ? HL_NN_RNN : (netType == "FFNN" ? HL_NN_FFNN : -1);
+    // settings the library does not serve die here rather than train something else (the reference's convention):
+    //  * any other nnType string makes plain dense layers in Builder::addLayer, "Recurrent" recurrent ones without a BPTT
+    //    window (HyperParameters.cpp:209 does not count it as recurrent);
+    //  * a partially observable MDP with nnType left non-recurrent gets "RNN" encoder layers under "MGU" layers
+    //    (Approximator.cpp:264-270 vs :221-223): one layer type per network here
+    if (c.nn_type < 0) die("nnType not served by the HIP library (FFNN, LSTM, MGU / GRU, RNN)");
+    bool anyEncoder = false; for (Uint v : S.encoderLayerSizes) anyEncoder = anyEncoder || v > 0;
+    if (M.isPartiallyObservable && S.bRecurrent == false && anyEncoder) die("encoderLayerSizes of a partially observable MDP with a non-recurrent nnType mix RNN and MGU layers: not served by the HIP library");
+    if ((M.conv2dDescriptors.size() > 0 || M.nAppendedObs > 0) && c.nn_type != HL_NN_FFNN) die("recurrent layers behind convolutional preprocessing / appended observations are not served by the HIP library");
     bRecurrent = c.nn_type != HL_NN_FFNN; c.nnBPTTseq = (int32_t) S.nnBPTTseq;
+    // MemoryProcessing::createReturnEstimator (:418-450); AlgoFactory.cpp:134-135 turns "default" into "retrace" for this learner
+    c.returnsEstimator = (S.returnsEstimator == "default" || S.returnsEstimator == "retrace") ? HL_RET_RETRACE :
+                         S.returnsEstimator == "retraceExplore" ? HL_RET_RETRACE_EXPLORE : S.returnsEstimator == "GAE" ? HL_RET_GAE :
+                         S.returnsEstimator == "none" ? HL_RET_NONE : HL_RET_RETRACE /* createReturnEstimator's own fall-through */;
     c.adv_kind = bDiscrete ? HL_ADV_DISCRETE : (bGaussAdv ? HL_ADV_GAUSSIAN : HL_ADV_ZERO);
     c.n_options = bDiscrete ? (int32_t) nA : 0;
     // removal rule of an over-full replay and minibatch sampler (getERfilterAlgo, MemoryProcessing.cpp:261-298;
@@ -195,6 +213,9 @@ class RACER_HIP : public Learner
   void initializeLearner() override
   {
     moveEpisodesToDevice();
+    // a restarted learner skips the start-up passes (Learner.cpp:51-54) -- Worker calls setupTasks() right after restart()
+    // (Core/Worker.cpp:293-294), which sends the task queue through here once more; hl_restart_memory left the library ready to step
+    if (nGradSteps() > 0) return;
     ck(hl_initialize(H));
     data->counters.nGatheredB4Startup = nObsB4StartTraining;
   }

@@ -79,7 +79,16 @@ enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU 
 /* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
 /* hidden layer type (Network/Builder.cpp:48-117): dense, or LSTM (Network/Layers/Layer_LSTM.h; BASELINE config 4).
  * HL_NN_LSTM: rec.hip (one workgroup per sample walks the BPTT window; cells <= 64 per layer, eager launches). */
-enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1, HL_NN_MGU = 2 /* Layer_GRU.h: what a partially observable MDP gets when nnType is left FFNN (Approximator.cpp:221-223) */ };
+enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1, HL_NN_MGU = 2 /* Layer_GRU.h: what a partially observable MDP gets when nnType is left FFNN (Approximator.cpp:221-223) */,
+       HL_NN_RNN = 3 /* "RNN" / "Recurrent" (Builder.cpp:76-81): dense layers with a recurrent term, y_t = f(W x_t + W_rec y_{t-1} + b)
+                        (BaseLayer with bRecurrent, Layer_Base.h:64-113) */ };
+
+/* settings key returnsEstimator (Settings/HyperParameters.cpp:135; MemoryProcessing::createReturnEstimator,
+ * ReplayMemory/MemoryProcessing.cpp:391-450): how the per-step return estimates are swept backwards over an episode */
+enum { HL_RET_RETRACE = 0,          /* "retrace" (what "default" means for RACER / VRACER, AlgoFactory.cpp:134-135): computeRetrace (:391-400) */
+       HL_RET_RETRACE_EXPLORE = 1,  /* "retraceExplore": computeRetraceExplBonus (:402-408), bonus (1 - gamma)(|Q_ret - Q| - maxAbsError) */
+       HL_RET_GAE = 2,              /* "GAE": computeGAE (:410-416) */
+       HL_RET_NONE = 3 };           /* "none": the estimates stay as stored (computeReturnEstimator returns at once, :455) */
 
 /* advantage head (Learners/AlgoFactory.cpp:109-152): Math/Zero_advantage.h (VRACER), Math/Gaus_advantage.h (RACER,
  * continuous actions: network outputs [V | coef, L+ x dA, L- x dA | mean x dA | sigma parameter x dA]);
@@ -166,6 +175,12 @@ typedef struct hl_config {
                                         normalisation and cumulative table are sequential double-precision passes, kept
                                         sequential on the device so that the drawn indices are the reference's (PERerr, PERseq;
                                         PERrank ranks equal errors in storage order where the reference's non-stable sort leaves it open) */
+  int32_t returnsEstimator;          /* HL_RET_*                                                                               */
+  int32_t nnOutputFunc;              /* HL_FUNC_*: activation of the output layer, settings key nnOutputFunc (Approximator.cpp:193,228;
+                                        default "Linear").  Its inverse also shapes the initial output biases (Layer_Base.h:122-125) */
+  int32_t n_encoder;                 /* len(encoderLayerSizes) (Learner_approximator::createEncoder, Learner_approximator.cpp:149-166):  */
+  int32_t encoder[HL_MAX_HIDDEN];    /*   dense layers of the preprocessing network, in front of nnLayerSizes in the same network
+                                          (Approximator::buildPreprocessing, Approximator.cpp:231-271); n_encoder + n_hidden <= HL_MAX_HIDDEN */
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */
@@ -186,6 +201,10 @@ typedef struct hl_scalars {
 typedef struct hl_stats {
   double avgKLdivergence, avgSquaredErr, maxAbsError, avgReturn, avgQ, stdevQ, minQ, maxQ;
   int64_t nFarPolicySteps;
+  /* ReplayStats::countReturnsEstimateUpdates / sumReturnsEstimateErrors (:253-258): estimates rewritten by the 1000-step
+   * sweeps since the last statistics line and the sum of their squared changes -- the "dRet" column; -1 / 0 once printed */
+  int64_t countReturnsEstimateUpdates;
+  double sumReturnsEstimateErrors;
 } hl_stats;
 
 /* per-sample / per-step taps of the LAST executed step (hl_readback) */

@@ -104,5 +104,45 @@ int main(int argc, char** argv)
          nEp, storedRef, storedHipHost, (long) sc.nStoredSteps, Lref->nGradSteps(), Lhip->nGradSteps(), (double) Lref->data->beta, sc.beta,
          wnRef, std::sqrt(wn), (unsigned long) Lref->networks[0]->net->weights->nParams, (unsigned long) w.size());
   printf("hip stats line:%s\n", mh.str().c_str());
+  if (argc > 2 && std::string(argv[2]) == "restart") {
+    // Both learners write their checkpoints (Learner_approximator::save -> <name>_net_*.raw, <name>_scaling.raw,
+    // <name>_rank_000_learner_{status,data}.raw) and two NEW learners start from them the way Core/Worker.cpp:291-295 does:
+    // restart(), then setupTasks() -- whose first task runs initializeLearner() again (a restarted learner must skip it,
+    // Learner.cpp:51-54) --, then train on.  The binding reads the REFERENCE's files as well as its own.
+    const long more = argc > 3 ? atol(argv[3]) : 100;
+    Lref->save(); Lhip->save();
+    hl_scalars before; hl_get_scalars(hp->handle(), &before);
+    info.restart = ".";
+    MDPdescriptor MDP3, MDP4, MDP5; makeMDP(MDP3); makeMDP(MDP4); makeMDP(MDP5);
+    auto HP3 = makeHP(), HP4 = makeHP(), HP5 = makeHP();
+    auto Rref = std::make_unique<REF>(MDP3, *HP3, info);
+    std::unique_ptr<Learner> Rhip = std::make_unique<HIP>(MDP4, *HP4, info);      // restarts from its own files
+    std::unique_ptr<Learner> Xhip = std::make_unique<HIP>(MDP5, *HP5, info);      // restarts from the reference's files
+    Rref->setLearnerName("ref_00", 0); Rhip->setLearnerName("hip_00", 1); Xhip->setLearnerName("ref_00", 2);
+    TaskQueue q3([]() { return false; }), q4([]() { return false; }), q5([]() { return false; });
+    Rref->restart(); Rref->setupTasks(q3);
+    Rhip->restart(); Rhip->setupTasks(q4);
+    Xhip->restart(); Xhip->setupTasks(q5);
+    HIP* rp = dynamic_cast<HIP*>(Rhip.get()); HIP* xp = dynamic_cast<HIP*>(Xhip.get());
+    hl_scalars r0, x0; hl_get_scalars(rp->handle(), &r0); hl_get_scalars(xp->handle(), &x0);
+    const long g0r = Rref->nGradSteps(), g0h = Rhip->nGradSteps(), g0x = Xhip->nGradSteps();
+    Rref->initializeLearner(); Rhip->initializeLearner(); Xhip->initializeLearner();      // what the first task does: no start-up passes for restarted learners
+    hl_scalars r1, x1; hl_get_scalars(rp->handle(), &r1); hl_get_scalars(xp->handle(), &x1);
+    while (Rref->nGradSteps() < g0r + more) q3.run();
+    while (Rhip->nGradSteps() < g0h + more) q4.run();
+    while (Xhip->nGradSteps() < g0x + more) q5.run();
+    hl_scalars r2, x2; hl_get_scalars(rp->handle(), &r2); hl_get_scalars(xp->handle(), &x2);
+    auto wnormOf = [](hl_learner* H) { std::vector<float> v((size_t) hl_num_params(H)); hl_get_params(H, v.data(), nullptr, nullptr);
+                                       long double a = 0; for (float x : v) a += (long double) x * x; return (double) std::sqrt(a); };
+    printf("{\"restart\": 1, \"grad0_ref\": %ld, \"grad0_hip\": %ld, \"grad0_x\": %ld, \"beta_saved\": %.12g, \"beta_restarted\": %.12g, "
+           "\"beta_after_init_task\": %.12g, \"beta_x_restarted\": %.12g, \"beta_x_after_init_task\": %.12g, \"beta_ref_saved\": %.12g, "
+           "\"stored_saved\": %ld, \"stored_restarted\": %ld, \"stored_x\": %ld, \"stored_ref\": %ld, "
+           "\"steps_ref\": %ld, \"steps_hip\": %ld, \"steps_x\": %ld, \"beta_ref\": %.9g, \"beta_hip\": %.9g, \"beta_x\": %.9g, "
+           "\"wnorm_ref\": %.9g, \"wnorm_hip\": %.9g, \"wnorm_x\": %.9g}\n",
+           g0r, g0h, g0x, before.beta, r0.beta, r1.beta, x0.beta, x1.beta, (double) Lref->data->beta,
+           (long) before.nStoredSteps, (long) r0.nStoredSteps, (long) x0.nStoredSteps, (long) Rref->locDataSetSize(),
+           Rref->nGradSteps(), Rhip->nGradSteps(), Xhip->nGradSteps(), (double) Rref->data->beta, r2.beta, x2.beta,
+           (double) Rref->networks[0]->net->weights->compute_weight_norm(), wnormOf(rp->handle()), wnormOf(xp->handle()));
+  }
   return 0;
 }

@@ -154,6 +154,24 @@ inline Real fInitFactor(int f, int inps, int outs) {
   }
   return 1;
 }
+// Function::inverse (Functions.h: Linear :80, Tanh :114, Sigm :167, HardSign :244, SoftSign :353, Relu :439, LRelu :482,
+// ExpPlus :502, SoftPlus :564, Exp :632), in nnReal like the reference: the initial bias of a layer is the pre-image of
+// the requested initial output (Layer_Base.h:122-125)
+inline nnReal fInverse(int f, nnReal in) {
+  switch (f) {
+    case HL_FUNC_LINEAR: return in;
+    case HL_FUNC_TANH: return std::log((1 + in) / (1 - in)) / 2;
+    case HL_FUNC_SIGM: return -std::log(1 / in - 1);
+    case HL_FUNC_HARDSIGN: return in / std::sqrt(1 - in * in);
+    case HL_FUNC_SOFTSIGN: return in / (1 - std::fabs(in));
+    case HL_FUNC_RELU: return in;
+    case HL_FUNC_LRELU: return in >= 0 ? in : in / (nnReal)0.1;
+    case HL_FUNC_EXPPLUS: return std::log(nnSafeExp(in) - 1);
+    case HL_FUNC_SOFTPLUS: return (in * in - (nnReal)0.25) / in;
+    case HL_FUNC_EXP: return std::log(in);
+  }
+  return in;
+}
 // SoftPlus used by the policy for the stdev ("cheap softplus", Functions.h:552-568)
 inline Real spEval(Real in) { return (in + std::sqrt(1 + in * in)) / 2; }
 inline Real spDiff(Real in) { return (1 + in / std::sqrt(1 + in * in)) / 2; }
@@ -182,6 +200,7 @@ struct Layer {
   LType type; int size = 0, nIn = 0, nOutSimd = 0, func = HL_FUNC_LINEAR;
   hl_conv2d cv{};                     // L_CONV: Conv2DLayer<SoftSign, ...> (Network/Layers/Layer_Conv2D.h:29-232)
   bool bOutput = false, skipInpGrad = false;
+  bool rec = false;                   // L_DENSE with a recurrent term: BaseLayer(bRecurrent) for nnType "RNN" (Builder.cpp:76-81, Layer_Base.h:83-93)
   int64_t indW = 0, nW = 0, indB = 0, nB = 0;
   std::vector<Real> biasInit;  // ParamLayer initial values
 };
@@ -272,6 +291,7 @@ void buildNet(ol_learner* h) {
     if (c.hidden[j] <= 0) continue;
     const int ID = (int)L.size();
     Layer d; d.type = c.nn_type == HL_NN_LSTM ? L_LSTM : (c.nn_type == HL_NN_MGU ? L_MGU : L_DENSE); d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
+    d.rec = c.nn_type == HL_NN_RNN;
     d.nOutSimd = (int)roundUp8(d.size); d.func = c.nnFunc;
     L.push_back(d);
     // skip connection except after the first layer (Builder.cpp:89-95)
@@ -286,9 +306,12 @@ void buildNet(ol_learner* h) {
   h->nAdv = nAdv; h->nOpt = discrete ? c.n_options : 0; h->polDim = discrete ? c.n_options : 2 * c.dimA;
   { const int ID = (int)L.size();
     Layer o; o.type = L_DENSE; o.size = nDense; o.nIn = L[ID - 1].size;
-    o.nOutSimd = (int)roundUp8(o.size); o.func = HL_FUNC_LINEAR; o.bOutput = true;
-    if (c.adv_kind == HL_ADV_GAUSSIAN) {   // Builder::setLastLayersBias(biases): Gaussian_advantage::setInitial (Gaus_advantage.h:31-34)
-      o.biasInit.assign(nDense, 0); o.biasInit[1] = -1;
+    o.nOutSimd = (int)roundUp8(o.size); o.func = c.nnOutputFunc; o.bOutput = true;   // settings nnOutputFunc (Approximator.cpp:193,228)
+    // continuous actions: Builder::setLastLayersBias(biases) with {0 (V) | Advantage_t::setInitial | Policy_t::setInitial_noStdev
+    // = zeros} (RACER_common.cpp:94-105); the layer stores the pre-images under its function.  Discrete: biases stay zero.
+    if (!discrete) o.biasInit.assign(nDense, 0);
+    if (c.adv_kind == HL_ADV_GAUSSIAN) {   // Gaussian_advantage::setInitial (Gaus_advantage.h:31-34)
+      o.biasInit[1] = -1;
       for (int e = 2; e < 1 + nAdv; ++e) o.biasInit[e] = 1;
     }
     L.push_back(o); }
@@ -303,7 +326,7 @@ void buildNet(ol_learner* h) {
   for (auto& l : L) {
     switch (l.type) {
       case L_INPUT: l.nW = 0; l.nB = 0; break;
-      case L_DENSE: l.nW = (int64_t)l.nOutSimd * l.nIn; l.nB = l.size; break;   // Layer_Base.h:24-28
+      case L_DENSE: l.nW = (int64_t)l.nOutSimd * (l.nIn + (l.rec ? l.size : 0)); l.nB = l.size; break;   // Layer_Base.h:24-28
       case L_PARAMRES: l.nW = l.size; l.nB = l.size; break;                    // Layers.h:334-338
       case L_PARAM: l.nW = 0; l.nB = l.size; break;                            // Layers.h:494-497
       case L_LSTM: l.nW = (int64_t)4 * l.size * (l.nIn + l.size); l.nB = 4 * l.size; break;   // Layer_LSTM.h:24-29
@@ -335,8 +358,8 @@ void initWeights(ol_learner* h) {
       const Real initializationFac = l.bOutput ? c.outWeightsPrefac : 1;
       const nnReal fac = (initializationFac > 0) ? initializationFac : 1;
       const nnReal init = fac * fInitFactor(l.func, l.nIn, l.size);
-      for (int o = 0; o < l.size; ++o) Bv[o] = l.biasInit.size() == (size_t)l.size ? (nnReal)l.biasInit[o] : 0;  // Linear inverse of the init values (Layer_Base.h:122-125)
-      for (int i = 0; i < l.nIn; ++i)
+      for (int o = 0; o < l.size; ++o) Bv[o] = l.biasInit.size() == (size_t)l.size ? fInverse(l.func, (nnReal)l.biasInit[o]) : 0;  // pre-image of the init values (Layer_Base.h:122-125)
+      for (int i = 0; i < l.nIn + (l.rec ? l.size : 0); ++i)      // input weights, then the recurrent ones (:127-140)
         for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = uniformFloat(h->gen, -init, init);
     } else if (l.type == L_LSTM) {   // Layer_LSTM.h:167-185: forget gate starts open, input / output gates closed (LSTM_PRIME_FAC = 1)
       const nnReal init = fInitFactor(l.func, l.nIn, l.size);
@@ -413,6 +436,10 @@ void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vecto
       for (int i = 0; i < l.nIn; ++i) {
         const nnReal* Wi = W + (int64_t)l.nOutSimd * i;
         for (int o = 0; o < l.size; ++o) suminp[o] += inputs[i] * Wi[o];
+      }
+      if (l.rec && prevY) {      // Layer_Base.h:83-93: + W_rec y_{t-1}
+        const nnReal* rin = (*prevY)[ID].data(); const nnReal* Wr = W + (int64_t)l.nOutSimd * l.nIn;
+        for (int i = 0; i < l.size; ++i) { const nnReal* Wi = Wr + (int64_t)l.nOutSimd * i; for (int o = 0; o < l.size; ++o) suminp[o] += rin[i] * Wi[o]; }
       }
       for (int o = 0; o < l.size; ++o) Y[ID][o] = fEval(l.func, suminp[o]);
     } else if (l.type == L_PARAMRES) {  // Layers.h:347-361
@@ -544,9 +571,12 @@ void backwardSeries(ol_learner* h, std::vector<Act>& series, int T) {
         nnReal* deltas = cur.E[ID].data();
         for (int o = 0; o < l.size; ++o) deltas[o] *= fDiff(l.func, cur.X[ID][o], cur.Y[ID][o]);
         if (!l.skipInpGrad) gemvOmp(l.size, l.nIn, l.nOutSimd, W, deltas, cur.E[ID - 1].data());
+        if (l.rec && prev) gemvOmp(l.size, l.size, l.nOutSimd, W + (int64_t)l.nOutSimd * l.nIn, deltas, prev->E[ID].data());   // Layers.h:148-159
         for (int o = 0; o < l.size; ++o) gB[o] += deltas[o];
         const nnReal* inputs = cur.Y[ID - 1].data();
         for (int i = 0; i < l.nIn; ++i) { nnReal* Gi = gW + (int64_t)l.nOutSimd * i; for (int o = 0; o < l.size; ++o) Gi[o] += inputs[i] * deltas[o]; }
+        if (l.rec && prev) { const nnReal* rin = prev->Y[ID].data(); nnReal* gR = gW + (int64_t)l.nOutSimd * l.nIn;                  // :178-187
+          for (int i = 0; i < l.size; ++i) { nnReal* Gi = gR + (int64_t)l.nOutSimd * i; for (int o = 0; o < l.size; ++o) Gi[o] += rin[i] * deltas[o]; } }
       } else if (l.type == L_PARAMRES) {
         const nnReal* delta = cur.E[ID].data();
         std::memcpy(cur.E[ID - 1].data(), delta, l.size * sizeof(nnReal));
@@ -817,16 +847,30 @@ void epRecompute(Episode& EP, Fval C, Fval invC) {
   EP.avgKL = invN * sk;
 }
 
-// computeRetrace + updateReturnEstimator (ReplayMemory/MemoryProcessing.cpp:23-44,391-400)
-void retraceEpisode(const ol_learner* h, Episode& EP) {
+// updateReturnEstimator (ReplayMemory/MemoryProcessing.cpp:23-44) with the estimator createReturnEstimator picks
+// (:418-450): computeRetrace (:391-400), computeRetraceExplBonus (:402-408; its baseline is ReplayStats::maxAbsError as
+// of the moment the estimator is created), computeGAE (:410-416).  Returns the sum of the squared changes (sumErr2).
+Fval retraceEpisode(const ol_learner* h, Episode& EP) {
+  const int kind = h->cfg.returnsEstimator;
+  if (kind == HL_RET_NONE) return 0;
   const Fval gamma = h->cfg.gamma, lambda = h->cfg.lambda;
+  const Fval coef = (1 - gamma), baseline = (Fval)h->stats.maxAbsError;
   if (!EP.term) EP.RET[EP.N - 1] = EP.V[EP.N - 1];
+  Fval sumErr2 = 0;
   for (int t = EP.N - 2; t >= 0; --t) {
+    const Fval oldEstimate = EP.RET[t];
     const Fval R = (Fval)((EP.R[t + 1] - h->rewMean) * h->rewScale);   // Episode::scaledReward<Fval> (:185-189)
     const Fval Q = EP.RET[t + 1], V = EP.V[t + 1], A = EP.ADV[t + 1];
-    const Fval w = EP.IMPW[t + 1] < 1 ? EP.IMPW[t + 1] : 1;            // clippedOffPolW (:191-195)
-    EP.RET[t] = R + gamma * (V + lambda * w * (Q - A - V));
+    if (kind == HL_RET_GAE) EP.RET[t] = R + gamma * (V + lambda * (Q - V));
+    else {
+      const Fval w = EP.IMPW[t + 1] < 1 ? EP.IMPW[t + 1] : 1;          // clippedOffPolW (:191-195)
+      const Fval ret = R + gamma * (V + lambda * w * (Q - A - V));
+      if (kind == HL_RET_RETRACE_EXPLORE) { const Fval E = std::fabs(Q - A - V) - baseline; EP.RET[t] = coef * E + ret; }
+      else EP.RET[t] = ret;
+    }
+    sumErr2 += std::pow(oldEstimate - EP.RET[t], 2);                   // (float, int) -> double arithmetic, stored as Fval
   }
+  return sumErr2;
 }
 
 // MemoryProcessing::updateCounters (MemoryProcessing.cpp:46-92)
@@ -898,10 +942,15 @@ void updateTrainingStatistics(ol_learner* h) {
   h->CinvRet = 1 / h->CmaxRet;
   size_t nOffPol = 0;
   Fval maxAbsE = -1e9, maxQ = -1e9, minQ = 1e9;
-  Real sumDKL = 0, sumE2 = 0, sumQ2 = 0, sumQ1 = 0, sumR = 0;
+  Real sumDKL = 0, sumE2 = 0, sumQ2 = 0, sumQ1 = 0, sumR = 0, sumERet = 0;
+  const bool bNeedsReturnEst = h->cfg.returnsEstimator != HL_RET_NONE;
+  size_t nRetUpdates = 0;
   for (auto& ep : h->episodes) {
     Episode& EP = *ep;
-    if (bRecompute) { epRecompute(EP, (Fval)h->CmaxRet, (Fval)h->CinvRet); retraceEpisode(h, EP); }
+    if (bRecompute) {
+      epRecompute(EP, (Fval)h->CmaxRet, (Fval)h->CinvRet);
+      if (bNeedsReturnEst) { sumERet += retraceEpisode(h, EP); nRetUpdates += EP.N - 1; }
+    }
     const Fval Nsteps = EP.N;
     maxAbsE = std::max(EP.maxAbsErr, maxAbsE);
     maxQ = std::max(EP.maxQ, maxQ); minQ = std::min(EP.minQ, minQ);
@@ -923,6 +972,11 @@ void updateTrainingStatistics(ol_learner* h) {
   h->stats.maxQ = maxQ; h->stats.minQ = minQ;
   h->stats.stdevQ = sumQ2 / nData - h->stats.avgQ * h->stats.avgQ;
   h->stats.stdevQ = std::sqrt(std::max(h->stats.stdevQ, 1e-16));
+  if (bNeedsReturnEst) {      // :250-258
+    if (h->stats.countReturnsEstimateUpdates < 0) h->stats.countReturnsEstimateUpdates = 0;
+    h->stats.countReturnsEstimateUpdates += (int64_t)nRetUpdates;
+    h->stats.sumReturnsEstimateErrors += sumERet;
+  } else { h->stats.countReturnsEstimateUpdates = -1; h->stats.sumReturnsEstimateErrors = 0; }
 }
 
 // MemoryProcessing::applyEpisodesRemovalAlgo, "oldest" filter (MemoryProcessing.cpp:261-275,327-351)
@@ -1095,6 +1149,10 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;
   if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
+  if (cfg->nnOutputFunc < HL_FUNC_LINEAR || cfg->nnOutputFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
+  if (cfg->returnsEstimator < HL_RET_RETRACE || cfg->returnsEstimator > HL_RET_NONE) return HL_ERR_BAD_ARG;
+  if (cfg->nn_type < HL_NN_FFNN || cfg->nn_type > HL_NN_RNN) return HL_ERR_UNSUPPORTED;
+  if (cfg->n_encoder < 0 || cfg->n_encoder + cfg->n_hidden > HL_MAX_HIDDEN) return HL_ERR_BAD_ARG;
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
@@ -1107,6 +1165,12 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
     if (d.outY != (d.inpY - d.filtery + 2 * d.paddiny) / d.stridey + 1 || d.outX != (d.inpX - d.filterx + 2 * d.paddinx) / d.stridex + 1) return HL_ERR_BAD_ARG;
   }
   auto* h = new ol_learner(); h->cfg = *cfg;
+  if (cfg->n_encoder > 0) {     // createEncoder: the encoder layers are the first hidden layers of the one network (Learner_approximator.cpp:149-166)
+    int n = 0;
+    for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 0) h->cfg.hidden[n++] = cfg->encoder[j];
+    for (int j = 0; j < cfg->n_hidden; ++j) h->cfg.hidden[n++] = cfg->hidden[j];
+    h->cfg.n_hidden = n; h->cfg.n_encoder = 0;
+  }
   h->dS = cfg->dimS; h->dA = cfg->dimA;
   // HyperParameters::defineDistributedLearning (Settings/HyperParameters.cpp:177-205)
   const Real nL = cfg->n_ranks;
@@ -1287,7 +1351,7 @@ int ol_step_begin(ol_learner* h, const int64_t* flat_in) {
     if (h->tap) std::copy(inp.begin(), inp.end(), h->tState.begin() + (size_t)b * dS);
     // recurrent nets: the window of MemoryBuffer::sampleMinibatch (:391-402), min(nnBPTTseq, t) steps before t; every
     // step is forwarded with the previous one as recurrent input (Approximator::forward, Approximator.h:116-173)
-    const bool recurrent = h->cfg.nn_type == HL_NN_LSTM || h->cfg.nn_type == HL_NN_MGU;
+    const bool recurrent = h->cfg.nn_type != HL_NN_FFNN;
     std::vector<Act> series; int T = 0;
     if (recurrent) {
       const int nBPTT = h->cfg.nnBPTTseq > 0 ? h->cfg.nnBPTTseq : 16;
@@ -1452,7 +1516,7 @@ int ol_pack_episode(ol_learner* h, int64_t pos, float* dst, int64_t cap) {
 static size_t packedSize(const ol_learner* h) {
   size_t n = 0;
   for (const Layer& l : h->layers) {
-    if (l.type == L_DENSE) n += (size_t)l.size * (l.nIn + 1);
+    if (l.type == L_DENSE) n += (size_t)l.size * (l.nIn + (l.rec ? l.size : 0) + 1);   // Layer_Base.h:143-153
     else if (l.type == L_PARAMRES) n += 2 * (size_t)l.size;
     else if (l.type == L_PARAM) n += (size_t)l.size;
     else if (l.type == L_LSTM || l.type == L_MGU) n += (size_t)actSize(l) * (l.nIn + l.size + 1);   // Layer_LSTM.h:186-197, Layer_GRU.h:248-258
@@ -1465,7 +1529,7 @@ static void packBlob(const ol_learner* h, const std::vector<nnReal>& P, std::vec
   for (const Layer& l : h->layers) {
     const nnReal* W = P.data() + l.indW; const nnReal* Bv = P.data() + l.indB;
     if (l.type == L_DENSE) {
-      for (int i = 0; i < l.nIn; ++i) for (int o = 0; o < l.size; ++o) out.push_back((float)W[o + (int64_t)l.nOutSimd * i]);
+      for (int i = 0; i < l.nIn + (l.rec ? l.size : 0); ++i) for (int o = 0; o < l.size; ++o) out.push_back((float)W[o + (int64_t)l.nOutSimd * i]);
       for (int o = 0; o < l.size; ++o) out.push_back((float)Bv[o]);
     } else if (l.type == L_PARAMRES) {
       for (int o = 0; o < l.size; ++o) out.push_back((float)W[o]);
@@ -1485,7 +1549,7 @@ static void unpackBlob(const ol_learner* h, const std::vector<float>& in, std::v
   for (const Layer& l : h->layers) {
     nnReal* W = P.data() + l.indW; nnReal* Bv = P.data() + l.indB;
     if (l.type == L_DENSE) {
-      for (int i = 0; i < l.nIn; ++i) for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = (nnReal)in[k++];
+      for (int i = 0; i < l.nIn + (l.rec ? l.size : 0); ++i) for (int o = 0; o < l.size; ++o) W[o + (int64_t)l.nOutSimd * i] = (nnReal)in[k++];
       for (int o = 0; o < l.size; ++o) Bv[o] = (nnReal)in[k++];
     } else if (l.type == L_PARAMRES) {
       for (int o = 0; o < l.size; ++o) W[o] = (nnReal)in[k++];
@@ -1611,6 +1675,57 @@ static void realToSS(std::ostringstream& B, const double V, const int W, const b
   else if (std::fabs(V) >= 1e1) B << std::setprecision(std::max(W - 4 + bPos, 0));
   else B << std::setprecision(std::max(W - 3 + bPos, 0));
   B << std::fixed << V;
+}
+// MemoryBuffer::getMetrics / getHeaders (ReplayMemory/MemoryBuffer.cpp:522-575) followed by AdamOptimizer::getMetrics /
+// getHeaders (Network/Optimizer.cpp:216-226), in the order Learner::processStats calls them (Learners/Learner.cpp:158-196):
+// the metrics first -- they consume the return-estimate counters --, then the header
+int ol_metrics(ol_learner* h, char* header, int32_t headerCap, char* line, int32_t lineCap) {
+  if (!h) return HL_ERR_BAD_ARG;
+  hl_stats& st = h->stats;
+  const bool qStats = st.minQ < st.maxQ;
+  if (line) {
+    std::ostringstream buff;
+    realToSS(buff, st.avgReturn, 9, 0); realToSS(buff, (double)h->rewMean, 6, 0); realToSS(buff, (double)h->rewStd, 6, 1);
+    realToSS(buff, st.avgKLdivergence, 5, 1);
+    if (qStats) {
+      const Real EPS = std::numeric_limits<float>::epsilon();
+      st.avgSquaredErr = std::max(EPS, st.avgSquaredErr);
+      realToSS(buff, std::sqrt(st.avgSquaredErr), 6, 1); realToSS(buff, st.maxAbsError, 6, 1);
+      if (st.countReturnsEstimateUpdates > 0) {
+        const int64_t nRet = std::max((int64_t)1, st.countReturnsEstimateUpdates);
+        const Real eRet = std::max(EPS, st.sumReturnsEstimateErrors);
+        realToSS(buff, std::sqrt(eRet / nRet), 6, 1);
+        st.countReturnsEstimateUpdates = 0; st.sumReturnsEstimateErrors = 0;
+      } else { st.countReturnsEstimateUpdates = -1; st.sumReturnsEstimateErrors = 0; }
+      realToSS(buff, st.stdevQ, 6, 1); realToSS(buff, st.avgQ, 6, 0); realToSS(buff, st.minQ, 6, 0); realToSS(buff, st.maxQ, 6, 0);
+    }
+    buff << " " << std::setw(5) << (long)h->episodes.size();
+    buff << " " << std::setw(7) << (long)h->nTransitions;
+    buff << " " << std::setw(7) << (long)h->seenEpsUpd;
+    buff << " " << std::setw(8) << (long)h->seenStepsUpd;
+    buff << " " << std::setw(7) << (long)st.nFarPolicySteps;
+    if (h->CmaxRet > 1) realToSS(buff, h->beta, 6, 1);
+    long double sum = 0; for (nnReal x : h->W) sum += (long double)x * (long double)x;
+    realToSS(buff, (double)std::sqrt(sum), 7, 1);
+    const std::string sLine = buff.str();
+    if ((int)sLine.size() + 1 > lineCap) return HL_ERR_BAD_ARG;
+    std::memcpy(line, sLine.c_str(), sLine.size() + 1);
+  }
+  if (header) {
+    std::ostringstream buff;
+    buff << "|  avgR  | avgr | stdr | DKL ";
+    if (qStats) {
+      if (st.countReturnsEstimateUpdates >= 0) buff << "| RMSE |maxErr| dRet | stdQ | avgQ | minQ | maxQ ";
+      else buff << "| RMSE |maxErr| stdQ | avgQ | minQ | maxQ ";
+    }
+    buff << "| nEp |  nObs | totEp | totObs | nFarP ";
+    if (h->CmaxRet > 1) buff << "| beta ";
+    buff << std::left << std::setfill(' ') << "| " << std::setw(6) << "net";
+    const std::string sHead = buff.str();
+    if ((int)sHead.size() + 1 > headerCap) return HL_ERR_BAD_ARG;
+    std::memcpy(header, sHead.c_str(), sHead.size() + 1);
+  }
+  return HL_OK;
 }
 int ol_impweight_histogram(ol_learner* h, char* text, int32_t cap, int64_t counts[HL_IMPW_BINS]) {
   if (!h) return HL_ERR_BAD_ARG;

@@ -181,7 +181,9 @@ struct Harness {
     MDP.policyVecDim = 2 * dA;
 #endif
     HP = std::make_unique<HyperParameters>(dS, dA);
-    HP->learner = kLearner; HP->returnsEstimator = "retrace";
+    HP->learner = kLearner; HP->returnsEstimator = A.s("retEst", "retrace");      // retrace | retraceExplore | GAE | none (MemoryProcessing.cpp:418-450)
+    HP->nnOutputFunc = A.s("nnOutputFunc", "Linear");                             // activation of the output layer (Approximator.cpp:193,228)
+    HP->encoderLayerSizes = parseList(A.s("encoder", ""));                        // Learner_approximator::createEncoder (:149-166)
     HP->nnLayerSizes = parseList(A.s("layers", "256,256"));
     HP->nnFunc = A.s("nnFunc", "SoftSign");
     HP->nnType = A.s("nnType", "FFNN"); HP->nnBPTTseq = (Uint)A.l("bptt", 16);   // "LSTM": recurrent hidden layers
@@ -327,6 +329,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   const std::vector<Uint> retSteps = parseList(A.s("retSteps", ""));
   const bool official = A.s("path", "manual") == "official";
   for (long e = 0; e < nEps; ++e) H.pushSynthEpisode((uint64_t)e);
+  std::remove((L.learner_name + "_stats.txt").c_str());      // (the run's own <learner>_stats.txt is captured below)
   // resume=<prefix>: instead of (or on top of) a synthetic fill, what Learner_approximator::restart does (Learner_approximator.cpp:
   // 118-131) with the files an earlier run of this harness wrote through ckpt=<prefix> memck=<prefix>: network and Adam moments,
   // replay memory with its counters and scaling, the optimizer's step count
@@ -345,7 +348,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     std::vector<int64_t> cfg = {(int64_t)H.MDP.dimStateObserved, (int64_t)H.MDP.dimAction,
         (int64_t)H.HP->batchSize, nEps, nSteps, (int64_t)PW->nParams, (int64_t)NET.nOutputs(),
         (int64_t)L.data->nStoredSteps(), (int64_t)H.SC.seed, H.SC.lenMin, H.SC.lenMax, kAdvKind, (int64_t)H.nOpt,
-        (int64_t)(H.HP->nnType == "LSTM" ? 1 : (H.HP->nnType == "MGU" ? 2 : 0)), (int64_t)H.HP->nnBPTTseq};
+        (int64_t)(H.HP->nnType == "LSTM" ? 1 : (H.HP->nnType == "MGU" ? 2 : (H.HP->nnType == "RNN" ? 3 : 0))), (int64_t)H.HP->nnBPTTseq};
     W.i64("cfg", cfg);
     {   // MDP preprocessing: appended observations and the convolutional layers (W, H, C, K, F, S per layer)
       std::vector<int64_t> pre = {(int64_t)H.MDP.nAppendedObs};
@@ -358,6 +361,13 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       W.i64("threads", std::vector<int64_t>{(int64_t)H.info.nThreads});
       W.i64("addEvery", std::vector<int64_t>{(int64_t)A.l("addEvery", 0)});
       W.i64("minObs", std::vector<int64_t>{(int64_t)H.HP->minTotObsNum});
+      const std::string re = H.HP->returnsEstimator;
+      W.i64("retEst", std::vector<int64_t>{re == "retraceExplore" ? 1 : (re == "GAE" ? 2 : (re == "none" ? 3 : 0))});
+      const char* fn[] = {"Linear", "Tanh", "SoftSign", "Relu", "LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp"};
+      int64_t of = 0; for (int i = 0; i < 10; ++i) if (H.HP->nnOutputFunc == fn[i]) of = i;
+      W.i64("outFunc", std::vector<int64_t>{of});
+      std::vector<int64_t> enc; for (auto v : H.HP->encoderLayerSizes) enc.push_back((int64_t)v);
+      W.i64("encoder", enc);
     }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);
@@ -501,6 +511,12 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     const std::string sb = buf.str(), sh = head.str();
     W.u8("metrics_line", std::vector<uint8_t>(sb.begin(), sb.end()));
     W.u8("metrics_head", std::vector<uint8_t>(sh.begin(), sh.end()));
+  }
+  {   // <learner>_stats.txt as the run wrote it (Learner::processStats, Learner.cpp:158-196: header + one line per 1000 steps)
+    FILE* f = fopen((L.learner_name + "_stats.txt").c_str(), "rb");
+    std::vector<uint8_t> bytes;
+    if (f) { int c; while ((c = fgetc(f)) != EOF) bytes.push_back((uint8_t)c); fclose(f); }
+    W.u8("stats_file", bytes);
   }
   {   // output-gradient statistics (Utils/StatsTracker.cpp): the file the run wrote at iter % 1000 == 0 and the
       // mean / RMS over the last minibatch

@@ -21,7 +21,8 @@ HL_MAX_HIDDEN = 8
 FUNC = {"Linear": 0, "Tanh": 1, "SoftSign": 2, "Relu": 3, "LRelu": 4, "Sigm": 5, "HardSign": 6,
         "SoftPlus": 7, "ExpPlus": 8, "Exp": 9}
 ADV_ZERO, ADV_GAUSSIAN, ADV_DISCRETE = 0, 1, 2
-NN_FFNN, NN_LSTM, NN_MGU = 0, 1, 2
+NN_FFNN, NN_LSTM, NN_MGU, NN_RNN = 0, 1, 2, 3
+RET = {"retrace": 0, "default": 0, "retraceExplore": 1, "GAE": 2, "none": 3}
 ORDER_STABLE, ORDER_REFERENCE = 0, 1
 
 (TAP_FLAT, TAP_EPISODE, TAP_TSTEP, TAP_TAG, TAP_STATE, TAP_OUTPUT, TAP_OUTGRAD, TAP_RHO, TAP_DKL,
@@ -54,6 +55,7 @@ class HlConfig(C.Structure):
         ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
         ("n_options", C.c_int32), ("nn_type", C.c_int32), ("nnBPTTseq", C.c_int32),
         ("nAppendedObs", C.c_int32), ("n_conv", C.c_int32), ("conv", HlConv2d * HL_MAX_CONV), ("ERoldSeqFilter", C.c_int32), ("dataSamplingAlgo", C.c_int32),
+        ("returnsEstimator", C.c_int32), ("nnOutputFunc", C.c_int32), ("n_encoder", C.c_int32), ("encoder", C.c_int32 * HL_MAX_HIDDEN),
     ]
 
 
@@ -69,7 +71,8 @@ class HlStats(C.Structure):
     _fields_ = [("avgKLdivergence", C.c_double), ("avgSquaredErr", C.c_double),
                 ("maxAbsError", C.c_double), ("avgReturn", C.c_double), ("avgQ", C.c_double),
                 ("stdevQ", C.c_double), ("minQ", C.c_double), ("maxQ", C.c_double),
-                ("nFarPolicySteps", C.c_int64)]
+                ("nFarPolicySteps", C.c_int64), ("countReturnsEstimateUpdates", C.c_int64),
+                ("sumReturnsEstimateErrors", C.c_double)]
 
 
 def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSign", batchSize=256,
@@ -77,7 +80,8 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
                 penalTol=0.1, epsAnneal=0.0, learnrate=1e-4, nnLambda=0.0, explNoise=0.4472135955,
                 outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
                 episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0, nn_type=0, nnBPTTseq=0,
-                nAppendedObs=0, conv=(), ERoldSeqFilter="oldest", dataSamplingAlgo="uniform"):
+                nAppendedObs=0, conv=(), ERoldSeqFilter="oldest", dataSamplingAlgo="uniform",
+                returnsEstimator="retrace", nnOutputFunc="Linear", encoder=()):
     """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
     c = HlConfig()
     c.struct_size = C.sizeof(HlConfig)
@@ -96,6 +100,11 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
     # Communicator::setPreprocessingConv2d (Communicator.cpp:136-162)
     c.ERoldSeqFilter = {"oldest": 0, "default": 0, "farpolfrac": 1, "maxkldiv": 2, "minerror": 3}[ERoldSeqFilter] if isinstance(ERoldSeqFilter, str) else int(ERoldSeqFilter)
     c.dataSamplingAlgo = {"uniform": 0, "PERrank": 1, "PERerr": 2, "PERseq": 3}[dataSamplingAlgo] if isinstance(dataSamplingAlgo, str) else int(dataSamplingAlgo)
+    c.returnsEstimator = RET[returnsEstimator] if isinstance(returnsEstimator, str) else int(returnsEstimator)
+    c.nnOutputFunc = FUNC[nnOutputFunc] if isinstance(nnOutputFunc, str) else int(nnOutputFunc)
+    c.n_encoder = len(encoder)
+    for i, hsz in enumerate(encoder):
+        c.encoder[i] = int(hsz)
     c.nAppendedObs, c.n_conv = nAppendedObs, len(conv)
     for i, (iw, ih, ic, kn, fs, st) in enumerate(conv):
         d = c.conv[i]

@@ -22,7 +22,7 @@ namespace hl {
 // path for the output layer; wider action spaces use the generic path below.
 template <int HQ>
 __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra) {
-  constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4;
+  constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 2 * 4 * 72 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[HEAD_LDS > TAIL_LDS_BYTES ? HEAD_LDS : TAIL_LDS_BYTES];
   // horizontal fusion: workgroup 0 (dispatched first) runs sampler phase C of the next step
   // ... and, for wide states, workgroups 1..helpers gather the minibatch it found (one workgroup keeps only a few dozen HBM
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   if ((int)blockIdx.x < nExtra) { gatherHelper(extra.samp, blockIdx.x - 1, extra.helpers, smem); return; }
   double (*sO)[HEAD_MAXOUT] = reinterpret_cast<double (*)[HEAD_MAXOUT]>(smem);
   float (*sDelta)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8);
+  float (*sXo)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4);   // pre-activations of the output layer (nnOutputFunc)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = (blockIdx.x - nExtra) * 4 + wave;
   const DevScalars* sc = a.sc;
@@ -113,7 +114,10 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q == lane) mine = p[q];
     const int o = 8 * c + lane;
-    if (lane < 8 && o < nDense) sO[wave][o] = (double)(mine + (c == 0 ? bo : a.params[a.indBo + o]));
+    if (lane < 8 && o < nDense) {      // BaseLayer::forward of the output layer: y = f(x), f = settings nnOutputFunc (Approximator.cpp:228)
+      const float x = mine + (c == 0 ? bo : a.params[a.indBo + o]);
+      sXo[wave][o] = x; sO[wave][o] = (double)(a.outFunc == HL_FUNC_LINEAR ? x : actEval(a.outFunc, x));
+    }
   }
   if (lane < a.nSig) sO[wave][nDense + lane] = (double)bp;   // ParamLayer, Linear (absent for the discrete head)
   __builtin_amdgcn_wave_barrier();
@@ -295,6 +299,11 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   // ---- deltas of the output layer and back-propagation into the last hidden block ----------------
+  if (a.outFunc != HL_FUNC_LINEAR) {     // BaseLayer::backward: deltas *= f'(x, y) (Layer_Base.h:104-109)
+    for (int o = lane; o < nDense; o += 64) sDelta[wave][o] *= actDiff(a.outFunc, sXo[wave][o], (float)sO[wave][o]);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
   for (int o = lane; o < nDense; o += 64) a.dOut[(size_t)b * a.ldDo + o] = sDelta[wave][o];
   {
     float acc[HQ];

@@ -40,6 +40,9 @@ struct DevScalars {
   long long seenUpd[2];           // seen episodes / steps (summed over the replicas) as of the last updateCounters: ReplayCounters::nSeenEpisodes,
                                   // nSeenTransitions (MemoryProcessing.cpp:60-61) -- what the stats line prints
   long long sampleSeq;            // minibatches drawn so far (sampler phase A): hand-off tag when the gather rides along the dW kernel
+  // ReplayStats::sumReturnsEstimateErrors / countReturnsEstimateUpdates (MemoryProcessing.cpp:250-258): squared changes of the
+  // return estimates in the 1000-step sweeps since the statistics line last printed them (hl_metrics resets; -1 = printed)
+  double sumRetErr; long long cntRetUpd;
   unsigned notifySeq;             // exact-size graphs replayed so far (their last node stores it into pinned host memory: hl_sync)
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };

@@ -52,6 +52,7 @@ struct HeadArgs {
   float* Dres; float* D; int ldD;   // gradient wrt last hidden block output / after act'
   unsigned char bounded[HL_MAX_DIMA];
   int parity;
+  int outFunc;                      // activation of the output layer (settings nnOutputFunc)
 };
 
 // recurrent (LSTM) hidden layers, rec.hip: per (sample, step) rows r = b * K + k, K = nnBPTTseq + 1
@@ -67,7 +68,9 @@ struct RecLayer {
 struct RecArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
   int B, dS, nL, K, nBPTT;
-  int gates;                       // 4: LSTM (cell input, input / forget / output gate), 2: MGU (forget gate, state)
+  int gates;                       // 4: LSTM (cell input, input / forget / output gate), 2: MGU (forget gate, state), 1: dense layer with a
+                                   // recurrent term (nnType "RNN": BaseLayer with bRecurrent, Layer_Base.h:64-113)
+  int func;                        // gates == 1: the layers' activation (settings nnFunc)
   const float* W;
   RecLayer L[HL_MAX_HIDDEN];
   float* Yout; int ldY;            // output of the last block at the sampled step (rows < B) and at t+1 (next rows): input of the head
@@ -166,6 +169,8 @@ struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
   float gamma, lambda; int recompute; // recompute=1: Episode::updateCumulative first
   int skipRetrace;                   // 1: aggregates only (restart from a checkpoint keeps the stored estimates)
   long long* redNFar; float* redMaxAbs;   // per-block partials (recompute only)
+  int retKind;                       // HL_RET_*: computeRetrace / computeRetraceExplBonus / computeGAE (MemoryProcessing.cpp:391-416)
+  double* redErr;                    // per-block sums of the squared changes of the estimates (recompute only: the dRet column)
 };
 
 struct MomentsArgs {
@@ -207,11 +212,12 @@ constexpr int INGEST_MAX_EP = 1024;
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 struct TouchArgs { const void* ptr[16]; long long bytes[16]; int n; float* sink; };
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)
+hipError_t launch_set_ret_counters(DevScalars* sc, long long cnt, hipStream_t s);   // the statistics line consumed the return-estimate counters (MemoryBuffer.cpp:534-544)
 hipError_t launch_notify(DevScalars* sc, unsigned* hostWord, hipStream_t s);   // ++sc->notifySeq -> pinned host word (completion stamp polled by hl_sync)
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s);
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
-                             int nDense, int dA, int n, double* O, hipStream_t s, unsigned* done = nullptr, unsigned tag = 0);
+                             int nDense, int dA, int n, double* O, hipStream_t s, unsigned* done = nullptr, unsigned tag = 0, int outFunc = 0);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 // rollout inference for a few agents (misc.hip: act_forward_kernel): the whole dense network for one raw state per workgroup, states
 // read from and outputs written to pinned host memory, completion stamped per row
@@ -221,11 +227,12 @@ struct ActArgs {
   const float* W; const float* stMean; const float* stScale;
   const float* in; double* out; volatile unsigned* done; unsigned tag;      // pinned host memory (device-mapped)
   int dS, dIn, nL, nDense, nSig, nOut, ldWo; long long indWo, indBo, indBp;
+  int outFunc;
   ActLayer L[HL_MAX_HIDDEN];
 };
 hipError_t launch_act_forward(const ActArgs& a, int n, hipStream_t s);
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);
-hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s);
+hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s);
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);          // partial sums + final sum
 hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s);    // EMA update of the scaling
 hipError_t launch_set_counts(DevScalars* sc, long long nTransitions, long long nEpisodes,

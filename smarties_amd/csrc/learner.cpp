@@ -110,7 +110,7 @@ struct hl_learner {
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
-  long long* dRedNFar = nullptr; float* dRedMax = nullptr; int redCap = 0;
+  long long* dRedNFar = nullptr; float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
   // replayed graphs: one per entry of GRAPH_SIZES and starting minibatch buffer (step_exec.h)
@@ -233,6 +233,7 @@ int buildNet(hl_learner* h) {
     Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
     const int gates = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : 0);     // Layer_LSTM.h:24-29, Layer_GRU.h:29-34
     if (gates) { lw.push_back((long long)gates * t.size * (t.nIn + t.size)); lb.push_back(gates * t.size); }
+    else if (c.nn_type == HL_NN_RNN) { lw.push_back(roundUp(t.size, 8) * (t.nIn + t.size)); lb.push_back(t.size); }   // [W_in; W_rec] (Layer_Base.h:24-28)
     else { lw.push_back(roundUp(t.size, 8) * t.nIn); lb.push_back(t.size); }
     t.hasRes = (t.denseLayer != 1);        // no skip connection after the first layer (Builder.cpp:89-95)
     t.resLayer = -1;
@@ -275,11 +276,11 @@ int buildNet(hl_learner* h) {
   }
   for (int j = 0; j < nH; ++j) {
     DevHidden& d = h->hid[j + hOff];
-    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : 0);   // gates per cell (0: dense)
-    d.ldW = d.lstm ? d.lstm * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
+    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : (c.nn_type == HL_NN_RNN ? 1 : 0));   // gates per cell (0: dense; 1: dense with a recurrent term)
+    d.ldW = d.lstm >= 2 ? d.lstm * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
     d.indW = h->indW[hs[j].denseLayer]; d.indB = h->indB[hs[j].denseLayer];
     d.hasRes = hs[j].hasRes; d.resW = std::min(d.nIn, d.size);
-    if (d.lstm && d.hasRes && d.nIn < d.size) return HL_ERR_UNSUPPORTED;   // (the reference's residual would read LSTM cell states there, Layers.h:357)
+    if (d.lstm >= 2 && d.hasRes && d.nIn < d.size) return HL_ERR_UNSUPPORTED;   // (the reference's residual would read LSTM cell states there, Layers.h:357)
     d.indWr = d.hasRes ? h->indW[hs[j].resLayer] : 0; d.indBr = d.hasRes ? h->indB[hs[j].resLayer] : 0;
     d.ldA = (int)roundUp(d.size, 16);
   }
@@ -290,6 +291,7 @@ int buildNet(hl_learner* h) {
   for (int j = 0; j < nH; ++j) {
     if (c.nn_type == HL_NN_LSTM) h->lay.push_back({4, hs[j].nIn, hs[j].size, 4 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     else if (c.nn_type == HL_NN_MGU) h->lay.push_back({5, hs[j].nIn, hs[j].size, 2 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    else if (c.nn_type == HL_NN_RNN) h->lay.push_back({1, hs[j].nIn + hs[j].size, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});   // BaseLayer::save: input rows, then recurrent rows (Layer_Base.h:143-153)
     else h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     if (hs[j].hasRes) h->lay.push_back({2, 0, hs[j].size, 0, h->indW[hs[j].resLayer], h->indB[hs[j].resLayer]});
   }
@@ -448,14 +450,17 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute, int skip
   const int nb = sweep_blocks(count);
   if (recompute && nb > h->redCap) {
     HIPCK(devGrow(&h->dRedNFar, 0, (size_t)nb, h->stream)); HIPCK(devGrow(&h->dRedMax, 0, (size_t)nb, h->stream));
+    HIPCK(devGrow(&h->dRedErr, 0, (size_t)nb, h->stream));
     h->redCap = nb;
   }
   EpisodeSweepArgs a{}; a.sc = h->sc; a.rp = h->rp; a.eids = dEids; a.count = count;
   a.gamma = (float)h->cfg.gamma; a.lambda = (float)h->cfg.lambda; a.recompute = recompute; a.skipRetrace = skipRetrace;
-  a.redNFar = h->dRedNFar; a.redMaxAbs = h->dRedMax;
+  a.redNFar = h->dRedNFar; a.redMaxAbs = h->dRedMax; a.redErr = h->dRedErr; a.retKind = h->cfg.returnsEstimator;
   HIPCK(timed(h, recompute ? "episode_sweep_recompute" : "episode_sweep_retrace", h->stream,
               [&] { return launch_episode_sweep(a, nb, h->stream); }));
-  if (recompute) HIPCK(launch_sweep_finish(h->sc, h->dRedNFar, h->dRedMax, nb, h->stream));
+  // (a recompute sweep that also rewrites the estimates -- the 1000th-step pass over all episodes -- counts nsteps - 1 updates each)
+  const bool rewrote = !skipRetrace && h->cfg.returnsEstimator != HL_RET_NONE;
+  if (recompute) HIPCK(launch_sweep_finish(h->sc, h->dRedNFar, h->dRedMax, h->dRedErr, rewrote ? (int)h->nTransitions : -1, nb, h->stream));
   return HL_OK;
 }
 
@@ -534,7 +539,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 32)) return HL_ERR_BAD_ARG;   // head kernel: one option per lane, deltas staged in 72 floats
   if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;   // the ten names of makeFunction (Functions.h:643-668)
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
-  if (cfg->nn_type != HL_NN_FFNN && cfg->nn_type != HL_NN_LSTM && cfg->nn_type != HL_NN_MGU) return HL_ERR_UNSUPPORTED;
+  if (cfg->nn_type < HL_NN_FFNN || cfg->nn_type > HL_NN_RNN) return HL_ERR_UNSUPPORTED;
+  if (cfg->returnsEstimator < HL_RET_RETRACE || cfg->returnsEstimator > HL_RET_NONE) return HL_ERR_BAD_ARG;
+  if (cfg->nnOutputFunc < HL_FUNC_LINEAR || cfg->nnOutputFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
+  if (cfg->n_encoder < 0 || cfg->n_encoder + cfg->n_hidden > HL_MAX_HIDDEN) return HL_ERR_BAD_ARG;
   if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: one gate per thread of a 256-thread workgroup
     if (cfg->dimS > 256) return HL_ERR_UNSUPPORTED;
     for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
@@ -558,6 +566,12 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return HL_ERR_NO_DEVICE;
   hl_learner* h = new hl_learner();
   h->cfg = *cfg;
+  if (cfg->n_encoder > 0) {     // createEncoder: the encoder layers are the first hidden layers of the one network (Learner_approximator.cpp:149-166)
+    int n = 0;
+    for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 0) h->cfg.hidden[n++] = cfg->encoder[j];
+    for (int j = 0; j < cfg->n_hidden; ++j) h->cfg.hidden[n++] = cfg->hidden[j];
+    h->cfg.n_hidden = n; h->cfg.n_encoder = 0;
+  }
   h->dev = cfg->device_id >= 0 ? cfg->device_id : (cfg->rank % nDev);
   *out = h;   // so that the caller can read hl_last_error and must hl_destroy
   HIPCK(hipSetDevice(h->dev));
@@ -637,7 +651,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     const bool off = e && e[0] == '1';
     if (!off && h->nHidden == 2 && !h->recurrent && !h->preproc) {
       const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
-      h->fusedOk = d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nAdv == 0 && h->nDense <= 8 && h->ldWo == 8 &&
+      h->fusedOk = cfg->nnOutputFunc == HL_FUNC_LINEAR && d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nAdv == 0 && h->nDense <= 8 && h->ldWo == 8 &&
                    !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
                    fused_lds_bytes(h->dS, d1.size) <= 160 * 1024;
     }
@@ -678,6 +692,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   s0.beta = cfg->clipImpWeight <= 0 ? 1 : 1e-4; s0.alpha = 0.5;
   s0.Cmax = 1 + cfg->clipImpWeight; s0.Cinv = 1 / cfg->clipImpWeight;
   s0.adam_bt1 = 0.9; s0.adam_bt2 = 0.999; s0.rewMean = 0; s0.rewScale = 1; s0.rewStd = 1;
+  s0.cntRetUpd = cfg->returnsEstimator == HL_RET_NONE ? -1 : 0;
   { HostMT g; uint32_t sd = (uint32_t)(cfg->randSeed + (uint64_t)cfg->rank); g.x[0] = sd;
     for (uint32_t i = 1; i < 624; ++i) g.x[i] = 1812433253u * (g.x[i - 1] ^ (g.x[i - 1] >> 30)) + i;
     g.p = 624;
@@ -709,7 +724,7 @@ int hl_destroy(hl_learner* h) {
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
   for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
-    h->dRedNFar, h->dRedMax, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
+    h->dRedNFar, h->dRedMax, h->dRedErr, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
     h->rp.stStd, h->rp.epTag, h->rp.posRec, h->panelCtr, h->dActS, h->dActO};
@@ -778,7 +793,9 @@ int hl_init_weights(hl_learner* h) {
   for (int j = h->nConv > 0 ? 1 : 0; j < h->nHidden; ++j) {
     const DevHidden& d = h->hid[j];
     const float fac = 1; const float init = fac * initFactor(d.func, d.nIn, d.size);
-    if (d.lstm) {   // Layer_LSTM.h:167-185 / Layer_GRU.h:232-246: forget gates start open, input / output gates closed; weights in memory order
+    if (d.lstm == 1) {   // BaseLayer::initialize with bRecurrent (Layer_Base.h:115-141): input weights, then the recurrent ones, one distribution
+      for (int i = 0; i < d.nIn + d.size; ++i) for (int o = 0; o < d.size; ++o) W[d.indW + o + (long long)d.ldW * i] = uni(-init, init);
+    } else if (d.lstm) {   // Layer_LSTM.h:167-185 / Layer_GRU.h:232-246: forget gates start open, input / output gates closed; weights in memory order
       const int nC = d.size;
       if (d.lstm == 4) for (int o = 0; o < nC; ++o) { W[d.indB + o] = 0.f; W[d.indB + nC + o] = -1.f; W[d.indB + 2 * nC + o] = 1.f; W[d.indB + 3 * nC + o] = -1.f; }
       else for (int o = 0; o < nC; ++o) { W[d.indB + o] = 1.f; W[d.indB + nC + o] = 0.f; }
@@ -789,9 +806,26 @@ int hl_init_weights(hl_learner* h) {
   }
   { const DevHidden& q = h->hid[h->nHidden - 1];
     const double iFac = h->cfg.outWeightsPrefac; const float fac = (iFac > 0) ? iFac : 1;
-    const float init = fac * initFactor(HL_FUNC_LINEAR, q.size, h->nDense);
-    // Builder::setLastLayersBias: Gaussian_advantage::setInitial (Gaus_advantage.h:31-34), Linear inverse = identity
-    if (h->cfg.adv_kind == HL_ADV_GAUSSIAN) { W[h->indBo + 1] = -1.f; for (int e = 2; e < 1 + h->nAdv; ++e) W[h->indBo + e] = 1.f; }
+    const int oF = h->cfg.nnOutputFunc;
+    const float init = fac * initFactor(oF, q.size, h->nDense);
+    // Builder::setLastLayersBias (continuous actions, RACER_common.cpp:94-105): initial outputs {0 | Gaussian_advantage::setInitial
+    // (Gaus_advantage.h:31-34) | zero means}; the layer stores their pre-images under nnOutputFunc (Function::inverse,
+    // Layer_Base.h:122-125).  Discrete heads leave the biases at zero.
+    auto inverse = [&](float in) -> float {
+      switch (oF) { case HL_FUNC_TANH: return std::log((1 + in) / (1 - in)) / 2; case HL_FUNC_SIGM: return -std::log(1 / in - 1);
+        case HL_FUNC_HARDSIGN: return in / std::sqrt(1 - in * in); case HL_FUNC_SOFTSIGN: return in / (1 - std::fabs(in));
+        case HL_FUNC_LRELU: return in >= 0 ? in : in / 0.1f; case HL_FUNC_EXPPLUS: return std::log(std::exp(std::min(8.f, std::max(-8.f, in))) - 1);
+        case HL_FUNC_SOFTPLUS: return (in * in - 0.25f) / in; case HL_FUNC_EXP: return std::log(in); default: return in; }
+    };
+    if (h->cfg.adv_kind != HL_ADV_DISCRETE) {
+      std::vector<float> iv((size_t)h->nDense, 0.f);
+      if (h->cfg.adv_kind == HL_ADV_GAUSSIAN) { iv[1] = -1.f; for (int e = 2; e < 1 + h->nAdv; ++e) iv[e] = 1.f; }
+      for (int o = 0; o < h->nDense; ++o) {
+        const float pre = inverse(iv[o]);
+        if (!std::isfinite(pre)) return fail(h, HL_ERR_UNSUPPORTED, "nnOutputFunc has no finite pre-image of an initial output value (the reference starts from inf / nan there)");
+        W[h->indBo + o] = pre;
+      }
+    }
     for (int i = 0; i < q.size; ++i) for (int o = 0; o < h->nDense; ++o) W[h->indWo + o + (long long)h->ldWo * i] = uni(-init, init);
     double S = h->cfg.explNoise; if (S < FLT_EPSILON) S = FLT_EPSILON;
     for (int o = 0; o < h->nSig; ++o) W[h->indBp + o] = (float)((S * S - 0.25) / S);   // SoftPlus::_inv (Functions.h:564-568)
@@ -1207,6 +1241,16 @@ int hl_metrics(hl_learner* h, char* header, int32_t headerCap, char* line, int32
     if (qStats) {
       const double EPS = std::numeric_limits<float>::epsilon();
       real2SS(buff, std::sqrt(std::max(EPS, st.avgSquaredErr)), 6, 1); real2SS(buff, st.maxAbsError, 6, 1);
+      // the "dRet" column (MemoryBuffer.cpp:534-544): root-mean-square change of the return estimates in the sweeps since
+      // the last line; printing consumes the counters
+      long long newCnt = -1;
+      if (st.countReturnsEstimateUpdates > 0) {
+        const double nRet = (double)std::max<int64_t>(1, st.countReturnsEstimateUpdates), eRet = std::max(EPS, st.sumReturnsEstimateErrors);
+        real2SS(buff, std::sqrt(eRet / nRet), 6, 1);
+        newCnt = 0;
+      }
+      st.countReturnsEstimateUpdates = newCnt;
+      HIPCK(launch_set_ret_counters(h->sc, newCnt, h->stream));
       real2SS(buff, st.stdevQ, 6, 1); real2SS(buff, st.avgQ, 6, 0); real2SS(buff, st.minQ, 6, 0); real2SS(buff, st.maxQ, 6, 0);
     }
     buff << " " << std::setw(5) << (long)h->order.size();
@@ -1227,7 +1271,7 @@ int hl_metrics(hl_learner* h, char* header, int32_t headerCap, char* line, int32
   if (header) {
     std::ostringstream buff;
     buff << "|  avgR  | avgr | stdr | DKL ";
-    if (qStats) buff << "| RMSE |maxErr| stdQ | avgQ | minQ | maxQ ";
+    if (qStats) buff << (st.countReturnsEstimateUpdates >= 0 ? "| RMSE |maxErr| dRet | stdQ | avgQ | minQ | maxQ " : "| RMSE |maxErr| stdQ | avgQ | minQ | maxQ ");
     buff << "| nEp |  nObs | totEp | totObs | nFarP ";
     if (sc.Cmax > 1) buff << "| beta ";
     buff << std::left << std::setfill(' ') << "| " << std::setw(6) << "net";
@@ -1535,7 +1579,7 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
     ActArgs aa{}; aa.W = h->W; aa.stMean = h->rp.stMean; aa.stScale = h->rp.stScale; aa.in = pIn; aa.out = pOut; aa.done = pDone;
     aa.tag = ++h->actTag; if (aa.tag == 0) aa.tag = ++h->actTag;
     aa.dS = h->dS; aa.dIn = h->dIn; aa.nL = h->nHidden; aa.nDense = h->nDense; aa.nSig = h->nSig; aa.nOut = h->nOut; aa.ldWo = h->ldWo;
-    aa.indWo = h->indWo; aa.indBo = h->indBo; aa.indBp = h->indBp;
+    aa.indWo = h->indWo; aa.indBo = h->indBo; aa.indBp = h->indBp; aa.outFunc = h->cfg.nnOutputFunc;
     for (int j = 0; j < h->nHidden; ++j) { const DevHidden& d = h->hid[j];
       aa.L[j] = ActLayer{d.nIn, d.size, d.ldW, d.func, d.hasRes, d.resW, d.indW, d.indB, d.indWr, d.indBr}; }
     HIPCK(launch_act_forward(aa, n, h->stream));
@@ -1553,7 +1597,7 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
     HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, m, h->dS, h->dIn, h->buf[0].X0, h->ldX0, h->stream));
     int rc = launchForward(h, 0, h->stream, false, /*gather*/false); if (rc) return rc;
     HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, m,
-                            h->dActO, h->stream));
+                            h->dActO, h->stream, nullptr, 0, h->cfg.nnOutputFunc));
     HIPCK(hipMemcpyAsync(outputs + (size_t)r0 * h->nOut, h->dActO, (size_t)m * h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
   }
@@ -1577,7 +1621,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
   RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = pIn; ra.actSteps = nSteps;
   HIPCK(launch_rec_forward(ra, h->stream));
   HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
-                          pOut, h->stream, const_cast<unsigned*>(pDone), tag));
+                          pOut, h->stream, const_cast<unsigned*>(pDone), tag, h->cfg.nnOutputFunc));
   { int rc = actWait(h, pDone, 1, tag); if (rc) return rc; }
   std::memcpy(outputs, pOut, (size_t)h->nOut * sizeof(double));
   return HL_OK;
@@ -1692,6 +1736,8 @@ int hl_get_stats(hl_learner* h, hl_stats* o) {
   HIPCK(hipStreamSynchronize(h->stream));
   o->avgKLdivergence = out[0]; o->avgSquaredErr = out[1]; o->maxAbsError = out[2]; o->avgReturn = out[3];
   o->avgQ = out[4]; o->stdevQ = out[5]; o->minQ = out[6]; o->maxQ = out[7]; o->nFarPolicySteps = (int64_t)out[8];
+  DevScalars sc; rc = syncScalarsToHost(h, &sc); if (rc) return rc;      // (live counters: a snapshot may predate the last statistics line)
+  o->countReturnsEstimateUpdates = (int64_t)sc.cntRetUpd; o->sumReturnsEstimateErrors = sc.sumRetErr;
   return HL_OK;
 }
 

@@ -46,10 +46,15 @@ __device__ __forceinline__ double rlD(double v, int l) {
 __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) {
   __shared__ long long sFar[4];
   __shared__ float sMax[4];
+  __shared__ double sErr[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nWaves = gridDim.x * 4;
   const DevScalars* sc = a.sc;
-  long long myFar = 0; float myMax = 0.f;
+  long long myFar = 0; float myMax = 0.f; double myErr = 0;
+  // computeRetraceExplBonus (:402-408): coefficient 1 - gamma, baseline = ReplayStats::maxAbsError as it stands when the
+  // sweep starts (createReturnEstimator captures it before this step's update, :431)
+  const int kind = a.retKind;
+  const float explCoef = 1 - a.gamma, explBase = (float)sc->maxAbsErrEMA;
   const float C = (float)sc->Cmax, invC = (float)sc->Cinv;
   const float gamma = a.gamma, lambda = a.lambda;
   const float rM = sc->rewMean, rS = sc->rewScale;
@@ -91,33 +96,59 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
       myFar += farSteps((float)N, invN * (float)nFarPol);
       myMax = fmaxf(myMax, fmaxf(maxAE, 0.f));
     }
-    if (a.skipRetrace) continue;
+    if (a.skipRetrace || kind == HL_RET_NONE) continue;
     float Q = term ? a.rp.RET[off + N - 1] : a.rp.V[off + N - 1];
     if (!term && lane == 0) a.rp.RET[off + N - 1] = Q;
+    float epErr = 0.f;                               // updateReturnEstimator's sumErr2 (Fval, each term added in double)
     for (int t1 = N - 2; t1 >= 0; t1 -= 64) {      // chunk covers t = t1, t1-1, ..., t1-63
       const int t = t1 - lane;
       const bool ok = t >= 0;
       const double rr = ok ? a.rp.R[off + t + 1] : 0.0;
       const float vv = ok ? a.rp.V[off + t + 1] : 0.f, ad = ok ? a.rp.ADV[off + t + 1] : 0.f, iw = ok ? a.rp.IMPW[off + t + 1] : 0.f;
+      const float old = (ok && a.recompute) ? a.rp.RET[off + t] : 0.f;
       const float Rl = (float)((rr - (double)rM) * (double)rS);      // per lane, same expression as the reference
       const float wl = iw < 1.f ? iw : 1.f;
       const int cnt = min(64, t1 + 1);
       float mine = 0.f;
+      if (kind == HL_RET_RETRACE) {
 #pragma unroll 8
-      for (int u = 0; u < cnt; ++u) {
-        const float Vu = rlF(vv, u), Au = rlF(ad, u);
-        Q = rlF(Rl, u) + gamma * (Vu + lambda * rlF(wl, u) * (Q - Au - Vu));
-        if (lane == u) mine = Q;
+        for (int u = 0; u < cnt; ++u) {
+          const float Vu = rlF(vv, u), Au = rlF(ad, u);
+          Q = rlF(Rl, u) + gamma * (Vu + lambda * rlF(wl, u) * (Q - Au - Vu));
+          if (lane == u) mine = Q;
+        }
+      } else if (kind == HL_RET_GAE) {
+#pragma unroll 8
+        for (int u = 0; u < cnt; ++u) {
+          const float Vu = rlF(vv, u);
+          Q = rlF(Rl, u) + gamma * (Vu + lambda * (Q - Vu));
+          if (lane == u) mine = Q;
+        }
+      } else {
+#pragma unroll 8
+        for (int u = 0; u < cnt; ++u) {
+          const float Vu = rlF(vv, u), Au = rlF(ad, u);
+          const float dl = Q - Au - Vu;
+          const float ret = rlF(Rl, u) + gamma * (Vu + lambda * rlF(wl, u) * dl);
+          Q = explCoef * (fabsf(dl) - explBase) + ret;
+          if (lane == u) mine = Q;
+        }
       }
       if (ok) a.rp.RET[off + t] = mine;
+      if (a.recompute) {
+        const float df = old - mine;
+        for (int u = 0; u < cnt; ++u) { const float du = rlF(df, u); epErr = (float)((double)epErr + (double)du * (double)du); }
+      }
     }
+    myErr += (double)epErr;
   }
   if (a.recompute) {
-    if (lane == 0) { sFar[wave] = myFar; sMax[wave] = myMax; }
+    if (lane == 0) { sFar[wave] = myFar; sMax[wave] = myMax; sErr[wave] = myErr; }
     __syncthreads();
     if (threadIdx.x == 0) {
       a.redNFar[blockIdx.x] = sFar[0] + sFar[1] + sFar[2] + sFar[3];
       a.redMaxAbs[blockIdx.x] = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+      a.redErr[blockIdx.x] = (sErr[0] + sErr[1]) + (sErr[2] + sErr[3]);
     }
   }
 }
@@ -127,19 +158,21 @@ hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStrea
   hipLaunchKernelGGL(episode_sweep_kernel, dim3(nBlocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-__global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int n) {
+// countRet >= 0: the sweep rewrote that many return estimates (MemoryProcessing.cpp:250-258); < 0: it did not touch them
+__global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, const double* redErr, int countRet, int n) {
   if (blockIdx.x != 0) return;
-  long long f = 0; float m = 0.f;                       // integer sum / max: any order gives the same result
-  for (int i = threadIdx.x; i < n; i += 64) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); }
-  for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); m = fmaxf(m, __shfl_xor(m, o, 64)); }
+  long long f = 0; float m = 0.f; double er = 0;        // integer sum / max: any order gives the same result
+  for (int i = threadIdx.x; i < n; i += 64) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); er += redErr[i]; }
+  for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); m = fmaxf(m, __shfl_xor(m, o, 64)); er += __shfl_xor(er, o, 64); }
   if (threadIdx.x != 0) return;
+  if (countRet >= 0) { sc->cntRetUpd = (sc->cntRetUpd < 0 ? 0 : sc->cntRetUpd) + countRet; sc->sumRetErr += er; }
   sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
   sc->maxAbsErrAll = m;
   sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
   sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1];
 }
-hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, int nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(64), 0, s, sc, redNFar, redMaxAbs, nBlocks);
+hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(64), 0, s, sc, redNFar, redMaxAbs, redErr, countRet, nBlocks);
   return hipGetLastError();
 }
 
@@ -309,14 +342,14 @@ __global__ __launch_bounds__(256) void act_standardize_kernel(DevScalars* sc, De
 }
 // done != nullptr (one row, outputs in pinned host memory): the row is stamped once its outputs are visible to the host
 __global__ __launch_bounds__(256) void act_output_kernel(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo,
-                                                         long long indBp, int ldWo, int nDense, int dA, int n, double* O, unsigned* done, unsigned tag) {
+                                                         long long indBp, int ldWo, int nDense, int dA, int n, double* O, unsigned* done, unsigned tag, int outFunc) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, nOut = nDense + dA;
   if (row >= n) return;
   for (int o = 0; o < nDense; ++o) {
     float p = 0.f;
     for (int k = lane; k < H; k += 64) p += Y[(size_t)row * ldY + k] * W[indWo + (long long)k * ldWo + o];
     p = waveSumF(p);
-    if (lane == 0) O[(size_t)row * nOut + o] = (double)(p + W[indBo + o]);
+    if (lane == 0) O[(size_t)row * nOut + o] = (double)actEval(outFunc, p + W[indBo + o]);
   }
   if (lane < dA) O[(size_t)row * nOut + nDense + lane] = (double)W[indBp + lane];
   if (done) {
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(256) void act_forward_kernel(ActArgs a) {
     float p = 0.f;
     for (int k = lane; k < H; k += 64) p = fmaf(in[k], W[a.indWo + (long long)k * a.ldWo + o], p);
     p = waveSumF(p);
-    if (lane == 0) a.out[(size_t)row * a.nOut + o] = (double)(p + W[a.indBo + o]);
+    if (lane == 0) a.out[(size_t)row * a.nOut + o] = (double)actEval(a.outFunc, p + W[a.indBo + o]);
   }
   if (tid < a.nSig) a.out[(size_t)row * a.nOut + a.nDense + tid] = (double)W[a.indBp + tid];
   __threadfence_system();
@@ -380,8 +413,8 @@ hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, 
   return hipGetLastError();
 }
 hipError_t launch_act_output(const float* Y, int ldY, int H, const float* W, long long indWo, long long indBo, long long indBp, int ldWo,
-                             int nDense, int dA, int n, double* O, hipStream_t s, unsigned* done, unsigned tag) {
-  hipLaunchKernelGGL(act_output_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Y, ldY, H, W, indWo, indBo, indBp, ldWo, nDense, dA, n, O, done, tag);
+                             int nDense, int dA, int n, double* O, hipStream_t s, unsigned* done, unsigned tag, int outFunc) {
+  hipLaunchKernelGGL(act_output_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Y, ldY, H, W, indWo, indBo, indBp, ldWo, nDense, dA, n, O, done, tag, outFunc);
   return hipGetLastError();
 }
 
@@ -489,6 +522,9 @@ __global__ __launch_bounds__(256) void touch_kernel(TouchArgs a) {
   if (acc == 1.2345e-30f) *a.sink = acc;
 }
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s) { hipLaunchKernelGGL(touch_kernel, dim3(256), dim3(256), 0, s, a); return hipGetLastError(); }
+
+__global__ void set_ret_counters_kernel(DevScalars* sc, long long cnt) { sc->cntRetUpd = cnt; sc->sumRetErr = 0; }
+hipError_t launch_set_ret_counters(DevScalars* sc, long long cnt, hipStream_t s) { hipLaunchKernelGGL(set_ret_counters_kernel, dim3(1), dim3(1), 0, s, sc, cnt); return hipGetLastError(); }
 
 __global__ void empty_kernel() {}
 hipError_t launch_empty(hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); return hipGetLastError(); }

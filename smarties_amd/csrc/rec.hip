@@ -1205,6 +1205,179 @@ __global__ __launch_bounds__(128) void mgu32_backward_wave_kernel(RecArgs a) {
   }
 }
 
+// ---- nnType "RNN": dense layers with a recurrent term (BaseLayer with bRecurrent; Network/Builder.cpp:76-81,
+// Network/Layers/Layer_Base.h:64-113): x_t = W_in^T in_t + W_rec^T y_{t-1} + b, y_t = f(x_t); weights [W_in; W_rec] row-major with the
+// dense layers' pitch roundUp(cells, 8); backward Layer::backward with NR = cells (Layers.h:123-188).  One workgroup per sample
+// walks the window; the weights of all layers sit in LDS (pitch + 1: the forward pass reads columns, the backward pass rows);
+// a cell's sum is split over the four wavefronts (rows i = wave, wave + 4, ...) and joined in wave order.  Rows kept per
+// (sample, step): [input | previous output] (A operand of the weight gradients), x, y, and the deltas after f'. ----
+__device__ __forceinline__ int rnnPitch(int nC) { return ((nC + 7) & ~7) + 1; }
+__device__ __forceinline__ void rnnStageWeights(const RecArgs& a, float* sW, int tid) {
+  int off = 0;
+  for (int j = 0; j < a.nL; ++j) {
+    const RecLayer& L = a.L[j];
+    const int ld = (L.nC + 7) & ~7, rows = L.nIn + L.nC, pitch = ld + 1;
+    const float* src = a.W + L.indW;
+    const int total = rows * ld;
+    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; v[u] = e < total ? src[e] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < total) { const int i = e / ld, o = e - i * ld; sW[off + i * pitch + o] = v[u]; } }
+    }
+    off += rows * pitch;
+  }
+}
+__device__ __forceinline__ int rnnLdsOffset(const RecArgs& a, int j) {
+  int off = 0;
+  for (int q = 0; q < j; ++q) off += (a.L[q].nIn + a.L[q].nC) * rnnPitch(a.L[q].nC);
+  return off;
+}
+template <bool LDSW>
+__global__ __launch_bounds__(256) void rnn_forward_kernel(RecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  __shared__ float sBuf[2][REC_MAXIN];
+  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC];
+  __shared__ float sPart[4][REC_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  const bool acting = a.actStates != nullptr;
+  const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
+  const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
+  const int nextRow = acting ? -1 : a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  if constexpr (LDSW) rnnStageWeights(a, sW, tid);
+  float bias[HL_MAX_HIDDEN], wr[HL_MAX_HIDDEN], br[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) {
+    bias[j] = 0.f; wr[j] = 0.f; br[j] = 0.f;
+    if (j < a.nL) {
+      const RecLayer& L = a.L[j];
+      if (tid < L.nC) bias[j] = W[L.indB + tid];
+      if (L.hasRes && tid < L.resW) { wr[j] = W[L.indWr + tid]; br[j] = W[L.indBr + tid]; }
+    }
+  }
+  const float sMean = tid < a.dS ? a.rp.stMean[tid] : 0.f, sScale = tid < a.dS ? a.rp.stScale[tid] : 1.f;
+  vmDrain(); ldsBarrier();
+  for (int k = 0; k < nSteps; ++k) {
+    const bool store = !acting && k <= T;
+    const long long r = (long long)b * a.K + k;
+    const long long sl = slot - T + k;
+    if (tid < a.dS) { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)sl * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
+    ldsBarrier();
+    int cur = 0;
+    for (int j = 0; j < a.nL; ++j) {
+      const RecLayer& L = a.L[j];
+      const int nIn = L.nIn, nC = L.nC, ld = (nC + 7) & ~7;
+      const float* in = sBuf[cur];
+      const int pitch = LDSW ? ld + 1 : ld, wOff = LDSW ? rnnLdsOffset(a, j) : 0;
+      const float* gWj = W + L.indW;
+      auto wAt = [&](int i, int o) -> float { if constexpr (LDSW) return sW[wOff + i * pitch + o]; else return gWj[(size_t)i * pitch + o]; };
+      if (store) {
+        for (int i = tid; i < nIn; i += 256) L.A[r * L.ldA + i] = in[i];
+        if (tid < nC) L.A[r * L.ldA + nIn + tid] = k > 0 ? sPrevOut[j][tid] : 0.f;
+      }
+      if (c < nC) {       // quarter sums over the rows i = part, part + 4, ...: first the inputs, then the previous outputs
+        float acc = 0.f;
+#pragma unroll 4
+        for (int i = part; i < nIn; i += 4) acc += in[i] * wAt(i, c);
+        if (k > 0) {
+#pragma unroll 4
+          for (int i = part; i < nC; i += 4) acc += sPrevOut[j][i] * wAt(nIn + i, c);
+        }
+        sPart[part][c] = acc;
+      }
+      ldsBarrier();
+      float out = 0.f;
+      if (tid < nC) {
+        const float x = bias[j] + ((sPart[0][tid] + sPart[1][tid]) + (sPart[2][tid] + sPart[3][tid]));
+        out = actEval(a.func, x);
+        if (store) { L.X[r * nC + tid] = x; L.Y[r * nC + tid] = out; }
+        float blk = out;                                   // ParametricResidualLayer::forward (Layers.h:347-361)
+        if (L.hasRes && tid < L.resW) blk += in[tid] * wr[j] + br[j];
+        sBuf[cur ^ 1][tid] = blk;
+      }
+      ldsBarrier();
+      if (tid < nC) sPrevOut[j][tid] = out;
+      cur ^= 1;
+    }
+    const int nCl = a.L[a.nL - 1].nC;
+    if (k == T && tid < nCl) a.Yout[(size_t)b * a.ldY + tid] = sBuf[cur][tid];
+    if (k == T + 1 && tid < nCl) a.Yout[(size_t)nextRow * a.ldY + tid] = sBuf[cur][tid];
+    ldsBarrier();
+  }
+}
+template <bool LDSW>
+__global__ __launch_bounds__(256) void rnn_backward_kernel(RecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  __shared__ float sTop[2][REC_MAXIN];                    // error w.r.t. the output of the current block (from above, same step)
+  __shared__ float sRec[HL_MAX_HIDDEN][REC_MAXC];          // error w.r.t. this step's output coming from step k+1
+  __shared__ float sD[REC_MAXC], sRes[REC_MAXC], sRecNew[REC_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = a.bt.t[b];
+  const int T = min(a.nBPTT, t);
+  const float* W = a.W;
+  if constexpr (LDSW) rnnStageWeights(a, sW, tid);
+  float wr[HL_MAX_HIDDEN];
+#pragma unroll
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) { wr[j] = 0.f; if (j < a.nL && a.L[j].hasRes && tid < a.L[j].resW) wr[j] = W[a.L[j].indWr + tid]; }
+  vmDrain(); ldsBarrier();
+  for (int k = T + 1; k < a.K; ++k) {      // rows of the steps this sample does not have: zero deltas
+    const long long r = (long long)b * a.K + k;
+    for (int j = 0; j < a.nL; ++j) {
+      const RecLayer& L = a.L[j];
+      if (tid < L.nC) { L.D[r * L.nC + tid] = 0.f; if (L.hasRes) L.Rd[r * L.ldR + tid] = 0.f; }
+    }
+  }
+  for (int k = T; k >= 0; --k) {
+    const long long r = (long long)b * a.K + k;
+    int cur = 0;
+    const int nCl = a.L[a.nL - 1].nC;
+    if (tid < nCl) sTop[0][tid] = k == T ? a.Dres[(size_t)b * a.ldD + tid] : 0.f;
+    ldsBarrier();
+    for (int j = a.nL - 1; j >= 0; --j) {
+      const RecLayer& L = a.L[j];
+      const int nIn = L.nIn, nC = L.nC, ld = (nC + 7) & ~7;
+      const int pitch = LDSW ? ld + 1 : ld, wOff = LDSW ? rnnLdsOffset(a, j) : 0;
+      const float* gWj = W + L.indW;
+      auto wAt = [&](int i, int o) -> float { if constexpr (LDSW) return sW[wOff + i * pitch + o]; else return gWj[(size_t)i * pitch + o]; };
+      if (tid < nC) {
+        const float eTop = sTop[cur][tid];
+        if (L.hasRes) { L.Rd[r * L.ldR + tid] = eTop; sRes[tid] = tid < L.resW ? eTop * wr[j] : 0.f; }
+        const float D = eTop + (k < T ? sRec[j][tid] : 0.f);
+        const float d = D * actDiff(a.func, L.X[r * nC + tid], L.Y[r * nC + tid]);     // BaseLayer::backward (Layer_Base.h:97-113)
+        sD[tid] = d; L.D[r * nC + tid] = d;
+      }
+      ldsBarrier();
+      // Layer::backward (Layers.h:123-188): rows 0..nIn-1 of [W_in; W_rec] give the error of the block below (not below the first
+      // layer), rows nIn.. the error handed to the previous step; one row per group of four lanes, quarter sums joined by shuffles
+      {
+        const int part = tid & 3, row0 = j > 0 ? 0 : nIn, nRow = nIn + (k > 0 ? nC : 0);
+        for (int i0 = row0; i0 < nRow; i0 += 64) {
+          const int i = i0 + (tid >> 2);
+          float e = 0.f;
+          if (i < nRow) for (int o = part; o < nC; o += 4) e += wAt(i, o) * sD[o];
+          e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64);
+          if (part == 0 && i < nRow) {
+            if (i < nIn) sTop[cur ^ 1][i] = (L.hasRes && i < L.resW ? sRes[i] : 0.f) + e;
+            else sRecNew[i - nIn] = e;
+          }
+        }
+      }
+      ldsBarrier();
+      if (tid < nC) sRec[j][tid] = k > 0 ? sRecNew[tid] : 0.f;
+      cur ^= 1;
+    }
+    ldsBarrier();
+  }
+}
+static size_t rnnLdsBytes(const RecArgs& a) {
+  size_t fl = 0;
+  for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (((a.L[j].nC + 7) & ~7) + 1);
+  return fl * sizeof(float);
+}
+
 static bool mgu32Wave(const RecArgs& a) {
   return a.gates == 2 && (a.actStates == nullptr || a.actSteps <= 17) && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
          a.L[0].nIn <= 32 && a.dS == a.L[0].nIn && a.K <= 17 && a.L[0].indW % 4 == 0 && a.L[1].indW % 4 == 0 && !a.L[0].hasRes;
@@ -1227,6 +1400,7 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
+  if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 120 * 1024 ? recLaunch(rnn_forward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_forward_kernel<false>, a, 0, &attr[1], s); }
   if (mgu32Wave(a)) {        // two layers of 32 cells, training pass: one wavefront per (sample, layer), weights in registers
     const int in0 = (a.L[0].nIn + 3) & ~3;
     if (in0 <= 4) hipLaunchKernelGGL(mgu32_forward_wave_kernel<4>, dim3(a.B), dim3(128), 0, s, a);
@@ -1266,6 +1440,7 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
+  if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 120 * 1024 ? recLaunch(rnn_backward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_backward_kernel<false>, a, 0, &attr[1], s); }
   if (a.gates == 2) {
     static size_t attrM[4] = {0, 0, 0, 0};
     if (mgu32Wave(a)) { hipLaunchKernelGGL(mgu32_backward_wave_kernel<32>, dim3(a.B), dim3(128), 0, s, a); return hipGetLastError(); }

@@ -77,7 +77,11 @@ int buildProblems(hl_learner* h) {
       // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
       // sample does not have carry zero deltas (rec_backward_kernel)
       const RecLayer& L = h->rec[j]; const int R = B * h->recK;
-      if (h->hid[j].lstm == 4) {
+      if (h->hid[j].lstm == 1) {   // dense layer with a recurrent term: rows [input | previous output | 1], one delta column block
+        GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = L.nC; p.K = R;
+        p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = L.nC; p.C = h->G + L.indW; p.ldc = h->hid[j].ldW; p.biasOut = h->G + L.indB;
+        setTiles(p, cur, true); P.push_back(p);
+      } else if (h->hid[j].lstm == 4) {
         GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = 4 * L.nC; p.K = R;
         p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 4 * L.nC; p.C = h->G + L.indW; p.ldc = 4 * L.nC; p.biasOut = h->G + L.indB;
         setTiles(p, cur, true); P.push_back(p);
@@ -203,7 +207,7 @@ HeadArgs headArgs(hl_learner* h, int parity) {
   HeadArgs ha{}; ha.sc = h->sc; ha.rp = h->rp; ha.bt = h->buf[parity].bt; ha.B = h->B; ha.dA = h->dA; ha.nDense = h->nDense; ha.nAdv = h->cfg.adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0; ha.nOpt = h->nOpt; ha.nSig = h->nSig;
   ha.nOut = h->nOut; ha.H = q.size; ha.Yin = q.hasRes ? q.Rr : q.Y; ha.ldY = q.ldA; ha.Xlast = q.X; ha.Ylast = q.Y;
   ha.func = q.func; ha.params = h->W; ha.indWo = h->indWo; ha.indBo = h->indBo; ha.indBp = h->indBp; ha.ldWo = h->ldWo;
-  ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA; ha.parity = parity;
+  ha.dOut = h->dOut; ha.ldDo = h->ldDo; ha.Dres = q.Dres; ha.D = q.D; ha.ldD = q.ldA; ha.parity = parity; ha.outFunc = h->cfg.nnOutputFunc;
   for (int i = 0; i < h->dA; ++i) ha.bounded[i] = h->cfg.bounded[i];
   return ha;
 }
@@ -501,7 +505,7 @@ bool evictionDue(const hl_learner* h) {
 RecArgs recArgs(hl_learner* h, int parity) {
   const DevHidden& q = h->hid[h->nHidden - 1];
   RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS; ra.nL = h->nHidden;
-  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[0].lstm;
+  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[0].lstm; ra.func = h->cfg.nnFunc;
   for (int j = 0; j < h->nHidden; ++j) ra.L[j] = h->rec[j];
   ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA;
   return ra;

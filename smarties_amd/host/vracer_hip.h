@@ -57,8 +57,11 @@ struct HyperParameters {
   Uint minTotObsNum = 0, maxTotObsNum = 1 << 20, batchSize = 256;
   std::vector<Uint> nnLayerSizes = {128, 128};
   std::string nnFunc = "Tanh";
-  std::string nnType = "FFNN";      // "FFNN", "LSTM" or "MGU" (Network/Builder.cpp:48-117); nnBPTTseq: steps of truncated BPTT
+  std::string nnType = "FFNN";      // "FFNN", "LSTM", "MGU" / "GRU" or "RNN" (Network/Builder.cpp:48-117); nnBPTTseq: steps of truncated BPTT
   Uint nnBPTTseq = 16;
+  std::string nnOutputFunc = "Linear";          // activation of the output layer (Network/Approximator.cpp:193,228)
+  std::vector<Uint> encoderLayerSizes = {};     // dense layers of the preprocessing network, ahead of nnLayerSizes (Learner_approximator.cpp:149-166)
+  std::string returnsEstimator = "default";     // "default" / "retrace", "retraceExplore", "GAE", "none" (MemoryProcessing.cpp:418-450)
   std::string learner = "VRACER";   // "VRACER" (Zero_advantage) or "RACER" (Gaussian_advantage), AlgoFactory.cpp:109-152
   std::string ERoldSeqFilter = "oldest";        // "oldest", "farpolfrac", "maxkldiv", "minerror" (MemoryProcessing.cpp:261-298)
   std::string dataSamplingAlgo = "uniform";     // "uniform", "PERrank", "PERerr", "PERseq" (Sampling.cpp:298-340)
@@ -123,7 +126,7 @@ class VRACER {
 
   VRACER(const MDPdescriptor& M, const HyperParameters& hp, int deviceID = 0, int nLearners = 1, int learnerRank = 0)
       : MDP(M), S(hp) {
-    if (M.dimAction > HL_MAX_DIMA || hp.nnLayerSizes.size() > HL_MAX_HIDDEN) die("problem too large for hl_config");
+    if (M.dimAction > HL_MAX_DIMA || hp.nnLayerSizes.size() + hp.encoderLayerSizes.size() > HL_MAX_HIDDEN) die("problem too large for hl_config");
     hl_config c{}; c.struct_size = sizeof(c);
     c.dimS = (int32_t)M.dimStateObserved; c.dimA = (int32_t)M.dimAction;
     for (Uint i = 0; i < M.dimAction; ++i) c.bounded[i] = i < M.bActionSpaceBounded.size() && M.bActionSpaceBounded[i];
@@ -132,7 +135,16 @@ class VRACER {
     c.nnFunc = funcId(hp.nnFunc);
     if (hp.nnType == "LSTM") { c.nn_type = HL_NN_LSTM; c.nnBPTTseq = (int32_t)hp.nnBPTTseq; recurrent = true; }
     else if (hp.nnType == "MGU" || hp.nnType == "GRU") { c.nn_type = HL_NN_MGU; c.nnBPTTseq = (int32_t)hp.nnBPTTseq; recurrent = true; }   // Builder.cpp:68-73
-    else if (hp.nnType != "FFNN") die("nnType " + hp.nnType + " is not served by the HIP library");
+    else if (hp.nnType == "RNN") { c.nn_type = HL_NN_RNN; c.nnBPTTseq = (int32_t)hp.nnBPTTseq; recurrent = true; }       // Builder.cpp:76-81
+    else if (hp.nnType != "FFNN") die("nnType " + hp.nnType + " is not served by the HIP library");      // ("Recurrent": recurrent layers without a BPTT window, HyperParameters.cpp:209)
+    c.nnOutputFunc = funcId(hp.nnOutputFunc);
+    c.n_encoder = (int32_t)hp.encoderLayerSizes.size();
+    for (Uint i = 0; i < hp.encoderLayerSizes.size(); ++i) c.encoder[i] = (int32_t)hp.encoderLayerSizes[i];
+    // AlgoFactory.cpp:134-135: "default" means Retrace for RACER / VRACER
+    c.returnsEstimator = (hp.returnsEstimator == "default" || hp.returnsEstimator == "retrace") ? HL_RET_RETRACE :
+                         hp.returnsEstimator == "retraceExplore" ? HL_RET_RETRACE_EXPLORE : hp.returnsEstimator == "GAE" ? HL_RET_GAE :
+                         hp.returnsEstimator == "none" ? HL_RET_NONE : -1;
+    if (c.returnsEstimator < 0) die("returnsEstimator " + hp.returnsEstimator + " not recognized");
     // AlgoFactory.cpp:78-152: discrete action spaces always get RACER<Discrete_advantage, Discrete_policy, Uint>
     if (M.bDiscreteActions()) {
       if (M.dimAction != 1 || M.discreteActionValues.size() != 1) die("one discrete action variable is served");

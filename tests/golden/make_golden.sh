@@ -123,5 +123,35 @@ a, b = load_blob(sys.argv[1]), load_blob(sys.argv[2])
 assert np.array_equal(a['Wfinal'], b['Wfinal']), "manual tap path diverged from the official task-queue path"
 print("harness check: manual == official (bit-identical weights)")
 PY
-rm -rf "$TMP"
 ls -la "$HERE"/*.bin
+
+# ---- round 3: the rest of the settings surface of this path -----------------------------------------------------------------
+# G-ret-*: returnsEstimator other than Retrace (MemoryProcessing::createReturnEstimator, MemoryProcessing.cpp:418-450) across the
+# 1000-step sweep; every fixture from here on also carries the <learner>_stats.txt the run wrote (header + the line of step 1000,
+# with its dRet column)
+"$DRV" fixture "$HERE/ret_gae.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=1,999,1000,1200 maxObs=2000 minObs=500 epsAnneal=5e-7 retEst=GAE lambda=0.9
+"$DRV" fixture "$HERE/ret_explore.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=1200 tapSteps=2 gradSteps=1000 retSteps=1,999,1000,1200 maxObs=2000 minObs=500 epsAnneal=5e-7 retEst=retraceExplore lambda=0.95 addEvery=7
+"$DRV" fixture "$HERE/ret_none.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=12 gradSteps=1,12 retSteps=12 maxObs=2000 minObs=500 retEst=none
+# G-stats-2100: plain Retrace over two statistics lines (steps 1000 and 2000): the dRet column and its counters' reset
+"$DRV" fixture "$HERE/stats_2100.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=2100 tapSteps=1 gradSteps=2000 retSteps=2000 maxObs=2000 minObs=500 epsAnneal=5e-7
+# G-outfunc-*: nnOutputFunc (Approximator.cpp:193,228): the output layer's activation and the pre-images of its initial biases
+"$DRV" fixture "$HERE/outfunc_tanh.bin" dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 \
+   nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 nnOutputFunc=Tanh
+"$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/outfunc_lrelu_gauss.bin" dimS=5 dimA=2 bounded=10 layers=24,16,8 nnFunc=Tanh batch=16 nEps=30 \
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 nnOutputFunc=LRelu
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/outfunc_sigm_discrete.bin" dimS=5 dimA=1 nOpt=4 layers=32,32 batch=16 nEps=30 \
+   lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 nnOutputFunc=Sigm
+# G-encoder: encoderLayerSizes (Learner_approximator::createEncoder, :149-166): dense layers of the preprocessing network ahead of
+# nnLayerSizes, one network; with a zero entry that createEncoder drops
+"$DRV" fixture "$HERE/encoder_dense.bin" dimS=5 dimA=2 bounded=10 encoder=24,0 layers=16,16 nnFunc=Tanh batch=16 nEps=30 lenMin=5 lenMax=40 \
+   pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_enc"
+# G-rnn: nnType "RNN": dense layers with a recurrent term (Builder.cpp:76-81, Layer_Base.h:64-113), truncated BPTT over 8 steps
+"$DRV" fixture "$HERE/vracer_rnn.bin" dimS=5 dimA=2 bounded=10 layers=32,32 nnType=RNN nnFunc=Tanh bptt=8 \
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_rnn"
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/discrete_rnn.bin" dimS=5 dimA=1 nOpt=4 layers=24 nnType=RNN nnFunc=SoftSign bptt=5 \
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+rm -rf "$TMP"

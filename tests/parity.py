@@ -39,6 +39,10 @@ def fixture_config(fx, **over):
         kw["minTotObsNum"] = int(fx["minObs"][0])
     if "threads" in fx:          # OpenMP threads of the reference run that recorded the fixture
         kw["ref_threads"] = int(fx["threads"][0])
+    if "retEst" in fx:           # settings keys returnsEstimator, nnOutputFunc, encoderLayerSizes of the recording run
+        kw["returnsEstimator"] = int(fx["retEst"][0])
+        kw["nnOutputFunc"] = int(fx["outFunc"][0])
+        kw["encoder"] = [int(x) for x in fx["encoder"]]
     kw.update(over)
     return capi.make_config(**kw)
 
@@ -165,9 +169,18 @@ def real2ss(v, w, bpos):
     return " %*.*f" % (w, max(w - drop + bpos, 0), v)
 
 
+def stats_file_lines(fx):
+    """(header, [lines]) of the <learner>_stats.txt the recording run wrote (Learner::processStats, Learner.cpp:158-196):
+    "ID #/T   <header>" once, then "<learnID> <step / 1000><columns>" per statistics line."""
+    txt = bytes(bytearray(fx["stats_file"])).decode().splitlines()
+    head = txt[0][len("ID #/T   "):]
+    return head, [l[len("00 00001"):] for l in txt[1:]]
+
+
 def stats_line(L):
     """The line Learner::logStats writes (MemoryBuffer::getMetrics, MemoryBuffer.cpp:522-548, then
-    AdamOptimizer::getMetrics, Optimizer.cpp:216-220), rebuilt from a learner's read-back state."""
+    AdamOptimizer::getMetrics, Optimizer.cpp:216-220), rebuilt from a learner's read-back state (without the dRet column
+    of the lines that follow a 1000-step sweep: metrics() of the library and of the oracle print -- and consume -- that)."""
     st, sc = L.stats(), L.scalars()
     rew = L.get_scaling()[2]
     out = real2ss(st.avgReturn, 9, 0) + real2ss(float(rew[0]), 6, 0) + real2ss(float(rew[2]), 6, 1)

@@ -36,3 +36,25 @@ def test_compiled_binding_trains_inside_the_reference_process(tmp_path):
     assert abs(r["beta_ref"] - r["beta_hip"]) < 1e-3 * r["beta_ref"]
     assert abs(r["wnorm_ref"] - r["wnorm_hip"]) < 2e-3 * r["wnorm_ref"]
     assert "hip stats line:" in out.stdout and os.path.exists(tmp_path / "hip_00_stats.txt") is False   # (no print step reached in 200)
+
+
+@pytest.mark.gpu
+def test_compiled_binding_resumes_like_the_reference(tmp_path):
+    """Core/Worker.cpp:291-295 on a restarted process: restart(), then setupTasks(), whose first task is initializeLearner() again
+    -- skipped for a restarted learner (Learner.cpp:51-54): the ReF-ER state read from the checkpoint must survive it.  The
+    binding resumes from its own files and from the files the reference's learner wrote, next to the reference resuming from
+    those."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/binding_check not built (needs /root/reference: make -C oracle binding)")
+    out = subprocess.run([EXE, "150", "restart", "100"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{\"restart\"")][-1])
+    # the reference writes nGradSteps + 1 into its status file (MemoryBuffer.cpp:183): both resume one step "later" than they saved
+    assert r["grad0_ref"] == r["grad0_hip"] == r["grad0_x"] == 151
+    assert r["beta_restarted"] == pytest.approx(r["beta_saved"], rel=1e-12)
+    assert r["beta_after_init_task"] == r["beta_restarted"]                 # the init task left the restored state alone
+    assert r["beta_x_restarted"] == pytest.approx(r["beta_ref_saved"], rel=1e-6) and r["beta_x_after_init_task"] == r["beta_x_restarted"]
+    assert r["stored_restarted"] == r["stored_saved"] and r["stored_x"] == r["stored_ref"]
+    assert r["steps_ref"] == r["steps_hip"] == r["steps_x"] == 251
+    assert abs(r["beta_ref"] - r["beta_x"]) < 2e-3 * r["beta_ref"] and abs(r["beta_ref"] - r["beta_hip"]) < 2e-3 * r["beta_ref"]
+    assert abs(r["wnorm_ref"] - r["wnorm_x"]) < 2e-3 * r["wnorm_ref"] and abs(r["wnorm_ref"] - r["wnorm_hip"]) < 2e-3 * r["wnorm_ref"]

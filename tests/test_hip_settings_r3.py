@@ -1,0 +1,193 @@
+"""GPU suite, round 3: the rest of the settings surface on the device -- returnsEstimator (GAE, retraceExplore, none), nnOutputFunc,
+encoderLayerSizes, nnType "RNN", the dRet column of the statistics line.  The HIP library against the fixtures the compiled
+reference recorded (fed the reference's own sampled (episode, t) pairs) and against the oracle over long runs."""
+import numpy as np
+import pytest
+
+from oracle_api import oracle_learner, synth_episode, fill_synth, synth_cfg
+from parity import (load_fixture, fixture_config, fixture_synth, setup_from_fixture, relinf, episode_arrays_by_tag,
+                    fixture_arrays_by_tag, flat_for, lines_agree)
+from smarties_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+FUNC_OF = {"outfunc_lrelu_gauss.bin": "Tanh", "encoder_dense.bin": "Tanh", "vracer_rnn.bin": "Tanh"}
+SHORT = ["ret_none.bin", "outfunc_tanh.bin", "outfunc_lrelu_gauss.bin", "outfunc_sigm_discrete.bin", "encoder_dense.bin",
+         "vracer_rnn.bin", "discrete_rnn.bin"]
+LONG = ["ret_gae.bin", "ret_explore.bin", "stats_2100.bin"]
+
+
+def hip_learner(hip_api, cfg):
+    return capi.Learner(hip_api, cfg)
+
+
+@pytest.mark.parametrize("name", SHORT + LONG)
+def test_init_weights_and_initialize_match_reference(hip_api, name):
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    assert L.nParams == int(fx["cfg"][5]) and L.nOut == int(fx["cfg"][6])
+    lay = L.layout()
+    assert np.array_equal(lay["indW"], fx["indWeights"]) and np.array_equal(lay["indB"], fx["indBiases"])
+    setup_from_fixture(L, fx)
+    w, m1, m2 = L.get_params()
+    assert np.array_equal(w, fx["W0"]) and not m1.any() and not m2.any()
+    assert np.array_equal(L.get_rng_state(), fx["rng0"])
+    s = L.scalars()
+    assert s.beta == fx["beta0"][0] and s.CmaxRet == fx["cmax0"][0]
+    nopt = getattr(L, "nOptions", 0)
+    lens = {e: synth_episode(fixture_synth(fx), e, nopt)["rewards"].size for e in range(int(fx["cfg"][3]))}
+    mine = episode_arrays_by_tag(L, capi.EP_RETURN)
+    for tag, arr in fixture_arrays_by_tag(fx, "ret0_tags", "ret0", lens).items():
+        assert np.allclose(mine[tag], arr, rtol=2e-6, atol=2e-6), tag
+
+
+@pytest.mark.parametrize("name", SHORT + LONG)
+def test_steps_follow_reference_fixture(hip_api, name):
+    """The (episode, t) pairs the reference sampled at each tapped step, fed to the library: outputs (through nnOutputFunc),
+    importance weights, output gradients (before the output layer's f'), summed weight gradient and Adam update."""
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    setup_from_fixture(L, fx)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        if sk + "flat" not in fx:
+            break
+        flat = flat_for(L, fx[sk + "tag"], fx[sk + "t"])
+        order = np.argsort(flat, kind="stable")
+        L.step(1, flat=flat[order])
+        assert np.array_equal(L.readback(capi.TAP_TSTEP), fx[sk + "t"][order])
+        assert relinf(L.readback(capi.TAP_OUTPUT), fx[sk + "O"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_RHO), fx[sk + "rho"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_DKL), fx[sk + "dkl"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_DELTAQ), fx[sk + "dq"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_OUTGRAD), fx[sk + "G"][order]) < TOL32
+        assert np.array_equal(L.readback(capi.TAP_FAR), fx[sk + "far"][order])
+        if sk + "gradSum" in fx:
+            assert relinf(L.readback(capi.TAP_GRADSUM), fx[sk + "gradSum"]) < TOL32
+        if sk + "W" in fx:
+            w, m1, m2 = L.get_params()
+            assert relinf(w, fx[sk + "W"]) < TOL32
+            assert relinf(m1, fx[sk + "M1"]) < TOL32 and relinf(m2, fx[sk + "M2"]) < 2 * TOL32
+        sca = L.scalars()
+        assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-12 * abs(sca.beta)
+
+
+def _pair(hip_api, cfg_kw, sc, n_eps):
+    G = hip_learner(hip_api, capi.make_config(**cfg_kw))
+    O = oracle_learner(capi.make_config(**cfg_kw))
+    for L in (G, O):
+        L.init_weights(); fill_synth(L, sc, n_eps); L.initialize(); L.set_tap(True)
+    return G, O
+
+
+@pytest.mark.parametrize("est", ["GAE", "retraceExplore", "none", "retrace"])
+def test_return_estimators_follow_the_oracle_across_sweeps(hip_api, est):
+    """2100 steps with episodes arriving and leaving: the estimates of new episodes (computed on insert with the statistics of
+    the moment), the 1000-step sweeps, beta, and the statistics lines with their dRet column -- printed when a sweep ran since
+    the last line, consumed by printing -- equal the oracle's (which the reference's own fixtures pin)."""
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=1200, minTotObsNum=500, randSeed=42,
+                  returnsEstimator=est, lambda_=0.9, epsAnneal=5e-7)
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5)
+    G, O = _pair(hip_api, cfg_kw, sc, 60)
+    nxt = 60
+    for chunk in range(21):
+        for L in (G, O):
+            L.step(100)
+        if chunk % 2 == 0:
+            for L in (G, O):
+                fill_synth(L, sc, 3, first=nxt)
+            nxt += 3
+        sg, so = G.scalars(), O.scalars()
+        assert sg.nGradSteps == so.nGradSteps and sg.nStoredSteps == so.nStoredSteps
+        assert abs(sg.beta - so.beta) < 1e-3 * so.beta + 1e-9
+        if chunk in (0, 9, 10, 19, 20):
+            mg, mo = episode_arrays_by_tag(G, capi.EP_RETURN), episode_arrays_by_tag(O, capi.EP_RETURN)
+            assert set(mg) == set(mo)
+            for tag in mo:
+                assert np.allclose(mg[tag], mo[tag], rtol=2e-4, atol=2e-4), (chunk, tag)
+            if est == "none":
+                assert not any(a.any() for a in mg.values())
+        if sg.nGradSteps % 1000 == 0:
+            stg, sto = G.stats(), O.stats()
+            if est == "none":
+                assert stg.countReturnsEstimateUpdates == sto.countReturnsEstimateUpdates == -1
+            else:
+                assert stg.countReturnsEstimateUpdates == sto.countReturnsEstimateUpdates > 0
+                assert abs(stg.sumReturnsEstimateErrors - sto.sumReturnsEstimateErrors) <= 2e-3 * sto.sumReturnsEstimateErrors
+            (hg, lg), (ho, lo) = G.metrics(), O.metrics()
+            assert hg == ho and ("dRet" in hg) == (est != "none")
+            assert len(lg) == len(lo) and lines_agree(lg, lo, hg, rel=2e-3), (lg, lo)
+            assert G.stats().countReturnsEstimateUpdates == (-1 if est == "none" else 0)
+    (hg, lg), (ho, lo) = G.metrics(), O.metrics()
+    assert hg == ho and "dRet" not in hg and lines_agree(lg, lo, hg, rel=2e-3)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 5e-4
+
+
+@pytest.mark.parametrize("extra", [dict(nnOutputFunc="Tanh"), dict(nnOutputFunc="LRelu", adv_kind=capi.ADV_GAUSSIAN, hidden=(24, 16, 8), nnFunc="Tanh"),
+                                   dict(nnOutputFunc="HardSign", dimA=1, bounded=[1], adv_kind=capi.ADV_DISCRETE, n_options=5),
+                                   dict(encoder=(24, 0), hidden=(16, 16)), dict(encoder=(32,), hidden=(32,)),
+                                   dict(nn_type=capi.NN_RNN, nnFunc="Tanh", nnBPTTseq=6), dict(nn_type=capi.NN_RNN, hidden=(40, 24, 12), nnBPTTseq=4),
+                                   dict(nn_type=capi.NN_RNN, hidden=(20,), nnFunc="SoftSign", dimA=1, bounded=[0], adv_kind=capi.ADV_DISCRETE, n_options=3, nnBPTTseq=9)],
+                         ids=["out-tanh", "out-lrelu-gauss", "out-hardsign-discrete", "encoder-24-0+16x16", "encoder-32+32", "rnn-2x32", "rnn-40x24x12", "rnn-20-discrete"])
+def test_random_configurations_match_oracle(hip_api, extra):
+    """Device sampler + update against the oracle (stable episode order) for the new settings: sample indices and masks bit-exact,
+    per-sample quantities and gradients to 1e-5, over eager steps, replayed graphs and arrivals; rollout inference likewise."""
+    cfg_kw = dict(dimS=6, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=3000, randSeed=11)
+    cfg_kw.update(extra)
+    dA = cfg_kw["dimA"]
+    sc = synth_cfg(seed=21, dimS=6, dimA=dA, lenMin=4, lenMax=40, pTerm=0.4)
+    G, O = _pair(hip_api, cfg_kw, sc, 50)
+    rec = cfg_kw.get("nn_type", 0) != 0
+
+    def compare():
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert relinf(G.readback(capi.TAP_OUTPUT), O.readback(capi.TAP_OUTPUT)) < TOL32
+        assert relinf(G.readback(capi.TAP_RHO), O.readback(capi.TAP_RHO)) < TOL32
+        assert relinf(G.readback(capi.TAP_OUTGRAD), O.readback(capi.TAP_OUTGRAD)) < TOL32
+        assert np.array_equal(G.readback(capi.TAP_FAR), O.readback(capi.TAP_FAR))
+        assert relinf(G.readback(capi.TAP_GRADSUM), O.readback(capi.TAP_GRADSUM)) < TOL32
+    nxt = 50
+    for i, n in enumerate([1, 1, 2, 7, 1, 20, 3]):
+        G.step(n); O.step(n)
+        compare()
+        assert relinf(G.get_params()[0], O.get_params()[0]) < 2e-5
+        if i == 3:
+            for L in (G, O):
+                fill_synth(L, sc, 2, first=nxt)
+            nxt += 2
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    rng = np.random.default_rng(3)
+    if rec:
+        for n in (1, 3, cfg_kw["nnBPTTseq"] + 1):
+            S = rng.normal(size=(n, 6)).astype(np.float32)
+            assert relinf(G.forward_sequence(S), O.forward_sequence(S)) < TOL32
+    else:
+        for n in (1, 5, 70):
+            S = rng.normal(size=(n, 6)).astype(np.float32)
+            assert relinf(G.forward(S), O.forward(S)) < TOL32
+
+
+def test_output_functions_without_a_finite_start_are_refused(hip_api):
+    """Tanh / SoftSign outputs cannot start from the Gaussian advantage's initial -1 / +1 (their pre-images are infinite:
+    the reference starts from inf there); the library says so instead of training on nan."""
+    L = hip_learner(hip_api, capi.make_config(dimS=5, dimA=2, hidden=(16, 16), batchSize=8, maxTotObsNum=500,
+                                              adv_kind=capi.ADV_GAUSSIAN, nnOutputFunc="Tanh"))
+    with pytest.raises(capi.HlError):
+        L.init_weights()
+
+
+@pytest.mark.parametrize("name", ["encoder_dense.bin", "vracer_rnn.bin"])
+def test_checkpoint_files_match_reference(hip_api, name, tmp_path):
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc=FUNC_OF.get(name)))
+    base = str(tmp_path / "ck_net")
+    for suf in ("_weights", "_1stMom", "_2ndMom"):
+        np.frombuffer(bytes(bytearray(fx["ckpt_net" + suf])), np.float32).tofile(base + suf + ".raw")
+    L.init_weights(); L.restart(base)
+    for a, b in zip(L.get_params(), (fx["Wfinal"], fx["M1final"], fx["M2final"])):
+        assert np.array_equal(a, b)
+    out = str(tmp_path / "again_net")
+    L.save(out)
+    for suf in ("_weights", "_1stMom", "_2ndMom"):
+        assert open(out + suf + ".raw", "rb").read() == bytes(bytearray(fx["ckpt_net" + suf]))
