@@ -278,6 +278,8 @@ class RACER_HIP : public Learner
       ck(hl_get_counts(H, &nObs, &nEps, &nGrad, &seenS, &seenE));
       data->counters.nTransitions = nObs; data->counters.nGradSteps = nGrad;
       data->counters.nSeenTransitions_loc = seenS; data->counters.nSeenEpisodes_loc = seenE;
+      int64_t nInit = 0; ck(hl_get_initial_data(H, &nInit));
+      data->counters.nGatheredB4Startup = (long) nInit;      // MemoryBuffer::restart (:249-250): blockGradientUpdates counts from here
       algoSubStepID = 0;                     // a restarted learner skips initializeLearner (Learner.cpp:51-54)
     }
   }

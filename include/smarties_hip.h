@@ -348,6 +348,10 @@ HL_API int hl_get_scalars(hl_learner* h, hl_scalars* out);
  * steps (Learners/Learner.h:84-101).  Any pointer may be NULL. */
 HL_API int hl_get_counts(hl_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int64_t* nGradSteps, int64_t* nSeenSteps, int64_t* nSeenEps);
 HL_API int hl_get_stats(hl_learner* h, hl_stats* out);
+/* ReplayCounters::nGatheredB4Startup ("nInitialData" of the status file, MemoryBuffer.cpp:249-250, 302-311): the locally seen
+ * observations from which Learner::nLocTimeStepsTrain counts -- set by hl_initialize, restored by hl_restart_memory; INT64_MAX
+ * before either.  A binding that keeps the reference's gating (blockGradientUpdates, Learner.cpp:116-123) copies it after a restart. */
+HL_API int hl_get_initial_data(hl_learner* h, int64_t* nInitialData);
 
 /* ---- statistics surface (third row) ---------------------------------------
  * The column header and the line Learner::logStats appends to <learner>_stats.txt

@@ -1762,6 +1762,7 @@ int ol_get_counts(ol_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int
   if (nGradSteps) *nGradSteps = h->nGradSteps; if (nSeenSteps) *nSeenSteps = h->nSeenSteps; if (nSeenEps) *nSeenEps = h->nSeenEps;
   return HL_OK;
 }
+int ol_get_initial_data(ol_learner* h, int64_t* n) { if (!h || !n) return HL_ERR_BAD_ARG; *n = h->nGatheredB4Startup; return HL_OK; }
 int ol_get_stats(ol_learner* h, hl_stats* o) { if (!h || !o) return HL_ERR_BAD_ARG; *o = h->stats; return HL_OK; }
 
 int ol_synth_episode_len(const synth_cfg* c, uint64_t e, int* term) { return synth_episode_len(c, e, term); }

@@ -61,6 +61,7 @@ HL_API int ol_set_tap(ol_learner* h, int32_t enable);
 HL_API int ol_readback(ol_learner* h, int32_t what, void* dst, int64_t dst_bytes);
 HL_API int ol_get_scalars(ol_learner* h, hl_scalars* out);
 HL_API int ol_get_stats(ol_learner* h, hl_stats* out);
+HL_API int ol_get_initial_data(ol_learner* h, int64_t* nInitialData);
 HL_API int ol_metrics(ol_learner* h, char* header, int32_t header_cap, char* line, int32_t line_cap);
 HL_API int ol_impweight_histogram(ol_learner* h, char* text, int32_t text_cap, int64_t counts[HL_IMPW_BINS]);
 HL_API int ol_get_counts(ol_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int64_t* nGradSteps, int64_t* nSeenSteps, int64_t* nSeenEps);

@@ -24,7 +24,9 @@ struct DevScalars {
   long long cnt[4];               // {seenEps, seenSteps, nFar, nStored}: local, then all-reduced (C2)
   long long seenLocal[2];         // this replica's seenEps / seenSteps (cnt[0..1] are reset from it each step)
   float rewMean, rewScale, rewStd;
-  float maxAbsErrAll;             // max over episodes of Episode::maxAbsError
+  float maxAbsErrAll;             // max over episodes of Episode::maxAbsError (running; recomputed after arrivals / removals and by the sweeps)
+  float maxAbsErrStep;            // ... as the statistics pass of the current step saw it, i.e. before that step's removals: what the
+                                  // ReplayStats::maxAbsError average of the step takes in (MemoryProcessing.cpp:223,241)
   // the minibatch workspace is double buffered (sampling of step k+1 overlaps the update of step k)
   int nNext[2];                   // rows B..B+nNext-1 of the minibatch hold truncated next states
   int nRows[2];                   // B + nNext

@@ -237,6 +237,7 @@ hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);          // part
 hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s);    // EMA update of the scaling
 hipError_t launch_set_counts(DevScalars* sc, long long nTransitions, long long nEpisodes,
                              long long seenEps, long long seenSteps, hipStream_t s);
+hipError_t launch_episode_max(DevScalars* sc, DevReplay rp, int nEp, hipStream_t s);   // sc->maxAbsErrAll = max over the stored episodes
 hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s);
 hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out /*16 doubles*/, hipStream_t s);
 // prioritised samplers (per.hip): probabilities, ranking and the sequential normalisation / cumulative table

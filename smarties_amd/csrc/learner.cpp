@@ -496,7 +496,11 @@ int flushPending(hl_learner* h) {
     int rc = dropPresample(h); if (rc) return rc;
   }
   { int rc = flushStaging(h); if (rc) return rc; }
+  const bool tableChanged = h->tableDirty;
   if (h->tableDirty) { int rc = uploadTable(h); if (rc) return rc; }
+  // the largest |TD error| over the stored episodes (MemoryProcessing.cpp:223, feeding ReplayStats::maxAbsError) is kept as a
+  // running maximum by the bookkeeping pass: episodes that left take theirs along, new ones bring their placeholder error
+  if (tableChanged && h->initialized && !h->order.empty()) HIPCK(launch_episode_max(h->sc, h->rp, (int)h->order.size(), h->stream));
   if (h->countsDirty) {
     HIPCK(launch_set_counts(h->sc, h->nTransitions, (long long)h->order.size(), h->nSeenEps, h->nSeenSteps, h->stream));
     h->countsDirty = false;
@@ -1719,6 +1723,12 @@ int hl_get_counts(hl_learner* h, int64_t* nStoredSteps, int64_t* nStoredEps, int
   if (nGradSteps) *nGradSteps = h->nGradSteps;
   if (nSeenSteps) *nSeenSteps = h->nSeenSteps;
   if (nSeenEps) *nSeenEps = h->nSeenEps;
+  return HL_OK;
+}
+int hl_get_initial_data(hl_learner* h, int64_t* n) {
+  if (!h || !n) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  *n = (int64_t)h->nGatheredB4Startup;
   return HL_OK;
 }
 int hl_get_stats(hl_learner* h, hl_stats* o) {

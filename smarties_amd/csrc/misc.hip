@@ -167,7 +167,7 @@ __global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, co
   if (threadIdx.x != 0) return;
   if (countRet >= 0) { sc->cntRetUpd = (sc->cntRetUpd < 0 ? 0 : sc->cntRetUpd) + countRet; sc->sumRetErr += er; }
   sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
-  sc->maxAbsErrAll = m;
+  sc->maxAbsErrAll = m; sc->maxAbsErrStep = m;
   sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
   sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1];
 }
@@ -275,6 +275,20 @@ __global__ void evict_kernel(DevScalars* sc, DevReplay rp, int eid) {
 }
 hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s) {
   hipLaunchKernelGGL(evict_kernel, dim3(1), dim3(1), 0, s, sc, rp, eid);
+  return hipGetLastError();
+}
+// max over the stored episodes of Episode::maxAbsError (one workgroup; after arrivals / removals)
+__global__ __launch_bounds__(256) void episode_max_kernel(DevScalars* sc, DevReplay rp, int nEp) {
+  __shared__ float sm[4];
+  float m = 0.f;
+  for (int p = threadIdx.x; p < nEp; p += 256) m = fmaxf(m, rp.epAgg[(size_t)rp.posEid[p] * AGG_N + AGG_MAXABSERR]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) sc->maxAbsErrAll = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+hipError_t launch_episode_max(DevScalars* sc, DevReplay rp, int nEp, hipStream_t s) {
+  hipLaunchKernelGGL(episode_max_kernel, dim3(1), dim3(256), 0, s, sc, rp, nEp);
   return hipGetLastError();
 }
 hipError_t launch_set_counts(DevScalars* sc, long long nT, long long nE, long long seenEps, long long seenSteps, hipStream_t s) {

@@ -61,7 +61,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
   const double ema0 = sc->maxAbsErrEMA, bt1 = sc->adam_bt1, bt2 = sc->adam_bt2;
   const long long nGrad0 = sc->nGradSteps, nFarTot0 = sc->nFarTotal, nFarStat0 = sc->nFarStat;
   const long long nTrans = sc->nTransitions, cnt2 = sc->cnt[2], cnt3 = sc->cnt[3], nStep0 = sc->nStep;
-  const float maxAll0 = sc->maxAbsErrAll;
+  const float maxAll0 = (a.mode & POST_AGG) ? sc->maxAbsErrAll : sc->maxAbsErrStep;
   TSTAMP(sc, 16);
   if (tid == 0) { *sFarDelta = 0; *sMaxAbs = 0u; }
   __syncthreads();
@@ -158,7 +158,7 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       // below zero right after the start when clipImpWeight < 1 (MemoryBuffer.h:44 starts CinvRet at 1/C0 > 1, so
       // never-sampled steps count as "were far") -- it stays exact, the statistic is clamped
       nFarStat = nFarTot > 0 ? nFarTot : 0;
-      sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
+      sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->maxAbsErrStep = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
       sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
       if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce
       if (a.cntMsg) {       // counters ride in the tail of the gradient buffer: one all-reduce per step instead of two

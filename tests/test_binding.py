@@ -46,12 +46,12 @@ def test_compiled_binding_resumes_like_the_reference(tmp_path):
     those."""
     if not os.path.exists(EXE):
         pytest.skip("oracle/_ref/binding_check not built (needs /root/reference: make -C oracle binding)")
-    out = subprocess.run([EXE, "150", "restart", "100"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    out = subprocess.run([EXE, "150", "restart", "100"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{\"restart\"")][-1])
     # the reference writes nGradSteps + 1 into its status file (MemoryBuffer.cpp:183): both resume one step "later" than they saved
     assert r["grad0_ref"] == r["grad0_hip"] == r["grad0_x"] == 151
-    assert r["beta_restarted"] == pytest.approx(r["beta_saved"], rel=1e-12)
+    assert r["beta_restarted"] == pytest.approx(r["beta_saved"], rel=1e-6)       # (the status file holds six digits, MemoryBuffer.cpp:313)
     assert r["beta_after_init_task"] == r["beta_restarted"]                 # the init task left the restored state alone
     assert r["beta_x_restarted"] == pytest.approx(r["beta_ref_saved"], rel=1e-6) and r["beta_x_after_init_task"] == r["beta_x_restarted"]
     assert r["stored_restarted"] == r["stored_saved"] and r["stored_x"] == r["stored_ref"]
