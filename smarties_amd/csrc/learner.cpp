@@ -140,7 +140,10 @@ struct hl_learner {
     unsigned char** dPeers = nullptr; XchgCtl* ctl = nullptr;
     std::vector<void*> opened;               // windows opened through hipIpc (closed by hl_destroy)
   } xchg;
-  long long xchgTimeoutTicks = 500000000LL;   // 5 s at 100 MHz (SMARTIES_HIP_XCHG_TIMEOUT_MS)
+  // wait of the exchange kernel for a peer's message (SMARTIES_HIP_XCHG_TIMEOUT_MS): replicas are gated independently by their data
+  // (blockGradientUpdates), so a peer may legitimately lag by seconds -- the reference's MPI_Iallreduce simply waits; ten minutes,
+  // then the learner's sticky device error (the state stays as it was before that collective)
+  long long xchgTimeoutTicks = 60000000000LL;   // 600 s at 100 MHz
   // moments exchange state
   bool momentsPending = false;
   // timing
@@ -929,7 +932,7 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
   if (!h->episodeLog.empty()) {      // MemoryBuffer.cpp:492-503: "%ld %ld %d %u %f" = nGradSteps, time stamp, agent, steps, total reward (Fval)
     float totRf = 0; for (int t = 1; t < N; ++t) totRf = (float)((double)totRf + rewards[t]);      // Fval totR += Real reward (:95-96)
     if (FILE* f = std::fopen(h->episodeLog.c_str(), "a")) { std::fprintf(f, "%ld %ld %d %u %f\n", (long)h->nGradSteps, (long)e.ID, 0, (unsigned)N, totRf); std::fclose(f); }
-    else return fail(h, HL_ERR_IO, "unable to open " + h->episodeLog);
+    else { h->err = "unable to open " + h->episodeLog + " (episode log switched off)"; h->episodeLog.clear(); }   // the episode is staged: it enters the training set regardless
   }
   h->nSeenSteps += 1; h->nSeenEps += 1;
   h->order.push_front(e);
@@ -967,8 +970,9 @@ int hl_set_scaling(hl_learner* h, const float* m, const float* sc, const float* 
   return HL_OK;
 }
 int hl_get_episode_info(hl_learner* h, int64_t pos, int64_t* tag, int32_t* nsteps, int32_t* term) {
-  if (!h || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  if (!h) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
+  if (pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
   const EpMeta& e = h->order[(size_t)pos];
   if (tag) *tag = e.tag;
   if (nsteps) *nsteps = e.N;
@@ -976,8 +980,9 @@ int hl_get_episode_info(hl_learner* h, int64_t pos, int64_t* tag, int32_t* nstep
   return HL_OK;
 }
 int hl_get_episode_field(hl_learner* h, int64_t pos, int32_t field, float* dst, int32_t cap) {
-  if (!h || !dst || pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  if (!h || !dst) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
+  if (pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
   const EpMeta& e = h->order[(size_t)pos];
   if (cap < e.N) return HL_ERR_BAD_ARG;
   int rc = flushPending(h); if (rc) return rc;
@@ -1611,7 +1616,14 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
 int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, double* outputs) {
   if (!h || nSteps < 1 || !states || !outputs) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
-  if (!h->recurrent) return hl_forward(h, 1, states + (size_t)(nSteps - 1) * h->dS, outputs);
+  if (!h->recurrent) {
+    if (h->nApp == 0) return hl_forward(h, 1, states + (size_t)(nSteps - 1) * h->dS, outputs);
+    // appended observations: the row hl_forward reads is the state of the last step followed by those of the steps before it
+    // (Episode::standardizedState, Episode.h:172-183; steps before the first given one repeat it)
+    std::vector<float> row((size_t)h->dIn);
+    for (int j = 0; j <= h->nApp; ++j) { const int tt = std::max(nSteps - 1 - j, 0); std::memcpy(row.data() + (size_t)j * h->dS, states + (size_t)tt * h->dS, (size_t)h->dS * sizeof(float)); }
+    return hl_forward(h, 1, row.data(), outputs);
+  }
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
   if (nSteps > h->recK) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1");
   // states and outputs through pinned host memory, completion by stamp (as hl_forward): two launches, no staged copies

@@ -28,10 +28,10 @@ __device__ __forceinline__ void stSys(unsigned long long* p, unsigned long long 
 template <typename T, bool FUSE>
 __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
   __shared__ unsigned long long sSeq;
-  __shared__ int sLast;
+  __shared__ int sLast, sFail;
   __shared__ long long sFarDelta; __shared__ unsigned sMaxAbs;
   const int tid = threadIdx.x, chunk = blockIdx.x, nCh = gridDim.x, R = a.nRanks, me = a.rank;
-  if (tid == 0) sSeq = __hip_atomic_load(&a.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) { sSeq = __hip_atomic_load(&a.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sFail = 0; }
   __syncthreads();
   const unsigned long long seq = sSeq, tag = seq + 1;
   const int par = (int)(seq & 1);
@@ -61,14 +61,18 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
     const long long t0 = wall_clock64();
     while (ldSys(f) < tag) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > a.timeoutTicks) { a.sc->errFlag = 79; break; }
+      if (wall_clock64() - t0 > a.timeoutTicks) { a.sc->errFlag = 79; sFail = 1; break; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
   }
   __syncthreads();
+  // A peer's message never came (or an earlier collective already failed: the error is sticky): no sum, no Adam, no bookkeeping --
+  // the slots hold an older collective's data.  Weights, moments and counters stay as they were; the host sees the error at its
+  // next read-back (HL_ERR_HIP, device-side failure 79).  The sequence still advances, so nothing waits on this collective later.
+  const bool failed = sFail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   // ---- sum in rank order ----
   const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
-  for (long long v = v0 + tid; v < v1; v += 256) {
+  if (!failed) for (long long v = v0 + tid; v < v1; v += 256) {
     V acc;
     for (int r = 0; r < R; ++r) {
       const V x = r == me ? msg[v] : reinterpret_cast<const V*>(mine + (size_t)r * a.slotBytes)[v];
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
       }
     }
   }
-  if (chunk == 0 && tid < (int)(a.n - tail0)) {
+  if (!failed && chunk == 0 && tid < (int)(a.n - tail0)) {
     T acc = 0;
     for (int r = 0; r < R; ++r) {
       const T x = r == me ? reinterpret_cast<const T*>(a.msg)[tail0 + tid] : reinterpret_cast<const T*>(mine + (size_t)r * a.slotBytes)[tail0 + tid];
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
   }
   if constexpr (FUSE) {
     __syncthreads();
-    if (sLast) { __threadfence(); postPart(a.post, &sFarDelta, &sMaxAbs); }      // (all chunks are summed and visible)
+    if (sLast && __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { __threadfence(); postPart(a.post, &sFarDelta, &sMaxAbs); }      // (all chunks are summed and visible)
   }
 }
 

@@ -647,6 +647,42 @@ def test_exchange_times_out_instead_of_hanging(hip_api):
 
 
 @pytest.mark.gpu
+def test_a_missing_peer_leaves_the_learner_state_intact():
+    """Two connected replicas step together, then only one issues a step: its exchange kernel gives up after the (shortened) wait,
+    raises the sticky device error -- and applies NOTHING of that step: no sum over stale slots, no Adam, no bookkeeping.  Weights,
+    moments and beta are those of the last completed step."""
+    import subprocess, sys, os
+    code = (
+        "import os, sys, threading; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from smarties_amd import capi, load_hip; from oracle_api import synth_cfg, synth_episode\n"
+        "api = load_hip(); sc = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)\n"
+        "Ls = []\n"
+        "for r in range(2):\n"
+        "    L = capi.Learner(api, capi.make_config(n_ranks=2, rank=r, dimS=5, dimA=2, hidden=(32, 32), batchSize=16, maxTotObsNum=4096))\n"
+        "    L.init_weights()\n"
+        "    for e in range(r, 40, 2): L.append_episode(**synth_episode(sc, e))\n"
+        "    Ls.append(L)\n"
+        "hs = [L.xchg_export() for L in Ls]\n"
+        "def both(fn):\n"
+        "    ts = [threading.Thread(target=fn, args=(L,)) for L in Ls]\n"
+        "    [t.start() for t in ts]; [t.join() for t in ts]\n"
+        "both(lambda L: (L.xchg_connect(hs), L.initialize()))\n"
+        "both(lambda L: (L.step(5), L.sync()))\n"
+        "before = [a.copy() for a in Ls[0].get_params()]; beta = Ls[0].scalars().beta\n"
+        "Ls[0].step(1)\n"                                     # replica 1 never comes
+        "try:\n    Ls[0].scalars(); print('NO_ERROR')\n"
+        "except capi.HlError as e:\n    print('TIMED_OUT', e)\n"
+        "after = Ls[0].get_params()\n"
+        "print('INTACT' if all(np.array_equal(a, b) for a, b in zip(before, after)) else 'CHANGED')\n"
+        "os._exit(0)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMARTIES_HIP_XCHG_TIMEOUT_MS="300", GPU_MAX_HW_QUEUES="8"),
+                         capture_output=True, text=True, timeout=300)
+    assert "TIMED_OUT" in out.stdout and "INTACT" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_two_replica_protocol_matches_oracle_replicas(hip_api):
     """n_ranks = 2 (batch and replay budget split): two HIP replicas on this GPU,
     exchanges summed on the host, against two oracle replicas driven the same way -- over a
