@@ -675,7 +675,7 @@ def test_a_missing_peer_leaves_the_learner_state_intact():
         "except capi.HlError as e:\n    print('TIMED_OUT', e)\n"
         "after = Ls[0].get_params()\n"
         "print('INTACT' if all(np.array_equal(a, b) for a, b in zip(before, after)) else 'CHANGED')\n"
-        "os._exit(0)\n"
+        "sys.stdout.flush(); os._exit(0)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMARTIES_HIP_XCHG_TIMEOUT_MS="300", GPU_MAX_HW_QUEUES="8"),
                          capture_output=True, text=True, timeout=300)
@@ -999,7 +999,11 @@ def test_stats_line_after_the_thousand_step_sweep_matches_oracle(hip_api):
     G, O = hip_learner(hip_api, fixture_config(fx)), oracle_learner(fixture_config(fx))
     for L in (G, O):
         setup_from_fixture(L, fx)
-        L.step(1200)
+        L.step(1000)
+    (hg, lg), (ho, lo) = G.metrics(), O.metrics()      # the line of step 1000 (Learner::logStats): with the dRet column of the sweep
+    assert hg == ho and "dRet" in hg and lines_agree(lg, lo, hg, rel=1e-3), (lg, lo)
+    for L in (G, O):
+        L.step(200)
     head, line = G.metrics()
     assert head == bytes(bytearray(fx["metrics_head"])).decode()
     assert lines_agree(line, stats_line(O), head, rel=1e-3), (line, stats_line(O))
