@@ -383,15 +383,9 @@ def main():
             L.prepare_steps(args.warmup)
         L.prepare_steps(args.steps)
 
-    # N = 1: the roofline passes run FIRST, on a second learner over the same replay, so that the timed region below starts on a
-    # device at working clocks (the driver's `--steps 20 --warmup 5` would otherwise time the first 0.5 ms after seconds of
-    # host-only set-up).  The W warm-up steps and the K timed steps of `L` follow back to back.
+    # (Round 2 ran the roofline passes of a second learner in front of the timed region "to bring the device to working clocks";
+    # measured this round -- tools/first_call5.py -- that costs the timed call 15-20 us: they now follow the timed region.)
     roof, P = None, None
-    if rank == 0 and n_ranks == 1:
-        P, _ = make_learner()
-        P.initialize()
-        P.step(64)
-        roof = roofline(P)                   # (P is closed after the timed region: freeing 300 MB idles the device for milliseconds)
 
     if dog is not None:
         try:
@@ -403,8 +397,6 @@ def main():
             start_over()
         dog.cancel()
 
-    if not (n_ranks > 1 and host_exchange):
-        L.prepare_steps(args.steps)          # (graphs exist: only the pass over the replay's pages, which the second learner's work displaced)
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -419,8 +411,14 @@ def main():
     B_global = CFG["batchSize"]
     value = B_global * args.steps / dt
 
-    if P is not None:
-        P.close()
+    # diagnostics, after the timed region and outside `value`: the same call once more (what a first call pays on top: page walks,
+    # first launch of the call's graph, clocks) and the sustained rate over 2000 steps
+    diag = {}
+    if n_ranks == 1:
+        t1 = time.perf_counter(); run(args.steps); barrier(); diag["same_call_again_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
+        run(400); barrier()
+        t1 = time.perf_counter(); run(2000); barrier(); diag["sustained_ms_per_step_2000_steps"] = (time.perf_counter() - t1) / 2000 * 1e3
+
     if rank == 0 and roof is None:
         roof = roofline(L)
 
@@ -439,6 +437,7 @@ def main():
                        "exchange": "host (gloo, split-step entry points)" if (n_ranks > 1 and host_exchange) else transport},
             "roofline": roof,
             "fill_seconds": t_fill,
+            "diagnostics": diag,
         }
         if not args.no_other_configs and n_ranks == 1:
             try:

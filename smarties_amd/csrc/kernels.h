@@ -210,7 +210,7 @@ struct IngestArgs {
 };
 constexpr int INGEST_MAX_EP = 1024;
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
-struct TouchArgs { const void* ptr[16]; long long bytes[16]; int n; float* sink; };
+struct TouchArgs { const void* ptr[24]; long long bytes[24]; int stride[24]; int n; float* sink; };
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)
 hipError_t launch_set_ret_counters(DevScalars* sc, long long cnt, hipStream_t s);   // the statistics line consumed the return-estimate counters (MemoryBuffer.cpp:534-544)
 hipError_t launch_notify(DevScalars* sc, unsigned* hostWord, hipStream_t s);   // ++sc->notifySeq -> pinned host word (completion stamp polled by hl_sync)

@@ -527,10 +527,14 @@ hipError_t launch_notify(DevScalars* sc, unsigned* hostWord, hipStream_t s) { hi
 // stepping phase starts (hl_prepare_steps).  A minibatch touches ~2000 random rows of a few hundred MB; a freshly filled
 // replay otherwise pays its page walks over the first few dozen steps (tools/first_call3.py).
 __global__ __launch_bounds__(256) void touch_kernel(TouchArgs a) {
+  // workgroups are dealt round-robin to the 8 XCDs: the 32 workgroups of one XCD together read every page, so that each XCD's
+  // own translation caches have seen the whole replay (a minibatch row is gathered by whichever XCD its workgroup landed on)
+  const int sub = blockIdx.x >> 3, nSub = gridDim.x >> 3;
   float acc = 0.f;
   for (int k = 0; k < a.n; ++k) {
     const char* base = (const char*)a.ptr[k];
-    for (long long off = ((long long)blockIdx.x * 256 + threadIdx.x) * 4096; off < a.bytes[k]; off += (long long)gridDim.x * 256 * 4096)
+    const long long st = a.stride[k];       // 4096: one word per page (translations); 64: every cache line (small tables: data resident)
+    for (long long off = ((long long)sub * 256 + threadIdx.x) * st; off < a.bytes[k]; off += (long long)nSub * 256 * st)
       acc += *(const volatile float*)(base + off);
   }
   if (acc == 1.2345e-30f) *a.sink = acc;

@@ -645,11 +645,16 @@ void invalidateGraphs(hl_learner* h) {
 // sweep, i.e. with buffer 0
 // the address translations of the whole replay and of the parameter arrays resident before a stepping phase (touch_kernel)
 int touchReplay(hl_learner* h) {
-  TouchArgs ta{}; const long long cap = h->capSlots;
-  auto add = [&](const void* p, long long bytes) { if (p && ta.n < 16) { ta.ptr[ta.n] = p; ta.bytes[ta.n] = bytes; ++ta.n; } };
-  add(h->rp.S, cap * h->dS * 4); add(h->rp.A, cap * h->dA * 8); add(h->rp.MU, cap * h->polDim * 8); add(h->rp.R, cap * 8);
-  add(h->rp.V, cap * 4); add(h->rp.ADV, cap * 4); add(h->rp.RET, cap * 4); add(h->rp.DQ, cap * 4); add(h->rp.IMPW, cap * 4); add(h->rp.DKL, cap * 4);
-  add(h->W, h->nParams * 4); add(h->M1, h->nParams * 4); add(h->M2, h->nParams * 4); add(h->G, h->nParams * 4);
+  TouchArgs ta{}; const long long cap = h->capSlots, nE = (long long)h->order.size();
+  auto add = [&](const void* p, long long bytes, int stride) { if (p && bytes > 0 && ta.n < 24) { ta.ptr[ta.n] = p; ta.bytes[ta.n] = bytes; ta.stride[ta.n] = stride; ++ta.n; } };
+  add(h->rp.S, cap * h->dS * 4, 4096); add(h->rp.A, cap * h->dA * 8, 4096); add(h->rp.MU, cap * h->polDim * 8, 4096); add(h->rp.R, cap * 8, 4096);
+  add(h->rp.V, cap * 4, 4096); add(h->rp.ADV, cap * 4, 4096); add(h->rp.RET, cap * 4, 4096); add(h->rp.DQ, cap * 4, 4096); add(h->rp.IMPW, cap * 4, 4096); add(h->rp.DKL, cap * 4, 4096);
+  // the per-episode tables the sampler searches and the bookkeeping pass gathers from: every line (a few hundred KB: a fresh
+  // learner otherwise warms them by its own random probes over its first dozens of steps -- tools/first_call4.py)
+  add(h->rp.posRec, (nE + 1) * (long long)sizeof(PosRec), 64); add(h->rp.posPrefix, (nE + 1) * 8, 64); add(h->rp.posEid, nE * 4, 64);
+  add(h->rp.epAgg, (long long)h->nextEid * AGG_N * 4, 64); add(h->rp.epOff, (long long)h->nextEid * 8, 64); add(h->rp.epN, (long long)h->nextEid * 4, 64);
+  add(h->rp.epTerm, (long long)h->nextEid, 64); add(h->rp.epTag, (long long)h->nextEid * 8, 64);
+  add(h->W, h->nParams * 4, 64); add(h->M1, h->nParams * 4, 64); add(h->M2, h->nParams * 4, 64); add(h->G, h->nParams * 4, 64);
   ta.sink = h->G + h->nParams + 200;
   HIPCK(launch_touch(ta, h->stream));
   return HL_OK;

@@ -71,6 +71,24 @@ int main() {
   };
   hipGraphExec_t g20, g16, g4, g20n, g18;
   if (capture(20, false, &g20) || capture(16, false, &g16) || capture(4, false, &g4) || capture(20, true, &g20n) || capture(18, false, &g18)) return 1;
+  {   // first launch of a freshly instantiated (and uploaded) graph exec against its later launches, with a warm device
+    for (int trial = 0; trial < 3; ++trial) {
+      hipGraphExec_t gf; if (capture(20, false, &gf)) return 1;
+      CK(hipGraphLaunch(g4, s)); CK(hipStreamSynchronize(s));
+      double ts[4];
+      for (int rep = 0; rep < 4; ++rep) { const double t0 = nowUs(); CK(hipGraphLaunch(gf, s)); CK(hipStreamSynchronize(s)); ts[rep] = nowUs() - t0; }
+      printf("fresh graph exec of 20 steps: launch 1..4 = %.1f %.1f %.1f %.1f us\n", ts[0], ts[1], ts[2], ts[3]);
+      CK(hipGraphExecDestroy(gf));
+    }
+    // ... and a graph that was launched before, then left alone while 200 other graph launches went by
+    hipGraphExec_t gf; if (capture(20, false, &gf)) return 1;
+    for (int rep = 0; rep < 3; ++rep) { CK(hipGraphLaunch(gf, s)); CK(hipStreamSynchronize(s)); }
+    for (int rep = 0; rep < 200; ++rep) CK(hipGraphLaunch(g4, s));
+    CK(hipStreamSynchronize(s));
+    double ts[3];
+    for (int rep = 0; rep < 3; ++rep) { const double t0 = nowUs(); CK(hipGraphLaunch(gf, s)); CK(hipStreamSynchronize(s)); ts[rep] = nowUs() - t0; }
+    printf("graph exec launched before, after 200 launches of another graph: %.1f %.1f %.1f us\n", ts[0], ts[1], ts[2]);
+  }
   unsigned expect = 0;
   const char* launchNames[] = {"one graph of 20", "graphs 16 + 4", "40 direct launches", "2 steps direct + graph of 18"};
   const char* syncNames[] = {"hipStreamSynchronize", "notify kernel + poll"};
