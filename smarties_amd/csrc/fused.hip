@@ -387,8 +387,13 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     // plain stores: the consumers are the workgroups of this panel, which share this XCD's L2 (the vector L1 is
     // write-through); other XCDs see y3 after the kernel boundary.  Agent-scope (write-through) stores made the
     // acknowledgement wait below ~1 us longer.
-    gR2[(size_t)row * ldA1 + n0 + en] = y3;                // also the A operand of dWout
-    gX2[(size_t)row * ldA1 + n0 + en] = f2;                // f'(x2)
+    if (a.xcdSafe) {      // (the probe found workgroups of a panel on different XCDs: through the coherence point)
+      __hip_atomic_store(gR2 + (size_t)row * ldA1 + n0 + en, y3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gX2 + (size_t)row * ldA1 + n0 + en, f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      gR2[(size_t)row * ldA1 + n0 + en] = y3;                // also the A operand of dWout
+      gX2[(size_t)row * ldA1 + n0 + en] = f2;                // f'(x2)
+    }
   }
   FSTAMP(4);
   if (!SPLITW) headPrecompute();
@@ -398,6 +403,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   __syncthreads();
   FVARIANT_STOP(3);
   FSTAMP(6);
+  // (safe mode: the agent-scope stores above are write-through and acknowledged -- vmcnt(0) -- before the arrival below; the
+  // agent-scope loads behind the barrier bypass this XCD's L2: no cache-wide release / acquire, which costs ~20 us each here)
   if (HT > 1 && tid == 0) {
     unsigned* ctr = a.panelCtr + panel * 32;
     const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -422,8 +429,14 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
       if (f < 16 * H4) {
         const int r = f / H4, c4 = f % H4;
         if (m0 + r < nRows) {
-          yv[q] = *reinterpret_cast<const f32x4*>(gR2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
-          fv[q] = *reinterpret_cast<const f32x4*>(gX2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
+          if (a.xcdSafe) {
+            const float* py = gR2 + (size_t)(m0 + r) * ldA1 + 4 * c4; const float* pf = gX2 + (size_t)(m0 + r) * ldA1 + 4 * c4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { yv[q][u] = __hip_atomic_load(py + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fv[q][u] = __hip_atomic_load(pf + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          } else {
+            yv[q] = *reinterpret_cast<const f32x4*>(gR2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
+            fv[q] = *reinterpret_cast<const f32x4*>(gX2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
+          }
         }
       }
     }
@@ -636,5 +649,20 @@ hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra,
 }
 
 size_t fused_lds_bytes(int dS, int H) { return fusedLdsBytes(dS, H); }
+int fused_threads() { return FUSED_NT; }
+
+// The panel exchange of the fused kernel passes y3 / f'(x2) between the workgroups of a panel with plain stores and loads,
+// which is only sound while those workgroups share one XCD's L2 -- i.e. while workgroup b runs on XCD b % 8, an observed
+// property of the dispatcher, not a promise of the runtime.  hl_create launches this kernel with the fused kernel's geometry
+// (blocks, threads, dynamic LDS) and reads back where every workgroup ran: HW_REG_XCC_ID (hwreg 20, bits 3:0).
+__global__ void xcc_probe_kernel(int* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char probeSmem[];
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15);
+}
+hipError_t launch_xcc_probe(int nBlocks, int nThreads, size_t ldsBytes, int* out, hipStream_t s) {
+  { hipError_t e = ensureDynLds(reinterpret_cast<const void*>(xcc_probe_kernel), ldsBytes); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3(nBlocks), dim3(nThreads), ldsBytes, s, out);
+  return hipGetLastError();
+}
 
 }  // namespace hl

@@ -160,6 +160,8 @@ struct FusedArgs {
   float* dOut; int ldDo;                  // output-layer deltas [B][ldDo]
   unsigned* panelCtr;                     // [panels][32] arrive counters of the panel barrier (monotonic)
   int variant;                            // development: stop after phase `variant` (0 = run everything)
+  int xcdSafe;                            // 1: the workgroups of a panel may sit on different XCDs (probe at hl_create): the panel exchange
+                                          // goes through agent-scope stores / loads instead of plain ones through the shared L2
   unsigned long long boundedMask;         // bit i: action component i is bounded (dA <= 7 here)
 };
 
@@ -198,6 +200,7 @@ hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 size_t fused_lds_bytes(int dS, int H);
+int fused_threads();
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);
 // episode ingestion (misc.hip: ingest_kernel): a batch of finished episodes staged in pinned host memory -- descriptor table
@@ -213,6 +216,8 @@ hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 struct TouchArgs { const void* ptr[24]; long long bytes[24]; int stride[24]; int n; float* sink; };
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)
 hipError_t launch_set_ret_counters(DevScalars* sc, long long cnt, hipStream_t s);   // the statistics line consumed the return-estimate counters (MemoryBuffer.cpp:534-544)
+// XCD of every workgroup of a launch shaped like the fused kernel's (fused.hip: xcc_probe_kernel): out[block] = HW_REG_XCC_ID
+hipError_t launch_xcc_probe(int nBlocks, int nThreads, size_t ldsBytes, int* out, hipStream_t s);
 hipError_t launch_notify(DevScalars* sc, unsigned* hostWord, hipStream_t s);   // ++sc->notifySeq -> pinned host word (completion stamp polled by hl_sync)
 hipError_t launch_rng_restore(DevScalars* sc, hipStream_t s);   // DevScalars::rngBak -> rng (a pre-sampled minibatch is discarded)
 hipError_t launch_act_standardize(DevScalars* sc, DevReplay rp, const float* S, int n, int dS, int dIn, float* X0, int ldX0, hipStream_t s);

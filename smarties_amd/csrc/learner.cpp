@@ -129,6 +129,7 @@ struct hl_learner {
   struct LayDesc { int type, nIn, size, ld; long long indW, indB; };   // 1 dense, 2 parametric residual, 3 ParamLayer, 4 LSTM, 5 MGU (ld = gates x cells), 6 convolution (nIn = filter floats, size = biases)
   std::vector<LayDesc> lay;       // trainable layers in network order (checkpoint packing, Network::save)
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
+  bool xcdSafe = false;      // fused kernel: panel exchange through agent-scope accesses (workgroup b was NOT found on XCD b % 8, or forced)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
   int dbgVariant = 0;
   // rccl
@@ -663,6 +664,18 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
                    fused_lds_bytes(h->dS, d1.size) <= 160 * 1024;
     }
     if (h->fusedOk) {
+      // where do the workgroups of a launch of the fused kernel's shape run?  Its panel exchange assumes that the H / 16
+      // workgroups of a panel (same blockIdx % 8) share an XCD's L2
+      const int HT = h->hid[1].size / 16, panels = (h->Mmax + 15) / 16, pg = (panels + 7) / 8, nBlk = 8 + 8 * HT * pg;
+      int* dX = nullptr; HIPCK(devAlloc(&dX, (size_t)nBlk));
+      HIPCK(launch_xcc_probe(nBlk, fused_threads(), fused_lds_bytes(h->dS, h->hid[1].size), dX, h->stream));
+      std::vector<int> xcc((size_t)nBlk);
+      HIPCK(hipMemcpyAsync(xcc.data(), dX, xcc.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCK(hipStreamSynchronize(h->stream)); hipFree(dX);
+      bool same = true;
+      for (int b = 8; b < nBlk; ++b) same = same && xcc[(size_t)b] == xcc[(size_t)(8 + ((b - 8) & 7))];
+      const char* f = getenv("SMARTIES_HIP_PANEL_SAFE");
+      h->xcdSafe = !same || (f && f[0] == '1');
       const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
       HIPCK(devAlloc(&h->panelCtr, nCtr));
       HIPCK(hipMemset(h->panelCtr, 0, nCtr * sizeof(unsigned)));
@@ -1972,6 +1985,8 @@ extern "C" HL_API int hl_kernel_profile(hl_learner* h, int which, int reps, doub
 
 // RCCL calls issued or captured so far (tests: eager and replayed steps speak the same wire protocol)
 extern "C" HL_API int64_t hl_debug_collectives(const hl_learner* h) { return h ? h->nCollectives : -1; }
+// fused kernel: -1 not in use, 0 panel exchange through the shared L2 (probe: workgroup b on XCD b % 8), 1 through agent-scope accesses
+extern "C" HL_API int hl_debug_panel_mode(const hl_learner* h) { return !h || !h->fusedOk ? -1 : (h->xcdSafe ? 1 : 0); }
 
 // the prioritised samplers' tables as the last step built them (tests: sequential normalisation / partial_sum)
 extern "C" HL_API int64_t hl_debug_per_table(hl_learner* h, float* prob, double* cp, int64_t cap) {

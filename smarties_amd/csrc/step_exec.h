@@ -262,7 +262,7 @@ FusedArgs fusedArgs(hl_learner* h, int parity) {
   fa.indWo = h->indWo; fa.indBo = h->indBo; fa.indBp = h->indBp; fa.ldW0 = d0.ldW; fa.ldW1 = d1.ldW;
   fa.Y1 = d0.Y; fa.D1 = d0.D; fa.Dres1 = d0.Dres; fa.ldA0 = d0.ldA;
   fa.X2 = d1.X; fa.R2 = d1.Rr; fa.D2 = d1.D; fa.Dres2 = d1.Dres; fa.ldA1 = d1.ldA;
-  fa.dOut = h->dOut; fa.ldDo = h->ldDo; fa.panelCtr = h->panelCtr; fa.variant = h->dbgVariant;
+  fa.dOut = h->dOut; fa.ldDo = h->ldDo; fa.panelCtr = h->panelCtr; fa.variant = h->dbgVariant; fa.xcdSafe = h->xcdSafe ? 1 : 0;
   for (int i = 0; i < h->dA; ++i) if (h->cfg.bounded[i]) fa.boundedMask |= 1ull << i;
   return fa;
 }

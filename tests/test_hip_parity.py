@@ -647,6 +647,35 @@ def test_exchange_times_out_instead_of_hanging(hip_api):
 
 
 @pytest.mark.gpu
+def test_panel_exchange_of_the_fused_kernel_checks_where_its_workgroups_run(hip_api):
+    """The fused kernel hands y3 / f'(x2) between the workgroups of a panel with plain stores and loads, sound only while they share an
+    XCD's L2.  hl_create probes HW_REG_XCC_ID with the kernel's launch shape; if workgroup b is not on XCD b % 8 -- or with
+    SMARTIES_HIP_PANEL_SAFE=1 -- the exchange goes through agent-scope accesses.  Same bits either way."""
+    import subprocess, sys, os
+    mode = hip_api.lib.hl_debug_panel_mode; mode.restype = C.c_int; mode.argtypes = [C.c_void_p]
+    L = hip_learner(hip_api, capi.make_config(dimS=5, dimA=2, hidden=(64, 64), batchSize=64, maxTotObsNum=4000))
+    assert mode(L.h) == 0, "the dispatcher no longer deals workgroup b to XCD b % 8 on this system (the library then takes the safe path)"
+    code = (
+        "import os, sys, hashlib, ctypes as C; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from smarties_amd import capi, load_hip; from oracle_api import synth_cfg, fill_synth\n"
+        "api = load_hip(); sc = synth_cfg(seed=3, dimS=17, dimA=6, lenMin=20, lenMax=60, pTerm=0.3)\n"
+        "L = capi.Learner(api, capi.make_config(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=40000))\n"
+        "L.init_weights(); fill_synth(L, sc, 300); L.initialize(); L.step(1); L.step(300); L.sync()\n"
+        "m = api.lib.hl_debug_panel_mode; m.restype = C.c_int; m.argtypes = [C.c_void_p]\n"
+        "print('MODE', m(L.h), 'HASH', hashlib.sha1(b''.join(a.tobytes() for a in L.get_params())).hexdigest(), L.scalars().beta)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for safe in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMARTIES_HIP_PANEL_SAFE=safe), capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("MODE")]
+        assert line, out.stdout + out.stderr[-2000:]
+        outs.append(line[-1].split())
+    assert outs[0][1] == "0" and outs[1][1] == "1"
+    assert outs[0][3:] == outs[1][3:], outs
+
+
+@pytest.mark.gpu
 def test_a_missing_peer_leaves_the_learner_state_intact():
     """Two connected replicas step together, then only one issues a step: its exchange kernel gives up after the (shortened) wait,
     raises the sticky device error -- and applies NOTHING of that step: no sum over stale slots, no Adam, no bookkeeping.  Weights,
