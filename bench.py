@@ -105,6 +105,10 @@ def other_configs(api, steps=1000):
                                                       gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
         "cfg4_mgu_2x32_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
                                            gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
+        # the bench network at larger batches: where the step stops being a latency chain (fraction of the fp32 MFMA peak below)
+        "cfgNS_2x256_b1024": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=131072), 400, 200, max(100, steps // 2)),
+        "cfgNS_2x256_b4096": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=131072), 400, 200, max(100, steps // 4)),
+        "cfgNS_2x256_b16384": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=16384, maxTotObsNum=131072), 400, 200, max(50, steps // 10)),
         "cfg5_racer_atari_conv4_512_b128": (dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3, conv=conv, hidden=(512,),
                                                  nnFunc="Tanh", batchSize=128, maxTotObsNum=20000, gamma=0.99, explNoise=0.05), 120, 60, max(100, steps // 5)),
     }
@@ -132,6 +136,9 @@ def other_configs(api, steps=1000):
         L.step(64); L.sync()
         t0 = time.perf_counter(); L.step(n); L.sync(); dt = time.perf_counter() - t0
         res[name] = {"us_per_step": round(dt / n * 1e6, 2), "transitions_per_s": round(kw["batchSize"] * n / dt), "steps": n}
+        if name.startswith("cfgNS_"):       # 421 376 FLOP per transition (forward, dX, dW of the 17-256-256-7 network)
+            tf = 421376.0 * kw["batchSize"] / (dt / n) / 1e12
+            res[name].update({"tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)})
         L.close()
     return res
 

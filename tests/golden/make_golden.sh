@@ -154,4 +154,9 @@ ls -la "$HERE"/*.bin
    batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 ckpt="$TMP/ck_rnn"
 "$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/discrete_rnn.bin" dimS=5 dimA=1 nOpt=4 layers=24 nnType=RNN nnFunc=SoftSign bptt=5 \
    batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+# G-nature: the convolutional stack of the Atari paper (Builder.cpp:189-194: 84x84x4 -> 32 k8 s4 -> 64 k4 s2 -> 64 k3 s1 -> 3136) in front
+# of a 512-unit dense layer, discrete RACER with 4 options, batch 32
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/nature_dqn.bin" dimS=7056 dimA=1 nOpt=4 nApp=3 \
+   "conv=84,84,4,32,8,4;20,20,32,64,4,2;9,9,64,64,3,1" layers=512 nnFunc=Tanh batch=32 nEps=16 lenMin=8 lenMax=14 pTerm=0.5 \
+   nSteps=3 gradSteps=2,3 maxObs=262144 minObs=131072 gamma=0.99 explNoise=0.05 lean=1
 rm -rf "$TMP"

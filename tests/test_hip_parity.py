@@ -1198,7 +1198,9 @@ REC_SHAPES = [  # (layer type, hidden, dimS, bptt, batch): every instantiation /
     ("lstm", (13,), 3, 5, 9),               # one layer, cells not a multiple of 4 (padded chunks, 4 lanes per gate)
     ("lstm", (5, 5, 5), 1, 3, 17),          # three layers, 8 lanes per gate
     ("lstm", (24, 16, 8, 8), 7, 6, 12),     # four layers: the general (runtime layer count) bodies
-    ("lstm", (32, 32), 4, 16, 33),          # the RACER_RNN.json shape: cells known at compile time
+    ("lstm", (32, 32), 4, 16, 33),          # the RACER_RNN.json network: cells known at compile time
+    ("lstm", (32, 32), 4, 16, 128, 1),      # ... and its exact row: batch 128, ONE action (partially observable cart-pole)
+    ("mgu", (32, 32), 4, 16, 128, 1),       # the same MDP with nnType left at its default
     ("lstm", (64, 64), 30, 4, 8),           # one lane per gate
     ("lstm", (64, 64), 200, 3, 6),          # weights too large for LDS: the one-thread-per-gate kernels
     ("lstm", (48, 40), 130, 11, 5),         # BPTT window + weights beyond the LDS budget of the BPTT kernel only
@@ -1218,10 +1220,13 @@ REC_SHAPES = [  # (layer type, hidden, dimS, bptt, batch): every instantiation /
 def test_recurrent_kernel_variants_match_oracle(hip_api, shape):
     """The recurrent kernels are instantiated per layer count / cell count and fall back to slower bodies when weights or the
     window's activations do not fit in LDS: one configuration per variant, against the oracle."""
-    kind, hidden, dS, bptt, batch = shape
-    kw = dict(dimS=dS, dimA=2, bounded=[1, 0], hidden=hidden, nnFunc="Tanh", batchSize=batch, maxTotObsNum=8000, randSeed=5,
+    kind, hidden, dS, bptt, batch = shape[:5]
+    dA = shape[5] if len(shape) > 5 else 2
+    kw = dict(dimS=dS, dimA=dA, bounded=[1, 0][:dA], hidden=hidden, nnFunc="Tanh", batchSize=batch, maxTotObsNum=8000, randSeed=5,
               nn_type=capi.NN_LSTM if kind == "lstm" else capi.NN_MGU, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=bptt)
-    G, O = _pair(hip_api, kw, synth_cfg(seed=21, dimS=dS, dimA=2, lenMin=2, lenMax=30, pTerm=0.5), 60)
+    if len(shape) > 5:      # settings/RACER_RNN.json
+        kw.update(gamma=0.99, nnLambda=1e-6, explNoise=0.1, epsAnneal=0.0)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=21, dimS=dS, dimA=dA, lenMin=2, lenMax=30, pTerm=0.5), 60 if batch < 100 else 120)
     for _ in range(3):
         G.step(1); O.step(1)
         _compare_step(G, O)
@@ -1335,7 +1340,7 @@ CONV_ATARI = [(84, 84, 4, 8, 8, 4), (20, 20, 8, 16, 6, 2), (8, 8, 16, 32, 4, 1),
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["conv_small.bin", "racer_atari.bin"])
+@pytest.mark.parametrize("name", ["conv_small.bin", "racer_atari.bin", "nature_dqn.bin"])
 def test_conv_steps_follow_reference_fixture(hip_api, name):
     """BASELINE config 5 (RACER_atari.json: 84x84 frames x (1 + 3 appended), four SoftSign convolutions, dense 512 + parametric
     residual, discrete RACER head, batch 128) and a two-layer variant: the (episode, t >= nAppendedObs) pairs of the compiled

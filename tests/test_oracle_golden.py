@@ -100,8 +100,8 @@ def test_steps_match_reference(name):
     assert relinf(w, fx["Wfinal"]) < 1e-6
 
 
-CONV_FIXTURES = ["conv_small.bin", "racer_atari.bin", "appended_dense.bin"]
-CONV_FUNC = {"conv_small.bin": "Tanh", "racer_atari.bin": "Tanh", "appended_dense.bin": "SoftSign"}      # (settings/RACER_atari.json leaves nnFunc at its default)
+CONV_FIXTURES = ["conv_small.bin", "racer_atari.bin", "appended_dense.bin", "nature_dqn.bin"]      # nature_dqn: the 32 / 64 / 64-channel stack of Builder.cpp:189-194
+CONV_FUNC = {"conv_small.bin": "Tanh", "racer_atari.bin": "Tanh", "appended_dense.bin": "SoftSign", "nature_dqn.bin": "Tanh"}      # (settings/RACER_atari.json leaves nnFunc at its default)
 
 
 @pytest.mark.parametrize("name", CONV_FIXTURES)
