@@ -533,9 +533,9 @@ def test_one_kernel_exchange_between_two_replicas(hip_api, extra):
     assert coll(X[0].h) == coll(X[1].h) >= 1005
 
 
-@pytest.mark.parametrize("n_ranks", [3, 4])
+@pytest.mark.parametrize("n_ranks", [3, 4, 8])
 def test_one_kernel_exchange_among_several_replicas(hip_api, n_ranks):
-    """The exchange among 3 and 4 replicas (one thread each, all on this GPU): every replica sums the contributions in rank order, so
+    """The exchange among 3, 4 and 8 replicas (one thread each, all on this GPU): every replica sums the contributions in rank order, so
     all end bit-identical; against host-formed sums in the same order -- ((g0 + g1) + g2) + g3 in fp32 -- over eager calls, replayed
     graphs and a 1000th-step sweep.  (Batch 24 splits 3 x 8 and 4 x 6.)"""
     from oracle_api import synth_episode
@@ -616,14 +616,16 @@ def test_one_kernel_exchange_at_start_up(hip_api):
     assert np.array_equal(Y[0].get_params()[0], Y[1].get_params()[0]) and Y[0].scalars().beta == Y[1].scalars().beta
 
 
-def test_one_kernel_exchange_between_two_processes():
-    """The same exchange between two PROCESSES sharing this GPU, windows mapped through hipIpc handles that travel over gloo
-    (tests/xchg_ipc_worker.py): replicas identical and equal to the host-summed run, bit for bit, after 1005 steps."""
+@pytest.mark.parametrize("n_procs", [2, 8])
+def test_one_kernel_exchange_between_processes(n_procs):
+    """The same exchange between 2 and 8 PROCESSES sharing this GPU -- the layout of a node's eight learner ranks, minus the
+    links --, windows mapped through hipIpc handles that travel over gloo (tests/xchg_ipc_worker.py): replicas identical and equal
+    to the host-summed run (rank-order fp32 sums), bit for bit, after 1005 steps."""
     import subprocess, sys, os
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMARTIES_HIP_XCHG_TIMEOUT_MS="20000")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29531", os.path.join(here, "xchg_ipc_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMARTIES_HIP_XCHG_TIMEOUT_MS="60000")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_procs, "--master-addr", "127.0.0.1",
+                          "--master-port", str(29531 + n_procs), os.path.join(here, "xchg_ipc_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert "XCHG_IPC_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 

@@ -1,4 +1,4 @@
-"""One replica per PROCESS, both on cuda:0, exchanging through hipIpc-mapped windows (hl_xchg_export / hl_xchg_connect):
+"""One replica per PROCESS (2 or 8 of them), all on cuda:0, exchanging through hipIpc-mapped windows (hl_xchg_export / hl_xchg_connect):
 launched twice by test_hip_parity.py::test_one_kernel_exchange_between_two_processes through torch.distributed.run (gloo carries
 the handles and, at the end, the weights).  Rank 0 then repeats the run with two host-summed replicas of its own and compares
 bit for bit."""
@@ -18,10 +18,13 @@ SC = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
 CALLS = [1, 1, 3, 20, 70, 900, 10]          # 1005 steps: eager calls, replayed graphs, the 1000th-step sweep (moments exchange)
 
 
+NR = int(os.environ.get("WORLD_SIZE", "2"))
+
+
 def replica(api, r, w0=None):
-    L = capi.Learner(api, capi.make_config(n_ranks=2, rank=r, **CFG))
+    L = capi.Learner(api, capi.make_config(n_ranks=NR, rank=r, **CFG))
     L.init_weights()
-    for e in range(r, 40, 2):
+    for e in range(r, 40 * max(1, NR // 2), NR):
         L.append_episode(**synth_episode(SC, e))
     return L
 
@@ -32,10 +35,10 @@ def main():
     api = load_hip()
     L = replica(api, rank)
     # same start as the host-summed run below: common weights, statistics of the local shard (host-exchange mode), THEN connected
-    w0 = [replica(api, 0).get_params()[0]] if rank == 1 else [L.get_params()[0]]
+    w0 = [replica(api, 0).get_params()[0]] if rank != 0 else [L.get_params()[0]]
     wv, m1, m2 = L.get_params(); L.set_params(w0[0], m1, m2)
     L.initialize()
-    handles = [None, None]
+    handles = [None] * NR
     dist.all_gather_object(handles, L.xchg_export())
     L.xchg_connect(handles)
     for n in CALLS:
@@ -43,26 +46,32 @@ def main():
     L.sync()
     w = torch.from_numpy(L.get_params()[0].copy())
     beta = torch.tensor([L.scalars().beta], dtype=torch.float64)
-    ws = [torch.zeros_like(w) for _ in range(2)]; bs = [torch.zeros_like(beta) for _ in range(2)]
+    ws = [torch.zeros_like(w) for _ in range(NR)]; bs = [torch.zeros_like(beta) for _ in range(NR)]
     dist.all_gather(ws, w); dist.all_gather(bs, beta)
     ok = True
     if rank == 0:
-        ok = bool(torch.equal(ws[0], ws[1])) and float(bs[0]) == float(bs[1])
+        ok = all(bool(torch.equal(ws[0], ws[r])) and float(bs[0]) == float(bs[r]) for r in range(1, NR))
         # the same run with the sums formed on the host (hl_step_begin / hl_grad_exchange ... hl_step_end)
-        H = [replica(api, r) for r in range(2)]
+        H = [replica(api, r) for r in range(NR)]
         w0 = H[0].get_params()[0]
         for Lh in H:
             wv, m1, m2 = Lh.get_params(); Lh.set_params(w0, m1, m2); Lh.initialize()
         for _ in range(sum(CALLS)):
             for Lh in H:
                 Lh.step_begin()
-            g = np.sum([Lh.grad_fetch() for Lh in H], axis=0, dtype=np.float32)
+            gs = [Lh.grad_fetch() for Lh in H]
+            g = gs[0].copy()
+            for q in gs[1:]:
+                g = (g + q).astype(np.float32)                 # rank order, fp32: what the exchange kernel does
             ms = [Lh.moments_fetch() for Lh in H]
             c = np.sum([Lh.counters_fetch() for Lh in H], axis=0)
             for Lh, m in zip(H, ms):
                 Lh.grad_store(g)
                 if m is not None:
-                    Lh.moments_store(np.sum(ms, axis=0))
+                    mm = ms[0].copy()
+                    for q in ms[1:]:
+                        mm = mm + q
+                    Lh.moments_store(mm)
                 Lh.counters_store(c)
                 Lh.step_end()
         wh = H[0].get_params()[0]
