@@ -581,34 +581,252 @@ hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s) {
   return hipGetLastError();
 }
 
-// sum of the chunk partials in chunk order (+ Adam): one thread per filter weight of any layer
+// ---------------------------------------------------------------------------------------------------------------
+// Row-block kernels for layers with a LARGE input image (the first layer of the Atari stacks: 84 x 84 x 4 -> k8 s4).
+// The gather kernels above fetch every patch element with a 4-byte load of its own -- 64 loads per lane and tile in the
+// forward pass, two gathers per MFMA step in the filter gradient: the vector-memory front end, not the matrix pipe, is
+// their limit (19.6 and 31 us on the RACER_atari shape).  Here a workgroup owns rbRows output rows of ONE sample: the
+// rbWin = (rbRows - 1) S + KnY input rows under them are contiguous per channel, so they are staged in LDS once with
+// 16-byte loads (32 KB for 5 output rows of the 84 x 84 x 4 layer) and every patch element is an LDS read; the MFMA A
+// operand -- the filter rows (forward) or the layer's deltas (filter gradient) -- is held in registers across the
+// workgroup's tiles, so a step costs ONE LDS read.
+//   forward:          Y[c][(b, p)] = sum_k K[c][k] patch_k(b, p)          tiles of 16 positions, waves take tiles 0, 4, ...
+//   filter gradient:  dK[c][k]    = sum_p D[b][c][p] patch_k(b, p)        one partial [KnC][K] per (sample, row block), summed in
+//                                                                         (sample, block) order by conv_reduce_adam_kernel
+// Requirements (conv_row_block): InX a multiple of 4, K a multiple of 16, window + operands within 64 KB of LDS.
+// ---------------------------------------------------------------------------------------------------------------
+int conv_row_block(const ConvGeo& g, int* win) {
+  if ((g.InX & 3) || (g.KnX & 3) || (g.K & 15) || g.K > 512 || g.KnC > 32 || (long long)g.InC * g.InY * g.InX < 4096) return 0;
+  int best = 0; double bestEff = 0;
+  for (int rb = 1; rb <= g.OpY; ++rb) {
+    const int wr = (rb - 1) * g.S + g.KnY;
+    const size_t lds = ((size_t)g.InC * wr * g.InX + (size_t)((g.KnC + 15) & ~15) * (g.K + 4) + g.K + 4 * 256) * 4;
+    if (lds > 56 * 1024) break;
+    const int tiles = (rb * g.OpX + 15) / 16;
+    const double eff = (double)(rb * g.OpX) / (16.0 * ((tiles + 3) / 4 * 4));      // filled MFMA columns per round of four wavefronts
+    if (eff > bestEff + 1e-9 || (eff > bestEff - 0.05 && rb > best)) { if (eff > bestEff) bestEff = eff; best = rb; }
+  }
+  if (best && win) *win = (best - 1) * g.S + g.KnY;
+  return best;
+}
+// stage rows [iy0, iy0 + wr) of every input channel of sample row `in` into sIn[ic][wr][InX] (16-byte loads, all in flight per batch)
+__device__ __forceinline__ void stageWindow(float* sIn, const float* in, const ConvGeo& g, int iy0, int wr, int wrValid) {
+  const int rowF4 = g.InX >> 2, perCh = wrValid * rowF4, total = g.InC * perCh;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in);
+  const int chStride4 = (g.InY * g.InX) >> 2, base4 = (iy0 * g.InX) >> 2, ldsCh4 = (wr * g.InX) >> 2;
+  f32x4* dst = reinterpret_cast<f32x4*>(sIn);
+  for (int q0 = 0; q0 < total; q0 += 256 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = q0 + threadIdx.x + 256 * u; if (i < total) { const int ic = i / perCh, r = i - ic * perCh; v[u] = src[ic * chStride4 + base4 + r]; } }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = q0 + threadIdx.x + 256 * u; if (i < total) { const int ic = i / perCh, r = i - ic * perCh; dst[ic * ldsCh4 + r] = v[u]; } }
+  }
+}
+template <int NK, int CT, int KNY, int KNX>       // MFMA steps per tile (K / 4), channel tiles of 16, filter size (compile time: no index divisions in the loop)
+__global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvGeo g = a.L[l];
+  const int row = blockIdx.y;
+  if (row >= a.sc->nRows[a.parity]) return;
+  const int rb = blockIdx.x, RB = g.rbRows, WR = g.rbWin, P = g.P, K = g.K, ldK = convPad4(K) + 4;
+  const int oy0 = rb * RB, nOy = min(RB, g.OpY - oy0), iy0 = oy0 * g.S, wrValid = min(WR, g.InY - iy0);
+  float* sIn = reinterpret_cast<float*>(smem);                       // [InC][WR][InX]
+  float* Ws = sIn + (size_t)g.InC * WR * g.InX;                      // [CT 16][ldK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  stageFlat<(CT * 16 * (4 * NK + 4) / 4 + 255) / 256>(Ws, g.Wf, CT * 16 * ldK);
+  stageWindow(sIn, g.in + (long long)row * g.ldIn, g, iy0, WR, wrValid);
+  // window-relative offset of patch element k = 4 s + lc: KnX is a multiple of 4, so the four elements of a step lie side by
+  // side in one filter row -- offset(4 s) is uniform (scalar registers), the lane adds lc
+  constexpr int fsz = KNY * KNX;
+  __syncthreads();
+  float av[CT][NK];                                                  // this lane's filter row (channel li of tile ct), elements 4 s + lc
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+    for (int s = 0; s < NK; ++s) av[ct][s] = Ws[(ct * 16 + li) * ldK + 4 * s + lc];
+  }
+  const int nPos = nOy * g.OpX, nTiles = (nPos + 15) >> 4;
+  const float* Bl = a.W + g.indB;
+  for (int t = wave; t < nTiles; t += 4) {
+    const int pl = t * 16 + li; const bool ok = pl < nPos;
+    const int plc = ok ? pl : 0, oyl = plc / g.OpX, ox = plc - oyl * g.OpX;
+    const float* pIn = sIn + oyl * g.S * g.InX + ox * g.S + lc;
+    f32x4 acc[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      constexpr int dummy = 0; (void)dummy;
+      const int k0 = 4 * s, ic = k0 / fsz, f = k0 - ic * fsz, fy = f / KNX, fx = f - fy * KNX;      // (constants after unrolling)
+      const float bv = pIn[(ic * WR + fy) * g.InX + fx];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct][s], bv, acc[ct][s & 1], 0, 0, 0);
+    }
+    if (ok) {
+      const int pp = oy0 * g.OpX + pl;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = ct * 16 + lc * 4 + q;
+          if (ch < g.KnC) {
+            const float x = (acc[ct][0][q] + acc[ct][1][q]) + Bl[(size_t)ch * P + pp];
+            const size_t o = (size_t)row * g.ldOut + (size_t)ch * P + pp;
+            g.X[o] = x; g.Y[o] = softsignEval(x);
+          }
+        }
+      }
+    }
+  }
+}
+static size_t convRowsFwdLds(const ConvGeo& g) { return ((size_t)g.InC * g.rbWin * g.InX + (size_t)((g.KnC + 15) & ~15) * (convPad4(g.K) + 4)) * 4; }
+template <int NK, int CT> static hipError_t launchFwdRowsT(const ConvArgs& a, int l, int maxRows, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  const size_t lds = convRowsFwdLds(g);
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_fwd_rows_kernel<NK, CT, 8, 8>), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((conv_fwd_rows_kernel<NK, CT, 8, 8>), dim3(g.rbCount, maxRows), dim3(256), lds, s, a, l);
+  return hipGetLastError();
+}
+hipError_t launch_conv_forward_rows(const ConvArgs& a, int l, int maxRows, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  const int nk = g.K / 4, ct = (g.KnC + 15) / 16;
+  if (nk == 64 && ct == 1) return launchFwdRowsT<64, 1>(a, l, maxRows, s);      // 4 x 8 x 8 patches, <= 16 filters (RACER_atari.json)
+  if (nk == 64 && ct == 2) return launchFwdRowsT<64, 2>(a, l, maxRows, s);      // ... 32 filters (the Atari paper's first layer)
+  return hipErrorInvalidValue;
+}
+bool conv_rows_ok(const ConvGeo& g) { return g.K == 256 && g.KnY == 8 && g.KnX == 8 && g.KnC <= 32; }      // the instantiated shape: 4 x 8 x 8 patches
+
+// filter gradient of such a layer: partial [KnC][K] of (sample b, row block rb) -> part[(b nRB + rb)][c][k]
+template <int CT>
+__global__ __launch_bounds__(256) void conv_dw_rows_kernel(ConvArgs a, int l) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvGeo g = a.L[l];
+  const int b = blockIdx.y, rb = blockIdx.x, RB = g.rbRows, WR = g.rbWin, P = g.P, K = g.K;
+  const int oy0 = rb * RB, nOy = min(RB, g.OpY - oy0), iy0 = oy0 * g.S, wrValid = min(WR, g.InY - iy0);
+  const int nPos = nOy * g.OpX, nPos4 = (nPos + 3) & ~3, ldD = RB * g.OpX + 4;
+  float* sIn = reinterpret_cast<float*>(smem);                       // [InC][WR][InX]
+  float* sD = sIn + (size_t)g.InC * WR * g.InX;                      // [CT 16][ldD]   deltas of this block's positions, zero padded
+  int* sPos = reinterpret_cast<int*>(sD + (size_t)CT * 16 * ldD);    // [RB OpX + 4]    window offset of the patch origin of position r
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  stageWindow(sIn, g.in + (long long)b * g.ldIn, g, iy0, WR, wrValid);
+  for (int i = tid; i < CT * 16 * ldD; i += 256) {
+    const int c = i / ldD, r = i - c * ldD;
+    sD[i] = (c < g.KnC && r < nPos) ? g.D[(size_t)b * g.ldOut + (size_t)c * P + oy0 * g.OpX + r] : 0.f;
+  }
+  for (int r = tid; r < nPos4; r += 256) { const int rr = r < nPos ? r : 0, oyl = rr / g.OpX, ox = rr - oyl * g.OpX; sPos[r] = oyl * g.S * g.InX + ox * g.S; }
+  __syncthreads();
+  const int nSteps = nPos4 >> 2;                                      // MFMA steps: four positions each
+  // this wave's patch-element tiles: kt = wave, wave + 4, ... (K / 16 tiles); the lane's element k = kt 16 + li
+  const int fsz = g.KnY * g.KnX, nKt = K >> 4;
+  float* part = g.part + ((size_t)b * g.rbCount + rb) * (size_t)g.KnC * K;
+  for (int kt0 = wave; kt0 < nKt; kt0 += 16) {                       // four tiles per pass: the delta operand is read once for all of them
+    int ko[4]; f32x4 acc[CT][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = min(kt0 + 4 * j, nKt - 1) * 16 + li, ic = k / fsz, f = k - ic * fsz, fy = f / g.KnX, fx = f - fy * g.KnX;
+      ko[j] = (ic * WR + fy) * g.InX + fx;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int s = 0; s < nSteps; ++s) {
+      const int r = 4 * s + lc, po = sPos[r];
+      float dv[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) dv[ct] = sD[(ct * 16 + li) * ldD + r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = sIn[po + ko[j]];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ct], pv, acc[ct][j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kt = kt0 + 4 * j;
+      if (kt < nKt) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int c = ct * 16 + lc * 4 + q; if (c < g.KnC) part[(size_t)c * K + kt * 16 + li] = acc[ct][j][q]; }
+        }
+      }
+    }
+  }
+}
+static size_t convRowsDwLds(const ConvGeo& g) {
+  const int ct = (g.KnC + 15) / 16, ldD = g.rbRows * g.OpX + 4;
+  return ((size_t)g.InC * g.rbWin * g.InX + (size_t)ct * 16 * ldD + (size_t)g.rbRows * g.OpX + 4) * 4;
+}
+hipError_t launch_conv_dw_rows(const ConvArgs& a, int l, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  const size_t lds = convRowsDwLds(g);
+  const int ct = (g.KnC + 15) / 16;
+  if (ct == 1) {
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_rows_kernel<1>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_dw_rows_kernel<1>, dim3(g.rbCount, a.B), dim3(256), lds, s, a, l);
+  } else if (ct == 2) {
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_rows_kernel<2>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_dw_rows_kernel<2>, dim3(g.rbCount, a.B), dim3(256), lds, s, a, l);
+  } else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// sum of the chunk partials (+ Adam): 16 filter weights x 16 slices of the chunk range per workgroup -- a slice is summed in chunk
+// order with eight partials in flight, the sixteen slice sums are added in slice order (fixed association: bit-deterministic);
+// the row-block kernels leave one partial per (sample, row block), i.e. hundreds per weight
 __global__ __launch_bounds__(256) void conv_reduce_adam_kernel(ConvArgs a, AdamHyper hyp, int fuseAdam) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sp[16][16];
+  const int wl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  long long i = (long long)blockIdx.x * 16 + wl;
   int l = 0;
   for (; l < a.nL; ++l) { const long long n = (long long)a.L[l].KnC * a.L[l].K; if (i < n) break; i -= n; }
-  if (l >= a.nL) return;
-  const ConvGeo& g = a.L[l];
+  const bool valid = l < a.nL;
+  const ConvGeo& g = a.L[valid ? l : 0];
   const size_t n = (size_t)g.KnC * g.K;
   float s = 0.f;
-  for (int c0 = 0; c0 < g.nChunks; c0 += 8) {       // eight partials in flight, summed in chunk order
-    float v[8];
+  if (valid) {
+    const int per = (g.nChunks + 15) / 16, c0s = sl * per, c1s = min(g.nChunks, c0s + per);
+    for (int c0 = c0s; c0 < c1s; c0 += 8) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = c0 + u < g.nChunks ? g.part[(size_t)(c0 + u) * n + i] : 0.f;
+      for (int u = 0; u < 8; ++u) v[u] = c0 + u < c1s ? g.part[(size_t)(c0 + u) * n + i] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
   }
+  sp[sl][wl] = s;
+  __syncthreads();
+  if (sl != 0 || !valid) return;
+  s = sp[0][wl];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) s += sp[q][wl];
   a.G[g.indW + i] = s;
   if (fuseAdam) {
     AdamCoef c; c.eta = a.sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac;
     float w = a.Wrw[g.indW + i], m1 = a.M1[g.indW + i], m2 = a.M2[g.indW + i];
     adamStep(c, s, w, m1, m2);
     a.Wrw[g.indW + i] = w; a.M1[g.indW + i] = m1; a.M2[g.indW + i] = m2;
+    // the new weight goes straight into the kernels' LDS layouts (what conv_prep_kernel would rebuild before the next forward pass)
+    const int cc = (int)(i / g.K), k = (int)(i - (long long)cc * g.K);
+    g.Wf[(size_t)cc * (convPad4(g.K) + 4) + k] = w;
+    if (l > 0) {
+      const int fsz = g.KnY * g.KnX, ic = k / fsz, f = k - ic * fsz;
+      if (convStrided(g)) {
+        const int S = g.S, TY = g.KnY / S, TX = g.KnX / S, ld = convPad4(g.KnC * TY * TX) + 4, rows = (g.InC + 15) & ~15;
+        const int fy = f / g.KnX, fx = f - fy * g.KnX, cls = (fy % S) * S + (fx % S), kc = cc * TY * TX + (fy / S) * TX + (fx / S);
+        g.Wx[((size_t)cls * rows + ic) * ld + kc] = w;
+      } else {
+        g.Wx[(size_t)ic * (convPad4(g.KnC * fsz) + 4) + cc * fsz + f] = w;
+      }
+    }
   }
 }
 hipError_t launch_conv_reduce_adam(const ConvArgs& a, const AdamHyper& hyp, int fuseAdam, hipStream_t s) {
   long long n = 0;
   for (int l = 0; l < a.nL; ++l) n += (long long)a.L[l].KnC * a.L[l].K;
-  hipLaunchKernelGGL(conv_reduce_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, hyp, fuseAdam);
+  hipLaunchKernelGGL(conv_reduce_adam_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, a, hyp, fuseAdam);
   return hipGetLastError();
 }
 

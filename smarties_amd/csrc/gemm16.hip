@@ -308,6 +308,106 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
   else gemmTile<GEMM_ROLE_DW>(P, bid - P.tileStart, smem, sc, hyp, 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward / dX tiles with a long reduction (256 < K <= 640: the dense layer behind a convolution stack, 576 -> 512, and
+// wide first layers): the chunked tile above walks K in 256-column chunks, one global round trip each (11 us for
+// 128 x 576 x 512).  Here EVERY operand load of the tile is in flight at once -- 2 x K / 64 16-byte loads per thread --,
+// the whole reduction is staged in LDS once, the four wavefronts take a quarter of K each.  One problem per launch.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int OS_KMAX = 640, OS_Q = OS_KMAX / 64;       // float4 loads per thread and operand
+__host__ __device__ inline size_t gemmOsLds(int K) { return ((size_t)2 * 16 * (K + 2) + 4 * 256) * 4; }
+template <int ROLE>
+__global__ __launch_bounds__(256) void gemm_os_kernel(const GemmProblem* __restrict__ probs, const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char osmem[];
+  if (extra.role && blockIdx.x == 0) { runExtra(extra, osmem); return; }
+  const int bid = blockIdx.x - (extra.role ? 1 : 0);
+  const int nRowsDyn = sc->nRows[hyp.parity];
+  const GemmProblem P = probs[0];
+  const bool isX = P.flavor == GEMM_X;
+  int tile = bid;
+  { const int nT = P.tilesM * P.tilesN; if ((nT & 7) == 0) tile = (tile & 7) * (nT >> 3) + (tile >> 3); }     // XCD-aware order (gemmTile)
+  const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN, m0 = tm * 16, n0 = tn * 16;
+  const int Mvalid = P.dynRows ? nRowsDyn : P.M;
+  if (m0 >= Mvalid) return;
+  const int K = P.K, K4 = K >> 2, ld = K + 2;
+  float* sA = reinterpret_cast<float*>(osmem);          // [16][K + 2]
+  float* sB = sA + 16 * ld;                              // forward: [K][16]; dX: [16][K + 2]
+  float* red = sB + 16 * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+  const bool outOk = m < Mvalid && n < P.N;
+  // epilogue operands first (independent of everything)
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+  if (outOk) {
+    if (!isX) { e0 = P.bias[n]; if (P.C3 && n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; e3 = P.resB[n]; } }
+    else { if (n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; } e0 = P.actX[(size_t)m * P.ldAct + n]; e3 = P.actY[(size_t)m * P.ldAct + n]; }
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 va[OS_Q], vb[OS_Q];
+  const int nA4 = 16 * K4;                                // float4 of a 16 x K rows tile == of a K x 16 columns tile
+#pragma unroll
+  for (int q = 0; q < OS_Q; ++q) {
+    const int idx = tid + 256 * q; va[q] = z4; vb[q] = z4;
+    if (idx < nA4) {
+      const int r = idx / K4, c = (idx - r * K4) * 4;
+      if (m0 + r < Mvalid) va[q] = *reinterpret_cast<const float4*>(P.A + (size_t)(m0 + r) * P.lda + c);
+      if (isX) { if (n0 + r < P.N) vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(n0 + r) * P.ldb + c); }
+      else { const int k = idx >> 2, cc = n0 + (idx & 3) * 4; if (cc < P.ldb) vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)k * P.ldb + cc); }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < OS_Q; ++q) {
+    const int idx = tid + 256 * q;
+    if (idx < nA4) {
+      const int r = idx / K4, c = (idx - r * K4) * 4;
+      float2* d = reinterpret_cast<float2*>(sA + r * ld + c);
+      d[0] = make_float2(va[q].x, va[q].y); d[1] = make_float2(va[q].z, va[q].w);
+      if (isX) { float2* e = reinterpret_cast<float2*>(sB + r * ld + c); e[0] = make_float2(vb[q].x, vb[q].y); e[1] = make_float2(vb[q].z, vb[q].w); }
+      else *reinterpret_cast<float4*>(sB + idx * 4) = vb[q];
+    }
+  }
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int kw = K >> 2, k0 = wave * kw;                  // K % 32 == 0 (checked by the launcher): kw is a multiple of 8
+  for (int s = 0; s < kw; s += 8) {
+    const int ka = k0 + s + lc, kb2 = ka + 4;
+    const float a0 = sA[li * ld + ka], a1 = sA[li * ld + kb2];
+    const float b0 = isX ? sB[li * ld + ka] : sB[ka * 16 + li], b1 = isX ? sB[li * ld + kb2] : sB[kb2 * 16 + li];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+  __syncthreads();
+  const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  if (!outOk) return;
+  if (!isX) {
+    const float x = v + e0;
+    P.C[(size_t)m * P.ldc + n] = x;
+    const float y = actEval(P.func, x);
+    P.C2[(size_t)m * P.ldc + n] = y;
+    if (P.C3) { float r = y; if (n < P.resN) r += e1 * e2 + e3; P.C3[(size_t)m * P.ldc + n] = r; }
+  } else {
+    float dres = v;
+    if (n < P.resN) dres += e1 * e2;
+    P.C[(size_t)m * P.ldc + n] = dres;
+    P.C2[(size_t)m * P.ldc + n] = dres * actDiff(P.func, e0, e3);
+  }
+}
+// usable for this problem?  (host side: K of the problem the launch carries)
+bool gemm_oneshot_ok(int flavor, int K) { return (flavor == GEMM_F || flavor == GEMM_X) && K > 256 && K <= OS_KMAX && (K & 31) == 0; }
+hipError_t launch_gemm_oneshot(int role, const GemmProblem* dProb, int K, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  size_t lds = gemmOsLds(K); if (lds < TAIL_LDS_BYTES) lds = TAIL_LDS_BYTES;
+  const dim3 grid(nBlocks + (ex.role ? 1 : 0)), block(256);
+  const void* k = role == GEMM_ROLE_DX ? reinterpret_cast<const void*>(gemm_os_kernel<GEMM_ROLE_DX>) : (role == GEMM_ROLE_FWD0 ? reinterpret_cast<const void*>(gemm_os_kernel<GEMM_ROLE_FWD0>) : reinterpret_cast<const void*>(gemm_os_kernel<GEMM_ROLE_FWD>));
+  { hipError_t e = ensureDynLds(k, lds); if (e != hipSuccess) return e; }
+  if (role == GEMM_ROLE_DX) hipLaunchKernelGGL(gemm_os_kernel<GEMM_ROLE_DX>, grid, block, lds, s, dProb, sc, hyp, ex);
+  else if (role == GEMM_ROLE_FWD0) hipLaunchKernelGGL(gemm_os_kernel<GEMM_ROLE_FWD0>, grid, block, lds, s, dProb, sc, hyp, ex);
+  else hipLaunchKernelGGL(gemm_os_kernel<GEMM_ROLE_FWD>, grid, block, lds, s, dProb, sc, hyp, ex);
+  return hipGetLastError();
+}
+
 // sum of the chunk partials of the split weight-gradient problems, in chunk order, + Adam
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* __restrict__ probs, const DevScalars* __restrict__ sc, AdamHyper hyp) {
   const GemmProblem P = probs[blockIdx.y];

@@ -17,6 +17,12 @@
 namespace hl {
 
 #define HEAD_MAXOUT 136
+// development time stamps of the first sample's wavefront (-DHL_HEAD_STAMPS), DevScalars::dbgT[0..]
+#ifdef HL_HEAD_STAMPS
+#define HSTAMP(i) do { if (row == 0 && lane == 0) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
 
 // HQ = ceil(H / 64): hidden activations per lane.  nDense <= 8 (dimA <= 7) takes the register
 // path for the output layer; wider action spaces use the generic path below.
@@ -36,7 +42,9 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = (blockIdx.x - nExtra) * 4 + wave;
   const DevScalars* sc = a.sc;
+  HSTAMP(0);
   if (row >= sc->nRows[a.parity]) return;
+  HSTAMP(1);
   const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H, nAdv = a.nAdv, pM = 1 + nAdv;
   const bool hasAdv = nAdv > 0 || a.nOpt > 0;
   const bool isNext = row >= B;
@@ -44,10 +52,11 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   const long long slot = a.bt.slot[b];
   const float* Wo = a.params + a.indWo;
   const bool small = nDense <= 8;
+  const bool mid = nDense > 8 && nDense <= 16;      // two chunks of eight outputs (RACER heads with a few options / actions): both in registers
 
   // ---- every load, up front -------------------------------------------------------------------
   float yv[HQ], xl[HQ], yl[HQ];
-  float4 w0[HQ], w1[HQ];
+  float4 w0[HQ], w1[HQ], w2[HQ], w3[HQ];
 #pragma unroll
   for (int q = 0; q < HQ; ++q) {
     const int k = lane + 64 * q;
@@ -55,16 +64,21 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     yv[q] = ok ? a.Yin[(size_t)row * a.ldY + k] : 0.f;
     xl[q] = (ok && !isNext) ? a.Xlast[(size_t)row * a.ldD + k] : 0.f;
     yl[q] = (ok && !isNext) ? a.Ylast[(size_t)row * a.ldD + k] : 0.f;
-    w0[q] = make_float4(0.f, 0.f, 0.f, 0.f); w1[q] = w0[q];
-    if (ok && small) {
+    w0[q] = make_float4(0.f, 0.f, 0.f, 0.f); w1[q] = w0[q]; w2[q] = w0[q]; w3[q] = w0[q];
+    if (ok && (small || mid)) {
       w0[q] = *reinterpret_cast<const float4*>(Wo + (size_t)k * a.ldWo);
       w1[q] = *reinterpret_cast<const float4*>(Wo + (size_t)k * a.ldWo + 4);
+    }
+    if (ok && mid) {      // (a chunk fetched inside the loops below costs a dependent round trip through the L2, twice: forward and back)
+      w2[q] = *reinterpret_cast<const float4*>(Wo + (size_t)k * a.ldWo + 8);
+      w3[q] = *reinterpret_cast<const float4*>(Wo + (size_t)k * a.ldWo + 12);
     }
   }
   // hand the (episode, next-row) map of THIS minibatch to the bookkeeping pass, which runs while
   // the sampler already overwrites bt.eid / bt.nextOf for the next step
   if (!isNext && lane == 0) { a.bt.pEid[b] = a.bt.eid[b]; a.bt.pNextOf[b] = a.bt.nextOf[b]; }
   const float bo = lane < nDense ? a.params[a.indBo + lane] : 0.f;
+  const float bo2 = (mid && lane < 8 && 8 + lane < nDense) ? a.params[a.indBo + 8 + lane] : 0.f;
   const float bp = lane < a.nSig ? a.params[a.indBp + lane] : 0.f;
   double act = 0, bMean = 0, bStd = 1;
   if (!isNext && a.nOpt) {     // discrete head: lane 0 holds the action message, lane j the behaviour probability of option j
@@ -84,15 +98,19 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     if (arr) misc = arr[sl];
   }
 
+  HSTAMP(2);
   // ---- output dense layer: O[o] = b[o] + sum_k y[k] W[k][o], eight outputs at a time; the weight rows of a chunk are
   // fetched as two 16-byte loads per hidden unit, all of them in flight before the first use (the first chunk was
   // requested up front, next to the activations) ------------------------------------------------------------------
   const int nChunkOut = isNext ? 1 : (nDense + 7) / 8;
   for (int c = 0; c < nChunkOut; ++c) {
     float4 wa[HQ], wb[HQ];
-    if (c == 0 && small) {
+    if (c == 0 && (small || mid)) {
 #pragma unroll
       for (int q = 0; q < HQ; ++q) { wa[q] = w0[q]; wb[q] = w1[q]; }
+    } else if (c == 1 && mid) {
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) { wa[q] = w2[q]; wb[q] = w3[q]; }
     } else {
 #pragma unroll
       for (int q = 0; q < HQ; ++q) {
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     for (int q = 0; q < 8; ++q) if (q == lane) mine = p[q];
     const int o = 8 * c + lane;
     if (lane < 8 && o < nDense) {      // BaseLayer::forward of the output layer: y = f(x), f = settings nnOutputFunc (Approximator.cpp:228)
-      const float x = mine + (c == 0 ? bo : a.params[a.indBo + o]);
+      const float x = mine + (c == 0 ? bo : ((c == 1 && mid) ? bo2 : a.params[a.indBo + o]));
       sXo[wave][o] = x; sO[wave][o] = (double)(a.outFunc == HL_FUNC_LINEAR ? x : actEval(a.outFunc, x));
     }
   }
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     return;
   }
 
+  HSTAMP(3);
   // ---- head: results shared by the write-back / back-propagation tail -------------------------------------
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
   double xRHO = 1, xDKL = 0, xV = 0, xdQ = 0, xAval = 0; bool xfar = false; double xg0 = 0;
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       a.bt.dq[b] = (double)E;
     }
   }
+  HSTAMP(4);
   for (int o = lane; o < a.nOut; o += 64) a.bt.O[(size_t)row * a.nOut + o] = sO[wave][o];
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
@@ -312,9 +332,12 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     const int nCh = (nDense + 7) / 8;
     for (int c = 0; c < nCh; ++c) {
       float4 wa[HQ], wb[HQ];
-      if (c == 0 && small) {
+      if (c == 0 && (small || mid)) {
 #pragma unroll
         for (int q = 0; q < HQ; ++q) { wa[q] = w0[q]; wb[q] = w1[q]; }
+      } else if (c == 1 && mid) {
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) { wa[q] = w2[q]; wb[q] = w3[q]; }
       } else {
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       }
     }
   }
+  HSTAMP(5);
 }
 
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {

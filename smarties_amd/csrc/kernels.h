@@ -92,6 +92,9 @@ struct ConvGeo {
   float* part;               // [nChunks][KnC K] partial filter gradients
   float* Wf; float* Wx;      // the filters in the kernels' LDS layouts (conv.hip: conv_prep_kernel)
   int nChunks, chunkRows, dwBlock0;   // reduction chunks of the filter gradient; first workgroup of this layer in the dW launch
+  // row-block kernels (conv.hip: conv_fwd_rows_kernel / conv_dw_rows_kernel; layers with a large input image): a workgroup owns
+  // rbRows output rows of one sample and stages the rbWin input rows under them in LDS.  rbRows = 0: not used for this layer.
+  int rbRows, rbCount, rbWin;
 };
 struct ConvArgs {
   DevScalars* sc; int parity, B, nL;
@@ -106,6 +109,10 @@ long long conv_prep_floats(const ConvGeo& g, int which);                   // fl
 hipError_t launch_conv_forward(const ConvArgs& a, int l, int maxRows, hipStream_t s);
 hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s);       // D of layer l-1 from D of layer l
 hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);
+int conv_row_block(const ConvGeo& g, int* win);
+bool conv_rows_ok(const ConvGeo& g);                                          // the shape the row-block kernels are instantiated for                               // rows per workgroup of the row-block kernels (0: layer not served)
+hipError_t launch_conv_forward_rows(const ConvArgs& a, int l, int maxRows, hipStream_t s);
+hipError_t launch_conv_dw_rows(const ConvArgs& a, int l, hipStream_t s);
 hipError_t launch_conv_reduce_adam(const ConvArgs& a, const AdamHyper& hyp, int fuseAdam, hipStream_t s);
 
 struct PostArgs {
@@ -213,6 +220,9 @@ struct IngestArgs {
 };
 constexpr int INGEST_MAX_EP = 1024;
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
+// forward / dX tile with the whole reduction in flight at once (gemm16.hip: gemm_os_kernel), 256 < K <= 640
+bool gemm_oneshot_ok(int flavor, int K);
+hipError_t launch_gemm_oneshot(int role, const GemmProblem* dProb, int K, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
 struct TouchArgs { const void* ptr[24]; long long bytes[24]; int stride[24]; int n; float* sink; };
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)
 hipError_t launch_set_ret_counters(DevScalars* sc, long long cnt, hipStream_t s);   // the statistics line consumed the return-estimate counters (MemoryBuffer.cpp:534-544)

@@ -59,6 +59,7 @@ struct hl_learner {
   // gathered by its own kernel; with convolutions hid[0] stands for the last convolutional layer (its X, Y, D, Dres are that
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
+  bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
   RecLayer rec[HL_MAX_HIDDEN]{};
@@ -628,7 +629,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       long long rowsPer = std::max<long long>(64, (R * tiles + 1023) / 1024);   // about a thousand workgroups per layer
       rowsPer = std::min<long long>(roundUp(rowsPer, 16), 2048);
       g.chunkRows = (int)rowsPer; g.nChunks = (int)((R + rowsPer - 1) / rowsPer);
-      g.dwBlock0 = blk; blk += g.nChunks * tiles;
+      // layers with a large input image (the first one of the Atari stacks): row-block kernels, one partial per (sample, row block)
+      { int win = 0; const int rb = getenv("SMARTIES_HIP_NO_CONV_ROWS") ? 0 : conv_row_block(g, &win);
+        g.rbRows = 0; g.rbCount = 0; g.rbWin = 0;
+        if (l == 0 && rb > 0 && conv_rows_ok(g)) { g.rbRows = rb; g.rbCount = (g.OpY + rb - 1) / rb; g.rbWin = win; g.nChunks = B * g.rbCount; } }
+      g.dwBlock0 = blk; blk += g.rbRows ? 0 : g.nChunks * tiles;
       HIPCK(devAlloc(&g.part, (size_t)g.nChunks * g.KnC * g.K));
       HIPCK(devAlloc(&g.Wf, (size_t)conv_prep_floats(g, 0))); HIPCK(devAlloc(&g.Wx, (size_t)conv_prep_floats(g, 1)));
       if ((long long)h->Mmax * g.P >= (1ll << 31) || (long long)h->Mmax * g.InY * g.InX >= (1ll << 31)) return fail(h, HL_ERR_UNSUPPORTED, "convolution: rows x positions >= 2^31");
@@ -851,6 +856,7 @@ int hl_init_weights(hl_learner* h) {
     for (int o = 0; o < h->nSig; ++o) W[h->indBp + o] = (float)((S * S - 0.25) / S);   // SoftPlus::_inv (Functions.h:564-568)
   }
   HIPCK(hipMemcpyAsync(h->W, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  h->convPrepStale = true;
   std::memcpy(s.rng, g.x, sizeof(g.x)); s.rngPos = g.p;
   HIPCK(hipMemcpyAsync(&h->sc->rng[0], s.rng, sizeof(s.rng), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(&h->sc->rngPos, &s.rngPos, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
@@ -862,7 +868,7 @@ int hl_set_params(hl_learner* h, const float* w, const float* m1, const float* m
   if (!h) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
   const size_t n = (size_t)h->nParams * sizeof(float);
-  if (w) HIPCK(hipMemcpyAsync(h->W, w, n, hipMemcpyHostToDevice, h->stream));
+  if (w) { HIPCK(hipMemcpyAsync(h->W, w, n, hipMemcpyHostToDevice, h->stream)); h->convPrepStale = true; }
   if (m1) HIPCK(hipMemcpyAsync(h->M1, m1, n, hipMemcpyHostToDevice, h->stream));
   if (m2) HIPCK(hipMemcpyAsync(h->M2, m2, n, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -1034,6 +1040,7 @@ static int preStepChecks(hl_learner* h) {
   if (!h->initialized) return fail(h, HL_ERR_STATE, "step before hl_initialize");
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_step_begin called twice");
   if (h->nTransitions < h->B) return fail(h, HL_ERR_TOO_FEW_DATA, "Parameter minTotObsNum is too low for given problem");
+  { const int rc = ensureConvPrep(h); if (rc) return rc; }
   return flushPending(h);
 }
 
@@ -1617,7 +1624,8 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
     const int m = std::min(h->Mmax, n - r0);
     HIPCK(hipMemcpyAsync(h->dActS, states + (size_t)r0 * h->dIn, (size_t)m * h->dIn * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, m, h->dS, h->dIn, h->buf[0].X0, h->ldX0, h->stream));
-    int rc = launchForward(h, 0, h->stream, false, /*gather*/false); if (rc) return rc;
+    int rc = ensureConvPrep(h); if (rc) return rc;
+    rc = launchForward(h, 0, h->stream, false, /*gather*/false); if (rc) return rc;
     HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, m,
                             h->dActO, h->stream, nullptr, 0, h->cfg.nnOutputFunc));
     HIPCK(hipMemcpyAsync(outputs + (size_t)r0 * h->nOut, h->dActO, (size_t)m * h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));

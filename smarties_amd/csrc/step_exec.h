@@ -276,6 +276,15 @@ int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = fals
   HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
   return HL_OK;
 }
+ConvArgs convArgs(hl_learner* h, int parity);
+// (never inside a stream capture: the launch has to RUN before the flag is cleared)
+int ensureConvPrep(hl_learner* h) {
+  if (h->nConv == 0 || !h->convPrepStale) return HL_OK;
+  const ConvArgs ca = convArgs(h, 0);
+  HIPCK(launch_conv_prep(ca, h->stream));
+  h->convPrepStale = false;
+  return HL_OK;
+}
 ConvArgs convArgs(hl_learner* h, int parity) {
   ConvArgs ca{}; ca.sc = h->sc; ca.parity = parity; ca.B = h->B; ca.nL = h->nConv;
   ca.W = h->W; ca.Wrw = h->W; ca.M1 = h->M1; ca.M2 = h->M2; ca.G = h->G;
@@ -296,9 +305,15 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
   const int j0 = h->nConv > 0 ? 1 : 0;
   if (j0) {
     const ConvArgs ca = convArgs(h, parity);
-    HIPCK(timed(h, "conv_prep", s, [&] { return launch_conv_prep(ca, s); }));
+    // filters -> the kernels' LDS layouts: kept current by the Adam pass of the filter gradients (conv_reduce_adam_kernel);
+    // rebuilt here only after something else wrote the weights (start-up, hl_set_params, a restart) or where Adam runs
+    // elsewhere (replica exchange)
+    if (exchanging(h)) HIPCK(timed(h, "conv_prep", s, [&] { return launch_conv_prep(ca, s); }));
+    else if (h->convPrepStale) return fail(h, HL_ERR_STATE, "convolution filter layouts are stale (ensureConvPrep was not called)");
     for (int l = 0; l < h->nConv; ++l) {
       snprintf(nm, sizeof(nm), "conv_fwd%d", l);
+      if (ca.L[l].rbRows) HIPCK(timed(h, nm, s, [&] { return launch_conv_forward_rows(ca, l, h->Mmax, s); }));
+      else
       HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
     }
   }
@@ -311,7 +326,11 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       if (j == h->nHidden - 1) ph |= PH_B;
       if (ph) { ex = extraSample(h, parity ^ 1, ph); pex = &ex; }
     }
-    HIPCK(timed(h, nm, s, [&] { return launch_gemm(j == j0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD, h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
+    const int role = j == j0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD;
+    if (gemm_oneshot_ok(GEMM_F, h->hid[j].nIn))      // long reductions (the dense layer behind a convolution stack): every operand load in flight at once
+      HIPCK(timed(h, nm, s, [&] { return launch_gemm_oneshot(role, h->dProbs + sb.fwdIdx[j], h->hid[j].nIn, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
+    else
+    HIPCK(timed(h, nm, s, [&] { return launch_gemm(role, h->dProbs + sb.fwdIdx[j], 1, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
   }
   return HL_OK;
 }
@@ -359,6 +378,10 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   char nm[32];
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
+    const int jx = h->nHidden - 1 - (int)i;          // problem i back-propagates through block jx: reduction over its outputs
+    if (gemm_oneshot_ok(GEMM_X, h->hid[jx].size))
+      HIPCK(timed(h, nm, s, [&] { return launch_gemm_oneshot(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], h->hid[jx].size, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
+    else
     HIPCK(timed(h, nm, s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
   }
   if (h->nConv > 0) {   // convolutional layers: input gradients from the last one down, then every filter gradient (+ Adam)
@@ -367,7 +390,8 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
       snprintf(nm, sizeof(nm), "conv_dx%d", l);
       HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s); }));
     }
-    HIPCK(timed(h, "conv_dw", s, [&] { return launch_conv_dw(ca, h->convDwBlocks, s); }));
+    for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) HIPCK(timed(h, "conv_dw_rows", s, [&] { return launch_conv_dw_rows(ca, l, s); }));
+    if (h->convDwBlocks > 0) HIPCK(timed(h, "conv_dw", s, [&] { return launch_conv_dw(ca, h->convDwBlocks, s); }));
     HIPCK(timed(h, "conv_reduce_adam", s, [&] { return launch_conv_reduce_adam(ca, hyp, fuseAdam ? 1 : 0, s); }));
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
@@ -419,6 +443,7 @@ int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
 bool evictionDue(const hl_learner* h);
 int prepareExact(hl_learner* h, int n);
 int touchReplay(hl_learner* h);
+int ensureConvPrep(hl_learner* h);
 int applyRemoval(hl_learner* h) {
   bool any = false;
   const int filter = h->cfg.ERoldSeqFilter;
@@ -693,6 +718,7 @@ int captureAllGraphs(hl_learner* h) {
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
   static_assert(NS <= 16, "hl_learner::graphs is too small");
   if (!h->useGraph || (exchanging(h) && !(h->exchGraph && wired(h)))) return HL_OK;
+  { const int rc = ensureConvPrep(h); if (rc) return rc; }
   for (int j = 0; j < NS; ++j) for (int p0 = 0; p0 < 2; ++p0) {
     if (!graphUsable(h, GRAPH_SIZES[j], p0) || h->graphs[j][p0].exec) continue;
     const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);

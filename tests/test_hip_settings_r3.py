@@ -126,10 +126,10 @@ def test_return_estimators_follow_the_oracle_across_sweeps(hip_api, est):
 
 @pytest.mark.parametrize("extra", [dict(nnOutputFunc="Tanh"), dict(nnOutputFunc="LRelu", adv_kind=capi.ADV_GAUSSIAN, hidden=(24, 16, 8), nnFunc="Tanh"),
                                    dict(nnOutputFunc="HardSign", dimA=1, bounded=[1], adv_kind=capi.ADV_DISCRETE, n_options=5),
-                                   dict(encoder=(24, 0), hidden=(16, 16)), dict(encoder=(32,), hidden=(32,)),
+                                   dict(encoder=(24, 0), hidden=(16, 16)), dict(encoder=(32,), hidden=(32,)), dict(hidden=(320, 288, 64), nnFunc="Tanh"),
                                    dict(nn_type=capi.NN_RNN, nnFunc="Tanh", nnBPTTseq=6), dict(nn_type=capi.NN_RNN, hidden=(40, 24, 12), nnBPTTseq=4),
                                    dict(nn_type=capi.NN_RNN, hidden=(20,), nnFunc="SoftSign", dimA=1, bounded=[0], adv_kind=capi.ADV_DISCRETE, n_options=3, nnBPTTseq=9)],
-                         ids=["out-tanh", "out-lrelu-gauss", "out-hardsign-discrete", "encoder-24-0+16x16", "encoder-32+32", "rnn-2x32", "rnn-40x24x12", "rnn-20-discrete"])
+                         ids=["out-tanh", "out-lrelu-gauss", "out-hardsign-discrete", "encoder-24-0+16x16", "encoder-32+32", "wide-320x288x64-oneshot-gemm", "rnn-2x32", "rnn-40x24x12", "rnn-20-discrete"])
 def test_random_configurations_match_oracle(hip_api, extra):
     """Device sampler + update against the oracle (stable episode order) for the new settings: sample indices and masks bit-exact,
     per-sample quantities and gradients to 1e-5, over eager steps, replayed graphs and arrivals; rollout inference likewise."""
