@@ -24,11 +24,17 @@ namespace hl {
 #define HSTAMP(i) do { } while (0)
 #endif
 
-// HQ = ceil(H / 64): hidden activations per lane.  nDense <= 8 (dimA <= 7) takes the register
-// path for the output layer; wider action spaces use the generic path below.
-template <int HQ>
+// HQ: hidden activations per lane.  nDense <= 8 (dimA <= 7) takes the register path for the output layer; wider action spaces
+// use the generic path below.
+// SPLIT = 1: one wavefront per sample, four samples per workgroup, HQ = ceil(H / 64).
+// SPLIT = 4 (hidden width > 128): the four wavefronts of a workgroup share ONE sample -- each takes a quarter of the hidden
+// units (HQ = ceil(H / 256)) in the output layer and in the back-propagation, partial outputs meet in LDS in wave order, the
+// first wavefront does the fp64 head.  Four times the workgroups, a quarter of the serial work and of the bytes per wavefront
+// (device time stamps on the RACER_atari shape, one wavefront per sample: 6.6 us until the loads are in, 2.7 us output layer,
+// 3.0 us head, 4.2 us write-backs and back-propagation).
+template <int HQ, int SPLIT>
 __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra) {
-  constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 2 * 4 * 72 * 4;
+  constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4 + 5 * 72 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[HEAD_LDS > TAIL_LDS_BYTES ? HEAD_LDS : TAIL_LDS_BYTES];
   // horizontal fusion: workgroup 0 (dispatched first) runs sampler phase C of the next step
   // ... and, for wide states, workgroups 1..helpers gather the minibatch it found (one workgroup keeps only a few dozen HBM
@@ -40,7 +46,11 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   float (*sDelta)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8);
   float (*sXo)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4);   // pre-activations of the output layer (nnOutputFunc)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = (blockIdx.x - nExtra) * 4 + wave;
+  const int ws = SPLIT == 4 ? 0 : wave;                 // slot of this wavefront's sample in the shared arrays
+  const int part = SPLIT == 4 ? wave : 0;               // which quarter of the hidden units
+  const int kBase = part * 64 * HQ;
+  float (*sPart)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4) + 1;   // SPLIT: partial outputs of the four wavefronts, rows 1..4 behind sXo[0]
+  const int row = SPLIT == 4 ? (int)(blockIdx.x - nExtra) : (int)(blockIdx.x - nExtra) * 4 + wave;
   const DevScalars* sc = a.sc;
   HSTAMP(0);
   if (row >= sc->nRows[a.parity]) return;
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   float4 w0[HQ], w1[HQ], w2[HQ], w3[HQ];
 #pragma unroll
   for (int q = 0; q < HQ; ++q) {
-    const int k = lane + 64 * q;
+    const int k = kBase + lane + 64 * q;
     const bool ok = k < H;
     yv[q] = ok ? a.Yin[(size_t)row * a.ldY + k] : 0.f;
     xl[q] = (ok && !isNext) ? a.Xlast[(size_t)row * a.ldD + k] : 0.f;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     } else {
 #pragma unroll
       for (int q = 0; q < HQ; ++q) {
-        const int k = lane + 64 * q; const bool ok = k < H;
+        const int k = kBase + lane + 64 * q; const bool ok = k < H;
         const float* wr = Wo + (size_t)(ok ? k : 0) * a.ldWo + 8 * c;
         wa[q] = *reinterpret_cast<const float4*>(wr); wb[q] = *reinterpret_cast<const float4*>(wr + 4);
         if (!ok) { wa[q] = make_float4(0.f, 0.f, 0.f, 0.f); wb[q] = wa[q]; }
@@ -132,22 +142,31 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q == lane) mine = p[q];
     const int o = 8 * c + lane;
-    if (lane < 8 && o < nDense) {      // BaseLayer::forward of the output layer: y = f(x), f = settings nnOutputFunc (Approximator.cpp:228)
+    if constexpr (SPLIT == 4) { if (lane < 8 && o < nDense) sPart[part][o] = mine; }
+    else if (lane < 8 && o < nDense) {      // BaseLayer::forward of the output layer: y = f(x), f = settings nnOutputFunc (Approximator.cpp:228)
       const float x = mine + (c == 0 ? bo : ((c == 1 && mid) ? bo2 : a.params[a.indBo + o]));
-      sXo[wave][o] = x; sO[wave][o] = (double)(a.outFunc == HL_FUNC_LINEAR ? x : actEval(a.outFunc, x));
+      sXo[ws][o] = x; sO[ws][o] = (double)(a.outFunc == HL_FUNC_LINEAR ? x : actEval(a.outFunc, x));
     }
   }
-  if (lane < a.nSig) sO[wave][nDense + lane] = (double)bp;   // ParamLayer, Linear (absent for the discrete head)
+  const bool lead = SPLIT == 1 || part == 0;              // the wavefront that does the head of this sample
+  if constexpr (SPLIT == 4) {
+    __syncthreads();
+    if (lead) for (int o = lane; o < (isNext ? 1 : nDense); o += 64) {      // the four quarter sums in wave order, then the bias
+      const float x = ((sPart[0][o] + sPart[1][o]) + (sPart[2][o] + sPart[3][o])) + (o == lane ? bo : a.params[a.indBo + o]);
+      sXo[ws][o] = x; sO[ws][o] = (double)(a.outFunc == HL_FUNC_LINEAR ? x : actEval(a.outFunc, x));
+    }
+  }
+  if (lead && lane < a.nSig) sO[ws][nDense + lane] = (double)bp;   // ParamLayer, Linear (absent for the discrete head)
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
 
   if (isNext) {   // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
     const float oV = __shfl(misc, 6, 64), oA = __shfl(misc, 7, 64);
-    if (lane == 0) {
-      const float Vn = (float)scaleNet2V(sO[wave][0]);
+    if (lead && lane == 0) {
+      const float Vn = (float)scaleNet2V(sO[ws][0]);
       a.bt.oldNextV[b] = oV; a.bt.oldNextADV[b] = oA;
       a.rp.V[slot + 1] = Vn; a.rp.ADV[slot + 1] = 0.f; a.bt.nextV[b] = Vn;
-      a.bt.O[(size_t)row * a.nOut] = sO[wave][0];
+      a.bt.O[(size_t)row * a.nOut] = sO[ws][0];
     }
     return;
   }
@@ -156,6 +175,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   // ---- head: results shared by the write-back / back-propagation tail -------------------------------------
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
   double xRHO = 1, xDKL = 0, xV = 0, xdQ = 0, xAval = 0; bool xfar = false; double xg0 = 0;
+  if (lead) {
   if (a.nOpt) {
     // ---- discrete actions: Discrete_policy (Math/Discrete_policy.h:17-208, SoftPlus-normalised probabilities) and
     // Discrete_advantage (Math/Discrete_advantage.h:17-100); outputs [V | A x nOpt | logits x nOpt], one option per lane
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     auto spD = [](double x) { return (1 + x / sqrt(1 + x * x)) / 2; };
     const bool on = lane < nOpt;
     const int label = (int)floor(__shfl(act, 0, 64));                      // ActionInfo::actionMessage2label
-    const double logit = on ? sO[wave][pP + lane] : 0.0, advJ = on ? sO[wave][pA + lane] : 0.0;
+    const double logit = on ? sO[ws][pP + lane] : 0.0, advJ = on ? sO[ws][pA + lane] : 0.0;
     const double unnorm = on ? sp(logit) : 0.0;
     const double norm = fmax(waveSum(unnorm), 2.220446049250313e-16);
     const double pj = unnorm / norm, mj = on ? bMean : 1.0;                 // bMean carries mu_j for this head
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);
     const double expA = waveSum(on ? pj * advJ : 0.0);
     const double Aval = __shfl(advJ, label, 64) - expA;                     // computeAdvantage (:64-70)
-    const double O0 = sO[wave][0], V = scaleNet2V(O0);
+    const double O0 = sO[ws][0], V = scaleNet2V(O0);
     const double Qret = (double)__shfl(misc, 0, 64);
     const double A_RET = Qret - V, dQ = A_RET - Aval;
     const double g0 = far ? 0.0 : fmin(1.0, RHO) * dQ * beta * scaleVdiff(O0);
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       if (!far) { const double factor = A_RET * fmin(Cmax, RHO); pol = ((lane == label ? factor / unnorm : 0.0) - factor / norm) * dpos; }   // policyGradient (:136-144)
       const double gP = beta * pol + (1 - beta) * penal;                    // penalizeReFER + makeNetworkGrad
       const double gA = Qer * ((lane == label ? 1.0 : 0.0) - pj);           // Discrete_advantage::grad (:51-58)
-      sDelta[wave][pP + lane] = (float)gP; sDelta[wave][pA + lane] = (float)gA;
+      sDelta[ws][pP + lane] = (float)gP; sDelta[ws][pA + lane] = (float)gA;
       a.bt.G[(size_t)b * a.nOut + pP + lane] = (double)(float)gP;
       a.bt.G[(size_t)b * a.nOut + pA + lane] = (double)(float)gA;
     }
@@ -202,8 +222,8 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     if (lane < dA) {
       const int i = lane;
       bnd = a.bounded[i] != 0;
-      mean = sO[wave][pM + i];
-      const double pp = sO[wave][nDense + i];
+      mean = sO[ws][pM + i];
+      const double pp = sO[ws][nDense + i];
       const double rt = sqrt(1 + pp * pp);
       stdev = (pp + rt) / 2; invStd = 1 / stdev; dPos = (1 + pp / rt) / 2;
       const double bInv = 1 / bStd;
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
     const float Wf = (float)RHO, Cf = (float)Cmax, iCf = (float)Cinv;
     const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
-    const double O0 = sO[wave][0];
+    const double O0 = sO[ws][0];
     const double V = scaleNet2V(O0);
     const double Qret = (double)__shfl(misc, 0, 64);
     // Gaussian_advantage::computeAdvantage (Gaus_advantage.h:76-88): A = coef (exp(-1/2 sum (a-m)^2 / L) - ratio),
@@ -234,7 +254,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     if (nAdv) {
       double quadI = 0, rI = 1;
       if (lane < dA) {
-        p1 = sp(sO[wave][2 + lane]); p2 = sp(sO[wave][2 + dA + lane]);
+        p1 = sp(sO[ws][2 + lane]); p2 = sp(sO[ws][2 + dA + lane]);
         pm = bnd ? (mean > MAXM ? MAXM : (mean < -MAXM ? -MAXM : mean)) : mean;
         const double d = act - pm, S = stdev * stdev;
         quadI = d * d / (act > pm ? p1 : p2);
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       }
       double quad = 0;
       for (int i = 0; i < dA; ++i) { quad += __shfl(quadI, i, 64); advRatio *= __shfl(rI, i, 64); }
-      advCoef = sp(sO[wave][1]); advOrig = exp(-quad / 2);
+      advCoef = sp(sO[ws][1]); advOrig = exp(-quad / 2);
       Aval = advCoef * (advOrig - advRatio);
     }
     const double A_RET = Qret - V, dQ = A_RET - Aval;                // Zero_advantage: A = 0
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       const double gM = beta * polM + (1 - beta) * penalM;
       const double gS = beta * polS + (1 - beta) * penalS;
       // Activation::addOutputDelta: nnReal += Real (Activation.h:108-117)
-      sDelta[wave][pM + lane] = (float)gM;
+      sDelta[ws][pM + lane] = (float)gM;
       a.bt.gParam[(size_t)b * dA + lane] = (float)gS;
       a.bt.G[(size_t)b * a.nOut + pM + lane] = (double)(float)gM;
       a.bt.G[(size_t)b * a.nOut + nDense + lane] = (double)(float)gS;
@@ -285,15 +305,15 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
         const double q1 = p1 + S, q2 = p2 + S;
         g1 += F * expect * advCoef * (S / sqrt(p1 * (q1 * q1 * q1)) / 4);
         g2 += F * expect * advCoef * (S / sqrt(p2 * (q2 * q2 * q2)) / 4);
-        g1 *= Qer * spD(sO[wave][2 + lane]); g2 *= Qer * spD(sO[wave][2 + dA + lane]);          // grad_matrix (:69-74)
-        sDelta[wave][2 + lane] = (float)g1; sDelta[wave][2 + dA + lane] = (float)g2;
+        g1 *= Qer * spD(sO[ws][2 + lane]); g2 *= Qer * spD(sO[ws][2 + dA + lane]);          // grad_matrix (:69-74)
+        sDelta[ws][2 + lane] = (float)g1; sDelta[ws][2 + dA + lane] = (float)g2;
         a.bt.G[(size_t)b * a.nOut + 2 + lane] = (double)(float)g1;
         a.bt.G[(size_t)b * a.nOut + 2 + dA + lane] = (double)(float)g2;
       }
     }
     if (nAdv && lane == 0) {   // coefficient output of the Gaussian advantage
-      const double gc = (advOrig - advRatio) * (Qer * spD(sO[wave][1]));
-      sDelta[wave][1] = (float)gc; a.bt.G[(size_t)b * a.nOut + 1] = (double)(float)gc;
+      const double gc = (advOrig - advRatio) * (Qer * spD(sO[ws][1]));
+      sDelta[ws][1] = (float)gc; a.bt.G[(size_t)b * a.nOut + 1] = (double)(float)gc;
     }
     xRHO = RHO; xDKL = DKL; xV = V; xdQ = dQ; xAval = Aval; xfar = far; xg0 = g0;
   }
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     const float oDQ = __shfl(misc, 1, 64), oDKL = __shfl(misc, 2, 64), oW = __shfl(misc, 3, 64);
     const float oV = __shfl(misc, 4, 64), oADV = __shfl(misc, 5, 64);
     if (lane == 0) {
-      sDelta[wave][0] = (float)xg0;
+      sDelta[ws][0] = (float)xg0;
       a.bt.G[(size_t)b * a.nOut] = (double)(float)xg0;
       a.bt.rho[b] = xRHO; a.bt.dkl[b] = xDKL; a.bt.far[b] = xfar ? 1 : 0;
       // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
@@ -315,16 +335,18 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     }
   }
   HSTAMP(4);
-  for (int o = lane; o < a.nOut; o += 64) a.bt.O[(size_t)row * a.nOut + o] = sO[wave][o];
+  for (int o = lane; o < a.nOut; o += 64) a.bt.O[(size_t)row * a.nOut + o] = sO[ws][o];
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   // ---- deltas of the output layer and back-propagation into the last hidden block ----------------
   if (a.outFunc != HL_FUNC_LINEAR) {     // BaseLayer::backward: deltas *= f'(x, y) (Layer_Base.h:104-109)
-    for (int o = lane; o < nDense; o += 64) sDelta[wave][o] *= actDiff(a.outFunc, sXo[wave][o], (float)sO[wave][o]);
+    for (int o = lane; o < nDense; o += 64) sDelta[ws][o] *= actDiff(a.outFunc, sXo[ws][o], (float)sO[ws][o]);
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
   }
-  for (int o = lane; o < nDense; o += 64) a.dOut[(size_t)b * a.ldDo + o] = sDelta[wave][o];
+  for (int o = lane; o < nDense; o += 64) a.dOut[(size_t)b * a.ldDo + o] = sDelta[ws][o];
+  }      // (lead)
+  if constexpr (SPLIT == 4) __syncthreads();
   {
     float acc[HQ];
 #pragma unroll
@@ -341,14 +363,14 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       } else {
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
-          const int k = lane + 64 * q;
+          const int k = kBase + lane + 64 * q;
           const float* wr = Wo + (size_t)(k < H ? k : 0) * a.ldWo + 8 * c;
           wa[q] = *reinterpret_cast<const float4*>(wr); wb[q] = *reinterpret_cast<const float4*>(wr + 4);
         }
       }
       float d[8];
 #pragma unroll
-      for (int o = 0; o < 8; ++o) d[o] = 8 * c + o < nDense ? sDelta[wave][8 * c + o] : 0.f;
+      for (int o = 0; o < 8; ++o) d[o] = 8 * c + o < nDense ? sDelta[ws][8 * c + o] : 0.f;
 #pragma unroll
       for (int q = 0; q < HQ; ++q)
         acc[q] += ((wa[q].x * d[0] + wa[q].y * d[1]) + (wa[q].z * d[2] + wa[q].w * d[3])) +
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
     }
 #pragma unroll
     for (int q = 0; q < HQ; ++q) {
-      const int k = lane + 64 * q;
+      const int k = kBase + lane + 64 * q;
       if (k < H) {
         a.Dres[(size_t)b * a.ldD + k] = acc[q];
         a.D[(size_t)b * a.ldD + k] = acc[q] * actDiff(a.func, xl[q], yl[q]);
@@ -368,13 +390,20 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
 
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {
   ExtraArgs ex{}; if (extra) ex = *extra;
-  const dim3 grid((maxRows + 3) / 4 + (ex.role ? 1 + ex.helpers : 0)), block(256);
+  const int nEx = ex.role ? 1 + ex.helpers : 0;
+  const dim3 block(256);
+  if (a.H > 128) {       // one sample per workgroup, a quarter of the hidden units per wavefront
+    const dim3 grid(maxRows + nEx);
+    const int HQ = (a.H + 255) / 256;
+    if (HQ <= 1) hipLaunchKernelGGL((head_kernel_t<1, 4>), grid, block, 0, s, a, ex);
+    else if (HQ <= 2) hipLaunchKernelGGL((head_kernel_t<2, 4>), grid, block, 0, s, a, ex);
+    else return hipErrorInvalidValue;   // hidden width > 512: not supported by this kernel
+    return hipGetLastError();
+  }
+  const dim3 grid((maxRows + 3) / 4 + nEx);
   const int HQ = (a.H + 63) / 64;
-  if (HQ <= 1) hipLaunchKernelGGL(head_kernel_t<1>, grid, block, 0, s, a, ex);
-  else if (HQ <= 2) hipLaunchKernelGGL(head_kernel_t<2>, grid, block, 0, s, a, ex);
-  else if (HQ <= 4) hipLaunchKernelGGL(head_kernel_t<4>, grid, block, 0, s, a, ex);
-  else if (HQ <= 8) hipLaunchKernelGGL(head_kernel_t<8>, grid, block, 0, s, a, ex);
-  else return hipErrorInvalidValue;   // hidden width > 512: not supported by this kernel
+  if (HQ <= 1) hipLaunchKernelGGL((head_kernel_t<1, 1>), grid, block, 0, s, a, ex);
+  else hipLaunchKernelGGL((head_kernel_t<2, 1>), grid, block, 0, s, a, ex);
   return hipGetLastError();
 }
 
