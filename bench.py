@@ -115,7 +115,11 @@ def other_configs(api, steps=1000):
     res = {}
     for name, (kw, nEp, N, n) in cases.items():
         g = np.random.default_rng(5)
-        L = capi.Learner(api, capi.make_config(randSeed=7, **kw))
+        try:
+            L = capi.Learner(api, capi.make_config(randSeed=7, **kw))
+        except capi.HlError as e:
+            res[name] = {"error": str(e)}
+            continue
         L.init_weights()
         dS, dA = kw["dimS"], kw["dimA"]
         nopt = kw.get("n_options", 0)
