@@ -267,6 +267,9 @@ HL_API int hl_get_scaling(hl_learner* h, float* stateMean, float* stateScale, fl
 HL_API int hl_set_scaling(hl_learner* h, const float* stateMean, const float* stateScale, const float* rew3);
 HL_API int hl_get_episode_field(hl_learner* h, int64_t episode_pos, int32_t field, float* dst, int32_t cap);
 HL_API int hl_get_episode_info(hl_learner* h, int64_t episode_pos, int64_t* tag, int32_t* nsteps, int32_t* terminated);
+/* the episode's running aggregates (Episode.h:82-85, the members ERoldSeqFilter and the statistics pass read), in this order:
+ * totR, avgKLDivergence, fracFarPolSteps, avgSquaredErr, maxAbsError, sumSquaredQ, sumQ, maxQ, minQ */
+HL_API int hl_get_episode_stats(hl_learner* h, int64_t episode_pos, float* dst9);
 
 /* ---- training ---------------------------------------------------------------- */
 HL_API int hl_initialize(hl_learner* h);                  /* Learner::initializeLearner */

@@ -1288,6 +1288,13 @@ int ol_get_episode_info(ol_learner* h, int64_t pos, int64_t* tag, int32_t* nstep
   if (tag) *tag = EP.tag; if (nsteps) *nsteps = EP.N; if (term) *term = EP.term;
   return HL_OK;
 }
+int ol_get_episode_stats(ol_learner* h, int64_t pos, float* dst) {
+  if (!h || !dst || pos < 0 || pos >= (int64_t)h->episodes.size()) return HL_ERR_BAD_ARG;
+  const Episode& EP = *h->episodes[pos];
+  const float v[9] = {EP.totR, EP.avgKL, EP.fracFar, EP.avgSqErr, EP.maxAbsErr, EP.sumQ2, EP.sumQ, EP.maxQ, EP.minQ};
+  std::copy(v, v + 9, dst);
+  return HL_OK;
+}
 int ol_get_episode_field(ol_learner* h, int64_t pos, int32_t field, float* dst, int32_t cap) {
   if (!h || !dst || pos < 0 || pos >= (int64_t)h->episodes.size()) return HL_ERR_BAD_ARG;
   const Episode& EP = *h->episodes[pos];

@@ -173,6 +173,7 @@ class CApi:
             "get_scaling": (C.c_int, [P, pf, pf, pf]), "set_scaling": (C.c_int, [P, pf, pf, pf]),
             "get_episode_field": (C.c_int, [P, I64, I32, pf, I32]),
             "get_episode_info": (C.c_int, [P, I64, pi64, pi32, pi32]),
+            "get_episode_stats": (C.c_int, [P, I64, pf]),
             "initialize": (C.c_int, [P]),
             "step": (C.c_int, [P, I32, pi64]),
             "step_begin": (C.c_int, [P, pi64]),
@@ -328,6 +329,12 @@ class Learner:
         tag, n, term = C.c_int64(), C.c_int32(), C.c_int32()
         self._ck(self.api.fn("get_episode_info")(self.h, pos, C.byref(tag), C.byref(n), C.byref(term)))
         return tag.value, n.value, term.value
+
+    def episode_stats(self, pos):
+        """totR, avgKLDivergence, fracFarPolSteps, avgSquaredErr, maxAbsError, sumSquaredQ, sumQ, maxQ, minQ (Episode.h:82-85)"""
+        out = np.zeros(9, np.float32)
+        self._ck(self.api.fn("get_episode_stats")(self.h, pos, _ptr(out, C.c_float)))
+        return out
 
     def episode_field(self, pos, field):
         _, n, _ = self.episode_info(pos)

@@ -17,7 +17,7 @@ struct DevScalars {
   double maxAbsErrEMA;            // ReplayStats::maxAbsError
   long long nStep;                // AdamOptimizer::nStep (completed prepare_update calls)
   long long nGradSteps;
-  long long nFarTotal;            // running sum over the episodes currently stored (this replica)
+  long long nFarTotal;            // ReplayStats::nFarPolicySteps of this replica as of the last statistics pass (dev_common.h: farExact)
   long long nFarStat;             // ReplayStats::nFarPolicySteps: value of the last statistics pass
   long long nTransitions;         // ReplayCounters::nTransitions (this replica)
   long long nEpisodes;
@@ -81,6 +81,9 @@ struct DevReplay {
   long long* posPrefix;    // [nEp+1]
   struct PosRec* posRec;   // [nEp+1] the same table as one 32-byte record per position (sampler)
   float* stMean; float* stScale; float* stStd;   // [dS]
+  // the far-policy count (dev_common.h): fracFarPolSteps and nsteps per table position in the layout of the walk
+  // [nEpCap + 256 each], and the 256 segment starts of the last pass (first guess of the next one)
+  float* farP; float* farN; unsigned long long* farStart;
 };
 enum { AGG_TOTR = 0, AGG_AVGKL, AGG_FRACFAR, AGG_AVGSQERR, AGG_MAXABSERR, AGG_SUMQ2, AGG_SUMQ,
        AGG_MAXQ, AGG_MINQ, AGG_USED, AGG_LEN = 9 /* staging only: episode length */, AGG_N = 12 };

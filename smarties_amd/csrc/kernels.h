@@ -177,7 +177,7 @@ struct EpisodeSweepArgs {   // Retrace / updateCumulative over episodes
   const int* eids; int count;        // eids == nullptr: all current positions (count = nEpisodes)
   float gamma, lambda; int recompute; // recompute=1: Episode::updateCumulative first
   int skipRetrace;                   // 1: aggregates only (restart from a checkpoint keeps the stored estimates)
-  long long* redNFar; float* redMaxAbs;   // per-block partials (recompute only)
+  float* redMaxAbs;   // per-block partials (recompute only)
   int retKind;                       // HL_RET_*: computeRetrace / computeRetraceExplBonus / computeGAE (MemoryProcessing.cpp:391-416)
   double* redErr;                    // per-block sums of the squared changes of the estimates (recompute only: the dRet column)
 };
@@ -247,13 +247,13 @@ struct ActArgs {
 };
 hipError_t launch_act_forward(const ActArgs& a, int n, hipStream_t s);
 hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStream_t s);
-hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s);
+hipError_t launch_far_build(DevReplay rp, int nEpisodes, hipStream_t s);    // after the table or all fractions changed
+hipError_t launch_sweep_finish(DevScalars* sc, DevReplay rp, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s);
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);          // partial sums + final sum
 hipError_t launch_moments_apply(const MomentsArgs& a, hipStream_t s);    // EMA update of the scaling
 hipError_t launch_set_counts(DevScalars* sc, long long nTransitions, long long nEpisodes,
                              long long seenEps, long long seenSteps, hipStream_t s);
 hipError_t launch_episode_max(DevScalars* sc, DevReplay rp, int nEp, hipStream_t s);   // sc->maxAbsErrAll = max over the stored episodes
-hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s);
 hipError_t launch_stats(DevScalars* sc, DevReplay rp, int nEpisodes, double* out /*16 doubles*/, hipStream_t s);
 // prioritised samplers (per.hip): probabilities, ranking and the sequential normalisation / cumulative table
 struct PerArgs {

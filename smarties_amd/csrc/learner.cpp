@@ -111,7 +111,7 @@ struct hl_learner {
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
-  long long* dRedNFar = nullptr; float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
+  float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
   // replayed graphs: one per entry of GRAPH_SIZES and starting minibatch buffer (step_exec.h)
@@ -397,6 +397,7 @@ int growEpisodes(hl_learner* h, int need) {
   HIPCK(devGrow(&h->rp.epTag, o, n, h->stream));
   HIPCK(devGrow(&h->rp.posRec, o + 1, n + 1, h->stream));
   HIPCK(devGrow(&h->rp.posEid, o, n, h->stream)); HIPCK(devGrow(&h->rp.posPrefix, o + 1, n + 1, h->stream));
+  HIPCK(devGrow(&h->rp.farP, 0, n + 256, h->stream)); HIPCK(devGrow(&h->rp.farN, 0, n + 256, h->stream));
   h->capEps = newCap; h->graphsStale = true;
   return HL_OK;
 }
@@ -454,18 +455,19 @@ int runSweep(hl_learner* h, const int* dEids, int count, int recompute, int skip
   if (count <= 0) return HL_OK;
   const int nb = sweep_blocks(count);
   if (recompute && nb > h->redCap) {
-    HIPCK(devGrow(&h->dRedNFar, 0, (size_t)nb, h->stream)); HIPCK(devGrow(&h->dRedMax, 0, (size_t)nb, h->stream));
+    HIPCK(devGrow(&h->dRedMax, 0, (size_t)nb, h->stream));
     HIPCK(devGrow(&h->dRedErr, 0, (size_t)nb, h->stream));
     h->redCap = nb;
   }
   EpisodeSweepArgs a{}; a.sc = h->sc; a.rp = h->rp; a.eids = dEids; a.count = count;
   a.gamma = (float)h->cfg.gamma; a.lambda = (float)h->cfg.lambda; a.recompute = recompute; a.skipRetrace = skipRetrace;
-  a.redNFar = h->dRedNFar; a.redMaxAbs = h->dRedMax; a.redErr = h->dRedErr; a.retKind = h->cfg.returnsEstimator;
+  a.redMaxAbs = h->dRedMax; a.redErr = h->dRedErr; a.retKind = h->cfg.returnsEstimator;
   HIPCK(timed(h, recompute ? "episode_sweep_recompute" : "episode_sweep_retrace", h->stream,
               [&] { return launch_episode_sweep(a, nb, h->stream); }));
   // (a recompute sweep that also rewrites the estimates -- the 1000th-step pass over all episodes -- counts nsteps - 1 updates each)
   const bool rewrote = !skipRetrace && h->cfg.returnsEstimator != HL_RET_NONE;
-  if (recompute) HIPCK(launch_sweep_finish(h->sc, h->dRedNFar, h->dRedMax, h->dRedErr, rewrote ? (int)h->nTransitions : -1, nb, h->stream));
+  if (recompute) HIPCK(launch_far_build(h->rp, (int)h->order.size(), h->stream));
+  if (recompute) HIPCK(launch_sweep_finish(h->sc, h->rp, h->dRedMax, h->dRedErr, rewrote ? (int)h->nTransitions : -1, nb, h->stream));
   return HL_OK;
 }
 
@@ -510,6 +512,8 @@ int flushPending(hl_learner* h) {
     HIPCK(launch_set_counts(h->sc, h->nTransitions, (long long)h->order.size(), h->nSeenEps, h->nSeenSteps, h->stream));
     h->countsDirty = false;
   }
+  // the terms of the far-policy count are kept by table position (dev_common.h)
+  if (tableChanged && !h->order.empty()) HIPCK(launch_far_build(h->rp, (int)h->order.size(), h->stream));
   if (!h->pendingRetrace.empty()) {
     const int n = (int)h->pendingRetrace.size();
     if (n > h->eidListCap) { HIPCK(devGrow(&h->dEidList, 0, (size_t)n * 2, h->stream)); h->eidListCap = n * 2; }
@@ -707,6 +711,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(devAlloc(&h->dFlatGiven, B));
   HIPCK(devAlloc(&h->dMoments, (size_t)2 * h->dS + 3)); HIPCK(devAlloc(&h->dStatsOut, 16)); HIPCK(devAlloc(&h->dStatsIns, 16));
   HIPCK(devAlloc(&h->rp.stMean, h->dS)); HIPCK(devAlloc(&h->rp.stScale, h->dS)); HIPCK(devAlloc(&h->rp.stStd, h->dS));
+  HIPCK(devAlloc(&h->rp.farStart, 4 * 256));
   {   // ring slack: an eighth of the budget plus room for the episodes in flight (bounded in bytes for image-sized states)
     const long long slack = std::max<long long>(512, std::min<long long>(8192, (64ll << 20) / ((long long)h->dS * 4)));
     rc = growSlots(h, h->maxObsLocal + h->maxObsLocal / 8 + slack); if (rc) return rc;
@@ -749,10 +754,10 @@ int hl_destroy(hl_learner* h) {
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
   for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
-    h->dRedNFar, h->dRedMax, h->dRedErr, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
+    h->dRedMax, h->dRedErr, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
-    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->panelCtr, h->dActS, h->dActO};
+    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->rp.farP, h->rp.farN, h->rp.farStart, h->panelCtr, h->dActS, h->dActO};
   for (int pb = 0; pb < 2; ++pb) {
     DevBatch& bt = h->buf[pb].bt;
     void* bp[] = {h->buf[pb].X0, bt.sVals, bt.tag, bt.pEid, bt.pNextOf, bt.flat, bt.pos, bt.eid, bt.t, bt.slot, bt.nextOf, bt.nextSrc,
@@ -996,6 +1001,16 @@ int hl_get_episode_info(hl_learner* h, int64_t pos, int64_t* tag, int32_t* nstep
   if (tag) *tag = e.tag;
   if (nsteps) *nsteps = e.N;
   if (term) *term = e.term;
+  return HL_OK;
+}
+int hl_get_episode_stats(hl_learner* h, int64_t pos, float* dst) {
+  if (!h || !dst) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  if (pos < 0 || pos >= (int64_t)h->order.size()) return HL_ERR_BAD_ARG;
+  int rc = flushPending(h); if (rc) return rc;
+  static_assert(AGG_TOTR == 0 && AGG_MINQ == 8, "the nine aggregates lead the record in Episode.h's order");
+  HIPCK(hipMemcpyAsync(dst, h->rp.epAgg + (size_t)h->order[(size_t)pos].eid * AGG_N, 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
   return HL_OK;
 }
 int hl_get_episode_field(hl_learner* h, int64_t pos, int32_t field, float* dst, int32_t cap) {

@@ -44,13 +44,12 @@ __device__ __forceinline__ double rlD(double v, int l) {
 }
 
 __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) {
-  __shared__ long long sFar[4];
   __shared__ float sMax[4];
   __shared__ double sErr[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nWaves = gridDim.x * 4;
   const DevScalars* sc = a.sc;
-  long long myFar = 0; float myMax = 0.f; double myErr = 0;
+  float myMax = 0.f; double myErr = 0;
   // computeRetraceExplBonus (:402-408): coefficient 1 - gamma, baseline = ReplayStats::maxAbsError as it stands when the
   // sweep starts (createReturnEstimator captures it before this step's update, :431)
   const int kind = a.retKind;
@@ -93,7 +92,6 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
         ag[AGG_SUMQ2] = sumQ2; ag[AGG_SUMQ] = sumQ1; ag[AGG_MAXQ] = maxQ; ag[AGG_MINQ] = minQ;
         ag[AGG_TOTR] = (float)totR; ag[AGG_AVGKL] = invN * sumKL;
       }
-      myFar += farSteps((float)N, invN * (float)nFarPol);
       myMax = fmaxf(myMax, fmaxf(maxAE, 0.f));
     }
     if (a.skipRetrace || kind == HL_RET_NONE) continue;
@@ -143,10 +141,9 @@ __global__ __launch_bounds__(256) void episode_sweep_kernel(EpisodeSweepArgs a) 
     myErr += (double)epErr;
   }
   if (a.recompute) {
-    if (lane == 0) { sFar[wave] = myFar; sMax[wave] = myMax; sErr[wave] = myErr; }
+    if (lane == 0) { sMax[wave] = myMax; sErr[wave] = myErr; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      a.redNFar[blockIdx.x] = sFar[0] + sFar[1] + sFar[2] + sFar[3];
       a.redMaxAbs[blockIdx.x] = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
       a.redErr[blockIdx.x] = (sErr[0] + sErr[1]) + (sErr[2] + sErr[3]);
     }
@@ -159,20 +156,41 @@ hipError_t launch_episode_sweep(const EpisodeSweepArgs& a, int nBlocks, hipStrea
   return hipGetLastError();
 }
 // countRet >= 0: the sweep rewrote that many return estimates (MemoryProcessing.cpp:250-258); < 0: it did not touch them
-__global__ void sweep_finish_kernel(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, const double* redErr, int countRet, int n) {
-  if (blockIdx.x != 0) return;
-  long long f = 0; float m = 0.f; double er = 0;        // integer sum / max: any order gives the same result
-  for (int i = threadIdx.x; i < n; i += 64) { f += redNFar[i]; m = fmaxf(m, redMaxAbs[i]); er += redErr[i]; }
-  for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); m = fmaxf(m, __shfl_xor(m, o, 64)); er += __shfl_xor(er, o, 64); }
-  if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void sweep_finish_kernel(DevScalars* sc, DevReplay rp, const float* redMaxAbs, const double* redErr, int countRet, int n) {
+  __shared__ unsigned long long sScan[4]; __shared__ float sMax[4]; __shared__ double sErr[4];
+  const int tid = threadIdx.x;
+  float m = 0.f; double er = 0;
+  for (int i = tid; i < n; i += 256) { m = fmaxf(m, redMaxAbs[i]); er += redErr[i]; }
+  for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); er += __shfl_xor(er, o, 64); }
+  if ((tid & 63) == 0) { sMax[tid >> 6] = m; sErr[tid >> 6] = er; }
+  __syncthreads();
+  // the far-policy count as the reference's loop over the episodes accumulates it (dev_common.h; far_build_kernel ran before)
+  const int nEp = (int)sc->nEpisodes, per = (nEp + 255) / 256, cnt = farSegment(nEp, per);
+  const unsigned long long f = farFixedPoint([&](unsigned long long n0) { return farWalkMem<false>(rp.farP, rp.farN, cnt, n0); }, rp.farStart, sScan);
+  if (tid != 0) return;
+  m = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3])); er = (sErr[0] + sErr[1]) + (sErr[2] + sErr[3]);
   if (countRet >= 0) { sc->cntRetUpd = (sc->cntRetUpd < 0 ? 0 : sc->cntRetUpd) + countRet; sc->sumRetErr += er; }
-  sc->nFarTotal = sc->Cmax <= 1 ? 0 : f;
+  sc->nFarTotal = sc->Cmax <= 1 ? 0 : (long long)f;
   sc->maxAbsErrAll = m; sc->maxAbsErrStep = m;
   sc->nFarStat = sc->nFarTotal; sc->cnt[2] = sc->nFarStat; sc->cnt[3] = sc->nTransitions;
   sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1];
 }
-hipError_t launch_sweep_finish(DevScalars* sc, const long long* redNFar, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(64), 0, s, sc, redNFar, redMaxAbs, redErr, countRet, nBlocks);
+// the terms of the far-policy count in the walk's layout (dev_common.h), for the table and the fractions as they stand
+__global__ __launch_bounds__(256) void far_build_kernel(DevReplay rp, int nEp) {
+  const int per = (nEp + 255) / 256;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= per * 256) return;
+  const int t = pos / per, i = pos - t * per;
+  float f = 0.f, l = 0.f;
+  if (pos < nEp) { const int e = rp.posEid[pos]; l = (float)rp.epN[e]; f = rp.epAgg[(size_t)e * AGG_N + AGG_FRACFAR]; }
+  rp.farP[(size_t)i * 256 + t] = f; rp.farN[(size_t)i * 256 + t] = l;
+}
+hipError_t launch_far_build(DevReplay rp, int nEpisodes, hipStream_t s) {
+  hipLaunchKernelGGL(far_build_kernel, dim3((nEpisodes + 255) / 256 + 1), dim3(256), 0, s, rp, nEpisodes);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_finish(DevScalars* sc, DevReplay rp, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s) {
+  hipLaunchKernelGGL(sweep_finish_kernel, dim3(1), dim3(256), 0, s, sc, rp, redMaxAbs, redErr, countRet, nBlocks);
   return hipGetLastError();
 }
 
@@ -267,15 +285,6 @@ __global__ void set_counts_kernel(DevScalars* sc, long long nT, long long nE, lo
   sc->nTransitions = nT; sc->nEpisodes = nE; sc->cnt[0] = seenEps; sc->cnt[1] = seenSteps;
   sc->seenLocal[0] = seenEps; sc->seenLocal[1] = seenSteps;
   sc->cnt[3] = nT;   // cnt[2] keeps the far-policy count of the last statistics pass
-}
-// removal of an episode (MemoryBuffer::removeBackEpisode): its far-policy steps leave the total
-__global__ void evict_kernel(DevScalars* sc, DevReplay rp, int eid) {
-  const long long c = farSteps((float)rp.epN[eid], rp.epAgg[(size_t)eid * AGG_N + AGG_FRACFAR]);
-  sc->nFarTotal -= c; if (sc->nFarTotal < 0) sc->nFarTotal = 0;
-}
-hipError_t launch_evict(DevScalars* sc, DevReplay rp, int eid, hipStream_t s) {
-  hipLaunchKernelGGL(evict_kernel, dim3(1), dim3(1), 0, s, sc, rp, eid);
-  return hipGetLastError();
 }
 // max over the stored episodes of Episode::maxAbsError (one workgroup; after arrivals / removals)
 __global__ __launch_bounds__(256) void episode_max_kernel(DevScalars* sc, DevReplay rp, int nEp) {

@@ -451,7 +451,6 @@ int applyRemoval(hl_learner* h) {
   if (filter == HL_ER_OLDEST) {
     while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
       const EpMeta e = h->order.back();
-      HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
       h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
     }
   } else if (!h->order.empty() && h->nTransitions - 2 > h->maxObsLocal) {
@@ -469,7 +468,6 @@ int applyRemoval(hl_learner* h) {
       }
       const EpMeta e = h->order[v];
       if (h->nTransitions - (long long)e.N <= h->maxObsLocal) break;
-      HIPCK(launch_evict(h->sc, h->rp, e.eid, h->stream));
       h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.erase(h->order.begin() + (long)v); any = true;
     }
   }

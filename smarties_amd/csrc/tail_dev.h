@@ -28,8 +28,10 @@ namespace hl {
 // development time stamps (100 MHz constant clock), enabled with -DHL_TAIL_STAMPS
 #ifdef HL_TAIL_STAMPS
 #define TSTAMP(sc, i) do { if (threadIdx.x == 0) (sc)->dbgT[i] = wall_clock64(); } while (0)
+#define FAR_CYC(sc) ((sc)->dbgT + 10)
 #else
 #define TSTAMP(sc, i) do { } while (0)
+#define FAR_CYC(sc) nullptr
 #endif
 
 #define SMAXB 1024
@@ -52,7 +54,7 @@ __device__ __forceinline__ void encodeCounters(float* msg, const long long c4[4]
   for (int c = 0; c < 4; ++c) for (int q = 0; q < 4; ++q) msg[4 * c + q] = (float)((c4[c] >> (16 * q)) & 0xFFFF);
 }
 
-__device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs) {
+__device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs, float* sFarP = nullptr, int farLdsFloats = 0) {
   DevScalars* sc = a.sc;
   const int tid = threadIdx.x, B = a.B;
   // every scalar the pass needs, fetched once up front (uniform loads); thread 0 writes the
@@ -64,6 +66,17 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
   const float maxAll0 = (a.mode & POST_AGG) ? sc->maxAbsErrAll : sc->maxAbsErrStep;
   TSTAMP(sc, 16);
   if (tid == 0) { *sFarDelta = 0; *sMaxAbs = 0u; }
+  // the terms of the far-policy count (dev_common.h): this thread's segment, fetched now, used after the aggregates are updated
+  const int nEp = (int)sc->nEpisodes, farPer = (nEp + 255) / 256;
+  const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
+  float farT[FAR_REGS], farL[FAR_REGS];
+  unsigned long long farG0[FAR_SUB] = {};
+  if (farLds) {
+#pragma unroll
+    for (int c = 0; c < FAR_SUB; ++c) farG0[c] = a.rp.farStart[c * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < FAR_REGS; ++i) { farT[i] = i < farPer ? a.rp.farP[i * 256 + tid] : 0.f; farL[i] = i < farPer ? a.rp.farN[i * 256 + tid] : 0.f; }
+  }
   __syncthreads();
   TSTAMP(sc, 17);
   long long nFarStat = nFarStat0; float maxAll = maxAll0;
@@ -91,7 +104,12 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
         s0 = st[0]; s1 = st[1]; s2 = st[2];
       }
       const bool leader = in && ePrev != e;               // first sample of this episode's run
-      float myMaxAbs = 0.f; long long myFarDelta = 0;
+      float myMaxAbs = 0.f;
+      if (b0 == 0 && farLds) {          // the terms go through LDS so that the leaders below can patch other threads' segments
+#pragma unroll
+        for (int i = 0; i < FAR_REGS; ++i) if (i < farPer) sFarP[i * 256 + tid] = farT[i];
+        __syncthreads();
+      }
       if (leader) {
       float* ag = a.rp.epAgg + (size_t)e * AGG_N;
       float g[AGG_N]; float Nf;
@@ -104,7 +122,6 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
         for (int q = 0; q < AGG_N; ++q) g[q] = ag[q];
       }
       const float invN = 1 / Nf;
-      const long long before = farSteps(Nf, g[AGG_FRACFAR]);
       int j = b; bool more = true;
       float Qf = Q0, E = E0, D = D0, W = W0, Vf = V0, oW = oW0, oE = oE0, oD = oD0, oV = oV0, oA = oA0, Vn = Vn0, oNV = oNV0, oNA = oNA0;
       int nxt = nxt0;
@@ -131,33 +148,52 @@ __device__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMax
       }
 #pragma unroll
       for (int q = 0; q < AGG_N; ++q) ag[q] = g[q];
-      const long long after = farSteps(Nf, g[AGG_FRACFAR]);
-      myFarDelta = after - before;
+      if (farOn) {      // this episode's term, updated
+        const int pos = a.bt.pos[b], t = pos / farPer, idx = (pos - t * farPer) * 256 + t;
+        a.rp.farP[idx] = g[AGG_FRACFAR];
+        if (farLds) sFarP[idx] = g[AGG_FRACFAR];
+      }
       myMaxAbs = fmaxf(g[AGG_MAXABSERR], 0.f);
       }
       // one LDS atomic per wavefront instead of one per episode (same-address LDS atomics serialise)
-      for (int o = 32; o > 0; o >>= 1) {
-        myMaxAbs = fmaxf(myMaxAbs, __shfl_xor(myMaxAbs, o, 64));
-        myFarDelta += __shfl_xor(myFarDelta, o, 64);
-      }
-      if ((tid & 63) == 0) {
-        if (myFarDelta != 0) atomicAdd((unsigned long long*)sFarDelta, (unsigned long long)myFarDelta);
-        atomicMax(sMaxAbs, __float_as_uint(myMaxAbs));
-      }
+      for (int o = 32; o > 0; o >>= 1) myMaxAbs = fmaxf(myMaxAbs, __shfl_xor(myMaxAbs, o, 64));
+      if ((tid & 63) == 0) atomicMax(sMaxAbs, __float_as_uint(myMaxAbs));
     }
     TSTAMP(sc, 18);
     __syncthreads();
     TSTAMP(sc, 19);
+    unsigned long long* sScan = reinterpret_cast<unsigned long long*>(sFarDelta) + 2;
+    const int farCnt = farSegment(nEp, farPer);
+    const float* const gFarP = a.rp.farP; const float* const gFarN = a.rp.farN;     // (locals: a lambda capturing `a` would put the whole record on the stack)
+    unsigned long long* const gFarStart = a.rp.farStart;
+    long long farTotal;
+    if (farLds) {
+#pragma unroll
+      for (int i = 0; i < FAR_REGS; ++i) { const float v = sFarP[i * 256 + tid]; farT[i] = i < farPer ? v : 0.f; }     // (the reads stay inside the LDS block)
+      TSTAMP(sc, 22);
+#ifdef HL_TAIL_STAMPS
+      const long long cyc0 = clock64();
+#endif
+      unsigned long long tot = 0;
+      // a count or a term outside the range of the float recurrence: the emulated loop over the LDS copy
+      if (!farCountRegs(farT, farL, farG0, gFarStart, reinterpret_cast<unsigned*>(sScan), &tot, FAR_CYC(sc))) tot = farCountMem<false>(sFarP, gFarN, farCnt, gFarStart, sScan);
+#ifdef HL_TAIL_STAMPS
+      if (tid == 0) { sc->dbgT[12] = (long long)(tot >> 48); sc->dbgT[11] = clock64() - cyc0; }
+      tot &= 0xffffffffffffull;
+#endif
+      farTotal = (long long)tot;
+      TSTAMP(sc, 23);
+    } else {
+      __threadfence();
+      farTotal = (long long)farCountMem<true>(gFarP, gFarN, farCnt, gFarStart, sScan);
+    }
     if (tid == 0) {
-      long long nFarTot = nFarTot0 + *sFarDelta;
+      long long nFarTot = farTotal;
       maxAll = fmaxf(maxAll0, __uint_as_float(*sMaxAbs));
       // updateTrainingStatistics: ReF-ER clip annealing for the NEXT sampling (:193-196)
       const double Cm = 1 + a.clipImpWeight / (1 + (double)(nGrad0 + 1) * a.epsAnneal);
       if (Cm <= 1) nFarTot = 0;
-      // the reported count is unsigned in the reference (ReplayStats::nFarPolicySteps); the running total may dip
-      // below zero right after the start when clipImpWeight < 1 (MemoryBuffer.h:44 starts CinvRet at 1/C0 > 1, so
-      // never-sampled steps count as "were far") -- it stays exact, the statistic is clamped
-      nFarStat = nFarTot > 0 ? nFarTot : 0;
+      nFarStat = nFarTot;
       sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->maxAbsErrStep = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
       sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
       if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce
@@ -338,7 +374,7 @@ __device__ void drawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* raw
 // through std::discrete_distribution -- generate_canonical<double, 53> from two generator words, lower_bound over the
 // cumulative table -- and, for PERseq, a step drawn with uniform_real_distribution<float> (one more word) times the episode's
 // length.  No rejection: every value consumes its two (three) words in order.
-__device__ void drawPER(const SampleArgs& a, unsigned* x, unsigned* xo, int* sPos, unsigned* raw, unsigned* vals, int from, int B) {
+__device__ __forceinline__ void drawPER(const SampleArgs& a, unsigned* x, unsigned* xo, int* sPos, unsigned* raw, unsigned* vals, int from, int B) {
   const int tid = threadIdx.x, Wn = a.perAlgo == HL_SAMPLE_PERSEQ ? 3 : 2;
   for (int c0 = from; c0 < B; c0 += 256) {
     const int n = min(256, B - c0);
@@ -385,7 +421,7 @@ __device__ int sortUnique(unsigned* vals, int* sWave, int B, int Bp, int K) {
 // workgroup does not otherwise use)
 #define TAIL_LDS_BYTES (8 * SMAXB + 4 * (624 + 624 + SMAXB + SMAXB + SMAXB) + 64)
 
-__device__ void samplePhases(const SampleArgs& a, int phases, unsigned char* smem) {
+__device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, unsigned char* smem) {
   long long* sSlot = reinterpret_cast<long long*>(smem);            // [SMAXB]   (8-byte aligned first)
   unsigned* x = reinterpret_cast<unsigned*>(smem + 8 * SMAXB);      // [624]
   unsigned* xo = x + 624;                                           // [624]
@@ -585,10 +621,10 @@ __device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int 
   if (part == 0) TSTAMP(sc, 23);
 }
 
-__device__ void postPhase(const PostArgs& a, unsigned char* smem) {
-  long long* sFarDelta = reinterpret_cast<long long*>(smem);
+__device__ __forceinline__ void postPhase(const PostArgs& a, unsigned char* smem) {
+  long long* sFarDelta = reinterpret_cast<long long*>(smem);        // [0] unused, [1] max |error| bits, [2..5] scan scratch of farExact
   unsigned* sMaxAbs = reinterpret_cast<unsigned*>(smem + 8);
-  postPart(a, sFarDelta, sMaxAbs);
+  postPart(a, sFarDelta, sMaxAbs, reinterpret_cast<float*>(smem + 64), (TAIL_LDS_BYTES - 64) / 4);
 }
 
 // the extra workgroup of an MLP kernel: role 1 = sampler phases (for the NEXT step), 2 = bookkeeping

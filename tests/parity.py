@@ -79,6 +79,49 @@ def fx_vec_dev(fx, key, mine):
     return float(d)
 
 
+def _f32_to_u64_x86(x):
+    """float -> unsigned long as gcc compiles it for x86-64 (cvttss2si; out of range: the 'integer indefinite' value)"""
+    cvtt = lambda v: int(v) if -2.0 ** 63 <= v < 2.0 ** 63 else -2 ** 63
+    if x < 2.0 ** 63:
+        return cvtt(x) % 2 ** 64
+    return (cvtt(np.float32(x - np.float32(2.0 ** 63))) % 2 ** 64) ^ 2 ** 63
+
+
+def _fma_f32(a, b, c):
+    """a * b + c rounded once to float32 (the reference's statement compiles to vfmadd in the build the fixtures come from)"""
+    from fractions import Fraction
+    x = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    f = np.float32(float(x))
+    best = f
+    for g in (np.nextafter(f, np.float32(-np.inf)), np.nextafter(f, np.float32(np.inf))):
+        if not np.isfinite(g):
+            continue
+        dg, db = abs(Fraction(float(g)) - x), abs(Fraction(float(best)) - x)
+        if dg < db or (dg == db and (int(np.float32(g).view(np.uint32)) & 1) == 0):
+            best = g
+    return np.float32(best)
+
+
+def far_count_loop(L, tags_in_order):
+    """ReplayStats::nFarPolicySteps as MemoryProcessing.cpp:202-238 accumulates it -- `Uint += float * float` per episode, in the
+    given storage order -- over the fractions learner L holds."""
+    rec = {}
+    for p in range(L.scalars().nStoredEps):
+        tag, N, _ = L.episode_info(p)
+        rec[tag] = (np.float32(N), np.float32(L.episode_stats(p)[2]))
+    n = 0
+    for tag in tags_in_order:
+        N, f = rec[int(tag)]
+        n = _f32_to_u64_x86(_fma_f32(N, f, np.float32(n)))
+    if L.scalars().CmaxRet <= 1:
+        n = 0
+    return n - 2 ** 64 if n >= 2 ** 63 else n
+
+
+def storage_order(L):
+    return [L.episode_info(p)[0] for p in range(L.scalars().nStoredEps)]
+
+
 def flat_for(L, tags, ts):
     """flat indices (in the learner's own episode order) selecting the given (tag, t) pairs"""
     n = L.scalars().nStoredEps
