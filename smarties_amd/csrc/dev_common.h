@@ -115,7 +115,6 @@ template <bool COHERENT> __device__ __forceinline__ unsigned long long farWalkMe
 // sum seen and the final count tell whether that held.  A thread's segment is cut into FAR_SUB pieces walked side by side from
 // their own start values (four independent dependency chains: the walk is latency bound, one wavefront per SIMD), so the
 // fixed point runs over 4 x 256 pieces; DevReplay::farStart keeps the start of piece c of thread t at [c * 256 + t].
-constexpr int FAR_REGS = 24, FAR_SUB = 4, FAR_Q = FAR_REGS / FAR_SUB;
 __device__ __forceinline__ bool farWalkRegs(const float (&f)[FAR_REGS], const float (&l)[FAR_REGS], const unsigned (&n0)[FAR_SUB], unsigned (&n)[FAR_SUB]) {
   float nf[FAR_SUB], lo = 0.f;
 #pragma unroll

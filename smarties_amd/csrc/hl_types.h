@@ -63,6 +63,9 @@ struct PosRec {
   int eidTerm;             // eid | (terminated << 31)
 };
 
+// far-policy count (dev_common.h): episodes a thread of the bookkeeping rider keeps in registers, pieces its segment is walked in
+constexpr int FAR_REGS = 24, FAR_SUB = 4, FAR_Q = FAR_REGS / FAR_SUB;
+
 struct DevReplay {
   float* S;        // [cap][dS]      states (raw; standardized on gather, Episode.h:172-183)
   double* A;       // [cap][dA]      actions (f64 as in the reference, Episode.h:73)

@@ -397,7 +397,8 @@ int growEpisodes(hl_learner* h, int need) {
   HIPCK(devGrow(&h->rp.epTag, o, n, h->stream));
   HIPCK(devGrow(&h->rp.posRec, o + 1, n + 1, h->stream));
   HIPCK(devGrow(&h->rp.posEid, o, n, h->stream)); HIPCK(devGrow(&h->rp.posPrefix, o + 1, n + 1, h->stream));
-  HIPCK(devGrow(&h->rp.farP, 0, n + 256, h->stream)); HIPCK(devGrow(&h->rp.farN, 0, n + 256, h->stream));
+  const size_t nFar = std::max<size_t>(n + 256, (size_t)FAR_REGS * 256);      // (the register walk reads FAR_REGS rows of 256 whatever the table holds)
+  HIPCK(devGrow(&h->rp.farP, 0, nFar, h->stream)); HIPCK(devGrow(&h->rp.farN, 0, nFar, h->stream));
   h->capEps = newCap; h->graphsStale = true;
   return HL_OK;
 }

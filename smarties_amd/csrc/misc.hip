@@ -179,14 +179,18 @@ __global__ __launch_bounds__(256) void sweep_finish_kernel(DevScalars* sc, DevRe
 __global__ __launch_bounds__(256) void far_build_kernel(DevReplay rp, int nEp) {
   const int per = (nEp + 255) / 256;
   const int pos = blockIdx.x * 256 + threadIdx.x;
-  if (pos >= per * 256) return;
+  if (pos >= per * 256) {      // rows behind the table up to what the register walk reads (FAR_REGS per thread): zero terms
+    if (pos < FAR_REGS * 256) { rp.farP[pos] = 0.f; rp.farN[pos] = 0.f; }
+    return;
+  }
   const int t = pos / per, i = pos - t * per;
   float f = 0.f, l = 0.f;
   if (pos < nEp) { const int e = rp.posEid[pos]; l = (float)rp.epN[e]; f = rp.epAgg[(size_t)e * AGG_N + AGG_FRACFAR]; }
   rp.farP[(size_t)i * 256 + t] = f; rp.farN[(size_t)i * 256 + t] = l;
 }
 hipError_t launch_far_build(DevReplay rp, int nEpisodes, hipStream_t s) {
-  hipLaunchKernelGGL(far_build_kernel, dim3((nEpisodes + 255) / 256 + 1), dim3(256), 0, s, rp, nEpisodes);
+  const int nb = (nEpisodes + 255) / 256 + 1;
+  hipLaunchKernelGGL(far_build_kernel, dim3(nb > FAR_REGS ? nb : FAR_REGS), dim3(256), 0, s, rp, nEpisodes);
   return hipGetLastError();
 }
 hipError_t launch_sweep_finish(DevScalars* sc, DevReplay rp, const float* redMaxAbs, const double* redErr, int countRet, int nBlocks, hipStream_t s) {

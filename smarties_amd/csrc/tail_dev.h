@@ -62,12 +62,12 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   const double Cmax0 = sc->Cmax, Cinv0 = sc->Cinv, beta0 = sc->beta, alpha0 = sc->alpha;
   const double ema0 = sc->maxAbsErrEMA, bt1 = sc->adam_bt1, bt2 = sc->adam_bt2;
   const long long nGrad0 = sc->nGradSteps, nFarTot0 = sc->nFarTotal, nFarStat0 = sc->nFarStat;
-  const long long nTrans = sc->nTransitions, cnt2 = sc->cnt[2], cnt3 = sc->cnt[3], nStep0 = sc->nStep;
+  const long long nTrans = sc->nTransitions, cnt0 = sc->cnt[0], cnt1 = sc->cnt[1], cnt2 = sc->cnt[2], cnt3 = sc->cnt[3], nStep0 = sc->nStep, nEpL = sc->nEpisodes;
   const float maxAll0 = (a.mode & POST_AGG) ? sc->maxAbsErrAll : sc->maxAbsErrStep;
   TSTAMP(sc, 16);
   if (tid == 0) { *sFarDelta = 0; *sMaxAbs = 0u; }
   // the terms of the far-policy count (dev_common.h): this thread's segment, fetched now, used after the aggregates are updated
-  const int nEp = (int)sc->nEpisodes, farPer = (nEp + 255) / 256;
+  const int nEp = (int)nEpL, farPer = (nEp + 255) / 256;
   const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
   float farT[FAR_REGS], farL[FAR_REGS];
   unsigned long long farG0[FAR_SUB] = {};
@@ -75,9 +75,9 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
 #pragma unroll
     for (int c = 0; c < FAR_SUB; ++c) farG0[c] = a.rp.farStart[c * 256 + tid];
 #pragma unroll
-    for (int i = 0; i < FAR_REGS; ++i) { farT[i] = i < farPer ? a.rp.farP[i * 256 + tid] : 0.f; farL[i] = i < farPer ? a.rp.farN[i * 256 + tid] : 0.f; }
+    for (int i = 0; i < FAR_REGS; ++i) { farT[i] = a.rp.farP[i * 256 + tid]; farL[i] = a.rp.farN[i * 256 + tid]; }      // (zeros behind the table: far_build_kernel)
   }
-  __syncthreads();
+  if (!farLds) __syncthreads();       // (thread 0's initialisation above; with farLds the barrier in front of the leaders' work orders it)
   TSTAMP(sc, 17);
   long long nFarStat = nFarStat0; float maxAll = maxAll0;
   if (a.mode & POST_AGG) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       float myMaxAbs = 0.f;
       if (b0 == 0 && farLds) {          // the terms go through LDS so that the leaders below can patch other threads' segments
 #pragma unroll
-        for (int i = 0; i < FAR_REGS; ++i) if (i < farPer) sFarP[i * 256 + tid] = farT[i];
+        for (int i = 0; i < FAR_REGS; ++i) sFarP[i * 256 + tid] = farT[i];
         __syncthreads();
       }
       if (leader) {
@@ -169,7 +169,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
     long long farTotal;
     if (farLds) {
 #pragma unroll
-      for (int i = 0; i < FAR_REGS; ++i) { const float v = sFarP[i * 256 + tid]; farT[i] = i < farPer ? v : 0.f; }     // (the reads stay inside the LDS block)
+      for (int i = 0; i < FAR_REGS; ++i) farT[i] = sFarP[i * 256 + tid];
       TSTAMP(sc, 22);
 #ifdef HL_TAIL_STAMPS
       const long long cyc0 = clock64();
@@ -209,7 +209,8 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   }
   if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {
     // updateCounters (:46-92); with several replicas cnt[] holds the all-reduced counters
-    long long cntR[4] = {sc->cnt[0], sc->cnt[1], cnt2, cnt3};
+    const bool rewritten = (a.mode & POST_AGG) && a.nRanks > 1;      // (the bookkeeping part above put the local counters back)
+    long long cntR[4] = {rewritten ? sc->cnt[0] : cnt0, rewritten ? sc->cnt[1] : cnt1, cnt2, cnt3};
     if (a.cntMsg && (a.mode & POST_BETA)) {         // decode the summed chunks (each sum < 2^24: exact)
       for (int c = 0; c < 4; ++c) {
         long long v = 0;
