@@ -192,8 +192,8 @@ __device__ __forceinline__ bool farCountRegs(const float (&f)[FAR_REGS], const f
 #endif
   return true;
 }
-// the whole count over terms in memory, out of line (the rider kernels keep only the register walk inline)
-template <bool COHERENT> __device__ __noinline__ unsigned long long farCountMem(const float* F, const float* L, int cnt, unsigned long long* gStart, unsigned long long* sScan) {
+// the whole count over terms in memory
+template <bool COHERENT> __device__ __forceinline__ unsigned long long farCountMem(const float* F, const float* L, int cnt, unsigned long long* gStart, unsigned long long* sScan) {
   return farFixedPoint([F, L, cnt](unsigned long long n0) { return farWalkMem<COHERENT>(F, L, cnt, n0); }, gStart, sScan);
 }
 __device__ __forceinline__ int farSegment(int nEp, int per) { return min(per, max(0, nEp - (int)threadIdx.x * per)); }

@@ -117,7 +117,7 @@ __host__ __device__ inline int fusedR3Floats(int H) { const int a = H * 16, b = 
 __host__ __device__ inline size_t fusedLdsBytes(int dS, int H) {
   const int dSp = (dS + 3) & ~3;
   const size_t fl = (size_t)16 * FLDR + fusedR2Floats(dSp, H) + fusedR3Floats(H) + (size_t)H * 8 /*Wout*/ + 16 * FLDS +
-                    2048 /*red*/ + 3 * (size_t)H /*b0, wres, bres*/ + 512 /*sO*/ + 128 /*sDo*/ + 256 /*own tile scratch*/ + 32 /*bo, bp*/;
+                    2048 /*red*/ + 3 * (size_t)H /*b0, wres, bres*/ + 512 /*sO*/ + 128 /*sDo*/ + 256 /*own tile scratch*/ + 32 /*bo, bp*/ + 4 /*beta hand-off*/;
   const size_t bytes = fl * 4;
   return bytes > TAIL_LDS_BYTES ? bytes : TAIL_LDS_BYTES;
 }
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (blockIdx.x < 8) {
     if (threadIdx.x >= 256) return;            // the tail code is written for 256 threads
     // the sampler runs in block 0; with PH_PUBLISH its gather is spread over blocks 1..7
-    if (blockIdx.x == 0) { if (extra.role) runExtra(extra, smem); }
+    if (blockIdx.x == 0) { if (extra.role == 1) samplePhases(extra.samp, extra.phases, smem); }      // (the bookkeeping never rides here: its register needs exceed this kernel's 128)
+    else if (blockIdx.x == 1 && a.deferBeta) farBetaPhase(extra.post, smem);      // what the bookkeeping of the step before left over
     else if (extra.role == 1 && (extra.phases & PH_PUBLISH)) gatherHelper(extra.samp, blockIdx.x - 1, 7, smem);
     return;
   }
@@ -170,6 +171,9 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   constexpr int QS = 512 / NT;                   // state-tile elements per thread
 #if defined(HL_FSTAMPS)
   if (threadIdx.x == 0 && blockIdx.x == 8 + 8) a.sc->dbgT[31] = wall_clock64();   // (panel 0, tile 1): kernel entry
+#endif
+#ifdef HL_TAIL_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 8 + 8) a.sc->dbgT[31] = wall_clock64();
 #endif
   const DevScalars* sc = a.sc;
   const int dS = a.dS, dSp = (dS + 3) & ~3, B = a.B, dA = a.dA, nDense = a.nDense;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   float* sT = sDo + 128;                                       // [16][16] own-tile scratch (x1, later delta_y3)
   float* sBo = sT + 256;                                       // [16] output bias, [16] ParamLayer bias
   float* sBp = sBo + 16;
+  double* sBeta = reinterpret_cast<double*>(sBp + 16);          // [0] beta of this step, [1] != 0: it has arrived (deferBeta)
 
   const int tid = threadIdx.x, lane = tid & 63;
   __builtin_assume(tid >= 0 && tid < NT);      // lets the `tid + NT * q < count` guards of full chunks fold away
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   const float wrv = tid < H ? W[a.indWr + tid] : 0.f, brv = tid < H ? W[a.indBr + tid] : 0.f;
   const float b1e = eth ? W[a.indB1 + n0 + en] : 0.f;
   const float bov = tid < nDense ? W[a.indBo + tid] : 0.f, bpv = tid < dA ? W[a.indBp + tid] : 0.f;
-  const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
+  double beta = sc->beta; const double Cmax = sc->Cmax, Cinv = sc->Cinv;
+  const long long betaWant = sc->nGradSteps;      // (deferBeta: the rider in block 1 publishes beta under this number)
   // ---- stage: states, W0 (k-major), W1 column tile (k-major), Wout, vectors ------------------------
 #pragma unroll
   for (int q = 0; q < QS; ++q) { const int idx = tid + NT * q, r = idx >> 5, c = idx & 31; sS[r * FLDS + c] = sv[q]; }
@@ -415,6 +421,16 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
       if (++spins > (1 << 22)) { a.sc->errFlag = 77; break; }   // never hang the GPU on a lost workgroup
     }
   }
+  // beta of this step may still be on its way (POST_DEFER: the count it hangs off is taken by the rider in block 1 while the
+  // panels run): one look now, so that the load's latency is hidden behind the output contraction; the wait proper sits in
+  // front of the head
+  if (a.deferBeta && tid == 0) {
+    double got = 0; double ok = 0;
+    if (__hip_atomic_load(&a.sc->betaSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == betaWant) {
+      got = __hip_atomic_load(&a.sc->beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 1;
+    }
+    sBeta[0] = got; sBeta[1] = ok;
+  }
   __syncthreads();
 
   FSTAMP(7);
@@ -475,7 +491,19 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
       df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
     }
   }
+  if (a.deferBeta && tid == 0 && sBeta[1] == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(&a.sc->betaSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != betaWant) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { a.sc->errFlag = 79; break; }
+    }
+    sBeta[0] = __hip_atomic_load(&a.sc->beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
+  if (a.deferBeta) beta = sBeta[0];
+#ifdef HL_TAIL_STAMPS
+  if (tid == 0 && blockIdx.x == 8 + 8) { a.sc->dbgT[13] = wall_clock64(); a.sc->dbgT[3] = sBeta[1] != 0 ? 1 : 0; }      // beta in hand; was it there at the first look
+#endif
   FSTAMP(9);
   // network outputs of sample em stay in registers: lane en holds O[em][en] (dense part); the
   // ParamLayer part (Linear) is its bias

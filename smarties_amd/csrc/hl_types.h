@@ -45,6 +45,7 @@ struct DevScalars {
   // ReplayStats::sumReturnsEstimateErrors / countReturnsEstimateUpdates (MemoryProcessing.cpp:250-258): squared changes of the
   // return estimates in the 1000-step sweeps since the statistics line last printed them (hl_metrics resets; -1 = printed)
   double sumRetErr; long long cntRetUpd;
+  long long betaSeq;              // nGradSteps for which farBetaPhase has published beta / alpha (POST_DEFER)
   unsigned notifySeq;             // exact-size graphs replayed so far (their last node stores it into pinned host memory: hl_sync)
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
 };

@@ -31,6 +31,7 @@ struct SampleArgs {
   int computeEta;         // also derive DevScalars::etaEff[parity] (first step of a launch sequence)
   int perAlgo;            // HL_SAMPLE_*: the prioritised samplers draw through the cumulative table `perCp` (per.hip)
   const double* perCp; long long perN;   // cumulative probabilities of the perN transitions (PERrank, PERerr) or episodes (PERseq); perN < 2: always 0
+  int selfSearch;         // gather helpers (gatherHelper) run the index -> (episode, step) search themselves instead of waiting for the rider's hand-off
   int tagSeq;             // gather hand-off tag: 0 = nStep + 1 (nothing in the publishing kernel changes nStep), 1 = sampleSeq (the dW kernel:
                           // its bookkeeping rider advances nStep while the sampler's phase C and the gather helpers run)
   int noGather;           // phase C stops after the index -> (episode, step) search: the states are gathered by
@@ -127,7 +128,9 @@ struct PostArgs {
   float* cntMsg;                     // != nullptr: the four replica counters travel inside the gradient message (16 floats, four
                                      // 16-bit chunks each: exact in fp32 for up to 256 replicas) instead of a collective of their own
 };
-enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4, POST_ENCODE = 8 /* write the counters message only */ };
+enum { POST_AGG = 1, POST_BETA = 2, POST_INIT = 4, POST_ENCODE = 8 /* write the counters message only */,
+       POST_DEFER = 16 /* with POST_AGG | POST_BETA: leave the far-policy count and the beta / alpha update that hangs off it to
+                          farBetaPhase -- a rider of the NEXT step's fused kernel, whose heads wait for it (tail_dev.h) */ };
 
 struct AdamArgs {
   const DevScalars* sc; float* W; float* M1; float* M2; const float* G; long long n;
@@ -167,6 +170,7 @@ struct FusedArgs {
   float* dOut; int ldDo;                  // output-layer deltas [B][ldDo]
   unsigned* panelCtr;                     // [panels][32] arrive counters of the panel barrier (monotonic)
   int variant;                            // development: stop after phase `variant` (0 = run everything)
+  int deferBeta;                          // 1: beta of this step is still being computed by the rider in block 1 (POST_DEFER): the heads wait for DevScalars::betaSeq
   int xcdSafe;                            // 1: the workgroups of a panel may sit on different XCDs (probe at hl_create): the panel exchange
                                           // goes through agent-scope stores / loads instead of plain ones through the shared L2
   unsigned long long boundedMask;         // bit i: action component i is bounded (dA <= 7 here)

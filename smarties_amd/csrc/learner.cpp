@@ -111,6 +111,8 @@ struct hl_learner {
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
+  bool helperHandOff = false;           // SMARTIES_HIP_HELPER_HANDOFF=1: the gather helpers of the dW launch wait for the rider's search (development)
+  bool noDeferBeta = false;             // SMARTIES_HIP_NO_DEFER_BETA=1: the whole bookkeeping stays in the dW launch (development)
   float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
@@ -686,6 +688,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       for (int b = 8; b < nBlk; ++b) same = same && xcc[(size_t)b] == xcc[(size_t)(8 + ((b - 8) & 7))];
       const char* f = getenv("SMARTIES_HIP_PANEL_SAFE");
       h->xcdSafe = !same || (f && f[0] == '1');
+      { const char* nd = getenv("SMARTIES_HIP_NO_DEFER_BETA"); h->noDeferBeta = nd && nd[0] == '1'; }
+      { const char* nd = getenv("SMARTIES_HIP_HELPER_HANDOFF"); h->helperHandOff = nd && nd[0] == '1'; }
       const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
       HIPCK(devAlloc(&h->panelCtr, nCtr));
       HIPCK(hipMemset(h->panelCtr, 0, nCtr * sizeof(unsigned)));

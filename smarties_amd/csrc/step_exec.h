@@ -268,11 +268,13 @@ FusedArgs fusedArgs(hl_learner* h, int parity) {
 }
 // forward + head + dX of the whole minibatch as one kernel (fused.hip); `nextSample`: sampler phases
 // A and B of the NEXT step ride along
-int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = false) {
-  const FusedArgs fa = fusedArgs(h, parity);
+// `deferBeta`: the step before ran its bookkeeping with POST_DEFER: block 1 finishes it (farBetaPhase), the heads wait for beta
+int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool deferBeta = false) {
+  FusedArgs fa = fusedArgs(h, parity);
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
   // (draws, sort, redraws of the next minibatch here; its search and gather ride along the dW kernel: launchWeightGrad)
   if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
+  if (deferBeta) { fa.deferBeta = 1; ex.post = postArgs(h, parity ^ 1, POST_BETA); pex = &ex; }
   HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
   return HL_OK;
 }
@@ -361,7 +363,7 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
   if (nextSampleC) exC = extraSample(h, parity ^ 1, PH_C);
   if (sb.dwCount <= DW_TABLE_MAX) {   // problem table in the kernel arguments
     const DwTable& tbl = fuseAdam ? sb.dwTableAdam : sb.dwTable;
-    if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; }
+    if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; exC.samp.selfSearch = h->helperHandOff ? 0 : 1; }
     HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s, nextSampleC ? &exC : nullptr); }));
     return HL_OK;
   }
@@ -606,8 +608,14 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   for (int j = 0; j < U && !rc; ++j) {
     const int p = (p0 + j) & 1;
     if (h->fusedOk) {
-      rc = launchFused(h, p, s0, true); if (rc) break;
-      if (!exchanging(h)) { rc = launchWeightGrad(h, p, true, s0, true, true); if (rc) break; continue; }
+      // one replica: the far-policy count and the beta update of every step but the last are taken out of the dW launch's
+      // bookkeeping rider, where they sat at the end of the kernel's longest workgroup, into a rider of the next fused kernel
+      const bool single = !exchanging(h) && !h->noDeferBeta;
+      rc = launchFused(h, p, s0, true, single && j > 0); if (rc) break;
+      if (!exchanging(h)) {
+        rc = launchWeightGrad(h, p, true, s0, true, true, POST_AGG | POST_BETA | (single && j + 1 < U ? POST_DEFER : 0)); if (rc) break;
+        continue;
+      }
       // replicas: the exchange is part of the replayed graph (RCCL calls are captured like kernels).  ONE collective per
       // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (four exact 16-bit
       // chunks each), the pass after Adam decodes their sums.

@@ -28,9 +28,11 @@ namespace hl {
 // development time stamps (100 MHz constant clock), enabled with -DHL_TAIL_STAMPS
 #ifdef HL_TAIL_STAMPS
 #define TSTAMP(sc, i) do { if (threadIdx.x == 0) (sc)->dbgT[i] = wall_clock64(); } while (0)
-#define FAR_CYC(sc) ((sc)->dbgT + 10)
+#define PSTAMP(sc, i) do { if (threadIdx.x == 0 && (a.mode & POST_DEFER)) (sc)->dbgT[i] = wall_clock64(); } while (0)      // (the steps inside a call, not its last)
+#define FAR_CYC(sc) nullptr
 #else
 #define TSTAMP(sc, i) do { } while (0)
+#define PSTAMP(sc, i) do { } while (0)
 #define FAR_CYC(sc) nullptr
 #endif
 
@@ -54,6 +56,21 @@ __device__ __forceinline__ void encodeCounters(float* msg, const long long c4[4]
   for (int c = 0; c < 4; ++c) for (int q = 0; q < 4; ++q) msg[4 * c + q] = (float)((c4[c] >> (16 * q)) & 0xFFFF);
 }
 
+// MemoryProcessing::updateCounters, the penalisation coefficients (:80-92); coherent: the stores are agent-scope atomics (read
+// by workgroups of the same kernel on other XCDs)
+__device__ __forceinline__ void refEerPenal(DevScalars* sc, double fracOffPol, double learnRefer, double penalTol, double beta0, double alpha0, bool coherent) {
+  const bool dec = fracOffPol > penalTol;
+  const double beta = dec ? (1 - fmin(learnRefer, beta0)) * beta0
+                          : (1 - fmin(learnRefer, beta0)) * beta0 + fmin(learnRefer, 1 - beta0);
+  const bool decA = fabs(penalTol - fracOffPol) < 1e-3;
+  const double alpha = decA ? (1 - fmin(learnRefer, alpha0)) * alpha0
+                            : (1 - fmin(learnRefer, alpha0)) * alpha0 + fmin(learnRefer, 1 - alpha0);
+  if (coherent) {
+    __hip_atomic_store(&sc->beta, beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sc->alpha, alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else { sc->beta = beta; sc->alpha = alpha; }
+}
+
 __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs, float* sFarP = nullptr, int farLdsFloats = 0) {
   DevScalars* sc = a.sc;
   const int tid = threadIdx.x, B = a.B;
@@ -64,11 +81,12 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   const long long nGrad0 = sc->nGradSteps, nFarTot0 = sc->nFarTotal, nFarStat0 = sc->nFarStat;
   const long long nTrans = sc->nTransitions, cnt0 = sc->cnt[0], cnt1 = sc->cnt[1], cnt2 = sc->cnt[2], cnt3 = sc->cnt[3], nStep0 = sc->nStep, nEpL = sc->nEpisodes;
   const float maxAll0 = (a.mode & POST_AGG) ? sc->maxAbsErrAll : sc->maxAbsErrStep;
-  TSTAMP(sc, 16);
+  PSTAMP(sc, 16);
   if (tid == 0) { *sFarDelta = 0; *sMaxAbs = 0u; }
   // the terms of the far-policy count (dev_common.h): this thread's segment, fetched now, used after the aggregates are updated
   const int nEp = (int)nEpL, farPer = (nEp + 255) / 256;
-  const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
+  const bool defer = (a.mode & POST_DEFER) != 0;      // the count itself is taken by farBetaPhase: only the fractions are patched here
+  const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && !defer && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
   float farT[FAR_REGS], farL[FAR_REGS];
   unsigned long long farG0[FAR_SUB] = {};
   if (farLds) {
@@ -78,7 +96,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
     for (int i = 0; i < FAR_REGS; ++i) { farT[i] = a.rp.farP[i * 256 + tid]; farL[i] = a.rp.farN[i * 256 + tid]; }      // (zeros behind the table: far_build_kernel)
   }
   if (!farLds) __syncthreads();       // (thread 0's initialisation above; with farLds the barrier in front of the leaders' work orders it)
-  TSTAMP(sc, 17);
+  PSTAMP(sc, 17);
   long long nFarStat = nFarStat0; float maxAll = maxAll0;
   if (a.mode & POST_AGG) {
     const float C = (float)Cmax0, invC = (float)Cinv0;
@@ -159,18 +177,19 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       for (int o = 32; o > 0; o >>= 1) myMaxAbs = fmaxf(myMaxAbs, __shfl_xor(myMaxAbs, o, 64));
       if ((tid & 63) == 0) atomicMax(sMaxAbs, __float_as_uint(myMaxAbs));
     }
-    TSTAMP(sc, 18);
+    PSTAMP(sc, 18);
     __syncthreads();
-    TSTAMP(sc, 19);
+    PSTAMP(sc, 19);
     unsigned long long* sScan = reinterpret_cast<unsigned long long*>(sFarDelta) + 2;
     const int farCnt = farSegment(nEp, farPer);
     const float* const gFarP = a.rp.farP; const float* const gFarN = a.rp.farN;     // (locals: a lambda capturing `a` would put the whole record on the stack)
     unsigned long long* const gFarStart = a.rp.farStart;
-    long long farTotal;
-    if (farLds) {
+    long long farTotal = nFarTot0;
+    if (defer) {
+    } else if (farLds) {
 #pragma unroll
       for (int i = 0; i < FAR_REGS; ++i) farT[i] = sFarP[i * 256 + tid];
-      TSTAMP(sc, 22);
+      TSTAMP(sc, 14);
 #ifdef HL_TAIL_STAMPS
       const long long cyc0 = clock64();
 #endif
@@ -182,7 +201,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       tot &= 0xffffffffffffull;
 #endif
       farTotal = (long long)tot;
-      TSTAMP(sc, 23);
+      TSTAMP(sc, 15);
     } else {
       __threadfence();
       farTotal = (long long)farCountMem<true>(gFarP, gFarN, farCnt, gFarStart, sScan);
@@ -194,8 +213,8 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       const double Cm = 1 + a.clipImpWeight / (1 + (double)(nGrad0 + 1) * a.epsAnneal);
       if (Cm <= 1) nFarTot = 0;
       nFarStat = nFarTot;
-      sc->nFarTotal = nFarTot; sc->maxAbsErrAll = maxAll; sc->maxAbsErrStep = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm;
-      sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; sc->cnt[3] = nTrans;
+      sc->maxAbsErrAll = maxAll; sc->maxAbsErrStep = maxAll; sc->Cmax = Cm; sc->Cinv = 1 / Cm; sc->cnt[3] = nTrans;
+      if (!defer) { sc->nFarTotal = nFarTot; sc->nFarStat = nFarStat; sc->cnt[2] = nFarStat; }
       if (a.nRanks > 1) { sc->cnt[0] = sc->seenLocal[0]; sc->cnt[1] = sc->seenLocal[1]; }   // undo the last all-reduce
       if (a.cntMsg) {       // counters ride in the tail of the gradient buffer: one all-reduce per step instead of two
         const long long c4[4] = {sc->seenLocal[0], sc->seenLocal[1], nFarStat, nTrans};
@@ -224,12 +243,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
     const double fracOffPol = (double)nFar / (double)(nStored > 1 ? nStored : 1);
     const double nDataSize = fmax(a.maxObsGlobal, (double)nStored);
     const double learnRefer = 0.1 * a.batchGlobal / nDataSize;
-    const bool dec = fracOffPol > a.penalTol;
-    sc->beta = dec ? (1 - fmin(learnRefer, beta0)) * beta0
-                   : (1 - fmin(learnRefer, beta0)) * beta0 + fmin(learnRefer, 1 - beta0);
-    const bool decA = fabs(a.penalTol - fracOffPol) < 1e-3;
-    sc->alpha = decA ? (1 - fmin(learnRefer, alpha0)) * alpha0
-                     : (1 - fmin(learnRefer, alpha0)) * alpha0 + fmin(learnRefer, 1 - alpha0);
+    if (!defer) refEerPenal(sc, fracOffPol, learnRefer, a.penalTol, beta0, alpha0, false);
     if (a.mode & POST_BETA) {
       // stats.maxAbsError EMA (:239-240) uses the replica-local data size
       const double lrLoc = 0.1 * a.batchGlobal / fmax(a.maxObsGlobal, (double)nTrans);
@@ -243,7 +257,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       sc->etaEff[a.parity ^ 1] = adamEtaEff(nStep0 + 1, nb1, nb2, a.eta0, a.epsAnneal);
     }
   }
-  TSTAMP(sc, 20);
+  PSTAMP(sc, 20);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,6 +436,22 @@ __device__ int sortUnique(unsigned* vals, int* sWave, int B, int Bp, int K) {
 // workgroup does not otherwise use)
 #define TAIL_LDS_BYTES (8 * SMAXB + 4 * (624 + 624 + SMAXB + SMAXB + SMAXB) + 64)
 
+// IDtoSeqStep for one flat index: interpolation guess into the per-position table, then binary search (Sampling.cpp:26-47)
+__device__ __forceinline__ PosRec findPosition(const DevReplay& rp, long long f, int nEp, unsigned long long nData, int* pos) {
+  int k0 = (int)(((double)f * (double)nEp) / (double)nData);
+  k0 = min(max(k0, 0), nEp - 1);
+  PosRec rec = rp.posRec[k0];
+  const long long p1 = rp.posRec[k0 + 1].prefix;
+  int lo = k0;
+  if (f < rec.prefix || f >= p1) {
+    int l = f < rec.prefix ? 0 : k0 + 1, hgh = f < rec.prefix ? k0 : nEp;   // largest k in [l,hgh): prefix[k] <= f
+    while (hgh - l > 1) { const int mid = (l + hgh) >> 1; if (rp.posRec[mid].prefix <= f) l = mid; else hgh = mid; }
+    lo = l; rec = rp.posRec[lo];
+  }
+  *pos = lo;
+  return rec;
+}
+
 __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, unsigned char* smem) {
   long long* sSlot = reinterpret_cast<long long*>(smem);            // [SMAXB]   (8-byte aligned first)
   unsigned* x = reinterpret_cast<unsigned*>(smem + 8 * SMAXB);      // [624]
@@ -488,16 +518,8 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
     hasNext[r] = false;
     if (b < B) {
       const long long f = (long long)vals[b];
-      int k0 = (int)(((double)f * (double)nEp) / (double)nData);
-      k0 = min(max(k0, 0), nEp - 1);
-      PosRec rec = a.rp.posRec[k0];
-      const long long p1 = a.rp.posRec[k0 + 1].prefix;
-      int lo = k0;
-      if (f < rec.prefix || f >= p1) {
-        int l = f < rec.prefix ? 0 : k0 + 1, hgh = f < rec.prefix ? k0 : nEp;   // largest k in [l,hgh): prefix[k] <= f
-        while (hgh - l > 1) { const int mid = (l + hgh) >> 1; if (a.rp.posRec[mid].prefix <= f) l = mid; else hgh = mid; }
-        lo = l; rec = a.rp.posRec[lo];
-      }
+      int lo;
+      const PosRec rec = findPosition(a.rp, f, nEp, nData, &lo);
       const int t = (int)(f - rec.prefix);
       const int e = rec.eidTerm & 0x7fffffff;
       const bool term = rec.eidTerm < 0;
@@ -579,6 +601,61 @@ __device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int 
   DevScalars* sc = a.sc;
   if (part == 0) TSTAMP(sc, 21);
   for (int i = tid; i < dS; i += 256) { sMean[i] = a.rp.stMean[i]; sScale[i] = a.rp.stScale[i]; }
+  if (a.selfSearch) {
+    // No hand-off: every helper runs the search over the sorted indices itself (the rider's copy of it feeds the bookkeeping
+    // arrays meanwhile) -- its publication (stores, their acknowledgement, the flag, the helpers' coherent re-reads: 2 us) was
+    // the longest chain of the dW launch.  Same table, same scan: the same slots and next-state rows as the rider finds.
+    long long* sSlot = reinterpret_cast<long long*>(smem + 8 * (SMAXB / 2));       // [SMAXB]  (behind mean | scale)
+    int* sNextRow = reinterpret_cast<int*>(sSlot + SMAXB);                         // [SMAXB]
+    int* sWave = sNextRow + SMAXB;                                                 // [4]
+    const unsigned long long nData = (unsigned long long)sc->nTransitions;
+    const int nEp = (int)sc->nEpisodes;
+    int Bp = 256; while (Bp < B) Bp <<= 1;
+    const int K = Bp / 256;
+    bool hasNext[SMAXK]; int nextIdx[SMAXK];
+    for (int r = 0; r < K; ++r) {
+      const int b = r * 256 + tid;
+      hasNext[r] = false;
+      if (b < B) {
+        const long long f = (long long)a.bt.sVals[b];
+        int lo;
+        const PosRec rec = findPosition(a.rp, f, nEp, nData, &lo);
+        const int t = (int)(f - rec.prefix);
+        sSlot[b] = rec.off + t;
+        hasNext[r] = (t + 2 == rec.N && !(rec.eidTerm < 0));
+      }
+    }
+    scanRows(K, hasNext, nextIdx, sWave);
+    for (int r = 0; r < K; ++r) { const int b = r * 256 + tid; if (b < B) sNextRow[b] = hasNext[r] ? B + nextIdx[r] : -1; }
+    __syncthreads();
+    if (part == 0) TSTAMP(sc, 22);
+    const int per = (B + nParts - 1) / nParts, b0 = part * per, b1 = min(B, b0 + per);
+    const int total = max(0, b1 - b0) * dS;
+    constexpr int GU = 4;
+    for (int e0 = tid; e0 < total; e0 += 256 * GU) {
+      float sv[GU], sn[GU]; int bb[GU], ii[GU], nr[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int e = e0 + 256 * u;
+        bb[u] = -1; sv[u] = 0.f; sn[u] = 0.f; ii[u] = 0; nr[u] = -1;
+        if (e < total) {
+          const int b = b0 + e / dS; bb[u] = b; ii[u] = e - (b - b0) * dS;
+          const long long sl = sSlot[b];
+          sv[u] = a.rp.S[(size_t)sl * dS + ii[u]];
+          nr[u] = sNextRow[b];
+          if (nr[u] >= 0) sn[u] = a.rp.S[(size_t)(sl + 1) * dS + ii[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) if (bb[u] >= 0) {
+        const float mu = sMean[ii[u]], scl = sScale[ii[u]];
+        a.X0[(size_t)bb[u] * a.ldX0 + ii[u]] = (sv[u] - mu) * scl;
+        if (nr[u] >= 0) a.X0[(size_t)nr[u] * a.ldX0 + ii[u]] = (sn[u] - mu) * scl;
+      }
+    }
+    if (part == 0) TSTAMP(sc, 23);
+    return;
+  }
   if (tid == 0) {
     const long long want = a.tagSeq ? -sc->sampleSeq : sc->nStep + 1;       // (negative: never equal to a tag of the other kind)
     int spins = 0;
@@ -626,6 +703,45 @@ __device__ __forceinline__ void postPhase(const PostArgs& a, unsigned char* smem
   long long* sFarDelta = reinterpret_cast<long long*>(smem);        // [0] unused, [1] max |error| bits, [2..5] scan scratch of farExact
   unsigned* sMaxAbs = reinterpret_cast<unsigned*>(smem + 8);
   postPart(a, sFarDelta, sMaxAbs, reinterpret_cast<float*>(smem + 64), (TAIL_LDS_BYTES - 64) / 4);
+}
+
+// What a POST_DEFER bookkeeping pass left over, as a rider (block 1) of the NEXT step's fused kernel: the far-policy count over
+// the fractions that pass patched (dev_common.h) and the beta / alpha update that needs it.  The heads of this kernel read
+// beta late (fused.hip): they wait for betaSeq, published here with agent-scope stores (the first acknowledged before the second
+// is issued; no cache-wide release, which costs tens of microseconds).  256 threads.
+__device__ __forceinline__ void farBetaPhase(const PostArgs& a, unsigned char* smem) {
+  DevScalars* sc = a.sc;
+  const int tid = threadIdx.x;
+  TSTAMP(sc, 10);
+  const double Cmax = sc->Cmax, beta0 = sc->beta, alpha0 = sc->alpha;
+  const long long nTrans = sc->nTransitions, nEpL = sc->nEpisodes, nGrad = sc->nGradSteps;
+  const int nEp = (int)nEpL, per = (nEp + 255) / 256;
+  unsigned long long* sScan = reinterpret_cast<unsigned long long*>(smem);
+  const float* const gFarP = a.rp.farP; const float* const gFarN = a.rp.farN; unsigned long long* const gFarStart = a.rp.farStart;
+  unsigned long long tot = 0;
+  bool done = false;
+  if (per <= FAR_REGS) {
+    float f[FAR_REGS], l[FAR_REGS]; unsigned long long g0[FAR_SUB];
+#pragma unroll
+    for (int c = 0; c < FAR_SUB; ++c) g0[c] = gFarStart[c * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < FAR_REGS; ++i) { f[i] = gFarP[i * 256 + tid]; l[i] = gFarN[i * 256 + tid]; }
+    done = farCountRegs(f, l, g0, gFarStart, reinterpret_cast<unsigned*>(sScan), &tot);
+#ifdef HL_TAIL_STAMPS
+    tot &= 0xffffffffffffull;
+#endif
+  }
+  if (!done) tot = farCountMem<false>(gFarP, gFarN, farSegment(nEp, per), gFarStart, sScan);
+  TSTAMP(sc, 11);
+  if (tid != 0) return;
+  const long long nFar = Cmax <= 1 ? 0 : (long long)tot;
+  sc->nFarTotal = nFar; sc->nFarStat = nFar; sc->cnt[2] = nFar;
+  const double fracOffPol = (double)nFar / (double)(nTrans > 1 ? nTrans : 1);
+  const double learnRefer = 0.1 * a.batchGlobal / fmax(a.maxObsGlobal, (double)nTrans);
+  refEerPenal(sc, fracOffPol, learnRefer, a.penalTol, beta0, alpha0, true);
+  __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): beta and alpha are in memory
+  __hip_atomic_store(&sc->betaSeq, nGrad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  TSTAMP(sc, 12);
 }
 
 // the extra workgroup of an MLP kernel: role 1 = sampler phases (for the NEXT step), 2 = bookkeeping
