@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the us/step of the other BASELINE configurations")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (counter-collection runs, which stall under their graph replays)")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the repeated call and the 2000-step sustained rate after the timed region (counter-collection runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -369,15 +371,15 @@ def main():
         dom = max(table, key=lambda n: table[n]["launch_us"])
         d = table[dom]
         # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process;
-        # the committed rocprofv3 --pmc passes (profiles/r02_pmc.json: commands, corrections) are quoted
+        # the committed rocprofv3 --pmc passes (profiles/r03_pmc.json: commands, corrections) are quoted
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
                 traffic = json.load(f)["kernels"][dom.split("<")[0]]["traffic_bytes"]
         except Exception:  # noqa: BLE001
             traffic = None
         roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r02_pmc.json)",
+                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r03_pmc.json)",
                 "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
                 "step_kernels": table,
                 "note": "latency-bound step: dependent launches of a few hundred workgroups; launch_us = HIP-event time "
@@ -425,12 +427,12 @@ def main():
     # diagnostics, after the timed region and outside `value`: the same call once more (what a first call pays on top: page walks,
     # first launch of the call's graph, clocks) and the sustained rate over 2000 steps
     diag = {}
-    if n_ranks == 1:
+    if n_ranks == 1 and not args.no_diagnostics:
         t1 = time.perf_counter(); run(args.steps); barrier(); diag["same_call_again_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
         run(400); barrier()
         t1 = time.perf_counter(); run(2000); barrier(); diag["sustained_ms_per_step_2000_steps"] = (time.perf_counter() - t1) / 2000 * 1e3
 
-    if rank == 0 and roof is None:
+    if rank == 0 and roof is None and not args.no_roofline:
         roof = roofline(L)
 
     out = None

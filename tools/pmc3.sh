@@ -3,7 +3,7 @@
 OUT=/root/repo/gpurun_out/pmc3
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  SMARTIES_HIP_NO_GRAPH=1 timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o r -- python /root/repo/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-other-configs > $OUT/$C.log 2>&1
+  SMARTIES_HIP_NO_GRAPH=1 timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o r -- python /root/repo/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-other-configs --no-diagnostics --no-roofline > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 python3 - <<'PY'
