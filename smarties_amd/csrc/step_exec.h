@@ -346,6 +346,8 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
       const long long fl = 2LL * h->B * h->dS;
       ex.helpers = (int)std::min<long long>(31, fl / 1024);
       if (ex.helpers > 0) ex.phases |= PH_PUBLISH;
+      // (the sorted indices of a dense net's next minibatch were left by phase B in an earlier launch: the helpers search them themselves)
+      if (ex.helpers > 0 && !h->recurrent && !h->helperHandOff) ex.samp.selfSearch = 1;
     }
   }
   HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
@@ -375,7 +377,12 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
 int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
-  ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+  ExtraArgs ex{}, exF{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pexF = nullptr;
+  // one replica, bookkeeping riding the first dX launch: its far-policy count and the beta update move on to the dW launch (the next
+  // reader of beta is the head kernel of the step after), off what was that launch's longest workgroup
+  if (fusePost && postMode == (POST_AGG | POST_BETA) && !sb.dxIdx.empty() && !h->noDeferBeta) {
+    postMode |= POST_DEFER; exF.role = 3; exF.post = postArgs(h, parity, POST_BETA); pexF = &exF;
+  }
   if (fusePost) { ex.role = 2; ex.post = postArgs(h, parity, postMode); pex = &ex; }
   char nm[32];
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
@@ -400,7 +407,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.
   const ExtraArgs* pexW = sb.dxIdx.empty() ? pex : nullptr;
   HIPCK(timed(h, "gemm16_dw", s, [&] {
-    return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s); }));
+    return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s, pexF); }));
   if (sb.splitMaxMN > 0)
     HIPCK(timed(h, "splitk_reduce", s, [&] {
       return launch_splitk_reduce(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.splitMaxMN, h->sc, hyp, s); }));

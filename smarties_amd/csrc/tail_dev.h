@@ -744,10 +744,11 @@ __device__ __forceinline__ void farBetaPhase(const PostArgs& a, unsigned char* s
   TSTAMP(sc, 12);
 }
 
-// the extra workgroup of an MLP kernel: role 1 = sampler phases (for the NEXT step), 2 = bookkeeping
+// the extra workgroup of an MLP kernel: role 1 = sampler phases (for the NEXT step), 2 = bookkeeping, 3 = far-policy count + beta
 __device__ __forceinline__ void runExtra(const ExtraArgs& ex, unsigned char* smem) {
   if (ex.role == 1) samplePhases(ex.samp, ex.phases, smem);
   else if (ex.role == 2) postPhase(ex.post, smem);
+  else if (ex.role == 3) farBetaPhase(ex.post, smem);      // what a POST_DEFER bookkeeping pass of an earlier launch of this step left over
 }
 
 }  // namespace hl

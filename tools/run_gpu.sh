@@ -8,7 +8,7 @@ timeout 1200 python -m pytest tests -m gpu -q --maxfail=5 2>&1 | grep -v "^  \|^
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > $OUT/bench_default.log 2>&1; grep "^{" $OUT/bench_default.log > $OUT/bench_default.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o r -- python /root/repo/bench.py --steps $STEPS --warmup 200 --no-cpu-baseline --no-other-configs > $OUT/bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o r -- python /root/repo/bench.py --steps $STEPS --warmup 200 --no-cpu-baseline --no-other-configs --no-diagnostics > $OUT/bench.log 2>&1
 grep "^{" $OUT/bench.log > $OUT/bench_rocprof.json
 rm -f $OUT/r_kernel_trace.csv
 python3 - <<PY
