@@ -74,7 +74,7 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
 // FL >= 0: the flavor (and with it the epilogue kind) is known at compile time and the development
 // ablation switches are compiled out -- the operand loads then form one straight-line batch instead
 // of a chain of branches with a wait at every join
-template <int ROLE, int FL = -1>
+template <int ROLE, int FL = -1, bool RAW = false>      // RAW: `tile` is tm * tilesN + tn as given (the caller placed its workgroups itself)
 __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* __restrict__ sc,
                                          const AdamHyper& hyp, int nRowsDyn) {
   const int flavor = FL >= 0 ? FL : P.flavor;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   // then share their A row-panels, and each L2 fetches 1/8 of A instead of all of it.
   {
     const int nT = P.tilesM * P.tilesN;
-    if ((nT & 7) == 0 && !(variant & 16) && !((variant >> 5) & (1 << ROLE))) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
+    if (!RAW && (nT & 7) == 0 && !(variant & 16) && !((variant >> 5) & (1 << ROLE))) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
   }
 
   const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
@@ -278,6 +278,58 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
   const GemmProblem P = probs[p];
   gemmTile<ROLE>(P, bid - P.tileStart, smem, sc, hyp, nRowsDyn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// All dense forward layers of a network off the fused path in ONE launch (round 3; before: one launch of ~7 us per layer,
+// of which the kernel boundary is 4-5).  Work is placed as in fused.hip: a 16-row panel of the minibatch belongs to a group
+// of HT workgroups (HT = column tiles of the widest layer) on blockIdx = const (mod 8), i.e. on one XCD sharing one L2
+// (checked by hl_create's probe; otherwise the per-layer launches stay).  Layer by layer every workgroup computes its
+// column tile of the panel with the common tile code, then the group meets at a counter barrier (plain stores acknowledged
+// by the L2 before the arrival, bounded spin) -- a layer needs all columns of the one before, of ITS panel only.
+// Blocks 0..7: riders (so that the panels keep blockIdx % 8 = XCD).
+// ---------------------------------------------------------------------------------------------------------------
+struct ChainArgs { int n; int idx[HL_MAX_HIDDEN]; int HT; unsigned* panelCtr; };
+__global__ __launch_bounds__(256) void fwd_chain_kernel(const GemmProblem* __restrict__ probs, ChainArgs ch, const DevScalars* __restrict__ sc, AdamHyper hyp,
+                                                        ExtraArgs extra, ExtraArgs extra2) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
+  if (blockIdx.x < 8) {
+    if (blockIdx.x == 0 && extra.role) runExtra(extra, smem);
+    else if (blockIdx.x == 1 && extra2.role) runExtra(extra2, smem);
+    return;
+  }
+  const int bid = blockIdx.x - 8, xcd = bid & 7, gi = bid >> 3;
+  const int HT = ch.HT, panel = (gi / HT) * 8 + xcd, n = gi % HT;
+  const int nRowsDyn = sc->nRows[hyp.parity];
+  if (panel * 16 >= nRowsDyn) return;                    // (the whole group of a panel leaves together)
+  for (int l = 0; l < ch.n; ++l) {
+    const GemmProblem P = probs[ch.idx[l]];
+    if (n < P.tilesN) gemmTile<GEMM_ROLE_FWD, -1, true>(P, panel * P.tilesN + n, smem, sc, hyp, nRowsDyn);
+    if (l + 1 == ch.n) break;
+    __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0): this tile's stores are acknowledged by the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned* ctr = ch.panelCtr + panel * 32;
+      const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (old / (unsigned)HT + 1u) * (unsigned)HT;
+      int spins = 0;
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { const_cast<DevScalars*>(sc)->errFlag = 80; break; }   // never hang the GPU on a lost workgroup
+      }
+    }
+    __syncthreads();
+  }
+}
+size_t fwd_chain_lds_bytes() { return GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES; }
+int fwd_chain_blocks(int maxRows, int HT) { const int panels = (maxRows + 15) / 16, pg = (panels + 7) / 8; return 8 + 8 * HT * pg; }
+hipError_t launch_fwd_chain(const GemmProblem* dProbs, const int* idx, int nLayers, int HT, int maxRows, unsigned* panelCtr, const DevScalars* sc,
+                            const AdamHyper& hyp, const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s) {
+  ChainArgs ch{}; ch.n = nLayers; ch.HT = HT; ch.panelCtr = panelCtr;
+  for (int l = 0; l < nLayers; ++l) ch.idx[l] = idx[l];
+  ExtraArgs ex{}, ex2{}; if (extra) ex = *extra; if (extra2) ex2 = *extra2;
+  hipLaunchKernelGGL(fwd_chain_kernel, dim3(fwd_chain_blocks(maxRows, HT)), dim3(256), 0, s, dProbs, ch, sc, hyp, ex, ex2);
+  return hipGetLastError();
 }
 
 // the weight-gradient launch of the fused path: the problem table travels in the kernel arguments

@@ -226,6 +226,11 @@ constexpr int INGEST_MAX_EP = 1024;
 hipError_t launch_ingest(const IngestArgs& a, hipStream_t s);
 // forward / dX tile with the whole reduction in flight at once (gemm16.hip: gemm_os_kernel), 256 < K <= 640
 bool gemm_oneshot_ok(int flavor, int K);
+// all dense forward layers in one launch (gemm16.hip: fwd_chain_kernel)
+size_t fwd_chain_lds_bytes();
+int fwd_chain_blocks(int maxRows, int HT);
+hipError_t launch_fwd_chain(const GemmProblem* dProbs, const int* idx, int nLayers, int HT, int maxRows, unsigned* panelCtr, const DevScalars* sc,
+                            const AdamHyper& hyp, const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);
 hipError_t launch_gemm_oneshot(int role, const GemmProblem* dProb, int K, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
 struct TouchArgs { const void* ptr[24]; long long bytes[24]; int stride[24]; int n; float* sink; };
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)

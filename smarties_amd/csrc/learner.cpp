@@ -111,6 +111,7 @@ struct hl_learner {
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
+  bool chainOk = false; int chainHT = 0;  // the dense forward layers of a network off the fused path go out as one launch (gemm16.hip: fwd_chain_kernel)
   bool helperHandOff = false;           // SMARTIES_HIP_HELPER_HANDOFF=1: the gather helpers of the dW launch wait for the rider's search (development)
   bool noDeferBeta = false;             // SMARTIES_HIP_NO_DEFER_BETA=1: the whole bookkeeping stays in the dW launch (development)
   float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
@@ -688,12 +689,37 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       for (int b = 8; b < nBlk; ++b) same = same && xcc[(size_t)b] == xcc[(size_t)(8 + ((b - 8) & 7))];
       const char* f = getenv("SMARTIES_HIP_PANEL_SAFE");
       h->xcdSafe = !same || (f && f[0] == '1');
-      { const char* nd = getenv("SMARTIES_HIP_NO_DEFER_BETA"); h->noDeferBeta = nd && nd[0] == '1'; }
-      { const char* nd = getenv("SMARTIES_HIP_HELPER_HANDOFF"); h->helperHandOff = nd && nd[0] == '1'; }
       const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
       HIPCK(devAlloc(&h->panelCtr, nCtr));
       HIPCK(hipMemset(h->panelCtr, 0, nCtr * sizeof(unsigned)));
       HIPCK(hipStreamSynchronize(nullptr));
+    }
+  }
+  { const char* nd = getenv("SMARTIES_HIP_NO_DEFER_BETA"); h->noDeferBeta = nd && nd[0] == '1'; }
+  { const char* nd = getenv("SMARTIES_HIP_HELPER_HANDOFF"); h->helperHandOff = nd && nd[0] == '1'; }
+  // networks off the fused path with two or more dense layers (short reductions): one forward launch if the groups of its
+  // panels run where the kernel assumes (same probe as above, with that kernel's geometry)
+  if (!h->fusedOk && !h->recurrent) {
+    const int j0 = h->nConv > 0 ? 1 : 0;
+    const char* nc = getenv("SMARTIES_HIP_NO_FWD_CHAIN");
+    bool ok = h->nHidden - j0 >= 2 && !(nc && nc[0] == '1');
+    int HT = 0;
+    for (int j = j0; j < h->nHidden; ++j) { ok = ok && !gemm_oneshot_ok(GEMM_F, h->hid[j].nIn); HT = std::max(HT, (h->hid[j].size + 15) / 16); }
+    if (ok) {
+      const int nBlk = fwd_chain_blocks(h->Mmax, HT);
+      int* dX = nullptr; HIPCK(devAlloc(&dX, (size_t)nBlk));
+      HIPCK(launch_xcc_probe(nBlk, 256, fwd_chain_lds_bytes(), dX, h->stream));
+      std::vector<int> xcc((size_t)nBlk);
+      HIPCK(hipMemcpyAsync(xcc.data(), dX, xcc.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCK(hipStreamSynchronize(h->stream)); hipFree(dX);
+      for (int b = 8; b < nBlk; ++b) ok = ok && xcc[(size_t)b] == xcc[(size_t)(8 + ((b - 8) & 7))];
+      const char* f = getenv("SMARTIES_HIP_PANEL_SAFE");
+      ok = ok && !(f && f[0] == '1');
+    }
+    if (ok) {
+      const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
+      HIPCK(devAlloc(&h->panelCtr, nCtr));
+      h->chainOk = true; h->chainHT = HT;
     }
   }
   h->ldDo = (int)roundUp(h->nDense, 16);

@@ -319,6 +319,14 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
     }
   }
+  if (h->chainOk) {      // every dense layer in one launch, sampler phases A and B of the next step riding along
+    ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+    if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
+    int idx[HL_MAX_HIDDEN];
+    for (int j = j0; j < h->nHidden; ++j) idx[j - j0] = sb.fwdIdx[j];
+    HIPCK(timed(h, "fwd_chain", s, [&] { return launch_fwd_chain(h->dProbs, idx, h->nHidden - j0, h->chainHT, h->Mmax, h->panelCtr, h->sc, hyp, pex, nullptr, s); }));
+    return HL_OK;
+  }
   for (int j = j0; j < h->nHidden; ++j) {
     snprintf(nm, sizeof(nm), "gemm16_fwd%d", j);
     ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
