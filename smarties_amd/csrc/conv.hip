@@ -521,15 +521,16 @@ hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s) {
 // dW: partial filter gradients per (layer, 16 x 16 tile of [KnC][K], chunk of the batch x positions reduction)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CONV_DW_MAXROWS = 2048;      // rows of one chunk (LDS tables)
-__global__ __launch_bounds__(256) void conv_dw_kernel(ConvArgs a) {
-  __shared__ long long sIn[CONV_DW_MAXROWS];      // offset of the patch origin of row r in the input array
-  __shared__ int sD[CONV_DW_MAXROWS];             // b * ldOut + p
-  __shared__ float red[4 * 256];
+constexpr size_t CONV_DW_LDS = (size_t)CONV_DW_MAXROWS * 12 + 4 * 256 * 4;
+__device__ __forceinline__ void convDwBody(const ConvArgs& a, int bx, unsigned char* smem) {
+  long long* sIn = reinterpret_cast<long long*>(smem);                       // [MAXROWS] offset of the patch origin of row r in the input array
+  int* sD = reinterpret_cast<int*>(smem + (size_t)CONV_DW_MAXROWS * 8);      // [MAXROWS] b * ldOut + p
+  float* red = reinterpret_cast<float*>(smem + (size_t)CONV_DW_MAXROWS * 12);  // [4][256]
   int l = 0;
-  for (int i = 1; i < a.nL; ++i) if ((int)blockIdx.x >= a.L[i].dwBlock0) l = i;
+  for (int i = 1; i < a.nL; ++i) if (bx >= a.L[i].dwBlock0) l = i;
   const ConvGeo g = a.L[l];
   const int K = g.K, P = g.P, tilesK = (K + 15) / 16, tilesC = (g.KnC + 15) / 16;
-  const int local = blockIdx.x - g.dwBlock0;
+  const int local = bx - g.dwBlock0;
   const int chunk = local / (tilesK * tilesC), tile = local - chunk * tilesK * tilesC;
   const int ct = tile / tilesK, kt = tile - ct * tilesK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
@@ -576,8 +577,12 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(ConvArgs a) {
   const int oc = ct * 16 + (tid >> 4), okk = kt * 16 + (tid & 15);
   if (oc < g.KnC && okk < K) g.part[(size_t)chunk * g.KnC * K + (size_t)oc * K + okk] = v;
 }
+__global__ __launch_bounds__(256) void conv_dw_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  convDwBody(a, (int)blockIdx.x, smem);
+}
 hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s) {
-  hipLaunchKernelGGL(conv_dw_kernel, dim3(totalBlocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(conv_dw_kernel, dim3(totalBlocks), dim3(256), CONV_DW_LDS, s, a);
   return hipGetLastError();
 }
 
@@ -700,10 +705,9 @@ bool conv_rows_ok(const ConvGeo& g) { return g.K == 256 && g.KnY == 8 && g.KnX =
 
 // filter gradient of such a layer: partial [KnC][K] of (sample b, row block rb) -> part[(b nRB + rb)][c][k]
 template <int CT>
-__global__ __launch_bounds__(256) void conv_dw_rows_kernel(ConvArgs a, int l) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void convDwRowsBody(const ConvArgs& a, int l, int rb, int b, unsigned char* smem) {
   const ConvGeo g = a.L[l];
-  const int b = blockIdx.y, rb = blockIdx.x, RB = g.rbRows, WR = g.rbWin, P = g.P, K = g.K;
+  const int RB = g.rbRows, WR = g.rbWin, P = g.P, K = g.K;
   const int oy0 = rb * RB, nOy = min(RB, g.OpY - oy0), iy0 = oy0 * g.S, wrValid = min(WR, g.InY - iy0);
   const int nPos = nOy * g.OpX, nPos4 = (nPos + 3) & ~3, ldD = RB * g.OpX + 4;
   float* sIn = reinterpret_cast<float*>(smem);                       // [InC][WR][InX]
@@ -754,6 +758,20 @@ __global__ __launch_bounds__(256) void conv_dw_rows_kernel(ConvArgs a, int l) {
       }
     }
   }
+}
+template <int CT>
+__global__ __launch_bounds__(256) void conv_dw_rows_kernel(ConvArgs a, int l) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  convDwRowsBody<CT>(a, l, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+// both filter-gradient launches as one (they depend on the deltas only): the first nRowBlocks workgroups take (sample, row block)
+// pairs of layer l, the others the (layer, tile, chunk) problems of conv_dw_kernel
+template <int CT>
+__global__ __launch_bounds__(256) void conv_dw_all_kernel(ConvArgs a, int l, int nRowBlocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bx = (int)blockIdx.x;
+  if (bx < nRowBlocks) { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); }
+  else convDwBody(a, bx - nRowBlocks, smem);
 }
 static size_t convRowsDwLds(const ConvGeo& g) {
   const int ct = (g.KnC + 15) / 16, ldD = g.rbRows * g.OpX + 4;
@@ -827,6 +845,20 @@ hipError_t launch_conv_reduce_adam(const ConvArgs& a, const AdamHyper& hyp, int 
   long long n = 0;
   for (int l = 0; l < a.nL; ++l) n += (long long)a.L[l].KnC * a.L[l].K;
   hipLaunchKernelGGL(conv_reduce_adam_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, a, hyp, fuseAdam);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_dw_all(const ConvArgs& a, int l, int dwBlocks, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  size_t lds = convRowsDwLds(g); if (lds < CONV_DW_LDS) lds = CONV_DW_LDS;
+  const int ct = (g.KnC + 15) / 16, nRowBlocks = g.rbCount * a.B;
+  if (ct == 1) {
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_all_kernel<1>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_dw_all_kernel<1>, dim3(nRowBlocks + dwBlocks), dim3(256), lds, s, a, l, nRowBlocks);
+  } else if (ct == 2) {
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_all_kernel<2>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_dw_all_kernel<2>, dim3(nRowBlocks + dwBlocks), dim3(256), lds, s, a, l, nRowBlocks);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -113,6 +113,7 @@ hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);
 int conv_row_block(const ConvGeo& g, int* win);
 bool conv_rows_ok(const ConvGeo& g);                                          // the shape the row-block kernels are instantiated for                               // rows per workgroup of the row-block kernels (0: layer not served)
 hipError_t launch_conv_forward_rows(const ConvArgs& a, int l, int maxRows, hipStream_t s);
+hipError_t launch_conv_dw_all(const ConvArgs& a, int l, int dwBlocks, hipStream_t s);      // launch_conv_dw_rows(l) and launch_conv_dw as one launch
 hipError_t launch_conv_dw_rows(const ConvArgs& a, int l, hipStream_t s);
 hipError_t launch_conv_reduce_adam(const ConvArgs& a, const AdamHyper& hyp, int fuseAdam, hipStream_t s);
 

@@ -407,8 +407,14 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
       snprintf(nm, sizeof(nm), "conv_dx%d", l);
       HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s); }));
     }
+    int nRb = 0, lRb = -1;
+    for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) { ++nRb; lRb = l; }
+    if (nRb == 1 && h->convDwBlocks > 0) {      // the two filter-gradient launches depend on the deltas only: one launch
+      HIPCK(timed(h, "conv_dw_all", s, [&] { return launch_conv_dw_all(ca, lRb, h->convDwBlocks, s); }));
+    } else {
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) HIPCK(timed(h, "conv_dw_rows", s, [&] { return launch_conv_dw_rows(ca, l, s); }));
     if (h->convDwBlocks > 0) HIPCK(timed(h, "conv_dw", s, [&] { return launch_conv_dw(ca, h->convDwBlocks, s); }));
+    }
     HIPCK(timed(h, "conv_reduce_adam", s, [&] { return launch_conv_reduce_adam(ca, hyp, fuseAdam ? 1 : 0, s); }));
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
