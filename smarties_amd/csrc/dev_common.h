@@ -152,19 +152,13 @@ __device__ __forceinline__ unsigned waveScanIncl(unsigned v) {
 // per round: the wavefronts exchange their totals together with "an increment differs from the round before" / "out of range"
 // in one LDS word each (sX: eight words, two rounds alternate); a round that reproduces all increments ends the iteration.
 __device__ __forceinline__ bool farCountRegs(const float (&f)[FAR_REGS], const float (&l)[FAR_REGS], const unsigned long long (&g0)[FAR_SUB],
-                                             unsigned long long* gStart, unsigned* sX, unsigned long long* total, long long* cyc = nullptr) {
+                                             unsigned long long* gStart, unsigned* sX, unsigned long long* total) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   unsigned n0[FAR_SUB], n[FAR_SUB], dPrev[FAR_SUB], tot = 0; int iterDone = 0; (void)iterDone;
 #pragma unroll
   for (int c = 0; c < FAR_SUB; ++c) { n0[c] = g0[c] < 16777216ull ? (unsigned)g0[c] : 0u; dPrev[c] = 0u; }
   for (int iter = 0; iter < 1030; ++iter) {
-#ifdef HL_TAIL_STAMPS
-    if (t == 0 && iter < 2) cyc[iter * 3] = clock64();
-#endif
     const bool ok = farWalkRegs(f, l, n0, n);
-#ifdef HL_TAIL_STAMPS
-    if (t == 0 && iter < 2) cyc[iter * 3 + 1] = clock64() + (n[0] & 0);
-#endif
     unsigned d = 0; bool same = iter > 0;
 #pragma unroll
     for (int c = 0; c < FAR_SUB; ++c) { const unsigned dc = n[c] - n0[c]; same = same && dc == dPrev[c]; dPrev[c] = dc; d += dc; }
@@ -174,9 +168,6 @@ __device__ __forceinline__ bool farCountRegs(const float (&f)[FAR_REGS], const f
     if (lane == 63) x[wv] = (inc & 0x3fffffffu) | fl;
     __syncthreads();
     const unsigned w0 = x[0], w1 = x[1], w2 = x[2], w3 = x[3], any = w0 | w1 | w2 | w3;
-#ifdef HL_TAIL_STAMPS
-    if (t == 0 && iter < 2) cyc[iter * 3 + 2] = clock64() + (any & 0);
-#endif
     if (any & 0x80000000u) return false;
     tot = (w0 & 0x3fffffffu) + (w1 & 0x3fffffffu) + (w2 & 0x3fffffffu) + (w3 & 0x3fffffffu);
     if (!(any & 0x40000000u)) { iterDone = iter + 1; break; }         // the starts of this round came from exactly these increments

@@ -29,11 +29,9 @@ namespace hl {
 #ifdef HL_TAIL_STAMPS
 #define TSTAMP(sc, i) do { if (threadIdx.x == 0) (sc)->dbgT[i] = wall_clock64(); } while (0)
 #define PSTAMP(sc, i) do { if (threadIdx.x == 0 && (a.mode & POST_DEFER)) (sc)->dbgT[i] = wall_clock64(); } while (0)      // (the steps inside a call, not its last)
-#define FAR_CYC(sc) nullptr
 #else
 #define TSTAMP(sc, i) do { } while (0)
 #define PSTAMP(sc, i) do { } while (0)
-#define FAR_CYC(sc) nullptr
 #endif
 
 #define SMAXB 1024
@@ -190,14 +188,11 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
 #pragma unroll
       for (int i = 0; i < FAR_REGS; ++i) farT[i] = sFarP[i * 256 + tid];
       TSTAMP(sc, 14);
-#ifdef HL_TAIL_STAMPS
-      const long long cyc0 = clock64();
-#endif
       unsigned long long tot = 0;
       // a count or a term outside the range of the float recurrence: the emulated loop over the LDS copy
-      if (!farCountRegs(farT, farL, farG0, gFarStart, reinterpret_cast<unsigned*>(sScan), &tot, FAR_CYC(sc))) tot = farCountMem<false>(sFarP, gFarN, farCnt, gFarStart, sScan);
+      if (!farCountRegs(farT, farL, farG0, gFarStart, reinterpret_cast<unsigned*>(sScan), &tot)) tot = farCountMem<false>(sFarP, gFarN, farCnt, gFarStart, sScan);
 #ifdef HL_TAIL_STAMPS
-      if (tid == 0) { sc->dbgT[12] = (long long)(tot >> 48); sc->dbgT[11] = clock64() - cyc0; }
+      if (tid == 0 && (long long)(tot >> 48) > sc->dbgT[12]) sc->dbgT[12] = (long long)(tot >> 48);
       tot &= 0xffffffffffffull;
 #endif
       farTotal = (long long)tot;
@@ -728,6 +723,7 @@ __device__ __forceinline__ void farBetaPhase(const PostArgs& a, unsigned char* s
     for (int i = 0; i < FAR_REGS; ++i) { f[i] = gFarP[i * 256 + tid]; l[i] = gFarN[i * 256 + tid]; }
     done = farCountRegs(f, l, g0, gFarStart, reinterpret_cast<unsigned*>(sScan), &tot);
 #ifdef HL_TAIL_STAMPS
+    if (tid == 0 && (long long)(tot >> 48) > sc->dbgT[12]) sc->dbgT[12] = (long long)(tot >> 48);      // most rounds seen in any step (tools/far_rounds.py)
     tot &= 0xffffffffffffull;
 #endif
   }
@@ -741,7 +737,6 @@ __device__ __forceinline__ void farBetaPhase(const PostArgs& a, unsigned char* s
   refEerPenal(sc, fracOffPol, learnRefer, a.penalTol, beta0, alpha0, true);
   __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): beta and alpha are in memory
   __hip_atomic_store(&sc->betaSeq, nGrad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  TSTAMP(sc, 12);
 }
 
 // the extra workgroup of an MLP kernel: role 1 = sampler phases (for the NEXT step), 2 = bookkeeping, 3 = far-policy count + beta
