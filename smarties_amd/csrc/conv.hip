@@ -628,6 +628,38 @@ __device__ __forceinline__ void stageWindow(float* sIn, const float* in, const C
     for (int u = 0; u < 8; ++u) { const int i = q0 + threadIdx.x + 256 * u; if (i < total) { const int ic = i / perCh, r = i - ic * perCh; dst[ic * ldsCh4 + r] = v[u]; } }
   }
 }
+// the same window straight from the replay (stack_gather_kernel's mapping): input channel ic = frame j = ic / C0 steps back (steps
+// before the first repeat the first), channel c0 = ic % C0 of that state; standardised with the per-component mean and scale
+__device__ __forceinline__ void stageWindowReplay(float* sIn, const ConvSource& src, int row, int B, const ConvGeo& g, int iy0, int wr, int wrValid) {
+  const int b = row < B ? row : src.nextSrc[row - B];
+  const long long slot = src.slot[b] + (row < B ? 0 : 1);
+  const int t = src.t[b] + (row < B ? 0 : 1);
+  const int rowF4 = g.InX >> 2, perCh = wrValid * rowF4, total = g.InC * perCh;
+  const int C0 = g.InC / (1 + src.nApp), chStride4 = (g.InY * g.InX) >> 2, base4 = (iy0 * g.InX) >> 2, ldsCh4 = (wr * g.InX) >> 2;
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(src.mean); const f32x4* s4 = reinterpret_cast<const f32x4*>(src.scale);
+  f32x4* dst = reinterpret_cast<f32x4*>(sIn);
+  for (int q0 = 0; q0 < total; q0 += 256 * 4) {
+    f32x4 v[4], mu[4], sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = q0 + threadIdx.x + 256 * u;
+      if (i < total) {
+        const int ic = i / perCh, r = i - ic * perCh, j = ic / C0, c0 = ic - j * C0, back = j < t ? j : t;
+        const int off4 = c0 * chStride4 + base4 + r;
+        v[u] = reinterpret_cast<const f32x4*>(src.S + (size_t)(slot - back) * src.dS)[off4]; mu[u] = m4[off4]; sc[u] = s4[off4];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = q0 + threadIdx.x + 256 * u;
+      if (i < total) {
+        const int ic = i / perCh, r = i - ic * perCh;
+        f32x4 o; o[0] = (v[u][0] - mu[u][0]) * sc[u][0]; o[1] = (v[u][1] - mu[u][1]) * sc[u][1]; o[2] = (v[u][2] - mu[u][2]) * sc[u][2]; o[3] = (v[u][3] - mu[u][3]) * sc[u][3];
+        dst[ic * ldsCh4 + r] = o;
+      }
+    }
+  }
+}
 template <int NK, int CT, int KNY, int KNX>       // MFMA steps per tile (K / 4), channel tiles of 16, filter size (compile time: no index divisions in the loop)
 __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -640,7 +672,8 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
   float* Ws = sIn + (size_t)g.InC * WR * g.InX;                      // [CT 16][ldK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
   stageFlat<(CT * 16 * (4 * NK + 4) / 4 + 255) / 256>(Ws, g.Wf, CT * 16 * ldK);
-  stageWindow(sIn, g.in + (long long)row * g.ldIn, g, iy0, WR, wrValid);
+  if (a.src.on) stageWindowReplay(sIn, a.src, row, a.B, g, iy0, WR, wrValid);
+  else stageWindow(sIn, g.in + (long long)row * g.ldIn, g, iy0, WR, wrValid);
   // window-relative offset of patch element k = 4 s + lc: KnX is a multiple of 4, so the four elements of a step lie side by
   // side in one filter row -- offset(4 s) is uniform (scalar registers), the lane adds lc
   constexpr int fsz = KNY * KNX;
@@ -714,7 +747,8 @@ __device__ __forceinline__ void convDwRowsBody(const ConvArgs& a, int l, int rb,
   float* sD = sIn + (size_t)g.InC * WR * g.InX;                      // [CT 16][ldD]   deltas of this block's positions, zero padded
   int* sPos = reinterpret_cast<int*>(sD + (size_t)CT * 16 * ldD);    // [RB OpX + 4]    window offset of the patch origin of position r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  stageWindow(sIn, g.in + (long long)b * g.ldIn, g, iy0, WR, wrValid);
+  if (a.src.on) stageWindowReplay(sIn, a.src, b, a.B, g, iy0, WR, wrValid);
+  else stageWindow(sIn, g.in + (long long)b * g.ldIn, g, iy0, WR, wrValid);
   for (int i = tid; i < CT * 16 * ldD; i += 256) {
     const int c = i / ldD, r = i - c * ldD;
     sD[i] = (c < g.KnC && r < nPos) ? g.D[(size_t)b * g.ldOut + (size_t)c * P + oy0 * g.OpX + r] : 0.f;

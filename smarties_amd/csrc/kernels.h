@@ -97,10 +97,18 @@ struct ConvGeo {
   // rbRows output rows of one sample and stages the rbWin input rows under them in LDS.  rbRows = 0: not used for this layer.
   int rbRows, rbCount, rbWin;
 };
+// where the row-block kernels of the first layer take their input rows from when no stacked minibatch rows X0 were written
+// (training steps: the replay itself, standardised on the way -- stack_gather_kernel's mapping, conv.hip)
+struct ConvSource {
+  int on;                       // 0: ConvGeo::in (X0 rows)
+  const float* S; const float* mean; const float* scale; int dS, nApp;
+  const long long* slot; const int* t; const int* nextSrc;
+};
 struct ConvArgs {
   DevScalars* sc; int parity, B, nL;
   const float* W; float* Wrw; float* M1; float* M2; float* G;
   ConvGeo L[HL_MAX_CONV];
+  ConvSource src;
 };
 struct StackGatherArgs { DevScalars* sc; DevReplay rp; DevBatch bt; int B, dS, nApp, parity; float* X0; int ldX0; };
 struct AdamHyper;

@@ -112,6 +112,7 @@ struct hl_learner {
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
   bool chainOk = false; int chainHT = 0;  // the dense forward layers of a network off the fused path go out as one launch (gemm16.hip: fwd_chain_kernel)
+  bool noConvReplay = false;            // SMARTIES_HIP_NO_CONV_REPLAY=1: stack the minibatch rows (stack_gather_kernel) also when the first layer could read the replay
   bool helperHandOff = false;           // SMARTIES_HIP_HELPER_HANDOFF=1: the gather helpers of the dW launch wait for the rider's search (development)
   bool noDeferBeta = false;             // SMARTIES_HIP_NO_DEFER_BETA=1: the whole bookkeeping stays in the dW launch (development)
   float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
@@ -697,6 +698,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   }
   { const char* nd = getenv("SMARTIES_HIP_NO_DEFER_BETA"); h->noDeferBeta = nd && nd[0] == '1'; }
   { const char* nd = getenv("SMARTIES_HIP_HELPER_HANDOFF"); h->helperHandOff = nd && nd[0] == '1'; }
+  { const char* nd = getenv("SMARTIES_HIP_NO_CONV_REPLAY"); h->noConvReplay = nd && nd[0] == '1'; }
   // networks off the fused path with two or more dense layers (short reductions): one forward launch if the groups of its
   // panels run where the kernel assumes (same probe as above, with that kernel's geometry)
   if (!h->fusedOk && !h->recurrent) {
@@ -1764,8 +1766,8 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
     }
     case HL_TAP_STATE: {
       if (bytes < (int64_t)B * h->dIn * 4) return HL_ERR_BAD_ARG;
-      if (h->recurrent) {   // recurrent layers read their windows straight from the replay: the rows are assembled on demand
-        StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = bt; ga.B = B; ga.dS = h->dS; ga.nApp = 0; ga.parity = h->lastParity;
+      if (h->recurrent || convFromReplay(h)) {   // recurrent layers and row-block convolutions read their windows straight from the replay: the rows are assembled on demand
+        StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = bt; ga.B = B; ga.dS = h->dS; ga.nApp = h->recurrent ? 0 : h->nApp; ga.parity = h->lastParity;
         ga.X0 = h->buf[h->lastParity].X0; ga.ldX0 = h->ldX0;
         HIPCK(launch_stack_gather(ga, h->Mmax, h->stream)); HIPCK(hipStreamSynchronize(h->stream));
       }

@@ -293,20 +293,34 @@ ConvArgs convArgs(hl_learner* h, int parity) {
   for (int l = 0; l < h->nConv; ++l) { ca.L[l] = h->cg[l]; ca.L[l].in = l == 0 ? h->buf[parity].X0 : h->cg[l - 1].Y; }
   return ca;
 }
+// training steps of a net whose first layer runs the row-block kernels: those read their input windows from the replay, the
+// stacked rows X0 (28 KB per row at 84 x 84 x 4, written and read once per step) and their launch are not needed
+bool convFromReplay(const hl_learner* h) {
+  if (h->nConv == 0 || !h->cg[0].rbRows || h->noConvReplay) return false;
+  const ConvGeo& g = h->cg[0];
+  return (h->dS & 3) == 0 && (g.InX & 3) == 0 && g.InC % (1 + h->nApp) == 0 && (long long)(g.InC / (1 + h->nApp)) * g.InY * g.InX == h->dS;
+}
+void convSource(hl_learner* h, int parity, ConvArgs* ca) {
+  const DevBatch& bt = h->buf[parity].bt;
+  ca->src.on = 1; ca->src.S = h->rp.S; ca->src.mean = h->rp.stMean; ca->src.scale = h->rp.stScale; ca->src.dS = h->dS; ca->src.nApp = h->nApp;
+  ca->src.slot = bt.slot; ca->src.t = bt.t; ca->src.nextSrc = bt.nextSrc;
+}
 // `gather`: states with appended observations / convolutional input are assembled here, from the sampled slots
 // (rollout inference writes the standardised rows itself)
 int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   char nm[32];
-  if (h->preproc && gather) {
+  const bool fromReplay = gather && convFromReplay(h);
+  if (h->preproc && gather && !fromReplay) {
     StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = h->buf[parity].bt; ga.B = h->B; ga.dS = h->dS; ga.nApp = h->nApp;
     ga.parity = parity; ga.X0 = h->buf[parity].X0; ga.ldX0 = h->ldX0;
     HIPCK(timed(h, "stack_gather", s, [&] { return launch_stack_gather(ga, h->Mmax, s); }));
   }
   const int j0 = h->nConv > 0 ? 1 : 0;
   if (j0) {
-    const ConvArgs ca = convArgs(h, parity);
+    ConvArgs ca = convArgs(h, parity);
+    if (fromReplay) convSource(h, parity, &ca);
     // filters -> the kernels' LDS layouts: kept current by the Adam pass of the filter gradients (conv_reduce_adam_kernel);
     // rebuilt here only after something else wrote the weights (start-up, hl_set_params, a restart) or where Adam runs
     // elsewhere (replica exchange)
@@ -402,7 +416,8 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     HIPCK(timed(h, nm, s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
   }
   if (h->nConv > 0) {   // convolutional layers: input gradients from the last one down, then every filter gradient (+ Adam)
-    const ConvArgs ca = convArgs(h, parity);
+    ConvArgs ca = convArgs(h, parity);
+    if (convFromReplay(h)) convSource(h, parity, &ca);      // (the backward pass belongs to a training step: the rows were never stacked)
     for (int l = h->nConv - 1; l >= 1; --l) {
       snprintf(nm, sizeof(nm), "conv_dx%d", l);
       HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s); }));
