@@ -176,3 +176,25 @@ def test_checkpoint_files_match_reference(name, tmp_path):
     M.init_weights(); M.restart(base)
     for a, b in zip(M.get_params(), (fx["Wfinal"], fx["M1final"], fx["M2final"])):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["small_mixed.bin", "ns_shape.bin", "hp_lowclip.bin", "threads3.bin", "hp_odd.bin"])
+def test_far_policy_count_is_the_reference_loop_over_the_storage_order(name):
+    """ReplayStats::nFarPolicySteps is `Uint += float * float` per episode in storage order (MemoryProcessing.cpp:202-238): the helper
+    the GPU suite uses (parity.far_count_loop: exact fused multiply-add, x86's float -> unsigned conversion) reproduces (i) the
+    fixture's number from the fractions of a learner in the OTHER (newest-first) storage order, walked in the reference's order, and
+    (ii) that learner's own number over its own order -- at every step."""
+    from parity import far_count_loop, storage_order, flat_for
+    fx = load_fixture(name)
+    R = oracle_learner(fixture_config(fx, episode_order=capi.ORDER_REFERENCE)); setup_from_fixture(R, fx)
+    S = oracle_learner(fixture_config(fx)); setup_from_fixture(S, fx)
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        if sk + "flat" not in fx:
+            break
+        ref_order = storage_order(R)                   # (a step's statistics pass runs before its std::sort)
+        R.step(1)
+        S.step(1, flat=np.sort(flat_for(S, fx[sk + "tag"], fx[sk + "t"])))
+        assert R.scalars().nFarPolicySteps == fx["traj_nfar"][k - 1]
+        assert far_count_loop(S, ref_order) == fx["traj_nfar"][k - 1], k
+        assert S.scalars().nFarPolicySteps == far_count_loop(S, storage_order(S)), k
