@@ -1694,3 +1694,25 @@ def test_full_size_retrace_round_trip(full_size):
             checked += 1
         assert checked > N // 2
         assert np.isfinite(Q).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_far_policy_count_over_more_episodes_than_the_register_walk_holds(hip_api, fused):
+    """7000 short episodes: 28 table positions per thread of the count's walk, more than its 24 registers (and than the LDS copy of
+    the bookkeeping rider) -- the general walk over memory, inside single steps (bookkeeping pass) and inside replayed calls (the
+    rider of the next step's kernel on the fused path, of the dW launch on the generic one).  Count, beta and the generator state
+    equal the oracle's; a low clip keeps many steps far from the behaviour policy."""
+    cfg_kw = dict(dimS=3, dimA=1, bounded=[1], hidden=(16, 16) if fused else (24, 16), batchSize=64, maxTotObsNum=60000, randSeed=77,
+                  clipImpWeight=0.3, learnrate=1e-3)
+    G, O = _pair(hip_api, cfg_kw, synth_cfg(seed=21, dimS=3, dimA=1, lenMin=3, lenMax=6, pTerm=0.3, muSpread=0.5), 7000)
+    assert G.scalars().nStoredEps == 7000
+    for k in range(4):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+        assert G.scalars().nFarPolicySteps == O.scalars().nFarPolicySteps and G.scalars().beta == pytest.approx(O.scalars().beta, rel=1e-12)
+    G.step(24); O.step(24)          # 16 + 8 replayed steps: the deferred count between them
+    sg, so = G.scalars(), O.scalars()
+    assert sg.nFarPolicySteps == so.nFarPolicySteps and sg.nFarPolicySteps > 0
+    assert abs(sg.beta - so.beta) <= 1e-12 * so.beta
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
