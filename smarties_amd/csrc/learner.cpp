@@ -707,6 +707,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     bool ok = h->nHidden - j0 >= 2 && !(nc && nc[0] == '1');
     int HT = 0;
     for (int j = j0; j < h->nHidden; ++j) { ok = ok && !gemm_oneshot_ok(GEMM_F, h->hid[j].nIn); HT = std::max(HT, (h->hid[j].size + 15) / 16); }
+    ok = ok && HT <= 64;      // a panel's group waits for all its workgroups: they must fit one XCD at once (32 CUs x 3 workgroups at this kernel's registers)
     if (ok) {
       const int nBlk = fwd_chain_blocks(h->Mmax, HT);
       int* dX = nullptr; HIPCK(devAlloc(&dX, (size_t)nBlk));
