@@ -461,7 +461,14 @@ hipError_t launch_gemm_oneshot(int role, const GemmProblem* dProb, int K, int nB
 }
 
 // sum of the chunk partials of the split weight-gradient problems, in chunk order, + Adam
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* __restrict__ probs, const DevScalars* __restrict__ sc, AdamHyper hyp) {
+// (one more row of the grid, blockIdx.y == nProbs: its first workgroup is a rider -- the far-policy count + beta update a POST_DEFER
+// bookkeeping pass of the dW launch left over)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* __restrict__ probs, const DevScalars* __restrict__ sc, AdamHyper hyp, int nProbs, PostArgs farBeta) {
+  if ((int)blockIdx.y == nProbs) {
+    __shared__ __attribute__((aligned(16))) unsigned char sFar[64];
+    if (blockIdx.x == 0) farBetaPhase(farBeta, sFar);
+    return;
+  }
   const GemmProblem P = probs[blockIdx.y];
   if (P.nSplit <= 1) return;
   const bool col = P.flavor == RED_COL;         // column sums: one row of N values
@@ -489,8 +496,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmProblem* _
     if (P.adamRed) adamApply(c, s, P.adbW, P.adbM1, P.adbM2, n);
   }
 }
-hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((maxMN + 255) / 256, nProbs), dim3(256), 0, s, dProbs, sc, hyp);
+hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s, const PostArgs* farBeta) {
+  PostArgs fb{}; if (farBeta) fb = *farBeta;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((maxMN + 255) / 256, nProbs + (farBeta ? 1 : 0)), dim3(256), 0, s, dProbs, sc, hyp, nProbs, fb);
   return hipGetLastError();
 }
 

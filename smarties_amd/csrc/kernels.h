@@ -216,7 +216,8 @@ hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc
 // up to two riders (extra, extra2) occupy workgroups 0 and 1 of the grid
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);
-hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s);
+hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s,
+                                const PostArgs* farBeta = nullptr);      // farBeta: a rider workgroup runs farBetaPhase (tail_dev.h)
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 size_t fused_lds_bytes(int dS, int H);

@@ -402,9 +402,16 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   ExtraArgs ex{}, exF{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pexF = nullptr;
   // one replica, bookkeeping riding the first dX launch: its far-policy count and the beta update move on to the dW launch (the next
   // reader of beta is the head kernel of the step after), off what was that launch's longest workgroup
-  if (fusePost && postMode == (POST_AGG | POST_BETA) && !sb.dxIdx.empty() && !h->noDeferBeta) {
-    postMode |= POST_DEFER; exF.role = 3; exF.post = postArgs(h, parity, POST_BETA); pexF = &exF;
+  // (no dX launch -- recurrent layers, a single hidden layer --: the bookkeeping rides the dW launch; where a split-row join follows,
+  // count and beta ride that one)
+  const bool viaSplit = sb.dxIdx.empty() && sb.splitMaxMN > 0;
+  PostArgs fbSplit{};
+  if (fusePost && postMode == (POST_AGG | POST_BETA) && (!sb.dxIdx.empty() || viaSplit) && !h->noDeferBeta) {
+    postMode |= POST_DEFER;
+    if (viaSplit) fbSplit = postArgs(h, parity, POST_BETA);
+    else { exF.role = 3; exF.post = postArgs(h, parity, POST_BETA); pexF = &exF; }
   }
+  const bool splitRider = viaSplit && (postMode & POST_DEFER);
   if (fusePost) { ex.role = 2; ex.post = postArgs(h, parity, postMode); pex = &ex; }
   char nm[32];
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
@@ -439,7 +446,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s, pexF); }));
   if (sb.splitMaxMN > 0)
     HIPCK(timed(h, "splitk_reduce", s, [&] {
-      return launch_splitk_reduce(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.splitMaxMN, h->sc, hyp, s); }));
+      return launch_splitk_reduce(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.splitMaxMN, h->sc, hyp, s, splitRider ? &fbSplit : nullptr); }));
   return HL_OK;
 }
 int launchAdam(hl_learner* h, int parity) {
