@@ -22,6 +22,7 @@
 #include <string>
 #include <sstream>
 #include <iomanip>
+#include <climits>
 #include <limits>
 #include <vector>
 
@@ -113,6 +114,7 @@ struct hl_learner {
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
   bool chainOk = false; int chainHT = 0;  // the dense forward layers of a network off the fused path go out as one launch (gemm16.hip: fwd_chain_kernel)
   bool noConvReplay = false;            // SMARTIES_HIP_NO_CONV_REPLAY=1: stack the minibatch rows (stack_gather_kernel) also when the first layer could read the replay
+  mutable int minLen = 0; mutable long long minLenAtN = -1; mutable size_t minLenAtCount = 0;      // shortest stored episode (evictionDue, removal rules other than "oldest")
   bool helperHandOff = false;           // SMARTIES_HIP_HELPER_HANDOFF=1: the gather helpers of the dW launch wait for the rider's search (development)
   bool noDeferBeta = false;             // SMARTIES_HIP_NO_DEFER_BETA=1: the whole bookkeeping stays in the dW launch (development)
   float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;

@@ -498,7 +498,7 @@ int applyRemoval(hl_learner* h) {
       const EpMeta e = h->order.back();
       h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
     }
-  } else if (!h->order.empty() && h->nTransitions - 2 > h->maxObsLocal) {
+  } else if (evictionDue(h)) {
     std::vector<float> agg((size_t)h->nextEid * AGG_N);
     HIPCK(hipMemcpyAsync(agg.data(), h->rp.epAgg, agg.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
@@ -566,7 +566,17 @@ int allreduceMoments(hl_learner* h) {
 // more than the shortest possible episode is the necessary condition)
 bool evictionDue(const hl_learner* h) {
   if (h->order.empty()) return false;
-  if (h->cfg.ERoldSeqFilter != HL_ER_OLDEST) return h->nTransitions - 2 > h->maxObsLocal;
+  if (h->cfg.ERoldSeqFilter != HL_ER_OLDEST) {
+    // which episode the rule picks depends on aggregates that live on the device, but no pick can leave unless even the shortest
+    // stored episode could: without this bound a full replay sat "due" for good and every step took the eager route with a
+    // device-to-host copy of the aggregates
+    if (h->minLenAtN != h->nTransitions || h->minLenAtCount != h->order.size()) {      // (recomputed when the table changed)
+      int minN = INT_MAX;
+      for (const EpMeta& e : h->order) minN = std::min(minN, e.N);
+      h->minLen = minN; h->minLenAtN = h->nTransitions; h->minLenAtCount = h->order.size();
+    }
+    return h->nTransitions - (long long)h->minLen > h->maxObsLocal;
+  }
   return h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
 }
 
