@@ -576,6 +576,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     const long long inSize = (long long)d.inpFeatures * d.inpY * d.inpX;
     const long long prev = j == 0 ? (long long)cfg->dimS * (1 + cfg->nAppendedObs)
                                   : (long long)cfg->conv[j - 1].outFeatures * cfg->conv[j - 1].outY * cfg->conv[j - 1].outX;
+    if (j == 0 && inSize < prev) return HL_ERR_UNSUPPORTED;      // state variables beside the image, appended behind the conv stack (Approximator.cpp:249-259): refused, not dropped
     if (inSize != prev || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.filterx < 1 || d.filtery < 1) return HL_ERR_BAD_ARG;
     if (d.outY != (d.inpY - d.filtery + 2 * d.paddiny) / d.stridey + 1 || d.outX != (d.inpX - d.filterx + 2 * d.paddinx) / d.stridex + 1) return HL_ERR_BAD_ARG;
     // conv.hip: zero padding, one power-of-two stride, <= 64 channels per layer, filters <= 32 wide
