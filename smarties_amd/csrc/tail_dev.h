@@ -519,7 +519,7 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
       const int e = rec.eidTerm & 0x7fffffff;
       const bool term = rec.eidTerm < 0;
       a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = e; a.bt.t[b] = t; a.bt.tag[b] = rec.tag;
-      if (phases & PH_PUBLISH) __hip_atomic_store(a.bt.slot + b, rec.off + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((phases & PH_PUBLISH) && !a.selfSearch) __hip_atomic_store(a.bt.slot + b, rec.off + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else a.bt.slot[b] = rec.off + t;
       sSlot[b] = rec.off + t;
       hasNext[r] = (t + 2 == rec.N && !term);      // Episode::isTruncated(t+1) (Episode.h:158-161)
@@ -533,7 +533,7 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
     if (b < B) {
       const int nr = hasNext[r] ? B + nextIdx[r] : -1;
       if (hasNext[r]) a.bt.nextSrc[nextIdx[r]] = b;
-      if (phases & PH_PUBLISH) __hip_atomic_store(a.bt.nextOf + b, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((phases & PH_PUBLISH) && !a.selfSearch) __hip_atomic_store(a.bt.nextOf + b, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else a.bt.nextOf[b] = nr;
       sNextRow[b] = nr;
     }
@@ -545,6 +545,7 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
   }
   if (a.noGather) return;      // the states are gathered by stack_gather_kernel (conv.hip)
   if (phases & PH_PUBLISH) {   // the gather is done by the helper workgroups (gatherHelper)
+    if (a.selfSearch) return;          // ... which ran the search themselves: nobody waits for these arrays inside this kernel
     __builtin_amdgcn_s_waitcnt(0);     // the agent-scope stores of slot / nextOf are acknowledged
     __syncthreads();
     if (tid == 0) __hip_atomic_store(sc->gatherFlag + a.parity, a.tagSeq ? -sc->sampleSeq : sc->nStep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
