@@ -1716,3 +1716,49 @@ def test_far_policy_count_over_more_episodes_than_the_register_walk_holds(hip_ap
     assert sg.nFarPolicySteps == so.nFarPolicySteps and sg.nFarPolicySteps > 0
     assert abs(sg.beta - so.beta) <= 1e-12 * so.beta
     assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+
+
+@pytest.mark.gpu
+def test_several_learners_of_one_process_step_side_by_side(hip_api):
+    """Four independent single-replica learners (one thread each, as a multi-agent run holds them) replay 20-step calls at the same
+    time on the one device: the kernels of different learners interleave, the in-kernel waits of each (panel barrier, beta handed
+    from the rider of the next fused kernel) only ever concern workgroups of their own launch -- no time-out, and every learner ends
+    bit-identical to the same learner stepped alone."""
+    import threading
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(64, 64), batchSize=64, maxTotObsNum=50000)
+    sc = synth_cfg(seed=31, dimS=17, dimA=6, lenMin=20, lenMax=60, pTerm=0.3)
+
+    def make(seed):
+        L = hip_learner(hip_api, capi.make_config(randSeed=seed, **cfg_kw))
+        L.init_weights(); fill_synth(L, sc, 120); L.initialize(); L.prepare_steps(20)
+        return L
+
+    def state(L):
+        w, m1, m2 = L.get_params(); s = L.scalars()
+        return w.tobytes(), m1.tobytes(), s.beta, s.nFarPolicySteps, L.get_rng_state().tobytes()
+
+    alone = []
+    for seed in range(4):
+        L = make(100 + seed)
+        for _ in range(40):
+            L.step(20)
+        alone.append(state(L)); L.close()
+    Ls = [make(100 + seed) for seed in range(4)]
+    errs = []
+
+    def run(L):
+        try:
+            for _ in range(40):
+                L.step(20)
+            L.sync()
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+
+    ths = [threading.Thread(target=run, args=(L,)) for L in Ls]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for L, ref in zip(Ls, alone):
+        assert state(L) == ref
