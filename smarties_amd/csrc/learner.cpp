@@ -565,7 +565,9 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->n_encoder < 0 || cfg->n_encoder + cfg->n_hidden > HL_MAX_HIDDEN) return HL_ERR_BAD_ARG;
   if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: one gate per thread of a 256-thread workgroup
     if (cfg->dimS > 256) return HL_ERR_UNSUPPORTED;
+    // (encoder layers are hidden layers of the same network, Learner_approximator.cpp:149-166: the same limits hold for them)
     for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
+    for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 64) return HL_ERR_UNSUPPORTED;
   }
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
@@ -605,8 +607,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);
   h->preproc = h->nApp > 0 || cfg->n_conv > 0;       // the states are gathered by stack_gather_kernel (conv.hip)
   if (!h->preproc && h->dS > 512) return fail(h, HL_ERR_UNSUPPORTED, "more than 512 observed state components");   // gather staging (tail_dev.h)
-  for (int j = 0; j < cfg->n_hidden; ++j)
-    if (cfg->hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
+  for (int j = 0; j < h->cfg.n_hidden; ++j)      // (the merged list: encoder layers first)
+    if (h->cfg.hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
   h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);
   h->maxObsLocal = h->maxObsGlobal / cfg->n_ranks;
   long long minObs = cfg->minTotObsNum <= 0 ? cfg->maxTotObsNum : cfg->minTotObsNum;
@@ -996,7 +998,7 @@ int hl_append_episode(hl_learner* h, int32_t N, const float* states, const doubl
     else { h->err = "unable to open " + h->episodeLog + " (episode log switched off)"; h->episodeLog.clear(); }   // the episode is staged: it enters the training set regardless
   }
   h->nSeenSteps += 1; h->nSeenEps += 1;
-  h->order.push_front(e);
+  h->order.push_front(e); h->minLenAtN = -1;
   h->nTransitions += N - 1;
   h->pendingRetrace.push_back(eid);
   h->tableDirty = true; h->countsDirty = true;
@@ -1230,6 +1232,9 @@ int hl_step_end(hl_learner* h) {
   int rc;
   if (h->momentsPending) { rc = launchMomentsApply(h, false, 10); if (rc) return rc; h->momentsPending = false; }
   rc = launchAdam(h, 0); if (rc) return rc;
+  // the stand-alone Adam pass rewrites the filters but not their LDS layouts (only conv_reduce_adam_kernel with its fused Adam
+  // keeps those current): the next forward rebuilds them (preStepChecks -> ensureConvPrep)
+  if (h->nConv > 0) h->convPrepStale = true;
   rc = launchPost(h, 0, POST_BETA, h->stream); if (rc) return rc;
   if (!h->logBase.empty() && (h->nGradSteps % 1000) == 0) { rc = appendGradStats(h); if (rc) return rc; }
   h->gsCalls += 1;

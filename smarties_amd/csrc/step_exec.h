@@ -496,7 +496,7 @@ int applyRemoval(hl_learner* h) {
   if (filter == HL_ER_OLDEST) {
     while (!h->order.empty() && h->nTransitions - (long long)h->order.back().N > h->maxObsLocal) {
       const EpMeta e = h->order.back();
-      h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true;
+      h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.pop_back(); any = true; h->minLenAtN = -1;
     }
   } else if (evictionDue(h)) {
     std::vector<float> agg((size_t)h->nextEid * AGG_N);
@@ -513,7 +513,7 @@ int applyRemoval(hl_learner* h) {
       }
       const EpMeta e = h->order[v];
       if (h->nTransitions - (long long)e.N <= h->maxObsLocal) break;
-      h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.erase(h->order.begin() + (long)v); any = true;
+      h->nTransitions -= e.N - 1; h->freeEids.push_back(e.eid); h->order.erase(h->order.begin() + (long)v); any = true; h->minLenAtN = -1;
     }
   }
   if (any) { h->tableDirty = true; h->countsDirty = true; }
@@ -570,7 +570,9 @@ bool evictionDue(const hl_learner* h) {
     // which episode the rule picks depends on aggregates that live on the device, but no pick can leave unless even the shortest
     // stored episode could: without this bound a full replay sat "due" for good and every step took the eager route with a
     // device-to-host copy of the aggregates
-    if (h->minLenAtN != h->nTransitions || h->minLenAtCount != h->order.size()) {      // (recomputed when the table changed)
+    // (invalidated -- minLenAtN = -1 -- wherever the order changes: append, removal, restart; the two counters alone can stay
+    //  equal across a removal plus arrivals that lower the minimum)
+    if (h->minLenAtN != h->nTransitions || h->minLenAtCount != h->order.size()) {
       int minN = INT_MAX;
       for (const EpMeta& e : h->order) minN = std::min(minN, e.N);
       h->minLen = minN; h->minLenAtN = h->nTransitions; h->minLenAtCount = h->order.size();
@@ -747,6 +749,7 @@ int touchReplay(hl_learner* h) {
 // graph of exactly n steps for both starting buffers, last node = the completion stamp (hl_prepare_steps)
 int prepareExact(hl_learner* h, int n) {
   if (!h->useGraph || n >= 1000 || (exchanging(h) && (!(h->exchGraph && wired(h)) || n > 64)) || h->cfg.dataSamplingAlgo != HL_SAMPLE_UNIFORM) return HL_OK;
+  { const int rc = ensureConvPrep(h); if (rc) return rc; }      // outside the capture: the captured forward refuses stale filter layouts
   if (!h->notifyPin) { HIPCK(hipHostMalloc((void**)&h->notifyPin, 64, hipHostMallocDefault)); *h->notifyPin = 0; }
   if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
   if (h->exactGraphs.size() >= 8 && !h->exactGraphs.count(n)) {      // a handful of call sizes at most

@@ -1,0 +1,180 @@
+"""GPU suite, round 4: regressions for the advisor's findings of round 3, the whole-buffer passes of every 1000th step at the
+BASELINE replay size, and a long run whose fp32 drift is taken out by re-synchronising the weights (VERDICT r03, items 4 / "weak 1, 2").
+Everything goes through the hl_* C-ABI; the oracle (same C-ABI, CPU) is the checker."""
+import numpy as np
+import pytest
+
+from oracle_api import oracle_learner, fill_synth, synth_cfg
+from parity import relinf, episode_arrays_by_tag
+from smarties_amd import capi
+
+pytestmark = pytest.mark.gpu
+TOL32 = 1e-5     # north_star: 1e-5 relative fp32
+
+
+def _pair(hip_api, cfg_kw, sc, n_eps, tap=True):
+    G = capi.Learner(hip_api, capi.make_config(**cfg_kw))
+    O = oracle_learner(capi.make_config(**cfg_kw))
+    for L in (G, O):
+        L.init_weights(); fill_synth(L, sc, n_eps); L.initialize(); L.set_tap(tap)
+    return G, O
+
+
+def _compare_step(G, O, tol=TOL32):
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert np.array_equal(G.readback(capi.TAP_TSTEP), O.readback(capi.TAP_TSTEP))
+    assert np.array_equal(G.readback(capi.TAP_FAR), O.readback(capi.TAP_FAR))
+    for tap in (capi.TAP_OUTPUT, capi.TAP_RHO, capi.TAP_DKL, capi.TAP_OUTGRAD, capi.TAP_GRADSUM):
+        assert relinf(G.readback(tap), O.readback(tap)) < tol, tap
+
+
+CONV_KW = dict(dimS=256, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=5, nAppendedObs=3, conv=[(8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)],
+               hidden=(48,), nnFunc="Tanh", batchSize=24, maxTotObsNum=2000, randSeed=3)
+CONV_SC = dict(seed=5, dimS=256, dimA=1, lenMin=3, lenMax=9, pTerm=0.3)
+
+
+def test_split_step_of_a_convolutional_net_keeps_its_filter_layouts_current(hip_api):
+    """hl_step_begin / hl_step_end on one rank without a communicator update the filters with the stand-alone
+    Adam pass, which does not rewrite the kernels' LDS layouts of the filters -- every later pass used the filters of step 0.
+    The split form must equal hl_step bit for bit over several steps, and both follow the oracle."""
+    sc = synth_cfg(**CONV_SC)
+    A, O = _pair(hip_api, CONV_KW, sc, 60)
+    Bq = capi.Learner(hip_api, capi.make_config(**CONV_KW))
+    Bq.init_weights(); fill_synth(Bq, sc, 60); Bq.initialize(); Bq.set_tap(True)
+    for k in range(6):
+        A.step(1); O.step(1)
+        Bq.step_begin(); g = Bq.grad_fetch(); Bq.grad_store(g); Bq.step_end()
+        _compare_step(Bq, O)
+        assert np.array_equal(A.readback(capi.TAP_GRADSUM), Bq.readback(capi.TAP_GRADSUM)), k
+    assert np.array_equal(A.get_params()[0], Bq.get_params()[0])
+    assert relinf(Bq.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    # ... and hl_step behind split steps finds current layouts too (fused Adam of conv_reduce_adam_kernel again)
+    A.step(3); Bq.step(3)
+    assert np.array_equal(A.get_params()[0], Bq.get_params()[0])
+
+
+def test_announcing_a_call_size_right_after_new_weights_on_a_convolutional_net(hip_api):
+    """hl_prepare_steps captures a graph; with stale filter layouts (hl_set_params just before) the captured
+    forward used to refuse ('convolution filter layouts are stale') although announcing a size is 'purely an optimisation'."""
+    sc = synth_cfg(**CONV_SC)
+    G, O = _pair(hip_api, CONV_KW, sc, 60)
+    w, m1, m2 = O.get_params()
+    G.set_params(w, m1, m2)
+    G.prepare_steps(5)
+    G.step(5); O.step(5)
+    _compare_step(G, O)
+    G.set_params(*O.get_params())
+    for _ in range(3):                       # the automatic path: third call of one size in a row
+        G.step(4); O.step(4)
+        G.set_params(*O.get_params())
+    G.step(4); O.step(4)
+    _compare_step(G, O)
+
+
+def test_oversized_encoder_layers_are_refused(hip_api):
+    """encoderLayerSizes are hidden layers of the one network; the width limits of the kernels apply to them
+    as to nnLayerSizes (before: an LSTM net with encoder (128,) passed hl_create and overran the 64-cell LDS arrays of rec.hip)."""
+    for kw in (dict(nn_type=capi.NN_LSTM, hidden=(32,), encoder=[128]),
+               dict(nn_type=capi.NN_MGU, hidden=(32,), encoder=[16, 65]),
+               dict(hidden=(64, 64), encoder=[4096])):
+        cfg = capi.make_config(dimS=6, dimA=2, bounded=[1, 0], batchSize=16, maxTotObsNum=2000, randSeed=1, nnFunc="Tanh", **kw)
+        with pytest.raises(capi.HlError) as e:
+            capi.Learner(hip_api, cfg)
+        assert e.value.status == 8, kw       # HL_ERR_UNSUPPORTED
+    ok = capi.Learner(hip_api, capi.make_config(dimS=6, dimA=2, bounded=[1, 0], batchSize=16, maxTotObsNum=2000, randSeed=1, nnFunc="Tanh",
+                                                 nn_type=capi.NN_LSTM, hidden=(32,), encoder=[64]))
+    ok.init_weights()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the whole-buffer passes of the 1000th step at the bench size: Retrace over 5000 episodes x 200 steps,
+# reward / state moments over 1M rows, the far-policy table rebuilt -- compared with the oracle AFTER they ran inside a stepping
+# learner (before: only at initialize() time at this size, and inside a step only on 30 episodes)
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def swept(hip_api):
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=256, maxTotObsNum=1000000, randSeed=42)
+    sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=201, lenMax=201, pTerm=0.0, muSpread=0.3)      # (perturbed behaviour means: far-policy samples exist)
+    G, O = _pair(hip_api, cfg_kw, sc, 5000)
+    # 998 steps of replayed graphs on the device, the oracle steps alone; every 100 steps the oracle's weights and moments go
+    # into the library so that what is compared behind the sweep is the sweep, not 1000 steps of fp32 drift
+    for k in range(0, 900, 100):
+        G.step(100); O.step(100)
+        assert relinf(G.get_params()[0], O.get_params()[0]) < 2e-4, k
+        G.set_params(*O.get_params())
+    G.step(98); O.step(98)
+    G.set_params(*O.get_params())
+    return G, O
+
+
+def test_full_size_thousandth_step_sweep_matches_oracle(swept):
+    G, O = swept
+    for k in (999, 1000, 1001):                # the step before, the step WITH the whole-buffer passes, the step after
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+        sg, so = G.scalars(), O.scalars()
+        assert sg.nFarPolicySteps == so.nFarPolicySteps, (k, sg.nFarPolicySteps, so.nFarPolicySteps)
+        assert abs(sg.beta - so.beta) <= 1e-9 * so.beta and sg.CmaxRet == so.CmaxRet, k
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert G.scalars().nFarPolicySteps > 0
+    # reward / state scaling after the moments pass (EMA with rate min(1, 10 eta), MemoryProcessing.cpp:94-185)
+    mG, sG, rG = G.get_scaling(); mO, sO, rO = O.get_scaling()
+    assert np.allclose(mG, mO, rtol=1e-6, atol=1e-7) and np.allclose(sG, sO, rtol=1e-6, atol=1e-7) and np.allclose(rG, rO, rtol=1e-6, atol=1e-7)
+    # Retrace estimates, values and importance weights of whole episodes after the sweep (MemoryProcessing.cpp:23-44, 391-400)
+    for pos in (0, 1, 777, 2500, 4998, 4999):
+        assert G.episode_info(pos) == O.episode_info(pos)
+        for field, tol in ((capi.EP_RETURN, 2e-4), (capi.EP_VALUE, 2e-4), (capi.EP_IMPW, 2e-4), (capi.EP_DKL, 2e-4), (capi.EP_DELTAQ, 2e-4)):
+            g, o = G.episode_field(pos, field), O.episode_field(pos, field)
+            assert np.allclose(g, o, rtol=tol, atol=tol), (pos, field, np.abs(g - o).max())
+        assert np.allclose(G.episode_stats(pos), O.episode_stats(pos), rtol=1e-3, atol=1e-5), pos
+    stg, sto = G.stats(), O.stats()
+    for f in ("avgKLdivergence", "avgSquaredErr", "avgReturn", "avgQ", "stdevQ", "minQ", "maxQ"):
+        assert np.isclose(getattr(stg, f), getattr(sto, f), rtol=1e-3, atol=1e-5), f
+
+
+def test_full_size_minibatches_behind_the_sweep(swept):
+    """The sampler rider, the index search and the gather after the tables were rebuilt by the sweep: a 20-step replayed call."""
+    G, O = swept
+    G.step(20); O.step(20)
+    _compare_step(G, O, tol=5e-5)              # (20 unsynchronised steps: a little drift in the weights)
+    assert G.scalars().nFarPolicySteps == O.scalars().nFarPolicySteps
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# long run, re-synchronised: the 5e-4 / 1e-3 bounds of the 2100-step fixture comparison say nothing about
+# WHY library and reference drift apart.  Here the oracle's weights and Adam moments are copied into the library every 100 steps:
+# if the drift is fp32 reassociation it stays at the 1e-5 level inside every 100-step leg, at every step, for 2100 steps
+# (two whole-buffer sweeps); a slow bug (a statistic or a counter going wrong) would survive the copies and show up in
+# beta / the far-policy count / the outputs of the later legs.
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("head", ["vracer_fused", "racer_gaussian_generic"])
+def test_resynchronised_long_run_stays_within_fp32_tolerance(hip_api, head):
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4000, randSeed=42, learnrate=1e-3)
+    if head == "racer_gaussian_generic":
+        cfg_kw.update(adv_kind=capi.ADV_GAUSSIAN, hidden=(24, 16, 8), nnFunc="Tanh")
+    sc = synth_cfg(seed=7, dimS=5, dimA=2, lenMin=5, lenMax=40, pTerm=0.5, muSpread=0.3)
+    G, O = _pair(hip_api, cfg_kw, sc, 150)
+    worst = 0.0
+    for leg in range(21):
+        for k in range(100):
+            if k in (0, 1, 50, 98, 99):       # single steps with taps at the start, the middle and the end of every leg
+                G.step(1); O.step(1)
+                tol = TOL32 if k < 2 else 2e-4
+                _compare_step(G, O, tol=tol)
+                sg, so = G.scalars(), O.scalars()
+                assert sg.nFarPolicySteps == so.nFarPolicySteps, (leg, k)
+                assert abs(sg.beta - so.beta) <= 1e-6 * so.beta, (leg, k, sg.beta, so.beta)
+        G.step(95); O.step(95)                  # replayed graphs in between (100 = 5 tapped + 95)
+        d = relinf(G.get_params()[0], O.get_params()[0])
+        worst = max(worst, d)
+        assert d < 1e-4, (leg, d)               # drift of one 100-step leg at learnrate 1e-3
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state()), leg
+        assert abs(G.scalars().beta - O.scalars().beta) <= 1e-6 * O.scalars().beta, leg
+        G.set_params(*O.get_params())
+    assert G.scalars().nGradSteps == 2100
+    # what 2100 steps wrote into the replay (no copies there: per-step fields follow within single-precision noise)
+    for field in (capi.EP_VALUE, capi.EP_RETURN, capi.EP_IMPW):
+        mg, mo = episode_arrays_by_tag(G, field), episode_arrays_by_tag(O, field)
+        for tag in mo:
+            assert np.allclose(mg[tag], mo[tag], rtol=2e-4, atol=2e-5), (field, tag)
