@@ -205,6 +205,30 @@ __device__ __forceinline__ double scaleVdiff(double x) {   // Learners/RACER_com
   return x > 0 ? 100 - 5000 / sqrt(2601 + 100 * x) : 100 - 5000 / sqrt(2601 - 100 * x);
 }
 
+__device__ __forceinline__ float resOut(float y, float in, float w, float b) { return y + fmaf(in, w, b); }
+// Cross-lane traffic inside a 16-lane row (one sample) goes through DPP row rotations -- one VALU
+// instruction each -- instead of ds_bpermute round trips through the LDS crossbar.
+// rowRor<N>: lane i of a row receives the value of lane (i - N) mod 16 of the same row.
+template <int N> __device__ __forceinline__ int rowRorI(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false); }
+template <int N> __device__ __forceinline__ float rowRorF(float v) { return __int_as_float(rowRorI<N>(__float_as_int(v))); }
+template <int N> __device__ __forceinline__ double rowRorD(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)rowRorI<N>((int)(unsigned)b), hi = (unsigned)rowRorI<N>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the 16 lanes of one sample, every lane gets it.  Same pairing as an xor butterfly
+// (8, 4, 2, 1: the partial sums are periodic, so rotating or exchanging gives the same operands).
+__device__ __forceinline__ double sum16(double v) {
+  v += rowRorD<8>(v); v += rowRorD<4>(v); v += rowRorD<2>(v); v += rowRorD<1>(v);
+  return v;
+}
+// value of lane 0 of the row in every lane (exact: the other lanes contribute +0)
+__device__ __forceinline__ float bcast0F(float v, int en) {
+  float x = en == 0 ? v : 0.f;
+  x += rowRorF<8>(x); x += rowRorF<4>(x); x += rowRorF<2>(x); x += rowRorF<1>(x);
+  return x;
+}
+
 // Adam::step (Network/Optimizer.cpp:61-108) with SMARTIES_NESTEROV_ADAM, SMARTIES_SAFE_ADAM,
 // SMARTIES_ADAMW (Settings/Bund.h); eta already carries the bias correction (Optimizer.cpp:66)
 struct AdamCoef { float eta, lambda, fac; };

@@ -16,253 +16,10 @@
 //                                                            Adam::step (Optimizer.cpp:61-108)
 // One launch can carry several problems (table in device memory); all dW / bias / residual
 // parameter gradients of a step are ONE launch.
-#include "tail_dev.h"
+#include "gemm_tile.h"
 
 namespace hl {
 
-#define KC 256
-#define LDR 258
-
-// development time stamps of one W1-gradient tile (-DHL_TAIL_STAMPS), DevScalars::dbgT[24..]
-#ifdef HL_TAIL_STAMPS
-#define GSTAMP(i) do { if (ROLE == GEMM_ROLE_DW && threadIdx.x == 0 && P.M > 200 && P.N > 200 && tile == 40) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
-#else
-#define GSTAMP(i) do { } while (0)
-#endif
-
-__device__ __forceinline__ void adamApply(const AdamCoef& c, float g, float* W, float* M1, float* M2, size_t i) {
-  float w = W[i], m1 = M1[i], m2 = M2[i];
-  adamStep(c, g, w, m1, m2);
-  W[i] = w; M1[i] = m1; M2[i] = m2;
-}
-
-__device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, float* red, const DevScalars* sc,
-                                            const AdamHyper& hyp, int ks) {
-  // out[j] = sum_m A[m][j] * (B ? B[m][j] : 1): 16 columns per workgroup, 16 row-partitions,
-  // 8 independent loads in flight per thread
-  const int tid = threadIdx.x, jj = tid & 15, part = tid >> 4;
-  const int j = tile * 16 + jj;
-  float acc = 0.f;
-  // split problems (many rows: batch x BPTT steps): this workgroup sums the 256 rows of chunk ks only
-  const int mBeg = P.nSplit > 1 ? ks * KC : 0, mEnd = P.nSplit > 1 ? min(P.K, mBeg + KC) : P.K;
-  if (j < P.N) {
-    for (int m0 = mBeg + part; m0 < mEnd; m0 += 128) {
-      float av[8], bv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int m = m0 + 16 * u;
-        av[u] = m < mEnd ? P.A[(size_t)m * P.lda + j] : 0.f;
-        bv[u] = (P.B && m < mEnd) ? P.B[(size_t)m * P.ldb + j] : 1.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += av[u] * bv[u];
-    }
-  }
-  red[part * 16 + jj] = acc;
-  __syncthreads();
-  if (part == 0 && j < P.N) {
-    float g = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) g += red[q * 16 + jj];
-    if (P.nSplit > 1) { P.part[(size_t)ks * P.N + j] = g; return; }
-    P.C[j] = g;
-    if (P.adam) { AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac; adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
-  }
-}
-
-// one 16x16 output tile (or 16 columns of a column reduction) of problem P
-// FL >= 0: the flavor (and with it the epilogue kind) is known at compile time and the development
-// ablation switches are compiled out -- the operand loads then form one straight-line batch instead
-// of a chain of branches with a wait at every join
-template <int ROLE, int FL = -1, bool RAW = false>      // RAW: `tile` is tm * tilesN + tn as given (the caller placed its workgroups itself)
-__device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* __restrict__ sc,
-                                         const AdamHyper& hyp, int nRowsDyn) {
-  const int flavor = FL >= 0 ? FL : P.flavor;
-#ifdef HL_DEV
-  const int variant = FL >= 0 ? 0 : hyp.variant;      // development ablation switches (HL_EXTRA_FLAGS=-DHL_DEV)
-#else
-  constexpr int variant = 0;
-#endif
-  const int epi = FL == GEMM_W ? EPI_DW : P.epi;
-  float* sA = reinterpret_cast<float*>(smem);
-  float* sB = sA + 16 * LDR;
-  float* red = sB + 16 * LDR;
-  int ks = 0;                                  // chunk of the reduction (split problems only)
-  if (FL < 0 && P.nSplit > 1) { const int nT0 = P.tilesM * P.tilesN; ks = tile / nT0; tile -= ks * nT0; }
-  if (flavor == RED_COL) { redcol_tile(P, tile, red, sc, hyp, ks); return; }
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.
-  // Give XCD x the contiguous (row-major) tile range [x*nT/8, (x+1)*nT/8): the tiles of one XCD
-  // then share their A row-panels, and each L2 fetches 1/8 of A instead of all of it.
-  {
-    const int nT = P.tilesM * P.tilesN;
-    if (!RAW && (nT & 7) == 0 && !(variant & 16) && !((variant >> 5) & (1 << ROLE))) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
-  }
-
-  const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
-  const int m0 = tm * 16, n0 = tn * 16;
-  const int Mvalid = P.dynRows ? nRowsDyn : P.M;
-  if (m0 >= Mvalid) return;
-  if (variant & 8) return;              // ablation: launch + problem-table fetch only
-
-  GSTAMP(24);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lc = lane >> 4;
-  const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
-  const bool outOk = m < Mvalid && n < P.N;
-  float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
-  AdamCoef ac{};
-  if (outOk && !(variant & 4)) {        // ablation: no epilogue prefetch
-    if (epi == EPI_FWD) {
-      e0 = P.bias[n];
-      if (P.C3 && n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; e3 = P.resB[n]; }
-    } else if (epi == EPI_DX) {
-      if (n < P.resN) { e1 = P.resIn[(size_t)m * P.ldRes + n]; e2 = P.resW[n]; }
-      e0 = P.actX[(size_t)m * P.ldAct + n]; e3 = P.actY[(size_t)m * P.ldAct + n];
-    } else if (epi == EPI_DW && P.adam && FL < 0) {
-      ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
-      if (m < P.M - 1) { const size_t i = (size_t)m * P.ldc + n; e0 = P.adW[i]; e1 = P.adM1[i]; e2 = P.adM2[i]; }
-      else { e0 = P.adbW[n]; e1 = P.adbM1[n]; e2 = P.adbM2[n]; }
-    }
-  }
-  if (FL == GEMM_W && P.adam) {   // branch-free variant: a divergent if/else here ends in a wait for its loads
-    ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
-    const bool isW = m < P.M - 1;
-    const size_t iw = outOk ? (isW ? (size_t)m * P.ldc + n : (size_t)n) : 0;
-    const float* pw = isW ? P.adW : P.adbW; const float* p1 = isW ? P.adM1 : P.adbM1; const float* p2 = isW ? P.adM2 : P.adbM2;
-    e0 = pw[iw]; e1 = p1[iw]; e2 = p2[iw];
-  }
-  const bool aRows = (flavor != GEMM_W);   // A tile is 16 rows x k  (else k x 16)
-  const bool bRows = (flavor == GEMM_X);   // B tile is 16 rows x k  (else k x 16)
-
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 va[4], vb[4];
-  // k handled by each wave: power of two in {8,16,32,64}; staged chunk kcp = 4*kw in {32..256}
-  auto chunkGeo = [&](int kb, int& kc, int& kw, int& sh) { kc = min(KC, P.K - kb); kw = 8; sh = 3; while (4 * kw < kc) { kw <<= 1; ++sh; } };
-  // every global load of one chunk (<= 8 x 16 B per thread), issued before any use.  With more than one chunk (weight gradients
-  // over batch x BPTT rows) the loads of chunk i+1 are issued right after chunk i is staged, so they fly during its MFMA loop.
-  auto loadChunk = [&](int kb) {
-    int kc, kw, sh; chunkGeo(kb, kc, kw, sh);
-    const int nf4 = kw;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      va[q] = z4; vb[q] = z4;
-      if (variant & 1) continue;        // ablation: no operand loads
-      if (aRows) {
-        const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
-        if (idx < 16 * nf4 && m0 + r < Mvalid && c < kc && kb + c < P.lda)
-          va[q] = *reinterpret_cast<const float4*>(P.A + (size_t)(m0 + r) * P.lda + kb + c);
-      } else {   // GEMM_W: rows = reduction (batch), columns m0.. = input features, + the ones column
-        const int k = idx >> 2, c = m0 + (idx & 3) * 4;
-        // (the ones column is patched in at staging time: touching the value here would make the
-        // compiler wait for every load before issuing the next one)
-        if (idx < 16 * nf4 && k < kc && c < P.lda) va[q] = *reinterpret_cast<const float4*>(P.A + (size_t)(kb + k) * P.lda + c);
-      }
-      if (bRows) {   // GEMM_X: weight rows n0.., reduction along the row
-        const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
-        if (idx < 16 * nf4 && n0 + r < P.N && c < kc && kb + c < P.ldb)
-          vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(n0 + r) * P.ldb + kb + c);
-      } else {
-        const int k = idx >> 2, c = n0 + (idx & 3) * 4;
-        if (idx < 16 * nf4 && k < kc && c < P.ldb && c < ((P.N + 3) & ~3))
-          vb[q] = *reinterpret_cast<const float4*>(P.B + (size_t)(kb + k) * P.ldb + c);
-      }
-    }
-  };
-  const int kBeg = ks * KC, kEnd = (FL < 0 && P.nSplit > 1) ? min(P.K, kBeg + KC) : P.K;
-  loadChunk(kBeg);
-  for (int kb = kBeg; kb < kEnd; kb += KC) {
-    int kc, kw, sh; chunkGeo(kb, kc, kw, sh);
-    const int nf4 = kw;                       // float4 per 16-row-tile row (= kcp/4)
-    GSTAMP(30);
-    // ---- stage into LDS ----
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < 16 * nf4) {
-        if (aRows) {
-          const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
-          float2* d = reinterpret_cast<float2*>(sA + r * LDR + c);
-          d[0] = make_float2(va[q].x, va[q].y); d[1] = make_float2(va[q].z, va[q].w);
-        } else {
-          float4 v = va[q];
-          const int k = idx >> 2, c = m0 + (idx & 3) * 4;
-          const int one = P.M - 1 - c;       // position of the ones column inside this float4
-          if (k < kc) { if (one == 0) v.x = 1.f; else if (one == 1) v.y = 1.f; else if (one == 2) v.z = 1.f; else if (one == 3) v.w = 1.f; }
-          if (one < 0) v = z4;
-          else { if (one < 1) v.y = 0.f; if (one < 2) v.z = 0.f; if (one < 3) v.w = 0.f; }
-          *reinterpret_cast<float4*>(sA + idx * 4) = v;           // [k][16]
-        }
-        if (bRows) {
-          const int r = idx >> sh, c = (idx & (nf4 - 1)) * 4;
-          float2* d = reinterpret_cast<float2*>(sB + r * LDR + c);
-          d[0] = make_float2(vb[q].x, vb[q].y); d[1] = make_float2(vb[q].z, vb[q].w);
-        } else {
-          *reinterpret_cast<float4*>(sB + idx * 4) = vb[q];
-        }
-      }
-    }
-    __syncthreads();
-    GSTAMP(25);
-    if (kb + KC < kEnd) loadChunk(kb + KC);
-    const int k0 = wave * kw;
-    if (!(variant & 2))                 // ablation: no MFMA loop
-    for (int s = 0; s < kw; s += 8) {
-      const int ka = k0 + s + lc, kb2 = ka + 4;
-      const float a0 = aRows ? sA[li * LDR + ka] : sA[ka * 16 + li];
-      const float b0 = bRows ? sB[li * LDR + ka] : sB[ka * 16 + li];
-      const float a1 = aRows ? sA[li * LDR + kb2] : sA[kb2 * 16 + li];
-      const float b1 = bRows ? sB[li * LDR + kb2] : sB[kb2 * 16 + li];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  GSTAMP(26);
-  // ---- cross-wave reduction of the 4 partial tiles ----
-#pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
-  __syncthreads();
-  const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-  GSTAMP(27);
-  if (!outOk) return;
-
-  if (epi == EPI_FWD) {
-    const float x = v + e0;
-    P.C[(size_t)m * P.ldc + n] = x;
-    const float y = actEval(P.func, x);
-    P.C2[(size_t)m * P.ldc + n] = y;
-    if (P.C3) {
-      float r = y;
-      if (n < P.resN) r += e1 * e2 + e3;
-      P.C3[(size_t)m * P.ldc + n] = r;
-    }
-  } else if (epi == EPI_DX) {
-    float dres = v;
-    if (n < P.resN) dres += e1 * e2;
-    P.C[(size_t)m * P.ldc + n] = dres;
-    P.C2[(size_t)m * P.ldc + n] = dres * actDiff(P.func, e0, e3);
-  } else if (epi == EPI_DW && FL < 0 && P.nSplit > 1) {
-    P.part[((size_t)ks * P.M + m) * P.N + n] = v;
-  } else if (epi == EPI_DW) {
-    if (m < P.M - 1) {
-      const size_t i = (size_t)m * P.ldc + n;
-      P.C[i] = v;
-      if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adW[i] = e0; P.adM1[i] = e1; P.adM2[i] = e2; }
-    } else {
-      P.biasOut[n] = v;
-      if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adbW[n] = e0; P.adbM1[n] = e1; P.adbM2[n] = e2; }
-    }
-  } else {
-    P.C[(size_t)m * P.ldc + n] = v;
-  }
-  GSTAMP(28);
-}
-
-// ROLE only names the instantiation (fwd0 / fwd / dx / dw) so that a kernel trace separates the four
-// launches of a step; the code is identical.
-constexpr int GEMM_LDS = (2 * 16 * LDR + 4 * 256) * 4;
 template <int ROLE>
 __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restrict__ probs, int nProbs,
                                                      const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra, ExtraArgs extra2) {
@@ -270,8 +27,10 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   // buffer) or by the tail code of the extra workgroup
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
   // horizontal fusion: workgroup 0 of the grid (dispatched first) runs a piece of the step tail
-  const int nRiders = (extra.role ? 1 : 0) + (extra2.role ? 1 : 0);
-  if ((int)blockIdx.x < nRiders) { runExtra(blockIdx.x == 0 ? extra : extra2, smem); return; }
+  // ... and, behind the riders, the workgroups that gather the minibatch a sampler rider found (PH_PUBLISH: extra.helpers of them)
+  const int nRid = (extra.role ? 1 : 0) + (extra2.role ? 1 : 0), nHelp = extra.role == 1 ? extra.helpers : 0, nRiders = nRid + nHelp;
+  if ((int)blockIdx.x < nRid) { runExtra(blockIdx.x == 0 ? extra : extra2, smem); return; }
+  if ((int)blockIdx.x < nRiders) { gatherHelper(extra.samp, blockIdx.x - nRid, nHelp, smem); return; }
   const int bid = blockIdx.x - nRiders;
   const int nRowsDyn = sc->nRows[hyp.parity];   // issued together with the problem-table fetch
   int p = 0;
@@ -340,6 +99,9 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
 #ifdef HL_TAIL_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 73) const_cast<DevScalars*>(sc)->dbgT[29] = wall_clock64();
+#endif
+#ifdef HL_STEP_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 73) const_cast<DevScalars*>(sc)->dbgStep[64 + (sc->sampleSeq & 63)] = wall_clock64();      // (sampleSeq: stable inside this launch)
 #endif
   // riders: the bookkeeping of this step, then the index -> (episode, step) search of the NEXT minibatch (drawn and sorted by the
   // rider of the fused kernel) and the workgroups that gather it -- the sampler's dependency chain is split over both kernels
@@ -516,7 +278,10 @@ hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlo
   if (nBlocks <= 0) return hipSuccess;
   ExtraArgs ex{}, ex2{}; if (extra) ex = *extra; if (extra2) ex2 = *extra2;
   if (!ex.role && ex2.role) { ex = ex2; ex2 = ExtraArgs{}; }
-  const dim3 grid(nBlocks + (ex.role ? 1 : 0) + (ex2.role ? 1 : 0)), block(256);
+  if (ex.role != 1 && ex2.role == 1) { const ExtraArgs t = ex; ex = ex2; ex2 = t; }      // (a sampler rider with helpers goes first)
+  if (ex2.role == 1) ex2.helpers = 0;
+  if (ex.role != 1) ex.helpers = 0;
+  const dim3 grid(nBlocks + (ex.role ? 1 : 0) + (ex2.role ? 1 : 0) + ex.helpers), block(256);
   switch (role) {
     case GEMM_ROLE_FWD0: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD0>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex, ex2); break;
     case GEMM_ROLE_FWD: hipLaunchKernelGGL(gemm16_kernel<GEMM_ROLE_FWD>, grid, block, 0, s, dProbs, nProbs, sc, hyp, ex, ex2); break;

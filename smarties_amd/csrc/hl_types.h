@@ -48,6 +48,7 @@ struct DevScalars {
   long long betaSeq;              // nGradSteps for which farBetaPhase has published beta / alpha (POST_DEFER)
   unsigned notifySeq;             // exact-size graphs replayed so far (their last node stores it into pinned host memory: hl_sync)
   long long dbgT[32];             // development: wall_clock64() stamps of the tail phases
+  long long dbgStep[128];         // development (-DHL_STEP_STAMPS): entry stamps of the two step kernels, by step number mod 64
 };
 
 // ---------------------------------------------------------------------------

@@ -219,6 +219,25 @@ hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlo
 hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s,
                                 const PostArgs* farBeta = nullptr);      // farBeta: a rider workgroup runs farBetaPhase (tail_dev.h)
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
+// forward chain + head + input-gradient chain of one minibatch panel per workgroup group, ONE launch (mlp_panel.hip): the generic
+// counterpart of the fused kernel -- any stack of dense layers (or none: recurrent nets hand over the last block's output), any head
+struct PanelArgs {
+  HeadArgs h;
+  int nFwd; int fwdIdx[HL_MAX_HIDDEN];      // dense forward layers (problems in the device table), first to last
+  int nDx; int dxIdx[HL_MAX_HIDDEN];        // input-gradient problems behind the head, last layer first
+  int G;                                    // workgroups per 16-row panel (>= column tiles of every chained problem)
+  int nRiders;                              // rider workgroups in front of the panels (a multiple of 8: panels keep blockIdx % 8 == XCD)
+  unsigned* panelCtr;                       // [panels][32] arrive counters of the group barrier (monotonic; zeroed by the host at start-up and every 1000th step)
+  int deferBeta;                            // 1: beta of this step is published by a rider of this launch (farBetaPhase): the heads wait for DevScalars::betaSeq
+  unsigned long long boundedMask;           // bit i: action component i is bounded (the kernel serves dA <= 32; indexing HeadArgs::bounded per lane
+                                            // would make the compiler walk the kernel arguments lane by lane)
+};
+bool mlp_panel_ok(const HeadArgs& a);       // shapes the panel kernel serves (the others keep head_kernel_t and the per-layer launches)
+size_t mlp_panel_lds_bytes(const HeadArgs& a);
+int mlp_panel_blocks(const PanelArgs& pa, int maxRows);
+// riders: extra in workgroup 0 (sampler phases of the next step), extra2 in workgroup 1, gather helpers (extra->helpers) behind them
+hipError_t launch_mlp_panel(const GemmProblem* dProbs, const PanelArgs& pa, int maxRows, const DevScalars* sc, const AdamHyper& hyp,
+                            const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 size_t fused_lds_bytes(int dS, int H);
 int fused_threads();

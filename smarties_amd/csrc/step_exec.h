@@ -307,7 +307,9 @@ void convSource(hl_learner* h, int parity, ConvArgs* ca) {
 }
 // `gather`: states with appended observations / convolutional input are assembled here, from the sampled slots
 // (rollout inference writes the standardised rows itself)
-int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true) {
+// `denseToo` = false: only what sits in front of the dense layers (stacked-state gather, convolutions) -- the dense layers
+// are then part of the panel kernel's launch (launchPanelStep)
+int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true, bool denseToo = true) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   char nm[32];
@@ -333,6 +335,7 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
     }
   }
+  if (!denseToo) return HL_OK;
   if (h->chainOk) {      // every dense layer in one launch, sampler phases A and B of the next step riding along
     ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
     if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
@@ -372,7 +375,34 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
       if (ex.helpers > 0 && !h->recurrent && !h->helperHandOff) ex.samp.selfSearch = 1;
     }
   }
+  if (h->panelHeadOk) {      // 16 samples per workgroup group, output layer on MFMA (mlp_panel.hip), no chained layers
+    PanelArgs pa{}; pa.h = ha; pa.G = h->panelHeadG; pa.panelCtr = h->panelCtrP;
+    for (int i = 0; i < h->dA && i < 64; ++i) if (h->cfg.bounded[i]) pa.boundedMask |= 1ull << i;
+    pa.nRiders = pex ? (int)roundUp(2 + ex.helpers, 8) : 0;
+    const AdamHyper hyp = adamHyper(h, parity);
+    HIPCK(timed(h, "head_kernel", s, [&] { return launch_mlp_panel(h->dProbs, pa, h->Mmax, h->sc, hyp, pex, nullptr, s); }));
+    return HL_OK;
+  }
   HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
+  return HL_OK;
+}
+// Dense layers forward + head + input gradients down the stack as ONE launch (mlp_panel.hip): with the weight-gradient launch
+// behind it, the two-kernel step of every dense network off the fused path.  `nextSample`: the sampler of the NEXT step rides along
+// (draws and sort; with convolutional preprocessing -- no gathered rows -- the whole sampler); `deferBeta`: the step before left its
+// far-policy count and beta update to a rider of this launch, the heads wait for it (as in launchFused)
+int launchPanelStep(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool deferBeta = false) {
+  const AdamHyper hyp = adamHyper(h, parity);
+  const StepBuf& sb = h->buf[parity];
+  PanelArgs pa{}; pa.h = headArgs(h, parity); pa.G = h->panelG; pa.panelCtr = h->panelCtrP;
+  for (int i = 0; i < h->dA && i < 64; ++i) if (h->cfg.bounded[i]) pa.boundedMask |= 1ull << i;
+  const int j0 = h->nConv > 0 ? 1 : 0;
+  for (int j = j0; j < h->nHidden; ++j) pa.fwdIdx[pa.nFwd++] = sb.fwdIdx[j];
+  for (size_t i = 0; i < sb.dxIdx.size(); ++i) pa.dxIdx[pa.nDx++] = sb.dxIdx[i];
+  ExtraArgs ex{}, ex2{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pex2 = nullptr;
+  if (nextSample) { ex = extraSample(h, parity ^ 1, h->preproc ? PH_ALL : (PH_A | PH_B)); pex = &ex; }
+  if (deferBeta) { pa.deferBeta = 1; ex2.role = 3; ex2.post = postArgs(h, parity ^ 1, POST_BETA); pex2 = &ex2; }
+  pa.nRiders = (pex || pex2) ? 8 : 0;
+  HIPCK(timed(h, "mlp_panel", s, [&] { return launch_mlp_panel(h->dProbs, pa, h->Mmax, h->sc, hyp, pex, pex2, s); }));
   return HL_OK;
 }
 // fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
@@ -391,14 +421,19 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
     HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s, nextSampleC ? &exC : nullptr); }));
     return HL_OK;
   }
+  // (more problems than the argument table holds: the table in device memory; the same riders, the gather helpers behind them)
+  if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; exC.samp.selfSearch = 1; }
   HIPCK(timed(h, "gemm16_dw", s, [&] {
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp,
                        nextSampleC ? &exC : nullptr, s, fusePost ? &exP : nullptr); }));
   return HL_OK;
 }
-int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA) {
+// `dxInPanel`: the input-gradient problems of the dense layers were part of the panel kernel's launch (launchPanelStep)
+int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA, bool dxInPanel = false) {
   const AdamHyper hyp = adamHyper(h, parity);
-  const StepBuf& sb = h->buf[parity];
+  StepBuf sbLocal = h->buf[parity];
+  if (dxInPanel) { sbLocal.dxIdx.clear(); sbLocal.dxBlocks.clear(); }
+  const StepBuf& sb = sbLocal;
   ExtraArgs ex{}, exF{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pexF = nullptr;
   // one replica, bookkeeping riding the first dX launch: its far-policy count and the beta update move on to the dW launch (the next
   // reader of beta is the head kernel of the step after), off what was that launch's longest workgroup
@@ -603,6 +638,12 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
     HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));
     return launchBackward(h, parity, fuseAdam, s);       // no dX problems for this layout: the dW launch only
   }
+  if (h->panelStepOk) {      // dense layers, head and input gradients in one launch; then the weight gradients
+    int rc = launchForward(h, parity, s, false, true, false); if (rc) return rc;
+    rc = launchPanelStep(h, parity, s); if (rc) return rc;
+    if (!h->preproc) return launchWeightGrad(h, parity, fuseAdam, s, false, false);
+    return launchBackward(h, parity, fuseAdam, s, false, POST_AGG | POST_BETA, true);
+  }
   int rc = launchForward(h, parity, s); if (rc) return rc;
   rc = launchHead(h, parity, s); if (rc) return rc;
   return launchBackward(h, parity, fuseAdam, s);
@@ -662,11 +703,12 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   const long long nColl0 = h->nCollectives;      // captured calls are counted when the graph is replayed
   for (int j = 0; j < U && !rc; ++j) {
     const int p = (p0 + j) & 1;
-    if (h->fusedOk) {
+    const bool twoKernel = h->fusedOk || (h->panelStepOk && !h->preproc);
+    if (twoKernel) {
       // one replica: the far-policy count and the beta update of every step but the last are taken out of the dW launch's
       // bookkeeping rider, where they sat at the end of the kernel's longest workgroup, into a rider of the next fused kernel
       const bool single = !exchanging(h) && !h->noDeferBeta;
-      rc = launchFused(h, p, s0, true, single && j > 0); if (rc) break;
+      rc = h->fusedOk ? launchFused(h, p, s0, true, single && j > 0) : launchPanelStep(h, p, s0, true, single && j > 0); if (rc) break;
       if (!exchanging(h)) {
         rc = launchWeightGrad(h, p, true, s0, true, true, POST_AGG | POST_BETA | (single && j + 1 < U ? POST_DEFER : 0)); if (rc) break;
         continue;
@@ -690,11 +732,14 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
       if (launch_rec_forward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_forward"); break; }
       rc = launchHead(h, p, s0, true); if (rc) break;
       if (launch_rec_backward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_backward"); break; }
+    } else if (h->panelStepOk) {      // convolutional front, then dense layers + head + their input gradients as one launch
+      rc = launchForward(h, p, s0, false, true, false); if (rc) break;
+      rc = launchPanelStep(h, p, s0, true); if (rc) break;
     } else {
       rc = launchForward(h, p, s0, true); if (rc) break;
       rc = launchHead(h, p, s0, true); if (rc) break;
     }
-    rc = launchBackward(h, p, !exch, s0, true, exch ? POST_AGG : (POST_AGG | POST_BETA)); if (rc) break;
+    rc = launchBackward(h, p, !exch, s0, true, exch ? POST_AGG : (POST_AGG | POST_BETA), h->panelStepOk && !h->recurrent); if (rc) break;
     if (exch) {
       if (h->xchg.on) { rc = xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p); if (rc) break; continue; }
       rc = allreduceGrad(h);
@@ -813,14 +858,14 @@ int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = fals
       return HL_OK;
     }
   }
-  if (h->eagerChain > 0 && avail <= h->eagerChain && h->fusedOk && !exchanging(h)) {
+  if (h->eagerChain > 0 && avail <= h->eagerChain && (h->fusedOk || (h->panelStepOk && !h->preproc)) && !exchanging(h)) {
     // short calls: the same two launches per step (riders included) issued directly -- no graph launch latency, no
     // first-launch cost of a graph that has not run yet
     if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
     const int U = (int)avail;
     for (int j = 0; j < U; ++j) {
       const int p = (p0 + j) & 1;
-      int rc = launchFused(h, p, h->stream, true); if (rc) return rc;
+      int rc = h->fusedOk ? launchFused(h, p, h->stream, true) : launchPanelStep(h, p, h->stream, true); if (rc) return rc;
       rc = launchWeightGrad(h, p, true, h->stream, true, true); if (rc) return rc;
     }
     h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;

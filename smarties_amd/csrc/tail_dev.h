@@ -460,8 +460,10 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
   DevScalars* sc = a.sc;
   TSTAMP(sc, 0);
   const int B = a.B;
-  int Bp = 256; while (Bp < B) Bp <<= 1;
-  const int K = Bp / 256;
+  // sort network of nextpow2(B) elements, 64 (one wavefront, no barriers) at least: at a local batch of 32 -- one Humanoid
+  // replica of eight -- the 256-element network was the longest chain of the launch this rider sits in
+  int Bp = 64; while (Bp < B) Bp <<= 1;
+  const int K = (Bp + 255) / 256;
   const bool rngNeeded = (phases & (PH_A | PH_B)) != 0;
   if (rngNeeded) {
     const bool bak = a.backupRng && (phases & PH_A);
@@ -606,8 +608,7 @@ __device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int 
     int* sWave = sNextRow + SMAXB;                                                 // [4]
     const unsigned long long nData = (unsigned long long)sc->nTransitions;
     const int nEp = (int)sc->nEpisodes;
-    int Bp = 256; while (Bp < B) Bp <<= 1;
-    const int K = Bp / 256;
+    const int K = (B + 255) / 256;
     bool hasNext[SMAXK]; int nextIdx[SMAXK];
     for (int r = 0; r < K; ++r) {
       const int b = r * 256 + tid;
