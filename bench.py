@@ -178,7 +178,8 @@ def cpu_baseline(steps_budget_s=20.0):
                     long_run = False
         if best is not None:
             return {"value": best["transitions_per_s"], "unit": "transitions/s", "cores": int(best["threads"]),
-                    "kind": "reference",
+                    "kind": "reference", "blas": "none (the reference's own OpenMP-SIMD loops: neither USE_MKL nor USE_OPENBLAS, as in its CMake build)",
+                    "march": "x86-64-v3", "flags": "-O3 -ffast-math -fopenmp -DSINGLE_PREC",
                     "sample": "compiled reference (oracle/_ref, -O3 -ffast-math, OpenMP) on a 1M-transition synthetic replay of "
                               "the same shape and distributions: 400-step probes at threads=%s on %d host CPUs, then %s at the best count"
                               % ([t for t, _ in tried], ncpu, "6000 gradient steps after 100 warm-up" if long_run else "(long run failed) the probe"),
@@ -264,89 +265,107 @@ def main():
     # replicas reach their first collectives seconds apart (set-up, graph capture): a generous bound for the exchange kernel's wait
     os.environ.setdefault("SMARTIES_HIP_XCHG_TIMEOUT_MS", "60000")
     api = load_hip()
-    cfg = capi.make_config(n_ranks=n_ranks, rank=rank, device_id=local_rank % ndev, **CFG)
-    per = N_EPISODES // n_ranks
+    state = {"host_exchange": host_exchange, "host_group": None}
 
-    def make_learner():
-        L_ = capi.Learner(api, cfg)
-        L_.init_weights()
-        t_ = time.time()
-        for e in range(rank * per, (rank + 1) * per):
-            L_.append_episode(**synthetic_episode(np, e))
-        return L_, time.time() - t_
+    def build(cfg_kw, n_episodes):
+        """learner of this rank for the configuration cfg_kw (batch and replay budget are GLOBAL figures, split over the replicas
+        as Settings/HyperParameters.cpp:186-197 does), filled with its share of n_episodes synthetic episodes, replicas connected"""
+        cfg = capi.make_config(n_ranks=n_ranks, rank=rank, device_id=local_rank % ndev, **cfg_kw)
+        per = n_episodes // n_ranks
 
-    L, t_fill = make_learner()
-    transport = "single replica"
-    if n_ranks > 1 and not host_exchange:
-        # 1st choice: the library's own one-kernel exchange through peer-mapped windows (xchg.hip; handles travel through the
-        # process group); 2nd: its RCCL communicator; 3rd: sums on the host (gloo).  Every decision is taken by ALL ranks.
-        pg_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        def make_learner():
+            L_ = capi.Learner(api, cfg)
+            L_.init_weights()
+            t_ = time.time()
+            for e in range(rank * per, (rank + 1) * per):
+                L_.append_episode(**synthetic_episode(np, e))
+            return L_, time.time() - t_
 
-        def all_ok(ok):
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=pg_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return int(flag.item()) == 1
+        L, t_fill = make_learner()
+        transport = "single replica"
+        if n_ranks > 1 and not state["host_exchange"]:
+            # 1st choice: the library's own one-kernel exchange through peer-mapped windows (xchg.hip; handles travel through the
+            # process group); 2nd: its RCCL communicator; 3rd: sums on the host (gloo).  Every decision is taken by ALL ranks.
+            pg_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
 
-        want = os.environ.get("SMARTIES_BENCH_EXCHANGE", "")
-        done = False
-        if want in ("", "xchg"):
-            hd = None
-            try:
-                hd = L.xchg_export()
-            except Exception as e:  # noqa: BLE001
-                print("rank %d: hl_xchg_export failed (%s)" % (rank, e), file=sys.stderr)
-            hs = [None] * n_ranks
-            dist.all_gather_object(hs, hd)
-            ok = all(h is not None for h in hs)
-            if ok:
+            def all_ok(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=pg_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+
+            want = os.environ.get("SMARTIES_BENCH_EXCHANGE", "")
+            done = False
+            if want in ("", "xchg"):
+                hd = None
                 try:
-                    L.xchg_connect(hs)
+                    hd = L.xchg_export()
+                except Exception as e:  # noqa: BLE001
+                    print("rank %d: hl_xchg_export failed (%s)" % (rank, e), file=sys.stderr)
+                hs = [None] * n_ranks
+                dist.all_gather_object(hs, hd)
+                ok = all(h is not None for h in hs)
+                if ok:
+                    try:
+                        L.xchg_connect(hs)
+                    except Exception as e:  # noqa: BLE001
+                        ok = False
+                        print("rank %d: hl_xchg_connect failed (%s)" % (rank, e), file=sys.stderr)
+                done = all_ok(ok)
+                if done:
+                    transport = "one-kernel exchange through peer-mapped windows over xGMI (xchg.hip), a node of the replayed graphs"
+                elif ok:                       # (connected here, not everywhere: start over with a clean learner)
+                    L.close()
+                    L, t_fill = make_learner()
+            if not done:
+                ok = True
+                try:
+                    idbuf = torch.zeros(128, dtype=torch.uint8, device=pg_dev)
+                    if rank == 0:
+                        import ctypes as C
+                        raw = (C.c_uint8 * 128)()
+                        assert api.fn("comm_unique_id")(raw) == 0
+                        idbuf = torch.tensor(list(raw), dtype=torch.uint8, device=pg_dev)
+                    dist.broadcast(idbuf, 0)
+                    L.comm_init(bytes(idbuf.cpu().tolist()))
                 except Exception as e:  # noqa: BLE001
                     ok = False
-                    print("rank %d: hl_xchg_connect failed (%s)" % (rank, e), file=sys.stderr)
-            done = all_ok(ok)
-            if done:
-                transport = "one-kernel exchange through peer-mapped windows over xGMI (xchg.hip), a node of the replayed graphs"
-            elif ok:                       # (connected here, not everywhere: start over with a clean learner)
-                L.close()
-                L, t_fill = make_learner()
-        if not done:
-            ok = True
-            try:
-                idbuf = torch.zeros(128, dtype=torch.uint8, device=pg_dev)
-                if rank == 0:
-                    import ctypes as C
-                    raw = (C.c_uint8 * 128)()
-                    assert api.fn("comm_unique_id")(raw) == 0
-                    idbuf = torch.tensor(list(raw), dtype=torch.uint8, device=pg_dev)
-                dist.broadcast(idbuf, 0)
-                L.comm_init(bytes(idbuf.cpu().tolist()))
-            except Exception as e:  # noqa: BLE001
-                ok = False
-                print("rank %d: RCCL communicator of the library failed (%s): host exchange instead" % (rank, e), file=sys.stderr)
-            if all_ok(ok):
-                transport = "RCCL inside the library (captured in the replayed graphs)"
-            else:
-                host_exchange = True
-                host_group = dist.new_group(backend="gloo")
-                L.close()
-                L, t_fill = make_learner()
+                    print("rank %d: RCCL communicator of the library failed (%s): host exchange instead" % (rank, e), file=sys.stderr)
+                if all_ok(ok):
+                    transport = "RCCL inside the library (captured in the replayed graphs)"
+                else:
+                    state["host_exchange"] = True
+                    state["host_group"] = dist.new_group(backend="gloo")
+                    L.close()
+                    L, t_fill = make_learner()
+        if n_ranks > 1 and state["host_exchange"]:
+            from smarties_amd import dist_host
+            dist_host.init_replica_weights(L, dist, group=state["host_group"])
+        L.initialize()
+        return L, t_fill, transport
+
+    L, t_fill, transport = build(CFG, N_EPISODES)
+    host_exchange, host_group = state["host_exchange"], state["host_group"]
     if n_ranks > 1 and host_exchange:
         from smarties_amd import dist_host
-        dist_host.init_replica_weights(L, dist, group=host_group)
-    L.initialize()
 
-    def run(n):
+    def run(n, Lx=None):
+        Lx = Lx or L
         if n_ranks > 1 and host_exchange:
-            dist_host.step_host_exchange(L, dist, n, group=host_group)
+            dist_host.step_host_exchange(Lx, dist, n, group=host_group)
         else:
-            L.step(n)
+            Lx.step(n)
 
-    def barrier():
+    def barrier(Lx=None):
         if n_ranks > 1:
             dist.barrier()
-        L.sync()                     # the library's own stream (a completion stamp polled in pinned memory when the call was one graph)
-        torch.cuda.synchronize()     # ... and the whole device
+        # the whole device first: torch.cuda.synchronize() queues the completion marker of the library's stream WHILE the call's
+        # kernels still run; after hl_sync's polled completion word it would start that round trip only then (tools/sync_cost.py:
+        # 375.6 against 382.0 us per 20-step call)
+        if os.environ.get("SMARTIES_BENCH_POLL_FIRST"):
+            (Lx or L).sync(); torch.cuda.synchronize()
+            return
+        torch.cuda.synchronize()     # the whole device ...
+        (Lx or L).sync()             # ... and the library's own stream (a completion stamp polled in pinned memory when the call was one graph)
 
     # ---- roofline of the dominant kernel ---------------------------------------------------------------
     def roofline(L):
@@ -463,8 +482,45 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "transitions/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %s" % e}
+    # N > 1: the same steps with batch 256 and a 1M-transition replay PER REPLICA (weak scaling: what a replica of BASELINE config 3
+    # sees -- the global batch grows with the replicas, Settings/HyperParameters.cpp:186-197 splits it back to 256 each), next to
+    # the strong-scaling value.  Outside `value`; measured last, under a watchdog that prints the line without it.
+    if n_ranks > 1 and os.environ.get("SMARTIES_BENCH_WEAK", "1") != "0":
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["weak_scaling_row"] = {"scaling": "weak", "error": "did not finish within %d s" % PROBE_SECONDS}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(PROBE_SECONDS, bail); wd.daemon = True; wd.start()
+        try:
+            L.close()
+            wk = dict(CFG, batchSize=CFG["batchSize"] * n_ranks, maxTotObsNum=CFG["maxTotObsNum"] * n_ranks)
+            L, _, tw = build(wk, N_EPISODES * n_ranks)
+            host_exchange, host_group = state["host_exchange"], state["host_group"]
+            if not host_exchange:
+                if args.warmup > 0:
+                    L.prepare_steps(args.warmup)
+                L.prepare_steps(args.steps)
+            run(args.warmup); barrier()
+            tw0 = time.perf_counter(); run(args.steps); barrier(); dtw = time.perf_counter() - tw0
+            t = torch.tensor([dtw], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtw = float(t.item())
+            weak = {"scaling": "weak", "value": wk["batchSize"] * args.steps / dtw, "unit": "transitions/s", "ms_per_step": dtw / args.steps * 1e3,
+                    "global_batch": wk["batchSize"], "replay_transitions": wk["maxTotObsNum"], "per_replica_batch": CFG["batchSize"], "exchange": tw}
+        except Exception as e:  # noqa: BLE001
+            weak = {"scaling": "weak", "error": str(e)}
+        wd.cancel()
+        if rank == 0:
+            out["weak_scaling_row"] = weak
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    L.close()
+    try:
+        L.close()
+    except Exception:  # noqa: BLE001
+        pass
     if n_ranks > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,6 +42,15 @@ namespace hl {
 #define FSTAMP(i) do { } while (0)
 #endif
 
+// (-DHL_FSTAMPS) when does the LAST workgroup of each kind finish?  dbgT[20] ordinary panels, [21] panels with next-state rows (they
+// start with a dependent load of the row count), [22] the sampler rider, [23] the far-policy / beta rider -- maxima of a monotonic clock:
+// after a call they belong to its last launch, like the entry stamp dbgT[31]
+#if defined(HL_FSTAMPS)
+#define FEND(i) do { __syncthreads(); if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&a.sc->dbgT[i]), (unsigned long long)wall_clock64()); } while (0)
+#else
+#define FEND(i) do { } while (0)
+#endif
+
 // development: stop after phase n (tools/ktime4.py; library built with HL_EXTRA_FLAGS=-DHL_DEV) -- compiled out otherwise
 #ifdef HL_DEV
 #define FVARIANT_STOP(n) do { if (a.variant == (n)) return; } while (0)
@@ -129,8 +138,8 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
   if (blockIdx.x < 8) {
     if (threadIdx.x >= 256) return;            // the tail code is written for 256 threads
     // the sampler runs in block 0; with PH_PUBLISH its gather is spread over blocks 1..7
-    if (blockIdx.x == 0) { if (extra.role == 1) samplePhases(extra.samp, extra.phases, smem); }      // (the bookkeeping never rides here: its register needs exceed this kernel's 128)
-    else if (blockIdx.x == 1 && a.deferBeta) farBetaPhase(extra.post, smem);      // what the bookkeeping of the step before left over
+    if (blockIdx.x == 0) { if (extra.role == 1) { samplePhases(extra.samp, extra.phases, smem); FEND(22); } }      // (the bookkeeping never rides here: its register needs exceed this kernel's 128)
+    else if (blockIdx.x == 1 && a.deferBeta) { farBetaPhase(extra.post, smem); if (threadIdx.x == 0) a.sc->dbgT[23] = wall_clock64(); }      // what the bookkeeping of the step before left over
     else if (extra.role == 1 && (extra.phases & PH_PUBLISH)) gatherHelper(extra.samp, blockIdx.x - 1, 7, smem);
     return;
   }
@@ -624,6 +633,7 @@ __global__ __launch_bounds__(NT, NT / 128) void fused_fwd_head_dx_kernel(FusedAr
     a.D1[(size_t)row * ldA0 + n0 + en] = dres * f1;
   }
   FSTAMP(13);
+  FEND(m0 + 16 > a.B ? 21 : 20);
 }
 
 template <int H, int CF>

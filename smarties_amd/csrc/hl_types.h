@@ -167,6 +167,9 @@ struct GemmProblem {
   // update, adamRed -- by splitk_reduce_kernel (gemm16.hip)
   int nSplit, adamRed;
   float* part;
+  // GEMM_W with a short reduction (K <= 128 minibatch rows) and many columns: 16 x 64 strips, one 16 x 16 tile per wavefront with the
+  // whole reduction -- a quarter of the workgroups, no cross-wave join (gemm_tile.h: gemmStripW; tilesN counts strips then)
+  int strip;
 };
 
 struct AdamHyper { float eta0, lambda, fac; double epsAnneal; int parity; /* minibatch buffer of this step */

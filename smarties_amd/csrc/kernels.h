@@ -240,6 +240,11 @@ hipError_t launch_mlp_panel(const GemmProblem* dProbs, const PanelArgs& pa, int 
                             const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 size_t fused_lds_bytes(int dS, int H);
+// the same step for two-hidden-layer nets with wide states (first layer streamed in slabs) and any head of head_rows.h (fusedw.hip)
+hipError_t launch_fused_wide(const FusedArgs& a, const HeadArgs& ha, int maxRows, const ExtraArgs* extra, hipStream_t s);
+bool fused_wide_ok(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int comps);
+size_t fused_wide_lds_bytes(int dS, int H, int nDense, int nOut, int ldWo, int nAdv);
+int fused_wide_threads();
 int fused_threads();
 hipError_t launch_post(const PostArgs& a, hipStream_t s);
 hipError_t launch_empty(hipStream_t s);

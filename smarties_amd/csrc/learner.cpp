@@ -126,6 +126,8 @@ struct hl_learner {
   // and its last node stamps a pinned host word, which hl_sync polls (tools/call_bench.hip)
   std::map<int, std::array<GraphSlot, 2>> exactGraphs;
   unsigned* notifyPin = nullptr; unsigned notifyIssued = 0; mutable bool tailNotify = false;
+  hipEvent_t tailEvent = nullptr; int tailEventMode = 0;      // SMARTIES_HIP_TAIL_EVENT=1 (experiment): an event recorded behind a whole-call graph, so that the queue's completion marker is
+                                                              // already in flight when the caller synchronises the device
   int lastCallN = 0, sameCallN = 0;
   // the sampler of step k+1 rides along step k, also along the LAST step of a replayed graph: the next call finds its
   // minibatch ready in buffer preParity.  Whatever changes what a sampler sees (new episodes, evictions, explicit
@@ -141,6 +143,7 @@ struct hl_learner {
   // panel kernel (mlp_panel.hip): panelHeadOk -- it serves the head of this network (16 samples per workgroup group, output layer
   // on MFMA) in place of head_kernel_t; panelStepOk -- dense layers forward, head and input gradients go out as ONE launch
   bool panelHeadOk = false, panelStepOk = false; int panelHeadG = 1, panelG = 1; unsigned* panelCtrP = nullptr;
+  bool fusedWideOk = false;  // two equal hidden blocks with a wide state and / or a head beyond the fused kernel's: fusedw.hip takes the two-kernel step
   int dbgVariant = 0;
   // rccl
   ncclComm_t comm = nullptr;
@@ -704,12 +707,35 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(hipStreamSynchronize(nullptr));
     }
   }
+  if (!h->fusedOk && h->nHidden == 2 && !h->recurrent && !h->preproc && getenv("SMARTIES_HIP_NO_FUSED_WIDE") == nullptr) {
+    // the wide variant of the fused kernel (fusedw.hip): same placement, same probe
+    const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
+    const int comps = h->nOpt ? h->nOpt : h->dA;
+    bool ok = d0.size == d1.size && !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
+              fused_wide_ok(h->dS, d1.size, h->nDense, h->nOut, h->ldWo, cfg->adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0, comps);
+    if (ok) {
+      const int HT = d1.size / 16, panels = (h->Mmax + 15) / 16, pg = (panels + 7) / 8, nBlk = 8 + 8 * HT * pg;
+      int* dX = nullptr; HIPCK(devAlloc(&dX, (size_t)nBlk));
+      HIPCK(launch_xcc_probe(nBlk, fused_wide_threads(), fused_wide_lds_bytes(h->dS, d1.size, h->nDense, h->nOut, h->ldWo, cfg->adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0), dX, h->stream));
+      std::vector<int> xcc((size_t)nBlk);
+      HIPCK(hipMemcpyAsync(xcc.data(), dX, xcc.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCK(hipStreamSynchronize(h->stream)); hipFree(dX);
+      for (int b = 8; b < nBlk; ++b) ok = ok && xcc[(size_t)b] == xcc[(size_t)(8 + ((b - 8) & 7))];
+      const char* f = getenv("SMARTIES_HIP_PANEL_SAFE");
+      ok = ok && !(f && f[0] == '1');
+    }
+    if (ok) {
+      const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
+      HIPCK(devAlloc(&h->panelCtr, nCtr));
+      h->fusedWideOk = true;
+    }
+  }
   { const char* nd = getenv("SMARTIES_HIP_NO_DEFER_BETA"); h->noDeferBeta = nd && nd[0] == '1'; }
   { const char* nd = getenv("SMARTIES_HIP_HELPER_HANDOFF"); h->helperHandOff = nd && nd[0] == '1'; }
   { const char* nd = getenv("SMARTIES_HIP_NO_CONV_REPLAY"); h->noConvReplay = nd && nd[0] == '1'; }
   // networks off the fused path with two or more dense layers (short reductions): one forward launch if the groups of its
   // panels run where the kernel assumes (same probe as above, with that kernel's geometry)
-  if (!h->fusedOk && !h->recurrent) {
+  if (!h->fusedOk && !h->fusedWideOk && !h->recurrent) {
     const int j0 = h->nConv > 0 ? 1 : 0;
     const char* nc = getenv("SMARTIES_HIP_NO_FWD_CHAIN");
     bool ok = h->nHidden - j0 >= 2 && !(nc && nc[0] == '1');
@@ -808,6 +834,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   rc = buildProblems(h); if (rc) return rc;
   if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) h->useGraph = !(e[0] == '1');
+  if (const char* e = getenv("SMARTIES_HIP_TAIL_EVENT")) h->tailEventMode = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_EAGER_CHAIN")) h->eagerChain = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_XCHG_TIMEOUT_MS")) h->xchgTimeoutTicks = std::max(1LL, atoll(e)) * 100000LL;
   if (const char* e = getenv("SMARTIES_HIP_NO_EXCH_GRAPH")) h->exchGraph = !(e[0] == '1');   // replicas: eager exchanges only
@@ -823,6 +850,7 @@ int hl_destroy(hl_learner* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->actPin) hipHostFree(h->actPin);
   if (h->notifyPin) hipHostFree(h->notifyPin);
+  if (h->tailEvent) hipEventDestroy(h->tailEvent);
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
   for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,

@@ -21,6 +21,7 @@
 // setValues (MiniBatch.h:161-175), Layer::backward (Layers.h:123-160).  The arithmetic of the head is head.hip's (the
 // one-wavefront-per-sample kernel this replaces and which stays as the fall-back for shapes outside mlp_panel_ok).
 #include "gemm_tile.h"
+#include "head_rows.h"
 
 namespace hl {
 
@@ -79,43 +80,6 @@ __device__ __forceinline__ void panelBarrier(unsigned* ctr, int G, DevScalars* s
   __syncthreads();
 }
 
-__device__ __forceinline__ double spD64(double x) { return (x + sqrt(1 + x * x)) / 2; }            // SoftPlus::_eval (Functions.h:541-584)
-__device__ __forceinline__ double spDiff64(double x) { return (1 + x / sqrt(1 + x * x)) / 2; }
-
-// output layer of the panel: wave `wave` takes hidden units [wave KW, (wave + 1) KW), NT column tiles of 16 outputs; partial
-// tiles -> red[(wave NT + t)][16 x 16].  pA: this lane's row of the Y panel at its first k; pB: W_out row of that k at output
-// column min(li, ldWo - 1) -- columns beyond ldWo feed result columns nobody reads
-template <int NT>
-__device__ __forceinline__ void panelOutMma(const float* pA, const float* sWoK, int ldWo, int li, int steps, float* redW) {
-  f32x4 acc[NT];
-  const float* pB[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; const int o = t * 16 + li; pB[t] = sWoK + (o < ldWo ? o : ldWo - 1); }
-  const int stride = 4 * ldWo;
-  constexpr int UN = NT <= 2 ? 8 : 4;             // steps whose operands are in flight together (one exposed LDS latency per batch)
-  for (int s0 = 0; s0 < steps; s0 += UN) {
-    float av[UN], bv[NT][UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int sc_ = s0 + u < steps ? s0 + u : steps - 1;      // (clamped: no predicated loads; the surplus steps multiply by zero)
-      av[u] = pA[4 * sc_];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t][u] = pB[t][(size_t)sc_ * stride];
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const float a_ = s0 + u < steps ? av[u] : 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv[t][u], acc[t], 0, 0, 0);
-    }
-  }
-  const int lane = threadIdx.x & 63, lc = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) redW[t * 256 + (lc * 4 + r) * 16 + li] = acc[t][r];
-  }
-}
 
 // NCH: chunks of 16 action components / options per sample row (1: <= 16, 2: <= 32)
 template <int NCH>
@@ -160,31 +124,18 @@ __global__ __launch_bounds__(256) void mlp_panel_kernel(const GemmProblem* __res
   float* sWoT = reinterpret_cast<float*>(smem + g.offWo);
   const int LY = g.LY, LW = g.LW, LD = g.LD, LO = g.LO, NT = g.NT, Hp = g.Hp;
 
+  // ---- the first forward layer's weight tile: the longest cold fetch of the launch goes out first ------------------------------
+  GemmProblem Pf{}; TileB tbf; bool haveF = false;
+  if (pa.nFwd > 0) { Pf = probs[pa.fwdIdx[0]]; if (n < Pf.tilesN) { gemmLoadB(Pf, panel * Pf.tilesN + n, tbf); haveF = true; } }
+
   // ---- loads that depend on nothing this launch computes, issued before the forward chain: the sample's replay rows
   // (dependent chain next-row map -> slot -> action / behaviour policy / per-step fields) ... ------------------------------------
   const int row = m0 + em;
   const bool rowValid = row < nRows, isNext = rowValid && row >= B, live = rowValid && !isNext;
   int b = 0; long long slot = 0;
   if (rowValid) { b = isNext ? a.bt.nextSrc[row - B] : row; slot = a.bt.slot[b]; }
-  double act[NCH], bMean[NCH], bStd[NCH];
-#pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    const int c = en + 16 * j;
-    act[j] = 0; bMean[j] = nOpt ? 1.0 : 0.0; bStd[j] = 1;
-    if (live) {
-      if (nOpt) { if (c < nOpt) bMean[j] = a.rp.MU[(size_t)slot * nOpt + c]; }       // behaviour probability of option c
-      else if (c < dA) { act[j] = a.rp.A[(size_t)slot * dA + c]; bMean[j] = a.rp.MU[(size_t)slot * 2 * dA + c]; bStd[j] = a.rp.MU[(size_t)slot * 2 * dA + dA + c]; }
-    }
-  }
-  double actMsg = 0;
-  if (live && nOpt && en == 0) actMsg = a.rp.A[slot];                                 // discrete head: the action message (label + 0.1)
-  float misc = 0.f;
-  if (rowValid) {   // lanes 0..5: RET, DQ, DKL, IMPW, V, ADV of the sampled step; next rows: lanes 6, 7: V, ADV of t+1
-    const float* arr = nullptr; long long sl = slot;
-    if (!isNext) arr = en == 0 ? a.rp.RET : en == 1 ? a.rp.DQ : en == 2 ? a.rp.DKL : en == 3 ? a.rp.IMPW : en == 4 ? a.rp.V : en == 5 ? a.rp.ADV : nullptr;
-    else { arr = en == 6 ? a.rp.V : en == 7 ? a.rp.ADV : nullptr; sl = slot + 1; }
-    if (arr) misc = arr[sl];
-  }
+  HeadRow<NCH> hr;
+  hr.load(a, rowValid, isNext, slot, en);
   float bov[PN_MAXNT];
 #pragma unroll
   for (int t = 0; t < PN_MAXNT; ++t) { const int o = t * 16 + en; bov[t] = (t < NT && o < nDense) ? a.params[a.indBo + o] : 0.f; }
@@ -211,43 +162,23 @@ __global__ __launch_bounds__(256) void mlp_panel_kernel(const GemmProblem* __res
   PSTMP(1);
   // ---- forward chain: this workgroup's column tile of every dense layer, the group meets between layers -------------------------
   // (the weight tile of layer l + 1 is requested in front of the barrier behind layer l: it depends on nothing layer l computes)
-  {
-    GemmProblem P{}; TileB tb; bool have = false;
-    if (pa.nFwd > 0) P = probs[pa.fwdIdx[0]];
-    for (int l = 0; l < pa.nFwd; ++l) {
-      if (n < P.tilesN) gemmTile<GEMM_ROLE_FWD, -1, true>(P, panel * P.tilesN + n, smem, sc, hyp, nRows, have ? &tb : nullptr);
-      have = false;
-      if (l + 1 < pa.nFwd) { P = probs[pa.fwdIdx[l + 1]]; if (n < P.tilesN) { gemmLoadB(P, panel * P.tilesN + n, tb); have = true; } }
-      panelBarrier(ctr, G, scw);
-    }
+  for (int l = 0; l < pa.nFwd; ++l) {
+    if (n < Pf.tilesN) gemmTile<GEMM_ROLE_FWD, GEMM_F, true>(Pf, panel * Pf.tilesN + n, smem, sc, hyp, nRows, haveF ? &tbf : nullptr);
+    haveF = false;
+    if (l + 1 < pa.nFwd) { Pf = probs[pa.fwdIdx[l + 1]]; if (n < Pf.tilesN) { gemmLoadB(Pf, panel * Pf.tilesN + n, tbf); haveF = true; } }
+    panelBarrier(ctr, G, scw);
   }
   PSTMP(2);
   // ---- the panel's rows of the last block's output -> LDS: one batch of loads (H <= 512: eight 16-byte loads per thread at most);
   // while they fly, the head terms that do not depend on this step's network outputs (the policy's standard deviation comes from
   // the ParamLayer bias alone; behaviour-policy terms from the replay rows requested at the top) ------------------------------------
-  const double MAXM = 8.31776613503286;
-  double stdev[NCH], invStd[NCH], dPos[NCH], bInv[NCH], invVarMu[NCH], u2[NCH], lq[NCH], CmuCpi[NCH]; bool bnd[NCH], onC[NCH];
   {
     const int H4 = Hp >> 2;                 // thread (em, en): row em of the panel, 16-byte columns en, en + 16, ... (H <= 512: eight at most)
     f32x4 v[8];
     const float* yRow = a.Yin + (size_t)(m0 + em) * a.ldY;
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const int c4 = en + 16 * u; v[u] = (c4 < H4 && rowValid) ? *reinterpret_cast<const f32x4*>(yRow + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int c = en + 16 * j; onC[j] = live && !nOpt && c < dA;
-      stdev[j] = 1; invStd[j] = 1; dPos[j] = 0; bInv[j] = 1; invVarMu[j] = 1; u2[j] = 0; lq[j] = 0; CmuCpi[j] = 1; bnd[j] = false;
-      if (onC[j]) {
-        bnd[j] = ((pa.boundedMask >> c) & 1ull) != 0;
-        const double pp = (double)bpv[j];
-        const double rt = sqrt(1 + pp * pp);
-        stdev[j] = (pp + rt) / 2; invStd[j] = 1 / stdev[j]; dPos[j] = (1 + pp / rt) / 2;
-        bInv[j] = 1 / bStd[j]; invVarMu[j] = 1 / (bStd[j] * bStd[j]);
-        u2[j] = (act[j] - bMean[j]) * bInv[j];
-        const double qq = stdev[j] * bInv[j];
-        lq[j] = log(qq); CmuCpi[j] = qq * qq;
-      }
-    }
+    hr.hoist(a, pa.boundedMask, bpv, live, en);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int c4 = en + 16 * u;
@@ -257,8 +188,8 @@ __global__ __launch_bounds__(256) void mlp_panel_kernel(const GemmProblem* __res
       }
     }
   }
-  if (en < 8) sMisc[em * 8 + en] = misc;
-  if (en == 0) sAct[em] = actMsg;
+  if (en < 8) sMisc[em * 8 + en] = hr.misc;
+  if (en == 0) sAct[em] = hr.actMsg;
   // beta of this step may still be on its way (POST_DEFER): first look now, the wait proper sits in front of the head
   if (pa.deferBeta && tid == 0) {
     double got = 0, ok = 0;
@@ -318,195 +249,14 @@ __global__ __launch_bounds__(256) void mlp_panel_kernel(const GemmProblem* __res
   if (pa.deferBeta) beta = sBeta[0];
   PSTMP(5);
 
-  // ---- head: thread = (sample em, component / option en + 16 j), fp64 --------------------------------------------------------------
+  // ---- head: thread = (sample em, component / option en + 16 j), fp64 (head_rows.h) -----------------------------------------------
   // every workgroup of the group holds the results of all 16 samples; workgroup (em mod min(G, 16)) publishes sample em
-  const int GW = G < 16 ? G : 16;
-  const bool writer = (em % GW) == n;
-  const double* O = sO + em * LO;
-  const double O0 = O[0];
-  if (rowValid && isNext) {     // RACER_train.cpp:23-27: V(s_{t+1}) of a truncated episode end
-    if (writer && en == 0) {
-      const float Vn = (float)scaleNet2V(O0);
-      a.bt.oldNextV[b] = sMisc[em * 8 + 6]; a.bt.oldNextADV[b] = sMisc[em * 8 + 7];
-      a.rp.V[slot + 1] = Vn; a.rp.ADV[slot + 1] = 0.f; a.bt.nextV[b] = Vn;
-      a.bt.O[(size_t)row * nOut] = O0;
-    }
-  }
   {
-    const double V = scaleNet2V(O0);
-    const double Qret = (double)sMisc[em * 8 + 0];
-    const float Cf = (float)Cmax, iCf = (float)Cinv;
-    double xRHO = 1, xDKL = 0, xdQ = 0, xAval = 0, xg0 = 0; bool xfar = false;
-    if (nOpt) {
-      // ---- discrete actions: Discrete_policy (SoftPlus-normalised probabilities) and Discrete_advantage; outputs
-      // [V | A x nOpt | logits x nOpt], option en + 16 j per lane ----
-      const int pA = 1, pP = 1 + nOpt;
-      const int label = (int)floor(sAct[em]);                                   // ActionInfo::actionMessage2label
-      double logit[NCH], advJ[NCH], unnorm[NCH]; bool on[NCH];
-      double su = 0;
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = en + 16 * j; on[j] = live && c < nOpt;
-        logit[j] = on[j] ? O[pP + c] : 0.0; advJ[j] = on[j] ? O[pA + c] : 0.0;
-        unnorm[j] = on[j] ? spD64(logit[j]) : 0.0; su += unnorm[j];
-      }
-      const double norm = fmax(sum16(su), 2.220446049250313e-16);
-      double pj[NCH], lr[NCH], sKl = 0, sEa = 0, sPl = 0, sMl = 0, sAl = 0, sTp = 0, tmp[NCH];
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = en + 16 * j;
-        pj[j] = unnorm[j] / norm;
-        const double mj = on[j] ? bMean[j] : 1.0;
-        lr[j] = on[j] ? log(pj[j] / mj) : 0.0;
-        sKl += on[j] ? pj[j] * lr[j] : 0.0; sEa += on[j] ? pj[j] * advJ[j] : 0.0;
-        const bool isL = on[j] && c == label;
-        sPl += isL ? pj[j] : 0.0; sMl += isL ? mj : 0.0; sAl += isL ? advJ[j] : 0.0;
-        tmp[j] = on[j] ? -(1 + lr[j]) / norm : 0.0; sTp += on[j] ? tmp[j] * pj[j] : 0.0;
-      }
-      const double RHO = sum16(sPl) / sum16(sMl);                                // importanceWeight (Discrete_policy.h:84-91), no clipping
-      const double DKL = sum16(sKl);                                             // KLDivergence (:126-130)
-      const float Wf = (float)RHO;
-      const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);
-      const double Aval = sum16(sAl) - sum16(sEa);                               // computeAdvantage (Discrete_advantage.h:64-70)
-      const double tp = sum16(sTp);
-      const double A_RET = Qret - V, dQ = A_RET - Aval;
-      const double g0 = far ? 0.0 : fmin(1.0, RHO) * dQ * beta * scaleVdiff(O0);
-      const double Qer = far ? 0.0 : beta * (fmin(Cmax, RHO) * dQ);
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) if (on[j]) {
-        const int c = en + 16 * j;
-        const double dpos = spDiff64(logit[j]);
-        const double penal = (tmp[j] - tp) * dpos;                               // KLDivGradient(mu, -1) (:152-162)
-        double pol = 0;
-        if (!far) { const double factor = A_RET * fmin(Cmax, RHO); pol = ((c == label ? factor / unnorm[j] : 0.0) - factor / norm) * dpos; }   // policyGradient (:136-144)
-        const double gP = beta * pol + (1 - beta) * penal;                       // penalizeReFER + makeNetworkGrad
-        const double gA = Qer * ((c == label ? 1.0 : 0.0) - pj[j]);              // Discrete_advantage::grad (:51-58)
-        sDelta[em * LD + pP + c] = (float)gP; sDelta[em * LD + pA + c] = (float)gA;
-        if (writer) { a.bt.G[(size_t)b * nOut + pP + c] = (double)(float)gP; a.bt.G[(size_t)b * nOut + pA + c] = (double)(float)gA; }
-      }
-      xRHO = RHO; xDKL = DKL; xdQ = dQ; xAval = Aval; xfar = far; xg0 = g0;
-    } else {
-      double mean[NCH], pm[NCH]; bool on[NCH];
-      double sLw = 0, sKl = 0;
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = en + 16 * j; on[j] = onC[j];
-        mean[j] = 0; pm[j] = 0;
-        if (on[j]) {
-          mean[j] = O[pM + c];
-          // log pi(a) - log mu(a) and D_KL(pi || mu) share one logarithm (see head.hip)
-          pm[j] = bnd[j] ? (mean[j] > MAXM ? MAXM : (mean[j] < -MAXM ? -MAXM : mean[j])) : mean[j];
-          const double u1 = (act[j] - pm[j]) * invStd[j];
-          sLw += (u2[j] * u2[j] - u1 * u1) / 2 - lq[j];
-          const double dm = (mean[j] - bMean[j]) * bInv[j];
-          sKl += (CmuCpi[j] - 1 + dm * dm - 2 * lq[j]) / 2;
-        }
-      }
-      const double logW = sum16(sLw), DKL = sum16(sKl);
-      const double RHO = exp(logW > 7 ? 7 : (logW < -7 ? -7 : logW));
-      const float Wf = (float)RHO;
-      const bool far = (Cf > 1.f) && (Wf > Cf || Wf < iCf);          // Episode.h:28-33 (Fval)
-      // Gaussian_advantage::computeAdvantage (Gaus_advantage.h:76-88): A = coef (exp(-1/2 sum (a-m)^2 / L) - ratio), sums and
-      // products in the reference's component order (through LDS: every lane of the row walks the components)
-      double Aval = 0, advCoef = 0, advOrig = 0, advRatio = 1, p1[NCH], p2[NCH];
-      if (nAdv) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-          const int c = en + 16 * j; p1[j] = 1; p2[j] = 1;
-          if (on[j]) {
-            p1[j] = spD64(O[2 + c]); p2[j] = spD64(O[2 + dA + c]);
-            const double d = act[j] - pm[j], S = stdev[j] * stdev[j];
-            sTq[em * 64 + c] = d * d / (act[j] > pm[j] ? p1[j] : p2[j]);
-            sTr[em * 64 + c] = sqrt(p1[j] / (p1[j] + S)) / 2 + sqrt(p2[j] / (p2[j] + S)) / 2;
-          }
-        }
-        __builtin_amdgcn_wave_barrier(); __threadfence_block(); __builtin_amdgcn_wave_barrier();      // (a sample's 16 lanes share a wavefront)
-        double quad = 0;
-        if (live) for (int i = 0; i < dA; ++i) { quad += sTq[em * 64 + i]; advRatio *= sTr[em * 64 + i]; }
-        advCoef = spD64(O[1]); advOrig = exp(-quad / 2);
-        Aval = advCoef * (advOrig - advRatio);
-      }
-      const double A_RET = Qret - V, dQ = A_RET - Aval;                // Zero_advantage: A = 0
-      const double Ver = fmin(1.0, RHO) * dQ;
-      const double Qer = far ? 0.0 : beta * (fmin(Cmax, RHO) * dQ);    // RACER_train.cpp:42,56
-      const double g0 = far ? 0.0 : Ver * beta * scaleVdiff(O0);
-      const double coef = A_RET * fmin(Cmax, RHO);
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) if (on[j]) {
-        const int c = en + 16 * j;
-        const double penalM = -1 * ((mean[j] - bMean[j]) * invVarMu[j]);
-        const double penalS = dPos[j] * -1 * ((invVarMu[j] - invStd[j] * invStd[j]) * stdev[j]);
-        double polM = 0, polS = 0;
-        if (!far) {
-          if (bnd[j]) {
-            const double dLogPdMean = (act[j] - mean[j]) * invStd[j] * invStd[j];
-            const double u = (act[j] - pm[j]) * invStd[j];
-            polS = dPos[j] * coef * ((u * u - 1) * invStd[j]);
-            if (mean[j] >= MAXM && coef * dLogPdMean > 0) polM = 0;
-            else if (mean[j] <= -MAXM && coef * dLogPdMean < 0) polM = 0;
-            else polM = coef * dLogPdMean;
-          } else {
-            const double u = (act[j] - mean[j]) * invStd[j];
-            polM = coef * (u * invStd[j]);
-            polS = dPos[j] * coef * ((u * u - 1) * invStd[j]);
-          }
-        }
-        const double gM = beta * polM + (1 - beta) * penalM;
-        const double gS = beta * polS + (1 - beta) * penalS;
-        sDelta[em * LD + pM + c] = (float)gM;                              // Activation::addOutputDelta: nnReal += Real (Activation.h:108-117)
-        if (writer) {
-          a.bt.gParam[(size_t)b * dA + c] = (float)gS;
-          a.bt.G[(size_t)b * nOut + pM + c] = (double)(float)gM;
-          a.bt.G[(size_t)b * nOut + nDense + c] = (double)(float)gS;
-        }
-        if (nAdv) {   // Gaussian_advantage::grad (Gaus_advantage.h:91-116) for the two precisions of this component
-          const double expect = -advRatio, S = stdev[j] * stdev[j], d = act[j] - pm[j];
-          double g1 = act[j] > pm[j] ? advOrig * advCoef * ((d / p1[j]) * (d / p1[j])) / 2 : 0;
-          double g2 = act[j] < pm[j] ? advOrig * advCoef * ((d / p2[j]) * (d / p2[j])) / 2 : 0;
-          const double F = 2 / (sqrt(p1[j] / (p1[j] + S)) + sqrt(p2[j] / (p2[j] + S)));
-          const double q1 = p1[j] + S, q2 = p2[j] + S;
-          g1 += F * expect * advCoef * (S / sqrt(p1[j] * (q1 * q1 * q1)) / 4);
-          g2 += F * expect * advCoef * (S / sqrt(p2[j] * (q2 * q2 * q2)) / 4);
-          g1 *= Qer * spDiff64(O[2 + c]); g2 *= Qer * spDiff64(O[2 + dA + c]);          // grad_matrix (:69-74)
-          sDelta[em * LD + 2 + c] = (float)g1; sDelta[em * LD + 2 + dA + c] = (float)g2;
-          if (writer) { a.bt.G[(size_t)b * nOut + 2 + c] = (double)(float)g1; a.bt.G[(size_t)b * nOut + 2 + dA + c] = (double)(float)g2; }
-        }
-      }
-      if (nAdv && live && en == 0) {   // coefficient output of the Gaussian advantage
-        const double gc = (advOrig - advRatio) * (Qer * spDiff64(O[1]));
-        sDelta[em * LD + 1] = (float)gc;
-        if (writer) a.bt.G[(size_t)b * nOut + 1] = (double)(float)gc;
-      }
-      xRHO = RHO; xDKL = DKL; xdQ = dQ; xAval = Aval; xfar = far; xg0 = g0;
-    }
-    if (live && en == 0) {
-      sDelta[em * LD + 0] = (float)xg0;
-      if (writer) {
-        a.bt.pEid[b] = a.bt.eid[b]; a.bt.pNextOf[b] = a.bt.nextOf[b];      // (the sampler of the next step overwrites eid / nextOf meanwhile)
-        a.bt.G[(size_t)b * nOut] = (double)(float)xg0;
-        a.bt.rho[b] = xRHO; a.bt.dkl[b] = xDKL; a.bt.far[b] = xfar ? 1 : 0;
-        // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
-        const float E = (float)xdQ, D = (float)xDKL, Wn = (float)xRHO, Vf = (float)V;
-        a.bt.oldDQ[b] = sMisc[em * 8 + 1]; a.bt.oldDKL[b] = sMisc[em * 8 + 2]; a.bt.oldW[b] = sMisc[em * 8 + 3]; a.bt.oldV[b] = sMisc[em * 8 + 4]; a.bt.oldADV[b] = sMisc[em * 8 + 5];
-        a.bt.newDQ[b] = E; a.bt.newDKL[b] = D; a.bt.newW[b] = Wn; a.bt.newV[b] = Vf;
-        const float Qf = (float)(xAval + V);                    // Episode::updateValues_atomic(t, V, Q): advantage = Q - V in Fval
-        a.rp.DQ[slot] = E; a.rp.DKL[slot] = D; a.rp.IMPW[slot] = Wn; a.rp.V[slot] = Vf; a.rp.ADV[slot] = hasAdv ? Qf - Vf : 0.f;
-        a.bt.newQ[b] = hasAdv ? Qf : Vf;
-        a.bt.dq[b] = (double)E;
-      }
-    }
-    if (live && writer) for (int o = en; o < nOut; o += 16) a.bt.O[(size_t)row * nOut + o] = O[o];
+    const int GW = G < 16 ? G : 16;
+    hr.compute(a, sO + em * LO, sDelta + em * LD, sXo + em * LD, sMisc + em * 8, sTq + em * 64, sTr + em * 64, rowValid, isNext, (em % GW) == n, b, slot, row, en,
+               beta, Cmax, Cinv, sAct[em]);
   }
   PSTMP(6);
-  __builtin_amdgcn_wave_barrier(); __threadfence_block(); __builtin_amdgcn_wave_barrier();
-  // deltas of the output layer: BaseLayer::backward, deltas *= f'(x, y) (Layer_Base.h:104-109)
-  if (live) {
-    for (int o = en; o < nDense; o += 16) {
-      float d = sDelta[em * LD + o];
-      if (a.outFunc != HL_FUNC_LINEAR) { d *= actDiff(a.outFunc, sXo[em * LD + o], (float)O[o]); sDelta[em * LD + o] = d; }
-      if (writer) a.dOut[(size_t)b * a.ldDo + o] = d;
-    }
-  }
   __syncthreads();
   PSTMP(7);
 
@@ -545,7 +295,7 @@ __global__ __launch_bounds__(256) void mlp_panel_kernel(const GemmProblem* __res
     TileB tb; const bool mine = n < P.tilesN;
     if (mine) gemmLoadB(P, panel * P.tilesN + n, tb);          // W rows of this tile: in flight across the barrier
     panelBarrier(ctr, G, scw);
-    if (mine) gemmTile<GEMM_ROLE_DX, -1, true>(P, panel * P.tilesN + n, smem, sc, hyp, nRows, &tb);
+    if (mine) gemmTile<GEMM_ROLE_DX, GEMM_X, true>(P, panel * P.tilesN + n, smem, sc, hyp, nRows, &tb);
   }
   PSTMP(9);
 }

@@ -30,8 +30,11 @@ constexpr int GRAPH_SIZES[] = {999, 256, 128, 64, 32, 16, 8, 4, 2, 1};
 constexpr int CNT_MSG_FLOATS = 16;     // four counters x four 16-bit chunks (tail_dev.h: postPart)
 constexpr int CNT_MSG_OFFSET = 128;    // counters message inside the PARAM_TAIL floats behind the gradient (learner.cpp)
 
-void setTiles(GemmProblem& p, int& cursor, bool maySplit = false) {
+void setTiles(GemmProblem& p, int& cursor, bool maySplit = false, bool mayStrip = false) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
+  // short reductions over many columns, in launches of gemm16_kernel<DW> only (the argument-table kernel keeps its LDS size): 16 x 64 strips
+  p.strip = (mayStrip && p.flavor == GEMM_W && p.K <= 128 && p.N >= 64) ? 1 : 0;
+  if (p.strip) p.tilesN = (p.N + 63) / 64;
   if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
   // weight gradients over >= 1024 rows (recurrent nets: batch x BPTT steps): one workgroup per (tile, 256-row chunk)
   p.nSplit = (maySplit && (p.flavor == GEMM_W || p.flavor == RED_COL) && p.K >= 1024) ? (p.K + 255) / 256 : 1;
@@ -73,6 +76,9 @@ int buildProblems(hl_learner* h) {
     }
     // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
     sb.dwIdx = (int)P.size(); int cur = 0;
+    // (nets whose weight gradients go out through launchBackward, i.e. gemm16_kernel<DW> with the table in memory: convolutional /
+    //  appended-observation nets; the two-kernel steps use the argument-table kernel when the table fits)
+    const bool viaGemm16 = !h->fusedOk && h->preproc && getenv("SMARTIES_HIP_NO_STRIPS") == nullptr;
     for (int j = 0; j < nH && h->recurrent; ++j) {
       // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
       // sample does not have carry zero deltas (rec_backward_kernel)
@@ -123,7 +129,7 @@ int buildProblems(hl_learner* h) {
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
       else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
       p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
-      setTiles(p, cur); P.push_back(p);
+      setTiles(p, cur, false, viaGemm16); P.push_back(p);
       if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
         r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
@@ -278,6 +284,17 @@ int launchFused(hl_learner* h, int parity, hipStream_t s, bool nextSample = fals
   HIPCK(timed(h, "fused_fwd_head_dx", s, [&] { return launch_fused(fa, h->Mmax, pex, s); }));
   return HL_OK;
 }
+HeadArgs headArgs(hl_learner* h, int parity);
+// the wide variant (fusedw.hip): the same launch with the head's description next to the fused kernel's
+int launchFusedWide(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool deferBeta = false) {
+  FusedArgs fa = fusedArgs(h, parity);
+  const HeadArgs ha = headArgs(h, parity);
+  ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+  if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
+  if (deferBeta) { fa.deferBeta = 1; ex.post = postArgs(h, parity ^ 1, POST_BETA); pex = &ex; }
+  HIPCK(timed(h, "fused_wide", s, [&] { return launch_fused_wide(fa, ha, h->Mmax, pex, s); }));
+  return HL_OK;
+}
 ConvArgs convArgs(hl_learner* h, int parity);
 // (never inside a stream capture: the launch has to RUN before the flag is cleared)
 int ensureConvPrep(hl_learner* h) {
@@ -391,6 +408,7 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
 // (draws and sort; with convolutional preprocessing -- no gathered rows -- the whole sampler); `deferBeta`: the step before left its
 // far-policy count and beta update to a rider of this launch, the heads wait for it (as in launchFused)
 int launchPanelStep(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool deferBeta = false) {
+  if (h->fusedWideOk) return launchFusedWide(h, parity, s, nextSample, deferBeta);
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   PanelArgs pa{}; pa.h = headArgs(h, parity); pa.G = h->panelG; pa.panelCtr = h->panelCtrP;
@@ -638,7 +656,7 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
     HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));
     return launchBackward(h, parity, fuseAdam, s);       // no dX problems for this layout: the dW launch only
   }
-  if (h->panelStepOk) {      // dense layers, head and input gradients in one launch; then the weight gradients
+  if (h->panelStepOk || h->fusedWideOk) {      // dense layers, head and input gradients in one launch; then the weight gradients
     int rc = launchForward(h, parity, s, false, true, false); if (rc) return rc;
     rc = launchPanelStep(h, parity, s); if (rc) return rc;
     if (!h->preproc) return launchWeightGrad(h, parity, fuseAdam, s, false, false);
@@ -703,7 +721,7 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   const long long nColl0 = h->nCollectives;      // captured calls are counted when the graph is replayed
   for (int j = 0; j < U && !rc; ++j) {
     const int p = (p0 + j) & 1;
-    const bool twoKernel = h->fusedOk || (h->panelStepOk && !h->preproc);
+    const bool twoKernel = h->fusedOk || h->fusedWideOk || (h->panelStepOk && !h->preproc);
     if (twoKernel) {
       // one replica: the far-policy count and the beta update of every step but the last are taken out of the dW launch's
       // bookkeeping rider, where they sat at the end of the kernel's longest workgroup, into a rider of the next fused kernel
@@ -851,6 +869,10 @@ int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = fals
       const int U = (int)avail;
       if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
       HIPCK(hipGraphLaunch(it->second[p0].exec, h->stream));
+      if (h->tailEventMode) {
+        if (!h->tailEvent) HIPCK(hipEventCreateWithFlags(&h->tailEvent, hipEventDisableTiming));
+        HIPCK(hipEventRecord(h->tailEvent, h->stream));
+      }
       h->notifyIssued += 1; h->tailNotify = true;
       h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;
       if (wired(h)) h->nCollectives += U;
@@ -858,7 +880,7 @@ int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = fals
       return HL_OK;
     }
   }
-  if (h->eagerChain > 0 && avail <= h->eagerChain && (h->fusedOk || (h->panelStepOk && !h->preproc)) && !exchanging(h)) {
+  if (h->eagerChain > 0 && avail <= h->eagerChain && (h->fusedOk || h->fusedWideOk || (h->panelStepOk && !h->preproc)) && !exchanging(h)) {
     // short calls: the same two launches per step (riders included) issued directly -- no graph launch latency, no
     // first-launch cost of a graph that has not run yet
     if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
