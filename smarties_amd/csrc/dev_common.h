@@ -229,6 +229,42 @@ __device__ __forceinline__ float bcast0F(float v, int en) {
   return x;
 }
 
+// activation evaluated with the function known at compile time; dispatchFunc() branches ONCE on the
+// (uniform) function id and runs the whole epilogue branch-free
+// n / d for d in [1, 2^60): reciprocal + Newton step + two residual corrections -- the IEEE division
+// expansion without its range scaling (v_div_scale / v_div_fmas serialise on VCC, so sixteen of
+// them per thread cannot overlap; these can)
+__device__ __forceinline__ float divNoScale(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  float q = n * r;
+  q = fmaf(fmaf(-d, q, n), r, q);
+  q = fmaf(fmaf(-d, q, n), r, q);
+  return q;
+}
+template <int F> __device__ __forceinline__ float actEvalT(float in) {
+  if constexpr (F == HL_FUNC_SOFTSIGN) return divNoScale(in, 1 + fabsf(in));
+  else return actEval(F, in);
+}
+template <int F> __device__ __forceinline__ float actDiffT(float in, float out) {
+  if constexpr (F == HL_FUNC_SOFTSIGN) { const float d = 1 + fabsf(in); return divNoScale(1.0f, d * d); }
+  else return actDiff(F, in, out);
+}
+template <int F> struct FuncTag { static constexpr int value = F; };
+// CF >= 0: the activation is a template parameter of the kernel (no other code is generated)
+template <int CF, class Body> __device__ __forceinline__ void dispatchFunc(int func, Body body) {
+  if constexpr (CF >= 0) body(FuncTag<CF>{});
+  else if (func == HL_FUNC_SOFTSIGN) body(FuncTag<HL_FUNC_SOFTSIGN>{});
+  else if (func == HL_FUNC_TANH) body(FuncTag<HL_FUNC_TANH>{});
+  else if (func == HL_FUNC_RELU) body(FuncTag<HL_FUNC_RELU>{});
+  else if (func == HL_FUNC_LRELU) body(FuncTag<HL_FUNC_LRELU>{});
+  else if (func == HL_FUNC_SIGM) body(FuncTag<HL_FUNC_SIGM>{});
+  else if (func == HL_FUNC_HARDSIGN) body(FuncTag<HL_FUNC_HARDSIGN>{});
+  else if (func == HL_FUNC_SOFTPLUS) body(FuncTag<HL_FUNC_SOFTPLUS>{});
+  else if (func == HL_FUNC_EXPPLUS) body(FuncTag<HL_FUNC_EXPPLUS>{});
+  else if (func == HL_FUNC_EXP) body(FuncTag<HL_FUNC_EXP>{});
+  else body(FuncTag<HL_FUNC_LINEAR>{});
+}
 // Adam::step (Network/Optimizer.cpp:61-108) with SMARTIES_NESTEROV_ADAM, SMARTIES_SAFE_ADAM,
 // SMARTIES_ADAMW (Settings/Bund.h); eta already carries the bias correction (Optimizer.cpp:66)
 struct AdamCoef { float eta, lambda, fac; };

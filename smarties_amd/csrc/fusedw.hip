@@ -1,14 +1,13 @@
 // smarties_amd/csrc/fusedw.hip -- the fused forward + head + dX kernel (fused.hip) for the two-hidden-layer networks that kernel
-// does not take: WIDE states (up to 512 observed components: the first layer's weights are streamed through LDS in 32-row slabs
-// instead of held whole) and ANY head the panel code serves (more than seven action components, the Gaussian and the discrete
+// does not take: WIDE states (up to 512 observed components: the first layer is taken tile-wise and exchanged through the panel's L2
+// like the second, instead of being recomputed by every workgroup) and ANY head the panel code serves (more than seven action components, the Gaussian and the discrete
 // advantage: head_rows.h, one (sample, component) per lane of a 16-lane row, further components in further chunks).
 // BASELINE config 3 -- Humanoid through the gym wrapper, 257 states, 17 unbounded actions, 2 x 256, local batch 32 per replica --
 // ran the generic launches (forward chain, head, dX, dW: 33.6 us per step); with this kernel it takes the two-kernel step.
 //
 // Placement and exchange are fused.hip's: a 16-row PANEL of the minibatch belongs to the HT = H / 16 workgroups with the same
-// blockIdx % 8 (one XCD, one L2); every workgroup recomputes h1 = f(S W0 + b0) of the whole panel (here: a K-loop over slabs
-// of W0, the next slab's loads in flight during the MFMA steps of the current one), takes its 16-column tile of x2 / y3 / f'(x2),
-// ONE panel barrier, reads the panel back, runs output layer and head for the 16 samples, forms delta_x2 of the whole panel
+// blockIdx % 8 (one XCD, one L2); every workgroup takes its 16-column tile of h1 = f(S W0 + b0), panel barrier, reads the panel's
+// h1 back, takes its tile of x2 / y3 / f'(x2), second panel barrier, reads the panel back, runs output layer and head for the 16 samples, forms delta_x2 of the whole panel
 // locally (delta_y3 = delta_out W_out^T by MFMA, times f'(x2)) and takes its tile of delta_h1 = delta_x2 W1^T.
 // Reference functions: as fused.hip (BaseLayer / ParametricResidualLayer forward and backward, RACER::Train, the policies and
 // advantages of Math/).
@@ -18,7 +17,6 @@ namespace hl {
 
 #define WLDR 258            // leading dimension of 16-row LDS tiles (== 2 mod 32)
 constexpr int FW_NT = 512;  // threads per workgroup
-constexpr int FW_SLAB = 32; // rows of W0 per slab
 constexpr int FW_MAXNT = 5; // 16-column tiles of the output layer
 
 // development time stamps of workgroup (panel 0, tile 1), 100 MHz clock: -DHL_PANEL_STAMPS (tools/panel_stamps.py)
@@ -28,13 +26,13 @@ constexpr int FW_MAXNT = 5; // 16-column tiles of the output layer
 #define WSTMP(i) do { } while (0)
 #endif
 
-struct FwGeo { int dSp, LS, nSlab, NTo, LD, LO; size_t oR2, oR3, oWo, oS, oRed, oVec, oO, oXo, oDelta, oMisc, oAct, oBeta, oT, total; };
+struct FwGeo { int dSp, LS, NTo, LD, LO; size_t oR2, oR3, oWo, oS, oRed, oVec, oO, oXo, oDelta, oMisc, oAct, oBeta, oT, total; };
 __host__ __device__ inline FwGeo fwGeo(int dS, int H, int nDense, int nOut, int ldWo, int nAdv) {
   FwGeo g;
-  g.dSp = (dS + 3) & ~3; g.LS = g.dSp + 2; g.nSlab = (g.dSp + FW_SLAB - 1) / FW_SLAB;
+  g.dSp = (dS + 3) & ~3; g.LS = g.dSp + 2;
   g.NTo = (nDense + 15) / 16; g.LD = g.NTo * 16 + 6; g.LO = nOut | 1;
   size_t o = (size_t)16 * WLDR * 4;                                       // sY1: h1 panel, later the W1 row tile
-  g.oR2 = o; { size_t a = (size_t)FW_SLAB * (H + 16) * 4, b = (size_t)16 * WLDR * 4, c = nAdv ? (size_t)2 * 16 * 64 * 8 : 0; if (b > a) a = b; if (c > a) a = c; o += a; }   // W0 slab, y3 panel, advantage scratch
+  g.oR2 = o; { size_t a = (size_t)g.dSp * 16 * 4, b = (size_t)16 * WLDR * 4, c = nAdv ? (size_t)2 * 16 * 64 * 8 : 0; if (b > a) a = b; if (c > a) a = c; o += a; }   // W0 column tile, y3 panel, advantage scratch
   g.oR3 = o; { size_t a = (size_t)H * 16 * 4, b = (size_t)16 * WLDR * 4; o += a > b ? a : b; }     // W1 column tile, later f'(x2) -> delta_x2 panel
   g.oWo = o; o += (size_t)H * ldWo * 4;
   g.oS = o; o += (size_t)16 * g.LS * 4;
@@ -81,17 +79,15 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
     else if (blockIdx.x == 1 && a.deferBeta) farBetaPhase(extra.post, smem);
     return;
   }
-  constexpr int NT = FW_NT, NW = NT / 64, HT = H / 16, H4 = H / 4, LDW0 = H + 16;
-  constexpr int TPW = HT >= NW ? HT / NW : 1;          // h1 column tiles per wave
+  constexpr int NT = FW_NT, NW = NT / 64, HT = H / 16, H4 = H / 4;
   constexpr int KW = H / NW, NK = KW / 4;              // K split of the H-long contractions over the 8 waves
   constexpr int QP = (16 * H4 + NT - 1) / NT;          // float4 per thread of a 16 x H panel
   constexpr int QC = (H * 4 + NT - 1) / NT;            // ... of the H x 16 column tile
-  constexpr int Q0 = (FW_SLAB * H4 + NT - 1) / NT;     // ... of a W0 slab
   const DevScalars* sc = a.sc;
   DevScalars* scw = a.sc;
   const int dS = a.dS, B = a.B, dA = a.dA, nDense = a.nDense, nOut = a.nOut, ldWo = ha.ldWo, nSig = ha.nSig;
   const FwGeo g = fwGeo(dS, H, nDense, nOut, ldWo, ha.nAdv);
-  const int dSp = g.dSp, LS = g.LS, nSlab = g.nSlab, NTo = g.NTo, LD = g.LD, LO = g.LO;
+  const int dSp = g.dSp, LS = g.LS, NTo = g.NTo, LD = g.LD, LO = g.LO;
   const int func = __builtin_amdgcn_readfirstlane(a.func);
   int resN = a.resN, ldA0 = a.ldA0, ldA1 = a.ldA1;
   asm volatile("" : "+v"(resN), "+v"(ldA0), "+v"(ldA1));
@@ -146,19 +142,16 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c4 = (tid & 31) + 32 * u; sv[u] = (c4 < d4 && m0 + r < nRows) ? *reinterpret_cast<const f32x4*>(xr + 4 * c4) : z4; }
   }
-  f32x4 w0v[Q0], w1c[QC], w1r[QP];
-  auto loadSlab = [&](int slab) {      // rows >= dS read row dS - 1 again (finite) and meet zero state columns
+  // this workgroup's 16-column tile of W0 ([dSp][16], rows beyond dS zero): at 257 states recomputing h1 of the whole panel in every
+  // workgroup -- fused.hip's way -- is 1040 MFMA steps and a 263 KB weight stream per workgroup (measured: 12.9 us); the tile
+  // with an exchange of h1 through the panel's L2 is 65 steps, one more panel barrier and a read-back (3 us)
+  constexpr int QW0 = 4;                               // 16-byte loads per thread of the [dSp][16] tile (dS <= 512)
+  f32x4 w0v[QW0], w1c[QC], w1r[QP];
 #pragma unroll
-    for (int q = 0; q < Q0; ++q) {
-      const int f = tid + NT * q, k = slab * FW_SLAB + f / H4, c4 = f % H4;
-      w0v[q] = *reinterpret_cast<const f32x4*>(W0 + (size_t)(k < dS ? k : dS - 1) * a.ldW0 + 4 * c4);
-    }
-  };
-  auto storeSlab = [&]() {
-#pragma unroll
-    for (int q = 0; q < Q0; ++q) { const int f = tid + NT * q; if (f < FW_SLAB * H4) { const int k = f / H4, c4 = f % H4; *reinterpret_cast<f32x4*>(sR2 + k * LDW0 + 4 * c4) = w0v[q]; } }
-  };
-  loadSlab(0);
+  for (int q = 0; q < QW0; ++q) {
+    const int f = tid + NT * q, k = f >> 2, c = n0 + (f & 3) * 4;
+    w0v[q] = (k < dS) ? *reinterpret_cast<const f32x4*>(W0 + (size_t)k * a.ldW0 + c) : z4;
+  }
 #pragma unroll
   for (int q = 0; q < QC; ++q) {
     const int f = tid + NT * q; w1c[q] = z4;
@@ -195,7 +188,8 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
       if (c4 < d4) { float2* d = reinterpret_cast<float2*>(sS + r * LS + 4 * c4); d[0] = make_float2(sv[u][0], sv[u][1]); d[1] = make_float2(sv[u][2], sv[u][3]); }
     }
   }
-  storeSlab();
+#pragma unroll
+  for (int q = 0; q < QW0; ++q) { const int f = tid + NT * q; if ((f >> 2) < dSp) *reinterpret_cast<f32x4*>(sR2 + (size_t)f * 4) = w0v[q]; }      // [k][16]
 #pragma unroll
   for (int q = 0; q < QC; ++q) { const int f = tid + NT * q; if (f < H * 4) *reinterpret_cast<f32x4*>(sR3 + (size_t)f * 4) = w1c[q]; }
   if (tid < H) { sB0[tid] = b0v; sWr[tid] = wrv; sBr[tid] = brv; }
@@ -210,55 +204,64 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   HeadRow<NCH> hr;
   hr.load(ha, rowValid, isNext, slot, en);
 
-  // ---- h1 = f(S W0 + b0), whole panel: a K-loop over the slabs of W0; wave w computes column tiles w, w + 8, ... ----------------
+  // ---- own tile of h1 = f(S W0 + b0): the dSp / 4 MFMA steps split over the 8 waves (contiguous runs), partial tiles joined in LDS ----
   {
-    f32x4 acc[TPW];
+    const int nk4 = dSp >> 2, per = (nk4 + NW - 1) / NW, s0 = wave * per, s1 = min(nk4, s0 + per);
+    f32x4 acc0 = z4, acc1 = z4;
+    constexpr int UN = 8;
+    for (int sb = s0; sb < s1; sb += UN) {
+      float av[UN], bv[UN];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = z4;
-    const int nk4 = dSp >> 2;
-    for (int slab = 0; slab < nSlab; ++slab) {
-      if (slab + 1 < nSlab) loadSlab(slab + 1);                       // in flight during this slab's MFMA steps
-      if (wave < HT) {
-        const int steps = min(FW_SLAB / 4, nk4 - slab * (FW_SLAB / 4));
-        float av[FW_SLAB / 4], bv[TPW][FW_SLAB / 4];
+      for (int u = 0; u < UN; ++u) { const int sc_ = sb + u < s1 ? sb + u : s1 - 1; av[u] = sS[li * LS + 4 * sc_ + lc]; bv[u] = sR2[(4 * sc_ + lc) * 16 + li]; }
 #pragma unroll
-        for (int s = 0; s < FW_SLAB / 4; ++s) {
-          const int sc_ = s < steps ? s : steps - 1;
-          av[s] = sS[li * LS + slab * FW_SLAB + 4 * sc_ + lc];
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) bv[t][s] = sR2[(4 * sc_ + lc) * LDW0 + (wave + NW * t) * 16 + li];
-        }
-#pragma unroll
-        for (int s = 0; s < FW_SLAB / 4; ++s) {
-          const float a_ = s < steps ? av[s] : 0.f;
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv[t][s], acc[t], 0, 0, 0);
-        }
+      for (int u = 0; u < UN; ++u) {
+        const float a_ = sb + u < s1 ? av[u] : 0.f;
+        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv[u], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv[u], acc0, 0, 0, 0);
       }
-      if (slab + 1 < nSlab) { __syncthreads(); storeSlab(); __syncthreads(); }
     }
-    WSTMP(2);
-    if (wave < HT) {
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const int nt = wave + NW * t, c = nt * 16 + li;
-        const float bb = sB0[c];
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+  }
+  __syncthreads();
+  WSTMP(2);
+  float x1o = 0.f, y1o = 0.f;
+  if (rowValid) {
+    x1o = fwRedSum<8>(red, tid) + sB0[n0 + en];
+    dispatchFunc<-1>(func, [&](auto F) { y1o = actEvalT<decltype(F)::value>(x1o); });
+    a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;        // the panel's h1 (exchange below); rows < B: the A operand of the dW1 contraction
+  }
+  // ---- first panel barrier: all HT tiles of h1 are in memory (plain stores: the group shares one XCD's L2), then the panel is read back ----
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (HT > 1 && tid == 256) {      // (a thread outside the element threads waits for the group: those compute meanwhile)
+    unsigned* ctr = a.panelCtr + panel * 32;
+    const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned barTarget = (old / (unsigned)HT + 1u) * (unsigned)HT;
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - barTarget) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { scw->errFlag = 77; break; }
+    }
+  }
+  // head terms that do not depend on this step's outputs: under the barrier's wait
+  hr.hoist(ha, a.boundedMask, bpv, live, en);
+  __syncthreads();
+  {
+    f32x4 hv[QP];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = lc * 4 + r;
-          const float x = acc[t][r] + bb;
-          sY1[i * WLDR + c] = actEval(func, x);
-          if (nt == n) sT[i * 16 + li] = x;
-        }
-      }
+    for (int q = 0; q < QP; ++q) {
+      const int f = tid + NT * q; hv[q] = z4;
+      if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; if (m0 + r < nRows) hv[q] = *reinterpret_cast<const f32x4*>(a.Y1 + (size_t)(m0 + r) * ldA0 + 4 * c4); }
+    }
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int f = tid + NT * q;
+      if (f < 16 * H4) { const int r = f / H4, c = 4 * (f % H4); float2* d = reinterpret_cast<float2*>(sY1 + r * WLDR + c); d[0] = make_float2(hv[q][0], hv[q][1]); d[1] = make_float2(hv[q][2], hv[q][3]); }
     }
   }
   __syncthreads();
   WSTMP(3);
-  const float x1o = sT[em * 16 + en], y1o = sY1[em * WLDR + n0 + en];
-  if (eth && row < B) a.Y1[(size_t)row * ldA0 + n0 + en] = y1o;       // A operand of the dW1 contraction
-  // head terms that do not depend on this step's outputs
-  hr.hoist(ha, a.boundedMask, bpv, live, en);
 
   WSTMP(4);
   // ---- own tile of x2 = h1 W1 + b1: K split over the 8 waves ------------------------------------------------------------------------
@@ -272,7 +275,8 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   if (rowValid) {
     const float v = fwRedSum<8>(red, tid);
     const float x2 = v + b1e;
-    const float y2 = actEval(func, x2), f2 = actDiff(func, x2, y2);
+    float y2 = 0.f, f2 = 0.f;
+    dispatchFunc<-1>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y2 = actEvalT<FN>(x2); f2 = actDiffT<FN>(x2, y2); });
     const float y3 = (n0 + en < resN) ? resOut(y2, y1o, sWr[n0 + en], sBr[n0 + en]) : y2;
     gR2[(size_t)row * ldA1 + n0 + en] = y3;                  // plain stores: the consumers share this XCD's L2 (fused.hip); also the A operand of dWout
     gX2[(size_t)row * ldA1 + n0 + en] = f2;                  // f'(x2)
@@ -422,7 +426,9 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
     float dres = v;
     if (n0 + en < resN) dres += dy3own * sWr[n0 + en];
     a.Dres1[(size_t)row * ldA0 + n0 + en] = dres;
-    a.D1[(size_t)row * ldA0 + n0 + en] = dres * actDiff(func, x1o, y1o);
+    float f1 = 1.f;
+    dispatchFunc<-1>(func, [&](auto F) { f1 = actDiffT<decltype(F)::value>(x1o, y1o); });
+    a.D1[(size_t)row * ldA0 + n0 + en] = dres * f1;
   }
   WSTMP(11);
 }

@@ -25,8 +25,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
                                                      const DevScalars* __restrict__ sc, AdamHyper hyp, ExtraArgs extra, ExtraArgs extra2) {
   // one LDS block, used either by a GEMM tile (two operand tiles + the cross-wave reduction
   // buffer) or by the tail code of the extra workgroup
-  constexpr int LDS0 = GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(ROLE == GEMM_ROLE_DW && STRIP_LDS > LDS0) ? STRIP_LDS : LDS0];      // (strips: weight-gradient launches only)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
   // horizontal fusion: workgroup 0 of the grid (dispatched first) runs a piece of the step tail
   // ... and, behind the riders, the workgroups that gather the minibatch a sampler rider found (PH_PUBLISH: extra.helpers of them)
   const int nRid = (extra.role ? 1 : 0) + (extra2.role ? 1 : 0), nHelp = extra.role == 1 ? extra.helpers : 0, nRiders = nRid + nHelp;
@@ -37,7 +36,6 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmProblem* __restri
   int p = 0;
   for (int i = 1; i < nProbs; ++i) if (bid >= probs[i].tileStart) p = i;
   const GemmProblem P = probs[p];
-  if constexpr (ROLE == GEMM_ROLE_DW) { if (P.strip) { gemmStripW(P, bid - P.tileStart, smem, sc, hyp); return; } }
   gemmTile<ROLE>(P, bid - P.tileStart, smem, sc, hyp, nRowsDyn);
 }
 

@@ -1,7 +1,6 @@
 // smarties_amd/csrc/gemm_tile.h -- the 16x16 output tile of the MLP contractions (one workgroup of 256 threads, the reduction
 // split over its four wavefronts on v_mfma_f32_16x16x4_f32) with its fused epilogues: shared by the per-layer launches, the
-// forward chain (gemm16.hip) and the panel kernel that carries forward chain, head and input-gradient chain in one launch
-// (mlp_panel.hip).  See gemm16.hip for the layout rationale.
+// forward chain (gemm16.hip).  See gemm16.hip for the layout rationale.
 #pragma once
 #include "tail_dev.h"
 
@@ -16,18 +15,17 @@ namespace hl {
 #else
 #define GSTAMP(i) do { } while (0)
 #endif
-// ... and of a tile inside the panel kernel's chain (-DHL_PANEL_STAMPS): workgroup (panel 0, member 0); forward tiles -> dbgT[16..21]
-// (the last layer's overwrite the first's), input-gradient tiles -> dbgT[22..27]
-#ifdef HL_PANEL_STAMPS
-#define CSTAMP(i) do { if (RAW && threadIdx.x == 0 && tile == 0) const_cast<DevScalars*>(sc)->dbgT[(ROLE == GEMM_ROLE_DX ? 22 : 16) + (i)] = wall_clock64(); } while (0)
-#else
-#define CSTAMP(i) do { } while (0)
-#endif
 
 __device__ __forceinline__ void adamApply(const AdamCoef& c, float g, float* W, float* M1, float* M2, size_t i) {
   float w = W[i], m1 = M1[i], m2 = M2[i];
   adamStep(c, g, w, m1, m2);
   W[i] = w; M1[i] = m1; M2[i] = m2;
+}
+
+// this replica's slot in a peer's window for the collective the gradient belongs to (byte offset inside the window)
+__device__ __forceinline__ size_t pushSlot(const PushArgs& pu) {
+  const unsigned long long seq = __hip_atomic_load(&pu.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (size_t)pu.slotsOffset + ((size_t)(seq & 1) * (size_t)pu.nRanks + (size_t)pu.rank) * (size_t)pu.slotBytes;
 }
 
 __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, float* red, const DevScalars* sc,
@@ -60,6 +58,10 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
     for (int q = 0; q < 16; ++q) g += red[q * 16 + jj];
     if (P.nSplit > 1) { P.part[(size_t)ks * P.N + j] = g; return; }
     P.C[j] = g;
+    if (hyp.push.on) {      // replicas: into the peers' windows too (a handful of columns: element stores)
+      const size_t so = pushSlot(hyp.push) + (size_t)((P.C - hyp.push.gBase) + j) * 4;
+      for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank) *reinterpret_cast<float*>(hyp.push.peers[p] + so) = g;
+    }
     if (P.adam) { AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac; adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
   }
 }
@@ -123,7 +125,6 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   if (variant & 8) return;              // ablation: launch + problem-table fetch only
 
   GSTAMP(24);
-  CSTAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lc = lane >> 4;
   const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
@@ -206,7 +207,6 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   };
   const int kBeg = ks * KC, kEnd = (FL < 0 && P.nSplit > 1) ? min(P.K, kBeg + KC) : Kmain;
   loadChunk(kBeg, preB != nullptr);
-  CSTAMP(1);
   for (int kb = kBeg; kb < kEnd; kb += KC) {
     int kc, kw, sh; chunkGeo(kb, kc, kw, sh);
     const int nf4 = kw;                       // float4 per 16-row-tile row (= kcp/4)
@@ -240,7 +240,6 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     }
     __syncthreads();
     GSTAMP(25);
-    CSTAMP(2);
     if (kb + KC < kEnd) loadChunk(kb + KC);
     const int k0 = wave * kw;
     if (!(variant & 2))                 // ablation: no MFMA loop
@@ -256,7 +255,6 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     __syncthreads();
   }
   GSTAMP(26);
-  CSTAMP(3);
   // ---- cross-wave reduction of the 4 partial tiles ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
@@ -265,7 +263,25 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
 #pragma unroll
   for (int q = 0; q < 4; ++q) if (q < kRem) v = fmaf(ra[q], rb[q], v);
   GSTAMP(27);
-  CSTAMP(4);
+  if (epi == EPI_DW && hyp.push.on && !(FL < 0 && P.nSplit > 1)) {
+    // replicas connected through peer windows: the tile goes into every peer's window as 16-byte stores (regrouped through LDS:
+    // a lane holds one element, a 16-byte store wants four of a row); columns beyond N carry zeros, like the padding of G
+    __syncthreads();                         // every thread has read the four partial tiles
+    red[tid] = outOk ? v : 0.f;
+    __syncthreads();
+    if (tid < 64) {
+      const int r = tid >> 2, c = (tid & 3) * 4, mm = m0 + r, nn = n0 + c;
+      const bool isW = mm < P.M - 1, isB = mm == P.M - 1;
+      const int lim = isW ? P.ldc : ((P.N + 7) & ~7);
+      if ((isW || isB) && nn < lim) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(red + r * 16 + c);
+        const size_t off = isW ? (size_t)(P.C - hyp.push.gBase) + (size_t)mm * P.ldc + nn : (size_t)(P.biasOut - hyp.push.gBase) + nn;
+        const size_t so = pushSlot(hyp.push) + off * 4;
+        for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank) *reinterpret_cast<f32x4*>(hyp.push.peers[p] + so) = x;
+        __builtin_amdgcn_s_waitcnt(0);          // acknowledged before this wavefront ends
+      }
+    }
+  }
   if (!outOk) return;
 
   if (epi == EPI_FWD) {
@@ -298,91 +314,6 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     P.C[(size_t)m * P.ldc + n] = v;
   }
   GSTAMP(28);
-  CSTAMP(5);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Weight gradients with a short reduction and many columns (the dense layer behind a convolution stack at batch 128: 577 x 512
-// over K = 128 -- 1184 sixteen-by-sixteen tiles, each spending its time on the launch of its workgroup, a cross-wave join and
-// 64-byte Adam segments): a workgroup takes a 16 x 64 STRIP, one tile per wavefront with the whole reduction (K / 4 MFMA steps,
-// two accumulators), A tile shared through LDS, Adam by the lane that holds the element, 256-byte row segments per strip.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int STRIP_KMAX = 128, STRIP_LDB = 80;      // (80 == 16 mod 32: the four k rows of an MFMA step hit disjoint banks)
-constexpr int STRIP_LDS = (STRIP_KMAX * 16 + STRIP_KMAX * STRIP_LDB) * 4;
-__device__ __forceinline__ void gemmStripW(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* __restrict__ sc, const AdamHyper& hyp) {
-  float* sA = reinterpret_cast<float*>(smem);             // [K][16]
-  float* sB = sA + STRIP_KMAX * 16;                        // [K][STRIP_LDB]
-  const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN, m0 = tm * 16, n0 = tn * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  const int K = P.K, Kp = (K + 3) & ~3;
-  const int n = n0 + 16 * wave + li;
-  const bool nOk = n < P.N;
-  // Adam operands of the four elements this lane will hold (rows m0 + 4 lc + r), requested first
-  AdamCoef ac{}; float ew[4] = {0.f, 0.f, 0.f, 0.f}, e1[4] = {0.f, 0.f, 0.f, 0.f}, e2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (P.adam) {
-    ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + lc * 4 + r;
-      const bool ok = nOk && m < P.M, isW = m < P.M - 1;
-      const size_t i = ok ? (isW ? (size_t)m * P.ldc + n : (size_t)n) : 0;
-      const float* pw = isW ? P.adW : P.adbW; const float* p1 = isW ? P.adM1 : P.adbM1; const float* p2 = isW ? P.adM2 : P.adbM2;
-      ew[r] = pw[i]; e1[r] = p1[i]; e2[r] = p2[i];
-    }
-  }
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 va[2], vb[8];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {       // A: rows = minibatch rows k, columns m0 .. m0 + 15 of the layer's input
-    const int idx = tid + 256 * q, k = idx >> 2, c = m0 + (idx & 3) * 4;
-    va[q] = (k < K && c < P.lda) ? *reinterpret_cast<const float4*>(P.A + (size_t)k * P.lda + c) : z4;
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {       // B: deltas, columns n0 .. n0 + 63
-    const int idx = tid + 256 * q, k = idx >> 4, c = n0 + (idx & 15) * 4;
-    vb[q] = (k < K && c < P.ldb && c < ((P.N + 3) & ~3)) ? *reinterpret_cast<const float4*>(P.B + (size_t)k * P.ldb + c) : z4;
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int idx = tid + 256 * q, k = idx >> 2, c = m0 + (idx & 3) * 4;
-    float4 v = va[q];
-    const int one = P.M - 1 - c;       // position of the ones column (bias row of the gradient) inside this float4
-    if (k < K) { if (one == 0) v.x = 1.f; else if (one == 1) v.y = 1.f; else if (one == 2) v.z = 1.f; else if (one == 3) v.w = 1.f; }
-    if (one < 0) v = z4;
-    else { if (one < 1) v.y = 0.f; if (one < 2) v.z = 0.f; if (one < 3) v.w = 0.f; }
-    if (k < STRIP_KMAX) *reinterpret_cast<float4*>(sA + idx * 4) = v;
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) { const int idx = tid + 256 * q, k = idx >> 4; if (k < STRIP_KMAX) *reinterpret_cast<float4*>(sB + k * STRIP_LDB + (idx & 15) * 4) = vb[q]; }
-  __syncthreads();
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const float* pA = sA + lc * 16 + li; const float* pB = sB + lc * STRIP_LDB + 16 * wave + li;
-  constexpr int UN = 8;
-  for (int s0 = 0; s0 < Kp; s0 += 4 * UN) {
-    float av[UN], bv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) { const int k = s0 + 4 * u < Kp ? s0 + 4 * u : 0; av[u] = pA[k * 16]; bv[u] = pB[k * STRIP_LDB]; }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const float a_ = s0 + 4 * u < Kp ? av[u] : 0.f;
-      if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv[u], acc1, 0, 0, 0);
-      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bv[u], acc0, 0, 0, 0);
-    }
-  }
-  if (!nOk) return;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m0 + lc * 4 + r;
-    const float v = acc0[r] + acc1[r];
-    if (m < P.M - 1) {
-      const size_t i = (size_t)m * P.ldc + n;
-      P.C[i] = v;
-      if (P.adam) { float w = ew[r], a1 = e1[r], a2 = e2[r]; adamStep(ac, v, w, a1, a2); P.adW[i] = w; P.adM1[i] = a1; P.adM2[i] = a2; }
-    } else if (m == P.M - 1) {
-      P.biasOut[n] = v;
-      if (P.adam) { float w = ew[r], a1 = e1[r], a2 = e2[r]; adamStep(ac, v, w, a1, a2); P.adbW[n] = w; P.adbM1[n] = a1; P.adbM2[n] = a2; }
-    }
-  }
 }
 
 // ROLE only names the instantiation (fwd0 / fwd / dx / dw) so that a kernel trace separates the four

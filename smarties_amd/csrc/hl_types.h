@@ -167,12 +167,22 @@ struct GemmProblem {
   // update, adamRed -- by splitk_reduce_kernel (gemm16.hip)
   int nSplit, adamRed;
   float* part;
-  // GEMM_W with a short reduction (K <= 128 minibatch rows) and many columns: 16 x 64 strips, one 16 x 16 tile per wavefront with the
-  // whole reduction -- a quarter of the workgroups, no cross-wave join (gemm_tile.h: gemmStripW; tilesN counts strips then)
-  int strip;
 };
 
+// one-kernel exchange between replicas (xchg.hip): sequence number of the next collective, arrival count of its workgroups
+struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int pad; };
+// replicas connected through peer windows: the weight-gradient launch stores every gradient tile into the peers' windows as well
+// (16-byte stores over xGMI from the tile's epilogue), so the transfer overlaps the launch and the exchange kernel behind it only
+// stamps, waits, sums and applies Adam (round 4; before: the exchange kernel pushed the whole message after the launch)
+struct PushArgs {
+  int on, nRanks, rank, pad;
+  unsigned char* const* peers;          // [nRanks] windows as this device addresses them
+  unsigned long long slotsOffset, slotBytes;
+  const XchgCtl* ctl;                   // parity of the collective the gradient belongs to = ctl->seq & 1
+  const float* gBase;                   // gradient array (offsets inside the message)
+};
 struct AdamHyper { float eta0, lambda, fac; double epsAnneal; int parity; /* minibatch buffer of this step */
-                   int variant; /* development ablation switches, 0 in production */ };
+                   int variant; /* development ablation switches, 0 in production */
+                   PushArgs push; };
 
 }  // namespace hl

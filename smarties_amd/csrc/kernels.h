@@ -149,7 +149,6 @@ struct AdamArgs {
 // one-kernel sum over the replicas' windows (xchg.hip)
 constexpr int XCHG_CHUNKS = 64;         // workgroups (= independently flagged chunks) of one collective, at most
 constexpr int XCHG_MAX_RANKS = 16;
-struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int pad; };
 struct XchgArgs {
   void* msg; long long n;                       // local message, summed in place
   int nRanks, rank;
@@ -158,8 +157,12 @@ struct XchgArgs {
   XchgCtl* ctl; DevScalars* sc;
   long long timeoutTicks;                       // wall_clock64 ticks (100 MHz) a workgroup waits for a peer's stamp
   int fuse; AdamArgs adam; PostArgs post;      // fuse != 0 (float messages): Adam on the summed chunk, then the bookkeeping pass
+  long long pushed;                             // leading elements of the message the producing launch already stored into the peers' windows (PushArgs)
 };
 hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype /* 0 float, 1 double, 2 int64 */, hipStream_t s);
+// zeroes, in this replica's own window, what the collective just finished left in the senders' slots (first `bytes` of each): the
+// gradient slots then hold zeros wherever no tile of a pushing launch writes (padding of the parameter layout)
+hipError_t launch_xchg_clean(unsigned char* win, size_t slotsOffset, size_t slotBytes, int nRanks, const XchgCtl* ctl, long long bytes, hipStream_t s);
 // extra workgroup appended to an MLP kernel's grid (tail_dev.h): role 0 none, 1 sampler phases
 // (PH_A/B/C mask) of the NEXT step's minibatch, 2 bookkeeping of the step just computed
 // PH_PUBLISH: phase C stops after the index -> (episode, step) search and hands the gather to helper
@@ -219,25 +222,6 @@ hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlo
 hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s,
                                 const PostArgs* farBeta = nullptr);      // farBeta: a rider workgroup runs farBetaPhase (tail_dev.h)
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
-// forward chain + head + input-gradient chain of one minibatch panel per workgroup group, ONE launch (mlp_panel.hip): the generic
-// counterpart of the fused kernel -- any stack of dense layers (or none: recurrent nets hand over the last block's output), any head
-struct PanelArgs {
-  HeadArgs h;
-  int nFwd; int fwdIdx[HL_MAX_HIDDEN];      // dense forward layers (problems in the device table), first to last
-  int nDx; int dxIdx[HL_MAX_HIDDEN];        // input-gradient problems behind the head, last layer first
-  int G;                                    // workgroups per 16-row panel (>= column tiles of every chained problem)
-  int nRiders;                              // rider workgroups in front of the panels (a multiple of 8: panels keep blockIdx % 8 == XCD)
-  unsigned* panelCtr;                       // [panels][32] arrive counters of the group barrier (monotonic; zeroed by the host at start-up and every 1000th step)
-  int deferBeta;                            // 1: beta of this step is published by a rider of this launch (farBetaPhase): the heads wait for DevScalars::betaSeq
-  unsigned long long boundedMask;           // bit i: action component i is bounded (the kernel serves dA <= 32; indexing HeadArgs::bounded per lane
-                                            // would make the compiler walk the kernel arguments lane by lane)
-};
-bool mlp_panel_ok(const HeadArgs& a);       // shapes the panel kernel serves (the others keep head_kernel_t and the per-layer launches)
-size_t mlp_panel_lds_bytes(const HeadArgs& a);
-int mlp_panel_blocks(const PanelArgs& pa, int maxRows);
-// riders: extra in workgroup 0 (sampler phases of the next step), extra2 in workgroup 1, gather helpers (extra->helpers) behind them
-hipError_t launch_mlp_panel(const GemmProblem* dProbs, const PanelArgs& pa, int maxRows, const DevScalars* sc, const AdamHyper& hyp,
-                            const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);
 hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 size_t fused_lds_bytes(int dS, int H);
 // the same step for two-hidden-layer nets with wide states (first layer streamed in slabs) and any head of head_rows.h (fusedw.hip)

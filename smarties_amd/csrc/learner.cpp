@@ -140,9 +140,7 @@ struct hl_learner {
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool xcdSafe = false;      // fused kernel: panel exchange through agent-scope accesses (workgroup b was NOT found on XCD b % 8, or forced)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
-  // panel kernel (mlp_panel.hip): panelHeadOk -- it serves the head of this network (16 samples per workgroup group, output layer
-  // on MFMA) in place of head_kernel_t; panelStepOk -- dense layers forward, head and input gradients go out as ONE launch
-  bool panelHeadOk = false, panelStepOk = false; int panelHeadG = 1, panelG = 1; unsigned* panelCtrP = nullptr;
+  bool pushOk = false, pushGrad = false;   // replicas over peer windows: the weight-gradient launch pushes its tiles itself (PushArgs); pushGrad: for the launch being issued
   bool fusedWideOk = false;  // two equal hidden blocks with a wide state and / or a head beyond the fused kernel's: fusedw.hip takes the two-kernel step
   int dbgVariant = 0;
   // rccl
@@ -761,36 +759,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   }
   h->ldDo = (int)roundUp(h->nDense, 16);
   HIPCK(devAlloc(&h->dOut, (size_t)B * h->ldDo));
-  if (!h->fusedOk) {
-    const char* np = getenv("SMARTIES_HIP_NO_PANEL");       // 1: the round-3 launches (head_kernel_t, forward chain, per-layer dX); 2: panel head only
-    const int off = np ? atoi(np) : 0;
-    const HeadArgs ha = headArgs(h, 0);
-    h->panelHeadOk = off != 1 && mlp_panel_ok(ha);
-    if (h->panelHeadOk) {
-      const int HT = (ha.H + 15) / 16;
-      h->panelHeadG = std::max(1, (HT + 3) / 4);            // one column tile of the last block per wavefront
-      int G = h->panelHeadG; bool ok = off == 0 && !h->recurrent;
-      const int j0 = h->nConv > 0 ? 1 : 0;
-      for (int j = j0; j < h->nHidden && ok; ++j) G = std::max(G, (h->hid[j].size + 15) / 16);
-      for (int j = h->nHidden - 1; j >= 1 && ok; --j) G = std::max(G, (h->hid[j].nIn + 15) / 16);
-      ok = ok && G <= 64;      // a panel's group meets at barriers: all of it has to be resident on one XCD (32 CUs x 2 workgroups)
-      const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
-      HIPCK(devAlloc(&h->panelCtrP, nCtr));
-      if (ok) {      // where do the workgroups of such a launch run?  (same probe as for the fused kernel)
-        PanelArgs pa{}; pa.h = ha; pa.G = G; pa.nRiders = 8;
-        const int nBlk = mlp_panel_blocks(pa, h->Mmax);
-        int* dX = nullptr; HIPCK(devAlloc(&dX, (size_t)nBlk));
-        HIPCK(launch_xcc_probe(nBlk, 256, mlp_panel_lds_bytes(ha), dX, h->stream));
-        std::vector<int> xcc((size_t)nBlk);
-        HIPCK(hipMemcpyAsync(xcc.data(), dX, xcc.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCK(hipStreamSynchronize(h->stream)); hipFree(dX);
-        for (int b = 8; b < nBlk; ++b) ok = ok && xcc[(size_t)b] == xcc[(size_t)(8 + ((b - 8) & 7))];
-        const char* f = getenv("SMARTIES_HIP_PANEL_SAFE");
-        ok = ok && !(f && f[0] == '1');
-      }
-      h->panelStepOk = ok; h->panelG = G;
-    }
-  }
   for (int pb = 0; pb < 2; ++pb) {
     DevBatch& bt = h->buf[pb].bt;
     HIPCK(devAlloc(&h->buf[pb].X0, (size_t)h->Mmax * h->ldX0));
@@ -857,7 +825,7 @@ int hl_destroy(hl_learner* h) {
     h->dRedMax, h->dRedErr, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,
-    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->rp.farP, h->rp.farN, h->rp.farStart, h->panelCtr, h->panelCtrP, h->dActS, h->dActO};
+    h->rp.stStd, h->rp.epTag, h->rp.posRec, h->rp.farP, h->rp.farN, h->rp.farStart, h->panelCtr, h->dActS, h->dActO};
   for (int pb = 0; pb < 2; ++pb) {
     DevBatch& bt = h->buf[pb].bt;
     void* bp[] = {h->buf[pb].X0, bt.sVals, bt.tag, bt.pEid, bt.pNextOf, bt.flat, bt.pos, bt.eid, bt.t, bt.slot, bt.nextOf, bt.nextSrc,
@@ -1998,6 +1966,10 @@ int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
   // identical initial weights on every replica: MPI_Bcast from rank 0 (Network/Builder.cpp:143-144) as a sum with zeros
   if (h->cfg.rank == 0) HIPCK(hipMemcpyAsync(h->G, h->W, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   else HIPCK(hipMemsetAsync(h->G, 0, (size_t)h->nParams * sizeof(float), h->stream));
+  // dense networks: every gradient element comes out of a tile of the weight-gradient launch, which then stores it into the peers'
+  // windows itself (recurrent and convolutional nets have further gradient producers -- split-row joins, filter gradients: the
+  // exchange kernel keeps pushing their message)
+  { const char* np = getenv("SMARTIES_HIP_NO_PUSH"); h->pushOk = !(np && np[0] == '1') && !h->recurrent && h->nConv == 0; }
   int rc = xchgAllreduce(h, h->G, (size_t)h->nParams, 0); if (rc) return rc;
   HIPCK(hipMemcpyAsync(h->W, h->G, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));

@@ -30,11 +30,8 @@ constexpr int GRAPH_SIZES[] = {999, 256, 128, 64, 32, 16, 8, 4, 2, 1};
 constexpr int CNT_MSG_FLOATS = 16;     // four counters x four 16-bit chunks (tail_dev.h: postPart)
 constexpr int CNT_MSG_OFFSET = 128;    // counters message inside the PARAM_TAIL floats behind the gradient (learner.cpp)
 
-void setTiles(GemmProblem& p, int& cursor, bool maySplit = false, bool mayStrip = false) {
+void setTiles(GemmProblem& p, int& cursor, bool maySplit = false) {
   p.tilesM = (p.M + 15) / 16; p.tilesN = (p.N + 15) / 16;
-  // short reductions over many columns, in launches of gemm16_kernel<DW> only (the argument-table kernel keeps its LDS size): 16 x 64 strips
-  p.strip = (mayStrip && p.flavor == GEMM_W && p.K <= 128 && p.N >= 64) ? 1 : 0;
-  if (p.strip) p.tilesN = (p.N + 63) / 64;
   if (p.flavor == RED_COL) { p.tilesM = 1; p.tilesN = (p.N + 15) / 16; }
   // weight gradients over >= 1024 rows (recurrent nets: batch x BPTT steps): one workgroup per (tile, 256-row chunk)
   p.nSplit = (maySplit && (p.flavor == GEMM_W || p.flavor == RED_COL) && p.K >= 1024) ? (p.K + 255) / 256 : 1;
@@ -76,9 +73,6 @@ int buildProblems(hl_learner* h) {
     }
     // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
     sb.dwIdx = (int)P.size(); int cur = 0;
-    // (nets whose weight gradients go out through launchBackward, i.e. gemm16_kernel<DW> with the table in memory: convolutional /
-    //  appended-observation nets; the two-kernel steps use the argument-table kernel when the table fits)
-    const bool viaGemm16 = !h->fusedOk && h->preproc && getenv("SMARTIES_HIP_NO_STRIPS") == nullptr;
     for (int j = 0; j < nH && h->recurrent; ++j) {
       // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
       // sample does not have carry zero deltas (rec_backward_kernel)
@@ -129,7 +123,7 @@ int buildProblems(hl_learner* h) {
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
       else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
       p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
-      setTiles(p, cur, false, viaGemm16); P.push_back(p);
+      setTiles(p, cur); P.push_back(p);
       if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
         r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
@@ -187,6 +181,10 @@ int buildProblems(hl_learner* h) {
 AdamHyper adamHyper(const hl_learner* h, int parity) {
   AdamHyper a{}; a.eta0 = (float)h->cfg.learnrate; a.lambda = (float)h->cfg.nnLambda; a.fac = (float)(1.0 / h->Bglobal);
   a.epsAnneal = h->cfg.epsAnneal; a.parity = parity; a.variant = h->dbgVariant;
+  if (h->pushGrad) {      // (set by the step sequences around their weight-gradient launches)
+    a.push.on = 1; a.push.nRanks = h->cfg.n_ranks; a.push.rank = h->cfg.rank; a.push.peers = h->xchg.dPeers;
+    a.push.slotsOffset = h->xchg.slotsOffset; a.push.slotBytes = h->xchg.slotBytes; a.push.ctl = h->xchg.ctl; a.push.gBase = h->G;
+  }
   return a;
 }
 SampleArgs sampleArgs(hl_learner* h, int parity, const long long* dFlat, bool computeEta) {
@@ -324,9 +322,7 @@ void convSource(hl_learner* h, int parity, ConvArgs* ca) {
 }
 // `gather`: states with appended observations / convolutional input are assembled here, from the sampled slots
 // (rollout inference writes the standardised rows itself)
-// `denseToo` = false: only what sits in front of the dense layers (stacked-state gather, convolutions) -- the dense layers
-// are then part of the panel kernel's launch (launchPanelStep)
-int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true, bool denseToo = true) {
+int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   char nm[32];
@@ -352,7 +348,6 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
     }
   }
-  if (!denseToo) return HL_OK;
   if (h->chainOk) {      // every dense layer in one launch, sampler phases A and B of the next step riding along
     ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
     if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
@@ -383,7 +378,9 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
   ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
   // (recurrent nets have no forward GEMM launches: the whole sampler of the next step rides along the head kernel)
   if (nextSample) {
-    ex = extraSample(h, parity ^ 1, h->recurrent ? PH_ALL : PH_C); pex = &ex;
+    // recurrent nets (no forward GEMM launches): draws and sort of the next minibatch ride here, its index search the weight-gradient
+    // launch (launchBackward, sampleC) -- the whole sampler (12 us) was this launch's longest workgroup
+    ex = extraSample(h, parity ^ 1, h->recurrent ? (PH_A | PH_B) : PH_C); pex = &ex;
     if (!ex.samp.noGather) {      // the gather of 2 B rows of dS floats: ~1024 floats per helper workgroup, at most 31 of them
       const long long fl = 2LL * h->B * h->dS;
       ex.helpers = (int)std::min<long long>(31, fl / 1024);
@@ -392,35 +389,7 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
       if (ex.helpers > 0 && !h->recurrent && !h->helperHandOff) ex.samp.selfSearch = 1;
     }
   }
-  if (h->panelHeadOk) {      // 16 samples per workgroup group, output layer on MFMA (mlp_panel.hip), no chained layers
-    PanelArgs pa{}; pa.h = ha; pa.G = h->panelHeadG; pa.panelCtr = h->panelCtrP;
-    for (int i = 0; i < h->dA && i < 64; ++i) if (h->cfg.bounded[i]) pa.boundedMask |= 1ull << i;
-    pa.nRiders = pex ? (int)roundUp(2 + ex.helpers, 8) : 0;
-    const AdamHyper hyp = adamHyper(h, parity);
-    HIPCK(timed(h, "head_kernel", s, [&] { return launch_mlp_panel(h->dProbs, pa, h->Mmax, h->sc, hyp, pex, nullptr, s); }));
-    return HL_OK;
-  }
   HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
-  return HL_OK;
-}
-// Dense layers forward + head + input gradients down the stack as ONE launch (mlp_panel.hip): with the weight-gradient launch
-// behind it, the two-kernel step of every dense network off the fused path.  `nextSample`: the sampler of the NEXT step rides along
-// (draws and sort; with convolutional preprocessing -- no gathered rows -- the whole sampler); `deferBeta`: the step before left its
-// far-policy count and beta update to a rider of this launch, the heads wait for it (as in launchFused)
-int launchPanelStep(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool deferBeta = false) {
-  if (h->fusedWideOk) return launchFusedWide(h, parity, s, nextSample, deferBeta);
-  const AdamHyper hyp = adamHyper(h, parity);
-  const StepBuf& sb = h->buf[parity];
-  PanelArgs pa{}; pa.h = headArgs(h, parity); pa.G = h->panelG; pa.panelCtr = h->panelCtrP;
-  for (int i = 0; i < h->dA && i < 64; ++i) if (h->cfg.bounded[i]) pa.boundedMask |= 1ull << i;
-  const int j0 = h->nConv > 0 ? 1 : 0;
-  for (int j = j0; j < h->nHidden; ++j) pa.fwdIdx[pa.nFwd++] = sb.fwdIdx[j];
-  for (size_t i = 0; i < sb.dxIdx.size(); ++i) pa.dxIdx[pa.nDx++] = sb.dxIdx[i];
-  ExtraArgs ex{}, ex2{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pex2 = nullptr;
-  if (nextSample) { ex = extraSample(h, parity ^ 1, h->preproc ? PH_ALL : (PH_A | PH_B)); pex = &ex; }
-  if (deferBeta) { pa.deferBeta = 1; ex2.role = 3; ex2.post = postArgs(h, parity ^ 1, POST_BETA); pex2 = &ex2; }
-  pa.nRiders = (pex || pex2) ? 8 : 0;
-  HIPCK(timed(h, "mlp_panel", s, [&] { return launch_mlp_panel(h->dProbs, pa, h->Mmax, h->sc, hyp, pex, pex2, s); }));
   return HL_OK;
 }
 // fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
@@ -446,12 +415,10 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
                        nextSampleC ? &exC : nullptr, s, fusePost ? &exP : nullptr); }));
   return HL_OK;
 }
-// `dxInPanel`: the input-gradient problems of the dense layers were part of the panel kernel's launch (launchPanelStep)
-int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA, bool dxInPanel = false) {
+// `sampleC`: the index search of the NEXT minibatch (sampler phase C; recurrent nets) rides the weight-gradient launch
+int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA, bool sampleC = false) {
   const AdamHyper hyp = adamHyper(h, parity);
-  StepBuf sbLocal = h->buf[parity];
-  if (dxInPanel) { sbLocal.dxIdx.clear(); sbLocal.dxBlocks.clear(); }
-  const StepBuf& sb = sbLocal;
+  const StepBuf& sb = h->buf[parity];
   ExtraArgs ex{}, exF{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pexF = nullptr;
   // one replica, bookkeeping riding the first dX launch: its far-policy count and the beta update move on to the dW launch (the next
   // reader of beta is the head kernel of the step after), off what was that launch's longest workgroup
@@ -495,6 +462,9 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
   // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.
   const ExtraArgs* pexW = sb.dxIdx.empty() ? pex : nullptr;
+  ExtraArgs exC{};
+  if (sampleC && pexF) return fail(h, HL_ERR_STATE, "no rider slot left for the sampler's index search on the weight-gradient launch");
+  if (sampleC) { exC = extraSample(h, parity ^ 1, PH_C); pexF = &exC; }
   HIPCK(timed(h, "gemm16_dw", s, [&] {
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s, pexF); }));
   if (sb.splitMaxMN > 0)
@@ -583,12 +553,16 @@ int xchgAllreduce(hl_learner* h, void* buf, size_t n, int dtype, int fuseParity 
     xa.adam.eta0 = (float)h->cfg.learnrate; xa.adam.lambda = (float)h->cfg.nnLambda; xa.adam.fac = (float)(1.0 / h->Bglobal);
     xa.adam.epsAnneal = h->cfg.epsAnneal; xa.adam.parity = fuseParity;
     xa.post = postArgs(h, fuseParity, POST_BETA);
+    xa.pushed = h->pushGrad ? h->nParams : 0;      // (the launch that produced this gradient pushed it)
   } xa.msg = buf; xa.n = (long long)n; xa.nRanks = h->cfg.n_ranks; xa.rank = h->cfg.rank; xa.peers = h->xchg.dPeers;
   xa.slotsOffset = h->xchg.slotsOffset; xa.slotBytes = h->xchg.slotBytes; xa.ctl = h->xchg.ctl; xa.sc = h->sc;
   xa.timeoutTicks = h->xchgTimeoutTicks;
   if (n * (dtype == 0 ? 4 : 8) > h->xchg.slotBytes) return fail(h, HL_ERR_COMM, "exchange message larger than the window slot");
   HIPCK(timed(h, "xchg_allreduce", h->stream, [&] { return launch_xchg_allreduce(xa, dtype, h->stream); }));
   h->nCollectives += 1;
+  // anything but a step's gradient (start-up counters, moments, the weight broadcast) leaves its bytes in the slots: zeroed again, so
+  // that the gradient slots hold zeros wherever no tile of a pushing launch writes
+  if (fuseParity < 0 && h->pushOk) HIPCK(launch_xchg_clean(h->xchg.win, h->xchg.slotsOffset, h->xchg.slotBytes, h->cfg.n_ranks, h->xchg.ctl, (long long)(n * (dtype == 0 ? 4 : 8)), h->stream));
   return HL_OK;
 }
 int allreduceGrad(hl_learner* h) {
@@ -656,11 +630,9 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
     HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));
     return launchBackward(h, parity, fuseAdam, s);       // no dX problems for this layout: the dW launch only
   }
-  if (h->panelStepOk || h->fusedWideOk) {      // dense layers, head and input gradients in one launch; then the weight gradients
-    int rc = launchForward(h, parity, s, false, true, false); if (rc) return rc;
-    rc = launchPanelStep(h, parity, s); if (rc) return rc;
-    if (!h->preproc) return launchWeightGrad(h, parity, fuseAdam, s, false, false);
-    return launchBackward(h, parity, fuseAdam, s, false, POST_AGG | POST_BETA, true);
+  if (h->fusedWideOk) {      // the wide fused kernel (fusedw.hip), then the weight gradients
+    int rc = launchFusedWide(h, parity, s); if (rc) return rc;
+    return launchWeightGrad(h, parity, fuseAdam, s, false, false);
   }
   int rc = launchForward(h, parity, s); if (rc) return rc;
   rc = launchHead(h, parity, s); if (rc) return rc;
@@ -684,6 +656,10 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   const long long k = h->nGradSteps + 1;
   const bool periodic = (k % 1000) == 0;
   const bool exch = exchanging(h);
+  // replicas over peer windows: the weight-gradient launch pushes the gradient itself -- unless another collective (the moments of a
+  // 1000th step) comes between that launch and the gradient's, taking the sequence number the push would have aimed at
+  struct PushScope { hl_learner* h; ~PushScope() { h->pushGrad = false; } } pushScope{h};
+  h->pushGrad = h->pushOk && h->xchg.on && !periodic;
   int p = 0, rc;
   if (h->preValid && !dFlat) { p = h->preParity; h->preValid = false; }     // drawn by the rider of the previous step
   else { rc = dropPresample(h); if (rc) return rc; rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc; }
@@ -718,15 +694,17 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   HIPCK(hipStreamSynchronize(s0));
   HIPCK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
   int rc = HL_OK;
+  struct PushScope { hl_learner* h; ~PushScope() { h->pushGrad = false; } } pushScope{h};
+  h->pushGrad = h->pushOk && h->xchg.on;         // (replayed steps never contain another collective than their gradient's)
   const long long nColl0 = h->nCollectives;      // captured calls are counted when the graph is replayed
   for (int j = 0; j < U && !rc; ++j) {
     const int p = (p0 + j) & 1;
-    const bool twoKernel = h->fusedOk || h->fusedWideOk || (h->panelStepOk && !h->preproc);
+    const bool twoKernel = h->fusedOk || h->fusedWideOk;
     if (twoKernel) {
       // one replica: the far-policy count and the beta update of every step but the last are taken out of the dW launch's
       // bookkeeping rider, where they sat at the end of the kernel's longest workgroup, into a rider of the next fused kernel
       const bool single = !exchanging(h) && !h->noDeferBeta;
-      rc = h->fusedOk ? launchFused(h, p, s0, true, single && j > 0) : launchPanelStep(h, p, s0, true, single && j > 0); if (rc) break;
+      rc = h->fusedOk ? launchFused(h, p, s0, true, single && j > 0) : launchFusedWide(h, p, s0, true, single && j > 0); if (rc) break;
       if (!exchanging(h)) {
         rc = launchWeightGrad(h, p, true, s0, true, true, POST_AGG | POST_BETA | (single && j + 1 < U ? POST_DEFER : 0)); if (rc) break;
         continue;
@@ -750,14 +728,11 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
       if (launch_rec_forward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_forward"); break; }
       rc = launchHead(h, p, s0, true); if (rc) break;
       if (launch_rec_backward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_backward"); break; }
-    } else if (h->panelStepOk) {      // convolutional front, then dense layers + head + their input gradients as one launch
-      rc = launchForward(h, p, s0, false, true, false); if (rc) break;
-      rc = launchPanelStep(h, p, s0, true); if (rc) break;
     } else {
       rc = launchForward(h, p, s0, true); if (rc) break;
       rc = launchHead(h, p, s0, true); if (rc) break;
     }
-    rc = launchBackward(h, p, !exch, s0, true, exch ? POST_AGG : (POST_AGG | POST_BETA), h->panelStepOk && !h->recurrent); if (rc) break;
+    rc = launchBackward(h, p, !exch, s0, true, exch ? POST_AGG : (POST_AGG | POST_BETA), h->recurrent); if (rc) break;
     if (exch) {
       if (h->xchg.on) { rc = xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p); if (rc) break; continue; }
       rc = allreduceGrad(h);
@@ -880,14 +855,14 @@ int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = fals
       return HL_OK;
     }
   }
-  if (h->eagerChain > 0 && avail <= h->eagerChain && (h->fusedOk || h->fusedWideOk || (h->panelStepOk && !h->preproc)) && !exchanging(h)) {
+  if (h->eagerChain > 0 && avail <= h->eagerChain && (h->fusedOk || h->fusedWideOk) && !exchanging(h)) {
     // short calls: the same two launches per step (riders included) issued directly -- no graph launch latency, no
     // first-launch cost of a graph that has not run yet
     if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
     const int U = (int)avail;
     for (int j = 0; j < U; ++j) {
       const int p = (p0 + j) & 1;
-      int rc = h->fusedOk ? launchFused(h, p, h->stream, true) : launchPanelStep(h, p, h->stream, true); if (rc) return rc;
+      int rc = h->fusedOk ? launchFused(h, p, h->stream, true) : launchFusedWide(h, p, h->stream, true); if (rc) return rc;
       rc = launchWeightGrad(h, p, true, h->stream, true, true); if (rc) return rc;
     }
     h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;

@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
   typedef Vec16<T> V;
   V* msg = reinterpret_cast<V*>(a.msg);
   const size_t slotOff = a.slotsOffset + ((size_t)par * R + me) * a.slotBytes;
-  // ---- push: this chunk into every peer's window ----
-  for (long long v = v0 + tid; v < v1; v += 256) {
+  // ---- push: this chunk into every peer's window (what the producing launch pushed itself -- the leading a.pushed elements of a
+  // gradient message, PushArgs -- is already there: its stores were acknowledged before that launch ended) ----
+  const long long vPushed = (a.pushed * (long long)sizeof(T)) >> 4;
+  for (long long v = max(v0, vPushed) + tid; v < v1; v += 256) {
     const V x = msg[v];
     for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<V*>(a.peers[p] + slotOff)[v] = x;
   }
@@ -66,9 +68,12 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
     __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
   }
   __syncthreads();
-  // A peer's message never came (or an earlier collective already failed: the error is sticky): no sum, no Adam, no bookkeeping --
-  // the slots hold an older collective's data.  Weights, moments and counters stay as they were; the host sees the error at its
-  // next read-back (HL_ERR_HIP, device-side failure 79).  The sequence still advances, so nothing waits on this collective later.
+  // A peer's message never came (or an earlier collective already failed: the error is sticky): this workgroup does no sum, no Adam,
+  // no bookkeeping -- the slots hold an older collective's data.  The guarantee is PER CHUNK, not per collective: a
+  // chunk whose peers did arrive may have summed and applied Adam to its slice before another chunk times out, so after device
+  // error 79 the parameter vector may be partially updated -- the error is fatal for the learner's state (the host sees
+  // HL_ERR_HIP at its next read-back and has to restart from a checkpoint); what the bounded wait buys is that the GPU is not
+  // hung.  The sequence still advances, so nothing waits on this collective later.
   const bool failed = sFail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   // ---- sum in rank order ----
   const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
@@ -119,6 +124,22 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
     __syncthreads();
     if (sLast && __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { __threadfence(); postPart(a.post, &sFarDelta, &sMaxAbs); }      // (all chunks are summed and visible)
   }
+}
+
+__global__ __launch_bounds__(256) void xchg_clean_kernel(unsigned char* win, size_t slotsOffset, size_t slotBytes, int nRanks, const XchgCtl* ctl, long long bytes) {
+  const unsigned long long seq = __hip_atomic_load(&ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the collective just closed was seq - 1)
+  const int par = (int)((seq - 1) & 1);
+  const long long n16 = (bytes + 15) >> 4;
+  for (int r = blockIdx.y; r < nRanks; r += gridDim.y) {
+    u32x4* q = reinterpret_cast<u32x4*>(win + slotsOffset + ((size_t)par * nRanks + r) * slotBytes);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) q[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+hipError_t launch_xchg_clean(unsigned char* win, size_t slotsOffset, size_t slotBytes, int nRanks, const XchgCtl* ctl, long long bytes, hipStream_t s) {
+  const long long n16 = (bytes + 15) >> 4;
+  int bx = (int)((n16 + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(xchg_clean_kernel, dim3(bx, nRanks), dim3(256), 0, s, win, slotsOffset, slotBytes, nRanks, ctl, bytes);
+  return hipGetLastError();
 }
 
 hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype, hipStream_t s) {

@@ -178,3 +178,34 @@ def test_resynchronised_long_run_stays_within_fp32_tolerance(hip_api, head):
         mg, mo = episode_arrays_by_tag(G, field), episode_arrays_by_tag(O, field)
         for tag in mo:
             assert np.allclose(mg[tag], mo[tag], rtol=2e-4, atol=2e-5), (field, tag)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# replicas over peer windows (xchg.hip), round 4: the weight-gradient launch stores its tiles into the peers' windows itself
+# (16-byte stores from the tile epilogue, PushArgs), the exchange kernel behind it only stamps, waits, sums and applies Adam
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("extra", [{}, dict(hidden=(24, 16, 8), nnFunc="Tanh"), dict(dimS=40, hidden=(64, 64), adv_kind=capi.ADV_GAUSSIAN)],
+                         ids=["fused-2x32", "generic-24x16x8", "wide-fused-gaussian-2x64"])
+def test_gradient_pushed_by_the_weight_gradient_launch_equals_the_exchange_kernels_own_push(hip_api, extra):
+    """Two pairs of replicas on this GPU, one pair with SMARTIES_HIP_NO_PUSH=1 (the exchange kernel pushes the whole message, as in
+    round 3): weights, Adam moments, beta and generator bit for bit over eager calls, replayed graphs and a 1000th-step sweep (whose
+    moments exchange takes a sequence number between the launch and the gradient's collective: that step pushes the old way)."""
+    import os
+    from test_hip_parity import _xchg_replicas, _both
+    cfg_kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4096, randSeed=11)
+    cfg_kw.update(extra)
+    sc = synth_cfg(seed=3, dimS=cfg_kw["dimS"], dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+    P = _xchg_replicas(hip_api, cfg_kw, sc, "after")
+    os.environ["SMARTIES_HIP_NO_PUSH"] = "1"
+    try:
+        Q = _xchg_replicas(hip_api, cfg_kw, sc, "after")
+    finally:
+        del os.environ["SMARTIES_HIP_NO_PUSH"]
+    for n in (1, 1, 3, 20, 70, 900, 10):
+        _both(P, lambda L: (L.step(n), L.sync()))
+        _both(Q, lambda L: (L.step(n), L.sync()))
+        for r in range(2):
+            for a, b in zip(P[r].get_params(), Q[r].get_params()):
+                assert np.array_equal(a, b), (n, r)
+            assert P[r].scalars().beta == Q[r].scalars().beta and np.array_equal(P[r].get_rng_state(), Q[r].get_rng_state())
+        assert np.array_equal(P[0].get_params()[0], P[1].get_params()[0])

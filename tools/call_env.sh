@@ -9,7 +9,7 @@ run X=1
 run ROC_ACTIVE_WAIT_TIMEOUT=1000
 run HSA_ENABLE_INTERRUPT=0
 run HSA_ENABLE_INTERRUPT=0 ROC_ACTIVE_WAIT_TIMEOUT=1000
-run ROC_SYSTEM_SCOPE_SIGNAL=0
+# (ROC_SYSTEM_SCOPE_SIGNAL=0 wedges the first synchronisation on this runtime: not run)
 run DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 run DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
 run SMARTIES_HIP_EAGER_CHAIN=64 NO_PREPARE=1

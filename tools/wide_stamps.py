@@ -1,5 +1,6 @@
-"""Device time stamps of workgroup (panel 0, member 0) of the panel kernel (mlp_panel.hip; library built with
-HL_EXTRA_FLAGS=-DHL_PANEL_STAMPS) inside replayed steps.  usage: panel_stamps.py humanoid|atari|rnn"""
+"""Device time stamps of workgroup (panel 0, tile 1) of the wide fused kernel (fusedw.hip; library built with
+HL_EXTRA_FLAGS=-DHL_PANEL_STAMPS) inside replayed steps, on one Humanoid replica's shape (257 states, 17 actions, 2 x 256, batch 32).
+usage: panel_stamps.py"""
 import ctypes as C
 import os
 import sys
@@ -45,23 +46,11 @@ for it in range(40):
     L.step(8)
     out = (C.c_longlong * 32)(); assert g(L.h, out) == 0
     acc.append(np.array(list(out), dtype=np.int64))
-if os.environ.get("WIDE"):      # the wide fused kernel (fusedw.hip) serves this shape: its own stamp points
+if True:
     a = np.array(acc)[:, 0:12]
     d = np.diff(a, axis=1) * 10
-    names = ["loads + stage", "h1 slab loop", "h1 epilogue", "own store + hoisted terms", "x2 tile + reduce + stores", "panel barrier", "read-back + stage", "output MFMA, reduce, beta", "head fp64", "delta_y3 / delta_x2 panel", "dX tile + epilogue"]
+    names = ["loads + stage", "h1 tile (MFMA, join)", "h1 store, barrier, read-back", "hoisted head terms", "x2 tile + reduce + stores", "panel barrier", "read-back + stage", "output MFMA, reduce, beta", "head fp64", "delta_y3 / delta_x2 panel", "dX tile + epilogue"]
     for nm, v in zip(names, np.median(d, axis=0)):
         print("%-28s %7.0f ns" % (nm, v))
     print("total %.0f ns" % (np.median(a[:, 11] - a[:, 0]) * 10))
     sys.exit(0)
-a = np.array(acc)[:, 0:10]
-d = np.diff(a, axis=1) * 10
-names = ["prefetch (rows, W_out^T)", "forward chain", "Y loads + hoisted terms", "output MFMA", "reduce -> outputs", "head fp64", "deltas", "own tiles", "dX chain"]
-med = np.median(d, axis=0)
-for nm, v in zip(names, med):
-    print("%-28s %7.0f ns" % (nm, v))
-print("total %.0f ns" % (np.median(a[:, 9] - a[:, 0]) * 10))
-full = np.array(acc)
-for nm, o in (("last forward tile", 16), ("first... last input-gradient tile", 22)):
-    dd = np.median(np.diff(full[:, o:o + 6], axis=1), axis=0) * 10
-    print("%-34s entry->loads issued %5.0f | ->staged %5.0f | ->MFMA done %5.0f | ->reduced %5.0f | ->epilogue %5.0f ns   (tile entry %.0f ns after kernel entry)"
-          % (nm, *dd, np.median(full[:, o] - full[:, 0]) * 10))
