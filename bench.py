@@ -11,11 +11,12 @@ before the timed region starts.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the reference's multi-learner mode
 (Settings/HyperParameters.cpp:186-197): batch 256 and the 1M replay are SPLIT over the replicas
-(strong scaling), one fp32 gradient all-reduce (RCCL over xGMI) per step.
+(strong scaling: `value`), one fp32 gradient sum per step (peer windows over xGMI, or RCCL); the same
+steps with batch 256 and 1M transitions PER replica follow as `weak_scaling_row` (outside `value`).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the library's
-stream (hl_kernel_profile: graph-replayed launches of each kernel of the step; at N = 1 these passes run before the
-timed region, on a second learner, which also brings the device to working clocks); `cpu_baseline` times the
+stream (hl_kernel_profile: graph-replayed launches of each kernel of the step; these passes run AFTER the timed region);
+`cpu_baseline` times the
 compiled reference (oracle/_ref, kind "reference") -- or the single-threaded CPU oracle
 (kind "port") when the reference binary is absent -- on a bounded sample of the same workload.
 """
@@ -390,15 +391,15 @@ def main():
         dom = max(table, key=lambda n: table[n]["launch_us"])
         d = table[dom]
         # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process;
-        # the committed rocprofv3 --pmc passes (profiles/r03_pmc.json: commands, corrections) are quoted
+        # the committed rocprofv3 --pmc passes (profiles/r04_pmc.json: commands, corrections) are quoted
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
                 traffic = json.load(f)["kernels"][dom.split("<")[0]]["traffic_bytes"]
         except Exception:  # noqa: BLE001
             traffic = None
         roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r03_pmc.json)",
+                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r04_pmc.json)",
                 "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
                 "step_kernels": table,
                 "note": "latency-bound step: dependent launches of a few hundred workgroups; launch_us = HIP-event time "
