@@ -195,7 +195,7 @@ inline bool isFarPolicy(Fval W, Fval C, Fval invC) {
 // ---------------------------------------------------------------------------
 // network description (Network/Builder.cpp:48-117, Layers/*.h)
 // ---------------------------------------------------------------------------
-enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM, L_MGU, L_CONV };
+enum LType { L_INPUT, L_DENSE, L_PARAMRES, L_PARAM, L_LSTM, L_MGU, L_CONV, L_JOIN };
 struct Layer {
   LType type; int size = 0, nIn = 0, nOutSimd = 0, func = HL_FUNC_LINEAR;
   hl_conv2d cv{};                     // L_CONV: Conv2DLayer<SoftSign, ...> (Network/Layers/Layer_Conv2D.h:29-232)
@@ -278,7 +278,11 @@ void buildNet(ol_learner* h) {
   std::vector<Layer>& L = h->layers;
   L.clear();
   // input: the observed state followed by the nAppendedObs previous ones (Approximator.cpp:208-209, 242-243)
-  { Layer in; in.type = L_INPUT; in.size = c.dimS * (1 + c.nAppendedObs); L.push_back(in); }
+  // with convolutions the first input layer is the first convolution's image; state variables beyond it become a second
+  // input layer behind the conv stack, glued to it by a JoinLayer (Approximator.cpp:245-259, Builder.cpp:26-46)
+  const int inAll = c.dimS * (1 + c.nAppendedObs);
+  const int inImg = c.n_conv > 0 ? c.conv[0].inpFeatures * c.conv[0].inpY * c.conv[0].inpX : inAll;
+  { Layer in; in.type = L_INPUT; in.size = inImg; L.push_back(in); }
   // Approximator::buildPreprocessing (Approximator.cpp:231-271) -> Builder::addConv2d (Builder.cpp:172-215): SoftSign
   // convolutions, no skip connections between them
   for (int j = 0; j < c.n_conv; ++j) {
@@ -286,6 +290,10 @@ void buildNet(ol_learner* h) {
     Layer cl; cl.type = L_CONV; cl.cv = d; cl.func = HL_FUNC_SOFTSIGN;
     cl.size = d.outFeatures * d.outY * d.outX; cl.nIn = d.inpFeatures * d.inpY * d.inpX;
     L.push_back(cl);
+  }
+  if (inAll > inImg) {
+    Layer in; in.type = L_INPUT; in.size = inAll - inImg; L.push_back(in);
+    Layer jn; jn.type = L_JOIN; jn.size = in.size + L[L.size() - 2].size; L.push_back(jn);      // JoinLayer(ID + 1, twoLayersSize, 2)
   }
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
@@ -325,7 +333,7 @@ void buildNet(ol_learner* h) {
   int64_t tot = 0;
   for (auto& l : L) {
     switch (l.type) {
-      case L_INPUT: l.nW = 0; l.nB = 0; break;
+      case L_INPUT: case L_JOIN: l.nW = 0; l.nB = 0; break;
       case L_DENSE: l.nW = (int64_t)l.nOutSimd * (l.nIn + (l.rec ? l.size : 0)); l.nB = l.size; break;   // Layer_Base.h:24-28
       case L_PARAMRES: l.nW = l.size; l.nB = l.size; break;                    // Layers.h:334-338
       case L_PARAM: l.nW = 0; l.nB = l.size; break;                            // Layers.h:494-497
@@ -425,9 +433,17 @@ inline nnReal sigmEval(nnReal in) {   // Sigm::_eval (Functions.h:158-165), safe
 void forwardNet(const ol_learner* h, const nnReal* input, std::vector<std::vector<nnReal>>& X,
                 std::vector<std::vector<nnReal>>& Y, const std::vector<std::vector<nnReal>>* prevY = nullptr) {
   const auto& L = h->layers;
-  std::copy(input, input + L[0].size, Y[0].begin());
+  { int k = 0;      // Activation::setInput (Layers/Activation.h:58-70): the input vector, cut over the input layers in order
+    for (size_t ID = 0; ID < L.size(); ++ID) if (L[ID].type == L_INPUT) { std::copy(input + k, input + k + L[ID].size, Y[ID].begin()); k += L[ID].size; } }
   for (size_t ID = 1; ID < L.size(); ++ID) {
     const Layer& l = L[ID];
+    if (l.type == L_INPUT) continue;
+    if (l.type == L_JOIN) {      // JoinLayer::forward (Layers.h:289-299): the layer before first, then the one before that
+      const int n1 = L[ID - 1].size, n2 = L[ID - 2].size;
+      std::copy(Y[ID - 1].begin(), Y[ID - 1].begin() + n1, Y[ID].begin());
+      std::copy(Y[ID - 2].begin(), Y[ID - 2].begin() + n2, Y[ID].begin() + n1);
+      continue;
+    }
     const nnReal* W = h->W.data() + l.indW; const nnReal* Bv = h->W.data() + l.indB;
     if (l.type == L_DENSE) {  // Layer_Base.h:64-95
       nnReal* suminp = X[ID].data();
@@ -550,6 +566,10 @@ void backwardNet(ol_learner* h) {
       }
     } else if (l.type == L_CONV) {
       convBackward(l, W, Y[ID - 1].data(), X[ID].data(), Y[ID].data(), E[ID].data(), ID > 1 ? E[ID - 1].data() : nullptr, gW, gB);
+    } else if (l.type == L_JOIN) {      // JoinLayer::backward (Layers.h:301-313): errors handed back, overwriting
+      const int n1 = L[ID - 1].size, n2 = L[ID - 2].size;
+      std::copy(E[ID].begin(), E[ID].begin() + n1, E[ID - 1].begin());
+      std::copy(E[ID].begin() + n1, E[ID].begin() + n1 + n2, E[ID - 2].begin());
     }
   }
 }
@@ -583,6 +603,12 @@ void backwardSeries(ol_learner* h, std::vector<Act>& series, int T) {
         nnReal* gradInp = cur.E[ID - 2].data(); const nnReal* inp = cur.Y[ID - 2].data();
         const int sizeInp = std::min(actSize(L[ID - 2]), l.size);
         for (int j = 0; j < sizeInp; ++j) { gradInp[j] += delta[j] * W[j]; gW[j] += delta[j] * inp[j]; gB[j] += delta[j]; }
+      } else if (l.type == L_CONV) {      // (a conv stack in front of recurrent layers: every step of the window passes through it)
+        convBackward(l, W, cur.Y[ID - 1].data(), cur.X[ID].data(), cur.Y[ID].data(), cur.E[ID].data(), ID > 1 ? cur.E[ID - 1].data() : nullptr, gW, gB);
+      } else if (l.type == L_JOIN) {
+        const int n1 = L[ID - 1].size, n2 = L[ID - 2].size;
+        std::copy(cur.E[ID].begin(), cur.E[ID].begin() + n1, cur.E[ID - 1].begin());
+        std::copy(cur.E[ID].begin() + n1, cur.E[ID].begin() + n1 + n2, cur.E[ID - 2].begin());
       } else if (l.type == L_MGU) {    // Layer_GRU.h:120-229
         const int nC = l.size;
         const nnReal* forget = cur.X[ID].data(); const nnReal* state = forget + nC;
@@ -1156,12 +1182,11 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
-  if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
-  for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
+  for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the stacked input or its first part
     const hl_conv2d& d = cfg->conv[j];
     const int inSize = d.inpFeatures * d.inpY * d.inpX;
     const int prev = j == 0 ? cfg->dimS * (1 + cfg->nAppendedObs) : cfg->conv[j - 1].outFeatures * cfg->conv[j - 1].outY * cfg->conv[j - 1].outX;
-    if (inSize != prev || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.stridey < 1) return HL_ERR_BAD_ARG;
+    if ((j == 0 ? inSize > prev : inSize != prev) || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.stridey < 1) return HL_ERR_BAD_ARG;
     if (d.outY != (d.inpY - d.filtery + 2 * d.paddiny) / d.stridey + 1 || d.outX != (d.inpX - d.filterx + 2 * d.paddinx) / d.stridex + 1) return HL_ERR_BAD_ARG;
   }
   auto* h = new ol_learner(); h->cfg = *cfg;

@@ -209,7 +209,7 @@ struct Harness {
     algo = std::make_unique<TaskQueue>([]() { return false; });
     dataQ = std::make_unique<TaskQueue>([]() { return false; });
     L->setupTasks(*algo); L->setupDataCollectionTasks(*dataQ);
-    if (MDP.nAppendedObs > 0) const_cast<std::unique_ptr<Sampling>&>(L->data->sampler) = std::make_unique<RestrictedSampler>(info.generators, L->data.get(), MDP.nAppendedObs, (unsigned)A.l("sampleSeed", 99));
+    if (MDP.nAppendedObs > 0 || A.kv.count("minT")) const_cast<std::unique_ptr<Sampling>&>(L->data->sampler) = std::make_unique<RestrictedSampler>(info.generators, L->data.get(), (Uint)A.l("minT", MDP.nAppendedObs), (unsigned)A.l("sampleSeed", 99));      // (minT = nApp + bptt for recurrent nets: the window's first steps are read the same way)
     SC.seed = (uint64_t)A.l("synthSeed", 7); SC.dimS = (int)dS; SC.dimA = (int)dA;
     SC.lenMin = (int)A.l("lenMin", 201); SC.lenMax = (int)A.l("lenMax", 201);
     SC.pTerminated = A.d("pTerm", 0.0); SC.muSpread = A.d("muSpread", 0.5);

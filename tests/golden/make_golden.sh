@@ -159,4 +159,24 @@ ls -la "$HERE"/*.bin
 "$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/nature_dqn.bin" dimS=7056 dimA=1 nOpt=4 nApp=3 \
    "conv=84,84,4,32,8,4;20,20,32,64,4,2;9,9,64,64,3,1" layers=512 nnFunc=Tanh batch=32 nEps=16 lenMin=8 lenMax=14 pTerm=0.5 \
    nSteps=3 gradSteps=2,3 maxObs=262144 minObs=131072 gamma=0.99 explNoise=0.05 lean=1
+# G-a22: the network combinations of Approximator::buildPreprocessing / buildFromSettings (Approximator.cpp:218-271) the other fixtures
+# do not hold.  minT = the harness sampler's first step: nAppendedObs + bptt for recurrent nets behind stacked observations, because the
+# reference reads the first steps of a BPTT window through the same unsigned subtraction (it segfaults with smaller t)
+#   recurrent layers behind appended observations
+"$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/lstm_appended.bin" dimS=5 dimA=2 bounded=10 nApp=2 minT=6 layers=32,32 nnType=LSTM nnFunc=Tanh bptt=4 \
+   batch=16 nEps=30 lenMin=10 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500 lean=1
+#   recurrent layers behind a convolutional stack (every step of the window passes through the convolutions)
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/conv_lstm.bin" dimS=256 dimA=1 nOpt=4 nApp=3 minT=7 "conv=8,8,16,32,4,1;5,5,32,64,3,1" \
+   layers=32 nnType=LSTM nnFunc=Tanh bptt=4 batch=16 nEps=30 lenMin=10 lenMax=40 pTerm=0.5 nSteps=6 gradSteps=1,2,6 retSteps=6 maxObs=2000 minObs=500 lean=1
+#   state variables beside the image: a second input layer behind the conv stack + JoinLayer (Approximator.cpp:249-259, Builder.cpp:26-46),
+#   without and with appended observations (there the image is the first 1024 entries of the stacked vector, whatever they are)
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/conv_extra.bin" dimS=1030 dimA=1 nOpt=4 minT=0 "conv=8,8,16,32,4,1;5,5,32,64,3,1" \
+   layers=64 nnFunc=Tanh batch=16 nEps=30 lenMin=6 lenMax=40 pTerm=0.5 nSteps=6 gradSteps=1,2,6 retSteps=6 maxObs=2000 minObs=500 lean=1
+"$ROOT/oracle/_ref/ref_driver_discrete" fixture "$HERE/conv_extra_appended.bin" dimS=515 dimA=1 nOpt=4 nApp=1 "conv=8,8,16,32,4,1;5,5,32,64,3,1" \
+   layers=48 nnFunc=Tanh batch=16 nEps=30 lenMin=6 lenMax=40 pTerm=0.5 nSteps=4 gradSteps=1,2,4 retSteps=4 maxObs=2000 minObs=500 lean=1
+#   recurrent layers of more than 64 cells
+"$ROOT/oracle/_ref/ref_driver_racer" fixture "$HERE/lstm_wide.bin" dimS=5 dimA=2 bounded=10 layers=96,80 nnType=LSTM nnFunc=Tanh bptt=6 \
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=6 gradSteps=1,2,6 retSteps=6 maxObs=2000 minObs=500 lean=1
+"$DRV" fixture "$HERE/mgu_wide.bin" dimS=6 dimA=2 bounded=01 layers=128 nnType=MGU nnFunc=Tanh bptt=5 \
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=6 gradSteps=1,2,6 retSteps=6 maxObs=2000 minObs=500 lean=1
 rm -rf "$TMP"
