@@ -326,7 +326,9 @@ HL_API int hl_pack_episode(hl_learner* h, int64_t episode_pos, float* dst, int64
 /* Acting with recurrent layers (MemoryBuffer::agentToMinibatch, MemoryBuffer.cpp:440-467 + Approximator::forward(agent)):
  * `states` = the agent's last n_steps raw observed states, oldest first, n_steps = min(nnBPTTseq, t) + 1; every one is
  * forwarded from a zero recurrent state, `outputs` (nOutputs doubles) are those of the last.  Dense nets: only the last
- * state matters (same result as hl_forward on it). */
+ * state matters (same result as hl_forward on it).  Recurrent layers behind appended observations: up to nAppendedObs further
+ * states may stand in front of the window (n_steps <= nnBPTTseq + 1 + nAppendedObs); they only fill the appended slots of the
+ * window's first steps, and steps before the first given state repeat it (Episode::standardizedState, Episode.h:172-183). */
 HL_API int hl_forward_sequence(hl_learner* h, int32_t n_steps, const float* states, double* outputs);
 HL_API int hl_save(hl_learner* h, const char* base);
 HL_API int hl_restart(hl_learner* h, const char* base);

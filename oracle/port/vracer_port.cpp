@@ -1648,14 +1648,20 @@ int ol_forward_sequence(ol_learner* h, int32_t nSteps, const float* states, doub
   if (!h || nSteps < 1 || !states || !outputs) return HL_ERR_BAD_ARG;
   const int dS = h->dS;
   if (h->cfg.nn_type == HL_NN_FFNN) return ol_forward(h, 1, states + (size_t)(nSteps - 1) * dS, outputs);
-  std::vector<Act> series((size_t)nSteps);
-  std::vector<nnReal> inp(dS);
-  for (int k = 0; k < nSteps; ++k) {
+  // appended observations: up to nAppendedObs further states may be given in front of the window of min(nnBPTTseq, t) + 1 steps; they
+  // only feed the first steps' appended slots, and steps before the first given one repeat it (Episode::standardizedState's intent)
+  const int nApp = h->cfg.nAppendedObs, recK = (h->cfg.nnBPTTseq > 0 ? h->cfg.nnBPTTseq : 16) + 1;
+  const int win = std::min((int)nSteps, recK), ctx = nSteps - win;
+  if (ctx > nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
+  std::vector<Act> series((size_t)win);
+  std::vector<nnReal> inp((size_t)dS * (1 + nApp));
+  for (int k = 0; k < win; ++k) {
     series[k].X = h->X; series[k].Y = h->Y;
-    for (int i = 0; i < dS; ++i) inp[i] = (states[(size_t)k * dS + i] - h->stMean[i]) * h->stScale[i];
+    for (int j = 0; j <= nApp; ++j) { const int g = std::max(ctx + k - j, 0);
+      for (int i = 0; i < dS; ++i) inp[(size_t)j * dS + i] = (states[(size_t)g * dS + i] - h->stMean[i]) * h->stScale[i]; }
     forwardNet(h, inp.data(), series[k].X, series[k].Y, k ? &series[k - 1].Y : nullptr);
   }
-  getOutput(h, series[nSteps - 1].Y, outputs);
+  getOutput(h, series[win - 1].Y, outputs);
   return HL_OK;
 }
 int ol_grad_stats(ol_learner* h, double* mean, double* rms) {

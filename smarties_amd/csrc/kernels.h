@@ -77,6 +77,9 @@ struct RecArgs {
   float* Yout; int ldY;            // output of the last block at the sampled step (rows < B) and at t+1 (next rows): input of the head
   const float* Dres; int ldD;      // head: gradient w.r.t. Yout, rows < B
   const float* actStates; int actSteps;   // acting (hl_forward_sequence): raw states of the agent's last steps instead of a minibatch
+  int actCtx;                      // ... of which the first actCtx lie in front of the window (they only feed appended observations)
+  int nApp;                        // appended observations: the first layer's input is the step's state followed by the nApp before it
+  const float* Xin; int ldXin;     // != nullptr: the first layer's input rows, written by launches in front (conv stack): row b K + k, next rows behind B K
 };
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);

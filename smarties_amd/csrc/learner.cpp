@@ -567,16 +567,16 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->returnsEstimator < HL_RET_RETRACE || cfg->returnsEstimator > HL_RET_NONE) return HL_ERR_BAD_ARG;
   if (cfg->nnOutputFunc < HL_FUNC_LINEAR || cfg->nnOutputFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
   if (cfg->n_encoder < 0 || cfg->n_encoder + cfg->n_hidden > HL_MAX_HIDDEN) return HL_ERR_BAD_ARG;
-  if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: one gate per thread of a 256-thread workgroup
-    if (cfg->dimS > 256) return HL_ERR_UNSUPPORTED;
+  if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: 256-thread workgroups looping over gates and cells (REC_GENC, REC_GENIN)
+    if (cfg->dimS > 256 || (long long)cfg->dimS * (1 + std::max(cfg->nAppendedObs, 0)) > 1024) return HL_ERR_UNSUPPORTED;
     // (encoder layers are hidden layers of the same network, Learner_approximator.cpp:149-166: the same limits hold for them)
-    for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 64) return HL_ERR_UNSUPPORTED;
-    for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 64) return HL_ERR_UNSUPPORTED;
+    for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 256) return HL_ERR_UNSUPPORTED;
+    for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 256) return HL_ERR_UNSUPPORTED;
   }
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
-  if ((cfg->nAppendedObs > 0 || cfg->n_conv > 0) && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
+  if (cfg->n_conv > 0 && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
     const hl_conv2d& d = cfg->conv[j];
     const long long inSize = (long long)d.inpFeatures * d.inpY * d.inpX;
@@ -1660,7 +1660,7 @@ int hl_restart(hl_learner* h, const char* base) {
 
 // rollout inference: Approximator::forward(agent) for n states (RACER.cpp:30-59)
 // pinned, device-mapped staging of rollout inference: outputs [ACT_MAXROWS][nOut] f64 | states f32 | completion stamps
-static size_t actPinFloats(const hl_learner* h) { return std::max((size_t)ACT_MAXROWS * h->dIn, (size_t)std::max(h->recK, 1) * h->dS); }
+static size_t actPinFloats(const hl_learner* h) { return std::max((size_t)ACT_MAXROWS * h->dIn, (size_t)(std::max(h->recK, 1) + h->nApp) * h->dS); }
 static int actPinEnsure(hl_learner* h) {
   if (h->actPin) return HL_OK;
   const size_t bytes = (size_t)ACT_MAXROWS * (h->nOut * sizeof(double) + sizeof(unsigned)) + actPinFloats(h) * sizeof(float) + 256;
@@ -1732,7 +1732,8 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
     return hl_forward(h, 1, row.data(), outputs);
   }
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
-  if (nSteps > h->recK) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1");
+  // (appended observations: up to nAppendedObs further states in front of the window, which only feed the window's first steps)
+  if (nSteps > h->recK + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
   // states and outputs through pinned host memory, completion by stamp (as hl_forward): two launches, no staged copies
   { int rc = actPinEnsure(h); if (rc) return rc; }
   double* pOut = reinterpret_cast<double*>(h->actPin);
@@ -1741,7 +1742,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
   std::memcpy(pIn, states, (size_t)nSteps * h->dS * sizeof(float));
   unsigned tag = ++h->actTag; if (tag == 0) tag = ++h->actTag;
   const DevHidden& q = h->hid[h->nHidden - 1];
-  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = pIn; ra.actSteps = nSteps;
+  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = pIn; ra.actSteps = std::min(nSteps, h->recK); ra.actCtx = nSteps - ra.actSteps;
   HIPCK(launch_rec_forward(ra, h->stream));
   HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
                           pOut, h->stream, const_cast<unsigned*>(pDone), tag, h->cfg.nnOutputFunc));
@@ -1805,7 +1806,7 @@ int hl_readback(hl_learner* h, int32_t what, void* dst, int64_t bytes) {
     case HL_TAP_STATE: {
       if (bytes < (int64_t)B * h->dIn * 4) return HL_ERR_BAD_ARG;
       if (h->recurrent || convFromReplay(h)) {   // recurrent layers and row-block convolutions read their windows straight from the replay: the rows are assembled on demand
-        StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = bt; ga.B = B; ga.dS = h->dS; ga.nApp = h->recurrent ? 0 : h->nApp; ga.parity = h->lastParity;
+        StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = bt; ga.B = B; ga.dS = h->dS; ga.nApp = h->nApp; ga.parity = h->lastParity;
         ga.X0 = h->buf[h->lastParity].X0; ga.ldX0 = h->ldX0;
         HIPCK(launch_stack_gather(ga, h->Mmax, h->stream)); HIPCK(hipStreamSynchronize(h->stream));
       }

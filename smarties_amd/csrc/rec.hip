@@ -17,6 +17,9 @@ namespace hl {
 #define REC_MAXC 64       // cells per layer (4 gates x 64 = 256 threads)
 #define REC_MAXIN 256     // inputs of the first layer
 #define REC_STATES 4608   // window states kept in LDS (e.g. 18 steps x 256 state components)
+// the one-gate-per-thread kernels (rec_*, mgu_*, rnn_*: every shape the specialised ones do not take) loop over gates and cells:
+#define REC_GENC 256      // cells per layer there
+#define REC_GENIN 1024    // inputs of the first layer there (stacked observations, or the output of a convolutional stack)
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the global stores of the step
 // (the rows kept for the backward pass / the dW launch), ~1 us each, and nothing in these kernels reads them back
@@ -32,6 +35,23 @@ __device__ __forceinline__ float recSigm(float in) {     // Sigm::_eval (Functio
 // inside the loop with s_waitcnt vmcnt(0) -- which also waits for every row store of the previous layer-step to be acknowledged.
 __device__ __forceinline__ void vmDrain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt untouched
 
+
+// Element e of the network input at step k of sample b's window (general form; T = steps in front of the sampled one, t its index
+// in the episode):
+//   Xin != nullptr   rows written by launches in front of this one (a convolutional stack): row b K + k, the next state's row behind
+//                    the B K window rows (row B K + nextRow - B)
+//   acting           the agent's last states, oldest first, `actCtx` of them in front of the window (they only feed appended
+//                    observations); steps before the first given one repeat it
+//   otherwise        Episode::standardizedState (Episode.h:172-183): the state of the step followed by the nApp ones before it,
+//                    steps before the episode's first repeat the first
+__device__ __forceinline__ float recInputAt(const RecArgs& a, bool acting, int b, long long slot, int t, int T, int nextRow, int k, int e) {
+  if (a.Xin) { const long long row = k <= T ? (long long)b * a.K + k : (long long)a.B * a.K + (nextRow - a.B); return a.Xin[row * a.ldXin + e]; }
+  const int j = e / a.dS, i = e - j * a.dS;
+  float raw;
+  if (acting) { const int g = a.actCtx + k - j; raw = a.actStates[(size_t)(g > 0 ? g : 0) * a.dS + i]; }
+  else { const int tt = t - T + k, back = j < tt ? j : tt; raw = a.rp.S[(size_t)(slot - T + k - back) * a.dS + i]; }
+  return (raw - a.rp.stMean[i]) * a.rp.stScale[i];
+}
 
 // weights of all LSTM layers staged in LDS with a padded row stride (4 nC + 1: the forward pass reads columns, the backward
 // pass rows, both conflict-free); nets that do not fit read them through the L2 (ldsW = 0)
@@ -69,9 +89,9 @@ __device__ unsigned long long recStamps[256];
 template <bool LDSW>
 __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  __shared__ float sBuf[2][REC_MAXIN];                    // input of the current layer / output of the current block
-  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC], sPrevSt[HL_MAX_HIDDEN][REC_MAXC];
-  __shared__ float sX[4 * REC_MAXC];
+  __shared__ float sBuf[2][REC_GENIN];                    // input of the current layer / output of the current block
+  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_GENC], sPrevSt[HL_MAX_HIDDEN][REC_GENC];
+  __shared__ float sX[4 * REC_GENC];
   const int b = blockIdx.x, tid = threadIdx.x;
   RSTAMP(0);
   // acting (MemoryBuffer::agentToMinibatch, MemoryBuffer.cpp:440-467): the agent's last steps, from a zero recurrent state
@@ -101,7 +121,9 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
   }
   // the standardised states of the whole window, fetched in one round (Episode::standardizedState, Episode.h:172-183)
   __shared__ float sStates[REC_STATES];
-  const bool preload = nSteps * a.dS <= REC_STATES;
+  const int dIn = a.L[0].nIn;
+  const bool plain = a.Xin == nullptr && a.nApp == 0;      // the input of a step is that step's observed state
+  const bool preload = plain && nSteps * a.dS <= REC_STATES;
   if (preload) for (int e = tid; e < nSteps * a.dS; e += 256) {
     const int kk = e / a.dS, i = e - kk * a.dS;
     const float raw = acting ? a.actStates[e] : a.rp.S[(size_t)(slot - T + kk) * a.dS + i];
@@ -114,7 +136,8 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
     const bool store = !acting && k <= T;
     const long long r = (long long)b * a.K + k;
     const long long sl = slot - T + k;
-    if (tid < a.dS) {
+    if (!plain) { for (int e = tid; e < dIn; e += 256) sBuf[0][e] = recInputAt(a, acting, b, slot, t, T, nextRow, k, e); }
+    else if (tid < a.dS) {
       if (preload) sBuf[0][tid] = sStates[k * a.dS + tid];
       else { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)sl * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
     }
@@ -134,18 +157,18 @@ __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
         for (int i = tid; i < nIn; i += 256) L.A[r * L.ldA + i] = in[i];
         if (tid < nC) L.A[r * L.ldA + nIn + tid] = k > 0 ? sPrevOut[j][tid] : 0.f;
       }
-      if (tid < NO) {
-        float acc = bias[j];
+      for (int o = tid; o < NO; o += 256) {                // (one gate per thread up to 64 cells, four at 256)
+        float acc = o == tid ? bias[j] : W[L.indB + o];
         // (unrolled: the LDS reads of eight terms are in flight together; a rolled loop pays the LDS latency per term)
 #pragma unroll 8
-        for (int i = 0; i < nIn; ++i) acc += in[i] * wAt(i, tid);
+        for (int i = 0; i < nIn; ++i) acc += in[i] * wAt(i, o);
         if (k > 0) {
 #pragma unroll 8
-          for (int i = 0; i < nC; ++i) acc += sPrevOut[j][i] * wAt(nIn + i, tid);
+          for (int i = 0; i < nC; ++i) acc += sPrevOut[j][i] * wAt(nIn + i, o);
         }
-        if (tid >= nC) acc = recSigm(acc);                 // the gates overwrite their inputs
-        sX[tid] = acc;
-        if (store) L.X[r * NO + tid] = acc;
+        if (o >= nC) acc = recSigm(acc);                   // the gates overwrite their inputs
+        sX[o] = acc;
+        if (store) L.X[r * NO + o] = acc;
       }
       ldsBarrier();
       if (j < 2) RSTAMP(4 + k * 5 + 1 + 2 * j);
@@ -351,10 +374,10 @@ __global__ __launch_bounds__(256) void lstm_forward_lds_kernel(RecArgs a) {
 template <bool LDSW>
 __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  __shared__ float sTop[2][REC_MAXIN];                    // error w.r.t. the output of the current block (from above, same step)
-  __shared__ float sRec[HL_MAX_HIDDEN][REC_MAXC];          // error w.r.t. this step's LSTM output coming from step k+1
-  __shared__ float sNxtSt[HL_MAX_HIDDEN][REC_MAXC], sNxtF[HL_MAX_HIDDEN][REC_MAXC];
-  __shared__ float sD[4 * REC_MAXC], sRes[REC_MAXC], sRecNew[REC_MAXC];
+  __shared__ float sTop[2][REC_GENIN];                    // error w.r.t. the output of the current block (from above, same step)
+  __shared__ float sRec[HL_MAX_HIDDEN][REC_GENC];          // error w.r.t. this step's LSTM output coming from step k+1
+  __shared__ float sNxtSt[HL_MAX_HIDDEN][REC_GENC], sNxtF[HL_MAX_HIDDEN][REC_GENC];
+  __shared__ float sD[4 * REC_GENC], sRes[REC_GENC], sRecNew[REC_GENC];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = a.bt.t[b];
   const int T = min(a.nBPTT, t);
@@ -374,7 +397,7 @@ __global__ __launch_bounds__(256) void rec_backward_kernel(RecArgs a) {
     const long long r = (long long)b * a.K + k;
     for (int j = 0; j < a.nL; ++j) {
       const RecLayer& L = a.L[j];
-      if (tid < 4 * L.nC) L.D[r * 4 * L.nC + tid] = 0.f;
+      for (int o = tid; o < 4 * L.nC; o += 256) L.D[r * 4 * L.nC + o] = 0.f;
       if (L.hasRes && tid < L.nC) L.Rd[r * L.ldR + tid] = 0.f;
     }
   }
@@ -605,9 +628,9 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
   constexpr int MAXL = NL ? NL : HL_MAX_HIDDEN;
   const int nL = NL ? NL : a.nL;
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  __shared__ float sBuf[2][REC_MAXIN];
-  __shared__ float sPrevOut[MAXL][REC_MAXC];
-  __shared__ float sF[REC_MAXC], sS[REC_MAXC];
+  __shared__ float sBuf[2][REC_GENIN];
+  __shared__ float sPrevOut[MAXL][REC_GENC];
+  __shared__ float sF[REC_GENC], sS[REC_GENC];
   __shared__ float sStates[REC_STATES];
   const int b = blockIdx.x, tid = threadIdx.x;
   const bool acting = a.actStates != nullptr;
@@ -632,7 +655,9 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
       if (L.hasRes && tid < L.resW) { wr[j] = W[L.indWr + tid]; br[j] = W[L.indBr + tid]; }
     }
   }
-  const bool preload = nSteps * a.dS <= REC_STATES;
+  const int dIn = a.L[0].nIn;
+  const bool plain = a.Xin == nullptr && a.nApp == 0;      // the input of a step is that step's observed state
+  const bool preload = plain && nSteps * a.dS <= REC_STATES;
   if (preload) for (int e = tid; e < nSteps * a.dS; e += 256) {
     const int kk = e / a.dS, i = e - kk * a.dS;
     const float raw = acting ? a.actStates[e] : a.rp.S[(size_t)(slot - T + kk) * a.dS + i];
@@ -643,7 +668,8 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
   for (int k = 0; k < nSteps; ++k) {
     const bool store = !acting && k <= T;
     const long long r = (long long)b * a.K + k;
-    if (tid < a.dS) {
+    if (!plain) { for (int e = tid; e < dIn; e += 256) sBuf[0][e] = recInputAt(a, acting, b, slot, t, T, nextRow, k, e); }
+    else if (tid < a.dS) {
       if (preload) sBuf[0][tid] = sStates[k * a.dS + tid];
       else { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)(slot - T + k) * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
     }
@@ -661,30 +687,31 @@ __global__ __launch_bounds__(256) void mgu_forward_kernel(RecArgs a) {
         for (int i = tid; i < nIn; i += 256) L.A[r * L.ldA + i] = in[i];
         if (tid < nC) L.A[r * L.ldA + nIn + tid] = k > 0 ? sPrevOut[j][tid] : 0.f;
       }
-      float acc = 0.f;
-      if (tid < NO) {
-        acc = bias[j];
+      // (one gate per thread up to 128 cells, two at 256; the state gates' input sums wait in sS for the forget gates)
+      for (int o = tid; o < NO; o += 256) {
+        float acc = o == tid ? bias[j] : W[L.indB + o];
 #pragma unroll 8
-        for (int i = 0; i < nIn; ++i) acc += in[i] * wAt(i, tid);
-        if (tid < nC) {          // forget gate
+        for (int i = 0; i < nIn; ++i) acc += in[i] * wAt(i, o);
+        if (o < nC) {          // forget gate
           if (k > 0) {
 #pragma unroll 8
-            for (int i = 0; i < nC; ++i) acc += wAt(nIn + i, tid) * sPrevOut[j][i];
+            for (int i = 0; i < nC; ++i) acc += wAt(nIn + i, o) * sPrevOut[j][i];
           }
           acc = recSigm(acc);
-          sF[tid] = acc;
-          if (store) L.X[r * NO + tid] = acc;
-        }
+          sF[o] = acc;
+          if (store) L.X[r * NO + o] = acc;
+        } else sS[o - nC] = acc;
       }
       ldsBarrier();
-      if (tid >= nC && tid < NO) {   // cell state
+      for (int o = nC + tid; o < NO; o += 256) {   // cell state
+        float acc = sS[o - nC];
         if (k > 0) {
 #pragma unroll 8
-          for (int i = 0; i < nC; ++i) acc += wAt(nIn + i, tid) * sPrevOut[j][i] * sF[i];
+          for (int i = 0; i < nC; ++i) acc += wAt(nIn + i, o) * sPrevOut[j][i] * sF[i];
         }
         acc = actEval(HL_FUNC_TANH, acc);
-        sS[tid - nC] = acc;
-        if (store) L.X[r * NO + tid] = acc;
+        sS[o - nC] = acc;
+        if (store) L.X[r * NO + o] = acc;
       }
       ldsBarrier();
       float out = 0.f;
@@ -712,9 +739,9 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
   constexpr int MAXL = NL ? NL : HL_MAX_HIDDEN;
   const int nL = NL ? NL : a.nL;
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  __shared__ float sTop[2][REC_MAXIN];
-  __shared__ float sRec[MAXL][REC_MAXC];          // dLdprevOut handed from step k+1 to step k
-  __shared__ float sDF[REC_MAXC], sDS[REC_MAXC], sFP[REC_MAXC], sRes[REC_MAXC];
+  __shared__ float sTop[2][REC_GENIN];
+  __shared__ float sRec[MAXL][REC_GENC];          // dLdprevOut handed from step k+1 to step k
+  __shared__ float sDF[REC_GENC], sDS[REC_GENC], sFP[REC_GENC], sRes[REC_GENC];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = a.bt.t[b];
   const int T = min(a.nBPTT, t);
@@ -733,7 +760,7 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
     const long long r = (long long)b * a.K + k;
     for (int j = 0; j < nL; ++j) {
       const RecLayer& L = a.L[j];
-      if (tid < 2 * L.nC) L.D[r * 2 * L.nC + tid] = 0.f;
+      for (int o = tid; o < 2 * L.nC; o += 256) L.D[r * 2 * L.nC + o] = 0.f;
       if (L.hasRes && tid < L.nC) L.Rd[r * L.ldR + tid] = 0.f;
     }
   }
@@ -1237,10 +1264,10 @@ __device__ __forceinline__ int rnnLdsOffset(const RecArgs& a, int j) {
 template <bool LDSW>
 __global__ __launch_bounds__(256) void rnn_forward_kernel(RecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  __shared__ float sBuf[2][REC_MAXIN];
-  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_MAXC];
-  __shared__ float sPart[4][REC_MAXC];
-  const int b = blockIdx.x, tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  __shared__ float sBuf[2][REC_GENIN];
+  __shared__ float sPrevOut[HL_MAX_HIDDEN][REC_GENC];
+  __shared__ float sPart[4][REC_GENC];
+  const int b = blockIdx.x, tid = threadIdx.x, c0 = tid & 63, part = tid >> 6;
   const bool acting = a.actStates != nullptr;
   const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
   const int T = acting ? a.actSteps - 1 : min(a.nBPTT, t);
@@ -1264,7 +1291,8 @@ __global__ __launch_bounds__(256) void rnn_forward_kernel(RecArgs a) {
     const bool store = !acting && k <= T;
     const long long r = (long long)b * a.K + k;
     const long long sl = slot - T + k;
-    if (tid < a.dS) { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)sl * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
+    if (a.Xin != nullptr || a.nApp > 0) { for (int e = tid; e < a.L[0].nIn; e += 256) sBuf[0][e] = recInputAt(a, acting, b, slot, t, T, nextRow, k, e); }
+    else if (tid < a.dS) { const float raw = acting ? a.actStates[(size_t)k * a.dS + tid] : a.rp.S[(size_t)sl * a.dS + tid]; sBuf[0][tid] = (raw - sMean) * sScale; }
     ldsBarrier();
     int cur = 0;
     for (int j = 0; j < a.nL; ++j) {
@@ -1278,7 +1306,7 @@ __global__ __launch_bounds__(256) void rnn_forward_kernel(RecArgs a) {
         for (int i = tid; i < nIn; i += 256) L.A[r * L.ldA + i] = in[i];
         if (tid < nC) L.A[r * L.ldA + nIn + tid] = k > 0 ? sPrevOut[j][tid] : 0.f;
       }
-      if (c < nC) {       // quarter sums over the rows i = part, part + 4, ...: first the inputs, then the previous outputs
+      for (int c = c0; c < nC; c += 64) {       // quarter sums over the rows i = part, part + 4, ...: first the inputs, then the previous outputs
         float acc = 0.f;
 #pragma unroll 4
         for (int i = part; i < nIn; i += 4) acc += in[i] * wAt(i, c);
@@ -1311,9 +1339,9 @@ __global__ __launch_bounds__(256) void rnn_forward_kernel(RecArgs a) {
 template <bool LDSW>
 __global__ __launch_bounds__(256) void rnn_backward_kernel(RecArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  __shared__ float sTop[2][REC_MAXIN];                    // error w.r.t. the output of the current block (from above, same step)
-  __shared__ float sRec[HL_MAX_HIDDEN][REC_MAXC];          // error w.r.t. this step's output coming from step k+1
-  __shared__ float sD[REC_MAXC], sRes[REC_MAXC], sRecNew[REC_MAXC];
+  __shared__ float sTop[2][REC_GENIN];                    // error w.r.t. the output of the current block (from above, same step)
+  __shared__ float sRec[HL_MAX_HIDDEN][REC_GENC];          // error w.r.t. this step's output coming from step k+1
+  __shared__ float sD[REC_GENC], sRes[REC_GENC], sRecNew[REC_GENC];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = a.bt.t[b];
   const int T = min(a.nBPTT, t);
@@ -1387,6 +1415,12 @@ static bool lstm32Wave(const RecArgs& a) {      // (forward: training windows an
   return a.gates == 4 && (a.actStates == nullptr || a.actSteps <= 17) && a.nL == 2 && a.L[0].nC == 32 && a.L[1].nC == 32 && a.L[1].nIn == 32 &&
          a.L[0].nIn <= 32 && a.dS == a.L[0].nIn && a.K <= 17 && a.L[0].indW % 4 == 0 && a.L[1].indW % 4 == 0 && !a.L[0].hasRes;
 }
+// shapes only the one-gate-per-thread kernels serve: inputs other than the step's own observed state, layers wider than 64 cells
+static bool recGeneral(const RecArgs& a) {
+  bool wide = false;
+  for (int j = 0; j < a.nL; ++j) wide = wide || a.L[j].nC > REC_MAXC || a.L[j].nIn > REC_MAXIN;
+  return wide || a.Xin != nullptr || a.nApp > 0;
+}
 static size_t recLdsBytes(const RecArgs& a) {
   size_t fl = 0;
   for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (a.gates * a.L[j].nC + 1);
@@ -1399,8 +1433,13 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 }
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
-  static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
-  if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 120 * 1024 ? recLaunch(rnn_forward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_forward_kernel<false>, a, 0, &attr[1], s); }
+  // (static LDS of the general kernels: up to 46 KB)
+  static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 100 * 1024; const bool general = recGeneral(a);
+  if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 100 * 1024 ? recLaunch(rnn_forward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_forward_kernel<false>, a, 0, &attr[1], s); }
+  if (general) {
+    if (a.gates == 2) return fit ? recLaunch(mgu_forward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_forward_kernel<false, 0>, a, 0, &attr[1], s);
+    return fit ? recLaunch(rec_forward_kernel<true>, a, lds, &attr[2], s) : recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
+  }
   if (mgu32Wave(a)) {        // two layers of 32 cells, training pass: one wavefront per (sample, layer), weights in registers
     const int in0 = (a.L[0].nIn + 3) & ~3;
     if (in0 <= 4) hipLaunchKernelGGL(mgu32_forward_wave_kernel<4>, dim3(a.B), dim3(128), 0, s, a);
@@ -1439,8 +1478,12 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
   return recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
-  static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 120 * 1024;
-  if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 120 * 1024 ? recLaunch(rnn_backward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_backward_kernel<false>, a, 0, &attr[1], s); }
+  static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 100 * 1024; const bool general = recGeneral(a);
+  if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 100 * 1024 ? recLaunch(rnn_backward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_backward_kernel<false>, a, 0, &attr[1], s); }
+  if (general) {
+    if (a.gates == 2) return fit ? recLaunch(mgu_backward_kernel<true, 0>, a, lds, &attr[0], s) : recLaunch(mgu_backward_kernel<false, 0>, a, 0, &attr[1], s);
+    return fit ? recLaunch(rec_backward_kernel<true>, a, lds, &attr[2], s) : recLaunch(rec_backward_kernel<false>, a, 0, &attr[3], s);
+  }
   if (a.gates == 2) {
     static size_t attrM[4] = {0, 0, 0, 0};
     if (mgu32Wave(a)) { hipLaunchKernelGGL(mgu32_backward_wave_kernel<32>, dim3(a.B), dim3(128), 0, s, a); return hipGetLastError(); }

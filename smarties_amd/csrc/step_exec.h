@@ -612,7 +612,7 @@ bool evictionDue(const hl_learner* h) {
 RecArgs recArgs(hl_learner* h, int parity) {
   const DevHidden& q = h->hid[h->nHidden - 1];
   RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS; ra.nL = h->nHidden;
-  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[0].lstm; ra.func = h->cfg.nnFunc;
+  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[0].lstm; ra.func = h->cfg.nnFunc; ra.nApp = h->nApp;
   for (int j = 0; j < h->nHidden; ++j) ra.L[j] = h->rec[j];
   ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA;
   return ra;

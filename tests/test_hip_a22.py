@@ -1,0 +1,98 @@
+"""Network combinations of Approximator::buildPreprocessing / buildFromSettings (Network/Approximator.cpp:218-271,
+Network/Builder.cpp:26-46,76-81) beyond the shipped settings files: recurrent layers behind appended observations, recurrent layers
+wider than 64 cells, (further down) state variables beside the image and recurrent layers behind a convolutional stack.
+Each against a fixture recorded from the compiled reference (tests/golden/make_golden.sh, "G-a22") and against the oracle on
+minibatches the library draws itself."""
+import numpy as np
+import pytest
+
+from smarties_amd import capi
+from oracle_api import synth_cfg
+from parity import load_fixture, fixture_config, setup_from_fixture, relinf, fx_vec_dev, flat_for
+from test_hip_parity import hip_learner, _pair, _compare_step, TOL32
+
+pytestmark = pytest.mark.gpu
+
+A22_FIXTURES = {  # name -> (nnFunc, minibatches drawn by the harness' restricted sampler?)
+    "lstm_wide.bin": ("Tanh", False), "mgu_wide.bin": ("Tanh", False), "lstm_appended.bin": ("Tanh", True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(A22_FIXTURES))
+def test_steps_follow_reference_fixture_a22(hip_api, name):
+    """The (episode, t) pairs of every tapped step of the reference run, fed to the library: per-sample outputs, importance weights,
+    gradients; summed gradient, weights and Adam moments where the fixture holds them (lean fixtures: every 53rd element + sums)."""
+    func, restricted = A22_FIXTURES[name]
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc=func))
+    assert L.nParams == int(fx["cfg"][5]) and L.nOut == int(fx["cfg"][6])
+    lay = L.layout()
+    assert np.array_equal(lay["indW"], fx["indWeights"]) and np.array_equal(lay["indB"], fx["indBiases"])
+    setup_from_fixture(L, fx)
+    w0 = L.get_params()[0]
+    assert fx_vec_dev(fx, "W0", w0) < 1e-12 and ("W0" in fx or np.array_equal(w0[::53], fx["W0_sub"]))
+    assert np.array_equal(L.get_rng_state(), fx["rng0"])
+    nSteps = int(fx["cfg"][4])
+    for k in range(1, nSteps + 1):
+        sk = "s%d_" % k
+        if sk + "tag" not in fx:
+            break
+        flat = flat_for(L, fx[sk + "tag"], fx[sk + "t"])
+        order = np.argsort(flat, kind="stable")
+        L.step(1, flat=flat[order])
+        assert np.array_equal(L.readback(capi.TAP_TAG), fx[sk + "tag"][order])
+        assert np.array_equal(L.readback(capi.TAP_TSTEP), fx[sk + "t"][order])
+        assert relinf(L.readback(capi.TAP_OUTPUT), fx[sk + "O"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_RHO), fx[sk + "rho"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_DKL), fx[sk + "dkl"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_DELTAQ), fx[sk + "dq"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_OUTGRAD), fx[sk + "G"][order]) < TOL32
+        assert np.array_equal(L.readback(capi.TAP_FAR), fx[sk + "far"][order])
+        if sk + "gradSum" in fx or sk + "gradSum_sub" in fx:
+            assert fx_vec_dev(fx, sk + "gradSum", L.readback(capi.TAP_GRADSUM)) < TOL32
+        if sk + "W" in fx or sk + "W_sub" in fx:
+            w, m1, m2 = L.get_params()
+            assert fx_vec_dev(fx, sk + "W", w) < TOL32
+            assert fx_vec_dev(fx, sk + "M1", m1) < TOL32 and fx_vec_dev(fx, sk + "M2", m2) < 2 * TOL32
+        sca = L.scalars()
+        assert abs(sca.beta - fx["traj_beta"][k - 1]) <= 1e-12 * abs(sca.beta)
+    assert fx_vec_dev(fx, "Wfinal", L.get_params()[0]) < 2 * TOL32
+
+
+WIDE_SHAPES = [  # (layer type, hidden, dimS, nAppendedObs, bptt, batch)
+    ("lstm", (96, 80), 5, 0, 6, 16),        # four gates x 96 cells: gates looped over the 256 threads
+    ("lstm", (256,), 7, 0, 3, 6),           # the widest: 1024 gates, weights read through the L2
+    ("mgu", (128,), 6, 0, 5, 16),
+    ("mgu", (200, 72), 9, 0, 4, 9),
+    ("rnn", (130, 70), 5, 0, 5, 12),        # dense layers with a recurrent term, more than 64 cells
+    ("lstm", (32, 32), 5, 2, 4, 16),        # appended observations in front of the shipped recurrent shape
+    ("lstm", (24,), 40, 7, 6, 10),          # 320 inputs
+    ("mgu", (32, 32), 4, 3, 16, 33),
+    ("rnn", (24, 16), 6, 1, 5, 12),
+    ("lstm", (80,), 11, 2, 5, 8),           # both
+]
+
+
+@pytest.mark.parametrize("shape", WIDE_SHAPES, ids=lambda sh: "%s-%s-dS%d-app%d" % (sh[0], "x".join(map(str, sh[1])), sh[2], sh[3]))
+def test_wide_and_appended_recurrent_layers_match_oracle(hip_api, shape):
+    """Minibatches the library draws itself -- including steps t < nAppendedObs and windows that begin before them, where the
+    appended slots repeat the episode's first state -- eager and replayed steps, then acting on windows of every length with and
+    without context states in front."""
+    kind, hidden, dS, nApp, bptt, batch = shape
+    nnt = {"lstm": capi.NN_LSTM, "mgu": capi.NN_MGU, "rnn": capi.NN_RNN}[kind]
+    kw = dict(dimS=dS, dimA=2, bounded=[1, 0], hidden=hidden, nnFunc="Tanh", batchSize=batch, maxTotObsNum=8000, randSeed=5,
+              nn_type=nnt, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=bptt, nAppendedObs=nApp)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=21, dimS=dS, dimA=2, lenMin=2, lenMax=30, pTerm=0.5), 60)
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(10); O.step(10)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    rng = np.random.default_rng(5)
+    for n in sorted({1, 2, bptt + 1, bptt + 1 + nApp}):
+        S = rng.normal(size=(n, dS)).astype(np.float32)
+        assert relinf(G.forward_sequence(S), O.forward_sequence(S)) < TOL32, n
+    with pytest.raises(capi.HlError):
+        G.forward_sequence(rng.normal(size=(bptt + 2 + nApp, dS)).astype(np.float32))
