@@ -61,6 +61,19 @@ hipError_t launch_stack_gather(const StackGatherArgs& a, int maxRows, hipStream_
   return hipGetLastError();
 }
 
+// State variables beside the image (Approximator.cpp:249-259: a second input layer behind the conv stack, glued to its output by a
+// JoinLayer -- the later layer first, Layers.h:289-299): columns [col0, col0 + n) of the stacked rows go in front of the last
+// convolution's outputs, dst[row][0 .. n)
+__global__ __launch_bounds__(256) void extras_copy_kernel(const DevScalars* sc, int parity, const float* X0, int ldX0, int col0, int n, float* dst, int ldDst) {
+  const int row = blockIdx.y;
+  if (row >= sc->nRows[parity]) return;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) dst[(size_t)row * ldDst + e] = X0[(size_t)row * ldX0 + col0 + e];
+}
+hipError_t launch_extras_copy(const DevScalars* sc, int parity, const float* X0, int ldX0, int col0, int n, float* dst, int ldDst, int maxRows, hipStream_t s) {
+  hipLaunchKernelGGL(extras_copy_kernel, dim3(std::min((n + 255) / 256, 8), maxRows), dim3(256), 0, s, sc, parity, X0, ldX0, col0, n, dst, ldDst);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward.  A workgroup = 4 wavefronts = (4 / CT) tiles of 16 output positions x CT tiles of 16 channels, one
 // (position tile, channel tile) per wavefront.  These layers are small (0.2 - 0.8 MFLOP per sample), so the kernels are

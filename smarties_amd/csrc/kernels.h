@@ -116,6 +116,7 @@ struct ConvArgs {
 struct StackGatherArgs { DevScalars* sc; DevReplay rp; DevBatch bt; int B, dS, nApp, parity; float* X0; int ldX0; };
 struct AdamHyper;
 hipError_t launch_stack_gather(const StackGatherArgs& a, int maxRows, hipStream_t s);
+hipError_t launch_extras_copy(const DevScalars* sc, int parity, const float* X0, int ldX0, int col0, int n, float* dst, int ldDst, int maxRows, hipStream_t s);
 hipError_t launch_conv_prep(const ConvArgs& a, hipStream_t s);              // filters -> LDS layouts (once per step)
 long long conv_prep_floats(const ConvGeo& g, int which);                   // floats of Wf (0) / Wx (1)
 hipError_t launch_conv_forward(const ConvArgs& a, int l, int maxRows, hipStream_t s);

@@ -60,6 +60,7 @@ struct hl_learner {
   // gathered by its own kernel; with convolutions hid[0] stands for the last convolutional layer (its X, Y, D, Dres are that
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
+  int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
@@ -243,6 +244,11 @@ int buildNet(hl_learner* h) {
     lw.push_back((long long)d.outFeatures * d.inpFeatures * d.filtery * d.filterx); lb.push_back((long long)d.outFeatures * d.outY * d.outX);
     prev = d.outFeatures * d.outY * d.outX;
   }
+  h->extras = 0;
+  if (c.n_conv > 0) {      // InputLayer + JoinLayer (Builder.cpp:26-46): no parameters, two entries in the layer list; the join puts the extras first
+    const int inAll = c.dimS * (1 + c.nAppendedObs), inImg = c.conv[0].inpFeatures * c.conv[0].inpY * c.conv[0].inpX;
+    if (inAll > inImg) { h->extras = inAll - inImg; lw.push_back(0); lb.push_back(0); lw.push_back(0); lb.push_back(0); prev += h->extras; }
+  }
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
@@ -287,7 +293,7 @@ int buildNet(hl_learner* h) {
     const ConvGeo& g = h->cg[c.n_conv - 1];
     DevHidden& d = h->hid[0]; d = DevHidden{};
     d.nIn = g.K; d.size = g.KnC * g.P; d.ldW = 0; d.func = HL_FUNC_SOFTSIGN; d.hasRes = 0; d.resW = 0; d.lstm = 0;
-    d.ldA = (int)roundUp(d.size, 16);
+    d.ldA = (int)roundUp(d.size + h->extras, 16);      // rows [extras | outputs of the last convolution]
   }
   for (int j = 0; j < nH; ++j) {
     DevHidden& d = h->hid[j + hOff];
@@ -582,8 +588,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     const long long inSize = (long long)d.inpFeatures * d.inpY * d.inpX;
     const long long prev = j == 0 ? (long long)cfg->dimS * (1 + cfg->nAppendedObs)
                                   : (long long)cfg->conv[j - 1].outFeatures * cfg->conv[j - 1].outY * cfg->conv[j - 1].outX;
-    if (j == 0 && inSize < prev) return HL_ERR_UNSUPPORTED;      // state variables beside the image, appended behind the conv stack (Approximator.cpp:249-259): refused, not dropped
-    if (inSize != prev || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.filterx < 1 || d.filtery < 1) return HL_ERR_BAD_ARG;
+    if ((j == 0 ? inSize > prev : inSize != prev) || d.outFeatures < 1 || d.outY < 1 || d.outX < 1 || d.stridex < 1 || d.filterx < 1 || d.filtery < 1) return HL_ERR_BAD_ARG;
     if (d.outY != (d.inpY - d.filtery + 2 * d.paddiny) / d.stridey + 1 || d.outX != (d.inpX - d.filterx + 2 * d.paddinx) / d.stridex + 1) return HL_ERR_BAD_ARG;
     // conv.hip: zero padding, one power-of-two stride, <= 64 channels per layer, filters <= 32 wide
     if (d.paddinx || d.paddiny || d.stridex != d.stridey || (d.stridex & (d.stridex - 1)) || d.stridex > 8) return HL_ERR_UNSUPPORTED;
@@ -640,7 +645,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       ConvGeo& g = h->cg[l];
       g.ldIn = l == 0 ? h->ldX0 : h->cg[l - 1].ldOut;
       g.ldOut = (int)roundUp((long long)g.KnC * g.P, 16);
-      if (l == h->nConv - 1) { g.X = h->hid[0].X; g.Y = h->hid[0].Y; g.D = h->hid[0].D; }
+      // (the last layer writes behind the extra state variables of its rows; its X / Y / D are accessed element-wise only)
+      if (l == h->nConv - 1) { g.ldOut = h->hid[0].ldA; g.X = h->hid[0].X + h->extras; g.Y = h->hid[0].Y + h->extras; g.D = h->hid[0].D + h->extras; }
       else { HIPCK(devAlloc(&g.X, (size_t)h->Mmax * g.ldOut)); HIPCK(devAlloc(&g.Y, (size_t)h->Mmax * g.ldOut)); HIPCK(devAlloc(&g.D, (size_t)B * g.ldOut)); }
       const long long R = (long long)B * g.P;                    // rows of the filter-gradient reduction
       const int tiles = ((g.K + 15) / 16) * ((g.KnC + 15) / 16);

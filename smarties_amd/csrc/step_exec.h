@@ -311,7 +311,7 @@ ConvArgs convArgs(hl_learner* h, int parity) {
 // training steps of a net whose first layer runs the row-block kernels: those read their input windows from the replay, the
 // stacked rows X0 (28 KB per row at 84 x 84 x 4, written and read once per step) and their launch are not needed
 bool convFromReplay(const hl_learner* h) {
-  if (h->nConv == 0 || !h->cg[0].rbRows || h->noConvReplay) return false;
+  if (h->nConv == 0 || !h->cg[0].rbRows || h->noConvReplay || h->extras > 0) return false;
   const ConvGeo& g = h->cg[0];
   return (h->dS & 3) == 0 && (g.InX & 3) == 0 && g.InC % (1 + h->nApp) == 0 && (long long)(g.InC / (1 + h->nApp)) * g.InY * g.InX == h->dS;
 }
@@ -333,6 +333,8 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
     HIPCK(timed(h, "stack_gather", s, [&] { return launch_stack_gather(ga, h->Mmax, s); }));
   }
   const int j0 = h->nConv > 0 ? 1 : 0;
+  if (h->extras > 0)
+    HIPCK(timed(h, "extras_copy", s, [&] { return launch_extras_copy(h->sc, parity, sb.X0, h->ldX0, h->dIn - h->extras, h->extras, h->hid[0].Y, h->hid[0].ldA, h->Mmax, s); }));
   if (j0) {
     ConvArgs ca = convArgs(h, parity);
     if (fromReplay) convSource(h, parity, &ca);

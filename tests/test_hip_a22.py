@@ -96,3 +96,33 @@ def test_wide_and_appended_recurrent_layers_match_oracle(hip_api, shape):
         assert relinf(G.forward_sequence(S), O.forward_sequence(S)) < TOL32, n
     with pytest.raises(capi.HlError):
         G.forward_sequence(rng.normal(size=(bptt + 2 + nApp, dS)).astype(np.float32))
+
+
+from test_hip_parity import test_conv_steps_follow_reference_fixture as _conv_fixture_body
+from test_hip_parity import test_conv_and_appended_observations_match_oracle as _conv_oracle_body
+
+
+@pytest.mark.parametrize("name", ["conv_extra.bin", "conv_extra_appended.bin"])
+def test_state_variables_beside_the_image_follow_reference_fixture(hip_api, name):
+    """A state wider than the first convolution's image: the surplus is a second input layer behind the conv stack, glued IN FRONT of
+    its outputs (Approximator.cpp:249-259, Builder.cpp:26-46, JoinLayer::forward); with appended observations the image is simply the
+    first entries of the stacked vector.  Same checks as for the other convolutional fixtures."""
+    _conv_fixture_body(hip_api, name)
+
+
+@pytest.mark.parametrize("cfg_kw,sc_kw,n_eps,steps", [
+    # 6 extra variables behind two convolutions, no appended observations; short episodes: truncated next states are sampled
+    (dict(dimS=1030, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=5, conv=[(8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)],
+          hidden=(48,), nnFunc="Tanh", batchSize=24, maxTotObsNum=2000, randSeed=3),
+     dict(seed=5, dimS=1030, dimA=1, lenMin=3, lenMax=9, pTerm=0.3), 60, 6),
+    # one extra variable (every offset behind it unaligned), continuous head, two dense layers, a strided first layer
+    (dict(dimS=801, dimA=2, bounded=[1, 0], nAppendedObs=3, conv=[(20, 20, 8, 16, 6, 2)], hidden=(40, 24), batchSize=16,
+          maxTotObsNum=1500, randSeed=4),
+     dict(seed=6, dimS=801, dimA=2, lenMin=4, lenMax=20, pTerm=0.5), 30, 5),
+    # more extras than the dense layer is wide (the parametric residual reads extras only)
+    (dict(dimS=229, dimA=2, nAppendedObs=0, conv=[(9, 7, 3, 5, 3, 1)], hidden=(32, 32), nnFunc="SoftSign", batchSize=10,
+          maxTotObsNum=800, randSeed=6),
+     dict(seed=8, dimS=229, dimA=2, lenMin=3, lenMax=12, pTerm=0.4), 25, 5),
+], ids=["6-extras", "1-extra-appended", "40-extras"])
+def test_state_variables_beside_the_image_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
+    _conv_oracle_body(hip_api, cfg_kw, sc_kw, n_eps, steps)
