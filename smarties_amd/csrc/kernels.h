@@ -81,6 +81,9 @@ struct RecArgs {
   int nApp;                        // appended observations: the first layer's input is the step's state followed by the nApp before it
   const float* Xin; int ldXin;     // != nullptr: the first layer's input rows, written by launches in front (conv stack): row b K + k, next rows behind B K
 };
+struct WinRowsArgs { const DevScalars* sc; DevScalars* scW; const long long* slot; const int* t; const int* nextSrc; int B, K, nBPTT, parity;
+                     long long* slotW; int* tW; int* nextSrcW; };
+hipError_t launch_window_rows(const WinRowsArgs& a, hipStream_t s);
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);
 

@@ -64,6 +64,10 @@ struct hl_learner {
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
+  // convolutions in front of recurrent layers: the conv launches run over the B recK window rows (+ next states) of a minibatch
+  // (rec.hip: window_rows_kernel); otherwise convB = B, convMmax = Mmax
+  int convB = 0, convMmax = 0;
+  long long* winSlot = nullptr; int* winT = nullptr; int* winNextSrc = nullptr; hl::DevScalars* scW = nullptr;
   RecLayer rec[HL_MAX_HIDDEN]{};
   int nOpt = 0, polDim = 0, nSig = 0;      // discrete head: options; entries of a stored policy (2 dA | nOpt); sigma ParamLayer size (dA | 0)
   long long maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
@@ -574,7 +578,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->nnOutputFunc < HL_FUNC_LINEAR || cfg->nnOutputFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;
   if (cfg->n_encoder < 0 || cfg->n_encoder + cfg->n_hidden > HL_MAX_HIDDEN) return HL_ERR_BAD_ARG;
   if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: 256-thread workgroups looping over gates and cells (REC_GENC, REC_GENIN)
-    if (cfg->dimS > 256 || (long long)cfg->dimS * (1 + std::max(cfg->nAppendedObs, 0)) > 1024) return HL_ERR_UNSUPPORTED;
+    if (cfg->n_conv <= 0 && (cfg->dimS > 256 || (long long)cfg->dimS * (1 + std::max(cfg->nAppendedObs, 0)) > 1024)) return HL_ERR_UNSUPPORTED;
     // (encoder layers are hidden layers of the same network, Learner_approximator.cpp:149-166: the same limits hold for them)
     for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 256) return HL_ERR_UNSUPPORTED;
     for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 256) return HL_ERR_UNSUPPORTED;
@@ -582,7 +586,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
-  if (cfg->n_conv > 0 && cfg->nn_type != HL_NN_FFNN) return HL_ERR_UNSUPPORTED;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
     const hl_conv2d& d = cfg->conv[j];
     const long long inSize = (long long)d.inpFeatures * d.inpY * d.inpX;
@@ -627,6 +630,18 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   int rc = buildNet(h); if (rc) return rc;
   const int B = h->B;
   h->Mmax = (int)roundUp(2 * B, 16);
+  h->recurrent = cfg->nn_type != HL_NN_FFNN;
+  if (h->recurrent) h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
+  h->convB = B; h->convMmax = h->Mmax;
+  if (h->recurrent && h->nConv > 0) {
+    // (the input gradient of the first recurrent layer is a GEMM over its gate deltas with 16-byte row loads; its input rows are staged in LDS)
+    if ((std::max(h->hid[1].lstm, 1) * h->hid[1].size) % 4 != 0) return fail(h, HL_ERR_UNSUPPORTED, "recurrent layer behind convolutions: gates x cells must be a multiple of 4");
+    if (h->hid[1].nIn > 1024) return fail(h, HL_ERR_UNSUPPORTED, "recurrent layer behind convolutions: more than 1024 inputs");
+    h->convB = B * h->recK; h->convMmax = (int)roundUp((long long)h->convB + B, 16);
+    HIPCK(devAlloc(&h->winSlot, (size_t)h->convB)); HIPCK(devAlloc(&h->winT, (size_t)h->convB)); HIPCK(devAlloc(&h->winNextSrc, (size_t)B));
+    HIPCK(devAlloc(&h->scW, 1));
+    h->useGraph = false;      // these nets step eagerly (no riders on their launches; no shipped settings file builds them)
+  }
   // (+ PARAM_TAIL unused floats: scratch "bias" rows of weight-gradient problems that have no bias, step_exec.h)
   HIPCK(devAlloc(&h->W, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams + PARAM_TAIL));
   HIPCK(devAlloc(&h->M2, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->G, (size_t)h->nParams + PARAM_TAIL));
@@ -634,10 +649,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->ldX0 = (int)roundUp(h->dIn, 16);
   for (int j = 0; j < h->nHidden; ++j) {
     DevHidden& d = h->hid[j];
-    const size_t n = (size_t)h->Mmax * d.ldA;
+    const bool convOut = j == 0 && h->nConv > 0;      // the last convolution's activations: one row per conv row
+    const size_t n = (size_t)(convOut ? h->convMmax : h->Mmax) * d.ldA, nd = (size_t)(convOut ? h->convB : B) * d.ldA;
     HIPCK(devAlloc(&d.X, n)); HIPCK(devAlloc(&d.Y, n));
     if (d.hasRes) HIPCK(devAlloc(&d.Rr, n)); else d.Rr = nullptr;
-    HIPCK(devAlloc(&d.D, (size_t)B * d.ldA)); HIPCK(devAlloc(&d.Dres, (size_t)B * d.ldA));
+    HIPCK(devAlloc(&d.D, nd)); HIPCK(devAlloc(&d.Dres, nd));
   }
   {   // convolutional layers: activations per layer (the last one's are hid[0]'s), chunking of the filter-gradient reduction
     int blk = 0;
@@ -647,8 +663,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       g.ldOut = (int)roundUp((long long)g.KnC * g.P, 16);
       // (the last layer writes behind the extra state variables of its rows; its X / Y / D are accessed element-wise only)
       if (l == h->nConv - 1) { g.ldOut = h->hid[0].ldA; g.X = h->hid[0].X + h->extras; g.Y = h->hid[0].Y + h->extras; g.D = h->hid[0].D + h->extras; }
-      else { HIPCK(devAlloc(&g.X, (size_t)h->Mmax * g.ldOut)); HIPCK(devAlloc(&g.Y, (size_t)h->Mmax * g.ldOut)); HIPCK(devAlloc(&g.D, (size_t)B * g.ldOut)); }
-      const long long R = (long long)B * g.P;                    // rows of the filter-gradient reduction
+      else { HIPCK(devAlloc(&g.X, (size_t)h->convMmax * g.ldOut)); HIPCK(devAlloc(&g.Y, (size_t)h->convMmax * g.ldOut)); HIPCK(devAlloc(&g.D, (size_t)h->convB * g.ldOut)); }
+      const long long R = (long long)h->convB * g.P;             // rows of the filter-gradient reduction
       const int tiles = ((g.K + 15) / 16) * ((g.KnC + 15) / 16);
       long long rowsPer = std::max<long long>(64, (R * tiles + 1023) / 1024);   // about a thousand workgroups per layer
       rowsPer = std::min<long long>(roundUp(rowsPer, 16), 2048);
@@ -656,21 +672,19 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       // layers with a large input image (the first one of the Atari stacks): row-block kernels, one partial per (sample, row block)
       { int win = 0; const int rb = getenv("SMARTIES_HIP_NO_CONV_ROWS") ? 0 : conv_row_block(g, &win);
         g.rbRows = 0; g.rbCount = 0; g.rbWin = 0;
-        if (l == 0 && rb > 0 && conv_rows_ok(g)) { g.rbRows = rb; g.rbCount = (g.OpY + rb - 1) / rb; g.rbWin = win; g.nChunks = B * g.rbCount; } }
+        if (l == 0 && rb > 0 && conv_rows_ok(g)) { g.rbRows = rb; g.rbCount = (g.OpY + rb - 1) / rb; g.rbWin = win; g.nChunks = h->convB * g.rbCount; } }
       g.dwBlock0 = blk; blk += g.rbRows ? 0 : g.nChunks * tiles;
       HIPCK(devAlloc(&g.part, (size_t)g.nChunks * g.KnC * g.K));
       HIPCK(devAlloc(&g.Wf, (size_t)conv_prep_floats(g, 0))); HIPCK(devAlloc(&g.Wx, (size_t)conv_prep_floats(g, 1)));
-      if ((long long)h->Mmax * g.P >= (1ll << 31) || (long long)h->Mmax * g.InY * g.InX >= (1ll << 31)) return fail(h, HL_ERR_UNSUPPORTED, "convolution: rows x positions >= 2^31");
+      if ((long long)h->convMmax * g.P >= (1ll << 31) || (long long)h->convMmax * g.InY * g.InX >= (1ll << 31)) return fail(h, HL_ERR_UNSUPPORTED, "convolution: rows x positions >= 2^31");
     }
     h->convDwBlocks = blk;
   }
-  h->recurrent = cfg->nn_type != HL_NN_FFNN;
   h->actFastOk = !h->recurrent && h->nConv == 0 && getenv("SMARTIES_HIP_NO_ACT_KERNEL") == nullptr;
   for (int j = 0; j < h->nHidden; ++j) if (h->hid[j].size > ACT_MAXW || h->hid[j].nIn > ACT_MAXW) h->actFastOk = false;
   if (h->recurrent) {
-    h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
     const size_t R = (size_t)B * h->recK;
-    for (int j = 0; j < h->nHidden; ++j) {
+    for (int j = h->nConv > 0 ? 1 : 0; j < h->nHidden; ++j) {      // (hid[0] of a convolutional net is its last convolution)
       const DevHidden& d = h->hid[j]; RecLayer& L = h->rec[j];
       L.nIn = d.nIn; L.nC = d.size; L.hasRes = d.hasRes; L.resW = d.resW; L.indW = d.indW; L.indB = d.indB; L.indWr = d.indWr; L.indBr = d.indBr;
       const size_t g = (size_t)d.lstm;         // gates per cell
@@ -767,7 +781,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(devAlloc(&h->dOut, (size_t)B * h->ldDo));
   for (int pb = 0; pb < 2; ++pb) {
     DevBatch& bt = h->buf[pb].bt;
-    HIPCK(devAlloc(&h->buf[pb].X0, (size_t)h->Mmax * h->ldX0));
+    HIPCK(devAlloc(&h->buf[pb].X0, (size_t)h->convMmax * h->ldX0));
     HIPCK(devAlloc(&bt.flat, B)); HIPCK(devAlloc(&bt.pos, B)); HIPCK(devAlloc(&bt.eid, B)); HIPCK(devAlloc(&bt.t, B));
     HIPCK(devAlloc(&bt.slot, B)); HIPCK(devAlloc(&bt.nextOf, B)); HIPCK(devAlloc(&bt.nextSrc, B));
     HIPCK(devAlloc(&bt.tag, B)); HIPCK(devAlloc(&bt.pEid, B)); HIPCK(devAlloc(&bt.pNextOf, B));
@@ -807,7 +821,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(hipMemcpy(h->rp.stScale, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   rc = buildProblems(h); if (rc) return rc;
-  if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) h->useGraph = !(e[0] == '1');
+  if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) { if (e[0] == '1') h->useGraph = false; }
   if (const char* e = getenv("SMARTIES_HIP_TAIL_EVENT")) h->tailEventMode = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_EAGER_CHAIN")) h->eagerChain = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_XCHG_TIMEOUT_MS")) h->xchgTimeoutTicks = std::max(1LL, atoll(e)) * 100000LL;
@@ -839,6 +853,7 @@ int hl_destroy(hl_learner* h) {
       bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam, bt.aggIn};
     for (void* q : bp) if (q) hipFree(q);
   }
+  for (void* q : {(void*)h->winSlot, (void*)h->winT, (void*)h->winNextSrc, (void*)h->scW}) if (q) hipFree(q);
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd, h->rec[j].A2}) if (q) hipFree(q);
   for (void* p : ptrs) if (p) hipFree(p);
   for (int l = 0; l < h->nConv; ++l) { ConvGeo& g = h->cg[l];
@@ -1738,6 +1753,27 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
     return hl_forward(h, 1, row.data(), outputs);
   }
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
+  if (h->nConv > 0) {      // the window's stacked rows through the conv stack (as hl_forward does), then the window kernel on its rows
+    if (nSteps > h->recK + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
+    { int rc = dropPresample(h); if (rc) return rc; }
+    const int win = std::min(nSteps, h->recK), ctx = nSteps - win;
+    std::vector<float> rows((size_t)win * h->dIn);
+    for (int k = 0; k < win; ++k) for (int j = 0; j <= h->nApp; ++j) { const int g = std::max(ctx + k - j, 0);
+      std::memcpy(rows.data() + (size_t)k * h->dIn + (size_t)j * h->dS, states + (size_t)g * h->dS, (size_t)h->dS * sizeof(float)); }
+    if (!h->dActS) { HIPCK(devAlloc(&h->dActS, (size_t)h->convMmax * h->dIn)); HIPCK(devAlloc(&h->dActO, (size_t)h->Mmax * h->nOut)); }
+    HIPCK(hipMemcpyAsync(h->dActS, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(launch_act_standardize(h->sc, h->rp, h->dActS, win, h->dS, h->dIn, h->buf[0].X0, h->ldX0, h->stream));
+    int rc = ensureConvPrep(h); if (rc) return rc;
+    rc = launchFront(h, 0, h->stream, /*gather*/false); if (rc) return rc;
+    const DevHidden& q = h->hid[h->nHidden - 1];
+    RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = h->dActS; ra.actSteps = win; ra.actCtx = 0;      // (the rows come from Xin; actStates only marks the call as acting)
+    HIPCK(launch_rec_forward(ra, h->stream));
+    HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
+                            h->dActO, h->stream, nullptr, 0, h->cfg.nnOutputFunc));
+    HIPCK(hipMemcpyAsync(outputs, h->dActO, (size_t)h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    return HL_OK;
+  }
   // (appended observations: up to nAppendedObs further states in front of the window, which only feed the window's first steps)
   if (nSteps > h->recK + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
   // states and outputs through pinned host memory, completion by stamp (as hl_forward): two launches, no staged copies

@@ -1400,6 +1400,28 @@ __global__ __launch_bounds__(256) void rnn_backward_kernel(RecArgs a) {
     ldsBarrier();
   }
 }
+// Convolutional layers in front of recurrent ones: every step of a sample's window passes through the conv stack, so the conv
+// launches run over B K window rows (+ the truncated next states behind them) instead of B sampled rows.  This kernel writes the
+// row -> (replay slot, step) map in the form stack_gather_kernel / the conv kernels already read: rows r = b K + k < B K hold step
+// t - T + min(k, T) of sample b (rows of steps a window does not have repeat its last one: their deltas are zero), next row j
+// belongs to window row b K + T; the row count goes into a DevScalars of its own.
+__global__ __launch_bounds__(256) void window_rows_kernel(WinRowsArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nNext = a.sc->nRows[a.parity] - a.B, BK = a.B * a.K;
+  if (i == 0) { a.scW->nRows[a.parity] = BK + nNext; a.scW->nNext[a.parity] = nNext; }
+  if (i < BK) {
+    const int b = i / a.K, k = i - b * a.K, t = a.t[b], T = min(a.nBPTT, t), kk = min(k, T);
+    a.slotW[i] = a.slot[b] - T + kk; a.tW[i] = t - T + kk;
+  } else if (i - BK < nNext) {
+    const int j = i - BK, b = a.nextSrc[j];
+    a.nextSrcW[j] = b * a.K + min(a.nBPTT, a.t[b]);
+  }
+}
+hipError_t launch_window_rows(const WinRowsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(window_rows_kernel, dim3((a.B * a.K + a.B + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 static size_t rnnLdsBytes(const RecArgs& a) {
   size_t fl = 0;
   for (int j = 0; j < a.nL; ++j) fl += (size_t)(a.L[j].nIn + a.L[j].nC) * (((a.L[j].nC + 7) & ~7) + 1);

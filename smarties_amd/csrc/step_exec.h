@@ -72,8 +72,21 @@ int buildProblems(hl_learner* h) {
       sb.dxIdx.push_back((int)P.size()); sb.dxBlocks.push_back(cur); P.push_back(p);
     }
     // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
+    // convolutions in front of recurrent layers: Dres of the last convolution's rows = (gate deltas of the first recurrent layer)
+    // W_in^T + the residual path, over the B K window rows (the deltas of the gates are what rec_backward left for the dW launch)
+    if (h->recurrent && j0) {
+      const DevHidden& d = h->hid[1]; const DevHidden& q = h->hid[0]; const RecLayer& L = h->rec[1];
+      const int NO = std::max(d.lstm, 1) * d.size;
+      GemmProblem p{}; p.flavor = GEMM_X; p.epi = EPI_DX; p.M = h->convB; p.N = d.nIn; p.K = NO;
+      p.A = L.D; p.lda = NO; p.B = h->W + d.indW; p.ldb = d.ldW;
+      p.C = q.Dres; p.C2 = q.D; p.ldc = q.ldA;
+      if (d.hasRes) { p.resIn = L.Rd; p.ldRes = L.ldR; p.resW = h->W + d.indWr; p.resN = d.resW; }
+      p.actX = q.X; p.actY = q.Y; p.ldAct = q.ldA; p.func = q.func;
+      int cur = 0; setTiles(p, cur);
+      sb.dxIdx.push_back((int)P.size()); sb.dxBlocks.push_back(cur); P.push_back(p);
+    }
     sb.dwIdx = (int)P.size(); int cur = 0;
-    for (int j = 0; j < nH && h->recurrent; ++j) {
+    for (int j = j0; j < nH && h->recurrent; ++j) {
       // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
       // sample does not have carry zero deltas (rec_backward_kernel)
       const RecLayer& L = h->rec[j]; const int R = B * h->recK;
@@ -113,7 +126,7 @@ int buildProblems(hl_learner* h) {
     }
     for (int l = 0; l < h->nConv; ++l) {   // convolution biases (one per output element): column sums of the layer's deltas
       const ConvGeo& g = h->cg[l];
-      GemmProblem s2{}; s2.flavor = RED_COL; s2.epi = EPI_NONE; s2.N = g.KnC * g.P; s2.K = B;
+      GemmProblem s2{}; s2.flavor = RED_COL; s2.epi = EPI_NONE; s2.N = g.KnC * g.P; s2.K = h->convB;
       s2.A = g.D; s2.lda = g.ldOut; s2.B = nullptr; s2.C = h->G + g.indB;
       setTiles(s2, cur); P.push_back(s2);
     }
@@ -303,7 +316,7 @@ int ensureConvPrep(hl_learner* h) {
   return HL_OK;
 }
 ConvArgs convArgs(hl_learner* h, int parity) {
-  ConvArgs ca{}; ca.sc = h->sc; ca.parity = parity; ca.B = h->B; ca.nL = h->nConv;
+  ConvArgs ca{}; ca.sc = h->sc; ca.parity = parity; ca.B = h->convB; ca.nL = h->nConv;
   ca.W = h->W; ca.Wrw = h->W; ca.M1 = h->M1; ca.M2 = h->M2; ca.G = h->G;
   for (int l = 0; l < h->nConv; ++l) { ca.L[l] = h->cg[l]; ca.L[l].in = l == 0 ? h->buf[parity].X0 : h->cg[l - 1].Y; }
   return ca;
@@ -322,22 +335,31 @@ void convSource(hl_learner* h, int parity, ConvArgs* ca) {
 }
 // `gather`: states with appended observations / convolutional input are assembled here, from the sampled slots
 // (rollout inference writes the standardised rows itself)
-int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true) {
-  const AdamHyper hyp = adamHyper(h, parity);
+// the launches in front of the first dense / recurrent layer: stacked rows, state variables beside the image, the conv stack
+int launchFront(hl_learner* h, int parity, hipStream_t s, bool gather) {
   const StepBuf& sb = h->buf[parity];
   char nm[32];
+  // convolutions in front of recurrent layers (training steps): rows = the samples' windows (rec.hip: window_rows_kernel)
+  const bool windows = gather && h->recurrent && h->nConv > 0;
+  DevBatch bt = sb.bt; DevScalars* sc = h->sc;
+  if (windows) {
+    WinRowsArgs wa{}; wa.sc = h->sc; wa.scW = h->scW; wa.slot = bt.slot; wa.t = bt.t; wa.nextSrc = bt.nextSrc; wa.B = h->B; wa.K = h->recK; wa.nBPTT = h->recK - 1;
+    wa.parity = parity; wa.slotW = h->winSlot; wa.tW = h->winT; wa.nextSrcW = h->winNextSrc;
+    HIPCK(timed(h, "window_rows", s, [&] { return launch_window_rows(wa, s); }));
+    bt.slot = h->winSlot; bt.t = h->winT; bt.nextSrc = h->winNextSrc; sc = h->scW;
+  }
   const bool fromReplay = gather && convFromReplay(h);
   if (h->preproc && gather && !fromReplay) {
-    StackGatherArgs ga{}; ga.sc = h->sc; ga.rp = h->rp; ga.bt = h->buf[parity].bt; ga.B = h->B; ga.dS = h->dS; ga.nApp = h->nApp;
-    ga.parity = parity; ga.X0 = h->buf[parity].X0; ga.ldX0 = h->ldX0;
-    HIPCK(timed(h, "stack_gather", s, [&] { return launch_stack_gather(ga, h->Mmax, s); }));
+    StackGatherArgs ga{}; ga.sc = sc; ga.rp = h->rp; ga.bt = bt; ga.B = h->convB; ga.dS = h->dS; ga.nApp = h->nApp;
+    ga.parity = parity; ga.X0 = sb.X0; ga.ldX0 = h->ldX0;
+    HIPCK(timed(h, "stack_gather", s, [&] { return launch_stack_gather(ga, h->convMmax, s); }));
   }
-  const int j0 = h->nConv > 0 ? 1 : 0;
   if (h->extras > 0)
-    HIPCK(timed(h, "extras_copy", s, [&] { return launch_extras_copy(h->sc, parity, sb.X0, h->ldX0, h->dIn - h->extras, h->extras, h->hid[0].Y, h->hid[0].ldA, h->Mmax, s); }));
-  if (j0) {
+    HIPCK(timed(h, "extras_copy", s, [&] { return launch_extras_copy(sc, parity, sb.X0, h->ldX0, h->dIn - h->extras, h->extras, h->hid[0].Y, h->hid[0].ldA, h->convMmax, s); }));
+  if (h->nConv > 0) {
     ConvArgs ca = convArgs(h, parity);
-    if (fromReplay) convSource(h, parity, &ca);
+    ca.sc = sc;
+    if (fromReplay) { convSource(h, parity, &ca); ca.src.slot = bt.slot; ca.src.t = bt.t; ca.src.nextSrc = bt.nextSrc; }
     // filters -> the kernels' LDS layouts: kept current by the Adam pass of the filter gradients (conv_reduce_adam_kernel);
     // rebuilt here only after something else wrote the weights (start-up, hl_set_params, a restart) or where Adam runs
     // elsewhere (replica exchange)
@@ -345,11 +367,19 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
     else if (h->convPrepStale) return fail(h, HL_ERR_STATE, "convolution filter layouts are stale (ensureConvPrep was not called)");
     for (int l = 0; l < h->nConv; ++l) {
       snprintf(nm, sizeof(nm), "conv_fwd%d", l);
-      if (ca.L[l].rbRows) HIPCK(timed(h, nm, s, [&] { return launch_conv_forward_rows(ca, l, h->Mmax, s); }));
+      if (ca.L[l].rbRows) HIPCK(timed(h, nm, s, [&] { return launch_conv_forward_rows(ca, l, h->convMmax, s); }));
       else
-      HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->Mmax, s); }));
+      HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->convMmax, s); }));
     }
   }
+  return HL_OK;
+}
+int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool gather = true) {
+  const AdamHyper hyp = adamHyper(h, parity);
+  const StepBuf& sb = h->buf[parity];
+  char nm[32];
+  { const int rc = launchFront(h, parity, s, gather); if (rc) return rc; }
+  const int j0 = h->nConv > 0 ? 1 : 0;
   if (h->chainOk) {      // every dense layer in one launch, sampler phases A and B of the next step riding along
     ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
     if (nextSample) { ex = extraSample(h, parity ^ 1, PH_A | PH_B); pex = &ex; }
@@ -438,15 +468,20 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   char nm[32];
   for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
-    const int jx = h->nHidden - 1 - (int)i;          // problem i back-propagates through block jx: reduction over its outputs
-    if (gemm_oneshot_ok(GEMM_X, h->hid[jx].size))
-      HIPCK(timed(h, nm, s, [&] { return launch_gemm_oneshot(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], h->hid[jx].size, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
+    const int jx = h->recurrent ? 1 : h->nHidden - 1 - (int)i;          // problem i back-propagates through block jx: reduction over its outputs
+    const int Kx = h->recurrent ? std::max(h->hid[jx].lstm, 1) * h->hid[jx].size : h->hid[jx].size;      // (recurrent layer under a conv stack: over its gates)
+    if (gemm_oneshot_ok(GEMM_X, Kx))
+      HIPCK(timed(h, nm, s, [&] { return launch_gemm_oneshot(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], Kx, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
     else
     HIPCK(timed(h, nm, s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
   }
   if (h->nConv > 0) {   // convolutional layers: input gradients from the last one down, then every filter gradient (+ Adam)
     ConvArgs ca = convArgs(h, parity);
-    if (convFromReplay(h)) convSource(h, parity, &ca);      // (the backward pass belongs to a training step: the rows were never stacked)
+    if (convFromReplay(h)) {      // (the backward pass belongs to a training step: the rows were never stacked)
+      convSource(h, parity, &ca);
+      if (h->recurrent) { ca.src.slot = h->winSlot; ca.src.t = h->winT; ca.src.nextSrc = h->winNextSrc; }      // (windows: launchFront)
+    }
+    if (h->recurrent) ca.sc = h->scW;
     for (int l = h->nConv - 1; l >= 1; --l) {
       snprintf(nm, sizeof(nm), "conv_dx%d", l);
       HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s); }));
@@ -459,6 +494,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) HIPCK(timed(h, "conv_dw_rows", s, [&] { return launch_conv_dw_rows(ca, l, s); }));
     if (h->convDwBlocks > 0) HIPCK(timed(h, "conv_dw", s, [&] { return launch_conv_dw(ca, h->convDwBlocks, s); }));
     }
+    ca.sc = h->sc;      // (the learning rate of the step)
     HIPCK(timed(h, "conv_reduce_adam", s, [&] { return launch_conv_reduce_adam(ca, hyp, fuseAdam ? 1 : 0, s); }));
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
@@ -614,8 +650,11 @@ bool evictionDue(const hl_learner* h) {
 RecArgs recArgs(hl_learner* h, int parity) {
   const DevHidden& q = h->hid[h->nHidden - 1];
   RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS; ra.nL = h->nHidden;
-  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[0].lstm; ra.func = h->cfg.nnFunc; ra.nApp = h->nApp;
-  for (int j = 0; j < h->nHidden; ++j) ra.L[j] = h->rec[j];
+  const int j0 = h->nConv > 0 ? 1 : 0;      // (hid[0] of a convolutional net is its last convolution: its rows are the first layer's input)
+  ra.nL = h->nHidden - j0;
+  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[j0].lstm; ra.func = h->cfg.nnFunc; ra.nApp = j0 ? 0 : h->nApp;
+  for (int j = j0; j < h->nHidden; ++j) ra.L[j - j0] = h->rec[j];
+  if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
   ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA;
   return ra;
 }
@@ -627,6 +666,7 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
   }
   if (h->recurrent) {      // LSTM layers: window forward, head, back-propagation through time, then the common dW (+ Adam) launch
     const RecArgs ra = recArgs(h, parity);
+    if (h->nConv > 0) { const int rc = launchFront(h, parity, s, true); if (rc) return rc; }      // the windows' rows through the conv stack
     HIPCK(timed(h, "rec_forward", s, [&] { return launch_rec_forward(ra, s); }));
     int rc = launchHead(h, parity, s); if (rc) return rc;
     HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));

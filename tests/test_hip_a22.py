@@ -126,3 +126,34 @@ def test_state_variables_beside_the_image_follow_reference_fixture(hip_api, name
 ], ids=["6-extras", "1-extra-appended", "40-extras"])
 def test_state_variables_beside_the_image_match_oracle(hip_api, cfg_kw, sc_kw, n_eps, steps):
     _conv_oracle_body(hip_api, cfg_kw, sc_kw, n_eps, steps)
+
+
+def test_recurrent_layers_behind_convolutions_follow_reference_fixture(hip_api):
+    """conv_lstm.bin: an LSTM layer behind two convolutions on 1 + 3 stacked frames, BPTT 4: every step of a sample's window passes
+    through the conv stack (rows = B x 5 window rows + next states), the filter gradients sum over all of them."""
+    _conv_fixture_body(hip_api, "conv_lstm.bin")
+
+
+@pytest.mark.parametrize("kind,hidden,extra", [("lstm", (32,), 0), ("mgu", (24, 16), 0), ("rnn", (20,), 0), ("lstm", (16, 16), 6)],
+                         ids=["lstm-32", "mgu-24x16", "rnn-20", "lstm-2x16-extras"])
+def test_recurrent_layers_behind_convolutions_match_oracle(hip_api, kind, hidden, extra):
+    """Minibatches the library draws itself (short episodes: windows shorter than the BPTT length, steps t < nAppendedObs, truncated
+    next states), eager steps only for these nets; then acting on windows of every length, with context states in front."""
+    nnt = {"lstm": capi.NN_LSTM, "mgu": capi.NN_MGU, "rnn": capi.NN_RNN}[kind]
+    dS = 256 + (extra and 2)          # (with 1 + 2 stacked observations: 3 x 258 = 768 + 6)
+    nApp = 2 if extra else 3
+    conv = [(8, 8, 12, 32, 4, 1), (5, 5, 32, 64, 3, 1)] if extra else [(8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)]
+    kw = dict(dimS=dS, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=5, nAppendedObs=nApp, conv=conv, hidden=hidden, nnFunc="Tanh",
+              batchSize=12, maxTotObsNum=2000, randSeed=3, nn_type=nnt, nnBPTTseq=4)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=5, dimS=dS, dimA=1, lenMin=3, lenMax=12, pTerm=0.3), 50)
+    for _ in range(4):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(9); O.step(9)
+    _compare_step(G, O)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    rng = np.random.default_rng(7)
+    for n in (1, 3, 5, 5 + nApp):
+        S = rng.normal(size=(n, dS)).astype(np.float32)
+        assert relinf(G.forward_sequence(S), O.forward_sequence(S)) < TOL32, n
