@@ -60,6 +60,7 @@ struct hl_learner {
   // gathered by its own kernel; with convolutions hid[0] stands for the last convolutional layer (its X, Y, D, Dres are that
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
+  bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
   int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
@@ -615,9 +616,14 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   const double nL = cfg->n_ranks;
   h->Bglobal = cfg->batchSize > 1 ? (int)(std::ceil(cfg->batchSize / nL) * nL) : cfg->batchSize;
   h->B = cfg->batchSize > 1 ? h->Bglobal / cfg->n_ranks : h->Bglobal;
-  if (h->B > 1024) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024");
+  if (h->B > 16384) return fail(h, HL_ERR_UNSUPPORTED, "local batch > 16384");
+  // 1024 < B <= 16384: one 1024-thread sampler workgroup (sample.hip: big_sample_kernel), states assembled by stack_gather_kernel,
+  // one launch per layer and direction, weight gradients split over the rows, eager steps
+  h->bigBatch = h->B > 1024;
+  if (h->bigBatch && (cfg->nn_type != HL_NN_FFNN || cfg->n_conv > 0 || cfg->dataSamplingAlgo != HL_SAMPLE_UNIFORM))
+    return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024: dense layers and the uniform sampler only");
   h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);
-  h->preproc = h->nApp > 0 || cfg->n_conv > 0;       // the states are gathered by stack_gather_kernel (conv.hip)
+  h->preproc = h->nApp > 0 || cfg->n_conv > 0 || h->bigBatch;       // the states are gathered by stack_gather_kernel (conv.hip)
   if (!h->preproc && h->dS > 512) return fail(h, HL_ERR_UNSUPPORTED, "more than 512 observed state components");   // gather staging (tail_dev.h)
   for (int j = 0; j < h->cfg.n_hidden; ++j)      // (the merged list: encoder layers first)
     if (h->cfg.hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
@@ -642,6 +648,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&h->scW, 1));
     h->useGraph = false;      // these nets step eagerly (no riders on their launches; no shipped settings file builds them)
   }
+  if (h->bigBatch) h->useGraph = false;
   // (+ PARAM_TAIL unused floats: scratch "bias" rows of weight-gradient problems that have no bias, step_exec.h)
   HIPCK(devAlloc(&h->W, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams + PARAM_TAIL));
   HIPCK(devAlloc(&h->M2, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->G, (size_t)h->nParams + PARAM_TAIL));
@@ -753,7 +760,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   { const char* nd = getenv("SMARTIES_HIP_NO_CONV_REPLAY"); h->noConvReplay = nd && nd[0] == '1'; }
   // networks off the fused path with two or more dense layers (short reductions): one forward launch if the groups of its
   // panels run where the kernel assumes (same probe as above, with that kernel's geometry)
-  if (!h->fusedOk && !h->fusedWideOk && !h->recurrent) {
+  if (!h->fusedOk && !h->fusedWideOk && !h->recurrent && !h->bigBatch) {
     const int j0 = h->nConv > 0 ? 1 : 0;
     const char* nc = getenv("SMARTIES_HIP_NO_FWD_CHAIN");
     bool ok = h->nHidden - j0 >= 2 && !(nc && nc[0] == '1');

@@ -24,7 +24,179 @@ hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStr
   hipLaunchKernelGGL(step_tail_kernel, dim3(blocks), dim3(256), 0, s, ta);
   return hipGetLastError();
 }
-hipError_t launch_sample(const SampleArgs& a, hipStream_t s) { return launch_step_tail(nullptr, &a, s); }
+// ---------------------------------------------------------------------------------------------------------------------
+// Large local batches (1024 < B <= 16384): the same sampler -- Sample_uniform::sample + IDtoSeqStep (Sampling.cpp:26-47,82-96):
+// Lemire draws from the learner's mt19937 consumed in order, sort, unique, redraw of the missing ones, the Adam draws, then flat
+// index -> (episode, step) and the truncated next states' rows -- as ONE workgroup of 1024 threads with the candidates in LDS
+// (64 KB at 16384).  The words are drawn 1024 at a time, never more than are still needed, so the generator ends where the
+// sequential algorithm leaves it; compactions run over chunks of 1024 elements in order.  No in-kernel gather (the states are
+// assembled by stack_gather_kernel), no prioritised samplers, no riders: these batches step eagerly.
+// ---------------------------------------------------------------------------------------------------------------------
+#define BIG_NT 1024
+#define BIG_MAXB 16384
+__device__ void bigTwist(unsigned* x, unsigned* xo) {
+  const int tid = threadIdx.x;
+  if (tid < 624) xo[tid] = x[tid];
+  __syncthreads();
+  if (tid < 227) x[tid] = xo[tid + 397] ^ mtF(xo[tid], xo[tid + 1]);
+  __syncthreads();
+  if (tid < 227) x[227 + tid] = x[tid] ^ mtF(xo[227 + tid], xo[228 + tid]);
+  __syncthreads();
+  if (tid < 169) x[454 + tid] = x[227 + tid] ^ mtF(xo[454 + tid], xo[455 + tid]);
+  __syncthreads();
+  if (tid == 0) x[623] = x[396] ^ mtF(xo[623], x[0]);
+  __syncthreads();
+}
+__device__ void bigDraw(unsigned* x, unsigned* xo, int* pPos, unsigned* raw, int n) {      // n <= BIG_NT tempered words into raw[0..n)
+  int done = 0;
+  while (done < n) {
+    int pos = *pPos;
+    __syncthreads();
+    if (pos >= 624) { bigTwist(x, xo); pos = 0; }
+    const int take = min(n - done, 624 - pos);
+    if ((int)threadIdx.x < take) raw[done + threadIdx.x] = mtTemper(x[pos + threadIdx.x]);
+    if (threadIdx.x == 0) *pPos = pos + take;
+    __syncthreads();
+    done += take;
+  }
+}
+// exclusive scan of one flag per thread over the workgroup's 16 wavefronts; returns the total (two barriers)
+__device__ int bigScan(bool flag, int* excl, int* sWave /*[16]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long m = __ballot(flag);
+  if (lane == 0) sWave[wave] = __popcll(m);
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < BIG_NT / 64; ++w) { const int c = sWave[w]; total += c; if (w < wave) before += c; }
+  *excl = before + __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  return total;
+}
+__device__ void bigDrawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* raw, unsigned* vals, int* sWave, int from, int B, unsigned range, unsigned threshold) {
+  int filled = from;
+  while (filled < B) {
+    const int need = min(B - filled, BIG_NT);
+    bigDraw(x, xo, sPos, raw, need);
+    bool fl = false; unsigned v = 0;
+    if ((int)threadIdx.x < need) {
+      const unsigned long long prod = (unsigned long long)raw[threadIdx.x] * (unsigned long long)range;
+      fl = (unsigned)prod >= threshold; v = (unsigned)(prod >> 32);
+    }
+    int ex; const int acc = bigScan(fl, &ex, sWave);
+    if (fl) vals[filled + ex] = v;
+    filled += acc;
+  }
+  __syncthreads();
+}
+__device__ void bigBitonicSort(unsigned* vals, int Bp) {      // Bp a power of two >= 2048
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto waveRounds = [&](int k, int jStart) {                 // strides below 64: inside the wavefronts, each owning the 64-element blocks wave, wave + 16, ...
+    for (int blk = wave; blk * 64 < Bp; blk += BIG_NT / 64) {
+      const int i = blk * 64 + lane;
+      unsigned key = vals[i];
+      if (k <= 64) {
+        for (int kk = 2; kk <= k; kk <<= 1)
+          for (int j = kk >> 1; j > 0; j >>= 1)
+            key = cmpx(key, (unsigned)__shfl_xor((int)key, j, 64), (i & j) == 0, (i & kk) == 0);
+      } else {
+        for (int j = jStart; j > 0; j >>= 1)
+          key = cmpx(key, (unsigned)__shfl_xor((int)key, j, 64), (i & j) == 0, (i & k) == 0);
+      }
+      vals[i] = key;
+    }
+  };
+  __syncthreads();
+  waveRounds(64, 32);
+  for (int k = 128; k <= Bp; k <<= 1) {
+    for (int j = k >> 1; j >= 64; j >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < Bp / 2; t += BIG_NT) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const unsigned a = vals[i], b = vals[i | j];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { vals[i] = b; vals[i | j] = a; }
+      }
+    }
+    __syncthreads();
+    waveRounds(k, 32);
+  }
+  __syncthreads();
+}
+__device__ int bigSortUnique(unsigned* vals, int* sWave, int B, int Bp) {
+  for (int i = B + threadIdx.x; i < Bp; i += BIG_NT) vals[i] = 0xFFFFFFFFu;
+  bigBitonicSort(vals, Bp);
+  int out = 0;
+  for (int c0 = 0; c0 < B; c0 += BIG_NT) {      // (a chunk writes at or below the positions it read; the element in front of a chunk keeps its value)
+    const int i = c0 + threadIdx.x;
+    const unsigned v = i < B ? vals[i] : 0u;
+    const bool fl = i < B && (i == 0 || v != vals[i - 1]);
+    int ex; const int n = bigScan(fl, &ex, sWave);
+    if (fl) vals[out + ex] = v;
+    out += n;
+    __syncthreads();
+  }
+  return out;
+}
+__global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* vals = reinterpret_cast<unsigned*>(smem);               // [Bp]
+  int Bp = 2048; while (Bp < a.B) Bp <<= 1;
+  unsigned* x = vals + Bp; unsigned* xo = x + 624; unsigned* raw = xo + 624;      // [624] [624] [BIG_NT]
+  int* sWave = reinterpret_cast<int*>(raw + BIG_NT); int* sPos = sWave + BIG_NT / 64;
+  const int tid = threadIdx.x, B = a.B;
+  DevScalars* sc = a.sc;
+  if (tid < 624) x[tid] = sc->rng[tid];
+  if (tid == 0) { *sPos = (int)sc->rngPos; sc->sampleSeq += 1; }
+  const unsigned long long nData = (unsigned long long)sc->nTransitions;
+  const int nEp = (int)sc->nEpisodes;
+  const unsigned range = (unsigned)nData;
+  const unsigned threshold = range ? (0u - range) % range : 0u;
+  __syncthreads();
+  if (a.flatGiven) { for (int i = tid; i < B; i += BIG_NT) vals[i] = (unsigned)a.flatGiven[i]; __syncthreads(); }
+  else {
+    bigDrawAccepted(x, xo, sPos, raw, vals, sWave, 0, B, range, threshold);
+    int have = bigSortUnique(vals, sWave, B, Bp);
+    while (have < B) {                       // duplicates: redraw the missing ones (Sampling.cpp:86-93)
+      bigDrawAccepted(x, xo, sPos, raw, vals, sWave, have, B, range, threshold);
+      have = bigSortUnique(vals, sWave, B, Bp);
+    }
+  }
+  for (int d = 0; d < a.adamDraws; d += BIG_NT) bigDraw(x, xo, sPos, raw, min(a.adamDraws - d, BIG_NT));      // AdamOptimizer::apply_update (Optimizer.cpp:139)
+  if (tid < 624) sc->rng[tid] = x[tid];
+  if (tid == 0) sc->rngPos = (unsigned)*sPos;
+  // ---- IDtoSeqStep + rows of the truncated next states, in minibatch order ----
+  int base = 0;
+  for (int c0 = 0; c0 < B; c0 += BIG_NT) {
+    const int b = c0 + tid;
+    bool hasNext = false;
+    if (b < B) {
+      const long long f = (long long)vals[b];
+      int lo;
+      const PosRec rec = findPosition(a.rp, f, nEp, nData, &lo);
+      const int t = (int)(f - rec.prefix);
+      a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = rec.eidTerm & 0x7fffffff; a.bt.t[b] = t; a.bt.tag[b] = rec.tag; a.bt.slot[b] = rec.off + t;
+      hasNext = (t + 2 == rec.N && rec.eidTerm >= 0);      // Episode::isTruncated(t+1) (Episode.h:158-161)
+    }
+    int ex; const int n = bigScan(hasNext, &ex, sWave);
+    if (b < B) { a.bt.nextOf[b] = hasNext ? B + base + ex : -1; if (hasNext) a.bt.nextSrc[base + ex] = b; }
+    base += n;
+  }
+  if (tid == 0) {
+    sc->nNext[a.parity] = base; sc->nRows[a.parity] = B + base;
+    if (a.computeEta) sc->etaEff[a.parity] = adamEtaEff(sc->nStep, sc->adam_bt1, sc->adam_bt2, a.eta0, a.epsAnneal);
+  }
+}
+hipError_t launch_big_sample(const SampleArgs& a, hipStream_t s) {
+  if (a.B > BIG_MAXB || a.perAlgo || !a.noGather) return hipErrorInvalidValue;
+  int Bp = 2048; while (Bp < a.B) Bp <<= 1;
+  const size_t lds = (size_t)4 * (Bp + 624 + 624 + BIG_NT) + 4 * (BIG_NT / 64 + 4);
+  static size_t have = 0;
+  if (lds > have) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(big_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; have = lds; }
+  hipLaunchKernelGGL(big_sample_kernel, dim3(1), dim3(BIG_NT), lds, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_sample(const SampleArgs& a, hipStream_t s) { return a.B > SMAXB ? launch_big_sample(a, s) : launch_step_tail(nullptr, &a, s); }
 hipError_t launch_post(const PostArgs& a, hipStream_t s) { return launch_step_tail(&a, nullptr, s); }
 
 }  // namespace hl

@@ -136,14 +136,14 @@ int buildProblems(hl_learner* h) {
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
       else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
       p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
-      setTiles(p, cur); P.push_back(p);
+      setTiles(p, cur, h->bigBatch); P.push_back(p);      // (large batches: one workgroup per (tile, 256-row chunk), as for the recurrent nets' rows)
       if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
         r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
-        setTiles(r, cur); P.push_back(r);
+        setTiles(r, cur, h->bigBatch); P.push_back(r);
         GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = d.resW; s.K = B;
         s.A = d.Dres; s.lda = d.ldA; s.B = nullptr; s.C = h->G + d.indBr;
-        setTiles(s, cur); P.push_back(s);
+        setTiles(s, cur, h->bigBatch); P.push_back(s);
       }
     }
     { // output InnerProduct layer
@@ -151,12 +151,12 @@ int buildProblems(hl_learner* h) {
       GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = q.size + 1; p.N = h->nDense; p.K = B;
       p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; p.B = h->dOut; p.ldb = h->ldDo;
       p.C = h->G + h->indWo; p.ldc = h->ldWo; p.biasOut = h->G + h->indBo;
-      setTiles(p, cur); P.push_back(p);
+      setTiles(p, cur, h->bigBatch); P.push_back(p);
       // ParamLayer::backward (Layers.h:522-546): bias gradient = column sums of the sigma-param deltas
       if (h->nSig) {      // (no sigma layer behind a discrete policy)
         GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
         s.A = sb.bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
-        setTiles(s, cur); P.push_back(s);
+        setTiles(s, cur, h->bigBatch); P.push_back(s);
       }
     }
     sb.dwCount = (int)P.size() - sb.dwIdx; sb.dwBlocks = cur;

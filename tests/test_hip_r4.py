@@ -74,8 +74,8 @@ def test_announcing_a_call_size_right_after_new_weights_on_a_convolutional_net(h
 def test_oversized_encoder_layers_are_refused(hip_api):
     """encoderLayerSizes are hidden layers of the one network; the width limits of the kernels apply to them
     as to nnLayerSizes (before: an LSTM net with encoder (128,) passed hl_create and overran the 64-cell LDS arrays of rec.hip)."""
-    for kw in (dict(nn_type=capi.NN_LSTM, hidden=(32,), encoder=[128]),
-               dict(nn_type=capi.NN_MGU, hidden=(32,), encoder=[16, 65]),
+    for kw in (dict(nn_type=capi.NN_LSTM, hidden=(32,), encoder=[300]),      # (recurrent layers: 256 cells since round 4, rec.hip REC_GENC)
+               dict(nn_type=capi.NN_MGU, hidden=(32,), encoder=[16, 257]),
                dict(hidden=(64, 64), encoder=[4096])):
         cfg = capi.make_config(dimS=6, dimA=2, bounded=[1, 0], batchSize=16, maxTotObsNum=2000, randSeed=1, nnFunc="Tanh", **kw)
         with pytest.raises(capi.HlError) as e:
@@ -84,6 +84,13 @@ def test_oversized_encoder_layers_are_refused(hip_api):
     ok = capi.Learner(hip_api, capi.make_config(dimS=6, dimA=2, bounded=[1, 0], batchSize=16, maxTotObsNum=2000, randSeed=1, nnFunc="Tanh",
                                                  nn_type=capi.NN_LSTM, hidden=(32,), encoder=[64]))
     ok.init_weights()
+    # the width that overran the 64-cell arrays in round 3 is served now: against the oracle
+    from test_hip_parity import _pair, _compare_step
+    G, O = _pair(hip_api, dict(dimS=6, dimA=2, bounded=[1, 0], batchSize=16, maxTotObsNum=2000, randSeed=1, nnFunc="Tanh", nn_type=capi.NN_LSTM,
+                               hidden=(32,), encoder=[128], nnBPTTseq=4), synth_cfg(seed=3, dimS=6, dimA=2, lenMin=3, lenMax=30, pTerm=0.5), 40)
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -209,3 +216,26 @@ def test_gradient_pushed_by_the_weight_gradient_launch_equals_the_exchange_kerne
                 assert np.array_equal(a, b), (n, r)
             assert P[r].scalars().beta == Q[r].scalars().beta and np.array_equal(P[r].get_rng_state(), Q[r].get_rng_state())
         assert np.array_equal(P[0].get_params()[0], P[1].get_params()[0])
+
+
+@pytest.mark.parametrize("B,hidden,dS,nEps", [(2048, (64, 64), 9, 150), (5000, (32, 48, 32), 5, 150), (16384, (32, 32), 4, 500), (1500, (256, 256), 17, 60)],
+                         ids=["2048-2x64", "5000-3-layers", "16384-2x32", "1500-2x256"])
+def test_large_local_batches_match_oracle(hip_api, B, hidden, dS, nEps):
+    """Local batches above 1024 (up to 16384): the 1024-thread sampler workgroup (sample.hip: big_sample_kernel) must leave the
+    generator, the sorted unique indices -- drawn from replays only a few times the batch, so that several redraw rounds happen --
+    and the next-state rows exactly where the sequential algorithm does (Sampling.cpp:82-96); one launch per layer and direction,
+    weight gradients split over 256-row chunks and joined in chunk order."""
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=dS, dimA=3, bounded=[1, 0, 0], hidden=hidden, nnFunc="Tanh", batchSize=B, maxTotObsNum=200000, randSeed=11)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=33, dimS=dS, dimA=3, lenMin=20, lenMax=140, pTerm=0.5), nEps)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+        _compare_step(G, O)
+    G.step(3); O.step(3)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    flat = np.sort(np.random.default_rng(1).choice(G.scalars().nStoredSteps, size=B, replace=False)).astype(np.int64)
+    G.step(1, flat=flat); O.step(1, flat=flat)
+    _compare_step(G, O)
