@@ -28,6 +28,7 @@ struct DevScalars {
   float maxAbsErrStep;            // ... as the statistics pass of the current step saw it, i.e. before that step's removals: what the
                                   // ReplayStats::maxAbsError average of the step takes in (MemoryProcessing.cpp:223,241)
   // the minibatch workspace is double buffered (sampling of step k+1 overlaps the update of step k)
+  unsigned maxAbsScratch;         // large batches: max |error| of the step's episode records, collected by post_agg_chunks_kernel (float bits)
   int nNext[2];                   // rows B..B+nNext-1 of the minibatch hold truncated next states
   int nRows[2];                   // B + nNext
   float etaEff[2];                // Adam step size incl. bias correction for the step using buffer p

@@ -141,6 +141,7 @@ struct PostArgs {
   float eta0;
   int aggStaged;                     // 1: bt.aggIn holds the episode aggregates (fused kernel), no gather needed
   int hasAdv;                        // 1: Q = bt.newQ (head with an advantage), 0: Q = V
+  int aggChunk;                      // large batches: 1 = the episode records of 256 samples per workgroup, nothing else; 2 = done by the launch in front (tail_dev.h: postPart)
   float* cntMsg;                     // != nullptr: the four replica counters travel inside the gradient message (16 floats, four
                                      // 16-bit chunks each: exact in fp32 for up to 256 replicas) instead of a collective of their own
 };
@@ -213,6 +214,7 @@ struct MomentsArgs {
 };
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
+hipError_t launch_post_agg_chunks(const PostArgs& a, hipStream_t s);
 // one launch, two independent workgroups: bookkeeping of a finished step (post) and sampling of a
 // minibatch (samp); either may be nullptr
 hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStream_t s, int phases = PH_ALL);

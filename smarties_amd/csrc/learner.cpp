@@ -61,6 +61,8 @@ struct hl_learner {
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
   bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
+  // ... whose sampler draws the NEXT step's minibatch on a stream of its own while this step's launches run
+  hipStream_t sideStream = nullptr; hipEvent_t evMain = nullptr, evSide = nullptr; bool sidePending = false;
   int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
@@ -648,7 +650,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     HIPCK(devAlloc(&h->scW, 1));
     h->useGraph = false;      // these nets step eagerly (no riders on their launches; no shipped settings file builds them)
   }
-  if (h->bigBatch) h->useGraph = false;
+  if (h->bigBatch) {
+    h->useGraph = false;
+    HIPCK(hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&h->evMain, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming));
+  }
   // (+ PARAM_TAIL unused floats: scratch "bias" rows of weight-gradient problems that have no bias, step_exec.h)
   HIPCK(devAlloc(&h->W, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->M1, (size_t)h->nParams + PARAM_TAIL));
   HIPCK(devAlloc(&h->M2, (size_t)h->nParams + PARAM_TAIL)); HIPCK(devAlloc(&h->G, (size_t)h->nParams + PARAM_TAIL));
@@ -840,6 +846,7 @@ int hl_destroy(hl_learner* h) {
   if (!h) return HL_OK;
   h->mu.lock();      // (released before the handle goes away; no other thread may still be using it)
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->sideStream) hipStreamSynchronize(h->sideStream);
   timerFlush(h);
   invalidateGraphs(h);
   if (h->comm) ncclCommDestroy(h->comm);
@@ -871,6 +878,9 @@ int hl_destroy(hl_learner* h) {
   if (h->pinned) hipHostFree(h->pinned);
   for (auto& st : h->stg) { if (st.host) hipHostFree(st.host); if (st.ev) hipEventDestroy(st.ev); }
   for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp}) if (q) hipFree(q);
+  if (h->sideStream) { hipStreamSynchronize(h->sideStream); hipStreamDestroy(h->sideStream); }
+  if (h->evMain) hipEventDestroy(h->evMain);
+  if (h->evSide) hipEventDestroy(h->evSide);
   if (h->stream) hipStreamDestroy(h->stream);
   h->mu.unlock();
   delete h; return HL_OK;

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   int* sWave = reinterpret_cast<int*>(raw + BIG_NT); int* sPos = sWave + BIG_NT / 64;
   const int tid = threadIdx.x, B = a.B;
   DevScalars* sc = a.sc;
-  if (tid < 624) x[tid] = sc->rng[tid];
-  if (tid == 0) { *sPos = (int)sc->rngPos; sc->sampleSeq += 1; }
+  if (tid < 624) { const unsigned v = sc->rng[tid]; x[tid] = v; if (a.backupRng) sc->rngBak[tid] = v; }      // (a minibatch drawn ahead may be discarded: dropPresample)
+  if (tid == 0) { const unsigned p0 = sc->rngPos; *sPos = (int)p0; if (a.backupRng) sc->rngBakPos = p0; sc->sampleSeq += 1; }
   const unsigned long long nData = (unsigned long long)sc->nTransitions;
   const int nEp = (int)sc->nEpisodes;
   const unsigned range = (unsigned)nData;
@@ -194,6 +194,16 @@ hipError_t launch_big_sample(const SampleArgs& a, hipStream_t s) {
   static size_t have = 0;
   if (lds > have) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(big_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; have = lds; }
   hipLaunchKernelGGL(big_sample_kernel, dim3(1), dim3(BIG_NT), lds, s, a);
+  return hipGetLastError();
+}
+// the episode records of a large minibatch: one workgroup per 256 samples (the rest of the bookkeeping pass follows as its own launch)
+__global__ __launch_bounds__(256) void post_agg_chunks_kernel(PostArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64];
+  postPart(a, reinterpret_cast<long long*>(smem), reinterpret_cast<unsigned*>(smem + 8));
+}
+hipError_t launch_post_agg_chunks(const PostArgs& a, hipStream_t s) {
+  PostArgs c = a; c.aggChunk = 1; c.mode = POST_AGG;
+  hipLaunchKernelGGL(post_agg_chunks_kernel, dim3((a.B + 255) / 256), dim3(256), 0, s, c);
   return hipGetLastError();
 }
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s) { return a.B > SMAXB ? launch_big_sample(a, s) : launch_step_tail(nullptr, &a, s); }

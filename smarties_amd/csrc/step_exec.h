@@ -518,7 +518,11 @@ int launchAdam(hl_learner* h, int parity) {
   return HL_OK;
 }
 int launchPost(hl_learner* h, int parity, int mode, hipStream_t s) {
-  const PostArgs pa = postArgs(h, parity, mode);
+  PostArgs pa = postArgs(h, parity, mode);
+  if (h->bigBatch && (mode & POST_AGG)) {      // large batches: the episode records by one workgroup per 256 samples
+    HIPCK(timed(h, "post_agg_chunks", s, [&] { return launch_post_agg_chunks(pa, s); }));
+    pa.aggChunk = 2;
+  }
   HIPCK(timed(h, "post_kernel", s, [&] { return launch_post(pa, s); }));
   return HL_OK;
 }
@@ -685,6 +689,7 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
 int dropPresample(hl_learner* h) {
   if (!h->preValid) return HL_OK;
   h->preValid = false;
+  if (h->sidePending) { HIPCK(hipStreamWaitEvent(h->stream, h->evSide, 0)); h->sidePending = false; }      // (large batches: drawn on the side stream)
   HIPCK(launch_rng_restore(h->sc, h->stream));
   return HL_OK;
 }
@@ -703,11 +708,24 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   struct PushScope { hl_learner* h; ~PushScope() { h->pushGrad = false; } } pushScope{h};
   h->pushGrad = h->pushOk && h->xchg.on && !periodic;
   int p = 0, rc;
-  if (h->preValid && !dFlat) { p = h->preParity; h->preValid = false; }     // drawn by the rider of the previous step
+  if (h->preValid && !dFlat) {     // drawn by the rider of the previous step (large batches: on the side stream)
+    p = h->preParity; h->preValid = false;
+    if (h->sidePending) { HIPCK(hipStreamWaitEvent(s, h->evSide, 0)); h->sidePending = false; }
+  }
   else { rc = dropPresample(h); if (rc) return rc; rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc; }
+  const bool evict = evictionDue(h);
+  if (h->bigBatch && !dFlat && !exch && !periodic && !evict && ((k + 1) % 1000) != 0) {
+    // large batches: the sampler of the NEXT step (one workgroup, hundreds of microseconds) runs beside this step's launches; it
+    // starts behind everything queued so far (the buffer it fills was the previous step's) and keeps the generator's state for
+    // dropPresample.  Nothing of this step changes what it reads (no removal, no whole-buffer pass).
+    HIPCK(hipEventRecord(h->evMain, s)); HIPCK(hipStreamWaitEvent(h->sideStream, h->evMain, 0));
+    SampleArgs sa = sampleArgs(h, p ^ 1, nullptr, false); sa.backupRng = 1;
+    HIPCK(timed(h, "big_sample_ahead", h->sideStream, [&] { return launch_sample(sa, h->sideStream); }));
+    HIPCK(hipEventRecord(h->evSide, h->sideStream));
+    h->preValid = true; h->preParity = p ^ 1; h->sidePending = true;
+  }
   rc = launchMlp(h, p, !exch, s); if (rc) return rc;
   h->lastParity = p;
-  const bool evict = evictionDue(h);
   if (!periodic && !evict && !exch) return launchPost(h, p, POST_AGG | POST_BETA, s);
   rc = launchPost(h, p, POST_AGG, s); if (rc) return rc;
   if (periodic) {

@@ -84,7 +84,11 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   // the terms of the far-policy count (dev_common.h): this thread's segment, fetched now, used after the aggregates are updated
   const int nEp = (int)nEpL, farPer = (nEp + 255) / 256;
   const bool defer = (a.mode & POST_DEFER) != 0;      // the count itself is taken by farBetaPhase: only the fractions are patched here
-  const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && !defer && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
+  // large batches (sample.hip: post_agg_chunks_kernel): aggChunk == 1 -- this workgroup updates the episode records of ITS 256 samples
+  // (a run of samples of one episode belongs to the workgroup of its first sample) and leaves; aggChunk == 2 -- that has been done
+  // by the launch in front, the maximum waits in DevScalars::maxAbsScratch
+  const int chunkMode = a.aggChunk;
+  const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && !defer && !chunkMode && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
   float farT[FAR_REGS], farL[FAR_REGS];
   unsigned long long farG0[FAR_SUB] = {};
   if (farLds) {
@@ -98,7 +102,8 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   long long nFarStat = nFarStat0; float maxAll = maxAll0;
   if (a.mode & POST_AGG) {
     const float C = (float)Cmax0, invC = (float)Cinv0;
-    for (int b0 = 0; b0 < B; b0 += 256) {
+    const int bBeg = chunkMode == 1 ? (int)blockIdx.x * 256 : 0, bEnd = chunkMode == 1 ? min(B, bBeg + 256) : (chunkMode == 2 ? 0 : B);
+    for (int b0 = bBeg; b0 < bEnd; b0 += 256) {
       const int b = b0 + tid;
       const bool in = b < B;
       // round 1: everything indexed by the sample (coalesced), unconditionally
@@ -173,8 +178,10 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       }
       // one LDS atomic per wavefront instead of one per episode (same-address LDS atomics serialise)
       for (int o = 32; o > 0; o >>= 1) myMaxAbs = fmaxf(myMaxAbs, __shfl_xor(myMaxAbs, o, 64));
-      if ((tid & 63) == 0) atomicMax(sMaxAbs, __float_as_uint(myMaxAbs));
+      if ((tid & 63) == 0) { if (chunkMode == 1) atomicMax(&sc->maxAbsScratch, __float_as_uint(myMaxAbs)); else atomicMax(sMaxAbs, __float_as_uint(myMaxAbs)); }
     }
+    if (chunkMode == 1) return;
+    if (chunkMode == 2 && tid == 0) { *sMaxAbs = sc->maxAbsScratch; sc->maxAbsScratch = 0u; }
     PSTAMP(sc, 18);
     __syncthreads();
     PSTAMP(sc, 19);
