@@ -1,0 +1,233 @@
+// smarties_amd/csrc/bigmm.hip -- dense layers at large local batches (1024 < B <= 16384), where the step is no latency chain any
+// more but 2 B x 0.42 MFLOP of fp32 matrix products (Network/Layers/Layer_Base.h:64-113 forward / backward, as gemm_tile.h).
+//
+//   big_panel_kernel   forward  C = f(A W + b) [+ parametric residual]   and   dX   Dres = D W^T [+ residual], D_below = Dres f'.
+//                      WEIGHT-STATIONARY: a workgroup stages a 64-column tile of W (all K <= 256 rows of it: 68 KB) in LDS once and
+//                      walks over the 64-row panels of its share of the minibatch; each of its four wavefronts owns 16 rows of a
+//                      panel -- their K values straight from HBM / L2 into registers as 16-byte loads, the next panel's in flight
+//                      while this one multiplies -- and reads its B operands for FOUR column tiles with one ds_read_b128
+//                      (W is stored [k][16 columns x 4 tiles]).  No cross-wave reduction, no barrier inside the loop.
+//                      Per 16 x 64 x K block: K/4 x 4 MFMAs (16x16x4 fp32) against K/4 LDS reads and K/16 global loads per lane.
+//   big_dw_kernel      weight gradients  G[m][n] = sum_rows A[row][m] D[row][n]  (+ the bias row): 64 x 64 output tiles, the rows cut
+//                      into chunks (about 640 workgroups per problem, one per (tile, chunk)); 32-row slices of A and D go through LDS (k-major,
+//                      pitch 80: the four row groups of an MFMA operand fall into different banks), each wavefront owns a 32 x 32
+//                      quadrant.  Partial tiles land where splitk_reduce_kernel (gemm16.hip) expects them: summed in chunk order
+//                      there, with the Adam update.
+// MFMA operand convention as in gemm_tile.h: lane (li = lane & 15, lc = lane >> 4) feeds A[row li][k lc] and B[k lc][col li] and
+// receives C[row 4 lc + i][col li], i = 0..3.  The k index of a step may be ANY assignment as long as A and B agree: step (j, c)
+// of lane group lc is k = 16 j + 4 lc + c, which is what a lane's j-th 16-byte load of its row holds.
+#include "dev_common.h"
+
+namespace hl {
+
+constexpr int BP_PITCH = 68;      // floats per k-row of the staged weight tile (64 + 4: rows stay 16-byte aligned)
+
+template <int KP, bool TRANSW>
+__global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const DevScalars* __restrict__ sc, int parity) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];      // [16 KP][BP_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int nRows = P.dynRows ? sc->nRows[parity] : P.M;
+  constexpr int KPAD = 16 * KP;
+  // ---- the weight tile, once: sW[k][4 (n & 15) + (n >> 4)] = Wop[k][n0 + n], zeros outside K x N ----
+  if constexpr (!TRANSW) {        // forward: W is [K][ldb], a row of it = the outputs of input k
+    for (int idx = tid; idx < KPAD * 16; idx += 256) {
+      const int k = idx >> 4, c4 = (idx & 15) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (k < P.K) {
+        if (n0 + c4 + 3 < P.ldb) { const float4 w = *reinterpret_cast<const float4*>(P.B + (size_t)k * P.ldb + n0 + c4); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+        else for (int e = 0; e < 4; ++e) if (n0 + c4 + e < P.ldb) v[e] = P.B[(size_t)k * P.ldb + n0 + c4 + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int n = c4 + e; sW[k * BP_PITCH + 4 * (n & 15) + (n >> 4)] = n0 + n < P.N ? v[e] : 0.f; }
+    }
+  } else {                        // dX: W is [N][ldb] (N = inputs of the layer), the reduction runs along its rows
+    for (int idx = tid; idx < 64 * (KPAD / 4); idx += 256) {
+      const int n = idx / (KPAD / 4), k4 = (idx - n * (KPAD / 4)) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + n < P.N) {
+        if (k4 + 3 < P.ldb) { const float4 w = *reinterpret_cast<const float4*>(P.B + (size_t)(n0 + n) * P.ldb + k4); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+        else for (int e = 0; e < 4; ++e) if (k4 + e < P.ldb) v[e] = P.B[(size_t)(n0 + n) * P.ldb + k4 + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sW[(k4 + e) * BP_PITCH + 4 * (n & 15) + (n >> 4)] = k4 + e < P.K ? v[e] : 0.f;
+    }
+  }
+  // per-column epilogue operands of this lane's four columns n0 + 16 t + li
+  float eb[4], ew[4], er[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + li;
+    eb[t] = (!TRANSW && n < P.N) ? P.bias[n] : 0.f;
+    ew[t] = (n < P.resN && P.resW) ? P.resW[n] : 0.f;
+    er[t] = (!TRANSW && n < P.resN && P.resB) ? P.resB[n] : 0.f;
+  }
+  __syncthreads();
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto loadA = [&](f32x4 (&a)[KP], int pb) {
+    const int row = (pb * 4 + wave) * 16 + li;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) a[j] = row < nRows ? *reinterpret_cast<const f32x4*>(P.A + (size_t)row * P.lda + 16 * j + 4 * lc) : z4;
+  };
+  f32x4 aCur[KP], aNxt[KP];
+  int pb = blockIdx.y;
+  if (pb * 64 < nRows) loadA(aCur, pb);
+  for (; pb * 64 < nRows; pb += gridDim.y) {
+    const bool more = (pb + (int)gridDim.y) * 64 < nRows;
+    if (more) loadA(aNxt, pb + gridDim.y);
+    f32x4 acc[4] = {z4, z4, z4, z4};
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sW + (16 * j + 4 * lc + c) * BP_PITCH + 4 * li);
+        const float av = aCur[j][c];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[1], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[2], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[3], acc[3], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (otherwise every LDS read of the panel is hoisted in front of the first MFMA: 128 more registers, spills)
+    }
+    // ---- epilogue: rows r0 + 4 lc + i, columns n0 + 16 t + li ----
+    const int r0 = (pb * 4 + wave) * 16 + 4 * lc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = n0 + 16 * t + li;
+      if (n >= P.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = r0 + i;
+        if (m >= nRows) continue;
+        const size_t o = (size_t)m * P.ldc + n;
+        if constexpr (!TRANSW) {
+          const float x = acc[t][i] + eb[t];
+          const float y = actEval(P.func, x);
+          P.C[o] = x; P.C2[o] = y;
+          if (P.C3) P.C3[o] = n < P.resN ? y + (P.resIn[(size_t)m * P.ldRes + n] * ew[t] + er[t]) : y;
+        } else {
+          float dres = acc[t][i];
+          if (n < P.resN) dres += P.resIn[(size_t)m * P.ldRes + n] * ew[t];
+          P.C[o] = dres;
+          P.C2[o] = dres * actDiff(P.func, P.actX[(size_t)m * P.ldAct + n], P.actY[(size_t)m * P.ldAct + n]);
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < KP; ++j) aCur[j] = aNxt[j];
+    }
+  }
+}
+
+template <int KP, bool TRANSW> static hipError_t bigPanelLaunch(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s) {
+  const size_t lds = (size_t)16 * KP * BP_PITCH * sizeof(float);
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(big_panel_kernel<KP, TRANSW>), lds); if (e != hipSuccess) return e;
+  const int colTiles = (P.N + 63) / 64;
+  int groups = std::max(1, 512 / colTiles);                   // two workgroups per CU
+  groups = std::min(groups, (P.M + 63) / 64);
+  hipLaunchKernelGGL((big_panel_kernel<KP, TRANSW>), dim3(colTiles, groups), dim3(256), lds, s, P, sc, parity);
+  return hipGetLastError();
+}
+bool big_panel_ok(const GemmProblem& P) {
+  const int K = P.K, kp = (K + 15) / 16, kpad = 16 * (kp <= 2 ? 2 : (kp <= 4 ? 4 : (kp <= 8 ? 8 : 16)));      // (the instantiation's K)
+  // (16-byte row loads up to the padded K: the rows of A are at least that long -- zeros or finite values behind K -- and 16-byte aligned)
+  return (P.flavor == GEMM_F || P.flavor == GEMM_X) && K <= 256 && kpad <= P.lda && (P.lda & 3) == 0 && (P.ldb & 3) == 0;
+}
+hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s) {
+  const int kp = (P.K + 15) / 16;
+  const bool tr = P.flavor == GEMM_X;
+#define BP_CASE(KPV) (tr ? bigPanelLaunch<KPV, true>(P, sc, parity, s) : bigPanelLaunch<KPV, false>(P, sc, parity, s))
+  if (kp <= 2) return BP_CASE(2);
+  if (kp <= 4) return BP_CASE(4);
+  if (kp <= 8) return BP_CASE(8);
+  return BP_CASE(16);
+#undef BP_CASE
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int BD_PITCH = 80, BD_ROWS = 32;
+
+__global__ __launch_bounds__(256, 2) void big_dw_kernel(GemmProblem P) {
+  __shared__ __attribute__((aligned(16))) float sA[2][BD_ROWS * BD_PITCH], sD[2][BD_ROWS * BD_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int tilesN = (P.N + 63) / 64;
+  const int m0 = ((int)blockIdx.x / tilesN) * 64, n0 = ((int)blockIdx.x % tilesN) * 64, ks = blockIdx.y;
+  const int rBeg = ks * P.bigChunk, rEnd = min(P.K, rBeg + P.bigChunk);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // a slice = 32 rows x 64 columns of each operand: 512 float4 per operand, two per thread
+  const int sr = tid >> 4, sc4 = (tid & 15) * 4;      // (+ 16 rows for the second one)
+  f32x4 va[2], vd[2];
+  auto loadSlice = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = r0 + sr + 16 * q;
+      va[q] = z4; vd[q] = z4;
+      if (row < rEnd) {
+        const int ca = m0 + sc4, cd = n0 + sc4;
+        if (ca < P.lda) va[q] = *reinterpret_cast<const f32x4*>(P.A + (size_t)row * P.lda + ca);
+        if (cd < P.ldb) vd[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)row * P.ldb + cd);
+        // columns beyond the inputs: the ones column (bias row of the product) at M - 1, zeros behind it; deltas beyond N: zeros
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { if (ca + e == P.M - 1) va[q][e] = 1.f; else if (ca + e >= P.M) va[q][e] = 0.f; if (cd + e >= P.N) vd[q][e] = 0.f; }
+      }
+    }
+  };
+  auto storeSlice = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<f32x4*>(&sA[buf][(sr + 16 * q) * BD_PITCH + sc4]) = va[q];
+      *reinterpret_cast<f32x4*>(&sD[buf][(sr + 16 * q) * BD_PITCH + sc4]) = vd[q];
+    }
+  };
+  f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+  loadSlice(rBeg); storeSlice(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rBeg; r0 < rEnd; r0 += BD_ROWS) {
+    const bool more = r0 + BD_ROWS < rEnd;
+    if (more) loadSlice(r0 + BD_ROWS);
+#pragma unroll
+    for (int s = 0; s < BD_ROWS / 4; ++s) {
+      const float* ra = &sA[buf][(4 * s + lc) * BD_PITCH + wm + li];
+      const float* rd = &sD[buf][(4 * s + lc) * BD_PITCH + wn + li];
+      const float a0 = ra[0], a1 = ra[16], d0 = rd[0], d1 = rd[16];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, d0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, d1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, d0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, d1, acc[1][1], 0, 0, 0);
+    }
+    if (more) storeSlice(buf ^ 1);      // (the other buffer: its readers passed the barrier of the previous iteration)
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial tile -> part[ks][M][N] (splitk_reduce_kernel sums the chunks in order; row M - 1 is the bias)
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = n0 + wn + 16 * tn + li;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm + 16 * tm + 4 * lc + i;
+        if (m < P.M && n < P.N) P.part[((size_t)ks * P.M + m) * P.N + n] = acc[tm][tn][i];
+      }
+    }
+}
+// rows per chunk: about 640 workgroups per problem (tiles x chunks), whole 32-row slices, 64 rows at least
+int big_dw_chunk_rows(int M, int N, int rows) {
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const int chunks = std::max(1, 640 / tiles);
+  int per = (rows + chunks - 1) / chunks;
+  per = std::max(64, (per + BD_ROWS - 1) / BD_ROWS * BD_ROWS);
+  return per;
+}
+bool big_dw_ok(const GemmProblem& P) { return P.flavor == GEMM_W && P.N >= 32 && (P.lda & 3) == 0 && (P.ldb & 3) == 0; }
+hipError_t launch_big_dw(const GemmProblem& P, hipStream_t s) {
+  const int tiles = ((P.M + 63) / 64) * ((P.N + 63) / 64);
+  hipLaunchKernelGGL(big_dw_kernel, dim3(tiles, P.nSplit), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+}  // namespace hl

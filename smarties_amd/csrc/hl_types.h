@@ -168,6 +168,7 @@ struct GemmProblem {
   // update, adamRed -- by splitk_reduce_kernel (gemm16.hip)
   int nSplit, adamRed;
   float* part;
+  int bigChunk;          // large batches (bigmm.hip: big_dw_kernel): rows per chunk; 0: the problem is served by the common launch
 };
 
 // one-kernel exchange between replicas (xchg.hip): sequence number of the next collective, arrival count of its workgroups

@@ -42,6 +42,7 @@ struct TimeRec { int name; hipEvent_t a, b; };
 constexpr int PARAM_TAIL = 256;
 struct StepBuf {
   DevBatch bt{}; float* X0 = nullptr;
+  std::vector<int> bigDw;                  // large batches: weight-gradient problems taken by big_dw_kernel (indices into the problem table)
   std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
   int splitMaxMN = 0;                      // > 0: some weight-gradient problems are split over the rows (largest M x N among them)
   DwTable dwTable{}, dwTableAdam{};        // the dW problems by value (kernel-argument table of dw_table_kernel)
@@ -61,6 +62,8 @@ struct hl_learner {
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
   bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
+  int bigMm = 0;              // ... with the kernels of bigmm.hip (bit 0: forward / dX panels, bit 1: weight gradients; SMARTIES_HIP_BIGMM overrides)
+  std::vector<hl::GemmProblem> hostProbs;      // the problem table as the host built it (large batches: kernels taking a problem by value)
   // ... whose sampler draws the NEXT step's minibatch on a stream of its own while this step's launches run
   hipStream_t sideStream = nullptr; hipEvent_t evMain = nullptr, evSide = nullptr; bool sidePending = false;
   int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
@@ -622,6 +625,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   // 1024 < B <= 16384: one 1024-thread sampler workgroup (sample.hip: big_sample_kernel), states assembled by stack_gather_kernel,
   // one launch per layer and direction, weight gradients split over the rows, eager steps
   h->bigBatch = h->B > 1024;
+  h->bigMm = h->bigBatch ? 3 : 0;
+  if (const char* e = getenv("SMARTIES_HIP_BIGMM")) h->bigMm = h->bigBatch ? atoi(e) : 0;
   if (h->bigBatch && (cfg->nn_type != HL_NN_FFNN || cfg->n_conv > 0 || cfg->dataSamplingAlgo != HL_SAMPLE_UNIFORM))
     return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024: dense layers and the uniform sampler only");
   h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);

@@ -138,12 +138,64 @@ __device__ int bigSortUnique(unsigned* vals, int* sWave, int B, int Bp) {
   }
   return out;
 }
+// Redraw rounds: vals[0..have) is sorted and unique, vals[have..have + m) holds the m <= BIG_TAIL new draws.  Sorting everything
+// again costs ~100 us at 16384; instead the tail is sorted on its own (in sT), every element finds its rank in the other sequence by
+// binary search (head elements first among equals), and one scatter merges the two; then the unique pass as above.
+#define BIG_TAIL 4096
+__device__ int bigMergeUnique(unsigned* vals, unsigned* sT, int* sWave, int have, int m) {
+  const int tid = threadIdx.x;
+  int P2 = 64; while (P2 < m) P2 <<= 1;
+  for (int i = tid; i < P2; i += BIG_NT) sT[i] = i < m ? vals[have + i] : 0xFFFFFFFFu;
+  bigBitonicSort(sT, P2);
+  unsigned hv[BIG_MAXB / BIG_NT], tv[BIG_TAIL / BIG_NT]; int hd[BIG_MAXB / BIG_NT], td[BIG_TAIL / BIG_NT];
+#pragma unroll
+  for (int q = 0; q < BIG_MAXB / BIG_NT; ++q) {
+    const int i = tid + BIG_NT * q;
+    hd[q] = -1; hv[q] = 0u;
+    if (i < have) {
+      const unsigned v = vals[i];
+      int lo = 0, len = m;                       // tail elements smaller than v
+      while (len > 0) { const int half = len >> 1; if (sT[lo + half] < v) { lo += half + 1; len -= half + 1; } else len = half; }
+      hv[q] = v; hd[q] = i + lo;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BIG_TAIL / BIG_NT; ++q) {
+    const int j = tid + BIG_NT * q;
+    td[q] = -1; tv[q] = 0u;
+    if (j < m) {
+      const unsigned v = sT[j];
+      int lo = 0, len = have;                    // head elements not larger than v
+      while (len > 0) { const int half = len >> 1; if (vals[lo + half] <= v) { lo += half + 1; len -= half + 1; } else len = half; }
+      tv[q] = v; td[q] = j + lo;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < BIG_MAXB / BIG_NT; ++q) if (hd[q] >= 0) vals[hd[q]] = hv[q];
+#pragma unroll
+  for (int q = 0; q < BIG_TAIL / BIG_NT; ++q) if (td[q] >= 0) vals[td[q]] = tv[q];
+  __syncthreads();
+  const int B = have + m;
+  int out = 0;
+  for (int c0 = 0; c0 < B; c0 += BIG_NT) {
+    const int i = c0 + tid;
+    const unsigned v = i < B ? vals[i] : 0u;
+    const bool fl = i < B && (i == 0 || v != vals[i - 1]);
+    int ex; const int n = bigScan(fl, &ex, sWave);
+    if (fl) vals[out + ex] = v;
+    out += n;
+    __syncthreads();
+  }
+  return out;
+}
 __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* vals = reinterpret_cast<unsigned*>(smem);               // [Bp]
   int Bp = 2048; while (Bp < a.B) Bp <<= 1;
   unsigned* x = vals + Bp; unsigned* xo = x + 624; unsigned* raw = xo + 624;      // [624] [624] [BIG_NT]
-  int* sWave = reinterpret_cast<int*>(raw + BIG_NT); int* sPos = sWave + BIG_NT / 64;
+  unsigned* sT = raw + BIG_NT;                                                    // [BIG_TAIL] the redrawn tail, sorted
+  int* sWave = reinterpret_cast<int*>(sT + BIG_TAIL); int* sPos = sWave + BIG_NT / 64;
   const int tid = threadIdx.x, B = a.B;
   DevScalars* sc = a.sc;
   if (tid < 624) { const unsigned v = sc->rng[tid]; x[tid] = v; if (a.backupRng) sc->rngBak[tid] = v; }      // (a minibatch drawn ahead may be discarded: dropPresample)
@@ -159,7 +211,7 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
     int have = bigSortUnique(vals, sWave, B, Bp);
     while (have < B) {                       // duplicates: redraw the missing ones (Sampling.cpp:86-93)
       bigDrawAccepted(x, xo, sPos, raw, vals, sWave, have, B, range, threshold);
-      have = bigSortUnique(vals, sWave, B, Bp);
+      have = B - have <= BIG_TAIL ? bigMergeUnique(vals, sT, sWave, have, B - have) : bigSortUnique(vals, sWave, B, Bp);
     }
   }
   for (int d = 0; d < a.adamDraws; d += BIG_NT) bigDraw(x, xo, sPos, raw, min(a.adamDraws - d, BIG_NT));      // AdamOptimizer::apply_update (Optimizer.cpp:139)
@@ -190,7 +242,7 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
 hipError_t launch_big_sample(const SampleArgs& a, hipStream_t s) {
   if (a.B > BIG_MAXB || a.perAlgo || !a.noGather) return hipErrorInvalidValue;
   int Bp = 2048; while (Bp < a.B) Bp <<= 1;
-  const size_t lds = (size_t)4 * (Bp + 624 + 624 + BIG_NT) + 4 * (BIG_NT / 64 + 4);
+  const size_t lds = (size_t)4 * (Bp + 624 + 624 + BIG_NT + BIG_TAIL) + 4 * (BIG_NT / 64 + 4);
   static size_t have = 0;
   if (lds > have) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(big_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; have = lds; }
   hipLaunchKernelGGL(big_sample_kernel, dim3(1), dim3(BIG_NT), lds, s, a);

@@ -44,7 +44,7 @@ int buildProblems(hl_learner* h) {
   const int nH = h->nHidden, B = h->B;
   for (int pb = 0; pb < 2; ++pb) {
     StepBuf& sb = h->buf[pb];
-    sb.fwdIdx.clear(); sb.fwdBlocks.clear(); sb.dxIdx.clear(); sb.dxBlocks.clear();
+    sb.fwdIdx.clear(); sb.fwdBlocks.clear(); sb.dxIdx.clear(); sb.dxBlocks.clear(); sb.bigDw.clear();
     // forward: one launch per hidden block (dense layers; LSTM layers have their own kernels, rec.hip; with convolutional
     // preprocessing hid[0] is the last convolution, computed by conv.hip)
     const int j0 = h->nConv > 0 ? 1 : 0;
@@ -136,7 +136,12 @@ int buildProblems(hl_learner* h) {
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
       else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
       p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
-      setTiles(p, cur, h->bigBatch); P.push_back(p);      // (large batches: one workgroup per (tile, 256-row chunk), as for the recurrent nets' rows)
+      if ((h->bigMm & 2) && big_dw_ok(p)) {      // large batches: 64 x 64 tiles over row chunks (bigmm.hip), no tiles in the common launch
+        p.bigChunk = big_dw_chunk_rows(p.M, p.N, p.K); p.nSplit = (p.K + p.bigChunk - 1) / p.bigChunk;
+        p.tilesM = 0; p.tilesN = 0; p.tileStart = cur; sb.bigDw.push_back((int)P.size());
+      } else
+      setTiles(p, cur, h->bigBatch);      // (large batches: one workgroup per (tile, 256-row chunk), as for the recurrent nets' rows)
+      P.push_back(p);
       if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
         r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
@@ -188,6 +193,7 @@ int buildProblems(hl_learner* h) {
   h->dProbs = nullptr;
   HIPCK(devAlloc(&h->dProbs, P.size()));
   HIPCK(hipMemcpy(h->dProbs, P.data(), P.size() * sizeof(GemmProblem), hipMemcpyHostToDevice));
+  h->hostProbs = P;
   return HL_OK;
 }
 
@@ -398,6 +404,9 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       if (ph) { ex = extraSample(h, parity ^ 1, ph); pex = &ex; }
     }
     const int role = j == j0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD;
+    if ((h->bigMm & 1) && big_panel_ok(h->hostProbs[sb.fwdIdx[j]]))
+      HIPCK(timed(h, nm, s, [&] { return launch_big_panel(h->hostProbs[sb.fwdIdx[j]], h->sc, parity, s); }));
+    else
     if (gemm_oneshot_ok(GEMM_F, h->hid[j].nIn))      // long reductions (the dense layer behind a convolution stack): every operand load in flight at once
       HIPCK(timed(h, nm, s, [&] { return launch_gemm_oneshot(role, h->dProbs + sb.fwdIdx[j], h->hid[j].nIn, sb.fwdBlocks[j], h->sc, hyp, pex, s); }));
     else
@@ -470,6 +479,9 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
     const int jx = h->recurrent ? 1 : h->nHidden - 1 - (int)i;          // problem i back-propagates through block jx: reduction over its outputs
     const int Kx = h->recurrent ? std::max(h->hid[jx].lstm, 1) * h->hid[jx].size : h->hid[jx].size;      // (recurrent layer under a conv stack: over its gates)
+    if ((h->bigMm & 1) && !pex && big_panel_ok(h->hostProbs[sb.dxIdx[i]]))
+      HIPCK(timed(h, nm, s, [&] { return launch_big_panel(h->hostProbs[sb.dxIdx[i]], h->sc, parity, s); }));
+    else
     if (gemm_oneshot_ok(GEMM_X, Kx))
       HIPCK(timed(h, nm, s, [&] { return launch_gemm_oneshot(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], Kx, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
     else
@@ -503,6 +515,9 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   ExtraArgs exC{};
   if (sampleC && pexF) return fail(h, HL_ERR_STATE, "no rider slot left for the sampler's index search on the weight-gradient launch");
   if (sampleC) { exC = extraSample(h, parity ^ 1, PH_C); pexF = &exC; }
+  // large batches: the dense layers' weight gradients as 64 x 64 tiles over row chunks (bigmm.hip); joined by splitk_reduce below
+  for (int idx : sb.bigDw)
+    HIPCK(timed(h, "big_dw", s, [&] { return launch_big_dw(h->hostProbs[(fuseAdam ? sb.dwAdamIdx : sb.dwIdx) + (idx - sb.dwIdx)], s); }));
   HIPCK(timed(h, "gemm16_dw", s, [&] {
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s, pexF); }));
   if (sb.splitMaxMN > 0)
