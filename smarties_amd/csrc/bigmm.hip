@@ -20,47 +20,72 @@
 
 namespace hl {
 
-constexpr int BP_PITCH = 68;      // floats per k-row of the staged weight tile (64 + 4: rows stay 16-byte aligned)
+constexpr int BP_PITCH = 64;      // floats per k-row of the staged weight tile (a quarter wavefront reads 256 contiguous bytes: no padding needed)
+constexpr int BP_OUT = 16 * 64;    // floats of a wavefront's output tile in LDS (the epilogue's transposition)
 
 template <int KP, bool TRANSW>
-__global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const DevScalars* __restrict__ sc, int parity) {
-  extern __shared__ __attribute__((aligned(16))) float sW[];      // [16 KP][BP_PITCH]
+__global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const DevScalars* __restrict__ sc, int parity, int nGroups) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];      // [16 KP][BP_PITCH] + [4 wavefronts][BP_OUT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  const int n0 = blockIdx.x * 64;
+  // workgroup -> (row group, column tile): the column tiles of one row group read the same rows of A, so they sit on ONE XCD
+  // (workgroup b runs on XCD b mod 8) and share its L2 -- otherwise every XCD fetches all of A
+  const int colTiles = (P.N + 63) / 64, slot = (int)blockIdx.x >> 3;
+  const int rowGroup = ((int)blockIdx.x & 7) + 8 * (slot / colTiles);
+  if (rowGroup >= nGroups) return;
+  const int n0 = (slot % colTiles) * 64;
   const int nRows = P.dynRows ? sc->nRows[parity] : P.M;
   constexpr int KPAD = 16 * KP;
   // ---- the weight tile, once: sW[k][4 (n & 15) + (n >> 4)] = Wop[k][n0 + n], zeros outside K x N ----
+  // (every load of the tile is requested before the first LDS write: a rolled load -> store loop pays one memory round trip per
+  //  iteration, 16 of them at K = 256 -- 23 us per workgroup, measured)
   if constexpr (!TRANSW) {        // forward: W is [K][ldb], a row of it = the outputs of input k
-    for (int idx = tid; idx < KPAD * 16; idx += 256) {
-      const int k = idx >> 4, c4 = (idx & 15) * 4;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (k < P.K) {
-        if (n0 + c4 + 3 < P.ldb) { const float4 w = *reinterpret_cast<const float4*>(P.B + (size_t)k * P.ldb + n0 + c4); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
-        else for (int e = 0; e < 4; ++e) if (n0 + c4 + e < P.ldb) v[e] = P.B[(size_t)k * P.ldb + n0 + c4 + e];
-      }
+    f32x4 w[KP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const int n = c4 + e; sW[k * BP_PITCH + 4 * (n & 15) + (n >> 4)] = n0 + n < P.N ? v[e] : 0.f; }
+    for (int q = 0; q < KP; ++q) {
+      const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+      w[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (k < P.K) {
+        if (n0 + c4 + 3 < P.ldb) w[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)k * P.ldb + n0 + c4);
+        else for (int e = 0; e < 4; ++e) if (n0 + c4 + e < P.ldb) w[q][e] = P.B[(size_t)k * P.ldb + n0 + c4 + e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      const int idx = tid + 256 * q, k = idx >> 4, c4 = (idx & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int n = c4 + e; sW[k * BP_PITCH + 4 * (n & 15) + (n >> 4)] = n0 + n < P.N ? w[q][e] : 0.f; }
     }
   } else {                        // dX: W is [N][ldb] (N = inputs of the layer), the reduction runs along its rows
-    for (int idx = tid; idx < 64 * (KPAD / 4); idx += 256) {
-      const int n = idx / (KPAD / 4), k4 = (idx - n * (KPAD / 4)) * 4;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + n < P.N) {
-        if (k4 + 3 < P.ldb) { const float4 w = *reinterpret_cast<const float4*>(P.B + (size_t)(n0 + n) * P.ldb + k4); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
-        else for (int e = 0; e < 4; ++e) if (k4 + e < P.ldb) v[e] = P.B[(size_t)(n0 + n) * P.ldb + k4 + e];
-      }
+    f32x4 w[KP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sW[(k4 + e) * BP_PITCH + 4 * (n & 15) + (n >> 4)] = k4 + e < P.K ? v[e] : 0.f;
+    for (int q = 0; q < KP; ++q) {
+      const int idx = tid + 256 * q, n = idx / (KPAD / 4), k4 = (idx - n * (KPAD / 4)) * 4;
+      w[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n0 + n < P.N) {
+        if (k4 + 3 < P.ldb) w[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)(n0 + n) * P.ldb + k4);
+        else for (int e = 0; e < 4; ++e) if (k4 + e < P.ldb) w[q][e] = P.B[(size_t)(n0 + n) * P.ldb + k4 + e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      const int idx = tid + 256 * q, n = idx / (KPAD / 4), k4 = (idx - n * (KPAD / 4)) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sW[(k4 + e) * BP_PITCH + 4 * (n & 15) + (n >> 4)] = k4 + e < P.K ? w[q][e] : 0.f;
     }
   }
-  // per-column epilogue operands of this lane's four columns n0 + 16 t + li
+  // Epilogue through LDS: a lane holds 4 rows x 1 column of each of its four 16 x 16 tiles, stores of that shape are 64-byte
+  // pieces (measured: the launch was bound by them).  The wavefront's 16 x 64 tile goes through its own 4 KB of LDS (columns
+  // rotated by 16 per group of four rows: conflict-free writes) and leaves as 16-byte pieces of whole rows: lane l owns the four
+  // columns 4 (l & 15) .. + 3 of the rows (l >> 4) + 4 q.  Their per-column operands:
+  float* sOut = sW + KPAD * BP_PITCH + wave * BP_OUT;
+  const int ec = 4 * (lane & 15);
   float eb[4], ew[4], er[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int n = n0 + 16 * t + li;
-    eb[t] = (!TRANSW && n < P.N) ? P.bias[n] : 0.f;
-    ew[t] = (n < P.resN && P.resW) ? P.resW[n] : 0.f;
-    er[t] = (!TRANSW && n < P.resN && P.resB) ? P.resB[n] : 0.f;
+  for (int e = 0; e < 4; ++e) {
+    const int n = n0 + ec + e;
+    eb[e] = (!TRANSW && n < P.N) ? P.bias[n] : 0.f;
+    ew[e] = (n < P.resN && P.resW) ? P.resW[n] : 0.f;
+    er[e] = (!TRANSW && n < P.resN && P.resB) ? P.resB[n] : 0.f;
   }
   __syncthreads();
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -70,49 +95,74 @@ __global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const 
     for (int j = 0; j < KP; ++j) a[j] = row < nRows ? *reinterpret_cast<const f32x4*>(P.A + (size_t)row * P.lda + 16 * j + 4 * lc) : z4;
   };
   f32x4 aCur[KP], aNxt[KP];
-  int pb = blockIdx.y;
+  int pb = rowGroup;
   if (pb * 64 < nRows) loadA(aCur, pb);
-  for (; pb * 64 < nRows; pb += gridDim.y) {
-    const bool more = (pb + (int)gridDim.y) * 64 < nRows;
-    if (more) loadA(aNxt, pb + gridDim.y);
+  for (; pb * 64 < nRows; pb += nGroups) {
+    const bool more = (pb + nGroups) * 64 < nRows;
+    if (more) loadA(aNxt, pb + nGroups);
     f32x4 acc[4] = {z4, z4, z4, z4};
+    // the LDS reads of step group j + 1 are issued in front of the 16 MFMAs of group j (the scheduling barrier keeps the compiler
+    // from hoisting ALL reads of the panel in front of the first MFMA: 128 more registers, spills)
+    f32x4 bCur[4], bNxt[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bCur[c] = *reinterpret_cast<const f32x4*>(sW + (4 * lc + c) * BP_PITCH + 4 * li);
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
+      if (j + 1 < KP) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bNxt[c] = *reinterpret_cast<const f32x4*>(sW + (16 * (j + 1) + 4 * lc + c) * BP_PITCH + 4 * li);
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(sW + (16 * j + 4 * lc + c) * BP_PITCH + 4 * li);
         const float av = aCur[j][c];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[1], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[2], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[3], acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bCur[c][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bCur[c][1], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bCur[c][2], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bCur[c][3], acc[3], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);      // (otherwise every LDS read of the panel is hoisted in front of the first MFMA: 128 more registers, spills)
-    }
-    // ---- epilogue: rows r0 + 4 lc + i, columns n0 + 16 t + li ----
-    const int r0 = (pb * 4 + wave) * 16 + 4 * lc;
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < KP) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int n = n0 + 16 * t + li;
-      if (n >= P.N) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = r0 + i;
-        if (m >= nRows) continue;
-        const size_t o = (size_t)m * P.ldc + n;
-        if constexpr (!TRANSW) {
-          const float x = acc[t][i] + eb[t];
-          const float y = actEval(P.func, x);
-          P.C[o] = x; P.C2[o] = y;
-          if (P.C3) P.C3[o] = n < P.resN ? y + (P.resIn[(size_t)m * P.ldRes + n] * ew[t] + er[t]) : y;
-        } else {
-          float dres = acc[t][i];
-          if (n < P.resN) dres += P.resIn[(size_t)m * P.ldRes + n] * ew[t];
-          P.C[o] = dres;
-          P.C2[o] = dres * actDiff(P.func, P.actX[(size_t)m * P.ldAct + n], P.actY[(size_t)m * P.ldAct + n]);
-        }
+        for (int c = 0; c < 4; ++c) bCur[c] = bNxt[c];
       }
     }
+    // ---- epilogue ----
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sOut[(4 * lc + i) * 64 + ((16 * t + li + 16 * lc) & 63)] = acc[t][i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wavefront's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int rBase = (pb * 4 + wave) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = (lane >> 4) + 4 * q, m = rBase + rr, n = n0 + ec;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sOut + rr * 64 + ((ec + 16 * (rr >> 2)) & 63));
+      if (m >= nRows || n >= P.N) continue;
+      const size_t o = (size_t)m * P.ldc + n;
+      const bool whole = n + 3 < P.N;
+      if constexpr (!TRANSW) {
+        f32x4 rin = z4;
+        if (P.C3 && n < P.resN) { if (n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n); }
+        f32x4 x, y, r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = v[e] + eb[e]; y[e] = actEval(P.func, x[e]); r[e] = n + e < P.resN ? y[e] + (rin[e] * ew[e] + er[e]) : y[e]; }
+        if (whole) {
+          *reinterpret_cast<f32x4*>(P.C + o) = x; *reinterpret_cast<f32x4*>(P.C2 + o) = y;
+          if (P.C3) *reinterpret_cast<f32x4*>(P.C3 + o) = r;
+        } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = x[e]; P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
+      } else {
+        f32x4 rin = z4, ax = z4, ay = z4;
+        if (n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
+        if (n + 3 < P.ldAct) { ax = *reinterpret_cast<const f32x4*>(P.actX + (size_t)m * P.ldAct + n); ay = *reinterpret_cast<const f32x4*>(P.actY + (size_t)m * P.ldAct + n); }
+        f32x4 dres, d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ay[e]); }
+        if (whole) { *reinterpret_cast<f32x4*>(P.C + o) = dres; *reinterpret_cast<f32x4*>(P.C2 + o) = d; }
+        else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = dres[e]; P.C2[o + e] = d[e]; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();               // (the next panel's tile overwrites sOut)
     if (more) {
 #pragma unroll
       for (int j = 0; j < KP; ++j) aCur[j] = aNxt[j];
@@ -121,18 +171,21 @@ __global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const 
 }
 
 template <int KP, bool TRANSW> static hipError_t bigPanelLaunch(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s) {
-  const size_t lds = (size_t)16 * KP * BP_PITCH * sizeof(float);
+  const size_t lds = ((size_t)16 * KP * BP_PITCH + 4 * BP_OUT) * sizeof(float);
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(big_panel_kernel<KP, TRANSW>), lds); if (e != hipSuccess) return e;
   const int colTiles = (P.N + 63) / 64;
   int groups = std::max(1, 512 / colTiles);                   // two workgroups per CU
   groups = std::min(groups, (P.M + 63) / 64);
-  hipLaunchKernelGGL((big_panel_kernel<KP, TRANSW>), dim3(colTiles, groups), dim3(256), lds, s, P, sc, parity);
+  hipLaunchKernelGGL((big_panel_kernel<KP, TRANSW>), dim3(8 * ((groups + 7) / 8) * colTiles), dim3(256), lds, s, P, sc, parity, groups);
   return hipGetLastError();
 }
 bool big_panel_ok(const GemmProblem& P) {
   const int K = P.K, kp = (K + 15) / 16, kpad = 16 * (kp <= 2 ? 2 : (kp <= 4 ? 4 : (kp <= 8 ? 8 : 16)));      // (the instantiation's K)
   // (16-byte row loads up to the padded K: the rows of A are at least that long -- zeros or finite values behind K -- and 16-byte aligned)
-  return (P.flavor == GEMM_F || P.flavor == GEMM_X) && K <= 256 && kpad <= P.lda && (P.lda & 3) == 0 && (P.ldb & 3) == 0;
+  // (16-byte epilogue accesses: every row pitch a multiple of 4, the residual input and the activations as long as the output rows)
+  const bool al = (P.lda & 3) == 0 && (P.ldb & 3) == 0 && (P.ldc & 3) == 0 && (!P.resN || ((P.ldRes & 3) == 0 && P.ldRes >= ((P.resN + 3) & ~3))) &&
+                  (P.flavor != GEMM_X || ((P.ldAct & 3) == 0 && P.ldAct >= ((P.N + 3) & ~3)));
+  return (P.flavor == GEMM_F || P.flavor == GEMM_X) && K <= 256 && kpad <= P.lda && al;
 }
 hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s) {
   const int kp = (P.K + 15) / 16;
