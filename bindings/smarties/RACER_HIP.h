@@ -129,12 +129,10 @@ class RACER_HIP : public Learner
     // settings the library does not serve die here rather than train something else (the reference's convention):
     //  * any other nnType string makes plain dense layers in Builder::addLayer, "Recurrent" recurrent ones without a BPTT
     //    window (HyperParameters.cpp:209 does not count it as recurrent);
-    //  * a partially observable MDP with nnType left non-recurrent gets "RNN" encoder layers under "MGU" layers
-    //    (Approximator.cpp:264-270 vs :221-223): one layer type per network here
     if (c.nn_type < 0) die("nnType not served by the HIP library (FFNN, LSTM, MGU / GRU, RNN)");
-    bool anyEncoder = false; for (Uint v : S.encoderLayerSizes) anyEncoder = anyEncoder || v > 0;
-    if (M.isPartiallyObservable && S.bRecurrent == false && anyEncoder) die("encoderLayerSizes of a partially observable MDP with a non-recurrent nnType mix RNN and MGU layers: not served by the HIP library");
-    if ((M.conv2dDescriptors.size() > 0 || M.nAppendedObs > 0) && c.nn_type != HL_NN_FFNN) die("recurrent layers behind convolutional preprocessing / appended observations are not served by the HIP library");
+    // a partially observable MDP with nnType left non-recurrent gets "RNN" encoder layers under its "MGU" layers
+    // (Approximator.cpp:264-270 vs :221-223)
+    c.encoder_rnn = (M.isPartiallyObservable && S.bRecurrent == false) ? 1 : 0;
     bRecurrent = c.nn_type != HL_NN_FFNN; c.nnBPTTseq = (int32_t) S.nnBPTTseq;
     // MemoryProcessing::createReturnEstimator (:418-450); AlgoFactory.cpp:134-135 turns "default" into "retrace" for this learner
     c.returnsEstimator = (S.returnsEstimator == "default" || S.returnsEstimator == "retrace") ? HL_RET_RETRACE :

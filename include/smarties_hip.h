@@ -181,6 +181,9 @@ typedef struct hl_config {
   int32_t n_encoder;                 /* len(encoderLayerSizes) (Learner_approximator::createEncoder, Learner_approximator.cpp:149-166):  */
   int32_t encoder[HL_MAX_HIDDEN];    /*   dense layers of the preprocessing network, in front of nnLayerSizes in the same network
                                           (Approximator::buildPreprocessing, Approximator.cpp:231-271); n_encoder + n_hidden <= HL_MAX_HIDDEN */
+  int32_t encoder_rnn;               /* 1: the encoder layers are plain recurrent layers ("RNN", Builder.cpp:76-81) whatever nn_type says -- what a
+                                          partially observable MDP gets for them when nnType is left non-recurrent (Approximator.cpp:264-270),
+                                          under the MGU layers of :221-223.  Only with nn_type == HL_NN_MGU. */
 } hl_config;
 
 typedef struct hl_learner hl_learner;  /* opaque */

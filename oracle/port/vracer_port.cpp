@@ -231,6 +231,7 @@ struct ol_learner {
   int dS = 0, dA = 0, nOut = 0, B = 0, Bglobal = 0;
   int64_t maxObsLocal = 0, maxObsGlobal = 0, minObsLocal = 0;
   std::vector<Layer> layers;
+  int nEncLayers = 0;           // hidden layers that came from encoderLayerSizes (the first ones of the merged list)
   int64_t nParams = 0;
   std::vector<nnReal> W, M1, M2, G;
   MT19937 gen;
@@ -295,11 +296,14 @@ void buildNet(ol_learner* h) {
     Layer in; in.type = L_INPUT; in.size = inAll - inImg; L.push_back(in);
     Layer jn; jn.type = L_JOIN; jn.size = in.size + L[L.size() - 2].size; L.push_back(jn);      // JoinLayer(ID + 1, twoLayersSize, 2)
   }
+  size_t nHid = 0;
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     const int ID = (int)L.size();
     Layer d; d.type = c.nn_type == HL_NN_LSTM ? L_LSTM : (c.nn_type == HL_NN_MGU ? L_MGU : L_DENSE); d.size = c.hidden[j]; d.nIn = L[ID - 1].size;
     d.rec = c.nn_type == HL_NN_RNN;
+    if (c.encoder_rnn && (int)nHid < h->nEncLayers) { d.type = L_DENSE; d.rec = true; }      // "RNN" encoder layers of a partially observable MDP (Approximator.cpp:264-270)
+    ++nHid;
     d.nOutSimd = (int)roundUp8(d.size); d.func = c.nnFunc;
     L.push_back(d);
     // skip connection except after the first layer (Builder.cpp:89-95)
@@ -1193,9 +1197,11 @@ int ol_create(const hl_config* cfg, ol_learner** out) {
   if (cfg->n_encoder > 0) {     // createEncoder: the encoder layers are the first hidden layers of the one network (Learner_approximator.cpp:149-166)
     int n = 0;
     for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 0) h->cfg.hidden[n++] = cfg->encoder[j];
+    h->nEncLayers = n;
     for (int j = 0; j < cfg->n_hidden; ++j) h->cfg.hidden[n++] = cfg->hidden[j];
     h->cfg.n_hidden = n; h->cfg.n_encoder = 0;
   }
+  if (cfg->encoder_rnn && cfg->nn_type != HL_NN_MGU) { delete h; return HL_ERR_BAD_ARG; }
   h->dS = cfg->dimS; h->dA = cfg->dimA;
   // HyperParameters::defineDistributedLearning (Settings/HyperParameters.cpp:177-205)
   const Real nL = cfg->n_ranks;

@@ -173,6 +173,7 @@ struct Harness {
     MDP.discreteActionValues = std::vector<Uint>(1, (Uint)nOpt);
 #endif
     MDP.nAppendedObs = (Uint)A.l("nApp", 0);
+    MDP.isPartiallyObservable = A.l("pomdp", 0) != 0;      // with nnType left at FFNN: RNN encoder layers under MGU layers (Approximator.cpp:221-223, 264-270)
     MDP.conv2dDescriptors = parseConv(A.s("conv", ""));
     MDP.synchronize([](void*, size_t) {});
 #ifdef REF_DISCRETE
@@ -368,6 +369,7 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
       W.i64("outFunc", std::vector<int64_t>{of});
       std::vector<int64_t> enc; for (auto v : H.HP->encoderLayerSizes) enc.push_back((int64_t)v);
       W.i64("encoder", enc);
+      if (H.MDP.isPartiallyObservable) W.i64("pomdp", std::vector<int64_t>{1});
     }
     std::vector<int64_t> lay; for (auto v : H.HP->nnLayerSizes) lay.push_back((int64_t)v);
     W.i64("layers", lay);

@@ -55,7 +55,7 @@ class HlConfig(C.Structure):
         ("device_id", C.c_int32), ("episode_order", C.c_int32), ("ref_threads", C.c_int32),
         ("n_options", C.c_int32), ("nn_type", C.c_int32), ("nnBPTTseq", C.c_int32),
         ("nAppendedObs", C.c_int32), ("n_conv", C.c_int32), ("conv", HlConv2d * HL_MAX_CONV), ("ERoldSeqFilter", C.c_int32), ("dataSamplingAlgo", C.c_int32),
-        ("returnsEstimator", C.c_int32), ("nnOutputFunc", C.c_int32), ("n_encoder", C.c_int32), ("encoder", C.c_int32 * HL_MAX_HIDDEN),
+        ("returnsEstimator", C.c_int32), ("nnOutputFunc", C.c_int32), ("n_encoder", C.c_int32), ("encoder", C.c_int32 * HL_MAX_HIDDEN), ("encoder_rnn", C.c_int32),
     ]
 
 
@@ -81,7 +81,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
                 outWeightsPrefac=0.1, randSeed=42, n_ranks=1, rank=0, device_id=-1,
                 episode_order=ORDER_STABLE, ref_threads=1, adv_kind=ADV_ZERO, n_options=0, nn_type=0, nnBPTTseq=0,
                 nAppendedObs=0, conv=(), ERoldSeqFilter="oldest", dataSamplingAlgo="uniform",
-                returnsEstimator="retrace", nnOutputFunc="Linear", encoder=()):
+                returnsEstimator="retrace", nnOutputFunc="Linear", encoder=(), encoder_rnn=0):
     """Defaults = the north-star synthetic of BASELINE.md (cfg-NS)."""
     c = HlConfig()
     c.struct_size = C.sizeof(HlConfig)
@@ -103,6 +103,7 @@ def make_config(dimS=17, dimA=6, bounded=None, hidden=(256, 256), nnFunc="SoftSi
     c.returnsEstimator = RET[returnsEstimator] if isinstance(returnsEstimator, str) else int(returnsEstimator)
     c.nnOutputFunc = FUNC[nnOutputFunc] if isinstance(nnOutputFunc, str) else int(nnOutputFunc)
     c.n_encoder = len(encoder)
+    c.encoder_rnn = int(encoder_rnn)
     for i, hsz in enumerate(encoder):
         c.encoder[i] = int(hsz)
     c.nAppendedObs, c.n_conv = nAppendedObs, len(conv)

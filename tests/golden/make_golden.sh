@@ -179,4 +179,7 @@ ls -la "$HERE"/*.bin
    batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=6 gradSteps=1,2,6 retSteps=6 maxObs=2000 minObs=500 lean=1
 "$DRV" fixture "$HERE/mgu_wide.bin" dimS=6 dimA=2 bounded=01 layers=128 nnType=MGU nnFunc=Tanh bptt=5 \
    batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=6 gradSteps=1,2,6 retSteps=6 maxObs=2000 minObs=500 lean=1
+#   a partially observable MDP with nnType left at its default: "RNN" encoder layers under "MGU" layers (Approximator.cpp:221-223, 264-270)
+"$DRV" fixture "$HERE/pomdp_encoder.bin" dimS=5 dimA=2 bounded=10 pomdp=1 encoder=24 layers=16,16 nnFunc=Tanh bptt=5 \
+   batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
 rm -rf "$TMP"

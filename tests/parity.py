@@ -43,6 +43,9 @@ def fixture_config(fx, **over):
         kw["returnsEstimator"] = int(fx["retEst"][0])
         kw["nnOutputFunc"] = int(fx["outFunc"][0])
         kw["encoder"] = [int(x) for x in fx["encoder"]]
+    if "pomdp" in fx and nnt == 0:   # a partially observable MDP with nnType left non-recurrent: RNN encoder layers under MGU layers (Approximator.cpp:221-223, 264-270)
+        kw["nn_type"] = capi.NN_MGU
+        kw["encoder_rnn"] = 1
     kw.update(over)
     return capi.make_config(**kw)
 

@@ -11,7 +11,7 @@ from smarties_amd import capi
 ACT_FIXTURES = ["act_%s.bin" % f for f in ("LRelu", "Sigm", "HardSign", "SoftPlus", "ExpPlus", "Exp")]     # the other names of makeFunction (Functions.h:643-668)
 PER_FIXTURES = ["sample_%s.bin" % f for f in ("PERrank", "PERerr", "PERseq")]      # dataSamplingAlgo (Sampling.cpp:101-296)
 EVICT_FIXTURES = ["evict_%s.bin" % f for f in ("farpolfrac", "maxkldiv", "minerror")]      # ERoldSeqFilter (MemoryProcessing.cpp:261-298)
-FUNC_OF = {"lstm_wide.bin": "Tanh", "mgu_wide.bin": "Tanh", "hp_odd.bin": "Tanh", "discrete_lstm.bin": "Tanh", "gauss_mgu.bin": "Tanh", "one_layer_relu.bin": "Relu", "deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
+FUNC_OF = {"pomdp_encoder.bin": "Tanh", "lstm_wide.bin": "Tanh", "mgu_wide.bin": "Tanh", "hp_odd.bin": "Tanh", "discrete_lstm.bin": "Tanh", "gauss_mgu.bin": "Tanh", "one_layer_relu.bin": "Relu", "deep_tanh.bin": "Tanh", "racer_lstm.bin": "Tanh", "vracer_mgu.bin": "Tanh", **{n: n[4:-4] for n in ACT_FIXTURES}}
 
 
 def make(name):
@@ -56,7 +56,7 @@ def test_initialize_matches_reference(name):
     assert np.array_equal(L.get_rng_state(), fx["rng0"])
 
 
-@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "crowded_sampler.bin", "moving_replay.bin", "lstm_wide.bin", "mgu_wide.bin"] + ACT_FIXTURES + EVICT_FIXTURES + PER_FIXTURES)
+@pytest.mark.parametrize("name", ["small_mixed.bin", "deep_tanh.bin", "ns_shape.bin", "racer_gauss.bin", "racer_discrete.bin", "racer_lstm.bin", "vracer_mgu.bin", "threads3.bin", "hp_odd.bin", "hp_lowclip.bin", "discrete_lstm.bin", "one_layer_relu.bin", "gauss_mgu.bin", "crowded_sampler.bin", "moving_replay.bin", "lstm_wide.bin", "mgu_wide.bin", "pomdp_encoder.bin"] + ACT_FIXTURES + EVICT_FIXTURES + PER_FIXTURES)
 def test_steps_match_reference(name):
     """Every tapped step: sampled flat indices / (episode, t) bit-exact (mt19937 + Lemire
     uniform_int + sort/unique/redraw + the reference's std::sort episode permutation); network
