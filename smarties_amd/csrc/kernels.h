@@ -80,6 +80,9 @@ struct RecArgs {
   int actCtx;                      // ... of which the first actCtx lie in front of the window (they only feed appended observations)
   int nApp;                        // appended observations: the first layer's input is the step's state followed by the nApp before it
   const float* Xin; int ldXin;     // != nullptr: the first layer's input rows, written by launches in front (conv stack): row b K + k, next rows behind B K
+  // a stack of two layer types runs as two launches (lower segment: the rnn kernels):
+  float* YoutRows; int ldYR;       // != nullptr: the last block's output of EVERY window step goes here (row b K + k, next rows behind B K): the upper segment's Xin
+  const float* DresRows; int ldDR; // != nullptr: gradient w.r.t. those outputs per window row, from the upper segment (instead of Dres at the sampled step only)
 };
 struct WinRowsArgs { const DevScalars* sc; DevScalars* scW; const long long* slot; const int* t; const int* nextSrc; int B, K, nBPTT, parity;
                      long long* slotW; int* tW; int* nextSrcW; };

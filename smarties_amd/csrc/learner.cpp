@@ -42,6 +42,7 @@ struct TimeRec { int name; hipEvent_t a, b; };
 constexpr int PARAM_TAIL = 256;
 struct StepBuf {
   DevBatch bt{}; float* X0 = nullptr;
+  int segDxIdx = -1, segDxBlocks = 0;      // two recurrent layer types: the GEMM between the segments' backward passes
   std::vector<int> bigDw;                  // large batches: weight-gradient problems taken by big_dw_kernel (indices into the problem table)
   std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
   int splitMaxMN = 0;                      // > 0: some weight-gradient problems are split over the rows (largest M x N among them)
@@ -70,6 +71,10 @@ struct hl_learner {
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
+  // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
+  // serve one layer type per launch: the stack runs as two segments, the lower one's outputs of EVERY window step are the upper one's
+  // input rows (segY), the upper one's input errors the lower one's top errors (segDres)
+  int nEncLayers = 0, recSplit = 0; float* segY = nullptr; float* segDres = nullptr; float* segScratch = nullptr; int ldSeg = 0;
   // convolutions in front of recurrent layers: the conv launches run over the B recK window rows (+ next states) of a minibatch
   // (rec.hip: window_rows_kernel); otherwise convB = B, convMmax = Mmax
   int convB = 0, convMmax = 0;
@@ -262,9 +267,10 @@ int buildNet(hl_learner* h) {
   for (int j = 0; j < c.n_hidden; ++j) {
     if (c.hidden[j] <= 0) continue;
     Tmp t; t.nIn = prev; t.size = c.hidden[j]; t.denseLayer = (int)lw.size();
-    const int gates = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : 0);     // Layer_LSTM.h:24-29, Layer_GRU.h:29-34
+    const int ltype = (c.encoder_rnn && nH < h->nEncLayers) ? HL_NN_RNN : c.nn_type;      // ("RNN" encoder layers of a partially observable MDP, Approximator.cpp:264-270)
+    const int gates = ltype == HL_NN_LSTM ? 4 : (ltype == HL_NN_MGU ? 2 : 0);     // Layer_LSTM.h:24-29, Layer_GRU.h:29-34
     if (gates) { lw.push_back((long long)gates * t.size * (t.nIn + t.size)); lb.push_back(gates * t.size); }
-    else if (c.nn_type == HL_NN_RNN) { lw.push_back(roundUp(t.size, 8) * (t.nIn + t.size)); lb.push_back(t.size); }   // [W_in; W_rec] (Layer_Base.h:24-28)
+    else if (ltype == HL_NN_RNN) { lw.push_back(roundUp(t.size, 8) * (t.nIn + t.size)); lb.push_back(t.size); }   // [W_in; W_rec] (Layer_Base.h:24-28)
     else { lw.push_back(roundUp(t.size, 8) * t.nIn); lb.push_back(t.size); }
     t.hasRes = (t.denseLayer != 1);        // no skip connection after the first layer (Builder.cpp:89-95)
     t.resLayer = -1;
@@ -307,7 +313,8 @@ int buildNet(hl_learner* h) {
   }
   for (int j = 0; j < nH; ++j) {
     DevHidden& d = h->hid[j + hOff];
-    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = c.nn_type == HL_NN_LSTM ? 4 : (c.nn_type == HL_NN_MGU ? 2 : (c.nn_type == HL_NN_RNN ? 1 : 0));   // gates per cell (0: dense; 1: dense with a recurrent term)
+    const int ltype = (c.encoder_rnn && j < h->nEncLayers) ? HL_NN_RNN : c.nn_type;
+    d.nIn = hs[j].nIn; d.size = hs[j].size; d.lstm = ltype == HL_NN_LSTM ? 4 : (ltype == HL_NN_MGU ? 2 : (ltype == HL_NN_RNN ? 1 : 0));   // gates per cell (0: dense; 1: dense with a recurrent term)
     d.ldW = d.lstm >= 2 ? d.lstm * d.size : (int)roundUp(d.size, 8); d.func = c.nnFunc;
     d.indW = h->indW[hs[j].denseLayer]; d.indB = h->indB[hs[j].denseLayer];
     d.hasRes = hs[j].hasRes; d.resW = std::min(d.nIn, d.size);
@@ -320,9 +327,10 @@ int buildNet(hl_learner* h) {
   h->lay.clear();
   for (int j = 0; j < c.n_conv; ++j) h->lay.push_back({6, (int)lw[convLayer[j]], (int)lb[convLayer[j]], 0, h->indW[convLayer[j]], h->indB[convLayer[j]]});
   for (int j = 0; j < nH; ++j) {
-    if (c.nn_type == HL_NN_LSTM) h->lay.push_back({4, hs[j].nIn, hs[j].size, 4 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
-    else if (c.nn_type == HL_NN_MGU) h->lay.push_back({5, hs[j].nIn, hs[j].size, 2 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
-    else if (c.nn_type == HL_NN_RNN) h->lay.push_back({1, hs[j].nIn + hs[j].size, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});   // BaseLayer::save: input rows, then recurrent rows (Layer_Base.h:143-153)
+    const int ltype = (c.encoder_rnn && j < h->nEncLayers) ? HL_NN_RNN : c.nn_type;
+    if (ltype == HL_NN_LSTM) h->lay.push_back({4, hs[j].nIn, hs[j].size, 4 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    else if (ltype == HL_NN_MGU) h->lay.push_back({5, hs[j].nIn, hs[j].size, 2 * hs[j].size, h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
+    else if (ltype == HL_NN_RNN) h->lay.push_back({1, hs[j].nIn + hs[j].size, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});   // BaseLayer::save: input rows, then recurrent rows (Layer_Base.h:143-153)
     else h->lay.push_back({1, hs[j].nIn, hs[j].size, (int)roundUp(hs[j].size, 8), h->indW[hs[j].denseLayer], h->indB[hs[j].denseLayer]});
     if (hs[j].hasRes) h->lay.push_back({2, 0, hs[j].size, 0, h->indW[hs[j].resLayer], h->indB[hs[j].resLayer]});
   }
@@ -590,6 +598,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 256) return HL_ERR_UNSUPPORTED;
   }
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
+  if (cfg->encoder_rnn && cfg->nn_type != HL_NN_MGU) return HL_ERR_BAD_ARG;      // (the one mix the reference builds: Approximator.cpp:221-223, 264-270)
   if (cfg->ERoldSeqFilter < HL_ER_OLDEST || cfg->ERoldSeqFilter > HL_ER_MINERROR) return HL_ERR_BAD_ARG;
   if (cfg->dataSamplingAlgo < HL_SAMPLE_UNIFORM || cfg->dataSamplingAlgo > HL_SAMPLE_PERSEQ) return HL_ERR_BAD_ARG;
   for (int j = 0; j < cfg->n_conv; ++j) {   // each layer takes the previous one's image; the first one the whole stacked input
@@ -610,6 +619,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->n_encoder > 0) {     // createEncoder: the encoder layers are the first hidden layers of the one network (Learner_approximator.cpp:149-166)
     int n = 0;
     for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 0) h->cfg.hidden[n++] = cfg->encoder[j];
+    h->nEncLayers = n;
     for (int j = 0; j < cfg->n_hidden; ++j) h->cfg.hidden[n++] = cfg->hidden[j];
     h->cfg.n_hidden = n; h->cfg.n_encoder = 0;
   }
@@ -700,6 +710,14 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   }
   h->actFastOk = !h->recurrent && h->nConv == 0 && getenv("SMARTIES_HIP_NO_ACT_KERNEL") == nullptr;
   for (int j = 0; j < h->nHidden; ++j) if (h->hid[j].size > ACT_MAXW || h->hid[j].nIn > ACT_MAXW) h->actFastOk = false;
+  if (h->recurrent && cfg->encoder_rnn && h->nEncLayers > 0 && h->nEncLayers < h->nHidden - (h->nConv > 0 ? 1 : 0)) {
+    const int j0 = h->nConv > 0 ? 1 : 0; const DevHidden& top = h->hid[j0 + h->nEncLayers - 1]; const DevHidden& up = h->hid[j0 + h->nEncLayers];
+    if ((up.lstm * up.size) % 4 != 0) return fail(h, HL_ERR_UNSUPPORTED, "MGU layer behind RNN encoder layers: an even number of cells is needed");
+    h->recSplit = h->nEncLayers; h->ldSeg = (int)roundUp(top.size, 16);
+    const size_t R = (size_t)B * h->recK;
+    HIPCK(devAlloc(&h->segY, (R + B) * h->ldSeg)); HIPCK(devAlloc(&h->segDres, R * h->ldSeg)); HIPCK(devAlloc(&h->segScratch, R * h->ldSeg));
+    h->useGraph = false;      // (eager steps, as for the other combinations no settings file builds)
+  }
   if (h->recurrent) {
     const size_t R = (size_t)B * h->recK;
     for (int j = h->nConv > 0 ? 1 : 0; j < h->nHidden; ++j) {      // (hid[0] of a convolutional net is its last convolution)
@@ -872,6 +890,7 @@ int hl_destroy(hl_learner* h) {
       bt.oldV, bt.oldADV, bt.nextV, bt.oldNextV, bt.oldNextADV, bt.gParam, bt.aggIn};
     for (void* q : bp) if (q) hipFree(q);
   }
+  for (void* q : {(void*)h->segY, (void*)h->segDres, (void*)h->segScratch}) if (q) hipFree(q);
   for (void* q : {(void*)h->winSlot, (void*)h->winT, (void*)h->winNextSrc, (void*)h->scW}) if (q) hipFree(q);
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd, h->rec[j].A2}) if (q) hipFree(q);
   for (void* p : ptrs) if (p) hipFree(p);
@@ -1763,6 +1782,20 @@ int hl_forward(hl_learner* h, int32_t n, const float* states, double* outputs) {
   return HL_OK;
 }
 
+// the window kernels on the agent's last `win` states (`ctx` more in front of them for appended observations); a stack of two layer
+// types as two launches, the lower segment's rows being the upper one's input
+static int recActingForward(hl_learner* h, const float* dStates, int win, int ctx) {
+  if (h->recSplit) {
+    RecArgs lo = recArgs(h, 0, 0); lo.B = 1; lo.actStates = dStates; lo.actSteps = win; lo.actCtx = ctx;
+    HIPCK(launch_rec_forward(lo, h->stream));
+    RecArgs up = recArgs(h, 0, 1); up.B = 1; up.actStates = dStates; up.actSteps = win; up.actCtx = 0;
+    HIPCK(launch_rec_forward(up, h->stream));
+    return HL_OK;
+  }
+  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = dStates; ra.actSteps = win; ra.actCtx = ctx;
+  HIPCK(launch_rec_forward(ra, h->stream));
+  return HL_OK;
+}
 int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, double* outputs) {
   if (!h || nSteps < 1 || !states || !outputs) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
@@ -1788,8 +1821,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
     int rc = ensureConvPrep(h); if (rc) return rc;
     rc = launchFront(h, 0, h->stream, /*gather*/false); if (rc) return rc;
     const DevHidden& q = h->hid[h->nHidden - 1];
-    RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = h->dActS; ra.actSteps = win; ra.actCtx = 0;      // (the rows come from Xin; actStates only marks the call as acting)
-    HIPCK(launch_rec_forward(ra, h->stream));
+    { const int rc2 = recActingForward(h, h->dActS, win, 0); if (rc2) return rc2; }      // (the rows come from Xin; the states only mark the call as acting)
     HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
                             h->dActO, h->stream, nullptr, 0, h->cfg.nnOutputFunc));
     HIPCK(hipMemcpyAsync(outputs, h->dActO, (size_t)h->nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1806,8 +1838,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
   std::memcpy(pIn, states, (size_t)nSteps * h->dS * sizeof(float));
   unsigned tag = ++h->actTag; if (tag == 0) tag = ++h->actTag;
   const DevHidden& q = h->hid[h->nHidden - 1];
-  RecArgs ra = recArgs(h, 0); ra.B = 1; ra.actStates = pIn; ra.actSteps = std::min(nSteps, h->recK); ra.actCtx = nSteps - ra.actSteps;
-  HIPCK(launch_rec_forward(ra, h->stream));
+  { const int win = std::min(nSteps, h->recK); const int rc2 = recActingForward(h, pIn, win, nSteps - win); if (rc2) return rc2; }
   HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
                           pOut, h->stream, const_cast<unsigned*>(pDone), tag, h->cfg.nnOutputFunc));
   { int rc = actWait(h, pDone, 1, tag); if (rc) return rc; }

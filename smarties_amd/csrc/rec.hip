@@ -1331,8 +1331,13 @@ __global__ __launch_bounds__(256) void rnn_forward_kernel(RecArgs a) {
       cur ^= 1;
     }
     const int nCl = a.L[a.nL - 1].nC;
+    if (a.YoutRows) {      // lower segment of a two-type stack: every step's output is an input row of the segment above
+      const long long ro = k <= T ? (long long)b * a.K + k : (long long)a.B * a.K + (nextRow - a.B);
+      if (tid < nCl) a.YoutRows[ro * a.ldYR + tid] = sBuf[cur][tid];
+    } else {
     if (k == T && tid < nCl) a.Yout[(size_t)b * a.ldY + tid] = sBuf[cur][tid];
     if (k == T + 1 && tid < nCl) a.Yout[(size_t)nextRow * a.ldY + tid] = sBuf[cur][tid];
+    }
     ldsBarrier();
   }
 }
@@ -1362,7 +1367,7 @@ __global__ __launch_bounds__(256) void rnn_backward_kernel(RecArgs a) {
     const long long r = (long long)b * a.K + k;
     int cur = 0;
     const int nCl = a.L[a.nL - 1].nC;
-    if (tid < nCl) sTop[0][tid] = k == T ? a.Dres[(size_t)b * a.ldD + tid] : 0.f;
+    if (tid < nCl) sTop[0][tid] = a.DresRows ? a.DresRows[r * a.ldDR + tid] : (k == T ? a.Dres[(size_t)b * a.ldD + tid] : 0.f);
     ldsBarrier();
     for (int j = a.nL - 1; j >= 0; --j) {
       const RecLayer& L = a.L[j];

@@ -72,6 +72,20 @@ int buildProblems(hl_learner* h) {
       sb.dxIdx.push_back((int)P.size()); sb.dxBlocks.push_back(cur); P.push_back(p);
     }
     // dW: every weight / bias / residual-parameter gradient in one multi-problem launch
+    // two layer types (hl_config::encoder_rnn): the error of the lower segment's outputs, per window row = (gate deltas of the upper
+    // segment's first layer) W_in^T + its residual path (C2 of the dX epilogue, the product with an activation's derivative, is not
+    // used here: a linear one into scratch)
+    if (h->recurrent && h->recSplit) {
+      const int ju = j0 + h->recSplit; const DevHidden& d = h->hid[ju]; const RecLayer& L = h->rec[ju];
+      const int NO = std::max(d.lstm, 1) * d.size;
+      GemmProblem p{}; p.flavor = GEMM_X; p.epi = EPI_DX; p.M = B * h->recK; p.N = d.nIn; p.K = NO;
+      p.A = L.D; p.lda = NO; p.B = h->W + d.indW; p.ldb = d.ldW;
+      p.C = h->segDres; p.C2 = h->segScratch; p.ldc = h->ldSeg;
+      if (d.hasRes) { p.resIn = L.Rd; p.ldRes = L.ldR; p.resW = h->W + d.indWr; p.resN = d.resW; }
+      p.actX = h->segY; p.actY = h->segY; p.ldAct = h->ldSeg; p.func = HL_FUNC_LINEAR;
+      int cur = 0; setTiles(p, cur);
+      sb.segDxIdx = (int)P.size(); sb.segDxBlocks = cur; P.push_back(p);
+    }
     // convolutions in front of recurrent layers: Dres of the last convolution's rows = (gate deltas of the first recurrent layer)
     // W_in^T + the residual path, over the B K window rows (the deltas of the gates are what rec_backward left for the dW launch)
     if (h->recurrent && j0) {
@@ -666,15 +680,19 @@ bool evictionDue(const hl_learner* h) {
   return h->nTransitions - (long long)h->order.back().N > h->maxObsLocal;
 }
 
-RecArgs recArgs(hl_learner* h, int parity) {
+// seg: -1 = the whole recurrent stack (one layer type); 0 / 1 = lower ("RNN" encoder layers) / upper segment of a two-type stack
+RecArgs recArgs(hl_learner* h, int parity, int seg = -1) {
   const DevHidden& q = h->hid[h->nHidden - 1];
-  RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS; ra.nL = h->nHidden;
+  RecArgs ra{}; ra.sc = h->sc; ra.rp = h->rp; ra.bt = h->buf[parity].bt; ra.B = h->B; ra.dS = h->dS;
   const int j0 = h->nConv > 0 ? 1 : 0;      // (hid[0] of a convolutional net is its last convolution: its rows are the first layer's input)
-  ra.nL = h->nHidden - j0;
-  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[j0].lstm; ra.func = h->cfg.nnFunc; ra.nApp = j0 ? 0 : h->nApp;
-  for (int j = j0; j < h->nHidden; ++j) ra.L[j - j0] = h->rec[j];
-  if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
-  ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA;
+  const int jBeg = seg == 1 ? j0 + h->recSplit : j0, jEnd = seg == 0 ? j0 + h->recSplit : h->nHidden;
+  ra.nL = jEnd - jBeg;
+  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[jBeg].lstm; ra.func = h->cfg.nnFunc; ra.nApp = (j0 || seg == 1) ? 0 : h->nApp;
+  for (int j = jBeg; j < jEnd; ++j) ra.L[j - jBeg] = h->rec[j];
+  if (seg == 1) { ra.Xin = h->segY; ra.ldXin = h->ldSeg; }
+  else if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
+  if (seg == 0) { ra.YoutRows = h->segY; ra.ldYR = h->ldSeg; ra.DresRows = h->segDres; ra.ldDR = h->ldSeg; }
+  else { ra.Yout = q.hasRes ? q.Rr : q.Y; ra.ldY = q.ldA; ra.Dres = q.Dres; ra.ldD = q.ldA; }
   return ra;
 }
 // forward, head, backward (dX and dW) of buffer `parity`, eager, no riders
@@ -684,8 +702,20 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
     return launchWeightGrad(h, parity, fuseAdam, s, false, false);
   }
   if (h->recurrent) {      // LSTM layers: window forward, head, back-propagation through time, then the common dW (+ Adam) launch
-    const RecArgs ra = recArgs(h, parity);
     if (h->nConv > 0) { const int rc = launchFront(h, parity, s, true); if (rc) return rc; }      // the windows' rows through the conv stack
+    if (h->recSplit) {      // two layer types: the "RNN" encoder layers, then the MGU layers on their rows; backward the other way round
+      const RecArgs lo = recArgs(h, parity, 0), up = recArgs(h, parity, 1);
+      const StepBuf& sb = h->buf[parity];
+      HIPCK(timed(h, "rec_forward_lower", s, [&] { return launch_rec_forward(lo, s); }));
+      HIPCK(timed(h, "rec_forward", s, [&] { return launch_rec_forward(up, s); }));
+      int rc = launchHead(h, parity, s); if (rc) return rc;
+      HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(up, s); }));
+      const AdamHyper hyp = adamHyper(h, parity);
+      HIPCK(timed(h, "gemm16_dx_segment", s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.segDxIdx, 1, sb.segDxBlocks, h->sc, hyp, nullptr, s); }));
+      HIPCK(timed(h, "rec_backward_lower", s, [&] { return launch_rec_backward(lo, s); }));
+      return launchBackward(h, parity, fuseAdam, s);
+    }
+    const RecArgs ra = recArgs(h, parity);
     HIPCK(timed(h, "rec_forward", s, [&] { return launch_rec_forward(ra, s); }));
     int rc = launchHead(h, parity, s); if (rc) return rc;
     HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));

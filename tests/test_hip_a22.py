@@ -157,3 +157,55 @@ def test_recurrent_layers_behind_convolutions_match_oracle(hip_api, kind, hidden
     for n in (1, 3, 5, 5 + nApp):
         S = rng.normal(size=(n, dS)).astype(np.float32)
         assert relinf(G.forward_sequence(S), O.forward_sequence(S)) < TOL32, n
+
+
+def test_rnn_encoder_under_mgu_layers_follows_reference_fixture(hip_api):
+    """pomdp_encoder.bin: a partially observable MDP with nnType left at its default -- Approximator::buildPreprocessing makes the
+    encoder layers plain recurrent ones ("RNN", Approximator.cpp:264-270), buildFromSettings the layers behind them MGU (:221-223).
+    On the device the stack runs as two window launches each way (rec.hip), the lower one's rows being the upper one's input."""
+    name = "pomdp_encoder.bin"
+    fx = load_fixture(name)
+    L = hip_learner(hip_api, fixture_config(fx, nnFunc="Tanh"))
+    assert L.nParams == int(fx["cfg"][5]) and L.nOut == int(fx["cfg"][6])
+    lay = L.layout()
+    assert np.array_equal(lay["indW"], fx["indWeights"]) and np.array_equal(lay["indB"], fx["indBiases"])
+    setup_from_fixture(L, fx)
+    w, m1, m2 = L.get_params()
+    assert np.array_equal(w, fx["W0"]) and np.array_equal(L.get_rng_state(), fx["rng0"])
+    for k in range(1, int(fx["cfg"][4]) + 1):
+        sk = "s%d_" % k
+        if sk + "flat" not in fx:
+            break
+        flat = flat_for(L, fx[sk + "tag"], fx[sk + "t"])
+        order = np.argsort(flat, kind="stable")
+        L.step(1, flat=flat[order])
+        assert relinf(L.readback(capi.TAP_OUTPUT), fx[sk + "O"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_RHO), fx[sk + "rho"][order]) < TOL32
+        assert relinf(L.readback(capi.TAP_OUTGRAD), fx[sk + "G"][order]) < TOL32
+        assert np.array_equal(L.readback(capi.TAP_FAR), fx[sk + "far"][order])
+        if sk + "gradSum" in fx:
+            assert relinf(L.readback(capi.TAP_GRADSUM), fx[sk + "gradSum"]) < TOL32
+        if sk + "W" in fx:
+            w, m1, m2 = L.get_params()
+            assert relinf(w, fx[sk + "W"]) < TOL32 and relinf(m1, fx[sk + "M1"]) < TOL32 and relinf(m2, fx[sk + "M2"]) < 2 * TOL32
+
+
+@pytest.mark.parametrize("enc,hidden,nApp,conv", [((24,), (16, 16), 0, None), ((20, 36), (32,), 2, None), ((16,), (16, 8), 0, [(8, 8, 4, 8, 3, 1)])],
+                         ids=["24|16x16", "20x36|32-appended", "conv|16|16x8"])
+def test_rnn_encoder_under_mgu_layers_matches_oracle(hip_api, enc, hidden, nApp, conv):
+    dS = 256 if conv else 6
+    kw = dict(dimS=dS, dimA=2, bounded=[1, 0], hidden=hidden, encoder=list(enc), encoder_rnn=1, nn_type=capi.NN_MGU, nnFunc="Tanh", batchSize=12,
+              maxTotObsNum=4000, randSeed=5, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=5, nAppendedObs=nApp)
+    if conv:
+        kw["conv"] = conv
+    G, O = _pair(hip_api, kw, synth_cfg(seed=21, dimS=dS, dimA=2, lenMin=2, lenMax=30, pTerm=0.5), 50)
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(10); O.step(10)
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    rng = np.random.default_rng(5)
+    for n in sorted({1, 3, 6, 6 + nApp}):
+        S = rng.normal(size=(n, dS)).astype(np.float32)
+        assert relinf(G.forward_sequence(S), O.forward_sequence(S)) < TOL32, n
