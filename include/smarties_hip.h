@@ -78,7 +78,7 @@ enum { HL_FUNC_LINEAR = 0, HL_FUNC_TANH = 1, HL_FUNC_SOFTSIGN = 2, HL_FUNC_RELU 
 
 /* advantage head: which RACER instantiation (Learners/RACER.cpp:114-116) */
 /* hidden layer type (Network/Builder.cpp:48-117): dense, or LSTM (Network/Layers/Layer_LSTM.h; BASELINE config 4).
- * HL_NN_LSTM: rec.hip (one workgroup per sample walks the BPTT window; cells <= 64 per layer, eager launches). */
+ * HL_NN_LSTM: rec.hip (a workgroup -- two wavefronts for the shipped 2 x 32 shape -- per sample walks the BPTT window; cells <= 256 per layer). */
 enum { HL_NN_FFNN = 0, HL_NN_LSTM = 1, HL_NN_MGU = 2 /* Layer_GRU.h: what a partially observable MDP gets when nnType is left FFNN (Approximator.cpp:221-223) */,
        HL_NN_RNN = 3 /* "RNN" / "Recurrent" (Builder.cpp:76-81): dense layers with a recurrent term, y_t = f(W x_t + W_rec y_{t-1} + b)
                         (BaseLayer with bRecurrent, Layer_Base.h:64-113) */ };
@@ -138,7 +138,7 @@ typedef struct hl_config {
   int32_t hidden[HL_MAX_HIDDEN];     /* nnLayerSizes                                       */
   int32_t nnFunc;                    /* HL_FUNC_*                                          */
   int32_t adv_kind;                  /* HL_ADV_*                                           */
-  int32_t batchSize;                 /* GLOBAL batch (split over ranks, HyperParameters.cpp:186-189) */
+  int32_t batchSize;                 /* GLOBAL batch (split over ranks, HyperParameters.cpp:186-189); the local share <= 16384 */
   int64_t maxTotObsNum;              /* GLOBAL replay size (split over ranks, :196-197)    */
   int64_t minTotObsNum;              /* GLOBAL; 0 = maxTotObsNum (HyperParameters.cpp:191)  */
   double gamma, lambda;              /* Retrace                                            */
