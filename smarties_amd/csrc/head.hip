@@ -392,6 +392,13 @@ hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, h
   ExtraArgs ex{}; if (extra) ex = *extra;
   const int nEx = ex.role ? 1 + ex.helpers : 0;
   const dim3 block(256);
+  if (a.H > 128 && maxRows >= 4096 && !nEx) {       // large batches: throughput, not latency -- a wavefront per sample, four samples per workgroup
+    const dim3 grid((maxRows + 3) / 4);
+    const int HQ = (a.H + 63) / 64;
+    if (HQ <= 4) hipLaunchKernelGGL((head_kernel_t<4, 1>), grid, block, 0, s, a, ex);
+    else hipLaunchKernelGGL((head_kernel_t<8, 1>), grid, block, 0, s, a, ex);
+    return hipGetLastError();
+  }
   if (a.H > 128) {       // one sample per workgroup, a quarter of the hidden units per wavefront
     const dim3 grid(maxRows + nEx);
     const int HQ = (a.H + 255) / 256;

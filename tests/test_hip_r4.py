@@ -218,8 +218,8 @@ def test_gradient_pushed_by_the_weight_gradient_launch_equals_the_exchange_kerne
         assert np.array_equal(P[0].get_params()[0], P[1].get_params()[0])
 
 
-@pytest.mark.parametrize("B,hidden,dS,nEps", [(2048, (64, 64), 9, 150), (5000, (32, 48, 32), 5, 150), (16384, (32, 32), 4, 500), (1500, (256, 256), 17, 60)],
-                         ids=["2048-2x64", "5000-3-layers", "16384-2x32", "1500-2x256"])
+@pytest.mark.parametrize("B,hidden,dS,nEps", [(2048, (64, 64), 9, 150), (5000, (32, 48, 32), 5, 150), (16384, (32, 32), 4, 500), (1500, (256, 256), 17, 60), (2304, (256, 192), 17, 90)],
+                         ids=["2048-2x64", "5000-3-layers", "16384-2x32", "1500-2x256", "2304-256x192"])
 def test_large_local_batches_match_oracle(hip_api, B, hidden, dS, nEps):
     """Local batches above 1024 (up to 16384): the 1024-thread sampler workgroup (sample.hip: big_sample_kernel) must leave the
     generator, the sorted unique indices -- drawn from replays only a few times the batch, so that several redraw rounds happen --
