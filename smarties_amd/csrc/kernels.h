@@ -222,6 +222,9 @@ hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int pari
 bool big_dw_ok(const GemmProblem& P);
 int big_dw_chunk_rows(int M, int N, int rows);
 hipError_t launch_big_dw(const GemmProblem& P, hipStream_t s);
+// output layer + head + dX of the output layer for panels of 16 samples (headp.hip): the throughput form of launch_head
+bool panel_head_ok(const HeadArgs& a);
+hipError_t launch_panel_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_sample(const SampleArgs& a, hipStream_t s);
 hipError_t launch_post_agg_chunks(const PostArgs& a, hipStream_t s);
 // one launch, two independent workgroups: bookkeeping of a finished step (post) and sampling of a

@@ -444,6 +444,7 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
       if (ex.helpers > 0 && !h->recurrent && !h->helperHandOff) ex.samp.selfSearch = 1;
     }
   }
+  if (h->panelHead && panel_head_ok(ha)) { HIPCK(timed(h, "panel_head", s, [&] { return launch_panel_head(ha, h->Mmax, pex, s); })); return HL_OK; }
   HIPCK(timed(h, "head_kernel", s, [&] { return launch_head(ha, h->Mmax, pex, s); }));
   return HL_OK;
 }
