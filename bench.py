@@ -108,8 +108,9 @@ def other_configs(api, steps=1000):
                                            gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
         # the bench network at larger batches: where the step stops being a latency chain (fraction of the fp32 MFMA peak below)
         "cfgNS_2x256_b1024": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=131072), 400, 200, max(100, steps // 2)),
-        "cfgNS_2x256_b4096": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=131072), 400, 200, max(100, steps // 4)),
-        "cfgNS_2x256_b16384": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=16384, maxTotObsNum=131072), 400, 200, max(50, steps // 10)),
+        # (a replay of 500 000 transitions: with one only five times the batch the sampler needs seven redraw rounds per minibatch)
+        "cfgNS_2x256_b4096": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=1048576), 2500, 200, max(100, steps // 4)),
+        "cfgNS_2x256_b16384": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=16384, maxTotObsNum=1048576), 2500, 200, max(50, steps // 10)),
         "cfg5_racer_atari_conv4_512_b128": (dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3, conv=conv, hidden=(512,),
                                                  nnFunc="Tanh", batchSize=128, maxTotObsNum=20000, gamma=0.99, explNoise=0.05), 120, 60, max(100, steps // 5)),
     }

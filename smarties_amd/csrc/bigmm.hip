@@ -199,6 +199,144 @@ hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int pari
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// big_mm_kernel: the same two products as 64 x 64 output tiles with BOTH operands in 32-deep k-slices through LDS (double-buffered:
+// the next slice's 16-byte loads are in flight while this one multiplies), each wavefront a 32 x 32 quadrant -- the weight-gradient
+// kernel's structure.  39 KB of LDS: four workgroups per CU, whose load / MFMA / epilogue phases overlap (the panel kernel above
+// has two with two panels each: its phases add up).  A slice [64 rows][32 k] at pitch 36 (rows 16 apart in a tile fall into
+// different banks with the four k groups); W slices [32 k][64 n] at pitch 80 (forward) or [64 n][32 k] at pitch 36 (dX: W rows are
+// the outputs there).  The epilogue goes through LDS as in the panel kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MM_PA = 36, MM_PB = 80, MM_KS = 32;
+template <bool TRANSW>
+__global__ __launch_bounds__(256, 4) void big_mm_kernel(GemmProblem P, const DevScalars* __restrict__ sc, int parity, int nRowTiles) {
+  __shared__ __attribute__((aligned(16))) float sA[2][64 * MM_PA];
+  __shared__ __attribute__((aligned(16))) float sB[2][TRANSW ? 64 * MM_PA : MM_KS * MM_PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int colTiles = (P.N + 63) / 64, slot = (int)blockIdx.x >> 3;
+  const int rowTile = ((int)blockIdx.x & 7) + 8 * (slot / colTiles);      // (the column tiles of a row tile on one XCD: they read the same rows of A)
+  if (rowTile >= nRowTiles) return;
+  const int m0 = rowTile * 64, n0 = (slot % colTiles) * 64;
+  const int nRows = P.dynRows ? sc->nRows[parity] : P.M;
+  if (m0 >= nRows) return;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int K = P.K;
+  f32x4 va[2], vb[2];
+  auto loadSlice = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      { const int r = (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;      // A: 64 rows x 8 pieces of four k (zeros behind K: the row pitch covers the padded K)
+        va[q] = (m0 + r < nRows && k < P.lda) ? *reinterpret_cast<const f32x4*>(P.A + (size_t)(m0 + r) * P.lda + k) : z4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e >= K) va[q][e] = 0.f; }
+      if constexpr (TRANSW) {      // W rows n0 .. n0 + 63, columns k
+        const int n = (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;
+        vb[q] = (n0 + n < P.N && k < P.ldb) ? *reinterpret_cast<const f32x4*>(P.B + (size_t)(n0 + n) * P.ldb + k) : z4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e >= K) vb[q][e] = 0.f;
+      } else {                     // W rows k, columns n0 .. n0 + 63
+        const int k = k0 + (tid >> 4) + 16 * q, c = n0 + (tid & 15) * 4;
+        vb[q] = (k < K && c < P.ldb) ? *reinterpret_cast<const f32x4*>(P.B + (size_t)k * P.ldb + c) : z4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e >= P.N) vb[q][e] = 0.f;
+      }
+    }
+  };
+  auto storeSlice = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<f32x4*>(&sA[buf][((tid >> 3) + 32 * q) * MM_PA + (tid & 7) * 4]) = va[q];
+      if constexpr (TRANSW) *reinterpret_cast<f32x4*>(&sB[buf][((tid >> 3) + 32 * q) * MM_PA + (tid & 7) * 4]) = vb[q];
+      else *reinterpret_cast<f32x4*>(&sB[buf][((tid >> 4) + 16 * q) * MM_PB + (tid & 15) * 4]) = vb[q];
+    }
+  };
+  f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+  loadSlice(0); storeSlice(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += MM_KS) {
+    const bool more = k0 + MM_KS < K;
+    if (more) loadSlice(k0 + MM_KS);
+#pragma unroll
+    for (int s = 0; s < MM_KS / 4; ++s) {
+      const float a0 = sA[buf][(wm + li) * MM_PA + 4 * s + lc], a1 = sA[buf][(wm + 16 + li) * MM_PA + 4 * s + lc];
+      float b0, b1;
+      if constexpr (TRANSW) { b0 = sB[buf][(wn + li) * MM_PA + 4 * s + lc]; b1 = sB[buf][(wn + 16 + li) * MM_PA + 4 * s + lc]; }
+      else { b0 = sB[buf][(4 * s + lc) * MM_PB + wn + li]; b1 = sB[buf][(4 * s + lc) * MM_PB + wn + 16 + li]; }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) storeSlice(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- epilogue through LDS (the slices are dead): sOut[64][64], columns rotated by 16 per group of four rows ----
+  float* sOut = &sA[0][0];                       // 64 x 64 floats = 16 KB <= the two A buffers (18 KB)
+  static_assert(2 * 64 * MM_PA >= 64 * 64, "output tile fits the A buffers");
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm + 16 * tm + 4 * lc + i, c = wn + 16 * tn + li;
+        sOut[r * 64 + ((c + 16 * (r >> 2)) & 63)] = acc[tm][tn][i];
+      }
+  __syncthreads();
+  const int ec = 4 * (tid & 15);
+  float eb[4], ew[4], er[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = n0 + ec + e;
+    eb[e] = (!TRANSW && n < P.N) ? P.bias[n] : 0.f;
+    ew[e] = (n < P.resN && P.resW) ? P.resW[n] : 0.f;
+    er[e] = (!TRANSW && n < P.resN && P.resB) ? P.resB[n] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = (tid >> 4) + 16 * q, m = m0 + rr, n = n0 + ec;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sOut + rr * 64 + ((ec + 16 * (rr >> 2)) & 63));
+    if (m >= nRows || n >= P.N) continue;
+    const size_t o = (size_t)m * P.ldc + n;
+    const bool whole = n + 3 < P.N;
+    if constexpr (!TRANSW) {
+      f32x4 rin = z4;
+      if (P.C3 && n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
+      f32x4 x, y, r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[e] = v[e] + eb[e]; y[e] = actEval(P.func, x[e]); r[e] = n + e < P.resN ? y[e] + (rin[e] * ew[e] + er[e]) : y[e]; }
+      if (whole) {
+        *reinterpret_cast<f32x4*>(P.C + o) = x; *reinterpret_cast<f32x4*>(P.C2 + o) = y;
+        if (P.C3) *reinterpret_cast<f32x4*>(P.C3 + o) = r;
+      } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = x[e]; P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
+    } else {
+      f32x4 rin = z4, ax = z4, ay = z4;
+      if (n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
+      if (n + 3 < P.ldAct) { ax = *reinterpret_cast<const f32x4*>(P.actX + (size_t)m * P.ldAct + n); ay = *reinterpret_cast<const f32x4*>(P.actY + (size_t)m * P.ldAct + n); }
+      f32x4 dres, d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ay[e]); }
+      if (whole) { *reinterpret_cast<f32x4*>(P.C + o) = dres; *reinterpret_cast<f32x4*>(P.C2 + o) = d; }
+      else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = dres[e]; P.C2[o + e] = d[e]; }
+    }
+  }
+}
+bool big_mm_ok(const GemmProblem& P) {
+  const bool al = (P.lda & 3) == 0 && (P.ldb & 3) == 0 && (P.ldc & 3) == 0 && (!P.resN || ((P.ldRes & 3) == 0 && P.ldRes >= ((P.resN + 3) & ~3))) &&
+                  (P.flavor != GEMM_X || ((P.ldAct & 3) == 0 && P.ldAct >= ((P.N + 3) & ~3)));
+  return (P.flavor == GEMM_F || P.flavor == GEMM_X) && al;
+}
+hipError_t launch_big_mm(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s) {
+  const int colTiles = (P.N + 63) / 64, rowTiles = (P.M + 63) / 64;
+  const dim3 grid(8 * ((rowTiles + 7) / 8) * colTiles);
+  if (P.flavor == GEMM_X) hipLaunchKernelGGL((big_mm_kernel<true>), grid, dim3(256), 0, s, P, sc, parity, rowTiles);
+  else hipLaunchKernelGGL((big_mm_kernel<false>), grid, dim3(256), 0, s, P, sc, parity, rowTiles);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 constexpr int BD_PITCH = 80, BD_ROWS = 32;
 
 __global__ __launch_bounds__(256, 2) void big_dw_kernel(GemmProblem P) {

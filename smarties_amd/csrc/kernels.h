@@ -219,6 +219,8 @@ struct MomentsArgs {
 // dense layers at large local batches (bigmm.hip): weight-stationary forward / dX panels, 64 x 64 weight-gradient tiles over row chunks
 bool big_panel_ok(const GemmProblem& P);
 hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s);
+bool big_mm_ok(const GemmProblem& P);
+hipError_t launch_big_mm(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s);
 bool big_dw_ok(const GemmProblem& P);
 int big_dw_chunk_rows(int M, int N, int rows);
 hipError_t launch_big_dw(const GemmProblem& P, hipStream_t s);

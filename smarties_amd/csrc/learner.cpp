@@ -64,7 +64,7 @@ struct hl_learner {
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
   bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
   bool panelHead = false;     // ... and headp.hip's 16-sample panels for the head (SMARTIES_HIP_PANEL_HEAD=0 / 1 overrides: 1 also for small batches, eager launches)
-  int bigMm = 0;              // ... with the kernels of bigmm.hip (bit 0: forward / dX panels, bit 1: weight gradients; SMARTIES_HIP_BIGMM overrides)
+  int bigMm = 0;              // ... with the kernels of bigmm.hip (bit 0: weight-stationary forward / dX panels, bit 1: weight gradients, bit 2: LDS-tiled forward / dX products, taken before the panels; SMARTIES_HIP_BIGMM overrides)
   std::vector<hl::GemmProblem> hostProbs;      // the problem table as the host built it (large batches: kernels taking a problem by value)
   // ... whose sampler draws the NEXT step's minibatch on a stream of its own while this step's launches run
   hipStream_t sideStream = nullptr; hipEvent_t evMain = nullptr, evSide = nullptr; bool sidePending = false;
@@ -636,7 +636,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   // 1024 < B <= 16384: one 1024-thread sampler workgroup (sample.hip: big_sample_kernel), states assembled by stack_gather_kernel,
   // one launch per layer and direction, weight gradients split over the rows, eager steps
   h->bigBatch = h->B > 1024;
-  h->bigMm = h->bigBatch ? 3 : 0;
+  h->bigMm = h->bigBatch ? 7 : 0;
   h->panelHead = h->B >= 2048 || cfg->nn_type != HL_NN_FFNN;      // (measured: recurrent nets 68.5 -> 66.5 us per step at 2 x 32 cells; the 512-wide Atari head 152.5 -> 156.9: one wavefront set per sample there)
   if (const char* e = getenv("SMARTIES_HIP_PANEL_HEAD")) h->panelHead = e[0] == '1';
   if (const char* e = getenv("SMARTIES_HIP_BIGMM")) h->bigMm = h->bigBatch ? atoi(e) : 0;

@@ -418,6 +418,9 @@ int launchForward(hl_learner* h, int parity, hipStream_t s, bool nextSample = fa
       if (ph) { ex = extraSample(h, parity ^ 1, ph); pex = &ex; }
     }
     const int role = j == j0 ? GEMM_ROLE_FWD0 : GEMM_ROLE_FWD;
+    if ((h->bigMm & 4) && big_mm_ok(h->hostProbs[sb.fwdIdx[j]]))
+      HIPCK(timed(h, nm, s, [&] { return launch_big_mm(h->hostProbs[sb.fwdIdx[j]], h->sc, parity, s); }));
+    else
     if ((h->bigMm & 1) && big_panel_ok(h->hostProbs[sb.fwdIdx[j]]))
       HIPCK(timed(h, nm, s, [&] { return launch_big_panel(h->hostProbs[sb.fwdIdx[j]], h->sc, parity, s); }));
     else
@@ -494,6 +497,9 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
     const int jx = h->recurrent ? 1 : h->nHidden - 1 - (int)i;          // problem i back-propagates through block jx: reduction over its outputs
     const int Kx = h->recurrent ? std::max(h->hid[jx].lstm, 1) * h->hid[jx].size : h->hid[jx].size;      // (recurrent layer under a conv stack: over its gates)
+    if ((h->bigMm & 4) && !pex && big_mm_ok(h->hostProbs[sb.dxIdx[i]]))
+      HIPCK(timed(h, nm, s, [&] { return launch_big_mm(h->hostProbs[sb.dxIdx[i]], h->sc, parity, s); }));
+    else
     if ((h->bigMm & 1) && !pex && big_panel_ok(h->hostProbs[sb.dxIdx[i]]))
       HIPCK(timed(h, nm, s, [&] { return launch_big_panel(h->hostProbs[sb.dxIdx[i]], h->sc, parity, s); }));
     else
