@@ -143,8 +143,6 @@ struct hl_learner {
   // and its last node stamps a pinned host word, which hl_sync polls (tools/call_bench.hip)
   std::map<int, std::array<GraphSlot, 2>> exactGraphs;
   unsigned* notifyPin = nullptr; unsigned notifyIssued = 0; mutable bool tailNotify = false;
-  hipEvent_t tailEvent = nullptr; int tailEventMode = 0;      // SMARTIES_HIP_TAIL_EVENT=1 (experiment): an event recorded behind a whole-call graph, so that the queue's completion marker is
-                                                              // already in flight when the caller synchronises the device
   int lastCallN = 0, sameCallN = 0;
   // the sampler of step k+1 rides along step k, also along the LAST step of a replayed graph: the next call finds its
   // minibatch ready in buffer preParity.  Whatever changes what a sampler sees (new episodes, evictions, explicit
@@ -861,7 +859,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   rc = buildProblems(h); if (rc) return rc;
   if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) { if (e[0] == '1') h->useGraph = false; }
-  if (const char* e = getenv("SMARTIES_HIP_TAIL_EVENT")) h->tailEventMode = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_EAGER_CHAIN")) h->eagerChain = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_XCHG_TIMEOUT_MS")) h->xchgTimeoutTicks = std::max(1LL, atoll(e)) * 100000LL;
   if (const char* e = getenv("SMARTIES_HIP_NO_EXCH_GRAPH")) h->exchGraph = !(e[0] == '1');   // replicas: eager exchanges only
@@ -878,7 +875,6 @@ int hl_destroy(hl_learner* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->actPin) hipHostFree(h->actPin);
   if (h->notifyPin) hipHostFree(h->notifyPin);
-  if (h->tailEvent) hipEventDestroy(h->tailEvent);
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
   for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,

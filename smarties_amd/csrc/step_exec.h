@@ -956,10 +956,6 @@ int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = fals
       const int U = (int)avail;
       if (!h->preValid) { int rc = launchSample(h, 0, nullptr, true, h->stream); if (rc) return rc; }
       HIPCK(hipGraphLaunch(it->second[p0].exec, h->stream));
-      if (h->tailEventMode) {
-        if (!h->tailEvent) HIPCK(hipEventCreateWithFlags(&h->tailEvent, hipEventDisableTiming));
-        HIPCK(hipEventRecord(h->tailEvent, h->stream));
-      }
       h->notifyIssued += 1; h->tailNotify = true;
       h->lastParity = (p0 + U - 1) & 1; h->preValid = true; h->preParity = (p0 + U) & 1;
       if (wired(h)) h->nCollectives += U;
