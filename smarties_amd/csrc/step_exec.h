@@ -521,7 +521,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     }
     int nRb = 0, lRb = -1;
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) { ++nRb; lRb = l; }
-    if (nRb == 1 && h->convDwBlocks > 0) {      // the two filter-gradient launches depend on the deltas only: one launch
+    if (nRb == 1 && h->convDwBlocks > 0 && !getenv("SMARTIES_HIP_CONV_DW_SPLIT")) {      // the two filter-gradient launches depend on the deltas only: one launch (the variable: two, for profiles)
       HIPCK(timed(h, "conv_dw_all", s, [&] { return launch_conv_dw_all(ca, lRb, h->convDwBlocks, s); }));
     } else {
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) HIPCK(timed(h, "conv_dw_rows", s, [&] { return launch_conv_dw_rows(ca, l, s); }));
