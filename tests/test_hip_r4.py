@@ -239,3 +239,22 @@ def test_large_local_batches_match_oracle(hip_api, B, hidden, dS, nEps):
     flat = np.sort(np.random.default_rng(1).choice(G.scalars().nStoredSteps, size=B, replace=False)).astype(np.int64)
     G.step(1, flat=flat); O.step(1, flat=flat)
     _compare_step(G, O)
+
+
+def test_large_batch_runs_are_deterministic(hip_api):
+    """The next step's sampler runs on a stream of its own beside this step's launches, partial weight gradients are joined in chunk
+    order: two runs must end bit-identical (weights, generator, beta, far-policy count)."""
+    sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=100, lenMax=200, pTerm=0.3)
+
+    def run():
+        L = capi.Learner(hip_api, capi.make_config(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=400000, randSeed=3))
+        L.init_weights(); fill_synth(L, sc, 400); L.initialize()
+        for n in (1, 7, 40):
+            L.step(n)
+        L.sync()
+        out = (L.get_params()[0].copy(), L.get_rng_state().copy(), L.scalars().beta, L.scalars().nFarPolicySteps)
+        L.close()
+        return out
+    a, b = run(), run()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert np.isfinite(a[0]).all()
