@@ -241,6 +241,24 @@ def test_large_local_batches_match_oracle(hip_api, B, hidden, dS, nEps):
     _compare_step(G, O)
 
 
+@pytest.mark.parametrize("extra", [dict(nAppendedObs=2), dict(adv_kind=capi.ADV_GAUSSIAN), dict(adv_kind=capi.ADV_DISCRETE, n_options=5, dimA=1, bounded=[0]),
+                                   dict(hidden=(128,), nnFunc="Relu", nnOutputFunc="Tanh")],
+                         ids=["appended-observations", "gaussian-advantage", "discrete-head", "one-layer-relu-tanh-out"])
+def test_large_local_batches_other_heads_and_inputs(hip_api, extra):
+    """The large-batch step (stack-gathered rows, tiled forward / dX / dW products, panel head) with stacked observations, both
+    RACER heads, a single hidden layer and an output activation: against the oracle."""
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=7, dimA=3, bounded=[1, 0, 0], hidden=(64, 64), nnFunc="Tanh", batchSize=2048, maxTotObsNum=200000, randSeed=13)
+    kw.update(extra)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=35, dimS=7, dimA=kw["dimA"], lenMin=20, lenMax=140, pTerm=0.5), 150)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(3); O.step(3)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+
+
 def test_large_batch_runs_are_deterministic(hip_api):
     """The next step's sampler runs on a stream of its own beside this step's launches, partial weight gradients are joined in chunk
     order: two runs must end bit-identical (weights, generator, beta, far-policy count)."""
