@@ -14,12 +14,15 @@ def bar():
     torch.cuda.synchronize(); L.sync()
 def timed(n):
     bar(); t0 = time.perf_counter(); L.step(n); bar(); return (time.perf_counter() - t0) / n * 1e6
-L.prepare_steps(20)
+if os.environ.get("NO_PREPARE") != "1":      # (NO_PREPARE=1 SMARTIES_HIP_EAGER_CHAIN=64: every call below is issued as direct launches)
+    L.prepare_steps(20)
 print("first launch of the 20-step executable          %.2f us/step" % timed(20))
 print("again                                           %.2f" % timed(20))
 for k in (1, 3, 5, 8):
     L.step(k); print("after a %d-step call                             %.2f" % (k, timed(20)))
 time.sleep(0.01); print("after 10 ms of idling                            %.2f" % timed(20))
 L.step(5); time.sleep(0.002); print("after a 5-step call and 2 ms                     %.2f" % timed(20))
-L.prepare_steps(5); L.step(5); print("after a 5-step call through ITS executable       %.2f" % timed(20))
+if os.environ.get("NO_PREPARE") != "1":
+    L.prepare_steps(5)
+L.step(5); print("after a 5-step call through ITS executable       %.2f" % timed(20))
 print("again                                           %.2f" % timed(20))
