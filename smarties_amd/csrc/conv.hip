@@ -180,6 +180,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   const int bb = (int)(rr / (unsigned)P), pp = (int)(rr - (unsigned)bb * (unsigned)P);
   const int oy = pp / g.OpX, ox = pp - oy * g.OpX;
   const float* inRow = g.in + (long long)bb * g.ldIn + (long long)oy * g.S * g.InX + ox * g.S;
+  // the biases of this lane's four outputs, requested now: behind the reduction's barrier they cost a round trip of their own
+  const float* Bl = a.W + g.indB;
+  float bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int ch = (ctBase + wave % CT) * 16 + lc * 4 + q; bq[q] = (ok && ch < g.KnC) ? Bl[(size_t)ch * P + pp] : 0.f; }
   for (int k = tid; k < Kp; k += 256) {
     int off = 0;
     if (k < K) { const int ic = k / (g.KnY * g.KnX), f = k - ic * g.KnY * g.KnX, fy = f / g.KnX, fx = f - fy * g.KnX;
@@ -232,12 +237,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
     }
   }
   if (!ok) return;
-  const float* Bl = a.W + g.indB;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int ch = (ctBase + ct) * 16 + lc * 4 + q;
     if (ch < g.KnC) {
-      const float x = (acc0[q] + acc1[q]) + Bl[(size_t)ch * P + pp];
+      const float x = (acc0[q] + acc1[q]) + bq[q];
       const size_t o = (size_t)bb * g.ldOut + (size_t)ch * P + pp;
       g.X[o] = x; g.Y[o] = softsignEval(x);
     }
@@ -313,6 +317,10 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
   const int iy = qq / g.InX, ix = qq - iy * g.InX;
   const float* dRow = g.D + (long long)bb * g.ldOut;
   const int fsz = g.KnY * g.KnX;
+  // pre-activations of this lane's four outputs (for act'), requested now rather than behind the reduction
+  float xq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int ic = (itBase + wave % IT) * 16 + lc * 4 + q; xq[q] = (ok && ic < g.InC) ? gp.X[(size_t)bb * gp.ldOut + (size_t)ic * Pin + qq] : 0.f; }
   for (int kk = tid; kk < KKp; kk += 256) {
     int v = -1;
     if (kk < KK) { const int c = kk / fsz, f = kk - c * fsz, fy = f / g.KnX, fx = f - fy * g.KnX; v = (c * P) | (fy << 20) | (fx << 26); }
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
     const int ic = (itBase + it) * 16 + lc * 4 + q;
     if (ic < g.InC) {
       const size_t o = (size_t)bb * gp.ldOut + (size_t)ic * Pin + qq;
-      gp.D[o] = (acc0[q] + acc1[q]) * softsignDiff(gp.X[o]);
+      gp.D[o] = (acc0[q] + acc1[q]) * softsignDiff(xq[q]);
     }
   }
 }
@@ -704,8 +712,11 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
     const int plc = ok ? pl : 0, oyl = plc / g.OpX, ox = plc - oyl * g.OpX;
     const float* pIn = sIn + oyl * g.S * g.InX + ox * g.S + lc;
     f32x4 acc[CT][2];
+    float bq[CT][4];      // the biases of this lane's outputs, requested in front of the tile's MFMA chain
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0]; }
+    for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = acc[ct][0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int ch = ct * 16 + lc * 4 + q; bq[ct][q] = (ok && ch < g.KnC) ? Bl[(size_t)ch * P + oy0 * g.OpX + pl] : 0.f; } }
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
       constexpr int dummy = 0; (void)dummy;
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
         for (int q = 0; q < 4; ++q) {
           const int ch = ct * 16 + lc * 4 + q;
           if (ch < g.KnC) {
-            const float x = (acc[ct][0][q] + acc[ct][1][q]) + Bl[(size_t)ch * P + pp];
+            const float x = (acc[ct][0][q] + acc[ct][1][q]) + bq[ct][q];
             const size_t o = (size_t)row * g.ldOut + (size_t)ch * P + pp;
             g.X[o] = x; g.Y[o] = softsignEval(x);
           }
