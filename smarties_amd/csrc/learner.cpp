@@ -641,8 +641,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (h->bigBatch && (cfg->nn_type != HL_NN_FFNN || cfg->n_conv > 0 || cfg->dataSamplingAlgo != HL_SAMPLE_UNIFORM))
     return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024: dense layers and the uniform sampler only");
   h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);
-  h->preproc = h->nApp > 0 || cfg->n_conv > 0 || h->bigBatch;       // the states are gathered by stack_gather_kernel (conv.hip)
-  if (!h->preproc && h->dS > 512) return fail(h, HL_ERR_UNSUPPORTED, "more than 512 observed state components");   // gather staging (tail_dev.h)
+  // the states are gathered by stack_gather_kernel (conv.hip): appended observations, convolutions, large batches -- and states
+  // wider than the 512 components the sampler's own gather stages (any width then; the fused steps are for narrower ones)
+  h->preproc = h->nApp > 0 || cfg->n_conv > 0 || h->bigBatch || (cfg->nn_type == HL_NN_FFNN && h->dS > 512);
+  if ((long long)h->dS * (1 + h->nApp) > (1 << 20)) return fail(h, HL_ERR_UNSUPPORTED, "more than 2^20 network inputs");
   for (int j = 0; j < h->cfg.n_hidden; ++j)      // (the merged list: encoder layers first)
     if (h->cfg.hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
   h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);

@@ -276,3 +276,19 @@ def test_large_batch_runs_are_deterministic(hip_api):
     a, b = run(), run()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
     assert np.isfinite(a[0]).all()
+
+
+def test_states_wider_than_512_components(hip_api):
+    """More observed state components than the sampler's own gather stages (512): the rows are assembled by the stacking kernel, the
+    first layer's long reduction by the chunked tiles -- 1500 components against the oracle, eager and replayed steps, rollout forward."""
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=1500, dimA=2, bounded=[1, 0], hidden=(48, 32), nnFunc="Tanh", batchSize=24, maxTotObsNum=3000, randSeed=4)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=9, dimS=1500, dimA=2, lenMin=3, lenMax=20, pTerm=0.5), 40)
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(21); O.step(21)
+    _compare_step(G, O)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    st = np.random.default_rng(0).normal(size=(5, 1500)).astype(np.float32)
+    assert relinf(G.forward(st), O.forward(st)) < TOL32
