@@ -107,8 +107,10 @@ def other_configs(api, steps=1000):
         "cfg4_mgu_2x32_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
                                            gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
         # the bench network at larger batches: where the step stops being a latency chain (fraction of the fp32 MFMA peak below)
-        "cfgNS_2x256_b1024": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=131072), 400, 200, max(100, steps // 2)),
-        # (a replay of 500 000 transitions: with one only five times the batch the sampler needs seven redraw rounds per minibatch)
+        # (replays of 500 000 transitions: the sampler redraws until the minibatch is unique (Sampling.cpp:86-93) -- at 80 000 stored
+        #  transitions a batch of 1024 needs several rounds (62 us per step, the sampler riding the step's kernels their longest
+        #  workgroup; 51 on this replay), at five times the batch seven)
+        "cfgNS_2x256_b1024": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=1048576), 2500, 200, max(100, steps // 2)),
         "cfgNS_2x256_b4096": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=1048576), 2500, 200, max(100, steps // 4)),
         "cfgNS_2x256_b16384": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=16384, maxTotObsNum=1048576), 2500, 200, max(50, steps // 10)),
         "cfg5_racer_atari_conv4_512_b128": (dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3, conv=conv, hidden=(512,),

@@ -37,7 +37,10 @@ namespace hl {
 // development time stamps of workgroup (panel 0, tile 1), 100 MHz clock: -DHL_FSTAMPS (its own flag: the tail stamps of
 // -DHL_TAIL_STAMPS use the same slots of DevScalars::dbgT)
 #if defined(HL_FSTAMPS)
-#define FSTAMP(i) do { if (threadIdx.x == 0 && panel == 0 && n == 1) a.sc->dbgT[i] = wall_clock64(); } while (0)
+#ifndef HL_FSTAMP_PANEL
+#define HL_FSTAMP_PANEL 0      // (another panel: a workgroup in the crowd of a larger batch)
+#endif
+#define FSTAMP(i) do { if (threadIdx.x == 0 && panel == HL_FSTAMP_PANEL && n == 1) a.sc->dbgT[i] = wall_clock64(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
 #endif

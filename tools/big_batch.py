@@ -9,7 +9,7 @@ from oracle_api import synth_cfg, fill_synth
 api = load_hip()
 sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=200, lenMax=200, pTerm=0.0)
 for B in [int(x) for x in (sys.argv[1:] or [256, 1024, 4096, 16384])]:
-    nEp = 400 if B <= 2048 else 2500            # (a replay only five times the batch costs the sampler seven redraw rounds per minibatch)
+    nEp = int(os.environ.get('NEP', 0)) or 400 if B <= 2048 else 2500            # (a replay only five times the batch costs the sampler seven redraw rounds per minibatch)
     L = capi.Learner(api, capi.make_config(dimS=17, dimA=6, hidden=(256, 256), batchSize=B, maxTotObsNum=1048576))
     L.init_weights(); fill_synth(L, sc, nEp); L.initialize()
     L.step(40); L.sync()

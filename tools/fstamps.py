@@ -4,7 +4,9 @@ import bench, numpy as np
 from smarties_amd import capi, load_hip
 api = load_hip()
 g = api.lib.hl_debug_stamps; g.restype = C.c_int; g.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-L = capi.Learner(api, capi.make_config(**bench.CFG)); L.init_weights()
+CFG = dict(bench.CFG)
+if len(sys.argv) > 1: CFG['batchSize'] = int(sys.argv[1])     # (with -DHL_FSTAMP_PANEL=p: a workgroup in the crowd)
+L = capi.Learner(api, capi.make_config(**CFG)); L.init_weights()
 for e in range(5000): L.append_episode(**bench.synthetic_episode(np, e))
 L.initialize()
 acc = []
