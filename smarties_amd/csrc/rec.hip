@@ -844,6 +844,12 @@ __global__ __launch_bounds__(256) void mgu_backward_kernel(RecArgs a) {
 // the tolerance these layers are tested to); the kernels above keep libm's.  Rows written for the weight-gradient launch
 // are the same as those of the kernels above.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// lanes 0..31 receive the value lane + 32 holds: one v_permlane32_swap (gfx950) instead of a trip through the LDS crossbar
+// (ds_bpermute).  What lanes 32..63 receive is not used by any caller.
+__device__ __forceinline__ float fromUpperHalf(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[1]);
+}
 __device__ __forceinline__ void pairBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float fastRcp(float d) { float r = __builtin_amdgcn_rcpf(d); return fmaf(fmaf(-d, r, 1.0f), r, r); }
 __device__ __forceinline__ float fastSigm(float in) {      // Sigm::_eval with safeExp cut at 8, one exponential for both branches
@@ -863,9 +869,15 @@ __device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (
   constexpr int NC = 32, NO = 128;
   f32x2 a0 = bias, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
   const f32x4* v4 = reinterpret_cast<const f32x4*>(vec);
+  // every operand read before the first FMA: left to itself the compiler reads two 16-byte pieces at a time into the same
+  // registers and waits for them (lgkmcnt(0)) in front of each batch of eight FMAs -- seven exposed LDS latencies per layer-step
+  f32x4 vq[NT / 4];
+#pragma unroll
+  for (int q = 0; q < NT / 4; ++q) vq[q] = v4[q];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < NT / 4; ++q) {
-    const f32x4 v = v4[q];
+    const f32x4 v = vq[q];
     a0 += w[4 * q] * f32x2{v[0], v[0]}; a1 += w[4 * q + 1] * f32x2{v[1], v[1]};
     a2 += w[4 * q + 2] * f32x2{v[2], v[2]}; a3 += w[4 * q + 3] * f32x2{v[3], v[3]};
   }
@@ -873,7 +885,7 @@ __device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (
   // lanes 0..31: acc = (cell input, forget gate); lanes 32..63: (input gate, output gate)
   const float g0 = lane < 32 ? acc[0] : fastSigm(acc[0]), g1 = fastSigm(acc[1]);
   if (store) { L.X[r * NO + lane] = g0; L.X[r * NO + lane + 64] = g1; }
-  const float ig = __shfl(g0, lane + 32, 64), og = __shfl(g1, lane + 32, 64);
+  const float ig = fromUpperHalf(g0), og = fromUpperHalf(g1);
   if (store) {         // the operand row: A operand of the weight-gradient contraction
     if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
     if (lane < NC) L.A[r * L.ldA + nInL + lane] = vec[inPad + lane];
@@ -899,6 +911,7 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
   __shared__ __attribute__((aligned(16))) float sV1[2][2 * NC];        // layer 1 operand [block-0 output of step k | h1_{k-1}]
   __shared__ float sStates[18 * 32];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  RSTAMP(0);
   const int layer = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform
   const bool acting = a.actStates != nullptr;                          // rollout inference: the agent's last states, nothing stored
   const int t = acting ? 0 : a.bt.t[b]; const long long slot = acting ? 0 : a.bt.slot[b];
@@ -931,11 +944,14 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
   }
   for (int i = tid; i < 2 * NTMAX; i += 128) (&sV0[0][0])[i] = 0.f;
   for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
+  RSTAMP(1);
   vmDrain(); pairBarrier();
+  RSTAMP(2);
   if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
   pairBarrier();
   float prevSt = 0.f;
   for (int it = 0; it <= nSteps; ++it) {
+    RSTAMP(4 + it);
     if (layer == 0) {
       const int k = it;
       if (k < nSteps) {
@@ -959,6 +975,7 @@ __global__ __launch_bounds__(128) void lstm32_forward_wave_kernel(RecArgs a) {
     }
     pairBarrier();
   }
+  RSTAMP(250);
 }
 
 template <int IN0>
@@ -1030,11 +1047,21 @@ __global__ __launch_bounds__(128) void lstm32_backward_wave_kernel(RecArgs a) {
         // e_i = sum_o W[i][o] delta[o] for this lane's row (Layer::backward, Layers.h:123-188)
         const f32x4* d4 = reinterpret_cast<const f32x4*>(sD[j]);
         f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f};
+        // (the reads of half the deltas before the first FMA of that half -- see lstm32LayerStep; all 32 pieces at once would
+        //  take the kernel past 256 VGPRs)
 #pragma unroll
-        for (int q = 0; q < NO / 4; q += 2) {
-          const f32x4 da = d4[q], db = d4[q + 1];
-          p0 += f32x2{wq[q][0], wq[q][1]} * f32x2{da[0], da[1]}; p1 += f32x2{wq[q][2], wq[q][3]} * f32x2{da[2], da[3]};
-          p2 += f32x2{wq[q + 1][0], wq[q + 1][1]} * f32x2{db[0], db[1]}; p3 += f32x2{wq[q + 1][2], wq[q + 1][3]} * f32x2{db[2], db[3]};
+        for (int h0 = 0; h0 < NO / 4; h0 += NO / 8) {
+          f32x4 dq[NO / 8];
+#pragma unroll
+          for (int q = 0; q < NO / 8; ++q) dq[q] = d4[h0 + q];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < NO / 8; q += 2) {
+            const f32x4 da = dq[q], db = dq[q + 1];
+            p0 += f32x2{wq[h0 + q][0], wq[h0 + q][1]} * f32x2{da[0], da[1]}; p1 += f32x2{wq[h0 + q][2], wq[h0 + q][3]} * f32x2{da[2], da[3]};
+            p2 += f32x2{wq[h0 + q + 1][0], wq[h0 + q + 1][1]} * f32x2{db[0], db[1]}; p3 += f32x2{wq[h0 + q + 1][2], wq[h0 + q + 1][3]} * f32x2{db[2], db[3]};
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         const f32x2 ps = (p0 + p1) + (p2 + p3);
         const float e = ps[0] + ps[1];
@@ -1056,8 +1083,12 @@ template <int IN>
 __device__ __forceinline__ float dotIn(const float (&w)[32], const float* vec) {
   const f32x4* v4 = reinterpret_cast<const f32x4*>(vec);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  f32x4 vq[IN / 4];      // (all reads before the first FMA: see lstm32LayerStep)
 #pragma unroll
-  for (int q = 0; q < IN / 4; ++q) { const f32x4 v = v4[q]; a0 += w[4 * q] * v[0]; a1 += w[4 * q + 1] * v[1]; a2 += w[4 * q + 2] * v[2]; a3 += w[4 * q + 3] * v[3]; }
+  for (int q = 0; q < IN / 4; ++q) vq[q] = v4[q];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < IN / 4; ++q) { const f32x4 v = vq[q]; a0 += w[4 * q] * v[0]; a1 += w[4 * q + 1] * v[1]; a2 += w[4 * q + 2] * v[2]; a3 += w[4 * q + 3] * v[3]; }
   return (a0 + a1) + (a2 + a3);
 }
 __device__ __forceinline__ void waveLdsSync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
@@ -1078,7 +1109,7 @@ __device__ __forceinline__ void mgu32LayerStep(const RecLayer& L, const float (&
     if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
     if (lane < NC) L.A[r * L.ldA + nInL + lane] = po;
   }
-  const float st = __shfl(sc, lane + 32, 64);
+  const float st = fromUpperHalf(sc);
   if (lane < NC) {
     const float out = f * st + (1.f - f) * po;                           // (po is 0 at the first step of the window)
     if (store) { L.Y[r * NO + lane] = out; L.A2[r * L.ldA2 + lane] = po * f; }
@@ -1213,7 +1244,7 @@ __global__ __launch_bounds__(128) void mgu32_backward_wave_kernel(RecArgs a) {
       waveLdsSync();
       const float viaS = dotIn<NC>(ws, sDS[j]);                                    // row i: sum_o W[i][nC + o] dLdS[o]
       // 2) dLdFprevOut of cell c = the recurrent row nIn + c
-      float fp = j == 1 ? __shfl(viaS, lane + 32, 64) : viaS;
+      float fp = j == 1 ? fromUpperHalf(viaS) : viaS;
       if (k == 0) fp = 0.f;
       if (lane < NC) {
         const float dF = ((sc - po) * dLdO + fp * po) * f * (1.f - f);             // 3) dLdF
@@ -1222,7 +1253,7 @@ __global__ __launch_bounds__(128) void mgu32_backward_wave_kernel(RecArgs a) {
       }
       waveLdsSync();
       const float viaF = dotIn<NC>(wf, sDF[j]);                                    // row i: sum_o W[i][o] dLdF[o]
-      const float g = j == 1 ? __shfl(viaF, lane + 32, 64) : viaF;
+      const float g = j == 1 ? fromUpperHalf(viaF) : viaF;
       if (lane < NC) {
         if (j == 1) sTop[k & 1][lane] = (res + viaF) + viaS;                       // error of block 0's output (+ the residual path)
         if (k > 0) sRec[j][lane] = ((1.f - f) * dLdO + f * fp) + g;                // 4) dLdprevOut
