@@ -12,9 +12,9 @@ namespace hl {
 
 // development time stamps of the first panel's workgroup (-DHL_HEAD_STAMPS), DevScalars::dbgT[0..] (tools/head_stamps.py panel)
 #ifdef HL_HEAD_STAMPS
-#define PSTAMP(i) do { if (m0 == 0 && threadIdx.x == 0) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
+#define HPSTAMP(i) do { if (m0 == 0 && threadIdx.x == 0) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
 #else
-#define PSTAMP(i) do { } while (0)
+#define HPSTAMP(i) do { } while (0)
 #endif
 constexpr int HP_NT = 512, HP_MAXNT = 5;
 struct HpGeo { int LDR, NTo, LD, LO; size_t oF, oWo, oRed, oO, oXo, oDelta, oMisc, oAct, oTq, total; };
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   const int m0 = ((int)blockIdx.x - nExtra) * 16;
   int nRows = B;
   if (m0 + 16 > B) { nRows = sc->nRows[ha.parity]; if (m0 >= nRows) return; }
-  PSTAMP(0);
+  HPSTAMP(0);
   float* sY = reinterpret_cast<float*>(smem);
   float* sF = reinterpret_cast<float*>(smem + g.oF);
   float* sWo = reinterpret_cast<float*>(smem + g.oWo);               // [H][ldWo]
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   for (int j = 0; j < NCH; ++j) { const int c = en + 16 * j; bpv[j] = (eth && c < nSig) ? W[ha.indBp + c] : 0.f; }
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
   const int func = __builtin_amdgcn_readfirstlane(ha.func);
-  PSTAMP(1);
+  HPSTAMP(1);
   // ---- stage the panel and f'(x) of the last hidden block ------------------------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
@@ -130,11 +130,11 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   }
   if (eth && en < 8) sMisc[em * 8 + en] = hr.misc;
   if (eth && en == 0) sAct[em] = hr.actMsg;
-  PSTAMP(2);
+  HPSTAMP(2);
   hr.hoist(ha, boundedMask, bpv, live, en);
-  PSTAMP(3);
+  HPSTAMP(3);
   __syncthreads();
-  PSTAMP(4);
+  HPSTAMP(4);
 
   // ---- output layer: O[16][nDense] = y W_out + b_out on MFMA, K split over the 8 waves ------------------------------------------------
   {
@@ -167,14 +167,14 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   }
   for (int i = tid; i < 16 * LD; i += NT) sDelta[i] = 0.f;
   __syncthreads();
-  PSTAMP(5);
+  HPSTAMP(5);
 
   // ---- head (head_rows.h): element threads, (sample em, component en + 16 j) -----------------------------------------------------
   if (eth) hr.compute(ha, sO + em * LO, sDelta + em * LD, sXo + em * LD, sMisc + em * 8, sTq + em * 64, sTr + em * 64, rowValid, isNext, true,
                       bSrc, slot, row, en, beta, Cmax, Cinv, sAct[em]);
-  PSTAMP(6);
+  HPSTAMP(6);
   __syncthreads();
-  PSTAMP(7);
+  HPSTAMP(7);
 
   // ---- delta_y = delta_out W_out^T for the whole panel by MFMA (wave w: column tiles w, w + 8, ...): gradient w.r.t. the last hidden
   // block's output, and times f'(x) the one w.r.t. its pre-activations (rows of sampled steps only) ----------------------------------
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
       if (rr < B) { const float dy = acc[r]; ha.Dres[(size_t)rr * ha.ldD + c] = dy; ha.D[(size_t)rr * ha.ldD + c] = dy * sF[i * LDR + c]; }
     }
   }
-  PSTAMP(8);
+  HPSTAMP(8);
 }
 
 template <int H> static hipError_t panelHeadLaunch(const HeadArgs& a, unsigned long long mask, int maxRows, const ExtraArgs& ex, hipStream_t s) {

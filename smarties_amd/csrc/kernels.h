@@ -89,6 +89,10 @@ struct WinRowsArgs { const DevScalars* sc; DevScalars* scW; const long long* slo
 hipError_t launch_window_rows(const WinRowsArgs& a, hipStream_t s);
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);
+// window forward + output layer + head + back-propagation through time of a sample as ONE launch (rec.hip: lstm32_step_wave_kernel)
+struct ExtraArgs;
+bool rec_step_fused_ok(const RecArgs& a, const HeadArgs& ha);
+hipError_t launch_rec_step_fused(const RecArgs& a, const HeadArgs& ha, const ExtraArgs* extra, hipStream_t s);
 
 // convolutional preprocessing (conv.hip): one layer's geometry and buffers
 struct ConvGeo {

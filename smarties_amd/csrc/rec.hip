@@ -10,7 +10,7 @@
 // (sample, step) row, the operands of the weight-gradient contractions -- inputs [in | previous output] and the four
 // gate deltas -- so that all weight gradients (and Adam) are formed by the same dW kernel as for dense layers, as
 // X^T delta over the rows; rows of unused steps carry zero deltas.
-#include "tail_dev.h"
+#include "head_rows.h"      // (tail_dev.h; the head of the one-launch step: lstm32_step_wave_kernel)
 
 namespace hl {
 
@@ -850,6 +850,7 @@ __device__ __forceinline__ float fromUpperHalf(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[1]);
 }
+__device__ __forceinline__ void waveLdsSync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void pairBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float fastRcp(float d) { float r = __builtin_amdgcn_rcpf(d); return fmaf(fmaf(-d, r, 1.0f), r, r); }
 __device__ __forceinline__ float fastSigm(float in) {      // Sigm::_eval with safeExp cut at 8, one exponential for both branches
@@ -863,9 +864,11 @@ __device__ __forceinline__ float fastTanh(float in) {      // Tanh::_eval (Funct
 
 // one layer-step: the two gates of this lane (NT terms each, operand broadcast from LDS), cell update on lanes 0..31, the
 // rows kept for the backward pass / the weight gradients
-template <int NT>
+// (LDSACT: gates, state and tanh(state) of the step go to `actRow` in LDS -- the one-launch step keeps them for its own backward pass)
+template <int NT, bool LDSACT = false>
 __device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (&w)[NT], f32x2 bias, const float* vec, int inPad, int nInL,
-                                                float& prevSt, float wr, float br, float* hNext, float& blkOut, bool store, long long r, int lane) {
+                                                float& prevSt, float wr, float br, float* hNext, float& blkOut, bool store, long long r, int lane,
+                                                float* actRow = nullptr) {
   constexpr int NC = 32, NO = 128;
   f32x2 a0 = bias, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
   const f32x4* v4 = reinterpret_cast<const f32x4*>(vec);
@@ -884,7 +887,7 @@ __device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (
   const f32x2 acc = (a0 + a1) + (a2 + a3);
   // lanes 0..31: acc = (cell input, forget gate); lanes 32..63: (input gate, output gate)
   const float g0 = lane < 32 ? acc[0] : fastSigm(acc[0]), g1 = fastSigm(acc[1]);
-  if (store) { L.X[r * NO + lane] = g0; L.X[r * NO + lane + 64] = g1; }
+  if (store) { if (LDSACT) { actRow[lane] = g0; actRow[lane + 64] = g1; } else { L.X[r * NO + lane] = g0; L.X[r * NO + lane + 64] = g1; } }
   const float ig = fromUpperHalf(g0), og = fromUpperHalf(g1);
   if (store) {         // the operand row: A operand of the weight-gradient contraction
     if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
@@ -895,7 +898,7 @@ __device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (
     const float co = fastTanh(st);
     const float out = og * co;
     prevSt = st;
-    if (store) { L.Y[r * NO + lane] = out; L.Y[r * NO + NC + lane] = st; L.Y[r * NO + 2 * NC + lane] = co; }
+    if (store) { if (LDSACT) { actRow[4 * NC + lane] = st; actRow[5 * NC + lane] = co; } else { L.Y[r * NO + lane] = out; L.Y[r * NO + NC + lane] = st; L.Y[r * NO + 2 * NC + lane] = co; } }
     float blk = out;                                   // ParametricResidualLayer::forward (Layers.h:347-361)
     if (L.hasRes && lane < L.resW) blk += vec[lane] * wr + br;
     hNext[lane] = out;
@@ -1074,6 +1077,229 @@ __global__ __launch_bounds__(128) void lstm32_backward_wave_kernel(RecArgs a) {
   }
 }
 
+// ---- the whole sample in ONE launch: window forward, output layer + RACER head, back-propagation through time ---------------------
+// A sample's chain -- forward over its window, the head of its sampled step (and of step t+1 of a truncated episode end), backward
+// over the window -- needs nothing from other samples, so the three launches of the recurrent step (lstm32_forward_wave_kernel,
+// the head kernel, lstm32_backward_wave_kernel) are one workgroup's work here: no two launch boundaries (2 x 2.8 us), the gates and
+// states of the window stay in LDS instead of going through memory (five of the forward pass's seven row stores per layer-step and
+// the backward pass's prologue of dependent loads), the head's replay rows are requested in the prologue and its output-independent
+// terms are formed while layer 0 runs its first step alone, the backward pass's weight rows arrive while the head runs.
+// Wavefront 0 = layer 0, wavefront 1 = layer 1 in the forward pass (one step apart), the head on wavefront 1 (16-lane rows of
+// head_rows.h: row 0 the sampled step, row 1 the next-state step), the top layer's backward on wavefront 0 as in the kernel above.
+// Same arithmetic as the three kernels except the output layer and delta_y = delta_out W_out^T, which are plain fp32 dot products in
+// index order here (MFMA contractions with K split over wavefronts there).  `extra`: a rider workgroup (launch of 256 threads).
+constexpr int LS_LD = 38, LS_LO = 49;        // head rows in LDS: up to 32 dense outputs, 48 outputs in all
+struct LsGeo { int oV0, oV1, oSt, oD, oTop, oRec, oY, oDres, oWo, oXo, oDelta, oMisc, oO, oActMsg, oTq, total; };
+template <int NTMAX> __host__ __device__ constexpr LsGeo lsGeo() {
+  LsGeo g{}; int o = 2 * 17 * 192 * 4;                    // sAct[2][17][192] first
+  g.oV0 = o; o += 2 * NTMAX * 4; g.oV1 = o; o += 2 * 64 * 4; g.oSt = o; o += 18 * 32 * 4; g.oD = o; o += 2 * 128 * 4;
+  g.oTop = o; o += 2 * 32 * 4; g.oRec = o; o += 2 * 32 * 4; g.oY = o; o += 2 * 32 * 4; g.oDres = o; o += 32 * 4;
+  g.oWo = o; o += 32 * 40 * 4; g.oXo = o; o += 2 * LS_LD * 4; g.oDelta = o; o += 2 * LS_LD * 4; g.oMisc = o; o += 2 * 8 * 4;
+  o = (o + 7) & ~7; g.oO = o; o += 2 * LS_LO * 8; g.oActMsg = o; o += 2 * 8; g.oTq = o; o += 2 * 2 * 64 * 8;
+  g.total = o > (int)TAIL_LDS_BYTES ? o : (int)TAIL_LDS_BYTES;
+  return g;
+}
+template <int IN0>
+__global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadArgs ha, unsigned long long boundedMask, ExtraArgs extra) {
+  constexpr int NC = 32, NO = 128, ACT = 6 * NC;
+  constexpr int NTMAX = (IN0 + NC) > 2 * NC ? (IN0 + NC) : 2 * NC;
+  constexpr LsGeo G = lsGeo<NTMAX>();
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G.total];
+  if (extra.role) { if (blockIdx.x == 0) { runExtra(extra, smem); return; } if (threadIdx.x >= 128) return; }
+  float* sAct = reinterpret_cast<float*>(smem);                                   // [2][17][ACT]: per (layer, step) [cell input | I | F | O | state | tanh(state)]
+  float (*sV0)[NTMAX] = reinterpret_cast<float (*)[NTMAX]>(smem + G.oV0);
+  float (*sV1)[2 * NC] = reinterpret_cast<float (*)[2 * NC]>(smem + G.oV1);
+  float* sStates = reinterpret_cast<float*>(smem + G.oSt);
+  float (*sD)[NO] = reinterpret_cast<float (*)[NO]>(smem + G.oD);
+  float (*sTop)[NC] = reinterpret_cast<float (*)[NC]>(smem + G.oTop);
+  float (*sRec)[NC] = reinterpret_cast<float (*)[NC]>(smem + G.oRec);
+  float (*sYo)[NC] = reinterpret_cast<float (*)[NC]>(smem + G.oY);                // last block's output: [0] sampled step, [1] step t + 1
+  float* sDres = reinterpret_cast<float*>(smem + G.oDres);
+  float* sWo = reinterpret_cast<float*>(smem + G.oWo);                            // W_out [32][ldWo]
+  float (*sXo)[LS_LD] = reinterpret_cast<float (*)[LS_LD]>(smem + G.oXo);
+  float (*sDelta)[LS_LD] = reinterpret_cast<float (*)[LS_LD]>(smem + G.oDelta);
+  float (*sMisc)[8] = reinterpret_cast<float (*)[8]>(smem + G.oMisc);
+  double (*sO)[LS_LO] = reinterpret_cast<double (*)[LS_LO]>(smem + G.oO);
+  double* sActMsg = reinterpret_cast<double*>(smem + G.oActMsg);
+  double* sTq = reinterpret_cast<double*>(smem + G.oTq); double* sTr = sTq + 2 * 64;
+
+  const int b = blockIdx.x - (extra.role ? 1 : 0), tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
+  const int T = min(a.nBPTT, t);
+  const int nextRow = a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  const int nIn = a.L[0].nIn, dS = a.dS;
+  const int nDense = ha.nDense, ldWo = ha.ldWo;
+  // head rows of this sample on wavefront 1: 16-lane row 0 = the sampled step, row 1 = step t + 1 of a truncated episode end
+  const int em = (lane >> 4) & 1, en = lane & 15;
+  const bool headLane = wv == 1 && lane < 32;
+  const bool rowValid = headLane && (em == 0 || nextRow >= 0), isNext = rowValid && em == 1, live = rowValid && !isNext;
+  HeadRow<1> hr;
+  hr.load(ha, rowValid, isNext, slot, en);
+  float bpv[1] = {0.f}, bov0 = 0.f, bov1 = 0.f;
+  if (headLane) {
+    if (en < ha.nSig) bpv[0] = ha.params[ha.indBp + en];
+    if (en < nDense) bov0 = ha.params[ha.indBo + en];
+    if (en + 16 < nDense) bov1 = ha.params[ha.indBo + en + 16];
+  }
+  const double beta = a.sc->beta, Cmax = a.sc->Cmax, Cinv = a.sc->Cinv;
+  {
+    // ================================================ forward over the window ==================================================
+    const int layer = wv;
+    const RecLayer L = a.L[layer];
+    f32x2 w[NTMAX];
+    {
+      const float* Wl = W + L.indW;
+#pragma unroll
+      for (int i = 0; i < NTMAX; ++i) {
+        int row;
+        if (layer == 0) row = i < IN0 ? (i < nIn ? i : -1) : (i < IN0 + NC ? nIn + (i - IN0) : -1);
+        else row = i < 2 * NC ? i : -1;
+        w[i] = row >= 0 ? f32x2{Wl[(size_t)row * NO + lane], Wl[(size_t)row * NO + lane + 64]} : f32x2{0.f, 0.f};
+      }
+    }
+    const f32x2 bias = {W[L.indB + lane], W[L.indB + lane + 64]};
+    const int c = lane & 31;
+    float wr = 0.f, br = 0.f;
+    if (L.hasRes && c < L.resW) { wr = W[L.indWr + c]; br = W[L.indBr + c]; }
+    for (int e = tid; e < nSteps * dS; e += 128) {
+      const int kk = e / dS, i = e - kk * dS;
+      sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
+    }
+    for (int e = tid; e < NC * ldWo; e += 128) sWo[e] = ha.params[ha.indWo + e];
+    for (int i = tid; i < 2 * NTMAX; i += 128) (&sV0[0][0])[i] = 0.f;
+    for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
+    if (headLane) { if (en < 8) sMisc[em][en] = hr.misc; if (en == 0) sActMsg[em] = hr.actMsg; }
+    vmDrain(); pairBarrier();
+    if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
+    pairBarrier();
+    float prevSt = 0.f;
+    for (int it = 0; it <= nSteps; ++it) {
+      if (layer == 0) {
+        const int k = it;
+        if (k < nSteps) {
+          const int cb = k & 1;
+          if (k + 1 < nSteps && lane < dS) sV0[cb ^ 1][lane] = sStates[(k + 1) * dS + lane];
+          float blk = 0.f;
+          lstm32LayerStep<NTMAX, true>(L, w, bias, sV0[cb], IN0, nIn, prevSt, wr, br, &sV0[cb ^ 1][IN0], blk, k <= T, (long long)b * a.K + k, lane,
+                                       sAct + (0 * 17 + (k <= T ? k : 0)) * ACT);
+          if (lane < NC) sV1[cb][lane] = blk;
+        }
+      } else {
+        const int k = it - 1;
+        if (k < 0) hr.hoist(ha, boundedMask, bpv, live, en);       // (this wavefront has no layer-step yet)
+        else {
+          const int cb = k & 1;
+          float blk = 0.f;
+          lstm32LayerStep<NTMAX, true>(L, w, bias, sV1[cb], NC, NC, prevSt, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane,
+                                       sAct + (1 * 17 + (k <= T ? k : 0)) * ACT);
+          if (lane < NC) {
+            if (k == T) { a.Yout[(size_t)b * a.ldY + lane] = blk; sYo[0][lane] = blk; }       // (memory: A operand of the output layer's weight gradient)
+            if (k == T + 1) sYo[1][lane] = blk;
+          }
+        }
+      }
+      pairBarrier();
+    }
+  }
+  // ======================================================= backward: weight rows requested now ==================================
+  const int j = 1 - wv;                                    // wavefront 0 = the top layer (one step ahead), wavefront 1 = layer 0
+  const RecLayer L = a.L[j];
+  f32x4 wq[NO / 4];
+  {
+    const f32x4* rw = reinterpret_cast<const f32x4*>(W + L.indW + (size_t)(j == 1 ? lane : nIn + (lane & 31)) * NO);
+#pragma unroll
+    for (int q = 0; q < NO / 4; ++q) wq[q] = rw[q];
+  }
+  const float wrB = (L.hasRes && lane < L.resW) ? W[L.indWr + lane] : 0.f;
+  for (int k = T + 1; k < a.K; ++k) {      // rows of the steps this sample does not have: zero deltas
+    const long long r = (long long)b * a.K + k;
+    L.D[r * NO + lane] = 0.f; L.D[r * NO + lane + 64] = 0.f;
+    if (L.hasRes && lane < NC) L.Rd[r * L.ldR + lane] = 0.f;
+  }
+  // ======================================================= output layer + head (wavefront 1) ====================================
+  if (wv == 1) {
+    const int emc = em;
+    if (lane < 32) {      // O[row][o] = y W_out + b_out, o = en and en + 16 (BaseLayer::forward of the output layer)
+      float x0 = 0.f, x1 = 0.f;
+      const float* y = sYo[emc];
+      const int o0 = en < ldWo ? en : ldWo - 1, o1 = en + 16 < ldWo ? en + 16 : ldWo - 1;
+#pragma unroll 8
+      for (int cc = 0; cc < NC; ++cc) { const float yv = y[cc]; x0 = fmaf(yv, sWo[cc * ldWo + o0], x0); x1 = fmaf(yv, sWo[cc * ldWo + o1], x1); }
+      x0 += bov0; x1 += bov1;
+      if (en < nDense) { sXo[emc][en] = x0; sO[emc][en] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x0 : actEval(ha.outFunc, x0)); }
+      if (en + 16 < nDense) { sXo[emc][en + 16] = x1; sO[emc][en + 16] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x1 : actEval(ha.outFunc, x1)); }
+      if (en < ha.nSig) sO[emc][nDense + en] = (double)bpv[0];      // ParamLayer, Linear
+      for (int o = en; o < LS_LD; o += 16) sDelta[emc][o] = 0.f;
+    }
+    waveLdsSync();
+    hr.compute(ha, sO[emc], sDelta[emc], sXo[emc], sMisc[emc], sTq + emc * 64, sTr + emc * 64, rowValid, isNext, true,
+               b, slot, em ? nextRow : b, en, beta, Cmax, Cinv, sActMsg[emc]);
+    waveLdsSync();
+    if (lane < NC) {      // delta_y = delta_out W_out^T: error w.r.t. the last block's output at the sampled step
+      float e = 0.f;
+      for (int o = 0; o < nDense; ++o) e = fmaf(sDelta[0][o], sWo[lane * ldWo + o], e);
+      sDres[lane] = e;
+    }
+  }
+  vmDrain(); pairBarrier();
+  // ======================================================= back-propagation through time ========================================
+  {
+    const float dres = (j == 1 && lane < NC) ? sDres[lane] : 0.f;
+    float nxtSt = 0.f, nxtF = 0.f;
+    for (int it = 0; it <= T + 1; ++it) {
+      const int k = T - it + (j == 1 ? 0 : 1);
+      if (k >= 0 && k <= T) {
+        const long long r = (long long)b * a.K + k;
+        float res = 0.f;
+        if (lane < NC) {
+          const float eTop = j == 1 ? (k == T ? dres : 0.f) : sTop[k & 1][lane];
+          const float* act = sAct + (j * 17 + k) * ACT;
+          if (L.hasRes) { L.Rd[r * L.ldR + lane] = eTop; res = lane < L.resW ? eTop * wrB : 0.f; }
+          const float D = eTop + (k < T ? sRec[j][lane] : 0.f);
+          const float cellInpt = act[lane], IG = act[NC + lane], FG = act[2 * NC + lane], OG = act[3 * NC + lane], co = act[5 * NC + lane];
+          const float prevSt = k > 0 ? (act - ACT)[4 * NC + lane] : 0.f;
+          const float diff = (1.f - co * co) * D;
+          const float sd = diff * OG + (k < T ? nxtSt * nxtF : 0.f);
+          const float d0 = IG * sd;
+          const float d1 = IG * (1.f - IG) * cellInpt * sd;
+          const float d2 = k > 0 ? FG * (1.f - FG) * prevSt * sd : 0.f;
+          const float d3 = OG * (1.f - OG) * D * co;
+          sD[j][lane] = d0; sD[j][NC + lane] = d1; sD[j][2 * NC + lane] = d2; sD[j][3 * NC + lane] = d3;
+          L.D[r * NO + lane] = d0; L.D[r * NO + NC + lane] = d1; L.D[r * NO + 2 * NC + lane] = d2; L.D[r * NO + 3 * NC + lane] = d3;
+          nxtSt = sd; nxtF = FG;
+        }
+        waveLdsSync();
+        if (j == 1 || k > 0) {
+          const f32x4* d4 = reinterpret_cast<const f32x4*>(sD[j]);
+          f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f};
+#pragma unroll
+          for (int h0 = 0; h0 < NO / 4; h0 += NO / 8) {
+            f32x4 dq[NO / 8];
+#pragma unroll
+            for (int q = 0; q < NO / 8; ++q) dq[q] = d4[h0 + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NO / 8; q += 2) {
+              const f32x4 da = dq[q], db = dq[q + 1];
+              p0 += f32x2{wq[h0 + q][0], wq[h0 + q][1]} * f32x2{da[0], da[1]}; p1 += f32x2{wq[h0 + q][2], wq[h0 + q][3]} * f32x2{da[2], da[3]};
+              p2 += f32x2{wq[h0 + q + 1][0], wq[h0 + q + 1][1]} * f32x2{db[0], db[1]}; p3 += f32x2{wq[h0 + q + 1][2], wq[h0 + q + 1][3]} * f32x2{db[2], db[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const f32x2 ps = (p0 + p1) + (p2 + p3);
+          const float e = ps[0] + ps[1];
+          if (j == 1) { if (lane < NC) sTop[k & 1][lane] = res + e; else sRec[1][lane - NC] = e; }
+          else if (lane < NC) sRec[0][lane] = e;
+        }
+      }
+      pairBarrier();
+    }
+  }
+}
+
 // ---- MGU, two layers of 32 cells: the same arrangement ---------------------------------------------------------------------
 // A layer-step has 64 gate columns -- forget gates on lanes 0..31, candidate states on lanes 32..63 (MGULayer::forward,
 // Layer_GRU.h:64-124) -- and two dependent halves: the candidate's recurrent operand is prevOut * forget.  Lane o keeps column o
@@ -1091,7 +1317,6 @@ __device__ __forceinline__ float dotIn(const float (&w)[32], const float* vec) {
   for (int q = 0; q < IN / 4; ++q) { const f32x4 v = vq[q]; a0 += w[4 * q] * v[0]; a1 += w[4 * q + 1] * v[1]; a2 += w[4 * q + 2] * v[2]; a3 += w[4 * q + 3] * v[3]; }
   return (a0 + a1) + (a2 + a3);
 }
-__device__ __forceinline__ void waveLdsSync() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
 
 template <int IN>      // IN: operand length of the input part as the unrolled loop walks it (zero weights behind the layer's own inputs)
 __device__ __forceinline__ void mgu32LayerStep(const RecLayer& L, const float (&win)[32], const float (&wrec)[32], float bias, const float* vec,
@@ -1534,6 +1759,25 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
     return recLaunch(lstm_forward_lds_kernel<0, 0>, a, fl * sizeof(float), &attr[2], s);
   }
   return recLaunch(rec_forward_kernel<false>, a, 0, &attr[3], s);
+}
+// the one-launch step (lstm32_step_wave_kernel): the shapes of the wave-per-(sample, layer) LSTM kernels with a head of up to 32
+// dense outputs and 16 action components / options
+bool rec_step_fused_ok(const RecArgs& a, const HeadArgs& ha) {
+  const int comps = ha.nOpt ? ha.nOpt : ha.dA;
+  return !recGeneral(a) && lstm32Wave(a) && a.actStates == nullptr && a.YoutRows == nullptr && a.DresRows == nullptr && a.K <= 17 &&
+         ha.H == 32 && ha.nDense <= 32 && ha.nOut <= 48 && comps <= 16 && ha.ldWo <= 40;
+}
+hipError_t launch_rec_step_fused(const RecArgs& a, const HeadArgs& ha, const ExtraArgs* extra, hipStream_t s) {
+  if (!rec_step_fused_ok(a, ha)) return hipErrorInvalidValue;
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  unsigned long long mask = 0; for (int c = 0; c < HL_MAX_DIMA && c < 64; ++c) if (ha.bounded[c]) mask |= 1ull << c;
+  const dim3 grid(a.B + (ex.role ? 1 : 0)), block(ex.role ? 256 : 128);
+  const int in0 = (a.L[0].nIn + 3) & ~3;
+  if (in0 <= 4) hipLaunchKernelGGL(lstm32_step_wave_kernel<4>, grid, block, 0, s, a, ha, mask, ex);
+  else if (in0 <= 8) hipLaunchKernelGGL(lstm32_step_wave_kernel<8>, grid, block, 0, s, a, ha, mask, ex);
+  else if (in0 <= 16) hipLaunchKernelGGL(lstm32_step_wave_kernel<16>, grid, block, 0, s, a, ha, mask, ex);
+  else hipLaunchKernelGGL(lstm32_step_wave_kernel<32>, grid, block, 0, s, a, ha, mask, ex);
+  return hipGetLastError();
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 100 * 1024; const bool general = recGeneral(a);

@@ -723,6 +723,13 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
       return launchBackward(h, parity, fuseAdam, s);
     }
     const RecArgs ra = recArgs(h, parity);
+    if (h->recFused && h->nConv == 0) {      // forward, head and backward of a sample as one workgroup's work
+      const HeadArgs ha = headArgs(h, parity);
+      if (rec_step_fused_ok(ra, ha)) {
+        HIPCK(timed(h, "rec_step_fused", s, [&] { return launch_rec_step_fused(ra, ha, nullptr, s); }));
+        return launchBackward(h, parity, fuseAdam, s);
+      }
+    }
     HIPCK(timed(h, "rec_forward", s, [&] { return launch_rec_forward(ra, s); }));
     int rc = launchHead(h, parity, s); if (rc) return rc;
     HIPCK(timed(h, "rec_backward", s, [&] { return launch_rec_backward(ra, s); }));
@@ -837,9 +844,16 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
     const bool exch = exchanging(h);
     if (h->recurrent) {      // window forward, head (+ the sampler of the next step), BPTT, weight gradients (+ bookkeeping)
       const RecArgs ra = recArgs(h, p);
-      if (launch_rec_forward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_forward"); break; }
-      rc = launchHead(h, p, s0, true); if (rc) break;
-      if (launch_rec_backward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_backward"); break; }
+      const HeadArgs ha = headArgs(h, p);
+      if (h->recFused && rec_step_fused_ok(ra, ha)) {
+        // one launch per sample chain; the draws and sort of the next minibatch ride it (they rode the head launch)
+        const ExtraArgs exS = extraSample(h, p ^ 1, PH_A | PH_B);
+        if (launch_rec_step_fused(ra, ha, &exS, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_step_fused"); break; }
+      } else {
+        if (launch_rec_forward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_forward"); break; }
+        rc = launchHead(h, p, s0, true); if (rc) break;
+        if (launch_rec_backward(ra, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "rec_backward"); break; }
+      }
     } else {
       rc = launchForward(h, p, s0, true); if (rc) break;
       rc = launchHead(h, p, s0, true); if (rc) break;
