@@ -292,3 +292,41 @@ def test_states_wider_than_512_components(hip_api):
     assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
     st = np.random.default_rng(0).normal(size=(5, 1500)).astype(np.float32)
     assert relinf(G.forward(st), O.forward(st)) < TOL32
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_one_launch_lstm_step_random_shapes_match_oracle(hip_api, seed, monkeypatch):
+    """Two LSTM layers of 32 cells run a sample's window forward, its head and its back-propagation through time as ONE launch
+    (rec.hip: lstm32_step_wave_kernel).  Shapes of its envelope drawn at random -- 1..32 observed states, 1..7 action components
+    with mixed bounds or 2..16 options, every advantage kind, windows of 1..16 steps, episodes that end truncated (next-state rows)
+    or terminated -- against the oracle, eager and replayed (the sampler's rider); the three-launch form (SMARTIES_HIP_REC_FUSED=0)
+    must give the same minibatches and the same weights to rounding."""
+    rng = np.random.default_rng(7100 + seed)
+    dS = int(rng.integers(1, 33))
+    kind = int(rng.integers(3))
+    if kind == 2:
+        dA, head = 1, dict(adv_kind=capi.ADV_DISCRETE, n_options=int(rng.integers(2, 17)), bounded=[0])
+    else:
+        dA = int(rng.integers(1, 8))
+        head = dict(adv_kind=capi.ADV_GAUSSIAN if kind == 1 else capi.ADV_ZERO, bounded=[int(x) for x in rng.integers(0, 2, dA)])
+    kw = dict(dimS=dS, dimA=dA, hidden=(32, 32), nnFunc="Tanh", batchSize=int(rng.integers(1, 140)), maxTotObsNum=8000,
+              randSeed=int(rng.integers(1, 1000)), nn_type=capi.NN_LSTM, nnBPTTseq=int(rng.integers(1, 17)),
+              clipImpWeight=float(rng.choice([0.7, 2.0, 4.0])), **head)
+    sc = synth_cfg(seed=int(rng.integers(1, 1000)), dimS=dS, dimA=dA, lenMin=2, lenMax=int(rng.integers(3, 40)),
+                   pTerm=float(rng.choice([0.0, 0.5, 1.0])))
+    G, O = _pair(hip_api, kw, sc, 100)
+    for _ in range(3):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(9); O.step(9)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    monkeypatch.setenv("SMARTIES_HIP_REC_FUSED", "0")
+    T = capi.Learner(hip_api, capi.make_config(**kw))
+    T.init_weights(); fill_synth(T, sc, 100); T.initialize(); T.set_tap(True)
+    T.step(1); T.step(1); T.step(1); T.step(9)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), T.readback(capi.TAP_FLAT))
+    assert np.array_equal(G.get_rng_state(), T.get_rng_state())
+    assert relinf(G.get_params()[0], T.get_params()[0]) < TOL32
+    assert G.scalars().nFarPolicySteps == T.scalars().nFarPolicySteps
