@@ -889,10 +889,8 @@ __device__ __forceinline__ void lstm32LayerStep(const RecLayer& L, const f32x2 (
   const float g0 = lane < 32 ? acc[0] : fastSigm(acc[0]), g1 = fastSigm(acc[1]);
   if (store) { if (LDSACT) { actRow[lane] = g0; actRow[lane + 64] = g1; } else { L.X[r * NO + lane] = g0; L.X[r * NO + lane + 64] = g1; } }
   const float ig = fromUpperHalf(g0), og = fromUpperHalf(g1);
-  if (store) {         // the operand row: A operand of the weight-gradient contraction
-    if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
-    if (lane < NC) L.A[r * L.ldA + nInL + lane] = vec[inPad + lane];
-  }
+  if (store && lane < nInL + NC)          // the operand row [input | previous output]: A operand of the weight-gradient contraction (one store)
+    L.A[r * L.ldA + lane] = vec[lane < nInL ? lane : inPad + (lane - nInL)];
   if (lane < NC) {
     const float st = g0 * ig + prevSt * g1;            // (prevSt is 0 at the first step of the window)
     const float co = fastTanh(st);
@@ -1089,39 +1087,87 @@ __global__ __launch_bounds__(128) void lstm32_backward_wave_kernel(RecArgs a) {
 // Same arithmetic as the three kernels except the output layer and delta_y = delta_out W_out^T, which are plain fp32 dot products in
 // index order here (MFMA contractions with K split over wavefronts there).  `extra`: a rider workgroup (launch of 256 threads).
 constexpr int LS_LD = 38, LS_LO = 49;        // head rows in LDS: up to 32 dense outputs, 48 outputs in all
-struct LsGeo { int oV0, oV1, oSt, oD, oTop, oRec, oY, oDres, oWo, oXo, oDelta, oMisc, oO, oActMsg, oTq, total; };
-template <int NTMAX> __host__ __device__ constexpr LsGeo lsGeo() {
-  LsGeo g{}; int o = 2 * 17 * 192 * 4;                    // sAct[2][17][192] first
-  g.oV0 = o; o += 2 * NTMAX * 4; g.oV1 = o; o += 2 * 64 * 4; g.oSt = o; o += 18 * 32 * 4; g.oD = o; o += 2 * 128 * 4;
-  g.oTop = o; o += 2 * 32 * 4; g.oRec = o; o += 2 * 32 * 4; g.oY = o; o += 2 * 32 * 4; g.oDres = o; o += 32 * 4;
-  g.oWo = o; o += 32 * 40 * 4; g.oXo = o; o += 2 * LS_LD * 4; g.oDelta = o; o += 2 * LS_LD * 4; g.oMisc = o; o += 2 * 8 * 4;
-  o = (o + 7) & ~7; g.oO = o; o += 2 * LS_LO * 8; g.oActMsg = o; o += 2 * 8; g.oTq = o; o += 2 * 2 * 64 * 8;
-  g.total = o > (int)TAIL_LDS_BYTES ? o : (int)TAIL_LDS_BYTES;
-  return g;
+// LDS of the head phase, shared by the LSTM and the MGU form: the last block's outputs ([0] sampled step, [1] step t + 1), the error
+// w.r.t. them, W_out [32][ldWo <= 40], and the rows HeadRow::compute works on
+struct StepHeadLds {
+  float (*sYo)[32]; float* sDres; float* sWo; float (*sXo)[LS_LD]; float (*sDelta)[LS_LD]; float (*sMisc)[8];
+  double (*sO)[LS_LO]; double* sActMsg; double* sTq; double* sTr;
+};
+constexpr int STEP_HEAD_LDS = 2 * 32 * 4 + 32 * 4 + 32 * 40 * 4 + 2 * LS_LD * 4 * 2 + 2 * 8 * 4 + 2 * LS_LO * 8 + 2 * 8 + 2 * 2 * 64 * 8;
+static_assert(STEP_HEAD_LDS % 8 == 0, "the double rows are 8-byte aligned");
+__device__ __forceinline__ StepHeadLds stepHeadLds(unsigned char* p) {      // p: 8-byte aligned
+  StepHeadLds S;
+  S.sO = reinterpret_cast<double (*)[LS_LO]>(p); p += 2 * LS_LO * 8;
+  S.sActMsg = reinterpret_cast<double*>(p); p += 2 * 8;
+  S.sTq = reinterpret_cast<double*>(p); S.sTr = S.sTq + 2 * 64; p += 2 * 2 * 64 * 8;
+  S.sYo = reinterpret_cast<float (*)[32]>(p); p += 2 * 32 * 4;
+  S.sDres = reinterpret_cast<float*>(p); p += 32 * 4;
+  S.sWo = reinterpret_cast<float*>(p); p += 32 * 40 * 4;
+  S.sXo = reinterpret_cast<float (*)[LS_LD]>(p); p += 2 * LS_LD * 4;
+  S.sDelta = reinterpret_cast<float (*)[LS_LD]>(p); p += 2 * LS_LD * 4;
+  S.sMisc = reinterpret_cast<float (*)[8]>(p);
+  return S;
 }
+// what the head lanes (wavefront 1, lanes 0..31: 16-lane row `em` = 0 the sampled step, 1 = step t + 1 of a truncated episode end)
+// fetch in the kernel's prologue
+struct StepHeadRegs { HeadRow<1> hr; float bpv[1]; float bov0, bov1; double beta, Cmax, Cinv; bool rowValid, isNext, live; int em, en; };
+__device__ __forceinline__ void stepHeadLoad(StepHeadRegs& R, const HeadArgs& ha, const DevScalars* sc, int wv, int lane, long long slot, int nextRow) {
+  R.em = (lane >> 4) & 1; R.en = lane & 15;
+  const bool headLane = wv == 1 && lane < 32;
+  R.rowValid = headLane && (R.em == 0 || nextRow >= 0); R.isNext = R.rowValid && R.em == 1; R.live = R.rowValid && !R.isNext;
+  R.hr.load(ha, R.rowValid, R.isNext, slot, R.en);
+  R.bpv[0] = 0.f; R.bov0 = 0.f; R.bov1 = 0.f;
+  if (headLane) {
+    if (R.en < ha.nSig) R.bpv[0] = ha.params[ha.indBp + R.en];
+    if (R.en < ha.nDense) R.bov0 = ha.params[ha.indBo + R.en];
+    if (R.en + 16 < ha.nDense) R.bov1 = ha.params[ha.indBo + R.en + 16];
+  }
+  R.beta = sc->beta; R.Cmax = sc->Cmax; R.Cinv = sc->Cinv;
+}
+// output layer + head of the sample's rows and the error w.r.t. the last block's output (S.sDres); all of wavefront 1
+__device__ __forceinline__ void stepHeadRun(StepHeadRegs& R, const HeadArgs& ha, const StepHeadLds& S, int lane, int b, long long slot, int nextRow) {
+  constexpr int NC = 32;
+  const int em = R.em, en = R.en, nDense = ha.nDense, ldWo = ha.ldWo;
+  if (lane < 32) {      // O[row][o] = y W_out + b_out, o = en and en + 16 (BaseLayer::forward of the output layer)
+    float x0 = 0.f, x1 = 0.f;
+    const float* y = S.sYo[em];
+    const int o0 = en < ldWo ? en : ldWo - 1, o1 = en + 16 < ldWo ? en + 16 : ldWo - 1;
+#pragma unroll 8
+    for (int cc = 0; cc < NC; ++cc) { const float yv = y[cc]; x0 = fmaf(yv, S.sWo[cc * ldWo + o0], x0); x1 = fmaf(yv, S.sWo[cc * ldWo + o1], x1); }
+    x0 += R.bov0; x1 += R.bov1;
+    if (en < nDense) { S.sXo[em][en] = x0; S.sO[em][en] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x0 : actEval(ha.outFunc, x0)); }
+    if (en + 16 < nDense) { S.sXo[em][en + 16] = x1; S.sO[em][en + 16] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x1 : actEval(ha.outFunc, x1)); }
+    if (en < ha.nSig) S.sO[em][nDense + en] = (double)R.bpv[0];      // ParamLayer, Linear
+    for (int o = en; o < LS_LD; o += 16) S.sDelta[em][o] = 0.f;
+  }
+  waveLdsSync();
+  R.hr.compute(ha, S.sO[em], S.sDelta[em], S.sXo[em], S.sMisc[em], S.sTq + em * 64, S.sTr + em * 64, R.rowValid, R.isNext, true,
+               b, slot, em ? nextRow : b, en, R.beta, R.Cmax, R.Cinv, S.sActMsg[em]);
+  waveLdsSync();
+  if (lane < NC) {      // delta_y = delta_out W_out^T: error w.r.t. the last block's output at the sampled step
+    float e = 0.f;
+    for (int o = 0; o < nDense; ++o) e = fmaf(S.sDelta[0][o], S.sWo[lane * ldWo + o], e);
+    S.sDres[lane] = e;
+  }
+}
+
 template <int IN0>
 __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadArgs ha, unsigned long long boundedMask, ExtraArgs extra) {
   constexpr int NC = 32, NO = 128, ACT = 6 * NC;
   constexpr int NTMAX = (IN0 + NC) > 2 * NC ? (IN0 + NC) : 2 * NC;
-  constexpr LsGeo G = lsGeo<NTMAX>();
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G.total];
+  constexpr int O_V0 = 2 * 17 * ACT * 4, O_V1 = O_V0 + 2 * NTMAX * 4, O_ST = O_V1 + 2 * 64 * 4, O_D = O_ST + 18 * 32 * 4, O_TOP = O_D + 2 * NO * 4,
+                O_REC = O_TOP + 2 * NC * 4, O_HEAD = O_REC + 2 * NC * 4, TOTAL = O_HEAD + STEP_HEAD_LDS;
+  static_assert(O_HEAD % 16 == 0, "alignment of the head rows");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TOTAL > (int)TAIL_LDS_BYTES ? TOTAL : (int)TAIL_LDS_BYTES];
   if (extra.role) { if (blockIdx.x == 0) { runExtra(extra, smem); return; } if (threadIdx.x >= 128) return; }
   float* sAct = reinterpret_cast<float*>(smem);                                   // [2][17][ACT]: per (layer, step) [cell input | I | F | O | state | tanh(state)]
-  float (*sV0)[NTMAX] = reinterpret_cast<float (*)[NTMAX]>(smem + G.oV0);
-  float (*sV1)[2 * NC] = reinterpret_cast<float (*)[2 * NC]>(smem + G.oV1);
-  float* sStates = reinterpret_cast<float*>(smem + G.oSt);
-  float (*sD)[NO] = reinterpret_cast<float (*)[NO]>(smem + G.oD);
-  float (*sTop)[NC] = reinterpret_cast<float (*)[NC]>(smem + G.oTop);
-  float (*sRec)[NC] = reinterpret_cast<float (*)[NC]>(smem + G.oRec);
-  float (*sYo)[NC] = reinterpret_cast<float (*)[NC]>(smem + G.oY);                // last block's output: [0] sampled step, [1] step t + 1
-  float* sDres = reinterpret_cast<float*>(smem + G.oDres);
-  float* sWo = reinterpret_cast<float*>(smem + G.oWo);                            // W_out [32][ldWo]
-  float (*sXo)[LS_LD] = reinterpret_cast<float (*)[LS_LD]>(smem + G.oXo);
-  float (*sDelta)[LS_LD] = reinterpret_cast<float (*)[LS_LD]>(smem + G.oDelta);
-  float (*sMisc)[8] = reinterpret_cast<float (*)[8]>(smem + G.oMisc);
-  double (*sO)[LS_LO] = reinterpret_cast<double (*)[LS_LO]>(smem + G.oO);
-  double* sActMsg = reinterpret_cast<double*>(smem + G.oActMsg);
-  double* sTq = reinterpret_cast<double*>(smem + G.oTq); double* sTr = sTq + 2 * 64;
+  float (*sV0)[NTMAX] = reinterpret_cast<float (*)[NTMAX]>(smem + O_V0);
+  float (*sV1)[2 * NC] = reinterpret_cast<float (*)[2 * NC]>(smem + O_V1);
+  float* sStates = reinterpret_cast<float*>(smem + O_ST);
+  float (*sD)[NO] = reinterpret_cast<float (*)[NO]>(smem + O_D);
+  float (*sTop)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_TOP);
+  float (*sRec)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_REC);
+  const StepHeadLds S = stepHeadLds(smem + O_HEAD);
 
   const int b = blockIdx.x - (extra.role ? 1 : 0), tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1131,20 +1177,8 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
   const int nIn = a.L[0].nIn, dS = a.dS;
-  const int nDense = ha.nDense, ldWo = ha.ldWo;
-  // head rows of this sample on wavefront 1: 16-lane row 0 = the sampled step, row 1 = step t + 1 of a truncated episode end
-  const int em = (lane >> 4) & 1, en = lane & 15;
-  const bool headLane = wv == 1 && lane < 32;
-  const bool rowValid = headLane && (em == 0 || nextRow >= 0), isNext = rowValid && em == 1, live = rowValid && !isNext;
-  HeadRow<1> hr;
-  hr.load(ha, rowValid, isNext, slot, en);
-  float bpv[1] = {0.f}, bov0 = 0.f, bov1 = 0.f;
-  if (headLane) {
-    if (en < ha.nSig) bpv[0] = ha.params[ha.indBp + en];
-    if (en < nDense) bov0 = ha.params[ha.indBo + en];
-    if (en + 16 < nDense) bov1 = ha.params[ha.indBo + en + 16];
-  }
-  const double beta = a.sc->beta, Cmax = a.sc->Cmax, Cinv = a.sc->Cinv;
+  StepHeadRegs R;
+  stepHeadLoad(R, ha, a.sc, wv, lane, slot, nextRow);
   {
     // ================================================ forward over the window ==================================================
     const int layer = wv;
@@ -1168,10 +1202,10 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
       const int kk = e / dS, i = e - kk * dS;
       sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
     }
-    for (int e = tid; e < NC * ldWo; e += 128) sWo[e] = ha.params[ha.indWo + e];
+    for (int e = tid; e < NC * ha.ldWo; e += 128) S.sWo[e] = ha.params[ha.indWo + e];
     for (int i = tid; i < 2 * NTMAX; i += 128) (&sV0[0][0])[i] = 0.f;
     for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
-    if (headLane) { if (en < 8) sMisc[em][en] = hr.misc; if (en == 0) sActMsg[em] = hr.actMsg; }
+    if (wv == 1 && lane < 32) { if (R.en < 8) S.sMisc[R.em][R.en] = R.hr.misc; if (R.en == 0) S.sActMsg[R.em] = R.hr.actMsg; }
     vmDrain(); pairBarrier();
     if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
     pairBarrier();
@@ -1189,15 +1223,15 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
         }
       } else {
         const int k = it - 1;
-        if (k < 0) hr.hoist(ha, boundedMask, bpv, live, en);       // (this wavefront has no layer-step yet)
+        if (k < 0) R.hr.hoist(ha, boundedMask, R.bpv, R.live, R.en);       // (this wavefront has no layer-step yet)
         else {
           const int cb = k & 1;
           float blk = 0.f;
           lstm32LayerStep<NTMAX, true>(L, w, bias, sV1[cb], NC, NC, prevSt, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane,
                                        sAct + (1 * 17 + (k <= T ? k : 0)) * ACT);
           if (lane < NC) {
-            if (k == T) { a.Yout[(size_t)b * a.ldY + lane] = blk; sYo[0][lane] = blk; }       // (memory: A operand of the output layer's weight gradient)
-            if (k == T + 1) sYo[1][lane] = blk;
+            if (k == T) { a.Yout[(size_t)b * a.ldY + lane] = blk; S.sYo[0][lane] = blk; }       // (memory: A operand of the output layer's weight gradient)
+            if (k == T + 1) S.sYo[1][lane] = blk;
           }
         }
       }
@@ -1220,34 +1254,11 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
     if (L.hasRes && lane < NC) L.Rd[r * L.ldR + lane] = 0.f;
   }
   // ======================================================= output layer + head (wavefront 1) ====================================
-  if (wv == 1) {
-    const int emc = em;
-    if (lane < 32) {      // O[row][o] = y W_out + b_out, o = en and en + 16 (BaseLayer::forward of the output layer)
-      float x0 = 0.f, x1 = 0.f;
-      const float* y = sYo[emc];
-      const int o0 = en < ldWo ? en : ldWo - 1, o1 = en + 16 < ldWo ? en + 16 : ldWo - 1;
-#pragma unroll 8
-      for (int cc = 0; cc < NC; ++cc) { const float yv = y[cc]; x0 = fmaf(yv, sWo[cc * ldWo + o0], x0); x1 = fmaf(yv, sWo[cc * ldWo + o1], x1); }
-      x0 += bov0; x1 += bov1;
-      if (en < nDense) { sXo[emc][en] = x0; sO[emc][en] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x0 : actEval(ha.outFunc, x0)); }
-      if (en + 16 < nDense) { sXo[emc][en + 16] = x1; sO[emc][en + 16] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x1 : actEval(ha.outFunc, x1)); }
-      if (en < ha.nSig) sO[emc][nDense + en] = (double)bpv[0];      // ParamLayer, Linear
-      for (int o = en; o < LS_LD; o += 16) sDelta[emc][o] = 0.f;
-    }
-    waveLdsSync();
-    hr.compute(ha, sO[emc], sDelta[emc], sXo[emc], sMisc[emc], sTq + emc * 64, sTr + emc * 64, rowValid, isNext, true,
-               b, slot, em ? nextRow : b, en, beta, Cmax, Cinv, sActMsg[emc]);
-    waveLdsSync();
-    if (lane < NC) {      // delta_y = delta_out W_out^T: error w.r.t. the last block's output at the sampled step
-      float e = 0.f;
-      for (int o = 0; o < nDense; ++o) e = fmaf(sDelta[0][o], sWo[lane * ldWo + o], e);
-      sDres[lane] = e;
-    }
-  }
+  if (wv == 1) stepHeadRun(R, ha, S, lane, b, slot, nextRow);
   vmDrain(); pairBarrier();
   // ======================================================= back-propagation through time ========================================
   {
-    const float dres = (j == 1 && lane < NC) ? sDres[lane] : 0.f;
+    const float dres = (j == 1 && lane < NC) ? S.sDres[lane] : 0.f;
     float nxtSt = 0.f, nxtF = 0.f;
     for (int it = 0; it <= T + 1; ++it) {
       const int k = T - it + (j == 1 ? 0 : 1);
@@ -1268,10 +1279,10 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
           const float d2 = k > 0 ? FG * (1.f - FG) * prevSt * sd : 0.f;
           const float d3 = OG * (1.f - OG) * D * co;
           sD[j][lane] = d0; sD[j][NC + lane] = d1; sD[j][2 * NC + lane] = d2; sD[j][3 * NC + lane] = d3;
-          L.D[r * NO + lane] = d0; L.D[r * NO + NC + lane] = d1; L.D[r * NO + 2 * NC + lane] = d2; L.D[r * NO + 3 * NC + lane] = d3;
           nxtSt = sd; nxtF = FG;
         }
         waveLdsSync();
+        { const float u0 = sD[j][lane], u1 = sD[j][64 + lane]; L.D[r * NO + lane] = u0; L.D[r * NO + 64 + lane] = u1; }      // the row for the weight gradients: two whole-wavefront stores
         if (j == 1 || k > 0) {
           const f32x4* d4 = reinterpret_cast<const f32x4*>(sD[j]);
           f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f};
@@ -1318,9 +1329,11 @@ __device__ __forceinline__ float dotIn(const float (&w)[32], const float* vec) {
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int IN>      // IN: operand length of the input part as the unrolled loop walks it (zero weights behind the layer's own inputs)
+// (LDSACT: forget gate, candidate and output of the step go to `actRow` in LDS -- the one-launch step keeps them for its backward pass)
+template <int IN, bool LDSACT = false>      // IN: operand length of the input part as the unrolled loop walks it (zero weights behind the layer's own inputs)
 __device__ __forceinline__ void mgu32LayerStep(const RecLayer& L, const float (&win)[32], const float (&wrec)[32], float bias, const float* vec,
-                                               float* hf, int nInL, float wr, float br, float* hNext, float& blkOut, bool store, long long r, int lane) {
+                                               float* hf, int nInL, float wr, float br, float* hNext, float& blkOut, bool store, long long r, int lane,
+                                               float* actRow = nullptr) {
   constexpr int NC = 32, NO = 64;
   const float* hPrev = vec + IN;
   const float accIn = bias + dotIn<IN>(win, vec);
@@ -1330,14 +1343,13 @@ __device__ __forceinline__ void mgu32LayerStep(const RecLayer& L, const float (&
   waveLdsSync();
   const float sc = fastTanh(accIn + dotIn<NC>(wrec, hf));              // (meaningful on the candidate lanes)
   if (store) {
-    L.X[r * NO + lane] = lane < NC ? f : sc;
-    if (lane < nInL) L.A[r * L.ldA + lane] = vec[lane];
-    if (lane < NC) L.A[r * L.ldA + nInL + lane] = po;
+    if (LDSACT) actRow[lane] = lane < NC ? f : sc; else L.X[r * NO + lane] = lane < NC ? f : sc;
+    if (lane < nInL + NC) L.A[r * L.ldA + lane] = vec[lane < nInL ? lane : IN + (lane - nInL)];      // [input | previous output], one store
   }
   const float st = fromUpperHalf(sc);
   if (lane < NC) {
     const float out = f * st + (1.f - f) * po;                           // (po is 0 at the first step of the window)
-    if (store) { L.Y[r * NO + lane] = out; L.A2[r * L.ldA2 + lane] = po * f; }
+    if (store) { if (LDSACT) actRow[NO + lane] = out; else L.Y[r * NO + lane] = out; L.A2[r * L.ldA2 + lane] = po * f; }
     float blk = out;
     if (L.hasRes && lane < L.resW) blk += vec[lane] * wr + br;
     hNext[lane] = out;
@@ -1485,6 +1497,152 @@ __global__ __launch_bounds__(128) void mgu32_backward_wave_kernel(RecArgs a) {
       }
     }
     pairBarrier();
+  }
+}
+
+// ---- the MGU form of the one-launch step (see lstm32_step_wave_kernel): window forward, output layer + head, back-propagation through
+// time of a sample in one workgroup; forget gates, candidates and outputs of the window stay in LDS ---------------------------------
+template <int IN0>
+__global__ __launch_bounds__(256) void mgu32_step_wave_kernel(RecArgs a, HeadArgs ha, unsigned long long boundedMask, ExtraArgs extra) {
+  constexpr int NC = 32, NO = 64, ACT = 3 * NC;            // per (step, layer): [forget | candidate | output]
+  constexpr int O_V0 = 2 * 17 * ACT * 4, O_V1 = O_V0 + 2 * (IN0 + NC) * 4, O_HF = O_V1 + 2 * 64 * 4, O_ST = O_HF + 2 * NC * 4, O_DS = O_ST + 18 * 32 * 4,
+                O_DF = O_DS + 2 * NC * 4, O_TOP = O_DF + 2 * NC * 4, O_REC = O_TOP + 2 * NC * 4, O_HEAD = O_REC + 2 * NC * 4, TOTAL = O_HEAD + STEP_HEAD_LDS;
+  static_assert(O_HEAD % 16 == 0 && O_V0 % 16 == 0 && O_V1 % 16 == 0 && O_HF % 16 == 0 && O_DS % 16 == 0 && O_DF % 16 == 0, "alignment of the 16-byte reads");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TOTAL > (int)TAIL_LDS_BYTES ? TOTAL : (int)TAIL_LDS_BYTES];
+  if (extra.role) { if (blockIdx.x == 0) { runExtra(extra, smem); return; } if (threadIdx.x >= 128) return; }
+  float* sAct = reinterpret_cast<float*>(smem);                                   // [2][17][ACT]
+  float (*sV0)[IN0 + NC] = reinterpret_cast<float (*)[IN0 + NC]>(smem + O_V0);
+  float (*sV1)[2 * NC] = reinterpret_cast<float (*)[2 * NC]>(smem + O_V1);
+  float (*sHF)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_HF);
+  float* sStates = reinterpret_cast<float*>(smem + O_ST);
+  float (*sDS)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_DS);
+  float (*sDF)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_DF);
+  float (*sTop)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_TOP);
+  float (*sRec)[NC] = reinterpret_cast<float (*)[NC]>(smem + O_REC);
+  const StepHeadLds S = stepHeadLds(smem + O_HEAD);
+
+  const int b = blockIdx.x - (extra.role ? 1 : 0), tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
+  const int T = min(a.nBPTT, t);
+  const int nextRow = a.bt.nextOf[b];
+  const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
+  const float* W = a.W;
+  const int nIn = a.L[0].nIn, dS = a.dS;
+  StepHeadRegs R;
+  stepHeadLoad(R, ha, a.sc, wv, lane, slot, nextRow);
+  {
+    // ================================================ forward over the window ==================================================
+    const int layer = wv;
+    const RecLayer L = a.L[layer];
+    float win[32], wrec[32];
+    {
+      const float* Wl = W + L.indW;
+      const int nInL = layer == 0 ? nIn : NC;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        win[i] = i < nInL ? Wl[(size_t)i * NO + lane] : 0.f;
+        wrec[i] = Wl[(size_t)(nInL + i) * NO + lane];
+      }
+    }
+    const float bias = W[L.indB + lane];
+    const int c = lane & 31;
+    float wr = 0.f, br = 0.f;
+    if (L.hasRes && c < L.resW) { wr = W[L.indWr + c]; br = W[L.indBr + c]; }
+    for (int e = tid; e < nSteps * dS; e += 128) {
+      const int kk = e / dS, i = e - kk * dS;
+      sStates[e] = (a.rp.S[(size_t)(slot - T + kk) * dS + i] - a.rp.stMean[i]) * a.rp.stScale[i];
+    }
+    for (int e = tid; e < NC * ha.ldWo; e += 128) S.sWo[e] = ha.params[ha.indWo + e];
+    for (int i = tid; i < 2 * (IN0 + NC); i += 128) (&sV0[0][0])[i] = 0.f;
+    for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
+    if (wv == 1 && lane < 32) { if (R.en < 8) S.sMisc[R.em][R.en] = R.hr.misc; if (R.en == 0) S.sActMsg[R.em] = R.hr.actMsg; }
+    vmDrain(); pairBarrier();
+    if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
+    pairBarrier();
+    for (int it = 0; it <= nSteps; ++it) {
+      if (layer == 0) {
+        const int k = it;
+        if (k < nSteps) {
+          const int cb = k & 1;
+          if (k + 1 < nSteps && lane < dS) sV0[cb ^ 1][lane] = sStates[(k + 1) * dS + lane];
+          float blk = 0.f;
+          mgu32LayerStep<IN0, true>(L, win, wrec, bias, sV0[cb], sHF[0], nIn, wr, br, &sV0[cb ^ 1][IN0], blk, k <= T, (long long)b * a.K + k, lane,
+                                    sAct + (0 * 17 + (k <= T ? k : 0)) * ACT);
+          if (lane < NC) sV1[cb][lane] = blk;
+        }
+      } else {
+        const int k = it - 1;
+        if (k < 0) R.hr.hoist(ha, boundedMask, R.bpv, R.live, R.en);       // (this wavefront has no layer-step yet)
+        else {
+          const int cb = k & 1;
+          float blk = 0.f;
+          mgu32LayerStep<NC, true>(L, win, wrec, bias, sV1[cb], sHF[1], NC, wr, br, &sV1[cb ^ 1][NC], blk, k <= T, (long long)b * a.K + k, lane,
+                                   sAct + (1 * 17 + (k <= T ? k : 0)) * ACT);
+          if (lane < NC) {
+            if (k == T) { a.Yout[(size_t)b * a.ldY + lane] = blk; S.sYo[0][lane] = blk; }
+            if (k == T + 1) S.sYo[1][lane] = blk;
+          }
+        }
+      }
+      pairBarrier();
+    }
+  }
+  // ======================================================= backward: weight rows requested now ==================================
+  const int j = 1 - wv;                                    // wavefront 0 = the top layer (one step ahead), wavefront 1 = layer 0
+  const RecLayer L = a.L[j];
+  float wf[32], ws[32];                                    // this lane's row: forget columns, candidate columns
+  {
+    const f32x4* rw = reinterpret_cast<const f32x4*>(W + L.indW + (size_t)(j == 1 ? lane : nIn + (lane & 31)) * NO);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const f32x4 u = rw[q], v = rw[8 + q]; wf[4 * q] = u[0]; wf[4 * q + 1] = u[1]; wf[4 * q + 2] = u[2]; wf[4 * q + 3] = u[3];
+                                  ws[4 * q] = v[0]; ws[4 * q + 1] = v[1]; ws[4 * q + 2] = v[2]; ws[4 * q + 3] = v[3]; }
+  }
+  const float wrB = (L.hasRes && lane < L.resW) ? W[L.indWr + lane] : 0.f;
+  for (int k = T + 1; k < a.K; ++k) {
+    const long long r = (long long)b * a.K + k;
+    L.D[r * NO + lane] = 0.f;
+    if (L.hasRes && lane < NC) L.Rd[r * L.ldR + lane] = 0.f;
+  }
+  // ======================================================= output layer + head (wavefront 1) ====================================
+  if (wv == 1) stepHeadRun(R, ha, S, lane, b, slot, nextRow);
+  vmDrain(); pairBarrier();
+  // ======================================================= back-propagation through time ========================================
+  {
+    const float dres = (j == 1 && lane < NC) ? S.sDres[lane] : 0.f;
+    for (int it = 0; it <= T + 1; ++it) {
+      const int k = T - it + (j == 1 ? 0 : 1);
+      if (k >= 0 && k <= T) {
+        const long long r = (long long)b * a.K + k;
+        float res = 0.f, dLdO = 0.f, f = 0.f, sc = 0.f, po = 0.f, dS_ = 0.f;
+        if (lane < NC) {
+          const float eTop = j == 1 ? (k == T ? dres : 0.f) : sTop[k & 1][lane];
+          const float* act = sAct + (j * 17 + k) * ACT;
+          if (L.hasRes) { L.Rd[r * L.ldR + lane] = eTop; res = lane < L.resW ? eTop * wrB : 0.f; }
+          dLdO = eTop + (k < T ? sRec[j][lane] : 0.f);
+          f = act[lane]; sc = act[NC + lane]; po = k > 0 ? (act - ACT)[2 * NC + lane] : 0.f;
+          dS_ = dLdO * f * (1.f - sc * sc);                                         // 1) dLdS
+          sDS[j][lane] = dS_;
+        }
+        waveLdsSync();
+        const float viaS = dotIn<NC>(ws, sDS[j]);                                    // row i: sum_o W[i][nC + o] dLdS[o]
+        float fp = j == 1 ? fromUpperHalf(viaS) : viaS;                              // 2) dLdFprevOut of cell c = the recurrent row nIn + c
+        if (k == 0) fp = 0.f;
+        if (lane < NC) {
+          const float dF = ((sc - po) * dLdO + fp * po) * f * (1.f - f);             // 3) dLdF
+          sDF[j][lane] = dF;
+        }
+        waveLdsSync();
+        L.D[r * NO + lane] = lane < NC ? sDF[j][lane] : sDS[j][lane - NC];          // the row for the weight gradients [dLdF | dLdS]: one whole-wavefront store
+        const float viaF = dotIn<NC>(wf, sDF[j]);                                    // row i: sum_o W[i][o] dLdF[o]
+        const float g = j == 1 ? fromUpperHalf(viaF) : viaF;
+        if (lane < NC) {
+          if (j == 1) sTop[k & 1][lane] = (res + viaF) + viaS;                       // error of block 0's output (+ the residual path)
+          if (k > 0) sRec[j][lane] = ((1.f - f) * dLdO + f * fp) + g;                // 4) dLdprevOut
+        }
+      }
+      pairBarrier();
+    }
   }
 }
 
@@ -1764,7 +1922,7 @@ hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
 // dense outputs and 16 action components / options
 bool rec_step_fused_ok(const RecArgs& a, const HeadArgs& ha) {
   const int comps = ha.nOpt ? ha.nOpt : ha.dA;
-  return !recGeneral(a) && lstm32Wave(a) && a.actStates == nullptr && a.YoutRows == nullptr && a.DresRows == nullptr && a.K <= 17 &&
+  return !recGeneral(a) && (lstm32Wave(a) || mgu32Wave(a)) && a.actStates == nullptr && a.YoutRows == nullptr && a.DresRows == nullptr && a.K <= 17 &&
          ha.H == 32 && ha.nDense <= 32 && ha.nOut <= 48 && comps <= 16 && ha.ldWo <= 40;
 }
 hipError_t launch_rec_step_fused(const RecArgs& a, const HeadArgs& ha, const ExtraArgs* extra, hipStream_t s) {
@@ -1773,6 +1931,13 @@ hipError_t launch_rec_step_fused(const RecArgs& a, const HeadArgs& ha, const Ext
   unsigned long long mask = 0; for (int c = 0; c < HL_MAX_DIMA && c < 64; ++c) if (ha.bounded[c]) mask |= 1ull << c;
   const dim3 grid(a.B + (ex.role ? 1 : 0)), block(ex.role ? 256 : 128);
   const int in0 = (a.L[0].nIn + 3) & ~3;
+  if (a.gates == 2) {
+    if (in0 <= 4) hipLaunchKernelGGL(mgu32_step_wave_kernel<4>, grid, block, 0, s, a, ha, mask, ex);
+    else if (in0 <= 8) hipLaunchKernelGGL(mgu32_step_wave_kernel<8>, grid, block, 0, s, a, ha, mask, ex);
+    else if (in0 <= 16) hipLaunchKernelGGL(mgu32_step_wave_kernel<16>, grid, block, 0, s, a, ha, mask, ex);
+    else hipLaunchKernelGGL(mgu32_step_wave_kernel<32>, grid, block, 0, s, a, ha, mask, ex);
+    return hipGetLastError();
+  }
   if (in0 <= 4) hipLaunchKernelGGL(lstm32_step_wave_kernel<4>, grid, block, 0, s, a, ha, mask, ex);
   else if (in0 <= 8) hipLaunchKernelGGL(lstm32_step_wave_kernel<8>, grid, block, 0, s, a, ha, mask, ex);
   else if (in0 <= 16) hipLaunchKernelGGL(lstm32_step_wave_kernel<16>, grid, block, 0, s, a, ha, mask, ex);

@@ -294,10 +294,10 @@ def test_states_wider_than_512_components(hip_api):
     assert relinf(G.forward(st), O.forward(st)) < TOL32
 
 
-@pytest.mark.parametrize("seed", range(10))
-def test_one_launch_lstm_step_random_shapes_match_oracle(hip_api, seed, monkeypatch):
-    """Two LSTM layers of 32 cells run a sample's window forward, its head and its back-propagation through time as ONE launch
-    (rec.hip: lstm32_step_wave_kernel).  Shapes of its envelope drawn at random -- 1..32 observed states, 1..7 action components
+@pytest.mark.parametrize("seed", range(16))
+def test_one_launch_recurrent_step_random_shapes_match_oracle(hip_api, seed, monkeypatch):
+    """Two LSTM or MGU layers of 32 cells run a sample's window forward, its head and its back-propagation through time as ONE launch
+    (rec.hip: lstm32_step_wave_kernel, mgu32_step_wave_kernel).  Shapes of its envelope drawn at random -- 1..32 observed states, 1..7 action components
     with mixed bounds or 2..16 options, every advantage kind, windows of 1..16 steps, episodes that end truncated (next-state rows)
     or terminated -- against the oracle, eager and replayed (the sampler's rider); the three-launch form (SMARTIES_HIP_REC_FUSED=0)
     must give the same minibatches and the same weights to rounding."""
@@ -310,7 +310,7 @@ def test_one_launch_lstm_step_random_shapes_match_oracle(hip_api, seed, monkeypa
         dA = int(rng.integers(1, 8))
         head = dict(adv_kind=capi.ADV_GAUSSIAN if kind == 1 else capi.ADV_ZERO, bounded=[int(x) for x in rng.integers(0, 2, dA)])
     kw = dict(dimS=dS, dimA=dA, hidden=(32, 32), nnFunc="Tanh", batchSize=int(rng.integers(1, 140)), maxTotObsNum=8000,
-              randSeed=int(rng.integers(1, 1000)), nn_type=capi.NN_LSTM, nnBPTTseq=int(rng.integers(1, 17)),
+              randSeed=int(rng.integers(1, 1000)), nn_type=capi.NN_LSTM if seed % 2 == 0 else capi.NN_MGU, nnBPTTseq=int(rng.integers(1, 17)),
               clipImpWeight=float(rng.choice([0.7, 2.0, 4.0])), **head)
     sc = synth_cfg(seed=int(rng.integers(1, 1000)), dimS=dS, dimA=dA, lenMin=2, lenMax=int(rng.integers(3, 40)),
                    pTerm=float(rng.choice([0.0, 0.5, 1.0])))
