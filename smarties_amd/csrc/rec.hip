@@ -83,8 +83,13 @@ __device__ __forceinline__ int recLdsOffset(const RecArgs& a, int j) {
 #ifdef REC_STAMPS
 __device__ unsigned long long recStamps[256];
 #define RSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 256) recStamps[i] = wall_clock64(); } while (0)
+// (the one-launch step: first sample's workgroup -- block 1 behind a rider --, wavefront 0 / wavefront 1)
+#define SSTAMP(i) do { if (b == 0 && threadIdx.x == 0 && (i) < 256) recStamps[i] = wall_clock64(); } while (0)
+#define SSTAMP1(i) do { if (b == 0 && threadIdx.x == 64 && (i) < 256) recStamps[i] = wall_clock64(); } while (0)
 #else
 #define RSTAMP(i) do {} while (0)
+#define SSTAMP(i) do {} while (0)
+#define SSTAMP1(i) do {} while (0)
 #endif
 template <bool LDSW>
 __global__ __launch_bounds__(256) void rec_forward_kernel(RecArgs a) {
@@ -1177,6 +1182,7 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const float* W = a.W;
   const int nIn = a.L[0].nIn, dS = a.dS;
+  SSTAMP(0);
   StepHeadRegs R;
   stepHeadLoad(R, ha, a.sc, wv, lane, slot, nextRow);
   {
@@ -1206,11 +1212,14 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
     for (int i = tid; i < 2 * NTMAX; i += 128) (&sV0[0][0])[i] = 0.f;
     for (int i = tid; i < 4 * NC; i += 128) (&sV1[0][0])[i] = 0.f;
     if (wv == 1 && lane < 32) { if (R.en < 8) S.sMisc[R.em][R.en] = R.hr.misc; if (R.en == 0) S.sActMsg[R.em] = R.hr.actMsg; }
+    SSTAMP(1);
     vmDrain(); pairBarrier();
+    SSTAMP(2);
     if (layer == 0 && lane < dS) sV0[0][lane] = sStates[lane];
     pairBarrier();
     float prevSt = 0.f;
     for (int it = 0; it <= nSteps; ++it) {
+      SSTAMP(4 + it);
       if (layer == 0) {
         const int k = it;
         if (k < nSteps) {
@@ -1238,6 +1247,7 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
       pairBarrier();
     }
   }
+  SSTAMP(30);
   // ======================================================= backward: weight rows requested now ==================================
   const int j = 1 - wv;                                    // wavefront 0 = the top layer (one step ahead), wavefront 1 = layer 0
   const RecLayer L = a.L[j];
@@ -1254,8 +1264,11 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
     if (L.hasRes && lane < NC) L.Rd[r * L.ldR + lane] = 0.f;
   }
   // ======================================================= output layer + head (wavefront 1) ====================================
+  SSTAMP(31);
   if (wv == 1) stepHeadRun(R, ha, S, lane, b, slot, nextRow);
+  if (wv == 1) SSTAMP1(32);
   vmDrain(); pairBarrier();
+  SSTAMP(33);
   // ======================================================= back-propagation through time ========================================
   {
     const float dres = (j == 1 && lane < NC) ? S.sDres[lane] : 0.f;
@@ -1309,6 +1322,7 @@ __global__ __launch_bounds__(256) void lstm32_step_wave_kernel(RecArgs a, HeadAr
       pairBarrier();
     }
   }
+  SSTAMP(250);
 }
 
 // ---- MGU, two layers of 32 cells: the same arrangement ---------------------------------------------------------------------

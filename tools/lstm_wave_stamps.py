@@ -1,5 +1,6 @@
-"""Device time stamps of the first sample's layer-0 wavefront in lstm32_forward_wave_kernel (library built with -DREC_STAMPS): entry,
-prologue loads issued, prologue drained, every iteration of the window loop, end."""
+"""Device time stamps of the first sample's layer-0 wavefront (library built with -DREC_STAMPS) in the one-launch LSTM step
+(lstm32_step_wave_kernel: entry, prologue, every iteration of the forward loop, head, backward, end) or, with
+SMARTIES_HIP_REC_FUSED=0, in lstm32_forward_wave_kernel (entry, prologue, every iteration of the window loop, end)."""
 import sys, ctypes as C
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
@@ -20,3 +21,5 @@ for rep in range(4):
     its = [int(rel[4 + i]) for i in range(19) if st[4 + i] >= st[0]]
     print("loads issued %d ns, drained %d, loop from %d to %d (end %d): %d iterations, %s ns each" % (
         rel[1], rel[2], its[0], its[-1], rel[250], len(its), np.diff(its).tolist()))
+    if st[30] >= st[0]:
+        print("   forward done %d ns, backward weights requested %d, head done (wavefront 1) %d, backward from %d to %d" % (rel[30], rel[31], rel[32], rel[33], rel[250]))
