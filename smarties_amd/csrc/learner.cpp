@@ -45,6 +45,7 @@ struct StepBuf {
   int segDxIdx = -1, segDxBlocks = 0;      // two recurrent layer types: the GEMM between the segments' backward passes
   std::vector<int> bigDw;                  // large batches: weight-gradient problems taken by big_dw_kernel (indices into the problem table)
   std::vector<int> fwdIdx, fwdBlocks, dxIdx, dxBlocks; int dwIdx = 0, dwAdamIdx = 0, dwCount = 0, dwBlocks = 0;
+  int dwWideIdx = -1, dwWideAdamIdx = -1, dwWideBlocks = 0;      // recurrent nets: the same problems unsplit, for dw_wide_kernel (gemm16.hip)
   int splitMaxMN = 0;                      // > 0: some weight-gradient problems are split over the rows (largest M x N among them)
   DwTable dwTable{}, dwTableAdam{};        // the dW problems by value (kernel-argument table of dw_table_kernel)
 };
@@ -63,6 +64,7 @@ struct hl_learner {
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
   bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
+  bool wideDw = true;         // recurrent nets: weight gradients over all (sample, step) rows as one launch without a split-row join (SMARTIES_HIP_WIDE_DW=0: (tile, chunk) workgroups + splitk_reduce_kernel)
   bool recFused = true;       // two LSTM layers of 32 cells: forward, head and backward of a sample as one launch (rec.hip: lstm32_step_wave_kernel; SMARTIES_HIP_REC_FUSED=0: the three launches)
   bool panelHead = false;     // ... and headp.hip's 16-sample panels for the head (SMARTIES_HIP_PANEL_HEAD=0 / 1 overrides: 1 also for small batches, eager launches)
   int bigMm = 0;              // ... with the kernels of bigmm.hip (bit 0: weight-stationary forward / dX panels, bit 1: weight gradients, bit 2: LDS-tiled forward / dX products, taken before the panels; SMARTIES_HIP_BIGMM overrides)
@@ -100,6 +102,7 @@ struct hl_learner {
   // gemm problem tables (device) + launch geometry
   GemmProblem* dProbs = nullptr;           // all GEMM problems of both buffers, contiguous
   float* splitPart = nullptr; size_t splitPartFloats = 0;   // partial tiles of the split weight-gradient problems
+  float* widePart = nullptr; unsigned* wideCtr = nullptr; int wideTiles = 0;      // dw_wide_kernel (gemm16.hip): four partial tiles and an arrival counter per tile
   // replay bookkeeping (host)
   long long capSlots = 0; int capEps = 0;
   long long ringHead = 0;                  // next free slot
@@ -639,6 +642,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->panelHead = h->B >= 2048 || cfg->nn_type != HL_NN_FFNN;      // (measured: recurrent nets 68.5 -> 66.5 us per step at 2 x 32 cells; the 512-wide Atari head 152.5 -> 156.9: one wavefront set per sample there)
   if (const char* e = getenv("SMARTIES_HIP_PANEL_HEAD")) h->panelHead = e[0] == '1';
   if (const char* e = getenv("SMARTIES_HIP_REC_FUSED")) h->recFused = e[0] == '1';
+  if (const char* e = getenv("SMARTIES_HIP_WIDE_DW")) h->wideDw = e[0] == '1';
   if (const char* e = getenv("SMARTIES_HIP_BIGMM")) h->bigMm = h->bigBatch ? atoi(e) : 0;
   if (h->bigBatch && (cfg->nn_type != HL_NN_FFNN || cfg->n_conv > 0 || cfg->dataSamplingAlgo != HL_SAMPLE_UNIFORM))
     return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024: dense layers and the uniform sampler only");
@@ -881,7 +885,7 @@ int hl_destroy(hl_learner* h) {
   if (h->notifyPin) hipHostFree(h->notifyPin);
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
   for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
-  void* ptrs[] = {h->splitPart, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
+  void* ptrs[] = {h->splitPart, h->widePart, h->wideCtr, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedMax, h->dRedErr, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
     h->rp.epOff, h->rp.epN, h->rp.epTerm, h->rp.epAgg, h->rp.posEid, h->rp.posPrefix, h->rp.stMean, h->rp.stScale,

@@ -197,6 +197,29 @@ int buildProblems(hl_learner* h) {
       if (p.biasOut) { const long long offB = p.biasOut - h->G; p.adbW = h->W + offB; p.adbM1 = h->M1 + offB; p.adbM2 = h->M2 + offB; }
       P.push_back(p);
     }
+    // recurrent nets: third and fourth copy for the one-launch form (gemm16.hip: dw_wide_kernel) -- no row chunks, eight wavefronts
+    // per tile over all rows, the Adam update in the tile's epilogue
+    sb.dwWideIdx = sb.dwWideAdamIdx = -1; sb.dwWideBlocks = 0;
+    if (h->recurrent && sb.splitMaxMN > 0) {
+      for (int pass = 0; pass < 2; ++pass) {
+        (pass ? sb.dwWideAdamIdx : sb.dwWideIdx) = (int)P.size();
+        int curW = 0;
+        for (int i = 0; i < sb.dwCount; ++i) {
+          GemmProblem q = P[(pass ? sb.dwAdamIdx : sb.dwIdx) + i];
+          q.nSplit = 1; q.part = nullptr; q.adamRed = 0; q.adam = pass;
+          q.tileStart = curW; curW += q.tilesM * q.tilesN;
+          P.push_back(q);
+        }
+        sb.dwWideBlocks = curW;
+      }
+      if (sb.dwWideBlocks > h->wideTiles) {      // (shared by both minibatch buffers: steps are sequential)
+        if (h->widePart) hipFree(h->widePart); if (h->wideCtr) hipFree(h->wideCtr);
+        h->widePart = nullptr; h->wideCtr = nullptr; h->wideTiles = (int)roundUp(sb.dwWideBlocks, 8);
+        HIPCK(devAlloc(&h->widePart, (size_t)h->wideTiles * DW_WIDE_Q * 256));
+        HIPCK(devAlloc(&h->wideCtr, (size_t)h->wideTiles));
+        HIPCK(hipMemset(h->wideCtr, 0, (size_t)h->wideTiles * sizeof(unsigned)));
+      }
+    }
     sb.dwTable = DwTable{}; sb.dwTableAdam = DwTable{};
     if (sb.dwCount <= DW_TABLE_MAX) {
       sb.dwTable.n = sb.dwTableAdam.n = sb.dwCount;
@@ -483,7 +506,10 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   // reader of beta is the head kernel of the step after), off what was that launch's longest workgroup
   // (no dX launch -- recurrent layers, a single hidden layer --: the bookkeeping rides the dW launch; where a split-row join follows,
   // count and beta ride that one)
-  const bool viaSplit = sb.dxIdx.empty() && sb.splitMaxMN > 0;
+  // recurrent nets: the weight gradients over all (sample, step) rows as ONE launch (no row chunks, no join) unless this replica
+  // pushes its tiles into peer windows from the launch
+  const bool wideDw = h->wideDw && sb.dwWideIdx >= 0 && !hyp.push.on && sb.bigDw.empty();
+  const bool viaSplit = sb.dxIdx.empty() && sb.splitMaxMN > 0 && !wideDw;
   PostArgs fbSplit{};
   if (fusePost && postMode == (POST_AGG | POST_BETA) && (!sb.dxIdx.empty() || viaSplit) && !h->noDeferBeta) {
     postMode |= POST_DEFER;
@@ -539,6 +565,11 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   // large batches: the dense layers' weight gradients as 64 x 64 tiles over row chunks (bigmm.hip); joined by splitk_reduce below
   for (int idx : sb.bigDw)
     HIPCK(timed(h, "big_dw", s, [&] { return launch_big_dw(h->hostProbs[(fuseAdam ? sb.dwAdamIdx : sb.dwIdx) + (idx - sb.dwIdx)], s); }));
+  if (wideDw) {
+    HIPCK(timed(h, "dw_wide", s, [&] {
+      return launch_dw_wide(h->dProbs + (fuseAdam ? sb.dwWideAdamIdx : sb.dwWideIdx), sb.dwCount, sb.dwWideBlocks, h->widePart, h->wideCtr, h->sc, hyp, pexW, pexF, s); }));
+    return HL_OK;
+  }
   HIPCK(timed(h, "gemm16_dw", s, [&] {
     return launch_gemm(GEMM_ROLE_DW, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, h->sc, hyp, pexW, s, pexF); }));
   if (sb.splitMaxMN > 0)

@@ -14,7 +14,7 @@ t0 = time.perf_counter(); L.step(3000); L.sync(); dt = time.perf_counter() - t0
 print(KIND.upper() + ' RACER_RNN config: %.1f us per step, %.0f transitions/s (batch 128, BPTT 16)' % (dt / 3000 * 1e6, 128 * 3000 / dt))
 L.timing_enable(True) if hasattr(L, 'timing_enable') else None
 L.timing_enable(True); L.step(200); L.sync()
-for k in ("step_tail_kernel", "rec_forward", "head_kernel", "rec_backward", "gemm16_dw", "splitk_reduce", "post_kernel", "adam_kernel"):
+for k in ("step_tail_kernel", "rec_step_fused", "rec_forward", "head_kernel", "panel_head", "rec_backward", "gemm16_dw", "dw_wide", "splitk_reduce", "post_kernel", "adam_kernel"):
     try:
         print(k, L.timing_get(k))
     except Exception as e:
