@@ -248,8 +248,8 @@ hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlo
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);
 // weight gradients over many rows (recurrent nets) as one launch of 16-wavefront workgroups, no split-row join (gemm16.hip: dw_wide_kernel)
 constexpr int DW_WIDE_Q = 4;      // row quarters per tile: `part` holds nTiles (rounded up to 8) x DW_WIDE_Q x 256 floats, `ctr` one counter per tile (zeroed once)
-hipError_t launch_dw_wide(const GemmProblem* dProbs, int nProbs, int nTiles, float* part, unsigned* ctr, const DevScalars* sc, const AdamHyper& hyp,
-                          const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);
+hipError_t launch_dw_wide(const GemmProblem* dProbs, int nProbs, int nTiles, int nq, float* part, unsigned* ctr, const DevScalars* sc, const AdamHyper& hyp,
+                          const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);      // nq: 1 (a tile's rows in one workgroup) or DW_WIDE_Q
 hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN, const DevScalars* sc, const AdamHyper& hyp, hipStream_t s,
                                 const PostArgs* farBeta = nullptr);      // farBeta: a rider workgroup runs farBetaPhase (tail_dev.h)
 hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);

@@ -567,7 +567,14 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     HIPCK(timed(h, "big_dw", s, [&] { return launch_big_dw(h->hostProbs[(fuseAdam ? sb.dwAdamIdx : sb.dwIdx) + (idx - sb.dwIdx)], s); }));
   if (wideDw) {
     HIPCK(timed(h, "dw_wide", s, [&] {
-      return launch_dw_wide(h->dProbs + (fuseAdam ? sb.dwWideAdamIdx : sb.dwWideIdx), sb.dwCount, sb.dwWideBlocks, h->widePart, h->wideCtr, h->sc, hyp, pexW, pexF, s); }));
+      return launch_dw_wide(h->dProbs + (fuseAdam ? sb.dwWideAdamIdx : sb.dwWideIdx), sb.dwCount, sb.dwWideBlocks, DW_WIDE_Q, h->widePart, h->wideCtr, h->sc, hyp, pexW, pexF, s); }));
+    return HL_OK;
+  }
+  // minibatch rows only and many tiles (the dense layer behind a convolutional stack: 1630): operands straight from memory into the
+  // MFMA, no staging and no barrier in front of the reduction (dw_wide_kernel with one workgroup per tile) -- shorter workgroups
+  if (h->directDw && sb.splitMaxMN == 0 && sb.bigDw.empty() && !hyp.push.on && sb.dwBlocks >= h->directDwMinTiles) {
+    HIPCK(timed(h, "dw_direct", s, [&] {
+      return launch_dw_wide(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, 1, nullptr, nullptr, h->sc, hyp, pexW, pexF, s); }));
     return HL_OK;
   }
   HIPCK(timed(h, "gemm16_dw", s, [&] {
