@@ -91,6 +91,77 @@ hipError_t launch_fwd_chain(const GemmProblem* dProbs, const int* idx, int nLaye
   return hipGetLastError();
 }
 
+// the reduction of one wavefront: rows [r0, rEnd) of A (columns m0 ..) and B (columns n0 ..), UN steps of four rows per batch of loads
+template <int UN>
+__device__ __forceinline__ void dwwRows(const GemmProblem& P, const float* pA, const float* pB, bool aOne, bool aOk, bool bOk, int r0, int rEnd, int lc,
+                                        f32x4& acc0, f32x4& acc1) {
+  for (int rb = r0; rb < rEnd; rb += 4 * UN) {
+    float av[UN], bv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {      // (clamped rows: no predicated loads; what they fetch is masked below)
+      const unsigned r = (unsigned)min(rb + 4 * u + lc, P.K - 1);
+      av[u] = pA[r * (unsigned)P.lda]; bv[u] = pB[r * (unsigned)P.ldb];      // (32-bit element offsets from the uniform bases)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UN; u += 2) {
+      const bool in0 = rb + 4 * u + lc < rEnd, in1 = rb + 4 * (u + 1) + lc < rEnd;
+      const float a0 = in0 ? (aOne ? 1.f : (aOk ? av[u] : 0.f)) : 0.f, b0 = (in0 && bOk) ? bv[u] : 0.f;
+      const float a1 = in1 ? (aOne ? 1.f : (aOk ? av[u + 1] : 0.f)) : 0.f, b1 = (in1 && bOk) ? bv[u + 1] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+    }
+  }
+}
+// One 16 x 16 weight-gradient tile of problem P (flavor GEMM_W, rows = the minibatch) with its whole reduction in this workgroup of four
+// wavefronts, operands straight from memory into the MFMA: no LDS staging and no barrier in front of the cross-wave reduction
+// (the staged form: gemm_tile.h).  Epilogue as gemmTile's EPI_DW without the peer-window push.
+__device__ __forceinline__ void dwDirectTile(const GemmProblem& P, int tile, unsigned char* smem, const DevScalars* sc, const AdamHyper& hyp) {
+  float* red = reinterpret_cast<float*>(smem);
+  {   // XCD-aware tile order, as gemmTile: the tiles of one XCD share their A row-panels
+    const int nT = P.tilesM * P.tilesN;
+    if ((nT & 7) == 0) tile = (tile & 7) * (nT >> 3) + (tile >> 3);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tm = tile / P.tilesN, tn = tile - tm * P.tilesN;
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int li = lane & 15, lc = lane >> 4;
+  const int m = m0 + (tid >> 4), n = n0 + (tid & 15);
+  const bool outOk = m < P.M && n < P.N;
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+  AdamCoef ac{};
+  if (P.adam) {
+    ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
+    const bool isW = m < P.M - 1;
+    const size_t iw = outOk ? (isW ? (size_t)m * P.ldc + n : (size_t)n) : 0;
+    const float* pw = isW ? P.adW : P.adbW; const float* p1 = isW ? P.adM1 : P.adbM1; const float* p2 = isW ? P.adM2 : P.adbM2;
+    e0 = pw[iw]; e1 = p1[iw]; e2 = p2[iw];
+  }
+  const int RW = (((P.K + 3) / 4) + 3) & ~3;      // rows per wavefront: a multiple of four
+  const int r0 = wave * RW, rEnd = min(P.K, r0 + RW);
+  const int ma = m0 + li, nb = n0 + li;
+  const bool aOne = ma == P.M - 1, aOk = ma < P.M - 1 && ma < P.lda, bOk = nb < P.N;
+  const float* pA = P.A + (aOk ? ma : 0);
+  const float* pB = P.B + (bOk ? nb : 0);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if (RW <= 32) dwwRows<8>(P, pA, pB, aOne, aOk, bOk, r0, rEnd, lc, acc0, acc1);
+  else if (RW <= 64) dwwRows<16>(P, pA, pB, aOne, aOk, bOk, r0, rEnd, lc, acc0, acc1);
+  else dwwRows<34>(P, pA, pB, aOne, aOk, bOk, r0, rEnd, lc, acc0, acc1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+  __syncthreads();
+  const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  if (!outOk) return;
+  if (m < P.M - 1) {
+    const size_t i = (size_t)m * P.ldc + n;
+    P.C[i] = v;
+    if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adW[i] = e0; P.adM1[i] = e1; P.adM2[i] = e2; }
+  } else {
+    P.biasOut[n] = v;
+    if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adbW[n] = e0; P.adbM1[n] = e1; P.adbM2[n] = e2; }
+  }
+}
+
 // the weight-gradient launch of the fused path: the problem table travels in the kernel arguments
 // (scalar loads from the kernarg segment instead of two dependent global round trips)
 // (the two riders' arguments travel unpacked: two whole ExtraArgs records would push the kernel-argument segment past 4 KB)
@@ -118,7 +189,12 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
 #pragma unroll
   for (int i = 1; i < DW_TABLE_MAX; ++i) if (i < tbl.n && bid >= tbl.p[i].tileStart) p = i;
   const GemmProblem P = tbl.p[p];      // by value: the whole record in one batch of scalar loads
-  if (P.flavor == GEMM_W) gemmTile<GEMM_ROLE_DW, GEMM_W>(P, bid - P.tileStart, smem, sc, hyp, 0);
+  if (P.flavor == GEMM_W) {
+#ifndef HL_DW_TABLE_STAGED
+    if (!hyp.push.on && P.K <= 1024) { dwDirectTile(P, bid - P.tileStart, smem, sc, hyp); return; }      // (peer-window push: the staged form's epilogue)
+#endif
+    gemmTile<GEMM_ROLE_DW, GEMM_W>(P, bid - P.tileStart, smem, sc, hyp, 0);
+  }
   else gemmTile<GEMM_ROLE_DW>(P, bid - P.tileStart, smem, sc, hyp, 0);
 }
 
@@ -303,28 +379,6 @@ hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlo
 // RED_COL problems (column sums over the same rows): the same four quarters, 16 row partitions each.  Riders as gemm16_kernel (256 threads).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DWW_NT = 256, DWW_NW = DWW_NT / 64, DWW_UN = 34;      // (four wavefronts: three workgroups per CU at the kernel's ~150 VGPRs -- 66 tiles x 4 quarters of the LSTM shape in one round; the riders are written for 256 threads)
-// the reduction of one wavefront: rows [r0, rEnd) of A (columns m0 ..) and B (columns n0 ..), UN steps of four rows per batch of loads
-template <int UN>
-__device__ __forceinline__ void dwwRows(const GemmProblem& P, const float* pA, const float* pB, bool aOne, bool aOk, bool bOk, int r0, int rEnd, int lc,
-                                        f32x4& acc0, f32x4& acc1) {
-  for (int rb = r0; rb < rEnd; rb += 4 * UN) {
-    float av[UN], bv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {      // (clamped rows: no predicated loads; what they fetch is masked below)
-      const unsigned r = (unsigned)min(rb + 4 * u + lc, P.K - 1);
-      av[u] = pA[r * (unsigned)P.lda]; bv[u] = pB[r * (unsigned)P.ldb];      // (32-bit element offsets from the uniform bases)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < UN; u += 2) {
-      const bool in0 = rb + 4 * u + lc < rEnd, in1 = rb + 4 * (u + 1) + lc < rEnd;
-      const float a0 = in0 ? (aOne ? 1.f : (aOk ? av[u] : 0.f)) : 0.f, b0 = (in0 && bOk) ? bv[u] : 0.f;
-      const float a1 = in1 ? (aOne ? 1.f : (aOk ? av[u + 1] : 0.f)) : 0.f, b1 = (in1 && bOk) ? bv[u + 1] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-    }
-  }
-}
 // nq: workgroups per tile (1: a tile's whole reduction in one workgroup -- minibatch rows only, no hand-off; DW_WIDE_Q: row quarters)
 __global__ __launch_bounds__(DWW_NT) void dw_wide_kernel(const GemmProblem* __restrict__ probs, int nProbs, int nTiles, int nq, float* __restrict__ part,
                                                          unsigned* __restrict__ ctr, const DevScalars* __restrict__ sc, AdamHyper hyp,
