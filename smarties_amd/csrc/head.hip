@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   }
   // hand the (episode, next-row) map of THIS minibatch to the bookkeeping pass, which runs while
   // the sampler already overwrites bt.eid / bt.nextOf for the next step
-  if (!isNext && lane == 0) { a.bt.pEid[b] = a.bt.eid[b]; a.bt.pNextOf[b] = a.bt.nextOf[b]; }
+  // (requested here, stored with the write-backs at the end: a store right behind its load makes the wavefront wait for EVERY load
+  //  issued so far -- a whole round trip in front of the replay rows' loads below)
+  int eidv = 0, nxtv = 0;
+  if (!isNext && lane == 0) { eidv = a.bt.eid[b]; nxtv = a.bt.nextOf[b]; }
+  const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;      // (no launch between the update of beta and this kernel: step_exec.h)
   const float bo = lane < nDense ? a.params[a.indBo + lane] : 0.f;
   const float bo2 = (mid && lane < 8 && 8 + lane < nDense) ? a.params[a.indBo + 8 + lane] : 0.f;
   const float bp = lane < a.nSig ? a.params[a.indBp + lane] : 0.f;
@@ -173,7 +177,6 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
 
   HSTAMP(3);
   // ---- head: results shared by the write-back / back-propagation tail -------------------------------------
-  const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
   double xRHO = 1, xDKL = 0, xV = 0, xdQ = 0, xAval = 0; bool xfar = false; double xg0 = 0;
   if (lead) {
   if (a.nOpt) {
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
       sDelta[ws][0] = (float)xg0;
       a.bt.G[(size_t)b * a.nOut] = (double)(float)xg0;
       a.bt.rho[b] = xRHO; a.bt.dkl[b] = xDKL; a.bt.far[b] = xfar ? 1 : 0;
+      a.bt.pEid[b] = eidv; a.bt.pNextOf[b] = nxtv;      // the (episode, next-row) map of THIS minibatch for the bookkeeping pass
       // write-backs (Fval casts, MiniBatch.h:161-175); old values kept for the aggregate updates
       const float E = (float)xdQ, D = (float)xDKL, Wn = (float)xRHO, Vf = (float)xV;
       a.bt.oldDQ[b] = oDQ; a.bt.oldDKL[b] = oDKL; a.bt.oldW[b] = oW; a.bt.oldV[b] = oV; a.bt.oldADV[b] = oADV;
