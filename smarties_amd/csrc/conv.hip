@@ -18,6 +18,7 @@
 //             in chunk order by conv_reduce_adam_kernel, which also applies Adam -- bit-deterministic
 //   bias      column sums of D over the batch: RED_COL problems of the common weight-gradient launch (gemm16.hip)
 #include "dev_common.h"
+#include "dw_wide_dev.h"
 
 namespace hl {
 
@@ -831,6 +832,20 @@ __global__ __launch_bounds__(256) void conv_dw_all_kernel(ConvArgs a, int l, int
   if (bx < nRowBlocks) { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); }
   else convDwBody(a, bx - nRowBlocks, smem);
 }
+// ... and, behind them, the tiles of the dense layers' weight gradients (dw_wide_dev.h: one workgroup per 16 x 16 tile, operands
+// straight from memory, Adam in the epilogue; minibatches of at most 128 rows) with that launch's far-policy count + beta rider in front: three independent latency-bound families of
+// workgroups share the chip instead of queueing as two launches (Layer_Conv2D.h:88-139 and Layers.h:164-187 need the deltas only)
+template <int CT>
+__global__ __launch_bounds__(256) void conv_dw_dense_kernel(ConvArgs a, int l, int nRowBlocks, int nConvDw, const GemmProblem* __restrict__ probs, int nProbs,
+                                                            int nTiles, AdamHyper hyp, ExtraArgs extra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int bx = (int)blockIdx.x;
+  if (extra.role) { if (bx == 0) { if (extra.role == 3) farBetaPhase(extra.post, smem); return; } --bx; }
+  if (bx < nRowBlocks) { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); return; }
+  bx -= nRowBlocks;
+  if (bx < nConvDw) { convDwBody(a, bx, smem); return; }
+  dwWideBody<16>(probs, nProbs, nTiles, 1, nullptr, nullptr, a.sc, hyp, bx - nConvDw, smem);      // (B <= 128: launch_conv_dw_dense)
+}
 static size_t convRowsDwLds(const ConvGeo& g) {
   const int ct = (g.KnC + 15) / 16, ldD = g.rbRows * g.OpX + 4;
   return ((size_t)g.InC * g.rbWin * g.InX + (size_t)ct * 16 * ldD + (size_t)g.rbRows * g.OpX + 4) * 4;
@@ -916,6 +931,27 @@ hipError_t launch_conv_dw_all(const ConvArgs& a, int l, int dwBlocks, hipStream_
   } else if (ct == 2) {
     hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_all_kernel<2>), lds); if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_dw_all_kernel<2>, dim3(nRowBlocks + dwBlocks), dim3(256), lds, s, a, l, nRowBlocks);
+  } else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_dw_dense(const ConvArgs& a, int l, int dwBlocks, const GemmProblem* dProbs, int nProbs, int nTiles, const AdamHyper& hyp,
+                                const ExtraArgs* extra, hipStream_t s) {
+  const ConvGeo& g = a.L[l];
+  size_t lds = convRowsDwLds(g); if (lds < CONV_DW_LDS) lds = CONV_DW_LDS;
+  if (lds < (size_t)DWW_LDS) lds = DWW_LDS;
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  ex.helpers = 0;
+  if (ex.role && lds < (size_t)TAIL_LDS_BYTES) lds = TAIL_LDS_BYTES;
+  if (hyp.push.on || (ex.role && ex.role != 3)) return hipErrorInvalidValue;      // (replicas pushing tiles into peer windows keep the common launch; the one rider served: far-policy count + beta)
+  const int ct = (g.KnC + 15) / 16, nRowBlocks = g.rbCount * a.B;
+  const unsigned grid = (unsigned)((ex.role ? 1 : 0) + nRowBlocks + dwBlocks + ((nTiles + 7) / 8) * 8);
+  if (ct == 1) {
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_dense_kernel<1>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_dw_dense_kernel<1>, dim3(grid), dim3(256), lds, s, a, l, nRowBlocks, dwBlocks, dProbs, nProbs, nTiles, hyp, ex);
+  } else if (ct == 2) {
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dw_dense_kernel<2>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_dw_dense_kernel<2>, dim3(grid), dim3(256), lds, s, a, l, nRowBlocks, dwBlocks, dProbs, nProbs, nTiles, hyp, ex);
   } else return hipErrorInvalidValue;
   return hipGetLastError();
 }

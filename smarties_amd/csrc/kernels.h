@@ -184,6 +184,9 @@ hipError_t launch_xchg_clean(unsigned char* win, size_t slotsOffset, size_t slot
 // workgroups (gatherHelper) through DevScalars::gatherFlag
 enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7, PH_PUBLISH = 8 };
 struct ExtraArgs { int role; int phases; SampleArgs samp; PostArgs post; int helpers; /* head kernel: gather helper workgroups behind the rider (PH_PUBLISH) */ };
+// conv_dw_all plus the dense layers' weight-gradient tiles (one workgroup per tile, dw_wide_dev.h) and that launch's rider as ONE launch
+hipError_t launch_conv_dw_dense(const ConvArgs& a, int l, int dwBlocks, const GemmProblem* dProbs, int nProbs, int nTiles, const AdamHyper& hyp,
+                                const ExtraArgs* extra, hipStream_t s);
 
 // fused forward + head + dX kernel of the two-hidden-layer MLP (fused.hip)
 struct FusedArgs {

@@ -534,6 +534,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     else
     HIPCK(timed(h, nm, s, [&] { return launch_gemm(GEMM_ROLE_DX, h->dProbs + sb.dxIdx[i], 1, sb.dxBlocks[i], h->sc, hyp, i == 0 ? pex : nullptr, s); }));
   }
+  bool denseMerged = false;
   if (h->nConv > 0) {   // convolutional layers: input gradients from the last one down, then every filter gradient (+ Adam)
     ConvArgs ca = convArgs(h, parity);
     if (convFromReplay(h)) {      // (the backward pass belongs to a training step: the rows were never stacked)
@@ -547,6 +548,15 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     }
     int nRb = 0, lRb = -1;
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) { ++nRb; lRb = l; }
+    // the dense layers' weight-gradient tiles depend on the deltas only, like the filter gradients: with one workgroup per tile and
+    // no second rider they join the filter-gradient launch (their Adam pass touches no parameter conv_reduce_adam touches)
+    denseMerged = nRb == 1 && h->convDwBlocks > 0 && h->convDwDense && h->directDw && !h->recurrent && sb.splitMaxMN == 0 && sb.bigDw.empty()
+                  && !hyp.push.on && sb.dwBlocks >= h->directDwMinTiles && !sampleC && !(sb.dxIdx.empty() && pex);
+    for (int i = 0; denseMerged && i < sb.dwCount; ++i) if (h->hostProbs[sb.dwIdx + i].K > 128) denseMerged = false;      // (the instantiated row batches)
+    if (denseMerged) {
+      HIPCK(timed(h, "conv_dw_dense", s, [&] {
+        return launch_conv_dw_dense(ca, lRb, h->convDwBlocks, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, hyp, pexF, s); }));
+    } else
     if (nRb == 1 && h->convDwBlocks > 0 && !getenv("SMARTIES_HIP_CONV_DW_SPLIT")) {      // the two filter-gradient launches depend on the deltas only: one launch (the variable: two, for profiles)
       HIPCK(timed(h, "conv_dw_all", s, [&] { return launch_conv_dw_all(ca, lRb, h->convDwBlocks, s); }));
     } else {
@@ -555,6 +565,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     }
     ca.sc = h->sc;      // (the learning rate of the step)
     HIPCK(timed(h, "conv_reduce_adam", s, [&] { return launch_conv_reduce_adam(ca, hyp, fuseAdam ? 1 : 0, s); }));
+    if (denseMerged) return HL_OK;
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
   // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.
