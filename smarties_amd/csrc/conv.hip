@@ -295,11 +295,18 @@ __host__ __device__ inline size_t convDxLds(const ConvGeo& g, int IT) {
 // KS waves share the reduction of one tile (NK > 0): the chain per wavefront is NK / KS steps, partial tiles meet in LDS in wave
 // order (fixed summation order), the first wave of a tile applies act' and stores
 template <int IT, int NK>     // input-channel tiles per workgroup (NK > 0: 1, the tile of blockIdx.y); MFMA steps (0: run-time)
-__global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l) {
+__global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l, DenseRide ride) {
   constexpr int KS = NK > 0 ? 4 / IT : 1;      // waves per tile
   const int itBase = NK > 0 ? blockIdx.y : 0;
   __shared__ float sRed[4][256];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // behind the launch's own workgroups: weight-gradient tiles of the dense layers (their deltas were final before this launch; a
+  // launch of this kind leaves most of the chip idle) -- dw_wide_dev.h, one workgroup per tile
+  if (ride.tile1 > ride.tile0 && (int)blockIdx.x >= ride.own) {
+    const int gt = ride.tile0 + ((int)blockIdx.x - ride.own) * (int)gridDim.y + (int)blockIdx.y;
+    if (gt < ride.tile1) dwWideBody<16>(ride.probs, ride.nProbs, ride.tile1, 1, nullptr, nullptr, a.sc, ride.hyp, gt, smem);
+    return;
+  }
   const ConvGeo g = a.L[l];
   const ConvGeo gp = a.L[l - 1];                    // the layer whose outputs are this layer's inputs
   const int KK = g.KnC * g.KnY * g.KnX, KKp = convPad4(KK), ldKK = KKp + 4, P = g.P, Pin = g.InY * g.InX;
@@ -507,35 +514,39 @@ template <int IT> static hipError_t launchConvDxsC(const ConvArgs& a, int l, hip
   if (nk == 36) return launchConvDxsT<1, 36>(a, l, IT, s);         // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
   return launchConvDxsT<IT, 0>(a, l, 1, s);
 }
-template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, int ity, hipStream_t s) {
-  const size_t lds = convDxLds(a.L[l], IT);
+template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, int ity, const DenseRide* ride, hipStream_t s) {
+  size_t lds = convDxLds(a.L[l], IT);
   constexpr int PW = NK > 0 ? 1 : 4 / IT;       // (NK > 0: the four waves of a workgroup share one tile's reduction)
   const int blocks = (int)((R + 16 * PW - 1) / (16 * PW));
+  DenseRide rd{}; int extra = 0;
+  if (ride && ride->tile1 > ride->tile0) { rd = *ride; rd.own = blocks; extra = (rd.tile1 - rd.tile0 + ity - 1) / ity; if (lds < (size_t)DWW_LDS) lds = DWW_LDS; }
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dx_kernel<IT, NK>), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((conv_dx_kernel<IT, NK>), dim3(blocks, ity), dim3(256), lds, s, a, l);
+  hipLaunchKernelGGL((conv_dx_kernel<IT, NK>), dim3(blocks + extra, ity), dim3(256), lds, s, a, l, rd);
   return hipGetLastError();
 }
-template <int IT> static hipError_t launchConvDxC(const ConvArgs& a, int l, long long R, hipStream_t s) {
+template <int IT> static hipError_t launchConvDxC(const ConvArgs& a, int l, long long R, const DenseRide* ride, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const int nk = convPad4(g.KnC * g.KnY * g.KnX) / 4;
-  if (nk == 128) return launchConvDxT<1, 128>(a, l, R, IT, s);      // 32 filters of 4 x 4
-  if (nk == 144) return launchConvDxT<1, 144>(a, l, R, IT, s);      // 16 of 6 x 6, 64 of 3 x 3
-  return launchConvDxT<IT, 0>(a, l, R, 1, s);
+  if (nk == 128) return launchConvDxT<1, 128>(a, l, R, IT, ride, s);      // 32 filters of 4 x 4
+  if (nk == 144) return launchConvDxT<1, 144>(a, l, R, IT, ride, s);      // 16 of 6 x 6, 64 of 3 x 3
+  return launchConvDxT<IT, 0>(a, l, R, 1, ride, s);
 }
-hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s) {
+bool conv_dx_rides(const ConvGeo& g) { return !convStrided(g) && (g.InC + 15) / 16 <= 4; }      // the launches that take DenseRide tiles
+hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s, const DenseRide* ride) {
   const ConvGeo& g = a.L[l];
   const long long R = (long long)a.B * g.InY * g.InX;
   const int IT = (g.InC + 15) / 16;
   if (convStrided(g)) {
+    if (ride && ride->tile1 > ride->tile0) return hipErrorInvalidValue;      // (conv_dx_rides)
     if (IT == 1) return launchConvDxsC<1>(a, l, s);
     if (IT == 2) return launchConvDxsC<2>(a, l, s);
     if (IT <= 4) return launchConvDxsC<4>(a, l, s);
     return hipErrorInvalidValue;
   }
-  if (IT == 1) return launchConvDxC<1>(a, l, R, s);
-  if (IT == 2) return launchConvDxC<2>(a, l, R, s);
-  if (IT <= 4) return launchConvDxC<4>(a, l, R, s);
+  if (IT == 1) return launchConvDxC<1>(a, l, R, ride, s);
+  if (IT == 2) return launchConvDxC<2>(a, l, R, ride, s);
+  if (IT <= 4) return launchConvDxC<4>(a, l, R, ride, s);
   return hipErrorInvalidValue;
 }
 

@@ -130,7 +130,11 @@ hipError_t launch_extras_copy(const DevScalars* sc, int parity, const float* X0,
 hipError_t launch_conv_prep(const ConvArgs& a, hipStream_t s);              // filters -> LDS layouts (once per step)
 long long conv_prep_floats(const ConvGeo& g, int which);                   // floats of Wf (0) / Wx (1)
 hipError_t launch_conv_forward(const ConvArgs& a, int l, int maxRows, hipStream_t s);
-hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s);       // D of layer l-1 from D of layer l
+// weight-gradient tiles [tile0, tile1) of a dW problem table riding behind the workgroups of another launch (dw_wide_dev.h)
+struct GemmProblem;
+struct DenseRide { const GemmProblem* probs; int nProbs, tile0, tile1, own; AdamHyper hyp; };
+hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s, const DenseRide* ride = nullptr);       // D of layer l-1 from D of layer l
+bool conv_dx_rides(const ConvGeo& g);
 hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);
 int conv_row_block(const ConvGeo& g, int* win);
 bool conv_rows_ok(const ConvGeo& g);                                          // the shape the row-block kernels are instantiated for                               // rows per workgroup of the row-block kernels (0: layer not served)

@@ -65,6 +65,7 @@ struct hl_learner {
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
   bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
   bool wideDw = true;         // recurrent nets: weight gradients over all (sample, step) rows as one launch without a split-row join (SMARTIES_HIP_WIDE_DW=0: (tile, chunk) workgroups + splitk_reduce_kernel)
+  bool convDxRide = true;       // ... and what of them needs no convolutional delta behind the unstrided layers' input-gradient launches (SMARTIES_HIP_CONV_DX_RIDE=0)
   bool convDwDense = true;      // convolutional nets: those tiles inside the filter-gradient launch (SMARTIES_HIP_CONV_DW_DENSE=0: a launch of their own)
   bool directDw = true; int directDwMinTiles = 128;      // weight-gradient launches of >= this many unsplit tiles take dw_wide_kernel's one-workgroup-per-tile form (SMARTIES_HIP_DIRECT_DW=0 / =<min tiles>)
   bool recFused = true;       // two LSTM layers of 32 cells: forward, head and backward of a sample as one launch (rec.hip: lstm32_step_wave_kernel; SMARTIES_HIP_REC_FUSED=0: the three launches)
@@ -644,6 +645,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->panelHead = h->B >= 2048 || cfg->nn_type != HL_NN_FFNN;      // (measured: recurrent nets 68.5 -> 66.5 us per step at 2 x 32 cells; the 512-wide Atari head 152.5 -> 156.9: one wavefront set per sample there)
   if (const char* e = getenv("SMARTIES_HIP_PANEL_HEAD")) h->panelHead = e[0] == '1';
   if (const char* e = getenv("SMARTIES_HIP_REC_FUSED")) h->recFused = e[0] == '1';
+  if (const char* e = getenv("SMARTIES_HIP_CONV_DX_RIDE")) h->convDxRide = atoi(e) != 0;
   if (const char* e = getenv("SMARTIES_HIP_CONV_DW_DENSE")) h->convDwDense = atoi(e) != 0;
   if (const char* e = getenv("SMARTIES_HIP_DIRECT_DW")) { const int v = atoi(e); h->directDw = v != 0; if (v > 1) h->directDwMinTiles = v; }
   if (const char* e = getenv("SMARTIES_HIP_WIDE_DW")) h->wideDw = e[0] == '1';

@@ -542,10 +542,6 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
       if (h->recurrent) { ca.src.slot = h->winSlot; ca.src.t = h->winT; ca.src.nextSrc = h->winNextSrc; }      // (windows: launchFront)
     }
     if (h->recurrent) ca.sc = h->scW;
-    for (int l = h->nConv - 1; l >= 1; --l) {
-      snprintf(nm, sizeof(nm), "conv_dx%d", l);
-      HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s); }));
-    }
     int nRb = 0, lRb = -1;
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) { ++nRb; lRb = l; }
     // the dense layers' weight-gradient tiles depend on the deltas only, like the filter gradients: with one workgroup per tile and
@@ -553,9 +549,28 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     denseMerged = nRb == 1 && h->convDwBlocks > 0 && h->convDwDense && h->directDw && !h->recurrent && sb.splitMaxMN == 0 && sb.bigDw.empty()
                   && !hyp.push.on && sb.dwBlocks >= h->directDwMinTiles && !sampleC && !(sb.dxIdx.empty() && pex);
     for (int i = 0; denseMerged && i < sb.dwCount; ++i) if (h->hostProbs[sb.dwIdx + i].K > 128) denseMerged = false;      // (the instantiated row batches)
+    // ... and the tiles behind the convolution biases' column sums (the table's first nConv problems) need no delta of a
+    // convolutional layer: they ride the input-gradient launches of the unstrided layers (a few hundred workgroups each), in equal shares
+    const GemmProblem* dwProbs = h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx);
+    int rideT0 = sb.dwBlocks, nRideL = 0;
+    if (denseMerged && h->convDxRide && sb.dwCount > h->nConv) {
+      for (int l = h->nConv - 1; l >= 1; --l) if (conv_dx_rides(ca.L[l])) ++nRideL;
+      if (nRideL) rideT0 = h->hostProbs[sb.dwIdx + h->nConv].tileStart;
+    }
+    int rideNext = rideT0, rideLeft = nRideL;
+    for (int l = h->nConv - 1; l >= 1; --l) {
+      snprintf(nm, sizeof(nm), "conv_dx%d", l);
+      DenseRide rd{}; const DenseRide* prd = nullptr;
+      if (rideLeft > 0 && conv_dx_rides(ca.L[l])) {
+        const int share = (sb.dwBlocks - rideNext + rideLeft - 1) / rideLeft;
+        rd.probs = dwProbs; rd.nProbs = sb.dwCount; rd.tile0 = rideNext; rd.tile1 = rideNext + share; rd.hyp = hyp; prd = &rd;
+        rideNext += share; --rideLeft;
+      }
+      HIPCK(timed(h, nm, s, [&] { return launch_conv_dx(ca, l, s, prd); }));
+    }
     if (denseMerged) {
       HIPCK(timed(h, "conv_dw_dense", s, [&] {
-        return launch_conv_dw_dense(ca, lRb, h->convDwBlocks, h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), sb.dwCount, sb.dwBlocks, hyp, pexF, s); }));
+        return launch_conv_dw_dense(ca, lRb, h->convDwBlocks, dwProbs, sb.dwCount, rideT0, hyp, pexF, s); }));
     } else
     if (nRb == 1 && h->convDwBlocks > 0 && !getenv("SMARTIES_HIP_CONV_DW_SPLIT")) {      // the two filter-gradient launches depend on the deltas only: one launch (the variable: two, for profiles)
       HIPCK(timed(h, "conv_dw_all", s, [&] { return launch_conv_dw_all(ca, lRb, h->convDwBlocks, s); }));
