@@ -644,6 +644,7 @@ int conv_row_block(const ConvGeo& g, int* win) {
     const double eff = (double)(rb * g.OpX) / (16.0 * ((tiles + 3) / 4 * 4));      // filled MFMA columns per round of four wavefronts
     if (eff > bestEff + 1e-9 || (eff > bestEff - 0.05 && rb > best)) { if (eff > bestEff) bestEff = eff; best = rb; }
   }
+  if (const char* e = getenv("SMARTIES_HIP_CONV_RB")) { const int v = atoi(e); if (v >= 1 && v <= g.OpY) best = v; }      // (experiments)
   if (best && win) *win = (best - 1) * g.S + g.KnY;
   return best;
 }
@@ -671,10 +672,14 @@ __device__ __forceinline__ void stageWindowReplay(float* sIn, const ConvSource& 
   const int C0 = g.InC / (1 + src.nApp), chStride4 = (g.InY * g.InX) >> 2, base4 = (iy0 * g.InX) >> 2, ldsCh4 = (wr * g.InX) >> 2;
   const f32x4* m4 = reinterpret_cast<const f32x4*>(src.mean); const f32x4* s4 = reinterpret_cast<const f32x4*>(src.scale);
   f32x4* dst = reinterpret_cast<f32x4*>(sIn);
-  for (int q0 = 0; q0 < total; q0 += 256 * 4) {
-    f32x4 v[4], mu[4], sc[4];
+#ifndef CONV_WU
+#define CONV_WU 4
+#endif
+  constexpr int WU = CONV_WU;      // (8 -- the whole 84 x 84 x 4 window of five output rows in one batch -- costs a wavefront per SIMD: 143.6 -> 152.5 us per step)
+  for (int q0 = 0; q0 < total; q0 += 256 * WU) {
+    f32x4 v[WU], mu[WU], sc[WU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < WU; ++u) {
       const int i = q0 + threadIdx.x + 256 * u;
       if (i < total) {
         const int ic = i / perCh, r = i - ic * perCh, j = ic / C0, c0 = ic - j * C0, back = j < t ? j : t;
@@ -683,7 +688,7 @@ __device__ __forceinline__ void stageWindowReplay(float* sIn, const ConvSource& 
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < WU; ++u) {
       const int i = q0 + threadIdx.x + 256 * u;
       if (i < total) {
         const int ic = i / perCh, r = i - ic * perCh;
@@ -704,9 +709,21 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
   float* sIn = reinterpret_cast<float*>(smem);                       // [InC][WR][InX]
   float* Ws = sIn + (size_t)g.InC * WR * g.InX;                      // [CT 16][ldK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  stageFlat<(CT * 16 * (4 * NK + 4) / 4 + 255) / 256>(Ws, g.Wf, CT * 16 * ldK);
+  // (the filter rows' loads are issued in front of the window's and stored behind them: one exposed latency, not two)
+  constexpr int WQ = (CT * 16 * (4 * NK + 4) / 4 + 255) / 256;
+  f32x4 wv[WQ];
+  {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.Wf); const int n4 = (CT * 16 * ldK) >> 2;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; wv[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
   if (a.src.on) stageWindowReplay(sIn, a.src, row, a.B, g, iy0, WR, wrValid);
   else stageWindow(sIn, g.in + (long long)row * g.ldIn, g, iy0, WR, wrValid);
+  {
+    f32x4* d4 = reinterpret_cast<f32x4*>(Ws); const int n4 = (CT * 16 * ldK) >> 2;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; if (i < n4) d4[i] = wv[q]; }
+  }
   // window-relative offset of patch element k = 4 s + lc: KnX is a multiple of 4, so the four elements of a step lie side by
   // side in one filter row -- offset(4 s) is uniform (scalar registers), the lane adds lc
   constexpr int fsz = KNY * KNX;
@@ -783,9 +800,20 @@ __device__ __forceinline__ void convDwRowsBody(const ConvArgs& a, int l, int rb,
   float* sD = sIn + (size_t)g.InC * WR * g.InX;                      // [CT 16][ldD]   deltas of this block's positions, zero padded
   int* sPos = reinterpret_cast<int*>(sD + (size_t)CT * 16 * ldD);    // [RB OpX + 4]    window offset of the patch origin of position r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  // (the first deltas are requested in front of the window's pieces and stored behind them: their latency hides under the window's)
+  constexpr int DQ = 8 * CT;
+  float dreg[DQ];
+  const int nD = CT * 16 * ldD;
+#pragma unroll
+  for (int q = 0; q < DQ; ++q) {
+    const int i = tid + 256 * q, c = i / ldD, r = i - c * ldD;
+    dreg[q] = (i < nD && c < g.KnC && r < nPos) ? g.D[(size_t)b * g.ldOut + (size_t)c * P + oy0 * g.OpX + r] : 0.f;
+  }
   if (a.src.on) stageWindowReplay(sIn, a.src, b, a.B, g, iy0, WR, wrValid);
   else stageWindow(sIn, g.in + (long long)b * g.ldIn, g, iy0, WR, wrValid);
-  for (int i = tid; i < CT * 16 * ldD; i += 256) {
+#pragma unroll
+  for (int q = 0; q < DQ; ++q) { const int i = tid + 256 * q; if (i < nD) sD[i] = dreg[q]; }
+  for (int i = tid + 256 * DQ; i < nD; i += 256) {
     const int c = i / ldD, r = i - c * ldD;
     sD[i] = (c < g.KnC && r < nPos) ? g.D[(size_t)b * g.ldOut + (size_t)c * P + oy0 * g.OpX + r] : 0.f;
   }

@@ -329,6 +329,7 @@ struct PerArgs {
 };
 hipError_t launch_per_prepare(const PerArgs& a, long long nTransitions, hipStream_t s);
 size_t per_sort_temp_bytes(long long n);
+hipError_t launch_per_scan(const float* prob, double* cp, long long n, int which, hipStream_t s);      // (tests: the table of any probability array)
 struct HistArgs { DevReplay rp; int nEpisodes; float bounds[82]; unsigned long long* counts; };
 hipError_t launch_impw_hist(const HistArgs& a, hipStream_t s);
 int sweep_blocks(int count);

@@ -2207,6 +2207,21 @@ extern "C" HL_API int64_t hl_debug_per_table(hl_learner* h, float* prob, double*
   if (cp && hipMemcpy(cp, h->perCp, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return n;
 }
+// the discrete distribution's cumulative table of n host probabilities by the scan kernel (which = 0) or the sequential walk
+// (which = 1) of per.hip; returns the kernel's milliseconds (HIP events), negative on failure
+extern "C" HL_API double hl_debug_per_scan(const float* prob, double* cp, int64_t n, int which) {
+  if (!prob || !cp || n < 2) return -1;
+  float* dP = nullptr; double* dC = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; float ms = -1;
+  bool ok = hipMalloc(&dP, n * sizeof(float)) == hipSuccess && hipMalloc(&dC, n * sizeof(double)) == hipSuccess
+            && hipMemcpy(dP, prob, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemset(dC, 0, n * sizeof(double)) == hipSuccess
+            && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  if (ok) ok = launch_per_scan(dP, dC, n, which, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;      // (warm)
+  if (ok) ok = hipEventRecord(e0, nullptr) == hipSuccess && launch_per_scan(dP, dC, n, which, nullptr) == hipSuccess && hipEventRecord(e1, nullptr) == hipSuccess
+               && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess
+               && hipMemcpy(cp, dC, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); if (dP) hipFree(dP); if (dC) hipFree(dC);
+  return ok ? (double)ms : -1.0;
+}
 extern "C" HL_API int hl_debug_step_stamps(hl_learner* h, long long out[128]) {      // (library built with -DHL_STEP_STAMPS)
   if (!h || !out) return HL_ERR_BAD_ARG;
   HL_LOCK(h);
