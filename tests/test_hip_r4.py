@@ -330,3 +330,37 @@ def test_one_launch_recurrent_step_random_shapes_match_oracle(hip_api, seed, mon
     assert np.array_equal(G.get_rng_state(), T.get_rng_state())
     assert relinf(G.get_params()[0], T.get_params()[0]) < TOL32
     assert G.scalars().nFarPolicySteps == T.scalars().nFarPolicySteps
+
+
+ATARI_KW = dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3,
+                conv=[(84, 84, 4, 8, 8, 4), (20, 20, 8, 16, 6, 2), (8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)],
+                hidden=(512,), nnFunc="Tanh", batchSize=16, maxTotObsNum=600, randSeed=11)
+ATARI_SC = dict(seed=9, dimS=7056, dimA=1, lenMin=4, lenMax=12, pTerm=0.5)
+
+
+def test_dense_weight_gradients_inside_the_convolutional_launches_change_nothing(hip_api, monkeypatch):
+    """RACER_atari-shaped step (round 4): the dense layers' weight-gradient tiles run inside the filter-gradient launch
+    (conv.hip: conv_dw_dense_kernel) and, where they need no convolutional delta, behind the unstrided layers' input-gradient
+    launches (DenseRide) instead of in a launch of their own.  Same tiles, same arithmetic: minibatches, generator and every
+    parameter must be bit-identical to the separate launches (SMARTIES_HIP_CONV_DW_DENSE=0, SMARTIES_HIP_CONV_DX_RIDE=0), eager
+    and replayed, and follow the oracle."""
+    sc = synth_cfg(**ATARI_SC)
+    G, O = _pair(hip_api, ATARI_KW, sc, 14)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(9); O.step(9)
+    _compare_step(G, O)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    ref = G.get_params()[0].copy()
+    for env in (dict(SMARTIES_HIP_CONV_DX_RIDE="0"), dict(SMARTIES_HIP_CONV_DW_DENSE="0")):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        T = capi.Learner(hip_api, capi.make_config(**ATARI_KW))
+        T.init_weights(); fill_synth(T, sc, 14); T.initialize(); T.set_tap(True)
+        T.step(1); T.step(1); T.step(9)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), T.readback(capi.TAP_FLAT))
+        assert np.array_equal(G.get_rng_state(), T.get_rng_state())
+        assert np.array_equal(ref, T.get_params()[0]), env
+        assert G.scalars().nFarPolicySteps == T.scalars().nFarPolicySteps
+        T.close()
+        for k in env: monkeypatch.delenv(k)
