@@ -326,10 +326,12 @@ struct PerArgs {
   float* prob; double* cp;                                   // [capSlots] (PERseq: [episodes])
   float *key, *keySorted; unsigned *idx, *idxSorted;         // PERrank: squared errors and flat indices, sorted descending (stable)
   void* temp; size_t tempBytes;
+  void* scan; size_t scanBytes;                              // scratch of the table's grid form (per_scan_scratch_bytes)
 };
 hipError_t launch_per_prepare(const PerArgs& a, long long nTransitions, hipStream_t s);
 size_t per_sort_temp_bytes(long long n);
-hipError_t launch_per_scan(const float* prob, double* cp, long long n, int which, hipStream_t s);      // (tests: the table of any probability array)
+size_t per_scan_scratch_bytes(long long n);
+hipError_t launch_per_scan(const float* prob, double* cp, long long n, int which, void* scratch, hipStream_t s);      // (tests: the table of any probability array; which = 0 grid form where long enough, 1 walk, 2 one workgroup)
 struct HistArgs { DevReplay rp; int nEpisodes; float bounds[82]; unsigned long long* counts; };
 hipError_t launch_impw_hist(const HistArgs& a, hipStream_t s);
 int sweep_blocks(int count);

@@ -130,7 +130,7 @@ struct hl_learner {
   double* dStatsIns = nullptr; bool statsFresh = false, anyStep = false;
   unsigned char* actPin = nullptr; unsigned actTag = 0; bool actFastOk = false;     // rollout inference of a few agents (hl_forward)
   // prioritised samplers (per.hip): probabilities / cumulative table of the stored transitions, rebuilt before every minibatch
-  float *perProb = nullptr, *perKey = nullptr, *perKeyS = nullptr; double* perCp = nullptr; unsigned *perIdx = nullptr, *perIdxS = nullptr;
+  float *perProb = nullptr, *perKey = nullptr, *perKeyS = nullptr; double* perCp = nullptr; unsigned *perIdx = nullptr, *perIdxS = nullptr; void* perScan = nullptr; size_t perScanBytes = 0;
   void* perTemp = nullptr; size_t perTempBytes = 0; long long perCap = 0;
   // staging
   void* pinned = nullptr; size_t pinnedBytes = 0;
@@ -914,7 +914,7 @@ int hl_destroy(hl_learner* h) {
     for (float* p : {d.X, d.Y, d.Rr, d.D, d.Dres}) if (p) hipFree(p); }
   if (h->pinned) hipHostFree(h->pinned);
   for (auto& st : h->stg) { if (st.host) hipHostFree(st.host); if (st.ev) hipEventDestroy(st.ev); }
-  for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp}) if (q) hipFree(q);
+  for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp, h->perScan}) if (q) hipFree(q);
   if (h->sideStream) { hipStreamSynchronize(h->sideStream); hipStreamDestroy(h->sideStream); }
   if (h->evMain) hipEventDestroy(h->evMain);
   if (h->evSide) hipEventDestroy(h->evSide);
@@ -2207,19 +2207,21 @@ extern "C" HL_API int64_t hl_debug_per_table(hl_learner* h, float* prob, double*
   if (cp && hipMemcpy(cp, h->perCp, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return n;
 }
-// the discrete distribution's cumulative table of n host probabilities by the scan kernel (which = 0) or the sequential walk
-// (which = 1) of per.hip; returns the kernel's milliseconds (HIP events), negative on failure
+// the discrete distribution's cumulative table of n host probabilities by per.hip's scan (which = 0: the grid form where the table
+// is long enough, 2: one workgroup) or its sequential walk (which = 1); returns the milliseconds of the launches (HIP events),
+// negative on failure
 extern "C" HL_API double hl_debug_per_scan(const float* prob, double* cp, int64_t n, int which) {
   if (!prob || !cp || n < 2) return -1;
-  float* dP = nullptr; double* dC = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; float ms = -1;
-  bool ok = hipMalloc(&dP, n * sizeof(float)) == hipSuccess && hipMalloc(&dC, n * sizeof(double)) == hipSuccess
+  float* dP = nullptr; double* dC = nullptr; void* dS = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; float ms = -1;
+  bool ok = hipMalloc(&dP, n * sizeof(float)) == hipSuccess && hipMalloc(&dC, n * sizeof(double)) == hipSuccess && hipMalloc(&dS, per_scan_scratch_bytes(n)) == hipSuccess
             && hipMemcpy(dP, prob, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess && hipMemset(dC, 0, n * sizeof(double)) == hipSuccess
             && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-  if (ok) ok = launch_per_scan(dP, dC, n, which, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;      // (warm)
-  if (ok) ok = hipEventRecord(e0, nullptr) == hipSuccess && launch_per_scan(dP, dC, n, which, nullptr) == hipSuccess && hipEventRecord(e1, nullptr) == hipSuccess
+  if (ok) ok = launch_per_scan(dP, dC, n, which, dS, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;      // (warm)
+  if (ok) ok = hipMemset(dC, 0, n * sizeof(double)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (ok) ok = hipEventRecord(e0, nullptr) == hipSuccess && launch_per_scan(dP, dC, n, which, dS, nullptr) == hipSuccess && hipEventRecord(e1, nullptr) == hipSuccess
                && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess
                && hipMemcpy(cp, dC, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-  if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); if (dP) hipFree(dP); if (dC) hipFree(dC);
+  if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); if (dP) hipFree(dP); if (dC) hipFree(dC); if (dS) hipFree(dS);
   return ok ? (double)ms : -1.0;
 }
 extern "C" HL_API int hl_debug_step_stamps(hl_learner* h, long long out[128]) {      // (library built with -DHL_STEP_STAMPS)

@@ -4,8 +4,8 @@
 // and builds the cumulative table with a SEQUENTIAL partial_sum; the drawn indices depend on every rounding of those two
 // chains.  Round 4: the chains are no longer WALKED -- inside a binade of the accumulator a round-to-nearest-even fp64 addition
 // is an integer step, so the table is an integer prefix sum with real additions only at binade crossings and exact ties
-// (per_scan_kernel below: bit-identical to the walk, 2.4 ms instead of 23 ms per million transitions; the reference's CPU takes
-// ~4 ms).  (The samplers are not selected by any shipped settings file, and the importance weights
+// (per_scan_kernel below: bit-identical to the walk, 2.4 ms instead of 23 ms per million transitions in one workgroup, 0.55 ms
+// in the grid form behind it; the reference's CPU takes ~4 ms).  (The samplers are not selected by any shipped settings file, and the importance weights
 // they define are not applied in this version of the reference, Approximator.h:196).  The draws themselves
 // (generate_canonical<double, 53> + lower_bound, sort / unique / redraw) run in the sampler kernel (tail_dev.h).
 #include "dev_common.h"
@@ -112,7 +112,8 @@ constexpr int PS_NT = 1024, PS_PER = 16, PS_CH = PS_NT * PS_PER, PS_HEAD = 4096;
 constexpr long long PS_TOP = 1ll << 53, PS_SAT = 1ll << 54;
 __device__ __forceinline__ long long psAdd(long long a, long long b) { const long long s = a + b; return s < PS_SAT ? s : PS_SAT; }      // (associative on non-negative numbers)
 template <bool DIV, bool WRITE>
-__device__ __forceinline__ double perChain(const float* __restrict__ prob, double S, double* __restrict__ cp, long long n, long long* sWave, double* sAcc, int* sStop, double* sHead) {
+__device__ __forceinline__ double perChain(const float* __restrict__ prob, double S, double* __restrict__ cp, long long n, long long* sWave, double* sAcc, int* sStop, double* sHead,
+                                           const long long* __restrict__ cT = nullptr, const int* __restrict__ cF = nullptr, double* __restrict__ accStart = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto elem = [&](long long j) -> double { const double p = (double)prob[j]; return DIV ? p / S : p; };
   const long long head = n < PS_HEAD ? n : PS_HEAD;
@@ -138,6 +139,19 @@ __device__ __forceinline__ double perChain(const float* __restrict__ prob, doubl
   double acc = *sAcc;
   for (long long pos = head; pos < n; pos += PS_CH) {
     const int cn = n - pos < PS_CH ? (int)(n - pos) : PS_CH;
+    if (cT) {      // grid form: a chunk whose integer total was computed beside (per_chunk_total_kernel) for the binade the accumulator is in, and stays in
+      const int ch = (int)((pos - head) / PS_CH), fe = cF[ch];
+      const long long bits = __double_as_longlong(acc);
+      const int ex = (int)((bits >> 52) & 0x7ff) - 1023;
+      bool easy = false;
+      if (fe && ex == fe - 4096) {
+        const double scale = __longlong_as_double((long long)(1023 + 52 - ex) << 52), u = __longlong_as_double((long long)(1023 + ex - 52) << 52);
+        const long long M1 = (long long)(acc * scale) + cT[ch];
+        if (M1 < PS_TOP) { easy = true; if (accStart && tid == 0) accStart[ch] = acc; acc = (double)M1 * u; }
+      }
+      if (easy) continue;                                                 // (uniform: every thread holds the same acc)
+      if (accStart && tid == 0) accStart[ch] = -1.0;                      // walked here, written here
+    }
     double x[PS_PER];
 #pragma unroll
     for (int i = 0; i < PS_PER; ++i) { const int g = tid * PS_PER + i; x[i] = g < cn ? elem(pos + g) : 0.0; }
@@ -210,6 +224,141 @@ __device__ __forceinline__ double perChain(const float* __restrict__ prob, doubl
   }
   return acc;
 }
+// ---- the grid form for long tables: the chunks' integer totals are computed by one workgroup per chunk beside each other, for the
+// binade a parallel (approximate) prefix sum PREDICTS for the chunk; the serial pass then steps over a chunk with one addition of
+// integers after CHECKING the prediction exactly (accumulator in that binade before and after the chunk, no tie inside) and walks
+// the others -- those with a binade crossing or a tie, and any the prediction got wrong -- as above; the cumulative values of the
+// stepped-over chunks are written by a grid again.  Scratch (doubles): [0] sum of the table, [1 .. nB] approximate sums of the head
+// and of the chunks, [1 + nB ..] the accumulator at the chunks' starts; behind them the int64 totals and the int flags.
+template <bool DIV> __device__ __forceinline__ double psElemAt(const float* __restrict__ prob, double S, long long j) { const double p = (double)prob[j]; return DIV ? p / S : p; }
+__device__ __forceinline__ double psBlockSumD(double v, double* sRed) {      // (any order: only the prediction uses it)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < PS_NT / 64; ++w) s += sRed[w];
+  return s;
+}
+template <bool DIV>
+__global__ __launch_bounds__(PS_NT) void per_chunk_approx_kernel(const float* __restrict__ prob, const double* __restrict__ scr, double* __restrict__ approx, long long n) {
+  __shared__ double sRed[PS_NT / 64];
+  const long long head = n < PS_HEAD ? n : PS_HEAD;
+  const double S = DIV ? scr[0] : 1.0;
+  const long long b0 = blockIdx.x == 0 ? 0 : head + (long long)(blockIdx.x - 1) * PS_CH;
+  const long long b1 = blockIdx.x == 0 ? head : (b0 + PS_CH < n ? b0 + PS_CH : n);
+  double v = 0.0;
+  for (long long j = b0 + threadIdx.x; j < b1; j += PS_NT) v += psElemAt<DIV>(prob, S, j);
+  v = psBlockSumD(v, sRed);
+  if (threadIdx.x == 0) approx[blockIdx.x] = v;
+}
+template <bool DIV>
+__global__ __launch_bounds__(PS_NT) void per_chunk_total_kernel(const float* __restrict__ prob, const double* __restrict__ scr, const double* __restrict__ approx,
+                                                               long long* __restrict__ cT, int* __restrict__ cF, long long n) {
+  __shared__ double sRed[PS_NT / 64];
+  __shared__ long long sTot[PS_NT / 64];
+  __shared__ int sTie;
+  const int ch = blockIdx.x, tid = threadIdx.x;
+  const long long head = n < PS_HEAD ? n : PS_HEAD;
+  const double S = DIV ? scr[0] : 1.0;
+  double v = 0.0;
+  for (int b = tid; b <= ch; b += PS_NT) v += approx[b];                  // head + the chunks in front of this one
+  if (tid == 0) sTie = 0;
+  const double s0 = psBlockSumD(v, sRed), s1 = s0 + approx[ch + 1];
+  const double lo = s0 * (1.0 - 1e-9), hi = s1 * (1.0 + 1e-9);
+  const int e0 = (int)((__double_as_longlong(lo) >> 52) & 0x7ff) - 1023, e1 = (int)((__double_as_longlong(hi) >> 52) & 0x7ff) - 1023;
+  if (e0 != e1 || !(lo > 0.0)) { if (tid == 0) { cF[ch] = 0; cT[ch] = 0; } return; }      // (uniform)
+  const double scale = __longlong_as_double((long long)(1023 + 52 - e0) << 52);
+  const long long pos = head + (long long)ch * PS_CH;
+  const int cn = n - pos < PS_CH ? (int)(n - pos) : PS_CH;
+  long long run = 0; bool tie = false;
+#pragma unroll
+  for (int i = 0; i < PS_PER; ++i) {
+    const int g = tid * PS_PER + i;
+    if (g < cn) {
+      const double y = psElemAt<DIV>(prob, S, pos + g) * scale;
+      if (y >= 9007199254740992.0) run = PS_SAT;
+      else { const long long k = (long long)y; const double f = y - (double)k; run = psAdd(run, k + (f > 0.5 ? 1 : 0)); tie = tie || f == 0.5; }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) run = psAdd(run, __shfl_xor(run, d, 64));
+  if ((tid & 63) == 0) sTot[tid >> 6] = run;
+  if (tie) sTie = 1;
+  __syncthreads();
+  if (tid == 0) {
+    long long t = 0;
+    for (int w = 0; w < PS_NT / 64; ++w) t = psAdd(t, sTot[w]);
+    cT[ch] = t; cF[ch] = (sTie || t >= PS_TOP) ? 0 : e0 + 4096;
+  }
+}
+// the serial pass (one workgroup); WRITE: the cumulative values of the head and of the chunks it walks, else the table's sum to scr[0]
+template <bool DIV, bool WRITE>
+__global__ __launch_bounds__(PS_NT) void per_chain_grid_kernel(const float* __restrict__ prob, double* __restrict__ scr, double* __restrict__ cp, long long n,
+                                                              const long long* __restrict__ cT, const int* __restrict__ cF, double* __restrict__ accStart) {
+  __shared__ long long sWave[PS_NT / 64];
+  __shared__ double sAcc;
+  __shared__ int sStop[1];
+  __shared__ double sHead[PS_HEAD];
+  const double S = perChain<DIV, WRITE>(prob, DIV ? scr[0] : 1.0, cp, n, sWave, &sAcc, sStop, sHead, cT, cF, WRITE ? accStart : nullptr);
+  __syncthreads();
+  if (threadIdx.x == 0) { if (WRITE) cp[n - 1] = 1.0; else scr[0] = S; }
+}
+// the cumulative values of the chunks the serial pass stepped over
+template <bool DIV>
+__global__ __launch_bounds__(PS_NT) void per_chunk_write_kernel(const float* __restrict__ prob, const double* __restrict__ scr, const double* __restrict__ accStart,
+                                                               double* __restrict__ cp, long long n) {
+  __shared__ long long sWave[PS_NT / 64];
+  const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double acc = accStart[ch];
+  if (!(acc > 0.0)) return;                                               // walked (and written) by the serial pass
+  const long long head = n < PS_HEAD ? n : PS_HEAD;
+  const double S = DIV ? scr[0] : 1.0;
+  const int ex = (int)((__double_as_longlong(acc) >> 52) & 0x7ff) - 1023;
+  const double scale = __longlong_as_double((long long)(1023 + 52 - ex) << 52), u = __longlong_as_double((long long)(1023 + ex - 52) << 52);
+  const long long M0 = (long long)(acc * scale);
+  const long long pos = head + (long long)ch * PS_CH;
+  const int cn = n - pos < PS_CH ? (int)(n - pos) : PS_CH;
+  long long loc[PS_PER]; long long run = 0;
+#pragma unroll
+  for (int i = 0; i < PS_PER; ++i) {
+    const int g = tid * PS_PER + i;
+    if (g < cn) { const double y = psElemAt<DIV>(prob, S, pos + g) * scale; const long long k = (long long)y; const double f = y - (double)k; run += k + (f > 0.5 ? 1 : 0); }
+    loc[i] = run;
+  }
+  long long inc = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  if (lane == 63) sWave[wave] = inc;
+  __syncthreads();
+  const long long left = __shfl_up(inc, 1, 64);
+  long long off = lane ? left : 0;
+  for (int w = 0; w < wave; ++w) off += sWave[w];
+#pragma unroll
+  for (int i = 0; i < PS_PER; ++i) { const int g = tid * PS_PER + i; if (g < cn) cp[pos + g] = pos + g == n - 1 ? 1.0 : (double)(M0 + off + loc[i]) * u; }
+}
+size_t per_scan_scratch_bytes(long long n) {
+  const long long nCh = n > PS_HEAD ? (n - PS_HEAD + PS_CH - 1) / PS_CH : 0;
+  return (size_t)(1 + (nCh + 1) + nCh) * 8 + (size_t)nCh * 8 + (size_t)nCh * 4 + 64;
+}
+constexpr long long PS_GRID_MIN = PS_HEAD + 8 * PS_CH;      // shorter tables: the one-workgroup form
+static hipError_t launchPerScanGrid(const float* prob, double* cp, long long n, void* scratch, hipStream_t s) {
+  const long long nCh = (n - PS_HEAD + PS_CH - 1) / PS_CH;
+  double* scr = reinterpret_cast<double*>(scratch);
+  double* approx = scr + 1; double* accStart = approx + (nCh + 1);
+  long long* cT = reinterpret_cast<long long*>(accStart + nCh); int* cF = reinterpret_cast<int*>(cT + nCh);
+  const unsigned g = (unsigned)nCh;
+  hipLaunchKernelGGL(per_chunk_approx_kernel<false>, dim3(g + 1), dim3(PS_NT), 0, s, prob, scr, approx, n);
+  hipLaunchKernelGGL(per_chunk_total_kernel<false>, dim3(g), dim3(PS_NT), 0, s, prob, scr, approx, cT, cF, n);
+  hipLaunchKernelGGL((per_chain_grid_kernel<false, false>), dim3(1), dim3(PS_NT), 0, s, prob, scr, cp, n, cT, cF, accStart);
+  hipLaunchKernelGGL(per_chunk_approx_kernel<true>, dim3(g + 1), dim3(PS_NT), 0, s, prob, scr, approx, n);
+  hipLaunchKernelGGL(per_chunk_total_kernel<true>, dim3(g), dim3(PS_NT), 0, s, prob, scr, approx, cT, cF, n);
+  hipLaunchKernelGGL((per_chain_grid_kernel<true, true>), dim3(1), dim3(PS_NT), 0, s, prob, scr, cp, n, cT, cF, accStart);
+  hipLaunchKernelGGL(per_chunk_write_kernel<true>, dim3(g), dim3(PS_NT), 0, s, prob, scr, accStart, cp, n);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(PS_NT) void per_scan_kernel(const float* __restrict__ prob, double* __restrict__ cp, long long n) {
   __shared__ long long sWave[PS_NT / 64];
   __shared__ double sAcc;
@@ -240,14 +389,16 @@ hipError_t launch_per_prepare(const PerArgs& a, long long nTransitions, hipStrea
   }
   static const bool seq = [] { const char* e = getenv("SMARTIES_HIP_PER_SEQ"); return e && atoi(e) != 0; }();
   if (seq) hipLaunchKernelGGL(per_scan_seq_kernel, dim3(1), dim3(64), 0, s, a.prob, a.cp, n);
+  else if (n >= PS_GRID_MIN && a.scan && a.scanBytes >= per_scan_scratch_bytes(n)) return launchPerScanGrid(a.prob, a.cp, n, a.scan, s);
   else hipLaunchKernelGGL(per_scan_kernel, dim3(1), dim3(PS_NT), 0, s, a.prob, a.cp, n);
   return hipGetLastError();
 }
 
 // the table of an arbitrary probability array (tests / tools): which = 0 the scan above, 1 the sequential walk
-hipError_t launch_per_scan(const float* prob, double* cp, long long n, int which, hipStream_t s) {
-  if (which) hipLaunchKernelGGL(per_scan_seq_kernel, dim3(1), dim3(64), 0, s, prob, cp, n);
-  else hipLaunchKernelGGL(per_scan_kernel, dim3(1), dim3(PS_NT), 0, s, prob, cp, n);
+hipError_t launch_per_scan(const float* prob, double* cp, long long n, int which, void* scratch, hipStream_t s) {
+  if (which == 1) hipLaunchKernelGGL(per_scan_seq_kernel, dim3(1), dim3(64), 0, s, prob, cp, n);
+  else if (which == 0 && scratch && n >= PS_GRID_MIN) return launchPerScanGrid(prob, cp, n, scratch, s);
+  else hipLaunchKernelGGL(per_scan_kernel, dim3(1), dim3(PS_NT), 0, s, prob, cp, n);      // (2: the one-workgroup form whatever the length)
   return hipGetLastError();
 }
 

@@ -278,9 +278,10 @@ int launchPerPrepare(hl_learner* h, hipStream_t s) {
   const long long n = std::max<long long>(h->nTransitions, (long long)h->order.size());
   if (n > h->perCap) {
     HIPCK(hipStreamSynchronize(s));
-    for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp}) if (q) hipFree(q);
+    for (void* q : {(void*)h->perProb, (void*)h->perKey, (void*)h->perKeyS, (void*)h->perCp, (void*)h->perIdx, (void*)h->perIdxS, h->perTemp, h->perScan}) if (q) hipFree(q);
     const size_t cap = (size_t)n + (size_t)n / 4 + 1024;
     HIPCK(devAlloc(&h->perProb, cap)); HIPCK(devAlloc(&h->perCp, cap));
+    { h->perScanBytes = per_scan_scratch_bytes((long long)cap); unsigned char* t = nullptr; HIPCK(devAlloc(&t, h->perScanBytes)); h->perScan = t; }
     if (h->cfg.dataSamplingAlgo == HL_SAMPLE_PERRANK) {
       HIPCK(devAlloc(&h->perKey, cap)); HIPCK(devAlloc(&h->perKeyS, cap)); HIPCK(devAlloc(&h->perIdx, cap)); HIPCK(devAlloc(&h->perIdxS, cap));
       h->perTempBytes = per_sort_temp_bytes((long long)cap);
@@ -291,6 +292,7 @@ int launchPerPrepare(hl_learner* h, hipStream_t s) {
   PerArgs pa{}; pa.rp = h->rp; pa.nEpisodes = (int)h->order.size(); pa.algo = h->cfg.dataSamplingAlgo;
   pa.prob = h->perProb; pa.cp = h->perCp; pa.key = h->perKey; pa.keySorted = h->perKeyS; pa.idx = h->perIdx; pa.idxSorted = h->perIdxS;
   pa.temp = h->perTemp; pa.tempBytes = h->perTempBytes;
+  pa.scan = h->perScan; pa.scanBytes = h->perScanBytes;
   HIPCK(timed(h, "per_prepare", s, [&] { return launch_per_prepare(pa, h->nTransitions, s); }));
   return HL_OK;
 }

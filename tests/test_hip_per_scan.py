@@ -1,7 +1,7 @@
 """GPU: the cumulative table of the prioritised samplers' std::discrete_distribution (Sampling.cpp:101-296; libstdc++'s
 param_type::_M_initialize: a sequential fp64 accumulate, a division, a sequential partial_sum) built WITHOUT walking it element by
-element (per.hip: per_scan_kernel -- integer prefix sums inside a binade, real fp64 additions at binade crossings and exact
-ties).  The drawn indices depend on every rounding of those chains, so the table must equal the sequential one bit for bit:
+element (per.hip: per_scan_kernel and its grid form -- integer prefix sums inside a binade, real fp64 additions at binade
+crossings and exact ties).  The drawn indices depend on every rounding of those chains, so the table must equal the sequential one bit for bit:
 against numpy's sequential cumsum on the host and against the sequential walk kernel, on a million elements of the samplers'
 value ranges and on inputs made of ties and binade crossings."""
 import ctypes as C
@@ -47,9 +47,21 @@ def _cases():
 @pytest.mark.parametrize("name,p", list(_cases()), ids=[c[0] for c in _cases()])
 def test_scanned_table_equals_the_sequential_chains_bit_for_bit(hip_api, name, p):
     ref = _host_table(np.asarray(p))
-    got, ms = _table(hip_api, p, 0)
+    got, ms = _table(hip_api, p, 0)              # the grid form where the table is long enough (else one workgroup)
     assert np.array_equal(got, ref), (name, int(np.sum(got != ref)), int(np.argmax(got != ref)))
+    one, ms_one = _table(hip_api, p, 2)          # one workgroup whatever the length
+    assert np.array_equal(one, ref), (name, int(np.sum(one != ref)), int(np.argmax(one != ref)))
     if len(ref) <= (1 << 18) or name == "PERerr-like":      # (the walk takes 23 ms per million elements)
         seq, ms_seq = _table(hip_api, p, 1)
         assert np.array_equal(seq, ref)
-        if name == "PERerr-like": print("\nper_scan_kernel %.3f ms, sequential walk %.3f ms on %d elements" % (ms, ms_seq, len(ref)))
+        if name == "PERerr-like": print("\ngrid form %.3f ms, one workgroup %.3f ms, sequential walk %.3f ms on %d elements" % (ms, ms_one, ms_seq, len(ref)))
+
+
+def test_grid_form_on_ten_million_elements(hip_api):
+    """A replay ten times the BASELINE size: 610 chunks, most of them stepped over by their integer totals."""
+    g = np.random.default_rng(5)
+    p = np.sqrt(np.sqrt(g.standard_normal(10_000_000) ** 2 + np.finfo(np.float32).eps))
+    ref = _host_table(p)
+    got, ms = _table(hip_api, p, 0)
+    assert np.array_equal(got, ref), (int(np.sum(got != ref)), int(np.argmax(got != ref)))
+    print("\ngrid form on 1e7 elements: %.3f ms" % ms)
