@@ -681,7 +681,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     h->useGraph = false;      // these nets step eagerly (no riders on their launches; no shipped settings file builds them)
   }
   if (h->bigBatch) {
-    h->useGraph = false;
+    if (const char* e = getenv("SMARTIES_HIP_BIG_GRAPH")) { if (e[0] == '0') h->useGraph = false; }      // (0: plain steps of large batches issued launch by launch, as before the end of round 4)
     HIPCK(hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&h->evMain, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming));
   }
@@ -1255,9 +1255,10 @@ int hl_step(hl_learner* h, int32_t n, const int64_t* flat) {
     if (plain) {
       if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
       // plain steps available before the next 1000-step sweep and within this call
-      const long long avail = std::min<long long>(n - s, 999 - (h->nGradSteps % 1000));
+      long long avail = std::min<long long>(n - s, 999 - (h->nGradSteps % 1000));
+      if (h->bigBatch) avail = std::min<long long>(avail, 998 - (h->nGradSteps % 1000));      // (the step in front of a 1000th one draws nothing ahead: stepEager)
       int done = 0;
-      rc = replaySteps(h, avail, &done, s == 0 && avail == n); if (rc) return rc;
+      if (avail > 0) { rc = replaySteps(h, avail, &done, s == 0 && avail == n); if (rc) return rc; }
       if (done > 0) { h->nGradSteps += done; h->gsCalls += done; s += done; continue; }
     }
     const long long* dFlat = nullptr;

@@ -877,6 +877,7 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   if (slot->graph) { hipGraphDestroy(slot->graph); slot->graph = nullptr; }
   hipStream_t s0 = h->stream;
   HIPCK(hipStreamSynchronize(s0));
+  if (h->bigBatch) HIPCK(hipStreamSynchronize(h->sideStream));      // (it joins the capture below)
   HIPCK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
   int rc = HL_OK;
   struct PushScope { hl_learner* h; ~PushScope() { h->pushGrad = false; } } pushScope{h};
@@ -884,6 +885,21 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   const long long nColl0 = h->nCollectives;      // captured calls are counted when the graph is replayed
   for (int j = 0; j < U && !rc; ++j) {
     const int p = (p0 + j) & 1;
+    if (h->bigBatch) {
+      // large batches (stepEager's plain step as graph nodes): the sampler of the NEXT step -- one workgroup, hundreds of microseconds --
+      // is a branch of the graph beside this step's launches (the side stream joins the capture through the event), joined in front
+      // of the next step; it keeps the generator's state for dropPresample.  Worth 2 - 4 % at 2048 - 4096 (131.5 -> 126.5, 154.0 -> 151.3 us per
+      // step), nothing at 16384: the steps are the sum of their kernels, not launch-bound.  The bookkeeping (25 - 32 us in two launches,
+      // needing the head's write-backs only) as a second branch beside the backward launches returned nothing (156.2 against 156.0 us
+      // at 4096: a graph branch costs what it overlaps) and was removed.
+      if (hipEventRecord(h->evMain, s0) != hipSuccess || hipStreamWaitEvent(h->sideStream, h->evMain, 0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "fork of the sampler branch"); break; }
+      SampleArgs sa = sampleArgs(h, p ^ 1, nullptr, false); sa.backupRng = 1;
+      if (launch_sample(sa, h->sideStream) != hipSuccess || hipEventRecord(h->evSide, h->sideStream) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "sampler branch"); break; }
+      rc = launchMlp(h, p, true, s0); if (rc) break;
+      rc = launchPost(h, p, POST_AGG | POST_BETA, s0); if (rc) break;
+      if (hipStreamWaitEvent(s0, h->evSide, 0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "join of the sampler branch"); break; }
+      continue;
+    }
     const bool twoKernel = h->fusedOk || h->fusedWideOk;
     if (twoKernel) {
       // one replica: the far-policy count and the beta update of every step but the last are taken out of the dW launch's
@@ -979,6 +995,7 @@ int touchReplay(hl_learner* h) {
 // graph of exactly n steps for both starting buffers, last node = the completion stamp (hl_prepare_steps)
 int prepareExact(hl_learner* h, int n) {
   if (!h->useGraph || n >= 1000 || (exchanging(h) && (!(h->exchGraph && wired(h)) || n > 64)) || h->cfg.dataSamplingAlgo != HL_SAMPLE_UNIFORM) return HL_OK;
+  if (h->bigBatch && (n > 64 || exchanging(h))) return HL_OK;
   { const int rc = ensureConvPrep(h); if (rc) return rc; }      // outside the capture: the captured forward refuses stale filter layouts
   if (!h->notifyPin) { HIPCK(hipHostMalloc((void**)&h->notifyPin, 64, hipHostMallocDefault)); *h->notifyPin = 0; }
   if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
@@ -998,6 +1015,7 @@ int prepareExact(hl_learner* h, int n) {
 
 bool graphUsable(const hl_learner* h, int U, int p0) {
   if (exchanging(h) && U > 64) return false;
+  if (h->bigBatch && (U > 64 || exchanging(h))) return false;      // (a dozen nodes and a branch per step; replicas with large local batches step eagerly)
   if (U == 999 && p0 != 0) return false;
   return true;
 }
@@ -1030,6 +1048,7 @@ int replaySteps(hl_learner* h, long long avail, int* done, bool wholeCall = fals
   constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
   if (!h->graphs[NS - 1][0].exec) { int rc = captureAllGraphs(h); if (rc) return rc; if (!h->graphs[NS - 1][0].exec) return HL_OK; }
   const int p0 = h->preValid ? h->preParity : 0;
+  if (h->sidePending) { HIPCK(hipStreamWaitEvent(h->stream, h->evSide, 0)); h->sidePending = false; }      // (large batches: a minibatch drawn beside an eager step)
   if (wholeCall) {      // the whole call as one launch, completion stamp behind it
     auto it = h->exactGraphs.find((int)avail);
     if (it != h->exactGraphs.end() && it->second[p0].exec) {

@@ -278,6 +278,32 @@ def test_large_batch_runs_are_deterministic(hip_api):
     assert np.isfinite(a[0]).all()
 
 
+def test_large_batch_steps_as_graphs_equal_the_eager_launches(hip_api, monkeypatch):
+    """Plain steps of large local batches replay as graphs whose sampler branch draws the next minibatch beside the step's launches
+    (step_exec.h: captureSteps); SMARTIES_HIP_BIG_GRAPH=0 issues the same launches one by one.  Calls of mixed lengths, new episodes
+    in between (the pre-drawn minibatch is dropped and the generator put back), an announced call size: bit-identical states."""
+    sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=100, lenMax=200, pTerm=0.3)
+
+    def run():
+        L = capi.Learner(hip_api, capi.make_config(dimS=17, dimA=6, hidden=(256, 256), batchSize=2048, maxTotObsNum=400000, randSeed=5))
+        L.init_weights(); fill_synth(L, sc, 300); L.initialize(); L.set_tap(True)
+        for n in (1, 2, 21, 5):
+            L.step(n)
+        fill_synth(L, sc, 3, first=300)
+        for n in (12, 12, 12, 12, 1):
+            L.step(n)
+        L.sync()
+        out = (L.get_params()[0].copy(), L.get_rng_state().copy(), L.scalars().beta, L.scalars().nFarPolicySteps, L.readback(capi.TAP_FLAT).copy())
+        L.close()
+        return out
+    a = run()
+    monkeypatch.setenv("SMARTIES_HIP_BIG_GRAPH", "0")
+    b = run()
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2] and a[3] == b[3]
+    assert np.isfinite(a[0]).all()
+
+
 def test_states_wider_than_512_components(hip_api):
     """More observed state components than the sampler's own gather stages (512): the rows are assembled by the stacking kernel, the
     first layer's long reduction by the chunked tiles -- 1500 components against the oracle, eager and replayed steps, rollout forward."""
