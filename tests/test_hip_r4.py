@@ -390,3 +390,13 @@ def test_dense_weight_gradients_inside_the_convolutional_launches_change_nothing
         assert G.scalars().nFarPolicySteps == T.scalars().nFarPolicySteps
         T.close()
         for k in env: monkeypatch.delenv(k)
+    # the split form (no fused Adam, no riders: the shared launches carry the tiles without their Adam pass) gives the same gradients
+    # and, through the stand-alone Adam pass, the same weights as hl_step
+    A = capi.Learner(hip_api, capi.make_config(**ATARI_KW)); Bq = capi.Learner(hip_api, capi.make_config(**ATARI_KW))
+    for L in (A, Bq):
+        L.init_weights(); fill_synth(L, sc, 14); L.initialize(); L.set_tap(True)
+    for k in range(3):
+        A.step(1)
+        Bq.step_begin(); g = Bq.grad_fetch(); Bq.grad_store(g); Bq.step_end()
+        assert np.array_equal(A.readback(capi.TAP_GRADSUM), Bq.readback(capi.TAP_GRADSUM)), k
+    assert np.array_equal(A.get_params()[0], Bq.get_params()[0])
