@@ -22,6 +22,7 @@
 
 namespace hl {
 
+__device__ __forceinline__ void convLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // workgroup barrier that settles LDS traffic only: global loads stay in flight
 __device__ __forceinline__ float softsignEval(float x) { return x / (1 + fabsf(x)); }
 __device__ __forceinline__ float softsignDiff(float x) { const float d = 1 + fabsf(x); return 1 / (d * d); }
 
@@ -170,7 +171,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   const int nRows = a.sc->nRows[a.parity];
   const unsigned R = (unsigned)nRows * (unsigned)P;                   // (rows x positions < 2^31, checked at creation)
   if (blockIdx.x * PW * 16u >= R) return;                             // whole workgroup beyond the minibatch
-  stageFlat<(NK > 0 ? (CT * 16 * (NK + 1) + 255) / 256 : 5)>(Ws, g.Wf + (size_t)ctBase * 16 * ldK, CT * 16 * ldK);     // one batch of loads when the shape is known
+  // NK > 0: the filter rows are only REQUESTED here and stored to LDS behind the patch gathers below (the offset table needs no global
+  // data): the workgroup's two round trips -- filters through the L2, the image rows from the launch in front -- overlap
+  constexpr int WQ = NK > 0 ? (CT * 16 * (NK + 1) + 255) / 256 : 1;
+  f32x4 wv[WQ];
+  if constexpr (NK > 0) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.Wf + (size_t)ctBase * 16 * ldK); const int n4 = (CT * 16 * ldK) >> 2;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; wv[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  } else stageFlat<5>(Ws, g.Wf + (size_t)ctBase * 16 * ldK, CT * 16 * ldK);
   const int ct = wave % CT, ks = (wave / CT) % KS;
   const unsigned tile = blockIdx.x * PW + wave / (CT * KS);
   // this lane's output position and the origin of its patch in the input image (the index arithmetic overlaps the
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
       off = ic * g.InY * g.InX + fy * g.InX + fx; }
     kOff[k] = off;
   }
-  __syncthreads();
+  if constexpr (NK > 0) convLdsBarrier(); else __syncthreads();
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* wRow = Ws + (ct * 16 + li) * ldK + lc;
   if constexpr (NK > 0) {
@@ -201,6 +210,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) bv[s] = inRow[kOff[4 * (ks * NS + s) + lc]];
     __builtin_amdgcn_sched_barrier(0);          // all gathers are in flight before the first MFMA
+    {
+      f32x4* d4 = reinterpret_cast<f32x4*>(Ws); const int n4 = (CT * 16 * ldK) >> 2;
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; if (i < n4) d4[i] = wv[q]; }
+    }
+    convLdsBarrier();
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float av = wRow[4 * (ks * NS + s)];
@@ -315,7 +330,15 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l, DenseRi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
   constexpr int PW = 4 / (IT * KS);
   const unsigned R = (unsigned)a.B * (unsigned)Pin;
-  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx + (size_t)itBase * 16 * ldKK, IT * 16 * ldKK);
+  // NK > 0: the filter rows are only REQUESTED here and stored to LDS behind the delta gathers below (the offset table needs no
+  // global data), so the two round trips of a workgroup -- filters through the L2, deltas from the launch in front -- overlap
+  constexpr int WQ = NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 1;
+  f32x4 wv[WQ];
+  if constexpr (NK > 0) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.Wx + (size_t)itBase * 16 * ldKK); const int n4 = (IT * 16 * ldKK) >> 2;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; wv[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  } else stageFlat<5>(Wx, g.Wx + (size_t)itBase * 16 * ldKK, IT * 16 * ldKK);
   const int it = wave % IT, ks = (wave / IT) % KS;
   const unsigned tile = blockIdx.x * PW + wave / (IT * KS);
   const unsigned r = tile * 16 + li;
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l, DenseRi
     if (kk < KK) { const int c = kk / fsz, f = kk - c * fsz, fy = f / g.KnX, fx = f - fy * g.KnX; v = (c * P) | (fy << 20) | (fx << 26); }
     kTab[kk] = v;
   }
-  __syncthreads();
+  if constexpr (NK > 0) convLdsBarrier(); else __syncthreads();      // (NK > 0: the table only; the filter loads stay in flight)
   const int S = g.S, sh = S == 1 ? 0 : (S == 2 ? 1 : (S == 4 ? 2 : 3));
   auto gatherD = [&](int kk) -> float {       // D[(b, c, (q - f) / S)] where that output position exists, else 0
     const int tab = kTab[kk];
@@ -353,6 +376,12 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l, DenseRi
 #pragma unroll
     for (int s = 0; s < NS; ++s) bv[s] = gatherD(4 * (ks * NS + s) + lc);
     __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x4* d4 = reinterpret_cast<f32x4*>(Wx); const int n4 = (IT * 16 * ldKK) >> 2;
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; if (i < n4) d4[i] = wv[q]; }
+    }
+    convLdsBarrier();
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float av = wRow[4 * (ks * NS + s)];
@@ -420,7 +449,13 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
   const unsigned tile = blockIdx.x * PW + wave / (IT * KS);
   const int cls = (int)(tile / tilesPerClass);                         // uniform over the workgroup (tilesPerClass is a multiple of PW)
   const unsigned tIn = tile - (unsigned)cls * tilesPerClass;
-  stageFlat<(NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 5)>(Wx, g.Wx + ((size_t)cls * rowsAll + (size_t)itBase * 16) * ld, IT * 16 * ld);
+  constexpr int WQ = NK > 0 ? (IT * 16 * (NK + 1) + 255) / 256 : 1;      // (as conv_dx_kernel: requested here, stored behind the delta gathers)
+  f32x4 wv[WQ];
+  if constexpr (NK > 0) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(g.Wx + ((size_t)cls * rowsAll + (size_t)itBase * 16) * ld); const int n4 = (IT * 16 * ld) >> 2;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; wv[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  } else stageFlat<5>(Wx, g.Wx + ((size_t)cls * rowsAll + (size_t)itBase * 16) * ld, IT * 16 * ld);
   const int it = wave % IT, ks = (wave / IT) % KS;
   const unsigned r = tIn * 16 + li;
   const bool ok = r < Rc;
@@ -434,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
     if (kc < KKc) { const int c = kc / (TY * TX), t = kc - c * TY * TX, ty = t / TX, tx = t - ty * TX; v = (c * P) | (ty << 20) | (tx << 26); }
     kTab[kc] = v;
   }
-  __syncthreads();
+  if constexpr (NK > 0) convLdsBarrier(); else __syncthreads();
   auto gatherD = [&](int kc) -> float {       // D[(b, c, (jy - ty, jx - tx))] where that output position exists, else 0
     const int tab = kTab[kc];
     const int offC = tab & 0xFFFFF, oy = jy - ((tab >> 20) & 63), ox = jx - ((tab >> 26) & 31);
@@ -450,6 +485,12 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
 #pragma unroll
     for (int s = 0; s < NS; ++s) bv[s] = gatherD(4 * (ks * NS + s) + lc);
     __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x4* d4 = reinterpret_cast<f32x4*>(Wx); const int n4 = (IT * 16 * ld) >> 2;
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; if (i < n4) d4[i] = wv[q]; }
+    }
+    convLdsBarrier();
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float av = wRow[4 * (ks * NS + s)];
