@@ -705,10 +705,19 @@ __device__ __forceinline__ void stageWindow(float* sIn, const float* in, const C
 }
 // the same window straight from the replay (stack_gather_kernel's mapping): input channel ic = frame j = ic / C0 steps back (steps
 // before the first repeat the first), channel c0 = ic % C0 of that state; standardised with the per-component mean and scale
-__device__ __forceinline__ void stageWindowReplay(float* sIn, const ConvSource& src, int row, int B, const ConvGeo& g, int iy0, int wr, int wrValid) {
+// (slot / step of the row's state: loads of their own so that a caller can request them in front of a test that itself waits for a load)
+__device__ __forceinline__ void replayRowOrigin(const ConvSource& src, int row, int B, long long* slot, int* t) {
   const int b = row < B ? row : src.nextSrc[row - B];
-  const long long slot = src.slot[b] + (row < B ? 0 : 1);
-  const int t = src.t[b] + (row < B ? 0 : 1);
+  *slot = src.slot[b] + (row < B ? 0 : 1);
+  *t = src.t[b] + (row < B ? 0 : 1);
+}
+__device__ __forceinline__ void stageWindowReplayAt(float* sIn, const ConvSource& src, long long slot, int t, const ConvGeo& g, int iy0, int wr, int wrValid);
+__device__ __forceinline__ void stageWindowReplay(float* sIn, const ConvSource& src, int row, int B, const ConvGeo& g, int iy0, int wr, int wrValid) {
+  long long slot; int t;
+  replayRowOrigin(src, row, B, &slot, &t);
+  stageWindowReplayAt(sIn, src, slot, t, g, iy0, wr, wrValid);
+}
+__device__ __forceinline__ void stageWindowReplayAt(float* sIn, const ConvSource& src, long long slot, int t, const ConvGeo& g, int iy0, int wr, int wrValid) {
   const int rowF4 = g.InX >> 2, perCh = wrValid * rowF4, total = g.InC * perCh;
   const int C0 = g.InC / (1 + src.nApp), chStride4 = (g.InY * g.InX) >> 2, base4 = (iy0 * g.InX) >> 2, ldsCh4 = (wr * g.InX) >> 2;
   const f32x4* m4 = reinterpret_cast<const f32x4*>(src.mean); const f32x4* s4 = reinterpret_cast<const f32x4*>(src.scale);
@@ -744,7 +753,12 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const ConvGeo g = a.L[l];
   const int row = blockIdx.y;
-  if (row >= a.sc->nRows[a.parity]) return;
+  // (the row's replay slot is requested beside the row count, not behind the test on it: one dependent round trip less in front of the window's loads)
+  const int nRowsNow = a.sc->nRows[a.parity];
+  long long rowSlot = 0; int rowT = 0;
+  if (a.src.on && row < a.B) replayRowOrigin(a.src, row, a.B, &rowSlot, &rowT);      // (minibatch rows: entries the sampler always writes)
+  if (row >= nRowsNow) return;
+  if (a.src.on && row >= a.B) replayRowOrigin(a.src, row, a.B, &rowSlot, &rowT);     // (next-state rows: their map is valid below the row count only)
   const int rb = blockIdx.x, RB = g.rbRows, WR = g.rbWin, P = g.P, K = g.K, ldK = convPad4(K) + 4;
   const int oy0 = rb * RB, nOy = min(RB, g.OpY - oy0), iy0 = oy0 * g.S, wrValid = min(WR, g.InY - iy0);
   float* sIn = reinterpret_cast<float*>(smem);                       // [InC][WR][InX]
@@ -758,7 +772,7 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(ConvArgs a, int l) {
 #pragma unroll
     for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; wv[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
-  if (a.src.on) stageWindowReplay(sIn, a.src, row, a.B, g, iy0, WR, wrValid);
+  if (a.src.on) stageWindowReplayAt(sIn, a.src, rowSlot, rowT, g, iy0, WR, wrValid);
   else stageWindow(sIn, g.in + (long long)row * g.ldIn, g, iy0, WR, wrValid);
   {
     f32x4* d4 = reinterpret_cast<f32x4*>(Ws); const int n4 = (CT * 16 * ldK) >> 2;
