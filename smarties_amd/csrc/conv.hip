@@ -168,9 +168,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
   int* kOff = reinterpret_cast<int*>(Ws + (size_t)CT * 16 * ldK);     // [Kp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
   constexpr int PW = 4 / (CT * KS);                                    // position tiles per workgroup
-  const int nRows = a.sc->nRows[a.parity];
-  const unsigned R = (unsigned)nRows * (unsigned)P;                   // (rows x positions < 2^31, checked at creation)
-  if (blockIdx.x * PW * 16u >= R) return;                             // whole workgroup beyond the minibatch
+  const int nRows = a.sc->nRows[a.parity];                            // (tested behind the filter requests below: they do not wait for it)
   // NK > 0: the filter rows are only REQUESTED here and stored to LDS behind the patch gathers below (the offset table needs no global
   // data): the workgroup's two round trips -- filters through the L2, the image rows from the launch in front -- overlap
   constexpr int WQ = NK > 0 ? (CT * 16 * (NK + 1) + 255) / 256 : 1;
@@ -179,7 +177,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a, int l) {
     const f32x4* s4 = reinterpret_cast<const f32x4*>(g.Wf + (size_t)ctBase * 16 * ldK); const int n4 = (CT * 16 * ldK) >> 2;
 #pragma unroll
     for (int q = 0; q < WQ; ++q) { const int i = tid + 256 * q; wv[q] = i < n4 ? s4[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
-  } else stageFlat<5>(Ws, g.Wf + (size_t)ctBase * 16 * ldK, CT * 16 * ldK);
+  }
+  const unsigned R = (unsigned)nRows * (unsigned)P;                   // (rows x positions < 2^31, checked at creation)
+  if (blockIdx.x * PW * 16u >= R) return;                             // whole workgroup beyond the minibatch
+  if constexpr (NK == 0) stageFlat<5>(Ws, g.Wf + (size_t)ctBase * 16 * ldK, CT * 16 * ldK);
   const int ct = wave % CT, ks = (wave / CT) % KS;
   const unsigned tile = blockIdx.x * PW + wave / (CT * KS);
   // this lane's output position and the origin of its patch in the input image (the index arithmetic overlaps the

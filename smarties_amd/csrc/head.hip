@@ -53,13 +53,18 @@ __global__ __launch_bounds__(256) void head_kernel_t(HeadArgs a, ExtraArgs extra
   const int row = SPLIT == 4 ? (int)(blockIdx.x - nExtra) : (int)(blockIdx.x - nExtra) * 4 + wave;
   const DevScalars* sc = a.sc;
   HSTAMP(0);
-  if (row >= sc->nRows[a.parity]) return;
+  // (a minibatch row's replay slot is requested beside the row count, not behind the test on it: one dependent round trip less in front
+  //  of the replay rows' loads below; the next-state rows' map is valid below the row count only)
+  const int nRowsNow = sc->nRows[a.parity];
+  long long slotEarly = 0;
+  if (row < a.B) slotEarly = a.bt.slot[row];
+  if (row >= nRowsNow) return;
   HSTAMP(1);
   const int B = a.B, dA = a.dA, nDense = a.nDense, H = a.H, nAdv = a.nAdv, pM = 1 + nAdv;
   const bool hasAdv = nAdv > 0 || a.nOpt > 0;
   const bool isNext = row >= B;
   const int b = isNext ? a.bt.nextSrc[row - B] : row;
-  const long long slot = a.bt.slot[b];
+  const long long slot = isNext ? a.bt.slot[b] : slotEarly;
   const float* Wo = a.params + a.indWo;
   const bool small = nDense <= 8;
   const bool mid = nDense > 8 && nDense <= 16;      // two chunks of eight outputs (RACER heads with a few options / actions): both in registers
