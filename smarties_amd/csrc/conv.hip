@@ -22,7 +22,7 @@
 
 namespace hl {
 
-__device__ __forceinline__ void convLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // workgroup barrier that settles LDS traffic only: global loads stay in flight
+__device__ __forceinline__ void convLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // workgroup barrier that settles LDS traffic only: global loads stay in flight (what __syncthreads compiles to for gfx950 as well; spelled out where the code relies on it)
 __device__ __forceinline__ float softsignEval(float x) { return x / (1 + fabsf(x)); }
 __device__ __forceinline__ float softsignDiff(float x) { const float d = 1 + fabsf(x); return 1 / (d * d); }
 
