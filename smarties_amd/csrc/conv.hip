@@ -431,9 +431,9 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(ConvArgs a, int l, DenseRi
 }
 // the same for a strided layer, one parity class of input positions per workgroup: tiles are laid out class-major
 // (class, sample, position inside the class), NK = KnC (KnY / S)(KnX / S) / 4 steps instead of KnC KnY KnX / 4
-template <int IT, int NK>
+template <int IT, int NK, int KSP = 0>      // KSP: wavefronts per tile (0: four for the instantiated shapes; 1: a tile per wavefront -- launches with thousands of tiles)
 __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsigned tilesPerClass) {
-  constexpr int KS = NK > 0 ? 4 / IT : 1;
+  constexpr int KS = KSP > 0 ? KSP : (NK > 0 ? 4 / IT : 1);
   __shared__ float sRed[4][256];
   const int itBase = NK > 0 ? blockIdx.y : 0;
   const int rowsAll = (a.L[l].InC + 15) & ~15;
@@ -538,22 +538,29 @@ __global__ __launch_bounds__(256) void conv_dxs_kernel(ConvArgs a, int l, unsign
     }
   }
 }
-template <int IT, int NK> static hipError_t launchConvDxsT(const ConvArgs& a, int l, int ity, hipStream_t s) {
+template <int IT, int NK, int KSP = 0> static hipError_t launchConvDxsT(const ConvArgs& a, int l, int ity, hipStream_t s) {
   const ConvGeo& g = a.L[l];
   const int KKp = convPad4(convClassK(g));
   const size_t lds = (size_t)IT * 16 * (KKp + 4) * 4 + (size_t)KKp * 4;
-  constexpr int PW = NK > 0 ? 1 : 4 / IT;
+  constexpr int PW = KSP > 0 ? 4 / (IT * KSP) : (NK > 0 ? 1 : 4 / IT);
   const long long Rc = (long long)a.B * (g.InY / g.S) * (g.InX / g.S);
   unsigned tpc = (unsigned)((Rc + 15) / 16); tpc = (tpc + PW - 1) / PW * PW;
   const int blocks = (int)((long long)g.S * g.S * tpc / PW);
-  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dxs_kernel<IT, NK>), lds);
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_dxs_kernel<IT, NK, KSP>), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((conv_dxs_kernel<IT, NK>), dim3(blocks, ity), dim3(256), lds, s, a, l, tpc);
+  hipLaunchKernelGGL((conv_dxs_kernel<IT, NK, KSP>), dim3(blocks, ity), dim3(256), lds, s, a, l, tpc);
   return hipGetLastError();
 }
 template <int IT> static hipError_t launchConvDxsC(const ConvArgs& a, int l, hipStream_t s) {
   const int nk = convPad4(convClassK(a.L[l])) / 4;
-  if (nk == 36) return launchConvDxsT<1, 36>(a, l, IT, s);         // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
+  if (nk == 36) {                                                  // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
+    // thousands of tiles (batch 128 of 20 x 20 positions: 3200): a tile per wavefront -- a quarter of the workgroups, no cross-wave join
+    static const int ksSel = [] { const char* e = getenv("SMARTIES_HIP_DXS_KS"); return e ? atoi(e) : 0; }();
+    const long long tiles = ((long long)a.B * (a.L[l].InY / a.L[l].S) * (a.L[l].InX / a.L[l].S) + 15) / 16 * a.L[l].S * a.L[l].S;
+    if (ksSel == 2) return launchConvDxsT<1, 36, 2>(a, l, IT, s);
+    if (ksSel == 1 || (ksSel == 0 && tiles >= 2048)) return launchConvDxsT<1, 36, 1>(a, l, IT, s);
+    return launchConvDxsT<1, 36>(a, l, IT, s);
+  }
   return launchConvDxsT<IT, 0>(a, l, 1, s);
 }
 template <int IT, int NK> static hipError_t launchConvDxT(const ConvArgs& a, int l, long long R, int ity, const DenseRide* ride, hipStream_t s) {

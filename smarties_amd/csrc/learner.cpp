@@ -709,7 +709,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       else { HIPCK(devAlloc(&g.X, (size_t)h->convMmax * g.ldOut)); HIPCK(devAlloc(&g.Y, (size_t)h->convMmax * g.ldOut)); HIPCK(devAlloc(&g.D, (size_t)h->convB * g.ldOut)); }
       const long long R = (long long)h->convB * g.P;             // rows of the filter-gradient reduction
       const int tiles = ((g.K + 15) / 16) * ((g.KnC + 15) / 16);
-      long long rowsPer = std::max<long long>(64, (R * tiles + 1023) / 1024);   // about a thousand workgroups per layer
+      static const long long dwWgs = [] { const char* e = getenv("SMARTIES_HIP_CONV_DW_WGS"); const long long v = e ? atoll(e) : 0; return v >= 16 ? v : 640; }();      // (640: RACER_atari step 139.3 us at 1024, 137.0 at 512 - 768, 140.4 at 256, 144.9 at 2048)
+      long long rowsPer = std::max<long long>(64, (R * tiles + dwWgs - 1) / dwWgs);   // several hundred workgroups per layer
       rowsPer = std::min<long long>(roundUp(rowsPer, 16), 2048);
       g.chunkRows = (int)rowsPer; g.nChunks = (int)((R + rowsPer - 1) / rowsPer);
       // layers with a large input image (the first one of the Atari stacks): row-block kernels, one partial per (sample, row block)
