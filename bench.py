@@ -73,6 +73,36 @@ def step_kernels(B, dS, dA, hidden, nParams, fused):
     return ks
 
 
+def pmc_traffic(kernel, profiles_dir=None):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary under profiles/ that lists it
+    (PMC counters cannot be read from inside this process).  Two layouts are understood: the curated one
+    ({"kernels": {name: {"traffic_bytes": ...}}}) and the raw summary tools/pmc3.sh writes ({name: {"FETCH_SIZE": [mean KB,
+    dispatches, max KB], "WRITE_SIZE": [...]}}).  For the raw one the corrections of MI355X_MICROARCH.md (HBM) are applied here:
+    FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950 -> doubled; WRITE_SIZE as reported (uncalibrated).
+    Returns (bytes or None, file name or None)."""
+    import glob
+    import re
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    base = kernel.split("<")[0].replace("void ", "").replace("hl::", "")
+
+    def rnd(f):
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        return int(m.group(1)) if m else -1
+    for f in sorted(glob.glob(os.path.join(d, "r*_pmc.json")), key=rnd, reverse=True):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+        except Exception:  # noqa: BLE001
+            continue
+        k = j.get("kernels", {}).get(base) if isinstance(j.get("kernels"), dict) else None
+        if isinstance(k, dict) and k.get("traffic_bytes") is not None:
+            return float(k["traffic_bytes"]), os.path.basename(f)
+        raw = j.get(base)
+        if isinstance(raw, dict) and "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
+            return (2.0 * raw["FETCH_SIZE"][0] + raw["WRITE_SIZE"][0]) * 1024.0, os.path.basename(f)
+    return None, None
+
+
 def synthetic_episode(np, e, dS=17, dA=6, N=EP_STATES):
     """Episode `e` of the synthetic replay: the distributions of oracle/synth.h (the generator the
     CPU baseline's harness uses), drawn from a numpy Generator seeded by the episode index."""
@@ -395,14 +425,9 @@ def main():
         d = table[dom]
         # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process;
         # the committed rocprofv3 --pmc passes (profiles/r04_pmc.json: commands, corrections) are quoted
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
-                traffic = json.load(f)["kernels"][dom.split("<")[0]]["traffic_bytes"]
-        except Exception:  # noqa: BLE001
-            traffic = None
+        traffic, traffic_src = pmc_traffic(dom)
         roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC pass, profiles/r04_pmc.json)",
+                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc passes of eager launches, profiles/%s)" % traffic_src,
                 "launch_us": d["launch_us"], "empty_launch_us": round(gap, 3),
                 "step_kernels": table,
                 "note": "latency-bound step: dependent launches of a few hundred workgroups; launch_us = HIP-event time "

@@ -11,6 +11,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Utilities::safeExp (Utils/FunctionUtilities.h:51-54), SMARTIES_EXP_CUT = 8 in the single-precision build (Definitions.h:43)
+// one of two pointers of a problem record by a per-lane condition, selected on the VALUES (two v_cndmask): written as `c ? P.a : P.b`
+// the compiler loads through a selected ADDRESS of the record's fields, which puts the record's pointers on the stack -- the 36 - 40
+// bytes of scratch per lane dw_table_kernel, fused_wide_kernel and panel_head_kernel carried until round 5
+__device__ __forceinline__ const float* pickPtr(bool first, const float* a, const float* b) {
+  unsigned long long ua = reinterpret_cast<unsigned long long>(a), ub = reinterpret_cast<unsigned long long>(b);
+  asm volatile("" : "+s"(ua), "+s"(ub));      // (the two values exist in registers before the select)
+  return reinterpret_cast<const float*>(first ? ua : ub);
+}
+__device__ __forceinline__ float* pickPtrW(bool first, float* a, float* b) { return const_cast<float*>(pickPtr(first, a, b)); }
 __device__ __forceinline__ float nnSafeExp(float v) { return expf(fminf(8.f, fmaxf(-8.f, v))); }
 __device__ __forceinline__ float actEval(int f, float in) {   // Network/Layers/Functions.h
   switch (f) {

@@ -112,7 +112,7 @@ __device__ __forceinline__ void dwDirectTile(const GemmProblem& P, int tile, uns
     ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
     const bool isW = m < P.M - 1;
     const size_t iw = outOk ? (isW ? (size_t)m * P.ldc + n : (size_t)n) : 0;
-    const float* pw = isW ? P.adW : P.adbW; const float* p1 = isW ? P.adM1 : P.adbM1; const float* p2 = isW ? P.adM2 : P.adbM2;
+    const float* pw = pickPtr(isW, P.adW, P.adbW); const float* p1 = pickPtr(isW, P.adM1, P.adbM1); const float* p2 = pickPtr(isW, P.adM2, P.adbM2);
     e0 = pw[iw]; e1 = p1[iw]; e2 = p2[iw];
   }
   const int RW = (((P.K + 3) / 4) + 3) & ~3;      // rows per wavefront: a multiple of four
@@ -130,13 +130,11 @@ __device__ __forceinline__ void dwDirectTile(const GemmProblem& P, int tile, uns
   __syncthreads();
   const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
   if (!outOk) return;
-  if (m < P.M - 1) {
-    const size_t i = (size_t)m * P.ldc + n;
-    P.C[i] = v;
-    if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adW[i] = e0; P.adM1[i] = e1; P.adM2[i] = e2; }
-  } else {
-    P.biasOut[n] = v;
-    if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adbW[n] = e0; P.adbM1[n] = e1; P.adbM2[n] = e2; }
+  {      // (one store sequence on selected pointer values: gemm_tile.h)
+    const bool isW = m < P.M - 1;
+    const size_t i = isW ? (size_t)m * P.ldc + n : (size_t)n;
+    pickPtrW(isW, P.C, P.biasOut)[i] = v;
+    if (P.adam) { adamStep(ac, v, e0, e1, e2); pickPtrW(isW, P.adW, P.adbW)[i] = e0; pickPtrW(isW, P.adM1, P.adbM1)[i] = e1; pickPtrW(isW, P.adM2, P.adbM2)[i] = e2; }
   }
 }
 

@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
     ac.eta = sc->etaEff[hyp.parity]; ac.lambda = hyp.lambda; ac.fac = hyp.fac;
     const bool isW = m < P.M - 1;
     const size_t iw = outOk ? (isW ? (size_t)m * P.ldc + n : (size_t)n) : 0;
-    const float* pw = isW ? P.adW : P.adbW; const float* p1 = isW ? P.adM1 : P.adbM1; const float* p2 = isW ? P.adM2 : P.adbM2;
+    const float* pw = pickPtr(isW, P.adW, P.adbW); const float* p1 = pickPtr(isW, P.adM1, P.adbM1); const float* p2 = pickPtr(isW, P.adM2, P.adbM2);
     e0 = pw[iw]; e1 = p1[iw]; e2 = p2[iw];
   }
   // a reduction one to four elements longer than a whole number of 256-element chunks (257 observed states: the Humanoid wrapper)
@@ -302,13 +302,12 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
   } else if (epi == EPI_DW && FL < 0 && P.nSplit > 1) {
     P.part[((size_t)ks * P.M + m) * P.N + n] = v;
   } else if (epi == EPI_DW) {
-    if (m < P.M - 1) {
-      const size_t i = (size_t)m * P.ldc + n;
-      P.C[i] = v;
-      if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adW[i] = e0; P.adM1[i] = e1; P.adM2[i] = e2; }
-    } else {
-      P.biasOut[n] = v;
-      if (P.adam) { adamStep(ac, v, e0, e1, e2); P.adbW[n] = e0; P.adbM1[n] = e1; P.adbM2[n] = e2; }
+    {      // weight rows and the bias row (the ones row of the product) through ONE store sequence on selected pointer values: as two
+           // branches the compiler merged their stores and indexed the record's pointers on the stack (scratch)
+      const bool isW = m < P.M - 1;
+      const size_t i = isW ? (size_t)m * P.ldc + n : (size_t)n;
+      pickPtrW(isW, P.C, P.biasOut)[i] = v;
+      if (P.adam) { adamStep(ac, v, e0, e1, e2); pickPtrW(isW, P.adW, P.adbW)[i] = e0; pickPtrW(isW, P.adM1, P.adbM1)[i] = e1; pickPtrW(isW, P.adM2, P.adbM2)[i] = e2; }
     }
   } else {
     P.C[(size_t)m * P.ldc + n] = v;

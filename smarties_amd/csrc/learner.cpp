@@ -632,6 +632,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->dev = cfg->device_id >= 0 ? cfg->device_id : (cfg->rank % nDev);
   *out = h;   // so that the caller can read hl_last_error and must hl_destroy
   HIPCK(hipSetDevice(h->dev));
+  {      // the kernels are written for gfx950's 160 KB of LDS per workgroup (rec.hip, conv.hip, fused.hip size their stages for it): refuse any other part here, not at the first launch
+    int ldsMax = 0;
+    HIPCK(hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, h->dev));
+    if (ldsMax < 160 * 1024) return fail(h, HL_ERR_NO_DEVICE, "device offers less than 160 KB of LDS per workgroup (the kernels are built for gfx950)");
+  }
   HIPCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->dS = cfg->dimS; h->dA = cfg->dimA;
   const double nL = cfg->n_ranks;
@@ -672,6 +677,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (h->recurrent) h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
   h->convB = B; h->convMmax = h->Mmax;
   if (h->recurrent && h->nConv > 0) {
+    if (h->nHidden < 2) return fail(h, HL_ERR_UNSUPPORTED, "recurrent network type behind convolutions without a recurrent layer (nnLayerSizes is empty)");
     // (the input gradient of the first recurrent layer is a GEMM over its gate deltas with 16-byte row loads; its input rows are staged in LDS)
     if ((std::max(h->hid[1].lstm, 1) * h->hid[1].size) % 4 != 0) return fail(h, HL_ERR_UNSUPPORTED, "recurrent layer behind convolutions: gates x cells must be a multiple of 4");
     if (h->hid[1].nIn > 1024) return fail(h, HL_ERR_UNSUPPORTED, "recurrent layer behind convolutions: more than 1024 inputs");
@@ -2080,7 +2086,7 @@ int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
   // dense networks: every gradient element comes out of a tile of the weight-gradient launch, which then stores it into the peers'
   // windows itself (recurrent and convolutional nets have further gradient producers -- split-row joins, filter gradients: the
   // exchange kernel keeps pushing their message)
-  { const char* np = getenv("SMARTIES_HIP_NO_PUSH"); h->pushOk = !(np && np[0] == '1') && !h->recurrent && h->nConv == 0; }
+  { const char* np = getenv("SMARTIES_HIP_NO_PUSH"); h->pushOk = !(np && np[0] == '1') && !h->recurrent && h->nConv == 0 && !h->bigBatch; }      // (local batches above 1024: split-row joins and the 64 x 64 tiles never push -- the exchange kernel sends their gradient)
   int rc = xchgAllreduce(h, h->G, (size_t)h->nParams, 0); if (rc) return rc;
   HIPCK(hipMemcpyAsync(h->W, h->G, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void lstm_backward_lds_kernel(RecArgs a) {
   float wr[MAXL];
 #pragma unroll
   for (int j = 0; j < MAXL; ++j) { wr[j] = 0.f; if (j < nL && LL[j].hasRes && tid < LL[j].resW) wr[j] = W[LL[j].indWr + tid]; }
-  const int nCl = LL[nL - 1].nC;
+  const int nCl = a.L[nL - 1].nC;      // (from the arguments: a run-time index into LL would put the whole array on the stack -- 976 bytes of scratch per lane in the any-depth variant until round 5)
   const float dres = tid < nCl ? a.Dres[(size_t)b * a.ldD + tid] : 0.f;
   vmDrain(); ldsBarrier();
   // rows of the steps this sample does not have: zero deltas (their stale inputs then add nothing to the gradients)

@@ -877,7 +877,7 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   if (slot->graph) { hipGraphDestroy(slot->graph); slot->graph = nullptr; }
   hipStream_t s0 = h->stream;
   HIPCK(hipStreamSynchronize(s0));
-  if (h->bigBatch) HIPCK(hipStreamSynchronize(h->sideStream));      // (it joins the capture below)
+  if (h->bigBatch) { HIPCK(hipStreamSynchronize(h->sideStream)); h->sidePending = false; }      // (it joins the capture below; what an eager step drew ahead is complete: nobody waits on evSide, which the capture re-records)
   HIPCK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
   int rc = HL_OK;
   struct PushScope { hl_learner* h; ~PushScope() { h->pushGrad = false; } } pushScope{h};

@@ -303,10 +303,10 @@ __device__ void mtDraw(unsigned* x, unsigned* xo, int* pPos, unsigned* raw, int 
 
 // exclusive scan of one flag per element, element index e = r*256 + tid (r < K); returns the total.
 // Two barriers per row of 256 elements (wave ballot + 4 wave totals through LDS).
-__device__ int scanRows(int K, const bool* flag, int* excl, int* sWave /*[4]*/) {
+__device__ __forceinline__ int scanRows(int K, const bool* flag, int* excl, int* sWave /*[4]*/) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int base = 0;
-  for (int r = 0; r < K; ++r) {
+  _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) {
     const unsigned long long m = __ballot(flag[r]);
     const int within = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) sWave[wave] = __popcll(m);
@@ -373,7 +373,7 @@ __device__ void drawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* raw
     const int need = B - filled;
     mtDraw(x, xo, sPos, raw, need);
     bool fl[SMAXK]; int ex[SMAXK]; unsigned v[SMAXK];
-    for (int r = 0; r < K; ++r) {
+    _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) {
       const int i = r * 256 + tid;
       fl[r] = false; v[r] = 0;
       if (i < need) {
@@ -382,7 +382,7 @@ __device__ void drawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* raw
       }
     }
     const int acc = scanRows(K, fl, ex, sWave);
-    for (int r = 0; r < K; ++r) if (fl[r]) vals[filled + ex[r]] = v[r];
+    _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) if (fl[r]) vals[filled + ex[r]] = v[r];
     filled += acc;
   }
   __syncthreads();
@@ -423,13 +423,13 @@ __device__ int sortUnique(unsigned* vals, int* sWave, int B, int Bp, int K) {
   for (int i = B + tid; i < Bp; i += 256) vals[i] = 0xFFFFFFFFu;
   bitonicSort(vals, Bp);
   bool fl[SMAXK]; int ex[SMAXK]; unsigned v[SMAXK];
-  for (int r = 0; r < K; ++r) {
+  _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) {
     const int i = r * 256 + tid;
     v[r] = i < B ? vals[i] : 0u;
     fl[r] = i < B && (i == 0 || v[r] != vals[i - 1]);
   }
   const int nu = scanRows(K, fl, ex, sWave);     // (barriers inside: all reads of vals are done)
-  for (int r = 0; r < K; ++r) if (fl[r]) vals[ex[r]] = v[r];
+  _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) if (fl[r]) vals[ex[r]] = v[r];
   __syncthreads();
   return nu;
 }
@@ -517,7 +517,7 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
 
   // ---- IDtoSeqStep: interpolation guess into the per-position table, then binary search ----
   bool hasNext[SMAXK]; int nextIdx[SMAXK];
-  for (int r = 0; r < K; ++r) {
+  _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) {
     const int b = r * 256 + tid;
     hasNext[r] = false;
     if (b < B) {
@@ -537,7 +537,7 @@ __device__ __forceinline__ void samplePhases(const SampleArgs& a, int phases, un
   TSTAMP(sc, 5);
   const int nNext = scanRows(K, hasNext, nextIdx, sWave);
   TSTAMP(sc, 6);
-  for (int r = 0; r < K; ++r) {
+  _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) {
     const int b = r * 256 + tid;
     if (b < B) {
       const int nr = hasNext[r] ? B + nextIdx[r] : -1;
@@ -617,7 +617,7 @@ __device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int 
     const int nEp = (int)sc->nEpisodes;
     const int K = (B + 255) / 256;
     bool hasNext[SMAXK]; int nextIdx[SMAXK];
-    for (int r = 0; r < K; ++r) {
+    _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) {
       const int b = r * 256 + tid;
       hasNext[r] = false;
       if (b < B) {
@@ -630,7 +630,7 @@ __device__ __forceinline__ void gatherHelper(const SampleArgs& a, int part, int 
       }
     }
     scanRows(K, hasNext, nextIdx, sWave);
-    for (int r = 0; r < K; ++r) { const int b = r * 256 + tid; if (b < B) sNextRow[b] = hasNext[r] ? B + nextIdx[r] : -1; }
+    _Pragma("unroll") for (int r = 0; r < SMAXK; ++r) if (r < K) { const int b = r * 256 + tid; if (b < B) sNextRow[b] = hasNext[r] ? B + nextIdx[r] : -1; }
     __syncthreads();
     if (part == 0) TSTAMP(sc, 22);
     const int per = (B + nParts - 1) / nParts, b0 = part * per, b1 = min(B, b0 + per);
