@@ -603,7 +603,112 @@ hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s, const DenseRi
 // dW: partial filter gradients per (layer, 16 x 16 tile of [KnC][K], chunk of the batch x positions reduction)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CONV_DW_MAXROWS = 2048;      // rows of one chunk (LDS tables)
-constexpr size_t CONV_DW_LDS = (size_t)CONV_DW_MAXROWS * 12 + 4 * 256 * 4;
+constexpr size_t CONV_DW_LDS = 40 * 1024;  // (gather form: MAXROWS * 12 + 4 KB; staged form: conv_dw_staged_group keeps a workgroup's operands below this)
+// ---- the same with BOTH operands staged in LDS (round 5; VERDICT r02 - r04: the gather form above requests each of its two operands
+// per MFMA step with a 4-byte load of its own -- 16 cache lines per wavefront load for the deltas -- and stalls at issue 28 - 44 % of its
+// cycles).  Behind the first layer a sample's input image and its deltas are a few KB, contiguous in memory: a workgroup copies the
+// images of G rows and the deltas of one tile of 16 channels into LDS with 16-byte loads (flat copies, all in flight at once) and
+// takes every MFMA operand from there.  A wavefront owns up to five of the K / 16 patch-element tiles and reads the delta operand
+// once per step for all of them.  One partial [16][K] per (group of rows, channel tile) -> part[group][c][k], summed in group order by
+// conv_reduce_adam_kernel: bit-deterministic.
+int conv_dw_staged_group(const ConvGeo& g, int B) {      // rows per workgroup (0: the layer keeps the gather form)
+  const long long inSize = (long long)g.InC * g.InY * g.InX;
+  if ((inSize & 3) || (g.ldIn & 3) || (g.ldOut & 3) || (g.P * 16) % 4 || g.KnC % 16 || g.K % 16 || g.K / 16 > 20) return 0;
+  const char* ge = getenv("SMARTIES_HIP_CONV_DW_G");      // (0: the gather form -- tests compare the two; n: rows per workgroup)
+  const int gEnv = ge ? atoi(ge) : -1;
+  if (gEnv == 0) return 0;
+  int G = 1;
+  while (2 * G <= 16 && 2 * G * g.P <= 128) G *= 2;      // reductions of about a hundred rows: 72 - 128 on the RACER_atari shape
+  if (gEnv > 0) G = gEnv;
+  if (G > B) G = B;
+  auto bytes = [&](int G_) { return ((long long)G_ * (inSize + 16 * (g.P | 1)) + 2 * (((long long)G_ * g.P + 3) & ~3)) * 4; };
+  while (G > 1 && bytes(G) > (long long)CONV_DW_LDS) G /= 2;
+  return bytes(G) <= (long long)CONV_DW_LDS ? G : 0;
+}
+__device__ __forceinline__ void convDwStaged(const ConvArgs& a, const ConvGeo& g, int local, unsigned char* smem) {
+  const int tilesC = g.KnC >> 4, grp = local / tilesC, ct = local - grp * tilesC;
+  const int G = g.dwG, b0 = grp * G, nb = min(G, a.B - b0);
+  const int P = g.P, PP = P | 1, K = g.K, inSize = g.InC * g.InY * g.InX, R = nb * P, R4 = (R + 3) & ~3;
+  float* sIn = reinterpret_cast<float*>(smem);                      // [G][inSize]
+  float* sDl = sIn + (size_t)G * inSize;                             // [G][16][PP]   (odd pitch: the sixteen channels of an operand read fall into different banks)
+  int* rIn = reinterpret_cast<int*>(sDl + (size_t)G * 16 * PP);      // [R4] patch origin of reduction row r in sIn
+  int* rD = rIn + (((size_t)G * P + 3) & ~3);                        // [R4] its delta in sDl (channel 0 of the tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  {      // the rows' images: flat 16-byte copies (inSize floats at pitch ldIn), every load of a batch in flight at once
+    const int q4 = inSize >> 2, nIn4 = nb * q4;
+    constexpr int U = 6;
+    for (int i0 = tid; i0 < nIn4; i0 += 256 * U) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < nIn4) { const int bl = i / q4, e = i - bl * q4; v[u] = reinterpret_cast<const f32x4*>(g.in + (size_t)(b0 + bl) * g.ldIn)[e]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < nIn4) { const int bl = i / q4, e = i - bl * q4; reinterpret_cast<f32x4*>(sIn + (size_t)bl * inSize)[e] = v[u]; }
+      }
+    }
+    // their deltas of this tile's 16 channels: 16 P consecutive floats per row -> [c][PP]
+    const int nD = 16 * P, totD = nb * nD;
+    for (int i = tid; i < totD; i += 256) {
+      const int bl = i / nD, e = i - bl * nD, c = e / P, p = e - c * P;
+      sDl[(bl * 16 + c) * PP + p] = g.D[(size_t)(b0 + bl) * g.ldOut + (size_t)ct * nD + e];
+    }
+  }
+  for (int r = tid; r < R4; r += 256) {
+    const int rr = r < R ? r : 0, bl = rr / P, p = rr - bl * P, oy = p / g.OpX, ox = p - oy * g.OpX;
+    rIn[r] = bl * inSize + oy * g.S * g.InX + ox * g.S;
+    rD[r] = bl * 16 * PP + p;
+  }
+  // this wavefront's patch-element tiles kt = wave, wave + 4, ...; the lane's element k = kt 16 + li of each
+  constexpr int TP = 5;
+  const int nKt = K >> 4, fsz = g.KnY * g.KnX;
+  int ko[TP]; f32x4 acc[TP];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int kt = min(wave + 4 * j, nKt - 1), k = kt * 16 + li, ic = k / fsz, f = k - ic * fsz, fy = f / g.KnX, fx = f - fy * g.KnX;
+    ko[j] = ic * g.InY * g.InX + fy * g.InX + fx;
+    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nT = (nKt - wave + 3) >> 2;      // tiles of this wavefront (<= TP: conv_dw_staged_group)
+  __syncthreads();
+  const int nSteps = R4 >> 2;
+  const float* dCol = sDl + li * PP;
+  // software pipeline: the operands of step s + 1 (two table entries, then the delta and the TP patch elements they address) are read
+  // while the MFMAs of step s run -- written as one loop the compiler leaves every step's LDS round trips in front of its MFMAs
+  float dv, pv[TP];
+  auto fetch = [&](int s, float& d, float (&pq)[TP]) {
+    const int r = min(4 * s + lc, R4 - 1);
+    const int oI = rIn[r], oD = rD[r];
+    d = dCol[oD];
+    d = r < R ? d : 0.f;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) pq[j] = sIn[oI + ko[j]];
+  };
+  fetch(0, dv, pv);
+  for (int s = 0; s < nSteps; ++s) {
+    float dn, pn[TP];
+    fetch(min(s + 1, nSteps - 1), dn, pn);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      if (j < nT) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, pv[j], acc[j], 0, 0, 0);
+    }
+    dv = dn;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) pv[j] = pn[j];
+  }
+  float* part = g.part + (size_t)grp * g.KnC * K + (size_t)(ct * 16 + lc * 4) * K + li;
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    if (j < nT) {
+      const int kt = wave + 4 * j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[(size_t)q * K + kt * 16] = acc[j][q];
+    }
+  }
+}
 __device__ __forceinline__ void convDwBody(const ConvArgs& a, int bx, unsigned char* smem) {
   long long* sIn = reinterpret_cast<long long*>(smem);                       // [MAXROWS] offset of the patch origin of row r in the input array
   int* sD = reinterpret_cast<int*>(smem + (size_t)CONV_DW_MAXROWS * 8);      // [MAXROWS] b * ldOut + p
@@ -611,6 +716,7 @@ __device__ __forceinline__ void convDwBody(const ConvArgs& a, int bx, unsigned c
   int l = 0;
   for (int i = 1; i < a.nL; ++i) if (bx >= a.L[i].dwBlock0) l = i;
   const ConvGeo g = a.L[l];
+  if (g.dwG) { convDwStaged(a, g, bx - g.dwBlock0, smem); return; }
   const int K = g.K, P = g.P, tilesK = (K + 15) / 16, tilesC = (g.KnC + 15) / 16;
   const int local = bx - g.dwBlock0;
   const int chunk = local / (tilesK * tilesC), tile = local - chunk * tilesK * tilesC;

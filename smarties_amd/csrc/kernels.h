@@ -109,6 +109,9 @@ struct ConvGeo {
   // row-block kernels (conv.hip: conv_fwd_rows_kernel / conv_dw_rows_kernel; layers with a large input image): a workgroup owns
   // rbRows output rows of one sample and stages the rbWin input rows under them in LDS.  rbRows = 0: not used for this layer.
   int rbRows, rbCount, rbWin;
+  // filter gradient with the operands staged in LDS (conv.hip: convDwStaged; layers behind the first): a workgroup owns dwG rows
+  // (samples) x one tile of 16 channels and leaves one partial per group of rows.  0: the gather workgroups (tile, chunk) above.
+  int dwG;
 };
 // where the row-block kernels of the first layer take their input rows from when no stacked minibatch rows X0 were written
 // (training steps: the replay itself, standardised on the way -- stack_gather_kernel's mapping, conv.hip)
@@ -137,11 +140,23 @@ hipError_t launch_conv_dx(const ConvArgs& a, int l, hipStream_t s, const DenseRi
 bool conv_dx_rides(const ConvGeo& g);
 hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);
 int conv_row_block(const ConvGeo& g, int* win);
+int conv_dw_staged_group(const ConvGeo& g, int B);                           // rows per workgroup of the LDS-staged filter gradient (0: gather form)
 bool conv_rows_ok(const ConvGeo& g);                                          // the shape the row-block kernels are instantiated for                               // rows per workgroup of the row-block kernels (0: layer not served)
 hipError_t launch_conv_forward_rows(const ConvArgs& a, int l, int maxRows, hipStream_t s);
 hipError_t launch_conv_dw_all(const ConvArgs& a, int l, int dwBlocks, hipStream_t s);      // launch_conv_dw_rows(l) and launch_conv_dw as one launch
 hipError_t launch_conv_dw_rows(const ConvArgs& a, int l, hipStream_t s);
 hipError_t launch_conv_reduce_adam(const ConvArgs& a, const AdamHyper& hyp, int fuseAdam, hipStream_t s);
+
+// convt.hip: the layers behind the first one by workgroups that keep a sample's maps and deltas in LDS
+struct ConvTailPlan {
+  int on;                       // 0: conv.hip's per-layer launches serve the stack
+  int icPer[HL_MAX_CONV];       // input gradient of layer l: input channels per pass of the T buffer
+  int bufD;                     // floats of one delta buffer (two of them: layer l reads one, writes the other)
+  int ldsBack;                  // bytes of LDS of conv_back_kernel
+  int atari;                    // the stack behind the first layer is RACER_atari.json's: kernels with the geometry at compile time
+};
+bool conv_tail_plan(const ConvGeo* L, int nL, ConvTailPlan* pl);
+hipError_t launch_conv_back(const ConvArgs& a, const ConvTailPlan& pl, hipStream_t s);      // D of layers nL-2 .. 0 from D of layer nL-1
 
 struct PostArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;

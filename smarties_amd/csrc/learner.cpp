@@ -77,6 +77,7 @@ struct hl_learner {
   int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
+  ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
   // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
   // serve one layer type per launch: the stack runs as two segments, the lower one's outputs of EVERY window step are the upper one's
@@ -723,12 +724,17 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       { int win = 0; const int rb = getenv("SMARTIES_HIP_NO_CONV_ROWS") ? 0 : conv_row_block(g, &win);
         g.rbRows = 0; g.rbCount = 0; g.rbWin = 0;
         if (l == 0 && rb > 0 && conv_rows_ok(g)) { g.rbRows = rb; g.rbCount = (g.OpY + rb - 1) / rb; g.rbWin = win; g.nChunks = h->convB * g.rbCount; } }
-      g.dwBlock0 = blk; blk += g.rbRows ? 0 : g.nChunks * tiles;
+      // layers behind the first: both operands staged in LDS, one workgroup per (group of rows, 16 channels)
+      g.dwG = (l > 0 && !g.rbRows) ? conv_dw_staged_group(g, h->convB) : 0;
+      if (g.dwG && (((uintptr_t)g.D | (uintptr_t)h->cg[l - 1].Y) & 15)) g.dwG = 0;      // (16-byte copies: the last layer's rows may start behind extra state variables)
+      if (g.dwG) { g.nChunks = (h->convB + g.dwG - 1) / g.dwG; g.chunkRows = g.dwG * g.P; }
+      g.dwBlock0 = blk; blk += g.rbRows ? 0 : (g.dwG ? g.nChunks * (g.KnC / 16) : g.nChunks * tiles);
       HIPCK(devAlloc(&g.part, (size_t)g.nChunks * g.KnC * g.K));
       HIPCK(devAlloc(&g.Wf, (size_t)conv_prep_floats(g, 0))); HIPCK(devAlloc(&g.Wx, (size_t)conv_prep_floats(g, 1)));
       if ((long long)h->convMmax * g.P >= (1ll << 31) || (long long)h->convMmax * g.InY * g.InX >= (1ll << 31)) return fail(h, HL_ERR_UNSUPPORTED, "convolution: rows x positions >= 2^31");
     }
     h->convDwBlocks = blk;
+    if (h->nConv > 1 && !(getenv("SMARTIES_HIP_CONV_TAIL") && getenv("SMARTIES_HIP_CONV_TAIL")[0] == '0')) conv_tail_plan(h->cg, h->nConv, &h->convTail);
   }
   h->actFastOk = !h->recurrent && h->nConv == 0 && getenv("SMARTIES_HIP_NO_ACT_KERNEL") == nullptr;
   for (int j = 0; j < h->nHidden; ++j) if (h->hid[j].size > ACT_MAXW || h->hid[j].nIn > ACT_MAXW) h->actFastOk = false;

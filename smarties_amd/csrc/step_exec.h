@@ -560,6 +560,10 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
       if (nRideL) rideT0 = h->hostProbs[sb.dwIdx + h->nConv].tileStart;
     }
     int rideNext = rideT0, rideLeft = nRideL;
+    if (h->convTail.on) {      // the input gradients of every layer behind the first: one launch, a workgroup per row (convt.hip)
+      rideT0 = sb.dwBlocks;
+      HIPCK(timed(h, "conv_back", s, [&] { return launch_conv_back(ca, h->convTail, s); }));
+    } else
     for (int l = h->nConv - 1; l >= 1; --l) {
       snprintf(nm, sizeof(nm), "conv_dx%d", l);
       DenseRide rd{}; const DenseRide* prd = nullptr;

@@ -38,7 +38,7 @@ L.step(50); L.sync()
 import ctypes as C
 tot = 0.0
 for nm in ("step_tail_kernel", "stack_gather", "conv_prep", "conv_fwd0", "conv_fwd1", "conv_fwd2", "conv_fwd3", "gemm16_fwd1", "head_kernel", "gemm16_dx1",
-           "conv_dx3", "conv_dx2", "conv_dx1", "conv_dw_dense", "conv_dw_all", "conv_dw_rows", "conv_dw", "conv_reduce_adam", "gemm16_dw", "dw_direct", "post_kernel"):
+           "conv_dx3", "conv_dx2", "conv_dx1", "conv_back", "conv_fwd_tail", "conv_dw_dense", "conv_dw_all", "conv_dw_rows", "conv_dw", "conv_reduce_adam", "gemm16_dw", "dw_direct", "post_kernel"):
     ms, n = C.c_double(), C.c_int64()
     api.fn("timing_get")(L.h, nm.encode(), C.byref(ms), C.byref(n))
     print("  %-18s %8.2f us  x%d" % (nm, ms.value * 1e3, n.value)); tot += ms.value * 1e3
