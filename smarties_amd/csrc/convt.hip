@@ -408,6 +408,112 @@ static bool ctIsShape(const ConvGeo& g, int inc, int knc, int ky, int kx, int s,
   return g.InC == inc && g.KnC == knc && g.KnY == ky && g.KnX == kx && g.S == s && g.OpY == oy && g.OpX == ox;
 }
 
+// ---- conv_fwd_atari_kernel: the FORWARD pass of the same three layers as one launch (three launches of 5.7 us each until round 4; a
+// first fused version in round 4 -- one wavefront per SIMD, run-time geometry, filters through LDS -- took the 20 us of the launches it
+// replaced).  A workgroup of 16 wavefronts per row; per layer four (16 channels x 16 positions) tiles, each tile's reduction over the
+// patch split over four wavefronts, joined in LDS in wave order (fixed summation order).  Layer_Conv2D.h:88-114:
+//   X[c][p] = B[c][p] + sum_k K[c][k] in[patch_k(p)],  Y = SoftSign(X);      MFMA: M = channels, N = positions, reduction over the patch
+// A operand = filter rows in the reference's layout, 16 bytes per lane and request (the reduction index is permuted inside groups of 16:
+// lane group lc takes k = 16 S + 4 lc + j in sub-step j, for both operands); B operand = the row's input map in LDS through a table of
+// patch offsets (one 16-byte LDS read per four steps).  The next layer's filter rows are requested in front of the join.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <class SH> struct CtFwdGeo {
+  static constexpr int NKS = SH::K / 16, MT = SH::KNC / 16, NT = SH::NNT, BASE = NKS / 4, REM = NKS % 4, MAXU = BASE + (REM ? 1 : 0);
+  static_assert(SH::K % 16 == 0 && MT * NT == 4 && MAXU <= 5, "four tiles per layer, at most five groups of 16 patch elements per wavefront");
+};
+template <class SH>
+__device__ __forceinline__ void ctFwdLoadA(const float* __restrict__ Wl, f32x4 (&av)[5]) {
+  using G = CtFwdGeo<SH>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lc = lane >> 4;
+  const int tile = wave >> 2, kq = wave & 3, mt = tile / G::NT;
+  const int start = kq * G::BASE + (kq < G::REM ? kq : G::REM), count = G::BASE + (kq < G::REM ? 1 : 0);
+  const f32x4* src = reinterpret_cast<const f32x4*>(Wl + (size_t)(mt * 16 + li) * SH::K + 16 * start + 4 * lc);
+#pragma unroll
+  for (int u = 0; u < G::MAXU; ++u) av[u] = src[u < count ? 4 * u : 0];
+}
+template <class SH, bool KEEP>
+__device__ __forceinline__ void ctFwdLayerT(const f32x4 (&av)[5], const float* __restrict__ Bl, const float* __restrict__ sIn, const int* __restrict__ sK,
+                                            float* __restrict__ sRed, float* __restrict__ sOut, float* __restrict__ Xg, float* __restrict__ Yg) {
+  using G = CtFwdGeo<SH>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int tile = wave >> 2, kq = wave & 3, nt = tile % G::NT;
+  const int start = kq * G::BASE + (kq < G::REM ? kq : G::REM), count = G::BASE + (kq < G::REM ? 1 : 0);
+  // the join's element of this thread and its bias, requested now
+  const int jt = tid >> 8, idx = tid & 255, jc = (jt / G::NT) * 16 + (idx >> 4), jp = (jt % G::NT) * 16 + (idx & 15);
+  const bool jOk = jp < SH::P;
+  const float bias = Bl[jOk ? jc * SH::P + jp : 0];
+  // this lane's output position and the origin of its patch
+  const int p = nt * 16 + li, pc = p < SH::P ? p : 0, oy = pc / SH::OPX, ox = pc - oy * SH::OPX;
+  const float* inP = sIn + oy * SH::SS * SH::INX + ox * SH::SS;
+  const i32x4* kt = reinterpret_cast<const i32x4*>(sK + 16 * start + 4 * lc);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < G::MAXU; ++u) {
+    if (u < count) {
+      const i32x4 ko = kt[4 * u];
+      const float b0 = inP[ko[0]], b1 = inP[ko[1]], b2 = inP[ko[2]], b3 = inP[ko[3]];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], b1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], b2, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], b3, acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sRed[wave * 256 + (4 * lc + r) * 16 + li] = acc0[r] + acc1[r];
+  __syncthreads();
+  const float* rp = sRed + jt * 1024 + idx;
+  const float x = ((rp[0] + rp[256]) + (rp[512] + rp[768])) + bias;
+  if (jOk) {
+    const float y = x / (1 + fabsf(x));
+    Xg[jc * SH::P + jp] = x; Yg[jc * SH::P + jp] = y;
+    if (KEEP) sOut[jc * SH::P + jp] = y;
+  }
+}
+template <class SH>
+__device__ __forceinline__ void ctFwdTable(int* __restrict__ sK) {      // patch element k = (ic, fy, fx) -> offset in the input map [ic][iy][ix]
+  for (int k = threadIdx.x; k < SH::K; k += CT_NT) { const int ic = k / SH::F, f = k - ic * SH::F, fy = f / SH::KNX, fx = f - fy * SH::KNX; sK[k] = ic * SH::PIN + fy * SH::INX + fx; }
+}
+constexpr int CT_FWD_LDS = (CtA1::INC * CtA1::PIN + CtA2::INC * CtA2::PIN + CtA3::INC * CtA3::PIN + 16 * 256 + CtA1::K + CtA2::K + CtA3::K) * 4;
+__global__ __launch_bounds__(CT_NT) void conv_fwd_atari_kernel(ConvArgs a) {      // a.nL == 4: layers 1 .. 3 of the RACER_atari stack
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int nRows = a.sc->nRows[a.parity];
+  const float* W = a.W;
+  f32x4 av[5];
+  ctFwdLoadA<CtA1>(W + a.L[1].indW, av);      // (before the test on the row count: itself a load)
+  if (b >= nRows) return;
+  float* sIn1 = reinterpret_cast<float*>(smem);                  // [8][20][20]   outputs of layer 0
+  float* sIn2 = sIn1 + CtA1::INC * CtA1::PIN;                     // [16][8][8]
+  float* sIn3 = sIn2 + CtA2::INC * CtA2::PIN;                     // [32][5][5]
+  float* sRed = sIn3 + CtA3::INC * CtA3::PIN;                     // [16][256]
+  int* sK1 = reinterpret_cast<int*>(sRed + 16 * 256); int* sK2 = sK1 + CtA1::K; int* sK3 = sK2 + CtA2::K;
+  const int tid = threadIdx.x;
+  {      // the row's first-layer outputs: flat 16-byte copy
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.L[0].Y + (size_t)b * a.L[0].ldOut);
+    constexpr int n4 = CtA1::INC * CtA1::PIN / 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tid < n4) v = src[tid];
+    ctFwdTable<CtA1>(sK1); ctFwdTable<CtA2>(sK2); ctFwdTable<CtA3>(sK3);
+    if (tid < n4) reinterpret_cast<f32x4*>(sIn1)[tid] = v;
+    static_assert(n4 <= CT_NT, "one piece per thread");
+  }
+  __syncthreads();
+  ctFwdLayerT<CtA1, true>(av, W + a.L[1].indB, sIn1, sK1, sRed, sIn2, a.L[1].X + (size_t)b * a.L[1].ldOut, a.L[1].Y + (size_t)b * a.L[1].ldOut);
+  ctFwdLoadA<CtA2>(W + a.L[2].indW, av);
+  __syncthreads();
+  ctFwdLayerT<CtA2, true>(av, W + a.L[2].indB, sIn2, sK2, sRed, sIn3, a.L[2].X + (size_t)b * a.L[2].ldOut, a.L[2].Y + (size_t)b * a.L[2].ldOut);
+  ctFwdLoadA<CtA3>(W + a.L[3].indW, av);
+  __syncthreads();
+  ctFwdLayerT<CtA3, false>(av, W + a.L[3].indB, sIn3, sK3, sRed, nullptr, a.L[3].X + (size_t)b * a.L[3].ldOut, a.L[3].Y + (size_t)b * a.L[3].ldOut);
+}
+hipError_t launch_conv_fwd_tail(const ConvArgs& a, const ConvTailPlan& pl, int maxRows, hipStream_t s) {
+  if (!pl.atari) return hipErrorInvalidValue;
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_fwd_atari_kernel), (size_t)CT_FWD_LDS);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(conv_fwd_atari_kernel, dim3(maxRows), dim3(CT_NT), (size_t)CT_FWD_LDS, s, a);
+  return hipGetLastError();
+}
+
 // the plan: which layers the sample-resident kernels serve and how their LDS is cut (false: conv.hip's per-layer launches stay)
 bool conv_tail_plan(const ConvGeo* L, int nL, ConvTailPlan* pl) {
   *pl = ConvTailPlan{};

@@ -156,7 +156,8 @@ struct ConvTailPlan {
   int atari;                    // the stack behind the first layer is RACER_atari.json's: kernels with the geometry at compile time
 };
 bool conv_tail_plan(const ConvGeo* L, int nL, ConvTailPlan* pl);
-hipError_t launch_conv_back(const ConvArgs& a, const ConvTailPlan& pl, hipStream_t s);      // D of layers nL-2 .. 0 from D of layer nL-1
+hipError_t launch_conv_back(const ConvArgs& a, const ConvTailPlan& pl, hipStream_t s);
+hipError_t launch_conv_fwd_tail(const ConvArgs& a, const ConvTailPlan& pl, int maxRows, hipStream_t s);      // (pl.atari) layers 1 .. 3 forward, one launch      // D of layers nL-2 .. 0 from D of layer nL-1
 
 struct PostArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;

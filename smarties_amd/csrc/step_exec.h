@@ -412,6 +412,10 @@ int launchFront(hl_learner* h, int parity, hipStream_t s, bool gather) {
     else if (h->convPrepStale) return fail(h, HL_ERR_STATE, "convolution filter layouts are stale (ensureConvPrep was not called)");
     for (int l = 0; l < h->nConv; ++l) {
       snprintf(nm, sizeof(nm), "conv_fwd%d", l);
+      if (l == 1 && h->convTail.atari && h->convTailFwd) {      // layers 1 .. 3 of the RACER_atari stack: one launch, a workgroup per row (convt.hip)
+        HIPCK(timed(h, "conv_fwd_tail", s, [&] { return launch_conv_fwd_tail(ca, h->convTail, h->convMmax, s); }));
+        break;
+      }
       if (ca.L[l].rbRows) HIPCK(timed(h, nm, s, [&] { return launch_conv_forward_rows(ca, l, h->convMmax, s); }));
       else
       HIPCK(timed(h, nm, s, [&] { return launch_conv_forward(ca, l, h->convMmax, s); }));

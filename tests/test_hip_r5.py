@@ -36,7 +36,7 @@ def test_every_form_of_the_convolutional_backward_pass_follows_the_reference(hip
     gradients staged in LDS (default) or gathered (DW_G=0).  Each follows the reference's taps; among themselves they differ by
     summation order only."""
     ws = {}
-    for tag, env in (("default", {}), ("any_geometry", {"SMARTIES_HIP_CONV_TAIL": "2"}), ("per_layer", {"SMARTIES_HIP_CONV_TAIL": "0"}),
+    for tag, env in (("default", {}), ("any_geometry", {"SMARTIES_HIP_CONV_TAIL": "2"}), ("per_layer", {"SMARTIES_HIP_CONV_TAIL": "0"}), ("backward_only", {"SMARTIES_HIP_CONV_TAIL": "3"}),
                      ("gather_dw", {"SMARTIES_HIP_CONV_DW_G": "0"}), ("one_row_dw", {"SMARTIES_HIP_CONV_DW_G": "1"})):
         for k in ("SMARTIES_HIP_CONV_TAIL", "SMARTIES_HIP_CONV_DW_G"):
             monkeypatch.delenv(k, raising=False)
