@@ -788,7 +788,9 @@ hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s) {
 //                                                                         (sample, block) order by conv_reduce_adam_kernel
 // Requirements (conv_row_block): InX a multiple of 4, K a multiple of 16, window + operands within 64 KB of LDS.
 // ---------------------------------------------------------------------------------------------------------------
+int conv_rows_atari_rb(const ConvGeo& g);
 int conv_row_block(const ConvGeo& g, int* win) {
+  if (const int rbA = conv_rows_atari_rb(g)) { if (win) *win = (rbA - 1) * g.S + g.KnY; return rbA; }      // (whole blocks: the kernels with this layer's geometry at compile time)
   if ((g.InX & 3) || (g.KnX & 3) || (g.K & 15) || g.K > 512 || g.KnC > 32 || (long long)g.InC * g.InY * g.InX < 4096) return 0;
   int best = 0; double bestEff = 0;
   for (int rb = 1; rb <= g.OpY; ++rb) {
@@ -949,14 +951,187 @@ template <int NK, int CT> static hipError_t launchFwdRowsT(const ConvArgs& a, in
   hipLaunchKernelGGL((conv_fwd_rows_kernel<NK, CT, 8, 8>), dim3(g.rbCount, maxRows), dim3(256), lds, s, a, l);
   return hipGetLastError();
 }
+hipError_t launch_conv_forward_rows_atari(const ConvArgs& a, int maxRows, hipStream_t s);
 hipError_t launch_conv_forward_rows(const ConvArgs& a, int l, int maxRows, hipStream_t s) {
   const ConvGeo& g = a.L[l];
+  if (l == 0 && g.rbKind == 1) return launch_conv_forward_rows_atari(a, maxRows, s);
   const int nk = g.K / 4, ct = (g.KnC + 15) / 16;
   if (nk == 64 && ct == 1) return launchFwdRowsT<64, 1>(a, l, maxRows, s);      // 4 x 8 x 8 patches, <= 16 filters (RACER_atari.json)
   if (nk == 64 && ct == 2) return launchFwdRowsT<64, 2>(a, l, maxRows, s);      // ... 32 filters (the Atari paper's first layer)
   return hipErrorInvalidValue;
 }
 bool conv_rows_ok(const ConvGeo& g) { return g.K == 256 && g.KnY == 8 && g.KnX == 8 && g.KnC <= 32; }      // the instantiated shape: 4 x 8 x 8 patches
+
+
+// ---- the same two kernels for THE first layer of RACER_atari.json (84 x 84 x (1 + 3 appended frames) -> 8 filters of 8 x 8, stride 4;
+// windows read from the replay) with the geometry at compile time (round 5).  The any-geometry kernels above spend most of their
+// instructions on index arithmetic (SQ_INSTS_VALU: 2.5 M wavefront instructions per launch of the forward kernel, 0.3 M of them
+// operand reads); these launches are bound by what their wavefronts ISSUE, so the arithmetic is removed:
+//   * the window of a row block (24 image rows x 4 frames) is one flat range of 504 float4 per frame: a thread owns two positions of
+//     that range, loads mean and scale ONCE and the pixel of each of the four frames (6 requests instead of 12, no divisions);
+//   * the reduction index is permuted inside groups of 16 (lane group lc takes k = 16 g + 4 lc + j in sub-step j, for both operands):
+//     the four patch elements of a lane's sub-steps are four neighbouring pixels -> ONE 16-byte LDS read per four MFMAs, and the
+//     filter rows come as 16-byte loads straight into registers (forward);
+//   * filter gradient: every LDS address is a per-lane base + a compile-time offset (a row of 20 positions = five groups of four).
+template <int RB_> struct Atari0 {
+  static constexpr int INC = 4, IN = 84, KN = 8, S = 4, KNC = 8, OP = 20, K = 256, P = 400, RB = RB_, WR = (RB_ - 1) * 4 + 8, RBC = OP / RB_;
+  static constexpr int ROW4 = IN / 4, WIN4 = WR * ROW4, DS4 = IN * IN / 4;      // float4 per image row / window of one frame / frame
+  static constexpr int NPOS = RB * OP, NTILE = (NPOS + 15) / 16, NU = (WIN4 + 255) / 256;
+  static constexpr int LD_D = NPOS;                                             // pitch of the staged deltas [16][LD_D]
+  static constexpr size_t LDS_FWD = (size_t)INC * WR * IN * 4;
+  static constexpr size_t LDS_DW = (size_t)(INC * WR * IN + 16 * LD_D) * 4;
+  static_assert(OP % RB_ == 0 && NPOS % 4 == 0 && KNC * (NPOS / 4) <= 256, "whole row blocks");
+};
+int conv_rows_atari_rb(const ConvGeo& g) {      // rows per block of this layer when it is the first layer of RACER_atari.json (0: another layer)
+  if (!(g.InC == 4 && g.InY == 84 && g.InX == 84 && g.KnY == 8 && g.KnX == 8 && g.S == 4 && g.KnC == 8 && g.OpY == 20 && g.OpX == 20)) return 0;
+  const char* e = getenv("SMARTIES_HIP_CONV_RB");
+  const int v = e ? atoi(e) : 0;
+  return (v == 2 || v == 4 || v == 5) ? v : 4;      // (RACER_atari step: 97.3 us at 4 -- five full position tiles per block --, 98.3 at 5, 103.5 at 2)
+}
+bool conv_rows_atari(const ConvGeo& g, const ConvSource& src) {
+  const int rb = conv_rows_atari_rb(g);
+  return rb && src.on && src.nApp == 3 && src.dS == 84 * 84 && (g.rbRows == 2 || g.rbRows == 4 || g.rbRows == 5) && g.rbWin == (g.rbRows - 1) * 4 + 8 && g.rbCount == 20 / g.rbRows;
+}
+// the window of row block rb of the state at (slot, t): sIn[frame][WR rows][84], standardised (Episode.h:172-183: frame j = j steps back, the
+// first state repeated in front of the episode's start)
+template <class A0>
+__device__ __forceinline__ void atari0StageWindow(float* __restrict__ sIn, const ConvSource& src, long long slot, int t, int rb) {
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(src.mean) + rb * (A0::RB * A0::S) * A0::ROW4;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src.scale) + rb * (A0::RB * A0::S) * A0::ROW4;
+  const f32x4* S4 = reinterpret_cast<const f32x4*>(src.S) + rb * (A0::RB * A0::S) * A0::ROW4;
+  const int tid = threadIdx.x;
+  f32x4 mu[A0::NU], sc[A0::NU], v[A0::NU][A0::INC];
+#pragma unroll
+  for (int u = 0; u < A0::NU; ++u) {
+    const int w = tid + 256 * u;
+    if (w < A0::WIN4) {
+      mu[u] = m4[w]; sc[u] = s4[w];
+#pragma unroll
+      for (int j = 0; j < A0::INC; ++j) { const int back = j < t ? j : t; v[u][j] = S4[(size_t)(slot - back) * A0::DS4 + w]; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < A0::NU; ++u) {
+    const int w = tid + 256 * u;
+    if (w < A0::WIN4) {
+#pragma unroll
+      for (int j = 0; j < A0::INC; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[u][j][e] - mu[u][e]) * sc[u][e];
+        reinterpret_cast<f32x4*>(sIn)[j * A0::WIN4 + w] = o;
+      }
+    }
+  }
+}
+template <int RB>
+__global__ __launch_bounds__(256) void conv_fwd_rows_atari_kernel(ConvArgs a) {
+  using A0 = Atari0<RB>;
+  constexpr int K = A0::K, IN = A0::IN, S = A0::S, OP = A0::OP, P = A0::P, WR = A0::WR, NPOS = A0::NPOS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const ConvGeo& g = a.L[0];
+  const int row = blockIdx.y, rb = blockIdx.x;
+  const int nRowsNow = a.sc->nRows[a.parity];
+  long long rowSlot = 0; int rowT = 0;
+  if (row < a.B) replayRowOrigin(a.src, row, a.B, &rowSlot, &rowT);      // (minibatch rows: requested beside the row count, not behind the test on it)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  // this lane's filter row (channel li; rows 8 .. 15 of the padded layout are zero), elements 16 G + 4 lc .. + 3 of every group G
+  f32x4 av[K / 16];
+  {
+    const f32x4* wf = reinterpret_cast<const f32x4*>(g.Wf + (size_t)li * (K + 4)) + lc;
+#pragma unroll
+    for (int G = 0; G < K / 16; ++G) av[G] = wf[4 * G];
+  }
+  if (row >= nRowsNow) return;
+  if (row >= a.B) replayRowOrigin(a.src, row, a.B, &rowSlot, &rowT);
+  float* sIn = reinterpret_cast<float*>(smem);
+  atari0StageWindow<A0>(sIn, a.src, rowSlot, rowT, rb);
+  __syncthreads();
+  const float* Bl = a.W + g.indB + rb * NPOS;
+  float* Xr = g.X + (size_t)row * g.ldOut + rb * NPOS; float* Yr = g.Y + (size_t)row * g.ldOut + rb * NPOS;
+  // patch element k = 16 G + 4 lc + j: frame G / 4, filter row 2 (G % 4) + lc / 2, filter columns 4 (lc % 2) + j
+  const int laneOff = (lc >> 1) * IN + (lc & 1) * 4;
+  for (int tl = wave; tl < A0::NTILE; tl += 4) {
+    const int pl = tl * 16 + li; const bool ok = pl < NPOS;
+    const int pc = ok ? pl : 0, oyl = pc / OP, ox = pc - oyl * OP;
+    float bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = (ok && lc < 2) ? Bl[(4 * lc + q) * P + pl] : 0.f;
+    const f32x4* pIn = reinterpret_cast<const f32x4*>(sIn + oyl * S * IN + ox * S + laneOff);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int G = 0; G < K / 16; ++G) {
+      const f32x4 bv = pIn[((G >> 2) * WR * IN + 2 * (G & 3) * IN) / 4];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[G][0], bv[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[G][1], bv[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[G][2], bv[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[G][3], bv[3], acc1, 0, 0, 0);
+    }
+    if (ok && lc < 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = (acc0[q] + acc1[q]) + bq[q];
+        Xr[(4 * lc + q) * P + pl] = x; Yr[(4 * lc + q) * P + pl] = softsignEval(x);
+      }
+    }
+  }
+}
+template <int RB> static hipError_t launchFwdRowsAtariT(const ConvArgs& a, int maxRows, hipStream_t s) {
+  hipError_t e = ensureDynLds(reinterpret_cast<const void*>(conv_fwd_rows_atari_kernel<RB>), Atari0<RB>::LDS_FWD);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(conv_fwd_rows_atari_kernel<RB>, dim3(Atari0<RB>::RBC, maxRows), dim3(256), Atari0<RB>::LDS_FWD, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_conv_forward_rows_atari(const ConvArgs& a, int maxRows, hipStream_t s) {
+  const int rb = a.L[0].rbRows;
+  return rb == 5 ? launchFwdRowsAtariT<5>(a, maxRows, s) : (rb == 4 ? launchFwdRowsAtariT<4>(a, maxRows, s) : launchFwdRowsAtariT<2>(a, maxRows, s));
+}
+// filter gradient of (row block rb, row b): part[(b RBC + rb)][c][k], c < 8
+template <int RB>
+__device__ __forceinline__ void convDwRowsAtariT(const ConvArgs& a, int rb, int b, unsigned char* smem) {
+  using A0 = Atari0<RB>;
+  constexpr int K = A0::K, IN = A0::IN, S = A0::S, P = A0::P, WR = A0::WR, NPOS = A0::NPOS, LD_D = A0::LD_D, KNC = A0::KNC;
+  const ConvGeo& g = a.L[0];
+  float* sIn = reinterpret_cast<float*>(smem);
+  float* sD = sIn + A0::INC * WR * IN;                   // [16][LD_D]: deltas of the block's positions, channels 8 .. 15 zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  long long slot; int t;
+  replayRowOrigin(a.src, b, a.B, &slot, &t);
+  f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+  const int dc = tid / (NPOS / 4), dq = tid - dc * (NPOS / 4);      // NPOS / 4 float4 per channel
+  if (tid < KNC * (NPOS / 4)) dv = reinterpret_cast<const f32x4*>(g.D + (size_t)b * g.ldOut + (size_t)dc * P + rb * NPOS)[dq];
+  atari0StageWindow<A0>(sIn, a.src, slot, t, rb);
+  if (tid < KNC * (NPOS / 4)) reinterpret_cast<f32x4*>(sD + dc * LD_D)[dq] = dv;
+  for (int i = tid; i < 8 * LD_D; i += 256) sD[8 * LD_D + i] = 0.f;
+  __syncthreads();
+  // this wavefront's patch-element tiles kt = wave, wave + 4, wave + 8, wave + 12; the lane's element k = kt 16 + li of each:
+  // frame k / 64, filter row (k % 64) / 8, column k % 8; reduction row r = 4 s + lc = position (s / 5, 4 (s % 5) + lc) of the block
+  const float* pB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int k = (wave + 4 * j) * 16 + li; pB[j] = sIn + (k >> 6) * WR * IN + ((k >> 3) & 7) * IN + (k & 7) + lc * S; }
+  const float* pA = sD + li * LD_D + lc;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int s = 0; s < NPOS / 4; ++s) {
+    const float d = pA[4 * s];
+    const int off = (s / 5) * S * IN + (s % 5) * 4 * S;      // (a constant after unrolling)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, pB[j][off], acc[j], 0, 0, 0);
+  }
+  if (lc < 2) {
+    float* part = g.part + ((size_t)b * A0::RBC + rb) * (size_t)KNC * K + (size_t)(4 * lc) * K + li;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[(size_t)q * K + (wave + 4 * j) * 16] = acc[j][q];
+  }
+}
+__device__ __forceinline__ void convDwRowsAtariBody(const ConvArgs& a, int bx, unsigned char* smem) {      // bx = b rbCount + rb
+  const int rbr = a.L[0].rbRows;
+  if (rbr == 5) convDwRowsAtariT<5>(a, bx & 3, bx >> 2, smem);
+  else if (rbr == 4) convDwRowsAtariT<4>(a, bx % 5, bx / 5, smem);
+  else convDwRowsAtariT<2>(a, bx % 10, bx / 10, smem);
+}
 
 // filter gradient of such a layer: partial [KnC][K] of (sample b, row block rb) -> part[(b nRB + rb)][c][k]
 template <int CT>
@@ -1029,7 +1204,8 @@ __device__ __forceinline__ void convDwRowsBody(const ConvArgs& a, int l, int rb,
 template <int CT>
 __global__ __launch_bounds__(256) void conv_dw_rows_kernel(ConvArgs a, int l) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  convDwRowsBody<CT>(a, l, (int)blockIdx.x, (int)blockIdx.y, smem);
+  if (CT == 1 && a.L[l].rbKind == 1) convDwRowsAtariBody(a, (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, smem);
+  else convDwRowsBody<CT>(a, l, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 // both filter-gradient launches as one (they depend on the deltas only): the first nRowBlocks workgroups take (sample, row block)
 // pairs of layer l, the others the (layer, tile, chunk) problems of conv_dw_kernel
@@ -1037,7 +1213,10 @@ template <int CT>
 __global__ __launch_bounds__(256) void conv_dw_all_kernel(ConvArgs a, int l, int nRowBlocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bx = (int)blockIdx.x;
-  if (bx < nRowBlocks) { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); }
+  if (bx < nRowBlocks) {
+    if (CT == 1 && a.L[l].rbKind == 1) convDwRowsAtariBody(a, bx, smem);
+    else { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); }
+  }
   else convDwBody(a, bx - nRowBlocks, smem);
 }
 // ... and, behind them, the tiles of the dense layers' weight gradients (dw_wide_dev.h: one workgroup per 16 x 16 tile, operands
@@ -1048,11 +1227,23 @@ __global__ __launch_bounds__(256) void conv_dw_dense_kernel(ConvArgs a, int l, i
                                                             int nTiles, AdamHyper hyp, ExtraArgs extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int bx = (int)blockIdx.x;
-  if (extra.role) { if (bx == 0) { if (extra.role == 3) farBetaPhase(extra.post, smem); return; } --bx; }
-  if (bx < nRowBlocks) { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); return; }
+#ifdef HL_CONVT_STAMPS
+  // development (tools/convt_stamps.py dw): start of the launch's first workgroup, last end per family of workgroups (100 MHz clock)
+  auto fin = [&](int fam) { __syncthreads(); if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(a.sc->dbgT) + 20 + fam, (unsigned long long)wall_clock64()); };
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sc->dbgT[19] = wall_clock64();
+#else
+  auto fin = [&](int) {};
+#endif
+  if (extra.role) { if (bx == 0) { if (extra.role == 3) farBetaPhase(extra.post, smem); fin(0); return; } --bx; }
+  if (bx < nRowBlocks) {
+    if (CT == 1 && a.L[l].rbKind == 1) convDwRowsAtariBody(a, bx, smem);
+    else { const int rbCount = a.L[l].rbCount; convDwRowsBody<CT>(a, l, bx % rbCount, bx / rbCount, smem); }
+    fin(1); return;
+  }
   bx -= nRowBlocks;
-  if (bx < nConvDw) { convDwBody(a, bx, smem); return; }
+  if (bx < nConvDw) { convDwBody(a, bx, smem); fin(2); return; }
   dwWideBody<16>(probs, nProbs, nTiles, 1, nullptr, nullptr, a.sc, hyp, bx - nConvDw, smem);      // (B <= 128: launch_conv_dw_dense)
+  fin(3);
 }
 static size_t convRowsDwLds(const ConvGeo& g) {
   const int ct = (g.KnC + 15) / 16, ldD = g.rbRows * g.OpX + 4;

@@ -109,6 +109,7 @@ struct ConvGeo {
   // row-block kernels (conv.hip: conv_fwd_rows_kernel / conv_dw_rows_kernel; layers with a large input image): a workgroup owns
   // rbRows output rows of one sample and stages the rbWin input rows under them in LDS.  rbRows = 0: not used for this layer.
   int rbRows, rbCount, rbWin;
+  int rbKind;                // 1: the first layer of RACER_atari.json read from the replay -- kernels with the geometry at compile time (set per launch: convArgs)
   // filter gradient with the operands staged in LDS (conv.hip: convDwStaged; layers behind the first): a workgroup owns dwG rows
   // (samples) x one tile of 16 channels and leaves one partial per group of rows.  0: the gather workgroups (tile, chunk) above.
   int dwG;
@@ -141,6 +142,7 @@ bool conv_dx_rides(const ConvGeo& g);
 hipError_t launch_conv_dw(const ConvArgs& a, int totalBlocks, hipStream_t s);
 int conv_row_block(const ConvGeo& g, int* win);
 int conv_dw_staged_group(const ConvGeo& g, int B);                           // rows per workgroup of the LDS-staged filter gradient (0: gather form)
+bool conv_rows_atari(const ConvGeo& g, const ConvSource& src);                // ... and their form with the geometry at compile time serves this layer / source
 bool conv_rows_ok(const ConvGeo& g);                                          // the shape the row-block kernels are instantiated for                               // rows per workgroup of the row-block kernels (0: layer not served)
 hipError_t launch_conv_forward_rows(const ConvArgs& a, int l, int maxRows, hipStream_t s);
 hipError_t launch_conv_dw_all(const ConvArgs& a, int l, int dwBlocks, hipStream_t s);      // launch_conv_dw_rows(l) and launch_conv_dw as one launch

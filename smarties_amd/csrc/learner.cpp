@@ -77,6 +77,7 @@ struct hl_learner {
   int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
+  bool convRowsAtari = true;    // the first layer's row-block kernels with the RACER_atari geometry at compile time (SMARTIES_HIP_CONV_ROWS_ATARI=0: any-geometry kernels)
   bool convTailFwd = true;      // ... the forward pass of those layers as well (SMARTIES_HIP_CONV_TAIL=3: backward only)
   ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
@@ -737,6 +738,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     h->convDwBlocks = blk;
     if (h->nConv > 1 && !(getenv("SMARTIES_HIP_CONV_TAIL") && getenv("SMARTIES_HIP_CONV_TAIL")[0] == '0')) conv_tail_plan(h->cg, h->nConv, &h->convTail);
     if (const char* e = getenv("SMARTIES_HIP_CONV_TAIL")) h->convTailFwd = e[0] != '3';
+    if (const char* e = getenv("SMARTIES_HIP_CONV_ROWS_ATARI")) h->convRowsAtari = e[0] != '0';
   }
   h->actFastOk = !h->recurrent && h->nConv == 0 && getenv("SMARTIES_HIP_NO_ACT_KERNEL") == nullptr;
   for (int j = 0; j < h->nHidden; ++j) if (h->hid[j].size > ACT_MAXW || h->hid[j].nIn > ACT_MAXW) h->actFastOk = false;

@@ -377,6 +377,7 @@ void convSource(hl_learner* h, int parity, ConvArgs* ca) {
   const DevBatch& bt = h->buf[parity].bt;
   ca->src.on = 1; ca->src.S = h->rp.S; ca->src.mean = h->rp.stMean; ca->src.scale = h->rp.stScale; ca->src.dS = h->dS; ca->src.nApp = h->nApp;
   ca->src.slot = bt.slot; ca->src.t = bt.t; ca->src.nextSrc = bt.nextSrc;
+  ca->L[0].rbKind = (h->convRowsAtari && conv_rows_atari(ca->L[0], ca->src)) ? 1 : 0;      // (the first layer of RACER_atari.json: geometry at compile time)
 }
 // `gather`: states with appended observations / convolutional input are assembled here, from the sampled slots
 // (rollout inference writes the standardised rows itself)

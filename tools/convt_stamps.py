@@ -24,5 +24,9 @@ for it in range(30):
     L.step(8)
     out = (C.c_longlong * 32)(); assert g(L.h, out) == 0
     acc.append(np.array(list(out), dtype=np.int64))
-d = np.diff(np.array(acc)[:, 0:n], axis=1) * 10
+a = np.array(acc)
+if len(sys.argv) > 2 and sys.argv[2] == "dw":
+    print("conv_dw_dense launch, ns after its first workgroup's start: last end of [rider, row blocks, layers 1-3, dense tiles] =",
+          [int(np.median(a[:, 20 + f] - a[:, 19]) * 10) for f in range(4)])
+d = np.diff(a[:, 0:n], axis=1) * 10
 print("ns between stamps (median of 30):", " ".join("%d" % v for v in np.median(d, axis=0)), "| total", int(np.median(d.sum(axis=1))))
