@@ -482,6 +482,7 @@ __global__ __launch_bounds__(CT_NT) void conv_fwd_atari_kernel(ConvArgs a) {    
   f32x4 av[5];
   ctFwdLoadA<CtA1>(W + a.L[1].indW, av);      // (before the test on the row count: itself a load)
   if (b >= nRows) return;
+  CTSTAMP(24);
   float* sIn1 = reinterpret_cast<float*>(smem);                  // [8][20][20]   outputs of layer 0
   float* sIn2 = sIn1 + CtA1::INC * CtA1::PIN;                     // [16][8][8]
   float* sIn3 = sIn2 + CtA2::INC * CtA2::PIN;                     // [32][5][5]
@@ -498,13 +499,19 @@ __global__ __launch_bounds__(CT_NT) void conv_fwd_atari_kernel(ConvArgs a) {    
     static_assert(n4 <= CT_NT, "one piece per thread");
   }
   __syncthreads();
+  CTSTAMP(25);
   ctFwdLayerT<CtA1, true>(av, W + a.L[1].indB, sIn1, sK1, sRed, sIn2, a.L[1].X + (size_t)b * a.L[1].ldOut, a.L[1].Y + (size_t)b * a.L[1].ldOut);
   ctFwdLoadA<CtA2>(W + a.L[2].indW, av);
+  CTSTAMP(26);
   __syncthreads();
+  CTSTAMP(27);
   ctFwdLayerT<CtA2, true>(av, W + a.L[2].indB, sIn2, sK2, sRed, sIn3, a.L[2].X + (size_t)b * a.L[2].ldOut, a.L[2].Y + (size_t)b * a.L[2].ldOut);
   ctFwdLoadA<CtA3>(W + a.L[3].indW, av);
+  CTSTAMP(28);
   __syncthreads();
+  CTSTAMP(29);
   ctFwdLayerT<CtA3, false>(av, W + a.L[3].indB, sIn3, sK3, sRed, nullptr, a.L[3].X + (size_t)b * a.L[3].ldOut, a.L[3].Y + (size_t)b * a.L[3].ldOut);
+  CTSTAMP(30);
 }
 hipError_t launch_conv_fwd_tail(const ConvArgs& a, const ConvTailPlan& pl, int maxRows, hipStream_t s) {
   if (!pl.atari) return hipErrorInvalidValue;

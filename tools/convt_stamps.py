@@ -28,5 +28,7 @@ a = np.array(acc)
 if len(sys.argv) > 2 and sys.argv[2] == "dw":
     print("conv_dw_dense launch, ns after its first workgroup's start: last end of [rider, row blocks, layers 1-3, dense tiles] =",
           [int(np.median(a[:, 20 + f] - a[:, 19]) * 10) for f in range(4)])
+if len(sys.argv) > 2 and sys.argv[2] == "fwd":
+    print("conv_fwd_atari_kernel, row 0 (ns): stage + tables %d | layer 1 to its join's barrier %d + %d | layer 2 %d + %d | layer 3 join %d" % tuple(np.median(np.diff(a[:, 24:31], axis=1), axis=0) * 10))
 d = np.diff(a[:, 0:n], axis=1) * 10
 print("ns between stamps (median of 30):", " ".join("%d" % v for v in np.median(d, axis=0)), "| total", int(np.median(d.sum(axis=1))))
