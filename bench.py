@@ -121,7 +121,7 @@ def synthetic_episode(np, e, dS=17, dA=6, N=EP_STATES):
     return dict(states=S, actions=A, mu=MU, rewards=R, values=V, terminated=0, tag=e)
 
 
-def other_configs(api, steps=1000):
+def other_configs(api, steps=1000, only=None):
     """us per gradient step of the other BASELINE.json configurations (parity-tested shapes, not the bench workload): small
     synthetic replays resident in HBM, `steps` replayed steps after a warm-up.  Reported next to the bench line."""
     import numpy as np
@@ -143,11 +143,22 @@ def other_configs(api, steps=1000):
         "cfgNS_2x256_b1024": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=1048576), 2500, 200, max(100, steps // 2)),
         "cfgNS_2x256_b4096": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=1048576), 2500, 200, max(100, steps // 4)),
         "cfgNS_2x256_b16384": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=16384, maxTotObsNum=1048576), 2500, 200, max(50, steps // 10)),
+        # settings/RACER_glider.json (a shipped preset): RACER with the Gaussian advantage, three hidden layers of 128 -- the generic launches
+        "glider_racer_3x128_gauss_b256": (dict(dimS=10, dimA=1, bounded=[1], hidden=(128, 128, 128), nnFunc="Tanh", batchSize=256, maxTotObsNum=524288,
+                                               gamma=1.0, adv_kind=capi.ADV_GAUSSIAN, epsAnneal=2e-7, nnLambda=1e-6, penalTol=0.05, clipImpWeight=1.0), 400, 200, steps),
+        # combinations no settings file builds, replayed as captured launch lists since round 5: an LSTM layer behind two convolutions on
+        # 1 + 3 stacked frames; an RNN encoder under MGU layers (a partially observable MDP with nnType left at its default)
+        "conv2_lstm32_b64_bptt4": (dict(dimS=256, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=5, nAppendedObs=3, conv=[(8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)],
+                                        hidden=(32,), nnFunc="Tanh", batchSize=64, maxTotObsNum=65536, nn_type=capi.NN_LSTM, nnBPTTseq=4), 300, 60, max(100, steps // 4)),
+        "pomdp_rnn24_mgu2x16_b128_bptt5": (dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(16, 16), encoder=[24], encoder_rnn=1, nn_type=capi.NN_MGU, nnFunc="Tanh",
+                                                batchSize=128, maxTotObsNum=131072, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=5), 300, 100, max(100, steps // 4)),
         "cfg5_racer_atari_conv4_512_b128": (dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3, conv=conv, hidden=(512,),
                                                  nnFunc="Tanh", batchSize=128, maxTotObsNum=20000, gamma=0.99, explNoise=0.05), 120, 60, max(100, steps // 5)),
     }
     res = {}
     for name, (kw, nEp, N, n) in cases.items():
+        if only and not any(o in name for o in only):
+            continue
         g = np.random.default_rng(5)
         try:
             L = capi.Learner(api, capi.make_config(randSeed=7, **kw))

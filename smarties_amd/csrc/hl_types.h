@@ -172,7 +172,7 @@ struct GemmProblem {
 };
 
 // one-kernel exchange between replicas (xchg.hip): sequence number of the next collective, arrival count of its workgroups
-struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int pad; };
+struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int arrived; /* workgroups of the running collective whose peers' stamps all came (FUSE: nobody applies Adam before all have) */ };
 // replicas connected through peer windows: the weight-gradient launch stores every gradient tile into the peers' windows as well
 // (16-byte stores over xGMI from the tile's epilogue), so the transfer overlaps the launch and the exchange kernel behind it only
 // stamps, waits, sums and applies Adam (round 4; before: the exchange kernel pushed the whole message after the launch)

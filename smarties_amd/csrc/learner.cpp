@@ -149,6 +149,7 @@ struct hl_learner {
   double* dStatsOut = nullptr;
   // replayed graphs: one per entry of GRAPH_SIZES and starting minibatch buffer (step_exec.h)
   GraphSlot graphs[16][2]; bool graphsStale = false, useGraph = true;
+  bool plainGraph = false;      // the replayed steps of this net are stepEager's launches as graph nodes (the next minibatch's sampler in front): nets none of the rider forms serves
   // graphs of exactly n steps (hl_prepare_steps, or a call size seen three times in a row): the whole call is one launch
   // and its last node stamps a pinned host word, which hl_sync polls (tools/call_bench.hip)
   std::map<int, std::array<GraphSlot, 2>> exactGraphs;
@@ -180,7 +181,7 @@ struct hl_learner {
   // wait of the exchange kernel for a peer's message (SMARTIES_HIP_XCHG_TIMEOUT_MS): replicas are gated independently by their data
   // (blockGradientUpdates), so a peer may legitimately lag by seconds -- the reference's MPI_Iallreduce simply waits; ten minutes,
   // then the learner's sticky device error (the state stays as it was before that collective)
-  long long xchgTimeoutTicks = 60000000000LL;   // 600 s at 100 MHz
+  long long xchgTimeoutTicks = 6000000000LL;    // 60 s at 100 MHz (SMARTIES_HIP_XCHG_TIMEOUT_MS): how long a replica waits inside the exchange kernel for its peers
   // moments exchange state
   bool momentsPending = false;
   // timing
@@ -687,7 +688,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     h->convB = B * h->recK; h->convMmax = (int)roundUp((long long)h->convB + B, 16);
     HIPCK(devAlloc(&h->winSlot, (size_t)h->convB)); HIPCK(devAlloc(&h->winT, (size_t)h->convB)); HIPCK(devAlloc(&h->winNextSrc, (size_t)B));
     HIPCK(devAlloc(&h->scW, 1));
-    h->useGraph = false;      // these nets step eagerly (no riders on their launches; no shipped settings file builds them)
+    h->plainGraph = true;     // (no riders on these nets' launches: their replayed steps are the eager launch list, captured -- step_exec.h: captureSteps)
   }
   if (h->bigBatch) {
     if (const char* e = getenv("SMARTIES_HIP_BIG_GRAPH")) { if (e[0] == '0') h->useGraph = false; }      // (0: plain steps of large batches issued launch by launch, as before the end of round 4)
@@ -748,7 +749,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     h->recSplit = h->nEncLayers; h->ldSeg = (int)roundUp(top.size, 16);
     const size_t R = (size_t)B * h->recK;
     HIPCK(devAlloc(&h->segY, (R + B) * h->ldSeg)); HIPCK(devAlloc(&h->segDres, R * h->ldSeg)); HIPCK(devAlloc(&h->segScratch, R * h->ldSeg));
-    h->useGraph = false;      // (eager steps, as for the other combinations no settings file builds)
+    h->plainGraph = true;     // (as for recurrent layers behind convolutions: the eager launch list, captured)
   }
   if (h->recurrent) {
     const size_t R = (size_t)B * h->recK;

@@ -894,6 +894,16 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
   const long long nColl0 = h->nCollectives;      // captured calls are counted when the graph is replayed
   for (int j = 0; j < U && !rc; ++j) {
     const int p = (p0 + j) & 1;
+    if (h->plainGraph) {
+      // nets whose launches take no riders (recurrent layers behind convolutions, an RNN encoder under MGU layers): stepEager's plain
+      // step as graph nodes -- the sampler of the NEXT step first (nothing of this step changes what it reads; it keeps the generator's
+      // state for dropPresample), then the step's launch list and its bookkeeping.  12 - 20 launches per step lose their host latency.
+      SampleArgs sa = sampleArgs(h, p ^ 1, nullptr, false); sa.backupRng = 1;
+      if (launch_sample(sa, s0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "sampler of the next step"); break; }
+      rc = launchMlp(h, p, true, s0); if (rc) break;
+      rc = launchPost(h, p, POST_AGG | POST_BETA, s0); if (rc) break;
+      continue;
+    }
     if (h->bigBatch) {
       // large batches (stepEager's plain step as graph nodes): the sampler of the NEXT step -- one workgroup, hundreds of microseconds --
       // is a branch of the graph beside this step's launches (the side stream joins the capture through the event), joined in front

@@ -63,17 +63,32 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
     const long long t0 = wall_clock64();
     while (ldSys(f) < tag) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > a.timeoutTicks) { a.sc->errFlag = 79; sFail = 1; break; }
+      if (wall_clock64() - t0 > a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sFail = 1; break; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
   }
   __syncthreads();
-  // A peer's message never came (or an earlier collective already failed: the error is sticky): this workgroup does no sum, no Adam,
-  // no bookkeeping -- the slots hold an older collective's data.  The guarantee is PER CHUNK, not per collective: a
-  // chunk whose peers did arrive may have summed and applied Adam to its slice before another chunk times out, so after device
-  // error 79 the parameter vector may be partially updated -- the error is fatal for the learner's state (the host sees
-  // HL_ERR_HIP at its next read-back and has to restart from a checkpoint); what the bounded wait buys is that the GPU is not
-  // hung.  The sequence still advances, so nothing waits on this collective later.
+  if constexpr (FUSE) {
+    // Two phases (round 5; ADVICE r03 / VERDICT r04): a chunk whose peers arrived used to sum and apply Adam at once -- if another
+    // chunk then timed out, the parameter vector was left PARTIALLY updated.  Now every workgroup reports that its stamps came and
+    // waits until all nCh have (they are resident together: at most XCHG_CHUNKS workgroups); a single failure -- the sticky device
+    // error -- makes every workgroup skip its sum and its Adam slice: after error 79 weights and moments are those of before the
+    // collective.  Costs one counter round trip among the launch's workgroups per gradient exchange.
+    if (tid == 0) {
+      if (!sFail) __hip_atomic_fetch_add(&a.ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t0 = wall_clock64();
+      while (!sFail && __hip_atomic_load(&a.ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nCh) {
+        if (__hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sFail = 1; break; }
+        if (wall_clock64() - t0 > 2 * a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sFail = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  }
+  // A peer's message never came (or an earlier collective already failed: the error is sticky): no workgroup sums, applies Adam or
+  // runs the bookkeeping -- the slots hold an older collective's data, the parameters stay as they were (gradient messages: the
+  // two-phase wait above; the other messages have no side effect beyond their own buffer).  The host sees HL_ERR_HIP at its next
+  // read-back.  The sequence still advances, so nothing waits on this collective later.
   const bool failed = sFail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   // ---- sum in rank order ----
   const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
     const bool last = atomicAdd(&a.ctl->done, 1u) == (unsigned)nCh - 1;
     sLast = last ? 1 : 0;
     if (last) {
-      a.ctl->done = 0;
+      a.ctl->done = 0; a.ctl->arrived = 0;      // (every workgroup left the two-phase wait before it added to `done`)
       __hip_atomic_store(&a.ctl->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

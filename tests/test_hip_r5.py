@@ -46,3 +46,43 @@ def test_every_form_of_the_convolutional_backward_pass_follows_the_reference(hip
     ref = ws["default"]
     for tag, w in ws.items():
         assert np.abs(w - ref).max() <= 1e-5 * np.abs(ref).max(), tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,nEps", [(4096, 250), (16384, 700)], ids=["b4096", "b16384"])
+def test_bench_network_at_the_timed_large_batches_matches_oracle(hip_api, B, nEps):
+    """bench.py's other_configs rows cfgNS_2x256_b4096 / b16384 (17 states, 6 bounded actions, 2 x 256 SoftSign) at their own shape:
+    the 64 x 64 weight-gradient tiles over row chunks and the weight-stationary panels (bigmm.hip) at K = B rows x N = 256 columns,
+    the panel head, the 1024-thread sampler -- sampled indices, generator state, per-sample taps and the updated weights against
+    the oracle (these rows were timed, not checked; Learner_approximator.cpp:67-77 is shape-agnostic)."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=B, maxTotObsNum=1048576, randSeed=42)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=7, dimS=17, dimA=6, lenMin=40, lenMax=200, pTerm=0.3), nEps)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+        _compare_step(G, O)
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+
+
+@pytest.mark.gpu
+def test_timed_out_gradient_exchange_leaves_the_parameters_as_they_were(hip_api, monkeypatch):
+    """One of two connected replicas steps, its peer never does: the exchange kernel's wait ends after SMARTIES_HIP_XCHG_TIMEOUT_MS and
+    the learner reports a device error -- with weights and both moments exactly those of before the step (round 5: no chunk applies
+    Adam before all chunks' peers have arrived; until round 4 the update could be partial).  Optimizer.cpp:110-132."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _xchg_replicas, _both
+    monkeypatch.setenv("SMARTIES_HIP_XCHG_TIMEOUT_MS", "300")
+    cfg_kw = dict(dimS=6, dimA=2, hidden=(64, 64), batchSize=32, maxTotObsNum=4000, randSeed=5)
+    Ls = _xchg_replicas(hip_api, cfg_kw, synth_cfg(seed=3, dimS=6, dimA=2, lenMin=8, lenMax=40, pTerm=0.5), "after")
+    _both(Ls, lambda L: (L.step(3), L.sync()))
+    before = [a.copy() for a in Ls[0].get_params()]
+    with pytest.raises(capi.HlError):
+        Ls[0].step(1)
+        Ls[0].sync()
+        Ls[0].scalars()
+    after = Ls[0].get_params()
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
