@@ -388,6 +388,28 @@ def main():
         L.initialize()
         return L, t_fill, transport
 
+    # N > 1: the single-replica value of THIS box first (rank 0 alone, the N = 1 workload, the same K steps after W warm-up steps), so
+    # that the weak-scaling row can state its efficiency against N x that value in the same run; the other ranks wait at the barrier
+    single_ref = None
+    if n_ranks > 1 and os.environ.get("SMARTIES_BENCH_SINGLE_REF", "1") != "0":
+        if rank == 0:
+            try:
+                L1 = capi.Learner(api, capi.make_config(device_id=local_rank % ndev, **CFG))
+                L1.init_weights()
+                for e in range(N_EPISODES):
+                    L1.append_episode(**synthetic_episode(np, e))
+                L1.initialize()
+                if args.warmup > 0:
+                    L1.prepare_steps(args.warmup)
+                L1.prepare_steps(args.steps)
+                L1.step(args.warmup); torch.cuda.synchronize(); L1.sync()
+                t1 = time.perf_counter(); L1.step(args.steps); torch.cuda.synchronize(); L1.sync()
+                single_ref = CFG["batchSize"] * args.steps / (time.perf_counter() - t1)
+                L1.close()
+            except Exception as e:  # noqa: BLE001
+                print("rank 0: single-replica reference failed (%s)" % e, file=sys.stderr, flush=True)
+        dist.barrier()
+
     L, t_fill, transport = build(CFG, N_EPISODES)
     host_exchange, host_group = state["host_exchange"], state["host_group"]
     if n_ranks > 1 and host_exchange:
@@ -482,6 +504,15 @@ def main():
 
     B_global = CFG["batchSize"]
     value = B_global * args.steps / dt
+    # which transport each rank ended up with (they agree by construction -- all_ok() -- but the line says so rank by rank)
+    transports = ["host (gloo, split-step entry points)" if (n_ranks > 1 and host_exchange) else transport]
+    if n_ranks > 1:
+        try:
+            gathered = [None] * n_ranks
+            dist.all_gather_object(gathered, transports[0])
+            transports = gathered
+        except Exception as e:  # noqa: BLE001
+            transports = transports + ["(gather failed: %s)" % e]
 
     # diagnostics, after the timed region and outside `value`: the same call once more (what a first call pays on top: page walks,
     # first launch of the call's graph, clocks) and the sustained rate over 2000 steps
@@ -506,7 +537,8 @@ def main():
                                    "global batch 256 split over %d replica(s), replay split likewise, "
                                    "device-side mt19937 sampler" % n_ranks,
                        "global_batch": B_global, "replay_transitions": 1000000, "parallelism": "dp%d" % n_ranks,
-                       "exchange": "host (gloo, split-step entry points)" if (n_ranks > 1 and host_exchange) else transport},
+                       "exchange": "host (gloo, split-step entry points)" if (n_ranks > 1 and host_exchange) else transport,
+                       "exchange_per_rank": transports},
             "roofline": roof,
             "fill_seconds": t_fill,
             "diagnostics": diag,
@@ -532,7 +564,7 @@ def main():
             if rank == 0:
                 out["weak_scaling_row"] = {"scaling": "weak", "error": "did not finish within %d s" % PROBE_SECONDS}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)      # (non-zero: the peers may sit in collectives; the launcher tears the group down)
         wd = threading.Timer(PROBE_SECONDS, bail); wd.daemon = True; wd.start()
         try:
             L.close()
@@ -549,7 +581,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtw = float(t.item())
             weak = {"scaling": "weak", "value": wk["batchSize"] * args.steps / dtw, "unit": "transitions/s", "ms_per_step": dtw / args.steps * 1e3,
-                    "global_batch": wk["batchSize"], "replay_transitions": wk["maxTotObsNum"], "per_replica_batch": CFG["batchSize"], "exchange": tw}
+                    "global_batch": wk["batchSize"], "replay_transitions": wk["maxTotObsNum"], "per_replica_batch": CFG["batchSize"], "exchange": tw,
+                    # against N x the single-replica value measured by rank 0 at the start of this run (same K / W)
+                    "single_replica_value": single_ref,
+                    "efficiency_vs_n_single": (wk["batchSize"] * args.steps / dtw) / (n_ranks * single_ref) if single_ref else None}
         except Exception as e:  # noqa: BLE001
             weak = {"scaling": "weak", "error": str(e)}
         wd.cancel()
