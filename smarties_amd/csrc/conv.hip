@@ -555,10 +555,8 @@ template <int IT> static hipError_t launchConvDxsC(const ConvArgs& a, int l, hip
   const int nk = convPad4(convClassK(a.L[l])) / 4;
   if (nk == 36) {                                                  // 16 filters of 6 x 6, stride 2: 16 x 3 x 3 taps per class
     // thousands of tiles (batch 128 of 20 x 20 positions: 3200): a tile per wavefront -- a quarter of the workgroups, no cross-wave join
-    static const int ksSel = [] { const char* e = getenv("SMARTIES_HIP_DXS_KS"); return e ? atoi(e) : 0; }();
     const long long tiles = ((long long)a.B * (a.L[l].InY / a.L[l].S) * (a.L[l].InX / a.L[l].S) + 15) / 16 * a.L[l].S * a.L[l].S;
-    if (ksSel == 2) return launchConvDxsT<1, 36, 2>(a, l, IT, s);
-    if (ksSel == 1 || (ksSel == 0 && tiles >= 2048)) return launchConvDxsT<1, 36, 1>(a, l, IT, s);
+    if (tiles >= 2048) return launchConvDxsT<1, 36, 1>(a, l, IT, s);      // (RACER_atari step, round 4: 139.6 -> 138.0 us; two wavefronts per tile: in between)
     return launchConvDxsT<1, 36>(a, l, IT, s);
   }
   return launchConvDxsT<IT, 0>(a, l, 1, s);
@@ -614,12 +612,8 @@ constexpr size_t CONV_DW_LDS = 40 * 1024;  // (gather form: MAXROWS * 12 + 4 KB;
 int conv_dw_staged_group(const ConvGeo& g, int B) {      // rows per workgroup (0: the layer keeps the gather form)
   const long long inSize = (long long)g.InC * g.InY * g.InX;
   if ((inSize & 3) || (g.ldIn & 3) || (g.ldOut & 3) || (g.P * 16) % 4 || g.KnC % 16 || g.K % 16 || g.K / 16 > 20) return 0;
-  const char* ge = getenv("SMARTIES_HIP_CONV_DW_G");      // (0: the gather form -- tests compare the two; n: rows per workgroup)
-  const int gEnv = ge ? atoi(ge) : -1;
-  if (gEnv == 0) return 0;
   int G = 1;
   while (2 * G <= 16 && 2 * G * g.P <= 128) G *= 2;      // reductions of about a hundred rows: 72 - 128 on the RACER_atari shape
-  if (gEnv > 0) G = gEnv;
   if (G > B) G = B;
   auto bytes = [&](int G_) { return ((long long)G_ * (inSize + 16 * (g.P | 1)) + 2 * (((long long)G_ * g.P + 3) & ~3)) * 4; };
   while (G > 1 && bytes(G) > (long long)CONV_DW_LDS) G /= 2;
@@ -801,7 +795,6 @@ int conv_row_block(const ConvGeo& g, int* win) {
     const double eff = (double)(rb * g.OpX) / (16.0 * ((tiles + 3) / 4 * 4));      // filled MFMA columns per round of four wavefronts
     if (eff > bestEff + 1e-9 || (eff > bestEff - 0.05 && rb > best)) { if (eff > bestEff) bestEff = eff; best = rb; }
   }
-  if (const char* e = getenv("SMARTIES_HIP_CONV_RB")) { const int v = atoi(e); if (v >= 1 && v <= g.OpY) best = v; }      // (experiments)
   if (best && win) *win = (best - 1) * g.S + g.KnY;
   return best;
 }
@@ -984,9 +977,7 @@ template <int RB_> struct Atari0 {
 };
 int conv_rows_atari_rb(const ConvGeo& g) {      // rows per block of this layer when it is the first layer of RACER_atari.json (0: another layer)
   if (!(g.InC == 4 && g.InY == 84 && g.InX == 84 && g.KnY == 8 && g.KnX == 8 && g.S == 4 && g.KnC == 8 && g.OpY == 20 && g.OpX == 20)) return 0;
-  const char* e = getenv("SMARTIES_HIP_CONV_RB");
-  const int v = e ? atoi(e) : 0;
-  return (v == 2 || v == 4 || v == 5) ? v : 4;      // (RACER_atari step: 97.3 us at 4 -- five full position tiles per block --, 98.3 at 5, 103.5 at 2)
+  return 4;      // (RACER_atari step: 97.3 us at 4 -- five full position tiles per block --, 98.3 at 5, 103.5 at 2)
 }
 bool conv_rows_atari(const ConvGeo& g, const ConvSource& src) {
   const int rb = conv_rows_atari_rb(g);

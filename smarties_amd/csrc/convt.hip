@@ -549,7 +549,6 @@ bool conv_tail_plan(const ConvGeo* L, int nL, ConvTailPlan* pl) {
   pl->ldsBack = (int)((2 * bufD + maxT) * 4);
   pl->on = 1;
   pl->atari = nL == 4 && ctIsShape(L[3], 32, 64, 3, 3, 1, 3, 3) && ctIsShape(L[2], 16, 32, 4, 4, 1, 5, 5) && ctIsShape(L[1], 8, 16, 6, 6, 2, 8, 8);
-  if (const char* e = getenv("SMARTIES_HIP_CONV_TAIL")) { if (e[0] == '2') pl->atari = 0; }      // (2: the any-geometry kernel on every stack -- tests)
   return true;
 }
 

@@ -64,21 +64,20 @@ struct hl_learner {
   // layer's), hid[1..] are the dense blocks behind it
   bool preproc = false; int dIn = 0, nApp = 0, nConv = 0;
   bool bigBatch = false;      // local batch above 1024 (sample.hip: big_sample_kernel)
-  bool wideDw = true;         // recurrent nets: weight gradients over all (sample, step) rows as one launch without a split-row join (SMARTIES_HIP_WIDE_DW=0: (tile, chunk) workgroups + splitk_reduce_kernel)
-  bool convDxRide = true;       // ... and what of them needs no convolutional delta behind the unstrided layers' input-gradient launches (SMARTIES_HIP_CONV_DX_RIDE=0)
-  bool convDwDense = true;      // convolutional nets: those tiles inside the filter-gradient launch (SMARTIES_HIP_CONV_DW_DENSE=0: a launch of their own)
-  bool directDw = true; int directDwMinTiles = 128;      // weight-gradient launches of >= this many unsplit tiles take dw_wide_kernel's one-workgroup-per-tile form (SMARTIES_HIP_DIRECT_DW=0 / =<min tiles>)
-  bool recFused = true;       // two LSTM layers of 32 cells: forward, head and backward of a sample as one launch (rec.hip: lstm32_step_wave_kernel; SMARTIES_HIP_REC_FUSED=0: the three launches)
-  bool panelHead = false;     // ... and headp.hip's 16-sample panels for the head (SMARTIES_HIP_PANEL_HEAD=0 / 1 overrides: 1 also for small batches, eager launches)
-  int bigMm = 0;              // ... with the kernels of bigmm.hip (bit 0: weight-stationary forward / dX panels, bit 1: weight gradients, bit 2: LDS-tiled forward / dX products, taken before the panels; SMARTIES_HIP_BIGMM overrides)
+  bool wideDw = true;         // recurrent nets: weight gradients over all (sample, step) rows as one launch without a split-row join (SMARTIES_HIP_GENERIC & 4: (tile, chunk) workgroups + splitk_reduce_kernel)
+  bool convDxRide = true;       // ... and what of them needs no convolutional delta behind the unstrided layers' input-gradient launches (SMARTIES_HIP_GENERIC & 256: none rides)
+  bool convDwDense = true;      // convolutional nets: those tiles inside the filter-gradient launch (SMARTIES_HIP_GENERIC & 256: a launch of their own)
+  bool directDw = true; int directDwMinTiles = 128;      // weight-gradient launches of >= this many unsplit tiles take dw_wide_kernel's one-workgroup-per-tile form
+  bool recFused = true;       // two LSTM layers of 32 cells: forward, head and backward of a sample as one launch (rec.hip: lstm32_step_wave_kernel; SMARTIES_HIP_GENERIC & 4: the three launches)
+  bool panelHead = false;     // ... and headp.hip's 16-sample panels for the head (recurrent nets and local batches >= 2048)
+  int bigMm = 0;              // ... with the kernels of bigmm.hip (bit 0: weight-stationary forward / dX panels, bit 1: weight gradients, bit 2: LDS-tiled forward / dX products, taken before the panels; SMARTIES_HIP_GENERIC & 128: none)
   std::vector<hl::GemmProblem> hostProbs;      // the problem table as the host built it (large batches: kernels taking a problem by value)
   // ... whose sampler draws the NEXT step's minibatch on a stream of its own while this step's launches run
   hipStream_t sideStream = nullptr; hipEvent_t evMain = nullptr, evSide = nullptr; bool sidePending = false;
   int extras = 0;      // state variables beyond the first convolution's image: a second input layer behind the conv stack (Approximator.cpp:249-259)
   bool convPrepStale = true;      // the filters' LDS layouts (ConvGeo::Wf, Wx) do not reflect W (conv.hip: conv_prep_kernel)
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
-  bool convRowsAtari = true;    // the first layer's row-block kernels with the RACER_atari geometry at compile time (SMARTIES_HIP_CONV_ROWS_ATARI=0: any-geometry kernels)
-  bool convTailFwd = true;      // ... the forward pass of those layers as well (SMARTIES_HIP_CONV_TAIL=3: backward only)
+  bool convRowsAtari = true;    // the first layer's row-block kernels with the RACER_atari geometry at compile time (SMARTIES_HIP_GENERIC & 16: any-geometry kernels)
   ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
   // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
@@ -140,15 +139,20 @@ struct hl_learner {
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
   bool chainOk = false; int chainHT = 0;  // the dense forward layers of a network off the fused path go out as one launch (gemm16.hip: fwd_chain_kernel)
-  bool noConvReplay = false;            // SMARTIES_HIP_NO_CONV_REPLAY=1: stack the minibatch rows (stack_gather_kernel) also when the first layer could read the replay
+  bool noConvReplay = false;            // (SMARTIES_HIP_GENERIC & 64) stack the minibatch rows (stack_gather_kernel) also when the first layer could read the replay
   mutable int minLen = 0; mutable long long minLenAtN = -1; mutable size_t minLenAtCount = 0;      // shortest stored episode (evictionDue, removal rules other than "oldest")
-  bool helperHandOff = false;           // SMARTIES_HIP_HELPER_HANDOFF=1: the gather helpers of the dW launch wait for the rider's search (development)
-  bool noDeferBeta = false;             // SMARTIES_HIP_NO_DEFER_BETA=1: the whole bookkeeping stays in the dW launch (development)
+  bool noDeferBeta = false;             // (SMARTIES_HIP_GENERIC & 2) the whole bookkeeping stays in the dW launch
   float* dRedMax = nullptr; double* dRedErr = nullptr; int redCap = 0;
   double* dMomPartial = nullptr; double* dMoments = nullptr; int momBlocksCap = 0;
   double* dStatsOut = nullptr;
   // replayed graphs: one per entry of GRAPH_SIZES and starting minibatch buffer (step_exec.h)
   GraphSlot graphs[16][2]; bool graphsStale = false, useGraph = true;
+  // SMARTIES_HIP_GENERIC (tests, comparisons): bits that make the learner take a GENERAL kernel / launch list where a specialised one
+  // would serve -- every such route exists anyway for the shapes the specialised one does not cover; nothing else selects code paths
+  //   1 no two-kernel fused step            2 no forward chain / activation kernel / deferred beta      4 recurrent: unfused launches, chunked dW
+  //   8 conv: per-layer launches behind the first layer       16 conv: any-geometry kernels       32 conv: gather-form filter gradients
+  //  64 conv: stacked rows, no row-block kernels              128 large batches: the common tile launches      256 weight-gradient tiles in launches of their own
+  int generic = 0;
   bool plainGraph = false;      // the replayed steps of this net are stepEager's launches as graph nodes (the next minibatch's sampler in front): nets none of the rider forms serves
   // graphs of exactly n steps (hl_prepare_steps, or a call size seen three times in a row): the whole call is one launch
   // and its last node stamps a pinned host word, which hl_sync polls (tools/call_bench.hip)
@@ -652,13 +656,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->bigBatch = h->B > 1024;
   h->bigMm = h->bigBatch ? 7 : 0;
   h->panelHead = h->B >= 2048 || cfg->nn_type != HL_NN_FFNN;      // (measured: recurrent nets 68.5 -> 66.5 us per step at 2 x 32 cells; the 512-wide Atari head 152.5 -> 156.9: one wavefront set per sample there)
-  if (const char* e = getenv("SMARTIES_HIP_PANEL_HEAD")) h->panelHead = e[0] == '1';
-  if (const char* e = getenv("SMARTIES_HIP_REC_FUSED")) h->recFused = e[0] == '1';
-  if (const char* e = getenv("SMARTIES_HIP_CONV_DX_RIDE")) h->convDxRide = atoi(e) != 0;
-  if (const char* e = getenv("SMARTIES_HIP_CONV_DW_DENSE")) h->convDwDense = atoi(e) != 0;
-  if (const char* e = getenv("SMARTIES_HIP_DIRECT_DW")) { const int v = atoi(e); h->directDw = v != 0; if (v > 1) h->directDwMinTiles = v; }
-  if (const char* e = getenv("SMARTIES_HIP_WIDE_DW")) h->wideDw = e[0] == '1';
-  if (const char* e = getenv("SMARTIES_HIP_BIGMM")) h->bigMm = h->bigBatch ? atoi(e) : 0;
+  if (const char* e = getenv("SMARTIES_HIP_GENERIC")) h->generic = atoi(e);
+  if (h->generic & 4) { h->recFused = false; h->wideDw = false; }
+  if (h->generic & 256) { h->convDxRide = false; h->convDwDense = false; }
+  if (h->generic & 128) h->bigMm = 0;
   if (h->bigBatch && (cfg->nn_type != HL_NN_FFNN || cfg->n_conv > 0 || cfg->dataSamplingAlgo != HL_SAMPLE_UNIFORM))
     return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024: dense layers and the uniform sampler only");
   h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);
@@ -691,7 +692,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     h->plainGraph = true;     // (no riders on these nets' launches: their replayed steps are the eager launch list, captured -- step_exec.h: captureSteps)
   }
   if (h->bigBatch) {
-    if (const char* e = getenv("SMARTIES_HIP_BIG_GRAPH")) { if (e[0] == '0') h->useGraph = false; }      // (0: plain steps of large batches issued launch by launch, as before the end of round 4)
     HIPCK(hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&h->evMain, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->evSide, hipEventDisableTiming));
   }
@@ -719,16 +719,16 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       else { HIPCK(devAlloc(&g.X, (size_t)h->convMmax * g.ldOut)); HIPCK(devAlloc(&g.Y, (size_t)h->convMmax * g.ldOut)); HIPCK(devAlloc(&g.D, (size_t)h->convB * g.ldOut)); }
       const long long R = (long long)h->convB * g.P;             // rows of the filter-gradient reduction
       const int tiles = ((g.K + 15) / 16) * ((g.KnC + 15) / 16);
-      static const long long dwWgs = [] { const char* e = getenv("SMARTIES_HIP_CONV_DW_WGS"); const long long v = e ? atoll(e) : 0; return v >= 16 ? v : 640; }();      // (640: RACER_atari step 139.3 us at 1024, 137.0 at 512 - 768, 140.4 at 256, 144.9 at 2048)
+      constexpr long long dwWgs = 640;      // (tile, chunk) workgroups per layer of the gather form (RACER_atari step, round 4: 139.3 us at 1024, 137.0 at 512 - 768, 140.4 at 256, 144.9 at 2048)
       long long rowsPer = std::max<long long>(64, (R * tiles + dwWgs - 1) / dwWgs);   // several hundred workgroups per layer
       rowsPer = std::min<long long>(roundUp(rowsPer, 16), 2048);
       g.chunkRows = (int)rowsPer; g.nChunks = (int)((R + rowsPer - 1) / rowsPer);
       // layers with a large input image (the first one of the Atari stacks): row-block kernels, one partial per (sample, row block)
-      { int win = 0; const int rb = getenv("SMARTIES_HIP_NO_CONV_ROWS") ? 0 : conv_row_block(g, &win);
+      { int win = 0; const int rb = (h->generic & 64) ? 0 : conv_row_block(g, &win);
         g.rbRows = 0; g.rbCount = 0; g.rbWin = 0;
         if (l == 0 && rb > 0 && conv_rows_ok(g)) { g.rbRows = rb; g.rbCount = (g.OpY + rb - 1) / rb; g.rbWin = win; g.nChunks = h->convB * g.rbCount; } }
       // layers behind the first: both operands staged in LDS, one workgroup per (group of rows, 16 channels)
-      g.dwG = (l > 0 && !g.rbRows) ? conv_dw_staged_group(g, h->convB) : 0;
+      g.dwG = (l > 0 && !g.rbRows && !(h->generic & 32)) ? conv_dw_staged_group(g, h->convB) : 0;
       if (g.dwG && (((uintptr_t)g.D | (uintptr_t)h->cg[l - 1].Y) & 15)) g.dwG = 0;      // (16-byte copies: the last layer's rows may start behind extra state variables)
       if (g.dwG) { g.nChunks = (h->convB + g.dwG - 1) / g.dwG; g.chunkRows = g.dwG * g.P; }
       g.dwBlock0 = blk; blk += g.rbRows ? 0 : (g.dwG ? g.nChunks * (g.KnC / 16) : g.nChunks * tiles);
@@ -737,11 +737,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       if ((long long)h->convMmax * g.P >= (1ll << 31) || (long long)h->convMmax * g.InY * g.InX >= (1ll << 31)) return fail(h, HL_ERR_UNSUPPORTED, "convolution: rows x positions >= 2^31");
     }
     h->convDwBlocks = blk;
-    if (h->nConv > 1 && !(getenv("SMARTIES_HIP_CONV_TAIL") && getenv("SMARTIES_HIP_CONV_TAIL")[0] == '0')) conv_tail_plan(h->cg, h->nConv, &h->convTail);
-    if (const char* e = getenv("SMARTIES_HIP_CONV_TAIL")) h->convTailFwd = e[0] != '3';
-    if (const char* e = getenv("SMARTIES_HIP_CONV_ROWS_ATARI")) h->convRowsAtari = e[0] != '0';
+    if (h->nConv > 1 && !(h->generic & 8)) conv_tail_plan(h->cg, h->nConv, &h->convTail);
+    if (h->generic & 16) { h->convTail.atari = 0; h->convRowsAtari = false; }
   }
-  h->actFastOk = !h->recurrent && h->nConv == 0 && getenv("SMARTIES_HIP_NO_ACT_KERNEL") == nullptr;
+  h->actFastOk = !h->recurrent && h->nConv == 0 && !(h->generic & 2);
   for (int j = 0; j < h->nHidden; ++j) if (h->hid[j].size > ACT_MAXW || h->hid[j].nIn > ACT_MAXW) h->actFastOk = false;
   if (h->recurrent && cfg->encoder_rnn && h->nEncLayers > 0 && h->nEncLayers < h->nHidden - (h->nConv > 0 ? 1 : 0)) {
     const int j0 = h->nConv > 0 ? 1 : 0; const DevHidden& top = h->hid[j0 + h->nEncLayers - 1]; const DevHidden& up = h->hid[j0 + h->nEncLayers];
@@ -767,8 +766,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     }
   }
   {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces
-    const char* e = getenv("SMARTIES_HIP_NO_FUSED");
-    const bool off = e && e[0] == '1';
+    const bool off = (h->generic & 1) != 0;
     if (!off && h->nHidden == 2 && !h->recurrent && !h->preproc) {
       const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
       h->fusedOk = cfg->nnOutputFunc == HL_FUNC_LINEAR && d0.size == d1.size && d1.size >= 16 && d1.size <= 256 && (d1.size & (d1.size - 1)) == 0 && h->dS <= 32 && h->nAdv == 0 && h->nDense <= 8 && h->ldWo == 8 &&
@@ -794,7 +792,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(hipStreamSynchronize(nullptr));
     }
   }
-  if (!h->fusedOk && h->nHidden == 2 && !h->recurrent && !h->preproc && getenv("SMARTIES_HIP_NO_FUSED_WIDE") == nullptr) {
+  if (!h->fusedOk && h->nHidden == 2 && !h->recurrent && !h->preproc && !(h->generic & 1)) {
     // the wide variant of the fused kernel (fusedw.hip): same placement, same probe
     const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
     const int comps = h->nOpt ? h->nOpt : h->dA;
@@ -817,15 +815,13 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       h->fusedWideOk = true;
     }
   }
-  { const char* nd = getenv("SMARTIES_HIP_NO_DEFER_BETA"); h->noDeferBeta = nd && nd[0] == '1'; }
-  { const char* nd = getenv("SMARTIES_HIP_HELPER_HANDOFF"); h->helperHandOff = nd && nd[0] == '1'; }
-  { const char* nd = getenv("SMARTIES_HIP_NO_CONV_REPLAY"); h->noConvReplay = nd && nd[0] == '1'; }
+  h->noDeferBeta = (h->generic & 2) != 0;
+  h->noConvReplay = (h->generic & 64) != 0;
   // networks off the fused path with two or more dense layers (short reductions): one forward launch if the groups of its
   // panels run where the kernel assumes (same probe as above, with that kernel's geometry)
   if (!h->fusedOk && !h->fusedWideOk && !h->recurrent && !h->bigBatch) {
     const int j0 = h->nConv > 0 ? 1 : 0;
-    const char* nc = getenv("SMARTIES_HIP_NO_FWD_CHAIN");
-    bool ok = h->nHidden - j0 >= 2 && !(nc && nc[0] == '1');
+    bool ok = h->nHidden - j0 >= 2 && !(h->generic & 2);
     int HT = 0;
     for (int j = j0; j < h->nHidden; ++j) { ok = ok && !gemm_oneshot_ok(GEMM_F, h->hid[j].nIn); HT = std::max(HT, (h->hid[j].size + 15) / 16); }
     ok = ok && HT <= 64;      // a panel's group waits for all its workgroups: they must fit one XCD at once (32 CUs x 3 workgroups at this kernel's registers)
@@ -891,9 +887,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   HIPCK(hipMemcpy(h->rp.stStd, ones.data(), h->dS * sizeof(float), hipMemcpyHostToDevice));
   rc = buildProblems(h); if (rc) return rc;
   if (const char* e = getenv("SMARTIES_HIP_NO_GRAPH")) { if (e[0] == '1') h->useGraph = false; }
-  if (const char* e = getenv("SMARTIES_HIP_EAGER_CHAIN")) h->eagerChain = atoi(e);
   if (const char* e = getenv("SMARTIES_HIP_XCHG_TIMEOUT_MS")) h->xchgTimeoutTicks = std::max(1LL, atoll(e)) * 100000LL;
-  if (const char* e = getenv("SMARTIES_HIP_NO_EXCH_GRAPH")) h->exchGraph = !(e[0] == '1');   // replicas: eager exchanges only
   return HL_OK;
 }
 

@@ -413,7 +413,7 @@ int launchFront(hl_learner* h, int parity, hipStream_t s, bool gather) {
     else if (h->convPrepStale) return fail(h, HL_ERR_STATE, "convolution filter layouts are stale (ensureConvPrep was not called)");
     for (int l = 0; l < h->nConv; ++l) {
       snprintf(nm, sizeof(nm), "conv_fwd%d", l);
-      if (l == 1 && h->convTail.atari && h->convTailFwd) {      // layers 1 .. 3 of the RACER_atari stack: one launch, a workgroup per row (convt.hip)
+      if (l == 1 && h->convTail.atari) {      // layers 1 .. 3 of the RACER_atari stack: one launch, a workgroup per row (convt.hip)
         HIPCK(timed(h, "conv_fwd_tail", s, [&] { return launch_conv_fwd_tail(ca, h->convTail, h->convMmax, s); }));
         break;
       }
@@ -474,7 +474,7 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
       ex.helpers = (int)std::min<long long>(31, fl / 1024);
       if (ex.helpers > 0) ex.phases |= PH_PUBLISH;
       // (the sorted indices of a dense net's next minibatch were left by phase B in an earlier launch: the helpers search them themselves)
-      if (ex.helpers > 0 && !h->recurrent && !h->helperHandOff) ex.samp.selfSearch = 1;
+      if (ex.helpers > 0 && !h->recurrent) ex.samp.selfSearch = 1;
     }
   }
   if (h->panelHead && panel_head_ok(ha)) { HIPCK(timed(h, "panel_head", s, [&] { return launch_panel_head(ha, h->Mmax, pex, s); })); return HL_OK; }
@@ -493,7 +493,7 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
   if (nextSampleC) exC = extraSample(h, parity ^ 1, PH_C);
   if (sb.dwCount <= DW_TABLE_MAX) {   // problem table in the kernel arguments
     const DwTable& tbl = fuseAdam ? sb.dwTableAdam : sb.dwTable;
-    if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; exC.samp.selfSearch = h->helperHandOff ? 0 : 1; }
+    if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; exC.samp.selfSearch = 1; }
     HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s, nextSampleC ? &exC : nullptr); }));
     return HL_OK;
   }
@@ -583,7 +583,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
       HIPCK(timed(h, "conv_dw_dense", s, [&] {
         return launch_conv_dw_dense(ca, lRb, h->convDwBlocks, dwProbs, sb.dwCount, rideT0, hyp, pexF, s); }));
     } else
-    if (nRb == 1 && h->convDwBlocks > 0 && !getenv("SMARTIES_HIP_CONV_DW_SPLIT")) {      // the two filter-gradient launches depend on the deltas only: one launch (the variable: two, for profiles)
+    if (nRb == 1 && h->convDwBlocks > 0) {      // the two filter-gradient launches depend on the deltas only: one launch
       HIPCK(timed(h, "conv_dw_all", s, [&] { return launch_conv_dw_all(ca, lRb, h->convDwBlocks, s); }));
     } else {
     for (int l = 0; l < h->nConv; ++l) if (ca.L[l].rbRows) HIPCK(timed(h, "conv_dw_rows", s, [&] { return launch_conv_dw_rows(ca, l, s); }));

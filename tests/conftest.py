@@ -4,7 +4,7 @@ import sys
 # several replicas of ONE process that wait for each other inside kernels (test_one_kernel_exchange_among_several_replicas) need a
 # hardware queue each: HIP maps streams onto 4 by default, a fifth stream shares one -- and a waiting kernel then blocks its peer
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-# a peer that never shows up: the exchange kernel gives up after this long (the library's own default is ten minutes)
+# a peer that never shows up: the exchange kernel gives up after this long (the library's own default is one minute)
 os.environ.setdefault("SMARTIES_HIP_XCHG_TIMEOUT_MS", "30000")
 
 import pytest

@@ -280,7 +280,7 @@ def test_large_batch_runs_are_deterministic(hip_api):
 
 def test_large_batch_steps_as_graphs_equal_the_eager_launches(hip_api, monkeypatch):
     """Plain steps of large local batches replay as graphs whose sampler branch draws the next minibatch beside the step's launches
-    (step_exec.h: captureSteps); SMARTIES_HIP_BIG_GRAPH=0 issues the same launches one by one.  Calls of mixed lengths, new episodes
+    (step_exec.h: captureSteps); SMARTIES_HIP_NO_GRAPH=1 issues the same launches one by one.  Calls of mixed lengths, new episodes
     in between (the pre-drawn minibatch is dropped and the generator put back), an announced call size: bit-identical states."""
     sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=100, lenMax=200, pTerm=0.3)
 
@@ -297,7 +297,7 @@ def test_large_batch_steps_as_graphs_equal_the_eager_launches(hip_api, monkeypat
         L.close()
         return out
     a = run()
-    monkeypatch.setenv("SMARTIES_HIP_BIG_GRAPH", "0")
+    monkeypatch.setenv("SMARTIES_HIP_NO_GRAPH", "1")
     b = run()
     assert np.array_equal(a[4], b[4]) and np.array_equal(a[1], b[1])
     assert np.array_equal(a[0], b[0]) and a[2] == b[2] and a[3] == b[3]
@@ -325,7 +325,7 @@ def test_one_launch_recurrent_step_random_shapes_match_oracle(hip_api, seed, mon
     """Two LSTM or MGU layers of 32 cells run a sample's window forward, its head and its back-propagation through time as ONE launch
     (rec.hip: lstm32_step_wave_kernel, mgu32_step_wave_kernel).  Shapes of its envelope drawn at random -- 1..32 observed states, 1..7 action components
     with mixed bounds or 2..16 options, every advantage kind, windows of 1..16 steps, episodes that end truncated (next-state rows)
-    or terminated -- against the oracle, eager and replayed (the sampler's rider); the three-launch form (SMARTIES_HIP_REC_FUSED=0)
+    or terminated -- against the oracle, eager and replayed (the sampler's rider); the three-launch form (SMARTIES_HIP_GENERIC=4)
     must give the same minibatches and the same weights to rounding."""
     rng = np.random.default_rng(7100 + seed)
     dS = int(rng.integers(1, 33))
@@ -348,7 +348,7 @@ def test_one_launch_recurrent_step_random_shapes_match_oracle(hip_api, seed, mon
     assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
     assert np.array_equal(G.get_rng_state(), O.get_rng_state())
     assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
-    monkeypatch.setenv("SMARTIES_HIP_REC_FUSED", "0")
+    monkeypatch.setenv("SMARTIES_HIP_GENERIC", "4")
     T = capi.Learner(hip_api, capi.make_config(**kw))
     T.init_weights(); fill_synth(T, sc, 100); T.initialize(); T.set_tap(True)
     T.step(1); T.step(1); T.step(1); T.step(9)
@@ -368,7 +368,7 @@ def test_dense_weight_gradients_inside_the_convolutional_launches_change_nothing
     """RACER_atari-shaped step (round 4): the dense layers' weight-gradient tiles run inside the filter-gradient launch
     (conv.hip: conv_dw_dense_kernel) and, where they need no convolutional delta, behind the unstrided layers' input-gradient
     launches (DenseRide) instead of in a launch of their own.  Same tiles, same arithmetic: minibatches, generator and every
-    parameter must be bit-identical to the separate launches (SMARTIES_HIP_CONV_DW_DENSE=0, SMARTIES_HIP_CONV_DX_RIDE=0), eager
+    parameter must be bit-identical to the separate launches (SMARTIES_HIP_GENERIC=256), eager
     and replayed, and follow the oracle."""
     sc = synth_cfg(**ATARI_SC)
     G, O = _pair(hip_api, ATARI_KW, sc, 14)
@@ -379,7 +379,7 @@ def test_dense_weight_gradients_inside_the_convolutional_launches_change_nothing
     _compare_step(G, O)
     assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
     ref = G.get_params()[0].copy()
-    for env in (dict(SMARTIES_HIP_CONV_DX_RIDE="0"), dict(SMARTIES_HIP_CONV_DW_DENSE="0")):
+    for env in (dict(SMARTIES_HIP_GENERIC="256"),):
         for k, v in env.items(): monkeypatch.setenv(k, v)
         T = capi.Learner(hip_api, capi.make_config(**ATARI_KW))
         T.init_weights(); fill_synth(T, sc, 14); T.initialize(); T.set_tap(True)

@@ -32,14 +32,13 @@ def run_fixture(hip_api, name):
 @pytest.mark.parametrize("name", ["racer_atari.bin", "conv_small.bin", "nature_dqn.bin"])
 def test_every_form_of_the_convolutional_backward_pass_follows_the_reference(hip_api, monkeypatch, name):
     """Layer_Conv2D.h:117-138 through (default) the kernels with the RACER_atari geometry at compile time / the any-geometry
-    sample-resident kernel, (TAIL=2) the any-geometry kernel on every stack, (TAIL=0) the per-layer launches of conv.hip; filter
-    gradients staged in LDS (default) or gathered (DW_G=0).  Each follows the reference's taps; among themselves they differ by
+    sample-resident kernel, (GENERIC & 16) the any-geometry kernels on every stack, (& 8) the per-layer launches of conv.hip; filter
+    gradients staged in LDS (default) or gathered (& 32); everything general at once (stacked rows, no row blocks, separate launches).  Each follows the reference's taps; among themselves they differ by
     summation order only."""
     ws = {}
-    for tag, env in (("default", {}), ("any_geometry", {"SMARTIES_HIP_CONV_TAIL": "2"}), ("per_layer", {"SMARTIES_HIP_CONV_TAIL": "0"}), ("backward_only", {"SMARTIES_HIP_CONV_TAIL": "3"}),
-                     ("gather_dw", {"SMARTIES_HIP_CONV_DW_G": "0"}), ("one_row_dw", {"SMARTIES_HIP_CONV_DW_G": "1"})):
-        for k in ("SMARTIES_HIP_CONV_TAIL", "SMARTIES_HIP_CONV_DW_G"):
-            monkeypatch.delenv(k, raising=False)
+    for tag, env in (("default", {}), ("any_geometry", {"SMARTIES_HIP_GENERIC": "16"}), ("per_layer", {"SMARTIES_HIP_GENERIC": "8"}),
+                     ("gather_dw", {"SMARTIES_HIP_GENERIC": "32"}), ("all_general", {"SMARTIES_HIP_GENERIC": str(8 + 16 + 32 + 64 + 256)})):
+        monkeypatch.delenv("SMARTIES_HIP_GENERIC", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ws[tag] = run_fixture(hip_api, name)

@@ -12,5 +12,3 @@ run HSA_ENABLE_INTERRUPT=0 ROC_ACTIVE_WAIT_TIMEOUT=1000
 # (ROC_SYSTEM_SCOPE_SIGNAL=0 wedges the first synchronisation on this runtime: not run)
 run DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 run DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
-run SMARTIES_HIP_EAGER_CHAIN=64 NO_PREPARE=1
-run SMARTIES_HIP_EAGER_CHAIN=64 NO_PREPARE=1 HSA_ENABLE_INTERRUPT=0 ROC_ACTIVE_WAIT_TIMEOUT=1000

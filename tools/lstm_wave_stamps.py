@@ -1,6 +1,6 @@
 """Device time stamps of the first sample's layer-0 wavefront (library built with -DREC_STAMPS) in the one-launch LSTM step
 (lstm32_step_wave_kernel: entry, prologue, every iteration of the forward loop, head, backward, end) or, with
-SMARTIES_HIP_REC_FUSED=0, in lstm32_forward_wave_kernel (entry, prologue, every iteration of the window loop, end)."""
+SMARTIES_HIP_GENERIC=4, in lstm32_forward_wave_kernel (entry, prologue, every iteration of the window loop, end)."""
 import sys, ctypes as C
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
