@@ -136,6 +136,11 @@ def other_configs(api, steps=1000, only=None):
                                                       gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
         "cfg4_mgu_2x32_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
                                            gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
+        # recurrent layers wider than the 32 cells of RACER_RNN.json (the any-width window kernels of rec.hip)
+        "lstm_2x128_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(128, 128), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
+                                        gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, max(50, steps // 10)),
+        "lstm_2x256_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(256, 256), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
+                                        gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, max(50, steps // 20)),
         # the bench network at larger batches: where the step stops being a latency chain (fraction of the fp32 MFMA peak below)
         # (replays of 500 000 transitions: the sampler redraws until the minibatch is unique (Sampling.cpp:86-93) -- at 80 000 stored
         #  transitions a batch of 1024 needs several rounds (62 us per step, the sampler riding the step's kernels their longest
