@@ -81,6 +81,9 @@ struct RecArgs {
   int nApp;                        // appended observations: the first layer's input is the step's state followed by the nApp before it
   const float* Xin; int ldXin;     // != nullptr: the first layer's input rows, written by launches in front (conv stack): row b K + k, next rows behind B K
   // a stack of two layer types runs as two launches (lower segment: the rnn kernels):
+  // time-step-major LSTM (rectm.hip): window geometry per sample and the errors carried between the (layer, step) launches
+  int* tmT; int* tmSteps; int* tmNext;                              // [B] steps in front of the sampled one / forward steps (next state included) / row of the next state's output
+  float* tmER[HL_MAX_HIDDEN]; float* tmSD[HL_MAX_HIDDEN];      // [B][nC]: error handed back by step k + 1 / state delta of step k + 1
   float* YoutRows; int ldYR;       // != nullptr: the last block's output of EVERY window step goes here (row b K + k, next rows behind B K): the upper segment's Xin
   const float* DresRows; int ldDR; // != nullptr: gradient w.r.t. those outputs per window row, from the upper segment (instead of Dres at the sampled step only)
 };
@@ -89,6 +92,9 @@ struct WinRowsArgs { const DevScalars* sc; DevScalars* scW; const long long* slo
 hipError_t launch_window_rows(const WinRowsArgs& a, hipStream_t s);
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);
+bool rec_tm_ok(const RecArgs& a);                                     // rectm.hip serves this net: a launch per (layer, window step) over the whole minibatch
+hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s);
+hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s);
 // window forward + output layer + head + back-propagation through time of a sample as ONE launch (rec.hip: lstm32_step_wave_kernel)
 struct ExtraArgs;
 bool rec_step_fused_ok(const RecArgs& a, const HeadArgs& ha);

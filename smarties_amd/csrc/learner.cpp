@@ -79,7 +79,10 @@ struct hl_learner {
   ConvGeo cg[HL_MAX_CONV]{}; int convDwBlocks = 0;
   bool convRowsAtari = true;    // the first layer's row-block kernels with the RACER_atari geometry at compile time (SMARTIES_HIP_GENERIC & 16: any-geometry kernels)
   ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
-  bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1)
+  bool recTm = false; int* tmT = nullptr; int* tmSteps = nullptr; int* tmNext = nullptr;      // wide LSTM layers: time-step-major launches (rectm.hip)
+  float* tmER[HL_MAX_HIDDEN] = {}; float* tmSD[HL_MAX_HIDDEN] = {};
+  bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1; one more for the time-step-major launches)
+  int recWin = 0;                          // ... steps of a window: nnBPTTseq + 1
   // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
   // serve one layer type per launch: the stack runs as two segments, the lower one's outputs of EVERY window step are the upper one's
   // input rows (segY), the upper one's input errors the lower one's top errors (segDres)
@@ -679,7 +682,15 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   const int B = h->B;
   h->Mmax = (int)roundUp(2 * B, 16);
   h->recurrent = cfg->nn_type != HL_NN_FFNN;
-  if (h->recurrent) h->recK = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
+  if (h->recurrent) h->recK = h->recWin = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
+  // LSTM layers wider than 64 cells: time-step-major launches (rectm.hip); the windows then carry the next state's step as a row
+  // of their own (one row more per sample)
+  if (h->recurrent && cfg->nn_type == HL_NN_LSTM && !(h->generic & 4) && cfg->n_encoder == 0 && cfg->n_conv == 0) {
+    bool wide = false, ok = true;
+    for (int j = 0; j < h->cfg.n_hidden; ++j) { wide = wide || h->cfg.hidden[j] > 64; ok = ok && h->cfg.hidden[j] % 16 == 0; }
+    h->recTm = wide && ok;
+    if (h->recTm) h->recK += 1;
+  }
   h->convB = B; h->convMmax = h->Mmax;
   if (h->recurrent && h->nConv > 0) {
     if (h->nHidden < 2) return fail(h, HL_ERR_UNSUPPORTED, "recurrent network type behind convolutions without a recurrent layer (nnLayerSizes is empty)");
@@ -763,7 +774,9 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(devAlloc(&L.D, R * g * d.size + 16));
       if (d.hasRes) HIPCK(devAlloc(&L.Rd, R * L.ldR));
       if (d.lstm == 2) HIPCK(devAlloc(&L.A2, R * L.ldA2 + 16));
+      if (h->recTm) { HIPCK(devAlloc(&h->tmER[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmSD[j], (size_t)B * d.size)); }
     }
+    if (h->recTm) { HIPCK(devAlloc(&h->tmT, (size_t)B)); HIPCK(devAlloc(&h->tmSteps, (size_t)B)); HIPCK(devAlloc(&h->tmNext, (size_t)B)); }
   }
   {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces
     const bool off = (h->generic & 1) != 0;
@@ -1748,7 +1761,7 @@ int hl_restart(hl_learner* h, const char* base) {
 
 // rollout inference: Approximator::forward(agent) for n states (RACER.cpp:30-59)
 // pinned, device-mapped staging of rollout inference: outputs [ACT_MAXROWS][nOut] f64 | states f32 | completion stamps
-static size_t actPinFloats(const hl_learner* h) { return std::max((size_t)ACT_MAXROWS * h->dIn, (size_t)(std::max(h->recK, 1) + h->nApp) * h->dS); }
+static size_t actPinFloats(const hl_learner* h) { return std::max((size_t)ACT_MAXROWS * h->dIn, (size_t)(std::max(h->recWin, 1) + h->nApp) * h->dS); }
 static int actPinEnsure(hl_learner* h) {
   if (h->actPin) return HL_OK;
   const size_t bytes = (size_t)ACT_MAXROWS * (h->nOut * sizeof(double) + sizeof(unsigned)) + actPinFloats(h) * sizeof(float) + 256;
@@ -1835,9 +1848,9 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
   }
   if (h->inStep) return fail(h, HL_ERR_STATE, "hl_forward_sequence between hl_step_begin and hl_step_end");
   if (h->nConv > 0) {      // the window's stacked rows through the conv stack (as hl_forward does), then the window kernel on its rows
-    if (nSteps > h->recK + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
+    if (nSteps > h->recWin + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
     { int rc = dropPresample(h); if (rc) return rc; }
-    const int win = std::min(nSteps, h->recK), ctx = nSteps - win;
+    const int win = std::min(nSteps, h->recWin), ctx = nSteps - win;
     std::vector<float> rows((size_t)win * h->dIn);
     for (int k = 0; k < win; ++k) for (int j = 0; j <= h->nApp; ++j) { const int g = std::max(ctx + k - j, 0);
       std::memcpy(rows.data() + (size_t)k * h->dIn + (size_t)j * h->dS, states + (size_t)g * h->dS, (size_t)h->dS * sizeof(float)); }
@@ -1855,7 +1868,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
     return HL_OK;
   }
   // (appended observations: up to nAppendedObs further states in front of the window, which only feed the window's first steps)
-  if (nSteps > h->recK + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
+  if (nSteps > h->recWin + h->nApp) return fail(h, HL_ERR_BAD_ARG, "more steps than nnBPTTseq + 1 (+ nAppendedObs)");
   // states and outputs through pinned host memory, completion by stamp (as hl_forward): two launches, no staged copies
   { int rc = actPinEnsure(h); if (rc) return rc; }
   double* pOut = reinterpret_cast<double*>(h->actPin);
@@ -1864,7 +1877,7 @@ int hl_forward_sequence(hl_learner* h, int32_t nSteps, const float* states, doub
   std::memcpy(pIn, states, (size_t)nSteps * h->dS * sizeof(float));
   unsigned tag = ++h->actTag; if (tag == 0) tag = ++h->actTag;
   const DevHidden& q = h->hid[h->nHidden - 1];
-  { const int win = std::min(nSteps, h->recK); const int rc2 = recActingForward(h, pIn, win, nSteps - win); if (rc2) return rc2; }
+  { const int win = std::min(nSteps, h->recWin); const int rc2 = recActingForward(h, pIn, win, nSteps - win); if (rc2) return rc2; }
   HIPCK(launch_act_output(q.hasRes ? q.Rr : q.Y, q.ldA, q.size, h->W, h->indWo, h->indBo, h->indBp, h->ldWo, h->nDense, h->nSig, 1,
                           pOut, h->stream, const_cast<unsigned*>(pDone), tag, h->cfg.nnOutputFunc));
   { int rc = actWait(h, pDone, 1, tag); if (rc) return rc; }

@@ -11,6 +11,7 @@
 // gate deltas -- so that all weight gradients (and Adam) are formed by the same dW kernel as for dense layers, as
 // X^T delta over the rows; rows of unused steps carry zero deltas.
 #include "head_rows.h"      // (tail_dev.h; the head of the one-launch step: lstm32_step_wave_kernel)
+#include "rec_dev.h"
 
 namespace hl {
 
@@ -25,33 +26,11 @@ namespace hl {
 // (the rows kept for the backward pass / the dW launch), ~1 us each, and nothing in these kernels reads them back
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ float recSigm(float in) {     // Sigm::_eval (Functions.h:158-165), safeExp cut at 8 (Definitions.h:43)
-  // (one exponential for both branches of the reference: the argument is -|in| cut at -8 either way)
-  const float ex = expf(fmaxf(-8.f, -fabsf(in)));
-  return in > 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
-}
 // End of a kernel prologue: every global load issued so far has landed.  Values fetched once before the step loops (biases,
 // residual parameters, state scales) otherwise look "possibly in flight" at the loop head, and the compiler guards each use
 // inside the loop with s_waitcnt vmcnt(0) -- which also waits for every row store of the previous layer-step to be acknowledged.
 __device__ __forceinline__ void vmDrain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt untouched
 
-
-// Element e of the network input at step k of sample b's window (general form; T = steps in front of the sampled one, t its index
-// in the episode):
-//   Xin != nullptr   rows written by launches in front of this one (a convolutional stack): row b K + k, the next state's row behind
-//                    the B K window rows (row B K + nextRow - B)
-//   acting           the agent's last states, oldest first, `actCtx` of them in front of the window (they only feed appended
-//                    observations); steps before the first given one repeat it
-//   otherwise        Episode::standardizedState (Episode.h:172-183): the state of the step followed by the nApp ones before it,
-//                    steps before the episode's first repeat the first
-__device__ __forceinline__ float recInputAt(const RecArgs& a, bool acting, int b, long long slot, int t, int T, int nextRow, int k, int e) {
-  if (a.Xin) { const long long row = k <= T ? (long long)b * a.K + k : (long long)a.B * a.K + (nextRow - a.B); return a.Xin[row * a.ldXin + e]; }
-  const int j = e / a.dS, i = e - j * a.dS;
-  float raw;
-  if (acting) { const int g = a.actCtx + k - j; raw = a.actStates[(size_t)(g > 0 ? g : 0) * a.dS + i]; }
-  else { const int tt = t - T + k, back = j < tt ? j : tt; raw = a.rp.S[(size_t)(slot - T + k - back) * a.dS + i]; }
-  return (raw - a.rp.stMean[i]) * a.rp.stScale[i];
-}
 
 // weights of all LSTM layers staged in LDS with a padded row stride (4 nC + 1: the forward pass reads columns, the backward
 // pass rows, both conflict-free); nets that do not fit read them through the L2 (ldsW = 0)
@@ -1888,6 +1867,7 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 }
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
+  if (rec_tm_ok(a)) return launch_rec_tm_forward(a, s);      // wide LSTM layers, training windows: time-step-major on the MFMA (rectm.hip)
   // (static LDS of the general kernels: up to 46 KB)
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 100 * 1024; const bool general = recGeneral(a);
   if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 100 * 1024 ? recLaunch(rnn_forward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_forward_kernel<false>, a, 0, &attr[1], s); }
@@ -1959,6 +1939,7 @@ hipError_t launch_rec_step_fused(const RecArgs& a, const HeadArgs& ha, const Ext
   return hipGetLastError();
 }
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s) {
+  if (rec_tm_ok(a)) return launch_rec_tm_backward(a, s);
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 100 * 1024; const bool general = recGeneral(a);
   if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 100 * 1024 ? recLaunch(rnn_backward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_backward_kernel<false>, a, 0, &attr[1], s); }
   if (general) {

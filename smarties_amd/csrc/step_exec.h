@@ -389,7 +389,7 @@ int launchFront(hl_learner* h, int parity, hipStream_t s, bool gather) {
   const bool windows = gather && h->recurrent && h->nConv > 0;
   DevBatch bt = sb.bt; DevScalars* sc = h->sc;
   if (windows) {
-    WinRowsArgs wa{}; wa.sc = h->sc; wa.scW = h->scW; wa.slot = bt.slot; wa.t = bt.t; wa.nextSrc = bt.nextSrc; wa.B = h->B; wa.K = h->recK; wa.nBPTT = h->recK - 1;
+    WinRowsArgs wa{}; wa.sc = h->sc; wa.scW = h->scW; wa.slot = bt.slot; wa.t = bt.t; wa.nextSrc = bt.nextSrc; wa.B = h->B; wa.K = h->recK; wa.nBPTT = h->recWin - 1;
     wa.parity = parity; wa.slotW = h->winSlot; wa.tW = h->winT; wa.nextSrcW = h->winNextSrc;
     HIPCK(timed(h, "window_rows", s, [&] { return launch_window_rows(wa, s); }));
     bt.slot = h->winSlot; bt.t = h->winT; bt.nextSrc = h->winNextSrc; sc = h->scW;
@@ -769,8 +769,9 @@ RecArgs recArgs(hl_learner* h, int parity, int seg = -1) {
   const int j0 = h->nConv > 0 ? 1 : 0;      // (hid[0] of a convolutional net is its last convolution: its rows are the first layer's input)
   const int jBeg = seg == 1 ? j0 + h->recSplit : j0, jEnd = seg == 0 ? j0 + h->recSplit : h->nHidden;
   ra.nL = jEnd - jBeg;
-  ra.K = h->recK; ra.nBPTT = h->recK - 1; ra.W = h->W; ra.gates = h->hid[jBeg].lstm; ra.func = h->cfg.nnFunc; ra.nApp = (j0 || seg == 1) ? 0 : h->nApp;
+  ra.K = h->recK; ra.nBPTT = h->recWin - 1; ra.W = h->W; ra.gates = h->hid[jBeg].lstm; ra.func = h->cfg.nnFunc; ra.nApp = (j0 || seg == 1) ? 0 : h->nApp;
   for (int j = jBeg; j < jEnd; ++j) ra.L[j - jBeg] = h->rec[j];
+  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; } }
   if (seg == 1) { ra.Xin = h->segY; ra.ldXin = h->ldSeg; }
   else if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
   if (seg == 0) { ra.YoutRows = h->segY; ra.ldYR = h->ldSeg; ra.DresRows = h->segDres; ra.ldDR = h->ldSeg; }
