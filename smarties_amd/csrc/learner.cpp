@@ -688,6 +688,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (h->recurrent && cfg->nn_type == HL_NN_LSTM && !(h->generic & 4) && cfg->n_encoder == 0 && cfg->n_conv == 0) {
     bool wide = false, ok = true;
     for (int j = 0; j < h->cfg.n_hidden; ++j) { wide = wide || h->cfg.hidden[j] > 64; ok = ok && h->cfg.hidden[j] % 16 == 0; }
+    // (the crossover, measured at batch 128 and 17 steps: 2 x 64 cells 325 us with the per-sample kernels against 452 time-step-major, 2 x 96: 631 against 499)
     h->recTm = wide && ok;
     if (h->recTm) h->recK += 1;
   }
