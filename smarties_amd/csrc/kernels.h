@@ -83,7 +83,7 @@ struct RecArgs {
   // a stack of two layer types runs as two launches (lower segment: the rnn kernels):
   // time-step-major LSTM (rectm.hip): window geometry per sample and the errors carried between the (layer, step) launches
   int* tmT; int* tmSteps; int* tmNext;                              // [B] steps in front of the sampled one / forward steps (next state included) / row of the next state's output
-  float* tmER[HL_MAX_HIDDEN]; float* tmSD[HL_MAX_HIDDEN];      // [B][nC]: error handed back by step k + 1 / state delta of step k + 1
+  float* tmER[HL_MAX_HIDDEN]; float* tmSD[HL_MAX_HIDDEN]; float* tmFP[HL_MAX_HIDDEN];      // [B][nC]: error handed back by step k + 1 / LSTM: state delta of step k + 1, MGU: dLdO of the step / MGU: W_sr dS of the step
   float* YoutRows; int ldYR;       // != nullptr: the last block's output of EVERY window step goes here (row b K + k, next rows behind B K): the upper segment's Xin
   const float* DresRows; int ldDR; // != nullptr: gradient w.r.t. those outputs per window row, from the upper segment (instead of Dres at the sampled step only)
 };

@@ -80,7 +80,7 @@ struct hl_learner {
   bool convRowsAtari = true;    // the first layer's row-block kernels with the RACER_atari geometry at compile time (SMARTIES_HIP_GENERIC & 16: any-geometry kernels)
   ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
   bool recTm = false; int* tmT = nullptr; int* tmSteps = nullptr; int* tmNext = nullptr;      // wide LSTM layers: time-step-major launches (rectm.hip)
-  float* tmER[HL_MAX_HIDDEN] = {}; float* tmSD[HL_MAX_HIDDEN] = {};
+  float* tmER[HL_MAX_HIDDEN] = {}; float* tmSD[HL_MAX_HIDDEN] = {}; float* tmFP[HL_MAX_HIDDEN] = {};
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1; one more for the time-step-major launches)
   int recWin = 0;                          // ... steps of a window: nnBPTTseq + 1
   // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
@@ -683,9 +683,9 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->Mmax = (int)roundUp(2 * B, 16);
   h->recurrent = cfg->nn_type != HL_NN_FFNN;
   if (h->recurrent) h->recK = h->recWin = (cfg->nnBPTTseq > 0 ? cfg->nnBPTTseq : 16) + 1;
-  // LSTM layers wider than 64 cells: time-step-major launches (rectm.hip); the windows then carry the next state's step as a row
+  // LSTM / MGU layers wider than 64 cells: time-step-major launches (rectm.hip); the windows then carry the next state's step as a row
   // of their own (one row more per sample)
-  if (h->recurrent && cfg->nn_type == HL_NN_LSTM && !(h->generic & 4) && cfg->n_encoder == 0 && cfg->n_conv == 0) {
+  if (h->recurrent && (cfg->nn_type == HL_NN_LSTM || cfg->nn_type == HL_NN_MGU) && !(h->generic & 4) && cfg->n_encoder == 0 && cfg->n_conv == 0) {
     bool wide = false, ok = true;
     for (int j = 0; j < h->cfg.n_hidden; ++j) { wide = wide || h->cfg.hidden[j] > 64; ok = ok && h->cfg.hidden[j] % 16 == 0; }
     // (the crossover, measured at batch 128 and 17 steps: 2 x 64 cells 325 us with the per-sample kernels against 452 time-step-major, 2 x 96: 631 against 499)
@@ -775,7 +775,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(devAlloc(&L.D, R * g * d.size + 16));
       if (d.hasRes) HIPCK(devAlloc(&L.Rd, R * L.ldR));
       if (d.lstm == 2) HIPCK(devAlloc(&L.A2, R * L.ldA2 + 16));
-      if (h->recTm) { HIPCK(devAlloc(&h->tmER[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmSD[j], (size_t)B * d.size)); }
+      if (h->recTm) { HIPCK(devAlloc(&h->tmER[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmSD[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmFP[j], (size_t)B * d.size)); }
     }
     if (h->recTm) { HIPCK(devAlloc(&h->tmT, (size_t)B)); HIPCK(devAlloc(&h->tmSteps, (size_t)B)); HIPCK(devAlloc(&h->tmNext, (size_t)B)); }
   }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void lstm_tm_zero_kernel(RecArgs a) {
     const long long r = (long long)b * a.K + k;
     for (int j = 0; j < a.nL; ++j) {
       const RecLayer& L = a.L[j];
-      for (int o = tid; o < 4 * L.nC; o += 256) L.D[r * 4 * L.nC + o] = 0.f;
+      for (int o = tid; o < a.gates * L.nC; o += 256) L.D[r * a.gates * L.nC + o] = 0.f;
       if (L.hasRes) for (int c = tid; c < L.nC; c += 256) L.Rd[r * L.ldR + c] = 0.f;
     }
   }
@@ -224,11 +224,217 @@ __global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j, int 
   }
 }
 
+// ---- MGU layers (Network/Layers/Layer_GRU.h:64-231), the same arrangement ------------------------------------------------------------
+//   forget f = sigm(b_f + W_ff in + W_fr prevOut),  state s = tanh(b_s + W_sf in + W_sr (f * prevOut)),  output = f s + (1 - f) prevOut
+// The state's recurrent term needs the forget gates of ALL cells: two products per (layer, step) --
+//   forward   phase 0: columns [0, nC) over [in | prevOut]       -> f, and the row A2 = f * prevOut (the dW operand of W_sr)
+//             phase 1: columns [nC, 2 nC) over [in | A2]          -> s, the output, the rows of the next layer / next step
+//   backward  phase 0: fp = dS W_sr^T (reduction over the state deltas)        -> dF = ((s - p) dLdO + fp p) f (1 - f)
+//             phase 1: [error below | g] = [dF | dS] W_in^T  |  dF W_fr^T      -> error of the block below; error to step k - 1 =
+//                      (1 - f) dLdO + f fp + g.  Its epilogue forms dLdO and dS of the cell whose inputs it completes (as the LSTM
+//                      kernel does): the block below at this step, the last layer at the previous step
+// W is [nIn + nC][2 nC] (forget columns first); rows kept per (sample, step): X = [f | s], Y = output, D = [dF | dS].
+__global__ __launch_bounds__(TM_FNT) void mgu_tm_fwd_kernel(RecArgs a, int j, int k, int phase) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const RecLayer& L = a.L[j];
+  const int nIn = L.nIn, nC = L.nC, NO = 2 * nC, Kt = nIn + nC, Kt4 = (Kt + 3) & ~3, lds = Kt4 + TM_LDA;
+  float* sA = sm;                        // [16][lds]
+  float* sG = sA + 16 * lds;             // [8][16][17]
+  __shared__ int sAct[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int b0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  if (tid < 16) sAct[tid] = (b0 + tid < a.B && a.tmSteps[b0 + tid] > k) ? 1 : 0;
+  // wavefront w: an eighth of the rows [W_in; W_rec] of column (phase, cell li)
+  const int nS = Kt4 >> 2, nSe = (nS + 7) >> 3, sBeg = wave * nSe, sEnd = min(nS, sBeg + nSe);
+  const float* Wg = a.W + L.indW + (size_t)phase * nC + c0 + li;
+  constexpr int UN = 16;
+  float bv[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) { const int i = min(4 * (sBeg + u) + lc, Kt - 1); bv[u] = Wg[(size_t)i * NO]; }
+  {      // A tile: [in | prevOut] (phase 0) or [in | f * prevOut] (phase 1), zeros behind Kt
+    const int q4 = Kt4 >> 2;
+    for (int i = tid; i < 16 * q4; i += TM_FNT) {
+      const int row = i / q4, q = i - row * q4, b = min(b0 + row, a.B - 1);
+      const long long r = (long long)b * a.K + k;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = 4 * q + e;
+        v[e] = x < nIn ? L.A[r * L.ldA + x] : (x < Kt ? (phase ? L.A2[r * L.ldA2 + (x - nIn)] : L.A[r * L.ldA + x]) : 0.f);
+      }
+      *reinterpret_cast<f32x4*>(sA + row * lds + 4 * q) = v;
+    }
+  }
+  __syncthreads();
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) any = any || sAct[i] != 0;
+  if (!any) return;
+  const float* ar = sA + li * lds + lc;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = sBeg; s0 < sEnd; s0 += UN) {
+    if (s0 > sBeg) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const int i = min(4 * (s0 + u) + lc, Kt - 1); bv[u] = Wg[(size_t)i * NO]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float av = s0 + u < sEnd ? ar[4 * (s0 + u)] : 0.f;
+      if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[u], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[u], acc0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sG[(wave * 16 + 4 * lc + q) * 17 + li] = acc0[q] + acc1[q];
+  __syncthreads();
+  if (tid >= 256) return;
+  const int row = tid >> 4, cc = tid & 15, b = b0 + row, c = c0 + cc;
+  if (!sAct[row]) return;
+  float sum = a.W[L.indB + phase * nC + c];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) sum += sG[(w * 16 + row) * 17 + cc];
+  const long long r = (long long)b * a.K + k;
+  const float po = sA[row * lds + nIn + c];      // phase 0: prevOut; phase 1: f * prevOut
+  if (phase == 0) {
+    const float f = recSigm(sum);
+    L.X[r * NO + c] = f;
+    L.A2[r * L.ldA2 + c] = po * f;
+    return;
+  }
+  const float st = actEval(HL_FUNC_TANH, sum);
+  L.X[r * NO + nC + c] = st;
+  const float f = L.X[r * NO + c], prev = L.A[r * L.ldA + nIn + c];
+  const float out = k > 0 ? f * st + (1.f - f) * prev : f * st;
+  L.Y[r * NO + c] = out;
+  float blk = out;
+  if (L.hasRes && c < L.resW) blk += sA[row * lds + c] * a.W[L.indWr + c] + a.W[L.indBr + c];
+  const int steps = a.tmSteps[b], T = a.tmT[b];
+  if (k + 1 < steps) L.A[(r + 1) * L.ldA + nIn + c] = out;
+  if (j + 1 < a.nL) { const RecLayer& U = a.L[j + 1]; U.A[r * U.ldA + c] = blk; }
+  else {
+    if (k == T) a.Yout[(size_t)b * a.ldY + c] = blk;
+    else if (k == T + 1) a.Yout[(size_t)a.tmNext[b] * a.ldY + c] = blk;
+  }
+}
+// dLdO and the state delta of (layer j, step k, sample b, cell c): eTop = error from the block above, eRec = error handed back by step k + 1
+__device__ __forceinline__ void tmMguOpen(const RecArgs& a, int j, int k, int b, int c, int T, float eTop, float eRec) {
+  const RecLayer& L = a.L[j];
+  const int nC = L.nC, NO = 2 * nC;
+  const long long r = (long long)b * a.K + k;
+  if (L.hasRes) L.Rd[r * L.ldR + c] = eTop;
+  const float dLdO = eTop + (k < T ? eRec : 0.f);
+  const float f = L.X[r * NO + c], st = L.X[r * NO + nC + c];
+  a.tmSD[j][(size_t)b * nC + c] = dLdO;
+  L.D[r * NO + nC + c] = dLdO * f * (1.f - st * st);
+}
+__global__ __launch_bounds__(256) void mgu_tm_bwd_kernel(RecArgs a, int j, int k, int phase) {
+  __shared__ float sR[4 * 256];
+  __shared__ int sT[16];
+  const RecLayer& L = a.L[j];
+  const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
+  const int b0 = blockIdx.y * 16;
+  if (tid < 16) sT[tid] = b0 + tid < a.B ? a.tmT[b0 + tid] : -2;
+  const int bl = min(b0 + li, a.B - 1);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int UG = 8;
+  if (phase == 0) {
+    // fp[b][c] = sum_o dS[b][o] W[nIn + c][nC + o]: the four wavefronts split the nC state deltas (k == 0: no recurrent input, fp = 0)
+    const int c0 = blockIdx.x * 16;
+    if (k > 0) {
+      const int q = nC >> 2;      // deltas per wavefront (nC is a multiple of 16)
+      const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + L.indW + (size_t)(nIn + c0 + li) * NO + nC + wave * q) + lc;
+      const f32x4* dr = reinterpret_cast<const f32x4*>(L.D + ((size_t)bl * a.K + k) * NO + nC + wave * q) + lc;
+      const int nG = q >> 4, rem = q & 15;      // whole groups of 16; nC % 64 != 0 leaves a group of `rem` (a multiple of 4)
+      for (int g0 = 0; g0 < nG; g0 += UG) {
+        f32x4 wv[UG], dv[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) { const int G = min(g0 + u, nG - 1); wv[u] = wr[4 * G]; dv[u] = dr[4 * G]; }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) if (g0 + u < nG) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][0], wv[u][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][1], wv[u][1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][2], wv[u][2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][3], wv[u][3], acc1, 0, 0, 0);
+        }
+      }
+      if (rem) {      // the last `rem` deltas of the wavefront's range, four per lane group: lane group lc takes element 16 nG + 4 e + lc in sub-step e < rem / 4
+        const float* wq = a.W + L.indW + (size_t)(nIn + c0 + li) * NO + nC + wave * q + 16 * nG;
+        const float* dq = L.D + ((size_t)bl * a.K + k) * NO + nC + wave * q + 16 * nG;
+        for (int e = 0; 4 * e < rem; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[4 * e + lc], wq[4 * e + lc], acc0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sR[wave * 256 + (4 * lc + q) * 16 + li] = acc0[q] + acc1[q];
+    __syncthreads();
+    const int row = tid >> 4, cc = tid & 15, b = b0 + row, c = c0 + cc, T = sT[row];
+    if (T < k) return;
+    const float fp = k > 0 ? (sR[tid] + sR[256 + tid]) + (sR[512 + tid] + sR[768 + tid]) : 0.f;
+    const long long r = (long long)b * a.K + k;
+    const float f = L.X[r * NO + c], st = L.X[r * NO + nC + c], p = k > 0 ? L.Y[(r - 1) * NO + c] : 0.f;
+    const float dLdO = a.tmSD[j][(size_t)b * nC + c];
+    a.tmFP[j][(size_t)b * nC + c] = fp;
+    L.D[r * NO + c] = ((st - p) * dLdO + fp * p) * f * (1.f - f);
+    return;
+  }
+  // phase 1: rows i of [W_in; W_rec]: i < nIn reduce over [dF | dS] (wavefronts 0, 1 the forget half, 2, 3 the state half), i >= nIn over dF only
+  const int row0 = j > 0 ? 0 : nIn, i0 = row0 + blockIdx.x * 16, nRowW = nIn + nC;
+  const int iw = min(i0 + li, nRowW - 1);
+  const int h = nC >> 1;                                      // deltas per wavefront: half of a gate's
+  const bool stateHalf = wave >= 2;
+  const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + L.indW + (size_t)iw * NO + wave * h) + lc;
+  const f32x4* dr = reinterpret_cast<const f32x4*>(L.D + ((size_t)bl * a.K + k) * NO + wave * h) + lc;
+  const float keep = (stateHalf && i0 + li >= nIn) ? 0.f : 1.f;      // (recurrent rows take the forget deltas only)
+  {
+    const int nG = h >> 4, rem = h & 15;
+    for (int g0 = 0; g0 < nG; g0 += UG) {
+      f32x4 wv[UG], dv[UG];
+#pragma unroll
+      for (int u = 0; u < UG; ++u) { const int G = min(g0 + u, nG - 1); wv[u] = wr[4 * G]; dv[u] = dr[4 * G]; }
+#pragma unroll
+      for (int u = 0; u < UG; ++u) if (g0 + u < nG) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][0], wv[u][0] * keep, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][1], wv[u][1] * keep, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][2], wv[u][2] * keep, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][3], wv[u][3] * keep, acc1, 0, 0, 0);
+      }
+    }
+    if (rem) {
+      const float* wq = a.W + L.indW + (size_t)iw * NO + wave * h + 16 * nG;
+      const float* dq = L.D + ((size_t)bl * a.K + k) * NO + wave * h + 16 * nG;
+      for (int e = 0; 4 * e < rem; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[4 * e + lc], wq[4 * e + lc] * keep, acc0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sR[wave * 256 + (4 * lc + q) * 16 + li] = acc0[q] + acc1[q];
+  __syncthreads();
+  const int row = tid >> 4, ii = tid & 15, b = b0 + row, i = i0 + ii, T = sT[row];
+  if (i >= nRowW || T < k - 1) return;
+  const float e = (sR[tid] + sR[256 + tid]) + (sR[512 + tid] + sR[768 + tid]);      // (zero for a sample without step k)
+  if (i < nIn) {
+    if (T < k) return;
+    float v = e;
+    if (L.hasRes && i < L.resW) v += L.Rd[((size_t)b * a.K + k) * L.ldR + i] * a.W[L.indWr + i];
+    tmMguOpen(a, j - 1, k, b, i, T, v, a.tmER[j - 1][(size_t)b * a.L[j - 1].nC + i]);
+  } else if (k > 0) {
+    const int c = i - nIn;
+    float rec = 0.f;
+    if (T >= k) {
+      const long long r = (long long)b * a.K + k;
+      const float f = L.X[r * NO + c];
+      rec = (1.f - f) * a.tmSD[j][(size_t)b * nC + c] + f * a.tmFP[j][(size_t)b * nC + c] + e;
+    }
+    if (j == a.nL - 1) tmMguOpen(a, j, k - 1, b, c, T, k - 1 == T ? a.Dres[(size_t)b * a.ldD + c] : 0.f, rec);
+    else a.tmER[j][(size_t)b * nC + c] = rec;
+  }
+}
+
 bool rec_tm_ok(const RecArgs& a) {
-  if (a.gates != 4 || a.actStates != nullptr || a.tmSteps == nullptr || a.YoutRows != nullptr || a.DresRows != nullptr || a.K < a.nBPTT + 2) return false;
+  if ((a.gates != 4 && a.gates != 2) || a.actStates != nullptr || a.tmSteps == nullptr || a.YoutRows != nullptr || a.DresRows != nullptr || a.K < a.nBPTT + 2) return false;
   for (int j = 0; j < a.nL; ++j) {
     const RecLayer& L = a.L[j];
     if (L.nC % 16 || L.indW % 4 || (L.ldA & 3) || (j > 0 && L.nIn != a.L[j - 1].nC)) return false;
+    if (a.gates == 2 && a.tmFP[j] == nullptr) return false;
     if ((size_t)(16 * (((L.nIn + L.nC + 3) & ~3) + TM_LDA) + 8 * 16 * 17) * 4 > 150 * 1024) return false;
   }
   return true;
@@ -238,6 +444,14 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(lstm_tm_prepare_kernel, dim3(a.B), dim3(256), 0, s, a);
   size_t ldsMax = 0;
   for (int j = 0; j < a.nL; ++j) ldsMax = std::max(ldsMax, tmFwdLds(a.L[j]));
+  if (a.gates == 2) {
+    hipError_t e2 = ensureDynLds(reinterpret_cast<const void*>(mgu_tm_fwd_kernel), ldsMax); if (e2 != hipSuccess) return e2;
+    for (int k = 0; k <= a.nBPTT + 1; ++k)
+      for (int j = 0; j < a.nL; ++j)
+        for (int ph = 0; ph < 2; ++ph)
+          hipLaunchKernelGGL(mgu_tm_fwd_kernel, dim3(a.L[j].nC / 16, (a.B + 15) / 16), dim3(TM_FNT), tmFwdLds(a.L[j]), s, a, j, k, ph);
+    return hipGetLastError();
+  }
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(lstm_tm_fwd_kernel), ldsMax); if (e != hipSuccess) return e;
   for (int k = 0; k <= a.nBPTT + 1; ++k)
     for (int j = 0; j < a.nL; ++j) {
@@ -248,6 +462,18 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
 }
 hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(lstm_tm_zero_kernel, dim3(a.B), dim3(256), 0, s, a);
+  if (a.gates == 2) {
+    for (int k = a.nBPTT + 1; k >= 0; --k)
+      for (int j = a.nL - 1; j >= 0; --j) {
+        const RecLayer& L = a.L[j];
+        const bool first = k == a.nBPTT + 1;      // (the chain's first launch: the last layer's dLdO and state deltas of step nBPTT)
+        if (first && j != a.nL - 1) continue;
+        if (!first) hipLaunchKernelGGL(mgu_tm_bwd_kernel, dim3(L.nC / 16, (a.B + 15) / 16), dim3(256), 0, s, a, j, k, 0);
+        const int row0 = j > 0 ? 0 : L.nIn, nOut = L.nIn + (k > 0 ? L.nC : 0) - row0;
+        if (nOut > 0) hipLaunchKernelGGL(mgu_tm_bwd_kernel, dim3((nOut + 15) / 16, (a.B + 15) / 16), dim3(256), 0, s, a, j, k, 1);
+      }
+    return hipGetLastError();
+  }
   for (int k = a.nBPTT + 1; k >= 0; --k)
     for (int j = a.nL - 1; j >= 0; --j) {
       if (k == a.nBPTT + 1 && j != a.nL - 1) continue;      // (the chain's first launch: the last layer's deltas of step nBPTT)

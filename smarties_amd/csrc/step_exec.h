@@ -771,7 +771,7 @@ RecArgs recArgs(hl_learner* h, int parity, int seg = -1) {
   ra.nL = jEnd - jBeg;
   ra.K = h->recK; ra.nBPTT = h->recWin - 1; ra.W = h->W; ra.gates = h->hid[jBeg].lstm; ra.func = h->cfg.nnFunc; ra.nApp = (j0 || seg == 1) ? 0 : h->nApp;
   for (int j = jBeg; j < jEnd; ++j) ra.L[j - jBeg] = h->rec[j];
-  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; } }
+  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; ra.tmFP[j - jBeg] = h->tmFP[j]; } }
   if (seg == 1) { ra.Xin = h->segY; ra.ldXin = h->ldSeg; }
   else if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
   if (seg == 0) { ra.YoutRows = h->segY; ra.ldYR = h->ldSeg; ra.DresRows = h->segDres; ra.ldDR = h->ldSeg; }
@@ -1037,6 +1037,9 @@ bool graphUsable(const hl_learner* h, int U, int p0) {
   if (exchanging(h) && U > 64) return false;
   if (h->bigBatch && (U > 64 || exchanging(h))) return false;      // (a dozen nodes and a branch per step; replicas with large local batches step eagerly)
   if (U == 999 && p0 != 0) return false;
+  // time-step-major recurrent layers: 2 (LSTM) or 4 (MGU) launches per layer and window step.  The runtime instantiated 83 k nodes in a
+  // chain (999 steps of 2 LSTM layers, 18 window steps) and died on 156 k (the same with MGU layers): 64 k nodes at most
+  if (h->recTm && (long long)U * (h->recK * h->cfg.n_hidden * (h->cfg.nn_type == HL_NN_MGU ? 4 : 2) + 12) > 65536) return false;
   return true;
 }
 
