@@ -276,6 +276,13 @@ HL_API int hl_get_episode_stats(hl_learner* h, int64_t episode_pos, float* dst9)
 
 /* ---- training ---------------------------------------------------------------- */
 HL_API int hl_initialize(hl_learner* h);                  /* Learner::initializeLearner */
+/* ... in two halves for host-exchange mode (n_ranks > 1, the caller owns the communicator): the reference's start-up reductions are
+ * accurate ones (updateCounters(true), updateRewardsStats(true): DelayedReductor::get(true) waits, Learner.cpp:58-59), every learner
+ * starts from the GLOBAL counters and reward / state moments.  Between the halves the caller sums hl_counters_exchange and
+ * hl_moments_exchange over the replicas (smarties_amd/dist_host.py: initialize_host_exchange).  hl_initialize = both halves with
+ * the exchange over the library's own communicator (hl_xchg_connect / hl_comm_init) in between. */
+HL_API int hl_initialize_begin(hl_learner* h);
+HL_API int hl_initialize_end(hl_learner* h);
 /* n_steps full gradient steps.  flat_indices == NULL: device-side sampler; else
  * n_steps * batch_local sorted unique indices to use instead (the RNG is then
  * advanced as if it had drawn them only by the per-step Adam draw). */
@@ -412,8 +419,9 @@ HL_API int hl_xchg_export(hl_learner* h, uint8_t handle[HL_XCHG_HANDLE_BYTES]);
 HL_API int hl_xchg_connect(hl_learner* h, const uint8_t* handles /* n_ranks x HL_XCHG_HANDLE_BYTES */);
 /* n_ranks > 1 WITHOUT hl_xchg_connect / hl_comm_init = host-exchange mode: the caller owns the communicator and
  * drives hl_step_begin / hl_grad_exchange / hl_counters_exchange / hl_moments_exchange /
- * hl_step_end itself (smarties_amd/dist_host.py); hl_initialize then takes the start-up reward /
- * state statistics from the local shard, and hl_step returns HL_ERR_COMM. */
+ * hl_step_end itself, and hl_initialize_begin / hl_counters_exchange / hl_moments_exchange / hl_initialize_end at start-up
+ * (smarties_amd/dist_host.py); a plain hl_initialize takes the start-up reward / state statistics from the local shard only, and
+ * hl_step returns HL_ERR_COMM. */
 
 /* ---- timing taps for bench.py ------------------------------------------------------ */
 /* average device time (ms) per launch of the named kernel over the launches since the

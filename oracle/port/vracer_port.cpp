@@ -245,7 +245,7 @@ struct ol_learner {
   int64_t seenEpsUpd = 0, seenStepsUpd = 0, seenEpsGlobal = 0, seenStepsGlobal = 0;
   int64_t nGatheredB4Startup = INT64_MAX;
   int64_t nFarGlobal = 0, nStoredGlobal = 0;  // result of counters reduction
-  bool countersReduced = false, momentsPending = false;
+  bool countersReduced = false, momentsPending = false, initPending = false;
   std::vector<long double> moments;
   hl_stats stats{};
   // adam (Network/Optimizer.h:38-47,96)
@@ -1340,15 +1340,28 @@ int ol_get_episode_field(ol_learner* h, int64_t pos, int32_t field, float* dst, 
   std::copy(v->begin(), v->end(), dst); return HL_OK;
 }
 
-// Learner::initializeLearner (Learners/Learner.cpp:47-72)
-int ol_initialize(ol_learner* h) {
+// Learner::initializeLearner (Learners/Learner.cpp:47-72), split at its two accurate reductions (updateCounters(true), updateRewardsStats(true):
+// DelayedReductor::get(true) waits, so with several learners every one starts from the GLOBAL counters and reward / state moments)
+int ol_initialize_begin(ol_learner* h) {
   if (!h) return HL_ERR_BAD_ARG;
   if (h->episodes.empty()) return fail(h, HL_ERR_TOO_FEW_DATA, "empty replay");
+  computeMoments(h, h->moments);
+  h->momentsPending = true; h->initPending = true;
+  return HL_OK;
+}
+int ol_initialize_end(ol_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  if (!h->initPending) return fail(h, HL_ERR_STATE, "initialize_end without initialize_begin");
   updateCounters(h, true);
-  { std::vector<long double> mom; computeMoments(h, mom); applyMoments(h, mom, true, 1); }
+  applyMoments(h, h->moments, true, 1);
+  h->momentsPending = false; h->initPending = false;
   h->nGatheredB4Startup = h->minObsLocal;
   for (auto& ep : h->episodes) retraceEpisode(h, *ep);   // rescaleAllReturnEstimator (:460-481)
   h->initialized = true; return HL_OK;
+}
+int ol_initialize(ol_learner* h) {
+  const int rc = ol_initialize_begin(h);
+  return rc ? rc : ol_initialize_end(h);
 }
 
 // Learner_approximator::spawnTrainTasks (Learner_approximator.cpp:36-92), nThreads = 1

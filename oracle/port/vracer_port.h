@@ -40,6 +40,8 @@ HL_API int ol_get_episode_field(ol_learner* h, int64_t pos, int32_t field, float
 HL_API int ol_get_episode_info(ol_learner* h, int64_t pos, int64_t* tag, int32_t* nsteps, int32_t* terminated);
 HL_API int ol_get_episode_stats(ol_learner* h, int64_t pos, float* dst9);
 HL_API int ol_initialize(ol_learner* h);
+HL_API int ol_initialize_begin(ol_learner* h);
+HL_API int ol_initialize_end(ol_learner* h);
 HL_API int ol_step(ol_learner* h, int32_t n_steps, const int64_t* flat_indices);
 HL_API int ol_step_begin(ol_learner* h, const int64_t* flat_indices);
 HL_API int ol_grad_exchange(ol_learner* h, float* grad_io, int32_t write_back);

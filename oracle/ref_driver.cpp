@@ -49,6 +49,19 @@
 
 using namespace smarties;
 
+// Runs with several learners (mpiexec -n 2 ref_driver fixture out.bin ...; learners_train_comm = the world): the reference polls its
+// delayed reductions with MPI_Test right behind their MPI_Iallreduce (DelayedReductor::get(false), Utils/DelayedReductor.cpp:36-48;
+// MemoryProcessing::updateCounters :56-58, updateRewardsStats :147-150), so a step uses this step's global sums or the previous
+// step's, whichever the network's timing gives.  The harness pins the timing through MPI's profiling interface, without touching the
+// reference: with gPromptReductions every poll finds its reduction complete (the order of operations of SURVEY.md 8(e)).
+static int gPromptReductions = 0;
+extern "C" int MPI_Test(MPI_Request* req, int* flag, MPI_Status* st) {
+  if (gPromptReductions) { *flag = 1; return PMPI_Wait(req, st); }
+  return PMPI_Test(req, flag, st);
+}
+static int worldSize() { int n = 1; MPI_Comm_size(MPI_COMM_WORLD, &n); return n; }
+static int worldRank() { int r = 0; MPI_Comm_rank(MPI_COMM_WORLD, &r); return r; }
+
 struct Args {
   std::map<std::string, std::string> kv;
   std::string s(const std::string& k, const std::string& d) const {
@@ -157,6 +170,10 @@ struct Harness {
     info.nThreads = nThr; omp_set_num_threads(nThr);
     info.randSeed = A.l("seed", 42); info.initialze();
     info.learners_train_comm = MPI_COMM_SELF; info.bIsMaster = true;
+    if (worldSize() > 1) {      // every rank a learner with its own share of the batch and of the replay (HyperParameters::defineDistributedLearning)
+      MPI_Comm c; MPI_Comm_dup(MPI_COMM_WORLD, &c); info.learners_train_comm = c;
+      gPromptReductions = (int)A.l("prompt", 1);
+    }
     info.nAgents = 1; info.nOwnedEnvironments = 1; info.nEnvironments = 1;
     info.logAllSamples = (int)A.l("rewlog", 0); info.learnersOnWorkers = false; info.restart = "none";
     if (info.logAllSamples) {     // cumulative_rewards.dat / obs.raw of MemoryBuffer::pushBackEpisode go to a scratch directory
@@ -329,8 +346,9 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
   const std::vector<Uint> gradSteps = parseList(A.s("gradSteps", "1,2"));
   const std::vector<Uint> retSteps = parseList(A.s("retSteps", ""));
   const bool official = A.s("path", "manual") == "official";
-  for (long e = 0; e < nEps; ++e) H.pushSynthEpisode((uint64_t)e);
-  std::remove((L.learner_name + "_stats.txt").c_str());      // (the run's own <learner>_stats.txt is captured below)
+  const int nRanks = worldSize(), rank = worldRank();
+  for (long e = 0; e < nEps; ++e) if (e % nRanks == rank) H.pushSynthEpisode((uint64_t)e);      // (round robin over the learners)
+  if (rank == 0) std::remove((L.learner_name + "_stats.txt").c_str());      // (the run's own <learner>_stats.txt is captured below)
   // resume=<prefix>: instead of (or on top of) a synthetic fill, what Learner_approximator::restart does (Learner_approximator.cpp:
   // 118-131) with the files an earlier run of this harness wrote through ckpt=<prefix> memck=<prefix>: network and Adam moments,
   // replay memory with its counters and scaling, the optimizer's step count
@@ -341,7 +359,8 @@ static int modeFixture(ExecutionInfo& info, const Args& A, const std::string& ou
     for (const auto& net : L.networks) net->setNgradSteps(L.nGradSteps());
   }
 
-  BlobWriter W(out);
+  BlobWriter W(nRanks > 1 ? out + ".r" + std::to_string(rank) : out);
+  if (nRanks > 1) W.i64("ranks", std::vector<int64_t>{nRanks, rank, gPromptReductions});
   Approximator& NET = *L.networks[0];
   AdamOptimizer* OPT = dynamic_cast<AdamOptimizer*>(NET.opt.get());
   const Parameters* PW = NET.net->weights.get();

@@ -176,6 +176,8 @@ class CApi:
             "get_episode_info": (C.c_int, [P, I64, pi64, pi32, pi32]),
             "get_episode_stats": (C.c_int, [P, I64, pf]),
             "initialize": (C.c_int, [P]),
+            "initialize_begin": (C.c_int, [P]),
+            "initialize_end": (C.c_int, [P]),
             "step": (C.c_int, [P, I32, pi64]),
             "step_begin": (C.c_int, [P, pi64]),
             "grad_exchange": (C.c_int, [P, pf, I32]),
@@ -346,6 +348,13 @@ class Learner:
     # -- training -----------------------------------------------------------------
     def initialize(self):
         self._ck(self.api.fn("initialize")(self.h))
+
+    def initialize_begin(self):
+        """First half of `initialize` (host-exchange mode: sum `counters_fetch` / `moments_fetch` over the replicas, store, then `initialize_end`)."""
+        self._ck(self.api.fn("initialize_begin")(self.h))
+
+    def initialize_end(self):
+        self._ck(self.api.fn("initialize_end")(self.h))
 
     def step(self, n=1, flat=None):
         if flat is not None:

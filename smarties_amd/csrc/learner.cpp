@@ -190,7 +190,7 @@ struct hl_learner {
   // then the learner's sticky device error (the state stays as it was before that collective)
   long long xchgTimeoutTicks = 6000000000LL;    // 60 s at 100 MHz (SMARTIES_HIP_XCHG_TIMEOUT_MS): how long a replica waits inside the exchange kernel for its peers
   // moments exchange state
-  bool momentsPending = false;
+  bool momentsPending = false, initPending = false;
   // timing
   bool timing = false; std::vector<std::string> tnames; std::vector<double> tsum; std::vector<long long> tcnt;
   std::vector<TimeRec> trecs;
@@ -1198,26 +1198,46 @@ int hl_get_episode_field(hl_learner* h, int64_t pos, int32_t field, float* dst, 
   return HL_OK;
 }
 
-// Learner::initializeLearner (Learners/Learner.cpp:47-72)
-int hl_initialize(hl_learner* h) {
-  if (!h) return HL_ERR_BAD_ARG;
-  HL_LOCK(h);
+// Learner::initializeLearner (Learners/Learner.cpp:47-72), split at its two accurate reductions (updateCounters(true),
+// updateRewardsStats(true): DelayedReductor::get(true) waits for them, so with several learners every one starts from the GLOBAL
+// counters and reward / state moments).  hl_initialize does the exchange itself over the communicator of hl_xchg_connect /
+// hl_comm_init; in host-exchange mode the caller sums hl_counters_exchange / hl_moments_exchange between the two halves.
+static int initializeBegin(hl_learner* h) {
   if (h->order.empty()) return fail(h, HL_ERR_TOO_FEW_DATA, "empty replay");
   int rc = flushPending(h); if (rc) return rc;
-  // n_ranks > 1 without hl_comm_init = host-exchange mode (hl_step_begin / hl_*_exchange /
-  // hl_step_end driven by the caller's own communicator): the start-up statistics then come from
-  // the local shard only; hl_step itself refuses to run (allreduceGrad).
-  rc = allreduceCounters(h); if (rc) return rc;
-  rc = launchPost(h, 0, POST_INIT, h->stream); if (rc) return rc;     // updateCounters(bInit)
-  rc = launchMoments(h); if (rc) return rc;                          // updateRewardsStats(bInit)
-  rc = allreduceMoments(h); if (rc) return rc;
+  rc = launchMoments(h); if (rc) return rc;                          // updateRewardsStats(bInit): the local sums
+  h->momentsPending = true; h->initPending = true;
+  return HL_OK;
+}
+static int initializeEnd(hl_learner* h) {
+  if (!h->initPending) return fail(h, HL_ERR_STATE, "hl_initialize_end without hl_initialize_begin");
+  int rc = launchPost(h, 0, POST_INIT, h->stream); if (rc) return rc;     // updateCounters(bInit)
   rc = launchMomentsApply(h, true, 1); if (rc) return rc;
+  h->momentsPending = false; h->initPending = false;
   h->nGatheredB4Startup = h->minObsLocal;
   rc = runSweep(h, nullptr, (int)h->order.size(), 0); if (rc) return rc;   // rescaleAllReturnEstimator
   HIPCK(hipStreamSynchronize(h->stream));
   h->initialized = true;
   if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
   return captureAllGraphs(h);      // one-off costs belong here, not in the first training step
+}
+int hl_initialize_begin(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  return initializeBegin(h);
+}
+int hl_initialize_end(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  return initializeEnd(h);
+}
+int hl_initialize(hl_learner* h) {
+  if (!h) return HL_ERR_BAD_ARG;
+  HL_LOCK(h);
+  int rc = initializeBegin(h); if (rc) return rc;
+  rc = allreduceCounters(h); if (rc) return rc;
+  rc = allreduceMoments(h); if (rc) return rc;
+  return initializeEnd(h);
 }
 
 static int preStepChecks(hl_learner* h) {

@@ -26,6 +26,20 @@ def init_replica_weights(L, dist, src=0, group=None):
     L.set_params(w, m1, m2)
 
 
+def initialize_host_exchange(L, dist, group=None):
+    """Learner::initializeLearner of one replica (Learners/Learner.cpp:47-72): the start-up counters and reward / state moments are
+    accurate reductions over the learners (DelayedReductor::get(true)), every replica starts from the global statistics."""
+    import torch
+    L.initialize_begin()
+    c = np.asarray(L.counters_fetch(), dtype=np.int64)
+    dist.all_reduce(torch.from_numpy(c), op=dist.ReduceOp.SUM, group=group)
+    L.counters_store(c)
+    m = L.moments_fetch()
+    dist.all_reduce(torch.from_numpy(m), op=dist.ReduceOp.SUM, group=group)
+    L.moments_store(m)
+    L.initialize_end()
+
+
 def step_host_exchange(L, dist, n_steps=1, flat=None, group=None):
     """`n_steps` gradient steps of one replica; collectives through `dist` (torch.distributed; `group`: a process group
     that takes host tensors, e.g. a gloo group next to an nccl default group)."""

@@ -744,7 +744,11 @@ def test_two_replica_protocol_matches_oracle_replicas(hip_api):
             Ls.append(L)
         w0 = Ls[0].get_params()[0]
         for L in Ls:
-            w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2); L.initialize()
+            w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2); L.initialize_begin()
+        c = np.sum([L.counters_fetch() for L in Ls], axis=0)      # the start-up statistics are global (Learner.cpp:58-59: accurate reductions)
+        m = np.sum([L.moments_fetch() for L in Ls], axis=0)
+        for L in Ls:
+            L.counters_store(c); L.moments_store(m); L.initialize_end()
         return Ls
 
     def one_step(Ls):

@@ -41,7 +41,7 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = _make(rank, world)
     dist_host.init_replica_weights(L, dist)
-    L.initialize()
+    dist_host.initialize_host_exchange(L, dist)
     dist_host.step_host_exchange(L, dist, N_STEPS)
     w, m1, m2 = L.get_params()
     sc = L.scalars()
@@ -58,7 +58,11 @@ def _emulate(world):
     for L in Ls:
         w, m1, m2 = L.get_params()
         L.set_params(w0, m1, m2)
-        L.initialize()
+        L.initialize_begin()
+    c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+    m = np.sum([L.moments_fetch() for L in Ls], axis=0)
+    for L in Ls:
+        L.counters_store(c); L.moments_store(m); L.initialize_end()
     for _ in range(N_STEPS):
         for L in Ls:
             L.step_begin()

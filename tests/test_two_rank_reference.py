@@ -1,0 +1,213 @@
+"""Two learners against the COMPILED REFERENCE run under `mpiexec -n 2` (tests/golden/make_golden.sh, oracle/ref_driver.cpp:
+learners_train_comm = the world; one fixture per rank, `<name>.r0` / `<name>.r1`).  The replicas here are driven through the split entry
+points -- initialize_begin / counters + moments sums / initialize_end, then per step step_begin / gradient + counters (+ moments) sums /
+step_end -- and every rank must follow its fixture: the rank-seeded generator and sampled (episode, t) pairs bit for bit, network
+outputs and gradients, the ReF-ER coefficient (both ranks the same: global counters), weights and Adam moments after the summed
+gradient, the start-up scaling from the GLOBAL reward / state moments and the 1000th step's moments exchange.
+
+The reference polls its delayed reductions with MPI_Test (Utils/DelayedReductor.cpp:36-48); the recording harness pinned every poll to
+"complete" (the timing this protocol implements), see oracle/ref_driver.cpp."""
+import numpy as np
+import pytest
+
+from oracle_api import oracle_learner, synth_episode
+from parity import load_fixture, fixture_config, fixture_synth, relinf, fx_vec_dev, episode_arrays_by_tag, fixture_arrays_by_tag, flat_for
+from smarties_amd import capi
+
+FIXTURES = ["two_rank.bin", "two_rank_traj.bin"]
+
+
+def replicas(make, name):
+    fx = [load_fixture("%s.r%d" % (name, r)) for r in range(2)]
+    Ls = []
+    for r in range(2):
+        assert [int(v) for v in fx[r]["ranks"]] == [2, r, 1]
+        L = make(fixture_config(fx[r], episode_order=capi.ORDER_REFERENCE, n_ranks=2, rank=r))
+        assert L.nParams == int(fx[r]["cfg"][5])
+        L.init_weights()                                   # every rank draws from its own generator (seed + rank, ExecutionInfo.cpp:387) ...
+        assert np.array_equal(L.get_rng_state(), fx[r]["rng_before_init"])
+        Ls.append(L)
+    w0 = Ls[0].get_params()[0]
+    assert np.array_equal(w0, fx[0]["W0"]) and np.array_equal(fx[1]["W0"], fx[0]["W0"])      # ... and takes rank 0's weights (Builder.cpp:141-143)
+    for r, L in enumerate(Ls):
+        w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2)
+        for e in range(r, int(fx[r]["cfg"][3]), 2):      # episodes round robin over the learners
+            L.append_episode(**synth_episode(fixture_synth(fx[r]), e))
+        L.initialize_begin()
+    c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+    m = np.sum([L.moments_fetch() for L in Ls], axis=0)
+    for L in Ls:
+        L.counters_store(c); L.moments_store(m); L.initialize_end()
+    return fx, Ls
+
+
+def one_step(Ls):
+    for L in Ls:
+        L.step_begin()
+    gs = [L.grad_fetch() for L in Ls]
+    g = np.sum(gs, axis=0, dtype=np.float32)
+    ms = [L.moments_fetch() for L in Ls]
+    c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+    return gs, g, ms, c
+
+
+def finish_step(Ls, g, ms, c):
+    for L, m in zip(Ls, ms):
+        L.grad_store(g)
+        if m is not None:
+            L.moments_store(np.sum(ms, axis=0))
+        L.counters_store(c)
+        L.step_end()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_restatement_replicas_follow_the_two_rank_reference(name):
+    fx, Ls = replicas(oracle_learner, name)
+    tol = 1e-6
+    for r, L in enumerate(Ls):
+        s = L.scalars()
+        assert s.nStoredSteps == int(fx[r]["cfg"][7])
+        assert s.beta == fx[r]["beta0"][0] and s.CmaxRet == fx[r]["cmax0"][0]
+        mean, scale, rew = L.get_scaling()
+        assert np.array_equal(np.concatenate([mean, scale, rew]), fx[r]["scaling0"])
+        assert np.array_equal(L.get_rng_state(), fx[r]["rng0"])
+        lens = {e: synth_episode(fixture_synth(fx[r]), e)["rewards"].size for e in range(r, int(fx[r]["cfg"][3]), 2)}
+        ret = fixture_arrays_by_tag(fx[r], "ret0_tags", "ret0", lens)
+        got = episode_arrays_by_tag(L, capi.EP_RETURN)
+        for tag, arr in ret.items():
+            assert np.allclose(got[tag], arr, rtol=1e-6, atol=1e-6), (r, tag)
+        L.set_tap(True)
+    assert np.array_equal(fx[0]["scaling0"], fx[1]["scaling0"])      # the start-up statistics are global
+    nSteps = int(fx[0]["cfg"][4])
+    for k in range(1, nSteps + 1):
+        sk = "s%d_" % k
+        for r, L in enumerate(Ls):
+            if sk + "rng" in fx[r]:
+                assert np.array_equal(L.get_rng_state(), fx[r][sk + "rng"]), (k, r)
+        gs, g, ms, c = one_step(Ls)
+        assert (ms[0] is not None) == (k % 1000 == 0)
+        for r, L in enumerate(Ls):
+            if sk + "flat" in fx[r]:
+                assert np.array_equal(L.readback(capi.TAP_FLAT), fx[r][sk + "flat"]), (k, r)
+                assert np.array_equal(L.readback(capi.TAP_TAG), fx[r][sk + "tag"])
+                assert np.array_equal(L.readback(capi.TAP_TSTEP), fx[r][sk + "t"])
+                assert relinf(L.readback(capi.TAP_OUTPUT), fx[r][sk + "O"]) < tol
+                assert relinf(L.readback(capi.TAP_RHO), fx[r][sk + "rho"]) < tol
+                assert relinf(L.readback(capi.TAP_DKL), fx[r][sk + "dkl"]) < tol
+                assert relinf(L.readback(capi.TAP_OUTGRAD), fx[r][sk + "G"]) < tol
+                assert np.array_equal(L.readback(capi.TAP_FAR), fx[r][sk + "far"])
+            if sk + "gradSum" in fx[r]:      # (tapped in front of the reduction: the rank's own sum)
+                assert relinf(gs[r], fx[r][sk + "gradSum"]) < 1e-5, (k, r)
+        finish_step(Ls, g, ms, c)
+        for r, L in enumerate(Ls):
+            sca = L.scalars()
+            assert abs(sca.beta - fx[r]["traj_beta"][k - 1]) <= 1e-14 * abs(sca.beta), (k, r)
+            assert sca.nFarPolicySteps == fx[r]["traj_nfar"][k - 1], (k, r)
+            if sk + "W" in fx[r]:
+                w, m1, m2 = L.get_params()
+                assert fx_vec_dev(fx[r], sk + "W", w) < tol and fx_vec_dev(fx[r], sk + "M1", m1) < 1e-5 and fx_vec_dev(fx[r], sk + "M2", m2) < 1e-5
+            if sk + "scaling" in fx[r]:      # (the 1000th step's moments: sums over both learners)
+                mean, scale, rew = L.get_scaling()
+                assert np.allclose(np.concatenate([mean, scale, rew]), fx[r][sk + "scaling"], rtol=1e-6, atol=1e-7), (k, r)
+        assert fx[0]["traj_beta"][k - 1] == fx[1]["traj_beta"][k - 1]      # one coefficient: global counters
+    assert np.array_equal(Ls[0].get_params()[0], Ls[1].get_params()[0])     # replicas stay identical
+    for r, L in enumerate(Ls):
+        assert fx_vec_dev(fx[r], "Wfinal", L.get_params()[0]) < tol
+
+
+def _hip_replicas(hip_api, fx):
+    """HIP replicas of the recording run's two ranks (the library keeps its own stable episode order: the minibatches are fed as the
+    (episode, t) pairs the reference drew)."""
+    from test_hip_parity import hip_learner
+    Ls = []
+    for r in range(2):
+        L = hip_learner(hip_api, fixture_config(fx[r], n_ranks=2, rank=r))
+        L.init_weights()
+        for e in range(r, int(fx[r]["cfg"][3]), 2):
+            L.append_episode(**synth_episode(fixture_synth(fx[r]), e))
+        Ls.append(L)
+    return Ls
+
+
+def _fed(L, fxr, k):
+    sk = "s%d_" % k
+    flat = flat_for(L, fxr[sk + "tag"], fxr[sk + "t"])
+    order = np.argsort(flat, kind="stable")
+    return flat[order], order
+
+
+def _check_taps(L, fxr, k, order, tol):
+    sk = "s%d_" % k
+    assert np.array_equal(L.readback(capi.TAP_TAG), fxr[sk + "tag"][order]) and np.array_equal(L.readback(capi.TAP_TSTEP), fxr[sk + "t"][order])
+    assert relinf(L.readback(capi.TAP_OUTPUT), fxr[sk + "O"][order]) < tol and relinf(L.readback(capi.TAP_RHO), fxr[sk + "rho"][order]) < tol
+    assert relinf(L.readback(capi.TAP_DKL), fxr[sk + "dkl"][order]) < tol and relinf(L.readback(capi.TAP_OUTGRAD), fxr[sk + "G"][order]) < tol
+    assert np.array_equal(L.readback(capi.TAP_FAR), fxr[sk + "far"][order])
+
+
+def _check_state(L, fxr, k, tol):
+    sk = "s%d_" % k
+    if sk + "W" in fxr:
+        w, m1, m2 = L.get_params()
+        assert relinf(w, fxr[sk + "W"]) < tol and relinf(m1, fxr[sk + "M1"]) < tol and relinf(m2, fxr[sk + "M2"]) < 2 * tol, k
+    sca = L.scalars()
+    assert abs(sca.beta - fxr["traj_beta"][k - 1]) <= 1e-6 * abs(sca.beta), k
+
+
+@pytest.mark.gpu
+def test_hip_replicas_follow_the_two_rank_reference(hip_api):
+    """Host-exchange mode (hl_initialize_begin / sums / hl_initialize_end, hl_step_begin / sums / hl_step_end)."""
+    fx = [load_fixture("two_rank.bin.r%d" % r) for r in range(2)]
+    Ls = _hip_replicas(hip_api, fx)
+    w0 = Ls[0].get_params()[0]
+    assert np.array_equal(w0, fx[0]["W0"])
+    for L in Ls:
+        w, m1, m2 = L.get_params(); L.set_params(w0, m1, m2); L.initialize_begin()
+    c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+    m = np.sum([L.moments_fetch() for L in Ls], axis=0)
+    for r, L in enumerate(Ls):
+        L.counters_store(c); L.moments_store(m); L.initialize_end()
+        mean, scale, rew = L.get_scaling()
+        assert np.allclose(np.concatenate([mean, scale, rew]), fx[r]["scaling0"], rtol=1e-6, atol=1e-7)
+        assert L.scalars().beta == fx[r]["beta0"][0]
+        L.set_tap(True)
+    for k in range(1, int(fx[0]["cfg"][4]) + 1):
+        orders = []
+        for r, L in enumerate(Ls):
+            flat, order = _fed(L, fx[r], k); orders.append(order)
+            L.step_begin(flat)
+        gs = [L.grad_fetch() for L in Ls]
+        g = np.sum(gs, axis=0, dtype=np.float32)
+        c = np.sum([L.counters_fetch() for L in Ls], axis=0)
+        for r, L in enumerate(Ls):
+            _check_taps(L, fx[r], k, orders[r], 1e-5)
+            if "s%d_gradSum" % k in fx[r]:      # (tapped in front of the reduction: the rank's own sum)
+                assert relinf(gs[r], fx[r]["s%d_gradSum" % k]) < 1e-5
+            L.grad_store(g); L.counters_store(c); L.step_end()
+            _check_state(L, fx[r], k, 1e-5)
+    assert np.array_equal(Ls[0].get_params()[0], Ls[1].get_params()[0])
+    assert relinf(Ls[0].get_params()[0], fx[0]["Wfinal"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_replicas_exchanging_on_the_device_follow_the_two_rank_reference(hip_api):
+    """The product path: two replicas connected through hl_xchg_connect before hl_initialize (rank 0's weights, the start-up counters
+    and moments and every step's gradient-and-counters message go through each other's windows, xchg.hip), stepped with hl_step."""
+    from test_hip_parity import _both
+    fx = [load_fixture("two_rank.bin.r%d" % r) for r in range(2)]
+    Ls = _hip_replicas(hip_api, fx)
+    handles = [L.xchg_export() for L in Ls]
+    _both(Ls, lambda L: (L.xchg_connect(handles), L.initialize()))
+    for r, L in enumerate(Ls):
+        assert np.array_equal(L.get_params()[0], fx[0]["W0"])
+        mean, scale, rew = L.get_scaling()
+        assert np.allclose(np.concatenate([mean, scale, rew]), fx[r]["scaling0"], rtol=1e-6, atol=1e-7)
+        assert L.scalars().beta == fx[r]["beta0"][0]
+        L.set_tap(True)
+    for k in range(1, int(fx[0]["cfg"][4]) + 1):
+        fed = {id(L): _fed(L, fx[r], k) for r, L in enumerate(Ls)}
+        _both(Ls, lambda L: (L.step(1, flat=fed[id(L)][0]), L.sync()))
+        for r, L in enumerate(Ls):
+            _check_taps(L, fx[r], k, fed[id(L)][1], 1e-5)
+            _check_state(L, fx[r], k, 1e-5)
+    assert np.array_equal(Ls[0].get_params()[0], Ls[1].get_params()[0])
+    assert relinf(Ls[0].get_params()[0], fx[0]["Wfinal"]) < 1e-5
