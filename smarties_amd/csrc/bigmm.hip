@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const 
   // columns 4 (l & 15) .. + 3 of the rows (l >> 4) + 4 q.  Their per-column operands:
   float* sOut = sW + KPAD * BP_PITCH + wave * BP_OUT;
   const int ec = 4 * (lane & 15);
+  // what later launches read of a hidden layer: f'(x) takes the pre-activation OR the output (actDiff), the layers above and the weight
+  // gradients the block output (C3 behind a parametric residual, else the output)
+  const bool keepX = !actDiffFromOutput(P.func), keepY = !keepX || P.C3 == nullptr;
+  const float* actSrc = keepX ? P.actX : P.actY;
   float eb[4], ew[4], er[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -148,16 +152,17 @@ __global__ __launch_bounds__(256, 2) void big_panel_kernel(GemmProblem P, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] = v[e] + eb[e]; y[e] = actEval(P.func, x[e]); r[e] = n + e < P.resN ? y[e] + (rin[e] * ew[e] + er[e]) : y[e]; }
         if (whole) {
-          *reinterpret_cast<f32x4*>(P.C + o) = x; *reinterpret_cast<f32x4*>(P.C2 + o) = y;
+          if (keepX) *reinterpret_cast<f32x4*>(P.C + o) = x;
+          if (keepY) *reinterpret_cast<f32x4*>(P.C2 + o) = y;
           if (P.C3) *reinterpret_cast<f32x4*>(P.C3 + o) = r;
-        } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = x[e]; P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
+        } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { if (keepX) P.C[o + e] = x[e]; if (keepY) P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
       } else {
-        f32x4 rin = z4, ax = z4, ay = z4;
+        f32x4 rin = z4, ax = z4;
         if (n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
-        if (n + 3 < P.ldAct) { ax = *reinterpret_cast<const f32x4*>(P.actX + (size_t)m * P.ldAct + n); ay = *reinterpret_cast<const f32x4*>(P.actY + (size_t)m * P.ldAct + n); }
+        if (n + 3 < P.ldAct) ax = *reinterpret_cast<const f32x4*>(actSrc + (size_t)m * P.ldAct + n);
         f32x4 dres, d;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ay[e]); }
+        for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ax[e]); }
         if (whole) { *reinterpret_cast<f32x4*>(P.C + o) = dres; *reinterpret_cast<f32x4*>(P.C2 + o) = d; }
         else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = dres[e]; P.C2[o + e] = d[e]; }
       }
@@ -206,9 +211,12 @@ hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int pari
 // different banks with the four k groups); W slices [32 k][64 n] at pitch 80 (forward) or [64 n][32 k] at pitch 36 (dX: W rows are
 // the outputs there).  The epilogue goes through LDS as in the panel kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int MM_PA = 36, MM_PB = 80, MM_KS = 32;
-template <bool TRANSW>
-__global__ __launch_bounds__(256, 4) void big_mm_kernel(GemmProblem P, const DevScalars* __restrict__ sc, int parity, int nRowTiles) {
+constexpr int MM_PB = 80;
+// MM_KS: depth of a k-slice.  32: 39 KB of LDS, four workgroups per CU (grids of many tiles: their phases overlap); 64: half as many
+// load -> barrier round trips per tile, 76 KB, two per CU -- for grids of at most two tiles per CU, where a tile's own chain is the launch
+template <bool TRANSW, int MM_KS>
+__global__ __launch_bounds__(256, MM_KS == 32 ? 4 : 2) void big_mm_kernel(GemmProblem P, const DevScalars* __restrict__ sc, int parity, int nRowTiles) {
+  constexpr int MM_PA = MM_KS + 4, PPR = MM_KS / 4, RPP = 256 / PPR, Q = PPR / 4;      // row pitch of a slice; 16-byte pieces per row, rows per pass, passes
   __shared__ __attribute__((aligned(16))) float sA[2][64 * MM_PA];
   __shared__ __attribute__((aligned(16))) float sB[2][TRANSW ? 64 * MM_PA : MM_KS * MM_PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
@@ -221,16 +229,16 @@ __global__ __launch_bounds__(256, 4) void big_mm_kernel(GemmProblem P, const Dev
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   const int K = P.K;
-  f32x4 va[2], vb[2];
+  f32x4 va[Q], vb[Q];
   auto loadSlice = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      { const int r = (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;      // A: 64 rows x 8 pieces of four k (zeros behind K: the row pitch covers the padded K)
+    for (int q = 0; q < Q; ++q) {
+      { const int r = tid / PPR + RPP * q, k = k0 + (tid % PPR) * 4;      // A: 64 rows x 8 pieces of four k (zeros behind K: the row pitch covers the padded K)
         va[q] = (m0 + r < nRows && k < P.lda) ? *reinterpret_cast<const f32x4*>(P.A + (size_t)(m0 + r) * P.lda + k) : z4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (k + e >= K) va[q][e] = 0.f; }
       if constexpr (TRANSW) {      // W rows n0 .. n0 + 63, columns k
-        const int n = (tid >> 3) + 32 * q, k = k0 + (tid & 7) * 4;
+        const int n = tid / PPR + RPP * q, k = k0 + (tid % PPR) * 4;
         vb[q] = (n0 + n < P.N && k < P.ldb) ? *reinterpret_cast<const f32x4*>(P.B + (size_t)(n0 + n) * P.ldb + k) : z4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (k + e >= K) vb[q][e] = 0.f;
@@ -244,9 +252,9 @@ __global__ __launch_bounds__(256, 4) void big_mm_kernel(GemmProblem P, const Dev
   };
   auto storeSlice = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<f32x4*>(&sA[buf][((tid >> 3) + 32 * q) * MM_PA + (tid & 7) * 4]) = va[q];
-      if constexpr (TRANSW) *reinterpret_cast<f32x4*>(&sB[buf][((tid >> 3) + 32 * q) * MM_PA + (tid & 7) * 4]) = vb[q];
+    for (int q = 0; q < Q; ++q) {
+      *reinterpret_cast<f32x4*>(&sA[buf][(tid / PPR + RPP * q) * MM_PA + (tid % PPR) * 4]) = va[q];
+      if constexpr (TRANSW) *reinterpret_cast<f32x4*>(&sB[buf][(tid / PPR + RPP * q) * MM_PA + (tid % PPR) * 4]) = vb[q];
       else *reinterpret_cast<f32x4*>(&sB[buf][((tid >> 4) + 16 * q) * MM_PB + (tid & 15) * 4]) = vb[q];
     }
   };
@@ -286,6 +294,10 @@ __global__ __launch_bounds__(256, 4) void big_mm_kernel(GemmProblem P, const Dev
       }
   __syncthreads();
   const int ec = 4 * (tid & 15);
+  // what later launches read of a hidden layer: f'(x) takes the pre-activation OR the output (actDiff), the layers above and the weight
+  // gradients the block output (C3 behind a parametric residual, else the output)
+  const bool keepX = !actDiffFromOutput(P.func), keepY = !keepX || P.C3 == nullptr;
+  const float* actSrc = keepX ? P.actX : P.actY;
   float eb[4], ew[4], er[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -308,16 +320,17 @@ __global__ __launch_bounds__(256, 4) void big_mm_kernel(GemmProblem P, const Dev
 #pragma unroll
       for (int e = 0; e < 4; ++e) { x[e] = v[e] + eb[e]; y[e] = actEval(P.func, x[e]); r[e] = n + e < P.resN ? y[e] + (rin[e] * ew[e] + er[e]) : y[e]; }
       if (whole) {
-        *reinterpret_cast<f32x4*>(P.C + o) = x; *reinterpret_cast<f32x4*>(P.C2 + o) = y;
+        if (keepX) *reinterpret_cast<f32x4*>(P.C + o) = x;
+        if (keepY) *reinterpret_cast<f32x4*>(P.C2 + o) = y;
         if (P.C3) *reinterpret_cast<f32x4*>(P.C3 + o) = r;
-      } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = x[e]; P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
+      } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { if (keepX) P.C[o + e] = x[e]; if (keepY) P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
     } else {
-      f32x4 rin = z4, ax = z4, ay = z4;
+      f32x4 rin = z4, ax = z4;
       if (n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
-      if (n + 3 < P.ldAct) { ax = *reinterpret_cast<const f32x4*>(P.actX + (size_t)m * P.ldAct + n); ay = *reinterpret_cast<const f32x4*>(P.actY + (size_t)m * P.ldAct + n); }
+      if (n + 3 < P.ldAct) ax = *reinterpret_cast<const f32x4*>(actSrc + (size_t)m * P.ldAct + n);
       f32x4 dres, d;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ay[e]); }
+      for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ax[e]); }
       if (whole) { *reinterpret_cast<f32x4*>(P.C + o) = dres; *reinterpret_cast<f32x4*>(P.C2 + o) = d; }
       else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = dres[e]; P.C2[o + e] = d[e]; }
     }
@@ -329,21 +342,23 @@ bool big_mm_ok(const GemmProblem& P) {
   return (P.flavor == GEMM_F || P.flavor == GEMM_X) && al;
 }
 hipError_t launch_big_mm(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s) {
-  const int colTiles = (P.N + 63) / 64, rowTiles = (P.M + 63) / 64;
+  const int rowTiles = (P.M + 63) / 64, colTiles = (P.N + 63) / 64;
   const dim3 grid(8 * ((rowTiles + 7) / 8) * colTiles);
-  if (P.flavor == GEMM_X) hipLaunchKernelGGL((big_mm_kernel<true>), grid, dim3(256), 0, s, P, sc, parity, rowTiles);
-  else hipLaunchKernelGGL((big_mm_kernel<false>), grid, dim3(256), 0, s, P, sc, parity, rowTiles);
+  // (measured at 256 and 512 tiles, K = 256: dX 18.6 -> 17.6 us with the deep slices, forward 17.7 -> 19.2 -- its three output arrays
+  //  per tile are what it waits for, not its slices)
+  const bool deep = P.flavor == GEMM_X && rowTiles * colTiles <= 512 && P.K >= 128;
+  if (P.flavor == GEMM_X) { if (deep) hipLaunchKernelGGL((big_mm_kernel<true, 64>), grid, dim3(256), 0, s, P, sc, parity, rowTiles); else hipLaunchKernelGGL((big_mm_kernel<true, 32>), grid, dim3(256), 0, s, P, sc, parity, rowTiles); }
+  else hipLaunchKernelGGL((big_mm_kernel<false, 32>), grid, dim3(256), 0, s, P, sc, parity, rowTiles);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int BD_PITCH = 80, BD_ROWS = 32;
 
-__global__ __launch_bounds__(256, 2) void big_dw_kernel(GemmProblem P) {
-  __shared__ __attribute__((aligned(16))) float sA[2][BD_ROWS * BD_PITCH], sD[2][BD_ROWS * BD_PITCH];
+__device__ __forceinline__ void bigDwBody(const GemmProblem& P, int blk, float (*sA)[BD_ROWS * BD_PITCH], float (*sD)[BD_ROWS * BD_PITCH]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
-  const int tilesN = (P.N + 63) / 64;
-  const int m0 = ((int)blockIdx.x / tilesN) * 64, n0 = ((int)blockIdx.x % tilesN) * 64, ks = blockIdx.y;
+  const int tilesN = (P.N + 63) / 64, tiles = ((P.M + 63) / 64) * tilesN, tile = blk % tiles, ks = blk / tiles;
+  const int m0 = (tile / tilesN) * 64, n0 = (tile % tilesN) * 64;
   const int rBeg = ks * P.bigChunk, rEnd = min(P.K, rBeg + P.bigChunk);
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -406,18 +421,76 @@ __global__ __launch_bounds__(256, 2) void big_dw_kernel(GemmProblem P) {
       }
     }
 }
-// rows per chunk: about 640 workgroups per problem (tiles x chunks), whole 32-row slices, 64 rows at least
-int big_dw_chunk_rows(int M, int N, int rows) {
-  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  const int chunks = std::max(1, 640 / tiles);
-  int per = (rows + chunks - 1) / chunks;
+// column sums over the rows (RED_COL: C[c] = sum_rows A[row][c] (x B[row][c]): gradients of the parametric residual's weight and
+// bias, of the policy's sigma parameters): a workgroup = 64 columns x one chunk of rows, 16 rows in flight per pass (256-byte row
+// pieces), the 16 row lanes joined in LDS in order; partial sums to part[chunk][N] as for the products
+__device__ __forceinline__ void bigRedBody(const GemmProblem& P, int blk, float* sm) {
+  const int tilesN = (P.N + 63) / 64, n0 = (blk % tilesN) * 64, ks = blk / tilesN;
+  const int rBeg = ks * P.bigChunk, rEnd = min(P.K, rBeg + P.bigChunk);
+  const int tid = threadIdx.x, rl = tid >> 4, c = n0 + (tid & 15) * 4;
+  const bool vec = (P.lda & 3) == 0 && (P.B == nullptr || (P.ldb & 3) == 0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;
+  if (vec) {
+    const bool in = c < P.lda && (P.B == nullptr || c < P.ldb);
+    for (int r0 = rBeg + rl; r0 < rEnd; r0 += 16 * U) {
+      f32x4 va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + 16 * u;
+        va[u] = f32x4{0.f, 0.f, 0.f, 0.f}; vb[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (in && r < rEnd) {
+          va[u] = *reinterpret_cast<const f32x4*>(P.A + (size_t)r * P.lda + c);
+          if (P.B) vb[u] = *reinterpret_cast<const f32x4*>(P.B + (size_t)r * P.ldb + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += va[u] * vb[u];
+    }
+  } else {
+    for (int r = rBeg + rl; r < rEnd; r += 16)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (c + e < P.N) acc[e] += P.A[(size_t)r * P.lda + c + e] * (P.B ? P.B[(size_t)r * P.ldb + c + e] : 1.f);
+  }
+  *reinterpret_cast<f32x4*>(sm + rl * 64 + (tid & 15) * 4) = acc;
+  __syncthreads();
+  if (tid < 64 && n0 + tid < P.N) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q * 64 + tid];
+    P.part[(size_t)ks * P.N + n0 + tid] = t;
+  }
+}
+// every weight gradient of a large-batch step in ONE launch: workgroup -> (problem of the list, tile or column block, row chunk)
+__global__ __launch_bounds__(256, 2) void big_dw_kernel(const GemmProblem* __restrict__ probs, BigDwList L) {
+  __shared__ __attribute__((aligned(16))) float sA[2][BD_ROWS * BD_PITCH], sD[2][BD_ROWS * BD_PITCH];
+  int k = 0, blk = (int)blockIdx.x;
+#pragma unroll
+  for (int q = 1; q < BIG_DW_MAX; ++q) if (q < L.n && blk >= L.start[q]) k = q;
+  blk -= L.start[k];
+  const GemmProblem& P = probs[L.idx[k]];
+  if (P.flavor == RED_COL) bigRedBody(P, blk, &sA[0][0]); else bigDwBody(P, blk, sA, sD);
+}
+// rows per chunk: about 640 workgroups per product (tiles x chunks), 512 per column-sum problem; whole 32-row slices, 64 rows at least
+int big_dw_chunk_rows(const GemmProblem& P) {
+  const bool red = P.flavor == RED_COL;
+  const int tiles = red ? (P.N + 63) / 64 : ((P.M + 63) / 64) * ((P.N + 63) / 64);
+  const int chunks = std::max(2, (red ? 512 : 640) / tiles);
+  int per = (P.K + chunks - 1) / chunks;
   per = std::max(64, (per + BD_ROWS - 1) / BD_ROWS * BD_ROWS);
   return per;
 }
-bool big_dw_ok(const GemmProblem& P) { return P.flavor == GEMM_W && P.N >= 32 && (P.lda & 3) == 0 && (P.ldb & 3) == 0; }
-hipError_t launch_big_dw(const GemmProblem& P, hipStream_t s) {
-  const int tiles = ((P.M + 63) / 64) * ((P.N + 63) / 64);
-  hipLaunchKernelGGL(big_dw_kernel, dim3(tiles, P.nSplit), dim3(256), 0, s, P);
+int big_dw_blocks(const GemmProblem& P) {
+  const int tiles = P.flavor == RED_COL ? (P.N + 63) / 64 : ((P.M + 63) / 64) * ((P.N + 63) / 64);
+  return tiles * P.nSplit;
+}
+bool big_dw_ok(const GemmProblem& P) {
+  if (P.flavor == RED_COL) return true;      // (any pitch: rows that are not 16-byte aligned take scalar loads)
+  return P.flavor == GEMM_W && (P.lda & 3) == 0 && (P.ldb & 3) == 0;
+}
+hipError_t launch_big_dw(const GemmProblem* dProbs, const BigDwList& L, hipStream_t s) {
+  if (L.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(big_dw_kernel, dim3(L.start[L.n]), dim3(256), 0, s, dProbs, L);
   return hipGetLastError();
 }
 

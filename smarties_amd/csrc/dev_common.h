@@ -37,6 +37,8 @@ __device__ __forceinline__ float actEval(int f, float in) {   // Network/Layers/
     default: return in;
   }
 }
+// which of its two arguments actDiff reads: the layer's output for these, its pre-activation for the others (never both)
+__host__ __device__ __forceinline__ bool actDiffFromOutput(int f) { return f == HL_FUNC_TANH || f == HL_FUNC_SIGM || f == HL_FUNC_EXP; }
 __device__ __forceinline__ float actDiff(int f, float in, float out) {
   switch (f) {
     case HL_FUNC_TANH: return 1 - out * out;

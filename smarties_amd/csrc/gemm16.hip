@@ -327,7 +327,7 @@ hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc
 
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2) {
-  if (nBlocks <= 0) return hipSuccess;
+  if (nBlocks <= 0 && !(extra && extra->role) && !(extra2 && extra2->role)) return hipSuccess;      // (riders keep the launch alive)
   ExtraArgs ex{}, ex2{}; if (extra) ex = *extra; if (extra2) ex2 = *extra2;
   if (!ex.role && ex2.role) { ex = ex2; ex2 = ExtraArgs{}; }
   if (ex.role != 1 && ex2.role == 1) { const ExtraArgs t = ex; ex = ex2; ex2 = t; }      // (a sampler rider with helpers goes first)

@@ -1,7 +1,7 @@
 // smarties_amd/csrc/headp.hip -- output layer + RACER / V-RACER head + back-propagation into the last hidden block for a PANEL of
 // 16 samples per workgroup (head.hip does the same with one sample per wavefront or per workgroup: the latency form of small
 // minibatches).  The pieces are fusedw.hip's second half on their own: the panel of the last hidden block's outputs and its W_out
-// in LDS, the output layer as MFMA contractions with K split over the eight wavefronts (head_rows.h: panelOutMma), the fp64 head with
+// in LDS, the output layer as MFMA contractions with K split over the four wavefronts (head_rows.h: panelOutMma), the fp64 head with
 // one (sample, action component or option) per lane of a 16-lane row (HeadRow), delta_y = delta_out W_out^T for the whole panel by
 // MFMA.  Reference functions: as head.hip (Layer_Base.h:64-113, RACER_train.cpp:14-67, Math/*).
 // Used where throughput counts -- local batches of 2048 and more (step_exec.h: launchHead) -- for hidden widths that are a multiple
@@ -16,16 +16,18 @@ namespace hl {
 #else
 #define HPSTAMP(i) do { } while (0)
 #endif
-constexpr int HP_NT = 512, HP_MAXNT = 5;
+// Two builds: eight wavefronts per workgroup (the shortest chain per panel: up to one panel per CU, 256 panels) and four (the fp64
+// head needs 135 registers, which eight wavefronts have only once per CU, four have three times: 49.0 -> 36.8 us at 2048 panels)
+constexpr int HP_MAXNT = 5;
 struct HpGeo { int LDR, NTo, LD, LO; size_t oF, oWo, oRed, oO, oXo, oDelta, oMisc, oAct, oTq, total; };
-__host__ __device__ inline HpGeo hpGeo(int H, int nDense, int nOut, int ldWo, int nAdv) {
+__host__ __device__ inline HpGeo hpGeo(int H, int nDense, int nOut, int ldWo, int nAdv, int nWaves) {
   HpGeo g;
   g.LDR = H + 2;                                     // (== 2 mod 32: the 16 rows of a tile fall into different banks)
   g.NTo = (nDense + 15) / 16; g.LD = g.NTo * 16 + 6; g.LO = nOut | 1;
   size_t o = (size_t)16 * g.LDR * 4;                 // sY: the panel's outputs of the last hidden block
   g.oF = o; o += (size_t)16 * g.LDR * 4;             // f'(x) of that block
   g.oWo = o; o += (size_t)H * ldWo * 4;
-  g.oRed = o; o += (size_t)8 * g.NTo * 256 * 4;
+  g.oRed = o; o += (size_t)nWaves * g.NTo * 256 * 4;
   g.oO = (o + 7) & ~(size_t)7; o = g.oO + (size_t)16 * g.LO * 8;
   g.oXo = o; o += (size_t)16 * g.LD * 4;
   g.oDelta = o; o += (size_t)16 * g.LD * 4;
@@ -36,8 +38,8 @@ __host__ __device__ inline HpGeo hpGeo(int H, int nDense, int nOut, int ldWo, in
   return g;
 }
 
-template <int H, int NCH>
-__global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsigned long long boundedMask, ExtraArgs extra) {
+template <int H, int NCH, int HP_NT>
+__global__ __launch_bounds__(HP_NT, HP_NT == 512 ? 2 : 3) void panel_head_kernel(HeadArgs ha, unsigned long long boundedMask, ExtraArgs extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // riders as in head.hip: workgroup 0 (dispatched first) runs sampler phases of the next step, workgroups 1..helpers gather for it
   const int nExtra = extra.role ? 1 + extra.helpers : 0;
@@ -47,11 +49,11 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
     return;
   }
   constexpr int NT = HP_NT, NW = NT / 64, HT = H / 16, H4 = H / 4;
-  constexpr int KW = H / NW, NK = KW / 4;                 // K split of the output layer over the 8 waves (H a multiple of 32)
+  constexpr int KW = H / NW, NK = KW / 4;                 // K split of the output layer over the waves (H a multiple of 32)
   constexpr int QP = (16 * H4 + NT - 1) / NT;             // float4 per thread of a 16 x H panel
   const DevScalars* sc = ha.sc;
   const int B = ha.B, nDense = ha.nDense, nOut = ha.nOut, ldWo = ha.ldWo, nSig = ha.nSig;
-  const HpGeo g = hpGeo(H, nDense, nOut, ldWo, ha.nAdv);
+  const HpGeo g = hpGeo(H, nDense, nOut, ldWo, ha.nAdv, NW);
   const int LDR = g.LDR, NTo = g.NTo, LD = g.LD, LO = g.LO;
   const int m0 = ((int)blockIdx.x - nExtra) * 16;
   int nRows = B;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   float* sY = reinterpret_cast<float*>(smem);
   float* sF = reinterpret_cast<float*>(smem + g.oF);
   float* sWo = reinterpret_cast<float*>(smem + g.oWo);               // [H][ldWo]
-  float* red = reinterpret_cast<float*>(smem + g.oRed);              // [8][NTo][256]
+  float* red = reinterpret_cast<float*>(smem + g.oRed);              // [NW][NTo][256]
   double* sO = reinterpret_cast<double*>(smem + g.oO);
   float* sXo = reinterpret_cast<float*>(smem + g.oXo);
   float* sDelta = reinterpret_cast<float*>(smem + g.oDelta);
@@ -82,26 +84,28 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   if (rowValid) { bSrc = isNext ? ha.bt.nextSrc[row - B] : row; slot = ha.bt.slot[bSrc]; }
   HeadRow<NCH> hr;
   hr.load(ha, rowValid, isNext, slot, en);
-  f32x4 yv[QP], xv[QP], lv[QP];
+  // (f'(x) of the last hidden block takes the pre-activation OR the output, never both -- actDiff: one array is read)
+  const int func = __builtin_amdgcn_readfirstlane(ha.func);
+  const float* Fsrc = actDiffFromOutput(func) ? ha.Ylast : ha.Xlast;
+  f32x4 yv[QP], xv[QP];
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
-    const int f = tid + NT * q; yv[q] = z4; xv[q] = z4; lv[q] = z4;
+    const int f = tid + NT * q; yv[q] = z4; xv[q] = z4;
     if (f < 16 * H4) {
       const int r = f / H4, c4 = f % H4;
       if (m0 + r < nRows) yv[q] = *reinterpret_cast<const f32x4*>(ha.Yin + (size_t)(m0 + r) * ha.ldY + 4 * c4);
-      if (m0 + r < B) { xv[q] = *reinterpret_cast<const f32x4*>(ha.Xlast + (size_t)(m0 + r) * ha.ldD + 4 * c4);
-                        lv[q] = *reinterpret_cast<const f32x4*>(ha.Ylast + (size_t)(m0 + r) * ha.ldD + 4 * c4); }
+      if (m0 + r < B) xv[q] = *reinterpret_cast<const f32x4*>(Fsrc + (size_t)(m0 + r) * ha.ldD + 4 * c4);
     }
   }
   {      // W_out, rows [hidden unit][ldWo] as in the parameter blob: flat copy
     const f32x4* src = reinterpret_cast<const f32x4*>(W + ha.indWo); f32x4* dst = reinterpret_cast<f32x4*>(sWo);
     const int total4 = (H * ldWo) >> 2;
-    for (int f0 = 0; f0 < total4; f0 += NT * 4) {
-      f32x4 v[4];
+    for (int f0 = 0; f0 < total4; f0 += NT * 2) {      // (H x ldWo / 4 = 512 sixteen-byte pieces at 256 x 8: one per thread)
+      f32x4 v[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int f = f0 + tid + NT * u; v[u] = f < total4 ? src[f] : z4; }
+      for (int u = 0; u < 2; ++u) { const int f = f0 + tid + NT * u; v[u] = f < total4 ? src[f] : z4; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int f = f0 + tid + NT * u; if (f < total4) dst[f] = v[u]; }
+      for (int u = 0; u < 2; ++u) { const int f = f0 + tid + NT * u; if (f < total4) dst[f] = v[u]; }
     }
   }
   float bov[HP_MAXNT];
@@ -111,7 +115,6 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
 #pragma unroll
   for (int j = 0; j < NCH; ++j) { const int c = en + 16 * j; bpv[j] = (eth && c < nSig) ? W[ha.indBp + c] : 0.f; }
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
-  const int func = __builtin_amdgcn_readfirstlane(ha.func);
   HPSTAMP(1);
   // ---- stage the panel and f'(x) of the last hidden block ------------------------------------------------------------------------
 #pragma unroll
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
       dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
       f32x4 fp;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) fp[e] = actDiff(func, xv[q][e], lv[q][e]);
+      for (int e = 0; e < 4; ++e) fp[e] = actDiff(func, xv[q][e], xv[q][e]);
       float2* df = reinterpret_cast<float2*>(sF + r * LDR + c);
       df[0] = make_float2(fp[0], fp[1]); df[1] = make_float2(fp[2], fp[3]);
     }
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   __syncthreads();
   HPSTAMP(4);
 
-  // ---- output layer: O[16][nDense] = y W_out + b_out on MFMA, K split over the 8 waves ------------------------------------------------
+  // ---- output layer: O[16][nDense] = y W_out + b_out on MFMA, K split over the waves ------------------------------------------------
   {
     const int k0 = wave * KW + lc;
     const float* pA = sY + li * LDR + k0; const float* sWoK = sWo + (size_t)k0 * ldWo; float* redW = red + wave * NTo * 256;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
         const int e = em * 16 + en;
         float x = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; w += 2) x += red[(w * NTo + t) * 256 + e] + red[((w + 1) * NTo + t) * 256 + e];
+        for (int w = 0; w < NW; w += 2) x += red[(w * NTo + t) * 256 + e] + red[((w + 1) * NTo + t) * 256 + e];
         x += bov[t];
         sXo[em * LD + o] = x; sO[em * LO + o] = (double)(ha.outFunc == HL_FUNC_LINEAR ? x : actEval(ha.outFunc, x));
       }
@@ -200,23 +203,27 @@ __global__ __launch_bounds__(HP_NT, 2) void panel_head_kernel(HeadArgs ha, unsig
   HPSTAMP(8);
 }
 
-template <int H> static hipError_t panelHeadLaunch(const HeadArgs& a, unsigned long long mask, int maxRows, const ExtraArgs& ex, hipStream_t s) {
-  const size_t lds = std::max(hpGeo(H, a.nDense, a.nOut, a.ldWo, a.nAdv).total, ex.role ? (size_t)TAIL_LDS_BYTES : (size_t)0);      // (the riders' LDS block)
+template <int H, int NT> static hipError_t panelHeadLaunchT(const HeadArgs& a, unsigned long long mask, int maxRows, const ExtraArgs& ex, hipStream_t s) {
+  const size_t lds = std::max(hpGeo(H, a.nDense, a.nOut, a.ldWo, a.nAdv, NT / 64).total, ex.role ? (size_t)TAIL_LDS_BYTES : (size_t)0);      // (the riders' LDS block)
   const int comps = a.nOpt ? a.nOpt : a.dA, nEx = ex.role ? 1 + ex.helpers : 0;
   if (comps <= 16) {
-    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(panel_head_kernel<H, 1>), lds); if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((panel_head_kernel<H, 1>), dim3((maxRows + 15) / 16 + nEx), dim3(HP_NT), lds, s, a, mask, ex);
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(panel_head_kernel<H, 1, NT>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((panel_head_kernel<H, 1, NT>), dim3((maxRows + 15) / 16 + nEx), dim3(NT), lds, s, a, mask, ex);
   } else {
-    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(panel_head_kernel<H, 2>), lds); if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((panel_head_kernel<H, 2>), dim3((maxRows + 15) / 16 + nEx), dim3(HP_NT), lds, s, a, mask, ex);
+    hipError_t e = ensureDynLds(reinterpret_cast<const void*>(panel_head_kernel<H, 2, NT>), lds); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((panel_head_kernel<H, 2, NT>), dim3((maxRows + 15) / 16 + nEx), dim3(NT), lds, s, a, mask, ex);
   }
   return hipGetLastError();
+}
+template <int H> static hipError_t panelHeadLaunch(const HeadArgs& a, unsigned long long mask, int maxRows, const ExtraArgs& ex, hipStream_t s) {
+  // more panels than CUs: the build with three workgroups per CU
+  return (maxRows + 15) / 16 > 256 ? panelHeadLaunchT<H, 256>(a, mask, maxRows, ex, s) : panelHeadLaunchT<H, 512>(a, mask, maxRows, ex, s);
 }
 bool panel_head_ok(const HeadArgs& a) {
   const int H = a.H, comps = a.nOpt ? a.nOpt : a.dA;
   if (!(H == 32 || H == 64 || H == 128 || H == 256 || H == 512) || a.nDense > HP_MAXNT * 16 || comps > 32) return false;
   if ((a.ldY & 3) || (a.ldD & 3) || ((a.H * a.ldWo) & 3) || (a.indWo & 3)) return false;      // 16-byte panel / weight loads
-  return hpGeo(H, a.nDense, a.nOut, a.ldWo, a.nAdv).total <= 156 * 1024;      // (two workgroups per CU up to 78 KB: every shape but 512-wide layers)
+  return hpGeo(H, a.nDense, a.nOut, a.ldWo, a.nAdv, 8).total <= 156 * 1024;      // (two workgroups per CU up to 78 KB: every shape but 512-wide layers)
 }
 hipError_t launch_panel_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s) {
   ExtraArgs ex{}; if (extra) ex = *extra;

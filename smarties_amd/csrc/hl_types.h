@@ -171,6 +171,10 @@ struct GemmProblem {
   int bigChunk;          // large batches (bigmm.hip: big_dw_kernel): rows per chunk; 0: the problem is served by the common launch
 };
 
+// the problems of the large-batch weight-gradient launch (bigmm.hip: big_dw_kernel): indices into the problem table, first workgroup of each
+constexpr int BIG_DW_MAX = 12;
+struct BigDwList { int n; int idx[BIG_DW_MAX]; int start[BIG_DW_MAX + 1]; };
+
 // one-kernel exchange between replicas (xchg.hip): sequence number of the next collective, arrival count of its workgroups
 struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int arrived; /* workgroups of the running collective whose peers' stamps all came (FUSE: nobody applies Adam before all have) */ };
 // replicas connected through peer windows: the weight-gradient launch stores every gradient tile into the peers' windows as well

@@ -257,8 +257,9 @@ hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int pari
 bool big_mm_ok(const GemmProblem& P);
 hipError_t launch_big_mm(const GemmProblem& P, const DevScalars* sc, int parity, hipStream_t s);
 bool big_dw_ok(const GemmProblem& P);
-int big_dw_chunk_rows(int M, int N, int rows);
-hipError_t launch_big_dw(const GemmProblem& P, hipStream_t s);
+int big_dw_chunk_rows(const GemmProblem& P);
+int big_dw_blocks(const GemmProblem& P);
+hipError_t launch_big_dw(const GemmProblem* dProbs, const BigDwList& L, hipStream_t s);      // (indices relative to dProbs)
 // output layer + head + dX of the output layer for panels of 16 samples (headp.hip): the throughput form of launch_head
 bool panel_head_ok(const HeadArgs& a);
 hipError_t launch_panel_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, hipStream_t s);

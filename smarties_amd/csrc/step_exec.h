@@ -100,6 +100,14 @@ int buildProblems(hl_learner* h) {
       sb.dxIdx.push_back((int)P.size()); sb.dxBlocks.push_back(cur); P.push_back(p);
     }
     sb.dwIdx = (int)P.size(); int cur = 0;
+    // large batches: every weight-gradient problem -- 64 x 64 tiles of the products, 64-column blocks of the column sums -- over row
+    // chunks in ONE launch (bigmm.hip: big_dw_kernel), joined by splitk_reduce; none of their tiles in the common launch
+    auto placeDw = [&](GemmProblem& p, bool maySplit) {
+      if ((h->bigMm & 2) && (int)sb.bigDw.size() < BIG_DW_MAX && big_dw_ok(p)) {
+        p.bigChunk = big_dw_chunk_rows(p); p.nSplit = (p.K + p.bigChunk - 1) / p.bigChunk;
+        p.tilesM = 0; p.tilesN = 0; p.tileStart = cur; sb.bigDw.push_back((int)P.size());
+      } else setTiles(p, cur, maySplit);
+    };
     for (int j = j0; j < nH && h->recurrent; ++j) {
       // LSTM layer: gradient of [W_in; W_rec] and of the bias as X^T delta over all (sample, step) rows; rows of steps a
       // sample does not have carry zero deltas (rec_backward_kernel)
@@ -150,19 +158,15 @@ int buildProblems(hl_learner* h) {
       if (j == 0) { p.A = sb.X0; p.lda = h->ldX0; }
       else { const DevHidden& q = h->hid[j - 1]; p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; }
       p.B = d.D; p.ldb = d.ldA; p.C = h->G + d.indW; p.ldc = d.ldW; p.biasOut = h->G + d.indB;
-      if ((h->bigMm & 2) && big_dw_ok(p)) {      // large batches: 64 x 64 tiles over row chunks (bigmm.hip), no tiles in the common launch
-        p.bigChunk = big_dw_chunk_rows(p.M, p.N, p.K); p.nSplit = (p.K + p.bigChunk - 1) / p.bigChunk;
-        p.tilesM = 0; p.tilesN = 0; p.tileStart = cur; sb.bigDw.push_back((int)P.size());
-      } else
-      setTiles(p, cur, h->bigBatch);      // (large batches: one workgroup per (tile, 256-row chunk), as for the recurrent nets' rows)
+      placeDw(p, h->bigBatch);      // (large batches off bigmm.hip: one workgroup per (tile, 256-row chunk), as for the recurrent nets' rows)
       P.push_back(p);
       if (d.hasRes) {   // ParametricResidualLayer::backward (Layers.h:363-393)
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = d.resW; r.K = B;
         r.A = d.Dres; r.lda = d.ldA; r.B = p.A; r.ldb = p.lda; r.C = h->G + d.indWr;
-        setTiles(r, cur, h->bigBatch); P.push_back(r);
+        placeDw(r, h->bigBatch); P.push_back(r);
         GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = d.resW; s.K = B;
         s.A = d.Dres; s.lda = d.ldA; s.B = nullptr; s.C = h->G + d.indBr;
-        setTiles(s, cur, h->bigBatch); P.push_back(s);
+        placeDw(s, h->bigBatch); P.push_back(s);
       }
     }
     { // output InnerProduct layer
@@ -170,12 +174,12 @@ int buildProblems(hl_learner* h) {
       GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = q.size + 1; p.N = h->nDense; p.K = B;
       p.A = q.hasRes ? q.Rr : q.Y; p.lda = q.ldA; p.B = h->dOut; p.ldb = h->ldDo;
       p.C = h->G + h->indWo; p.ldc = h->ldWo; p.biasOut = h->G + h->indBo;
-      setTiles(p, cur, h->bigBatch); P.push_back(p);
+      placeDw(p, h->bigBatch); P.push_back(p);
       // ParamLayer::backward (Layers.h:522-546): bias gradient = column sums of the sigma-param deltas
       if (h->nSig) {      // (no sigma layer behind a discrete policy)
         GemmProblem s{}; s.flavor = RED_COL; s.epi = EPI_NONE; s.N = h->dA; s.K = B;
         s.A = sb.bt.gParam; s.lda = h->dA; s.B = nullptr; s.C = h->G + h->indBp;
-        setTiles(s, cur, h->bigBatch); P.push_back(s);
+        placeDw(s, h->bigBatch); P.push_back(s);
       }
     }
     sb.dwCount = (int)P.size() - sb.dwIdx; sb.dwBlocks = cur;
@@ -600,8 +604,11 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   if (sampleC && pexF) return fail(h, HL_ERR_STATE, "no rider slot left for the sampler's index search on the weight-gradient launch");
   if (sampleC) { exC = extraSample(h, parity ^ 1, PH_C); pexF = &exC; }
   // large batches: the dense layers' weight gradients as 64 x 64 tiles over row chunks (bigmm.hip); joined by splitk_reduce below
-  for (int idx : sb.bigDw)
-    HIPCK(timed(h, "big_dw", s, [&] { return launch_big_dw(h->hostProbs[(fuseAdam ? sb.dwAdamIdx : sb.dwIdx) + (idx - sb.dwIdx)], s); }));
+  if (!sb.bigDw.empty()) {
+    BigDwList L{}; L.n = (int)sb.bigDw.size();
+    for (int i = 0; i < L.n; ++i) { L.idx[i] = sb.bigDw[i] - sb.dwIdx; L.start[i + 1] = L.start[i] + big_dw_blocks(h->hostProbs[sb.bigDw[i]]); }
+    HIPCK(timed(h, "big_dw", s, [&] { return launch_big_dw(h->dProbs + (fuseAdam ? sb.dwAdamIdx : sb.dwIdx), L, s); }));
+  }
   if (wideDw) {
     HIPCK(timed(h, "dw_wide", s, [&] {
       return launch_dw_wide(h->dProbs + (fuseAdam ? sb.dwWideAdamIdx : sb.dwWideIdx), sb.dwCount, sb.dwWideBlocks, DW_WIDE_Q, h->widePart, h->wideCtr, h->sc, hyp, pexW, pexF, s); }));

@@ -21,7 +21,7 @@ HOT = ("dw_table_kernel", "fused_fwd_head_dx_kernel", "fused_wide_kernel", "pane
        "gemm16_kernel", "dw_wide_kernel", "head_kernel_t", "big_", "splitk_reduce_kernel", "step_tail_kernel", "xchg_", "adam_kernel",
        "rec_step_fused", "lstm_", "mgu_", "rec_")
 # reserved-and-untouched frame slots: kernel -> bytes per lane at most (checked against the ISA below)
-DEAD_SLOT = {"fused_wide_kernel<256, 2>": 64, "step_tail_kernel": 64}
+DEAD_SLOT = {"fused_wide_kernel<256, 2>": 64, "step_tail_kernel": 64, "panel_head_kernel<256, 2, 256>": 64}
 # real spills that remain, with the reason; anything else fails
 KNOWN_SPILLS = {}
 
