@@ -136,16 +136,19 @@ def other_configs(api, steps=1000, only=None):
                                                       gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
         "cfg4_mgu_2x32_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(32, 32), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
                                            gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, steps),
-        # recurrent layers wider than the 32 cells of RACER_RNN.json (the any-width window kernels of rec.hip)
+        # recurrent layers wider than the 32 cells of RACER_RNN.json: time-step-major launches on the MFMA (rectm.hip)
         "lstm_2x128_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(128, 128), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
                                         gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, max(50, steps // 10)),
         "lstm_2x256_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(256, 256), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
                                         gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_LSTM, nnLambda=1e-6, explNoise=0.1), 300, 200, max(50, steps // 20)),
+        "mgu_2x256_b128_bptt16": (dict(dimS=4, dimA=1, bounded=[1], hidden=(256, 256), nnFunc="Tanh", batchSize=128, maxTotObsNum=262144,
+                                       gamma=0.99, adv_kind=capi.ADV_GAUSSIAN, nn_type=capi.NN_MGU, nnLambda=1e-6, explNoise=0.1), 300, 200, max(50, steps // 20)),
         # the bench network at larger batches: where the step stops being a latency chain (fraction of the fp32 MFMA peak below)
         # (replays of 500 000 transitions: the sampler redraws until the minibatch is unique (Sampling.cpp:86-93) -- at 80 000 stored
         #  transitions a batch of 1024 needs several rounds (62 us per step, the sampler riding the step's kernels their longest
         #  workgroup; 51 on this replay), at five times the batch seven)
         "cfgNS_2x256_b1024": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=1024, maxTotObsNum=1048576), 2500, 200, max(100, steps // 2)),
+        "cfgNS_2x256_b2048": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=2048, maxTotObsNum=1048576), 2500, 200, max(100, steps // 4)),      # (first batch of the large-batch launches: bigmm.hip)
         "cfgNS_2x256_b4096": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=4096, maxTotObsNum=1048576), 2500, 200, max(100, steps // 4)),
         "cfgNS_2x256_b16384": (dict(dimS=17, dimA=6, hidden=(256, 256), batchSize=16384, maxTotObsNum=1048576), 2500, 200, max(50, steps // 10)),
         # settings/RACER_glider.json (a shipped preset): RACER with the Gaussian advantage, three hidden layers of 128 -- the generic launches

@@ -212,6 +212,14 @@ hipError_t launch_big_panel(const GemmProblem& P, const DevScalars* sc, int pari
 // the outputs there).  The epilogue goes through LDS as in the panel kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MM_PB = 80;
+// development time stamps of one tile's workgroup of the K > 64 forward product (-DHL_BIGMM_STAMPS; tools/bigmm_stamps.py)
+#ifdef HL_BIGMM_STAMPS
+#define MMSTAMP(i) do { if (!TRANSW && P.K > 64 && threadIdx.x == 0 && blockIdx.x == 40) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
+#define MMEND() do { if (!TRANSW && P.K > 64) { __syncthreads(); if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&const_cast<DevScalars*>(sc)->dbgT[10]), (unsigned long long)wall_clock64()); } } while (0)
+#else
+#define MMSTAMP(i) do { } while (0)
+#define MMEND() do { } while (0)
+#endif
 // MM_KS: depth of a k-slice.  32: 39 KB of LDS, four workgroups per CU (grids of many tiles: their phases overlap); 64: half as many
 // load -> barrier round trips per tile, 76 KB, two per CU -- for grids of at most two tiles per CU, where a tile's own chain is the launch
 template <bool TRANSW, int MM_KS>
@@ -223,34 +231,93 @@ __global__ __launch_bounds__(256, MM_KS == 32 ? 4 : 2) void big_mm_kernel(GemmPr
   const int colTiles = (P.N + 63) / 64, slot = (int)blockIdx.x >> 3;
   const int rowTile = ((int)blockIdx.x & 7) + 8 * (slot / colTiles);      // (the column tiles of a row tile on one XCD: they read the same rows of A)
   if (rowTile >= nRowTiles) return;
+  MMSTAMP(0);
   const int m0 = rowTile * 64, n0 = (slot % colTiles) * 64;
   const int nRows = P.dynRows ? sc->nRows[parity] : P.M;
   if (m0 >= nRows) return;
+  MMSTAMP(1);
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   const int K = P.K;
   f32x4 va[Q], vb[Q];
+  // a slice's loads touch nothing but their destination registers -- addresses clamped into the arrays, what lies outside the operands
+  // zeroed when the slice is stored: with guards or masks at the load the compiler waited for the data in front of the slice's
+  // products (s_waitcnt vmcnt(0) right behind the requests: one exposed memory round trip per slice, 1.15 us of it stamped)
   auto loadSlice = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      { const int r = tid / PPR + RPP * q, k = k0 + (tid % PPR) * 4;      // A: 64 rows x 8 pieces of four k (zeros behind K: the row pitch covers the padded K)
-        va[q] = (m0 + r < nRows && k < P.lda) ? *reinterpret_cast<const f32x4*>(P.A + (size_t)(m0 + r) * P.lda + k) : z4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (k + e >= K) va[q][e] = 0.f; }
+      { const int r = min(m0 + tid / PPR + RPP * q, nRows - 1), k = min(k0 + (tid % PPR) * 4, P.lda - 4);
+        va[q] = *reinterpret_cast<const f32x4*>(P.A + (size_t)r * P.lda + k); }
       if constexpr (TRANSW) {      // W rows n0 .. n0 + 63, columns k
-        const int n = tid / PPR + RPP * q, k = k0 + (tid % PPR) * 4;
-        vb[q] = (n0 + n < P.N && k < P.ldb) ? *reinterpret_cast<const f32x4*>(P.B + (size_t)(n0 + n) * P.ldb + k) : z4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (k + e >= K) vb[q][e] = 0.f;
+        const int n = min(n0 + tid / PPR + RPP * q, P.N - 1), k = min(k0 + (tid % PPR) * 4, P.ldb - 4);
+        vb[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)n * P.ldb + k);
       } else {                     // W rows k, columns n0 .. n0 + 63
-        const int k = k0 + (tid >> 4) + 16 * q, c = n0 + (tid & 15) * 4;
-        vb[q] = (k < K && c < P.ldb) ? *reinterpret_cast<const f32x4*>(P.B + (size_t)k * P.ldb + c) : z4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (c + e >= P.N) vb[q][e] = 0.f;
+        const int k = min(k0 + (tid >> 4) + 16 * q, K - 1), c = min(n0 + (tid & 15) * 4, P.ldb - 4);
+        vb[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)k * P.ldb + c);
       }
     }
   };
-  auto storeSlice = [&](int buf) {
+  auto storeSlice = [&](int buf, int k0) {      // (k0: the slice the registers hold)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      { const int r = m0 + tid / PPR + RPP * q, k = k0 + (tid % PPR) * 4;
+        f32x4 v = va[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (r >= nRows || k + e >= K) v[e] = 0.f;
+        *reinterpret_cast<f32x4*>(&sA[buf][(tid / PPR + RPP * q) * MM_PA + (tid % PPR) * 4]) = v; }
+      f32x4 w = vb[q];
+      if constexpr (TRANSW) {
+        const int n = n0 + tid / PPR + RPP * q, k = k0 + (tid % PPR) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (n >= P.N || k + e >= K) w[e] = 0.f;
+        *reinterpret_cast<f32x4*>(&sB[buf][(tid / PPR + RPP * q) * MM_PA + (tid % PPR) * 4]) = w;
+      } else {
+        const int k = k0 + (tid >> 4) + 16 * q, c = n0 + (tid & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k >= K || c + e >= P.N) w[e] = 0.f;
+        *reinterpret_cast<f32x4*>(&sB[buf][((tid >> 4) + 16 * q) * MM_PB + (tid & 15) * 4]) = w;
+      }
+    }
+  };
+  f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
+  // a slice's products: the operands of k-step s + 1 are read from LDS while the four MFMAs of step s run -- a lone workgroup on its
+  // CU (one wavefront per SIMD: grids of up to 256 tiles) otherwise waits out the LDS latency in front of every step (stamped: 1.15 us
+  // per 32-deep slice against 0.45 us of MFMA issue; requesting the global loads two slices ahead instead changed nothing)
+  auto readOps = [&](int buf, int s, float& a0, float& a1, float& b0, float& b1) {
+    a0 = sA[buf][(wm + li) * MM_PA + 4 * s + lc]; a1 = sA[buf][(wm + 16 + li) * MM_PA + 4 * s + lc];
+    if constexpr (TRANSW) { b0 = sB[buf][(wn + li) * MM_PA + 4 * s + lc]; b1 = sB[buf][(wn + 16 + li) * MM_PA + 4 * s + lc]; }
+    else { b0 = sB[buf][(4 * s + lc) * MM_PB + wn + li]; b1 = sB[buf][(4 * s + lc) * MM_PB + wn + 16 + li]; }
+  };
+  auto mma = [&](int buf) {
+    float a0, a1, b0, b1;
+    readOps(buf, 0, a0, a1, b0, b1);
+#pragma unroll
+    for (int s = 0; s < MM_KS / 4; ++s) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (s + 1 < MM_KS / 4) readOps(buf, s + 1, na0, na1, nb0, nb1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+  };
+  // whole slices (K a multiple of the slice depth) of a tile inside the operands: row pointers formed once, a slice = one add per load,
+  // nothing to mask (a lone workgroup on its CU issues a slice's address arithmetic and masks between its products, not beside them)
+  const bool interior = K % MM_KS == 0 && m0 + 64 <= nRows && n0 + 64 <= P.N;
+  const float* pa[Q]; const float* pb[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    pa[q] = P.A + (size_t)(m0 + tid / PPR + RPP * q) * P.lda + (tid % PPR) * 4;
+    if constexpr (TRANSW) pb[q] = P.B + (size_t)(n0 + tid / PPR + RPP * q) * P.ldb + (tid % PPR) * 4;
+    else pb[q] = P.B + (size_t)((tid >> 4) + 16 * q) * P.ldb + n0 + (tid & 15) * 4;
+  }
+  const size_t stepB = TRANSW ? (size_t)MM_KS : (size_t)MM_KS * P.ldb;
+  auto loadWhole = [&]() {      // (the next slice: the pointers advance)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { va[q] = *reinterpret_cast<const f32x4*>(pa[q]); vb[q] = *reinterpret_cast<const f32x4*>(pb[q]); pa[q] += MM_KS; pb[q] += stepB; }
+  };
+  auto storeWhole = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       *reinterpret_cast<f32x4*>(&sA[buf][(tid / PPR + RPP * q) * MM_PA + (tid % PPR) * 4]) = va[q];
@@ -258,41 +325,36 @@ __global__ __launch_bounds__(256, MM_KS == 32 ? 4 : 2) void big_mm_kernel(GemmPr
       else *reinterpret_cast<f32x4*>(&sB[buf][((tid >> 4) + 16 * q) * MM_PB + (tid & 15) * 4]) = vb[q];
     }
   };
-  f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
-  loadSlice(0); storeSlice(0);
-  __syncthreads();
   int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += MM_KS) {
-    const bool more = k0 + MM_KS < K;
-    if (more) loadSlice(k0 + MM_KS);
-#pragma unroll
-    for (int s = 0; s < MM_KS / 4; ++s) {
-      const float a0 = sA[buf][(wm + li) * MM_PA + 4 * s + lc], a1 = sA[buf][(wm + 16 + li) * MM_PA + 4 * s + lc];
-      float b0, b1;
-      if constexpr (TRANSW) { b0 = sB[buf][(wn + li) * MM_PA + 4 * s + lc]; b1 = sB[buf][(wn + 16 + li) * MM_PA + 4 * s + lc]; }
-      else { b0 = sB[buf][(4 * s + lc) * MM_PB + wn + li]; b1 = sB[buf][(4 * s + lc) * MM_PB + wn + 16 + li]; }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (more) storeSlice(buf ^ 1);
+  if (interior) loadWhole(); else loadSlice(0);
+  if (interior) {
+    storeWhole(0);
     __syncthreads();
-    buf ^= 1;
+    MMSTAMP(2);
+    for (int k0 = 0; k0 < K; k0 += MM_KS) {
+      const bool more = k0 + MM_KS < K;
+      if (more) loadWhole();
+      mma(buf);
+      if (more) storeWhole(buf ^ 1);      // (the other buffer: its readers passed the barrier of the previous slice)
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    storeSlice(0, 0);
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += MM_KS) {
+      const bool more = k0 + MM_KS < K;
+      if (more) loadSlice(k0 + MM_KS);
+      mma(buf);
+      if (more) storeSlice(buf ^ 1, k0 + MM_KS);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
-  // ---- epilogue through LDS (the slices are dead): sOut[64][64], columns rotated by 16 per group of four rows ----
-  float* sOut = &sA[0][0];                       // 64 x 64 floats = 16 KB <= the two A buffers (18 KB)
-  static_assert(2 * 64 * MM_PA >= 64 * 64, "output tile fits the A buffers");
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wm + 16 * tm + 4 * lc + i, c = wn + 16 * tn + li;
-        sOut[r * 64 + ((c + 16 * (r >> 2)) & 63)] = acc[tm][tn][i];
-      }
-  __syncthreads();
+  MMSTAMP(3);
+  // ---- epilogue operands: every load of it requested here, in ONE round trip (inside the loop below each of the four row groups waited
+  //      for its own: 4.2 of the 14 us of a lone tile's workgroup, stamped.  Requested in front of the slices they delay the first slice
+  //      by what they save here -- the counter of outstanding loads is in order -- and cost 50 registers) ----
   const int ec = 4 * (tid & 15);
   // what later launches read of a hidden layer: f'(x) takes the pre-activation OR the output (actDiff), the layers above and the weight
   // gradients the block output (C3 behind a parametric residual, else the output)
@@ -306,6 +368,33 @@ __global__ __launch_bounds__(256, MM_KS == 32 ? 4 : 2) void big_mm_kernel(GemmPr
     ew[e] = (n < P.resN && P.resW) ? P.resW[n] : 0.f;
     er[e] = (!TRANSW && n < P.resN && P.resB) ? P.resB[n] : 0.f;
   }
+  f32x4 rinv[4], axv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + (tid >> 4) + 16 * q, n = n0 + ec;
+    rinv[q] = z4; axv[q] = z4;
+    if (m < nRows && n < P.N) {
+      if ((TRANSW || P.C3) && n < P.resN && n + 3 < P.ldRes) rinv[q] = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
+      if constexpr (TRANSW) { if (n + 3 < P.ldAct) axv[q] = *reinterpret_cast<const f32x4*>(actSrc + (size_t)m * P.ldAct + n); }
+    }
+  }
+  // ---- the tile through LDS (the slices are dead): sOut[64][64], columns rotated by 16 per group of four rows ----
+  float* sOut = &sA[0][0];                       // 64 x 64 floats = 16 KB <= the two A buffers (18 KB)
+  static_assert(2 * 64 * MM_PA >= 64 * 64, "output tile fits the A buffers");
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm + 16 * tm + 4 * lc + i, c = wn + 16 * tn + li;
+        sOut[r * 64 + ((c + 16 * (r >> 2)) & 63)] = acc[tm][tn][i];
+      }
+  __syncthreads();
+  MMSTAMP(4);
+  // (the activation as a compile-time constant inside: one switch per workgroup instead of one per element)
+  dispatchFunc<-1>(P.func, [&](auto F) {
+  constexpr int FN = decltype(F)::value;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int rr = (tid >> 4) + 16 * q, m = m0 + rr, n = n0 + ec;
@@ -313,28 +402,28 @@ __global__ __launch_bounds__(256, MM_KS == 32 ? 4 : 2) void big_mm_kernel(GemmPr
     if (m >= nRows || n >= P.N) continue;
     const size_t o = (size_t)m * P.ldc + n;
     const bool whole = n + 3 < P.N;
+    const f32x4 rin = rinv[q];
     if constexpr (!TRANSW) {
-      f32x4 rin = z4;
-      if (P.C3 && n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
       f32x4 x, y, r;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { x[e] = v[e] + eb[e]; y[e] = actEval(P.func, x[e]); r[e] = n + e < P.resN ? y[e] + (rin[e] * ew[e] + er[e]) : y[e]; }
+      for (int e = 0; e < 4; ++e) { x[e] = v[e] + eb[e]; y[e] = actEvalT<FN>(x[e]); r[e] = n + e < P.resN ? y[e] + (rin[e] * ew[e] + er[e]) : y[e]; }
       if (whole) {
         if (keepX) *reinterpret_cast<f32x4*>(P.C + o) = x;
         if (keepY) *reinterpret_cast<f32x4*>(P.C2 + o) = y;
         if (P.C3) *reinterpret_cast<f32x4*>(P.C3 + o) = r;
       } else for (int e = 0; e < 4; ++e) if (n + e < P.N) { if (keepX) P.C[o + e] = x[e]; if (keepY) P.C2[o + e] = y[e]; if (P.C3) P.C3[o + e] = r[e]; }
     } else {
-      f32x4 rin = z4, ax = z4;
-      if (n < P.resN && n + 3 < P.ldRes) rin = *reinterpret_cast<const f32x4*>(P.resIn + (size_t)m * P.ldRes + n);
-      if (n + 3 < P.ldAct) ax = *reinterpret_cast<const f32x4*>(actSrc + (size_t)m * P.ldAct + n);
+      const f32x4 ax = axv[q];
       f32x4 dres, d;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiff(P.func, ax[e], ax[e]); }
+      for (int e = 0; e < 4; ++e) { dres[e] = n + e < P.resN ? v[e] + rin[e] * ew[e] : v[e]; d[e] = dres[e] * actDiffT<FN>(ax[e], ax[e]); }
       if (whole) { *reinterpret_cast<f32x4*>(P.C + o) = dres; *reinterpret_cast<f32x4*>(P.C2 + o) = d; }
       else for (int e = 0; e < 4; ++e) if (n + e < P.N) { P.C[o + e] = dres[e]; P.C2[o + e] = d[e]; }
     }
   }
+  });
+  MMSTAMP(6);
+  MMEND();
 }
 bool big_mm_ok(const GemmProblem& P) {
   const bool al = (P.lda & 3) == 0 && (P.ldb & 3) == 0 && (P.ldc & 3) == 0 && (!P.resN || ((P.ldRes & 3) == 0 && P.ldRes >= ((P.resN + 3) & ~3))) &&
@@ -365,46 +454,55 @@ __device__ __forceinline__ void bigDwBody(const GemmProblem& P, int blk, float (
   // a slice = 32 rows x 64 columns of each operand: 512 float4 per operand, two per thread
   const int sr = tid >> 4, sc4 = (tid & 15) * 4;      // (+ 16 rows for the second one)
   f32x4 va[2], vd[2];
+  // (loads with clamped addresses and nothing else; masks when the slice is stored -- as in big_mm_kernel: no wait for the data in
+  //  front of the slice's products)
   auto loadSlice = [&](int r0) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int row = r0 + sr + 16 * q;
-      va[q] = z4; vd[q] = z4;
-      if (row < rEnd) {
-        const int ca = m0 + sc4, cd = n0 + sc4;
-        if (ca < P.lda) va[q] = *reinterpret_cast<const f32x4*>(P.A + (size_t)row * P.lda + ca);
-        if (cd < P.ldb) vd[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)row * P.ldb + cd);
-        // columns beyond the inputs: the ones column (bias row of the product) at M - 1, zeros behind it; deltas beyond N: zeros
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { if (ca + e == P.M - 1) va[q][e] = 1.f; else if (ca + e >= P.M) va[q][e] = 0.f; if (cd + e >= P.N) vd[q][e] = 0.f; }
-      }
+      const int row = min(r0 + sr + 16 * q, rEnd - 1), ca = min(m0 + sc4, P.lda - 4), cd = min(n0 + sc4, P.ldb - 4);
+      va[q] = *reinterpret_cast<const f32x4*>(P.A + (size_t)row * P.lda + ca);
+      vd[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)row * P.ldb + cd);
     }
   };
-  auto storeSlice = [&](int buf) {
+  auto storeSlice = [&](int buf, int r0) {      // (r0: the slice the registers hold)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<f32x4*>(&sA[buf][(sr + 16 * q) * BD_PITCH + sc4]) = va[q];
-      *reinterpret_cast<f32x4*>(&sD[buf][(sr + 16 * q) * BD_PITCH + sc4]) = vd[q];
+      const bool in = r0 + sr + 16 * q < rEnd;
+      const int ca = m0 + sc4, cd = n0 + sc4;
+      f32x4 a = va[q], d = vd[q];
+      // columns beyond the inputs: the ones column (bias row of the product) at M - 1, zeros behind it; deltas beyond N: zeros
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!in || ca + e >= P.M) a[e] = 0.f; else if (ca + e == P.M - 1) a[e] = 1.f;
+        if (!in || cd + e >= P.N) d[e] = 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&sA[buf][(sr + 16 * q) * BD_PITCH + sc4]) = a;
+      *reinterpret_cast<f32x4*>(&sD[buf][(sr + 16 * q) * BD_PITCH + sc4]) = d;
     }
   };
   f32x4 acc[2][2] = {{z4, z4}, {z4, z4}};
-  loadSlice(rBeg); storeSlice(0);
+  loadSlice(rBeg); storeSlice(0, rBeg);
   __syncthreads();
   int buf = 0;
   for (int r0 = rBeg; r0 < rEnd; r0 += BD_ROWS) {
     const bool more = r0 + BD_ROWS < rEnd;
     if (more) loadSlice(r0 + BD_ROWS);
+    {      // (the operands of step s + 1 are read while the MFMAs of step s run)
+      const float* ra = &sA[buf][lc * BD_PITCH + wm + li];
+      const float* rd = &sD[buf][lc * BD_PITCH + wn + li];
+      float a0 = ra[0], a1 = ra[16], d0 = rd[0], d1 = rd[16];
 #pragma unroll
-    for (int s = 0; s < BD_ROWS / 4; ++s) {
-      const float* ra = &sA[buf][(4 * s + lc) * BD_PITCH + wm + li];
-      const float* rd = &sD[buf][(4 * s + lc) * BD_PITCH + wn + li];
-      const float a0 = ra[0], a1 = ra[16], d0 = rd[0], d1 = rd[16];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, d0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, d1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, d0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, d1, acc[1][1], 0, 0, 0);
+      for (int s = 0; s < BD_ROWS / 4; ++s) {
+        float na0 = 0.f, na1 = 0.f, nd0 = 0.f, nd1 = 0.f;
+        if (s + 1 < BD_ROWS / 4) { const int o = 4 * (s + 1) * BD_PITCH; na0 = ra[o]; na1 = ra[o + 16]; nd0 = rd[o]; nd1 = rd[o + 16]; }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, d0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, d1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, d0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, d1, acc[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; d0 = nd0; d1 = nd1;
+      }
     }
-    if (more) storeSlice(buf ^ 1);      // (the other buffer: its readers passed the barrier of the previous iteration)
+    if (more) storeSlice(buf ^ 1, r0 + BD_ROWS);      // (the other buffer: its readers passed the barrier of the previous iteration)
     __syncthreads();
     buf ^= 1;
   }

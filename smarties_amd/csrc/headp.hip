@@ -117,20 +117,23 @@ __global__ __launch_bounds__(HP_NT, HP_NT == 512 ? 2 : 3) void panel_head_kernel
   const double beta = sc->beta, Cmax = sc->Cmax, Cinv = sc->Cinv;
   HPSTAMP(1);
   // ---- stage the panel and f'(x) of the last hidden block ------------------------------------------------------------------------
+  dispatchFunc<-1>(func, [&](auto F) {      // (the activation a compile-time constant inside: one switch per workgroup, not one per element)
+    constexpr int FN = decltype(F)::value;
 #pragma unroll
-  for (int q = 0; q < QP; ++q) {
-    const int f = tid + NT * q;
-    if (f < 16 * H4) {
-      const int r = f / H4, c = 4 * (f % H4);
-      float2* dy = reinterpret_cast<float2*>(sY + r * LDR + c);
-      dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
-      f32x4 fp;
+    for (int q = 0; q < QP; ++q) {
+      const int f = tid + NT * q;
+      if (f < 16 * H4) {
+        const int r = f / H4, c = 4 * (f % H4);
+        float2* dy = reinterpret_cast<float2*>(sY + r * LDR + c);
+        dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
+        f32x4 fp;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) fp[e] = actDiff(func, xv[q][e], xv[q][e]);
-      float2* df = reinterpret_cast<float2*>(sF + r * LDR + c);
-      df[0] = make_float2(fp[0], fp[1]); df[1] = make_float2(fp[2], fp[3]);
+        for (int e = 0; e < 4; ++e) fp[e] = actDiffT<FN>(xv[q][e], xv[q][e]);
+        float2* df = reinterpret_cast<float2*>(sF + r * LDR + c);
+        df[0] = make_float2(fp[0], fp[1]); df[1] = make_float2(fp[2], fp[3]);
+      }
     }
-  }
+  });
   if (eth && en < 8) sMisc[em * 8 + en] = hr.misc;
   if (eth && en == 0) sAct[em] = hr.actMsg;
   HPSTAMP(2);

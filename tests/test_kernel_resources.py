@@ -21,7 +21,8 @@ HOT = ("dw_table_kernel", "fused_fwd_head_dx_kernel", "fused_wide_kernel", "pane
        "gemm16_kernel", "dw_wide_kernel", "head_kernel_t", "big_", "splitk_reduce_kernel", "step_tail_kernel", "xchg_", "adam_kernel",
        "rec_step_fused", "lstm_", "mgu_", "rec_")
 # reserved-and-untouched frame slots: kernel -> bytes per lane at most (checked against the ISA below)
-DEAD_SLOT = {"fused_wide_kernel<256, 2>": 64, "step_tail_kernel": 64, "panel_head_kernel<256, 2, 256>": 64}
+# (prefix match: which instantiation of panel_head_kernel gets such a slot changes with every edit of the kernel)
+DEAD_SLOT = {"fused_wide_kernel<256, 2>": 64, "step_tail_kernel": 64, "panel_head_kernel<": 64}
 # real spills that remain, with the reason; anything else fails
 KNOWN_SPILLS = {}
 
@@ -48,7 +49,8 @@ def test_no_scratch_in_the_kernels_of_the_step(usage):
             seen[hot[0]] += 1
             if k["scratch"] == 0 or k["name"] in KNOWN_SPILLS:
                 continue
-            if k["name"] in DEAD_SLOT and k["scratch"] <= DEAD_SLOT[k["name"]] and k["vgpr_spill"] == 0:
+            slot = [v for n, v in DEAD_SLOT.items() if k["name"].startswith(n)]
+            if slot and k["scratch"] <= slot[0] and k["vgpr_spill"] == 0:
                 if src not in isa:
                     isa[src] = usage.scratch_instructions(src)
                 if isa[src].get(k["name"], 1) == 0:
