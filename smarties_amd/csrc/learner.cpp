@@ -691,6 +691,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     // (the crossover, measured at batch 128 and 17 steps: 2 x 64 cells 325 us with the per-sample kernels against 452 time-step-major, 2 x 96: 631 against 499)
     h->recTm = wide && ok;
     if (h->recTm) h->recK += 1;
+    // their weight gradients (2304 rows x 513 x 1024 per layer at 2 x 256 cells): the large-batch launch's 64 x 64 tiles over row chunks
+    // (bigmm.hip: big_dw_kernel + the split-row join: 74 + 14 us against 197 of dw_wide_kernel's 16 x 16 tiles, which read their operands
+    // 4 x as often)
+    if (h->recTm && !(h->generic & 128)) h->bigMm |= 2;
   }
   h->convB = B; h->convMmax = h->Mmax;
   if (h->recurrent && h->nConv > 0) {

@@ -103,8 +103,9 @@ int buildProblems(hl_learner* h) {
     // large batches: every weight-gradient problem -- 64 x 64 tiles of the products, 64-column blocks of the column sums -- over row
     // chunks in ONE launch (bigmm.hip: big_dw_kernel), joined by splitk_reduce; none of their tiles in the common launch
     auto placeDw = [&](GemmProblem& p, bool maySplit) {
-      if ((h->bigMm & 2) && (int)sb.bigDw.size() < BIG_DW_MAX && big_dw_ok(p)) {
-        p.bigChunk = big_dw_chunk_rows(p); p.nSplit = (p.K + p.bigChunk - 1) / p.bigChunk;
+      const int chunk = big_dw_chunk_rows(p);
+      if ((h->bigMm & 2) && (int)sb.bigDw.size() < BIG_DW_MAX && big_dw_ok(p) && p.K > chunk) {      // (two chunks at least: the join owns the gradient and Adam)
+        p.bigChunk = chunk; p.nSplit = (p.K + chunk - 1) / chunk;
         p.tilesM = 0; p.tilesN = 0; p.tileStart = cur; sb.bigDw.push_back((int)P.size());
       } else setTiles(p, cur, maySplit);
     };
@@ -115,11 +116,11 @@ int buildProblems(hl_learner* h) {
       if (h->hid[j].lstm == 1) {   // dense layer with a recurrent term: rows [input | previous output | 1], one delta column block
         GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = L.nC; p.K = R;
         p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = L.nC; p.C = h->G + L.indW; p.ldc = h->hid[j].ldW; p.biasOut = h->G + L.indB;
-        setTiles(p, cur, true); P.push_back(p);
+        placeDw(p, true); P.push_back(p);
       } else if (h->hid[j].lstm == 4) {
         GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + L.nC + 1; p.N = 4 * L.nC; p.K = R;
         p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 4 * L.nC; p.C = h->G + L.indW; p.ldc = 4 * L.nC; p.biasOut = h->G + L.indB;
-        setTiles(p, cur, true); P.push_back(p);
+        placeDw(p, true); P.push_back(p);
       } else {
         // MGU (Layer_GRU.h:196-229): [Wff Wsf] and the biases from the inputs; Wfr from the previous output and dLdF; Wsr from
         // (previous output x forget) and dLdS.  The two recurrent blocks have no bias: their bias row goes to the unused tail
@@ -127,23 +128,23 @@ int buildProblems(hl_learner* h) {
         const int nC = L.nC;
         GemmProblem p{}; p.flavor = GEMM_W; p.epi = EPI_DW; p.M = L.nIn + 1; p.N = 2 * nC; p.K = R;
         p.A = L.A; p.lda = L.ldA; p.B = L.D; p.ldb = 2 * nC; p.C = h->G + L.indW; p.ldc = 2 * nC; p.biasOut = h->G + L.indB;
-        setTiles(p, cur, true); P.push_back(p);
+        placeDw(p, true); P.push_back(p);
         GemmProblem f{}; f.flavor = GEMM_W; f.epi = EPI_DW; f.M = nC + 1; f.N = nC; f.K = R;
         f.A = L.A + L.nIn; f.lda = L.ldA; f.B = L.D; f.ldb = 2 * nC; f.C = h->G + L.indW + (long long)2 * nC * L.nIn; f.ldc = 2 * nC;
         f.biasOut = h->G + h->nParams;
-        setTiles(f, cur, true); P.push_back(f);
+        placeDw(f, true); P.push_back(f);
         GemmProblem q{}; q.flavor = GEMM_W; q.epi = EPI_DW; q.M = nC + 1; q.N = nC; q.K = R;
         q.A = L.A2; q.lda = L.ldA2; q.B = L.D + nC; q.ldb = 2 * nC; q.C = h->G + L.indW + (long long)2 * nC * L.nIn + nC; q.ldc = 2 * nC;
         q.biasOut = h->G + h->nParams + 64;
-        setTiles(q, cur, true); P.push_back(q);
+        placeDw(q, true); P.push_back(q);
       }
       if (L.hasRes) {
         GemmProblem r{}; r.flavor = RED_COL; r.epi = EPI_NONE; r.N = L.resW; r.K = R;
         r.A = L.Rd; r.lda = L.ldR; r.B = L.A; r.ldb = L.ldA; r.C = h->G + L.indWr;
-        setTiles(r, cur, true); P.push_back(r);
+        placeDw(r, true); P.push_back(r);
         GemmProblem s2{}; s2.flavor = RED_COL; s2.epi = EPI_NONE; s2.N = L.resW; s2.K = R;
         s2.A = L.Rd; s2.lda = L.ldR; s2.B = nullptr; s2.C = h->G + L.indBr;
-        setTiles(s2, cur, true); P.push_back(s2);
+        placeDw(s2, true); P.push_back(s2);
       }
     }
     for (int l = 0; l < h->nConv; ++l) {   // convolution biases (one per output element): column sums of the layer's deltas
