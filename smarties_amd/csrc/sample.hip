@@ -34,6 +34,12 @@ hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStr
 // ---------------------------------------------------------------------------------------------------------------------
 #define BIG_NT 1024
 #define BIG_MAXB 16384
+// development time stamps of the sampler's phases, 100 MHz clock: -DHL_BIGSAMPLE_STAMPS (tools/bigsample_stamps.py)
+#ifdef HL_BIGSAMPLE_STAMPS
+#define BSTMP(i) do { if (threadIdx.x == 0) sc->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define BSTMP(i) do { } while (0)
+#endif
 __device__ void bigTwist(unsigned* x, unsigned* xo) {
   const int tid = threadIdx.x;
   if (tid < 624) xo[tid] = x[tid];
@@ -70,6 +76,56 @@ __device__ int bigScan(bool flag, int* excl, int* sWave /*[16]*/) {
 #pragma unroll
   for (int w = 0; w < BIG_NT / 64; ++w) { const int c = sWave[w]; total += c; if (w < wave) before += c; }
   *excl = before + __popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  return total;
+}
+#define BIG_Q (BIG_MAXB / BIG_NT)
+// the same scan for BIG_Q flags per thread at once (bit q of `flags`: element q * 1024 + tid, elements in index order): exclusive ranks in
+// ex[], returns the total; three barriers instead of two per 1024 elements.  sCnt: [BIG_Q * 16 + 4]
+__device__ int bigScanAll(unsigned flags, int* ex, int* sCnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long m[BIG_Q];
+#pragma unroll
+  for (int q = 0; q < BIG_Q; ++q) { m[q] = __ballot((flags >> q) & 1u); if (lane == 0) sCnt[q * 16 + wave] = __popcll(m[q]); }
+  __syncthreads();
+  int c = 0, inc = 0;
+  if (tid < BIG_Q * 16) {
+    c = sCnt[tid]; inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) sCnt[BIG_Q * 16 + wave] = inc;
+  }
+  __syncthreads();
+  if (tid < BIG_Q * 16) {
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += sCnt[BIG_Q * 16 + w];
+    sCnt[tid] = before + inc - c;
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < BIG_Q; ++q) ex[q] = sCnt[q * 16 + wave] + __popcll(m[q] & lt);
+  int total = 0;
+#pragma unroll
+  for (int w = 0; w < BIG_Q * 16 / 64; ++w) total += sCnt[BIG_Q * 16 + w];
+  __syncthreads();
+  return total;
+}
+// vals[0..B) sorted: keeps the first of every run of equal values, in order; returns how many remain.  Every element is read before
+// the scan's barriers, written behind them.
+__device__ int bigUnique(unsigned* vals, int* sCnt, int B) {
+  const int tid = threadIdx.x;
+  unsigned v[BIG_Q]; unsigned flags = 0u;
+#pragma unroll
+  for (int q = 0; q < BIG_Q; ++q) {
+    const int i = tid + BIG_NT * q;
+    v[q] = i < B ? vals[i] : 0u;
+    if (i < B && (i == 0 || v[q] != vals[i - 1])) flags |= 1u << q;
+  }
+  int ex[BIG_Q];
+  const int total = bigScanAll(flags, ex, sCnt);
+#pragma unroll
+  for (int q = 0; q < BIG_Q; ++q) if ((flags >> q) & 1u) vals[ex[q]] = v[q];
   __syncthreads();
   return total;
 }
@@ -123,20 +179,63 @@ __device__ void bigBitonicSort(unsigned* vals, int Bp) {      // Bp a power of t
   }
   __syncthreads();
 }
-__device__ int bigSortUnique(unsigned* vals, int* sWave, int B, int Bp) {
-  for (int i = B + threadIdx.x; i < Bp; i += BIG_NT) vals[i] = 0xFFFFFFFFu;
-  bigBitonicSort(vals, Bp);
-  int out = 0;
-  for (int c0 = 0; c0 < B; c0 += BIG_NT) {      // (a chunk writes at or below the positions it read; the element in front of a chunk keeps its value)
-    const int i = c0 + threadIdx.x;
-    const unsigned v = i < B ? vals[i] : 0u;
-    const bool fl = i < B && (i == 0 || v != vals[i - 1]);
-    int ex; const int n = bigScan(fl, &ex, sWave);
-    if (fl) vals[out + ex] = v;
-    out += n;
-    __syncthreads();
+// The draws are uniform over [0, range): 4096 buckets by v * 4096 / range (monotone in v), counted and scattered with LDS atomics (the
+// elements of a bucket then stand together, in any order); every element then counts the elements of its bucket in front of it -- four
+// on average at 16384, read four at a time; a wavefront's 64 neighbours share a few buckets, so the lanes of a read mostly hit the same
+// addresses -- and goes to its place.  The sorting network over 16384 elements took ~125 of the sampler's 258 us, this 12.  A bucket
+// beyond 64 elements (a replay of a few thousand transitions: most draws collide) or a range below 2^16 leaves vals untouched and
+// returns false: the network then.
+#define BIG_NB 4096
+__device__ bool bigBucketSort(unsigned* vals, unsigned* tmp /*[B + 3]*/, int* cnt /*[BIG_NB]*/, int* sWave, int B, unsigned range, DevScalars* sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (range < (1u << 16)) return false;
+  const unsigned scale = (unsigned)(((unsigned long long)BIG_NB << 32) / range);      // v * scale >> 32 < 4096 for v < range
+  BSTMP(8);
+  int4* cnt4 = reinterpret_cast<int4*>(cnt);
+  cnt4[tid] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < B; i += BIG_NT) atomicAdd(&cnt[__umulhi(vals[i], scale)], 1);
+  __syncthreads();
+  BSTMP(9);
+  const int4 c = cnt4[tid];                      // the thread's four buckets
+  const int csum = (c.x + c.y) + (c.z + c.w);
+  if (__syncthreads_or(c.x > 64 || c.y > 64 || c.z > 64 || c.w > 64)) return false;
+  int inc = csum;                                // inclusive prefix over the workgroup
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  if (lane == 63) sWave[wave] = inc;
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int w = 0; w < BIG_NT / 64; ++w) if (w < wave) before += sWave[w];
+  const int st = before + inc - csum;
+  cnt4[tid] = make_int4(st, st + c.x, st + c.x + c.y, st + c.x + c.y + c.z);
+  __syncthreads();
+  BSTMP(10);
+  for (int i = tid; i < B; i += BIG_NT) { const unsigned v = vals[i]; tmp[atomicAdd(&cnt[__umulhi(v, scale)], 1)] = v; }
+  __syncthreads();                               // cnt[b] is now the end of bucket b
+  BSTMP(11);
+#pragma unroll 2
+  for (int i = tid; i < B; i += BIG_NT) {
+    const unsigned v = tmp[i];
+    const int b = (int)__umulhi(v, scale), s0 = b ? cnt[b - 1] : 0, e0 = cnt[b];
+    int r = 0;
+    for (int j = s0; j < e0; j += 4) {           // (reads up to three words behind the bucket: inside tmp or the scan's scratch behind it)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int jj = j + k; const unsigned u = tmp[jj]; r += (jj < e0 && (u < v || (u == v && jj < i))) ? 1 : 0; }      // (equal values: in the order they stand)
+    }
+    vals[s0 + r] = v;
   }
-  return out;
+  __syncthreads();
+  BSTMP(12);
+  return true;
+}
+__device__ int bigSortUnique(unsigned* vals, unsigned* tmp, int* cnt, int* sWave, int B, int Bp, unsigned range, DevScalars* sc) {
+  if (!bigBucketSort(vals, tmp, cnt, sWave, B, range, sc)) {
+    for (int i = B + threadIdx.x; i < Bp; i += BIG_NT) vals[i] = 0xFFFFFFFFu;
+    bigBitonicSort(vals, Bp);
+  }
+  return bigUnique(vals, sWave, B);
 }
 // Redraw rounds: vals[0..have) is sorted and unique, vals[have..have + m) holds the m <= BIG_TAIL new draws.  Sorting everything
 // again costs ~100 us at 16384; instead the tail is sorted on its own (in sT), every element finds its rank in the other sequence by
@@ -148,17 +247,16 @@ __device__ int bigMergeUnique(unsigned* vals, unsigned* sT, int* sWave, int have
   for (int i = tid; i < P2; i += BIG_NT) sT[i] = i < m ? vals[have + i] : 0xFFFFFFFFu;
   bigBitonicSort(sT, P2);
   unsigned hv[BIG_MAXB / BIG_NT], tv[BIG_TAIL / BIG_NT]; int hd[BIG_MAXB / BIG_NT], td[BIG_TAIL / BIG_NT];
+  // head elements: how many of the tail are smaller (the tail stands padded with 0xFFFFFFFF to P2 = 2^k, above every draw): log2(P2) steps
+  // of a fixed-length search, the thread's sixteen searches side by side
 #pragma unroll
-  for (int q = 0; q < BIG_MAXB / BIG_NT; ++q) {
-    const int i = tid + BIG_NT * q;
-    hd[q] = -1; hv[q] = 0u;
-    if (i < have) {
-      const unsigned v = vals[i];
-      int lo = 0, len = m;                       // tail elements smaller than v
-      while (len > 0) { const int half = len >> 1; if (sT[lo + half] < v) { lo += half + 1; len -= half + 1; } else len = half; }
-      hv[q] = v; hd[q] = i + lo;
-    }
+  for (int q = 0; q < BIG_MAXB / BIG_NT; ++q) { const int i = tid + BIG_NT * q; hv[q] = i < have ? vals[i] : 0u; hd[q] = 0; }
+  for (int hs = P2 >> 1; hs >= 1; hs >>= 1) {
+#pragma unroll
+    for (int q = 0; q < BIG_MAXB / BIG_NT; ++q) if (sT[hd[q] + hs - 1] < hv[q]) hd[q] += hs;
   }
+#pragma unroll
+  for (int q = 0; q < BIG_MAXB / BIG_NT; ++q) { const int i = tid + BIG_NT * q; if (sT[hd[q]] < hv[q]) hd[q] += 1; hd[q] = i < have ? i + hd[q] : -1; }      // (the last element: a tail of exactly P2 draws has no padding)
 #pragma unroll
   for (int q = 0; q < BIG_TAIL / BIG_NT; ++q) {
     const int j = tid + BIG_NT * q;
@@ -176,18 +274,7 @@ __device__ int bigMergeUnique(unsigned* vals, unsigned* sT, int* sWave, int have
 #pragma unroll
   for (int q = 0; q < BIG_TAIL / BIG_NT; ++q) if (td[q] >= 0) vals[td[q]] = tv[q];
   __syncthreads();
-  const int B = have + m;
-  int out = 0;
-  for (int c0 = 0; c0 < B; c0 += BIG_NT) {
-    const int i = c0 + tid;
-    const unsigned v = i < B ? vals[i] : 0u;
-    const bool fl = i < B && (i == 0 || v != vals[i - 1]);
-    int ex; const int n = bigScan(fl, &ex, sWave);
-    if (fl) vals[out + ex] = v;
-    out += n;
-    __syncthreads();
-  }
-  return out;
+  return bigUnique(vals, sWave, have + m);
 }
 __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -195,7 +282,8 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   int Bp = 2048; while (Bp < a.B) Bp <<= 1;
   unsigned* x = vals + Bp; unsigned* xo = x + 624; unsigned* raw = xo + 624;      // [624] [624] [BIG_NT]
   unsigned* sT = raw + BIG_NT;                                                    // [BIG_TAIL] the redrawn tail, sorted
-  int* sWave = reinterpret_cast<int*>(sT + BIG_TAIL); int* sPos = sWave + BIG_NT / 64;
+  unsigned* tmp = sT + BIG_TAIL;                                                  // [Bp] the bucket sort's scatter target (its counters: raw)
+  int* sWave = reinterpret_cast<int*>(tmp + Bp); int* sPos = sWave + BIG_Q * 16 + 4;      // sWave: [BIG_Q * 16 + 4] (bigScanAll)
   const int tid = threadIdx.x, B = a.B;
   DevScalars* sc = a.sc;
   if (tid < 624) { const unsigned v = sc->rng[tid]; x[tid] = v; if (a.backupRng) sc->rngBak[tid] = v; }      // (a minibatch drawn ahead may be discarded: dropPresample)
@@ -205,35 +293,61 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   const unsigned range = (unsigned)nData;
   const unsigned threshold = range ? (0u - range) % range : 0u;
   __syncthreads();
+  BSTMP(0);
   if (a.flatGiven) { for (int i = tid; i < B; i += BIG_NT) vals[i] = (unsigned)a.flatGiven[i]; __syncthreads(); }
   else {
     bigDrawAccepted(x, xo, sPos, raw, vals, sWave, 0, B, range, threshold);
-    int have = bigSortUnique(vals, sWave, B, Bp);
+    BSTMP(1);
+    int have = bigSortUnique(vals, tmp, reinterpret_cast<int*>(sT), sWave, B, Bp, range, sc);
+    BSTMP(2);
     while (have < B) {                       // duplicates: redraw the missing ones (Sampling.cpp:86-93)
       bigDrawAccepted(x, xo, sPos, raw, vals, sWave, have, B, range, threshold);
-      have = B - have <= BIG_TAIL ? bigMergeUnique(vals, sT, sWave, have, B - have) : bigSortUnique(vals, sWave, B, Bp);
+      have = B - have <= BIG_TAIL ? bigMergeUnique(vals, sT, sWave, have, B - have) : bigSortUnique(vals, tmp, reinterpret_cast<int*>(sT), sWave, B, Bp, range, sc);
     }
   }
+  BSTMP(3);
   for (int d = 0; d < a.adamDraws; d += BIG_NT) bigDraw(x, xo, sPos, raw, min(a.adamDraws - d, BIG_NT));      // AdamOptimizer::apply_update (Optimizer.cpp:139)
+  BSTMP(4);
   if (tid < 624) sc->rng[tid] = x[tid];
   if (tid == 0) sc->rngPos = (unsigned)*sPos;
-  // ---- IDtoSeqStep + rows of the truncated next states, in minibatch order ----
-  int base = 0;
-  for (int c0 = 0; c0 < B; c0 += BIG_NT) {
-    const int b = c0 + tid;
-    bool hasNext = false;
-    if (b < B) {
-      const long long f = (long long)vals[b];
-      int lo;
-      const PosRec rec = findPosition(a.rp, f, nEp, nData, &lo);
-      const int t = (int)(f - rec.prefix);
-      a.bt.flat[b] = f; a.bt.pos[b] = lo; a.bt.eid[b] = rec.eidTerm & 0x7fffffff; a.bt.t[b] = t; a.bt.tag[b] = rec.tag; a.bt.slot[b] = rec.off + t;
-      hasNext = (t + 2 == rec.N && rec.eidTerm >= 0);      // Episode::isTruncated(t+1) (Episode.h:158-161)
+  // ---- IDtoSeqStep + rows of the truncated next states, in minibatch order: four elements' table records requested at once (the guess
+  //      of findPosition, tail_dev.h; the search behind it on a miss), one scan over all the next-state flags ----
+  unsigned nf = 0u;
+  for (int q0 = 0; q0 < BIG_Q; q0 += 4) {
+    if (q0 * BIG_NT >= B) break;
+    PosRec rec[4]; long long p1[4], f[4]; int k0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = (q0 + u) * BIG_NT + tid;
+      f[u] = b < B ? (long long)vals[b] : 0ll;
+      int k = (int)(((double)f[u] * (double)nEp) / (double)nData);
+      k0[u] = min(max(k, 0), nEp - 1);
+      rec[u] = a.rp.posRec[k0[u]]; p1[u] = a.rp.posRec[k0[u] + 1].prefix;
     }
-    int ex; const int n = bigScan(hasNext, &ex, sWave);
-    if (b < B) { a.bt.nextOf[b] = hasNext ? B + base + ex : -1; if (hasNext) a.bt.nextSrc[base + ex] = b; }
-    base += n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = (q0 + u) * BIG_NT + tid;
+      if (b < B) {
+        int lo = k0[u];
+        if (f[u] < rec[u].prefix || f[u] >= p1[u]) {
+          int l = f[u] < rec[u].prefix ? 0 : k0[u] + 1, hgh = f[u] < rec[u].prefix ? k0[u] : nEp;   // largest k in [l,hgh): prefix[k] <= f
+          while (hgh - l > 1) { const int mid = (l + hgh) >> 1; if (a.rp.posRec[mid].prefix <= f[u]) l = mid; else hgh = mid; }
+          lo = l; rec[u] = a.rp.posRec[lo];
+        }
+        const int t = (int)(f[u] - rec[u].prefix);
+        a.bt.flat[b] = f[u]; a.bt.pos[b] = lo; a.bt.eid[b] = rec[u].eidTerm & 0x7fffffff; a.bt.t[b] = t; a.bt.tag[b] = rec[u].tag; a.bt.slot[b] = rec[u].off + t;
+        if (t + 2 == rec[u].N && rec[u].eidTerm >= 0) nf |= 1u << (q0 + u);      // Episode::isTruncated(t+1) (Episode.h:158-161)
+      }
+    }
   }
+  int exn[BIG_Q];
+  const int base = bigScanAll(nf, exn, sWave);
+#pragma unroll
+  for (int q = 0; q < BIG_Q; ++q) {
+    const int b = q * BIG_NT + tid;
+    if (b < B) { const bool hn = (nf >> q) & 1u; a.bt.nextOf[b] = hn ? B + exn[q] : -1; if (hn) a.bt.nextSrc[exn[q]] = b; }
+  }
+  BSTMP(5);
   if (tid == 0) {
     sc->nNext[a.parity] = base; sc->nRows[a.parity] = B + base;
     if (a.computeEta) sc->etaEff[a.parity] = adamEtaEff(sc->nStep, sc->adam_bt1, sc->adam_bt2, a.eta0, a.epsAnneal);
@@ -242,7 +356,7 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
 hipError_t launch_big_sample(const SampleArgs& a, hipStream_t s) {
   if (a.B > BIG_MAXB || a.perAlgo || !a.noGather) return hipErrorInvalidValue;
   int Bp = 2048; while (Bp < a.B) Bp <<= 1;
-  const size_t lds = (size_t)4 * (Bp + 624 + 624 + BIG_NT + BIG_TAIL) + 4 * (BIG_NT / 64 + 4);
+  const size_t lds = (size_t)4 * (2 * Bp + 624 + 624 + BIG_NT + BIG_TAIL) + 4 * (BIG_Q * 16 + 4 + 4);
   static size_t have = 0;
   if (lds > have) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(big_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; have = lds; }
   hipLaunchKernelGGL(big_sample_kernel, dim3(1), dim3(BIG_NT), lds, s, a);
