@@ -401,7 +401,7 @@ hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, h
   ExtraArgs ex{}; if (extra) ex = *extra;
   const int nEx = ex.role ? 1 + ex.helpers : 0;
   const dim3 block(256);
-  if (a.H > 128 && maxRows >= 4096 && !nEx) {       // large batches: throughput, not latency -- a wavefront per sample, four samples per workgroup
+  if (a.H > 128 && a.H <= 512 && maxRows >= 4096 && !nEx) {       // large batches: throughput, not latency -- a wavefront per sample, four samples per workgroup
     const dim3 grid((maxRows + 3) / 4);
     const int HQ = (a.H + 63) / 64;
     if (HQ <= 4) hipLaunchKernelGGL((head_kernel_t<4, 1>), grid, block, 0, s, a, ex);
@@ -413,7 +413,9 @@ hipError_t launch_head(const HeadArgs& a, int maxRows, const ExtraArgs* extra, h
     const int HQ = (a.H + 255) / 256;
     if (HQ <= 1) hipLaunchKernelGGL((head_kernel_t<1, 4>), grid, block, 0, s, a, ex);
     else if (HQ <= 2) hipLaunchKernelGGL((head_kernel_t<2, 4>), grid, block, 0, s, a, ex);
-    else return hipErrorInvalidValue;   // hidden width > 512: not supported by this kernel
+    else if (HQ <= 4) hipLaunchKernelGGL((head_kernel_t<4, 4>), grid, block, 0, s, a, ex);
+    else if (HQ <= 8) hipLaunchKernelGGL((head_kernel_t<8, 4>), grid, block, 0, s, a, ex);
+    else return hipErrorInvalidValue;   // hidden width > 2048: refused by hl_create
     return hipGetLastError();
   }
   const dim3 grid((maxRows + 3) / 4 + nEx);

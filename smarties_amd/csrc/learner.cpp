@@ -671,7 +671,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   h->preproc = h->nApp > 0 || cfg->n_conv > 0 || h->bigBatch || (cfg->nn_type == HL_NN_FFNN && h->dS > 512);
   if ((long long)h->dS * (1 + h->nApp) > (1 << 20)) return fail(h, HL_ERR_UNSUPPORTED, "more than 2^20 network inputs");
   for (int j = 0; j < h->cfg.n_hidden; ++j)      // (the merged list: encoder layers first)
-    if (h->cfg.hidden[j] > 512) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 512");
+    if (h->cfg.hidden[j] > 2048) return fail(h, HL_ERR_UNSUPPORTED, "hidden layer wider than 2048");
   h->maxObsGlobal = (long long)(std::ceil(cfg->maxTotObsNum / nL) * nL);
   h->maxObsLocal = h->maxObsGlobal / cfg->n_ranks;
   long long minObs = cfg->minTotObsNum <= 0 ? cfg->maxTotObsNum : cfg->minTotObsNum;

@@ -85,3 +85,26 @@ def test_timed_out_gradient_exchange_leaves_the_parameters_as_they_were(hip_api,
     after = Ls[0].get_params()
     for a, b in zip(before, after):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,hidden,extra", [(48, (1024, 768), {}), (32, (1000, 520, 640), dict(adv_kind=capi.ADV_GAUSSIAN)),
+                                            (2048, (768, 1024), {}), (40, (2048,), dict(adv_kind=capi.ADV_DISCRETE, n_options=5, dimA=1, bounded=[0]))],
+                         ids=["1024x768", "1000x520x640-gauss", "b2048-768x1024", "2048-discrete"])
+def test_hidden_layers_up_to_2048_units_match_oracle(hip_api, B, hidden, extra):
+    """Layer_Base.h:64-113 has no width limit; the library served 512 units until round 5 (the head launch's quarter-of-the-units-per-
+    wavefront form stopped there).  Widths up to 2048, not multiples of 16, as last and as inner layers, small and large batches,
+    all three heads: per-sample taps and the updated weights against the oracle."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=9, dimA=3, bounded=[1, 0, 0], hidden=hidden, nnFunc="Tanh", batchSize=B, maxTotObsNum=200000, randSeed=17)
+    kw.update(extra)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=21, dimS=9, dimA=kw["dimA"], lenMin=20, lenMax=120, pTerm=0.5), 150)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(3); O.step(3)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    st = np.random.default_rng(5).standard_normal((70, 9)).astype(np.float32)      # rollout inference at these widths (hl_forward)
+    assert relinf(G.forward(st[:3]), O.forward(st[:3])) < TOL32 and relinf(G.forward(st), O.forward(st)) < TOL32
