@@ -17,6 +17,7 @@
 // One launch can carry several problems (table in device memory); all dW / bias / residual
 // parameter gradients of a step are ONE launch.
 #include "dw_wide_dev.h"
+#include "head_body.h"
 
 namespace hl {
 
@@ -88,6 +89,92 @@ hipError_t launch_fwd_chain(const GemmProblem* dProbs, const int* idx, int nLaye
   for (int l = 0; l < nLayers; ++l) ch.idx[l] = idx[l];
   ExtraArgs ex{}, ex2{}; if (extra) ex = *extra; if (extra2) ex2 = *extra2;
   hipLaunchKernelGGL(fwd_chain_kernel, dim3(fwd_chain_blocks(maxRows, HT)), dim3(256), 0, s, dProbs, ch, sc, hyp, ex, ex2);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole step in front of the weight gradients in ONE launch, for dense networks off the fused kernels (three or more hidden layers,
+// unequal widths: settings/RACER_glider.json is 3 x 128 under the Gaussian advantage): the forward chain above, then the head of the
+// panel's 16 samples (head_body.h: four per workgroup, or one per workgroup above 128 units), then the input-gradient products from the
+// last hidden layer down -- every stage a column tile per workgroup, the panel's group meeting at the counter barrier in between.  What a
+// stage reads was written by workgroups of its own group (one XCD, one L2): plain stores, acknowledged before the arrival.
+// Five launches (forward chain, head, a dX launch per layer, dW) become two.  Blocks 0..7: riders as in fused.hip (block 0: draws and
+// sort of the next minibatch); its index search, the gather and this step's bookkeeping ride the dW launch (launchWeightGrad).
+// ---------------------------------------------------------------------------------------------------------------
+struct StepChainArgs { int nF, nX; int fIdx[HL_MAX_HIDDEN], xIdx[HL_MAX_HIDDEN]; int HT; unsigned* panelCtr; };
+__device__ __forceinline__ void chainBarrier(unsigned* ctr, int HT, const DevScalars* sc) {
+  __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0): this workgroup's stores are acknowledged by the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (old / (unsigned)HT + 1u) * (unsigned)HT;
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { const_cast<DevScalars*>(sc)->errFlag = 80; break; }   // never hang the GPU on a lost workgroup
+    }
+  }
+  __syncthreads();
+}
+template <int HQ, int SPLIT>
+__global__ __launch_bounds__(256) void step_chain_kernel(const GemmProblem* __restrict__ probs, StepChainArgs ch, HeadArgs ha, const DevScalars* __restrict__ sc,
+                                                         AdamHyper hyp, ExtraArgs extra) {
+  constexpr int LDS0 = GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS0 > HEAD_LDS ? LDS0 : HEAD_LDS];
+  if (blockIdx.x < 8) {
+    if (blockIdx.x == 0 && extra.role) runExtra(extra, smem);
+    else if (blockIdx.x == 1 && ha.deferBeta) farBetaPhase(extra.post, smem);      // (the count and beta the bookkeeping of the step before left over)
+    return;
+  }
+  const int bid = blockIdx.x - 8, xcd = bid & 7, gi = bid >> 3;
+  const int HT = ch.HT, panel = (gi / HT) * 8 + xcd, n = gi % HT;
+  const int nRowsDyn = sc->nRows[hyp.parity];
+  if (panel * 16 >= nRowsDyn) return;                    // (the whole group of a panel leaves together)
+  unsigned* ctr = ch.panelCtr + panel * 32;
+  // development time stamps of workgroup (panel 0, tile 0), 100 MHz clock: -DHL_CHAIN_STAMPS (tools/chain_stamps.py)
+#ifdef HL_CHAIN_STAMPS
+#define CSTMP(i) do { if (threadIdx.x == 0 && panel == 0 && n == 0) const_cast<DevScalars*>(sc)->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define CSTMP(i) do { } while (0)
+#endif
+  CSTMP(0);
+  for (int l = 0; l < ch.nF; ++l) {
+    const GemmProblem P = probs[ch.fIdx[l]];
+    if (n < P.tilesN) gemmTile<GEMM_ROLE_FWD, -1, true>(P, panel * P.tilesN + n, smem, sc, hyp, nRowsDyn);
+    CSTMP(1 + 2 * l);
+    chainBarrier(ctr, HT, sc);
+    CSTMP(2 + 2 * l);
+  }
+  // the panel's samples: rows 4 g + wave of workgroup g (SPLIT = 1) / row g (SPLIT = 4), further ones by the same workgroup where the
+  // group is smaller than that
+  if constexpr (SPLIT == 1) {
+    for (int g = n; g < 4; g += HT) headBody<HQ, 1>(ha, panel * 16 + 4 * g + (int)(threadIdx.x >> 6), smem);
+  } else {
+    for (int g = n; g < 16; g += HT) { headBody<HQ, 4>(ha, panel * 16 + g, smem); __syncthreads(); }
+  }
+  CSTMP(16);
+  for (int l = 0; l < ch.nX; ++l) {
+    chainBarrier(ctr, HT, sc);
+    CSTMP(17 + 2 * l);
+    const GemmProblem P = probs[ch.xIdx[l]];
+    if (n < P.tilesN) gemmTile<GEMM_ROLE_DX, -1, true>(P, panel * P.tilesN + n, smem, sc, hyp, nRowsDyn);
+    CSTMP(18 + 2 * l);
+  }
+}
+hipError_t launch_step_chain(const GemmProblem* dProbs, const int* fIdx, int nF, const int* xIdx, int nX, int HT, int maxRows, unsigned* panelCtr,
+                             const HeadArgs& ha, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s) {
+  StepChainArgs ch{}; ch.nF = nF; ch.nX = nX; ch.HT = HT; ch.panelCtr = panelCtr;
+  for (int l = 0; l < nF; ++l) ch.fIdx[l] = fIdx[l];
+  for (int l = 0; l < nX; ++l) ch.xIdx[l] = xIdx[l];
+  ExtraArgs ex{}; if (extra) ex = *extra;
+  const dim3 grid(fwd_chain_blocks(maxRows, HT)), block(256);
+  if (ha.H > 128) {
+    const int HQ = (ha.H + 255) / 256;
+    if (HQ <= 1) hipLaunchKernelGGL((step_chain_kernel<1, 4>), grid, block, 0, s, dProbs, ch, ha, sc, hyp, ex);
+    else if (HQ <= 2) hipLaunchKernelGGL((step_chain_kernel<2, 4>), grid, block, 0, s, dProbs, ch, ha, sc, hyp, ex);
+    else return hipErrorInvalidValue;
+  } else if (ha.H > 64) hipLaunchKernelGGL((step_chain_kernel<2, 1>), grid, block, 0, s, dProbs, ch, ha, sc, hyp, ex);
+  else hipLaunchKernelGGL((step_chain_kernel<1, 1>), grid, block, 0, s, dProbs, ch, ha, sc, hyp, ex);
   return hipGetLastError();
 }
 

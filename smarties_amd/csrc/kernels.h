@@ -43,6 +43,7 @@ struct SampleArgs {
 struct HeadArgs {
   DevScalars* sc; DevReplay rp; DevBatch bt;
   int B, dA, nDense, nOut, H;       // H = width of the last hidden block
+  int deferBeta;                    // 1 (gemm16.hip: step_chain_kernel only): beta of this step comes from a rider of the same launch, the heads wait for its number
   int nAdv;                         // advantage outputs between V and the policy mean: 0 (VRACER) or 1 + 2 dA (Gaussian)
   int nOpt, nSig;                   // discrete head: number of options (else 0); size of the sigma ParamLayer (dA or 0)
   const float* Yin; int ldY;        // input of the output layer [Mmax][ldY]
@@ -312,6 +313,9 @@ size_t fwd_chain_lds_bytes();
 int fwd_chain_blocks(int maxRows, int HT);
 hipError_t launch_fwd_chain(const GemmProblem* dProbs, const int* idx, int nLayers, int HT, int maxRows, unsigned* panelCtr, const DevScalars* sc,
                             const AdamHyper& hyp, const ExtraArgs* extra, const ExtraArgs* extra2, hipStream_t s);
+// forward chain + head + input-gradient chain in one launch (gemm16.hip: step_chain_kernel); xIdx: the dX problems from the last hidden layer down
+hipError_t launch_step_chain(const GemmProblem* dProbs, const int* fIdx, int nF, const int* xIdx, int nX, int HT, int maxRows, unsigned* panelCtr,
+                             const HeadArgs& ha, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
 hipError_t launch_gemm_oneshot(int role, const GemmProblem* dProb, int K, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s);
 struct TouchArgs { const void* ptr[24]; long long bytes[24]; int stride[24]; int n; float* sink; };
 hipError_t launch_touch(const TouchArgs& a, hipStream_t s);      // reads one word per 4 KB of each array (address translations resident)

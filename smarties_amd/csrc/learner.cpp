@@ -141,6 +141,7 @@ struct hl_learner {
   void* pinned = nullptr; size_t pinnedBytes = 0;
   long long* dFlatGiven = nullptr; int* dEidList = nullptr; int eidListCap = 0;
   float* dActS = nullptr; double* dActO = nullptr;     // staging of hl_forward: raw states in, outputs out [Mmax rows]
+  bool stepChainOk = false;               // ... and the head and the input-gradient products with them (gemm16.hip: step_chain_kernel): the two-launch step for those networks
   bool chainOk = false; int chainHT = 0;  // the dense forward layers of a network off the fused path go out as one launch (gemm16.hip: fwd_chain_kernel)
   bool noConvReplay = false;            // (SMARTIES_HIP_GENERIC & 64) stack the minibatch rows (stack_gather_kernel) also when the first layer could read the replay
   mutable int minLen = 0; mutable long long minLenAtN = -1; mutable size_t minLenAtCount = 0;      // shortest stored episode (evictionDue, removal rules other than "oldest")
@@ -858,6 +859,11 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       const size_t nCtr = (size_t)roundUp((h->Mmax + 15) / 16, 8) * 32;
       HIPCK(devAlloc(&h->panelCtr, nCtr));
       h->chainOk = true; h->chainHT = HT;
+      // the head and the input gradients in the same launch: no convolutions in front, no layer whose input-gradient product takes the
+      // long-reduction kernel (256 < units <= 640), one replica's gradient or a pushed one alike (launchWeightGrad)
+      bool sc = h->nConv == 0 && !(h->generic & 512) && HT <= 32;      // (<= 512 units: a panel's group fits its XCD at one workgroup per CU, the kernel's registers at their worst)
+      for (int j = 1; j < h->nHidden; ++j) sc = sc && !gemm_oneshot_ok(GEMM_X, h->hid[j].size);
+      h->stepChainOk = sc;
     }
   }
   h->ldDo = (int)roundUp(h->nDense, 16);

@@ -356,6 +356,25 @@ int launchFusedWide(hl_learner* h, int parity, hipStream_t s, bool nextSample = 
   HIPCK(timed(h, "fused_wide", s, [&] { return launch_fused_wide(fa, ha, h->Mmax, pex, s); }));
   return HL_OK;
 }
+int launchFront(hl_learner* h, int parity, hipStream_t s, bool gather);
+// dense networks off the fused kernels: forward chain, head and input-gradient chain as one launch (gemm16.hip: step_chain_kernel)
+// `wholeSampler`: the rider draws, sorts, searches and gathers the next minibatch (a few state components: no gather helpers needed)
+// `deferBeta`: as launchFused
+int launchStepChain(hl_learner* h, int parity, hipStream_t s, bool nextSample = false, bool wholeSampler = false, bool deferBeta = false) {
+  const AdamHyper hyp = adamHyper(h, parity);
+  const StepBuf& sb = h->buf[parity];
+  { const int rc = launchFront(h, parity, s, true); if (rc) return rc; }
+  HeadArgs ha = headArgs(h, parity);
+  ExtraArgs ex{}; const ExtraArgs* pex = nullptr;
+  if (nextSample) { ex = extraSample(h, parity ^ 1, wholeSampler ? PH_ALL : (PH_A | PH_B)); pex = &ex; }
+  if (deferBeta) { ha.deferBeta = 1; ex.post = postArgs(h, parity ^ 1, POST_BETA); pex = &ex; }
+  int fIdx[HL_MAX_HIDDEN], xIdx[HL_MAX_HIDDEN];
+  for (int j = 0; j < h->nHidden; ++j) fIdx[j] = sb.fwdIdx[j];
+  const int nX = (int)sb.dxIdx.size();
+  for (int i = 0; i < nX; ++i) xIdx[i] = sb.dxIdx[i];
+  HIPCK(timed(h, "step_chain", s, [&] { return launch_step_chain(h->dProbs, fIdx, h->nHidden, xIdx, nX, h->chainHT, h->Mmax, h->panelCtr, ha, h->sc, hyp, pex, s); }));
+  return HL_OK;
+}
 ConvArgs convArgs(hl_learner* h, int parity);
 // (never inside a stream capture: the launch has to RUN before the flag is cleared)
 int ensureConvPrep(hl_learner* h) {
@@ -510,10 +529,12 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
   return HL_OK;
 }
 // `sampleC`: the index search of the NEXT minibatch (sampler phase C; recurrent nets) rides the weight-gradient launch
-int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA, bool sampleC = false) {
+// `skipDx`: the input gradients were taken by the launch in front (gemm16.hip: step_chain_kernel): the weight gradients and their riders only
+int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost = false, int postMode = POST_AGG | POST_BETA, bool sampleC = false, bool skipDx = false) {
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   ExtraArgs ex{}, exF{}; const ExtraArgs* pex = nullptr; const ExtraArgs* pexF = nullptr;
+  const bool noDx = skipDx || sb.dxIdx.empty();
   // one replica, bookkeeping riding the first dX launch: its far-policy count and the beta update move on to the dW launch (the next
   // reader of beta is the head kernel of the step after), off what was that launch's longest workgroup
   // (no dX launch -- recurrent layers, a single hidden layer --: the bookkeeping rides the dW launch; where a split-row join follows,
@@ -521,9 +542,9 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   // recurrent nets: the weight gradients over all (sample, step) rows as ONE launch (no row chunks, no join) unless this replica
   // pushes its tiles into peer windows from the launch
   const bool wideDw = h->wideDw && sb.dwWideIdx >= 0 && !hyp.push.on && sb.bigDw.empty();
-  const bool viaSplit = sb.dxIdx.empty() && sb.splitMaxMN > 0 && !wideDw;
+  const bool viaSplit = noDx && sb.splitMaxMN > 0 && !wideDw;
   PostArgs fbSplit{};
-  if (fusePost && postMode == (POST_AGG | POST_BETA) && (!sb.dxIdx.empty() || viaSplit) && !h->noDeferBeta) {
+  if (fusePost && postMode == (POST_AGG | POST_BETA) && (!noDx || viaSplit) && !h->noDeferBeta) {
     postMode |= POST_DEFER;
     if (viaSplit) fbSplit = postArgs(h, parity, POST_BETA);
     else { exF.role = 3; exF.post = postArgs(h, parity, POST_BETA); pexF = &exF; }
@@ -531,7 +552,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   const bool splitRider = viaSplit && (postMode & POST_DEFER);
   if (fusePost) { ex.role = 2; ex.post = postArgs(h, parity, postMode); pex = &ex; }
   char nm[32];
-  for (size_t i = 0; i < sb.dxIdx.size(); ++i) {
+  for (size_t i = 0; i < sb.dxIdx.size() && !skipDx; ++i) {
     snprintf(nm, sizeof(nm), "gemm16_dx%d", h->nHidden - 1 - (int)i);
     const int jx = h->recurrent ? 1 : h->nHidden - 1 - (int)i;          // problem i back-propagates through block jx: reduction over its outputs
     const int Kx = h->recurrent ? std::max(h->hid[jx].lstm, 1) * h->hid[jx].size : h->hid[jx].size;      // (recurrent layer under a conv stack: over its gates)
@@ -559,7 +580,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
     // the dense layers' weight-gradient tiles depend on the deltas only, like the filter gradients: with one workgroup per tile and
     // no second rider they join the filter-gradient launch (their Adam pass touches no parameter conv_reduce_adam touches)
     denseMerged = nRb == 1 && h->convDwBlocks > 0 && h->convDwDense && h->directDw && !h->recurrent && sb.splitMaxMN == 0 && sb.bigDw.empty()
-                  && !hyp.push.on && sb.dwBlocks >= h->directDwMinTiles && !sampleC && !(sb.dxIdx.empty() && pex);
+                  && !hyp.push.on && sb.dwBlocks >= h->directDwMinTiles && !sampleC && !(noDx && pex);
     for (int i = 0; denseMerged && i < sb.dwCount; ++i) if (h->hostProbs[sb.dwIdx + i].K > 128) denseMerged = false;      // (the instantiated row batches)
     // ... and the tiles behind the convolution biases' column sums (the table's first nConv problems) need no delta of a
     // convolutional layer: they ride the input-gradient launches of the unstrided layers (a few hundred workgroups each), in equal shares
@@ -600,7 +621,7 @@ int launchBackward(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool
   }
   // a single hidden layer has no dX launch: the bookkeeping then rides along the dW launch.  It
   // writes etaEff[parity^1] only, never the slot the fused Adam of this launch reads.
-  const ExtraArgs* pexW = sb.dxIdx.empty() ? pex : nullptr;
+  const ExtraArgs* pexW = noDx ? pex : nullptr;
   ExtraArgs exC{};
   if (sampleC && pexF) return fail(h, HL_ERR_STATE, "no rider slot left for the sampler's index search on the weight-gradient launch");
   if (sampleC) { exC = extraSample(h, parity ^ 1, PH_C); pexF = &exC; }
@@ -823,6 +844,10 @@ int launchMlp(hl_learner* h, int parity, bool fuseAdam, hipStream_t s) {
     int rc = launchFusedWide(h, parity, s); if (rc) return rc;
     return launchWeightGrad(h, parity, fuseAdam, s, false, false);
   }
+  if (h->stepChainOk) {      // forward chain + head + input-gradient chain (gemm16.hip: step_chain_kernel), then the weight gradients
+    int rc = launchStepChain(h, parity, s); if (rc) return rc;
+    return launchBackward(h, parity, fuseAdam, s, false, POST_AGG | POST_BETA, false, true);
+  }
   int rc = launchForward(h, parity, s); if (rc) return rc;
   rc = launchHead(h, parity, s); if (rc) return rc;
   return launchBackward(h, parity, fuseAdam, s);
@@ -928,12 +953,19 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
       if (hipStreamWaitEvent(s0, h->evSide, 0) != hipSuccess) { rc = fail(h, HL_ERR_HIP, "join of the sampler branch"); break; }
       continue;
     }
-    const bool twoKernel = h->fusedOk || h->fusedWideOk;
+    const bool twoKernel = h->fusedOk || h->fusedWideOk || h->stepChainOk;
     if (twoKernel) {
       // one replica: the far-policy count and the beta update of every step but the last are taken out of the dW launch's
       // bookkeeping rider, where they sat at the end of the kernel's longest workgroup, into a rider of the next fused kernel
       const bool single = !exchanging(h) && !h->noDeferBeta;
-      rc = h->fusedOk ? launchFused(h, p, s0, true, single && j > 0) : launchFusedWide(h, p, s0, true, single && j > 0); if (rc) break;
+      // (the chained step with a few state components: the whole sampler of the next minibatch as its rider -- a 10 us chain beside a 30 us
+      //  launch --, the bookkeeping alone on the dW launch of the generic steps; wider states keep the gather helpers of launchWeightGrad)
+      const bool chainNarrow = h->stepChainOk && !exchanging(h) && !h->preproc && 2ll * h->B * h->dS <= 16384;
+      rc = h->fusedOk ? launchFused(h, p, s0, true, single && j > 0) : (h->fusedWideOk ? launchFusedWide(h, p, s0, true, single && j > 0) : launchStepChain(h, p, s0, true, chainNarrow, single && j > 0)); if (rc) break;
+      if (chainNarrow) {
+        rc = launchBackward(h, p, true, s0, true, POST_AGG | POST_BETA | (single && j + 1 < U ? POST_DEFER : 0), false, true); if (rc) break;
+        continue;
+      }
       if (!exchanging(h)) {
         rc = launchWeightGrad(h, p, true, s0, true, true, POST_AGG | POST_BETA | (single && j + 1 < U ? POST_DEFER : 0)); if (rc) break;
         continue;

@@ -108,3 +108,33 @@ def test_hidden_layers_up_to_2048_units_match_oracle(hip_api, B, hidden, extra):
     assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
     st = np.random.default_rng(5).standard_normal((70, 9)).astype(np.float32)      # rollout inference at these widths (hl_forward)
     assert relinf(G.forward(st[:3]), O.forward(st[:3])) < TOL32 and relinf(G.forward(st), O.forward(st)) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,extra", [((128, 128, 128), dict(adv_kind=capi.ADV_GAUSSIAN, dimA=1, bounded=[1])), ((96, 48), {}),
+                                          ((320, 256, 64), dict(adv_kind=capi.ADV_DISCRETE, n_options=4, dimA=1, bounded=[0]))],
+                         ids=["glider-3x128-gauss", "96x48", "320x256x64-discrete"])
+def test_chained_step_equals_the_separate_launches(hip_api, monkeypatch, hidden, extra):
+    """Dense nets off the fused kernels: forward chain + head + input-gradient chain as ONE launch (gemm16.hip: step_chain_kernel) against
+    the launch list it replaces (SMARTIES_HIP_GENERIC=512: forward chain, head launch, one dX launch per layer) -- the same tile and head
+    code in both, so eager and replayed steps must end bit-identical -- and against the oracle."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=10, dimA=3, bounded=[1, 0, 0], hidden=hidden, nnFunc="Tanh", batchSize=64, maxTotObsNum=20000, randSeed=19)
+    kw.update(extra)
+    sc = synth_cfg(seed=23, dimS=10, dimA=kw["dimA"], lenMin=5, lenMax=60, pTerm=0.5)
+    out = {}
+    for tag, env in (("chained", None), ("separate", "512")):
+        monkeypatch.delenv("SMARTIES_HIP_GENERIC", raising=False)
+        if env:
+            monkeypatch.setenv("SMARTIES_HIP_GENERIC", env)
+        G, O = _pair(hip_api, kw, sc, 80)
+        for _ in range(2):
+            G.step(1); O.step(1)
+            _compare_step(G, O)
+        G.step(37); O.step(37)
+        assert relinf(G.get_params()[0], O.get_params()[0]) < 4 * TOL32
+        out[tag] = (G.get_params()[0].copy(), G.get_rng_state().copy(), G.scalars().beta, G.scalars().nFarPolicySteps)
+        G.close()
+    assert np.array_equal(out["chained"][0], out["separate"][0]) and np.array_equal(out["chained"][1], out["separate"][1])
+    assert out["chained"][2] == out["separate"][2] and out["chained"][3] == out["separate"][3]
