@@ -48,9 +48,14 @@ __global__ __launch_bounds__(256) void lstm_tm_prepare_kernel(RecArgs a) {
 
 // forward of layer j at window step k: samples with tmSteps[b] > k.  512 threads: wavefront w = gate (w & 3) x half (w >> 2) of the reduction
 constexpr int TM_FNT = 512;
-__global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j, int k) {
+// One launch = one DIAGONAL of the (layer, step) grid: blockIdx.z picks (j0 + z, k0 - z) -- layer j at step k needs layer j - 1 at step k
+// and its own step k - 1, both on the diagonal in front, so a window of K steps through nL layers is K + nL - 1 launches instead of K nL
+// (what they write into a shared row -- the block output of the layer below, the recurrent input of the step before -- are different columns)
+__global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, int k0) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int j = j0 + (int)blockIdx.z, k = k0 - (int)blockIdx.z;
   const RecLayer& L = a.L[j];
+  if ((int)blockIdx.x * 16 >= L.nC) return;      // (the grid is as wide as the diagonal's widest layer)
   const int nIn = L.nIn, nC = L.nC, NO = 4 * nC, Kt = nIn + nC, Kt4 = (Kt + 3) & ~3, lds = Kt4 + TM_LDA;
   float* sA = sm;                        // [16][lds]
   float* sG = sA + 16 * lds;             // [8][16][17]
@@ -234,9 +239,11 @@ __global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j, int 
 //                      (1 - f) dLdO + f fp + g.  Its epilogue forms dLdO and dS of the cell whose inputs it completes (as the LSTM
 //                      kernel does): the block below at this step, the last layer at the previous step
 // W is [nIn + nC][2 nC] (forget columns first); rows kept per (sample, step): X = [f | s], Y = output, D = [dF | dS].
-__global__ __launch_bounds__(TM_FNT) void mgu_tm_fwd_kernel(RecArgs a, int j, int k, int phase) {
+__global__ __launch_bounds__(TM_FNT) void mgu_tm_fwd_kernel(RecArgs a, int j0, int k0, int phase) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int j = j0 + (int)blockIdx.z, k = k0 - (int)blockIdx.z;      // (a diagonal per launch: lstm_tm_fwd_kernel)
   const RecLayer& L = a.L[j];
+  if ((int)blockIdx.x * 16 >= L.nC) return;
   const int nIn = L.nIn, nC = L.nC, NO = 2 * nC, Kt = nIn + nC, Kt4 = (Kt + 3) & ~3, lds = Kt4 + TM_LDA;
   float* sA = sm;                        // [16][lds]
   float* sG = sA + 16 * lds;             // [8][16][17]
@@ -444,20 +451,26 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(lstm_tm_prepare_kernel, dim3(a.B), dim3(256), 0, s, a);
   size_t ldsMax = 0;
   for (int j = 0; j < a.nL; ++j) ldsMax = std::max(ldsMax, tmFwdLds(a.L[j]));
+  // diagonal d of the (layer, step) grid: layers jLo .. jLo + nz - 1 at steps d - j
+  auto diag = [&](int d, int* jLo, int* nz, int* gx, size_t* lds) {
+    *jLo = std::max(0, d - (a.nBPTT + 1)); const int jHi = std::min(a.nL - 1, d);
+    *nz = jHi - *jLo + 1; *gx = 0; *lds = 0;
+    for (int j = *jLo; j <= jHi; ++j) { *gx = std::max(*gx, a.L[j].nC / 16); *lds = std::max(*lds, tmFwdLds(a.L[j])); }
+  };
   if (a.gates == 2) {
     hipError_t e2 = ensureDynLds(reinterpret_cast<const void*>(mgu_tm_fwd_kernel), ldsMax); if (e2 != hipSuccess) return e2;
-    for (int k = 0; k <= a.nBPTT + 1; ++k)
-      for (int j = 0; j < a.nL; ++j)
-        for (int ph = 0; ph < 2; ++ph)
-          hipLaunchKernelGGL(mgu_tm_fwd_kernel, dim3(a.L[j].nC / 16, (a.B + 15) / 16), dim3(TM_FNT), tmFwdLds(a.L[j]), s, a, j, k, ph);
+    for (int d = 0; d <= a.nBPTT + 1 + a.nL - 1; ++d) {
+      int jLo, nz, gx; size_t lds; diag(d, &jLo, &nz, &gx, &lds);
+      for (int ph = 0; ph < 2; ++ph)
+        hipLaunchKernelGGL(mgu_tm_fwd_kernel, dim3(gx, (a.B + 15) / 16, nz), dim3(TM_FNT), lds, s, a, jLo, d - jLo, ph);
+    }
     return hipGetLastError();
   }
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(lstm_tm_fwd_kernel), ldsMax); if (e != hipSuccess) return e;
-  for (int k = 0; k <= a.nBPTT + 1; ++k)
-    for (int j = 0; j < a.nL; ++j) {
-      const RecLayer& L = a.L[j];
-      hipLaunchKernelGGL(lstm_tm_fwd_kernel, dim3(L.nC / 16, (a.B + 15) / 16), dim3(TM_FNT), tmFwdLds(L), s, a, j, k);
-    }
+  for (int d = 0; d <= a.nBPTT + 1 + a.nL - 1; ++d) {
+    int jLo, nz, gx; size_t lds; diag(d, &jLo, &nz, &gx, &lds);
+    hipLaunchKernelGGL(lstm_tm_fwd_kernel, dim3(gx, (a.B + 15) / 16, nz), dim3(TM_FNT), lds, s, a, jLo, d - jLo);
+  }
   return hipGetLastError();
 }
 hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s) {
