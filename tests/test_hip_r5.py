@@ -138,3 +138,23 @@ def test_chained_step_equals_the_separate_launches(hip_api, monkeypatch, hidden,
         G.close()
     assert np.array_equal(out["chained"][0], out["separate"][0]) and np.array_equal(out["chained"][1], out["separate"][1])
     assert out["chained"][2] == out["separate"][2] and out["chained"][3] == out["separate"][3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,nEps,lenMin,lenMax", [(2048, 900, 60, 160), (4096, 900, 60, 160), (10000, 1500, 40, 100), (16384, 2600, 30, 50)],
+                         ids=["b2048", "b4096", "b10000", "b16384-crowded"])
+def test_large_batch_sampler_bucket_sort_matches_the_sequential_algorithm(hip_api, B, nEps, lenMin, lenMax):
+    """Sample_uniform::sample (Sampling.cpp:82-96) at local batches above 1024 with replays of 70 - 110 thousand transitions -- the range in
+    which sample.hip: big_sample_kernel sorts the draws by buckets (below 2^16 transitions it keeps the sorting network) -- from a few
+    duplicates per minibatch to a fifth of it (several redraw rounds, merged or sorted again): sorted unique indices, generator state
+    and next-state rows against the oracle, minibatch after minibatch."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair
+    kw = dict(dimS=4, dimA=2, bounded=[1, 0], hidden=(32, 32), nnFunc="Tanh", batchSize=B, maxTotObsNum=400000, randSeed=29)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=31, dimS=4, dimA=2, lenMin=lenMin, lenMax=lenMax, pTerm=0.4), nEps)
+    assert G.scalars().nStoredSteps >= 65536
+    for _ in range(4):
+        G.step(1); O.step(1)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+        assert np.array_equal(G.readback(capi.TAP_STATE), O.readback(capi.TAP_STATE))
