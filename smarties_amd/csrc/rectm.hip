@@ -171,26 +171,35 @@ __device__ __forceinline__ void tmDelta(const RecArgs& a, int j, int k, int b, i
   L.D[r * NO + 3 * nC + c] = og * (1.f - og) * D * co;
   a.tmSD[j][(size_t)b * nC + c] = sd;
 }
+__device__ __forceinline__ int c0tile(int i0, int nIn, bool below) { return (below ? i0 : i0 - nIn) >> 4; }
 // Layer::backward of layer j at step k (Layers.h:123-188): e[b][i] = sum_o W[i][o] D[r][o] for rows i of [W_in; W_rec], samples with T >= k - 1
-// (the deltas of a step a sample does not have are zero rows: lstm_tm_zero_kernel).  The epilogue also forms the deltas whose inputs
-// this product completes, so that the backward pass is ONE launch per (layer, step):
-//   i <  nIn (j > 0)   e + residual path = the error of the block below at THIS step  ->  deltas of (j - 1, k)   (its error from step
-//                      k + 1 was left in tmER[j - 1] by the launch (j - 1, k + 1))
-//   i >= nIn           the error handed to step k - 1: the last layer forms its deltas of (j, k - 1) at once (its error from above is the
-//                      head's gradient at the sample's last step, else zero); the other layers leave it in tmER[j] for the launch (j + 1, k - 1)
+// (the deltas of a step a sample does not have are zero rows: lstm_tm_zero_kernel).  The epilogues also form the cell deltas whose inputs
+// the products complete, and a launch is one ANTI-DIAGONAL of the (layer, step) grid -- blockIdx.z picks (j0 + z, k0 - z):
+//   tiles i <  nIn (j > 0)   e + residual path = the error of the block below at THIS step: one of the two inputs of the deltas of (j - 1, k)
+//   tiles i >= nIn           the error handed to step k - 1: the last layer forms its deltas of (j, k - 1) at once (its error from above is
+//                            the head's gradient at the sample's last step, else zero); for the other layers it is the second input of the
+//                            deltas of (j, k - 1), whose first one comes from the launch (j + 1, k - 1) -- a member of the SAME diagonal.
+// The two producers of a (layer, 16 cells, 16 samples) tile of deltas meet at an arrival counter: the first leaves its values (agent-scope
+// stores, acknowledged before the arrival), the second reads them and forms the deltas (the pattern of dw_wide_kernel's row quarters).
+// Deltas formed on diagonal e are the operands of diagonal e - 1: 18 launches instead of 34 at two layers and 17 steps.
 // Launch (nL - 1, nBPTT + 1) -- a step no sample has -- starts the chain with the last layer's deltas of step nBPTT.
 // Both operands come straight from memory as 16-byte loads (the reduction index permuted inside groups of 16: lane group lc takes
 // o = 16 G + 4 lc + e in sub-step e); wavefront w reduces over gate w's deltas, the four partial tiles meet in LDS.
-__global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j, int k) {
+__global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j0, int k0) {
   __shared__ float sR[4 * 256];
   __shared__ int sT[16];
+  __shared__ unsigned sArr;
+  const int j = j0 + (int)blockIdx.z, k = k0 - (int)blockIdx.z;
+  const int top = a.nL - 1;
+  if (k == a.nBPTT + 1 && j != top) return;      // (only the last layer has a launch at the step behind the windows)
   const RecLayer& L = a.L[j];
   const int nIn = L.nIn, nC = L.nC, NO = 4 * nC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
   const int row0 = j > 0 ? 0 : nIn;      // (no error below the first layer)
-  const int b0 = blockIdx.y * 16, i0 = row0 + blockIdx.x * 16;
-  if (tid < 16) sT[tid] = b0 + tid < a.B ? a.tmT[b0 + tid] : -2;
   const int nRowW = nIn + nC;
+  const int b0 = blockIdx.y * 16, i0 = row0 + blockIdx.x * 16;
+  if (i0 >= nIn + (k > 0 ? nC : 0)) return;      // (the grid is as wide as the diagonal's widest member; no error to a step in front of the first)
+  if (tid < 16) sT[tid] = b0 + tid < a.B ? a.tmT[b0 + tid] : -2;
   const int iw = min(i0 + li, nRowW - 1), bl = min(b0 + li, a.B - 1);
   const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + L.indW + (size_t)iw * NO + wave * nC) + lc;
   const f32x4* dr = reinterpret_cast<const f32x4*>(L.D + ((size_t)bl * a.K + k) * NO + wave * nC) + lc;
@@ -215,18 +224,35 @@ __global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j, int 
   for (int q = 0; q < 4; ++q) sR[wave * 256 + (4 * lc + q) * 16 + li] = acc0[q] + acc1[q];
   __syncthreads();
   const int row = tid >> 4, ii = tid & 15, b = b0 + row, i = i0 + ii, T = sT[row];
-  if (i >= nRowW || T < k - 1) return;
   const float e = (sR[tid] + sR[256 + tid]) + (sR[512 + tid] + sR[768 + tid]);      // (zero for a sample without step k)
-  if (i < nIn) {
-    if (T < k) return;
-    float v = e;
-    if (L.hasRes && i < L.resW) v += L.Rd[((size_t)b * a.K + k) * L.ldR + i] * a.W[L.indWr + i];
-    tmDelta(a, j - 1, k, b, i, T, v, a.tmER[j - 1][(size_t)b * a.L[j - 1].nC + i]);
-  } else if (k > 0) {
-    const int c = i - nIn;
-    if (j == a.nL - 1) tmDelta(a, j, k - 1, b, c, T, k - 1 == T ? a.Dres[(size_t)b * a.ldD + c] : 0.f, e);
-    else a.tmER[j][(size_t)b * nC + c] = e;
+  // the tile's cells: (J, Kc), the same for the whole workgroup (layer inputs and cells come in multiples of 16)
+  const bool below = i0 < nIn;
+  const int J = below ? j - 1 : j, Kc = below ? k : k - 1, c = below ? i : i - nIn;
+  const int nCJ = a.L[J].nC;
+  const bool live = b < a.B && c < nCJ && T >= Kc;      // (this sample has step Kc: its rows of deltas exist)
+  float v = e;
+  if (below && L.hasRes && i < L.resW && b < a.B) v += L.Rd[((size_t)b * a.K + k) * L.ldR + i] * a.W[L.indWr + i];
+  if (!below && j == top) {      // the last layer's deltas of the previous step: nothing else feeds them
+    if (live) tmDelta(a, j, Kc, b, c, T, Kc == T ? a.Dres[(size_t)b * a.ldD + c] : 0.f, v);
+    return;
   }
+  // the other producer of these deltas -- (j - 1, k + 1) for a tile below, (j + 1, k - 1) else -- is a member of this diagonal, unless it
+  // would lie behind the windows
+  if (below && k + 1 > a.nBPTT) {
+    if (live) tmDelta(a, J, Kc, b, c, T, v, 0.f);
+    return;
+  }
+  float* mine = below ? a.tmFP[J] : a.tmER[J];
+  const float* other = below ? a.tmER[J] : a.tmFP[J];
+  const size_t at = (size_t)min(b, a.B - 1) * nCJ + min(c, nCJ - 1);
+  if (b < a.B && c < nCJ) __hip_atomic_store(mine + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): this tile's values are at the coherence point
+  __syncthreads();
+  if (tid == 0) sArr = __hip_atomic_fetch_add(a.tmCtr + a.tmCtrOff[J] + (c0tile(i0, nIn, below)) * (int)gridDim.y + (int)blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if ((sArr & 1u) == 0u) return;          // the first of the two
+  const float o = __hip_atomic_load(other + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (live) tmDelta(a, J, Kc, b, c, T, below ? v : o, below ? o : v);
 }
 
 // ---- MGU layers (Network/Layers/Layer_GRU.h:64-231), the same arrangement ------------------------------------------------------------
@@ -487,14 +513,19 @@ hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s) {
       }
     return hipGetLastError();
   }
-  for (int k = a.nBPTT + 1; k >= 0; --k)
-    for (int j = a.nL - 1; j >= 0; --j) {
-      if (k == a.nBPTT + 1 && j != a.nL - 1) continue;      // (the chain's first launch: the last layer's deltas of step nBPTT)
+  for (int e = a.nL - 1 + a.nBPTT + 1; e >= 0; --e) {      // anti-diagonals j + k = e; the members: layers jLo .. jHi at steps e - j
+    const int jLo = std::max(0, e - (a.nBPTT + 1)), jHi = std::min(a.nL - 1, e);
+    int gx = 0;
+    for (int j = jLo; j <= jHi; ++j) {
+      const int k = e - j;
+      if (k == a.nBPTT + 1 && j != a.nL - 1) continue;
       const RecLayer& L = a.L[j];
       const int row0 = j > 0 ? 0 : L.nIn, nOut = L.nIn + (k > 0 ? L.nC : 0) - row0;
-      if (nOut <= 0) continue;
-      hipLaunchKernelGGL(lstm_tm_bwd_kernel, dim3((nOut + 15) / 16, (a.B + 15) / 16), dim3(256), 0, s, a, j, k);
+      gx = std::max(gx, (nOut + 15) / 16);
     }
+    if (gx <= 0) continue;
+    hipLaunchKernelGGL(lstm_tm_bwd_kernel, dim3(gx, (a.B + 15) / 16, jHi - jLo + 1), dim3(256), 0, s, a, jLo, e - jLo);
+  }
   return hipGetLastError();
 }
 
