@@ -665,8 +665,6 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (h->generic & 4) { h->recFused = false; h->wideDw = false; }
   if (h->generic & 256) { h->convDxRide = false; h->convDwDense = false; }
   if (h->generic & 128) h->bigMm = 0;
-  if (h->bigBatch && (cfg->nn_type != HL_NN_FFNN || cfg->n_conv > 0 || cfg->dataSamplingAlgo != HL_SAMPLE_UNIFORM))
-    return fail(h, HL_ERR_UNSUPPORTED, "local batch > 1024: dense layers and the uniform sampler only");
   h->nApp = cfg->nAppendedObs; h->dIn = h->dS * (1 + h->nApp);
   // the states are gathered by stack_gather_kernel (conv.hip): appended observations, convolutions, large batches -- and states
   // wider than the 512 components the sampler's own gather stages (any width then; the fused steps are for narrower ones)

@@ -30,7 +30,7 @@ hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStr
 // index -> (episode, step) and the truncated next states' rows -- as ONE workgroup of 1024 threads with the candidates in LDS
 // (64 KB at 16384).  The words are drawn 1024 at a time, never more than are still needed, so the generator ends where the
 // sequential algorithm leaves it; compactions run over chunks of 1024 elements in order.  No in-kernel gather (the states are
-// assembled by stack_gather_kernel), no prioritised samplers, no riders: these batches step eagerly.
+// assembled by stack_gather_kernel), no riders: these batches step eagerly or as graphs with the sampler as a branch.
 // ---------------------------------------------------------------------------------------------------------------------
 #define BIG_NT 1024
 #define BIG_MAXB 16384
@@ -142,6 +142,35 @@ __device__ void bigDrawAccepted(unsigned* x, unsigned* xo, int* sPos, unsigned* 
     int ex; const int acc = bigScan(fl, &ex, sWave);
     if (fl) vals[filled + ex] = v;
     filled += acc;
+  }
+  __syncthreads();
+}
+// the prioritised samplers' draws (tail_dev.h: drawPER -- std::discrete_distribution over the cumulative table, for PERseq a step inside
+// the drawn episode): BIG_NT / words-per-value values per round, every value consuming its two (three) generator words in order
+__device__ void bigDrawPER(const SampleArgs& a, unsigned* x, unsigned* xo, int* sPos, unsigned* raw, unsigned* vals, int from, int B) {
+  const int tid = threadIdx.x, Wn = a.perAlgo == HL_SAMPLE_PERSEQ ? 3 : 2, per = BIG_NT / Wn;
+  for (int c0 = from; c0 < B; c0 += per) {
+    const int n = min(per, B - c0);
+    bigDraw(x, xo, sPos, raw, n * Wn);
+    if (tid < n) {
+      const unsigned w0 = raw[Wn * tid], w1 = raw[Wn * tid + 1];
+      double p = ((double)w0 + (double)w1 * 4294967296.0) / 18446744073709551616.0;
+      if (p >= 1.0) p = 0.99999999999999988898;                  // nextafter(1, 0)
+      long long lo = 0;
+      if (a.perN >= 2) {                                          // std::lower_bound: first entry not less than p
+        long long len = a.perN;
+        while (len > 0) { const long long half = len >> 1; if (a.perCp[lo + half] < p) { lo += half + 1; len -= half + 1; } else len = half; }
+      }
+      unsigned v = (unsigned)lo;
+      if (a.perAlgo == HL_SAMPLE_PERSEQ) {
+        float u = (float)raw[Wn * tid + 2] / 4294967296.0f;
+        if (u >= 1.0f) u = 0.99999994f;                           // nextafterf(1, 0)
+        const PosRec rec = a.rp.posRec[lo];
+        v = (unsigned)(rec.prefix + (long long)(unsigned long long)(u * (float)(unsigned long long)(rec.N - 1)));
+      }
+      vals[c0 + tid] = v;
+    }
+    __syncthreads();
   }
   __syncthreads();
 }
@@ -296,12 +325,14 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   BSTMP(0);
   if (a.flatGiven) { for (int i = tid; i < B; i += BIG_NT) vals[i] = (unsigned)a.flatGiven[i]; __syncthreads(); }
   else {
-    bigDrawAccepted(x, xo, sPos, raw, vals, sWave, 0, B, range, threshold);
+    if (a.perAlgo) bigDrawPER(a, x, xo, sPos, raw, vals, 0, B);
+    else bigDrawAccepted(x, xo, sPos, raw, vals, sWave, 0, B, range, threshold);
     BSTMP(1);
     int have = bigSortUnique(vals, tmp, reinterpret_cast<int*>(sT), sWave, B, Bp, range, sc);
     BSTMP(2);
     while (have < B) {                       // duplicates: redraw the missing ones (Sampling.cpp:86-93)
-      bigDrawAccepted(x, xo, sPos, raw, vals, sWave, have, B, range, threshold);
+      if (a.perAlgo) bigDrawPER(a, x, xo, sPos, raw, vals, have, B);
+      else bigDrawAccepted(x, xo, sPos, raw, vals, sWave, have, B, range, threshold);
       have = B - have <= BIG_TAIL ? bigMergeUnique(vals, sT, sWave, have, B - have) : bigSortUnique(vals, tmp, reinterpret_cast<int*>(sT), sWave, B, Bp, range, sc);
     }
   }
@@ -354,7 +385,7 @@ __global__ __launch_bounds__(BIG_NT) void big_sample_kernel(SampleArgs a) {
   }
 }
 hipError_t launch_big_sample(const SampleArgs& a, hipStream_t s) {
-  if (a.B > BIG_MAXB || a.perAlgo || !a.noGather) return hipErrorInvalidValue;
+  if (a.B > BIG_MAXB || !a.noGather) return hipErrorInvalidValue;
   int Bp = 2048; while (Bp < a.B) Bp <<= 1;
   const size_t lds = (size_t)4 * (2 * Bp + 624 + 624 + BIG_NT + BIG_TAIL) + 4 * (BIG_Q * 16 + 4 + 4);
   static size_t have = 0;

@@ -882,7 +882,7 @@ int stepEager(hl_learner* h, const long long* dFlat) {
   }
   else { rc = dropPresample(h); if (rc) return rc; rc = launchSample(h, 0, dFlat, true, s); if (rc) return rc; }
   const bool evict = evictionDue(h);
-  if (h->bigBatch && !dFlat && !exch && !periodic && !evict && ((k + 1) % 1000) != 0) {
+  if (h->bigBatch && !dFlat && !exch && !periodic && !evict && ((k + 1) % 1000) != 0 && h->cfg.dataSamplingAlgo == HL_SAMPLE_UNIFORM) {      // (the prioritised samplers' table follows this step's errors)
     // large batches: the sampler of the NEXT step (one workgroup, hundreds of microseconds) runs beside this step's launches; it
     // starts behind everything queued so far (the buffer it fills was the previous step's) and keeps the generator's state for
     // dropPresample.  Nothing of this step changes what it reads (no removal, no whole-buffer pass).

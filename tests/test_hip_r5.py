@@ -158,3 +158,71 @@ def test_large_batch_sampler_bucket_sort_matches_the_sequential_algorithm(hip_ap
         assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
         assert np.array_equal(G.get_rng_state(), O.get_rng_state())
         assert np.array_equal(G.readback(capi.TAP_STATE), O.readback(capi.TAP_STATE))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,hidden,B,bptt", [(capi.NN_LSTM, (32, 32), 1536, 4), (capi.NN_MGU, (32, 32), 1100, 3), (capi.NN_LSTM, (128, 96), 1280, 3),
+                                                (capi.NN_MGU, (96, 80), 2048, 2), (capi.NN_RNN, (24, 16), 1200, 3)],
+                         ids=["lstm-2x32", "mgu-2x32", "lstm-128x96", "mgu-96x80-b2048", "rnn-24x16"])
+def test_recurrent_nets_at_large_local_batches_match_oracle(hip_api, kind, hidden, B, bptt):
+    """Learner_approximator.cpp:67-77 loops over any batch for any network; the library refused recurrent layers above 1024 samples until
+    round 5.  The 1024-thread sampler, the per-sample / time-step-major recurrent launches over B windows, the panel head, the weight
+    gradients over B x window rows in row chunks: eager and replayed steps against the oracle."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=6, dimA=2, bounded=[1, 0], hidden=hidden, nnFunc="Tanh", batchSize=B, maxTotObsNum=200000, randSeed=37,
+              nn_type=kind, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=bptt)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=41, dimS=6, dimA=2, lenMin=2, lenMax=40, pTerm=0.5), 400)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(5); O.step(5)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_kw,dS", [
+    (dict(dimS=576, dimA=2, nAppendedObs=0, conv=[(12, 12, 4, 8, 3, 1), (10, 10, 8, 16, 4, 2)], hidden=(32,), nnFunc="Tanh"), 576),
+    (dict(dimS=189, dimA=2, nAppendedObs=0, conv=[(9, 7, 3, 5, 3, 1)], hidden=(32, 24), nnFunc="SoftSign"), 189),
+    (dict(dimS=200, dimA=2, bounded=[1, 0], nAppendedObs=3, conv=[(10, 10, 8, 16, 6, 2)], hidden=(40,)), 200),
+    (dict(dimS=7056, dimA=1, adv_kind=capi.ADV_DISCRETE, n_options=6, nAppendedObs=3, nnFunc="SoftSign", hidden=(64,),
+          conv=[(84, 84, 4, 8, 8, 4), (20, 20, 8, 16, 6, 2), (8, 8, 16, 32, 4, 1), (5, 5, 32, 64, 3, 1)]), 7056)],
+    ids=["two-layers-strided", "odd-geometry", "appended-frames", "racer-atari-stack"])
+def test_convolutional_nets_at_large_local_batches_match_oracle(hip_api, cfg_kw, dS):
+    """Convolutional preprocessing above 1024 samples per step (refused until round 5): the stacked rows, the per-layer / sample-resident
+    convolution launches over 2 x B rows, the filter gradients over B samples, the large-batch sampler and bookkeeping -- against the oracle."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    atari = dS == 7056      # (the compile-time geometry of RACER_atari.json; the oracle takes ~10 s per step there: fewer of them)
+    kw = dict(batchSize=1040 if atari else 1200, maxTotObsNum=60000, randSeed=43); kw.update(cfg_kw)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=47, dimS=dS, dimA=kw["dimA"], lenMin=4, lenMax=30, pTerm=0.4), 120 if atari else 250)
+    for _ in range(1 if atari else 2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(2 if atari else 3); O.step(2 if atari else 3)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,B,extra", [("PERrank", 1500, {}), ("PERerr", 2048, {}), ("PERseq", 1280, {}),
+                                          ("PERerr", 1100, dict(nn_type=capi.NN_LSTM, nnFunc="Tanh", nnBPTTseq=4))],
+                         ids=["PERrank-b1500", "PERerr-b2048", "PERseq-b1280", "PERerr-lstm-b1100"])
+def test_prioritised_samplers_at_large_local_batches_follow_the_oracle(hip_api, algo, B, extra):
+    """dataSamplingAlgo PERrank / PERerr / PERseq (Sampling.cpp:101-296) above 1024 samples per step (refused until round 5): the
+    discrete-distribution draws of the 1024-thread sampler -- two (three) generator words per value in order, duplicates redrawn --
+    with the table rebuilt from every step's errors: minibatches, generator state and weights against the oracle."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=B, maxTotObsNum=100000, randSeed=4, dataSamplingAlgo=algo)
+    kw.update(extra)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=13, dimS=5, dimA=2, lenMin=20, lenMax=120, pTerm=0.4), 300)
+    for k in range(6):
+        n = 1 if k % 3 else 2
+        G.step(n); O.step(n)
+        _compare_step(G, O)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
