@@ -95,6 +95,7 @@ hipError_t launch_window_rows(const WinRowsArgs& a, hipStream_t s);
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_backward(const RecArgs& a, hipStream_t s);
 bool rec_tm_ok(const RecArgs& a);                                     // rectm.hip serves this net: a launch per (layer, window step) over the whole minibatch
+bool rec_tm_act_ok(const RecArgs& a);                                 // ... and this acting window (layers beyond 256 cells)
 hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s);
 hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s);
 // window forward + output layer + head + back-propagation through time of a sample as ONE launch (rec.hip: lstm32_step_wave_kernel)

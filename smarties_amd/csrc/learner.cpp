@@ -613,7 +613,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   if (cfg->nn_type != HL_NN_FFNN) {   // rec.hip: 256-thread workgroups looping over gates and cells (REC_GENC, REC_GENIN)
     if (cfg->n_conv <= 0 && (cfg->dimS > 256 || (long long)cfg->dimS * (1 + std::max(cfg->nAppendedObs, 0)) > 1024)) return HL_ERR_UNSUPPORTED;
     // (encoder layers are hidden layers of the same network, Learner_approximator.cpp:149-166: the same limits hold for them)
-    for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > 256) return HL_ERR_UNSUPPORTED;
+    // (LSTM / MGU layers of up to 1024 cells, all multiples of 16, without encoder layers or convolutions in front: the time-step-major
+    //  launches -- rectm.hip -- serve their training windows and their acting windows; checked again where recTm is decided)
+    const bool tmKind = (cfg->nn_type == HL_NN_LSTM || cfg->nn_type == HL_NN_MGU) && cfg->n_encoder == 0 && cfg->n_conv <= 0;
+    for (int j = 0; j < cfg->n_hidden; ++j) if (cfg->hidden[j] > (tmKind && cfg->hidden[j] % 16 == 0 ? 1024 : 256)) return HL_ERR_UNSUPPORTED;
     for (int j = 0; j < cfg->n_encoder; ++j) if (cfg->encoder[j] > 256) return HL_ERR_UNSUPPORTED;
   }
   if (cfg->nAppendedObs < 0 || cfg->n_conv < 0 || cfg->n_conv > HL_MAX_CONV) return HL_ERR_BAD_ARG;
@@ -696,6 +699,8 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
     // 4 x as often)
     if (h->recTm && !(h->generic & 128)) h->bigMm |= 2;
   }
+  if (h->recurrent && !h->recTm)
+    for (int j = 0; j < h->cfg.n_hidden; ++j) if (h->cfg.hidden[j] > 256) return fail(h, HL_ERR_UNSUPPORTED, "recurrent layer wider than 256 cells: every layer must be a multiple of 16 cells (time-step-major launches)");
   h->convB = B; h->convMmax = h->Mmax;
   if (h->recurrent && h->nConv > 0) {
     if (h->nHidden < 2) return fail(h, HL_ERR_UNSUPPORTED, "recurrent network type behind convolutions without a recurrent layer (nnLayerSizes is empty)");

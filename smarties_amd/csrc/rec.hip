@@ -1868,6 +1868,7 @@ template <class K> static hipError_t recLaunch(K kernel, const RecArgs& a, size_
 // (static LDS of the kernels comes on top of the weights; 160 KB per workgroup)
 hipError_t launch_rec_forward(const RecArgs& a, hipStream_t s) {
   if (rec_tm_ok(a)) return launch_rec_tm_forward(a, s);      // wide LSTM layers, training windows: time-step-major on the MFMA (rectm.hip)
+  if (rec_tm_act_ok(a)) return launch_rec_tm_forward(a, s);  // ... and the acting window of nets wider than the kernels below hold
   // (static LDS of the general kernels: up to 46 KB)
   static size_t attr[4] = {0, 0, 0, 0}; const size_t lds = recLdsBytes(a); const bool fit = lds <= 100 * 1024; const bool general = recGeneral(a);
   if (a.gates == 1) { const size_t l1 = rnnLdsBytes(a); return l1 <= 100 * 1024 ? recLaunch(rnn_forward_kernel<true>, a, l1, &attr[0], s) : recLaunch(rnn_forward_kernel<false>, a, 0, &attr[1], s); }

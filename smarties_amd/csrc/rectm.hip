@@ -46,6 +46,23 @@ __global__ __launch_bounds__(256) void lstm_tm_prepare_kernel(RecArgs a) {
   }
 }
 
+// rollout inference of nets whose layers are wider than the per-sample kernels hold (256 cells): the agent's window as ONE sample of the
+// time-step-major launches -- its geometry, the first layer's input rows from the given states, zero recurrent input at its first step
+__global__ __launch_bounds__(256) void lstm_tm_prepare_act_kernel(RecArgs a) {
+  const int tid = threadIdx.x, T = a.actSteps - 1;
+  if (tid == 0) { a.tmT[0] = T; a.tmSteps[0] = T + 1; a.tmNext[0] = -1; }
+  const RecLayer& L0 = a.L[0];
+  const int dIn = L0.nIn;
+  for (int e = tid; e < (T + 1) * dIn; e += 256) {
+    const int k = e / dIn, i = e - k * dIn;
+    L0.A[(size_t)k * L0.ldA + i] = recInputAt(a, true, 0, 0, 0, T, -1, k, i);
+  }
+  for (int j = 0; j < a.nL; ++j) {
+    const RecLayer& L = a.L[j];
+    for (int c = tid; c < L.nC; c += 256) L.A[L.nIn + c] = 0.f;
+  }
+}
+
 // forward of layer j at window step k: samples with tmSteps[b] > k.  512 threads: wavefront w = gate (w & 3) x half (w >> 2) of the reduction
 constexpr int TM_FNT = 512;
 // One launch = one DIAGONAL of the (layer, step) grid: blockIdx.z picks (j0 + z, k0 - z) -- layer j at step k needs layer j - 1 at step k
@@ -462,8 +479,19 @@ __global__ __launch_bounds__(256) void mgu_tm_bwd_kernel(RecArgs a, int j, int k
   }
 }
 
+static bool tmLayersOk(const RecArgs& a);
+// acting (one window of a.actSteps given states) through the same launches: used where a layer is wider than the per-sample kernels hold
+bool rec_tm_act_ok(const RecArgs& a) {
+  if ((a.gates != 4 && a.gates != 2) || a.actStates == nullptr || a.B != 1 || a.tmSteps == nullptr || a.YoutRows != nullptr || a.Xin != nullptr || a.actSteps < 1 || a.actSteps > a.K) return false;
+  bool wide = false;
+  for (int j = 0; j < a.nL; ++j) wide = wide || a.L[j].nC > 256;
+  return wide && tmLayersOk(a);
+}
 bool rec_tm_ok(const RecArgs& a) {
   if ((a.gates != 4 && a.gates != 2) || a.actStates != nullptr || a.tmSteps == nullptr || a.YoutRows != nullptr || a.DresRows != nullptr || a.K < a.nBPTT + 2) return false;
+  return tmLayersOk(a);
+}
+static bool tmLayersOk(const RecArgs& a) {
   for (int j = 0; j < a.nL; ++j) {
     const RecLayer& L = a.L[j];
     if (L.nC % 16 || L.indW % 4 || (L.ldA & 3) || (j > 0 && L.nIn != a.L[j - 1].nC)) return false;
@@ -474,18 +502,21 @@ bool rec_tm_ok(const RecArgs& a) {
 }
 static size_t tmFwdLds(const RecLayer& L) { return (size_t)(16 * (((L.nIn + L.nC + 3) & ~3) + TM_LDA) + 8 * 16 * 17) * 4; }
 hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_tm_prepare_kernel, dim3(a.B), dim3(256), 0, s, a);
+  const bool acting = a.actStates != nullptr;
+  const int kLast = acting ? a.actSteps - 1 : a.nBPTT + 1;      // the last window step any sample can have
+  if (acting) hipLaunchKernelGGL(lstm_tm_prepare_act_kernel, dim3(1), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lstm_tm_prepare_kernel, dim3(a.B), dim3(256), 0, s, a);
   size_t ldsMax = 0;
   for (int j = 0; j < a.nL; ++j) ldsMax = std::max(ldsMax, tmFwdLds(a.L[j]));
   // diagonal d of the (layer, step) grid: layers jLo .. jLo + nz - 1 at steps d - j
   auto diag = [&](int d, int* jLo, int* nz, int* gx, size_t* lds) {
-    *jLo = std::max(0, d - (a.nBPTT + 1)); const int jHi = std::min(a.nL - 1, d);
+    *jLo = std::max(0, d - kLast); const int jHi = std::min(a.nL - 1, d);
     *nz = jHi - *jLo + 1; *gx = 0; *lds = 0;
     for (int j = *jLo; j <= jHi; ++j) { *gx = std::max(*gx, a.L[j].nC / 16); *lds = std::max(*lds, tmFwdLds(a.L[j])); }
   };
   if (a.gates == 2) {
     hipError_t e2 = ensureDynLds(reinterpret_cast<const void*>(mgu_tm_fwd_kernel), ldsMax); if (e2 != hipSuccess) return e2;
-    for (int d = 0; d <= a.nBPTT + 1 + a.nL - 1; ++d) {
+    for (int d = 0; d <= kLast + a.nL - 1; ++d) {
       int jLo, nz, gx; size_t lds; diag(d, &jLo, &nz, &gx, &lds);
       for (int ph = 0; ph < 2; ++ph)
         hipLaunchKernelGGL(mgu_tm_fwd_kernel, dim3(gx, (a.B + 15) / 16, nz), dim3(TM_FNT), lds, s, a, jLo, d - jLo, ph);
@@ -493,7 +524,7 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
     return hipGetLastError();
   }
   hipError_t e = ensureDynLds(reinterpret_cast<const void*>(lstm_tm_fwd_kernel), ldsMax); if (e != hipSuccess) return e;
-  for (int d = 0; d <= a.nBPTT + 1 + a.nL - 1; ++d) {
+  for (int d = 0; d <= kLast + a.nL - 1; ++d) {
     int jLo, nz, gx; size_t lds; diag(d, &jLo, &nz, &gx, &lds);
     hipLaunchKernelGGL(lstm_tm_fwd_kernel, dim3(gx, (a.B + 15) / 16, nz), dim3(TM_FNT), lds, s, a, jLo, d - jLo);
   }

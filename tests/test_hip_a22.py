@@ -64,6 +64,9 @@ WIDE_SHAPES = [  # (layer type, hidden, dimS, nAppendedObs, bptt, batch)
     ("lstm", (256,), 7, 0, 3, 6),           # the widest: 1024 gates, weights read through the L2
     ("lstm", (96, 80, 64), 6, 0, 5, 20),    # three layers time-step-major: the middle layer's deltas have both their producers on one diagonal
     ("lstm", (128, 128), 5, 0, 16, 40),     # the window the shipped preset uses, samples in three blocks of 16 (one partial)
+    ("lstm", (512,), 7, 0, 3, 6),           # beyond the per-sample kernels' 256 cells (round 5): training AND acting windows time-step-major
+    ("lstm", (320, 272), 9, 2, 4, 12),      # ... with appended observations in front
+    ("mgu", (384, 320), 6, 0, 3, 10),
     ("mgu", (128,), 6, 0, 5, 16),
     ("mgu", (200, 72), 9, 0, 4, 9),
     ("mgu", (96, 80), 5, 0, 6, 16),         # time-step-major launches, reductions that are not whole groups of 16 per wavefront
