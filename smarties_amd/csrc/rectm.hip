@@ -73,6 +73,13 @@ __global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, 
   const int j = j0 + (int)blockIdx.z, k = k0 - (int)blockIdx.z;
   const RecLayer& L = a.L[j];
   if ((int)blockIdx.x * 16 >= L.nC) return;      // (the grid is as wide as the diagonal's widest layer)
+  // development time stamps (-DHL_TM_STAMPS, tools/tm_stamps.py): the last layer's workgroup (0, 0) at window step 5
+#ifdef HL_TM_STAMPS
+#define TMSTMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && j == a.nL - 1 && k == 5) a.sc->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define TMSTMP(i) do { } while (0)
+#endif
+  TMSTMP(0);
   const int nIn = L.nIn, nC = L.nC, NO = 4 * nC, Kt = nIn + nC, Kt4 = (Kt + 3) & ~3, lds = Kt4 + TM_LDA;
   float* sA = sm;                        // [16][lds]
   float* sG = sA + 16 * lds;             // [8][16][17]
@@ -88,6 +95,16 @@ __global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, 
   float bv[UN];
 #pragma unroll
   for (int u = 0; u < UN; ++u) { const int i = min(4 * (sBeg + u) + lc, Kt - 1); bv[u] = Wg[(size_t)i * NO]; }      // (rows behind Kt: a valid row, the A element is zero)
+  // what the cell's epilogue reads from memory -- the four biases, the state of the step before, the window's length: requested here, used
+  // behind the products (a load issued there is a round trip of its own at the end of every launch of the chain)
+  const int eRow = (tid >> 4) & 15, eC = c0 + (tid & 15), eB = min(b0 + eRow, a.B - 1);
+  const float* Bi = a.W + L.indB;
+  const long long eR = (long long)eB * a.K + k;
+  const float bi0 = Bi[eC], bi1 = Bi[nC + eC], bi2 = Bi[2 * nC + eC], bi3 = Bi[3 * nC + eC];
+  const float prevStE = k > 0 ? L.Y[(eR - 1) * NO + nC + eC] : 0.f;
+  const int stepsE = a.tmSteps[eB], TE = a.tmT[eB];
+  float wrE = 0.f, brE = 0.f;
+  if (L.hasRes && eC < L.resW) { wrE = a.W[L.indWr + eC]; brE = a.W[L.indBr + eC]; }
   // the A tile: rows r = b K + k, Kt floats each, 16-byte pieces (the row pitch is a multiple of 16 floats); zeros behind Kt
   {
     const int q4 = Kt4 >> 2;
@@ -99,7 +116,9 @@ __global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, 
       *reinterpret_cast<f32x4*>(sA + row * lds + 4 * q) = v;
     }
   }
+  TMSTMP(1);
   __syncthreads();
+  TMSTMP(2);
   bool any = false;
 #pragma unroll
   for (int i = 0; i < 16; ++i) any = any || sAct[i] != 0;
@@ -125,35 +144,37 @@ __global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, 
       for (int u = 0; u < UN; ++u) bv[u] = bn[u];
     }
   }
+  TMSTMP(3);
 #pragma unroll
   for (int q = 0; q < 4; ++q) sG[(wave * 16 + 4 * lc + q) * 17 + li] = acc0[q] + acc1[q];
   __syncthreads();
+  TMSTMP(4);
   // the cell of (sample row, cell c): Layer_LSTM.h:77-125
   if (tid >= 256) return;
   const int row = tid >> 4, cc = tid & 15, b = b0 + row, c = c0 + cc;
   if (!sAct[row]) return;
-  const float* Bi = a.W + L.indB;
   const long long r = (long long)b * a.K + k;
   auto gsum = [&](int g) { return sG[(g * 16 + row) * 17 + cc] + sG[((4 + g) * 16 + row) * 17 + cc]; };
-  const float ci = gsum(0) + Bi[c];
-  const float ig = recSigm(gsum(1) + Bi[nC + c]);
-  const float fg = recSigm(gsum(2) + Bi[2 * nC + c]);
-  const float og = recSigm(gsum(3) + Bi[3 * nC + c]);
-  const float prevSt = k > 0 ? L.Y[(r - 1) * NO + nC + c] : 0.f;
+  const float ci = gsum(0) + bi0;
+  const float ig = recSigm(gsum(1) + bi1);
+  const float fg = recSigm(gsum(2) + bi2);
+  const float og = recSigm(gsum(3) + bi3);
+  const float prevSt = prevStE;
   const float st = ci * ig + prevSt * fg;
   const float co = actEval(HL_FUNC_TANH, st);
   const float out = og * co;
   L.X[r * NO + c] = ci; L.X[r * NO + nC + c] = ig; L.X[r * NO + 2 * nC + c] = fg; L.X[r * NO + 3 * nC + c] = og;
   L.Y[r * NO + c] = out; L.Y[r * NO + nC + c] = st; L.Y[r * NO + 2 * nC + c] = co;
   float blk = out;                                       // ParametricResidualLayer::forward (Layers.h:347-361)
-  if (L.hasRes && c < L.resW) blk += sA[row * lds + c] * a.W[L.indWr + c] + a.W[L.indBr + c];
-  const int steps = a.tmSteps[b], T = a.tmT[b];
+  if (L.hasRes && c < L.resW) blk += sA[row * lds + c] * wrE + brE;
+  const int steps = stepsE, T = TE;
   if (k + 1 < steps) L.A[(r + 1) * L.ldA + nIn + c] = out;          // the next step's recurrent input
   if (j + 1 < a.nL) { const RecLayer& U = a.L[j + 1]; U.A[r * U.ldA + c] = blk; }      // the layer above, same step
   else {
     if (k == T) a.Yout[(size_t)b * a.ldY + c] = blk;
     else if (k == T + 1) a.Yout[(size_t)a.tmNext[b] * a.ldY + c] = blk;
   }
+  TMSTMP(5);
 }
 
 // rows a sample does not have (k > T, the next state's row included): zero deltas -- their stale inputs add nothing to the gradients
