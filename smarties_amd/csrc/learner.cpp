@@ -81,7 +81,7 @@ struct hl_learner {
   ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
   bool recTm = false; int* tmT = nullptr; int* tmSteps = nullptr; int* tmNext = nullptr;      // wide LSTM layers: time-step-major launches (rectm.hip)
   float* tmER[HL_MAX_HIDDEN] = {}; float* tmSD[HL_MAX_HIDDEN] = {}; float* tmFP[HL_MAX_HIDDEN] = {};
-  unsigned* tmCtr = nullptr; int tmCtrOff[HL_MAX_HIDDEN] = {};
+  unsigned* tmCtr = nullptr; int tmCtrOff[HL_MAX_HIDDEN] = {}; float* tmET[HL_MAX_HIDDEN] = {};
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1; one more for the time-step-major launches)
   int recWin = 0;                          // ... steps of a window: nnBPTTseq + 1
   // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
@@ -784,7 +784,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(devAlloc(&L.D, R * g * d.size + 16));
       if (d.hasRes) HIPCK(devAlloc(&L.Rd, R * L.ldR));
       if (d.lstm == 2) HIPCK(devAlloc(&L.A2, R * L.ldA2 + 16));
-      if (h->recTm) { HIPCK(devAlloc(&h->tmER[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmSD[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmFP[j], (size_t)B * d.size)); }
+      if (h->recTm) { HIPCK(devAlloc(&h->tmER[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmSD[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmFP[j], (size_t)B * d.size)); HIPCK(devAlloc(&h->tmET[j], (size_t)B * d.size)); }
     }
     if (h->recTm) {
       HIPCK(devAlloc(&h->tmT, (size_t)B)); HIPCK(devAlloc(&h->tmSteps, (size_t)B)); HIPCK(devAlloc(&h->tmNext, (size_t)B));
@@ -951,7 +951,7 @@ int hl_destroy(hl_learner* h) {
   for (void* q : {(void*)h->segY, (void*)h->segDres, (void*)h->segScratch}) if (q) hipFree(q);
   for (void* q : {(void*)h->winSlot, (void*)h->winT, (void*)h->winNextSrc, (void*)h->scW}) if (q) hipFree(q);
   for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->rec[j].A, h->rec[j].X, h->rec[j].Y, h->rec[j].D, h->rec[j].Rd, h->rec[j].A2}) if (q) hipFree(q);
-  for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->tmER[j], h->tmSD[j], h->tmFP[j]}) if (q) hipFree(q);
+  for (int j = 0; j < HL_MAX_HIDDEN; ++j) for (float* q : {h->tmER[j], h->tmSD[j], h->tmFP[j], h->tmET[j]}) if (q) hipFree(q);
   for (void* q : {(void*)h->tmT, (void*)h->tmSteps, (void*)h->tmNext, (void*)h->tmCtr}) if (q) hipFree(q);
   for (void* p : ptrs) if (p) hipFree(p);
   for (int l = 0; l < h->nConv; ++l) { ConvGeo& g = h->cg[l];

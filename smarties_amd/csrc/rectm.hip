@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j0, int
     if (live) tmDelta(a, J, Kc, b, c, T, v, 0.f);
     return;
   }
-  float* mine = below ? a.tmFP[J] : a.tmER[J];
-  const float* other = below ? a.tmER[J] : a.tmFP[J];
+  float* mine = below ? a.tmET[J] : a.tmER[J];
+  const float* other = below ? a.tmER[J] : a.tmET[J];
   const size_t at = (size_t)min(b, a.B - 1) * nCJ + min(c, nCJ - 1);
   if (b < a.B && c < nCJ) __hip_atomic_store(mine + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): this tile's values are at the coherence point
@@ -398,11 +398,16 @@ __device__ __forceinline__ void tmMguOpen(const RecArgs& a, int j, int k, int b,
   a.tmSD[j][(size_t)b * nC + c] = dLdO;
   L.D[r * NO + nC + c] = dLdO * f * (1.f - st * st);
 }
-__global__ __launch_bounds__(256) void mgu_tm_bwd_kernel(RecArgs a, int j, int k, int phase) {
+// (a launch is one anti-diagonal of the (layer, step) grid and one phase, blockIdx.z picks (j0 + z, k0 - z): lstm_tm_bwd_kernel)
+__global__ __launch_bounds__(256) void mgu_tm_bwd_kernel(RecArgs a, int j0, int k0, int phase) {
   __shared__ float sR[4 * 256];
   __shared__ int sT[16];
+  __shared__ unsigned sArr;
+  const int j = j0 + (int)blockIdx.z, k = k0 - (int)blockIdx.z, top = a.nL - 1;
+  if (k == a.nBPTT + 1 && (j != top || phase == 0)) return;      // (behind the windows: the last layer's phase 1 only -- it starts the chain)
   const RecLayer& L = a.L[j];
   const int nIn = L.nIn, nC = L.nC, NO = 2 * nC;
+  if (phase == 0 ? (int)blockIdx.x * 16 >= nC : (j > 0 ? 0 : nIn) + (int)blockIdx.x * 16 >= nIn + (k > 0 ? nC : 0)) return;      // (the grid is as wide as the diagonal's widest member)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lc = lane >> 4;
   const int b0 = blockIdx.y * 16;
   if (tid < 16) sT[tid] = b0 + tid < a.B ? a.tmT[b0 + tid] : -2;
@@ -480,24 +485,41 @@ __global__ __launch_bounds__(256) void mgu_tm_bwd_kernel(RecArgs a, int j, int k
   for (int q = 0; q < 4; ++q) sR[wave * 256 + (4 * lc + q) * 16 + li] = acc0[q] + acc1[q];
   __syncthreads();
   const int row = tid >> 4, ii = tid & 15, b = b0 + row, i = i0 + ii, T = sT[row];
-  if (i >= nRowW || T < k - 1) return;
   const float e = (sR[tid] + sR[256 + tid]) + (sR[512 + tid] + sR[768 + tid]);      // (zero for a sample without step k)
-  if (i < nIn) {
-    if (T < k) return;
-    float v = e;
-    if (L.hasRes && i < L.resW) v += L.Rd[((size_t)b * a.K + k) * L.ldR + i] * a.W[L.indWr + i];
-    tmMguOpen(a, j - 1, k, b, i, T, v, a.tmER[j - 1][(size_t)b * a.L[j - 1].nC + i]);
-  } else if (k > 0) {
-    const int c = i - nIn;
-    float rec = 0.f;
-    if (T >= k) {
+  // the tile's cells (J, Kc) and their two producers: as in lstm_tm_bwd_kernel
+  const bool below = i0 < nIn;
+  const int J = below ? j - 1 : j, Kc = below ? k : k - 1, c = below ? i : i - nIn;
+  const int nCJ = a.L[J].nC;
+  const bool live = b < a.B && c < nCJ && T >= Kc;
+  float v = e;
+  if (below) { if (L.hasRes && i < L.resW && b < a.B) v += L.Rd[((size_t)b * a.K + k) * L.ldR + i] * a.W[L.indWr + i]; }
+  else {
+    v = 0.f;
+    if (b < a.B && c < nC && T >= k) {
       const long long r = (long long)b * a.K + k;
       const float f = L.X[r * NO + c];
-      rec = (1.f - f) * a.tmSD[j][(size_t)b * nC + c] + f * a.tmFP[j][(size_t)b * nC + c] + e;
+      v = (1.f - f) * a.tmSD[j][(size_t)b * nC + c] + f * a.tmFP[j][(size_t)b * nC + c] + e;
     }
-    if (j == a.nL - 1) tmMguOpen(a, j, k - 1, b, c, T, k - 1 == T ? a.Dres[(size_t)b * a.ldD + c] : 0.f, rec);
-    else a.tmER[j][(size_t)b * nC + c] = rec;
   }
+  if (!below && j == top) {
+    if (live) tmMguOpen(a, j, Kc, b, c, T, Kc == T ? a.Dres[(size_t)b * a.ldD + c] : 0.f, v);
+    return;
+  }
+  if (below && k + 1 > a.nBPTT) {      // (no launch of the layer below behind the windows: these deltas have one producer)
+    if (live) tmMguOpen(a, J, Kc, b, c, T, v, 0.f);
+    return;
+  }
+  float* mine = below ? a.tmET[J] : a.tmER[J];
+  const float* other = below ? a.tmER[J] : a.tmET[J];
+  const size_t at = (size_t)min(b, a.B - 1) * nCJ + min(c, nCJ - 1);
+  if (b < a.B && c < nCJ) __hip_atomic_store(mine + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (tid == 0) sArr = __hip_atomic_fetch_add(a.tmCtr + a.tmCtrOff[J] + c0tile(i0, nIn, below) * (int)gridDim.y + (int)blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if ((sArr & 1u) == 0u) return;          // the first of the two
+  const float o = __hip_atomic_load(other + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (live) tmMguOpen(a, J, Kc, b, c, T, below ? v : o, below ? o : v);
 }
 
 static bool tmLayersOk(const RecArgs& a);
@@ -554,15 +576,20 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
 hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(lstm_tm_zero_kernel, dim3(a.B), dim3(256), 0, s, a);
   if (a.gates == 2) {
-    for (int k = a.nBPTT + 1; k >= 0; --k)
-      for (int j = a.nL - 1; j >= 0; --j) {
+    for (int e = a.nL - 1 + a.nBPTT + 1; e >= 0; --e) {      // anti-diagonals j + k = e: phase 0 of every member, then phase 1 of every member
+      const int jLo = std::max(0, e - (a.nBPTT + 1)), jHi = std::min(a.nL - 1, e);
+      int gx0 = 0, gx1 = 0;
+      for (int j = jLo; j <= jHi; ++j) {
+        const int k = e - j;
+        if (k == a.nBPTT + 1 && j != a.nL - 1) continue;
         const RecLayer& L = a.L[j];
-        const bool first = k == a.nBPTT + 1;      // (the chain's first launch: the last layer's dLdO and state deltas of step nBPTT)
-        if (first && j != a.nL - 1) continue;
-        if (!first) hipLaunchKernelGGL(mgu_tm_bwd_kernel, dim3(L.nC / 16, (a.B + 15) / 16), dim3(256), 0, s, a, j, k, 0);
         const int row0 = j > 0 ? 0 : L.nIn, nOut = L.nIn + (k > 0 ? L.nC : 0) - row0;
-        if (nOut > 0) hipLaunchKernelGGL(mgu_tm_bwd_kernel, dim3((nOut + 15) / 16, (a.B + 15) / 16), dim3(256), 0, s, a, j, k, 1);
+        if (k != a.nBPTT + 1) gx0 = std::max(gx0, L.nC / 16);
+        gx1 = std::max(gx1, (nOut + 15) / 16);
       }
+      if (gx0 > 0) hipLaunchKernelGGL(mgu_tm_bwd_kernel, dim3(gx0, (a.B + 15) / 16, jHi - jLo + 1), dim3(256), 0, s, a, jLo, e - jLo, 0);
+      if (gx1 > 0) hipLaunchKernelGGL(mgu_tm_bwd_kernel, dim3(gx1, (a.B + 15) / 16, jHi - jLo + 1), dim3(256), 0, s, a, jLo, e - jLo, 1);
+    }
     return hipGetLastError();
   }
   for (int e = a.nL - 1 + a.nBPTT + 1; e >= 0; --e) {      // anti-diagonals j + k = e; the members: layers jLo .. jHi at steps e - j

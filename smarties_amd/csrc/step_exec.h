@@ -800,7 +800,7 @@ RecArgs recArgs(hl_learner* h, int parity, int seg = -1) {
   ra.nL = jEnd - jBeg;
   ra.K = h->recK; ra.nBPTT = h->recWin - 1; ra.W = h->W; ra.gates = h->hid[jBeg].lstm; ra.func = h->cfg.nnFunc; ra.nApp = (j0 || seg == 1) ? 0 : h->nApp;
   for (int j = jBeg; j < jEnd; ++j) ra.L[j - jBeg] = h->rec[j];
-  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; ra.tmFP[j - jBeg] = h->tmFP[j]; ra.tmCtrOff[j - jBeg] = h->tmCtrOff[j]; } ra.tmCtr = h->tmCtr; }
+  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; ra.tmFP[j - jBeg] = h->tmFP[j]; ra.tmCtrOff[j - jBeg] = h->tmCtrOff[j]; ra.tmET[j - jBeg] = h->tmET[j]; } ra.tmCtr = h->tmCtr; }
   if (seg == 1) { ra.Xin = h->segY; ra.ldXin = h->ldSeg; }
   else if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
   if (seg == 0) { ra.YoutRows = h->segY; ra.ldYR = h->ldSeg; ra.DresRows = h->segDres; ra.ldDR = h->ldSeg; }

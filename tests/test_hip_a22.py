@@ -71,6 +71,7 @@ WIDE_SHAPES = [  # (layer type, hidden, dimS, nAppendedObs, bptt, batch)
     ("mgu", (200, 72), 9, 0, 4, 9),
     ("mgu", (96, 80), 5, 0, 6, 16),         # time-step-major launches, reductions that are not whole groups of 16 per wavefront
     ("mgu", (256, 128), 7, 0, 3, 20),       # ... a partial block of 16 samples
+    ("mgu", (96, 80, 64), 6, 0, 5, 20),     # three layers: the middle layer's deltas have both their producers on one diagonal
     ("rnn", (130, 70), 5, 0, 5, 12),        # dense layers with a recurrent term, more than 64 cells
     ("lstm", (32, 32), 5, 2, 4, 16),        # appended observations in front of the shipped recurrent shape
     ("lstm", (24,), 40, 7, 6, 10),          # 320 inputs
