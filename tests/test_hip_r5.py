@@ -226,3 +226,25 @@ def test_prioritised_samplers_at_large_local_batches_follow_the_oracle(hip_api, 
         assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
         assert np.array_equal(G.get_rng_state(), O.get_rng_state())
     assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [capi.NN_LSTM, capi.NN_MGU], ids=["lstm", "mgu"])
+def test_time_step_major_backward_by_diagonals_is_deterministic(hip_api, kind):
+    """rectm.hip: the two producers of a tile of cell deltas run in one launch and whichever arrives second forms the deltas -- from the same
+    two inputs either way: two runs must end bit-identical (weights, generator, beta)."""
+    from oracle_api import synth_cfg, fill_synth
+    sc = synth_cfg(seed=7, dimS=6, dimA=2, lenMin=5, lenMax=60, pTerm=0.4)
+
+    def run():
+        L = capi.Learner(hip_api, capi.make_config(dimS=6, dimA=2, bounded=[1, 0], hidden=(128, 96, 64), nnFunc="Tanh", batchSize=72, maxTotObsNum=50000, randSeed=3,
+                                                   nn_type=kind, adv_kind=capi.ADV_GAUSSIAN, nnBPTTseq=9))
+        L.init_weights(); fill_synth(L, sc, 200); L.initialize()
+        for n in (1, 5, 30):
+            L.step(n)
+        L.sync()
+        out = (L.get_params()[0].copy(), L.get_rng_state().copy(), L.scalars().beta)
+        L.close()
+        return out
+    a, b = run(), run()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
