@@ -13,3 +13,5 @@ for k in lstm mgu; do for n in 128 256; do
 done; done
 for k in lstm mgu; do for n in 128 256; do KIND=$k timeout 200 python tools/lstm_wide_time.py $n 2>&1 | tail -1; done; done | tee $O/wide_time_untraced.txt
 timeout 300 python tools/glider_time.py 2>&1 | tail -1 | tee $O/glider_time.txt
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/glider -- python /root/repo/tools/glider_time.py 2>&1 | grep shape)
+cp $(ls $O/glider/*/*kernel_stats.csv | head -1) $O/glider_kernel_stats.csv; rm -rf $O/glider
