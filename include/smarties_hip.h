@@ -157,7 +157,7 @@ typedef struct hl_config {
                                         generators from the main one (ExecutionInfo.cpp:392-393), which shifts the stream all
                                         samples and weights are drawn from by T - 1 draws; per Adam step the main generator
                                         gives one draw whatever T is (thread 0's, Network/Optimizer.cpp:139) */
-  int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..32) of the ONE
+  int32_t n_options;                 /* HL_ADV_DISCRETE: number of action options (MDP.maxActionLabel, 2..64) of the ONE
                                         discrete action variable (dimA = 1; actions hold label + 0.1 as in
                                         Core/StateAction.h:322-341, policies the nOptions probabilities); else 0 */
   int32_t nn_type;                   /* HL_NN_*: settings nnType of the hidden layers                  */

@@ -22,19 +22,20 @@ namespace hl {
 // first wavefront does the fp64 head.  Four times the workgroups, a quarter of the serial work and of the bytes per wavefront
 // (device time stamps on the RACER_atari shape, one wavefront per sample: 6.6 us until the loads are in, 2.7 us output layer,
 // 3.0 us head, 4.2 us write-backs and back-propagation).
-constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4 + 5 * 72 * 4;
+constexpr int HEAD_LDD = 136;      // staged deltas / pre-activations per sample: 1 + 2 x 64 options at most
+constexpr int HEAD_LDS = 4 * HEAD_MAXOUT * 8 + 4 * HEAD_LDD * 4 + 5 * HEAD_LDD * 4;
 // `row`: the minibatch row of this wavefront (SPLIT = 1) / of this workgroup (SPLIT = 4: the same for its four wavefronts; the barriers
 // inside are then passed by all of them or by none)
 template <int HQ, int SPLIT>
 __device__ __forceinline__ void headBody(const HeadArgs& a, const int row, unsigned char* smem) {
   double (*sO)[HEAD_MAXOUT] = reinterpret_cast<double (*)[HEAD_MAXOUT]>(smem);
-  float (*sDelta)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8);
-  float (*sXo)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4);   // pre-activations of the output layer (nnOutputFunc)
+  float (*sDelta)[HEAD_LDD] = reinterpret_cast<float (*)[HEAD_LDD]>(smem + 4 * HEAD_MAXOUT * 8);
+  float (*sXo)[HEAD_LDD] = reinterpret_cast<float (*)[HEAD_LDD]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * HEAD_LDD * 4);   // pre-activations of the output layer (nnOutputFunc)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ws = SPLIT == 4 ? 0 : wave;                 // slot of this wavefront's sample in the shared arrays
   const int part = SPLIT == 4 ? wave : 0;               // which quarter of the hidden units
   const int kBase = part * 64 * HQ;
-  float (*sPart)[72] = reinterpret_cast<float (*)[72]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * 72 * 4) + 1;   // SPLIT: partial outputs of the four wavefronts, rows 1..4 behind sXo[0]
+  float (*sPart)[HEAD_LDD] = reinterpret_cast<float (*)[HEAD_LDD]>(smem + 4 * HEAD_MAXOUT * 8 + 4 * HEAD_LDD * 4) + 1;   // SPLIT: partial outputs of the four wavefronts, rows 1..4 behind sXo[0]
   const DevScalars* sc = a.sc;
   HSTAMP(0);
   // (a minibatch row's replay slot is requested beside the row count, not behind the test on it: one dependent round trip less in front

@@ -248,3 +248,26 @@ def test_time_step_major_backward_by_diagonals_is_deterministic(hip_api, kind):
         return out
     a, b = run(), run()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nOpt,hidden,kind", [(40, (64, 64), capi.NN_FFNN), (64, (96,), capi.NN_FFNN), (48, (160, 96, 64), capi.NN_FFNN), (36, (32, 32), capi.NN_LSTM)],
+                         ids=["40-options", "64-options-one-layer", "48-options-chained", "36-options-lstm"])
+def test_more_than_32_discrete_options_match_oracle(hip_api, nOpt, hidden, kind):
+    """Math/Discrete_policy.h:19-208 and Discrete_advantage have no option limit; the library served 32 (one option per lane of a
+    16-lane row, two chunks) until round 5.  Up to 64 options on the head launch (one option per lane of the sample's wavefront):
+    per-sample taps, write-backs and the updated weights against the oracle, rollout outputs included."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=8, dimA=1, bounded=[0], hidden=hidden, nnFunc="Tanh", batchSize=48, maxTotObsNum=20000, randSeed=53,
+              adv_kind=capi.ADV_DISCRETE, n_options=nOpt, nn_type=kind, nnBPTTseq=4)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=57, dimS=8, dimA=1, lenMin=4, lenMax=50, pTerm=0.5), 80)
+    for _ in range(2):
+        G.step(1); O.step(1)
+        _compare_step(G, O)
+    G.step(12); O.step(12)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+    if kind == capi.NN_FFNN:
+        st = np.random.default_rng(5).standard_normal((9, 8)).astype(np.float32)
+        assert relinf(G.forward(st), O.forward(st)) < TOL32
