@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HOT = ("dw_table_kernel", "fused_fwd_head_dx_kernel", "fused_wide_kernel", "panel_head_kernel", "lstm32_step_wave_kernel",
        "mgu32_step_wave_kernel", "lstm32_forward_wave_kernel", "lstm32_backward_wave_kernel", "conv_", "gemm_os_kernel",
        "gemm16_kernel", "dw_wide_kernel", "head_kernel_t", "big_", "splitk_reduce_kernel", "step_tail_kernel", "xchg_", "adam_kernel",
-       "rec_step_fused", "lstm_", "mgu_", "rec_")
+       "rec_step_fused", "lstm_", "mgu_", "rec_", "step_chain_kernel", "fwd_chain_kernel", "stack_gather")
 # reserved-and-untouched frame slots: kernel -> bytes per lane at most (checked against the ISA below)
 # (prefix match: which instantiation of panel_head_kernel gets such a slot changes with every edit of the kernel)
 DEAD_SLOT = {"fused_wide_kernel<256, 2>": 64, "step_tail_kernel": 64, "panel_head_kernel<": 64}
