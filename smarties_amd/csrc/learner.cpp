@@ -82,6 +82,7 @@ struct hl_learner {
   bool recTm = false; int* tmT = nullptr; int* tmSteps = nullptr; int* tmNext = nullptr;      // wide LSTM layers: time-step-major launches (rectm.hip)
   float* tmER[HL_MAX_HIDDEN] = {}; float* tmSD[HL_MAX_HIDDEN] = {}; float* tmFP[HL_MAX_HIDDEN] = {};
   unsigned* tmCtr = nullptr; int tmCtrOff[HL_MAX_HIDDEN] = {}; float* tmET[HL_MAX_HIDDEN] = {};
+  int tmMinCells = 64;      // layers wider than this: time-step-major
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1; one more for the time-step-major launches)
   int recWin = 0;                          // ... steps of a window: nnBPTTseq + 1
   // hl_config::encoder_rnn: the first recSplit recurrent layers are plain recurrent ("RNN") ones under MGU layers.  The window kernels
@@ -690,7 +691,10 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
   // of their own (one row more per sample)
   if (h->recurrent && (cfg->nn_type == HL_NN_LSTM || cfg->nn_type == HL_NN_MGU) && !(h->generic & 4) && cfg->n_encoder == 0 && cfg->n_conv == 0) {
     bool wide = false, ok = true;
-    for (int j = 0; j < h->cfg.n_hidden; ++j) { wide = wide || h->cfg.hidden[j] > 64; ok = ok && h->cfg.hidden[j] % 16 == 0; }
+    // (measured again with a launch per diagonal, batch 128, 17 steps: LSTM 2 x 64 cells 314 us per-sample against 284 time-step-major, 2 x 48: 204 / 282;
+    //  MGU 2 x 64: 238 / 488 -- the time-step-major chain has a floor of 37 (LSTM) / 74 (MGU) dependent launches)
+    h->tmMinCells = cfg->nn_type == HL_NN_LSTM ? 48 : 64;
+    for (int j = 0; j < h->cfg.n_hidden; ++j) { wide = wide || h->cfg.hidden[j] > h->tmMinCells; ok = ok && h->cfg.hidden[j] % 16 == 0; }
     // (the crossover, measured at batch 128 and 17 steps: 2 x 64 cells 325 us with the per-sample kernels against 452 time-step-major, 2 x 96: 631 against 499)
     h->recTm = wide && ok;
     if (h->recTm) h->recK += 1;
