@@ -271,3 +271,26 @@ def test_more_than_32_discrete_options_match_oracle(hip_api, nOpt, hidden, kind)
     if kind == capi.NN_FFNN:
         st = np.random.default_rng(5).standard_normal((9, 8)).astype(np.float32)
         assert relinf(G.forward(st), O.forward(st)) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,hidden,dS", [(512, (64, 64), 9), (1024, (256, 256), 17), (768, (128, 128), 60)], ids=["b512-2x64", "b1024-2x256", "b768-wide-states"])
+def test_fused_steps_at_512_to_1024_samples_match_oracle(hip_api, B, hidden, dS):
+    """Two-kernel fused steps at 512 - 1024 samples (two to four workgroups per CU, the sampler riders' chains two to four times as
+    long as at the bench's 256): eager steps, replayed graphs of several lengths, a discarded pre-drawn minibatch (a given one in
+    between): minibatches, generator state and weights against the oracle."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=dS, dimA=3, bounded=[1, 0, 0], hidden=hidden, nnFunc="SoftSign", batchSize=B, maxTotObsNum=200000, randSeed=61)
+    G, O = _pair(hip_api, kw, synth_cfg(seed=63, dimS=dS, dimA=3, lenMin=20, lenMax=120, pTerm=0.4), 300)
+    for n in (1, 1, 7, 20):
+        G.step(n); O.step(n)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert np.array_equal(G.get_rng_state(), O.get_rng_state())
+    _compare_step(G, O)
+    flat = np.sort(np.random.default_rng(1).choice(G.scalars().nStoredSteps, size=B, replace=False)).astype(np.int64)
+    G.step(1, flat=flat); O.step(1, flat=flat)
+    _compare_step(G, O)
+    G.step(12); O.step(12)
+    assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT)) and np.array_equal(G.get_rng_state(), O.get_rng_state())
+    assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
