@@ -4,6 +4,8 @@
 // advantage: head_rows.h, one (sample, component) per lane of a 16-lane row, further components in further chunks).
 // BASELINE config 3 -- Humanoid through the gym wrapper, 257 states, 17 unbounded actions, 2 x 256, local batch 32 per replica --
 // ran the generic launches (forward chain, head, dX, dW: 33.6 us per step); with this kernel it takes the two-kernel step.
+// NLH = 3 (end of round 5): a THIRD equal hidden block (settings/RACER_glider.json: 3 x 128, Gaussian advantage: 40.2 -> 27.4 us per step) --
+// one more tile stage, panel barrier and read-back each way; its panels and W2 tiles in LDS of their own (fwGeo: oY4 ...).
 //
 // Placement and exchange are fused.hip's: a 16-row PANEL of the minibatch belongs to the HT = H / 16 workgroups with the same
 // blockIdx % 8 (one XCD, one L2); every workgroup takes its 16-column tile of h1 = f(S W0 + b0), panel barrier, reads the panel's
@@ -26,8 +28,8 @@ constexpr int FW_MAXNT = 5; // 16-column tiles of the output layer
 #define WSTMP(i) do { } while (0)
 #endif
 
-struct FwGeo { int dSp, LS, NTo, LD, LO; size_t oR2, oR3, oWo, oS, oRed, oVec, oO, oXo, oDelta, oMisc, oAct, oBeta, oT, total; };
-__host__ __device__ inline FwGeo fwGeo(int dS, int H, int nDense, int nOut, int ldWo, int nAdv) {
+struct FwGeo { int dSp, LS, NTo, LD, LO; size_t oR2, oR3, oWo, oS, oRed, oVec, oO, oXo, oDelta, oMisc, oAct, oBeta, oT, oY4, oF3, oBx2, oW2c, oVec2, total; };
+__host__ __device__ inline FwGeo fwGeo(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int nLH = 2) {
   FwGeo g;
   g.dSp = (dS + 3) & ~3; g.LS = g.dSp + 2;
   g.NTo = (nDense + 15) / 16; g.LD = g.NTo * 16 + 6; g.LO = nOut | 1;
@@ -45,6 +47,11 @@ __host__ __device__ inline FwGeo fwGeo(int dS, int H, int nDense, int nOut, int 
   g.oAct = (o + 7) & ~(size_t)7; o = g.oAct + 16 * 8;
   g.oBeta = o; o += 16;
   g.oT = o; o += 256 * 4;
+  g.oY4 = g.oF3 = g.oBx2 = g.oW2c = g.oVec2 = o;
+  if (nLH == 3) {      // a third hidden block: its output panel, f'(x3) -> delta_x3 panel, W2 row tile, W2 column tile, residual vectors
+    g.oY4 = o; o += (size_t)16 * WLDR * 4; g.oF3 = o; o += (size_t)16 * WLDR * 4; g.oBx2 = o; o += (size_t)16 * WLDR * 4;
+    g.oW2c = o; o += (size_t)H * 16 * 4; g.oVec2 = o; o += (size_t)2 * H * 4;
+  }
   g.total = o > (size_t)TAIL_LDS_BYTES ? o : (size_t)TAIL_LDS_BYTES;
   return g;
 }
@@ -70,7 +77,7 @@ __device__ __forceinline__ f32x4 fwWaveMma(FA fa, FB fb) {
 }
 
 // H in {64, 128, 256}; NCH: chunks of 16 action components / options per sample row
-template <int H, int NCH>
+template <int H, int NCH, int NLH>
 __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadArgs ha, ExtraArgs extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (blockIdx.x < 8) {      // riders, as in fused.hip: 8 of them keep blockIdx % 8 == XCD for the panels
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   const DevScalars* sc = a.sc;
   DevScalars* scw = a.sc;
   const int dS = a.dS, B = a.B, dA = a.dA, nDense = a.nDense, nOut = a.nOut, ldWo = ha.ldWo, nSig = ha.nSig;
-  const FwGeo g = fwGeo(dS, H, nDense, nOut, ldWo, ha.nAdv);
+  const FwGeo g = fwGeo(dS, H, nDense, nOut, ldWo, ha.nAdv, NLH);
   const int dSp = g.dSp, LS = g.LS, NTo = g.NTo, LD = g.LD, LO = g.LO;
   const int func = __builtin_amdgcn_readfirstlane(a.func);
   int resN = a.resN, ldA0 = a.ldA0, ldA1 = a.ldA1;
@@ -117,6 +124,12 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   float* sT = reinterpret_cast<float*>(smem + g.oT);                 // [16][16] own-tile scratch (x1)
   double* sTq = reinterpret_cast<double*>(sR2);                      // Gaussian advantage scratch (the y3 panel is dead by then)
   double* sTr = sTq + 16 * 64;
+  // (NLH == 3) the third block's panels and tiles
+  float* sY4 = reinterpret_cast<float*>(smem + g.oY4);               // [16][WLDR] output of the third block (the output layer's input)
+  float* sF3 = reinterpret_cast<float*>(smem + g.oF3);               // [16][WLDR] f'(x3) -> delta_x3
+  float* sBx2 = reinterpret_cast<float*>(smem + g.oBx2);             // [16][WLDR] W2 row tile
+  float* sW2c = reinterpret_cast<float*>(smem + g.oW2c);             // [H][16] W2 column tile
+  float* sWr2 = reinterpret_cast<float*>(smem + g.oVec2); float* sBr2 = sWr2 + H;
 
   const int tid = threadIdx.x, lane = tid & 63;
   __builtin_assume(tid >= 0 && tid < NT);
@@ -171,6 +184,18 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   const float b0v = tid < H ? W[a.indB0 + tid] : 0.f;
   const float wrv = tid < H ? W[a.indWr + tid] : 0.f, brv = tid < H ? W[a.indBr + tid] : 0.f;
   const float b1e = eth ? W[a.indB1 + n0 + en] : 0.f;
+  const float* W2 = W + a.indW2;
+  f32x4 w2c[QC], w2r[QP];
+  float wr2v = 0.f, br2v = 0.f, b2e = 0.f;
+  if constexpr (NLH == 3) {
+#pragma unroll
+    for (int q = 0; q < QC; ++q) {
+      const int f = tid + NT * q; w2c[q] = z4;
+      if (f < H * 4) { const int k = f >> 2, c = n0 + (f & 3) * 4; w2c[q] = *reinterpret_cast<const f32x4*>(W2 + (size_t)k * a.ldW2 + c); }
+    }
+    if (tid < H) { wr2v = W[a.indWr2 + tid]; br2v = W[a.indBr2 + tid]; }
+    if (eth) b2e = W[a.indB2 + n0 + en];
+  }
   float bov[FW_MAXNT];
 #pragma unroll
   for (int t = 0; t < FW_MAXNT; ++t) { const int o = t * 16 + en; bov[t] = (eth && t < NTo && o < nDense) ? W[a.indBo + o] : 0.f; }
@@ -193,6 +218,11 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
 #pragma unroll
   for (int q = 0; q < QC; ++q) { const int f = tid + NT * q; if (f < H * 4) *reinterpret_cast<f32x4*>(sR3 + (size_t)f * 4) = w1c[q]; }
   if (tid < H) { sB0[tid] = b0v; sWr[tid] = wrv; sBr[tid] = brv; }
+  if constexpr (NLH == 3) {
+#pragma unroll
+    for (int q = 0; q < QC; ++q) { const int f = tid + NT * q; if (f < H * 4) *reinterpret_cast<f32x4*>(sW2c + (size_t)f * 4) = w2c[q]; }
+    if (tid < H) { sWr2[tid] = wr2v; sBr2[tid] = br2v; }
+  }
   __syncthreads();
   WSTMP(1);
   // the W1 row tile is needed only by the dX contraction; the replay rows of the head hang off `slot`
@@ -200,6 +230,13 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   for (int q = 0; q < QP; ++q) {
     const int f = tid + NT * q; w1r[q] = z4;
     if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w1r[q] = *reinterpret_cast<const f32x4*>(W1 + (size_t)(n0 + r) * a.ldW1 + 4 * c4); }
+  }
+  if constexpr (NLH == 3) {
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int f = tid + NT * q; w2r[q] = z4;
+      if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; w2r[q] = *reinterpret_cast<const f32x4*>(W2 + (size_t)(n0 + r) * a.ldW2 + 4 * c4); }
+    }
   }
   HeadRow<NCH> hr;
   hr.load(ha, rowValid, isNext, slot, en);
@@ -272,6 +309,7 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
     for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
   }
   __syncthreads();
+  float y3own = 0.f, f2own = 0.f;      // (NLH == 3: the second block's output and f'(x2) of this thread's element stay here)
   if (rowValid) {
     const float v = fwRedSum<8>(red, tid);
     const float x2 = v + b1e;
@@ -279,7 +317,8 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
     dispatchFunc<-1>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y2 = actEvalT<FN>(x2); f2 = actDiffT<FN>(x2, y2); });
     const float y3 = (n0 + en < resN) ? resOut(y2, y1o, sWr[n0 + en], sBr[n0 + en]) : y2;
     gR2[(size_t)row * ldA1 + n0 + en] = y3;                  // plain stores: the consumers share this XCD's L2 (fused.hip); also the A operand of dWout
-    gX2[(size_t)row * ldA1 + n0 + en] = f2;                  // f'(x2)
+    if constexpr (NLH == 3) { y3own = y3; f2own = f2; }
+    else gX2[(size_t)row * ldA1 + n0 + en] = f2;             // f'(x2)
   }
   WSTMP(5);
   // ---- group barrier: all HT tiles of this panel are in memory ------------------------------------------------------------------------
@@ -314,7 +353,7 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
         const int r = f / H4, c4 = f % H4;
         if (m0 + r < nRows) {
           yv[q] = *reinterpret_cast<const f32x4*>(gR2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
-          fv[q] = *reinterpret_cast<const f32x4*>(gX2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
+          if constexpr (NLH == 2) fv[q] = *reinterpret_cast<const f32x4*>(gX2 + (size_t)(m0 + r) * ldA1 + 4 * c4);
         }
       }
     }
@@ -325,8 +364,10 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
         const int r = f / H4, c = 4 * (f % H4);
         float2* dy = reinterpret_cast<float2*>(sY3 + r * WLDR + c);
         dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
-        float2* df = reinterpret_cast<float2*>(sF2 + r * WLDR + c);
-        df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
+        if constexpr (NLH == 2) {
+          float2* df = reinterpret_cast<float2*>(sF2 + r * WLDR + c);
+          df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
+        }
         float2* d = reinterpret_cast<float2*>(sBx + r * WLDR + c);          // h1 is dead (own tile kept in registers): the W1 row tile
         d[0] = make_float2(w1r[q][0], w1r[q][1]); d[1] = make_float2(w1r[q][2], w1r[q][3]);
       }
@@ -336,11 +377,76 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   if (eth && en == 0) sAct[em] = hr.actMsg;
   __syncthreads();
 
+  // ---- (NLH == 3) the third block: own tile of x3 = y3 W2 + b2, its output with the parametric residual of y3, third panel barrier,
+  //      read-back of the panel's outputs and f'(x3) -- the same steps as for the second block ----
+  float* sYo = sY3; float* sFl = sF2;      // the output layer's input panel / the panel of f'(x) of the last block -> its deltas
+  float* gDresL = gDres2; float* gDL = gD2; int ldAL = ldA1;
+  if constexpr (NLH == 3) {
+    {
+      const int k0 = wave * KW + lc;
+      const f32x4 acc = fwWaveMma<NK>([&](int s) { return sY3[li * WLDR + k0 + 4 * s]; }, [&](int s) { return sW2c[(k0 + 4 * s) * 16 + li]; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+    }
+    __syncthreads();
+    float* gR3 = a.R3; float* gX3 = a.X3;
+    const int ldA2 = a.ldA2;
+    if (rowValid) {
+      const float x3 = fwRedSum<8>(red, tid) + b2e;
+      float y3a = 0.f, f3 = 0.f;
+      dispatchFunc<-1>(func, [&](auto F) { constexpr int FN = decltype(F)::value; y3a = actEvalT<FN>(x3); f3 = actDiffT<FN>(x3, y3a); });
+      const float r3 = (n0 + en < a.resN2) ? resOut(y3a, y3own, sWr2[n0 + en], sBr2[n0 + en]) : y3a;
+      gR3[(size_t)row * ldA2 + n0 + en] = r3;
+      gX3[(size_t)row * ldA2 + n0 + en] = f3;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (HT > 1 && tid == 0) {
+      unsigned* ctr = a.panelCtr + panel * 32;
+      const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned barTarget = (old / (unsigned)HT + 1u) * (unsigned)HT;
+      int spins = 0;
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - barTarget) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { scw->errFlag = 77; break; }
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 yv[QP], fv[QP];
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const int f = tid + NT * q; yv[q] = z4; fv[q] = z4;
+        if (f < 16 * H4) {
+          const int r = f / H4, c4 = f % H4;
+          if (m0 + r < nRows) {
+            yv[q] = *reinterpret_cast<const f32x4*>(gR3 + (size_t)(m0 + r) * ldA2 + 4 * c4);
+            fv[q] = *reinterpret_cast<const f32x4*>(gX3 + (size_t)(m0 + r) * ldA2 + 4 * c4);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const int f = tid + NT * q;
+        if (f < 16 * H4) {
+          const int r = f / H4, c = 4 * (f % H4);
+          float2* dy = reinterpret_cast<float2*>(sY4 + r * WLDR + c);
+          dy[0] = make_float2(yv[q][0], yv[q][1]); dy[1] = make_float2(yv[q][2], yv[q][3]);
+          float2* df = reinterpret_cast<float2*>(sF3 + r * WLDR + c);
+          df[0] = make_float2(fv[q][0], fv[q][1]); df[1] = make_float2(fv[q][2], fv[q][3]);
+          float2* d = reinterpret_cast<float2*>(sBx2 + r * WLDR + c);
+          d[0] = make_float2(w2r[q][0], w2r[q][1]); d[1] = make_float2(w2r[q][2], w2r[q][3]);
+        }
+      }
+    }
+    __syncthreads();
+    sYo = sY4; sFl = sF3; gDresL = a.Dres3; gDL = a.D3; ldAL = ldA2;
+  }
   WSTMP(7);
   // ---- output layer: O[16][nDense] = y3 W_out + b_out on MFMA, K split over the 8 waves ---------------------------------------------
   {
     const int k0 = wave * KW + lc;
-    const float* pA = sY3 + li * WLDR + k0; const float* sWoK = sWo + (size_t)k0 * ldWo; float* redW = red + wave * NTo * 256;
+    const float* pA = sYo + li * WLDR + k0; const float* sWoK = sWo + (size_t)k0 * ldWo; float* redW = red + wave * NTo * 256;
     switch (NTo) {
       case 1: panelOutMma<1>(pA, sWoK, ldWo, li, NK, redW); break;
       case 2: panelOutMma<2>(pA, sWoK, ldWo, li, NK, redW); break;
@@ -404,14 +510,60 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lc * 4 + r, c = c0 + li, rr = m0 + i;
-      const float dy3 = acc[r], f2 = sF2[i * WLDR + c];
-      sF2[i * WLDR + c] = dy3 * f2;                                       // delta_x2 (each element read and written by its own lane)
-      if (tile == n && rr < B) { gDres2[(size_t)rr * ldA1 + c] = dy3; gD2[(size_t)rr * ldA1 + c] = dy3 * f2; sT[i * 16 + li] = dy3; }
+      const float dy3 = acc[r], f2 = sFl[i * WLDR + c];
+      sFl[i * WLDR + c] = dy3 * f2;                                       // delta_x of the last block (each element read and written by its own lane)
+      if (tile == n && rr < B) { gDresL[(size_t)rr * ldAL + c] = dy3; gDL[(size_t)rr * ldAL + c] = dy3 * f2; sT[i * 16 + li] = dy3; }
     }
   }
   __syncthreads();
   WSTMP(10);
   dy3own = sT[em * 16 + en];
+  // ---- (NLH == 3) own tile of the error of the second block's output = delta_x3 W2^T (+ the third block's residual path), its delta_x2;
+  //      fourth panel barrier; the panel's delta_x2 read back as the A operand of the last contraction ----
+  if constexpr (NLH == 3) {
+    {
+      const int k0 = wave * KW + lc;
+      const f32x4 acc = fwWaveMma<NK>([&](int s) { return sF3[li * WLDR + k0 + 4 * s]; }, [&](int s) { return sBx2[li * WLDR + k0 + 4 * s]; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave * 256 + (lc * 4 + r) * 16 + li] = acc[r];
+    }
+    __syncthreads();
+    float dres2 = 0.f;
+    if (eth && row < B) {
+      dres2 = fwRedSum<8>(red, tid);
+      if (n0 + en < a.resN2) dres2 += dy3own * sWr2[n0 + en];
+      gDres2[(size_t)row * ldA1 + n0 + en] = dres2;
+      gD2[(size_t)row * ldA1 + n0 + en] = dres2 * f2own;
+    }
+    dy3own = dres2;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (HT > 1 && tid == 0) {
+      unsigned* ctr = a.panelCtr + panel * 32;
+      const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned barTarget = (old / (unsigned)HT + 1u) * (unsigned)HT;
+      int spins = 0;
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - barTarget) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { scw->errFlag = 77; break; }
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 dv[QP];
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const int f = tid + NT * q; dv[q] = z4;
+        if (f < 16 * H4) { const int r = f / H4, c4 = f % H4; if (m0 + r < B) dv[q] = *reinterpret_cast<const f32x4*>(gD2 + (size_t)(m0 + r) * ldA1 + 4 * c4); }
+      }
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const int f = tid + NT * q;
+        if (f < 16 * H4) { const int r = f / H4, c = 4 * (f % H4); float2* d = reinterpret_cast<float2*>(sF2 + r * WLDR + c); d[0] = make_float2(dv[q][0], dv[q][1]); d[1] = make_float2(dv[q][2], dv[q][3]); }
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- own tile of delta_h1 = delta_x2 W1^T (+ residual path), delta_x1 = delta_h1 f'(x1) ----------------------------------------------
   {
@@ -433,13 +585,17 @@ __global__ __launch_bounds__(FW_NT, 2) void fused_wide_kernel(FusedArgs a, HeadA
   WSTMP(11);
 }
 
+template <int H, int NCH, int NLH>
+static hipError_t launchFusedWideL(const FusedArgs& a, const HeadArgs& ha, int maxRows, const ExtraArgs& ex, hipStream_t s) {
+  const int HT = H / 16, panels = (maxRows + 15) / 16, pg = (panels + 7) / 8;
+  const size_t lds = fwGeo(a.dS, H, a.nDense, a.nOut, ha.ldWo, ha.nAdv, NLH).total;
+  { hipError_t e = ensureDynLds(reinterpret_cast<const void*>(fused_wide_kernel<H, NCH, NLH>), lds); if (e != hipSuccess) return e; }
+  hipLaunchKernelGGL((fused_wide_kernel<H, NCH, NLH>), dim3(8 + 8 * HT * pg), dim3(FW_NT), lds, s, a, ha, ex);
+  return hipGetLastError();
+}
 template <int H, int NCH>
 static hipError_t launchFusedWideT(const FusedArgs& a, const HeadArgs& ha, int maxRows, const ExtraArgs& ex, hipStream_t s) {
-  const int HT = H / 16, panels = (maxRows + 15) / 16, pg = (panels + 7) / 8;
-  const size_t lds = fwGeo(a.dS, H, a.nDense, a.nOut, ha.ldWo, ha.nAdv).total;
-  { hipError_t e = ensureDynLds(reinterpret_cast<const void*>(fused_wide_kernel<H, NCH>), lds); if (e != hipSuccess) return e; }
-  hipLaunchKernelGGL((fused_wide_kernel<H, NCH>), dim3(8 + 8 * HT * pg), dim3(FW_NT), lds, s, a, ha, ex);
-  return hipGetLastError();
+  return a.nLH == 3 ? launchFusedWideL<H, NCH, 3>(a, ha, maxRows, ex, s) : launchFusedWideL<H, NCH, 2>(a, ha, maxRows, ex, s);
 }
 template <int H>
 static hipError_t launchFusedWideH(const FusedArgs& a, const HeadArgs& ha, int maxRows, const ExtraArgs& ex, hipStream_t s) {
@@ -455,11 +611,11 @@ hipError_t launch_fused_wide(const FusedArgs& a, const HeadArgs& ha, int maxRows
     default: return hipErrorInvalidValue;
   }
 }
-size_t fused_wide_lds_bytes(int dS, int H, int nDense, int nOut, int ldWo, int nAdv) { return fwGeo(dS, H, nDense, nOut, ldWo, nAdv).total; }
+size_t fused_wide_lds_bytes(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int nLH) { return fwGeo(dS, H, nDense, nOut, ldWo, nAdv, nLH).total; }
 int fused_wide_threads() { return FW_NT; }
-bool fused_wide_ok(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int comps) {
-  if (!(H == 64 || H == 128 || H == 256) || dS < 1 || dS > 512 || nDense > FW_MAXNT * 16 || comps > 32) return false;
-  return fwGeo(dS, H, nDense, nOut, ldWo, nAdv).total <= 160 * 1024;
+bool fused_wide_ok(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int comps, int nLH) {
+  if (!(H == 64 || H == 128 || H == 256) || dS < 1 || dS > 512 || nDense > FW_MAXNT * 16 || comps > 32 || (nLH != 2 && nLH != 3)) return false;
+  return fwGeo(dS, H, nDense, nOut, ldWo, nAdv, nLH).total <= 160 * 1024;
 }
 
 }  // namespace hl

@@ -229,6 +229,9 @@ struct FusedArgs {
   long long indW0, indB0, indW1, indB1, indWr, indBr, indWo, indBo, indBp; int ldW0, ldW1;
   float* Y1; float* D1; float* Dres1; int ldA0;               // hidden block 0: activations, deltas
   float* X2; float* R2; float* D2; float* Dres2; int ldA1;    // hidden block 1: pre-activations (exchange), y3, deltas
+  // a THIRD equal hidden block (fusedw.hip, nLH == 3: settings/RACER_glider.json): its weights, f'(x), block output, deltas
+  int nLH; long long indW2, indB2, indWr2, indBr2; int ldW2, resN2;
+  float* X3; float* R3; float* D3; float* Dres3; int ldA2;
   float* dOut; int ldDo;                  // output-layer deltas [B][ldDo]
   unsigned* panelCtr;                     // [panels][32] arrive counters of the panel barrier (monotonic)
   int variant;                            // development: stop after phase `variant` (0 = run everything)
@@ -293,8 +296,8 @@ hipError_t launch_fused(const FusedArgs& a, int maxRows, const ExtraArgs* extra,
 size_t fused_lds_bytes(int dS, int H);
 // the same step for two-hidden-layer nets with wide states (first layer streamed in slabs) and any head of head_rows.h (fusedw.hip)
 hipError_t launch_fused_wide(const FusedArgs& a, const HeadArgs& ha, int maxRows, const ExtraArgs* extra, hipStream_t s);
-bool fused_wide_ok(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int comps);
-size_t fused_wide_lds_bytes(int dS, int H, int nDense, int nOut, int ldWo, int nAdv);
+bool fused_wide_ok(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int comps, int nLH = 2);      // nLH: two or three equal hidden blocks
+size_t fused_wide_lds_bytes(int dS, int H, int nDense, int nOut, int ldWo, int nAdv, int nLH = 2);
 int fused_wide_threads();
 int fused_threads();
 hipError_t launch_post(const PostArgs& a, hipStream_t s);

@@ -824,16 +824,17 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(hipStreamSynchronize(nullptr));
     }
   }
-  if (!h->fusedOk && h->nHidden == 2 && !h->recurrent && !h->preproc && !(h->generic & 1)) {
-    // the wide variant of the fused kernel (fusedw.hip): same placement, same probe
+  if (!h->fusedOk && (h->nHidden == 2 || h->nHidden == 3) && !h->recurrent && !h->preproc && !(h->generic & 1)) {
+    // the wide variant of the fused kernel (fusedw.hip): same placement, same probe; also for THREE equal hidden blocks (settings/RACER_glider.json)
     const DevHidden& d0 = h->hid[0]; const DevHidden& d1 = h->hid[1];
-    const int comps = h->nOpt ? h->nOpt : h->dA;
+    const int comps = h->nOpt ? h->nOpt : h->dA, nLH = h->nHidden;
     bool ok = d0.size == d1.size && !d0.hasRes && d1.hasRes && d1.nIn == d0.size && d0.func == d1.func &&
-              fused_wide_ok(h->dS, d1.size, h->nDense, h->nOut, h->ldWo, cfg->adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0, comps);
+              fused_wide_ok(h->dS, d1.size, h->nDense, h->nOut, h->ldWo, cfg->adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0, comps, nLH);
+    if (nLH == 3) { const DevHidden& d2 = h->hid[2]; ok = ok && d2.size == d1.size && d2.hasRes && d2.nIn == d1.size && d2.func == d1.func && !(h->generic & 512); }
     if (ok) {
       const int HT = d1.size / 16, panels = (h->Mmax + 15) / 16, pg = (panels + 7) / 8, nBlk = 8 + 8 * HT * pg;
       int* dX = nullptr; HIPCK(devAlloc(&dX, (size_t)nBlk));
-      HIPCK(launch_xcc_probe(nBlk, fused_wide_threads(), fused_wide_lds_bytes(h->dS, d1.size, h->nDense, h->nOut, h->ldWo, cfg->adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0), dX, h->stream));
+      HIPCK(launch_xcc_probe(nBlk, fused_wide_threads(), fused_wide_lds_bytes(h->dS, d1.size, h->nDense, h->nOut, h->ldWo, cfg->adv_kind == HL_ADV_GAUSSIAN ? h->nAdv : 0, nLH), dX, h->stream));
       std::vector<int> xcc((size_t)nBlk);
       HIPCK(hipMemcpyAsync(xcc.data(), dX, xcc.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCK(hipStreamSynchronize(h->stream)); hipFree(dX);

@@ -329,6 +329,12 @@ FusedArgs fusedArgs(hl_learner* h, int parity) {
   fa.indWo = h->indWo; fa.indBo = h->indBo; fa.indBp = h->indBp; fa.ldW0 = d0.ldW; fa.ldW1 = d1.ldW;
   fa.Y1 = d0.Y; fa.D1 = d0.D; fa.Dres1 = d0.Dres; fa.ldA0 = d0.ldA;
   fa.X2 = d1.X; fa.R2 = d1.Rr; fa.D2 = d1.D; fa.Dres2 = d1.Dres; fa.ldA1 = d1.ldA;
+  fa.nLH = 2;
+  if (h->fusedWideOk && h->nHidden == 3) {      // three equal hidden blocks (fusedw.hip)
+    const DevHidden& d2 = h->hid[2];
+    fa.nLH = 3; fa.indW2 = d2.indW; fa.indB2 = d2.indB; fa.indWr2 = d2.indWr; fa.indBr2 = d2.indBr; fa.ldW2 = d2.ldW; fa.resN2 = d2.resW;
+    fa.X3 = d2.X; fa.R3 = d2.Rr; fa.D3 = d2.D; fa.Dres3 = d2.Dres; fa.ldA2 = d2.ldA;
+  }
   fa.dOut = h->dOut; fa.ldDo = h->ldDo; fa.panelCtr = h->panelCtr; fa.variant = h->dbgVariant; fa.xcdSafe = h->xcdSafe ? 1 : 0;
   for (int i = 0; i < h->dA; ++i) if (h->cfg.bounded[i]) fa.boundedMask |= 1ull << i;
   return fa;

@@ -111,9 +111,9 @@ def test_hidden_layers_up_to_2048_units_match_oracle(hip_api, B, hidden, extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden,extra", [((128, 128, 128), dict(adv_kind=capi.ADV_GAUSSIAN, dimA=1, bounded=[1])), ((96, 48), {}),
+@pytest.mark.parametrize("hidden,extra", [((128, 112, 96), dict(adv_kind=capi.ADV_GAUSSIAN, dimA=1, bounded=[1])), ((96, 48), {}),
                                           ((320, 256, 64), dict(adv_kind=capi.ADV_DISCRETE, n_options=4, dimA=1, bounded=[0]))],
-                         ids=["glider-3x128-gauss", "96x48", "320x256x64-discrete"])
+                         ids=["128x112x96-gauss", "96x48", "320x256x64-discrete"])
 def test_chained_step_equals_the_separate_launches(hip_api, monkeypatch, hidden, extra):
     """Dense nets off the fused kernels: forward chain + head + input-gradient chain as ONE launch (gemm16.hip: step_chain_kernel) against
     the launch list it replaces (SMARTIES_HIP_GENERIC=512: forward chain, head launch, one dX launch per layer) -- the same tile and head
@@ -294,3 +294,33 @@ def test_fused_steps_at_512_to_1024_samples_match_oracle(hip_api, B, hidden, dS)
     G.step(12); O.step(12)
     assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT)) and np.array_equal(G.get_rng_state(), O.get_rng_state())
     assert relinf(G.get_params()[0], O.get_params()[0]) < 2 * TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,B,dS,extra", [((128, 128, 128), 256, 10, dict(adv_kind=capi.ADV_GAUSSIAN, dimA=1, bounded=[1], nnFunc="Tanh")),
+                                               ((64, 64, 64), 40, 37, dict(nnFunc="SoftSign")),
+                                               ((256, 256, 256), 72, 9, dict(adv_kind=capi.ADV_DISCRETE, n_options=6, dimA=1, bounded=[0], nnFunc="Tanh")),
+                                               ((128, 128, 128), 100, 300, dict(dimA=9, bounded=[1, 0, 0, 1, 0, 0, 0, 1, 0], nnFunc="Relu"))],
+                         ids=["glider-3x128-gauss", "3x64-vracer", "3x256-discrete", "3x128-wide-state-9-actions"])
+def test_three_equal_hidden_blocks_on_the_fused_kernel_match_oracle(hip_api, monkeypatch, hidden, B, dS, extra):
+    """fusedw.hip with a third hidden block (settings/RACER_glider.json is 3 x 128 under the Gaussian advantage): forward, head and
+    input gradients of the whole minibatch in one launch -- four panel barriers instead of two --, then the weight gradients.  Per-sample
+    taps, write-backs, weights (eager and replayed steps, next-state rows of truncated episodes) against the oracle; the separate
+    launches (SMARTIES_HIP_GENERIC=1) must land within the same tolerance of it."""
+    from oracle_api import synth_cfg
+    from test_hip_parity import _pair, _compare_step
+    kw = dict(dimS=dS, dimA=3, bounded=[1, 0, 0], hidden=hidden, batchSize=B, maxTotObsNum=50000, randSeed=71)
+    kw.update(extra)
+    sc = synth_cfg(seed=73, dimS=dS, dimA=kw["dimA"], lenMin=3, lenMax=50, pTerm=0.5)
+    for env in (None, "1"):
+        monkeypatch.delenv("SMARTIES_HIP_GENERIC", raising=False)
+        if env:
+            monkeypatch.setenv("SMARTIES_HIP_GENERIC", env)
+        G, O = _pair(hip_api, kw, sc, 120)
+        for _ in range(3):
+            G.step(1); O.step(1)
+            _compare_step(G, O)
+        G.step(25); O.step(25)
+        assert np.array_equal(G.readback(capi.TAP_FLAT), O.readback(capi.TAP_FLAT))
+        assert relinf(G.get_params()[0], O.get_params()[0]) < 4 * TOL32      # (28 steps of two fp32 summation orders: the weights, not the last step's taps)
+        G.close()
