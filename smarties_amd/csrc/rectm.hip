@@ -14,7 +14,7 @@
 //             v_mfma_f32_16x16x4_f32: A tile staged in LDS with 16-byte loads, W columns as 64-byte runs from the L2); epilogue =
 //             the cell (Layer_LSTM.h:77-125), the rows kept for the backward pass and the dW launch, this step's block output into the
 //             next layer's input row, this step's output into the next step's recurrent input
-//   backward  lstm_tm_zero_kernel (zero deltas for the rows a sample does not have), then ONE launch per step (last first) and layer
+//   backward  (the deltas of the rows a sample does not have were zeroed by the prepare launch), then ONE launch per step (last first) and layer
 //             (top first), lstm_tm_bwd_kernel: [error to the block below | error to the previous step] = D[r] W^T, 16 samples x 16
 //             rows of W per workgroup, the reduction over the 4 nC deltas split over the four wavefronts (both operands as 16-byte
 //             loads, the reduction index permuted inside groups of 16); its epilogue forms the cell deltas (Layer_LSTM.h:127-165)
@@ -27,7 +27,8 @@ namespace hl {
 
 constexpr int TM_LDA = 4;      // padding of the staged A tile's rows (floats)
 
-// window geometry of every sample + the first layer's input rows + zero recurrent input at the first step
+__device__ __forceinline__ void tmZeroRows(const RecArgs& a, int b, int T);
+// window geometry of every sample + the first layer's input rows + zero recurrent input at the first step + zero deltas for the rows a sample does not have
 __global__ __launch_bounds__(256) void lstm_tm_prepare_kernel(RecArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void lstm_tm_prepare_kernel(RecArgs a) {
     const RecLayer& L = a.L[j];
     for (int c = tid; c < L.nC; c += 256) L.A[(size_t)b * a.K * L.ldA + L.nIn + c] = 0.f;
   }
+  tmZeroRows(a, b, T);
 }
 
 // rollout inference of nets whose layers are wider than the per-sample kernels hold (256 cells): the agent's window as ONE sample of the
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, 
 }
 
 // rows a sample does not have (k > T, the next state's row included): zero deltas -- their stale inputs add nothing to the gradients
-__global__ __launch_bounds__(256) void lstm_tm_zero_kernel(RecArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x, T = a.tmT[b];
+// (part of the prepare launch at the head of the forward pass: nothing in between writes these rows)
+__device__ __forceinline__ void tmZeroRows(const RecArgs& a, int b, int T) {
+  const int tid = threadIdx.x;
   for (int k = T + 1; k < a.K; ++k) {
     const long long r = (long long)b * a.K + k;
     for (int j = 0; j < a.nL; ++j) {
@@ -211,7 +214,7 @@ __device__ __forceinline__ void tmDelta(const RecArgs& a, int j, int k, int b, i
 }
 __device__ __forceinline__ int c0tile(int i0, int nIn, bool below) { return (below ? i0 : i0 - nIn) >> 4; }
 // Layer::backward of layer j at step k (Layers.h:123-188): e[b][i] = sum_o W[i][o] D[r][o] for rows i of [W_in; W_rec], samples with T >= k - 1
-// (the deltas of a step a sample does not have are zero rows: lstm_tm_zero_kernel).  The epilogues also form the cell deltas whose inputs
+// (the deltas of a step a sample does not have are zero rows: tmZeroRows).  The epilogues also form the cell deltas whose inputs
 // the products complete, and a launch is one ANTI-DIAGONAL of the (layer, step) grid -- blockIdx.z picks (j0 + z, k0 - z):
 //   tiles i <  nIn (j > 0)   e + residual path = the error of the block below at THIS step: one of the two inputs of the deltas of (j - 1, k)
 //   tiles i >= nIn           the error handed to step k - 1: the last layer forms its deltas of (j, k - 1) at once (its error from above is
@@ -574,7 +577,6 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_rec_tm_backward(const RecArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_tm_zero_kernel, dim3(a.B), dim3(256), 0, s, a);
   if (a.gates == 2) {
     for (int e = a.nL - 1 + a.nBPTT + 1; e >= 0; --e) {      // anti-diagonals j + k = e: phase 0 of every member, then phase 1 of every member
       const int jLo = std::max(0, e - (a.nBPTT + 1)), jHi = std::min(a.nL - 1, e);
