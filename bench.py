@@ -263,6 +263,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event passes (counter-collection runs, which stall under their graph replays)")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the repeated call and the 2000-step sustained rate after the timed region (counter-collection runs)")
     args = ap.parse_args()
+    # the ONE JSON line goes to the real stdout; everything else this process or its libraries print there (RCCL's version banner when
+    # a communicator comes up, gloo's connection notes) is sent to stderr
+    real_out_fd = os.dup(1)
+    sys.stdout.flush(); os.dup2(2, 1)
+    real_out = os.fdopen(real_out_fd, "w")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -294,6 +299,7 @@ def main():
                 rank, PROBE_SECONDS), file=sys.stderr, flush=True)
             env = dict(os.environ, SMARTIES_BENCH_EXCHANGE="host", SMARTIES_BENCH_REEXEC="1")
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)     # (else every rank of the second life is a store client)
+            os.dup2(real_out_fd, 1)      # (the second life prints its line where this one would have)
             os.execve(sys.executable, [sys.executable] + sys.argv, env)
 
         dog = threading.Timer(PROBE_SECONDS, start_over)
@@ -571,7 +577,7 @@ def main():
         def bail():
             if rank == 0:
                 out["weak_scaling_row"] = {"scaling": "weak", "error": "did not finish within %d s" % PROBE_SECONDS}
-                print(json.dumps(out), flush=True)
+                print(json.dumps(out), file=real_out, flush=True)
             os._exit(3)      # (non-zero: the peers may sit in collectives; the launcher tears the group down)
         wd = threading.Timer(PROBE_SECONDS, bail); wd.daemon = True; wd.start()
         try:
@@ -599,7 +605,7 @@ def main():
         if rank == 0:
             out["weak_scaling_row"] = weak
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_out, flush=True)
     try:
         L.close()
     except Exception:  # noqa: BLE001
