@@ -604,7 +604,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       cfg->n_hidden > HL_MAX_HIDDEN || cfg->batchSize <= 0 || cfg->n_ranks < 1) return HL_ERR_BAD_ARG;
   if (cfg->n_ranks > 256) return HL_ERR_UNSUPPORTED;   // the replica counters travel as 16-bit chunks in fp32 (tail_dev.h: encodeCounters)
   if (cfg->adv_kind != HL_ADV_ZERO && cfg->adv_kind != HL_ADV_GAUSSIAN && cfg->adv_kind != HL_ADV_DISCRETE) return HL_ERR_UNSUPPORTED;
-  if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 64)) return HL_ERR_BAD_ARG;   // head kernel: one option per lane, deltas staged in 72 floats
+  if (cfg->adv_kind == HL_ADV_DISCRETE && (cfg->dimA != 1 || cfg->n_options < 2 || cfg->n_options > 64)) return HL_ERR_BAD_ARG;   // head launch: one option per lane of the sample's wavefront, 1 + 2 x 64 staged deltas (above 32 options: not the panel / fused heads)
   if (cfg->nnFunc < HL_FUNC_LINEAR || cfg->nnFunc > HL_FUNC_EXP) return HL_ERR_UNSUPPORTED;   // the ten names of makeFunction (Functions.h:643-668)
   if (cfg->episode_order != HL_ORDER_STABLE) return HL_ERR_UNSUPPORTED;   // reference permutation: oracle only
   if (cfg->nn_type < HL_NN_FFNN || cfg->nn_type > HL_NN_RNN) return HL_ERR_UNSUPPORTED;
