@@ -27,25 +27,32 @@ namespace hl {
 
 constexpr int TM_LDA = 4;      // padding of the staged A tile's rows (floats)
 
-__device__ __forceinline__ void tmZeroRows(const RecArgs& a, int b, int T);
-// window geometry of every sample + the first layer's input rows + zero recurrent input at the first step + zero deltas for the rows a sample does not have
+// window geometry of every sample + the first layer's input rows + zero recurrent input at the first step + zero deltas for the rows a
+// sample does not have: a workgroup per (sample, window row) -- a workgroup per sample walked its eighteen rows one after the other (13 us)
 __global__ __launch_bounds__(256) void lstm_tm_prepare_kernel(RecArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
   const int t = a.bt.t[b]; const long long slot = a.bt.slot[b];
   const int T = min(a.nBPTT, t), nextRow = a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
-  if (tid == 0) { a.tmT[b] = T; a.tmSteps[b] = nSteps; a.tmNext[b] = nextRow; }
-  const RecLayer& L0 = a.L[0];
-  const int dIn = L0.nIn;
-  for (int e = tid; e < nSteps * dIn; e += 256) {
-    const int k = e / dIn, i = e - k * dIn;
-    L0.A[((size_t)b * a.K + k) * L0.ldA + i] = recInputAt(a, false, b, slot, t, T, nextRow, k, i);
+  const long long r = (long long)b * a.K + k;
+  if (k == 0) {
+    if (tid == 0) { a.tmT[b] = T; a.tmSteps[b] = nSteps; a.tmNext[b] = nextRow; }
+    for (int j = 0; j < a.nL; ++j) {
+      const RecLayer& L = a.L[j];
+      for (int c = tid; c < L.nC; c += 256) L.A[r * L.ldA + L.nIn + c] = 0.f;
+    }
   }
-  for (int j = 0; j < a.nL; ++j) {
-    const RecLayer& L = a.L[j];
-    for (int c = tid; c < L.nC; c += 256) L.A[(size_t)b * a.K * L.ldA + L.nIn + c] = 0.f;
+  if (k < nSteps) {
+    const RecLayer& L0 = a.L[0];
+    for (int i = tid; i < L0.nIn; i += 256) L0.A[r * L0.ldA + i] = recInputAt(a, false, b, slot, t, T, nextRow, k, i);
   }
-  tmZeroRows(a, b, T);
+  if (k > T) {      // rows a sample does not have (the next state's row included): zero deltas -- their stale inputs add nothing to the gradients
+    for (int j = 0; j < a.nL; ++j) {
+      const RecLayer& L = a.L[j];
+      for (int o = tid; o < a.gates * L.nC; o += 256) L.D[r * a.gates * L.nC + o] = 0.f;
+      if (L.hasRes) for (int c = tid; c < L.nC; c += 256) L.Rd[r * L.ldR + c] = 0.f;
+    }
+  }
 }
 
 // rollout inference of nets whose layers are wider than the per-sample kernels hold (256 cells): the agent's window as ONE sample of the
@@ -179,20 +186,6 @@ __global__ __launch_bounds__(TM_FNT) void lstm_tm_fwd_kernel(RecArgs a, int j0, 
   TMSTMP(5);
 }
 
-// rows a sample does not have (k > T, the next state's row included): zero deltas -- their stale inputs add nothing to the gradients
-// (part of the prepare launch at the head of the forward pass: nothing in between writes these rows)
-__device__ __forceinline__ void tmZeroRows(const RecArgs& a, int b, int T) {
-  const int tid = threadIdx.x;
-  for (int k = T + 1; k < a.K; ++k) {
-    const long long r = (long long)b * a.K + k;
-    for (int j = 0; j < a.nL; ++j) {
-      const RecLayer& L = a.L[j];
-      for (int o = tid; o < a.gates * L.nC; o += 256) L.D[r * a.gates * L.nC + o] = 0.f;
-      if (L.hasRes) for (int c = tid; c < L.nC; c += 256) L.Rd[r * L.ldR + c] = 0.f;
-    }
-  }
-}
-
 // the cell's deltas of (layer j, step k, sample b, cell c), Layer_LSTM.h:127-165: eTop = error from the block above (same step), eRec = error
 // handed back by step k + 1 (zero at the sample's last step)
 __device__ __forceinline__ void tmDelta(const RecArgs& a, int j, int k, int b, int c, int T, float eTop, float eRec) {
@@ -214,7 +207,7 @@ __device__ __forceinline__ void tmDelta(const RecArgs& a, int j, int k, int b, i
 }
 __device__ __forceinline__ int c0tile(int i0, int nIn, bool below) { return (below ? i0 : i0 - nIn) >> 4; }
 // Layer::backward of layer j at step k (Layers.h:123-188): e[b][i] = sum_o W[i][o] D[r][o] for rows i of [W_in; W_rec], samples with T >= k - 1
-// (the deltas of a step a sample does not have are zero rows: tmZeroRows).  The epilogues also form the cell deltas whose inputs
+// (the deltas of a step a sample does not have are zero rows: lstm_tm_prepare_kernel).  The epilogues also form the cell deltas whose inputs
 // the products complete, and a launch is one ANTI-DIAGONAL of the (layer, step) grid -- blockIdx.z picks (j0 + z, k0 - z):
 //   tiles i <  nIn (j > 0)   e + residual path = the error of the block below at THIS step: one of the two inputs of the deltas of (j - 1, k)
 //   tiles i >= nIn           the error handed to step k - 1: the last layer forms its deltas of (j, k - 1) at once (its error from above is
@@ -551,7 +544,7 @@ hipError_t launch_rec_tm_forward(const RecArgs& a, hipStream_t s) {
   const bool acting = a.actStates != nullptr;
   const int kLast = acting ? a.actSteps - 1 : a.nBPTT + 1;      // the last window step any sample can have
   if (acting) hipLaunchKernelGGL(lstm_tm_prepare_act_kernel, dim3(1), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(lstm_tm_prepare_kernel, dim3(a.B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lstm_tm_prepare_kernel, dim3(a.B, a.K), dim3(256), 0, s, a);
   size_t ldsMax = 0;
   for (int j = 0; j < a.nL; ++j) ldsMax = std::max(ldsMax, tmFwdLds(a.L[j]));
   // diagonal d of the (layer, step) grid: layers jLo .. jLo + nz - 1 at steps d - j
