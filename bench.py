@@ -399,7 +399,11 @@ def main():
         if n_ranks > 1 and state["host_exchange"]:
             from smarties_amd import dist_host
             dist_host.init_replica_weights(L, dist, group=state["host_group"])
-        L.initialize()
+            # (the start-up counters and reward / state moments summed over ALL shards, as the reference's accurate start-up
+            #  reductions do -- Learner.cpp:58-59; a plain hl_initialize would scale every replica by its own shard: ADVICE r05)
+            dist_host.initialize_host_exchange(L, dist, group=state["host_group"])
+        else:
+            L.initialize()
         return L, t_fill, transport
 
     # N > 1: the single-replica value of THIS box first (rank 0 alone, the N = 1 workload, the same K steps after W warm-up steps), so

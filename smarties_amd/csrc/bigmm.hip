@@ -454,12 +454,15 @@ __device__ __forceinline__ void bigDwBody(const GemmProblem& P, int blk, float (
   // a slice = 32 rows x 64 columns of each operand: 512 float4 per operand, two per thread
   const int sr = tid >> 4, sc4 = (tid & 15) * 4;      // (+ 16 rows for the second one)
   f32x4 va[2], vd[2];
+  const int caMax = max(0, min(P.lda, (P.M - 1 + 3) & ~3) - 4), cdMax = max(0, min(P.ldb, (P.N + 3) & ~3) - 4);
   // (loads with clamped addresses and nothing else; masks when the slice is stored -- as in big_mm_kernel: no wait for the data in
   //  front of the slice's products)
   auto loadSlice = [&](int r0) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int row = min(r0 + sr + 16 * q, rEnd - 1), ca = min(m0 + sc4, P.lda - 4), cd = min(n0 + sc4, P.ldb - 4);
+      // (clamped to the PROBLEM's columns -- M - 1 inputs, N deltas, rounded up to a 16-byte unit --, not to the row pitch: the operand
+      //  of a recurrent block starts inside its row (A = row + nIn), where pitch - 4 from that base lies behind the row's end)
+      const int row = min(r0 + sr + 16 * q, rEnd - 1), ca = min(m0 + sc4, caMax), cd = min(n0 + sc4, cdMax);
       va[q] = *reinterpret_cast<const f32x4*>(P.A + (size_t)row * P.lda + ca);
       vd[q] = *reinterpret_cast<const f32x4*>(P.B + (size_t)row * P.ldb + cd);
     }

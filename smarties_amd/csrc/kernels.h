@@ -86,7 +86,7 @@ struct RecArgs {
   int* tmT; int* tmSteps; int* tmNext;                              // [B] steps in front of the sampled one / forward steps (next state included) / row of the next state's output
   float* tmER[HL_MAX_HIDDEN]; float* tmSD[HL_MAX_HIDDEN]; float* tmFP[HL_MAX_HIDDEN];      // [B][nC]: error handed back by step k + 1 / LSTM: state delta of step k + 1, MGU: dLdO of the step / MGU: W_sr dS of the step
   float* tmET[HL_MAX_HIDDEN];      // [B][nC]: backward by diagonals -- the error from the layer above at this step, left by whichever producer of a tile of deltas arrives first
-  unsigned* tmCtr; int tmCtrOff[HL_MAX_HIDDEN];      // LSTM backward by diagonals: one arrival counter per (layer, 16-cell tile, 16-sample block), the layer's first one
+  unsigned* tmCtr; int tmCtrN; int tmCtrOff[HL_MAX_HIDDEN];      // LSTM backward by diagonals: one arrival counter per (layer, 16-cell tile, 16-sample block), the layer's first one
   float* YoutRows; int ldYR;       // != nullptr: the last block's output of EVERY window step goes here (row b K + k, next rows behind B K): the upper segment's Xin
   const float* DresRows; int ldDR; // != nullptr: gradient w.r.t. those outputs per window row, from the upper segment (instead of Dres at the sampled step only)
 };

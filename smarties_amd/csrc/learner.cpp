@@ -81,7 +81,7 @@ struct hl_learner {
   ConvTailPlan convTail{};      // convt.hip: sample-resident kernels for the layers behind the first (on = 0: per-layer launches)
   bool recTm = false; int* tmT = nullptr; int* tmSteps = nullptr; int* tmNext = nullptr;      // wide LSTM layers: time-step-major launches (rectm.hip)
   float* tmER[HL_MAX_HIDDEN] = {}; float* tmSD[HL_MAX_HIDDEN] = {}; float* tmFP[HL_MAX_HIDDEN] = {};
-  unsigned* tmCtr = nullptr; int tmCtrOff[HL_MAX_HIDDEN] = {}; float* tmET[HL_MAX_HIDDEN] = {};
+  unsigned* tmCtr = nullptr; int tmCtrN = 0; int tmCtrOff[HL_MAX_HIDDEN] = {}; float* tmET[HL_MAX_HIDDEN] = {};
   int tmMinCells = 64;      // layers wider than this: time-step-major
   bool recurrent = false; int recK = 0;    // LSTM hidden layers: rows per sample of the per-step buffers (nnBPTTseq + 1; one more for the time-step-major launches)
   int recWin = 0;                          // ... steps of a window: nnBPTTseq + 1
@@ -189,9 +189,10 @@ struct hl_learner {
     std::vector<void*> opened;               // windows opened through hipIpc (closed by hl_destroy)
   } xchg;
   // wait of the exchange kernel for a peer's message (SMARTIES_HIP_XCHG_TIMEOUT_MS): replicas are gated independently by their data
-  // (blockGradientUpdates), so a peer may legitimately lag by seconds -- the reference's MPI_Iallreduce simply waits; ten minutes,
-  // then the learner's sticky device error (the state stays as it was before that collective)
-  long long xchgTimeoutTicks = 6000000000LL;    // 60 s at 100 MHz (SMARTIES_HIP_XCHG_TIMEOUT_MS): how long a replica waits inside the exchange kernel for its peers
+  // (blockGradientUpdates), so a peer may legitimately lag by seconds or minutes behind a slow simulator -- the reference's
+  // MPI_Iallreduce simply waits.  Ten minutes (60 s killed a training run the reference would have carried on), then the
+  // learner's sticky device error (the state stays as it was before that collective); tests and bench.py set their own shorter bound
+  long long xchgTimeoutTicks = 60000000000LL;   // 600 s at 100 MHz (SMARTIES_HIP_XCHG_TIMEOUT_MS): how long a replica waits inside the exchange kernel for its peers
   // moments exchange state
   bool momentsPending = false, initPending = false;
   // timing
@@ -794,7 +795,7 @@ int hl_create(const hl_config* cfg, hl_learner** out) {
       HIPCK(devAlloc(&h->tmT, (size_t)B)); HIPCK(devAlloc(&h->tmSteps, (size_t)B)); HIPCK(devAlloc(&h->tmNext, (size_t)B));
       int nCtr = 0;
       for (int j = 0; j < h->nHidden; ++j) { h->tmCtrOff[j] = nCtr; nCtr += (h->hid[j].size / 16) * ((B + 15) / 16); }      // (recTm: no convolutions in front)
-      HIPCK(devAlloc(&h->tmCtr, (size_t)nCtr));
+      HIPCK(devAlloc(&h->tmCtr, (size_t)nCtr)); h->tmCtrN = nCtr;
     }
   }
   {   // fused forward + head + dX kernel: two equal hidden blocks of width H <= 256, small state / action spaces

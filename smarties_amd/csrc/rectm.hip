@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void lstm_tm_prepare_kernel(RecArgs a) {
   const int T = min(a.nBPTT, t), nextRow = a.bt.nextOf[b];
   const int nSteps = T + 1 + (nextRow >= 0 ? 1 : 0);
   const long long r = (long long)b * a.K + k;
+  // the backward launches tell the first of a tile's two producers from the second by the parity of an arrival counter: zeroed here, in
+  // front of every window, so that a launch that never completed (device fault, failed replay) cannot leave a parity behind that would
+  // make every later step pair values of different steps
+  if (b == 0 && k == 0) for (int i = tid; i < a.tmCtrN; i += 256) a.tmCtr[i] = 0u;
   if (k == 0) {
     if (tid == 0) { a.tmT[b] = T; a.tmSteps[b] = nSteps; a.tmNext[b] = nextRow; }
     for (int j = 0; j < a.nL; ++j) {
@@ -279,6 +283,9 @@ __global__ __launch_bounds__(256) void lstm_tm_bwd_kernel(RecArgs a, int j0, int
   float* mine = below ? a.tmET[J] : a.tmER[J];
   const float* other = below ? a.tmER[J] : a.tmET[J];
   const size_t at = (size_t)min(b, a.B - 1) * nCJ + min(c, nCJ - 1);
+  // (hand-off without a release / acquire pair, on purpose: the ONLY data that changes hands are these values, written by agent-scope
+  //  atomic stores -- which go to the coherence point themselves -- and acknowledged (vmcnt(0)) before the arrival is counted; the
+  //  second producer reads them back with agent-scope atomic loads.  A release here would write back this XCD's whole L2: ~15 us.)
   if (b < a.B && c < nCJ) __hip_atomic_store(mine + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): this tile's values are at the coherence point
   __syncthreads();

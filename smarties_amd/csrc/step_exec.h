@@ -698,6 +698,7 @@ int launchMomentsApply(hl_learner* h, bool bInit, double rRateFac) {
 // keys; the keys are the per-episode aggregates the device maintains, fetched when a removal may be due.
 bool evictionDue(const hl_learner* h);
 int prepareExact(hl_learner* h, int n);
+bool graphUsable(const hl_learner* h, int U, int p0);
 int touchReplay(hl_learner* h);
 int ensureConvPrep(hl_learner* h);
 int applyRemoval(hl_learner* h) {
@@ -806,7 +807,7 @@ RecArgs recArgs(hl_learner* h, int parity, int seg = -1) {
   ra.nL = jEnd - jBeg;
   ra.K = h->recK; ra.nBPTT = h->recWin - 1; ra.W = h->W; ra.gates = h->hid[jBeg].lstm; ra.func = h->cfg.nnFunc; ra.nApp = (j0 || seg == 1) ? 0 : h->nApp;
   for (int j = jBeg; j < jEnd; ++j) ra.L[j - jBeg] = h->rec[j];
-  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; ra.tmFP[j - jBeg] = h->tmFP[j]; ra.tmCtrOff[j - jBeg] = h->tmCtrOff[j]; ra.tmET[j - jBeg] = h->tmET[j]; } ra.tmCtr = h->tmCtr; }
+  if (h->recTm && seg < 0) { ra.tmT = h->tmT; ra.tmSteps = h->tmSteps; ra.tmNext = h->tmNext; for (int j = jBeg; j < jEnd; ++j) { ra.tmER[j - jBeg] = h->tmER[j]; ra.tmSD[j - jBeg] = h->tmSD[j]; ra.tmFP[j - jBeg] = h->tmFP[j]; ra.tmCtrOff[j - jBeg] = h->tmCtrOff[j]; ra.tmET[j - jBeg] = h->tmET[j]; } ra.tmCtr = h->tmCtr; ra.tmCtrN = h->tmCtrN; }
   if (seg == 1) { ra.Xin = h->segY; ra.ldXin = h->ldSeg; }
   else if (j0) { ra.Xin = h->hid[0].Y; ra.ldXin = h->hid[0].ldA; }
   if (seg == 0) { ra.YoutRows = h->segY; ra.ldYR = h->ldSeg; ra.DresRows = h->segDres; ra.ldDR = h->ldSeg; }
@@ -1062,6 +1063,7 @@ int touchReplay(hl_learner* h) {
 int prepareExact(hl_learner* h, int n) {
   if (!h->useGraph || n >= 1000 || (exchanging(h) && (!(h->exchGraph && wired(h)) || n > 64)) || h->cfg.dataSamplingAlgo != HL_SAMPLE_UNIFORM) return HL_OK;
   if (h->bigBatch && (n > 64 || exchanging(h))) return HL_OK;
+  if (!graphUsable(h, n, 0)) return HL_OK;      // (the node cap of the time-step-major recurrent nets holds for exact graphs too: ADVICE r05)
   { const int rc = ensureConvPrep(h); if (rc) return rc; }      // outside the capture: the captured forward refuses stale filter layouts
   if (!h->notifyPin) { HIPCK(hipHostMalloc((void**)&h->notifyPin, 64, hipHostMallocDefault)); *h->notifyPin = 0; }
   if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
