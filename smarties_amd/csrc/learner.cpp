@@ -202,6 +202,25 @@ struct hl_learner {
 
 namespace {
 
+// Exchange windows (hl_xchg_export) are UNCACHED device memory, and uncached memory must never go back to the allocator: on this
+// runtime (ROCm 7.2, gfx950) memory freed after a life as hipDeviceMallocUncached and handed out again by hipMalloc made kernels of
+// LATER learners read stale values -- gradients off by whole tiles, a problem table with wild pointers (memory aperture violation);
+// found in round 6 by the replica tests at the BASELINE shapes, which create and destroy dozens of learners in one process
+// (tools/dbg_xchg3.py reproduces it: 7 of 8 iterations; never with the windows kept, nor with cached or fine-grained windows).
+// A destroyed learner's window therefore waits here for the next learner that needs one of its size on its device.
+struct WindowPool { std::mutex mu; std::multimap<std::pair<int, size_t>, unsigned char*> free; };
+WindowPool& windowPool() { static WindowPool* p = new WindowPool; return *p; }      // (never destructed: the runtime may be gone by then)
+unsigned char* windowPoolGet(int dev, size_t bytes) {
+  WindowPool& wp = windowPool(); std::lock_guard<std::mutex> g(wp.mu);
+  auto it = wp.free.find({dev, bytes});
+  if (it == wp.free.end()) return nullptr;
+  unsigned char* q = it->second; wp.free.erase(it); return q;
+}
+void windowPoolPut(int dev, size_t bytes, unsigned char* q) {
+  WindowPool& wp = windowPool(); std::lock_guard<std::mutex> g(wp.mu);
+  wp.free.insert({{dev, bytes}, q});
+}
+
 int fail(hl_learner* h, int code, const std::string& m) { if (h) h->err = m; return code; }
 int hipFail(hl_learner* h, hipError_t e, const char* what) {
   return fail(h, HL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -941,7 +960,8 @@ int hl_destroy(hl_learner* h) {
   if (h->actPin) hipHostFree(h->actPin);
   if (h->notifyPin) hipHostFree(h->notifyPin);
   for (void* q : h->xchg.opened) hipIpcCloseMemHandle(q);
-  for (void* q : {(void*)h->xchg.win, (void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
+  if (h->xchg.win) { windowPoolPut(h->dev, h->xchg.winBytes, h->xchg.win); h->xchg.win = nullptr; }      // (never back to the allocator: windowPoolGet)
+  for (void* q : {(void*)h->xchg.dPeers, (void*)h->xchg.ctl}) if (q) hipFree(q);
   void* ptrs[] = {h->splitPart, h->widePart, h->wideCtr, h->W, h->M1, h->M2, h->G, h->sc, h->dOut, h->dProbs, h->dFlatGiven, h->dEidList,
     h->dRedMax, h->dRedErr, h->dMomPartial, h->dMoments, h->dStatsOut, h->dStatsIns,
     h->rp.S, h->rp.A, h->rp.MU, h->rp.R, h->rp.V, h->rp.ADV, h->rp.RET, h->rp.DQ, h->rp.IMPW, h->rp.DKL,
@@ -2096,7 +2116,8 @@ int hl_xchg_export(hl_learner* h, uint8_t out[HL_XCHG_HANDLE_BYTES]) {
     x.slotsOffset = (2 * R * XCHG_CHUNKS * sizeof(unsigned long long) + 255) & ~(size_t)255;
     x.winBytes = x.slotsOffset + 2 * R * x.slotBytes;
     // uncached: the peers' stores land in HBM behind this device's L2, the owner's loads must not be served from it
-    HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&x.win), x.winBytes, hipDeviceMallocUncached));
+    x.win = windowPoolGet(h->dev, x.winBytes);
+    if (!x.win) HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&x.win), x.winBytes, hipDeviceMallocUncached));
     HIPCK(hipMemset(x.win, 0, x.winBytes));
     HIPCK(devAlloc(&x.ctl, 1));
     HIPCK(devAlloc(&x.dPeers, R));
