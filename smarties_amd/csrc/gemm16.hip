@@ -18,6 +18,7 @@
 // parameter gradients of a step are ONE launch.
 #include "dw_wide_dev.h"
 #include "head_body.h"
+#include "xchg_dev.h"
 
 namespace hl {
 
@@ -228,8 +229,11 @@ __device__ __forceinline__ void dwDirectTile(const GemmProblem& P, int tile, uns
 // the weight-gradient launch of the fused path: the problem table travels in the kernel arguments
 // (scalar loads from the kernarg segment instead of two dependent global round trips)
 // (the two riders' arguments travel unpacked: two whole ExtraArgs records would push the kernel-argument segment past 4 KB)
+// fold.on (replicas over peer windows, replayed steps): the exchange of the gradient this launch produces is part of the launch -- the
+// tiles store into every window (the own one too) and count themselves, the bookkeeping rider pushes the counters message, and
+// fold.nCh chunk workgroups at the END of the grid do what the exchange launch did (xchg_dev.h): a replica's step = K1 + this launch
 __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevScalars* __restrict__ sc, AdamHyper hyp, int postOn, PostArgs post,
-                                                       int sampPhases, int helpers, SampleArgs samp) {
+                                                       int sampPhases, int helpers, SampleArgs samp, FoldArgs fold) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[GEMM_LDS > TAIL_LDS_BYTES ? GEMM_LDS : TAIL_LDS_BYTES];
 #ifdef HL_TAIL_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 73) const_cast<DevScalars*>(sc)->dbgT[29] = wall_clock64();
@@ -242,12 +246,32 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
   const int r1 = postOn ? 1 : 0, r2 = sampPhases ? 1 + helpers : 0, nRiders = r1 + r2;
   if ((int)blockIdx.x < nRiders) {
     const int b = blockIdx.x;
-    if (b < r1) postPhase(post, smem);
+    if (b < r1) {
+      postPhase(post, smem);
+      if (fold.on) {      // the counters message (sixteen floats thread 0 just wrote behind the gradient) into every window, then this producer's arrival
+        __syncthreads();
+        if (threadIdx.x < 16) {
+          const float x = __hip_atomic_load(post.cntMsg + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const size_t so = pushSlot(hyp.push) + (size_t)((post.cntMsg - hyp.push.gBase) + threadIdx.x) * 4;
+          for (int p = 0; p < hyp.push.nRanks; ++p) *reinterpret_cast<float*>(hyp.push.peers[p] + so) = x;
+        }
+        __threadfence();      // (the scalars this pass wrote -- the step's largest error -- are read by the chunk workgroup that closes the step, on whichever XCD it runs)
+        foldArrive(fold.ctl);
+      }
+    }
     else if (b == r1) samplePhases(samp, sampPhases, smem);
     else gatherHelper(samp, b - r1 - 1, helpers, smem);
     return;
   }
   const int bid = blockIdx.x - nRiders;
+  if (fold.on && bid >= fold.nTiles) {      // chunk workgroups of the folded exchange
+    XchgCore c; c.msg = fold.msg; c.n = fold.n; c.nRanks = hyp.push.nRanks; c.rank = hyp.push.rank; c.peers = hyp.push.peers;
+    c.slotsOffset = (size_t)hyp.push.slotsOffset; c.slotBytes = (size_t)hyp.push.slotBytes; c.ctl = fold.ctl; c.sc = const_cast<DevScalars*>(sc);
+    c.timeoutTicks = fold.timeoutTicks; c.pushed = fold.n; c.localTarget = (unsigned)fold.nTiles + 1u;
+    XchgAdam ad; ad.W = fold.W; ad.M1 = fold.M1; ad.M2 = fold.M2; ad.n = fold.nAdam; ad.lambda = hyp.lambda; ad.fac = hyp.fac; ad.parity = hyp.parity;
+    xchgChunk<float, true, true>(c, ad, post, POST_BETA, bid - fold.nTiles, fold.nCh, reinterpret_cast<XchgLds*>(smem));
+    return;
+  }
   int p = 0;
 #pragma unroll
   for (int i = 1; i < DW_TABLE_MAX; ++i) if (i < tbl.n && bid >= tbl.p[i].tileStart) p = i;
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
     gemmTile<GEMM_ROLE_DW, GEMM_W>(P, bid - P.tileStart, smem, sc, hyp, 0);
   }
   else gemmTile<GEMM_ROLE_DW>(P, bid - P.tileStart, smem, sc, hyp, 0);
+  if (fold.on) foldArrive(fold.ctl);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -404,11 +429,15 @@ hipError_t launch_splitk_reduce(const GemmProblem* dProbs, int nProbs, int maxMN
 }
 
 hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s,
-                           const ExtraArgs* extra2) {
+                           const ExtraArgs* extra2, const FoldArgs* fold) {
   PostArgs post{}; SampleArgs samp{}; int postOn = 0, phases = 0, helpers = 0;
   if (extra && extra->role == 2) { post = extra->post; postOn = 1; }
   if (extra2 && extra2->role == 1) { samp = extra2->samp; phases = extra2->phases; helpers = extra2->helpers; }
-  hipLaunchKernelGGL(dw_table_kernel, dim3(nBlocks + postOn + (phases ? 1 + helpers : 0)), dim3(256), 0, s, tbl, sc, hyp, postOn, post, phases, helpers, samp);
+  FoldArgs fo{}; if (fold) fo = *fold;
+  // (a folded launch needs its bookkeeping rider -- it produces the counters message and is one of the counted producers -- and windows
+  //  that take the own values too)
+  if (fo.on && (!postOn || !hyp.push.on || !hyp.push.self || !post.cntMsg || fo.nTiles != nBlocks || fo.nCh < 1 || fo.nCh > XCHG_CHUNKS)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dw_table_kernel, dim3(nBlocks + postOn + (phases ? 1 + helpers : 0) + (fo.on ? fo.nCh : 0)), dim3(256), 0, s, tbl, sc, hyp, postOn, post, phases, helpers, samp, fo);
   return hipGetLastError();
 }
 

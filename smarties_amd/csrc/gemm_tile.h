@@ -60,7 +60,7 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
     P.C[j] = g;
     if (hyp.push.on) {      // replicas: into the peers' windows too (a handful of columns: element stores)
       const size_t so = pushSlot(hyp.push) + (size_t)((P.C - hyp.push.gBase) + j) * 4;
-      for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank) *reinterpret_cast<float*>(hyp.push.peers[p] + so) = g;
+      for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank || hyp.push.self) *reinterpret_cast<float*>(hyp.push.peers[p] + so) = g;
     }
     if (P.adam) { AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac; adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
   }
@@ -277,7 +277,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
         const f32x4 x = *reinterpret_cast<const f32x4*>(red + r * 16 + c);
         const size_t off = isW ? (size_t)(P.C - hyp.push.gBase) + (size_t)mm * P.ldc + nn : (size_t)(P.biasOut - hyp.push.gBase) + nn;
         const size_t so = pushSlot(hyp.push) + off * 4;
-        for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank) *reinterpret_cast<f32x4*>(hyp.push.peers[p] + so) = x;
+        for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank || hyp.push.self) *reinterpret_cast<f32x4*>(hyp.push.peers[p] + so) = x;
         __builtin_amdgcn_s_waitcnt(0);          // acknowledged before this wavefront ends
       }
     }

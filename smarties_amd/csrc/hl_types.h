@@ -176,12 +176,13 @@ constexpr int BIG_DW_MAX = 12;
 struct BigDwList { int n; int idx[BIG_DW_MAX]; int start[BIG_DW_MAX + 1]; };
 
 // one-kernel exchange between replicas (xchg.hip): sequence number of the next collective, arrival count of its workgroups
-struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int arrived; /* workgroups of the running collective whose peers' stamps all came (FUSE: nobody applies Adam before all have) */ };
+struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int arrived; /* workgroups of the running collective whose peers' stamps all came (FUSE: nobody applies Adam before all have) */
+                 unsigned int pushed; /* folded weight-gradient launch: its producers (tiles, bookkeeping rider) whose window stores are acknowledged */ unsigned int pad; };
 // replicas connected through peer windows: the weight-gradient launch stores every gradient tile into the peers' windows as well
 // (16-byte stores over xGMI from the tile's epilogue), so the transfer overlaps the launch and the exchange kernel behind it only
 // stamps, waits, sums and applies Adam (round 4; before: the exchange kernel pushed the whole message after the launch)
 struct PushArgs {
-  int on, nRanks, rank, pad;
+  int on, nRanks, rank, self;           // self: the own window takes the values too (folded launch: the chunk workgroups read windows only)
   unsigned char* const* peers;          // [nRanks] windows as this device addresses them
   unsigned long long slotsOffset, slotBytes;
   const XchgCtl* ctl;                   // parity of the collective the gradient belongs to = ctl->seq & 1

@@ -205,7 +205,9 @@ struct XchgArgs {
   long long timeoutTicks;                       // wall_clock64 ticks (100 MHz) a workgroup waits for a peer's stamp
   int fuse; AdamArgs adam; PostArgs post;      // fuse != 0 (float messages): Adam on the summed chunk, then the bookkeeping pass
   long long pushed;                             // leading elements of the message the producing launch already stored into the peers' windows (PushArgs)
+  int maxChunks;                                // workgroups (chunks) of a collective at most: XCHG_CHUNKS, fewer where replicas share a device (hl_xchg_connect)
 };
+int xchg_chunks(long long bytes, int maxChunks);      // how a message is cut: part of the wire protocol (every replica, folded or not, cuts alike)
 hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype /* 0 float, 1 double, 2 int64 */, hipStream_t s);
 // zeroes, in this replica's own window, what the collective just finished left in the senders' slots (first `bytes` of each): the
 // gradient slots then hold zeros wherever no tile of a pushing launch writes (padding of the parameter layout)
@@ -278,10 +280,13 @@ hipError_t launch_step_tail(const PostArgs* post, const SampleArgs* samp, hipStr
 enum { GEMM_ROLE_FWD0 = 0, GEMM_ROLE_FWD = 1, GEMM_ROLE_DX = 2, GEMM_ROLE_DW = 3 };
 constexpr int DW_TABLE_MAX = 8;
 struct DwTable { GemmProblem p[DW_TABLE_MAX]; int n; };
+// the replicas' exchange folded into the weight-gradient launch (round 6): nCh chunk workgroups behind the nTiles tile workgroups stamp,
+// wait, sum in rank order, apply Adam and close the step (xchg_dev.h: xchgChunk<float, true, true>); windows and ranks: AdamHyper::push
+struct FoldArgs { int on, nCh, nTiles, pad; float* msg; long long n; float* W; float* M1; float* M2; long long nAdam; XchgCtl* ctl; long long timeoutTicks; };
 // riders: `extra` (bookkeeping of this step) in workgroup 0, `extra2` (sampler phase C of the next minibatch, PH_PUBLISH) behind it,
 // followed by extra2->helpers gather workgroups
 hipError_t launch_dw_table(const DwTable& tbl, int nBlocks, const DevScalars* sc, const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s,
-                           const ExtraArgs* extra2 = nullptr);
+                           const ExtraArgs* extra2 = nullptr, const FoldArgs* fold = nullptr);
 // up to two riders (extra, extra2) occupy workgroups 0 and 1 of the grid
 hipError_t launch_gemm(int role, const GemmProblem* dProbs, int nProbs, int nBlocks, const DevScalars* sc,
                        const AdamHyper& hyp, const ExtraArgs* extra, hipStream_t s, const ExtraArgs* extra2 = nullptr);

@@ -176,6 +176,7 @@ struct hl_learner {
   bool exchGraph = true;     // replica exchanges may be captured into the replayed graphs (cleared if a capture fails)
   bool xcdSafe = false;      // fused kernel: panel exchange through agent-scope accesses (workgroup b was NOT found on XCD b % 8, or forced)
   bool fusedOk = false; unsigned* panelCtr = nullptr;   // fused forward/head/dX kernel (fused.hip) usable for this network
+  bool foldOk = false, foldNow = false;    // ... and runs the exchange itself (round 6: dw_table_kernel's chunk workgroups); foldNow: for the launch being issued
   bool pushOk = false, pushGrad = false;   // replicas over peer windows: the weight-gradient launch pushes its tiles itself (PushArgs); pushGrad: for the launch being issued
   bool fusedWideOk = false;  // two equal hidden blocks with a wide state and / or a head beyond the fused kernel's: fusedw.hip takes the two-kernel step
   int dbgVariant = 0;
@@ -187,6 +188,7 @@ struct hl_learner {
     unsigned char* win = nullptr; size_t winBytes = 0, slotsOffset = 0, slotBytes = 0;
     unsigned char** dPeers = nullptr; XchgCtl* ctl = nullptr;
     std::vector<void*> opened;               // windows opened through hipIpc (closed by hl_destroy)
+    int maxChunks = XCHG_CHUNKS;             // chunk workgroups of a collective at most (fewer where replicas share a device: hl_xchg_connect)
   } xchg;
   // wait of the exchange kernel for a peer's message (SMARTIES_HIP_XCHG_TIMEOUT_MS): replicas are gated independently by their data
   // (blockGradientUpdates), so a peer may legitimately lag by seconds or minutes behind a slow simulator -- the reference's
@@ -2165,6 +2167,18 @@ int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
     }
   }
   HIPCK(hipMemcpy(x.dPeers, peers.data(), (size_t)R * sizeof(unsigned char*), hipMemcpyHostToDevice));
+  // Replicas that SHARE a device (the one-GPU test box: 2 - 8 of them; never on a node, one process per GPU) wait for each other inside
+  // their kernels while competing for the same CUs: 8 x 64 waiting chunk workgroups of the folded weight-gradient launch (each with that
+  // launch's registers and LDS) kept the peers' fused kernels from getting their panel groups resident -- bounded spins, device error
+  // 77.  The message is therefore cut into fewer chunks the more replicas sit on the busiest device; the cut is part of the wire
+  // protocol and every replica derives the same figure from the same handles.
+  { int most = 1;
+    for (int r = 0; r < R; ++r) {
+      int devR, same = 0; std::memcpy(&devR, handles + (size_t)r * HL_XCHG_HANDLE_BYTES + 76, 4);
+      for (int q = 0; q < R; ++q) { int devQ; std::memcpy(&devQ, handles + (size_t)q * HL_XCHG_HANDLE_BYTES + 76, 4); same += devQ == devR ? 1 : 0; }
+      most = std::max(most, same);
+    }
+    x.maxChunks = most <= 1 ? XCHG_CHUNKS : std::max(4, XCHG_CHUNKS / most); }
   x.on = true;
   h->graphsStale = true;
   // identical initial weights on every replica: MPI_Bcast from rank 0 (Network/Builder.cpp:143-144) as a sum with zeros
@@ -2174,6 +2188,7 @@ int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
   // windows itself (recurrent and convolutional nets have further gradient producers -- split-row joins, filter gradients: the
   // exchange kernel keeps pushing their message)
   { const char* np = getenv("SMARTIES_HIP_NO_PUSH"); h->pushOk = !(np && np[0] == '1') && !h->recurrent && h->nConv == 0 && !h->bigBatch; }      // (local batches above 1024: split-row joins and the 64 x 64 tiles never push -- the exchange kernel sends their gradient)
+  { const char* nf = getenv("SMARTIES_HIP_NO_FOLD"); h->foldOk = h->pushOk && !(nf && nf[0] == '1'); }      // (the round-5 step: a separate exchange launch behind the pushing one)
   int rc = xchgAllreduce(h, h->G, (size_t)h->nParams, 0); if (rc) return rc;
   HIPCK(hipMemcpyAsync(h->W, h->G, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));

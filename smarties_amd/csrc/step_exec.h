@@ -245,6 +245,7 @@ AdamHyper adamHyper(const hl_learner* h, int parity) {
   if (h->pushGrad) {      // (set by the step sequences around their weight-gradient launches)
     a.push.on = 1; a.push.nRanks = h->cfg.n_ranks; a.push.rank = h->cfg.rank; a.push.peers = h->xchg.dPeers;
     a.push.slotsOffset = h->xchg.slotsOffset; a.push.slotBytes = h->xchg.slotBytes; a.push.ctl = h->xchg.ctl; a.push.gBase = h->G;
+    a.push.self = h->foldNow ? 1 : 0;      // (folded launch: launchWeightGrad)
   }
   return a;
 }
@@ -514,8 +515,17 @@ int launchHead(hl_learner* h, int parity, hipStream_t s, bool nextSample = false
 // fuseAdam: apply the Adam update inside the dW epilogue (only valid without a gradient exchange)
 // dW launch of the fused path: the dX contractions were done by the fused kernel; riders: the
 // bookkeeping of THIS step and sampler phase C of the NEXT one
+// `fold` (replicas over peer windows, replayed steps): the gradient's exchange, Adam and the step's closing bookkeeping run inside this
+// launch (gemm16.hip: dw_table_kernel, xchg_dev.h) -- the caller issues no exchange launch; only with h->foldOk, the bookkeeping rider
+// and a problem table that travels in the kernel arguments
+bool foldUsable(const hl_learner* h, int parity) {
+  return h->foldOk && h->pushGrad && h->xchg.on && h->buf[parity].dwCount <= DW_TABLE_MAX && ((h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS) & 3) == 0;
+}
 int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bool fusePost, bool nextSampleC,
-                     int postMode = POST_AGG | POST_BETA) {
+                     int postMode = POST_AGG | POST_BETA, bool fold = false) {
+  struct FoldScope { hl_learner* h; ~FoldScope() { h->foldNow = false; } } foldScope{h};
+  if (fold && !(fusePost && !fuseAdam && foldUsable(h, parity))) return fail(h, HL_ERR_STATE, "folded weight-gradient launch asked for where it cannot run");
+  h->foldNow = fold;
   const AdamHyper hyp = adamHyper(h, parity);
   const StepBuf& sb = h->buf[parity];
   ExtraArgs exP{}, exC{};
@@ -524,7 +534,15 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
   if (sb.dwCount <= DW_TABLE_MAX) {   // problem table in the kernel arguments
     const DwTable& tbl = fuseAdam ? sb.dwTableAdam : sb.dwTable;
     if (nextSampleC && !exC.samp.noGather) { exC.phases |= PH_PUBLISH; exC.helpers = 7; exC.samp.tagSeq = 1; exC.samp.selfSearch = 1; }
-    HIPCK(timed(h, "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s, nextSampleC ? &exC : nullptr); }));
+    FoldArgs fo{};
+    if (fold) {
+      const long long n = (long long)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, bytes = n * 4;
+      fo.on = 1; fo.nCh = xchg_chunks(bytes, h->xchg.maxChunks);      // (as launch_xchg_allreduce cuts the message) fo.nTiles = sb.dwBlocks; fo.msg = h->G; fo.n = n; fo.W = h->W; fo.M1 = h->M1; fo.M2 = h->M2; fo.nAdam = h->nParams;
+      fo.ctl = h->xchg.ctl; fo.timeoutTicks = h->xchgTimeoutTicks;
+      if ((size_t)bytes > h->xchg.slotBytes) return fail(h, HL_ERR_COMM, "exchange message larger than the window slot");
+    }
+    HIPCK(timed(h, fold ? "dw_table_fold" : "dw_table_kernel", s, [&] { return launch_dw_table(tbl, sb.dwBlocks, h->sc, hyp, fusePost ? &exP : nullptr, s, nextSampleC ? &exC : nullptr, fold ? &fo : nullptr); }));
+    if (fold) h->nCollectives += 1;
     return HL_OK;
   }
   // (more problems than the argument table holds: the table in device memory; the same riders, the gather helpers behind them)
@@ -745,7 +763,7 @@ int xchgAllreduce(hl_learner* h, void* buf, size_t n, int dtype, int fuseParity 
     xa.pushed = h->pushGrad ? h->nParams : 0;      // (the launch that produced this gradient pushed it)
   } xa.msg = buf; xa.n = (long long)n; xa.nRanks = h->cfg.n_ranks; xa.rank = h->cfg.rank; xa.peers = h->xchg.dPeers;
   xa.slotsOffset = h->xchg.slotsOffset; xa.slotBytes = h->xchg.slotBytes; xa.ctl = h->xchg.ctl; xa.sc = h->sc;
-  xa.timeoutTicks = h->xchgTimeoutTicks;
+  xa.timeoutTicks = h->xchgTimeoutTicks; xa.maxChunks = h->xchg.maxChunks;
   if (n * (dtype == 0 ? 4 : 8) > h->xchg.slotBytes) return fail(h, HL_ERR_COMM, "exchange message larger than the window slot");
   HIPCK(timed(h, "xchg_allreduce", h->stream, [&] { return launch_xchg_allreduce(xa, dtype, h->stream); }));
   h->nCollectives += 1;
@@ -980,6 +998,10 @@ int captureSteps(hl_learner* h, int U, int p0, GraphSlot* slot, bool notify = fa
       // replicas: the exchange is part of the replayed graph (RCCL calls are captured like kernels).  ONE collective per
       // step: the bookkeeping rider of the dW launch appends the four counters to the gradient buffer (four exact 16-bit
       // chunks each), the pass after Adam decodes their sums.
+      if (foldUsable(h, p)) {      // the exchange, Adam and the closing bookkeeping inside the weight-gradient launch: two launches per step
+        rc = launchWeightGrad(h, p, false, s0, true, true, POST_AGG, true); if (rc) break;
+        continue;
+      }
       rc = launchWeightGrad(h, p, false, s0, true, true, POST_AGG);
       if (!rc && h->xchg.on) { rc = xchgAllreduce(h, h->G, (size_t)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, 0, p); if (rc) break; continue; }
       if (!rc) rc = allreduceGrad(h);

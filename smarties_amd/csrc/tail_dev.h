@@ -69,7 +69,10 @@ __device__ __forceinline__ void refEerPenal(DevScalars* sc, double fracOffPol, d
   } else { sc->beta = beta; sc->alpha = alpha; }
 }
 
-__device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs, float* sFarP = nullptr, int farLdsFloats = 0) {
+// modeOv >= 0: the pass runs in that mode instead of a.mode (the folded weight-gradient launch closes its step with the record of its
+// bookkeeping rider: no second PostArgs among the kernel arguments, no copy on the stack)
+__device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta, unsigned* sMaxAbs, float* sFarP = nullptr, int farLdsFloats = 0, int modeOv = -1) {
+  const int mode = modeOv >= 0 ? modeOv : a.mode;
   DevScalars* sc = a.sc;
   const int tid = threadIdx.x, B = a.B;
   // every scalar the pass needs, fetched once up front (uniform loads); thread 0 writes the
@@ -78,17 +81,17 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   const double ema0 = sc->maxAbsErrEMA, bt1 = sc->adam_bt1, bt2 = sc->adam_bt2;
   const long long nGrad0 = sc->nGradSteps, nFarTot0 = sc->nFarTotal, nFarStat0 = sc->nFarStat;
   const long long nTrans = sc->nTransitions, cnt0 = sc->cnt[0], cnt1 = sc->cnt[1], cnt2 = sc->cnt[2], cnt3 = sc->cnt[3], nStep0 = sc->nStep, nEpL = sc->nEpisodes;
-  const float maxAll0 = (a.mode & POST_AGG) ? sc->maxAbsErrAll : sc->maxAbsErrStep;
+  const float maxAll0 = (mode & POST_AGG) ? sc->maxAbsErrAll : sc->maxAbsErrStep;
   PSTAMP(sc, 16);
   if (tid == 0) { *sFarDelta = 0; *sMaxAbs = 0u; }
   // the terms of the far-policy count (dev_common.h): this thread's segment, fetched now, used after the aggregates are updated
   const int nEp = (int)nEpL, farPer = (nEp + 255) / 256;
-  const bool defer = (a.mode & POST_DEFER) != 0;      // the count itself is taken by farBetaPhase: only the fractions are patched here
+  const bool defer = (mode & POST_DEFER) != 0;      // the count itself is taken by farBetaPhase: only the fractions are patched here
   // large batches (sample.hip: post_agg_chunks_kernel): aggChunk == 1 -- this workgroup updates the episode records of ITS 256 samples
   // (a run of samples of one episode belongs to the workgroup of its first sample) and leaves; aggChunk == 2 -- that has been done
   // by the launch in front, the maximum waits in DevScalars::maxAbsScratch
   const int chunkMode = a.aggChunk;
-  const bool farOn = (a.mode & POST_AGG) != 0, farLds = farOn && !defer && !chunkMode && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
+  const bool farOn = (mode & POST_AGG) != 0, farLds = farOn && !defer && !chunkMode && sFarP && farPer <= FAR_REGS && FAR_REGS * 256 <= farLdsFloats;
   float farT[FAR_REGS], farL[FAR_REGS];
   unsigned long long farG0[FAR_SUB] = {};
   if (farLds) {
@@ -100,7 +103,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
   if (!farLds) __syncthreads();       // (thread 0's initialisation above; with farLds the barrier in front of the leaders' work orders it)
   PSTAMP(sc, 17);
   long long nFarStat = nFarStat0; float maxAll = maxAll0;
-  if (a.mode & POST_AGG) {
+  if (mode & POST_AGG) {
     const float C = (float)Cmax0, invC = (float)Cinv0;
     const int bBeg = chunkMode == 1 ? (int)blockIdx.x * 256 : 0, bEnd = chunkMode == 1 ? min(B, bBeg + 256) : (chunkMode == 2 ? 0 : B);
     for (int b0 = bBeg; b0 < bEnd; b0 += 256) {
@@ -224,15 +227,15 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
       }
     }
   }
-  if ((a.mode & POST_ENCODE) && a.cntMsg && tid == 0) {   // eager steps: the counters as they stand after the removal pass
+  if ((mode & POST_ENCODE) && a.cntMsg && tid == 0) {   // eager steps: the counters as they stand after the removal pass
     const long long c4[4] = {sc->seenLocal[0], sc->seenLocal[1], sc->cnt[2], sc->cnt[3]};
     encodeCounters(a.cntMsg, c4);
   }
-  if ((a.mode & (POST_BETA | POST_INIT)) && tid == 0) {
+  if ((mode & (POST_BETA | POST_INIT)) && tid == 0) {
     // updateCounters (:46-92); with several replicas cnt[] holds the all-reduced counters
-    const bool rewritten = (a.mode & POST_AGG) && a.nRanks > 1;      // (the bookkeeping part above put the local counters back)
+    const bool rewritten = (mode & POST_AGG) && a.nRanks > 1;      // (the bookkeeping part above put the local counters back)
     long long cntR[4] = {rewritten ? sc->cnt[0] : cnt0, rewritten ? sc->cnt[1] : cnt1, cnt2, cnt3};
-    if (a.cntMsg && (a.mode & POST_BETA)) {         // decode the summed chunks (each sum < 2^24: exact)
+    if (a.cntMsg && (mode & POST_BETA)) {         // decode the summed chunks (each sum < 2^24: exact)
       for (int c = 0; c < 4; ++c) {
         long long v = 0;
         for (int q = 0; q < 4; ++q) v += (long long)(a.cntMsg[4 * c + q] + 0.5f) << (16 * q);
@@ -246,7 +249,7 @@ __device__ __forceinline__ void postPart(const PostArgs& a, long long* sFarDelta
     const double nDataSize = fmax(a.maxObsGlobal, (double)nStored);
     const double learnRefer = 0.1 * a.batchGlobal / nDataSize;
     if (!defer) refEerPenal(sc, fracOffPol, learnRefer, a.penalTol, beta0, alpha0, false);
-    if (a.mode & POST_BETA) {
+    if (mode & POST_BETA) {
       // stats.maxAbsError EMA (:239-240) uses the replica-local data size
       const double lrLoc = 0.1 * a.batchGlobal / fmax(a.maxObsGlobal, (double)nTrans);
       sc->maxAbsErrEMA = ema0 + lrLoc * ((double)maxAll - ema0);

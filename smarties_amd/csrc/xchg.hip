@@ -12,133 +12,18 @@
 // peers' flags, waits for the peers' stamps on ITS chunk only (no device-wide barrier), and sums the nRanks contributions in
 // rank order -- the own one from the local buffer -- so that every replica gets the same bits.  The waits are bounded: a lost
 // peer raises the learner's sticky device error (hl_sync then returns HL_ERR_HIP) instead of hanging the GPU.
-#include "tail_dev.h"
+#include "xchg_dev.h"
 
 namespace hl {
 
-template <typename T> struct Vec16 { T v[16 / sizeof(T)]; };
-
-// (relaxed: the window is uncached memory, every load goes to HBM; an acquire load would invalidate this XCD's L2 at every poll)
-__device__ __forceinline__ unsigned long long ldSys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void stSys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-// FUSE (the gradient message of a step): the workgroup that summed a chunk applies Adam to it (AdamOptimizer::apply_update,
-// Network/Optimizer.cpp:122-160) and the last workgroup to finish runs the bookkeeping that needs the summed counters
-// (MemoryProcessing::updateCounters ... beta, the next step's Adam scalars) -- a replica's step is then three launches.
+// (the chunk's work: xchg_dev.h -- shared with the chunk workgroups of the folded weight-gradient launch, gemm16.hip)
 template <typename T, bool FUSE>
 __global__ __launch_bounds__(256) void xchg_allreduce_kernel(XchgArgs a) {
-  __shared__ unsigned long long sSeq;
-  __shared__ int sLast, sFail;
-  __shared__ long long sFarDelta; __shared__ unsigned sMaxAbs;
-  const int tid = threadIdx.x, chunk = blockIdx.x, nCh = gridDim.x, R = a.nRanks, me = a.rank;
-  if (tid == 0) { sSeq = __hip_atomic_load(&a.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sFail = 0; }
-  __syncthreads();
-  const unsigned long long seq = sSeq, tag = seq + 1;
-  const int par = (int)(seq & 1);
-  // 16-byte units of the message; the last one may be partial (handled element-wise)
-  const long long bytes = a.n * (long long)sizeof(T), full = bytes >> 4;
-  const long long per = (full + nCh - 1) / nCh, v0 = per * chunk, v1 = min(full, v0 + per);
-  typedef Vec16<T> V;
-  V* msg = reinterpret_cast<V*>(a.msg);
-  const size_t slotOff = a.slotsOffset + ((size_t)par * R + me) * a.slotBytes;
-  // ---- push: this chunk into every peer's window (what the producing launch pushed itself -- the leading a.pushed elements of a
-  // gradient message, PushArgs -- is already there: its stores were acknowledged before that launch ended) ----
-  const long long vPushed = (a.pushed * (long long)sizeof(T)) >> 4;
-  for (long long v = max(v0, vPushed) + tid; v < v1; v += 256) {
-    const V x = msg[v];
-    for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<V*>(a.peers[p] + slotOff)[v] = x;
-  }
-  const long long tail0 = full * (16 / (long long)sizeof(T));          // elements behind the last full unit: chunk 0 carries them
-  if (chunk == 0 && tid < (int)(a.n - tail0)) {
-    const T x = reinterpret_cast<const T*>(a.msg)[tail0 + tid];
-    for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<T*>(a.peers[p] + slotOff)[tail0 + tid] = x;
-  }
-  __threadfence_system();
-  __syncthreads();
-  unsigned long long* myFlags = reinterpret_cast<unsigned long long*>(a.peers[me]) + (size_t)par * R * XCHG_CHUNKS;
-  if (tid < R && tid != me) {
-    stSys(reinterpret_cast<unsigned long long*>(a.peers[tid]) + ((size_t)par * R + me) * XCHG_CHUNKS + chunk, tag);
-    // ---- wait for the same chunk of every peer ----
-    const unsigned long long* f = myFlags + (size_t)tid * XCHG_CHUNKS + chunk;
-    const long long t0 = wall_clock64();
-    while (ldSys(f) < tag) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sFail = 1; break; }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
-  }
-  __syncthreads();
-  if constexpr (FUSE) {
-    // Two phases (round 5; ADVICE r03 / VERDICT r04): a chunk whose peers arrived used to sum and apply Adam at once -- if another
-    // chunk then timed out, the parameter vector was left PARTIALLY updated.  Now every workgroup reports that its stamps came and
-    // waits until all nCh have (they are resident together: at most XCHG_CHUNKS workgroups); a single failure -- the sticky device
-    // error -- makes every workgroup skip its sum and its Adam slice: after error 79 weights and moments are those of before the
-    // collective.  Costs one counter round trip among the launch's workgroups per gradient exchange.
-    if (tid == 0) {
-      if (!sFail) __hip_atomic_fetch_add(&a.ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const long long t0 = wall_clock64();
-      while (!sFail && __hip_atomic_load(&a.ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nCh) {
-        if (__hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sFail = 1; break; }
-        if (wall_clock64() - t0 > 2 * a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sFail = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __syncthreads();
-  }
-  // A peer's message never came (or an earlier collective already failed: the error is sticky): no workgroup sums, applies Adam or
-  // runs the bookkeeping -- the slots hold an older collective's data, the parameters stay as they were (gradient messages: the
-  // two-phase wait above; the other messages have no side effect beyond their own buffer).  The host sees HL_ERR_HIP at its next
-  // read-back.  The sequence still advances, so nothing waits on this collective later.
-  const bool failed = sFail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  // ---- sum in rank order ----
-  const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
-  if (!failed) for (long long v = v0 + tid; v < v1; v += 256) {
-    V acc;
-    for (int r = 0; r < R; ++r) {
-      const V x = r == me ? msg[v] : reinterpret_cast<const V*>(mine + (size_t)r * a.slotBytes)[v];
-      if (r == 0) acc = x;
-      else {
-#pragma unroll
-        for (int q = 0; q < (int)(16 / sizeof(T)); ++q) acc.v[q] += x.v[q];
-      }
-    }
-    msg[v] = acc;
-    if constexpr (FUSE) {
-      AdamCoef c; c.eta = a.adam.sc->etaEff[a.adam.parity]; c.lambda = a.adam.lambda; c.fac = a.adam.fac;
-#pragma unroll
-      for (int q = 0; q < (int)(16 / sizeof(T)); ++q) {
-        const long long i = v * (long long)(16 / sizeof(T)) + q;
-        if (i < a.adam.n) {
-          float w = a.adam.W[i], m1 = a.adam.M1[i], m2 = a.adam.M2[i];
-          adamStep(c, (float)acc.v[q], w, m1, m2);
-          a.adam.W[i] = w; a.adam.M1[i] = m1; a.adam.M2[i] = m2;
-        }
-      }
-    }
-  }
-  if (!failed && chunk == 0 && tid < (int)(a.n - tail0)) {
-    T acc = 0;
-    for (int r = 0; r < R; ++r) {
-      const T x = r == me ? reinterpret_cast<const T*>(a.msg)[tail0 + tid] : reinterpret_cast<const T*>(mine + (size_t)r * a.slotBytes)[tail0 + tid];
-      acc = r == 0 ? x : acc + x;
-    }
-    reinterpret_cast<T*>(a.msg)[tail0 + tid] = acc;
-  }
-  // ---- the last workgroup to get here closes the collective: every workgroup has read `seq` by then ----
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    const bool last = atomicAdd(&a.ctl->done, 1u) == (unsigned)nCh - 1;
-    sLast = last ? 1 : 0;
-    if (last) {
-      a.ctl->done = 0; a.ctl->arrived = 0;      // (every workgroup left the two-phase wait before it added to `done`)
-      __hip_atomic_store(&a.ctl->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if constexpr (FUSE) {
-    __syncthreads();
-    if (sLast && __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { __threadfence(); postPart(a.post, &sFarDelta, &sMaxAbs); }      // (all chunks are summed and visible)
-  }
+  __shared__ XchgLds L;
+  XchgCore c; c.msg = a.msg; c.n = a.n; c.nRanks = a.nRanks; c.rank = a.rank; c.peers = a.peers; c.slotsOffset = a.slotsOffset; c.slotBytes = a.slotBytes;
+  c.ctl = a.ctl; c.sc = a.sc; c.timeoutTicks = a.timeoutTicks; c.pushed = a.pushed; c.localTarget = 0u;
+  XchgAdam ad; ad.W = a.adam.W; ad.M1 = a.adam.M1; ad.M2 = a.adam.M2; ad.n = a.adam.n; ad.lambda = a.adam.lambda; ad.fac = a.adam.fac; ad.parity = a.adam.parity;
+  xchgChunk<T, FUSE, false>(c, ad, a.post, 0, (int)blockIdx.x, (int)gridDim.x, &L);
 }
 
 __global__ __launch_bounds__(256) void xchg_clean_kernel(unsigned char* win, size_t slotsOffset, size_t slotBytes, int nRanks, const XchgCtl* ctl, long long bytes) {
@@ -157,9 +42,14 @@ hipError_t launch_xchg_clean(unsigned char* win, size_t slotsOffset, size_t slot
   return hipGetLastError();
 }
 
+int xchg_chunks(long long bytes, int maxChunks) {
+  const int cap = maxChunks >= 1 && maxChunks <= XCHG_CHUNKS ? maxChunks : XCHG_CHUNKS;
+  int nCh = (int)((bytes + 4095) / 4096); if (nCh < 1) nCh = 1; if (nCh > cap) nCh = cap;
+  return nCh;
+}
 hipError_t launch_xchg_allreduce(const XchgArgs& a, int dtype, hipStream_t s) {
   const long long bytes = a.n * (dtype == 0 ? 4 : 8);
-  int nCh = (int)((bytes + 4095) / 4096); if (nCh < 1) nCh = 1; if (nCh > XCHG_CHUNKS) nCh = XCHG_CHUNKS;
+  const int nCh = xchg_chunks(bytes, a.maxChunks);
   if (a.fuse && dtype == 0) hipLaunchKernelGGL((xchg_allreduce_kernel<float, true>), dim3(nCh), dim3(256), 0, s, a);
   else if (dtype == 0) hipLaunchKernelGGL((xchg_allreduce_kernel<float, false>), dim3(nCh), dim3(256), 0, s, a);
   else if (dtype == 1) hipLaunchKernelGGL((xchg_allreduce_kernel<double, false>), dim3(nCh), dim3(256), 0, s, a);

@@ -1,0 +1,173 @@
+// smarties_amd/csrc/xchg_dev.h -- one chunk of a replica collective: what a workgroup of xchg_allreduce_kernel (xchg.hip) does, and --
+// FOLD -- what the chunk workgroups at the end of the weight-gradient launch's grid do (gemm16.hip: dw_table_kernel), so that a
+// replica's step is two launches instead of three.  The reference: MPI_Iallreduce of the gradient and AdamOptimizer::apply_update
+// (Network/Optimizer.cpp:110-160), the counters' reduction (Utils/DelayedReductor.cpp:53-83).  Protocol: xchg.hip's header.
+#pragma once
+#include "tail_dev.h"
+
+namespace hl {
+
+template <typename T> struct Vec16 { T v[16 / sizeof(T)]; };
+
+// (relaxed: the window is uncached memory, every load goes to HBM; an acquire load would invalidate this XCD's L2 at every poll)
+__device__ __forceinline__ unsigned long long ldSys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void stSys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// what a chunk workgroup needs of a collective (kernel arguments of either launch; no record on the stack)
+struct XchgCore {
+  void* msg; long long n;                       // local message, summed in place
+  int nRanks, rank;
+  unsigned char* const* peers; size_t slotsOffset, slotBytes;
+  XchgCtl* ctl; DevScalars* sc; long long timeoutTicks;
+  long long pushed;                             // leading elements already in the peers' windows (FOLD: all of them)
+  unsigned localTarget;                         // FOLD: arrivals (tiles + the bookkeeping rider of THIS launch) this replica's own push consists of
+};
+struct XchgAdam { float* W; float* M1; float* M2; long long n; float lambda, fac; int parity; };
+// LDS of a chunk workgroup: 48 bytes, 8-byte aligned
+struct XchgLds { unsigned long long seq; int last, fail; long long farDelta[2]; unsigned maxAbs, pad; };
+
+// FUSE (the gradient message of a step): the workgroup that summed a chunk applies Adam to it and the last workgroup to finish runs the
+// bookkeeping that needs the summed counters (MemoryProcessing::updateCounters ... beta, the next step's Adam scalars).
+// FOLD (round 6; implies FUSE): the caller is a workgroup of the launch that PRODUCES the gradient.  Its tiles stored their values into
+// every window -- the own one included: what this workgroup sums is read from the windows only, never from the tiles' cached stores,
+// which another XCD's L2 may still hold -- and counted themselves on ctl->pushed once those stores were acknowledged; this workgroup
+// waits for that count, then stamps the peers' flags and goes on as the separate exchange launch does.  Chunk workgroups sit at the
+// END of the grid: every tile workgroup has been dispatched when the first of them starts, so they wait for running workgroups only.
+template <typename T, bool FUSE, bool FOLD>
+__device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad, const PostArgs& post, int postModeClose, int chunk, int nCh, XchgLds* L) {
+  const int tid = threadIdx.x, R = a.nRanks, me = a.rank;
+  if (tid == 0) { L->seq = __hip_atomic_load(&a.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 0; }
+  __syncthreads();
+  const unsigned long long seq = L->seq, tag = seq + 1;
+  const int par = (int)(seq & 1);
+  // 16-byte units of the message; the last one may be partial (handled element-wise)
+  const long long bytes = a.n * (long long)sizeof(T), full = bytes >> 4;
+  const long long per = (full + nCh - 1) / nCh, v0 = per * chunk, v1 = min(full, v0 + per);
+  typedef Vec16<T> V;
+  V* msg = reinterpret_cast<V*>(a.msg);
+  const size_t slotOff = a.slotsOffset + ((size_t)par * R + me) * a.slotBytes;
+  const long long tail0 = full * (16 / (long long)sizeof(T));          // elements behind the last full unit: chunk 0 carries them
+  if constexpr (FOLD) {
+    // ---- this replica's own message is complete in every window once all of this launch's producers have arrived ----
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(&a.ctl->pushed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.localTarget) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 1; break; }
+      }
+    }
+    __syncthreads();
+  } else {
+    // ---- push: this chunk into every peer's window (what the producing launch pushed itself -- the leading a.pushed elements of a
+    // gradient message, PushArgs -- is already there: its stores were acknowledged before that launch ended) ----
+    const long long vPushed = (a.pushed * (long long)sizeof(T)) >> 4;
+    for (long long v = max(v0, vPushed) + tid; v < v1; v += 256) {
+      const V x = msg[v];
+      for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<V*>(a.peers[p] + slotOff)[v] = x;
+    }
+    if (chunk == 0 && tid < (int)(a.n - tail0)) {
+      const T x = reinterpret_cast<const T*>(a.msg)[tail0 + tid];
+      for (int p = 0; p < R; ++p) if (p != me) reinterpret_cast<T*>(a.peers[p] + slotOff)[tail0 + tid] = x;
+    }
+    __threadfence_system();
+    __syncthreads();
+  }
+  unsigned long long* myFlags = reinterpret_cast<unsigned long long*>(a.peers[me]) + (size_t)par * R * XCHG_CHUNKS;
+  if (tid < R && tid != me) {
+    if (!FOLD || !L->fail) stSys(reinterpret_cast<unsigned long long*>(a.peers[tid]) + ((size_t)par * R + me) * XCHG_CHUNKS + chunk, tag);
+    // ---- wait for the same chunk of every peer ----
+    const unsigned long long* f = myFlags + (size_t)tid * XCHG_CHUNKS + chunk;
+    const long long t0 = wall_clock64();
+    while (ldSys(f) < tag) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 1; break; }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
+  }
+  __syncthreads();
+  if constexpr (FUSE) {
+    // Two phases (round 5; ADVICE r03 / VERDICT r04): a chunk whose peers arrived used to sum and apply Adam at once -- if another
+    // chunk then timed out, the parameter vector was left PARTIALLY updated.  Now every workgroup reports that its stamps came and
+    // waits until all nCh have (they are resident together: at most XCHG_CHUNKS workgroups); a single failure -- the sticky device
+    // error -- makes every workgroup skip its sum and its Adam slice: after error 79 weights and moments are those of before the
+    // collective.  Costs one counter round trip among the launch's workgroups per gradient exchange.
+    if (tid == 0) {
+      if (!L->fail) __hip_atomic_fetch_add(&a.ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t0 = wall_clock64();
+      while (!L->fail && __hip_atomic_load(&a.ctl->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nCh) {
+        if (__hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { L->fail = 1; break; }
+        if (wall_clock64() - t0 > 2 * a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  }
+  // A peer's message never came (or an earlier collective already failed: the error is sticky): no workgroup sums, applies Adam or
+  // runs the bookkeeping -- the slots hold an older collective's data, the parameters stay as they were (gradient messages: the
+  // two-phase wait above; the other messages have no side effect beyond their own buffer).  The host sees HL_ERR_HIP at its next
+  // read-back.  The sequence still advances, so nothing waits on this collective later.
+  const bool failed = L->fail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  // ---- sum in rank order ----
+  const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
+  if (!failed) for (long long v = v0 + tid; v < v1; v += 256) {
+    V acc;
+    for (int r = 0; r < R; ++r) {
+      const V x = (!FOLD && r == me) ? msg[v] : reinterpret_cast<const V*>(mine + (size_t)r * a.slotBytes)[v];
+      if (r == 0) acc = x;
+      else {
+#pragma unroll
+        for (int q = 0; q < (int)(16 / sizeof(T)); ++q) acc.v[q] += x.v[q];
+      }
+    }
+    msg[v] = acc;
+    if constexpr (FUSE) {
+      AdamCoef c; c.eta = a.sc->etaEff[ad.parity]; c.lambda = ad.lambda; c.fac = ad.fac;
+#pragma unroll
+      for (int q = 0; q < (int)(16 / sizeof(T)); ++q) {
+        const long long i = v * (long long)(16 / sizeof(T)) + q;
+        if (i < ad.n) {
+          float w = ad.W[i], m1 = ad.M1[i], m2 = ad.M2[i];
+          adamStep(c, (float)acc.v[q], w, m1, m2);
+          ad.W[i] = w; ad.M1[i] = m1; ad.M2[i] = m2;
+        }
+      }
+    }
+  }
+  if (!FOLD && !failed && chunk == 0 && tid < (int)(a.n - tail0)) {      // (FOLD: the message is a whole number of 16-byte units, checked by the host)
+    T acc = 0;
+    for (int r = 0; r < R; ++r) {
+      const T x = r == me ? reinterpret_cast<const T*>(a.msg)[tail0 + tid] : reinterpret_cast<const T*>(mine + (size_t)r * a.slotBytes)[tail0 + tid];
+      acc = r == 0 ? x : acc + x;
+    }
+    reinterpret_cast<T*>(a.msg)[tail0 + tid] = acc;
+  }
+  // ---- the last workgroup to get here closes the collective: every workgroup has read `seq` by then ----
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const bool last = atomicAdd(&a.ctl->done, 1u) == (unsigned)nCh - 1;
+    L->last = last ? 1 : 0;
+    if (last) {
+      a.ctl->done = 0; a.ctl->arrived = 0;      // (every workgroup left the two-phase wait before it added to `done`)
+      if constexpr (FOLD) __hip_atomic_store(&a.ctl->pushed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (all chunk workgroups are past their wait for it)
+      __hip_atomic_store(&a.ctl->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if constexpr (FUSE) {
+    __syncthreads();
+    if (L->last && __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // (all chunks are summed and visible)
+      __threadfence();
+      postPart(post, L->farDelta, &L->maxAbs, nullptr, 0, FOLD ? postModeClose : -1);
+    }
+  }
+}
+
+// the arrival of one producer of a folded launch (a tile workgroup, the bookkeeping rider): every wavefront's window stores are
+// acknowledged, then one count
+__device__ __forceinline__ void foldArrive(XchgCtl* ctl) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&ctl->pushed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace hl
