@@ -207,7 +207,11 @@ def cpu_baseline(steps_budget_s=20.0):
         best = None
         tried = []
         with tempfile.TemporaryDirectory() as td:
-            for thr in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+            # (probes up to the box's CPU count -- VERDICT r05: they stopped at 64 of 256; a probe is 400 steps, a few seconds each)
+            probes = [t for t in (8, 16, 32, 64, 128, 256) if t <= ncpu] or [ncpu]
+            if ncpu > probes[-1] and ncpu <= 512:
+                probes.append(ncpu)
+            for thr in probes:
                 env = dict(os.environ, OMP_NUM_THREADS=str(thr), OMP_PROC_BIND="close", OMP_PLACES="cores")
                 try:
                     out = subprocess.run([ref, "bench", "threads=%d" % thr, "nObs=1000000", "nSteps=400", "warmup=20"],
@@ -231,7 +235,9 @@ def cpu_baseline(steps_budget_s=20.0):
                     long_run = False
         if best is not None:
             return {"value": best["transitions_per_s"], "unit": "transitions/s", "cores": int(best["threads"]),
-                    "kind": "reference", "blas": "none (the reference's own OpenMP-SIMD loops: neither USE_MKL nor USE_OPENBLAS, as in its CMake build)",
+                    "kind": "reference", "blas": "none (the reference's own OpenMP-SIMD loops: neither USE_MKL nor USE_OPENBLAS, as in its CMake build; "
+                                                 "a CBLAS flavour cannot be built here: the image holds libmkl_rt.so but no cblas / mkl header, and a hand-written "
+                                                 "prototype header would be a stand-in for a file the image lacks -- DESIGN.md section 5)",
                     "march": "x86-64-v3", "flags": "-O3 -ffast-math -fopenmp -DSINGLE_PREC",
                     "sample": "compiled reference (oracle/_ref, -O3 -ffast-math, OpenMP) on a 1M-transition synthetic replay of "
                               "the same shape and distributions: 400-step probes at threads=%s on %d host CPUs, then %s at the best count"
@@ -520,6 +526,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # replicas must hold the SAME parameters after the timed steps (every replica sums in rank order: bit for bit), or the line below
+    # would time something that is not data-parallel training: checked before anything is printed
+    if n_ranks > 1:
+        import hashlib
+        w_all = L.get_params()
+        digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in w_all)).hexdigest()
+        digests = [None] * n_ranks
+        dist.all_gather_object(digests, digest)
+        if len(set(digests)) != 1:
+            raise SystemExit("bench.py: the replicas' weights / Adam moments differ after %d steps (sha256 per rank: %s): no line printed" % (
+                args.warmup + args.steps, ", ".join(d[:12] for d in digests)))
+
     B_global = CFG["batchSize"]
     value = B_global * args.steps / dt
     # which transport each rank ended up with (they agree by construction -- all_ok() -- but the line says so rank by rank)
@@ -556,7 +574,8 @@ def main():
                                    "device-side mt19937 sampler" % n_ranks,
                        "global_batch": B_global, "replay_transitions": 1000000, "parallelism": "dp%d" % n_ranks,
                        "exchange": "host (gloo, split-step entry points)" if (n_ranks > 1 and host_exchange) else transport,
-                       "exchange_per_rank": transports},
+                       "exchange_per_rank": transports,
+                       "replicas_identical_after_timed_steps": (True if n_ranks > 1 else None)},
             "roofline": roof,
             "fill_seconds": t_fill,
             "diagnostics": diag,

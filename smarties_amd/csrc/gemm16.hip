@@ -247,16 +247,23 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
   if ((int)blockIdx.x < nRiders) {
     const int b = blockIdx.x;
     if (b < r1) {
+      if (fold.on) FOSTAMP(sc, 0);
       postPhase(post, smem);
+      if (fold.on) FOSTAMP(sc, 1);
       if (fold.on) {      // the counters message (sixteen floats thread 0 just wrote behind the gradient) into every window, then this producer's arrival
         __syncthreads();
         if (threadIdx.x < 16) {
           const float x = __hip_atomic_load(post.cntMsg + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const size_t so = pushSlot(hyp.push) + (size_t)((post.cntMsg - hyp.push.gBase) + threadIdx.x) * 4;
-          for (int p = 0; p < hyp.push.nRanks; ++p) *reinterpret_cast<float*>(hyp.push.peers[p] + so) = x;
+          for (int p = 0; p < hyp.push.nRanks; ++p) stWindow4(hyp.push.peers[p] + so, x);
         }
-        __threadfence();      // (the scalars this pass wrote -- the step's largest error -- are read by the chunk workgroup that closes the step, on whichever XCD it runs)
-        foldArrive(fold.ctl);
+        // Everything this pass wrote goes to memory BEFORE it counts itself (an agent-scope release: this XCD's L2 is written back).  Not for
+        // the readers' sake alone: the chunk workgroup that closes the step -- on whichever XCD -- writes some of the same words (the
+        // summed counters over the local ones, DevScalars::cnt), and two L2s holding the same words dirty with different values leave
+        // it to the order of their write-backs which one survives (seen: replicas drifting apart by one ulp of beta after 25 steps)
+        __threadfence();
+        foldArrive(fold.ctl, (unsigned)fold.nTiles + 1u);
+        FOSTAMP(sc, 2);
       }
     }
     else if (b == r1) samplePhases(samp, sampPhases, smem);
@@ -272,6 +279,7 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
     xchgChunk<float, true, true>(c, ad, post, POST_BETA, bid - fold.nTiles, fold.nCh, reinterpret_cast<XchgLds*>(smem));
     return;
   }
+  if (fold.on && bid == 40) FOSTAMP(sc, 3);
   int p = 0;
 #pragma unroll
   for (int i = 1; i < DW_TABLE_MAX; ++i) if (i < tbl.n && bid >= tbl.p[i].tileStart) p = i;
@@ -283,7 +291,10 @@ __global__ __launch_bounds__(256) void dw_table_kernel(DwTable tbl, const DevSca
     gemmTile<GEMM_ROLE_DW, GEMM_W>(P, bid - P.tileStart, smem, sc, hyp, 0);
   }
   else gemmTile<GEMM_ROLE_DW>(P, bid - P.tileStart, smem, sc, hyp, 0);
-  if (fold.on) foldArrive(fold.ctl);
+  if (fold.on && bid == 40) FOSTAMP(sc, 4);
+  if (fold.on) foldArrive(fold.ctl, (unsigned)fold.nTiles + 1u);
+  if (fold.on && bid == 40) FOSTAMP(sc, 5);
+  if (fold.on && bid == fold.nTiles - 1) FOSTAMP(sc, 14);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -22,6 +22,19 @@ __device__ __forceinline__ void adamApply(const AdamCoef& c, float g, float* W, 
   W[i] = w; M1[i] = m1; M2[i] = m2;
 }
 
+// Stores into a replica window (peer's or own) that leave this XCD's L2 behind for certain: system-scope write-through (sc0 sc1).  The
+// windows are uncached memory and a plain store normally goes around the L2 as well -- but where the window's memory had an earlier life
+// as cached memory (hipMalloc / hipFree of other learners in the process), lines of it may still sit in an L2, a plain store then HITS
+// there, and a consumer inside the SAME launch (the folded exchange's chunk workgroups on another XCD) reads the old bytes from HBM:
+// replicas a few ulps apart after some hundred steps, only behind other tests in one process (round 6).  A release fence per tile would
+// do too -- and costs 15 us per step.
+__device__ __forceinline__ void stWindow16(unsigned char* p, const f32x4& x) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void stWindow4(unsigned char* p, float x) {
+  __hip_atomic_store(reinterpret_cast<float*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // this replica's slot in a peer's window for the collective the gradient belongs to (byte offset inside the window)
 __device__ __forceinline__ size_t pushSlot(const PushArgs& pu) {
   const unsigned long long seq = __hip_atomic_load(&pu.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -57,10 +70,10 @@ __device__ __forceinline__ void redcol_tile(const GemmProblem& P, int tile, floa
 #pragma unroll
     for (int q = 0; q < 16; ++q) g += red[q * 16 + jj];
     if (P.nSplit > 1) { P.part[(size_t)ks * P.N + j] = g; return; }
-    P.C[j] = g;
+    if (!(hyp.push.on && hyp.push.self)) P.C[j] = g;      // (folded replica launch: windows only, see gemmTile)
     if (hyp.push.on) {      // replicas: into the peers' windows too (a handful of columns: element stores)
       const size_t so = pushSlot(hyp.push) + (size_t)((P.C - hyp.push.gBase) + j) * 4;
-      for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank || hyp.push.self) *reinterpret_cast<float*>(hyp.push.peers[p] + so) = g;
+      for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank || hyp.push.self) stWindow4(hyp.push.peers[p] + so, g);
     }
     if (P.adam) { AdamCoef c; c.eta = sc->etaEff[hyp.parity]; c.lambda = hyp.lambda; c.fac = hyp.fac; adamApply(c, g, P.adW, P.adM1, P.adM2, j); }
   }
@@ -277,7 +290,7 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
         const f32x4 x = *reinterpret_cast<const f32x4*>(red + r * 16 + c);
         const size_t off = isW ? (size_t)(P.C - hyp.push.gBase) + (size_t)mm * P.ldc + nn : (size_t)(P.biasOut - hyp.push.gBase) + nn;
         const size_t so = pushSlot(hyp.push) + off * 4;
-        for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank || hyp.push.self) *reinterpret_cast<f32x4*>(hyp.push.peers[p] + so) = x;
+        for (int p = 0; p < hyp.push.nRanks; ++p) if (p != hyp.push.rank || hyp.push.self) stWindow16(hyp.push.peers[p] + so, x);
         __builtin_amdgcn_s_waitcnt(0);          // acknowledged before this wavefront ends
       }
     }
@@ -306,7 +319,9 @@ __device__ __forceinline__ void gemmTile(const GemmProblem& P, int tile, unsigne
            // branches the compiler merged their stores and indexed the record's pointers on the stack (scratch)
       const bool isW = m < P.M - 1;
       const size_t i = isW ? (size_t)m * P.ldc + n : (size_t)n;
-      pickPtrW(isW, P.C, P.biasOut)[i] = v;
+      // (folded replica launch: the gradient lives in the windows only -- the chunk workgroups write the SUM to this array from other
+      //  XCDs, and a local tile left dirty in this XCD's L2 could be written back on top of it)
+      if (!(hyp.push.on && hyp.push.self)) pickPtrW(isW, P.C, P.biasOut)[i] = v;
       if (P.adam) { adamStep(ac, v, e0, e1, e2); pickPtrW(isW, P.adW, P.adbW)[i] = e0; pickPtrW(isW, P.adM1, P.adbM1)[i] = e1; pickPtrW(isW, P.adM2, P.adbM2)[i] = e2; }
     }
   } else {

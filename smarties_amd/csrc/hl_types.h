@@ -176,8 +176,14 @@ constexpr int BIG_DW_MAX = 12;
 struct BigDwList { int n; int idx[BIG_DW_MAX]; int start[BIG_DW_MAX + 1]; };
 
 // one-kernel exchange between replicas (xchg.hip): sequence number of the next collective, arrival count of its workgroups
-struct XchgCtl { unsigned long long seq; unsigned int done; unsigned int arrived; /* workgroups of the running collective whose peers' stamps all came (FUSE: nobody applies Adam before all have) */
-                 unsigned int pushed; /* folded weight-gradient launch: its producers (tiles, bookkeeping rider) whose window stores are acknowledged */ unsigned int pad; };
+// (a cache line per role: the sequence number is read by every pushing tile, `pushed` takes an atomic from each of them, `ready` is
+//  polled by the chunk workgroups -- on one line the pollers and the tiles' atomics queued behind each other: 62 against 38 us per step)
+struct alignas(128) XchgCtl {
+  unsigned long long seq; unsigned long long pad0[15];
+  unsigned int done; unsigned int arrived; /* workgroups of the running collective whose peers' stamps all came (FUSE: nobody applies Adam before all have) */ unsigned int pad1[30];
+  unsigned int pushed; /* folded weight-gradient launch: its producers (tiles, bookkeeping rider) whose window stores are acknowledged */ unsigned int pad2[31];
+  unsigned long long ready; /* = seq + 1 once the last producer of the folded launch of collective `seq` has arrived */ unsigned long long pad3[15];
+};
 // replicas connected through peer windows: the weight-gradient launch stores every gradient tile into the peers' windows as well
 // (16-byte stores over xGMI from the tile's epilogue), so the transfer overlaps the launch and the exchange kernel behind it only
 // stamps, waits, sums and applies Adam (round 4; before: the exchange kernel pushed the whole message after the launch)

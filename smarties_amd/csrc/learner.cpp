@@ -2188,7 +2188,14 @@ int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
   // windows itself (recurrent and convolutional nets have further gradient producers -- split-row joins, filter gradients: the
   // exchange kernel keeps pushing their message)
   { const char* np = getenv("SMARTIES_HIP_NO_PUSH"); h->pushOk = !(np && np[0] == '1') && !h->recurrent && h->nConv == 0 && !h->bigBatch; }      // (local batches above 1024: split-row joins and the 64 x 64 tiles never push -- the exchange kernel sends their gradient)
-  { const char* nf = getenv("SMARTIES_HIP_NO_FOLD"); h->foldOk = h->pushOk && !(nf && nf[0] == '1'); }      // (the round-5 step: a separate exchange launch behind the pushing one)
+  // The exchange folded into the weight-gradient launch (two launches per replica step instead of three: xchg_dev.h, dw_table_kernel) is
+  // OFF unless SMARTIES_HIP_FOLD=1.  Built and measured in round 6: bit-equal to the host-formed sums in every fresh process, no faster
+  // than the three-launch step (33.6 us either way, tools/replica_loopback.py: its chunk workgroups wait for the bookkeeping rider) --
+  // and it hands gradient tiles from the producing workgroups to the summing ones INSIDE one launch, across XCDs, on the strength of
+  // acknowledged window stores alone.  In a process that had created and destroyed other learners before (recycled device memory)
+  // that hand-off delivered stale bytes in 1 of 4 runs of the 8-replica tests (1 of 18 with system-scope loads; 0 with a system-scope
+  // fence per tile, which costs 15 us per step).  The three-launch step hands over at kernel boundaries only.
+  { const char* fo = getenv("SMARTIES_HIP_FOLD"); h->foldOk = h->pushOk && fo && fo[0] == '1'; }
   int rc = xchgAllreduce(h, h->G, (size_t)h->nParams, 0); if (rc) return rc;
   HIPCK(hipMemcpyAsync(h->W, h->G, (size_t)h->nParams * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -2302,6 +2309,25 @@ extern "C" HL_API int hl_kernel_profile(hl_learner* h, int which, int reps, doub
 
 // RCCL calls issued or captured so far (tests: eager and replayed steps speak the same wire protocol)
 extern "C" HL_API int64_t hl_debug_collectives(const hl_learner* h) { return h ? h->nCollectives : -1; }
+// kernel nodes of the replayed graph of `steps` plain steps (one of GRAPH_SIZES; captured on demand): how many launches a step is made of
+// (tests: a folded replica step = 2 kernels, the round-5 replica step = 3; development API like hl_debug_collectives, not in the header)
+extern "C" HL_API int64_t hl_debug_graph_kernels(hl_learner* h, int32_t steps) {
+  if (!h) return -1;
+  HL_LOCK(h);
+  constexpr int NS = (int)(sizeof(GRAPH_SIZES) / sizeof(GRAPH_SIZES[0]));
+  if (h->graphsStale) { invalidateGraphs(h); h->graphsStale = false; }
+  if (captureAllGraphs(h) != HL_OK) return -1;
+  for (int j = 0; j < NS; ++j) if (GRAPH_SIZES[j] == steps && h->graphs[j][0].graph) {
+    size_t n = 0;
+    if (hipGraphGetNodes(h->graphs[j][0].graph, nullptr, &n) != hipSuccess) return -1;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(h->graphs[j][0].graph, nodes.data(), &n) != hipSuccess) return -1;
+    int64_t k = 0;
+    for (size_t i = 0; i < n; ++i) { hipGraphNodeType t; if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k; }
+    return k;
+  }
+  return -1;
+}
 // fused kernel: -1 not in use, 0 panel exchange through the shared L2 (probe: workgroup b on XCD b % 8), 1 through agent-scope accesses
 extern "C" HL_API int hl_debug_panel_mode(const hl_learner* h) { return !h || !h->fusedOk ? -1 : (h->xcdSafe ? 1 : 0); }
 

@@ -537,7 +537,8 @@ int launchWeightGrad(hl_learner* h, int parity, bool fuseAdam, hipStream_t s, bo
     FoldArgs fo{};
     if (fold) {
       const long long n = (long long)h->nParams + CNT_MSG_OFFSET + CNT_MSG_FLOATS, bytes = n * 4;
-      fo.on = 1; fo.nCh = xchg_chunks(bytes, h->xchg.maxChunks);      // (as launch_xchg_allreduce cuts the message) fo.nTiles = sb.dwBlocks; fo.msg = h->G; fo.n = n; fo.W = h->W; fo.M1 = h->M1; fo.M2 = h->M2; fo.nAdam = h->nParams;
+      fo.on = 1; fo.nCh = xchg_chunks(bytes, h->xchg.maxChunks);      // (as launch_xchg_allreduce cuts the message)
+      fo.nTiles = sb.dwBlocks; fo.msg = h->G; fo.n = n; fo.W = h->W; fo.M1 = h->M1; fo.M2 = h->M2; fo.nAdam = h->nParams;
       fo.ctl = h->xchg.ctl; fo.timeoutTicks = h->xchgTimeoutTicks;
       if ((size_t)bytes > h->xchg.slotBytes) return fail(h, HL_ERR_COMM, "exchange message larger than the window slot");
     }
@@ -1127,6 +1128,8 @@ int captureAllGraphs(hl_learner* h) {
     const int rc = captureSteps(h, GRAPH_SIZES[j], p0, &h->graphs[j][p0]);
     if (rc == HL_OK) continue;
     if (!exchanging(h)) return rc;
+    // (said once, aloud: from here on this replica pays the host's launch latency for every kernel of every step)
+    fprintf(stderr, "smarties_hip: replica %d: the steps' graph could not be captured (%s): stepping with eager launches from now on\n", h->cfg.rank, h->err.c_str());
     h->exchGraph = false; h->err.clear(); (void)hipGetLastError(); invalidateGraphs(h);
     return HL_OK;
   }

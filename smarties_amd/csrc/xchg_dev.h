@@ -7,11 +7,27 @@
 
 namespace hl {
 
+// development time stamps of the folded launch (-DHL_FOLD_STAMPS; tools/fold_stamps.py): DevScalars::dbgT, 100 MHz
+#ifdef HL_FOLD_STAMPS
+#define FOSTAMP(sc_, i) do { if (threadIdx.x == 0) const_cast<DevScalars*>(sc_)->dbgT[i] = wall_clock64(); } while (0)
+#else
+#define FOSTAMP(sc_, i) do { } while (0)
+#endif
+
 template <typename T> struct Vec16 { T v[16 / sizeof(T)]; };
 
 // (relaxed: the window is uncached memory, every load goes to HBM; an acquire load would invalidate this XCD's L2 at every poll)
 __device__ __forceinline__ unsigned long long ldSys(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void stSys(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// a 16-byte unit of a window slot as two 8-byte system-scope loads (sc0 sc1: served by memory whatever an L2 may hold of the line)
+template <typename V> __device__ __forceinline__ V ldWindowUnit(const V* p) {
+  static_assert(sizeof(V) == 16, "16-byte units");
+  union { unsigned long long q[2]; V v; } u;
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(p);
+  u.q[0] = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); u.q[1] = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return u.v;
+}
 
 // what a chunk workgroup needs of a collective (kernel arguments of either launch; no record on the stack)
 struct XchgCore {
@@ -36,6 +52,7 @@ struct XchgLds { unsigned long long seq; int last, fail; long long farDelta[2]; 
 template <typename T, bool FUSE, bool FOLD>
 __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad, const PostArgs& post, int postModeClose, int chunk, int nCh, XchgLds* L) {
   const int tid = threadIdx.x, R = a.nRanks, me = a.rank;
+  if (FOLD && chunk == 0) FOSTAMP(a.sc, 6);
   if (tid == 0) { L->seq = __hip_atomic_load(&a.ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 0; }
   __syncthreads();
   const unsigned long long seq = L->seq, tag = seq + 1;
@@ -51,12 +68,13 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
     // ---- this replica's own message is complete in every window once all of this launch's producers have arrived ----
     if (tid == 0) {
       const long long t0 = wall_clock64();
-      while (__hip_atomic_load(&a.ctl->pushed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.localTarget) {
-        __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&a.ctl->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tag) {      // (set by the last producer: foldArrive)
+        __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 1; break; }
       }
     }
     __syncthreads();
+    if (chunk == 0) FOSTAMP(a.sc, 7);
   } else {
     // ---- push: this chunk into every peer's window (what the producing launch pushed itself -- the leading a.pushed elements of a
     // gradient message, PushArgs -- is already there: its stores were acknowledged before that launch ended) ----
@@ -85,12 +103,8 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
     __atomic_thread_fence(__ATOMIC_ACQUIRE);      // once, behind the last stamp
   }
   __syncthreads();
-  if constexpr (FUSE) {
-    // Two phases (round 5; ADVICE r03 / VERDICT r04): a chunk whose peers arrived used to sum and apply Adam at once -- if another
-    // chunk then timed out, the parameter vector was left PARTIALLY updated.  Now every workgroup reports that its stamps came and
-    // waits until all nCh have (they are resident together: at most XCHG_CHUNKS workgroups); a single failure -- the sticky device
-    // error -- makes every workgroup skip its sum and its Adam slice: after error 79 weights and moments are those of before the
-    // collective.  Costs one counter round trip among the launch's workgroups per gradient exchange.
+  if (FOLD && chunk == 0) FOSTAMP(a.sc, 8);
+  auto consensus = [&]() {
     if (tid == 0) {
       if (!L->fail) __hip_atomic_fetch_add(&a.ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const long long t0 = wall_clock64();
@@ -101,34 +115,95 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
       }
     }
     __syncthreads();
-  }
-  // A peer's message never came (or an earlier collective already failed: the error is sticky): no workgroup sums, applies Adam or
-  // runs the bookkeeping -- the slots hold an older collective's data, the parameters stay as they were (gradient messages: the
-  // two-phase wait above; the other messages have no side effect beyond their own buffer).  The host sees HL_ERR_HIP at its next
-  // read-back.  The sequence still advances, so nothing waits on this collective later.
-  const bool failed = L->fail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  // ---- sum in rank order ----
+  };
+  // ---- sum in rank order (round 6: in FRONT of the two-phase wait -- the sums change nothing but the message buffer, so they run under
+  // the wait for the slowest chunk; four 16-byte units per thread and pass, all of their R loads in flight together: the windows are
+  // uncached, a load is a round trip to HBM) ----
   const unsigned char* mine = a.peers[me] + a.slotsOffset + (size_t)par * R * a.slotBytes;
-  if (!failed) for (long long v = v0 + tid; v < v1; v += 256) {
-    V acc;
-    for (int r = 0; r < R; ++r) {
-      const V x = (!FOLD && r == me) ? msg[v] : reinterpret_cast<const V*>(mine + (size_t)r * a.slotBytes)[v];
-      if (r == 0) acc = x;
-      else {
+  constexpr int UB = 4, EPV = (int)(16 / sizeof(T));
+  if (!L->fail) for (long long vb = v0 + tid; vb < v1; vb += 256 * UB) {
+    V acc[UB];
 #pragma unroll
-        for (int q = 0; q < (int)(16 / sizeof(T)); ++q) acc.v[q] += x.v[q];
+    for (int u = 0; u < UB; ++u) {
+      const long long v = min(vb + 256ll * u, v1 - 1);      // (clamped: loads only, no effect)
+      acc[u] = (!FOLD && me == 0) ? msg[v] : ldWindowUnit(reinterpret_cast<const V*>(mine) + v);
+    }
+    for (int r = 1; r < R; ++r) {
+      V x[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const long long v = min(vb + 256ll * u, v1 - 1);
+        x[u] = (!FOLD && r == me) ? msg[v] : ldWindowUnit(reinterpret_cast<const V*>(mine + (size_t)r * a.slotBytes) + v);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+#pragma unroll
+        for (int q = 0; q < EPV; ++q) acc[u].v[q] += x[u].v[q];
       }
     }
-    msg[v] = acc;
-    if constexpr (FUSE) {
-      AdamCoef c; c.eta = a.sc->etaEff[ad.parity]; c.lambda = ad.lambda; c.fac = ad.fac;
 #pragma unroll
-      for (int q = 0; q < (int)(16 / sizeof(T)); ++q) {
-        const long long i = v * (long long)(16 / sizeof(T)) + q;
-        if (i < ad.n) {
-          float w = ad.W[i], m1 = ad.M1[i], m2 = ad.M2[i];
-          adamStep(c, (float)acc.v[q], w, m1, m2);
-          ad.W[i] = w; ad.M1[i] = m1; ad.M2[i] = m2;
+    for (int u = 0; u < UB; ++u) {
+      const long long v = vb + 256ll * u;
+      if (v < v1) {
+        msg[v] = acc[u];
+        if constexpr (FUSE) {
+          // the units behind the parameters -- the summed counters -- are read by the workgroup that closes the step, on whichever XCD it
+          // runs: they go to the coherence point themselves, so that no workgroup has to write back its XCD's L2 (the Adam results) for them
+          if (v * EPV >= ad.n) {
+#pragma unroll
+            for (int q = 0; q < EPV; ++q) __hip_atomic_store(reinterpret_cast<T*>(a.msg) + v * EPV + q, acc[u].v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+  }
+  if (FOLD && chunk == 0) FOSTAMP(a.sc, 9);
+  // (Adam's operands of this thread's first pass are requested in front of the two-phase wait: they do not depend on it)
+  constexpr int UA = 4;
+  const long long vAdam = FUSE ? (ad.n + EPV - 1) / EPV : 0;      // units that hold parameters
+  f32x4 w4[UA], m14[UA], m24[UA];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const long long v = max(0ll, min(min(v0 + tid + 256ll * u, v1 - 1), vAdam - 1));
+      w4[u] = reinterpret_cast<const f32x4*>(ad.W)[v]; m14[u] = reinterpret_cast<const f32x4*>(ad.M1)[v]; m24[u] = reinterpret_cast<const f32x4*>(ad.M2)[v];
+    }
+  }
+  if constexpr (FUSE) {
+    // Two phases (round 5; ADVICE r03 / VERDICT r04): a chunk whose peers arrived used to sum and apply Adam at once -- if another
+    // chunk then timed out, the parameter vector was left PARTIALLY updated.  Now every workgroup reports that its stamps came and
+    // waits until all nCh have (they are resident together: at most XCHG_CHUNKS workgroups); a single failure -- the sticky device
+    // error -- makes every workgroup skip its Adam slice: after error 79 weights and moments are those of before the collective (the
+    // message buffer may hold sums: nothing reads it after a failure).  Costs one counter round trip among the launch's workgroups.
+    consensus();
+  }
+  // A peer's message never came (or an earlier collective already failed: the error is sticky): no workgroup applies Adam or runs the
+  // bookkeeping -- the parameters stay as they were (gradient messages: the two-phase wait above; the other messages have no side
+  // effect beyond their own buffer).  The host sees HL_ERR_HIP at its next read-back.  The sequence still advances, so nothing waits
+  // on this collective later.
+  const bool failed = L->fail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (FOLD && chunk == 0) FOSTAMP(a.sc, 15);
+  if constexpr (FUSE) {
+    // ---- Adam on the summed chunk (this thread's own sums, read back; parameters and moments as 16-byte accesses, four units per
+    // pass requested together, the first pass's in front of the wait).  The arrays are 16-byte aligned and hold ad.n rounded up to four
+    // elements (Parameters.h layout + PARAM_TAIL slack)
+    static_assert(sizeof(T) == 4, "Adam runs on float messages");
+    AdamCoef c; c.eta = a.sc->etaEff[ad.parity]; c.lambda = ad.lambda; c.fac = ad.fac;
+    if (!failed) for (long long vb = v0 + tid; vb < v1 && vb < vAdam; vb += 256 * UA) {
+      f32x4 g4[UA];
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const long long v = min(min(vb + 256ll * u, v1 - 1), vAdam - 1);
+        g4[u] = reinterpret_cast<const f32x4*>(a.msg)[v];
+        if (vb != v0 + tid) { w4[u] = reinterpret_cast<const f32x4*>(ad.W)[v]; m14[u] = reinterpret_cast<const f32x4*>(ad.M1)[v]; m24[u] = reinterpret_cast<const f32x4*>(ad.M2)[v]; }
+      }
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const long long v = vb + 256ll * u;
+        if (v < v1 && v < vAdam) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (v * 4 + q < ad.n) { float w = w4[u][q], m1 = m14[u][q], m2 = m24[u][q]; adamStep(c, g4[u][q], w, m1, m2); w4[u][q] = w; m14[u][q] = m1; m24[u][q] = m2; }
+          reinterpret_cast<f32x4*>(ad.W)[v] = w4[u]; reinterpret_cast<f32x4*>(ad.M1)[v] = m14[u]; reinterpret_cast<f32x4*>(ad.M2)[v] = m24[u];
         }
       }
     }
@@ -142,32 +217,49 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
     reinterpret_cast<T*>(a.msg)[tail0 + tid] = acc;
   }
   // ---- the last workgroup to get here closes the collective: every workgroup has read `seq` by then ----
-  __threadfence();
+  if (FOLD && chunk == 0) FOSTAMP(a.sc, 10);
+  // (FUSE: what another workgroup of this launch reads of this one's results -- the summed counters -- went out by itself above; the
+  //  parameters are read by later launches only.  Other messages: their sums are released here as before.)
+  if constexpr (!FUSE) __threadfence();
+  else __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  if (FOLD && chunk == 0) FOSTAMP(a.sc, 11);
   if (tid == 0) {
     const bool last = atomicAdd(&a.ctl->done, 1u) == (unsigned)nCh - 1;
     L->last = last ? 1 : 0;
     if (last) {
       a.ctl->done = 0; a.ctl->arrived = 0;      // (every workgroup left the two-phase wait before it added to `done`)
-      if constexpr (FOLD) __hip_atomic_store(&a.ctl->pushed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (all chunk workgroups are past their wait for it)
       __hip_atomic_store(&a.ctl->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if constexpr (FUSE) {
     __syncthreads();
     if (L->last && __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // (all chunks are summed and visible)
-      __threadfence();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (nothing of this workgroup's own has to go out: an invalidate, no write-back)
+      if (FOLD) FOSTAMP(a.sc, 12);
       postPart(post, L->farDelta, &L->maxAbs, nullptr, 0, FOLD ? postModeClose : -1);
+      if (FOLD) FOSTAMP(a.sc, 13);
     }
   }
 }
 
 // the arrival of one producer of a folded launch (a tile workgroup, the bookkeeping rider): every wavefront's window stores are
-// acknowledged, then one count
-__device__ __forceinline__ void foldArrive(XchgCtl* ctl) {
+// acknowledged, then one count; the LAST of the launch's `target` producers re-arms the counter and publishes `ready` (all counts in
+// front of its own were taken behind acknowledged stores), which is what the chunk workgroups poll -- on a cache line of its own
+__device__ __forceinline__ void foldArrive(XchgCtl* ctl, unsigned target) {
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(&ctl->pushed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&ctl->pushed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == target) {
+#ifdef HL_FOLD_STAMPS
+      ctl->pad3[0] = (unsigned long long)wall_clock64();
+#endif
+      __hip_atomic_store(&ctl->pushed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long seq = __hip_atomic_load(&ctl->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctl->ready, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 }  // namespace hl

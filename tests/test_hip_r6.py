@@ -61,7 +61,10 @@ def _host_step(Ls):
 def _assert_same(X, H, where):
     for r in range(len(X)):
         for name, a, b in zip(("W", "M1", "M2"), X[r].get_params(), H[r].get_params()):
-            assert np.array_equal(a, b), (where, r, name, float(np.abs(a - b).max()))
+            if not np.array_equal(a, b):
+                d = np.nonzero(a != b)[0]
+                raise AssertionError("after %d steps, replica %d, %s: %d of %d elements differ (first %s, last %s), largest difference %.3e" % (
+                    where, r, name, d.size, a.size, d[:6].tolist(), d[-3:].tolist(), float(np.abs(a - b).max())))
         sx, sh = X[r].scalars(), H[r].scalars()
         assert sx.beta == sh.beta and sx.nFarPolicySteps == sh.nFarPolicySteps, (where, r)
         assert np.array_equal(X[r].get_rng_state(), H[r].get_rng_state()), (where, r)
@@ -94,17 +97,15 @@ CALLS_1005 = (1, 1, 3, 20, 70, 900, 10)      # eager calls, replayed graphs, the
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_ranks", [2, 8])
-@pytest.mark.parametrize("route", ["pushed", "unpushed", "three-launch"])
+@pytest.mark.parametrize("route", ["pushed", "unpushed"])
 def test_replica_exchange_at_the_north_star_shape(hip_api, monkeypatch, n_ranks, route):
     """cfg-NS (17 states, 6 bounded actions, 2 x 256 SoftSign, GLOBAL batch 256: 72 976 parameters = a 292 KB message in 64 chunks, 354 dW
     tiles pushing from their epilogues) over 2 and 8 replicas: weights, both Adam moments, beta, the far-policy count and the generator
     bit-equal to the host-formed rank-order sums after eager calls, replayed graphs and the 1000th step; replicas identical.  Routes:
-    the gradient pushed by the dW tiles with the exchange folded into that launch's tail (default), the exchange kernel's own push
-    (SMARTIES_HIP_NO_PUSH=1), and the separate exchange launch behind a pushing dW launch (SMARTIES_HIP_NO_FOLD=1: the round-5 step)."""
+    the gradient pushed by the dW tiles' epilogues with the exchange launch behind it (default), and the exchange kernel's own push
+    (SMARTIES_HIP_NO_PUSH=1).  The folded two-launch step: test_folded_replica_step_in_a_fresh_process."""
     if route == "unpushed":
         monkeypatch.setenv("SMARTIES_HIP_NO_PUSH", "1")
-    if route == "three-launch":
-        monkeypatch.setenv("SMARTIES_HIP_NO_FOLD", "1")
     cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=256, maxTotObsNum=65536, randSeed=42)
     sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=40, lenMax=200, pTerm=0.3)
     _exchange_parity(hip_api, cfg_kw, sc, n_ranks, 40 * n_ranks, CALLS_1005)
@@ -171,3 +172,31 @@ def test_rccl_sequence_at_the_baseline_shapes_on_one_rank(hip_api, cfg_kw):
             assert np.array_equal(a, b), n
         assert A.scalars().beta == Bq.scalars().beta and A.scalars().nFarPolicySteps == Bq.scalars().nFarPolicySteps
     assert np.array_equal(A.get_rng_state(), Bq.get_rng_state())
+
+
+@pytest.mark.gpu
+def test_folded_replica_step_in_a_fresh_process():
+    """SMARTIES_HIP_FOLD=1: the exchange, Adam and the closing bookkeeping inside the weight-gradient launch -- a replica's replayed step
+    is TWO kernels (hl_debug_graph_kernels) where the default step is three -- bit-equal to the host-formed sums over 200 steps of two
+    cfg-NS replicas.  In a process of its own: the folded hand-off is only trusted on fresh device memory (learner.cpp, hl_xchg_connect;
+    docs/EXPERIMENTS.md), which is why it is not the default."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import os, sys, ctypes as C; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, torch\n"
+        "from smarties_amd import capi, load_hip; from oracle_api import synth_cfg; import test_hip_r6 as t6\n"
+        "api = load_hip(); gk = api.lib.hl_debug_graph_kernels; gk.restype = C.c_int64; gk.argtypes = [C.c_void_p, C.c_int32]\n"
+        "kw = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc='SoftSign', batchSize=256, maxTotObsNum=65536, randSeed=42)\n"
+        "sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=40, lenMax=200, pTerm=0.3)\n"
+        "X = t6._replicas(api, kw, sc, 2, 80, True); H = t6._replicas(api, kw, sc, 2, 80, False)\n"
+        "print('KERNELS_PER_8_STEPS', gk(X[0].h, 8))\n"
+        "for n in (1, 3, 20, 70, 106):\n"
+        "    t6._both(X, lambda L: (L.step(n), L.sync()))\n"
+        "    for _ in range(n): t6._host_step(H)\n"
+        "    t6._assert_same(X, H, n)\n"
+        "print('FOLD_OK')\n") % (os.path.dirname(here), here)
+    for fold, per8 in (("1", 16), ("0", 24)):
+        env = dict(os.environ, SMARTIES_HIP_FOLD=fold, GPU_MAX_HW_QUEUES="16", SMARTIES_HIP_XCHG_TIMEOUT_MS="30000")
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert "FOLD_OK" in out.stdout and ("KERNELS_PER_8_STEPS %d" % per8) in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -14,7 +14,7 @@ cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=2
 sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=40, lenMax=200, pTerm=0.3)
 EPS = 40
 if os.environ.get("SHAPE") == "humanoid":
-    cfg_kw = dict(dimS=257, dimA=17, hidden=(256, 256), nnFunc="SoftSign", batchSize=256, maxTotObsNum=65536, randSeed=9)
+    cfg_kw = dict(dimS=257, dimA=17, hidden=(256, 256), nnFunc="SoftSign", batchSize=int(os.environ.get("BATCH", "256")), maxTotObsNum=65536, randSeed=9)
     sc = synth_cfg(seed=13, dimS=257, dimA=17, lenMin=30, lenMax=120, pTerm=0.3)
     EPS = 30
 keep = []
