@@ -54,8 +54,26 @@ using namespace smarties;
 // MemoryProcessing::updateCounters :56-58, updateRewardsStats :147-150), so a step uses this step's global sums or the previous
 // step's, whichever the network's timing gives.  The harness pins the timing through MPI's profiling interface, without touching the
 // reference: with gPromptReductions every poll finds its reduction complete (the order of operations of SURVEY.md 8(e)).
+// prompt=2 pins the OTHER end of that freedom (round 6): no poll of a delayed reduction ever finds it complete -- it completes in the
+// MPI_Wait of the next update() -- so every step uses the PREVIOUS step's global sums (the first one the start-up sums), the 1000th
+// step's statistics update the start-up moments once more.  Only the delayed reductors' requests are held back (they reduce MPI_LONG /
+// MPI_LONG_DOUBLE, tagged where they are issued); the gradient's MPI_Test (Optimizer.h:110-116) is left alone or the step would never end.
 static int gPromptReductions = 0;
+static std::set<MPI_Request> gDelayedRequests;
+extern "C" int MPI_Iallreduce(const void* sb, void* rb, int count, MPI_Datatype dt, MPI_Op op, MPI_Comm comm, MPI_Request* req) {
+  const int rc = PMPI_Iallreduce(sb, rb, count, dt, op, comm, req);
+  if (gPromptReductions == 2 && (dt == MPI_LONG || dt == MPI_LONG_DOUBLE)) gDelayedRequests.insert(*req);
+  return rc;
+}
+extern "C" int MPI_Wait(MPI_Request* req, MPI_Status* st) {
+  if (gPromptReductions == 2) gDelayedRequests.erase(*req);
+  return PMPI_Wait(req, st);
+}
 extern "C" int MPI_Test(MPI_Request* req, int* flag, MPI_Status* st) {
+  if (gPromptReductions == 2) {
+    if (gDelayedRequests.count(*req)) { *flag = 0; return MPI_SUCCESS; }
+    return PMPI_Test(req, flag, st);
+  }
   if (gPromptReductions) { *flag = 1; return PMPI_Wait(req, st); }
   return PMPI_Test(req, flag, st);
 }

@@ -182,4 +182,16 @@ ls -la "$HERE"/*.bin
 #   a partially observable MDP with nnType left at its default: "RNN" encoder layers under "MGU" layers (Approximator.cpp:221-223, 264-270)
 "$DRV" fixture "$HERE/pomdp_encoder.bin" dimS=5 dimA=2 bounded=10 pomdp=1 encoder=24 layers=16,16 nnFunc=Tanh bptt=5 \
    batch=16 nEps=30 lenMin=5 lenMax=40 pTerm=0.5 nSteps=12 gradSteps=1,2,12 retSteps=12 maxObs=2000 minObs=500
+# G-two-rank: TWO learners (mpiexec -n 2; learners_train_comm = the world; one fixture per rank: <name>.r0 / .r1).  prompt=1 pins every
+# poll of the delayed reductions to "complete" (this step's global sums), prompt=2 to "never at the poll" (the previous step's sums:
+# the other end of the reference's timing freedom, Utils/DelayedReductor.cpp:34-60; round 6).  The round-5 pair two_rank_traj.bin was
+# recorded before its command was written down here; the line below reproduces its trajectory (traj_beta, traj_nfar) value for value,
+# its per-step taps were a different selection, so the committed files are kept.  Odd batch and budgets: rounded up to the learners.
+MPIEXEC=${MPIEXEC:-/opt/conda/bin/mpiexec}
+TWO="dimS=5 dimA=2 bounded=10 layers=32,32 batch=15 nEps=40 lenMin=8 lenMax=30 pTerm=0.5 nSteps=1003 tapSteps=2 gradSteps=1,2,1000,1003 maxObs=601 minObs=99 epsAnneal=5e-7"
+# (cd "$TMP" && "$MPIEXEC" -n 2 "$DRV" fixture "$HERE/two_rank_traj.bin" prompt=1 $TWO)
+(cd "$TMP" && "$MPIEXEC" -n 2 "$DRV" fixture "$HERE/two_rank_stale.bin" prompt=2 $TWO)
+# ... and eight fully tapped steps (two_rank.bin: this line reproduces the round-5 files byte for byte), in both timings
+TWO8="dimS=5 dimA=2 bounded=10 layers=32,32 batch=16 nEps=40 lenMin=8 lenMax=30 pTerm=0.5 nSteps=8 gradSteps=1,2,8 retSteps=8 maxObs=4096 minObs=512"
+(cd "$TMP" && "$MPIEXEC" -n 2 "$DRV" fixture "$HERE/two_rank.bin" prompt=1 $TWO8)
 rm -rf "$TMP"
