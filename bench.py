@@ -221,6 +221,8 @@ def cpu_baseline(steps_budget_s=20.0):
                     tried.append((thr, r["transitions_per_s"]))
                     if best is None or r["transitions_per_s"] > best["transitions_per_s"]:
                         best = r
+                    elif r["transitions_per_s"] < 0.5 * best["transitions_per_s"]:
+                        break      # (past the knee: the next probes only get slower -- 256 threads took more than three minutes for 400 steps)
                 except Exception as e:  # noqa: BLE001
                     tried.append((thr, "failed: %s" % e))
             if best is not None:      # the quoted value: a longer run at the best thread count (the 400-step probes are noisy)
