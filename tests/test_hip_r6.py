@@ -200,3 +200,32 @@ def test_folded_replica_step_in_a_fresh_process():
         env = dict(os.environ, SMARTIES_HIP_FOLD=fold, GPU_MAX_HW_QUEUES="16", SMARTIES_HIP_XCHG_TIMEOUT_MS="30000")
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert "FOLD_OK" in out.stdout and ("KERNELS_PER_8_STEPS %d" % per8) in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_exchange_windows_survive_generations_of_learners(hip_api):
+    """The finding behind learner.cpp's window pool: an exchange window (uncached device memory) that went back to the allocator made
+    kernels of LATER learners in the process read stale values -- the host-summed replicas of the next generation computed gradients
+    off by whole tiles (7 of 8 generations; once a wild pointer).  Six generations of {two connected replicas + two host-summed ones}:
+    every generation's gradients, weights and moments must be those of the first, bit for bit."""
+    cfg_kw = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=256, maxTotObsNum=65536, randSeed=42)
+    sc = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=40, lenMax=200, pTerm=0.3)
+    first = None
+    for gen in range(6):
+        X = _replicas(hip_api, cfg_kw, sc, 2, 80, True)
+        H = _replicas(hip_api, cfg_kw, sc, 2, 80, False)
+        _both(X, lambda L: (L.step(2), L.sync()))
+        for L in H:
+            L.step_begin()
+        gs = [L.grad_fetch() for L in H]
+        for L in H:
+            L.grad_store((gs[0] + gs[1]).astype(np.float32)); L.counters_store(np.sum([q.counters_fetch() for q in H], axis=0)); L.step_end()
+        _host_step(H)
+        _assert_same(X, H, 2)
+        state = [g.copy() for g in gs] + [a.copy() for a in X[0].get_params()]
+        if first is None:
+            first = state
+        for a, b in zip(state, first):
+            assert np.array_equal(a, b), gen
+        for L in X + H:
+            L.close()
