@@ -628,16 +628,17 @@ def test_one_kernel_exchange_at_start_up(hip_api):
     assert np.array_equal(Y[0].get_params()[0], Y[1].get_params()[0]) and Y[0].scalars().beta == Y[1].scalars().beta
 
 
-@pytest.mark.parametrize("n_procs", [2, 8])
-def test_one_kernel_exchange_between_processes(n_procs):
+@pytest.mark.parametrize("n_procs,shape", [(2, "small"), (8, "small"), (2, "north-star"), (8, "north-star")], ids=["2", "8", "2-north-star", "8-north-star"])
+def test_one_kernel_exchange_between_processes(n_procs, shape):
     """The same exchange between 2 and 8 PROCESSES sharing this GPU -- the layout of a node's eight learner ranks, minus the
     links --, windows mapped through hipIpc handles that travel over gloo (tests/xchg_ipc_worker.py): replicas identical and equal
-    to the host-summed run (rank-order fp32 sums), bit for bit, after 1005 steps."""
+    to the host-summed run (rank-order fp32 sums), bit for bit, after 1005 steps; round 6: also at BASELINE.json's metric
+    configuration (2 x 256, global batch 256: the 292 KB message pushed by 354 dW tiles into hipIpc-mapped windows)."""
     import subprocess, sys, os
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMARTIES_HIP_XCHG_TIMEOUT_MS="60000")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SMARTIES_HIP_XCHG_TIMEOUT_MS="60000", XCHG_IPC_SHAPE=shape)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_procs, "--master-addr", "127.0.0.1",
-                          "--master-port", str(29531 + n_procs), os.path.join(here, "xchg_ipc_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+                          "--master-port", str(29531 + n_procs + (40 if shape != "small" else 0)), os.path.join(here, "xchg_ipc_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert "XCHG_IPC_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 

@@ -15,6 +15,9 @@ from oracle_api import synth_cfg, synth_episode
 
 CFG = dict(dimS=5, dimA=2, bounded=[1, 0], hidden=(32, 32), batchSize=16, maxTotObsNum=4096, randSeed=11)
 SC = synth_cfg(seed=3, dimS=5, dimA=2, lenMin=8, lenMax=30, pTerm=0.5)
+if os.environ.get("XCHG_IPC_SHAPE") == "north-star":      # BASELINE.json's metric configuration: a 292 KB message, 354 pushing dW tiles (round 6)
+    CFG = dict(dimS=17, dimA=6, hidden=(256, 256), nnFunc="SoftSign", batchSize=256, maxTotObsNum=65536, randSeed=42)
+    SC = synth_cfg(seed=7, dimS=17, dimA=6, lenMin=40, lenMax=200, pTerm=0.3)
 CALLS = [1, 1, 3, 20, 70, 900, 10]          # 1005 steps: eager calls, replayed graphs, the 1000th-step sweep (moments exchange)
 
 
