@@ -33,7 +33,7 @@ def _make(rank, world):
     return L
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, stale=False):
     import torch.distributed as dist
     from smarties_amd import dist_host
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,8 +41,9 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = _make(rank, world)
     dist_host.init_replica_weights(L, dist)
-    dist_host.initialize_host_exchange(L, dist)
-    dist_host.step_host_exchange(L, dist, N_STEPS)
+    sums = list(dist_host.initialize_host_exchange(L, dist))
+    dist_host.step_host_exchange(L, dist, N_STEPS - 400, stale=sums if stale else None)
+    dist_host.step_host_exchange(L, dist, 400, stale=sums if stale else None)      # (the one-behind sums carry over between calls)
     w, m1, m2 = L.get_params()
     sc = L.scalars()
     np.savez(os.path.join(outdir, "r%d.npz" % rank), w=w, m1=m1, m2=m2, beta=sc.beta, nGrad=sc.nGradSteps,
@@ -51,8 +52,9 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def _emulate(world):
-    """Same protocol, one process: the collectives are numpy sums over the replicas."""
+def _emulate(world, stale=False):
+    """Same protocol, one process: the collectives are numpy sums over the replicas.  stale: every replica stores the sums of the
+    reduction BEFORE the current one (the reference's other timing, dist_host.step_host_exchange)."""
     Ls = [_make(r, world) for r in range(world)]
     w0 = Ls[0].get_params()[0]
     for L in Ls:
@@ -63,6 +65,7 @@ def _emulate(world):
     m = np.sum([L.moments_fetch() for L in Ls], axis=0)
     for L in Ls:
         L.counters_store(c); L.moments_store(m); L.initialize_end()
+    c_prev, m_prev = c, m
     for _ in range(N_STEPS):
         for L in Ls:
             L.step_begin()
@@ -72,9 +75,12 @@ def _emulate(world):
         for L, m in zip(Ls, ms):
             L.grad_store(g)
             if m is not None:
-                L.moments_store(np.sum(ms, axis=0))
-            L.counters_store(c)
+                L.moments_store(m_prev if stale else np.sum(ms, axis=0))
+            L.counters_store(c_prev if stale else c)
             L.step_end()
+        c_prev = c
+        if ms[0] is not None:
+            m_prev = np.sum(ms, axis=0)
     return Ls
 
 
@@ -98,6 +104,25 @@ def test_two_replicas_over_gloo_match_single_process_emulation():
     for i, L in enumerate(Ls):
         sc = np.concatenate([np.ravel(x) for x in L.get_scaling()])
         assert np.array_equal(sc, r[i]["scaling"])
+
+
+def test_two_replicas_over_gloo_one_reduction_behind():
+    """dist_host.step_host_exchange(stale=...): the reference's other reduction timing over gloo (two processes, two calls: the sums
+    carry over) equals the single-process emulation of it -- and is not the current-sums trajectory."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker, args=(2, port, td, True), nprocs=2, join=True)
+        r = [np.load(os.path.join(td, "r%d.npz" % i)) for i in range(2)]
+    for k in ("w", "m1", "m2", "beta", "nGrad"):
+        assert np.array_equal(r[0][k], r[1][k]), k
+    Ls = _emulate(2, stale=True)
+    assert np.array_equal(Ls[0].get_params()[0], r[0]["w"]) and Ls[0].scalars().beta == float(r[0]["beta"])
+    for i, L in enumerate(Ls):
+        assert np.array_equal(np.concatenate([np.ravel(x) for x in L.get_scaling()]), r[i]["scaling"])
+    assert _emulate(2)[0].scalars().beta != float(r[0]["beta"]) or not np.array_equal(_emulate(2)[0].get_params()[0], r[0]["w"])
 
 
 def test_split_sizes_follow_reference_rule():
