@@ -195,6 +195,7 @@ struct AdamArgs {
 
 // one-kernel sum over the replicas' windows (xchg.hip)
 constexpr int XCHG_CHUNKS = 64;         // workgroups (= independently flagged chunks) of one collective, at most
+constexpr int XCHG_CHUNKS_NODE = 32;    // ... as cut where every replica has a device of its own (hl_xchg_connect: fewer where they share one)
 constexpr int XCHG_MAX_RANKS = 16;
 struct XchgArgs {
   void* msg; long long n;                       // local message, summed in place

@@ -159,7 +159,7 @@ struct hl_learner {
     unsigned char* win = nullptr; size_t winBytes = 0, slotsOffset = 0, slotBytes = 0;
     unsigned char** dPeers = nullptr; XchgCtl* ctl = nullptr;
     std::vector<void*> opened;               // windows opened through hipIpc (closed by hl_destroy)
-    int maxChunks = XCHG_CHUNKS;             // chunk workgroups of a collective at most (fewer where replicas share a device: hl_xchg_connect)
+    int maxChunks = XCHG_CHUNKS_NODE;             // chunk workgroups of a collective at most (fewer where replicas share a device: hl_xchg_connect)
   } xchg;
   // wait of the exchange kernel for a peer's message (SMARTIES_HIP_XCHG_TIMEOUT_MS): replicas are gated independently by their data
   // (blockGradientUpdates), so a peer may legitimately lag by seconds or minutes behind a slow simulator -- the reference's

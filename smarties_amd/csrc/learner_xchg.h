@@ -104,7 +104,9 @@ int hl_xchg_connect(hl_learner* h, const uint8_t* handles) {
       for (int q = 0; q < R; ++q) { int devQ; std::memcpy(&devQ, handles + (size_t)q * HL_XCHG_HANDLE_BYTES + 76, 4); same += devQ == devR ? 1 : 0; }
       most = std::max(most, same);
     }
-    x.maxChunks = most <= 1 ? XCHG_CHUNKS : std::max(4, XCHG_CHUNKS / most); }
+    // (one replica per device: 32 chunks -- measured in loopback with caps of 16 / 24 / 32 / 48 / 64: 34.3 / 32.7 / 32.7 / 33.3 / 35.0 us per step at
+    //  2 replicas, 37.6 / 33.9 / 33.2 / 33.9 / 34.9 at 8: more workgroups lengthen the two-phase wait, fewer the sums and Adam slices)
+    x.maxChunks = (most <= 1 || (h->generic & 1024)) ? XCHG_CHUNKS_NODE : std::max(4, XCHG_CHUNKS / most); }      // (GENERIC & 1024: a node's cut on a shared device -- tools/replica_loopback.py, where only ONE replica steps)
   x.on = true;
   h->graphsStale = true;
   // identical initial weights on every replica: MPI_Bcast from rank 0 (Network/Builder.cpp:143-144) as a sum with zeros

@@ -113,6 +113,8 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
         if (wall_clock64() - t0 > 2 * a.timeoutTicks) { __hip_atomic_store(&a.sc->errFlag, 79, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); L->fail = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      // (ONE verdict per workgroup, taken here: the bookkeeping behind it holds barriers)
+      if (__hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) L->fail = 1;
     }
     __syncthreads();
   };
@@ -158,15 +160,27 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
     }
   }
   if (FOLD && chunk == 0) FOSTAMP(a.sc, 9);
-  // (Adam's operands of this thread's first pass are requested in front of the two-phase wait: they do not depend on it)
+  // (Adam's first pass -- four units per thread: all of them on a node, where a 292 KB message has 64 chunks -- is COMPUTED in front of the
+  //  two-phase wait, from this thread's own sums and operands that do not depend on the wait; only its stores stand behind it)
   constexpr int UA = 4;
   const long long vAdam = FUSE ? (ad.n + EPV - 1) / EPV : 0;      // units that hold parameters
   f32x4 w4[UA], m14[UA], m24[UA];
+  AdamCoef c{};
   if constexpr (FUSE) {
+    static_assert(sizeof(T) == 4, "Adam runs on float messages");
+    c.eta = a.sc->etaEff[ad.parity]; c.lambda = ad.lambda; c.fac = ad.fac;
+    f32x4 g4[UA];
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
       const long long v = max(0ll, min(min(v0 + tid + 256ll * u, v1 - 1), vAdam - 1));
+      g4[u] = reinterpret_cast<const f32x4*>(a.msg)[v];      // (this thread's own store of a moment ago)
       w4[u] = reinterpret_cast<const f32x4*>(ad.W)[v]; m14[u] = reinterpret_cast<const f32x4*>(ad.M1)[v]; m24[u] = reinterpret_cast<const f32x4*>(ad.M2)[v];
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const long long v = v0 + tid + 256ll * u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (v < v1 && v * 4 + q < ad.n) { float w = w4[u][q], m1 = m14[u][q], m2 = m24[u][q]; adamStep(c, g4[u][q], w, m1, m2); w4[u][q] = w; m14[u][q] = m1; m24[u][q] = m2; }
     }
   }
   if constexpr (FUSE) {
@@ -181,21 +195,38 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
   // bookkeeping -- the parameters stay as they were (gradient messages: the two-phase wait above; the other messages have no side
   // effect beyond their own buffer).  The host sees HL_ERR_HIP at its next read-back.  The sequence still advances, so nothing waits
   // on this collective later.
-  const bool failed = L->fail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  const bool failed = FUSE ? L->fail != 0 : (L->fail != 0 || __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
   if (FOLD && chunk == 0) FOSTAMP(a.sc, 15);
   if constexpr (FUSE) {
-    // ---- Adam on the summed chunk (this thread's own sums, read back; parameters and moments as 16-byte accesses, four units per
-    // pass requested together, the first pass's in front of the wait).  The arrays are 16-byte aligned and hold ad.n rounded up to four
-    // elements (Parameters.h layout + PARAM_TAIL slack)
-    static_assert(sizeof(T) == 4, "Adam runs on float messages");
-    AdamCoef c; c.eta = a.sc->etaEff[ad.parity]; c.lambda = ad.lambda; c.fac = ad.fac;
-    if (!failed) for (long long vb = v0 + tid; vb < v1 && vb < vAdam; vb += 256 * UA) {
+    // ---- Adam on the summed chunk: the first pass's results are stored, further passes (fewer, larger chunks: replicas sharing a device)
+    // load, compute and store; parameters and moments as 16-byte accesses (the arrays are 16-byte aligned and hold ad.n rounded up to four
+    // elements: Parameters.h layout + PARAM_TAIL slack)
+    if (!failed) {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const long long v = v0 + tid + 256ll * u;
+        if (v < v1 && v < vAdam) { reinterpret_cast<f32x4*>(ad.W)[v] = w4[u]; reinterpret_cast<f32x4*>(ad.M1)[v] = m14[u]; reinterpret_cast<f32x4*>(ad.M2)[v] = m24[u]; }
+      }
+    }
+    // ---- the step's closing bookkeeping (MemoryProcessing::updateCounters ... beta, the next step's Adam scalars) by the workgroup that
+    // summed the END of the message -- the counters: its own stores -- as soon as it knows that nobody failed, beside the other workgroups'
+    // Adam stores and -- it is one thread's work behind one barrier -- beside this workgroup's own later passes (until round 6: by the last
+    // workgroup to finish, behind everything).  It touches scalars no Adam slice reads
+    // (etaEff of the OTHER buffer slot), so nothing has to wait for it but the end of the launch.
+    if (chunk == nCh - 1 && !failed) {
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the bookkeeping rider's scalars, where it ran in this launch: an invalidate, no write-back)
+      if (FOLD) FOSTAMP(a.sc, 12);
+      postPart(post, L->farDelta, &L->maxAbs, nullptr, 0, FOLD ? postModeClose : -1);
+      if (FOLD) FOSTAMP(a.sc, 13);
+    }
+    if (!failed) for (long long vb = v0 + tid + 256ll * UA; vb < v1 && vb < vAdam; vb += 256 * UA) {
       f32x4 g4[UA];
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
         const long long v = min(min(vb + 256ll * u, v1 - 1), vAdam - 1);
         g4[u] = reinterpret_cast<const f32x4*>(a.msg)[v];
-        if (vb != v0 + tid) { w4[u] = reinterpret_cast<const f32x4*>(ad.W)[v]; m14[u] = reinterpret_cast<const f32x4*>(ad.M1)[v]; m24[u] = reinterpret_cast<const f32x4*>(ad.M2)[v]; }
+        w4[u] = reinterpret_cast<const f32x4*>(ad.W)[v]; m14[u] = reinterpret_cast<const f32x4*>(ad.M1)[v]; m24[u] = reinterpret_cast<const f32x4*>(ad.M2)[v];
       }
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
@@ -230,15 +261,6 @@ __device__ __forceinline__ void xchgChunk(const XchgCore& a, const XchgAdam& ad,
     if (last) {
       a.ctl->done = 0; a.ctl->arrived = 0;      // (every workgroup left the two-phase wait before it added to `done`)
       __hip_atomic_store(&a.ctl->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if constexpr (FUSE) {
-    __syncthreads();
-    if (L->last && __hip_atomic_load(&a.sc->errFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // (all chunks are summed and visible)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (nothing of this workgroup's own has to go out: an invalidate, no write-back)
-      if (FOLD) FOSTAMP(a.sc, 12);
-      postPart(post, L->farDelta, &L->maxAbs, nullptr, 0, FOLD ? postModeClose : -1);
-      if (FOLD) FOSTAMP(a.sc, 13);
     }
   }
 }
