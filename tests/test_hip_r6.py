@@ -115,8 +115,8 @@ def test_replica_exchange_at_the_north_star_shape(hip_api, monkeypatch, n_ranks,
 @pytest.mark.parametrize("n_ranks,batch", [(8, 128), (4, 128)], ids=["8xB16", "4xB32"])
 @pytest.mark.parametrize("route", ["pushed", "unpushed"])
 def test_replica_exchange_at_the_humanoid_shape(hip_api, monkeypatch, route, n_ranks, batch):
-    """BASELINE config 3 (Humanoid-v2 under 8 learner replicas; the survey's figures: 257 states, 17 actions, 2 x 256, 32 samples per
-    replica) on fused_wide_kernel: the same bit-equality over 1005 steps.  The configuration itself -- 8 replicas x 32 samples -- cannot
+    """BASELINE config 3 (Humanoid-v2 through apps/OpenAI_gym/HumanoidWrapper.py under 8 learner replicas: 257 observed states, 17 actions,
+    2 x 256, 32 samples per replica) on fused_wide_kernel: the same bit-equality over 1005 steps.  The configuration itself -- 8 replicas x 32 samples -- cannot
     run on ONE device: at 257 states a workgroup of the fused kernel owns its CU's LDS, 8 x (2 panels x 16 + 8 rider slots) = 320
     workgroups want 256 CUs, and the panel groups of different replicas then wait inside their kernels for CUs held by each other's
     (bounded spins, device error 77: seen).  On a node every replica has 256 CUs of its own.  Here: 8 replicas x 16 samples (192
